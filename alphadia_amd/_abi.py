@@ -1,0 +1,320 @@
+"""ctypes mirror of ``include/alphadia_hip.h`` (struct layouts + array marshalling).
+
+Pure data-layout code: no compute happens here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+NUM_FEATURES = 46  # alphadia/constants/settings.py:5
+FLAG_SKIP = 1
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class AlphaRaw(C.Structure):
+    _fields_ = [
+        ("cycle", _f64p),
+        ("cycle_len", C.c_int32),
+        ("cycle_scans", C.c_int32),
+        ("rt_values", _f32p),
+        ("n_spectra", C.c_int64),
+        ("mobility_values", _f32p),
+        ("n_mobility", C.c_int64),
+        ("peak_start_idx", _i64p),
+        ("peak_stop_idx", _i64p),
+        ("mz_values", _f32p),
+        ("intensity_values", _f32p),
+        ("n_peaks", C.c_int64),
+    ]
+
+
+class Fragments(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("mz_library", _f32p),
+        ("mz", _f32p),
+        ("intensity", _f32p),
+        ("type", _u8p),
+        ("loss_type", _u8p),
+        ("charge", _u8p),
+        ("number", _u8p),
+        ("position", _u8p),
+        ("cardinality", _u8p),
+    ]
+
+
+class Candidates(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("precursor_idx", _u32p),
+        ("rank", _u8p),
+        ("flags", _u8p),
+        ("frag_start_idx", _u32p),
+        ("frag_stop_idx", _u32p),
+        ("scan_start", _i64p),
+        ("scan_stop", _i64p),
+        ("scan_center", _i64p),
+        ("frame_start", _i64p),
+        ("frame_stop", _i64p),
+        ("frame_center", _i64p),
+        ("charge", _u8p),
+        ("precursor_mz", _f32p),
+        ("isotope_intensity", _f32p),
+        ("n_isotope_cols", C.c_int32),
+    ]
+
+
+class ScoringConfig(C.Structure):
+    _fields_ = [
+        ("collect_fragments", C.c_int32),
+        ("score_grouped", C.c_int32),
+        ("exclude_shared_ions", C.c_int32),
+        ("top_k_fragments", C.c_uint32),
+        ("top_k_isotopes", C.c_uint32),
+        ("reference_channel", C.c_int32),
+        ("quant_window", C.c_uint32),
+        ("quant_all", C.c_int32),
+        ("precursor_mz_tolerance", C.c_float),
+        ("fragment_mz_tolerance", C.c_float),
+        ("experimental_xic", C.c_int32),
+    ]
+
+
+class Output(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("top_k", C.c_int32),
+        ("valid", _u8p),
+        ("precursor_idx", _u32p),
+        ("rank", _u8p),
+        ("features", _f32p),
+        ("fragment_precursor_idx", _u32p),
+        ("fragment_rank", _u8p),
+        ("fragment_mz_library", _f32p),
+        ("fragment_mz", _f32p),
+        ("fragment_mz_observed", _f32p),
+        ("fragment_height", _f32p),
+        ("fragment_intensity", _f32p),
+        ("fragment_mass_error", _f32p),
+        ("fragment_correlation", _f32p),
+        ("fragment_position", _u8p),
+        ("fragment_number", _u8p),
+        ("fragment_type", _u8p),
+        ("fragment_charge", _u8p),
+        ("fragment_loss_type", _u8p),
+        ("stat_matched_peaks", _u32p),
+    ]
+
+
+# (name, dtype, per-row width: 1 | "features" | "top_k")
+OUTPUT_FIELDS = [
+    ("valid", np.uint8, 1),
+    ("precursor_idx", np.uint32, 1),
+    ("rank", np.uint8, 1),
+    ("features", np.float32, "features"),
+    ("fragment_precursor_idx", np.uint32, "top_k"),
+    ("fragment_rank", np.uint8, "top_k"),
+    ("fragment_mz_library", np.float32, "top_k"),
+    ("fragment_mz", np.float32, "top_k"),
+    ("fragment_mz_observed", np.float32, "top_k"),
+    ("fragment_height", np.float32, "top_k"),
+    ("fragment_intensity", np.float32, "top_k"),
+    ("fragment_mass_error", np.float32, "top_k"),
+    ("fragment_correlation", np.float32, "top_k"),
+    ("fragment_position", np.uint8, "top_k"),
+    ("fragment_number", np.uint8, "top_k"),
+    ("fragment_type", np.uint8, "top_k"),
+    ("fragment_charge", np.uint8, "top_k"),
+    ("fragment_loss_type", np.uint8, "top_k"),
+]
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+_CT = {
+    np.dtype(np.float32): C.c_float,
+    np.dtype(np.float64): C.c_double,
+    np.dtype(np.int64): C.c_int64,
+    np.dtype(np.uint32): C.c_uint32,
+    np.dtype(np.uint8): C.c_uint8,
+}
+
+
+def as_c(a, dtype) -> np.ndarray:
+    """Contiguous array of exactly ``dtype`` (no copy when already so)."""
+    a = np.asarray(a)
+    if a.dtype == np.bool_ and np.dtype(dtype) == np.uint8:
+        a = a.view(np.uint8)
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Marshalled:
+    """A ctypes struct plus the numpy arrays that keep its pointers alive."""
+
+    def __init__(self, struct, keep):
+        self.struct = struct
+        self.keep = keep
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def pack_alpharaw(dia) -> Marshalled:
+    """``dia`` exposes the AlphaRawJIT field names (alpharaw_jit.py:78-138)."""
+    cycle = as_c(dia.cycle, np.float64)
+    if cycle.ndim != 4 or cycle.shape[0] != 1 or cycle.shape[3] != 2:
+        raise ValueError("cycle must have shape (1, n_precursor, n_scan, 2)")
+    rt = as_c(dia.rt_values, np.float32)
+    mob = as_c(dia.mobility_values, np.float32)
+    ps = as_c(dia.peak_start_idx_list, np.int64)
+    pe = as_c(dia.peak_stop_idx_list, np.int64)
+    mz = as_c(dia.mz_values, np.float32)
+    it = as_c(dia.intensity_values, np.float32)
+    if ps.shape != rt.shape or pe.shape != rt.shape:
+        raise ValueError("peak_start/stop_idx_list must have one entry per spectrum")
+    if mz.shape != it.shape:
+        raise ValueError("mz_values and intensity_values differ in length")
+    s = AlphaRaw(
+        _ptr(cycle, C.c_double),
+        cycle.shape[1],
+        cycle.shape[2],
+        _ptr(rt, C.c_float),
+        rt.shape[0],
+        _ptr(mob, C.c_float),
+        mob.shape[0],
+        _ptr(ps, C.c_int64),
+        _ptr(pe, C.c_int64),
+        _ptr(mz, C.c_float),
+        _ptr(it, C.c_float),
+        mz.shape[0],
+    )
+    return Marshalled(s, [cycle, rt, mob, ps, pe, mz, it])
+
+
+def pack_fragments(mz_library, mz, intensity, type_, loss_type, charge, number, position, cardinality):
+    arrs = [as_c(mz_library, np.float32), as_c(mz, np.float32), as_c(intensity, np.float32)]
+    arrs += [as_c(a, np.uint8) for a in (type_, loss_type, charge, number, position, cardinality)]
+    n = arrs[0].shape[0]
+    if any(a.shape != (n,) for a in arrs):
+        raise ValueError("fragment columns differ in length")
+    s = Fragments(
+        n,
+        *[_ptr(a, C.c_float) for a in arrs[:3]],
+        *[_ptr(a, C.c_uint8) for a in arrs[3:]],
+    )
+    return Marshalled(s, arrs)
+
+
+def pack_candidates(
+    precursor_idx,
+    rank,
+    frag_start_idx,
+    frag_stop_idx,
+    scan_start,
+    scan_stop,
+    scan_center,
+    frame_start,
+    frame_stop,
+    frame_center,
+    charge,
+    precursor_mz,
+    isotope_intensity,
+    flags=None,
+) -> Marshalled:
+    pi = as_c(precursor_idx, np.uint32)
+    n = pi.shape[0]
+    rk = as_c(rank, np.uint8)
+    fs = as_c(frag_start_idx, np.uint32)
+    fe = as_c(frag_stop_idx, np.uint32)
+    i64 = [
+        as_c(a, np.int64)
+        for a in (scan_start, scan_stop, scan_center, frame_start, frame_stop, frame_center)
+    ]
+    ch = as_c(charge, np.uint8)
+    pm = as_c(precursor_mz, np.float32)
+    iso = as_c(isotope_intensity, np.float32)
+    if iso.ndim != 2 or iso.shape[0] != n:
+        raise ValueError("isotope_intensity must be (n_candidates, n_isotopes)")
+    if iso.shape[1] == 0:
+        raise ValueError("precursor isotopes empty")  # score_group.py:198-199
+    fl = as_c(flags, np.uint8) if flags is not None else None
+    for a in [rk, fs, fe, ch, pm, *i64] + ([fl] if fl is not None else []):
+        if a.shape != (n,):
+            raise ValueError("candidate columns differ in length")
+    s = Candidates(
+        n,
+        _ptr(pi, C.c_uint32),
+        _ptr(rk, C.c_uint8),
+        _ptr(fl, C.c_uint8) if fl is not None else None,
+        _ptr(fs, C.c_uint32),
+        _ptr(fe, C.c_uint32),
+        *[_ptr(a, C.c_int64) for a in i64],
+        _ptr(ch, C.c_uint8),
+        _ptr(pm, C.c_float),
+        _ptr(iso, C.c_float),
+        iso.shape[1],
+    )
+    return Marshalled(s, [pi, rk, fl, fs, fe, *i64, ch, pm, iso])
+
+
+def output_shapes(n: int, top_k: int):
+    shapes = {}
+    for name, dt, w in OUTPUT_FIELDS:
+        if w == 1:
+            shapes[name] = ((n,), dt)
+        elif w == "features":
+            shapes[name] = ((n, NUM_FEATURES), dt)
+        else:
+            shapes[name] = ((n, top_k), dt)
+    return shapes
+
+
+def alloc_output(n: int, top_k: int, with_stats: bool = False):
+    """Zeroed host OutputPsmDF buffers (output.py:44-70) and the ctypes view of them."""
+    arrays = {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
+    stats = np.zeros(n, dtype=np.uint32) if with_stats else None
+    s = Output(
+        n,
+        top_k,
+        *[_ptr(arrays[name], _CT[np.dtype(dt)]) for name, dt, _ in OUTPUT_FIELDS],
+        _ptr(stats, C.c_uint32) if stats is not None else None,
+    )
+    if stats is not None:
+        arrays["stat_matched_peaks"] = stats
+    return Marshalled(s, arrays), arrays
+
+
+def output_from_device_pointers(n: int, top_k: int, ptrs: dict, stats_ptr: int = 0) -> Output:
+    """Build an ``adh_output_t`` from raw device addresses (ints)."""
+    vals = []
+    for name, dt, _ in OUTPUT_FIELDS:
+        vals.append(C.cast(C.c_void_p(ptrs[name]), C.POINTER(_CT[np.dtype(dt)])))
+    st = C.cast(C.c_void_p(stats_ptr), C.POINTER(C.c_uint32)) if stats_ptr else None
+    return Output(n, top_k, *vals, st)
+
+
+def pack_config(cfg) -> ScoringConfig:
+    """``cfg`` exposes the CandidateScoringConfigJIT attribute names (config.py:13-60)."""
+    return ScoringConfig(
+        int(bool(cfg.collect_fragments)),
+        int(bool(cfg.score_grouped)),
+        int(bool(cfg.exclude_shared_ions)),
+        int(cfg.top_k_fragments),
+        int(cfg.top_k_isotopes),
+        int(cfg.reference_channel),
+        int(cfg.quant_window),
+        int(bool(cfg.quant_all)),
+        float(cfg.precursor_mz_tolerance),
+        float(cfg.fragment_mz_tolerance),
+        int(bool(cfg.experimental_xic)),
+    )

@@ -1,0 +1,568 @@
+"""Host side of the MI355X candidate-scoring path.
+
+Mirrors the reference operator interface so that callers can switch classes
+without touching their code:
+
+* ``CandidateScoringConfig``  <- alphadia/search/scoring/config.py:63-222
+* ``OutputPsmDF``             <- alphadia/search/scoring/output.py:17-97
+* ``HipCandidateScoring``     <- ``CandidateScoring`` alphadia/search/scoring/scoring.py:140-661
+  (same constructor keywords, same ``__call__`` signature, same returned
+  ``(features_df, fragments_df)`` column contract)
+
+All per-candidate arithmetic runs in hand-written HIP kernels behind the C ABI
+of ``include/alphadia_hip.h``.  There is no CPU fallback: if the shared
+library is missing, construction fails.
+"""
+
+from __future__ import annotations
+
+import logging
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+
+from alphadia_amd import _abi
+
+logger = logging.getLogger(__name__)
+
+# scoring.py:34-81
+DEFAULT_FEATURE_COLUMNS = [
+    "base_width_mobility",
+    "base_width_rt",
+    "rt_observed",
+    "mobility_observed",
+    "mono_ms1_intensity",
+    "top_ms1_intensity",
+    "sum_ms1_intensity",
+    "weighted_ms1_intensity",
+    "weighted_mass_deviation",
+    "weighted_mass_error",
+    "mz_observed",
+    "mono_ms1_height",
+    "top_ms1_height",
+    "sum_ms1_height",
+    "weighted_ms1_height",
+    "isotope_intensity_correlation",
+    "isotope_height_correlation",
+    "n_observations",
+    "intensity_correlation",
+    "height_correlation",
+    "intensity_fraction",
+    "height_fraction",
+    "intensity_fraction_weighted",
+    "height_fraction_weighted",
+    "mean_observation_score",
+    "sum_b_ion_intensity",
+    "sum_y_ion_intensity",
+    "diff_b_y_ion_intensity",
+    "f_masked",
+    "fragment_scan_correlation",
+    "template_scan_correlation",
+    "fragment_frame_correlation",
+    "top3_frame_correlation",
+    "template_frame_correlation",
+    "top3_b_ion_correlation",
+    "n_b_ions",
+    "top3_y_ion_correlation",
+    "n_y_ions",
+    "cycle_fwhm",
+    "mobility_fwhm",
+    "delta_frame_peak",
+    "top_3_ms2_mass_error",
+    "mean_ms2_mass_error",
+    "n_overlapping",
+    "mean_overlapping_intensity",
+    "mean_overlapping_mass_error",
+]
+assert len(DEFAULT_FEATURE_COLUMNS) == _abi.NUM_FEATURES
+
+# scoring.py:83-107
+DEFAULT_CANDIDATE_COLUMNS = [
+    "elution_group_idx",
+    "scan_center",
+    "scan_start",
+    "scan_stop",
+    "frame_center",
+    "frame_start",
+    "frame_stop",
+]
+DEFAULT_PRECURSOR_COLUMNS = [
+    "rt_library",
+    "mobility_library",
+    "mz_library",
+    "charge",
+    "decoy",
+    "channel",
+    "flat_frag_start_idx",
+    "flat_frag_stop_idx",
+    "proteins",
+    "genes",
+    "sequence",
+    "mods",
+    "mod_sites",
+]
+# scoring.py:542-557
+FRAGMENT_DF_COLUMNS = [
+    "precursor_idx",
+    "rank",
+    "mz_library",
+    "mz",
+    "mz_observed",
+    "height",
+    "intensity",
+    "mass_error",
+    "correlation",
+    "position",
+    "number",
+    "type",
+    "charge",
+    "loss_type",
+]
+MAX_FRAGMENT_MZ_TOLERANCE = 200  # constants/settings.py:6
+
+
+class CandidateScoringConfig:
+    """Hyper-parameters of candidate scoring (config.py:63-222)."""
+
+    _FIELDS = (
+        "collect_fragments",
+        "score_grouped",
+        "exclude_shared_ions",
+        "top_k_fragments",
+        "top_k_isotopes",
+        "reference_channel",
+        "quant_window",
+        "quant_all",
+        "precursor_mz_tolerance",
+        "fragment_mz_tolerance",
+        "experimental_xic",
+    )
+
+    def __init__(self):
+        self.collect_fragments = True
+        self.score_grouped = False
+        self.exclude_shared_ions = True
+        self.top_k_fragments = 12
+        self.top_k_isotopes = 4
+        self.reference_channel = -1
+        self.quant_window = 3
+        self.quant_all = False
+        self.precursor_mz_tolerance = 15
+        self.fragment_mz_tolerance = 15
+        self.experimental_xic = False
+
+    def update(self, input_dict: dict) -> None:
+        """Type-checked update (jit_config.py:69-138)."""
+        for key, value in input_dict.items():
+            if key not in self._FIELDS:
+                raise ValueError(f"Parameter {key} does not exist in CandidateScoringConfig")
+            current = getattr(self, key)
+            if not isinstance(value, type(current)):
+                try:
+                    value = type(current)(value)
+                except Exception as e:
+                    raise ValueError(f"Parameter {key} has wrong type {type(value)}") from e
+            setattr(self, key, value)
+
+    def validate(self) -> None:
+        """config.py:197-219"""
+        assert isinstance(self.score_grouped, bool), "score_grouped must be a boolean"
+        assert self.top_k_fragments > 0, "top_k_fragments must be greater than 0"
+        assert self.top_k_isotopes > 0, "top_k_isotopes must be greater than 0"
+        assert self.reference_channel >= -1, (
+            "reference_channel must be greater than or equal to -1"
+        )
+        assert self.precursor_mz_tolerance >= 0, (
+            "precursor_mz_tolerance must be greater than or equal to 0"
+        )
+        assert self.precursor_mz_tolerance < 200, "precursor_mz_tolerance must be less than 200"
+        assert self.fragment_mz_tolerance >= 0, (
+            "fragment_mz_tolerance must be greater than or equal to 0"
+        )
+        assert self.fragment_mz_tolerance <= MAX_FRAGMENT_MZ_TOLERANCE, (
+            f"fragment_mz_tolerance must be less than or equal {MAX_FRAGMENT_MZ_TOLERANCE}"
+        )
+
+    def to_jitclass(self):
+        """Plain value object with the CandidateScoringConfigJIT field names/dtypes."""
+        self.validate()
+        return SimpleNamespace(
+            collect_fragments=bool(self.collect_fragments),
+            score_grouped=bool(self.score_grouped),
+            exclude_shared_ions=bool(self.exclude_shared_ions),
+            top_k_fragments=np.uint32(self.top_k_fragments),
+            top_k_isotopes=np.uint32(self.top_k_isotopes),
+            reference_channel=np.int16(self.reference_channel),
+            quant_window=np.uint32(self.quant_window),
+            quant_all=bool(self.quant_all),
+            precursor_mz_tolerance=np.float32(self.precursor_mz_tolerance),
+            fragment_mz_tolerance=np.float32(self.fragment_mz_tolerance),
+            experimental_xic=bool(self.experimental_xic),
+        )
+
+    def __repr__(self) -> str:
+        return "<CandidateScoringConfig " + ", ".join(
+            f"{k}={getattr(self, k)}" for k in self._FIELDS
+        ) + ">"
+
+
+class OutputPsmDF:
+    """SoA result buffers (output.py:17-97) filled by the HIP kernels."""
+
+    def __init__(self, arrays: dict):
+        self.__dict__.update(arrays)
+        self.valid = self.valid.view(np.bool_)
+
+    def to_fragment_df(self):
+        mask = self.fragment_mz_library.reshape(-1) > 0
+        cols = (
+            "fragment_precursor_idx fragment_rank fragment_mz_library fragment_mz "
+            "fragment_mz_observed fragment_height fragment_intensity fragment_mass_error "
+            "fragment_correlation fragment_position fragment_number fragment_type "
+            "fragment_charge fragment_loss_type"
+        ).split()
+        return tuple(getattr(self, c).reshape(-1)[mask] for c in cols)
+
+    def to_precursor_df(self):
+        v = self.valid
+        return self.precursor_idx[v], self.rank[v], self.features[v]
+
+
+def get_isotope_column_names(colnames) -> list[str]:
+    """alphadia/utils.py:55-71 + scoring.py:110-111"""
+    iso = []
+    for col in colnames:
+        if col[:2] == "i_":
+            try:
+                iso.append(int(col[2:]))
+            except ValueError:
+                logger.warning(f"Column {col} does not seem to be a valid isotope column")
+    return [f"i_{i}" for i in sorted(iso)]
+
+
+def merge_missing_columns(left_df, right_df, right_columns, on=None, how="left"):
+    """scoring/utils.py:203-266"""
+    if isinstance(on, str):
+        on = [on]
+    if isinstance(right_columns, str):
+        right_columns = [right_columns]
+    missing_from_left = [c for c in dict.fromkeys(right_columns) if c not in left_df.columns]
+    missing_from_right = [c for c in missing_from_left if c not in right_df.columns]
+    if len(missing_from_left) == 0:
+        return left_df
+    if missing_from_right:
+        raise ValueError(f"Columns {missing_from_right} must be present in right_df")
+    if on is None:
+        raise ValueError("Parameter on must be specified")
+    if not all(col in left_df.columns for col in on):
+        raise ValueError(f"Columns {on} must be present in left_df")
+    if not all(col in right_df.columns for col in on):
+        raise ValueError(f"Columns {on} must be present in right_df")
+    if how not in ["left", "right", "inner", "outer"]:
+        raise ValueError("Parameter how must be one of left, right, inner, outer")
+    return left_df.merge(right_df[on + missing_from_left], on=on, how=how)
+
+
+_CAND_REQUIRED = {
+    "elution_group_idx": np.uint32,
+    "precursor_idx": np.uint32,
+    "rank": np.uint8,
+    "scan_start": np.int64,
+    "scan_stop": np.int64,
+    "scan_center": np.int64,
+    "frame_start": np.int64,
+    "frame_stop": np.int64,
+    "frame_center": np.int64,
+}
+
+
+def assemble_candidates(
+    candidates_df: pd.DataFrame,
+    precursors_flat_df: pd.DataFrame,
+    precursor_mz_column: str,
+    score_grouped: bool = False,
+    reference_channel: int = -1,
+) -> dict:
+    """Candidate table -> struct of arrays in score-group order.
+
+    Does the work of ``assemble_score_group_container`` (scoring.py:273-353),
+    ``calculate_score_groups`` (scoring/utils.py:269-410) and
+    ``ScoreGroupContainer.build_from_df`` (score_group.py:145-229) without
+    creating one object per candidate: precursor columns are looked up with a
+    searchsorted on ``precursor_idx`` and the order is one lexsort.
+    """
+    n = len(candidates_df)
+    for col in _CAND_REQUIRED:
+        if col not in candidates_df.columns and col != "rank":
+            raise KeyError(f"candidates_df is missing required column '{col}'")
+    cols = {
+        c: np.ascontiguousarray(candidates_df[c].values, dtype=dt)
+        for c, dt in _CAND_REQUIRED.items()
+        if c in candidates_df.columns
+    }
+    if "rank" not in cols:
+        cols["rank"] = np.zeros(n, dtype=np.uint8)
+
+    lib_pidx = precursors_flat_df["precursor_idx"].values
+    if len(lib_pidx) > 1 and not np.all(lib_pidx[1:] > lib_pidx[:-1]):
+        order = np.argsort(lib_pidx, kind="stable")
+        precursors_flat_df = precursors_flat_df.iloc[order]
+        lib_pidx = precursors_flat_df["precursor_idx"].values
+    pos = np.searchsorted(lib_pidx, cols["precursor_idx"])
+    pos_c = np.minimum(pos, max(len(lib_pidx) - 1, 0))
+    if n and (len(lib_pidx) == 0 or not np.array_equal(lib_pidx[pos_c], cols["precursor_idx"])):
+        raise ValueError("candidates_df contains precursor_idx values missing from precursors_flat")
+
+    def from_lib(name, dtype, default=None):
+        if name in candidates_df.columns:
+            return np.ascontiguousarray(candidates_df[name].values, dtype=dtype)
+        if name in precursors_flat_df.columns:
+            return np.ascontiguousarray(precursors_flat_df[name].values[pos_c], dtype=dtype)
+        if default is None:
+            raise ValueError(f"Columns ['{name}'] must be present in right_df")
+        return np.full(n, default, dtype=dtype)
+
+    channel = from_lib("channel", np.uint8, default=0)
+    decoy = from_lib("decoy", np.uint8)
+    frag_start = from_lib("flat_frag_start_idx", np.uint32)
+    frag_stop = from_lib("flat_frag_stop_idx", np.uint32)
+    charge = from_lib("charge", np.uint8)
+    prec_mz = from_lib(precursor_mz_column, np.float32)
+    iso_names = get_isotope_column_names(
+        list(dict.fromkeys(list(candidates_df.columns) + list(precursors_flat_df.columns)))
+    )
+    if iso_names:
+        iso = np.stack([from_lib(c, np.float32) for c in iso_names], axis=1)
+    else:
+        iso = np.ones((n, 1), dtype=np.float32)  # scoring.py:322-323
+
+    order = np.lexsort((cols["precursor_idx"], cols["rank"], decoy, cols["elution_group_idx"]))
+    eg, dc, rk, pi = (
+        cols["elution_group_idx"][order],
+        decoy[order],
+        cols["rank"][order],
+        cols["precursor_idx"][order],
+    )
+    if score_grouped and n:
+        change = np.ones(n, dtype=bool)
+        change[1:] = (eg[1:] != eg[:-1]) | (dc[1:] != dc[:-1]) | (rk[1:] != rk[:-1])
+        score_group_idx = (np.cumsum(change) - 1).astype(np.uint32)
+    else:
+        score_group_idx = np.arange(n, dtype=np.uint32)
+    if n > 1:
+        dup = (pi[1:] == pi[:-1]) & (score_group_idx[1:] == score_group_idx[:-1])
+        if dup.any():
+            raise ValueError("precursor_idx must be unique within a score group")
+
+    ch = channel[order]
+    flags = np.zeros(n, dtype=np.uint8)
+    if reference_channel >= 0 and n:
+        has_ref = np.zeros(int(score_group_idx[-1]) + 1, dtype=bool)
+        has_ref[score_group_idx[ch == reference_channel]] = True
+        flags[~has_ref[score_group_idx]] = _abi.FLAG_SKIP
+
+    out = {
+        "order": order,
+        "score_group_idx": score_group_idx,
+        "elution_group_idx": eg,
+        "decoy": dc,
+        "channel": ch,
+        "precursor_idx": pi,
+        "rank": rk,
+        "flags": flags,
+        "frag_start_idx": frag_start[order],
+        "frag_stop_idx": frag_stop[order],
+        "charge": charge[order],
+        "precursor_mz": prec_mz[order],
+        "isotope_intensity": np.ascontiguousarray(iso[order]),
+    }
+    for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center"):
+        out[c] = cols[c][order]
+    return out
+
+
+def pack_assembled(soa: dict) -> _abi.Marshalled:
+    return _abi.pack_candidates(
+        soa["precursor_idx"],
+        soa["rank"],
+        soa["frag_start_idx"],
+        soa["frag_stop_idx"],
+        soa["scan_start"],
+        soa["scan_stop"],
+        soa["scan_center"],
+        soa["frame_start"],
+        soa["frame_stop"],
+        soa["frame_center"],
+        soa["charge"],
+        soa["precursor_mz"],
+        soa["isotope_intensity"],
+        flags=soa["flags"],
+    )
+
+
+def fragment_columns(fragments_flat: pd.DataFrame, fragment_mz_column: str) -> tuple:
+    """assemble_fragments (scoring.py:355-392): the nine FragmentContainer arrays."""
+    if "cardinality" not in fragments_flat.columns:
+        logger.warning(
+            "Fragment cardinality column not found in fragment dataframe. Setting cardinality to 1."
+        )
+        fragments_flat["cardinality"] = np.ones(len(fragments_flat), dtype=np.uint8)
+    return (
+        fragments_flat["mz_library"].values,
+        fragments_flat[fragment_mz_column].values,
+        fragments_flat["intensity"].values,
+        fragments_flat["type"].values,
+        fragments_flat["loss_type"].values,
+        fragments_flat["charge"].values,
+        fragments_flat["number"].values,
+        fragments_flat["position"].values,
+        fragments_flat["cardinality"].values,
+    )
+
+
+def collect_candidates(
+    candidates_df: pd.DataFrame,
+    psm_proto_df: OutputPsmDF,
+    precursors_flat_df: pd.DataFrame,
+    rt_column: str,
+    mobility_column: str,
+    precursor_mz_column: str,
+) -> pd.DataFrame:
+    """scoring.py:394-467 (column names, order and merges)."""
+    precursor_idx, rank, features = psm_proto_df.to_precursor_df()
+    df = pd.DataFrame(features, columns=DEFAULT_FEATURE_COLUMNS)
+    df["precursor_idx"] = precursor_idx
+    df["rank"] = rank
+
+    candidate_columns = DEFAULT_CANDIDATE_COLUMNS.copy()
+    candidate_columns += ["score"] if "score" in candidates_df.columns else []
+    if "rank" not in candidates_df.columns:
+        candidates_df = candidates_df.assign(rank=np.zeros(len(candidates_df), dtype=np.uint8))
+    df = merge_missing_columns(
+        df, candidates_df, candidate_columns, on=["precursor_idx", "rank"], how="left"
+    )
+
+    precursor_df_columns = DEFAULT_PRECURSOR_COLUMNS + get_isotope_column_names(
+        precursors_flat_df.columns
+    )
+    for col in [rt_column, mobility_column, precursor_mz_column]:
+        if col not in precursor_df_columns:
+            precursor_df_columns.append(col)
+    df = merge_missing_columns(
+        df, precursors_flat_df, precursor_df_columns, on=["precursor_idx"], how="left"
+    )
+    df["delta_rt"] = df["rt_observed"] - df[rt_column]
+    df["n_K"] = df["sequence"].str.count("K")
+    df["n_R"] = df["sequence"].str.count("R")
+    df["n_P"] = df["sequence"].str.count("P")
+    return df
+
+
+def collect_fragments(psm_proto_df: OutputPsmDF, precursors_flat_df: pd.DataFrame) -> pd.DataFrame:
+    """scoring.py:520-580"""
+    df = pd.DataFrame(dict(zip(FRAGMENT_DF_COLUMNS, psm_proto_df.to_fragment_df(), strict=True)))
+    return merge_missing_columns(
+        df, precursors_flat_df, ["elution_group_idx", "decoy"], on=["precursor_idx"], how="left"
+    )
+
+
+def _jit_view(dia_data):
+    return dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
+
+
+class HipCandidateScoring:
+    """Calculate features for each precursor candidate on the GPU.
+
+    Drop-in for ``CandidateScoring`` (scoring.py:140-661): same keyword-only
+    constructor, same ``__call__``.  ``device`` selects the GPU (default: the
+    current HIP device / LOCAL_RANK).
+    """
+
+    def __init__(
+        self,
+        *,
+        dia_data,
+        precursors_flat: pd.DataFrame,
+        fragments_flat: pd.DataFrame,
+        rt_column: str,
+        mobility_column: str,
+        precursor_mz_column: str,
+        fragment_mz_column: str,
+        config: CandidateScoringConfig | None = None,
+        quadrupole_calibration=None,
+        device: int | None = None,
+    ):
+        from alphadia_amd import runtime  # loads libalphadia_hip.so; raises when missing
+
+        self._dia_data = dia_data
+        self.precursors_flat_df = precursors_flat.sort_values(by="precursor_idx")
+        self.fragments_flat = fragments_flat
+        if quadrupole_calibration is not None:
+            jit = getattr(quadrupole_calibration, "jit", None)
+            if jit is None:
+                raise AttributeError("quadrupole_calibration must have a jit method")
+            if not (
+                np.allclose(jit.sigma, 0.2)
+                and np.allclose(jit.delta_mu, 0.0)
+                and np.array_equal(jit.cycle, _jit_view(dia_data).cycle)
+            ):
+                raise NotImplementedError(
+                    "fitted quadrupole calibrations are not supported by the HIP backend "
+                    "(the reference workflow never fits one: scoring.py:209-212)"
+                )
+        self.config = config if config is not None else CandidateScoringConfig()
+        self.config.validate()
+        self.rt_column = rt_column
+        self.mobility_column = mobility_column
+        self.precursor_mz_column = precursor_mz_column
+        self.fragment_mz_column = fragment_mz_column
+
+        self._ctx = runtime.get_context(device)
+        self._ctx.stage_run(_jit_view(dia_data))
+        self._ctx.stage_fragments(*fragment_columns(self.fragments_flat, fragment_mz_column))
+
+    @property
+    def dia_data(self):
+        return self._dia_data
+
+    def score_soa(self, soa: dict, with_stats: bool = False) -> OutputPsmDF:
+        """Run the kernels on an assembled candidate SoA; returns host OutputPsmDF."""
+        arrays = self._ctx.score_host(
+            pack_assembled(soa), self.config.to_jitclass(), with_stats=with_stats
+        )
+        return OutputPsmDF(arrays)
+
+    def __call__(
+        self,
+        candidates_df: pd.DataFrame,
+        thread_count: int = 10,
+        debug: bool = False,
+        include_decoy_fragment_features: bool = False,
+    ):
+        del thread_count, include_decoy_fragment_features  # CPU-threading knobs of the reference
+        logger.info("Starting candidate scoring")
+        soa = assemble_candidates(
+            candidates_df,
+            self.precursors_flat_df,
+            self.precursor_mz_column,
+            score_grouped=self.config.score_grouped,
+            reference_channel=self.config.reference_channel,
+        )
+        if debug:  # scoring.py:628-631: first 10 score groups only
+            keep = soa["score_group_idx"] < 10
+            soa["flags"] = np.where(keep, soa["flags"], _abi.FLAG_SKIP).astype(np.uint8)
+        psm_proto_df = self.score_soa(soa)
+        logger.info("Collecting candidate features")
+        features_df = collect_candidates(
+            candidates_df,
+            psm_proto_df,
+            self.precursors_flat_df,
+            self.rt_column,
+            self.mobility_column,
+            self.precursor_mz_column,
+        )
+        logger.info("Collecting fragment features")
+        fragments_df = collect_fragments(psm_proto_df, self.precursors_flat_df)
+        logger.info("Finished candidate scoring")
+        return features_df, fragments_df

@@ -1,0 +1,481 @@
+"""Deterministic synthetic DIA runs, spectral libraries and candidate tables.
+
+These generators produce exactly the arrays the reference hands across the
+scoring boundary:
+
+* a Thermo-style run in the ``AlphaRawJIT`` layout
+  (reference ``alphadia/search/jitclasses/alpharaw_jit.py:78-138``): CSR peak
+  lists per spectrum (``peak_start_idx_list`` / ``peak_stop_idx_list``), float32
+  ``mz_values`` sorted ascending inside every spectrum and float32
+  ``intensity_values``;
+* a flat spectral library with the dtypes enforced by the reference schemas
+  (``alphadia/validation/schemas.py:11-48``);
+* a candidates table with the ``candidates_schema`` dtypes
+  (``alphadia/validation/schemas.py:51-73``).
+
+Nothing here is derived from reference code; it is our own data synthesis used
+by the tests, the golden-vector generator and ``bench.py``.
+"""
+
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+
+import numpy as np
+import pandas as pd
+
+ISOTOPE_DELTA = 1.0033548350700006  # same constant as candidate.py:160
+BASE_SEED = 20260928
+
+
+@dataclass
+class AlphaRawArrays:
+    """Host arrays of a non-ion-mobility run (field names follow AlphaRawJIT)."""
+
+    cycle: np.ndarray  # float64 (1, L, 1, 2); MS1 row is (-1, -1)
+    rt_values: np.ndarray  # float32 [n_spec]
+    peak_start_idx_list: np.ndarray  # int64 [n_spec]
+    peak_stop_idx_list: np.ndarray  # int64 [n_spec]
+    mz_values: np.ndarray  # float32 [n_peaks]
+    intensity_values: np.ndarray  # float32 [n_peaks]
+    mobility_values: np.ndarray = field(
+        default_factory=lambda: np.array([1e-6, 0.0], dtype=np.float32)
+    )
+    zeroth_frame: int = 0
+    scan_max_index: int = 1
+    has_mobility: bool = False
+
+    @property
+    def cycle_len(self) -> int:
+        return int(self.cycle.shape[1])
+
+    @property
+    def n_spectra(self) -> int:
+        return int(self.rt_values.shape[0])
+
+    @property
+    def n_cycles(self) -> int:
+        return self.n_spectra // self.cycle_len
+
+    @property
+    def frame_max_index(self) -> int:
+        return self.n_spectra - 1
+
+    @property
+    def precursor_cycle_max_index(self) -> int:
+        return self.n_spectra // self.cycle_len
+
+    @property
+    def max_mz_value(self) -> np.float32:
+        return np.float32(self.mz_values.max()) if self.mz_values.size else np.float32(0)
+
+    @property
+    def min_mz_value(self) -> np.float32:
+        return np.float32(self.mz_values.min()) if self.mz_values.size else np.float32(0)
+
+    def nbytes(self) -> int:
+        return int(
+            self.mz_values.nbytes
+            + self.intensity_values.nbytes
+            + self.peak_start_idx_list.nbytes
+            + self.peak_stop_idx_list.nbytes
+            + self.rt_values.nbytes
+        )
+
+
+@dataclass
+class SyntheticLibrary:
+    precursor_df: pd.DataFrame
+    fragment_df: pd.DataFrame
+
+
+def make_cycle(n_ms2: int = 60, mz_lo: float = 400.0, mz_hi: float = 1000.0) -> np.ndarray:
+    """DIA cycle: 1 MS1 row (-1,-1) + ``n_ms2`` contiguous isolation windows."""
+    cycle = np.zeros((1, n_ms2 + 1, 1, 2), dtype=np.float64)
+    cycle[0, 0, 0, :] = -1.0
+    edges = np.linspace(mz_lo, mz_hi, n_ms2 + 1)
+    cycle[0, 1:, 0, 0] = edges[:-1]
+    cycle[0, 1:, 0, 1] = edges[1:]
+    return cycle
+
+
+def make_library(
+    n_precursors: int,
+    seed: int,
+    k_fragments: int = 12,
+    n_isotopes: int = 4,
+    mz_lo: float = 400.0,
+    mz_hi: float = 1000.0,
+    rt_max: float = 600.0,
+    few_fragment_fraction: float = 0.0,
+    frag_mz_lo: float = 200.0,
+    frag_mz_hi: float = 1800.0,
+) -> SyntheticLibrary:
+    """Flat library: 50 % decoys, target/decoy pairs share an elution group.
+
+    ``few_fragment_fraction`` > 0 gives that share of precursors only 2-3
+    fragments (exercises the "<=3 fragments" early exit, candidate.py:190).
+    """
+    rng = np.random.default_rng([seed, 1])
+    n = int(n_precursors)
+    precursor_idx = np.arange(n, dtype=np.uint32)
+    elution_group_idx = (precursor_idx // 2).astype(np.uint32)
+    decoy = (precursor_idx % 2).astype(np.uint8)
+    charge = rng.choice(np.array([2, 3], dtype=np.uint8), size=n, p=[0.6, 0.4])
+    mz = rng.uniform(mz_lo, mz_hi, n).astype(np.float32)
+    rt = rng.uniform(0.0, rt_max, n).astype(np.float32)
+
+    # averagine-like isotope envelope, normalised to 1
+    lam = (mz.astype(np.float64) * charge) / 1800.0
+    iso = np.empty((n, n_isotopes), dtype=np.float64)
+    term = np.exp(-lam)
+    for i in range(n_isotopes):
+        iso[:, i] = term
+        term = term * lam / (i + 1)
+    iso *= rng.uniform(0.9, 1.1, iso.shape)
+    iso /= iso.sum(axis=1, keepdims=True)
+    iso = iso.astype(np.float32)
+
+    n_frag = np.full(n, k_fragments, dtype=np.int64)
+    if few_fragment_fraction > 0:
+        few = rng.random(n) < few_fragment_fraction
+        n_frag[few] = rng.integers(2, 4, few.sum())
+    stop = np.cumsum(n_frag)
+    start = stop - n_frag
+    total = int(stop[-1]) if n else 0
+
+    frag_mz = rng.uniform(frag_mz_lo, frag_mz_hi, total).astype(np.float32)
+    # distinct intensities inside one precursor: a random permutation of a jittered grid
+    base = rng.random(total)
+    frag_int = (0.01 + 0.99 * base).astype(np.float32)
+    within = np.arange(total, dtype=np.int64) - np.repeat(start, n_frag)
+    frag_type = np.where(rng.random(total) < 0.5, 98, 121).astype(np.uint8)
+    frag_number = (within + 1).astype(np.uint8)
+    frag_position = within.astype(np.uint8)
+
+    precursor_df = pd.DataFrame(
+        {
+            "elution_group_idx": elution_group_idx,
+            "precursor_idx": precursor_idx,
+            "channel": np.zeros(n, dtype=np.uint32),
+            "decoy": decoy,
+            "flat_frag_start_idx": start.astype(np.uint32),
+            "flat_frag_stop_idx": stop.astype(np.uint32),
+            "charge": charge,
+            "rt_library": rt,
+            "mobility_library": np.zeros(n, dtype=np.float32),
+            "mz_library": mz,
+            "proteins": np.full(n, "P", dtype=object),
+            "genes": np.full(n, "G", dtype=object),
+            "sequence": np.full(n, "PEPTIDEK", dtype=object),
+            "mods": np.full(n, "", dtype=object),
+            "mod_sites": np.full(n, "", dtype=object),
+        }
+    )
+    for i in range(n_isotopes):
+        precursor_df[f"i_{i}"] = iso[:, i]
+
+    fragment_df = pd.DataFrame(
+        {
+            "mz_library": frag_mz,
+            "intensity": frag_int,
+            "cardinality": np.ones(total, dtype=np.uint8),
+            "type": frag_type,
+            "loss_type": np.zeros(total, dtype=np.uint8),
+            "charge": np.ones(total, dtype=np.uint8),
+            "number": frag_number,
+            "position": frag_position,
+        }
+    )
+    return SyntheticLibrary(precursor_df, fragment_df)
+
+
+@dataclass
+class PlantedPeaks:
+    """Peaks to be merged into the noise of a run (global spectrum index)."""
+
+    spec_idx: np.ndarray  # int64
+    mz: np.ndarray  # float32
+    intensity: np.ndarray  # float32
+    apex_cycle: np.ndarray  # int64 [n_precursors], -1 when not planted
+
+
+def plant_peptides(
+    library: SyntheticLibrary,
+    cycle: np.ndarray,
+    n_cycles: int,
+    seed: int,
+    fraction: float = 0.3,
+    sigma_cycles: float = 2.5,
+    half_width: int = 8,
+    n_isotopes: int = 3,
+) -> PlantedPeaks:
+    """Gaussian elution profiles for ``fraction`` of the target precursors."""
+    rng = np.random.default_rng([seed, 2])
+    pdf, fdf = library.precursor_df, library.fragment_df
+    n = len(pdf)
+    L = cycle.shape[1]
+    targets = np.flatnonzero(pdf["decoy"].values == 0)
+    chosen = targets[rng.random(targets.size) < fraction]
+    apex = np.full(n, -1, dtype=np.int64)
+    lo, hi = 16, max(17, n_cycles - 16)
+    apex[chosen] = rng.integers(lo, hi, chosen.size)
+
+    win_lo = cycle[0, 1:, 0, 0]
+    win_hi = cycle[0, 1:, 0, 1]
+
+    spec_parts, mz_parts, int_parts = [], [], []
+    offs = np.arange(-half_width, half_width + 1)
+    gauss = np.exp(-0.5 * (offs / sigma_cycles) ** 2)
+
+    p_mz = pdf["mz_library"].values.astype(np.float64)[chosen]
+    p_ch = pdf["charge"].values.astype(np.float64)[chosen]
+    p_apex = apex[chosen]
+    cyc = p_apex[:, None] + offs[None, :]  # (P, W)
+    ok = (cyc >= 0) & (cyc < n_cycles)
+
+    # MS1 isotopes
+    for i in range(n_isotopes):
+        iso_int = pdf[f"i_{i}"].values.astype(np.float64)[chosen]
+        iso_mz = p_mz + i * ISOTOPE_DELTA / p_ch
+        ppm = rng.normal(2.0, 1.0, cyc.shape)
+        mzv = iso_mz[:, None] * (1.0 + ppm * 1e-6)
+        inten = 2e4 * iso_int[:, None] * gauss[None, :]
+        spec = cyc * L
+        spec_parts.append(spec[ok])
+        mz_parts.append(mzv[ok])
+        int_parts.append(inten[ok])
+
+    # MS2 fragments in the window that contains the precursor m/z
+    w = np.searchsorted(win_hi, p_mz, side="right")
+    w = np.clip(w, 0, len(win_lo) - 1)
+    fstart = pdf["flat_frag_start_idx"].values.astype(np.int64)[chosen]
+    fstop = pdf["flat_frag_stop_idx"].values.astype(np.int64)[chosen]
+    kmax = int((fstop - fstart).max()) if chosen.size else 0
+    fmz_all = fdf["mz_library"].values
+    fint_all = fdf["intensity"].values
+    for k in range(kmax):
+        has = (fstart + k) < fstop
+        idx = np.where(has, fstart + k, fstart)
+        fmz = fmz_all[idx].astype(np.float64)
+        fin = fint_all[idx].astype(np.float64)
+        ppm = rng.normal(2.0, 1.0, cyc.shape)
+        mzv = fmz[:, None] * (1.0 + ppm * 1e-6)
+        inten = 8e3 * fin[:, None] * gauss[None, :]
+        spec = cyc * L + 1 + w[:, None]
+        m = ok & has[:, None]
+        spec_parts.append(spec[m])
+        mz_parts.append(mzv[m])
+        int_parts.append(inten[m])
+
+    if spec_parts:
+        spec_idx = np.concatenate(spec_parts).astype(np.int64)
+        mz = np.concatenate(mz_parts).astype(np.float32)
+        inten = np.concatenate(int_parts).astype(np.float32)
+    else:
+        spec_idx = np.zeros(0, np.int64)
+        mz = np.zeros(0, np.float32)
+        inten = np.zeros(0, np.float32)
+    return PlantedPeaks(spec_idx, mz, inten, apex)
+
+
+def _gen_chunk(args):
+    (seed, chunk_id, c0, c1, L, ms1_peaks, ms2_peaks, p_spec, p_mz, p_int, r1, r2) = args
+    rng = np.random.default_rng([seed, 3, chunk_id])
+    n_cyc = c1 - c0
+    n_spec = n_cyc * L
+    per_spec = np.full(L, ms2_peaks, dtype=np.int64)
+    per_spec[0] = ms1_peaks
+    counts = np.tile(per_spec, n_cyc)
+    n_noise = int(counts.sum())
+    spec_local = np.repeat(np.arange(n_spec, dtype=np.int64), counts)
+    is_ms1 = (spec_local % L) == 0
+    u = rng.random(n_noise, dtype=np.float32)
+    mz = np.where(is_ms1, r1[0] + (r1[1] - r1[0]) * u, r2[0] + (r2[1] - r2[0]) * u).astype(np.float32)
+    inten = np.exp(rng.standard_normal(n_noise, dtype=np.float32) + np.float32(3.0)).astype(
+        np.float32
+    )
+    if p_spec.size:
+        spec_local = np.concatenate([spec_local, p_spec - c0 * L])
+        mz = np.concatenate([mz, p_mz])
+        inten = np.concatenate([inten, p_int])
+    key = (spec_local.astype(np.uint64) << np.uint64(32)) | mz.view(np.uint32).astype(np.uint64)
+    order = np.argsort(key, kind="stable")
+    mz = mz[order]
+    inten = inten[order]
+    cnt = np.bincount(spec_local, minlength=n_spec).astype(np.int64)
+    return mz, inten, cnt
+
+
+def make_thermo_run(
+    n_cycles: int,
+    seed: int,
+    cycle: np.ndarray | None = None,
+    ms1_peaks: int = 4000,
+    ms2_peaks: int = 1500,
+    cycle_time: float = 1.5,
+    planted: PlantedPeaks | None = None,
+    chunk_cycles: int = 100,
+    threads: int = 8,
+    ms1_mz_range: tuple = (350.0, 1100.0),
+    ms2_mz_range: tuple = (150.0, 1600.0),
+) -> AlphaRawArrays:
+    """Thermo-style run "T" of SURVEY.md section 8(d)."""
+    if cycle is None:
+        cycle = make_cycle()
+    L = cycle.shape[1]
+    n_spec = n_cycles * L
+    rt = (np.arange(n_spec, dtype=np.float64) * (cycle_time / L)).astype(np.float32)
+
+    if planted is not None and planted.spec_idx.size:
+        order = np.argsort(planted.spec_idx, kind="stable")
+        ps, pm, pi = planted.spec_idx[order], planted.mz[order], planted.intensity[order]
+    else:
+        ps = np.zeros(0, np.int64)
+        pm = np.zeros(0, np.float32)
+        pi = np.zeros(0, np.float32)
+
+    jobs = []
+    for cid, c0 in enumerate(range(0, n_cycles, chunk_cycles)):
+        c1 = min(n_cycles, c0 + chunk_cycles)
+        a = np.searchsorted(ps, c0 * L, side="left")
+        b = np.searchsorted(ps, c1 * L, side="left")
+        jobs.append(
+            (seed, cid, c0, c1, L, ms1_peaks, ms2_peaks, ps[a:b], pm[a:b], pi[a:b],
+             ms1_mz_range, ms2_mz_range)
+        )
+
+    if threads > 1 and len(jobs) > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(_gen_chunk, jobs))
+    else:
+        parts = [_gen_chunk(j) for j in jobs]
+
+    mz = np.concatenate([p[0] for p in parts])
+    inten = np.concatenate([p[1] for p in parts])
+    cnt = np.concatenate([p[2] for p in parts])
+    stop = np.cumsum(cnt)
+    start = stop - cnt
+    return AlphaRawArrays(
+        cycle=cycle,
+        rt_values=rt,
+        peak_start_idx_list=start.astype(np.int64),
+        peak_stop_idx_list=stop.astype(np.int64),
+        mz_values=mz,
+        intensity_values=inten,
+    )
+
+
+def make_candidates(
+    library: SyntheticLibrary,
+    n_cycles: int,
+    cycle_len: int,
+    seed: int,
+    per_precursor: int = 3,
+    apex_cycle: np.ndarray | None = None,
+    h_lo: int = 3,
+    h_hi: int = 14,
+    even_fraction: float = 0.0,
+) -> pd.DataFrame:
+    """Candidate boxes: rank 0 sits on the planted apex when there is one."""
+    rng = np.random.default_rng([seed, 4])
+    pdf = library.precursor_df
+    n = len(pdf)
+    C = per_precursor
+    pidx = np.repeat(pdf["precursor_idx"].values.astype(np.uint32), C)
+    eg = np.repeat(pdf["elution_group_idx"].values.astype(np.uint32), C)
+    rank = np.tile(np.arange(C, dtype=np.uint8), n)
+    h = rng.integers(h_lo, h_hi + 1, n * C)
+    c = rng.integers(0, n_cycles, n * C)
+    if apex_cycle is not None:
+        ap = np.repeat(apex_cycle, C)
+        use = (ap >= 0) & (rank == 0)
+        c = np.where(use, ap, c)
+    c = np.clip(c, h, n_cycles - h - 1)
+    frame_center = c * cycle_len
+    frame_start = (c - h) * cycle_len
+    frame_stop = (c + h + 1) * cycle_len
+    if even_fraction > 0:
+        ev = rng.random(n * C) < even_fraction
+        frame_stop = np.where(ev, frame_stop - cycle_len, frame_stop)
+    df = pd.DataFrame(
+        {
+            "elution_group_idx": eg,
+            "precursor_idx": pidx,
+            "rank": rank,
+            "scan_start": np.zeros(n * C, dtype=np.int64),
+            "scan_stop": np.ones(n * C, dtype=np.int64),
+            "scan_center": np.zeros(n * C, dtype=np.int64),
+            "frame_start": frame_start.astype(np.int64),
+            "frame_stop": frame_stop.astype(np.int64),
+            "frame_center": frame_center.astype(np.int64),
+            "score": rng.uniform(0, 100, n * C).astype(np.float32),
+        }
+    )
+    return df
+
+
+@dataclass
+class SyntheticCase:
+    dia: AlphaRawArrays
+    library: SyntheticLibrary
+    candidates_df: pd.DataFrame
+    apex_cycle: np.ndarray
+
+
+def make_case(
+    n_precursors: int,
+    n_cycles: int,
+    config_id: int = 1,
+    per_precursor: int = 3,
+    ms1_peaks: int = 4000,
+    ms2_peaks: int = 1500,
+    n_ms2: int = 60,
+    planted_fraction: float = 0.3,
+    few_fragment_fraction: float = 0.0,
+    even_fraction: float = 0.0,
+    threads: int = 8,
+    seed: int | None = None,
+    mz_lo: float = 400.0,
+    mz_hi: float = 1000.0,
+    frag_mz_lo: float = 200.0,
+    frag_mz_hi: float = 1800.0,
+    ms1_mz_range: tuple = (350.0, 1100.0),
+    ms2_mz_range: tuple = (150.0, 1600.0),
+) -> SyntheticCase:
+    """One full synthetic workload (run + library + candidates)."""
+    seed = BASE_SEED + config_id if seed is None else seed
+    cycle = make_cycle(n_ms2=n_ms2, mz_lo=mz_lo, mz_hi=mz_hi)
+    lib = make_library(
+        n_precursors,
+        seed,
+        mz_lo=mz_lo,
+        mz_hi=mz_hi,
+        rt_max=n_cycles * 1.5,
+        few_fragment_fraction=few_fragment_fraction,
+        frag_mz_lo=frag_mz_lo,
+        frag_mz_hi=frag_mz_hi,
+    )
+    planted = plant_peptides(lib, cycle, n_cycles, seed, fraction=planted_fraction)
+    dia = make_thermo_run(
+        n_cycles,
+        seed,
+        cycle=cycle,
+        ms1_peaks=ms1_peaks,
+        ms2_peaks=ms2_peaks,
+        planted=planted,
+        threads=threads,
+        ms1_mz_range=ms1_mz_range,
+        ms2_mz_range=ms2_mz_range,
+    )
+    cands = make_candidates(
+        lib,
+        n_cycles,
+        cycle.shape[1],
+        seed,
+        per_precursor=per_precursor,
+        apex_cycle=planted.apex_cycle,
+        even_fraction=even_fraction,
+    )
+    return SyntheticCase(dia, lib, cands, planted.apex_cycle)

@@ -1,0 +1,214 @@
+/*
+ * alphadia_hip.h - C ABI of libalphadia_hip.so, the MI355X-native drop-in for
+ * alphaDIA's peptide-centric candidate scoring hot path.
+ *
+ * Nothing like this exists in the reference (it is pure Python + Numba); each
+ * entry point below names the reference interface whose work it replaces.
+ * All paths are relative to the MannLabs/alphadia source tree.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types cross this ABI
+ *   - every function returns ADH_OK (0) or a negative error code; the message
+ *     is available from adh_last_error() (thread local)
+ *   - per-candidate soft failures are DATA (valid[i] == 0), never errors,
+ *     exactly like `Candidate.failed` (search/scoring/containers/candidate.py:190-325)
+ *   - host buffers are owned by the caller; device buffers live behind the
+ *     opaque handle until adh_destroy()
+ *   - a handle is bound to one GPU and is not re-entrant (one host thread per GPU)
+ */
+#ifndef ALPHADIA_HIP_H
+#define ALPHADIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADH_OK 0
+#define ADH_ERR_INVALID_ARGUMENT (-1)
+#define ADH_ERR_HIP (-2)
+#define ADH_ERR_NOT_STAGED (-3)
+#define ADH_ERR_UNSUPPORTED (-4)
+#define ADH_ERR_OUT_OF_MEMORY (-5)
+
+#define ADH_NUM_FEATURES 46 /* alphadia/constants/settings.py:5 */
+
+/* candidate flag bits */
+#define ADH_FLAG_SKIP 1u /* score group without its reference channel: score_group.py:50-64 */
+
+/*
+ * Raw data of a non-ion-mobility run: the fields of AlphaRawJIT
+ * (search/jitclasses/alpharaw_jit.py:78-138) that the scoring path reads.
+ * Peaks are CSR by spectrum, m/z ascending inside each spectrum.
+ */
+typedef struct adh_alpharaw {
+    const double *cycle;            /* (1, cycle_len, cycle_scans, 2) float64, C order */
+    int32_t cycle_len;              /* cycle.shape[1] */
+    int32_t cycle_scans;            /* cycle.shape[2] (1 for AlphaRaw) */
+    const float *rt_values;         /* [n_spectra] seconds */
+    int64_t n_spectra;
+    const float *mobility_values;   /* [n_mobility]; {1e-6, 0} for AlphaRaw */
+    int64_t n_mobility;
+    const int64_t *peak_start_idx;  /* [n_spectra] */
+    const int64_t *peak_stop_idx;   /* [n_spectra] */
+    const float *mz_values;         /* [n_peaks] */
+    const float *intensity_values;  /* [n_peaks] */
+    int64_t n_peaks;
+} adh_alpharaw_t;
+
+/*
+ * Flat fragment library: the nine arrays of FragmentContainer
+ * (search/jitclasses/fragment_container.py:11-46) as assembled by
+ * CandidateScoring.assemble_fragments (search/scoring/scoring.py:355-392).
+ */
+typedef struct adh_fragments {
+    int64_t n;
+    const float *mz_library;
+    const float *mz;          /* the configured fragment m/z column (library or calibrated) */
+    const float *intensity;
+    const uint8_t *type;
+    const uint8_t *loss_type;
+    const uint8_t *charge;
+    const uint8_t *number;
+    const uint8_t *position;
+    const uint8_t *cardinality;
+} adh_fragments_t;
+
+/*
+ * Candidate table in struct-of-arrays form: the columns
+ * ScoreGroupContainer.build_from_df receives
+ * (search/scoring/containers/score_group.py:145-229), already in
+ * score-group order; row i of every output belongs to candidate i.
+ */
+typedef struct adh_candidates {
+    int64_t n;
+    const uint32_t *precursor_idx;
+    const uint8_t *rank;
+    const uint8_t *flags;            /* ADH_FLAG_* or NULL */
+    const uint32_t *frag_start_idx;
+    const uint32_t *frag_stop_idx;
+    const int64_t *scan_start;
+    const int64_t *scan_stop;
+    const int64_t *scan_center;
+    const int64_t *frame_start;
+    const int64_t *frame_stop;
+    const int64_t *frame_center;
+    const uint8_t *charge;
+    const float *precursor_mz;
+    const float *isotope_intensity;  /* [n, n_isotope_cols] row major */
+    int32_t n_isotope_cols;
+} adh_candidates_t;
+
+/* CandidateScoringConfigJIT (search/scoring/config.py:13-60) */
+typedef struct adh_scoring_config {
+    int32_t collect_fragments;
+    int32_t score_grouped;
+    int32_t exclude_shared_ions;
+    uint32_t top_k_fragments;
+    uint32_t top_k_isotopes;
+    int32_t reference_channel;
+    uint32_t quant_window;
+    int32_t quant_all;
+    float precursor_mz_tolerance;
+    float fragment_mz_tolerance;
+    int32_t experimental_xic;
+} adh_scoring_config_t;
+
+/*
+ * OutputPsmDF (search/scoring/output.py:17-70): `valid`, `precursor_idx`,
+ * `rank`, `features[n,46]` and thirteen per-fragment tables [n, top_k].
+ * Buffers must be zero-initialised by the caller for the *_device entry
+ * point; the host entry point zero-fills them itself.
+ */
+typedef struct adh_output {
+    int64_t n;
+    int32_t top_k;
+    uint8_t *valid;
+    uint32_t *precursor_idx;
+    uint8_t *rank;
+    float *features;               /* [n, 46] */
+    uint32_t *fragment_precursor_idx;
+    uint8_t *fragment_rank;
+    float *fragment_mz_library;
+    float *fragment_mz;
+    float *fragment_mz_observed;
+    float *fragment_height;
+    float *fragment_intensity;
+    float *fragment_mass_error;
+    float *fragment_correlation;
+    uint8_t *fragment_position;
+    uint8_t *fragment_number;
+    uint8_t *fragment_type;
+    uint8_t *fragment_charge;
+    uint8_t *fragment_loss_type;
+    uint32_t *stat_matched_peaks;  /* optional [n]: peaks accumulated by get_dense, or NULL */
+} adh_output_t;
+
+typedef struct adh_handle adh_handle_t;
+
+/* Thread-local message of the last failing call. */
+const char *adh_last_error(void);
+
+/* Number of visible HIP devices. */
+int adh_device_count(int *count);
+
+/* Create / destroy a per-GPU context. */
+int adh_create(adh_handle_t **handle, int device);
+int adh_destroy(adh_handle_t *handle);
+
+/*
+ * Stage the run in HBM once (replaces DiaData.to_jitclass(),
+ * raw_data/alpharaw_wrapper.py:124-142, as consumed at scoring.py:639).
+ * Also builds the per-spectrum m/z bucket index used instead of the
+ * reference's binary search (alpharaw_jit.py:53-64,293-297).
+ */
+int adh_stage_alpharaw(adh_handle_t *handle, const adh_alpharaw_t *dia);
+
+/* Stage the flat fragment library (replaces assemble_fragments, scoring.py:355-392). */
+int adh_stage_fragments(adh_handle_t *handle, const adh_fragments_t *fragments);
+
+/*
+ * Score candidates: host table in, host OutputPsmDF out.  Replaces the
+ * pjit loop `_process_score_groups` (scoring.py:114-137,634-643) i.e.
+ * ScoreGroup.process -> Candidate.process for every candidate.
+ */
+int adh_score_candidates(adh_handle_t *handle, const adh_candidates_t *candidates,
+                         const adh_scoring_config_t *config, adh_output_t *out);
+
+/*
+ * Same, but `out` holds DEVICE pointers (zero-initialised, on the handle's
+ * GPU) and the work is enqueued on `hip_stream` (a hipStream_t, may be NULL
+ * for the handle's own stream) without synchronising.  Used when the tables
+ * are reassembled across GPUs with an RCCL all-gather before leaving HBM.
+ */
+int adh_score_candidates_device(adh_handle_t *handle, const adh_candidates_t *candidates,
+                                const adh_scoring_config_t *config, adh_output_t *out_device,
+                                void *hip_stream);
+
+/* Block until all work enqueued on the handle's stream has finished. */
+int adh_synchronize(adh_handle_t *handle);
+
+/*
+ * Average duration (milliseconds) of the dominant scoring kernel over the
+ * launches since the last reset, measured with HIP events on the launch stream.
+ */
+int adh_kernel_time_ms(adh_handle_t *handle, double *avg_ms, int64_t *launches, int reset);
+
+/*
+ * Fragment competition inside one run (replaces `_compete_for_fragments`,
+ * fragcomp/fragcomp.py:51-143).  PSMs are sorted by (window, proba, precursor)
+ * and windows are given as [start, stop) row ranges exactly as
+ * FragmentCompetition.__call__ prepares them (fragcomp.py:268-289).
+ * valid[] is input/output (all ones on entry).
+ */
+int adh_fragcomp(adh_handle_t *handle, int64_t n_windows, const int64_t *window_start,
+                 const int64_t *window_stop, int64_t n_psm, const float *rt,
+                 const int64_t *frag_start_idx, const int64_t *frag_stop_idx,
+                 int64_t n_frag, const float *fragment_mz, double rt_tol_seconds,
+                 double mass_tol_ppm, uint8_t *valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALPHADIA_HIP_H */

@@ -1,0 +1,1242 @@
+/*
+ * adh_oracle.cpp - CPU restatement of alphaDIA's candidate-scoring hot path.
+ *
+ * TEST INFRASTRUCTURE.  This is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it.  The
+ * product (alphadia_amd/, libalphadia_hip.so) never links, imports or calls
+ * anything in this directory.
+ *
+ * What it restates (paths relative to the MannLabs/alphadia tree):
+ *   AlphaRawJIT.get_dense                 search/jitclasses/alpharaw_jit.py:208-337
+ *   mass_range                            search/jitclasses/utils.py:15-20
+ *   FragmentContainer filters             search/jitclasses/fragment_container.py:56-120
+ *   Candidate.process                     search/scoring/containers/candidate.py:166-481
+ *   quadrupole transfer fn / template     search/scoring/quadrupole.py:40-43,80-115,261-335
+ *   profiles / envelopes / correlations   search/scoring/utils.py:21-66,478-647
+ *   location / precursor / fragment / profile features
+ *                                         search/scoring/features/*.py
+ *   correlation_coefficient etc.          search/scoring/scoring_utils.py:14-152
+ *   _compete_for_fragments                fragcomp/fragcomp.py:19-143
+ *
+ * Arithmetic follows NUMBA's typing of the reference source (the production
+ * behaviour), not NumPy's:
+ *   - python float literals are float64, int literals int64
+ *   - scalar  f32 (op) f64 -> f64 ; scalar f32 (op) int64 -> f64
+ *   - array   f32 (op) f64 scalar -> f64 array
+ *   - array   f32 (op) integer scalar -> f32 array (numba ufunc_can_cast lets
+ *     integers cast to any float when inputs are mixed)
+ *   - np.sum / np.mean of a float32 array accumulate sequentially in float32,
+ *     np.sum(axis=k) adds slices in index order
+ *   - np.zeros(n) / np.ones(n) default to float64; np.corrcoef works in float64
+ *   - stores into float32 arrays round to nearest even
+ * Compile with -ffp-contract=off: Numba does not fuse mul+add in this code.
+ *
+ * Parity pinning: checked against the golden vectors in tests/golden/*.npz,
+ * which were produced by running the reference itself (tests/golden/make_golden.py),
+ * and against the reference's own known-answer tests restated in tests/.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "../include/alphadia_hip.h"
+
+namespace {
+
+constexpr double ISOTOPE_DELTA = 1.0033548350700006; /* candidate.py:160 */
+
+/*
+ * 0 (default): Numba typing, the production behaviour and what the HIP path must match.
+ * 1: NumPy-2 typing of the three expressions where running the reference under the
+ *    numba stub (tests/golden/ref_shim.py) keeps float32 although Numba promotes to
+ *    float64.  Only used to pin this restatement against the golden vectors.
+ */
+int g_numpy_typing = 0;
+
+/* ------------------------------------------------------------------ helpers */
+
+/* python slice(start, stop) on a sequence of length n -> [a, b) */
+inline void py_slice(int64_t start, int64_t stop, int64_t n, int64_t &a, int64_t &b) {
+    if (start < 0) start += n;
+    if (stop < 0) stop += n;
+    a = std::min<int64_t>(std::max<int64_t>(start, 0), n);
+    b = std::min<int64_t>(std::max<int64_t>(stop, 0), n);
+    if (b < a) b = a;
+}
+
+/* np.argsort (stable for the sizes that occur; ties keep index order) */
+template <typename T>
+std::vector<int64_t> argsort(const std::vector<T> &v) {
+    std::vector<int64_t> idx(v.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return v[a] < v[b]; });
+    return idx;
+}
+
+/* np.median of a small vector (numba _median_inner: (a + b) / 2 for even n) */
+inline double median_f32(std::vector<float> v) {
+    size_t n = v.size();
+    std::sort(v.begin(), v.end());
+    if (n & 1) return v[n / 2];
+    float s = v[n / 2 - 1] + v[n / 2];
+    return (double)s / 2.0;
+}
+inline double median_i64(std::vector<int64_t> v) {
+    size_t n = v.size();
+    std::sort(v.begin(), v.end());
+    if (n & 1) return (double)v[n / 2];
+    return (double)(v[n / 2 - 1] + v[n / 2]) / 2.0;
+}
+
+/* alpharaw_jit.py:53-64 */
+inline int64_t search_sorted_left(const float *slice, int64_t len, float value) {
+    int64_t left = 0, right = len;
+    while (left < right) {
+        int64_t mid = (left + right) >> 1;
+        if (slice[mid] < value)
+            left = mid + 1;
+        else
+            right = mid;
+    }
+    return left;
+}
+
+/* dense tile (2, K, O, S, F) float32 */
+struct Dense {
+    int K = 0, O = 0, S = 0, F = 0;
+    std::vector<float> v;
+    void init(int k, int o, int s, int f) {
+        K = k; O = o; S = s; F = f;
+        v.assign((size_t)2 * k * o * s * f, 0.0f);
+    }
+    inline float &at(int c, int k, int o, int s, int f) {
+        return v[((((size_t)c * K + k) * O + o) * S + s) * F + f];
+    }
+    inline float at(int c, int k, int o, int s, int f) const {
+        return v[((((size_t)c * K + k) * O + o) * S + s) * F + f];
+    }
+};
+
+/* ------------------------------------------------------------- get_dense */
+
+/* _calculate_valid_scans, alpharaw_jit.py:19-50 */
+void valid_scans(const adh_alpharaw_t &d, double q_lo, double q_hi, std::vector<int64_t> &out) {
+    out.clear();
+    int64_t rows = (int64_t)d.cycle_len * d.cycle_scans;
+    for (int64_t i = 0; i < rows; ++i) {
+        double mz_start = d.cycle[2 * i], mz_stop = d.cycle[2 * i + 1];
+        if (q_lo <= mz_stop && q_hi >= mz_start) out.push_back(i);
+    }
+}
+
+/* AlphaRawJIT.get_dense, alpharaw_jit.py:208-337 */
+void get_dense_alpharaw(const adh_alpharaw_t &d, int64_t frame_start, int64_t frame_stop,
+                        const float *mzq, int K, float tol, double q_lo, double q_hi,
+                        bool absolute, Dense &out, std::vector<int64_t> &pidx,
+                        uint32_t *matched) {
+    const double HIGH_EPSILON = 1e-26, LOW_EPSILON = 1e-36;
+    /* mass_range, jitclasses/utils.py:15-20: all float32 (int literal 10**6 casts to f32) */
+    std::vector<float> lo(K), hi(K);
+    for (int k = 0; k < K; ++k) {
+        float t = tol * mzq[k];
+        float q = t / 1000000.0f;
+        lo[k] = mzq[k] - q;
+        hi[k] = mzq[k] + q;
+    }
+    valid_scans(d, q_lo, q_hi, pidx);
+    int O = (int)pidx.size();
+    int64_t L = d.cycle_len;
+    int64_t c0 = frame_start / L, c1 = frame_stop / L;
+    int F = (int)std::max<int64_t>(c1 - c0, 0);
+    out.init(K, O, 2, F);
+    if (!absolute)
+        for (size_t i = out.v.size() / 2; i < out.v.size(); ++i) out.v[i] = tol;
+    for (int i = 0; i < F; ++i) {
+        int64_t cycle_idx = c0 + i;
+        for (int j = 0; j < O; ++j) {
+            int64_t scan_idx = pidx[j] + cycle_idx * L;
+            int64_t stop = d.peak_stop_idx[scan_idx];
+            int64_t idx = d.peak_start_idx[scan_idx];
+            for (int k = 0; k < K; ++k) {
+                idx += search_sorted_left(d.mz_values + idx, stop - idx, lo[k]);
+                while (idx < stop && d.mz_values[idx] <= hi[k]) {
+                    float acc_int = out.at(0, k, j, 0, i);
+                    float acc_d1 = out.at(1, k, j, 0, i);
+                    float new_int = d.intensity_values[idx];
+                    new_int = ((double)new_int > HIGH_EPSILON) ? new_int : new_int * 0.0f;
+                    float new_mz = d.mz_values[idx];
+                    float new_d1;
+                    if (absolute) {
+                        float a = acc_d1 * acc_int;
+                        float b = new_int * new_mz;
+                        float n32 = a + b;
+                        float d32 = acc_int + new_int;
+                        new_d1 = (float)(((double)n32 + LOW_EPSILON) / ((double)d32 + LOW_EPSILON));
+                    } else {
+                        float e0 = new_mz - mzq[k];
+                        float e1 = e0 / mzq[k];
+                        double err = (double)e1 * 1000000.0; /* f32 * int64 scalar -> f64 */
+                        float a = acc_d1 * acc_int;
+                        double num = (double)a + (double)new_int * err + LOW_EPSILON;
+                        float d32 = acc_int + new_int;
+                        new_d1 = (float)(num / ((double)d32 + LOW_EPSILON));
+                    }
+                    float s = acc_int + new_int;
+                    out.at(0, k, j, 0, i) = s;
+                    out.at(0, k, j, 1, i) = s;
+                    out.at(1, k, j, 0, i) = new_d1;
+                    out.at(1, k, j, 1, i) = new_d1;
+                    if (matched) ++*matched;
+                    ++idx;
+                }
+            }
+        }
+    }
+}
+
+/* ----------------------------------------------------------- small kernels */
+
+/* features_utils.py:9-25 weighted_center_mean on one (S,F) plane of a tile */
+template <typename CT>
+double weighted_center_mean(const Dense &t, int c, int k, int o, CT scan_center, CT frame_center) {
+    double values = 0, weights = 0;
+    bool any = false;
+    for (int s = 0; s < t.S; ++s)
+        for (int f = 0; f < t.F; ++f) {
+            float value = t.at(c, k, o, s, f);
+            if (!(value > 0)) continue;
+            any = true;
+            double ds = (double)s - (double)scan_center, df = (double)f - (double)frame_center;
+            double distance = std::sqrt(ds * ds + df * df);
+            double weight = std::exp(-0.1 * distance);
+            values += (double)value * weight;
+            weights += weight;
+        }
+    if (!any) return 0.0;
+    return weights > 0 ? values / weights : 0.0;
+}
+
+/* fragment_features.py:71-159 center_envelope_1d on a row of length n (float32, in place) */
+void center_envelope_row(float *x, int n) {
+    if (n <= 0) return;
+    auto X = [&](int64_t i) -> float & { return x[i < 0 ? i + n : i]; }; /* numba wraparound */
+    if (n % 2 == 0) {
+        int cr = n / 2, cl = cr - 1;
+        double left = X(cl), right = X(cr);
+        for (int i = 1; i <= cl; ++i) {
+            X(cl - i) = (float)std::min(left, (double)X(cl - i));
+            left = (double)(float)(X(cl - i) + X(cl - i + 1)) * 0.5;
+            X(cr + i) = (float)std::min(right, (double)X(cr + i));
+            right = (double)(float)(X(cr + i) + X(cr + i - 1)) * 0.5;
+        }
+    } else {
+        int c = n / 2;
+        if (n == 1) return; /* loops are empty; the two look-ups only read */
+        double left = (double)(float)(X(c - 1) + X(c)) * 0.5;
+        double right = (double)(float)(X(c + 1) + X(c)) * 0.5;
+        for (int i = 1; i <= c; ++i) {
+            X(c - i) = (float)std::min(left, (double)X(c - i));
+            left = (double)(float)(X(c - i) + X(c - i + 1)) * 0.5;
+            X(c + i) = (float)std::min(right, (double)X(c + i));
+            right = (double)(float)(X(c + i) + X(c + i - 1)) * 0.5;
+        }
+    }
+}
+
+/* scoring/utils.py:46-66 or_envelope on rows of length n: out-of-place */
+void or_envelope_rows(std::vector<float> &x, int rows, int n) {
+    std::vector<float> res = x;
+    for (int r = 0; r < rows; ++r)
+        for (int i = 1; i < n - 1; ++i) {
+            const float *p = &x[(size_t)r * n];
+            if (p[i] < p[i - 1] || p[i] < p[i + 1]) {
+                float s = p[i - 1] + p[i + 1];
+                res[(size_t)r * n + i] = (float)((double)s / 2.0);
+            }
+        }
+    x.swap(res);
+}
+
+/* np.corrcoef(x, y)[0, 1] in float64 (numba np_cov_impl_inner + np_corrcoef) */
+double corrcoef01(const std::vector<double> &x, const std::vector<double> &y) {
+    size_t n = x.size();
+    double sx = 0, sy = 0;
+    for (size_t i = 0; i < n; ++i) sx += x[i];
+    for (size_t i = 0; i < n; ++i) sy += y[i];
+    double mx = sx / (double)n, my = sy / (double)n;
+    double cxx = 0, cyy = 0, cxy = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double a = x[i] - mx, b = y[i] - my;
+        cxx += a * a;
+        cyy += b * b;
+        cxy += a * b;
+    }
+    double fact = std::max((double)n - 1.0, 0.0);
+    double inv = 1.0 / fact;
+    cxx *= inv; cyy *= inv; cxy *= inv;
+    double s0 = std::sqrt(cxx), s1 = std::sqrt(cyy);
+    double c = cxy / s1 / s0;
+    if (std::fabs(c) > 1.0) c = (c > 0) ? 1.0 : -1.0; /* NaN falls through */
+    return c;
+}
+
+/* scoring/utils.py:478-510 save_corrcoeff for (f32, f32) */
+double save_corrcoeff_ff(const std::vector<float> &x, const std::vector<float> &y) {
+    size_t n = x.size();
+    float sx = 0, sy = 0;
+    for (size_t i = 0; i < n; ++i) sx += x[i];
+    for (size_t i = 0; i < n; ++i) sy += y[i];
+    float xb = (float)((double)sx / (double)n), yb = (float)((double)sy / (double)n);
+    float num = 0, sxx = 0, syy = 0;
+    std::vector<float> xc(n), yc(n);
+    for (size_t i = 0; i < n; ++i) { xc[i] = x[i] - xb; yc[i] = y[i] - yb; }
+    for (size_t i = 0; i < n; ++i) num += xc[i] * yc[i];
+    for (size_t i = 0; i < n; ++i) sxx += xc[i] * xc[i];
+    for (size_t i = 0; i < n; ++i) syy += yc[i] * yc[i];
+    float den = std::sqrt(sxx * syy);
+    return (double)num / ((double)den + 1e-12);
+}
+/* same for (f32, f64) */
+double save_corrcoeff_fd(const std::vector<float> &x, const std::vector<double> &y) {
+    size_t n = x.size();
+    float sx = 0;
+    double sy = 0;
+    for (size_t i = 0; i < n; ++i) sx += x[i];
+    for (size_t i = 0; i < n; ++i) sy += y[i];
+    float xb = (float)((double)sx / (double)n);
+    double yb = sy / (double)n;
+    std::vector<float> xc(n);
+    std::vector<double> yc(n);
+    for (size_t i = 0; i < n; ++i) { xc[i] = x[i] - xb; yc[i] = y[i] - yb; }
+    double num = 0, syy = 0;
+    float sxx = 0;
+    for (size_t i = 0; i < n; ++i) num += (double)xc[i] * yc[i];
+    for (size_t i = 0; i < n; ++i) sxx += xc[i] * xc[i];
+    for (size_t i = 0; i < n; ++i) syy += yc[i] * yc[i];
+    double den = std::sqrt((double)sxx * syy);
+    return num / (den + 1e-12);
+}
+
+/*
+ * scoring/utils.py:513-571 fragment_correlation on x (K, O, N) -> out (O, K, K) float32.
+ * np.dot is a BLAS sgemm in the reference; we accumulate sequentially in float32.
+ */
+void fragment_correlation(const std::vector<float> &x, int K, int O, int N, std::vector<float> &out) {
+    out.assign((size_t)O * K * K, 0.0f);
+    if (N == 0) return;
+    std::vector<float> cen((size_t)K * N), sd(K);
+    for (int o = 0; o < O; ++o) {
+        for (int k = 0; k < K; ++k) {
+            const float *p = &x[((size_t)k * O + o) * N];
+            float s = 0;
+            for (int i = 0; i < N; ++i) s += p[i];
+            float mean = s / (float)N;
+            float q = 0;
+            for (int i = 0; i < N; ++i) {
+                float c = p[i] - mean;
+                cen[(size_t)k * N + i] = c;
+            }
+            for (int i = 0; i < N; ++i) q += cen[(size_t)k * N + i] * cen[(size_t)k * N + i];
+            sd[k] = std::sqrt(q / (float)N);
+        }
+        for (int a = 0; a < K; ++a)
+            for (int b = 0; b < K; ++b) {
+                float dot = 0;
+                for (int i = 0; i < N; ++i) dot += cen[(size_t)a * N + i] * cen[(size_t)b * N + i];
+                float cov = dot / (float)N;
+                float sm = sd[a] * sd[b];
+                out[((size_t)o * K + a) * K + b] = (float)((double)cov / ((double)sm + 1e-12));
+            }
+    }
+}
+
+/*
+ * scoring/utils.py:574-647 fragment_correlation_different for y with ONE row:
+ * x (K, O, N), y (1, O, N) -> out (O, K)
+ */
+void fragment_correlation_template(const std::vector<float> &x, int K, int O, int N,
+                                   const std::vector<float> &y, std::vector<float> &out) {
+    out.assign((size_t)O * K, 0.0f);
+    if (N == 0) return;
+    std::vector<float> yc(N), xc(N);
+    for (int o = 0; o < O; ++o) {
+        const float *py = &y[(size_t)o * N];
+        float s = 0;
+        for (int i = 0; i < N; ++i) s += py[i];
+        float ym = s / (float)N;
+        float q = 0;
+        for (int i = 0; i < N; ++i) yc[i] = py[i] - ym;
+        for (int i = 0; i < N; ++i) q += yc[i] * yc[i];
+        float ysd = std::sqrt(q / (float)N);
+        for (int k = 0; k < K; ++k) {
+            const float *px = &x[((size_t)k * O + o) * N];
+            float sx = 0;
+            for (int i = 0; i < N; ++i) sx += px[i];
+            float xm = sx / (float)N;
+            float qx = 0;
+            for (int i = 0; i < N; ++i) xc[i] = px[i] - xm;
+            for (int i = 0; i < N; ++i) qx += xc[i] * xc[i];
+            float xsd = std::sqrt(qx / (float)N);
+            float dot = 0;
+            for (int i = 0; i < N; ++i) dot += xc[i] * yc[i];
+            float cov = dot / (float)N;
+            float sm = xsd * ysd;
+            out[(size_t)o * K + k] = (float)((double)cov / ((double)sm + 1e-12));
+        }
+    }
+}
+
+/* quadrupole.py:12-43,80-115 logistic rectangle with sigma = 0.2, delta_mu = 0 */
+inline double logistic(double x, double mu, double sigma) {
+    double a = (x - mu) / sigma;
+    return 1.0 / (1.0 + std::exp(-a));
+}
+
+/* ---------------------------------------------------- fragments of a candidate */
+
+struct Frags {
+    std::vector<float> mz_library, mz, intensity;
+    std::vector<uint8_t> type, loss_type, charge, number, position, cardinality;
+    size_t size() const { return mz.size(); }
+    void take(const std::vector<int64_t> &idx) {
+        auto g = [&](auto &v) {
+            std::decay_t<decltype(v)> t(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) t[i] = v[idx[i]];
+            v.swap(t);
+        };
+        g(mz_library); g(mz); g(intensity); g(type); g(loss_type);
+        g(charge); g(number); g(position); g(cardinality);
+    }
+};
+
+/* ------------------------------------------------------------ one candidate */
+
+struct CandIn {
+    uint32_t precursor_idx; uint8_t rank; uint32_t frag_start, frag_stop;
+    int64_t scan_start, scan_stop, scan_center, frame_start, frame_stop, frame_center;
+    uint8_t charge; float precursor_mz; const float *iso; int n_iso_cols;
+};
+
+/* Candidate.process, candidate.py:166-481.  Returns true when valid. */
+bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, const CandIn &c,
+                       const adh_scoring_config_t &cfg, int64_t row, adh_output_t &out) {
+    const int top_k = out.top_k;
+    out.precursor_idx[row] = c.precursor_idx;
+    out.rank[row] = c.rank;
+
+    /* assemble_isotope_mz, candidate.py:151-163 */
+    int I = std::min<int>(c.n_iso_cols, (int)cfg.top_k_isotopes);
+    std::vector<float> iso_int(c.iso, c.iso + I), iso_mz(I);
+    for (int i = 0; i < I; ++i) {
+        double off = (double)i * ISOTOPE_DELTA / (double)c.charge;
+        iso_mz[i] = (float)off + c.precursor_mz;
+    }
+
+    /* fragment container: slice, cardinality filter, top-k, sort by mz (candidate.py:181-188) */
+    Frags fr;
+    for (uint32_t j = c.frag_start; j < c.frag_stop; ++j) {
+        if (cfg.exclude_shared_ions && lib.cardinality[j] > 1) continue;
+        fr.mz_library.push_back(lib.mz_library[j]);
+        fr.mz.push_back(lib.mz[j]);
+        fr.intensity.push_back(lib.intensity[j]);
+        fr.type.push_back(lib.type[j]);
+        fr.loss_type.push_back(lib.loss_type[j]);
+        fr.charge.push_back(lib.charge[j]);
+        fr.number.push_back(lib.number[j]);
+        fr.position.push_back(lib.position[j]);
+        fr.cardinality.push_back(lib.cardinality[j]);
+    }
+    {
+        std::vector<int64_t> ord = argsort(fr.intensity);
+        std::reverse(ord.begin(), ord.end());
+        if (ord.size() > cfg.top_k_fragments) ord.resize(cfg.top_k_fragments);
+        fr.take(ord);
+        fr.take(argsort(fr.mz));
+    }
+    if (fr.size() <= 3) return false;
+    int K = (int)fr.size();
+
+    float iso_min = *std::min_element(iso_mz.begin(), iso_mz.end());
+    float iso_max = *std::max_element(iso_mz.begin(), iso_mz.end());
+    float q_lo = (float)((double)iso_min - 0.5), q_hi = (float)((double)iso_max + 0.5);
+
+    Dense df;
+    std::vector<int64_t> frag_pidx, prec_pidx;
+    uint32_t matched = 0;
+    get_dense_alpharaw(d, c.frame_start, c.frame_stop, fr.mz.data(), K, cfg.fragment_mz_tolerance,
+                       (double)q_lo, (double)q_hi, true, df, frag_pidx, &matched);
+    if (df.F == 0) return false;
+    if (df.K <= 1) return false;
+
+    Dense dp_raw;
+    get_dense_alpharaw(d, c.frame_start, c.frame_stop, iso_mz.data(), I, cfg.precursor_mz_tolerance,
+                       -1.0, -1.0, true, dp_raw, prec_pidx, &matched);
+    if (out.stat_matched_peaks) out.stat_matched_peaks[row] = matched;
+
+    const int O = df.O, S = df.S, F = df.F;
+    /* collapse MS1 observations, candidate.py:248-269 */
+    Dense dp;
+    dp.init(I, 1, S, F);
+    for (int i = 0; i < I; ++i)
+        for (int s = 0; s < S; ++s)
+            for (int f = 0; f < F; ++f) {
+                float acc = 0;
+                double sum = 0;
+                int count = 0;
+                for (int j = 0; j < dp_raw.O; ++j) {
+                    acc += dp_raw.at(0, i, j, s, f);
+                    float m = dp_raw.at(1, i, j, s, f);
+                    sum += (double)m;
+                    if (m > 0) ++count;
+                }
+                dp.at(0, i, 0, s, f) = acc;
+                if (g_numpy_typing) {
+                    float s32 = 0;
+                    for (int j = 0; j < dp_raw.O; ++j) s32 += dp_raw.at(1, i, j, s, f);
+                    dp.at(1, i, 0, s, f) = s32 / (float)((double)count + 1e-6);
+                } else {
+                    dp.at(1, i, 0, s, f) = (float)(sum / ((double)count + 1e-6));
+                }
+            }
+
+    /* quadrupole transfer function, quadrupole.py:261-301 -> (I, O, n_scans) float64 */
+    int n_scans = (int)(c.scan_stop - c.scan_start);
+    if (n_scans < 0) n_scans = 0;
+    std::vector<double> qtf((size_t)I * O * n_scans);
+    for (int i = 0; i < I; ++i)
+        for (int o = 0; o < O; ++o)
+            for (int s = 0; s < n_scans; ++s) {
+                int64_t obs = frag_pidx[o];
+                int64_t scan = c.scan_start + s;
+                const double *cy = d.cycle + 2 * (obs * d.cycle_scans + scan);
+                double x = (double)iso_mz[i];
+                qtf[((size_t)i * O + o) * n_scans + s] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+            }
+    /* broadcasting of a size-1 scan axis against S (non-IM data: n_scans = 1, S = 2) */
+    auto qs = [&](int s) { return n_scans == 1 ? 0 : s; };
+    if (n_scans != 1 && n_scans != S) return false; /* numba would raise; not reachable with valid input */
+
+    /* qtf mask on fragment intensities, candidate.py:286-290 */
+    for (int o = 0; o < O; ++o)
+        for (int s = 0; s < S; ++s) {
+            double sum = 0;
+            for (int i = 0; i < I; ++i) sum += qtf[((size_t)i * O + o) * n_scans + qs(s)];
+            float mask = (float)(sum / (double)I);
+            for (int k = 0; k < K; ++k)
+                for (int f = 0; f < F; ++f) df.at(0, k, o, s, f) = df.at(0, k, o, s, f) * mask;
+        }
+
+    /* template (O, S, F), quadrupole.py:304-324 */
+    std::vector<float> templ((size_t)O * S * F);
+    for (int o = 0; o < O; ++o)
+        for (int s = 0; s < S; ++s)
+            for (int f = 0; f < F; ++f) {
+                double acc = 0;
+                for (int i = 0; i < I; ++i) {
+                    float a = dp.at(0, i, 0, s, f) * iso_int[i];
+                    acc += (double)a * qtf[((size_t)i * O + o) * n_scans + qs(s)];
+                }
+                templ[((size_t)o * S + s) * F + f] = (float)acc;
+            }
+    auto T = [&](int o, int s, int f) -> float { return templ[((size_t)o * S + s) * F + f]; };
+
+    /* observation importance, quadrupole.py:327-335 */
+    std::vector<float> oi(O);
+    {
+        float tot = 0;
+        for (int o = 0; o < O; ++o) {
+            float so = 0;
+            for (int s = 0; s < S; ++s) {
+                float sf = 0;
+                for (int f = 0; f < F; ++f) sf += T(o, s, f);
+                so += sf;
+            }
+            oi[o] = so;
+        }
+        for (int o = 0; o < O; ++o) tot += oi[o];
+        if (tot == 0)
+            for (int o = 0; o < O; ++o) oi[o] = 1.0f / (float)O;
+        else
+            for (int o = 0; o < O; ++o) oi[o] = oi[o] / tot;
+    }
+
+    /* fragment presence mask, candidate.py:319-329 */
+    std::vector<uint8_t> fmask(K);
+    int n_present = 0;
+    for (int k = 0; k < K; ++k) {
+        float so = 0;
+        for (int o = 0; o < O; ++o) {
+            float ss = 0;
+            for (int s = 0; s < S; ++s) {
+                float sf = 0;
+                for (int f = 0; f < F; ++f) sf += df.at(0, k, o, s, f);
+                ss += sf;
+            }
+            so += ss;
+        }
+        fmask[k] = so > 0;
+        n_present += fmask[k];
+    }
+    if (n_present < 2) return false;
+
+    const int K0 = K;
+    {
+        std::vector<int64_t> keep;
+        for (int k = 0; k < K; ++k)
+            if (fmask[k]) keep.push_back(k);
+        Dense nd;
+        nd.init((int)keep.size(), O, S, F);
+        for (int ch = 0; ch < 2; ++ch)
+            for (size_t kk = 0; kk < keep.size(); ++kk)
+                for (int o = 0; o < O; ++o)
+                    for (int s = 0; s < S; ++s)
+                        for (int f = 0; f < F; ++f)
+                            nd.at(ch, (int)kk, o, s, f) = df.at(ch, (int)keep[kk], o, s, f);
+        df = nd;
+        fr.take(keep);
+        K = (int)keep.size();
+        float s = 0;
+        for (int k = 0; k < K; ++k) s += fr.intensity[k];
+        for (int k = 0; k < K; ++k) fr.intensity[k] = fr.intensity[k] / s;
+    }
+
+    /* profiles, candidate.py:333-347 */
+    std::vector<float> ffp((size_t)K * O * F), fsp((size_t)K * O * S), tfp((size_t)O * F), tsp((size_t)O * S);
+    for (int k = 0; k < K; ++k)
+        for (int o = 0; o < O; ++o) {
+            for (int f = 0; f < F; ++f) {
+                float a = 0;
+                for (int s = 0; s < S; ++s) a += df.at(0, k, o, s, f);
+                ffp[((size_t)k * O + o) * F + f] = a;
+            }
+            for (int s = 0; s < S; ++s) {
+                float a = 0;
+                for (int f = 0; f < F; ++f) a += df.at(0, k, o, s, f);
+                fsp[((size_t)k * O + o) * S + s] = a;
+            }
+        }
+    for (int o = 0; o < O; ++o) {
+        for (int f = 0; f < F; ++f) {
+            float a = 0;
+            for (int s = 0; s < S; ++s) a += T(o, s, f);
+            tfp[(size_t)o * F + f] = a;
+        }
+        for (int s = 0; s < S; ++s) {
+            float a = 0;
+            for (int f = 0; f < F; ++f) a += T(o, s, f);
+            tsp[(size_t)o * S + s] = a;
+        }
+    }
+    or_envelope_rows(tfp, O, F);
+    or_envelope_rows(fsp, K * O, S);
+    or_envelope_rows(tsp, O, S);
+
+    const int64_t L = d.cycle_len;
+    std::vector<float> frame_rt;
+    for (int64_t fidx = c.frame_start; fidx < c.frame_stop; fidx += L) frame_rt.push_back(d.rt_values[fidx]);
+
+    float feat[ADH_NUM_FEATURES];
+    for (float &v : feat) v = 0.0f;
+    feat[28] = (float)((double)n_present / (double)K0);
+
+    /* location_features.py:8-33 */
+    feat[0] = d.mobility_values[c.scan_start] - d.mobility_values[c.scan_stop - 1];
+    feat[1] = d.rt_values[c.frame_stop - 1] - d.rt_values[c.frame_start];
+    feat[2] = d.rt_values[c.frame_center];
+    feat[3] = d.mobility_values[c.scan_center];
+
+    /* ---------------- precursor_features.py:13-102 ---------------- */
+    {
+        std::vector<float> spi(I);
+        for (int i = 0; i < I; ++i) {
+            float ss = 0;
+            for (int s = 0; s < S; ++s) {
+                float sf = 0;
+                for (int f = 0; f < F; ++f) sf += dp.at(0, i, 0, s, f);
+                ss += sf;
+            }
+            spi[i] = ss;
+        }
+        std::vector<float> w(I);
+        for (int i = 0; i < I; ++i) {
+            float a = 0;
+            for (int o = 0; o < O; ++o) a += spi[i] * oi[o];
+            w[i] = a;
+        }
+        int amax = 0;
+        for (int i = 1; i < I; ++i)
+            if (iso_int[i] > iso_int[amax]) amax = i;
+        feat[4] = w[0];
+        feat[5] = w[amax];
+        { float a = 0; for (int i = 0; i < I; ++i) a += w[i]; feat[6] = a; }
+        { float a = 0; for (int i = 0; i < I; ++i) a += w[i] * iso_int[i]; feat[7] = a; }
+
+        std::vector<double> height(I), omz(I);
+        for (int i = 0; i < I; ++i) {
+            /* expected centre is (shape[3], shape[2]) = (S, 1): precursor_features.py:52-57 */
+            height[i] = weighted_center_mean<int64_t>(dp, 0, i, 0, (int64_t)S, (int64_t)1);
+            omz[i] = weighted_center_mean<int64_t>(dp, 1, i, 0, (int64_t)S, (int64_t)1);
+        }
+        double wme = 0;
+        for (int i = 0; i < I; ++i)
+            if (omz[i] > 0) {
+                double me = (omz[i] - (double)iso_mz[i]) / (double)iso_mz[i] * 1e6;
+                wme += me * (double)iso_int[i];
+            }
+        feat[8] = (float)wme;
+        feat[9] = (float)std::fabs(wme);
+        feat[10] = (float)((double)iso_mz[0] + wme * 1e-6 * (double)iso_mz[0]);
+        feat[11] = (float)height[0];
+        feat[12] = (float)height[amax];
+        { double a = 0; for (int i = 0; i < I; ++i) a += height[i]; feat[13] = (float)a; }
+        { double a = 0; for (int i = 0; i < I; ++i) a += height[i] * (double)iso_int[i]; feat[14] = (float)a; }
+        feat[15] = (float)save_corrcoeff_ff(iso_int, spi);
+        feat[16] = (float)save_corrcoeff_fd(iso_int, height);
+    }
+
+    /* ---------------- fragment_features.py:198-427 ---------------- */
+    std::vector<double> mz_obs_mean(K), mass_error(K), obs_height(K), area_norm(K);
+    {
+        feat[17] = (float)O;
+        std::vector<float> fin(K);
+        {
+            float s = 0;
+            for (int k = 0; k < K; ++k) s += fr.intensity[k];
+            for (int k = 0; k < K; ++k) fin[k] = fr.intensity[k] / s;
+        }
+        /* weighted_center_of_mass per observation of the template */
+        std::vector<double> esc(O), efc(O);
+        for (int o = 0; o < O; ++o) {
+            double isum = 0, ssum = 0, fsum = 0;
+            bool any = false;
+            for (int s = 0; s < S; ++s)
+                for (int f = 0; f < F; ++f) {
+                    float v = T(o, s, f);
+                    if (v > 0) { any = true; isum += (double)v; }
+                }
+            if (!any) { esc[o] = 0; efc[o] = 0; continue; }
+            for (int s = 0; s < S; ++s)
+                for (int f = 0; f < F; ++f) {
+                    float v = T(o, s, f);
+                    if (v > 0) ssum += (double)s * (double)v;
+                }
+            for (int s = 0; s < S; ++s)
+                for (int f = 0; f < F; ++f) {
+                    float v = T(o, s, f);
+                    if (v > 0) fsum += (double)f * (double)v;
+                }
+            esc[o] = isum > 0 ? ssum / isum : 0.0;
+            efc[o] = isum > 0 ? fsum / isum : 0.0;
+        }
+
+        /* best profile (K, F) */
+        std::vector<float> bp((size_t)K * F);
+        int best_obs = 0;
+        if (cfg.quant_all) {
+            for (int k = 0; k < K; ++k)
+                for (int f = 0; f < F; ++f) {
+                    float a = 0;
+                    for (int o = 0; o < O; ++o) a += ffp[((size_t)k * O + o) * F + f];
+                    bp[(size_t)k * F + f] = a;
+                }
+            for (int k = 0; k < K; ++k) center_envelope_row(&bp[(size_t)k * F], F);
+        } else {
+            for (int o = 1; o < O; ++o)
+                if (oi[o] > oi[best_obs]) best_obs = o;
+            /* a VIEW in the reference: the envelope mutates fragments_frame_profile (Appendix B-5) */
+            for (int k = 0; k < K; ++k) {
+                center_envelope_row(&ffp[((size_t)k * O + best_obs) * F], F);
+                for (int f = 0; f < F; ++f) bp[(size_t)k * F + f] = ffp[((size_t)k * O + best_obs) * F + f];
+            }
+        }
+        int64_t qw = std::min<int64_t>((int64_t)(F / 2) - 1, (int64_t)cfg.quant_window);
+        int64_t center = F / 2;
+        int64_t a, b;
+        py_slice(center - qw, center + qw + 1, F, a, b);
+        int64_t ra, rb;
+        py_slice(center - qw, center + qw + 1, (int64_t)frame_rt.size(), ra, rb);
+        int W = (int)(b - a);
+        std::vector<float> delta_rt;
+        for (int64_t i = ra; i + 1 < rb; ++i) delta_rt.push_back(frame_rt[i + 1] - frame_rt[i]);
+        std::vector<float> obs_int(K);
+        for (int k = 0; k < K; ++k) {
+            const float *p = &bp[(size_t)k * F + a];
+            double area = 0;
+            for (int i = 0; i + 1 < W; ++i) {
+                float s = p[i + 1] + p[i];
+                float m = s * delta_rt[i];
+                area += (double)m * 0.5;
+            }
+            area_norm[k] = area * (double)qw;
+            float t = 0;
+            for (int i = 0; i < W; ++i) t += p[i];
+            obs_int[k] = t;
+        }
+
+        /* (K, O) sums of fragment intensities and template sums */
+        std::vector<float> sfi((size_t)K * O), sti(O);
+        for (int k = 0; k < K; ++k)
+            for (int o = 0; o < O; ++o) {
+                float ss = 0;
+                for (int s = 0; s < S; ++s) {
+                    float sf = 0;
+                    for (int f = 0; f < F; ++f) sf += df.at(0, k, o, s, f);
+                    ss += sf;
+                }
+                sfi[(size_t)k * O + o] = ss;
+            }
+        for (int o = 0; o < O; ++o) {
+            float ss = 0;
+            for (int s = 0; s < S; ++s) {
+                float sf = 0;
+                for (int f = 0; f < F; ++f) sf += T(o, s, f);
+                ss += sf;
+            }
+            sti[o] = ss;
+        }
+
+        std::vector<double> omz((size_t)K * O), ohe((size_t)K * O);
+        for (int k = 0; k < K; ++k)
+            for (int o = 0; o < O; ++o) {
+                omz[(size_t)k * O + o] = weighted_center_mean<double>(df, 1, k, o, esc[o], efc[o]);
+                ohe[(size_t)k * O + o] = weighted_center_mean<double>(df, 0, k, o, esc[o], efc[o]);
+            }
+        int n_height_rows = 0;
+        for (int k = 0; k < K; ++k) {
+            /* fragment_height_weights_2d row, normalised in float64 */
+            std::vector<float> w32(O);
+            float ws = 0;
+            int cnt = 0;
+            for (int o = 0; o < O; ++o) {
+                bool m = ohe[(size_t)k * O + o] > 0;
+                cnt += m;
+                w32[o] = m ? oi[o] : oi[o] * 0.0f;
+            }
+            for (int o = 0; o < O; ++o) ws += w32[o];
+            n_height_rows += cnt > 0;
+            std::vector<double> w(O);
+            for (int o = 0; o < O; ++o) w[o] = (double)w32[o] / ((double)ws + 1e-20);
+            if (g_numpy_typing)
+                for (int o = 0; o < O; ++o) w[o] = (double)(w32[o] / (ws + 1e-20f));
+            /* weighted_mean_a1 */
+            double msum = 0;
+            int nm = 0;
+            for (int o = 0; o < O; ++o)
+                if (w[o] > 0) { msum += w[o]; ++nm; }
+            double m1 = 0, m2 = 0;
+            if (nm > 0) {
+                if (g_numpy_typing) {
+                    float m32 = 0;
+                    for (int o = 0; o < O; ++o)
+                        if (w[o] > 0) m32 += (float)w[o];
+                    msum = (double)m32;
+                }
+                for (int o = 0; o < O; ++o)
+                    if (w[o] > 0) {
+                        double lw = w[o] / msum;
+                        if (g_numpy_typing) lw = (double)((float)w[o] / (float)msum);
+                        m1 += omz[(size_t)k * O + o] * lw;
+                        m2 += ohe[(size_t)k * O + o] * lw;
+                    }
+            }
+            mz_obs_mean[k] = m1;
+            obs_height[k] = m2;
+        }
+
+        std::vector<double> fin64(K);
+        for (int k = 0; k < K; ++k) fin64[k] = (double)fin[k];
+        if (n_height_rows > 0) feat[18] = (float)corrcoef01(area_norm, fin64);
+        {
+            double s = 0;
+            for (int k = 0; k < K; ++k) s += obs_height[k];
+            if (s > 0.0) feat[19] = (float)corrcoef01(obs_height, fin64);
+        }
+        int n_int = 0, n_hei = 0;
+        float w_int = 0, w_hei = 0;
+        for (int k = 0; k < K; ++k) {
+            if (obs_int[k] > 0.0f) { ++n_int; w_int += fin[k]; }
+        }
+        for (int k = 0; k < K; ++k) {
+            if (obs_height[k] > 0.0) { ++n_hei; w_hei += fin[k]; }
+        }
+        feat[20] = (float)((double)n_int / (double)K);
+        feat[21] = (float)((double)n_hei / (double)K);
+        feat[22] = w_int;
+        feat[23] = w_hei;
+
+        if (n_int > 0) {
+            /* cosine_similarity_a1, features_utils.py:40-47 */
+            float tn = 0;
+            for (int o = 0; o < O; ++o) tn += sti[o] * sti[o];
+            tn = std::sqrt(tn);
+            float acc = 0;
+            int cnt = 0;
+            for (int k = 0; k < K; ++k) {
+                if (!(obs_int[k] > 0)) continue;
+                float fn = 0, dot = 0;
+                for (int o = 0; o < O; ++o) fn += sfi[(size_t)k * O + o] * sfi[(size_t)k * O + o];
+                fn = std::sqrt(fn);
+                for (int o = 0; o < O; ++o) dot += sfi[(size_t)k * O + o] * sti[o];
+                float pr = fn * tn;
+                float score = (float)((double)dot / ((double)pr + 0.0001));
+                acc += score;
+                ++cnt;
+            }
+            feat[24] = (float)((double)acc / (double)cnt);
+        }
+
+        float sb = 0, sy = 0;
+        int nb = 0, ny = 0;
+        for (int k = 0; k < K; ++k) {
+            if (fr.type[k] == 98) { sb += obs_int[k]; ++nb; }
+        }
+        for (int k = 0; k < K; ++k) {
+            if (fr.type[k] == 121) { sy += obs_int[k]; ++ny; }
+        }
+        feat[25] = nb > 0 ? (float)std::log((double)sb + 1.0) : 0.0f;
+        feat[26] = ny > 0 ? (float)std::log((double)sy + 1.0) : 0.0f;
+        feat[27] = feat[25] - feat[26];
+
+        for (int k = 0; k < K; ++k)
+            mass_error[k] = (mz_obs_mean[k] - (double)fr.mz[k]) / (double)fr.mz[k] * 1e6;
+
+        std::vector<int64_t> ord = argsort(fr.intensity);
+        std::reverse(ord.begin(), ord.end());
+        {
+            int n3 = std::min(K, 3);
+            double s = 0;
+            for (int i = 0; i < n3; ++i) s += mass_error[ord[i]];
+            feat[41] = (float)(s / (double)n3);
+            double t = 0;
+            for (int k = 0; k < K; ++k) t += mass_error[k];
+            feat[42] = (float)(t / (double)K);
+        }
+        if (nb > 0 && ny > 0) {
+            int min_y = 255, max_b = 0;
+            for (int k = 0; k < K; ++k) {
+                if (fr.type[k] == 121) min_y = std::min<int>(min_y, fr.position[k]);
+                if (fr.type[k] == 98) max_b = std::max<int>(max_b, fr.position[k]);
+            }
+            int n_ov = 0;
+            double sa = 0, se = 0;
+            for (int k = 0; k < K; ++k) {
+                bool ov = (fr.type[k] == 121 && fr.position[k] < max_b) ||
+                          (fr.type[k] == 98 && fr.position[k] > min_y);
+                if (ov) { ++n_ov; sa += area_norm[k]; se += mass_error[k]; }
+            }
+            feat[43] = (float)n_ov;
+            if (n_ov > 0) {
+                feat[44] = (float)(sa / (double)n_ov);
+                feat[45] = (float)(se / (double)n_ov);
+            } else {
+                feat[44] = 0;
+                feat[45] = 15;
+            }
+        }
+    }
+
+    /* fragment table rows, candidate.py:403-442 */
+    if (cfg.collect_fragments) {
+        int n = std::min(K, top_k);
+        size_t base = (size_t)row * top_k;
+        for (int k = 0; k < n; ++k) {
+            out.fragment_precursor_idx[base + k] = c.precursor_idx;
+            out.fragment_rank[base + k] = c.rank;
+            out.fragment_mz_library[base + k] = fr.mz_library[k];
+            out.fragment_mz[base + k] = fr.mz[k];
+            out.fragment_mz_observed[base + k] = (float)mz_obs_mean[k];
+            out.fragment_height[base + k] = (float)obs_height[k];
+            out.fragment_intensity[base + k] = (float)area_norm[k];
+            out.fragment_mass_error[base + k] = (float)mass_error[k];
+            out.fragment_position[base + k] = fr.position[k];
+            out.fragment_number[base + k] = fr.number[k];
+            out.fragment_type[base + k] = fr.type[k];
+            out.fragment_charge[base + k] = fr.charge[k];
+            out.fragment_loss_type[base + k] = fr.loss_type[k];
+        }
+    }
+
+    /* fragment_mobility_correlation (IM only), fragment_features.py:430-480: skipped for AlphaRaw */
+
+    /* ---------------- profile_features.py:18-206 ---------------- */
+    std::vector<float> corr_list(K);
+    {
+        std::vector<int64_t> ord = argsort(fr.intensity);
+        std::reverse(ord.begin(), ord.end());
+        int n3 = std::min(K, 3);
+        float top3;
+        if (cfg.experimental_xic) {
+            std::vector<float> isl((size_t)K * F), nrm((size_t)K * F, 0.0f);
+            for (int k = 0; k < K; ++k)
+                for (int f = 0; f < F; ++f) {
+                    float a = 0;
+                    for (int o = 0; o < O; ++o) a += ffp[((size_t)k * O + o) * F + f];
+                    isl[(size_t)k * F + f] = a;
+                }
+            int64_t cidx = F / 2, wa, wb;
+            py_slice(cidx - 1, cidx + 2, F, wa, wb);
+            for (int k = 0; k < K; ++k) {
+                float s = 0;
+                for (int64_t i = wa; i < wb; ++i) s += isl[(size_t)k * F + i];
+                double ci = (double)s / (double)(wb - wa);
+                if (ci > 0)
+                    for (int f = 0; f < F; ++f) nrm[(size_t)k * F + f] = (float)((double)isl[(size_t)k * F + f] / ci);
+            }
+            std::vector<float> med(F);
+            for (int f = 0; f < F; ++f) {
+                std::vector<float> col(K);
+                for (int k = 0; k < K; ++k) col[k] = nrm[(size_t)k * F + f];
+                med[f] = (float)median_f32(col);
+            }
+            /* correlation_coefficient, scoring_utils.py:14-68 */
+            float sx = 0;
+            for (int f = 0; f < F; ++f) sx += med[f];
+            float mx = (float)((double)sx / (double)F);
+            std::vector<float> xm(F);
+            for (int f = 0; f < F; ++f) xm[f] = med[f] - mx;
+            float sxx = 0;
+            for (int f = 0; f < F; ++f) sxx += xm[f] * xm[f];
+            double var_x = (double)sxx / (double)F;
+            for (int k = 0; k < K; ++k) {
+                float sy = 0;
+                for (int f = 0; f < F; ++f) sy += isl[(size_t)k * F + f];
+                float my = (float)((double)sy / (double)F);
+                float sxy = 0, syy = 0;
+                std::vector<float> ym(F);
+                for (int f = 0; f < F; ++f) ym[f] = isl[(size_t)k * F + f] - my;
+                for (int f = 0; f < F; ++f) sxy += xm[f] * ym[f];
+                for (int f = 0; f < F; ++f) syy += ym[f] * ym[f];
+                double cov = (double)sxy / (double)F;
+                double var_y = (double)syy / (double)F;
+                double var_xy = var_x * var_y;
+                corr_list[k] = var_xy == 0 ? 0.0f : (float)(cov / std::sqrt(var_xy));
+            }
+            float s = 0;
+            for (int i = 0; i < n3; ++i) s += corr_list[ord[i]];
+            top3 = (float)((double)s / (double)n3);
+        } else {
+            std::vector<float> cm;
+            fragment_correlation(ffp, K, O, F, cm);
+            std::vector<float> red((size_t)K * K, 0.0f);
+            for (int o = 0; o < O; ++o)
+                for (int i = 0; i < K * K; ++i) red[i] += cm[(size_t)o * K * K + i] * oi[o];
+            for (int a = 0; a < K; ++a) {
+                float s = 0;
+                for (int b = 0; b < K; ++b) s += red[(size_t)a * K + b] * fr.intensity[b];
+                corr_list[a] = s;
+            }
+            float s = 0;
+            for (int i = 0; i < n3; ++i)
+                for (int j = 0; j < n3; ++j) s += red[(size_t)ord[i] * K + ord[j]];
+            top3 = (float)((double)s / (double)(n3 * n3));
+        }
+        {
+            float s = 0;
+            for (int k = 0; k < K; ++k) s += corr_list[k];
+            feat[31] = (float)((double)s / (double)K);
+        }
+        feat[32] = top3;
+
+        std::vector<float> ftc;
+        fragment_correlation_template(ffp, K, O, F, tfp, ftc);
+        {
+            float dot = 0;
+            for (int k = 0; k < K; ++k) {
+                float r = 0;
+                for (int o = 0; o < O; ++o) r += ftc[(size_t)o * K + k] * oi[o];
+                dot += r * fr.intensity[k];
+            }
+            feat[33] = dot;
+        }
+
+        /* b / y top-3: mask in ORIGINAL order applied to the SORTED index array (Appendix A 34/36) */
+        std::vector<int64_t> bidx, yidx;
+        for (int k = 0; k < K; ++k) {
+            if (fr.type[k] == 98) bidx.push_back(ord[k]);
+            if (fr.type[k] == 121) yidx.push_back(ord[k]);
+        }
+        if (!bidx.empty()) {
+            int lim = std::min<int>((int)bidx.size(), 3);
+            float s = 0;
+            for (int i = 0; i < lim; ++i) s += corr_list[bidx[i]];
+            feat[34] = (float)((double)s / (double)lim);
+            feat[35] = (float)bidx.size();
+        }
+        if (!yidx.empty()) {
+            int lim = std::min<int>((int)yidx.size(), 3);
+            float s = 0;
+            for (int i = 0; i < lim; ++i) s += corr_list[yidx[i]];
+            feat[36] = (float)((double)s / (double)lim);
+            feat[37] = (float)yidx.size();
+        }
+
+        /* FWHM RT */
+        float rt_width = d.rt_values[c.frame_stop - 1] - d.rt_values[c.frame_start];
+        {
+            float agg = 0;
+            for (int k = 0; k < K; ++k) {
+                float ml = 0;
+                for (int o = 0; o < O; ++o) {
+                    const float *p = &ffp[((size_t)k * O + o) * F];
+                    float mx = p[0];
+                    for (int f = 1; f < F; ++f) mx = p[f] > mx ? p[f] : mx;
+                    double half = (double)mx / 2.0;
+                    int n_above = 0;
+                    for (int f = 0; f < F; ++f) n_above += ((double)p[f] > half);
+                    double frac = (double)n_above / (double)F;
+                    float fw = (float)(frac * (double)rt_width);
+                    ml += fw * oi[o];
+                }
+                agg += ml * fr.intensity[k];
+            }
+            feat[38] = agg;
+        }
+        /* FWHM mobility: has_mobility only */
+
+        /* RT shift */
+        {
+            double acc = 0;
+            for (int o = 0; o < O; ++o) {
+                std::vector<int64_t> pk(K);
+                for (int k = 0; k < K; ++k) {
+                    const float *p = &ffp[((size_t)k * O + o) * F];
+                    int am = 0;
+                    for (int f = 1; f < F; ++f)
+                        if (p[f] > p[am]) am = f;
+                    pk[k] = am;
+                }
+                float med = (float)median_i64(pk);
+                double delta = (double)med - std::floor((double)F / 2.0);
+                acc += delta * (double)oi[o];
+            }
+            feat[40] = (float)acc;
+        }
+    }
+    if (cfg.collect_fragments) {
+        int n = std::min(K, top_k);
+        for (int k = 0; k < n; ++k) out.fragment_correlation[(size_t)row * top_k + k] = corr_list[k];
+    }
+    std::memcpy(out.features + (size_t)row * ADH_NUM_FEATURES, feat, sizeof(feat));
+    return true;
+}
+
+} /* namespace */
+
+/* =============================================================== C entry points */
+extern "C" {
+
+/* Score all candidates; threads follow alphatims.utils.pjit's static stride (iterable[t::T]). */
+int adh_oracle_score(const adh_alpharaw_t *dia, const adh_fragments_t *lib,
+                     const adh_candidates_t *cands, const adh_scoring_config_t *cfg,
+                     adh_output_t *out, int n_threads) {
+    if (!dia || !lib || !cands || !cfg || !out) return ADH_ERR_INVALID_ARGUMENT;
+    int64_t n = cands->n;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int64_t i = 0; i < n; ++i) {
+        if (cands->flags && (cands->flags[i] & ADH_FLAG_SKIP)) continue;
+        CandIn c;
+        c.precursor_idx = cands->precursor_idx[i];
+        c.rank = cands->rank[i];
+        c.frag_start = cands->frag_start_idx[i];
+        c.frag_stop = cands->frag_stop_idx[i];
+        c.scan_start = cands->scan_start[i];
+        c.scan_stop = cands->scan_stop[i];
+        c.scan_center = cands->scan_center[i];
+        c.frame_start = cands->frame_start[i];
+        c.frame_stop = cands->frame_stop[i];
+        c.frame_center = cands->frame_center[i];
+        c.charge = cands->charge[i];
+        c.precursor_mz = cands->precursor_mz[i];
+        c.iso = cands->isotope_intensity + (size_t)i * cands->n_isotope_cols;
+        c.n_iso_cols = cands->n_isotope_cols;
+        out->valid[i] = process_candidate(*dia, *lib, c, *cfg, i, *out) ? 1 : 0;
+    }
+    return ADH_OK;
+}
+
+void adh_oracle_set_numpy_typing(int on) { g_numpy_typing = on; }
+
+/* get_dense for unit tests: writes (2,K,O,2,F) into `dense` (capacity checked by caller). */
+int adh_oracle_get_dense(const adh_alpharaw_t *dia, int64_t frame_start, int64_t frame_stop,
+                         const float *mz_query, int32_t k, float tol, double quad_lo,
+                         double quad_hi, int32_t absolute, float *dense, int64_t dense_capacity,
+                         int64_t *precursor_idx, int32_t *n_obs, int32_t *n_frames) {
+    Dense d;
+    std::vector<int64_t> pidx;
+    get_dense_alpharaw(*dia, frame_start, frame_stop, mz_query, k, tol, quad_lo, quad_hi,
+                       absolute != 0, d, pidx, nullptr);
+    *n_obs = d.O;
+    *n_frames = d.F;
+    if ((int64_t)d.v.size() > dense_capacity) return ADH_ERR_INVALID_ARGUMENT;
+    std::memcpy(dense, d.v.data(), d.v.size() * sizeof(float));
+    for (size_t i = 0; i < pidx.size(); ++i) precursor_idx[i] = pidx[i];
+    return ADH_OK;
+}
+
+int64_t adh_oracle_search_sorted_left(const float *slice, int64_t n, float value) {
+    return search_sorted_left(slice, n, value);
+}
+
+void adh_oracle_center_envelope(float *x, int32_t rows, int32_t n) {
+    for (int r = 0; r < rows; ++r) center_envelope_row(x + (size_t)r * n, n);
+}
+
+void adh_oracle_fragment_correlation(const float *x, int32_t K, int32_t O, int32_t N, float *out) {
+    std::vector<float> xv(x, x + (size_t)K * O * N), o;
+    fragment_correlation(xv, K, O, N, o);
+    std::memcpy(out, o.data(), o.size() * sizeof(float));
+}
+
+double adh_oracle_save_corrcoeff(const float *x, const float *y, int32_t n) {
+    return save_corrcoeff_ff(std::vector<float>(x, x + n), std::vector<float>(y, y + n));
+}
+
+/* quadrupole_transfer_function_single for a (1, L, S, 2) cycle -> (I, O, n_scans) */
+void adh_oracle_qtf(const double *cycle, int32_t cycle_scans, const int64_t *obs, int32_t n_obs,
+                    const int64_t *scans, int32_t n_scans, const double *iso_mz, int32_t n_iso,
+                    double *out) {
+    for (int i = 0; i < n_iso; ++i)
+        for (int o = 0; o < n_obs; ++o)
+            for (int s = 0; s < n_scans; ++s) {
+                const double *cy = cycle + 2 * (obs[o] * cycle_scans + scans[s]);
+                out[((size_t)i * n_obs + o) * n_scans + s] =
+                    logistic(iso_mz[i], cy[0], 0.2) - logistic(iso_mz[i], cy[1], 0.2);
+            }
+}
+
+/* _compete_for_fragments over all windows, fragcomp/fragcomp.py:19-143 */
+int adh_oracle_fragcomp(int64_t n_windows, const int64_t *window_start, const int64_t *window_stop,
+                        const float *rt, const int64_t *frag_start_idx, const int64_t *frag_stop_idx,
+                        const float *fragment_mz, double rt_tol_seconds, double mass_tol_ppm,
+                        uint8_t *valid, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int64_t w = 0; w < n_windows; ++w) {
+        int64_t p0 = window_start[w], p1 = window_stop[w];
+        for (int64_t i = p0; i < p1; ++i) {
+            if (!valid[i]) continue;
+            for (int64_t j = p0; j < p1; ++j) {
+                if (i == j || !valid[j]) continue;
+                float delta_rt = std::fabs(rt[i] - rt[j]);
+                if (!((double)delta_rt < rt_tol_seconds)) continue;
+                int64_t overlap = 0;
+                for (int64_t a = frag_start_idx[i]; a < frag_stop_idx[i]; ++a)
+                    for (int64_t b = frag_start_idx[j]; b < frag_stop_idx[j]; ++b) {
+                        float delta = std::fabs(fragment_mz[a] - fragment_mz[b]);
+                        float rel = delta / fragment_mz[a];
+                        double ppm = (double)rel * 1e6;
+                        overlap += ppm < mass_tol_ppm;
+                    }
+                if (overlap >= 3) valid[j] = 0;
+            }
+        }
+    }
+    return ADH_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,186 @@
+"""ctypes front-end of the CPU parity oracle (oracle/adh_oracle.cpp).
+
+TEST INFRASTRUCTURE: imported only by tests/, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py``.  The product never imports this.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from alphadia_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libadh_oracle.so")
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "adh_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.adh_oracle_score.restype = C.c_int
+        _lib.adh_oracle_get_dense.restype = C.c_int
+        _lib.adh_oracle_search_sorted_left.restype = C.c_int64
+        _lib.adh_oracle_save_corrcoeff.restype = C.c_double
+        _lib.adh_oracle_fragcomp.restype = C.c_int
+    return _lib
+
+
+def score(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with_stats=False):
+    """Run the restated ``Candidate.process`` over a packed candidate table."""
+    m_dia = _abi.pack_alpharaw(dia)
+    m_frag = _abi.pack_fragments(*fragment_cols)
+    cfg = _abi.pack_config(cfg_jit)
+    n = int(cand_marshalled.struct.n)
+    m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+    rc = lib().adh_oracle_score(
+        m_dia.ref(), m_frag.ref(), cand_marshalled.ref(), C.byref(cfg), m_out.ref(), C.c_int(n_threads)
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_score failed: {rc}")
+    return arrays
+
+
+def set_numpy_typing(on: bool) -> None:
+    """Switch the three shim-vs-Numba promotion sites (see adh_oracle.cpp)."""
+    lib().adh_oracle_set_numpy_typing(C.c_int(int(bool(on))))
+
+
+def get_dense(dia, frame_start, frame_stop, mz_query, tol, quad_lo, quad_hi, absolute):
+    m_dia = _abi.pack_alpharaw(dia)
+    mzq = np.ascontiguousarray(mz_query, dtype=np.float32)
+    K = mzq.shape[0]
+    L = m_dia.struct.cycle_len
+    F = max(int(frame_stop) // L - int(frame_start) // L, 0)
+    omax = L * m_dia.struct.cycle_scans
+    cap = 2 * K * omax * 2 * F
+    dense = np.zeros(max(cap, 1), dtype=np.float32)
+    pidx = np.zeros(omax, dtype=np.int64)
+    n_obs = C.c_int32()
+    n_frames = C.c_int32()
+    rc = lib().adh_oracle_get_dense(
+        m_dia.ref(),
+        C.c_int64(int(frame_start)),
+        C.c_int64(int(frame_stop)),
+        mzq.ctypes.data_as(C.POINTER(C.c_float)),
+        C.c_int32(K),
+        C.c_float(float(tol)),
+        C.c_double(float(quad_lo)),
+        C.c_double(float(quad_hi)),
+        C.c_int32(int(bool(absolute))),
+        dense.ctypes.data_as(C.POINTER(C.c_float)),
+        C.c_int64(cap),
+        pidx.ctypes.data_as(C.POINTER(C.c_int64)),
+        C.byref(n_obs),
+        C.byref(n_frames),
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_get_dense failed: {rc}")
+    O, F = n_obs.value, n_frames.value
+    return dense[: 2 * K * O * 2 * F].reshape(2, K, O, 2, F).copy(), pidx[:O].copy()
+
+
+def search_sorted_left(arr, value) -> int:
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    return int(
+        lib().adh_oracle_search_sorted_left(
+            a.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(a.shape[0]), C.c_float(value)
+        )
+    )
+
+
+def center_envelope_1d(x):
+    a = np.ascontiguousarray(x, dtype=np.float32).copy()
+    rows, n = a.shape
+    lib().adh_oracle_center_envelope(
+        a.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(rows), C.c_int32(n)
+    )
+    return a
+
+
+def fragment_correlation(x):
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    K, O, N = a.shape
+    out = np.zeros((O, K, K), dtype=np.float32)
+    lib().adh_oracle_fragment_correlation(
+        a.ctypes.data_as(C.POINTER(C.c_float)),
+        C.c_int32(K),
+        C.c_int32(O),
+        C.c_int32(N),
+        out.ctypes.data_as(C.POINTER(C.c_float)),
+    )
+    return out
+
+
+def save_corrcoeff(x, y) -> float:
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    b = np.ascontiguousarray(y, dtype=np.float32)
+    return float(
+        lib().adh_oracle_save_corrcoeff(
+            a.ctypes.data_as(C.POINTER(C.c_float)),
+            b.ctypes.data_as(C.POINTER(C.c_float)),
+            C.c_int32(a.shape[0]),
+        )
+    )
+
+
+def quadrupole_transfer_function(cycle, observation_indices, scan_indices, isotope_mz):
+    cy = np.ascontiguousarray(cycle, dtype=np.float64)
+    obs = np.ascontiguousarray(observation_indices, dtype=np.int64)
+    sc = np.ascontiguousarray(scan_indices, dtype=np.int64)
+    iso = np.ascontiguousarray(isotope_mz, dtype=np.float64)
+    out = np.zeros((iso.shape[0], obs.shape[0], sc.shape[0]), dtype=np.float64)
+    lib().adh_oracle_qtf(
+        cy.ctypes.data_as(C.POINTER(C.c_double)),
+        C.c_int32(cy.shape[2]),
+        obs.ctypes.data_as(C.POINTER(C.c_int64)),
+        C.c_int32(obs.shape[0]),
+        sc.ctypes.data_as(C.POINTER(C.c_int64)),
+        C.c_int32(sc.shape[0]),
+        iso.ctypes.data_as(C.POINTER(C.c_double)),
+        C.c_int32(iso.shape[0]),
+        out.ctypes.data_as(C.POINTER(C.c_double)),
+    )
+    return out
+
+
+def fragcomp(window_start, window_stop, rt, frag_start, frag_stop, fragment_mz, rt_tol, mass_tol, n_threads=1):
+    ws = np.ascontiguousarray(window_start, dtype=np.int64)
+    we = np.ascontiguousarray(window_stop, dtype=np.int64)
+    rtv = np.ascontiguousarray(rt, dtype=np.float32)
+    fs = np.ascontiguousarray(frag_start, dtype=np.int64)
+    fe = np.ascontiguousarray(frag_stop, dtype=np.int64)
+    fm = np.ascontiguousarray(fragment_mz, dtype=np.float32)
+    valid = np.ones(rtv.shape[0], dtype=np.uint8)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+    rc = lib().adh_oracle_fragcomp(
+        C.c_int64(ws.shape[0]),
+        p(ws, C.c_int64),
+        p(we, C.c_int64),
+        p(rtv, C.c_float),
+        p(fs, C.c_int64),
+        p(fe, C.c_int64),
+        p(fm, C.c_float),
+        C.c_double(rt_tol),
+        C.c_double(mass_tol),
+        p(valid, C.c_uint8),
+        C.c_int(n_threads),
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_fragcomp failed: {rc}")
+    return valid.view(np.bool_)

@@ -1,0 +1,421 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+TEST INFRASTRUCTURE.  Run in the build container only (``/root/reference`` is
+mounted there):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules through ``ref_shim`` (which stubs the
+missing third-party packages numba / alphatims / alpharaw, nothing else), feeds
+them synthetic inputs from ``alphadia_amd.synthetic`` and stores inputs AND
+outputs as small ``.npz`` fixtures, so that the tests need neither the
+reference nor bit-reproducible random streams on the GPU box.
+
+Shim caveats (NumPy-2 promotion, pairwise sums, argsort ties) are listed in
+``ref_shim.py`` and repeated in every fixture's ``caveat`` field.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from alphadia.fragcomp.fragcomp import FragmentCompetition  # noqa: E402
+from alphadia.search.jitclasses.alpharaw_jit import AlphaRawJIT  # noqa: E402
+from alphadia.search.scoring import scoring as ref_scoring  # noqa: E402
+from alphadia.search.scoring.config import CandidateScoringConfig  # noqa: E402
+from alphadia.search.scoring.output import OutputPsmDF  # noqa: E402
+
+from alphadia_amd import synthetic as syn  # noqa: E402
+
+CAVEAT = (
+    "reference executed as pure Python under a numba stub with NumPy "
+    + np.__version__
+    + ": float32-with-python-float stays float32 (Numba: float64), np.sum is "
+    "pairwise (Numba: sequential), argsort tie order may differ"
+)
+
+
+def to_jit(dia: syn.AlphaRawArrays) -> AlphaRawJIT:
+    return AlphaRawJIT(
+        dia.cycle,
+        dia.rt_values,
+        dia.mobility_values,
+        dia.zeroth_frame,
+        dia.max_mz_value,
+        dia.min_mz_value,
+        np.float32(dia.cycle[0, 1:, :, 1].max()),
+        np.float32(dia.cycle[0, 1:, :, 0].min()),
+        dia.precursor_cycle_max_index,
+        dia.peak_start_idx_list,
+        dia.peak_stop_idx_list,
+        dia.mz_values,
+        dia.intensity_values,
+        dia.scan_max_index,
+        dia.frame_max_index,
+    )
+
+
+class DuckDia:
+    def __init__(self, dia):
+        self._dia = dia
+        self.cycle = dia.cycle
+        self._jit = to_jit(dia)
+
+    def to_jitclass(self):
+        return self._jit
+
+
+def dia_to_dict(dia: syn.AlphaRawArrays) -> dict:
+    return {
+        "dia_cycle": dia.cycle,
+        "dia_rt_values": dia.rt_values,
+        "dia_mobility_values": dia.mobility_values,
+        "dia_peak_start": dia.peak_start_idx_list,
+        "dia_peak_stop": dia.peak_stop_idx_list,
+        "dia_mz": dia.mz_values,
+        "dia_intensity": dia.intensity_values,
+    }
+
+
+FRAG_COLS = [
+    "mz_library",
+    "intensity",
+    "cardinality",
+    "type",
+    "loss_type",
+    "charge",
+    "number",
+    "position",
+]
+PREC_NUM_COLS = [
+    "elution_group_idx",
+    "precursor_idx",
+    "channel",
+    "decoy",
+    "flat_frag_start_idx",
+    "flat_frag_stop_idx",
+    "charge",
+    "rt_library",
+    "mobility_library",
+    "mz_library",
+    "i_0",
+    "i_1",
+    "i_2",
+    "i_3",
+]
+CAND_COLS = [
+    "elution_group_idx",
+    "precursor_idx",
+    "rank",
+    "scan_start",
+    "scan_stop",
+    "scan_center",
+    "frame_start",
+    "frame_stop",
+    "frame_center",
+    "score",
+]
+
+
+def run_scoring(case: syn.SyntheticCase, cfg_updates: dict):
+    cfg = CandidateScoringConfig()
+    cfg.update(cfg_updates)
+    dia = DuckDia(case.dia)
+    cs = ref_scoring.CandidateScoring(
+        dia_data=dia,
+        precursors_flat=case.library.precursor_df.copy(),
+        fragments_flat=case.library.fragment_df.copy(),
+        rt_column="rt_library",
+        mobility_column="mobility_library",
+        precursor_mz_column="mz_library",
+        fragment_mz_column="mz_library",
+        config=cfg,
+    )
+    cands = case.candidates_df.copy()
+    fragment_container = cs.assemble_fragments()
+    sgc = cs.assemble_score_group_container(cands)
+    n = sgc.get_candidate_count()
+    out = OutputPsmDF(n, cs.config.top_k_fragments)
+    ref_scoring._process_score_groups(
+        range(len(sgc)),
+        sgc,
+        out,
+        fragment_container,
+        dia.to_jitclass(),
+        cs.config.to_jitclass(),
+        cs.quadrupole_calibration.jit,
+        False,
+    )
+    features_df = cs.collect_candidates(cands, out)
+    fragments_df = cs.collect_fragments(cands, out)
+    # order of rows in `out` = order of candidates inside the score group container
+    order_pidx = np.array(
+        [c.precursor_idx for sg in sgc.score_groups for c in sg.candidates], dtype=np.uint32
+    )
+    order_rank = np.array(
+        [c.rank for sg in sgc.score_groups for c in sg.candidates], dtype=np.uint8
+    )
+    return out, features_df, fragments_df, order_pidx, order_rank, cs.config
+
+
+def out_to_dict(out: OutputPsmDF) -> dict:
+    names = [
+        "valid",
+        "precursor_idx",
+        "rank",
+        "features",
+        "fragment_precursor_idx",
+        "fragment_rank",
+        "fragment_mz_library",
+        "fragment_mz",
+        "fragment_mz_observed",
+        "fragment_height",
+        "fragment_intensity",
+        "fragment_mass_error",
+        "fragment_correlation",
+        "fragment_position",
+        "fragment_number",
+        "fragment_type",
+        "fragment_charge",
+        "fragment_loss_type",
+    ]
+    return {"out_" + n: np.asarray(getattr(out, n)) for n in names}
+
+
+def case_to_dict(case: syn.SyntheticCase) -> dict:
+    d = dia_to_dict(case.dia)
+    for c in FRAG_COLS:
+        d["frag_" + c] = case.library.fragment_df[c].values
+    for c in PREC_NUM_COLS:
+        d["prec_" + c] = case.library.precursor_df[c].values
+    for c in CAND_COLS:
+        d["cand_" + c] = case.candidates_df[c].values
+    return d
+
+
+def small_case(config_id: int, **kw) -> syn.SyntheticCase:
+    args = dict(
+        n_precursors=300,
+        n_cycles=60,
+        config_id=config_id,
+        per_precursor=2,
+        n_ms2=8,
+        ms1_peaks=400,
+        ms2_peaks=150,
+        mz_lo=400,
+        mz_hi=480,
+        frag_mz_lo=200,
+        frag_mz_hi=350,
+        ms1_mz_range=(395, 500),
+        ms2_mz_range=(195, 355),
+        few_fragment_fraction=0.05,
+        even_fraction=0.3,
+        planted_fraction=0.5,
+        threads=1,
+    )
+    args.update(kw)
+    return syn.make_case(**args)
+
+
+SCORING_CONFIGS = {
+    # what ClassicExtractionHandler passes (extraction_handler.py:370-376,400-409,460-468
+    # with default.yaml:158-199 and target tolerances)
+    "handler_default": dict(
+        score_grouped=False,
+        top_k_isotopes=3,
+        reference_channel=-1,
+        precursor_mz_tolerance=10,
+        fragment_mz_tolerance=15,
+        exclude_shared_ions=True,
+        quant_window=3,
+        quant_all=True,
+        experimental_xic=True,
+        top_k_fragments=12,
+    ),
+    # CandidateScoringConfig() defaults (config.py:73-85); used by multiplex requant
+    "class_default": dict(),
+    # top-k filtering active + narrow tolerances
+    "topk6": dict(
+        top_k_isotopes=2,
+        precursor_mz_tolerance=5,
+        fragment_mz_tolerance=7,
+        quant_window=2,
+        quant_all=True,
+        experimental_xic=True,
+        top_k_fragments=6,
+    ),
+}
+
+
+def golden_scoring():
+    for name, upd in SCORING_CONFIGS.items():
+        case = small_case(101)
+        if name == "topk6":
+            # give some fragments cardinality 2 so exclude_shared_ions drops them
+            rng = np.random.default_rng(7)
+            card = case.library.fragment_df["cardinality"].values.copy()
+            card[rng.random(card.size) < 0.15] = 2
+            case.library.fragment_df["cardinality"] = card
+        out, fdf, frdf, opidx, orank, cfg = run_scoring(case, upd)
+        d = case_to_dict(case)
+        d.update(out_to_dict(out))
+        d["order_precursor_idx"] = opidx
+        d["order_rank"] = orank
+        cfgj = cfg.to_jitclass()
+        for k in (
+            "collect_fragments score_grouped exclude_shared_ions top_k_fragments top_k_isotopes "
+            "reference_channel quant_window quant_all precursor_mz_tolerance "
+            "fragment_mz_tolerance experimental_xic"
+        ).split():
+            d["cfg_" + k] = np.asarray(getattr(cfgj, k))
+        d["features_df_columns"] = np.array(list(fdf.columns), dtype="U")
+        d["fragments_df_columns"] = np.array(list(frdf.columns), dtype="U")
+        d["features_df_precursor_idx"] = fdf["precursor_idx"].values
+        d["features_df_rank"] = fdf["rank"].values
+        d["features_df_delta_rt"] = fdf["delta_rt"].values
+        d["fragments_df_precursor_idx"] = frdf["precursor_idx"].values
+        d["fragments_df_mz_observed"] = frdf["mz_observed"].values
+        d["fragments_df_n"] = np.asarray(len(frdf))
+        d["caveat"] = np.asarray(CAVEAT)
+        path = os.path.join(HERE, f"scoring_{name}.npz")
+        np.savez_compressed(path, **d)
+        v = np.asarray(out.valid)
+        print(
+            f"{path}: {v.sum()}/{len(v)} valid, nan rows "
+            f"{np.isnan(out.features[v]).any(axis=1).sum()}, {os.path.getsize(path)/1e6:.2f} MB"
+        )
+
+
+def golden_get_dense():
+    """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
+    case = small_case(102, n_precursors=40)
+    jit = to_jit(case.dia)
+    rng = np.random.default_rng(11)
+    L = case.dia.cycle_len
+    d = dia_to_dict(case.dia)
+    n_cases = 24
+    for i in range(n_cases):
+        c0 = int(rng.integers(0, 40))
+        nc = int(rng.integers(1, 18))
+        frame_limits = np.array([[c0 * L, (c0 + nc) * L, 1]], dtype=np.uint64)
+        k = int(rng.integers(2, 13))
+        ms1 = i % 3 == 0
+        if ms1:
+            mzq = np.sort(rng.uniform(400, 480, k)).astype(np.float32)
+            quad = np.array([[-1.0, -1.0]])
+            tol = np.float32(10)
+        else:
+            mzq = np.sort(rng.uniform(200, 350, k)).astype(np.float32)
+            lo = rng.uniform(400, 478)
+            quad = np.array([[lo, lo + rng.uniform(0.5, 12.0)]], dtype=np.float32)
+            tol = np.float32(15)
+        if i % 4 == 1:
+            # overlapping windows: duplicate / near-duplicate queries, huge tolerance
+            mzq[1] = mzq[0] * np.float32(1 + 5e-6)
+            tol = np.float32(200)
+            mzq = np.sort(mzq)
+        if i % 5 == 4 and nc > 0:
+            # use the real m/z of peaks so windows are hit for sure
+            s = int(rng.integers(0, case.dia.n_spectra))
+            a, b = case.dia.peak_start_idx_list[s], case.dia.peak_stop_idx_list[s]
+            mzq = np.sort(rng.choice(case.dia.mz_values[a:b], size=k, replace=False)).astype(
+                np.float32
+            )
+        absolute = i % 2 == 0
+        dense, pidx = jit.get_dense(
+            frame_limits,
+            np.array([[0, 1, 1]], dtype=np.uint64),
+            mzq,
+            tol,
+            quad,
+            absolute_masses=absolute,
+        )
+        d[f"q{i}_frame_limits"] = frame_limits
+        d[f"q{i}_mz"] = mzq
+        d[f"q{i}_tol"] = np.asarray(tol)
+        d[f"q{i}_quad"] = np.asarray(quad, dtype=np.float64)
+        d[f"q{i}_absolute"] = np.asarray(absolute)
+        d[f"q{i}_dense"] = dense
+        d[f"q{i}_pidx"] = np.asarray(pidx, dtype=np.int64)
+    d["n_cases"] = np.asarray(n_cases)
+    d["caveat"] = np.asarray(CAVEAT)
+    path = os.path.join(HERE, "get_dense_alpharaw.npz")
+    np.savez_compressed(path, **d)
+    print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
+def golden_fragcomp():
+    """G6: FragmentCompetition.__call__ on a synthetic PSM / fragment table."""
+    rng = np.random.default_rng(13)
+    n_psm = 1500
+    cycle = syn.make_cycle(n_ms2=8, mz_lo=400, mz_hi=480)
+    precursor_idx = rng.permutation(n_psm).astype(np.uint32)
+    rank = rng.integers(0, 2, n_psm).astype(np.uint8)
+    mz_observed = rng.uniform(400, 480, n_psm).astype(np.float32)
+    rt_observed = rng.uniform(0, 120, n_psm).astype(np.float32)
+    proba = rng.random(n_psm).astype(np.float32)
+    nfrag = rng.integers(3, 13, n_psm)
+    # a pool of shared fragment m/z values so that overlaps >= 3 really happen
+    pool = np.sort(rng.uniform(200, 350, 160)).astype(np.float32)
+    f_pidx, f_rank, f_mz = [], [], []
+    for i in range(n_psm):
+        mz = rng.choice(pool, nfrag[i], replace=False) * (
+            1 + rng.normal(0, 4e-6, nfrag[i])
+        ).astype(np.float32)
+        f_pidx.append(np.full(nfrag[i], precursor_idx[i], np.uint32))
+        f_rank.append(np.full(nfrag[i], rank[i], np.uint8))
+        f_mz.append(np.sort(mz).astype(np.float32))
+    psm_df = pd.DataFrame(
+        {
+            "precursor_idx": precursor_idx,
+            "rank": rank,
+            "mz_observed": mz_observed,
+            "rt_observed": rt_observed,
+            "proba": proba,
+        }
+    )
+    frag_df = pd.DataFrame(
+        {
+            "precursor_idx": np.concatenate(f_pidx),
+            "rank": np.concatenate(f_rank),
+            "mz_observed": np.concatenate(f_mz),
+        }
+    )
+    d = {
+        "psm_precursor_idx": precursor_idx,
+        "psm_rank": rank,
+        "psm_mz_observed": mz_observed,
+        "psm_rt_observed": rt_observed,
+        "psm_proba": proba,
+        "frag_precursor_idx": frag_df["precursor_idx"].values,
+        "frag_rank": frag_df["rank"].values,
+        "frag_mz_observed": frag_df["mz_observed"].values,
+        "cycle": cycle,
+    }
+    fc = FragmentCompetition(rt_tol_seconds=3, mass_tol_ppm=15, thread_count=1)
+    res = fc(psm_df.copy(), frag_df.copy(), cycle)
+    d["surviving_precursor_idx"] = res["precursor_idx"].values
+    d["surviving_rank"] = res["rank"].values
+    d["caveat"] = np.asarray(CAVEAT)
+    path = os.path.join(HERE, "fragcomp.npz")
+    np.savez_compressed(path, **d)
+    print(path, f"{len(res)}/{n_psm} survive, {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    golden_get_dense()
+    golden_fragcomp()
+    golden_scoring()
