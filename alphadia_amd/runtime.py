@@ -1,0 +1,200 @@
+"""ctypes binding of ``libalphadia_hip.so`` (the C ABI in include/alphadia_hip.h).
+
+There is deliberately no fallback: importing this module without the built
+library, or creating a context without a GPU, raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from alphadia_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalphadia_hip.so")
+
+EXPORTED_SYMBOLS = [
+    "adh_last_error",
+    "adh_device_count",
+    "adh_create",
+    "adh_destroy",
+    "adh_stage_alpharaw",
+    "adh_stage_fragments",
+    "adh_score_candidates",
+    "adh_upload_candidates",
+    "adh_score_uploaded",
+    "adh_synchronize",
+    "adh_kernel_time_ms",
+    "adh_fragcomp",
+]
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.adh_last_error.restype = C.c_char_p
+    for name in EXPORTED_SYMBOLS[1:]:
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib.adh_last_error()
+        raise HipBackendError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib.adh_device_count(C.byref(n)), "adh_device_count")
+    return n.value
+
+
+class Context:
+    """One GPU: staged run + library + candidate table (an ``adh_handle_t``)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib.adh_create(C.byref(self._h), C.c_int(device)), "adh_create")
+        self.device = device
+        self._run_key = None
+        self._lib_key = None
+        self.n_candidates = 0
+
+    def close(self):
+        if self._h:
+            lib.adh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging ---------------------------------------------------------
+    @staticmethod
+    def _key(*arrays):
+        return tuple(
+            (a.__array_interface__["data"][0], a.shape, str(a.dtype)) for a in map(np.asarray, arrays)
+        )
+
+    def stage_run(self, dia, force: bool = False) -> bool:
+        """Copy the run to HBM unless this very run is already staged."""
+        key = self._key(dia.mz_values, dia.intensity_values, dia.peak_start_idx_list, dia.rt_values)
+        if not force and key == self._run_key:
+            return False
+        m = _abi.pack_alpharaw(dia)
+        _check(lib.adh_stage_alpharaw(self._h, m.ref()), "adh_stage_alpharaw")
+        self._run_key = key
+        self._run_keepalive = (dia.mz_values, dia.intensity_values)
+        return True
+
+    def stage_fragments(self, *columns, force: bool = False) -> bool:
+        key = self._key(*columns)
+        if not force and key == self._lib_key:
+            return False
+        m = _abi.pack_fragments(*columns)
+        _check(lib.adh_stage_fragments(self._h, m.ref()), "adh_stage_fragments")
+        self._lib_key = key
+        self._lib_keepalive = columns
+        return True
+
+    # -- scoring ---------------------------------------------------------
+    def score_host(self, cands: _abi.Marshalled, cfg_jit, with_stats: bool = False) -> dict:
+        """Host table in, host OutputPsmDF arrays out."""
+        n = int(cands.struct.n)
+        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+        cfg = _abi.pack_config(cfg_jit)
+        _check(
+            lib.adh_score_candidates(self._h, cands.ref(), C.byref(cfg), m_out.ref()),
+            "adh_score_candidates",
+        )
+        self.n_candidates = n
+        return arrays
+
+    def upload_candidates(self, cands: _abi.Marshalled) -> None:
+        _check(lib.adh_upload_candidates(self._h, cands.ref()), "adh_upload_candidates")
+        self.n_candidates = int(cands.struct.n)
+
+    def score_uploaded(self, cfg_jit, out_struct: _abi.Output, stream: int = 0) -> None:
+        """Enqueue scoring of the uploaded table into device buffers; does not synchronise."""
+        cfg = _abi.pack_config(cfg_jit)
+        _check(
+            lib.adh_score_uploaded(self._h, C.byref(cfg), C.byref(out_struct), C.c_void_p(stream)),
+            "adh_score_uploaded",
+        )
+
+    def synchronize(self) -> None:
+        _check(lib.adh_synchronize(self._h), "adh_synchronize")
+
+    def kernel_time_ms(self, reset: bool = True):
+        avg = C.c_double(0)
+        n = C.c_int64(0)
+        _check(
+            lib.adh_kernel_time_ms(self._h, C.byref(avg), C.byref(n), C.c_int(int(reset))),
+            "adh_kernel_time_ms",
+        )
+        return avg.value, n.value
+
+    # -- fragment competition -------------------------------------------
+    def fragcomp(self, window_start, window_stop, rt, frag_start, frag_stop, fragment_mz,
+                 rt_tol_seconds: float, mass_tol_ppm: float) -> np.ndarray:
+        ws = _abi.as_c(window_start, np.int64)
+        we = _abi.as_c(window_stop, np.int64)
+        rtv = _abi.as_c(rt, np.float32)
+        fs = _abi.as_c(frag_start, np.int64)
+        fe = _abi.as_c(frag_stop, np.int64)
+        fm = _abi.as_c(fragment_mz, np.float32)
+        valid = np.ones(rtv.shape[0], dtype=np.uint8)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        _check(
+            lib.adh_fragcomp(
+                self._h,
+                C.c_int64(ws.shape[0]),
+                p(ws, C.c_int64),
+                p(we, C.c_int64),
+                C.c_int64(rtv.shape[0]),
+                p(rtv, C.c_float),
+                p(fs, C.c_int64),
+                p(fe, C.c_int64),
+                C.c_int64(fm.shape[0]),
+                p(fm, C.c_float),
+                C.c_double(float(rt_tol_seconds)),
+                C.c_double(float(mass_tol_ppm)),
+                p(valid, C.c_uint8),
+            ),
+            "adh_fragcomp",
+        )
+        return valid.view(np.bool_)
+
+
+_contexts: dict[int, Context] = {}
+
+
+def default_device() -> int:
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def get_context(device: int | None = None) -> Context:
+    """Process-wide context per GPU (so the staged run survives between batches)."""
+    device = default_device() if device is None else int(device)
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx

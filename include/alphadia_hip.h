@@ -169,22 +169,27 @@ int adh_stage_alpharaw(adh_handle_t *handle, const adh_alpharaw_t *dia);
 int adh_stage_fragments(adh_handle_t *handle, const adh_fragments_t *fragments);
 
 /*
- * Score candidates: host table in, host OutputPsmDF out.  Replaces the
- * pjit loop `_process_score_groups` (scoring.py:114-137,634-643) i.e.
- * ScoreGroup.process -> Candidate.process for every candidate.
+ * Score candidates: host table in, host OutputPsmDF out (upload + kernels +
+ * download).  Replaces the pjit loop `_process_score_groups`
+ * (scoring.py:114-137,634-643), i.e. ScoreGroup.process -> Candidate.process
+ * for every candidate.  `out` buffers are zero-filled by the call.
  */
 int adh_score_candidates(adh_handle_t *handle, const adh_candidates_t *candidates,
                          const adh_scoring_config_t *config, adh_output_t *out);
 
 /*
- * Same, but `out` holds DEVICE pointers (zero-initialised, on the handle's
- * GPU) and the work is enqueued on `hip_stream` (a hipStream_t, may be NULL
- * for the handle's own stream) without synchronising.  Used when the tables
- * are reassembled across GPUs with an RCCL all-gather before leaving HBM.
+ * The same work split so that tables can stay in HBM:
+ *   adh_upload_candidates  - copy the candidate SoA to the GPU (kept in the handle)
+ *   adh_score_uploaded     - enqueue the kernels on `hip_stream` (a hipStream_t;
+ *                            NULL = the handle's own stream) writing into DEVICE
+ *                            buffers `out_device` (zero-initialised by the caller,
+ *                            on the handle's GPU); does not synchronise.
+ * Used when the per-GPU tables are reassembled with an RCCL all-gather before
+ * they leave HBM.
  */
-int adh_score_candidates_device(adh_handle_t *handle, const adh_candidates_t *candidates,
-                                const adh_scoring_config_t *config, adh_output_t *out_device,
-                                void *hip_stream);
+int adh_upload_candidates(adh_handle_t *handle, const adh_candidates_t *candidates);
+int adh_score_uploaded(adh_handle_t *handle, const adh_scoring_config_t *config,
+                       adh_output_t *out_device, void *hip_stream);
 
 /* Block until all work enqueued on the handle's stream has finished. */
 int adh_synchronize(adh_handle_t *handle);

@@ -14,7 +14,7 @@
  *   quadrupole transfer fn / template     search/scoring/quadrupole.py:40-43,80-115,261-335
  *   profiles / envelopes / correlations   search/scoring/utils.py:21-66,478-647
  *   location / precursor / fragment / profile features
- *                                         search/scoring/features/*.py
+ *                                         search/scoring/features/ (all modules)
  *   correlation_coefficient etc.          search/scoring/scoring_utils.py:14-152
  *   _compete_for_fragments                fragcomp/fragcomp.py:19-143
  *
@@ -31,7 +31,7 @@
  *   - stores into float32 arrays round to nearest even
  * Compile with -ffp-contract=off: Numba does not fuse mul+add in this code.
  *
- * Parity pinning: checked against the golden vectors in tests/golden/*.npz,
+ * Parity pinning: checked against the golden vectors in tests/golden/ (npz files),
  * which were produced by running the reference itself (tests/golden/make_golden.py),
  * and against the reference's own known-answer tests restated in tests/.
  */
