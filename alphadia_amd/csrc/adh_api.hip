@@ -3,6 +3,7 @@
 // library and the candidate table, sizes the LDS of the scoring kernel per batch
 // and times the kernel with HIP events on its launch stream.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -291,7 +292,19 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
     UP(h->cand_buf, c->charge, c->n, &d.charge);
     UP(h->cand_buf, c->precursor_mz, c->n, &d.precursor_mz);
     UP(h->cand_buf, c->isotope_intensity, c->n * c->n_isotope_cols, &d.isotope_intensity);
-    d.order = nullptr;
+    // processing order: by first cycle, so that concurrently resident wavefronts gather
+    // from the same few spectra (L2 / Infinity-Cache reuse); output rows are unaffected
+    {
+        const int64_t n_cyc = h->run.n_spectra / L + 2;
+        std::vector<uint32_t> head((size_t)n_cyc + 1, 0), order((size_t)c->n);
+        for (int64_t i = 0; i < c->n; ++i) ++head[(size_t)(c->frame_start[i] / L) + 1];
+        for (int64_t k = 0; k < n_cyc; ++k) head[(size_t)k + 1] += head[(size_t)k];
+        for (int64_t i = 0; i < c->n; ++i) order[head[(size_t)(c->frame_start[i] / L)]++] = (uint32_t)i;
+        if (getenv("ADH_DEBUG_NO_ORDER"))
+            d.order = nullptr;
+        else
+            UP(h->cand_buf, order.data(), c->n, &d.order);
+    }
 
     // LDS capacities of this batch (upper bounds: all isotope columns)
     HIP_TRY(hipMemsetAsync(h->d_maxima, 0, 4 * sizeof(int32_t), h->stream));
@@ -332,6 +345,10 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     caps.f = std::max(h->plan_f, 1);
     caps.i = std::max<int32_t>(
         (int32_t)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)h->cands.n_isotope_cols), 1);
+    {
+        const char *dbg = getenv("ADH_DEBUG_STOP_PHASE");  // developer ablation switch
+        caps.stop_phase = dbg ? atoi(dbg) : 0;
+    }
     if (cfg->collect_fragments && caps.k > out->top_k)
         return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
     size_t lds = adh_score_lds_bytes(caps);

@@ -74,6 +74,7 @@ struct Caps {
     int32_t o;       // observations
     int32_t f;       // cycles
     int32_t i;       // isotopes
+    int32_t stop_phase;  // developer ablation switch (0 = run everything)
 };
 
 // monotone bucket function shared by index build and lookup

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
         s.f_pos[slot] = lib.position[g];
     }
     if (K <= 3) return;  // candidate.py:190
+    if (caps.stop_phase == 1) return;
 
     // ---- isotopes (candidate.py:151-163) and quadrupole limits (candidate.py:203-205)
     const int I = min((int)cd.n_isotope_cols, (int)cfg.top_k_isotopes);
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
         if (lane == 0) out.stat_matched_peaks[row] = hits;
     }
 
+    if (caps.stop_phase == 2) return;
     // ---- quadrupole transfer function (quadrupole.py:261-301), n_scans == 1 (non-IM)
     for (int c = lane; c < I * O; c += ADH_WAVE) {
         int i = c / O, o = c - i * O;
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
     if (lane < ADH_NUM_FEATURES) s.feat[lane] = 0.0f;
     __syncthreads();
 
+    if (caps.stop_phase == 3) return;
     // =========================== features ===========================
     // ---- precursor weight table around (scan, frame) = (S, 1) = (2, 1)
     //      (precursor_features.py:52-57, features_utils.py:9-25)
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
     }
     __syncthreads();
 
+    if (caps.stop_phase == 4) return;
     // ---- best profile + centre envelope (fragment_features.py:240-250)
     int best_obs = 0;
     if (!cfg.quant_all)
@@ -743,6 +747,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
     }
     __syncthreads();
 
+    if (caps.stop_phase == 5) return;
     // ---- scalar feature assembly by lane 0 (short sequential float sums)
     if (lane == 0) {
         float *feat = s.feat;
@@ -912,6 +917,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
         }
     }
 
+    if (caps.stop_phase == 6) return;
     // =========================== profile features (profile_features.py:18-206)
     // fi / fm are dead from here on: reuse them as isl[K][F] and nrm[K][F]
     __syncthreads();
@@ -1160,6 +1166,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_score_kernel(DevRun run, DevLib 
     }
     __syncthreads();
 
+    if (caps.stop_phase == 7) return;
     // ---- write the row: features, fragment table, valid flag (candidate.py:403-481)
     if (lane < ADH_NUM_FEATURES) out.features[row * ADH_NUM_FEATURES + lane] = s.feat[lane];
     if (cfg.collect_fragments) {

@@ -1,0 +1,110 @@
+"""Candidate sharding across the GPUs of one node and table reassembly.
+
+Score groups are independent (reference: disjoint ``output_idx`` rows,
+search/scoring/containers/score_group.py:66-75), so the candidate table is cut
+into contiguous score-group ranges, one per rank; the run and the library are
+replicated in every GPU's HBM.  Each rank fills one packed device buffer holding
+its slice of every OutputPsmDF table; ONE all-gather (RCCL over xGMI when the
+process group backend is "nccl", gloo on CPU in the tests) reassembles the
+tables on every rank.  PyTorch is used here only for device memory, streams and
+``torch.distributed``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from alphadia_amd import _abi
+
+_ALIGN = 256
+
+
+def shard_bounds(score_group_idx: np.ndarray, rank: int, world: int) -> tuple[int, int]:
+    """Row range [a, b) of ``rank``: contiguous score groups, balanced by group count.
+
+    ``score_group_idx`` is the non-decreasing group id per candidate row.
+    """
+    n = len(score_group_idx)
+    if n == 0:
+        return 0, 0
+    n_groups = int(score_group_idx[-1]) + 1
+    g0 = (n_groups * rank) // world
+    g1 = (n_groups * (rank + 1)) // world
+    a = int(np.searchsorted(score_group_idx, g0, side="left"))
+    b = int(np.searchsorted(score_group_idx, g1, side="left"))
+    return a, b
+
+
+def slice_soa(soa: dict, a: int, b: int) -> dict:
+    return {k: (v[a:b] if isinstance(v, np.ndarray) and v.shape[:1] == (len(soa["precursor_idx"]),) else v)
+            for k, v in soa.items()}
+
+
+def packed_layout(n_rows: int, top_k: int, with_stats: bool = True):
+    """Byte offsets of every OutputPsmDF table inside one packed buffer of ``n_rows`` rows."""
+    shapes = _abi.output_shapes(n_rows, top_k)
+    offsets = {}
+    off = 0
+    for name, (shape, dt) in shapes.items():
+        offsets[name] = (off, shape, np.dtype(dt))
+        off += int(np.prod(shape)) * np.dtype(dt).itemsize
+        off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+    if with_stats:
+        offsets["stat_matched_peaks"] = (off, (n_rows,), np.dtype(np.uint32))
+        off += n_rows * 4
+        off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+    return offsets, off
+
+
+class DeviceTables:
+    """OutputPsmDF tables of one rank as ONE packed ``torch.uint8`` device buffer."""
+
+    def __init__(self, n_rows: int, top_k: int, device, with_stats: bool = True):
+        import torch
+
+        self.n_rows = int(n_rows)
+        self.top_k = int(top_k)
+        self.offsets, self.nbytes = packed_layout(self.n_rows, self.top_k, with_stats)
+        self.buffer = torch.zeros(max(self.nbytes, 1), dtype=torch.uint8, device=device)
+        self._with_stats = with_stats
+
+    def zero_(self):
+        self.buffer.zero_()
+
+    def as_output(self, n: int | None = None) -> _abi.Output:
+        """``adh_output_t`` of device pointers; ``n`` <= n_rows is the live row count."""
+        base = self.buffer.data_ptr()
+        ptrs = {k: base + off for k, (off, _, _) in self.offsets.items()}
+        stats = ptrs.pop("stat_matched_peaks", 0)
+        return _abi.output_from_device_pointers(
+            self.n_rows if n is None else int(n), self.top_k, ptrs, stats_ptr=stats
+        )
+
+    def to_host(self, buffer=None) -> dict:
+        """Unpack a packed buffer (this rank's, or one gathered slice) into numpy tables."""
+        raw = (self.buffer if buffer is None else buffer).cpu().numpy()
+        out = {}
+        for name, (off, shape, dt) in self.offsets.items():
+            cnt = int(np.prod(shape))
+            out[name] = raw[off : off + cnt * dt.itemsize].view(dt).reshape(shape).copy()
+        return out
+
+
+def all_gather_tables(local, world: int, group=None):
+    """One all-gather of the packed per-rank buffers -> [world, nbytes] tensor."""
+    import torch
+    import torch.distributed as dist
+
+    gathered = torch.empty((world, local.shape[0]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    return gathered
+
+
+def merge_gathered(tables_per_rank: list[dict], rows_per_rank: list[int]) -> dict:
+    """Concatenate the live rows of every rank's tables in rank order."""
+    out = {}
+    for name in tables_per_rank[0]:
+        out[name] = np.concatenate(
+            [t[name][:r] for t, r in zip(tables_per_rank, rows_per_rank, strict=True)], axis=0
+        )
+    return out
