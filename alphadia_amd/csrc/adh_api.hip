@@ -10,7 +10,8 @@
 #include <string>
 #include <vector>
 
-#include "adh_score.hip"
+#include "adh_gather.hip"
+#include "adh_features.hip"
 #include "adh_fragcomp.hip"
 
 namespace {
@@ -42,17 +43,44 @@ struct DeviceBuffers {
 
 }  // namespace
 
+// host copy of the candidate columns the plan needs
+struct HostCands {
+    int64_t n = 0;
+    int32_t n_iso_cols = 0;
+    std::vector<uint32_t> precursor_idx, frag_start, frag_stop;
+    std::vector<uint8_t> rank, flags, charge;
+    std::vector<int32_t> scan_start, scan_stop, scan_center, frame_start, frame_stop, frame_center;
+    std::vector<float> precursor_mz;
+};
+
+// one processing plan = CandRec table + scratch, for a given (top_k_fragments, top_k_isotopes)
+struct Plan {
+    bool ready = false;
+    uint32_t top_k_fragments = 0, top_k_isotopes = 0;
+    CandRec *d_recs = nullptr;
+    unsigned char *d_scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    int64_t n_class[2] = {0, 0};   // candidates with one / several observations
+    Caps caps_class[2];
+    Caps caps_all;
+};
+
 struct adh_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     DevRun run{};
-    DevLib lib{};
-    DevCands cands{};
+    std::vector<double> h_cycle;    // host copy for planning
+    const LibRec *d_lib = nullptr;
+    int64_t n_lib = 0;
+    const float *d_iso = nullptr;
+    HostCands hc;
+    Plan plan;
     bool run_staged = false, lib_staged = false, cands_uploaded = false;
-    DeviceBuffers run_buf, lib_buf, cand_buf;
-    int32_t *d_maxima = nullptr;
-    int32_t plan_n_lib = 0, plan_o = 0, plan_f = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // per-launch event pairs
+    DeviceBuffers run_buf, lib_buf, cand_buf, plan_buf;
+    struct Timed {
+        hipEvent_t e0, e1, e2;
+    };
+    std::vector<Timed> timed;  // per step: before gather, between, after features
     std::vector<hipEvent_t> free_events;
 };
 
@@ -113,14 +141,10 @@ int adh_create(adh_handle_t **handle, int device) {
         delete h;
         return fail(ADH_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    e = hipMalloc((void **)&h->d_maxima, 4 * sizeof(int32_t));
-    if (e != hipSuccess) {
-        (void)hipStreamDestroy(h->stream);
-        delete h;
-        return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
-    }
-    // the scoring kernel may need more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void *)adh_score_kernel,
+    // the kernels may need more than the default 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void *)adh_feature_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)adh_gather_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *handle = h;
     return ADH_OK;
@@ -133,12 +157,13 @@ int adh_destroy(adh_handle_t *h) {
     h->run_buf.release();
     h->lib_buf.release();
     h->cand_buf.release();
+    h->plan_buf.release();
     for (auto &p : h->timed) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        (void)hipEventDestroy(p.e2);
     }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
-    if (h->d_maxima) (void)hipFree(h->d_maxima);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return ADH_OK;
@@ -152,10 +177,15 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
         return fail(ADH_ERR_UNSUPPORTED,
                     "cycle with a scan axis (ion mobility) is not an AlphaRaw run");
     if (d->n_mobility < 1) return fail(ADH_ERR_INVALID_ARGUMENT, "mobility_values is empty");
+    if (d->n_peaks >= (int64_t)0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "runs with 2^32 or more peaks are not supported yet");
+    if (d->n_spectra >= (int64_t)0x7FFFFFFFll || d->cycle_len > 65535)
+        return fail(ADH_ERR_UNSUPPORTED, "too many spectra / cycle positions");
     HIP_TRY(hipSetDevice(h->device));
     h->run_buf.release();
+    h->plan_buf.release();
+    h->plan = Plan();
     h->run_staged = false;
-    h->cands_uploaded = false;
 
     // validate the CSR on the host: kernels index with it unchecked
     float mz_lo = 0.f, mz_hi = 0.f;
@@ -164,8 +194,6 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
         int64_t a = d->peak_start_idx[s], b = d->peak_stop_idx[s];
         if (a < 0 || b < a || b > d->n_peaks)
             return fail(ADH_ERR_INVALID_ARGUMENT, "peak_start/stop_idx out of range");
-        if (b - a > (int64_t)0xFFFFFFFFll)
-            return fail(ADH_ERR_UNSUPPORTED, "more than 2^32 peaks in one spectrum");
         if (b > a) {
             float lo = d->mz_values[a], hi = d->mz_values[b - 1];
             if (!any || lo < mz_lo) mz_lo = lo;
@@ -183,35 +211,61 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     r.cycle_len = d->cycle_len;
     r.cycle_scans = d->cycle_scans;
     r.n_ms1_obs = (int32_t)ms1.size();
-    UP(h->run_buf, d->mz_values, d->n_peaks, &r.mz);
-    UP(h->run_buf, d->intensity_values, d->n_peaks, &r.intensity);
-    UP(h->run_buf, d->peak_start_idx, d->n_spectra, &r.pstart);
-    UP(h->run_buf, d->peak_stop_idx, d->n_spectra, &r.pstop);
     UP(h->run_buf, d->rt_values, d->n_spectra, &r.rt);
     UP(h->run_buf, d->mobility_values, d->n_mobility, &r.mobility);
     UP(h->run_buf, d->cycle, (int64_t)d->cycle_len * d->cycle_scans * 2, &r.cycle);
     UP(h->run_buf, ms1.data(), (int64_t)ms1.size(), &r.ms1_obs);
+    h->h_cycle.assign(d->cycle, d->cycle + (size_t)d->cycle_len * d->cycle_scans * 2);
 
-    // m/z bucket index: about one bucket per peak of an average spectrum
+    // peaks as (m/z, intensity) pairs
+    float2 *peaks = nullptr;
+    HIP_TRY(hipMalloc((void **)&peaks, (size_t)std::max<int64_t>(d->n_peaks, 1) * sizeof(float2)));
+    h->run_buf.ptrs.push_back(peaks);
+    r.peaks = peaks;
+    DeviceBuffers tmp;
+    const float *d_mz = nullptr, *d_int = nullptr;
+    const int64_t *d_ps = nullptr, *d_pe = nullptr;
+    int rc = upload(tmp, d->mz_values, d->n_peaks, &d_mz, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, d->intensity_values, d->n_peaks, &d_int, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_start_idx, d->n_spectra, &d_ps, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_stop_idx, d->n_spectra, &d_pe, h->stream);
+    if (rc != ADH_OK) {
+        tmp.release();
+        return rc;
+    }
+    if (d->n_peaks > 0) {
+        hipLaunchKernelGGL(adh_interleave_kernel, dim3(4096), dim3(256), 0, h->stream, d_mz, d_int,
+                           d->n_peaks, peaks);
+    }
+
+    // m/z bucket table: about two buckets per peak of an average spectrum
     int64_t avg = d->n_spectra > 0 ? d->n_peaks / d->n_spectra : 0;
-    int nb = (int)std::min<int64_t>(std::max<int64_t>(avg, 64), 4096);
+    int64_t want = 2 * avg;
+    if (const char *env = getenv("ADH_BUCKETS")) want = atoll(env);
+    int nb = (int)std::min<int64_t>(std::max<int64_t>(want, 64), 16384);
     float span = mz_hi - mz_lo;
     if (!(span > 0.f)) span = 1.0f;
     r.n_buckets = nb;
     r.bucket_min = mz_lo;
     r.bucket_inv_width = (float)nb / span;
-    uint32_t *bucket = nullptr;
-    size_t bbytes = (size_t)std::max<int64_t>(d->n_spectra, 1) * (size_t)(nb + 1) * sizeof(uint32_t);
-    HIP_TRY(hipMalloc((void **)&bucket, bbytes));
-    h->run_buf.ptrs.push_back(bucket);
-    r.bucket = bucket;
+    uint32_t *tab = nullptr;
+    size_t tbytes = (size_t)std::max<int64_t>(d->n_spectra, 1) * (size_t)(nb + 2) * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&tab, tbytes);
+    if (e != hipSuccess) {
+        tmp.release();
+        return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(bucket table): ") + hipGetErrorString(e));
+    }
+    h->run_buf.ptrs.push_back(tab);
+    r.tab = tab;
     if (d->n_spectra > 0) {
         hipLaunchKernelGGL(adh_bucket_build_kernel, dim3((unsigned)d->n_spectra), dim3(256), 0,
-                           h->stream, r.mz, r.pstart, r.pstop, r.n_spectra, bucket, nb,
-                           r.bucket_min, r.bucket_inv_width);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(h->stream));
+                           h->stream, r.peaks, d_ps, d_pe, r.n_spectra, tab, nb, r.bucket_min,
+                           r.bucket_inv_width);
     }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    tmp.release();
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("staging kernels: ") + hipGetErrorString(e));
     h->run = r;
     h->run_staged = true;
     return ADH_OK;
@@ -220,21 +274,26 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
 int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     if (!h || !f) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (f->n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative fragment count");
+    if (f->n >= (int64_t)0xFFFFFFFFll) return fail(ADH_ERR_UNSUPPORTED, "too many fragments");
     HIP_TRY(hipSetDevice(h->device));
     h->lib_buf.release();
     h->lib_staged = false;
-    DevLib l{};
-    l.n = f->n;
-    UP(h->lib_buf, f->mz_library, f->n, &l.mz_library);
-    UP(h->lib_buf, f->mz, f->n, &l.mz);
-    UP(h->lib_buf, f->intensity, f->n, &l.intensity);
-    UP(h->lib_buf, f->type, f->n, &l.type);
-    UP(h->lib_buf, f->loss_type, f->n, &l.loss_type);
-    UP(h->lib_buf, f->charge, f->n, &l.charge);
-    UP(h->lib_buf, f->number, f->n, &l.number);
-    UP(h->lib_buf, f->position, f->n, &l.position);
-    UP(h->lib_buf, f->cardinality, f->n, &l.cardinality);
-    h->lib = l;
+    std::vector<LibRec> recs((size_t)f->n);
+    for (int64_t i = 0; i < f->n; ++i) {
+        LibRec &r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        r.mz_library = f->mz_library[i];
+        r.mz = f->mz[i];
+        r.intensity = f->intensity[i];
+        r.type = f->type[i];
+        r.loss_type = f->loss_type[i];
+        r.charge = f->charge[i];
+        r.number = f->number[i];
+        r.position = f->position[i];
+        r.cardinality = f->cardinality[i];
+    }
+    UP(h->lib_buf, recs.data(), f->n, &h->d_lib);
+    h->n_lib = f->n;
     h->lib_staged = true;
     return ADH_OK;
 }
@@ -249,13 +308,15 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
         return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 candidates in one batch");
     HIP_TRY(hipSetDevice(h->device));
     h->cand_buf.release();
+    h->plan_buf.release();
+    h->plan = Plan();
     h->cands_uploaded = false;
 
     // bounds the kernels rely on
     const int64_t L = h->run.cycle_len;
     for (int64_t i = 0; i < c->n; ++i) {
         if (c->flags && (c->flags[i] & ADH_FLAG_SKIP)) continue;
-        if (c->frag_stop_idx[i] < c->frag_start_idx[i] || (int64_t)c->frag_stop_idx[i] > h->lib.n)
+        if (c->frag_stop_idx[i] < c->frag_start_idx[i] || (int64_t)c->frag_stop_idx[i] > h->n_lib)
             return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
         int64_t fs = c->frame_start[i], fe = c->frame_stop[i], fc = c->frame_center[i];
         if (fs < 0 || fe < fs || fe > h->run.n_spectra || fc < 0 || fc >= h->run.n_spectra)
@@ -271,105 +332,214 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
                         "AlphaRaw candidates must have scan_start=0, scan_stop=1, scan_center=0");
         if (c->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge is 0");
     }
-
-    DevCands d{};
-    d.n = c->n;
-    d.n_isotope_cols = c->n_isotope_cols;
-    UP(h->cand_buf, c->precursor_idx, c->n, &d.precursor_idx);
-    UP(h->cand_buf, c->rank, c->n, &d.rank);
+    HostCands &hc = h->hc;
+    hc.n = c->n;
+    hc.n_iso_cols = c->n_isotope_cols;
+    const size_t n = (size_t)c->n;
+    hc.precursor_idx.assign(c->precursor_idx, c->precursor_idx + n);
+    hc.frag_start.assign(c->frag_start_idx, c->frag_start_idx + n);
+    hc.frag_stop.assign(c->frag_stop_idx, c->frag_stop_idx + n);
+    hc.rank.assign(c->rank, c->rank + n);
     if (c->flags)
-        UP(h->cand_buf, c->flags, c->n, &d.flags);
+        hc.flags.assign(c->flags, c->flags + n);
     else
-        d.flags = nullptr;
-    UP(h->cand_buf, c->frag_start_idx, c->n, &d.frag_start);
-    UP(h->cand_buf, c->frag_stop_idx, c->n, &d.frag_stop);
-    UP(h->cand_buf, c->scan_start, c->n, &d.scan_start);
-    UP(h->cand_buf, c->scan_stop, c->n, &d.scan_stop);
-    UP(h->cand_buf, c->scan_center, c->n, &d.scan_center);
-    UP(h->cand_buf, c->frame_start, c->n, &d.frame_start);
-    UP(h->cand_buf, c->frame_stop, c->n, &d.frame_stop);
-    UP(h->cand_buf, c->frame_center, c->n, &d.frame_center);
-    UP(h->cand_buf, c->charge, c->n, &d.charge);
-    UP(h->cand_buf, c->precursor_mz, c->n, &d.precursor_mz);
-    UP(h->cand_buf, c->isotope_intensity, c->n * c->n_isotope_cols, &d.isotope_intensity);
-    // processing order: by first cycle, so that concurrently resident wavefronts gather
-    // from the same few spectra (L2 / Infinity-Cache reuse); output rows are unaffected
-    {
-        const int64_t n_cyc = h->run.n_spectra / L + 2;
-        std::vector<uint32_t> head((size_t)n_cyc + 1, 0), order((size_t)c->n);
-        for (int64_t i = 0; i < c->n; ++i) ++head[(size_t)(c->frame_start[i] / L) + 1];
-        for (int64_t k = 0; k < n_cyc; ++k) head[(size_t)k + 1] += head[(size_t)k];
-        for (int64_t i = 0; i < c->n; ++i) order[head[(size_t)(c->frame_start[i] / L)]++] = (uint32_t)i;
-        if (getenv("ADH_DEBUG_NO_ORDER"))
-            d.order = nullptr;
-        else
-            UP(h->cand_buf, order.data(), c->n, &d.order);
-    }
-
-    // LDS capacities of this batch (upper bounds: all isotope columns)
-    HIP_TRY(hipMemsetAsync(h->d_maxima, 0, 4 * sizeof(int32_t), h->stream));
-    if (d.n > 0) {
-        unsigned blocks = (unsigned)((d.n + 255) / 256);
-        hipLaunchKernelGGL(adh_plan_kernel, dim3(blocks), dim3(256), 0, h->stream, h->run, d,
-                           (uint32_t)d.n_isotope_cols, h->d_maxima);
-        HIP_TRY(hipGetLastError());
-    }
-    int32_t mx[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(mx, h->d_maxima, sizeof(mx), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->plan_n_lib = mx[0];
-    h->plan_o = mx[1];
-    h->plan_f = mx[2];
-    h->cands = d;
+        hc.flags.assign(n, 0);
+    hc.charge.assign(c->charge, c->charge + n);
+    hc.precursor_mz.assign(c->precursor_mz, c->precursor_mz + n);
+    auto narrow = [n](const int64_t *src, std::vector<int32_t> &dst) {
+        dst.resize(n);
+        for (size_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i];
+    };
+    narrow(c->scan_start, hc.scan_start);
+    narrow(c->scan_stop, hc.scan_stop);
+    narrow(c->scan_center, hc.scan_center);
+    narrow(c->frame_start, hc.frame_start);
+    narrow(c->frame_stop, hc.frame_stop);
+    narrow(c->frame_center, hc.frame_center);
+    UP(h->cand_buf, c->isotope_intensity, c->n * c->n_isotope_cols, &h->d_iso);
     h->cands_uploaded = true;
     return ADH_OK;
 }
+
+namespace {
+
+// Build the processing plan for (top_k_fragments, top_k_isotopes): observation lists,
+// tile sizes, scratch offsets, and a processing order by (observation class, first cycle) so
+// that concurrently resident wavefronts gather from the same few spectra.
+int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
+    Plan &p = h->plan;
+    if (p.ready && p.top_k_fragments == cfg->top_k_fragments && p.top_k_isotopes == cfg->top_k_isotopes)
+        return ADH_OK;
+    h->plan_buf.release();
+    p = Plan();
+    const HostCands &hc = h->hc;
+    const int64_t n = hc.n;
+    const int L = h->run.cycle_len;
+    const int rows = h->run.cycle_len * h->run.cycle_scans;
+    const int I = (int)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)hc.n_iso_cols);
+    const double *cyc = h->h_cycle.data();
+    const double ISOTOPE_DELTA = 1.0033548350700006;
+
+    std::vector<CandRec> recs((size_t)n);
+    std::vector<uint8_t> cls((size_t)n, 0);
+    const int64_t n_cyc = h->run.n_spectra / L + 2;
+    std::vector<uint32_t> head[2];
+    head[0].assign((size_t)n_cyc + 1, 0);
+    head[1].assign((size_t)n_cyc + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        CandRec &r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        r.precursor_idx = hc.precursor_idx[i];
+        r.frag_start = hc.frag_start[i];
+        r.frag_stop = hc.frag_stop[i];
+        r.frame_start = hc.frame_start[i];
+        r.frame_stop = hc.frame_stop[i];
+        r.frame_center = hc.frame_center[i];
+        r.scan_start = hc.scan_start[i];
+        r.scan_stop = hc.scan_stop[i];
+        r.scan_center = hc.scan_center[i];
+        r.precursor_mz = hc.precursor_mz[i];
+        r.charge = hc.charge[i];
+        r.rank = hc.rank[i];
+        r.flags = hc.flags[i];
+        r.row = (uint32_t)i;
+        if (r.flags & ADH_FLAG_SKIP) {
+            ++head[0][1];  // parked in cycle bin 0 of class 0; the kernels return at once
+            continue;
+        }
+        // isotope m/z range exactly as the kernels compute it (candidate.py:151-163,203-205)
+        float mn = 0.f, mx = 0.f;
+        for (int k = 0; k < I; ++k) {
+            float m = (float)((double)k * ISOTOPE_DELTA / (double)r.charge) + r.precursor_mz;
+            if (k == 0 || m < mn) mn = m;
+            if (k == 0 || m > mx) mx = m;
+        }
+        const float q_lo = (float)((double)mn - 0.5), q_hi = (float)((double)mx + 0.5);
+        int O = 0;
+        for (int row = 0; row < rows; ++row) {
+            if ((double)q_lo <= cyc[2 * row + 1] && (double)q_hi >= cyc[2 * row]) {
+                if (O >= ADH_MAX_OBS)
+                    return fail(ADH_ERR_UNSUPPORTED,
+                                "a precursor overlaps more than 8 isolation windows");
+                r.obs[O++] = (uint16_t)row;
+            }
+        }
+        r.n_obs = (uint8_t)O;
+        r.k_cap = (uint32_t)std::min<int64_t>((int64_t)cfg->top_k_fragments,
+                                              (int64_t)r.frag_stop - (int64_t)r.frag_start);
+        cls[(size_t)i] = O > 1 ? 1 : 0;
+        ++head[cls[(size_t)i]][(size_t)(r.frame_start / L) + 1];
+    }
+    // counting sort by (class, first cycle)
+    for (int c = 0; c < 2; ++c)
+        for (int64_t k = 0; k < n_cyc; ++k) head[c][(size_t)k + 1] += head[c][(size_t)k];
+    p.n_class[0] = head[0][(size_t)n_cyc];
+    p.n_class[1] = head[1][(size_t)n_cyc];
+    std::vector<CandRec> ordered((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const CandRec &r = recs[(size_t)i];
+        int c = cls[(size_t)i];
+        size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)(r.frame_start / L);
+        size_t pos = (size_t)head[c][bin]++ + (c ? (size_t)p.n_class[0] : 0);
+        ordered[pos] = r;
+    }
+    // scratch offsets + capacities
+    Caps zero{1, 1, 1, std::max(I, 1), 1, 0};
+    p.caps_class[0] = p.caps_class[1] = p.caps_all = zero;
+    uint64_t off = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        CandRec &r = ordered[(size_t)j];
+        if (r.flags & ADH_FLAG_SKIP) continue;
+        const int F = r.frame_stop / L - r.frame_start / L;
+        const int O = r.n_obs;
+        r.scratch_off = off;
+        off += adh_scratch_bytes(r.k_cap, O, std::max(F, 0), I);
+        Caps &cc = p.caps_class[j < p.n_class[0] ? 0 : 1];
+        cc.k = std::max<int32_t>(cc.k, (int32_t)r.k_cap);
+        cc.o = std::max<int32_t>(cc.o, O);
+        cc.f = std::max<int32_t>(cc.f, F);
+        cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
+    }
+    p.caps_all.k = std::max(p.caps_class[0].k, p.caps_class[1].k);
+    p.caps_all.o = std::max(p.caps_class[0].o, p.caps_class[1].o);
+    p.caps_all.f = std::max(p.caps_class[0].f, p.caps_class[1].f);
+    p.caps_all.n_lib = std::max(p.caps_class[0].n_lib, p.caps_class[1].n_lib);
+    p.scratch_bytes = std::max<uint64_t>(off, 32);
+    const CandRec *d_recs = nullptr;
+    UP(h->plan_buf, ordered.data(), n, &d_recs);
+    p.d_recs = const_cast<CandRec *>(d_recs);
+    void *sp = nullptr;
+    HIP_TRY(hipMalloc(&sp, p.scratch_bytes));
+    h->plan_buf.ptrs.push_back(sp);
+    p.d_scratch = static_cast<unsigned char *>(sp);
+    p.top_k_fragments = cfg->top_k_fragments;
+    p.top_k_isotopes = cfg->top_k_isotopes;
+    p.ready = true;
+    return ADH_OK;
+}
+
+}  // namespace
 
 int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_output_t *out,
                        void *hip_stream) {
     if (!h || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!h->cands_uploaded) return fail(ADH_ERR_NOT_STAGED, "no candidate table uploaded");
-    if (out->n != h->cands.n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
+    if (out->n != h->hc.n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
     if (cfg->top_k_fragments == 0 || cfg->top_k_isotopes == 0)
         return fail(ADH_ERR_INVALID_ARGUMENT, "top_k_fragments / top_k_isotopes must be > 0");
     if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->cands.n == 0) return ADH_OK;
+    if (h->hc.n == 0) return ADH_OK;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
-
-    Caps caps;
-    caps.n_lib = std::max(h->plan_n_lib, 1);
-    caps.k = (int32_t)std::max<int64_t>(
-        std::min<int64_t>((int64_t)cfg->top_k_fragments, (int64_t)caps.n_lib), 1);
-    caps.o = std::max(h->plan_o, 1);
-    caps.f = std::max(h->plan_f, 1);
-    caps.i = std::max<int32_t>(
-        (int32_t)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)h->cands.n_isotope_cols), 1);
-    {
-        const char *dbg = getenv("ADH_DEBUG_STOP_PHASE");  // developer ablation switch
-        caps.stop_phase = dbg ? atoi(dbg) : 0;
-    }
-    if (cfg->collect_fragments && caps.k > out->top_k)
+    int rc = build_plan(h, cfg);
+    if (rc != ADH_OK) return rc;
+    Plan &p = h->plan;
+    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
         return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
-    size_t lds = adh_score_lds_bytes(caps);
-    if (lds > 160 * 1024) {
-        char buf[256];
-        snprintf(buf, sizeof(buf),
-                 "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", lds,
-                 caps.k, caps.o, caps.f);
-        return fail(ADH_ERR_UNSUPPORTED, buf);
+    int stop_phase = 0;
+    if (const char *dbg = getenv("ADH_DEBUG_STOP_PHASE")) stop_phase = atoi(dbg);  // developer switch
+
+    Caps gcaps = p.caps_all;
+    const size_t g_lds = adh_gather_lds_bytes(gcaps);
+    size_t f_lds[2];
+    for (int c = 0; c < 2; ++c) {
+        p.caps_class[c].stop_phase = stop_phase;
+        f_lds[c] = adh_feature_lds_bytes(p.caps_class[c]);
+        if (p.n_class[c] > 0 && f_lds[c] > 160 * 1024) {
+            char buf[256];
+            snprintf(buf, sizeof(buf),
+                     "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB",
+                     f_lds[c], p.caps_class[c].k, p.caps_class[c].o, p.caps_class[c].f);
+            return fail(ADH_ERR_UNSUPPORTED, buf);
+        }
     }
-    hipEvent_t e0, e1;
-    int rc = get_event(h, &e0);
+    if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice too long for the gather kernel");
+
+    adh_handle::Timed t;
+    rc = get_event(h, &t.e0);
+    if (rc == ADH_OK) rc = get_event(h, &t.e1);
+    if (rc == ADH_OK) rc = get_event(h, &t.e2);
     if (rc != ADH_OK) return rc;
-    rc = get_event(h, &e1);
-    if (rc != ADH_OK) return rc;
-    HIP_TRY(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(adh_score_kernel, dim3((unsigned)h->cands.n), dim3(ADH_WAVE), lds, st,
-                       h->run, h->lib, h->cands, *cfg, *out, caps);
+    const int32_t n_iso = h->hc.n_iso_cols;
+    HIP_TRY(hipEventRecord(t.e0, st));
+    hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), g_lds, st, h->run,
+                       h->d_lib, p.d_recs, *cfg, n_iso, p.d_scratch, *out, gcaps);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, st));
-    h->timed.emplace_back(e0, e1);
+    HIP_TRY(hipEventRecord(t.e1, st));
+    if (stop_phase != 2) {
+        int64_t first = 0;
+        for (int c = 0; c < 2; ++c) {
+            if (p.n_class[c] > 0) {
+                hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[c]), dim3(ADH_WAVE),
+                                   f_lds[c], st, h->run, p.d_recs + first, h->d_iso, n_iso, *cfg,
+                                   p.d_scratch, *out, p.caps_class[c]);
+                HIP_TRY(hipGetLastError());
+            }
+            first += p.n_class[c];
+        }
+    }
+    HIP_TRY(hipEventRecord(t.e2, st));
+    h->timed.push_back(t);
     return ADH_OK;
 }
 
@@ -380,24 +550,30 @@ int adh_synchronize(adh_handle_t *h) {
     return ADH_OK;
 }
 
-int adh_kernel_time_ms(adh_handle_t *h, double *avg_ms, int64_t *launches, int reset) {
-    if (!h || !avg_ms || !launches) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+int adh_kernel_time_ms(adh_handle_t *h, double *gather_ms, double *feature_ms, int64_t *launches,
+                       int reset) {
+    if (!h || !gather_ms || !feature_ms || !launches)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    double sum = 0;
+    double sg = 0, sf = 0;
     int64_t n = 0;
-    for (auto &p : h->timed) {
-        HIP_TRY(hipEventSynchronize(p.second));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-        sum += ms;
+    for (auto &t : h->timed) {
+        HIP_TRY(hipEventSynchronize(t.e2));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, t.e0, t.e1));
+        HIP_TRY(hipEventElapsedTime(&b, t.e1, t.e2));
+        sg += a;
+        sf += b;
         ++n;
     }
-    *avg_ms = n ? sum / (double)n : 0.0;
+    *gather_ms = n ? sg / (double)n : 0.0;
+    *feature_ms = n ? sf / (double)n : 0.0;
     *launches = n;
     if (reset) {
-        for (auto &p : h->timed) {
-            h->free_events.push_back(p.first);
-            h->free_events.push_back(p.second);
+        for (auto &t : h->timed) {
+            h->free_events.push_back(t.e0);
+            h->free_events.push_back(t.e1);
+            h->free_events.push_back(t.e2);
         }
         h->timed.clear();
     }

@@ -1,5 +1,15 @@
 // Device-side views shared by the kernels and the C-ABI host layer.
 // Plain structs passed to kernels by value; every pointer is a device pointer.
+//
+// HBM layout:
+//   peaks   float2[n_peaks]            (m/z, intensity) interleaved: a window hit needs no
+//                                      second dependent load
+//   tab     uint32[n_spectra][NB + 2]  per-spectrum m/z bucket table with ABSOLUTE peak
+//                                      offsets; entry NB + 1 is the end of the spectrum
+//   lib     LibRec[n_fragments]        32-byte fragment records (one vector load per lane)
+//   plan    CandRec[n_candidates]      80-byte candidate records in PROCESSING order
+//   scratch per-candidate blocks       selected fragments + XIC tile, written by the gather
+//                                      kernel, read by the feature kernel
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,18 +17,15 @@
 #include "../../include/alphadia_hip.h"
 
 #define ADH_WAVE 64
+#define ADH_MAX_OBS 8
 
-// Run staged in HBM: AlphaRawJIT arrays (alpharaw_jit.py:78-138) + our m/z bucket index.
 struct DevRun {
-    const float *mz;          // [n_peaks]
-    const float *intensity;   // [n_peaks]
-    const int64_t *pstart;    // [n_spectra]
-    const int64_t *pstop;     // [n_spectra]
+    const float2 *peaks;      // [n_peaks] (mz, intensity)
+    const uint32_t *tab;      // [n_spectra][n_buckets + 2]
     const float *rt;          // [n_spectra]
     const float *mobility;    // [n_mobility]
     const double *cycle;      // [cycle_len * cycle_scans * 2]
     const int32_t *ms1_obs;   // rows of the cycle selected by quadrupole (-1,-1)
-    const uint32_t *bucket;   // [n_spectra * (n_buckets + 1)] offsets relative to pstart
     int64_t n_spectra;
     int64_t n_peaks;
     int32_t cycle_len;
@@ -29,51 +36,57 @@ struct DevRun {
     float bucket_inv_width;   // 1 / width
 };
 
-// FragmentContainer arrays (fragment_container.py:11-46)
-struct DevLib {
-    const float *mz_library;
-    const float *mz;
-    const float *intensity;
-    const uint8_t *type;
-    const uint8_t *loss_type;
-    const uint8_t *charge;
-    const uint8_t *number;
-    const uint8_t *position;
-    const uint8_t *cardinality;
-    int64_t n;
+// one library fragment (fragment_container.py:11-46), 32 bytes
+struct __attribute__((aligned(16))) LibRec {
+    float mz_library;
+    float mz;
+    float intensity;
+    uint8_t type, loss_type, charge, number;
+    uint8_t position, cardinality, pad0, pad1;
+    uint32_t pad2[3];
 };
+static_assert(sizeof(LibRec) == 32, "LibRec must be 32 bytes");
 
-// Candidate SoA (score_group.py:145-229)
-struct DevCands {
-    int64_t n;
-    const uint32_t *precursor_idx;
-    const uint8_t *rank;
-    const uint8_t *flags;
-    const uint32_t *frag_start;
-    const uint32_t *frag_stop;
-    const int64_t *scan_start;
-    const int64_t *scan_stop;
-    const int64_t *scan_center;
-    const int64_t *frame_start;
-    const int64_t *frame_stop;
-    const int64_t *frame_center;
-    const uint8_t *charge;
-    const float *precursor_mz;
-    const float *isotope_intensity;
-    const uint32_t *order;    // processing permutation or nullptr
-    int32_t n_isotope_cols;
+// one candidate in processing order (score_group.py:145-229 columns + the plan)
+struct __attribute__((aligned(16))) CandRec {
+    uint32_t precursor_idx, frag_start, frag_stop;
+    int32_t frame_start, frame_stop, frame_center;
+    int32_t scan_start, scan_stop, scan_center;
+    float precursor_mz;
+    uint8_t charge, rank, flags, n_obs;
+    uint16_t obs[ADH_MAX_OBS];  // cycle rows overlapping the precursor isolation range
+    uint32_t row;               // row of the output tables
+    uint64_t scratch_off;       // byte offset of this candidate's scratch block
+    uint32_t k_cap;             // min(top_k, library slice length)
+    uint32_t pad;
 };
+static_assert(sizeof(CandRec) == 80, "CandRec must be 80 bytes");
 
-// OutputPsmDF (output.py:17-70); same member order as adh_output_t
+// scratch block of one candidate (all sizes multiples of 32 bytes):
+//   [0, 32)                      header: uint32 K (0 = failed before the gather), uint32 hits
+//   [32, 32 + k_cap * 32)        selected fragments, ascending m/z (LibRec)
+//   then  float2[k_cap * O * F]  fragment cells, index ((o * F + f) * K + k)
+//   then  float2[I * F]          precursor cells, index (i * F + f)
+__host__ __device__ inline uint64_t adh_scratch_frag_off(uint32_t k_cap) {
+    return 32 + (uint64_t)k_cap * 32;
+}
+__host__ __device__ inline uint64_t adh_scratch_prec_off(uint32_t k_cap, int O, int F) {
+    return adh_scratch_frag_off(k_cap) + (uint64_t)k_cap * O * F * 8;
+}
+__host__ __device__ inline uint64_t adh_scratch_bytes(uint32_t k_cap, int O, int F, int I) {
+    uint64_t b = adh_scratch_prec_off(k_cap, O, F) + (uint64_t)I * F * 8;
+    return (b + 31) / 32 * 32;
+}
+
 typedef adh_output_t DevOut;
 
-// LDS capacities for one launch (maxima over the batch, from the plan kernel)
+// LDS capacities of one launch (maxima over the launch's candidates)
 struct Caps {
-    int32_t n_lib;   // longest library slice
     int32_t k;       // fragments kept (<= top_k)
     int32_t o;       // observations
     int32_t f;       // cycles
     int32_t i;       // isotopes
+    int32_t n_lib;   // longest library slice (gather kernel scratch)
     int32_t stop_phase;  // developer ablation switch (0 = run everything)
 };
 

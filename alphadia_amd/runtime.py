@@ -143,13 +143,15 @@ class Context:
         _check(lib.adh_synchronize(self._h), "adh_synchronize")
 
     def kernel_time_ms(self, reset: bool = True):
-        avg = C.c_double(0)
+        """(gather_ms, feature_ms, launches): HIP-event averages per scoring call."""
+        g = C.c_double(0)
+        f = C.c_double(0)
         n = C.c_int64(0)
         _check(
-            lib.adh_kernel_time_ms(self._h, C.byref(avg), C.byref(n), C.c_int(int(reset))),
+            lib.adh_kernel_time_ms(self._h, C.byref(g), C.byref(f), C.byref(n), C.c_int(int(reset))),
             "adh_kernel_time_ms",
         )
-        return avg.value, n.value
+        return g.value, f.value, n.value
 
     # -- fragment competition -------------------------------------------
     def fragcomp(self, window_start, window_stop, rt, frag_start, frag_stop, fragment_mz,

@@ -176,7 +176,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms, launches = ctx.kernel_time_ms(reset=True)
+    gather_ms, feature_ms, launches = ctx.kernel_time_ms(reset=True)
+    kernel_ms = gather_ms + feature_ms
 
     # ---------------- results of the last step (sanity + roofline inputs) ----------------
     host = tables.to_host()
@@ -227,8 +228,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "adh_score_kernel",
+            "kernel": "adh_gather_kernel + adh_feature_kernel (the hot path; sum of both)",
             "kernel_ms": kernel_ms,
+            "gather_kernel_ms": gather_ms,
+            "feature_kernel_ms": feature_ms,
             "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_per_candidate": bytes_per_launch / max(n_local, 1),

@@ -195,10 +195,12 @@ int adh_score_uploaded(adh_handle_t *handle, const adh_scoring_config_t *config,
 int adh_synchronize(adh_handle_t *handle);
 
 /*
- * Average duration (milliseconds) of the dominant scoring kernel over the
- * launches since the last reset, measured with HIP events on the launch stream.
+ * Average durations (milliseconds per adh_score_uploaded call) of the two scoring
+ * kernels since the last reset, measured with HIP events on the launch stream:
+ * `gather_ms` = fragment selection + XIC gather, `feature_ms` = the feature stack.
  */
-int adh_kernel_time_ms(adh_handle_t *handle, double *avg_ms, int64_t *launches, int reset);
+int adh_kernel_time_ms(adh_handle_t *handle, double *gather_ms, double *feature_ms,
+                       int64_t *launches, int reset);
 
 /*
  * Fragment competition inside one run (replaces `_compete_for_fragments`,

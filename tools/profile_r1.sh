@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp
 # 1. ablation: kernel time when the kernel returns after phase p
 for p in 1 2 3 4 5 6 0; do
-  ADH_DEBUG_STOP_PHASE=$p python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('stop_phase $p kernel_ms', r['roofline']['kernel_ms'])"
+  ADH_DEBUG_STOP_PHASE=$p python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read())[\"roofline\"]; print(\"stop_phase $p\", r[\"gather_kernel_ms\"], r[\"feature_kernel_ms\"])"
 done > $OUT/ablation.txt 2>&1
 cat $OUT/ablation.txt
 # 2. kernel trace + stats
