@@ -80,6 +80,19 @@ class DeviceTables:
             self.n_rows if n is None else int(n), self.top_k, ptrs, stats_ptr=stats
         )
 
+    def load_host(self, arrays: dict) -> None:
+        """Fill the packed buffer from host tables with at most ``n_rows`` rows."""
+        import torch
+
+        raw = np.zeros(self.nbytes, dtype=np.uint8)
+        for name, (off, shape, dt) in self.offsets.items():
+            if name not in arrays:
+                continue
+            a = np.ascontiguousarray(arrays[name]).astype(dt, copy=False)
+            flat = a.reshape(-1).view(np.uint8)
+            raw[off : off + flat.size] = flat
+        self.buffer.copy_(torch.from_numpy(raw).to(self.buffer.device))
+
     def to_host(self, buffer=None) -> dict:
         """Unpack a packed buffer (this rank's, or one gathered slice) into numpy tables."""
         raw = (self.buffer if buffer is None else buffer).cpu().numpy()
@@ -96,7 +109,10 @@ def all_gather_tables(local, world: int, group=None):
     import torch.distributed as dist
 
     gathered = torch.empty((world, local.shape[0]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local, group=group)
+    try:
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the flat variant
+        dist.all_gather(list(gathered.unbind(0)), local, group=group)
     return gathered
 
 

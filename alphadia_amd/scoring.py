@@ -566,3 +566,62 @@ class HipCandidateScoring:
         fragments_df = collect_fragments(psm_proto_df, self.precursors_flat_df)
         logger.info("Finished candidate scoring")
         return features_df, fragments_df
+
+
+def calculate_score_groups(input_df: pd.DataFrame, group_channels: bool = False) -> pd.DataFrame:
+    """Score groups for DIA multiplexing (scoring/utils.py:269-410).
+
+    Rows are sorted by (elution_group_idx, decoy, rank, precursor_idx); with
+    ``group_channels`` every change of (elution group, decoy, rank) opens a new
+    group, otherwise each row is its own group.
+    """
+    if "rank" in input_df.columns:
+        input_df = input_df.sort_values(by=["elution_group_idx", "decoy", "rank", "precursor_idx"])
+        rank_values = input_df["rank"].values
+    else:
+        input_df = input_df.sort_values(by=["elution_group_idx", "decoy", "precursor_idx"])
+        rank_values = np.zeros(len(input_df), dtype=np.uint32)
+    n = len(input_df)
+    if group_channels and n:
+        eg = input_df["elution_group_idx"].values
+        dc = input_df["decoy"].values
+        change = np.zeros(n, dtype=bool)
+        change[1:] = (eg[1:] != eg[:-1]) | (dc[1:] != dc[:-1]) | (rank_values[1:] != rank_values[:-1])
+        input_df["score_group_idx"] = np.cumsum(change).astype(np.uint32)
+    else:
+        input_df["score_group_idx"] = np.arange(n, dtype=np.uint32)
+    return input_df.sort_values(by=["score_group_idx", "precursor_idx"]).reset_index(drop=True)
+
+
+def multiplex_candidates(
+    candidates_df: pd.DataFrame,
+    precursors_flat_df: pd.DataFrame,
+    remove_decoys: bool = True,
+    channels: list[int] | None = None,
+) -> pd.DataFrame:
+    """Spread the best candidate of every elution group over all channels
+    (scoring/utils.py:114-200)."""
+    if channels is None:
+        channels = [0, 4, 8, 12]
+    precursors_flat_view = precursors_flat_df.copy()
+    best_candidate_view = candidates_df.copy()
+    if remove_decoys:
+        precursors_flat_view = precursors_flat_df[precursors_flat_df["decoy"] == 0]
+        if "decoy" in best_candidate_view.columns:
+            best_candidate_view = best_candidate_view[best_candidate_view["decoy"] == 0]
+    best_candidate_view = (
+        best_candidate_view.sort_values(["proba", "precursor_idx"])
+        .groupby("elution_group_idx")
+        .first()
+        .reset_index()
+    )
+    candidate_elution_group_idxs = best_candidate_view["elution_group_idx"].unique()
+    precursors_flat_view = precursors_flat_view[precursors_flat_view["channel"].isin(channels)]
+    precursors_flat_view = precursors_flat_view[
+        precursors_flat_view["elution_group_idx"].isin(candidate_elution_group_idxs)
+    ]
+    precursors_flat_view = precursors_flat_view[["elution_group_idx", "precursor_idx", "channel"]]
+    best_candidate_view = best_candidate_view.drop(columns=["precursor_idx"])
+    if "channel" in best_candidate_view.columns:
+        best_candidate_view = best_candidate_view.drop(columns=["channel"])
+    return precursors_flat_view.merge(best_candidate_view, on="elution_group_idx", how="left")

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: candidate sharding by score group + ONE all-gather of the
+packed tables reproduces the unsharded result.  The per-rank tables are filled by the
+oracle here (no GPU in this container); on the GPU the same code path is fed by the kernels
+(bench.py --gpus N)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+from alphadia_amd.distributed import (
+    DeviceTables,
+    all_gather_tables,
+    merge_gathered,
+    packed_layout,
+    shard_bounds,
+    slice_soa,
+)
+
+
+def test_shard_bounds_keep_score_groups_intact():
+    sg = np.array([0, 0, 0, 1, 2, 2, 3, 3, 3, 3, 4], dtype=np.uint32)
+    for world in (1, 2, 3, 4, 8):
+        cuts = [shard_bounds(sg, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(sg)
+        for (a0, b0), (a1, b1) in zip(cuts[:-1], cuts[1:]):
+            assert b0 == a1
+        for a, b in cuts:
+            if 0 < a < len(sg):
+                assert sg[a] != sg[a - 1]
+    assert shard_bounds(np.zeros(0, np.uint32), 0, 2) == (0, 0)
+
+
+def test_packed_layout_is_aligned_and_disjoint():
+    offsets, nbytes = packed_layout(1000, 12)
+    spans = sorted((off, off + int(np.prod(shape)) * dt.itemsize) for off, shape, dt in offsets.values())
+    for (a0, b0), (a1, b1) in zip(spans[:-1], spans[1:]):
+        assert b0 <= a1
+    assert all(off % 256 == 0 for off, _, _ in offsets.values()) and spans[-1][1] <= nbytes
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+
+    g = H.load_scoring_golden("handler_default")
+    soa_all = H.soa_for(g, g.config)
+    a, b = shard_bounds(soa_all["score_group_idx"], rank, world)
+    local, _ = H.oracle_score(oracle, g, g.config, soa=slice_soa(soa_all, a, b))
+    n_rows = -(-len(soa_all["precursor_idx"]) // world) + 3
+    tables = DeviceTables(n_rows, int(g.config.top_k_fragments), "cpu", with_stats=False)
+    tables.load_host(local)
+    gathered = all_gather_tables(tables.buffer, world)
+    rows = [shard_bounds(soa_all["score_group_idx"], r, world) for r in range(world)]
+    merged = merge_gathered([tables.to_host(gathered[r]) for r in range(world)], [e - s for s, e in rows])
+    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **merged)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = H.load_scoring_golden("handler_default")
+    full, _ = H.oracle_score(oracle_lib, g, g.config)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for k, v in full.items():
+            assert np.array_equal(z[k], v, equal_nan=True), (r, k)

@@ -126,3 +126,161 @@ def test_empty_and_skipped(ctx, oracle_lib):
     exp, _ = H.oracle_score(oracle_lib, g, g.config, soa=soa)
     compare(got, exp, PPM_ABS_TOL_ORACLE)
     assert not got["valid"][::3].any() and not got["precursor_idx"][::3].any()
+
+
+def test_fragcomp_matches_reference_and_oracle(ctx, oracle_lib):
+    import pandas as pd
+
+    from alphadia_amd.fragcomp import FragmentCompetition
+
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm_df = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag_df = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    res = FragmentCompetition(rt_tol_seconds=3, mass_tol_ppm=15, device=0)(psm_df, frag_df, z["cycle"])
+    assert np.array_equal(res["precursor_idx"].values, z["surviving_precursor_idx"])
+    assert np.array_equal(res["rank"].values, z["surviving_rank"])
+
+
+def test_fragcomp_reference_kats(ctx):
+    import pandas as pd
+
+    from alphadia_amd.fragcomp import FragmentCompetition
+
+    # tests/unit_tests/fragcomp/test_fragcomp.py:38-57
+    rt = np.array([10.0, 20.0, 20.0, 10.0, 10.0, 20])
+    valid = ctx.fragcomp(np.array([0, 3]), np.array([3, 6]), rt, np.array([0, 10, 20, 30, 40, 50]),
+                         np.array([10, 20, 30, 40, 50, 60]), np.tile(np.arange(100, 110), 6), 3, 15)
+    assert np.all(valid == np.array([True, True, False, True, False, True]))
+    # tests/unit_tests/fragcomp/test_fragcomp.py:60-100
+    cycle = np.array([[[[90, 110]], [[190, 210]]]])
+    psm_df = pd.DataFrame(
+        {
+            "precursor_idx": np.arange(6, dtype=np.uint32),
+            "rt_observed": np.array([10.0, 20.0, 20.0, 10.0, 10.0, 20]),
+            "valid": np.array([True] * 6),
+            "mz_observed": np.array([100, 100, 100, 200, 200, 200]),
+            "proba": np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]),
+            "rank": np.zeros(6, dtype=np.uint8),
+        }
+    )
+    frag_df = pd.DataFrame(
+        {
+            "precursor_idx": np.repeat(np.arange(6, dtype=np.uint32), 10),
+            "mz_observed": np.tile(np.arange(100, 110), 6),
+            "rank": np.zeros(60, dtype=np.uint8),
+        }
+    )
+    out = FragmentCompetition(device=0)(psm_df, frag_df, cycle).reset_index(drop=True)
+    assert out["precursor_idx"].tolist() == [0, 1, 3, 5]
+    assert out["_candidate_idx"].tolist() == [0, 1, 3, 5] and out["valid"].all()
+    assert list(out.columns) == ["precursor_idx", "rt_observed", "valid", "mz_observed", "proba", "rank",
+                                 "_candidate_idx"]
+
+
+def test_fragcomp_large_random_vs_oracle(ctx, oracle_lib):
+    rng = np.random.default_rng(5)
+    n_win, per = 12, 900
+    n = n_win * per
+    rt = rng.uniform(0, 60, n).astype(np.float32)
+    nfrag = rng.integers(0, 13, n)
+    stop = np.cumsum(nfrag)
+    start = stop - nfrag
+    pool = np.sort(rng.uniform(200, 1800, 400)).astype(np.float32)
+    mz = (rng.choice(pool, int(stop[-1])) * (1 + rng.normal(0, 5e-6, int(stop[-1])))).astype(np.float32)
+    ws = np.arange(n_win) * per
+    got = ctx.fragcomp(ws, ws + per, rt, start, stop, mz, 3, 15)
+    exp = oracle_lib.fragcomp(ws, ws + per, rt, start, stop, mz, 3, 15, n_threads=8)
+    assert np.array_equal(got, exp) and 0 < exp.sum() < n
+
+
+def test_operator_and_handler_dataframes(ctx):
+    """HipCandidateScoring / HipExtractionHandler: same frames as the reference produced."""
+    from types import SimpleNamespace
+
+    from alphadia_amd.extraction_handler import HipExtractionHandler, create_handler
+    from alphadia_amd.scoring import DEFAULT_FEATURE_COLUMNS, HipCandidateScoring
+
+    g = H.load_scoring_golden("handler_default")
+    scorer = HipCandidateScoring(
+        dia_data=g.dia, precursors_flat=g.library.precursor_df, fragments_flat=g.library.fragment_df,
+        rt_column="rt_library", mobility_column="mobility_library", precursor_mz_column="mz_library",
+        fragment_mz_column="mz_library", config=g.config, device=0,
+    )
+    fdf, frdf = scorer(g.candidates_df, thread_count=4)
+    assert list(fdf.columns[:46]) == DEFAULT_FEATURE_COLUMNS
+    assert sorted(fdf.columns) == sorted(g.z["features_df_columns"].tolist())
+    assert list(frdf.columns) == g.z["fragments_df_columns"].tolist()
+    assert np.array_equal(fdf["precursor_idx"].values, g.z["features_df_precursor_idx"])
+    assert np.array_equal(fdf["rank"].values, g.z["features_df_rank"])
+    assert len(frdf) == int(g.z["fragments_df_n"])
+    assert np.array_equal(frdf["precursor_idx"].values, g.z["fragments_df_precursor_idx"])
+    assert np.abs(frdf["mz_observed"].values - g.z["fragments_df_mz_observed"]).max() < 1e-4
+
+    config = {"search": {"extraction_backend": "hip", "exclude_shared_ions": True, "quant_window": 3,
+                         "quant_all": True, "experimental_xic": True, "top_k_fragments_scoring": 12},
+              "general": {"thread_count": 4}}
+    opt = SimpleNamespace(ms1_error=10, ms2_error=15)
+    names = SimpleNamespace(get_rt_column=lambda: "rt_library", get_mobility_column=lambda: "mobility_library",
+                            get_precursor_mz_column=lambda: "mz_library",
+                            get_fragment_mz_column=lambda: "mz_library")
+    reporter = SimpleNamespace(log_string=lambda *a, **k: None)
+    handler = create_handler(config, opt, None, reporter, names)
+    assert isinstance(handler, HipExtractionHandler)
+    lib = SimpleNamespace(precursor_df=g.library.precursor_df, fragment_df=g.library.fragment_df)
+    f2, fr2 = handler.score_and_quantify_candidates(g.candidates_df, g.dia, lib)
+    pd_equal = f2[DEFAULT_FEATURE_COLUMNS].to_numpy()
+    assert np.array_equal(pd_equal, fdf[DEFAULT_FEATURE_COLUMNS].to_numpy(), equal_nan=True)
+    none, fr3 = handler.quantify_candidates(g.candidates_df, None, g.dia, lib, top_k_fragments=9999)
+    assert none is None and len(fr3) >= len(fr2)
+    with pytest.raises(NotImplementedError):
+        handler.select_candidates(g.dia, lib)
+    with pytest.raises(ValueError):
+        create_handler({"search": {"extraction_backend": "python"}}, opt, None, reporter, names)
+
+
+def test_invalid_inputs_fail_loudly(ctx):
+    from alphadia_amd.runtime import HipBackendError
+
+    g = H.load_scoring_golden("handler_default")
+    soa = H.soa_for(g, g.config)
+    ctx.stage_run(g.dia, force=True)
+    ctx.stage_fragments(*fragment_columns(g.library.fragment_df, "mz_library"), force=True)
+    bad = dict(soa)
+    bad["frame_stop"] = soa["frame_stop"].copy()
+    bad["frame_stop"][0] = g.dia.n_spectra + g.dia.cycle_len * 5
+    with pytest.raises(HipBackendError, match="frame limits"):
+        ctx.score_host(pack_assembled(bad), g.config.to_jitclass())
+    bad = dict(soa)
+    bad["frag_stop_idx"] = soa["frag_stop_idx"].copy()
+    bad["frag_stop_idx"][0] = 10**9
+    with pytest.raises(HipBackendError, match="fragment slice"):
+        ctx.score_host(pack_assembled(bad), g.config.to_jitclass())
+
+
+def test_config2_scale_properties(ctx, oracle_lib):
+    """BASELINE config 2 shape at reduced run length (same 61-spectrum cycle, same peak
+    densities): order independence, bounded sample vs the oracle, matched-peak checksum."""
+    case = syn.make_case(20000, 1200, config_id=2, per_precursor=3, threads=16)
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15,
+                    quant_all=True, experimental_xic=True))
+    got, soa = hip_score(ctx, case, cfg, with_stats=True)
+    n = len(soa["precursor_idx"])
+    # (1) a permuted candidate table gives the same rows
+    perm = np.random.default_rng(0).permutation(n)
+    soa_p = {k: (v[perm] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in soa.items()}
+    got_p, _ = hip_score(ctx, case, cfg, soa=soa_p, with_stats=True)
+    for k in got:
+        assert np.array_equal(got[k][perm], got_p[k], equal_nan=True), k
+    # (2) the first 6000 rows equal the oracle's
+    from alphadia_amd.distributed import slice_soa
+
+    sub = slice_soa(soa, 0, 6000)
+    exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=sub, n_threads=16, with_stats=True)
+    compare({k: v[:6000] for k, v in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"][:6000], exp["stat_matched_peaks"])
+    # (3) planted precursors at rank 0 are found with near-complete fragment evidence
+    planted = case.apex_cycle[soa["precursor_idx"]] >= 0
+    r0 = planted & (soa["rank"] == 0)
+    assert got["valid"][r0].mean() > 0.99
+    assert np.nanmean(got["features"][r0][:, 20]) > 0.9 > np.nanmean(got["features"][~planted][:, 20])

@@ -1,0 +1,186 @@
+"""CPU: host-side mirror of the reference interface (no kernels involved)."""
+
+import re
+import subprocess
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import helpers as H
+from alphadia_amd import _abi
+from alphadia_amd.scoring import (
+    DEFAULT_FEATURE_COLUMNS,
+    CandidateScoringConfig,
+    OutputPsmDF,
+    assemble_candidates,
+    calculate_score_groups,
+    collect_candidates,
+    collect_fragments,
+    merge_missing_columns,
+    multiplex_candidates,
+)
+
+
+def test_score_groups_kat():
+    # tests/unit_tests/search/scoring/test_scoring_utils.py:63-120
+    base = dict(
+        precursor_idx=np.arange(10),
+        elution_group_idx=np.array([0, 0, 0, 0, 0, 1, 1, 1, 1, 1]),
+        channel=np.array([0, 1, 2, 3, 0, 0, 1, 2, 3, 0]),
+        decoy=np.array([0, 0, 0, 0, 1, 0, 0, 0, 0, 1]),
+    )
+    assert np.allclose(calculate_score_groups(pd.DataFrame(base))["score_group_idx"], np.arange(10))
+    g = calculate_score_groups(pd.DataFrame(base), group_channels=True)
+    assert np.allclose(g["score_group_idx"], [0, 0, 0, 0, 1, 2, 2, 2, 2, 3])
+    with_rank = dict(base, rank=np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4]))
+    g = calculate_score_groups(pd.DataFrame(with_rank), group_channels=True)
+    assert np.allclose(g["score_group_idx"], np.arange(10))
+    df = pd.DataFrame(
+        dict(
+            precursor_idx=np.arange(10),
+            elution_group_idx=np.array([0, 0, 0, 0, 1, 1, 1, 1, 0, 0]),
+            channel=np.array([0, 0, 1, 1, 0, 0, 1, 1, 0, 0]),
+            decoy=np.array([0, 0, 0, 0, 0, 0, 0, 0, 1, 1]),
+            rank=np.array([0, 1, 0, 1, 0, 1, 0, 1, 0, 1]),
+        )
+    )
+    g = calculate_score_groups(df, group_channels=True)
+    assert np.allclose(g["score_group_idx"], [0, 0, 1, 1, 2, 3, 4, 4, 5, 5])
+
+
+def test_multiplex_candidates_kat():
+    # tests/unit_tests/search/scoring/test_scoring_utils.py:15-60
+    cand = pd.DataFrame(
+        {
+            "elution_group_idx": [0, 0, 1], "precursor_idx": [0, 1, 3], "proba": [0.1, 0.4, 0.3],
+            "rank": [0, 0, 0], "frame_start": [0, 0, 0], "frame_center": [0, 0, 0],
+            "frame_stop": [0, 0, 0], "scan_start": [0, 0, 0], "scan_stop": [0, 0, 0],
+            "scan_center": [0, 0, 0],
+        }
+    )
+    prec = pd.DataFrame(
+        {
+            "precursor_idx": [0, 1, 2, 3, 4, 5], "elution_group_idx": [0, 0, 0, 1, 1, 1],
+            "decoy": [0] * 6, "channel": [0, 4, 8, 0, 4, 8], "flat_frag_start_idx": [0] * 6,
+            "flat_frag_stop_idx": [0] * 6, "charge": [2] * 6, "rt_library": [0] * 6,
+            "mobility_library": [0] * 6, "mz_library": [0] * 6, "proteins": ["A"] * 6,
+            "genes": ["A"] * 6,
+        }
+    )
+    assert len(multiplex_candidates(cand, prec, channels=[])) == 0
+    m = multiplex_candidates(cand, prec, channels=[0, 4, 8])
+    assert m["precursor_idx"].tolist() == [0, 1, 2, 3, 4, 5]
+    assert np.allclose(m["proba"], [0.1, 0.1, 0.1, 0.3, 0.3, 0.3])
+
+
+def test_merge_missing_columns_kat():
+    left = pd.DataFrame([{"idx": 1, "col_1": 0, "col_2": 0}])
+    right = pd.DataFrame([{"idx": 1, "col_3": 0, "col_4": 0}])
+    with pytest.raises(ValueError):
+        merge_missing_columns(left, right, ["col_3"], on="idx_doesnt_exist")
+    with pytest.raises(ValueError):
+        merge_missing_columns(left, right, ["col_5"], on="idx")
+    df = merge_missing_columns(left, right, ["col_3"], on="idx")
+    assert list(df.columns) == ["idx", "col_1", "col_2", "col_3"]
+
+
+def test_assemble_candidates_order_matches_reference():
+    g = H.load_scoring_golden("handler_default")
+    shuffled = g.candidates_df.sample(frac=1.0, random_state=5).reset_index(drop=True)
+    soa = assemble_candidates(shuffled, g.library.precursor_df, "mz_library")
+    assert np.array_equal(soa["precursor_idx"], g.z["order_precursor_idx"])
+    assert np.array_equal(soa["rank"], g.z["order_rank"])
+    assert soa["isotope_intensity"].shape == (len(shuffled), 4)
+    assert soa["isotope_intensity"].dtype == np.float32 and soa["frame_start"].dtype == np.int64
+
+
+def test_assemble_candidates_errors_and_reference_channel():
+    g = H.load_scoring_golden("handler_default")
+    bad = g.candidates_df.copy()
+    bad.loc[0, "precursor_idx"] = 10_000_000
+    with pytest.raises(ValueError):
+        assemble_candidates(bad, g.library.precursor_df, "mz_library")
+    dup = pd.concat([g.candidates_df.iloc[:1], g.candidates_df.iloc[:1]])
+    with pytest.raises(ValueError, match="unique within a score group"):
+        assemble_candidates(dup, g.library.precursor_df, "mz_library", score_grouped=True)
+    # reference channel 4 never occurs -> every group is skipped (score_group.py:50-64)
+    soa = assemble_candidates(g.candidates_df, g.library.precursor_df, "mz_library", reference_channel=4)
+    assert (soa["flags"] == _abi.FLAG_SKIP).all()
+    soa = assemble_candidates(g.candidates_df, g.library.precursor_df, "mz_library", reference_channel=0)
+    assert (soa["flags"] == 0).all()
+
+
+def test_collect_frames_follow_reference_column_contract():
+    """Feed the reference's own OutputPsmDF (golden) through our collectors: the column
+    names/order and derived columns must equal what the reference produced."""
+    g = H.load_scoring_golden("handler_default")
+    psm = OutputPsmDF({k: v.copy() for k, v in g.expected.items()})
+    psm.valid = g.expected["valid"].astype(bool)
+    fdf = collect_candidates(
+        g.candidates_df, psm, g.library.precursor_df, "rt_library", "mobility_library", "mz_library"
+    )
+    assert list(fdf.columns[:46]) == DEFAULT_FEATURE_COLUMNS
+    assert sorted(fdf.columns) == sorted(g.z["features_df_columns"].tolist())
+    assert np.array_equal(fdf["precursor_idx"].values, g.z["features_df_precursor_idx"])
+    assert np.array_equal(fdf["rank"].values, g.z["features_df_rank"])
+    assert np.allclose(fdf["delta_rt"].values, g.z["features_df_delta_rt"], equal_nan=True)
+    assert (fdf["n_K"] == 1).all() and (fdf["n_P"] == 2).all() and (fdf["n_R"] == 0).all()
+    frdf = collect_fragments(psm, g.library.precursor_df)
+    assert list(frdf.columns) == g.z["fragments_df_columns"].tolist()
+    assert len(frdf) == int(g.z["fragments_df_n"])
+    assert np.array_equal(frdf["precursor_idx"].values, g.z["fragments_df_precursor_idx"])
+    assert np.array_equal(frdf["mz_observed"].values, g.z["fragments_df_mz_observed"])
+
+
+def test_config_update_and_validate():
+    cfg = CandidateScoringConfig()
+    # defaults of config.py:73-85
+    assert (cfg.top_k_fragments, cfg.top_k_isotopes, cfg.quant_window) == (12, 4, 3)
+    assert cfg.quant_all is False and cfg.experimental_xic is False and cfg.reference_channel == -1
+    cfg.update({"top_k_fragments": 9999, "precursor_mz_tolerance": 7.5, "quant_all": 1})
+    assert cfg.top_k_fragments == 9999 and cfg.precursor_mz_tolerance == 7 and cfg.quant_all is True
+    with pytest.raises(ValueError):
+        cfg.update({"does_not_exist": 1})
+    with pytest.raises(ValueError):
+        cfg.update({"top_k_fragments": "many"})
+    cfg.fragment_mz_tolerance = 500
+    with pytest.raises(AssertionError):
+        cfg.validate()
+    j = CandidateScoringConfig().to_jitclass()
+    assert j.precursor_mz_tolerance.dtype == np.float32 and j.top_k_fragments.dtype == np.uint32
+
+
+def test_candidate_hash_kat():
+    # tests/unit_tests/fragcomp/test_fragcomp.py:103-113
+    from alphadia_amd.fragcomp import candidate_hash
+
+    h = candidate_hash(np.array([1, 2, 1000000]), np.array([0, 1, 2]))
+    assert all(h == np.array([1, 4294967298, 8590934592])) and h.dtype == np.uint64
+
+
+def test_abi_header_symbols_are_exported():
+    """The C-ABI library loads and exports every function include/alphadia_hip.h declares."""
+    import os
+
+    from alphadia_amd import runtime
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "alphadia_hip.h")).read()
+    declared = set(re.findall(r"\b(adh_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 12
+    nm = subprocess.run(["nm", "-D", "--defined-only", runtime.LIB_PATH], capture_output=True, text=True)
+    exported = {line.split()[-1] for line in nm.stdout.splitlines() if line.strip()}
+    assert declared <= exported, declared - exported
+    assert declared == set(runtime.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(runtime.lib, name) is not None
+
+
+def test_abi_struct_sizes():
+    import ctypes as C
+
+    assert C.sizeof(_abi.ScoringConfig) == 44
+    assert C.sizeof(_abi.Output) == 8 + 8 + 19 * 8  # n, top_k(+pad), 19 pointers
+    assert C.sizeof(_abi.Candidates) == 8 + 14 * 8 + 8
+    assert C.sizeof(_abi.AlphaRaw) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8

@@ -1,0 +1,197 @@
+"""CPU: the oracle (oracle/adh_oracle.cpp) against golden vectors produced by running
+the REFERENCE itself (tests/golden/make_golden.py) and against the reference's own
+known-answer tests."""
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+PPM_FEATURES = [8, 9, 41, 42, 45]
+EXACT_FEATURES = [17, 20, 21, 28, 35, 37, 43]
+INT_TABLES = ("fragment_precursor_idx fragment_rank fragment_position fragment_number "
+              "fragment_type fragment_charge fragment_loss_type").split()
+
+
+def _compare(got, exp, ppm_tol, rel_tol, corr_abs):
+    assert np.array_equal(got["valid"].astype(bool), exp["valid"].astype(bool))
+    assert np.array_equal(got["precursor_idx"], exp["precursor_idx"])
+    assert np.array_equal(got["rank"], exp["rank"])
+    v = exp["valid"].astype(bool)
+    for name in INT_TABLES + ["fragment_mz_library", "fragment_mz"]:
+        assert np.array_equal(got[name][v], exp[name][v]), name
+    gf, ef = got["features"][v], exp["features"][v]
+    assert np.array_equal(np.isnan(gf), np.isnan(ef))
+    for f in EXACT_FEATURES:
+        assert np.array_equal(gf[:, f], ef[:, f]), f
+    for f in PPM_FEATURES:
+        assert np.nanmax(np.abs(gf[:, f].astype(np.float64) - ef[:, f])) <= ppm_tol, f
+    rest = [f for f in range(46) if f not in PPM_FEATURES]
+    err = H.rel_err(gf[:, rest], ef[:, rest])
+    err = np.where(np.abs(gf[:, rest].astype(np.float64) - ef[:, rest]) <= corr_abs, 0.0, err)
+    assert err.max() <= rel_tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    for name in ("fragment_mz_observed", "fragment_height", "fragment_intensity", "fragment_correlation"):
+        e = H.rel_err(got[name][v], exp[name][v])
+        e = np.where(np.abs(got[name][v].astype(np.float64) - exp[name][v]) <= corr_abs, 0.0, e)
+        assert e.max() <= rel_tol, name
+    d = np.abs(got["fragment_mass_error"][v].astype(np.float64) - exp["fragment_mass_error"][v])
+    assert d.max() <= ppm_tol
+
+
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6"])
+def test_oracle_numba_typing_vs_reference_goldens(oracle_lib, name):
+    """Production (Numba) typing vs goldens captured under NumPy typing: validity, every
+    integer table and the row order are exact; float features within 1e-4 relative except the
+    documented shim artefacts (ppm errors: float32 MS1 collapse / weight normalisation;
+    correlations: pairwise float32 sums), see tests/golden/ref_shim.py."""
+    g = H.load_scoring_golden(name)
+    got, soa = H.oracle_score(oracle_lib, g, g.config)
+    assert np.array_equal(soa["precursor_idx"], g.z["order_precursor_idx"])
+    assert np.array_equal(soa["rank"], g.z["order_rank"])
+    _compare(got, g.expected, ppm_tol=0.15, rel_tol=1e-4, corr_abs=1e-3)
+
+
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6"])
+def test_oracle_numpy_typing_pins_precursor_mass_errors(oracle_lib, name):
+    """With the three promotion sites switched to what the shim executed, the MS1 mass
+    error features agree to 1e-4 relative: the restatement itself is pinned."""
+    g = H.load_scoring_golden(name)
+    oracle_lib.set_numpy_typing(True)
+    try:
+        got, _ = H.oracle_score(oracle_lib, g, g.config)
+    finally:
+        oracle_lib.set_numpy_typing(False)
+    v = g.expected["valid"].astype(bool)
+    for f in (8, 9, 10):
+        e = H.rel_err(got["features"][v][:, f], g.expected["features"][v][:, f])
+        assert e.max() <= 1e-4, (f, e.max())
+    # single-observation candidates: fragment m/z is bit exact
+    single = v & (g.expected["features"][:, 17] == 1)
+    assert np.array_equal(got["fragment_mz_observed"][single], g.expected["fragment_mz_observed"][single])
+
+
+def test_get_dense_matches_reference(oracle_lib):
+    z = np.load(H.golden_path("get_dense_alpharaw.npz"))
+    dia = H.dia_from_npz(z)
+    n_hits = 0
+    for i in range(int(z["n_cases"])):
+        fl, quad = z[f"q{i}_frame_limits"], z[f"q{i}_quad"]
+        absolute = bool(z[f"q{i}_absolute"])
+        dense, pidx = oracle_lib.get_dense(
+            dia, fl[0, 0], fl[0, 1], z[f"q{i}_mz"], z[f"q{i}_tol"], quad[0, 0], quad[0, 1], absolute
+        )
+        e = z[f"q{i}_dense"]
+        assert dense.shape == e.shape
+        assert np.array_equal(pidx, z[f"q{i}_pidx"])
+        assert np.array_equal(dense[0], e[0]), f"intensity channel, case {i}"
+        if absolute:  # the channel the scoring path uses: bit exact
+            assert np.array_equal(dense[1], e[1]), f"m/z channel, case {i}"
+        else:  # ppm channel: Numba types `* 10**6` as float64, the shim ran it in float32
+            assert np.allclose(dense[1], e[1], rtol=0, atol=2e-3)
+        n_hits += int((e[0] > 0).sum())
+    assert n_hits > 100
+
+
+def test_fragcomp_matches_reference(oracle_lib):
+    import pandas as pd
+
+    from alphadia_amd.fragcomp import FragmentCompetition, add_frag_start_stop_idx, candidate_hash
+
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm_df = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag_df = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    psm_df["_candidate_idx"] = candidate_hash(psm_df["precursor_idx"].values, psm_df["rank"].values)
+    frag_df["_candidate_idx"] = candidate_hash(frag_df["precursor_idx"].values, frag_df["rank"].values)
+    psm_df = add_frag_start_stop_idx(psm_df, frag_df)
+    psm_df = FragmentCompetition._add_window_idx(psm_df, z["cycle"])
+    psm_df.sort_values(by=["window_idx", "proba", "precursor_idx"], inplace=True)
+    plan = FragmentCompetition._get_thread_plan_df(psm_df)
+    valid = oracle_lib.fragcomp(
+        plan["start_idx"].values, plan["stop_idx"].values, psm_df["rt_observed"].values,
+        psm_df["_frag_start_idx"].values, psm_df["_frag_stop_idx"].values,
+        frag_df["mz_observed"].values, 3, 15,
+    )
+    got = psm_df[valid]
+    assert np.array_equal(got["precursor_idx"].values, z["surviving_precursor_idx"])
+    assert np.array_equal(got["rank"].values, z["surviving_rank"])
+    assert 0 < len(got) < len(psm_df)
+
+
+# ---- known-answer tests of the reference, restated against the oracle ----------------
+
+@pytest.mark.parametrize(
+    "x, expected",
+    [  # tests/unit_tests/search/scoring/test_features.py:7-53
+        ([1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1]),
+        ([100, 10, 1, 1, 1, 10, 100], [1, 1, 1, 1, 1, 1, 1]),
+        ([100, 0, 0, 1, 0, 0, 100], [0, 0, 0, 1, 0, 0, 0]),
+        ([1, 1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1, 1]),
+        ([100, 10, 1, 1, 1, 1, 10, 100], [1, 1, 1, 1, 1, 1, 1, 1]),
+        ([100, 0, 0, 1, 1, 0, 0, 100], [0, 0, 0, 1, 1, 0, 0, 0]),
+    ],
+)
+def test_center_envelope_kat(oracle_lib, x, expected):
+    out = oracle_lib.center_envelope_1d(np.array([x], dtype=np.float32))
+    np.testing.assert_array_almost_equal(out, np.array([expected], dtype=np.float32))
+
+
+def test_center_envelope_rows_shrink_edges(oracle_lib):
+    rng = np.random.default_rng(3)
+    x = rng.random((10, 11)).astype(np.float32)
+    out = oracle_lib.center_envelope_1d(x)
+    assert np.all(out[:, 0] <= x[:, 0]) and np.all(out[:, -1] <= x[:, -1])
+
+
+def test_fragment_correlation_kat(oracle_lib):
+    # tests/unit_tests/search/scoring/test_scoring_utils.py:183-200
+    a = np.array([[[1, 2, 3], [1, 2, 3]], [[3, 2, 1], [1, 2, 3]], [[0, 0, 0], [0, 0, 0]]])
+    corr = oracle_lib.fragment_correlation(a)
+    assert corr.shape == (2, 3, 3)
+    expected = np.array(
+        [[[1.0, -1.0, 0.0], [-1.0, 1.0, 0.0], [0.0, 0.0, 0.0]],
+         [[1.0, 1.0, 0.0], [1.0, 1.0, 0.0], [0.0, 0.0, 0.0]]]
+    )
+    assert np.allclose(corr, expected)
+    assert np.allclose(oracle_lib.fragment_correlation(np.zeros((10, 10, 10))), 0)
+
+
+def test_save_corrcoeff_kat(oracle_lib):
+    # tests/unit_tests/search/scoring/test_scoring_utils.py:158-180
+    up = np.arange(1, 11, dtype=np.float32)
+    assert np.isclose(oracle_lib.save_corrcoeff(up, up[::-1].copy()), -1.0)
+    assert np.isclose(oracle_lib.save_corrcoeff(up, up), 1.0)
+    assert np.isclose(oracle_lib.save_corrcoeff(np.zeros(10), np.zeros(10)), 0.0)
+
+
+def test_search_sorted_left_kat(oracle_lib):
+    # tests/unit_tests/search/jitclasses/test_alpharaw_jit.py:6-9
+    assert oracle_lib.search_sorted_left(np.arange(100), 50) == 50
+
+
+def test_quadrupole_transfer_function_kat(oracle_lib):
+    # tests/unit_tests/search/scoring/test_quadrupole.py:59-79
+    fake_cycle = np.array([[780.0, 801], [801, 820]])
+    fake_cycle = np.repeat(fake_cycle[:, np.newaxis, :], 10, axis=1)[np.newaxis, :, :, :]
+    isotope_mz = np.array([800.0, 800.1, 800.2, 802.42944, 802.9311, 803.1])
+    qtf = oracle_lib.quadrupole_transfer_function(fake_cycle, np.array([0, 1]), np.arange(2, 9), isotope_mz)
+    assert qtf.shape == (6, 2, 7)
+    assert np.all(qtf[:3, 0, :] > 0.9) and np.all(qtf[:3, 1, :] < 0.1)
+    assert np.all(qtf[3:, 0, :] < 0.1) and np.all(qtf[3:, 1, :] > 0.9)
+
+
+def test_compete_for_fragments_kat(oracle_lib):
+    # tests/unit_tests/fragcomp/test_fragcomp.py:38-57
+    rt = np.array([10.0, 20.0, 20.0, 10.0, 10.0, 20])
+    valid = oracle_lib.fragcomp(
+        np.array([0, 3]), np.array([3, 6]), rt, np.array([0, 10, 20, 30, 40, 50]),
+        np.array([10, 20, 30, 40, 50, 60]), np.tile(np.arange(100, 110), 6), 3, 15,
+    )
+    assert np.all(valid == np.array([True, True, False, True, False, True]))
+
+
+def test_threads_do_not_change_results(oracle_lib):
+    g = H.load_scoring_golden("handler_default")
+    a, soa = H.oracle_score(oracle_lib, g, g.config, n_threads=1)
+    b, _ = H.oracle_score(oracle_lib, g, g.config, n_threads=4, soa=soa)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
