@@ -250,22 +250,36 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
 
-        cores = os.cpu_count() or 1
+        ncpu = os.cpu_count() or 1
         cols = fragment_columns(case.library.fragment_df, "mz_library")
-        probe = min(2000 * cores, n_local)
-        t0 = time.perf_counter()
-        oracle.score(case.dia, cols, pack_assembled(slice_soa(soa, 0, probe)), cfgj, n_threads=cores)
-        rate = probe / (time.perf_counter() - t0)
-        sample = int(min(n_local, max(probe, rate * args.cpu_seconds)))
+        # pick the thread count that is fastest on this host (memory-latency bound: more
+        # threads than memory channels x a few does not help)
+        best = (0.0, 1)
+        for th in sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)}):
+            probe = min(400 * th, n_local)
+            packed = pack_assembled(slice_soa(soa, 0, probe))
+            oracle.score(case.dia, cols, packed, cfgj, n_threads=th)
+            t0 = time.perf_counter()
+            oracle.score(case.dia, cols, packed, cfgj, n_threads=th, reuse=oracle.score.last_buffers)
+            rate = probe / (time.perf_counter() - t0)
+            log(f"[bench] cpu oracle {th:4d} threads: {rate:,.0f} candidates/s")
+            if rate > best[0]:
+                best = (rate, th)
+        rate, cores = best
+        sample = int(min(n_local, max(2000, rate * args.cpu_seconds)))
         sub = slice_soa(soa, 0, sample)
+        packed = pack_assembled(sub)
+        oracle.score(case.dia, cols, packed, cfgj, n_threads=cores)  # touches the output pages
         t0 = time.perf_counter()
-        exp = oracle.score(case.dia, cols, pack_assembled(sub), cfgj, n_threads=cores)
+        exp = oracle.score(case.dia, cols, packed, cfgj, n_threads=cores, reuse=oracle.score.last_buffers)
         dt = time.perf_counter() - t0
         cpu_prec = len(np.unique(sub["precursor_idx"]))
         same_valid = bool(np.array_equal(exp["valid"].astype(bool), valid[:sample]))
         fe, fg = exp["features"][exp["valid"].astype(bool)], host["features"][:sample][valid[:sample]] if same_valid else None
         max_rel = None
         if same_valid and fe.size:
+            keep = [f for f in range(46) if f not in (8, 9, 41, 42, 45)]  # ppm errors: absolute metric
+            fe, fg = fe[:, keep], fg[:, keep]
             d = np.abs(fe.astype(np.float64) - fg) / np.maximum(np.maximum(np.abs(fe), np.abs(fg)), 1e-6)
             d = np.where(np.isnan(fe) & np.isnan(fg), 0.0, d)
             max_rel = float(np.nanmax(d))
@@ -275,7 +289,8 @@ def main():
             "cores": cores,
             "kind": "port",
             "sample": f"first {sample} candidates ({cpu_prec} precursors) of the same batch, "
-                      f"{dt:.1f}s, OpenMP static stride over {cores} threads",
+                      f"{dt:.1f}s, OpenMP over {cores} threads (fastest of the thread counts tried "
+                      f"on this {ncpu}-thread host)",
             "valid_identical_to_gpu": same_valid,
             "max_rel_feature_diff_vs_gpu": max_rel,
         }

@@ -41,13 +41,23 @@ def lib():
     return _lib
 
 
-def score(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with_stats=False):
-    """Run the restated ``Candidate.process`` over a packed candidate table."""
+def score(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with_stats=False,
+          reuse=None):
+    """Run the restated ``Candidate.process`` over a packed candidate table.
+
+    ``reuse``: the ``(marshalled, arrays)`` pair of an earlier call with the same shape
+    (its pages are already touched; used when timing the CPU baseline)."""
     m_dia = _abi.pack_alpharaw(dia)
     m_frag = _abi.pack_fragments(*fragment_cols)
     cfg = _abi.pack_config(cfg_jit)
     n = int(cand_marshalled.struct.n)
-    m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+    if reuse is not None:
+        m_out, arrays = reuse
+        for a in arrays.values():
+            a.fill(0)
+    else:
+        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+    score.last_buffers = (m_out, arrays)
     rc = lib().adh_oracle_score(
         m_dia.ref(), m_frag.ref(), cand_marshalled.ref(), C.byref(cfg), m_out.ref(), C.c_int(n_threads)
     )
