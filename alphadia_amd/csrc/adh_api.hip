@@ -12,6 +12,7 @@
 
 #include "adh_gather.hip"
 #include "adh_features.hip"
+#include "adh_features_fast.hip"
 #include "adh_fragcomp.hip"
 
 namespace {
@@ -57,22 +58,27 @@ struct HostCands {
 struct Plan {
     bool ready = false;
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
+    bool fast_ok = false;          // class 0 runs through adh_feature_fast_kernel
     CandRec *d_recs = nullptr;
     unsigned char *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
-    int64_t n_class[2] = {0, 0};   // candidates with one / several observations
-    Caps caps_class[2];
+    // classes 0..2: register kernels for F <= 16 / 24 / 32; class 3: generic LDS kernel
+    int64_t n_class[4] = {0, 0, 0, 0};
+    Caps caps_generic;
     Caps caps_all;
 };
 
 struct adh_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // the generic feature kernel overlaps the register kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevRun run{};
     std::vector<double> h_cycle;    // host copy for planning
     const LibRec *d_lib = nullptr;
     int64_t n_lib = 0;
     const float *d_iso = nullptr;
+    double *d_wtp = nullptr;        // precursor weight table [2][64]
     HostCands hc;
     Plan plan;
     bool run_staged = false, lib_staged = false, cands_uploaded = false;
@@ -141,6 +147,16 @@ int adh_create(adh_handle_t **handle, int device) {
         delete h;
         return fail(ADH_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_wtp, 2 * 64 * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(adh_wtp_table_kernel, dim3(1), dim3(128), 0, h->stream, h->d_wtp);
     // the kernels may need more than the default 64 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)adh_feature_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -164,6 +180,10 @@ int adh_destroy(adh_handle_t *h) {
         (void)hipEventDestroy(p.e2);
     }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
+    if (h->d_wtp) (void)hipFree(h->d_wtp);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return ADH_OK;
@@ -368,7 +388,9 @@ namespace {
 // that concurrently resident wavefronts gather from the same few spectra.
 int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     Plan &p = h->plan;
-    if (p.ready && p.top_k_fragments == cfg->top_k_fragments && p.top_k_isotopes == cfg->top_k_isotopes)
+    const bool fast_cfg = cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST");
+    if (p.ready && p.top_k_fragments == cfg->top_k_fragments &&
+        p.top_k_isotopes == cfg->top_k_isotopes && p.fast_ok == fast_cfg)
         return ADH_OK;
     h->plan_buf.release();
     p = Plan();
@@ -383,9 +405,9 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     std::vector<CandRec> recs((size_t)n);
     std::vector<uint8_t> cls((size_t)n, 0);
     const int64_t n_cyc = h->run.n_spectra / L + 2;
-    std::vector<uint32_t> head[2];
-    head[0].assign((size_t)n_cyc + 1, 0);
-    head[1].assign((size_t)n_cyc + 1, 0);
+    const int NCLS = 4;
+    std::vector<uint32_t> head[NCLS];
+    for (int c = 0; c < NCLS; ++c) head[c].assign((size_t)n_cyc + 1, 0);
     for (int64_t i = 0; i < n; ++i) {
         CandRec &r = recs[(size_t)i];
         memset(&r, 0, sizeof(r));
@@ -404,7 +426,8 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         r.flags = hc.flags[i];
         r.row = (uint32_t)i;
         if (r.flags & ADH_FLAG_SKIP) {
-            ++head[0][1];  // parked in cycle bin 0 of class 0; the kernels return at once
+            cls[(size_t)i] = 3;
+            ++head[3][1];  // parked in cycle bin 0 of the generic class; the kernels return at once
             continue;
         }
         // isotope m/z range exactly as the kernels compute it (candidate.py:151-163,203-205)
@@ -427,25 +450,32 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         r.n_obs = (uint8_t)O;
         r.k_cap = (uint32_t)std::min<int64_t>((int64_t)cfg->top_k_fragments,
                                               (int64_t)r.frag_stop - (int64_t)r.frag_start);
-        cls[(size_t)i] = O > 1 ? 1 : 0;
+        {
+            // shape handled by the register-resident kernel (adh_features_fast.hip)
+            const int F = r.frame_stop / L - r.frame_start / L;
+            const bool fast = fast_cfg && O == 1 && F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
+            cls[(size_t)i] = !fast ? 3 : (F <= 16 ? 0 : (F <= 24 ? 1 : 2));
+        }
         ++head[cls[(size_t)i]][(size_t)(r.frame_start / L) + 1];
     }
     // counting sort by (class, first cycle)
-    for (int c = 0; c < 2; ++c)
+    size_t class_first[NCLS + 1] = {0};
+    for (int c = 0; c < NCLS; ++c) {
         for (int64_t k = 0; k < n_cyc; ++k) head[c][(size_t)k + 1] += head[c][(size_t)k];
-    p.n_class[0] = head[0][(size_t)n_cyc];
-    p.n_class[1] = head[1][(size_t)n_cyc];
+        p.n_class[c] = head[c][(size_t)n_cyc];
+        class_first[c + 1] = class_first[c] + (size_t)p.n_class[c];
+    }
     std::vector<CandRec> ordered((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         const CandRec &r = recs[(size_t)i];
         int c = cls[(size_t)i];
         size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)(r.frame_start / L);
-        size_t pos = (size_t)head[c][bin]++ + (c ? (size_t)p.n_class[0] : 0);
+        size_t pos = (size_t)head[c][bin]++ + class_first[c];
         ordered[pos] = r;
     }
     // scratch offsets + capacities
     Caps zero{1, 1, 1, std::max(I, 1), 1, 0};
-    p.caps_class[0] = p.caps_class[1] = p.caps_all = zero;
+    p.caps_generic = p.caps_all = zero;
     uint64_t off = 0;
     for (int64_t j = 0; j < n; ++j) {
         CandRec &r = ordered[(size_t)j];
@@ -454,16 +484,14 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         const int O = r.n_obs;
         r.scratch_off = off;
         off += adh_scratch_bytes(r.k_cap, O, std::max(F, 0), I);
-        Caps &cc = p.caps_class[j < p.n_class[0] ? 0 : 1];
-        cc.k = std::max<int32_t>(cc.k, (int32_t)r.k_cap);
-        cc.o = std::max<int32_t>(cc.o, O);
-        cc.f = std::max<int32_t>(cc.f, F);
-        cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
+        for (Caps *cc : {&p.caps_all, (size_t)j >= class_first[3] ? &p.caps_generic : (Caps *)nullptr}) {
+            if (!cc) continue;
+            cc->k = std::max<int32_t>(cc->k, (int32_t)r.k_cap);
+            cc->o = std::max<int32_t>(cc->o, O);
+            cc->f = std::max<int32_t>(cc->f, F);
+            cc->n_lib = std::max<int32_t>(cc->n_lib, (int32_t)(r.frag_stop - r.frag_start));
+        }
     }
-    p.caps_all.k = std::max(p.caps_class[0].k, p.caps_class[1].k);
-    p.caps_all.o = std::max(p.caps_class[0].o, p.caps_class[1].o);
-    p.caps_all.f = std::max(p.caps_class[0].f, p.caps_class[1].f);
-    p.caps_all.n_lib = std::max(p.caps_class[0].n_lib, p.caps_class[1].n_lib);
     p.scratch_bytes = std::max<uint64_t>(off, 32);
     const CandRec *d_recs = nullptr;
     UP(h->plan_buf, ordered.data(), n, &d_recs);
@@ -474,6 +502,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     p.d_scratch = static_cast<unsigned char *>(sp);
     p.top_k_fragments = cfg->top_k_fragments;
     p.top_k_isotopes = cfg->top_k_isotopes;
+    p.fast_ok = fast_cfg;
     p.ready = true;
     return ADH_OK;
 }
@@ -501,17 +530,14 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
 
     Caps gcaps = p.caps_all;
     const size_t g_lds = adh_gather_lds_bytes(gcaps);
-    size_t f_lds[2];
-    for (int c = 0; c < 2; ++c) {
-        p.caps_class[c].stop_phase = stop_phase;
-        f_lds[c] = adh_feature_lds_bytes(p.caps_class[c]);
-        if (p.n_class[c] > 0 && f_lds[c] > 160 * 1024) {
-            char buf[256];
-            snprintf(buf, sizeof(buf),
-                     "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB",
-                     f_lds[c], p.caps_class[c].k, p.caps_class[c].o, p.caps_class[c].f);
-            return fail(ADH_ERR_UNSUPPORTED, buf);
-        }
+    p.caps_generic.stop_phase = stop_phase;
+    const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
+    if (p.n_class[3] > 0 && f_lds > 160 * 1024) {
+        char buf[256];
+        snprintf(buf, sizeof(buf),
+                 "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", f_lds,
+                 p.caps_generic.k, p.caps_generic.o, p.caps_generic.f);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
     }
     if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice too long for the gather kernel");
 
@@ -527,16 +553,47 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(t.e1, st));
     if (stop_phase != 2) {
+        const int64_t first3 = p.n_class[0] + p.n_class[1] + p.n_class[2];
+        bool forked = false;
+        if (p.n_class[3] > 0) {
+            // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
+            hipStream_t gs = st;
+            if (first3 > 0) {
+                HIP_TRY(hipEventRecord(h->ev_fork, st));
+                HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                gs = h->side_stream;
+                forked = true;
+            }
+            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[3]), dim3(ADH_WAVE), f_lds,
+                               gs, h->run, p.d_recs + first3, h->d_iso, n_iso, *cfg, p.d_scratch, *out,
+                               p.caps_generic);
+            HIP_TRY(hipGetLastError());
+            if (forked) HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+        }
+        const unsigned per_block = ADH_WAVE / ADH_GS;
         int64_t first = 0;
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 3; ++c) {
             if (p.n_class[c] > 0) {
-                hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[c]), dim3(ADH_WAVE),
-                                   f_lds[c], st, h->run, p.d_recs + first, h->d_iso, n_iso, *cfg,
-                                   p.d_scratch, *out, p.caps_class[c]);
+                const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
+                const CandRec *recs = p.d_recs + first;
+                const int32_t nc = (int32_t)p.n_class[c];
+                if (c == 0)
+                    hipLaunchKernelGGL(adh_feature_fast_kernel<16>, dim3(blocks), dim3(ADH_WAVE), 0, st,
+                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
+                                       *out, (int32_t)stop_phase);
+                else if (c == 1)
+                    hipLaunchKernelGGL(adh_feature_fast_kernel<24>, dim3(blocks), dim3(ADH_WAVE), 0, st,
+                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
+                                       *out, (int32_t)stop_phase);
+                else
+                    hipLaunchKernelGGL(adh_feature_fast_kernel<32>, dim3(blocks), dim3(ADH_WAVE), 0, st,
+                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
+                                       *out, (int32_t)stop_phase);
                 HIP_TRY(hipGetLastError());
             }
             first += p.n_class[c];
         }
+        if (forked) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     }
     HIP_TRY(hipEventRecord(t.e2, st));
     h->timed.push_back(t);

@@ -22,6 +22,7 @@
 //     kernel agrees with the CPU restatement bit for bit wherever libm agrees
 //   * compile with -ffp-contract=off
 #include "adh_device.h"
+#include "adh_feature_common.h"
 
 namespace feat {
 
@@ -37,30 +38,6 @@ __device__ __forceinline__ void py_slice(int start, int stop, int n, int &a, int
 __device__ __forceinline__ double logistic(double x, double mu, double sigma) {
     double a = (x - mu) / sigma;
     return 1.0 / (1.0 + exp(-a));
-}
-
-// np.corrcoef(x, y)[0, 1] in float64 (sequential sums)
-__device__ double corrcoef01(const double *x, const float *y, int n) {
-    double sx = 0, sy = 0;
-    for (int i = 0; i < n; ++i) sx += x[i];
-    for (int i = 0; i < n; ++i) sy += (double)y[i];
-    double mx = sx / (double)n, my = sy / (double)n;
-    double cxx = 0, cyy = 0, cxy = 0;
-    for (int i = 0; i < n; ++i) {
-        double a = x[i] - mx, b = (double)y[i] - my;
-        cxx += a * a;
-        cyy += b * b;
-        cxy += a * b;
-    }
-    double fact = fmax((double)n - 1.0, 0.0);
-    double inv = 1.0 / fact;
-    cxx *= inv;
-    cyy *= inv;
-    cxy *= inv;
-    double s0 = sqrt(cxx), s1 = sqrt(cyy);
-    double c = cxy / s1 / s0;
-    if (fabs(c) > 1.0) c = (c > 0) ? 1.0 : -1.0;
-    return c;
 }
 
 // LDS regions.  Element counts depend only on the launch capacities.
@@ -537,173 +514,17 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     if (caps.stop_phase == 5) return;
 
     // ---- scalar feature assembly by lane 0 (short sequential float sums)
-    if (lane == 0) {
-        float *ft = featv;
-        ft[28] = (float)((double)n_present / (double)K0);  // candidate.py:362
-        // location_features.py:8-33
-        ft[0] = run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1];
-        ft[1] = run.rt[r.frame_stop - 1] - run.rt[r.frame_start];
-        ft[2] = run.rt[r.frame_center];
-        ft[3] = run.mobility[r.scan_center];
-
-        // precursor_features.py:13-102
-        int amax = 0;
-        for (int i = 1; i < I; ++i)
-            if (iso_int[i] > iso_int[amax]) amax = i;
-        float w4 = 0, w5 = 0, f6 = 0, f7 = 0;
-        for (int i = 0; i < I; ++i) {
-            float a = 0;
-            for (int o = 0; o < O; ++o) a += spi[i] * oi[o];
-            if (i == 0) w4 = a;
-            if (i == amax) w5 = a;
-            f6 += a;
-            f7 += a * iso_int[i];
-        }
-        ft[4] = w4;
-        ft[5] = w5;
-        ft[6] = f6;
-        ft[7] = f7;
-        double wme = 0;
-        for (int i = 0; i < I; ++i)
-            if (omzp[i] > 0) {
-                double me = (omzp[i] - (double)iso_mz[i]) / (double)iso_mz[i] * 1e6;
-                wme += me * (double)iso_int[i];
-            }
-        ft[8] = (float)wme;
-        ft[9] = (float)fabs(wme);
-        ft[10] = (float)((double)iso_mz[0] + wme * 1e-6 * (double)iso_mz[0]);
-        ft[11] = (float)hp[0];
-        ft[12] = (float)hp[amax];
-        {
-            double a = 0, b = 0;
-            for (int i = 0; i < I; ++i) a += hp[i];
-            for (int i = 0; i < I; ++i) b += hp[i] * (double)iso_int[i];
-            ft[13] = (float)a;
-            ft[14] = (float)b;
-        }
-        {
-            // save_corrcoeff (scoring/utils.py:478-510): (f32, f32) and (f32, f64)
-            float sx = 0, sy = 0;
-            double sh = 0;
-            for (int i = 0; i < I; ++i) sx += iso_int[i];
-            for (int i = 0; i < I; ++i) sy += spi[i];
-            for (int i = 0; i < I; ++i) sh += hp[i];
-            float xb = (float)((double)sx / (double)I), yb = (float)((double)sy / (double)I);
-            double hb = sh / (double)I;
-            float num = 0, sxx = 0, syy = 0;
-            for (int i = 0; i < I; ++i) num += (iso_int[i] - xb) * (spi[i] - yb);
-            for (int i = 0; i < I; ++i) sxx += (iso_int[i] - xb) * (iso_int[i] - xb);
-            for (int i = 0; i < I; ++i) syy += (spi[i] - yb) * (spi[i] - yb);
-            float den = sqrtf(sxx * syy);
-            ft[15] = (float)((double)num / ((double)den + 1e-12));
-            double numd = 0, shh = 0;
-            for (int i = 0; i < I; ++i) numd += (double)(iso_int[i] - xb) * (hp[i] - hb);
-            for (int i = 0; i < I; ++i) shh += (hp[i] - hb) * (hp[i] - hb);
-            double dend = sqrt((double)sxx * shh);
-            ft[16] = (float)(numd / (dend + 1e-12));
-        }
-
-        // fragment_features.py:198-427
-        ft[17] = (float)O;
-        int n_height_rows = 0;
-        for (int k = 0; k < K; ++k) {
-            int cnt = 0;
-            for (int o = 0; o < O; ++o) cnt += ohe[k * O + o] > 0;
-            n_height_rows += cnt > 0;
-        }
-        if (n_height_rows > 0) ft[18] = (float)corrcoef01(area, g_fin, K);
-        {
-            double sh = 0;
-            for (int k = 0; k < K; ++k) sh += height[k];
-            if (sh > 0.0) ft[19] = (float)corrcoef01(height, g_fin, K);
-        }
-        int n_int = 0, n_hei = 0;
-        float w_int = 0, w_hei = 0;
-        for (int k = 0; k < K; ++k)
-            if (obs_int[k] > 0.0f) {
-                ++n_int;
-                w_int += g_fin[k];
-            }
-        for (int k = 0; k < K; ++k)
-            if (height[k] > 0.0) {
-                ++n_hei;
-                w_hei += g_fin[k];
-            }
-        ft[20] = (float)((double)n_int / (double)K);
-        ft[21] = (float)((double)n_hei / (double)K);
-        ft[22] = w_int;
-        ft[23] = w_hei;
-        if (n_int > 0) {
-            // cosine_similarity_a1 (features_utils.py:40-47)
-            float tn = 0;
-            for (int o = 0; o < O; ++o) tn += tsum[o] * tsum[o];
-            tn = sqrtf(tn);
-            float acc = 0;
-            int cnt = 0;
-            for (int k = 0; k < K; ++k) {
-                if (!(obs_int[k] > 0.0f)) continue;
-                const float *rs = rowsum + kmap[k] * O;
-                float fn = 0, dot = 0;
-                for (int o = 0; o < O; ++o) fn += rs[o] * rs[o];
-                fn = sqrtf(fn);
-                for (int o = 0; o < O; ++o) dot += rs[o] * tsum[o];
-                float pr = fn * tn;
-                float score = (float)((double)dot / ((double)pr + 0.0001));
-                acc += score;
-                ++cnt;
-            }
-            ft[24] = (float)((double)acc / (double)cnt);
-        }
-        float sb = 0, sy = 0;
-        int nb = 0, ny = 0;
-        for (int k = 0; k < K; ++k)
-            if (g_type[k] == 98) {
-                sb += obs_int[k];
-                ++nb;
-            }
-        for (int k = 0; k < K; ++k)
-            if (g_type[k] == 121) {
-                sy += obs_int[k];
-                ++ny;
-            }
-        ft[25] = nb > 0 ? (float)log((double)sb + 1.0) : 0.0f;
-        ft[26] = ny > 0 ? (float)log((double)sy + 1.0) : 0.0f;
-        ft[27] = ft[25] - ft[26];
-        {
-            int n3 = min(K, 3);
-            double a = 0, b = 0;
-            for (int i = 0; i < n3; ++i) a += merr[ord[i]];
-            for (int k = 0; k < K; ++k) b += merr[k];
-            ft[41] = (float)(a / (double)n3);
-            ft[42] = (float)(b / (double)K);
-        }
-        if (nb > 0 && ny > 0) {
-            int min_y = 255, max_b = 0;
-            for (int k = 0; k < K; ++k) {
-                if (g_type[k] == 121) min_y = min(min_y, (int)g_pos[k]);
-                if (g_type[k] == 98) max_b = max(max_b, (int)g_pos[k]);
-            }
-            int n_ov = 0;
-            double sa = 0, se = 0;
-            for (int k = 0; k < K; ++k) {
-                bool ov = (g_type[k] == 121 && (int)g_pos[k] < max_b) ||
-                          (g_type[k] == 98 && (int)g_pos[k] > min_y);
-                if (ov) {
-                    ++n_ov;
-                    sa += area[k];
-                    se += merr[k];
-                }
-            }
-            ft[43] = (float)n_ov;
-            if (n_ov > 0) {
-                ft[44] = (float)(sa / (double)n_ov);
-                ft[45] = (float)(se / (double)n_ov);
-            } else {
-                ft[44] = 0.0f;
-                ft[45] = 15.0f;
-            }
-        }
-    }
+    Assemble asmv;
+    asmv.run = &run;
+    asmv.rec = &r;
+    asmv.featv = featv;
+    asmv.iso_int = iso_int; asmv.iso_mz = iso_mz; asmv.spi = spi; asmv.oi = oi; asmv.tsum = tsum;
+    asmv.rowsum = rowsum; asmv.g_fin = g_fin; asmv.g_int = g_int; asmv.obs_int = obs_int;
+    asmv.corr = corr; asmv.ftc = ftc; asmv.fw = fw; asmv.medpk = medpk;
+    asmv.omzp = omzp; asmv.hp = hp; asmv.ohe = ohe; asmv.area = area; asmv.height = height;
+    asmv.merr = merr; asmv.kmap = kmap; asmv.ord = ord; asmv.g_type = g_type; asmv.g_pos = g_pos;
+    asmv.n_present = n_present; asmv.K0 = K0; asmv.top3 = 0.0f;
+    if (lane == 0) assemble_part1(asmv, run, I, O, K);
     if (caps.stop_phase == 6) return;
 
     // =========================== profile features (profile_features.py:18-206)
@@ -903,54 +724,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     }
     __syncthreads();
     if (lane == 0) {
-        float *ft = featv;
-        float sm = 0;
-        for (int k = 0; k < K; ++k) sm += corr[k];
-        ft[31] = (float)((double)sm / (double)K);
-        ft[32] = top3;
-        float dot = 0;
-        for (int k = 0; k < K; ++k) {
-            float rr = 0;
-            for (int o = 0; o < O; ++o) rr += ftc[o * K + k] * oi[o];
-            dot += rr * g_int[k];
-        }
-        ft[33] = dot;
-        // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
-        int nbi = 0, nyi = 0;
-        float sbv = 0, syv = 0;
-        for (int k = 0; k < K; ++k) {
-            if (g_type[k] == 98) {
-                if (nbi < 3) sbv += corr[ord[k]];
-                ++nbi;
-            }
-        }
-        for (int k = 0; k < K; ++k) {
-            if (g_type[k] == 121) {
-                if (nyi < 3) syv += corr[ord[k]];
-                ++nyi;
-            }
-        }
-        if (nbi > 0) {
-            ft[34] = (float)((double)sbv / (double)min(nbi, 3));
-            ft[35] = (float)nbi;
-        }
-        if (nyi > 0) {
-            ft[36] = (float)((double)syv / (double)min(nyi, 3));
-            ft[37] = (float)nyi;
-        }
-        float agg = 0;
-        for (int k = 0; k < K; ++k) {
-            float ml = 0;
-            for (int o = 0; o < O; ++o) ml += fw[k * O + o] * oi[o];
-            agg += ml * g_int[k];
-        }
-        ft[38] = agg;
-        double acc = 0;
-        for (int o = 0; o < O; ++o) {
-            double delta = (double)medpk[o] - floor((double)F / 2.0);
-            acc += delta * (double)oi[o];
-        }
-        ft[40] = (float)acc;
+        asmv.top3 = top3;
+        assemble_part2(asmv, O, K, F);
     }
     __syncthreads();
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# kernel-trace summary of one bench run (GPU box, from repo root)
+export TMPDIR=/tmp
+REPO=$PWD
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp
+rm -rf $OUT/prof_stats
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o r1 -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+python $REPO/tools/rocpd_summary.py $OUT/prof_stats/r1_results.db | cut -c1-60,100-400 | grep -v "at::native" | head -12
