@@ -268,8 +268,8 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     r.n_buckets = nb;
     r.bucket_min = mz_lo;
     r.bucket_inv_width = (float)nb / span;
-    uint32_t *tab = nullptr;
-    size_t tbytes = (size_t)std::max<int64_t>(d->n_spectra, 1) * (size_t)(nb + 2) * sizeof(uint32_t);
+    uint2 *tab = nullptr;
+    size_t tbytes = (size_t)std::max<int64_t>(d->n_spectra, 1) * (size_t)(nb + 2) * sizeof(uint2);
     hipError_t e = hipMalloc((void **)&tab, tbytes);
     if (e != hipSuccess) {
         tmp.release();

@@ -4,8 +4,10 @@
 // HBM layout:
 //   peaks   float2[n_peaks]            (m/z, intensity) interleaved: a window hit needs no
 //                                      second dependent load
-//   tab     uint32[n_spectra][NB + 2]  per-spectrum m/z bucket table with ABSOLUTE peak
-//                                      offsets; entry NB + 1 is the end of the spectrum
+//   tab     uint2[n_spectra][NB + 2]   per-spectrum m/z bucket table: .x = ABSOLUTE offset of the
+//                                      first peak at/after the bucket, .y = that peak's m/z bits
+//                                      (most probes end after this one 8-byte load: no peak can
+//                                      be in the window); entry NB + 1 holds the spectrum end
 //   lib     LibRec[n_fragments]        32-byte fragment records (one vector load per lane)
 //   plan    CandRec[n_candidates]      80-byte candidate records in PROCESSING order
 //   scratch per-candidate blocks       selected fragments + XIC tile, written by the gather
@@ -21,7 +23,7 @@
 
 struct DevRun {
     const float2 *peaks;      // [n_peaks] (mz, intensity)
-    const uint32_t *tab;      // [n_spectra][n_buckets + 2]
+    const uint2 *tab;         // [n_spectra][n_buckets + 2]: (peak offset, m/z bits of that peak)
     const float *rt;          // [n_spectra]
     const float *mobility;    // [n_mobility]
     const double *cycle;      // [cycle_len * cycle_scans * 2]

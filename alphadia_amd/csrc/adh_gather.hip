@@ -31,7 +31,7 @@ constexpr int UNROLL = 4;
 struct Cell {
     uint32_t idx, pe;
     float2 p;
-    float lo, hi, excl;
+    float lo, hi, excl, first_mz;
     bool live;
 };
 
@@ -63,14 +63,19 @@ __device__ __forceinline__ void resolve(const DevRun &run, Cell &c, float &acc_i
 }
 
 __device__ __forceinline__ void issue_tab(const DevRun &run, Cell &c, int64_t spec) {
-    const uint32_t *t = run.tab + spec * (int64_t)(run.n_buckets + 2);
+    const uint2 *t = run.tab + spec * (int64_t)(run.n_buckets + 2);
     const int b = adh_bucket_of(c.lo, run.bucket_min, run.bucket_inv_width, run.n_buckets);
-    c.idx = t[b];
-    c.pe = t[run.n_buckets + 1];
+    const uint2 e = t[b];
+    c.idx = e.x;
+    c.first_mz = __uint_as_float(e.y);  // +inf when no peak at/after this bucket
+    c.pe = t[run.n_buckets + 1].x;
 }
 
 __device__ __forceinline__ void issue_peak(const DevRun &run, Cell &c) {
     c.p = make_float2(INFINITY, 0.0f);
+    // the table already knows the m/z of peaks[idx]: beyond the window -> nothing to gather,
+    // and no second sector has to be fetched
+    if (c.first_mz > c.hi) c.live = false;
     if (c.live && c.idx < c.pe) c.p = run.peaks[c.idx];
 }
 
@@ -264,16 +269,18 @@ __global__ void adh_interleave_kernel(const float *__restrict__ mz, const float 
 __global__ void adh_bucket_build_kernel(const float2 *__restrict__ peaks,
                                         const int64_t *__restrict__ pstart,
                                         const int64_t *__restrict__ pstop, int64_t n_spectra,
-                                        uint32_t *__restrict__ tab, int nb, float bmin, float binv) {
+                                        uint2 *__restrict__ tab, int nb, float bmin, float binv) {
     int64_t spec = blockIdx.x;
     if (spec >= n_spectra) return;
     const int64_t ps = pstart[spec], pe = pstop[spec];
-    uint32_t *t = tab + spec * (int64_t)(nb + 2);
+    uint2 *t = tab + spec * (int64_t)(nb + 2);
     const int64_t n = pe - ps;
     for (int64_t j = threadIdx.x; j <= n; j += blockDim.x) {
         int b_prev = (j == 0) ? -1 : adh_bucket_of(peaks[ps + j - 1].x, bmin, binv, nb);
         int b_cur = (j == n) ? nb : adh_bucket_of(peaks[ps + j].x, bmin, binv, nb);
-        for (int b = b_prev + 1; b <= b_cur; ++b) t[b] = (uint32_t)(ps + j);
+        const float mzj = (j == n) ? INFINITY : peaks[ps + j].x;
+        for (int b = b_prev + 1; b <= b_cur; ++b)
+            t[b] = make_uint2((uint32_t)(ps + j), __float_as_uint(mzj));
     }
-    if (threadIdx.x == 0) t[nb + 1] = (uint32_t)pe;
+    if (threadIdx.x == 0) t[nb + 1] = make_uint2((uint32_t)pe, __float_as_uint(INFINITY));
 }
