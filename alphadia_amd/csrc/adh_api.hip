@@ -519,7 +519,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
     HIP_TRY(hipSetDevice(h->device));
     if (h->hc.n == 0) return ADH_OK;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's default stream, taken literally
     int rc = build_plan(h, cfg);
     if (rc != ADH_OK) return rc;
     Plan &p = h->plan;
@@ -597,6 +597,12 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     }
     HIP_TRY(hipEventRecord(t.e2, st));
     h->timed.push_back(t);
+    return ADH_OK;
+}
+
+int adh_get_stream(adh_handle_t *h, void **hip_stream) {
+    if (!h || !hip_stream) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *hip_stream = (void *)h->stream;
     return ADH_OK;
 }
 
@@ -704,7 +710,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         e = hipMemsetAsync(p, 0, std::max<size_t>(fields[i].bytes, 1), h->stream);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
     }
-    if (rc == ADH_OK) rc = adh_score_uploaded(h, cfg, &dev, nullptr);
+    if (rc == ADH_OK) rc = adh_score_uploaded(h, cfg, &dev, (void *)h->stream);
     if (rc == ADH_OK) {
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess)

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "adh_score_candidates",
     "adh_upload_candidates",
     "adh_score_uploaded",
+    "adh_get_stream",
     "adh_synchronize",
     "adh_kernel_time_ms",
     "adh_fragcomp",
@@ -131,8 +132,16 @@ class Context:
         _check(lib.adh_upload_candidates(self._h, cands.ref()), "adh_upload_candidates")
         self.n_candidates = int(cands.struct.n)
 
+    def stream_handle(self) -> int:
+        """The context's own hipStream_t as an integer."""
+        p = C.c_void_p()
+        _check(lib.adh_get_stream(self._h, C.byref(p)), "adh_get_stream")
+        return p.value or 0
+
     def score_uploaded(self, cfg_jit, out_struct: _abi.Output, stream: int = 0) -> None:
-        """Enqueue scoring of the uploaded table into device buffers; does not synchronise."""
+        """Enqueue scoring of the uploaded table into device buffers on ``stream`` (a raw
+        hipStream_t; 0 = HIP's default stream); does not synchronise.  The caller must have
+        zeroed the buffers on the same stream."""
         cfg = _abi.pack_config(cfg_jit)
         _check(
             lib.adh_score_uploaded(self._h, C.byref(cfg), C.byref(out_struct), C.c_void_p(stream)),

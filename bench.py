@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--cycles", type=int, default=4800)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="debug: every rank uses cuda:0 (smoke-test the N>1 path on a 1-GPU box; "
+                         "needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,6 +101,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -104,7 +110,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from alphadia_amd import runtime, synthetic as syn
     from alphadia_amd.distributed import DeviceTables, all_gather_tables, shard_bounds, slice_soa
@@ -122,6 +131,10 @@ def main():
     case = syn.make_case(n_prec_total, args.cycles, config_id=2, per_precursor=3, threads=threads)
     log(f"[bench] synthetic run: {case.dia.n_spectra} spectra, {case.dia.mz_values.size/1e6:.1f}M peaks, "
         f"{len(case.candidates_df)} candidates, generated in {time.time()-t0:.1f}s ({threads} threads)")
+    if os.environ.get("ADH_BENCH_DEBUG"):
+        print(f"[debug] rank {rank} mz checksum {float(case.dia.mz_values[::1000].astype(np.float64).sum())} "
+              f"int checksum {float(case.dia.intensity_values[::1000].astype(np.float64).sum())} "
+              f"cand checksum {int(case.candidates_df['frame_start'].sum())}", file=sys.stderr, flush=True)
     cfg = CandidateScoringConfig()
     # ClassicExtractionHandler defaults (extraction_handler.py:370-376,400-409; default.yaml:158-199)
     cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1,
@@ -148,14 +161,17 @@ def main():
     n_rows = -(-len(soa_all["precursor_idx"]) // world)  # pad to the largest shard
     tables = DeviceTables(n_rows, int(cfgj.top_k_fragments), device, with_stats=True)
     out_struct = tables.as_output(n_local)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-default) torch stream carries the memset, the kernels and the collective
+    work_stream = torch.cuda.Stream(device=device)
+    stream = work_stream.cuda_stream
 
     def step():
-        tables.zero_()
-        ctx.score_uploaded(cfgj, out_struct, stream)
-        if world > 1:
-            return all_gather_tables(tables.buffer, world)
-        return tables.buffer
+        with torch.cuda.stream(work_stream):
+            tables.zero_()
+            ctx.score_uploaded(cfgj, out_struct, stream)
+            if world > 1:
+                return all_gather_tables(tables.buffer, world)
+            return tables.buffer
 
     def fence():
         torch.cuda.synchronize()
@@ -182,6 +198,7 @@ def main():
     # ---------------- results of the last step (sanity + roofline inputs) ----------------
     host = tables.to_host()
     valid = host["valid"][:n_local].astype(bool)
+    print(f"[bench] rank {rank}: {int(valid.sum())}/{n_local} candidates valid", file=sys.stderr, flush=True)
     matched = host["stat_matched_peaks"][:n_local]
     if world > 1:
         first = tables.to_host(gathered[0])

@@ -180,16 +180,21 @@ int adh_score_candidates(adh_handle_t *handle, const adh_candidates_t *candidate
 /*
  * The same work split so that tables can stay in HBM:
  *   adh_upload_candidates  - copy the candidate SoA to the GPU (kept in the handle)
- *   adh_score_uploaded     - enqueue the kernels on `hip_stream` (a hipStream_t;
- *                            NULL = the handle's own stream) writing into DEVICE
- *                            buffers `out_device` (zero-initialised by the caller,
- *                            on the handle's GPU); does not synchronise.
+ *   adh_score_uploaded     - enqueue the kernels on `hip_stream` (a hipStream_t taken
+ *                            literally: NULL is HIP's default stream; use
+ *                            adh_get_stream for the handle's own stream) writing into
+ *                            DEVICE buffers `out_device` (zero-initialised by the
+ *                            caller ON THAT STREAM, on the handle's GPU); does not
+ *                            synchronise.
  * Used when the per-GPU tables are reassembled with an RCCL all-gather before
  * they leave HBM.
  */
 int adh_upload_candidates(adh_handle_t *handle, const adh_candidates_t *candidates);
 int adh_score_uploaded(adh_handle_t *handle, const adh_scoring_config_t *config,
                        adh_output_t *out_device, void *hip_stream);
+
+/* The handle's own (non-blocking) stream as a hipStream_t. */
+int adh_get_stream(adh_handle_t *handle, void **hip_stream);
 
 /* Block until all work enqueued on the handle's stream has finished. */
 int adh_synchronize(adh_handle_t *handle);
