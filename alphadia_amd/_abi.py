@@ -36,6 +36,25 @@ class AlphaRaw(C.Structure):
     ]
 
 
+class TimsTOF(C.Structure):
+    _fields_ = [
+        ("cycle", _f64p),
+        ("cycle_len", C.c_int32),
+        ("scan_max_index", C.c_int32),
+        ("dia_precursor_cycle", _i64p),
+        ("rt_values", _f64p),
+        ("n_frames", C.c_int64),
+        ("mobility_values", _f64p),
+        ("mz_values", _f64p),
+        ("n_tof", C.c_int64),
+        ("tof_indptr", _i64p),
+        ("push_indices", _u32p),
+        ("intensity_values", C.POINTER(C.c_uint16)),
+        ("n_events", C.c_int64),
+        ("zeroth_frame", C.c_int32),
+    ]
+
+
 class Fragments(C.Structure):
     _fields_ = [
         ("n", C.c_int64),
@@ -199,6 +218,33 @@ def pack_alpharaw(dia) -> Marshalled:
         mz.shape[0],
     )
     return Marshalled(s, [cycle, rt, mob, ps, pe, mz, it])
+
+
+def pack_timstof(dia) -> Marshalled:
+    """``dia`` exposes the TimsTOFTransposeJIT field names (bruker_jit.py:22-137)."""
+    cycle = as_c(dia.cycle, np.float64)
+    if cycle.ndim != 4 or cycle.shape[0] != 1 or cycle.shape[3] != 2:
+        raise ValueError("cycle must have shape (1, n_frames_per_cycle, n_scans, 2)")
+    if cycle.shape[2] != int(dia.scan_max_index):
+        raise ValueError("cycle scan axis must equal scan_max_index")
+    dpc = as_c(dia.dia_precursor_cycle, np.int64)
+    rt = as_c(dia.rt_values, np.float64)
+    mob = as_c(dia.mobility_values, np.float64)
+    mz = as_c(dia.mz_values, np.float64)
+    ptr = as_c(dia.tof_indptr, np.int64)
+    push = as_c(dia.push_indices, np.uint32)
+    inten = np.ascontiguousarray(dia.intensity_values, dtype=np.uint16)
+    if dpc.shape[0] != cycle.shape[1] * cycle.shape[2]:
+        raise ValueError("dia_precursor_cycle must have one entry per (frame, scan) of the cycle")
+    if ptr.shape[0] != mz.shape[0] + 1 or push.shape != inten.shape:
+        raise ValueError("inconsistent TOF index arrays")
+    s = TimsTOF(
+        _ptr(cycle, C.c_double), cycle.shape[1], cycle.shape[2], _ptr(dpc, C.c_int64),
+        _ptr(rt, C.c_double), rt.shape[0], _ptr(mob, C.c_double), _ptr(mz, C.c_double), mz.shape[0],
+        _ptr(ptr, C.c_int64), _ptr(push, C.c_uint32), inten.ctypes.data_as(C.POINTER(C.c_uint16)),
+        push.shape[0], int(bool(dia.zeroth_frame)),
+    )
+    return Marshalled(s, [cycle, dpc, rt, mob, mz, ptr, push, inten])
 
 
 def pack_fragments(mz_library, mz, intensity, type_, loss_type, charge, number, position, cardinality):

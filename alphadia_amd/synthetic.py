@@ -479,3 +479,219 @@ def make_case(
         even_fraction=even_fraction,
     )
     return SyntheticCase(dia, lib, cands, planted.apex_cycle)
+
+
+# --------------------------------------------------------------------------- timsTOF-style run
+@dataclass
+class TimsTOFArrays:
+    """Host arrays of an ion-mobility run in the transposed (TOF-major) layout.
+
+    Field names follow ``TimsTOFTransposeJIT``
+    (alphadia/search/jitclasses/bruker_jit.py:22-137): for every TOF index the detector
+    events are listed as (push index, intensity) with push = frame * scan_max_index + scan,
+    ascending inside a TOF bin.
+    """
+
+    cycle: np.ndarray  # float64 (1, L, scan_max_index, 2); (-1, -1) = unfragmented
+    dia_precursor_cycle: np.ndarray  # int64 [L * scan_max_index]: cycle row of every push
+    rt_values: np.ndarray  # float64 [n_frames]
+    mobility_values: np.ndarray  # float64 [scan_max_index], descending
+    mz_values: np.ndarray  # float64 [n_tof], ascending
+    tof_indptr: np.ndarray  # int64 [n_tof + 1]
+    push_indices: np.ndarray  # uint32 [n_events]
+    intensity_values: np.ndarray  # uint16 [n_events]
+    scan_max_index: int
+    zeroth_frame: bool = True
+    has_mobility: bool = True
+
+    @property
+    def cycle_len(self) -> int:
+        return int(self.cycle.shape[1])
+
+    @property
+    def frame_max_index(self) -> int:
+        return int(self.rt_values.shape[0]) - 1
+
+    @property
+    def n_cycles(self) -> int:
+        return (int(self.rt_values.shape[0]) - int(self.zeroth_frame)) // self.cycle_len
+
+    @property
+    def dia_mz_cycle(self) -> np.ndarray:
+        return self.cycle.reshape(-1, 2)
+
+
+def make_timstof_cycle(n_ms2_frames: int, windows_per_frame: int, scan_max_index: int,
+                       mz_lo: float, mz_hi: float, uncovered_scans: int = 2) -> np.ndarray:
+    """diaPASEF-like cycle: frame 0 = MS1 (all scans -1), every MS2 frame carries
+    ``windows_per_frame`` isolation windows stacked over scan ranges."""
+    L = n_ms2_frames + 1
+    cycle = np.full((1, L, scan_max_index, 2), -1.0, dtype=np.float64)
+    n_win = n_ms2_frames * windows_per_frame
+    edges = np.linspace(mz_lo, mz_hi, n_win + 1)
+    usable = scan_max_index - uncovered_scans
+    bounds = np.linspace(0, usable, windows_per_frame + 1).astype(int)
+    w = 0
+    for j in range(windows_per_frame):
+        for fr in range(1, L):
+            # high m/z at low scan numbers (high mobility), like real diaPASEF schemes
+            cycle[0, fr, bounds[j] : bounds[j + 1], 0] = edges[n_win - 1 - w]
+            cycle[0, fr, bounds[j] : bounds[j + 1], 1] = edges[n_win - w]
+            w += 1
+    return cycle
+
+
+@dataclass
+class TimsTOFCase:
+    dia: TimsTOFArrays
+    library: SyntheticLibrary
+    candidates_df: pd.DataFrame
+
+
+def make_timstof_case(
+    n_precursors: int = 200,
+    n_cycles: int = 40,
+    config_id: int = 4,
+    per_precursor: int = 2,
+    n_ms2_frames: int = 4,
+    windows_per_frame: int = 2,
+    scan_max_index: int = 64,
+    n_tof: int = 60000,
+    events_per_push: float = 40.0,
+    tof_mz_lo: float = 195.0,
+    tof_mz_hi: float = 490.0,
+    mz_lo: float = 400.0,
+    mz_hi: float = 480.0,
+    frag_mz_lo: float = 200.0,
+    frag_mz_hi: float = 350.0,
+    planted_fraction: float = 0.5,
+    seed: int | None = None,
+) -> TimsTOFCase:
+    """Run "B" of SURVEY.md section 8(d) at a configurable (test) scale."""
+    seed = BASE_SEED + config_id if seed is None else seed
+    rng = np.random.default_rng([seed, 7])
+    cycle = make_timstof_cycle(n_ms2_frames, windows_per_frame, scan_max_index, mz_lo, mz_hi)
+    L = cycle.shape[1]
+    S = scan_max_index
+    n_frames = n_cycles * L + 1  # frame 0 is alphatims' empty zeroth frame
+    rt = np.arange(n_frames, dtype=np.float64) * 0.1
+    mobility = np.linspace(1.6, 0.6, S).astype(np.float64)
+    # quadratic TOF -> m/z, spanning fragments and precursors
+    t = np.arange(n_tof, dtype=np.float64)
+    mz_table = (np.sqrt(tof_mz_lo) + t * (np.sqrt(tof_mz_hi) - np.sqrt(tof_mz_lo)) / (n_tof - 1)) ** 2
+
+    lib = make_library(n_precursors, seed, mz_lo=mz_lo, mz_hi=mz_hi, rt_max=float(rt[-1]),
+                       frag_mz_lo=frag_mz_lo, frag_mz_hi=frag_mz_hi)
+    pdf, fdf = lib.precursor_df, lib.fragment_df
+    pdf["mobility_library"] = rng.uniform(0.7, 1.5, n_precursors).astype(np.float32)
+
+    # ---- noise events
+    n_push = n_frames * S
+    n_noise = rng.poisson(events_per_push * (n_push - S))
+    ev_push = rng.integers(S, n_push, n_noise).astype(np.int64)
+    ev_tof = rng.integers(0, n_tof, n_noise).astype(np.int64)
+    ev_int = np.clip(rng.lognormal(3.0, 1.0, n_noise), 1, 60000).astype(np.int64)
+
+    # ---- planted peptides: Gaussian in cycle and in scan
+    targets = np.flatnonzero(pdf["decoy"].values == 0)
+    chosen = targets[rng.random(targets.size) < planted_fraction]
+    apex_cycle = np.full(n_precursors, -1, dtype=np.int64)
+    apex_scan = np.full(n_precursors, -1, dtype=np.int64)
+    apex_cycle[chosen] = rng.integers(8, max(9, n_cycles - 8), chosen.size)
+    pp, pt, pi_ = [], [], []
+    flat_cycle = cycle.reshape(-1, 2)
+    for p in chosen:
+        pmz = float(pdf["mz_library"].values[p])
+        charge = float(pdf["charge"].values[p])
+        # a (frame, scan) cell whose window contains the precursor decides the apex scan
+        rows = np.flatnonzero((flat_cycle[:, 0] <= pmz) & (flat_cycle[:, 1] > pmz))
+        if rows.size == 0:
+            apex_cycle[p] = -1
+            continue
+        r0 = int(rng.choice(rows))
+        fr_in_cycle, sc0 = divmod(r0, S)
+        apex_scan[p] = sc0
+        for dc in range(-6, 7):
+            c = int(apex_cycle[p]) + dc
+            if c < 0 or c >= n_cycles:
+                continue
+            gc = np.exp(-0.5 * (dc / 2.0) ** 2)
+            for ds in range(-5, 6):
+                sc = sc0 + ds
+                if sc < 0 or sc >= S:
+                    continue
+                g = gc * np.exp(-0.5 * (ds / 1.8) ** 2)
+                # isotopes in the MS1 frame of the cycle
+                push1 = (c * L + 1) * S + sc
+                for i in range(3):
+                    mzv = (pmz + i * ISOTOPE_DELTA / charge) * (1 + rng.normal(2e-6, 1e-6))
+                    amp = 3000.0 * float(pdf[f"i_{i}"].values[p]) * g
+                    if amp >= 1:
+                        pp.append(push1)
+                        pt.append(int(np.searchsorted(mz_table, mzv)))
+                        pi_.append(int(amp))
+                # fragments in every MS2 frame row of this scan that isolates the precursor
+                for fr in range(1, L):
+                    lo, hi = cycle[0, fr, sc]
+                    if lo <= pmz < hi:
+                        push2 = (c * L + 1 + fr) * S + sc
+                        a, b = int(pdf["flat_frag_start_idx"].values[p]), int(pdf["flat_frag_stop_idx"].values[p])
+                        for k in range(a, b):
+                            mzv = float(fdf["mz_library"].values[k]) * (1 + rng.normal(2e-6, 1e-6))
+                            amp = 1500.0 * float(fdf["intensity"].values[k]) * g
+                            if amp >= 1:
+                                pp.append(push2)
+                                pt.append(int(np.searchsorted(mz_table, mzv)))
+                                pi_.append(int(amp))
+    if pp:
+        ev_push = np.concatenate([ev_push, np.array(pp, dtype=np.int64)])
+        ev_tof = np.concatenate([ev_tof, np.clip(np.array(pt, dtype=np.int64), 0, n_tof - 1)])
+        ev_int = np.concatenate([ev_int, np.clip(np.array(pi_, dtype=np.int64), 1, 60000)])
+    order = np.lexsort((ev_push, ev_tof))
+    ev_push, ev_tof, ev_int = ev_push[order], ev_tof[order], ev_int[order]
+    tof_indptr = np.concatenate([[0], np.cumsum(np.bincount(ev_tof, minlength=n_tof))]).astype(np.int64)
+
+    dia = TimsTOFArrays(
+        cycle=cycle,
+        dia_precursor_cycle=np.repeat(np.arange(L, dtype=np.int64), S),
+        rt_values=rt,
+        mobility_values=mobility,
+        mz_values=mz_table,
+        tof_indptr=tof_indptr,
+        push_indices=ev_push.astype(np.uint32),
+        intensity_values=ev_int.astype(np.uint16),
+        scan_max_index=S,
+    )
+
+    # ---- candidates: rank 0 on the planted apex, boxes of 5-21 cycles x 6-24 scans
+    C = per_precursor
+    n = n_precursors * C
+    pidx = np.repeat(pdf["precursor_idx"].values.astype(np.uint32), C)
+    rank = np.tile(np.arange(C, dtype=np.uint8), n_precursors)
+    h = rng.integers(2, 11, n)
+    cc = rng.integers(0, n_cycles, n)
+    ap = np.repeat(apex_cycle, C)
+    use = (ap >= 0) & (rank == 0)
+    cc = np.where(use, ap, cc)
+    cc = np.clip(cc, h, n_cycles - h - 1)
+    even = rng.random(n) < 0.3
+    c_stop = cc + h + 1 - even.astype(np.int64)
+    hs = rng.integers(3, 13, n)
+    sc = rng.integers(0, S, n)
+    sc = np.where(use, np.repeat(np.maximum(apex_scan, 0), C), sc)
+    sc = np.clip(sc, hs, S - hs - 1)
+    cands = pd.DataFrame(
+        {
+            "elution_group_idx": np.repeat(pdf["elution_group_idx"].values.astype(np.uint32), C),
+            "precursor_idx": pidx,
+            "rank": rank,
+            "scan_start": (sc - hs).astype(np.int64),
+            "scan_stop": (sc + hs).astype(np.int64),
+            "scan_center": sc.astype(np.int64),
+            "frame_start": ((cc - h) * L + 1).astype(np.int64),
+            "frame_stop": (c_stop * L + 1).astype(np.int64),
+            "frame_center": (cc * L + 1).astype(np.int64),
+            "score": rng.uniform(0, 100, n).astype(np.float32),
+        }
+    )
+    return TimsTOFCase(dia, lib, cands)

@@ -58,6 +58,28 @@ typedef struct adh_alpharaw {
 } adh_alpharaw_t;
 
 /*
+ * Raw data of an ion-mobility run in the transposed (TOF-major) layout: the fields of
+ * TimsTOFTransposeJIT (search/jitclasses/bruker_jit.py:22-137) that the scoring path reads.
+ * push index = frame * scan_max_index + scan; events are ascending in push inside a TOF bin.
+ */
+typedef struct adh_timstof {
+    const double *cycle;                /* (1, cycle_len, scan_max_index, 2) float64 */
+    int32_t cycle_len;
+    int32_t scan_max_index;
+    const int64_t *dia_precursor_cycle; /* [cycle_len * scan_max_index] cycle row of a push */
+    const double *rt_values;            /* [n_frames] */
+    int64_t n_frames;
+    const double *mobility_values;      /* [scan_max_index] */
+    const double *mz_values;            /* [n_tof] m/z of a TOF index, ascending */
+    int64_t n_tof;
+    const int64_t *tof_indptr;          /* [n_tof + 1] */
+    const uint32_t *push_indices;       /* [n_events] */
+    const uint16_t *intensity_values;   /* [n_events] */
+    int64_t n_events;
+    int32_t zeroth_frame;               /* 1 when frame 0 is the empty alphatims frame */
+} adh_timstof_t;
+
+/*
  * Flat fragment library: the nine arrays of FragmentContainer
  * (search/jitclasses/fragment_container.py:11-46) as assembled by
  * CandidateScoring.assemble_fragments (search/scoring/scoring.py:355-392).

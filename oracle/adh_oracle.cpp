@@ -198,6 +198,109 @@ void get_dense_alpharaw(const adh_alpharaw_t &d, int64_t frame_start, int64_t fr
     }
 }
 
+/* view of either run layout; typing of rt / mobility differs (float32 in AlphaRawJIT,
+ * float64 in TimsTOFTransposeJIT: alpharaw_jit.py:82-83 vs bruker_jit.py:35,45) */
+struct RunView {
+    const adh_alpharaw_t *ar = nullptr;
+    const adh_timstof_t *tt = nullptr;
+    bool im() const { return tt != nullptr; }
+    const double *cycle() const { return ar ? ar->cycle : tt->cycle; }
+    int cycle_len() const { return ar ? ar->cycle_len : tt->cycle_len; }
+    int cycle_scans() const { return ar ? ar->cycle_scans : tt->scan_max_index; }
+    int zeroth() const { return ar ? 0 : tt->zeroth_frame; }
+    /* differences computed in the array's own precision, then widened */
+    double rt_diff(int64_t a, int64_t b) const {
+        return ar ? (double)(float)(ar->rt_values[a] - ar->rt_values[b]) : tt->rt_values[a] - tt->rt_values[b];
+    }
+    double rt(int64_t i) const { return ar ? (double)ar->rt_values[i] : tt->rt_values[i]; }
+    double mob_diff(int64_t a, int64_t b) const {
+        return ar ? (double)(float)(ar->mobility_values[a] - ar->mobility_values[b])
+                  : tt->mobility_values[a] - tt->mobility_values[b];
+    }
+    double mob(int64_t i) const { return ar ? (double)ar->mobility_values[i] : tt->mobility_values[i]; }
+};
+
+/* TimsTOFTransposeJIT.get_dense, bruker_jit.py:273-504,586-615 (absolute_masses=True) */
+void get_dense_timstof(const adh_timstof_t &d, int64_t frame_start, int64_t frame_stop,
+                       int64_t scan_start, int64_t scan_stop, const float *mzq, int K, float tol,
+                       double q_lo, double q_hi, Dense &out, std::vector<int64_t> &pidx,
+                       uint32_t *matched) {
+    const double HIGH_EPSILON = 1e-26, LOW_EPSILON = 1e-36;
+    const int64_t S_max = d.scan_max_index, L = d.cycle_len;
+    /* tof limits: searchsorted(mz_values, mass_range(...), 'left') */
+    std::vector<int64_t> t0(K), t1(K);
+    for (int k = 0; k < K; ++k) {
+        float t = tol * mzq[k];
+        float q = t / 1000000.0f;
+        double lo = (double)(float)(mzq[k] - q), hi = (double)(float)(mzq[k] + q);
+        t0[k] = std::lower_bound(d.mz_values, d.mz_values + d.n_tof, lo) - d.mz_values;
+        t1[k] = std::lower_bound(d.mz_values, d.mz_values + d.n_tof, hi) - d.mz_values;
+    }
+    /* _cycle_mask + _get_push_indices */
+    const int64_t rows = L * S_max;
+    std::vector<uint8_t> mask((size_t)rows);
+    for (int64_t r = 0; r < rows; ++r)
+        mask[(size_t)r] = (q_lo <= d.cycle[2 * r + 1]) && (q_hi >= d.cycle[2 * r]);
+    std::vector<uint32_t> pq;
+    std::vector<int64_t> prec;
+    for (int64_t fr = frame_start; fr < frame_stop; ++fr)
+        for (int64_t sc = scan_start; sc < scan_stop; ++sc) {
+            int64_t push = fr * S_max + sc;
+            int64_t cyc = d.zeroth_frame ? push - S_max : push;
+            int64_t row = ((cyc % rows) + rows) % rows;
+            if (mask[(size_t)row]) {
+                pq.push_back((uint32_t)push);
+                prec.push_back(d.dia_precursor_cycle[row]);
+            }
+        }
+    pidx.clear();
+    if (prec.empty()) {
+        out.init(0, 0, 0, 0);
+        return;
+    }
+    pidx = prec;
+    std::sort(pidx.begin(), pidx.end());
+    pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
+    std::vector<int> rel(prec.size());
+    for (size_t i = 0; i < prec.size(); ++i)
+        rel[i] = (int)(std::lower_bound(pidx.begin(), pidx.end(), prec[i]) - pidx.begin());
+    const int O = (int)pidx.size();
+    const int S = (int)(scan_stop - scan_start);
+    const int64_t c0 = (frame_start - d.zeroth_frame) / L, c1 = (frame_stop - d.zeroth_frame) / L;
+    const int F = (int)std::max<int64_t>(c1 - c0, 0);
+    out.init(K, O, S, F);
+    for (int j = 0; j < K; ++j) {
+        for (int64_t tof = t0[j]; tof < t1[j]; ++tof) {
+            const double measured = d.mz_values[tof];
+            int64_t idx = d.tof_indptr[tof];
+            const int64_t stop = d.tof_indptr[tof + 1];
+            size_t i = 0;
+            while (idx < stop && i < pq.size()) {
+                if (pq[i] < d.push_indices[idx]) {
+                    ++i;
+                } else {
+                    if (pq[i] == d.push_indices[idx]) {
+                        int64_t frame = d.push_indices[idx] / S_max, scan = d.push_indices[idx] % S_max;
+                        int cyc = (int)((frame - d.zeroth_frame) / L - c0);
+                        int rs = (int)(scan - scan_start);
+                        float acc_int = out.at(0, j, rel[i], rs, cyc);
+                        float acc_d1 = out.at(1, j, rel[i], rs, cyc);
+                        int64_t ni = d.intensity_values[idx];
+                        ni = ni * ((double)ni > HIGH_EPSILON ? 1 : 0);
+                        float a = acc_d1 * acc_int;
+                        double num = (double)a + (double)ni * measured + LOW_EPSILON;
+                        double den = ((double)acc_int + (double)ni) + LOW_EPSILON;
+                        out.at(1, j, rel[i], rs, cyc) = (float)(num / den);
+                        out.at(0, j, rel[i], rs, cyc) = (float)((double)acc_int + (double)ni);
+                        if (matched) ++*matched;
+                    }
+                    ++idx;
+                }
+            }
+        }
+    }
+}
+
 /* ----------------------------------------------------------- small kernels */
 
 /* features_utils.py:9-25 weighted_center_mean on one (S,F) plane of a tile */
@@ -422,7 +525,7 @@ struct CandIn {
 };
 
 /* Candidate.process, candidate.py:166-481.  Returns true when valid. */
-bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, const CandIn &c,
+bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const CandIn &c,
                        const adh_scoring_config_t &cfg, int64_t row, adh_output_t &out) {
     const int top_k = out.top_k;
     out.precursor_idx[row] = c.precursor_idx;
@@ -467,14 +570,23 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
     Dense df;
     std::vector<int64_t> frag_pidx, prec_pidx;
     uint32_t matched = 0;
-    get_dense_alpharaw(d, c.frame_start, c.frame_stop, fr.mz.data(), K, cfg.fragment_mz_tolerance,
-                       (double)q_lo, (double)q_hi, true, df, frag_pidx, &matched);
+    if (rv.im())
+        get_dense_timstof(*rv.tt, c.frame_start, c.frame_stop, c.scan_start, c.scan_stop, fr.mz.data(), K,
+                          cfg.fragment_mz_tolerance, (double)q_lo, (double)q_hi, df, frag_pidx, &matched);
+    else
+        get_dense_alpharaw(*rv.ar, c.frame_start, c.frame_stop, fr.mz.data(), K, cfg.fragment_mz_tolerance,
+                           (double)q_lo, (double)q_hi, true, df, frag_pidx, &matched);
+    if (df.v.empty() && df.F == 0) return false; /* candidate.py:230 (also the empty timsTOF result) */
     if (df.F == 0) return false;
     if (df.K <= 1) return false;
 
     Dense dp_raw;
-    get_dense_alpharaw(d, c.frame_start, c.frame_stop, iso_mz.data(), I, cfg.precursor_mz_tolerance,
-                       -1.0, -1.0, true, dp_raw, prec_pidx, &matched);
+    if (rv.im())
+        get_dense_timstof(*rv.tt, c.frame_start, c.frame_stop, c.scan_start, c.scan_stop, iso_mz.data(), I,
+                          cfg.precursor_mz_tolerance, -1.0, -1.0, dp_raw, prec_pidx, &matched);
+    else
+        get_dense_alpharaw(*rv.ar, c.frame_start, c.frame_stop, iso_mz.data(), I, cfg.precursor_mz_tolerance,
+                           -1.0, -1.0, true, dp_raw, prec_pidx, &matched);
     if (out.stat_matched_peaks) out.stat_matched_peaks[row] = matched;
 
     const int O = df.O, S = df.S, F = df.F;
@@ -512,7 +624,7 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
             for (int s = 0; s < n_scans; ++s) {
                 int64_t obs = frag_pidx[o];
                 int64_t scan = c.scan_start + s;
-                const double *cy = d.cycle + 2 * (obs * d.cycle_scans + scan);
+                const double *cy = rv.cycle() + 2 * (obs * rv.cycle_scans() + scan);
                 double x = (double)iso_mz[i];
                 qtf[((size_t)i * O + o) * n_scans + s] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
             }
@@ -635,19 +747,20 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
     or_envelope_rows(fsp, K * O, S);
     or_envelope_rows(tsp, O, S);
 
-    const int64_t L = d.cycle_len;
-    std::vector<float> frame_rt;
-    for (int64_t fidx = c.frame_start; fidx < c.frame_stop; fidx += L) frame_rt.push_back(d.rt_values[fidx]);
+    const int64_t L = rv.cycle_len();
+    const bool IM = rv.im();
+    std::vector<double> frame_rt; /* float32 values for AlphaRaw, float64 for timsTOF */
+    for (int64_t fidx = c.frame_start; fidx < c.frame_stop; fidx += L) frame_rt.push_back(rv.rt(fidx));
 
     float feat[ADH_NUM_FEATURES];
     for (float &v : feat) v = 0.0f;
     feat[28] = (float)((double)n_present / (double)K0);
 
     /* location_features.py:8-33 */
-    feat[0] = d.mobility_values[c.scan_start] - d.mobility_values[c.scan_stop - 1];
-    feat[1] = d.rt_values[c.frame_stop - 1] - d.rt_values[c.frame_start];
-    feat[2] = d.rt_values[c.frame_center];
-    feat[3] = d.mobility_values[c.scan_center];
+    feat[0] = (float)rv.mob_diff(c.scan_start, c.scan_stop - 1);
+    feat[1] = (float)rv.rt_diff(c.frame_stop - 1, c.frame_start);
+    feat[2] = (float)rv.rt(c.frame_center);
+    feat[3] = (float)rv.mob(c.scan_center);
 
     /* ---------------- precursor_features.py:13-102 ---------------- */
     {
@@ -760,16 +873,19 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
         int64_t ra, rb;
         py_slice(center - qw, center + qw + 1, (int64_t)frame_rt.size(), ra, rb);
         int W = (int)(b - a);
-        std::vector<float> delta_rt;
-        for (int64_t i = ra; i + 1 < rb; ++i) delta_rt.push_back(frame_rt[i + 1] - frame_rt[i]);
+        std::vector<double> delta_rt; /* f32 - f32 (AlphaRaw) or f64 - f64 (timsTOF) */
+        for (int64_t i = ra; i + 1 < rb; ++i)
+            delta_rt.push_back(IM ? frame_rt[i + 1] - frame_rt[i]
+                                  : (double)((float)frame_rt[i + 1] - (float)frame_rt[i]));
         std::vector<float> obs_int(K);
         for (int k = 0; k < K; ++k) {
             const float *p = &bp[(size_t)k * F + a];
             double area = 0;
             for (int i = 0; i + 1 < W; ++i) {
                 float s = p[i + 1] + p[i];
-                float m = s * delta_rt[i];
-                area += (double)m * 0.5;
+                /* f32 * f32 -> f32 (AlphaRaw);  f32 * f64 -> f64 (timsTOF rt_values are float64) */
+                double m = IM ? (double)s * delta_rt[i] : (double)(float)(s * (float)delta_rt[i]);
+                area += m * 0.5;
             }
             area_norm[k] = area * (double)qw;
             float t = 0;
@@ -960,7 +1076,50 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
         }
     }
 
-    /* fragment_mobility_correlation (IM only), fragment_features.py:430-480: skipped for AlphaRaw */
+    /* fragment_mobility_correlation (IM only), fragment_features.py:430-480 */
+    if (IM) {
+        std::vector<int> keep;
+        for (int k = 0; k < K; ++k) {
+            float so = 0;
+            for (int o = 0; o < O; ++o) {
+                float ss = 0;
+                for (int s2 = 0; s2 < S; ++s2) ss += fsp[((size_t)k * O + o) * S + s2];
+                so += ss;
+            }
+            if (so > 0) keep.push_back(k);
+        }
+        if ((int)keep.size() >= 3) {
+            const int Km = (int)keep.size();
+            float isum = 0;
+            for (int k : keep) isum += fr.intensity[k];
+            std::vector<float> norm(Km), sub((size_t)Km * O * S);
+            for (int a = 0; a < Km; ++a) {
+                norm[a] = fr.intensity[keep[a]] / isum;
+                for (int i = 0; i < O * S; ++i) sub[(size_t)a * O * S + i] = fsp[(size_t)keep[a] * O * S + i];
+            }
+            std::vector<float> cm;
+            fragment_correlation(sub, Km, O, S, cm);
+            std::vector<float> red((size_t)Km * Km, 0.0f);
+            for (int o = 0; o < O; ++o)
+                for (int i = 0; i < Km * Km; ++i) red[i] += cm[(size_t)o * Km * Km + i] * oi[o];
+            float lsum = 0;
+            for (int a = 0; a < Km; ++a) {
+                float acc = 0;
+                for (int b = 0; b < Km; ++b) acc += red[(size_t)a * Km + b] * norm[b];
+                lsum += acc;
+            }
+            feat[29] = (float)((double)lsum / (double)Km);
+            std::vector<float> ftsc;
+            fragment_correlation_template(sub, Km, O, S, tsp, ftsc);
+            float dot = 0;
+            for (int a = 0; a < Km; ++a) {
+                float r = 0;
+                for (int o = 0; o < O; ++o) r += ftsc[(size_t)o * Km + a] * oi[o];
+                dot += r * norm[a];
+            }
+            feat[30] = dot;
+        }
+    }
 
     /* ---------------- profile_features.py:18-206 ---------------- */
     std::vector<float> corr_list(K);
@@ -1075,7 +1234,7 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
         }
 
         /* FWHM RT */
-        float rt_width = d.rt_values[c.frame_stop - 1] - d.rt_values[c.frame_start];
+        const double rt_width = rv.rt_diff(c.frame_stop - 1, c.frame_start);
         {
             float agg = 0;
             for (int k = 0; k < K; ++k) {
@@ -1088,14 +1247,34 @@ bool process_candidate(const adh_alpharaw_t &d, const adh_fragments_t &lib, cons
                     int n_above = 0;
                     for (int f = 0; f < F; ++f) n_above += ((double)p[f] > half);
                     double frac = (double)n_above / (double)F;
-                    float fw = (float)(frac * (double)rt_width);
+                    float fw = (float)(frac * rt_width);
                     ml += fw * oi[o];
                 }
                 agg += ml * fr.intensity[k];
             }
             feat[38] = agg;
         }
-        /* FWHM mobility: has_mobility only */
+        /* FWHM mobility (profile_features.py:151-188): has_mobility only */
+        if (IM) {
+            const double mob_width = rv.mob_diff(c.scan_start, c.scan_stop - 1);
+            float agg = 0;
+            for (int k = 0; k < K; ++k) {
+                float ml = 0;
+                for (int o = 0; o < O; ++o) {
+                    const float *p = &fsp[((size_t)k * O + o) * S];
+                    float mx = p[0];
+                    for (int s2 = 1; s2 < S; ++s2) mx = p[s2] > mx ? p[s2] : mx;
+                    double half = (double)mx / 2.0;
+                    int n_above = 0;
+                    for (int s2 = 0; s2 < S; ++s2) n_above += ((double)p[s2] > half);
+                    double frac = (double)n_above / (double)S;
+                    float fw = (float)(frac * mob_width);
+                    ml += fw * oi[o];
+                }
+                agg += ml * fr.intensity[k];
+            }
+            feat[39] = agg;
+        }
 
         /* RT shift */
         {
@@ -1135,10 +1314,10 @@ extern "C" {
  * interleaving makes neighbouring output rows ping-pong between cores, so the
  * baseline uses blocks of 64 consecutive candidates per thread instead.
  */
-int adh_oracle_score(const adh_alpharaw_t *dia, const adh_fragments_t *lib,
-                     const adh_candidates_t *cands, const adh_scoring_config_t *cfg,
-                     adh_output_t *out, int n_threads) {
-    if (!dia || !lib || !cands || !cfg || !out) return ADH_ERR_INVALID_ARGUMENT;
+static int oracle_score_view(const RunView &rv, const adh_fragments_t *lib,
+                             const adh_candidates_t *cands, const adh_scoring_config_t *cfg,
+                             adh_output_t *out, int n_threads) {
+    if (!lib || !cands || !cfg || !out) return ADH_ERR_INVALID_ARGUMENT;
     int64_t n = cands->n;
     if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for num_threads(n_threads) schedule(dynamic, 64)
@@ -1159,12 +1338,49 @@ int adh_oracle_score(const adh_alpharaw_t *dia, const adh_fragments_t *lib,
         c.precursor_mz = cands->precursor_mz[i];
         c.iso = cands->isotope_intensity + (size_t)i * cands->n_isotope_cols;
         c.n_iso_cols = cands->n_isotope_cols;
-        out->valid[i] = process_candidate(*dia, *lib, c, *cfg, i, *out) ? 1 : 0;
+        out->valid[i] = process_candidate(rv, *lib, c, *cfg, i, *out) ? 1 : 0;
     }
     return ADH_OK;
 }
 
 void adh_oracle_set_numpy_typing(int on) { g_numpy_typing = on; }
+
+int adh_oracle_score(const adh_alpharaw_t *dia, const adh_fragments_t *lib,
+                     const adh_candidates_t *cands, const adh_scoring_config_t *cfg,
+                     adh_output_t *out, int n_threads) {
+    if (!dia) return ADH_ERR_INVALID_ARGUMENT;
+    RunView rv;
+    rv.ar = dia;
+    return oracle_score_view(rv, lib, cands, cfg, out, n_threads);
+}
+
+int adh_oracle_score_timstof(const adh_timstof_t *dia, const adh_fragments_t *lib,
+                             const adh_candidates_t *cands, const adh_scoring_config_t *cfg,
+                             adh_output_t *out, int n_threads) {
+    if (!dia) return ADH_ERR_INVALID_ARGUMENT;
+    RunView rv;
+    rv.tt = dia;
+    return oracle_score_view(rv, lib, cands, cfg, out, n_threads);
+}
+
+/* timsTOF get_dense for unit tests: writes (2,K,O,S,F) */
+int adh_oracle_get_dense_timstof(const adh_timstof_t *dia, int64_t frame_start, int64_t frame_stop,
+                                 int64_t scan_start, int64_t scan_stop, const float *mz_query,
+                                 int32_t k, float tol, double quad_lo, double quad_hi, float *dense,
+                                 int64_t dense_capacity, int64_t *precursor_idx, int32_t *n_obs,
+                                 int32_t *n_scans, int32_t *n_frames) {
+    Dense d;
+    std::vector<int64_t> pidx;
+    get_dense_timstof(*dia, frame_start, frame_stop, scan_start, scan_stop, mz_query, k, tol, quad_lo,
+                      quad_hi, d, pidx, nullptr);
+    *n_obs = d.O;
+    *n_scans = d.S;
+    *n_frames = d.F;
+    if ((int64_t)d.v.size() > dense_capacity) return ADH_ERR_INVALID_ARGUMENT;
+    if (!d.v.empty()) std::memcpy(dense, d.v.data(), d.v.size() * sizeof(float));
+    for (size_t i = 0; i < pidx.size(); ++i) precursor_idx[i] = pidx[i];
+    return ADH_OK;
+}
 
 /* get_dense for unit tests: writes (2,K,O,2,F) into `dense` (capacity checked by caller). */
 int adh_oracle_get_dense(const adh_alpharaw_t *dia, int64_t frame_start, int64_t frame_stop,

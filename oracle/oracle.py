@@ -66,6 +66,48 @@ def score(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with
     return arrays
 
 
+def score_timstof(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with_stats=False):
+    """The same restatement over an ion-mobility run (TimsTOFTransposeJIT layout)."""
+    m_dia = _abi.pack_timstof(dia)
+    m_frag = _abi.pack_fragments(*fragment_cols)
+    cfg = _abi.pack_config(cfg_jit)
+    n = int(cand_marshalled.struct.n)
+    m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+    lib().adh_oracle_score_timstof.restype = C.c_int
+    rc = lib().adh_oracle_score_timstof(
+        m_dia.ref(), m_frag.ref(), cand_marshalled.ref(), C.byref(cfg), m_out.ref(), C.c_int(n_threads)
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_score_timstof failed: {rc}")
+    return arrays
+
+
+def get_dense_timstof(dia, frame_start, frame_stop, scan_start, scan_stop, mz_query, tol, quad_lo, quad_hi):
+    m_dia = _abi.pack_timstof(dia)
+    mzq = np.ascontiguousarray(mz_query, dtype=np.float32)
+    K = mzq.shape[0]
+    L = m_dia.struct.cycle_len
+    z = m_dia.struct.zeroth_frame
+    F = max((int(frame_stop) - z) // L - (int(frame_start) - z) // L, 0)
+    S = int(scan_stop) - int(scan_start)
+    cap = 2 * K * L * S * F
+    dense = np.zeros(max(cap, 1), dtype=np.float32)
+    pidx = np.zeros(L, dtype=np.int64)
+    n_obs, n_sc, n_fr = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().adh_oracle_get_dense_timstof.restype = C.c_int
+    rc = lib().adh_oracle_get_dense_timstof(
+        m_dia.ref(), C.c_int64(int(frame_start)), C.c_int64(int(frame_stop)), C.c_int64(int(scan_start)),
+        C.c_int64(int(scan_stop)), mzq.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(K),
+        C.c_float(float(tol)), C.c_double(float(quad_lo)), C.c_double(float(quad_hi)),
+        dense.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(cap),
+        pidx.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n_obs), C.byref(n_sc), C.byref(n_fr),
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_get_dense_timstof failed: {rc}")
+    O, S2, F2 = n_obs.value, n_sc.value, n_fr.value
+    return dense[: 2 * K * O * S2 * F2].reshape(2, K, O, S2, F2).copy(), pidx[:O].copy()
+
+
 def set_numpy_typing(on: bool) -> None:
     """Switch the three shim-vs-Numba promotion sites (see adh_oracle.cpp)."""
     lib().adh_oracle_set_numpy_typing(C.c_int(int(bool(on))))

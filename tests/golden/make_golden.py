@@ -415,7 +415,129 @@ def golden_fragcomp():
     print(path, f"{len(res)}/{n_psm} survive, {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def timstof_to_jit(dia):
+    from alphadia.search.jitclasses.bruker_jit import TimsTOFTransposeJIT
+
+    n_frames = dia.rt_values.shape[0]
+    return TimsTOFTransposeJIT(
+        np.ones(n_frames),                      # accumulation_times
+        dia.cycle,
+        dia.dia_mz_cycle,
+        dia.dia_precursor_cycle,
+        dia.frame_max_index,
+        np.ones(dia.mz_values.shape[0]),        # intensity_corrections
+        60000, 0,                               # intensity max / min
+        dia.intensity_values,
+        1.0,                                    # max_accumulation_time
+        float(dia.mobility_values.max()), float(dia.mobility_values.min()),
+        dia.mobility_values,
+        dia.mz_values,
+        np.zeros(1, np.int64), 0,               # precursor_indices, precursor_max_index
+        np.zeros(1, np.int64),                  # quad_indptr
+        float(dia.cycle.max()), float(dia.cycle[dia.cycle > 0].min()),
+        np.zeros((1, 2)),                       # quad_mz_values
+        np.zeros(1, np.int64),                  # raw_quad_indptr
+        dia.rt_values,
+        dia.scan_max_index,
+        dia.mz_values.shape[0],                 # tof_max_index
+        0,                                      # use_calibrated_mz_values_as_default
+        dia.zeroth_frame,
+        dia.push_indices,
+        dia.tof_indptr,
+    )
+
+
+class DuckTims:
+    def __init__(self, dia):
+        self.cycle = dia.cycle
+        self._jit = timstof_to_jit(dia)
+
+    def to_jitclass(self):
+        return self._jit
+
+
+TIMS_COLS = ["cycle", "dia_precursor_cycle", "rt_values", "mobility_values", "mz_values",
+             "tof_indptr", "push_indices", "intensity_values"]
+
+
+def golden_timstof():
+    """G2 + G4 for ion-mobility data: TimsTOFTransposeJIT.get_dense and full scoring."""
+    case = syn.make_timstof_case(n_precursors=160, n_cycles=36)
+    d = {"tims_" + c: getattr(case.dia, c) for c in TIMS_COLS}
+    d["tims_scan_max_index"] = np.asarray(case.dia.scan_max_index)
+    d["tims_zeroth_frame"] = np.asarray(case.dia.zeroth_frame)
+    for c in FRAG_COLS:
+        d["frag_" + c] = case.library.fragment_df[c].values
+    for c in PREC_NUM_COLS:
+        d["prec_" + c] = case.library.precursor_df[c].values
+    for c in CAND_COLS:
+        d["cand_" + c] = case.candidates_df[c].values
+
+    # direct get_dense cases
+    jit = timstof_to_jit(case.dia)
+    rng = np.random.default_rng(17)
+    L, S = case.dia.cycle_len, case.dia.scan_max_index
+    n_cases = 12
+    for i in range(n_cases):
+        c0 = int(rng.integers(0, 20)); nc = int(rng.integers(3, 12))
+        s0 = int(rng.integers(0, S - 24)); ns = int(rng.integers(4, 24))
+        frame_limits = np.array([[c0 * L + 1, (c0 + nc) * L + 1, 1]], dtype=np.uint64)
+        scan_limits = np.array([[s0, s0 + ns, 1]], dtype=np.uint64)
+        k = int(rng.integers(2, 10))
+        if i % 3 == 0:
+            mzq = np.sort(rng.uniform(400, 480, k)).astype(np.float32)
+            quad = np.array([[-1.0, -1.0]])
+        else:
+            mzq = np.sort(rng.uniform(200, 350, k)).astype(np.float32)
+            lo = rng.uniform(400, 470)
+            quad = np.array([[lo, lo + rng.uniform(1.0, 25.0)]], dtype=np.float32)
+        tol = np.float32(30 if i % 2 else 80)
+        dense, pidx = jit.get_dense(frame_limits, scan_limits, mzq, tol, quad, absolute_masses=True)
+        d[f"q{i}_frame_limits"] = frame_limits
+        d[f"q{i}_scan_limits"] = scan_limits
+        d[f"q{i}_mz"] = mzq
+        d[f"q{i}_tol"] = np.asarray(tol)
+        d[f"q{i}_quad"] = np.asarray(quad, dtype=np.float64)
+        d[f"q{i}_dense"] = dense
+        d[f"q{i}_pidx"] = np.asarray(pidx, dtype=np.int64)
+    d["n_cases"] = np.asarray(n_cases)
+
+    # full scoring (handler defaults)
+    cfg = CandidateScoringConfig()
+    cfg.update(SCORING_CONFIGS["handler_default"])
+    dia = DuckTims(case.dia)
+    cs = ref_scoring.CandidateScoring(
+        dia_data=dia,
+        precursors_flat=case.library.precursor_df.copy(),
+        fragments_flat=case.library.fragment_df.copy(),
+        rt_column="rt_library", mobility_column="mobility_library",
+        precursor_mz_column="mz_library", fragment_mz_column="mz_library", config=cfg,
+    )
+    cands = case.candidates_df.copy()
+    fragment_container = cs.assemble_fragments()
+    sgc = cs.assemble_score_group_container(cands)
+    out = OutputPsmDF(sgc.get_candidate_count(), cs.config.top_k_fragments)
+    ref_scoring._process_score_groups(range(len(sgc)), sgc, out, fragment_container, dia.to_jitclass(),
+                                      cs.config.to_jitclass(), cs.quadrupole_calibration.jit, False)
+    d.update(out_to_dict(out))
+    cfgj = cfg.to_jitclass()
+    for kk in ("collect_fragments score_grouped exclude_shared_ions top_k_fragments top_k_isotopes "
+               "reference_channel quant_window quant_all precursor_mz_tolerance "
+               "fragment_mz_tolerance experimental_xic").split():
+        d["cfg_" + kk] = np.asarray(getattr(cfgj, kk))
+    d["caveat"] = np.asarray(CAVEAT)
+    path = os.path.join(HERE, "scoring_timstof.npz")
+    np.savez_compressed(path, **d)
+    v = np.asarray(out.valid)
+    print(f"{path}: {v.sum()}/{len(v)} valid, {os.path.getsize(path)/1e6:.2f} MB, "
+          f"mean f29 {np.nanmean(out.features[v][:, 29]):.3f}")
+
+
 if __name__ == "__main__":
+    if "--timstof-only" in sys.argv:
+        golden_timstof()
+        sys.exit(0)
     golden_get_dense()
     golden_fragcomp()
     golden_scoring()
+    golden_timstof()

@@ -195,3 +195,61 @@ def test_threads_do_not_change_results(oracle_lib):
     b, _ = H.oracle_score(oracle_lib, g, g.config, n_threads=4, soa=soa)
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+# ---- ion-mobility (timsTOF) layout ---------------------------------------------------
+
+def _tims_golden():
+    import pandas as pd
+
+    from alphadia_amd import synthetic as syn
+    from alphadia_amd.scoring import CandidateScoringConfig
+
+    z = np.load(H.golden_path("scoring_timstof.npz"))
+    dia = syn.TimsTOFArrays(
+        cycle=z["tims_cycle"], dia_precursor_cycle=z["tims_dia_precursor_cycle"],
+        rt_values=z["tims_rt_values"], mobility_values=z["tims_mobility_values"],
+        mz_values=z["tims_mz_values"], tof_indptr=z["tims_tof_indptr"],
+        push_indices=z["tims_push_indices"], intensity_values=z["tims_intensity_values"],
+        scan_max_index=int(z["tims_scan_max_index"]), zeroth_frame=bool(z["tims_zeroth_frame"]),
+    )
+    fragment_df = pd.DataFrame({c: z["frag_" + c] for c in H.FRAG_COLS})
+    precursor_df = pd.DataFrame({c: z["prec_" + c] for c in H.PREC_COLS})
+    cand = pd.DataFrame({c: z["cand_" + c] for c in H.CAND_COLS})
+    cfg = CandidateScoringConfig()
+    cfg.update({k: z["cfg_" + k].item() for k in H.CFG_KEYS})
+    return z, dia, fragment_df, precursor_df, cand, cfg
+
+
+def test_timstof_get_dense_matches_reference(oracle_lib):
+    z, dia, *_ = _tims_golden()
+    hits = 0
+    for i in range(int(z["n_cases"])):
+        fl, sl, quad = z[f"q{i}_frame_limits"], z[f"q{i}_scan_limits"], z[f"q{i}_quad"]
+        dense, pidx = oracle_lib.get_dense_timstof(
+            dia, fl[0, 0], fl[0, 1], sl[0, 0], sl[0, 1], z[f"q{i}_mz"], z[f"q{i}_tol"], quad[0, 0], quad[0, 1]
+        )
+        e = z[f"q{i}_dense"]
+        if e.size == 0:  # no push matches the quadrupole: bruker_jit.py:363-366
+            assert dense.size == 0
+            continue
+        assert dense.shape == e.shape and np.array_equal(pidx, z[f"q{i}_pidx"])
+        assert np.array_equal(dense, e), f"case {i}"
+        hits += int((e[0] > 0).sum())
+    assert hits > 20
+
+
+def test_timstof_scoring_matches_reference(oracle_lib):
+    """Ion-mobility path incl. fragment/template scan correlation (features 29, 30) and
+    mobility FWHM (39): same bar as for the AlphaRaw layout."""
+    from alphadia_amd.scoring import assemble_candidates, fragment_columns, pack_assembled
+
+    z, dia, fragment_df, precursor_df, cand, cfg = _tims_golden()
+    soa = assemble_candidates(cand, precursor_df, "mz_library")
+    got = oracle_lib.score_timstof(
+        dia, fragment_columns(fragment_df, "mz_library"), pack_assembled(soa), cfg.to_jitclass()
+    )
+    exp = {n: z["out_" + n] for n in H.OUT_NAMES}
+    _compare(got, exp, ppm_tol=0.15, rel_tol=1e-4, corr_abs=1e-3)
+    v = exp["valid"].astype(bool)
+    assert v.sum() > 100 and (exp["features"][v][:, 29] != 0).sum() > 50
