@@ -13,6 +13,8 @@
 #include "adh_gather.hip"
 #include "adh_features.hip"
 #include "adh_features_fast.hip"
+#include "adh_gather_im.hip"
+#include "adh_features_im.hip"
 #include "adh_fragcomp.hip"
 
 namespace {
@@ -60,6 +62,7 @@ struct Plan {
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
     bool fast_ok = false;          // class 0 runs through adh_feature_fast_kernel
     CandRec *d_recs = nullptr;
+    CandRecIM *d_recs_im = nullptr;
     unsigned char *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // classes 0..2: register kernels for F <= 16 / 24 / 32; class 3: generic LDS kernel
@@ -74,6 +77,9 @@ struct adh_handle {
     hipStream_t side_stream = nullptr;   // the generic feature kernel overlaps the register kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevRun run{};
+    DevTims tims{};
+    bool tims_staged = false;
+    std::vector<int32_t> h_dpc;     // host copy of dia_precursor_cycle (ion-mobility plan)
     std::vector<double> h_cycle;    // host copy for planning
     const LibRec *d_lib = nullptr;
     int64_t n_lib = 0;
@@ -162,6 +168,10 @@ int adh_create(adh_handle_t **handle, int device) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)adh_gather_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *handle = h;
     return ADH_OK;
 }
@@ -206,6 +216,7 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     h->plan_buf.release();
     h->plan = Plan();
     h->run_staged = false;
+    h->tims_staged = false;
 
     // validate the CSR on the host: kernels index with it unchecked
     float mz_lo = 0.f, mz_hi = 0.f;
@@ -291,6 +302,57 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     return ADH_OK;
 }
 
+int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
+    if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->cycle_len <= 0 || d->scan_max_index <= 0 || d->n_frames <= 0 || d->n_tof <= 0 || d->n_events < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid run dimensions");
+    if (d->cycle_len > 65535 || d->n_tof >= 0x7FFFFFFFll ||
+        d->n_frames * (int64_t)d->scan_max_index >= 0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "run too large for 32-bit push / TOF indices");
+    HIP_TRY(hipSetDevice(h->device));
+    h->run_buf.release();
+    h->plan_buf.release();
+    h->plan = Plan();
+    h->run_staged = false;
+    h->tims_staged = false;
+    // validate the index arrays on the host: kernels use them unchecked
+    if (d->tof_indptr[0] != 0 || d->tof_indptr[d->n_tof] != d->n_events)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indptr does not span the event arrays");
+    for (int64_t t = 0; t < d->n_tof; ++t) {
+        if (d->tof_indptr[t + 1] < d->tof_indptr[t])
+            return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indptr is not monotone");
+        if (t > 0 && !(d->mz_values[t] >= d->mz_values[t - 1]))
+            return fail(ADH_ERR_INVALID_ARGUMENT, "mz_values must be ascending");
+    }
+    const int64_t rows = (int64_t)d->cycle_len * d->scan_max_index;
+    std::vector<int32_t> dpc((size_t)rows);
+    for (int64_t i = 0; i < rows; ++i) {
+        if (d->dia_precursor_cycle[i] < 0 || d->dia_precursor_cycle[i] >= d->cycle_len)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "dia_precursor_cycle must index the cycle");
+        dpc[(size_t)i] = (int32_t)d->dia_precursor_cycle[i];
+    }
+    DevTims t{};
+    t.n_tof = d->n_tof;
+    t.n_events = d->n_events;
+    t.n_frames = d->n_frames;
+    t.cycle_len = d->cycle_len;
+    t.scan_max = d->scan_max_index;
+    t.zeroth = d->zeroth_frame ? 1 : 0;
+    UP(h->run_buf, d->tof_indptr, d->n_tof + 1, &t.tof_indptr);
+    UP(h->run_buf, d->push_indices, d->n_events, &t.push);
+    UP(h->run_buf, d->intensity_values, d->n_events, &t.inten);
+    UP(h->run_buf, d->mz_values, d->n_tof, &t.mz);
+    UP(h->run_buf, d->cycle, rows * 2, &t.cycle);
+    UP(h->run_buf, dpc.data(), rows, &t.dpc);
+    UP(h->run_buf, d->rt_values, d->n_frames, &t.rt);
+    UP(h->run_buf, d->mobility_values, (int64_t)d->scan_max_index, &t.mobility);
+    h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
+    h->h_dpc = dpc;
+    h->tims = t;
+    h->tims_staged = true;
+    return ADH_OK;
+}
+
 int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     if (!h || !f) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (f->n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative fragment count");
@@ -320,7 +382,7 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
 
 int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
     if (!h || !c) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!h->run_staged || !h->lib_staged)
+    if (!(h->run_staged || h->tims_staged) || !h->lib_staged)
         return fail(ADH_ERR_NOT_STAGED, "stage the run and the fragment library first");
     if (c->n < 0 || c->n_isotope_cols < 1)
         return fail(ADH_ERR_INVALID_ARGUMENT, "invalid candidate table dimensions");
@@ -333,23 +395,29 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
     h->cands_uploaded = false;
 
     // bounds the kernels rely on
-    const int64_t L = h->run.cycle_len;
+    const bool im = h->tims_staged;
+    const int64_t L = im ? h->tims.cycle_len : h->run.cycle_len;
+    const int64_t zf = im ? h->tims.zeroth : 0;
+    const int64_t n_fr = im ? h->tims.n_frames : h->run.n_spectra;
     for (int64_t i = 0; i < c->n; ++i) {
         if (c->flags && (c->flags[i] & ADH_FLAG_SKIP)) continue;
         if (c->frag_stop_idx[i] < c->frag_start_idx[i] || (int64_t)c->frag_stop_idx[i] > h->n_lib)
             return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
         int64_t fs = c->frame_start[i], fe = c->frame_stop[i], fc = c->frame_center[i];
-        if (fs < 0 || fe < fs || fe > h->run.n_spectra || fc < 0 || fc >= h->run.n_spectra)
+        if (fs < zf || fe < fs || fe > n_fr + (im ? 0 : 0) || fc < 0 || fc >= n_fr)
             return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
-        if ((fe - fs) % L != 0)
+        if ((fs - zf) % L != 0 || (fe - zf) % L != 0)
             return fail(ADH_ERR_INVALID_ARGUMENT,
-                        "frame_stop - frame_start must be a multiple of the cycle length");
-        if ((fe / L) * L > h->run.n_spectra)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
+                        "frame_start / frame_stop must sit on cycle boundaries");
         int64_t ss = c->scan_start[i], se = c->scan_stop[i], sc = c->scan_center[i];
-        if (se - ss != 1 || ss != 0 || sc != 0)
+        if (im) {
+            if (ss < 0 || se < ss || se > h->tims.scan_max || sc < 0 || sc >= h->tims.scan_max)
+                return fail(ADH_ERR_INVALID_ARGUMENT, "scan limits outside the staged run");
+            if (fe - 1 >= n_fr) return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
+        } else if (se - ss != 1 || ss != 0 || sc != 0) {
             return fail(ADH_ERR_UNSUPPORTED,
                         "AlphaRaw candidates must have scan_start=0, scan_stop=1, scan_center=0");
+        }
         if (c->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge is 0");
     }
     HostCands &hc = h->hc;
@@ -507,6 +575,156 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     return ADH_OK;
 }
 
+
+// Ion-mobility plan: observation lists (sorted unique dia_precursor_cycle values of the cycle
+// rows inside the scan range that overlap the quadrupole range), tile sizes, scratch offsets.
+int build_plan_im(adh_handle *h, const adh_scoring_config_t *cfg) {
+    Plan &p = h->plan;
+    if (p.ready && p.top_k_fragments == cfg->top_k_fragments && p.top_k_isotopes == cfg->top_k_isotopes)
+        return ADH_OK;
+    h->plan_buf.release();
+    p = Plan();
+    const HostCands &hc = h->hc;
+    const int64_t n = hc.n;
+    const int L = h->tims.cycle_len, S_max = h->tims.scan_max, z = h->tims.zeroth;
+    const int I = (int)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)hc.n_iso_cols);
+    const double *cyc = h->h_cycle.data();
+    const double ISOTOPE_DELTA = 1.0033548350700006;
+    const int64_t n_cyc = h->tims.n_frames / L + 2;
+    std::vector<uint32_t> head((size_t)n_cyc + 1, 0);
+    std::vector<CandRecIM> recs((size_t)n);
+    std::vector<uint8_t> seen((size_t)L);
+    for (int64_t i = 0; i < n; ++i) {
+        CandRecIM &r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        r.precursor_idx = hc.precursor_idx[i];
+        r.frag_start = hc.frag_start[i];
+        r.frag_stop = hc.frag_stop[i];
+        r.frame_start = hc.frame_start[i];
+        r.frame_stop = hc.frame_stop[i];
+        r.frame_center = hc.frame_center[i];
+        r.scan_start = hc.scan_start[i];
+        r.scan_stop = hc.scan_stop[i];
+        r.scan_center = hc.scan_center[i];
+        r.precursor_mz = hc.precursor_mz[i];
+        r.charge = hc.charge[i];
+        r.rank = hc.rank[i];
+        r.flags = hc.flags[i];
+        r.row = (uint32_t)i;
+        if (r.flags & ADH_FLAG_SKIP) {
+            ++head[1];
+            continue;
+        }
+        float mn = 0.f, mx = 0.f;
+        for (int k = 0; k < I; ++k) {
+            float m = (float)((double)k * ISOTOPE_DELTA / (double)r.charge) + r.precursor_mz;
+            if (k == 0 || m < mn) mn = m;
+            if (k == 0 || m > mx) mx = m;
+        }
+        const double q_lo = (double)(float)((double)mn - 0.5), q_hi = (double)(float)((double)mx + 0.5);
+        for (int pass = 0; pass < 2; ++pass) {
+            const double lo = pass ? -1.0 : q_lo, hi = pass ? -1.0 : q_hi;
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int fr = 0; fr < L; ++fr)
+                for (int sc = r.scan_start; sc < r.scan_stop; ++sc) {
+                    const int64_t rowi = (int64_t)fr * S_max + sc;
+                    if (lo <= cyc[2 * rowi + 1] && hi >= cyc[2 * rowi]) seen[(size_t)h->h_dpc[(size_t)rowi]] = 1;
+                }
+            int cnt = 0;
+            for (int v = 0; v < L; ++v) {
+                if (!seen[(size_t)v]) continue;
+                if (pass == 0) {
+                    if (cnt >= ADH_MAX_OBS)
+                        return fail(ADH_ERR_UNSUPPORTED, "a precursor overlaps more than 8 cycle rows");
+                    r.obs[cnt] = (uint16_t)v;
+                } else {
+                    if (cnt >= ADH_MAX_OBS)
+                        return fail(ADH_ERR_UNSUPPORTED, "more than 8 unfragmented cycle rows in the scan range");
+                    r.ms1_obs[cnt] = (uint16_t)v;
+                }
+                ++cnt;
+            }
+            if (pass == 0) r.n_obs = (uint8_t)cnt; else r.n_ms1 = (uint8_t)cnt;
+        }
+        r.k_cap = (uint32_t)std::min<int64_t>((int64_t)cfg->top_k_fragments,
+                                              (int64_t)r.frag_stop - (int64_t)r.frag_start);
+        ++head[(size_t)((r.frame_start - z) / L) + 1];
+    }
+    for (int64_t k = 0; k < n_cyc; ++k) head[(size_t)k + 1] += head[(size_t)k];
+    std::vector<CandRecIM> ordered((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const CandRecIM &r = recs[(size_t)i];
+        size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)((r.frame_start - z) / L);
+        ordered[(size_t)head[bin]++] = r;
+    }
+    Caps zero{1, 1, 1, std::max(I, 1), 1, 0, 1, 1};
+    p.caps_generic = p.caps_all = zero;
+    uint64_t off = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        CandRecIM &r = ordered[(size_t)j];
+        if (r.flags & ADH_FLAG_SKIP) continue;
+        const int F = std::max((r.frame_stop - z) / L - (r.frame_start - z) / L, 0);
+        const int S = std::max(r.scan_stop - r.scan_start, 0);
+        r.scratch_off = off;
+        off += adh_im_scratch_bytes(r.k_cap, r.n_obs, S, F, I, r.n_ms1);
+        Caps &cc = p.caps_all;
+        cc.k = std::max<int32_t>(cc.k, (int32_t)r.k_cap);
+        cc.o = std::max<int32_t>(cc.o, (int32_t)r.n_obs);
+        cc.f = std::max<int32_t>(cc.f, F);
+        cc.s = std::max<int32_t>(cc.s, S);
+        cc.op = std::max<int32_t>(cc.op, (int32_t)r.n_ms1);
+        cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
+    }
+    p.caps_generic = p.caps_all;
+    p.n_class[3] = n;
+    p.scratch_bytes = std::max<uint64_t>(off, 32);
+    const CandRecIM *d_recs = nullptr;
+    UP(h->plan_buf, ordered.data(), n, &d_recs);
+    p.d_recs_im = const_cast<CandRecIM *>(d_recs);
+    void *sp = nullptr;
+    HIP_TRY(hipMalloc(&sp, p.scratch_bytes));
+    h->plan_buf.ptrs.push_back(sp);
+    p.d_scratch = static_cast<unsigned char *>(sp);
+    p.top_k_fragments = cfg->top_k_fragments;
+    p.top_k_isotopes = cfg->top_k_isotopes;
+    p.ready = true;
+    return ADH_OK;
+}
+
+int score_uploaded_im(adh_handle *h, const adh_scoring_config_t *cfg, adh_output_t *out, hipStream_t st) {
+    int rc = build_plan_im(h, cfg);
+    if (rc != ADH_OK) return rc;
+    Plan &p = h->plan;
+    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
+    const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all);
+    const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all);
+    if (f_lds > 160 * 1024 || g_lds > 160 * 1024) {
+        char buf[256];
+        snprintf(buf, sizeof(buf),
+                 "ion-mobility tile needs %zu bytes of LDS (K=%d O=%d S=%d F=%d): exceeds 160 KiB", f_lds,
+                 p.caps_all.k, p.caps_all.o, p.caps_all.s, p.caps_all.f);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    adh_handle::Timed t;
+    rc = get_event(h, &t.e0);
+    if (rc == ADH_OK) rc = get_event(h, &t.e1);
+    if (rc == ADH_OK) rc = get_event(h, &t.e2);
+    if (rc != ADH_OK) return rc;
+    const int32_t n_iso = h->hc.n_iso_cols;
+    HIP_TRY(hipEventRecord(t.e0, st));
+    hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), g_lds, st, h->tims,
+                       h->d_lib, p.d_recs_im, *cfg, n_iso, p.d_scratch, *out, p.caps_all);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.e1, st));
+    hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), f_lds, st, h->tims,
+                       p.d_recs_im, h->d_iso, n_iso, *cfg, p.d_scratch, *out, p.caps_all);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.e2, st));
+    h->timed.push_back(t);
+    return ADH_OK;
+}
+
 }  // namespace
 
 int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_output_t *out,
@@ -520,6 +738,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     HIP_TRY(hipSetDevice(h->device));
     if (h->hc.n == 0) return ADH_OK;
     hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's default stream, taken literally
+    if (h->tims_staged) return score_uploaded_im(h, cfg, out, st);
     int rc = build_plan(h, cfg);
     if (rc != ADH_OK) return rc;
     Plan &p = h->plan;

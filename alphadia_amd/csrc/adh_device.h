@@ -80,6 +80,47 @@ __host__ __device__ inline uint64_t adh_scratch_bytes(uint32_t k_cap, int O, int
     return (b + 31) / 32 * 32;
 }
 
+// Ion-mobility run staged in HBM: TimsTOFTransposeJIT arrays (bruker_jit.py:22-137)
+struct DevTims {
+    const int64_t *tof_indptr;   // [n_tof + 1]
+    const uint32_t *push;        // [n_events] frame * scan_max + scan, ascending inside a TOF bin
+    const uint16_t *inten;       // [n_events]
+    const double *mz;            // [n_tof]
+    const double *cycle;         // [cycle_len * scan_max * 2]
+    const int32_t *dpc;          // [cycle_len * scan_max] dia_precursor_cycle
+    const double *rt;            // [n_frames]
+    const double *mobility;      // [scan_max]
+    int64_t n_tof, n_events, n_frames;
+    int32_t cycle_len, scan_max, zeroth;
+};
+
+// candidate record of the ion-mobility plan (processing order)
+struct __attribute__((aligned(16))) CandRecIM {
+    uint32_t precursor_idx, frag_start, frag_stop;
+    int32_t frame_start, frame_stop, frame_center;
+    int32_t scan_start, scan_stop, scan_center;
+    float precursor_mz;
+    uint8_t charge, rank, flags, n_obs;
+    uint16_t obs[ADH_MAX_OBS];   // sorted unique dia_precursor_cycle values hit by the fragment quad range
+    uint8_t n_ms1, pad8[3];
+    uint16_t ms1_obs[ADH_MAX_OBS];  // the same for the (-1, -1) precursor query
+    uint32_t row, k_cap;
+    uint32_t pad32;
+    uint64_t scratch_off;
+    uint64_t pad64[2];
+};
+static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
+
+// ion-mobility scratch block: header (32 B), selected fragments (k_cap x 32 B),
+// fragment cells float2[k_cap][O][S][F], precursor cells float2[I][Op][S][F]
+__host__ __device__ inline uint64_t adh_im_prec_off(uint32_t k_cap, int O, int S, int F) {
+    return adh_scratch_frag_off(k_cap) + (uint64_t)k_cap * O * S * F * 8;
+}
+__host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
+    uint64_t b = adh_im_prec_off(k_cap, O, S, F) + (uint64_t)I * Op * S * F * 8;
+    return (b + 31) / 32 * 32;
+}
+
 typedef adh_output_t DevOut;
 
 // LDS capacities of one launch (maxima over the launch's candidates)
@@ -90,6 +131,8 @@ struct Caps {
     int32_t i;       // isotopes
     int32_t n_lib;   // longest library slice (gather kernel scratch)
     int32_t stop_phase;  // developer ablation switch (0 = run everything)
+    int32_t s;       // scans (ion-mobility kernels only)
+    int32_t op;      // MS1 observations (ion-mobility kernels only)
 };
 
 // monotone bucket function shared by index build and lookup

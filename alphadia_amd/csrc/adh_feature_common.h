@@ -47,15 +47,16 @@ struct Assemble {
 };
 
 // features 0-28, 41-45
-__device__ __forceinline__ void assemble_part1(const Assemble &q, const DevRun &run_, int I, int O, int K) {
-    (void)run_;
+__device__ __forceinline__ void assemble_part1(const Assemble &q, int I, int O, int K) {
         float *ft = q.featv;
         ft[28] = (float)((double)q.n_present / (double)q.K0);  // candidate.py:362
         // location_features.py:8-33
-        ft[0] = q.run->mobility[q.rec->scan_start] - q.run->mobility[q.rec->scan_stop - 1];
-        ft[1] = q.run->rt[q.rec->frame_stop - 1] - q.run->rt[q.rec->frame_start];
-        ft[2] = q.run->rt[q.rec->frame_center];
-        ft[3] = q.run->mobility[q.rec->scan_center];
+        if (q.run) {  // the ion-mobility kernel fills 0-3 itself (float64 rt / mobility arrays)
+            ft[0] = q.run->mobility[q.rec->scan_start] - q.run->mobility[q.rec->scan_stop - 1];
+            ft[1] = q.run->rt[q.rec->frame_stop - 1] - q.run->rt[q.rec->frame_start];
+            ft[2] = q.run->rt[q.rec->frame_center];
+            ft[3] = q.run->mobility[q.rec->scan_center];
+        }
 
         // precursor_features.py:13-102
         int amax = 0;

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     asmv.height = L.height; asmv.merr = L.merr; asmv.kmap = L.idmap; asmv.ord = L.ord;
     asmv.g_type = L.g_type; asmv.g_pos = L.g_pos;
     asmv.n_present = n_present; asmv.K0 = K0; asmv.top3 = 0.0f;
-    if (alive && sub == 0) feat::assemble_part1(asmv, run, I, 1, K);
+    if (alive && sub == 0) feat::assemble_part1(asmv, I, 1, K);
     if (stop_phase == 6) return;
 
     // ================= profile features (profile_features.py:18-206), experimental_xic =======

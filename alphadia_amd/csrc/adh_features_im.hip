@@ -1,32 +1,26 @@
-// adh_features.hip - kernel 2 of the scoring path: the 46-feature stack.
+// adh_features_im.hip - the 46-feature stack for ion-mobility (timsTOF) candidates.
 //
-// One 64-lane wavefront per candidate; the candidate's XIC tile (written by the
-// gather kernel) is loaded coalesced into LDS and everything from the quadrupole
-// transfer function onwards is computed there.  Replaces
-//   Candidate.process (after get_dense)  alphadia/search/scoring/containers/candidate.py:278-481
-//   quadrupole transfer fn / template    alphadia/search/scoring/quadrupole.py:261-335
-//   profiles and envelopes               alphadia/search/scoring/utils.py:26-66
-//   location / precursor / fragment / profile features
-//                                        alphadia/search/scoring/features/ (all modules)
-//   correlation helpers                  alphadia/search/scoring/scoring_utils.py:14-152,
-//                                        alphadia/search/scoring/utils.py:478-647
-//
-// Design notes
-//   * the duplicated "scan" axis of non-IM data (alpharaw_jit.py:326-333) is never
-//     materialised: every sum over the two identical scan slots is x + x
-//   * weighted_center_mean's exp() weights (features_utils.py:9-25) depend only on
-//     (observation, scan, cycle): one LDS table per candidate instead of one exp per
-//     non-zero cell per fragment
-//   * float32 reductions keep the reference's sequential order (one lane walks the
-//     short axis), float64 where Numba's typing makes the expression float64, so the
-//     kernel agrees with the CPU restatement bit for bit wherever libm agrees
-//   * compile with -ffp-contract=off
+// Same phases as adh_features.hip (the restatement of Candidate.process after get_dense,
+// alphadia/search/scoring/containers/candidate.py:248-481) with a REAL scan axis:
+//   * tiles are [K][O][S][F] in LDS; rt / mobility arrays are float64
+//     (TimsTOFTransposeJIT, alphadia/search/jitclasses/bruker_jit.py:35,45), which changes
+//     the typing of the quantification area and of the location / FWHM features
+//   * the quadrupole transfer function is evaluated per scan (quadrupole.py:261-301)
+//   * scan profiles get their OR-envelope (scoring/utils.py:56-66)
+//   * the ion-mobility-only features are computed: fragment / template scan correlation
+//     (fragment_features.py:430-480 -> features 29, 30) and mobility FWHM
+//     (profile_features.py:151-188 -> feature 39)
+// One 64-lane wavefront per candidate; float32 reductions keep the reference's order.
+// The K x K scan-profile correlation is the one dense contraction of the path
+// (12 x 12 x S per candidate); it is computed with ordered float32 sums here to stay
+// bit-comparable with the CPU restatement - an MFMA (v_mfma_f32_16x16x4_f32) variant
+// is the planned follow-up once a tolerance-based check replaces the bitwise one.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
-namespace feat {
+namespace featim {
+using feat::Assemble;
 
-// python slice(start, stop) on length n
 __device__ __forceinline__ void py_slice(int start, int stop, int n, int &a, int &b) {
     if (start < 0) start += n;
     if (stop < 0) stop += n;
@@ -40,38 +34,42 @@ __device__ __forceinline__ double logistic(double x, double mu, double sigma) {
     return 1.0 / (1.0 + exp(-a));
 }
 
-// LDS regions.  Element counts depend only on the launch capacities.
 struct Layout {
-    int Kc, Oc, Fc, Ic;
-    __host__ __device__ Layout(const Caps &c) : Kc(c.k), Oc(c.o), Fc(c.f), Ic(c.i) {}
+    int Kc, Oc, Sc, Fc, Ic;
+    __host__ __device__ Layout(const Caps &c) : Kc(c.k), Oc(c.o), Sc(c.s), Fc(c.f), Ic(c.i) {}
     // doubles
-    __host__ __device__ int d_wt() const { return 0; }
-    __host__ __device__ int d_wtp() const { return d_wt() + Oc * 2 * Fc; }
-    __host__ __device__ int d_qtf() const { return d_wtp() + 2 * Fc; }
-    __host__ __device__ int d_omz() const { return d_qtf() + Ic * Oc; }
+    __host__ __device__ int d_wt() const { return 0; }                       // [Oc][Sc][Fc]
+    __host__ __device__ int d_wtp() const { return d_wt() + Oc * Sc * Fc; }  // [Sc][Fc]
+    __host__ __device__ int d_qtf() const { return d_wtp() + Sc * Fc; }      // [Ic][Oc][Sc]
+    __host__ __device__ int d_omz() const { return d_qtf() + Ic * Oc * Sc; }
     __host__ __device__ int d_ohe() const { return d_omz() + Kc * Oc; }
-    __host__ __device__ int d_pk() const { return d_ohe() + Kc * Oc; }   // [4][Kc]: mzmean,height,area,merr
-    __host__ __device__ int d_po() const { return d_pk() + 4 * Kc; }     // [2][Oc]: esc, efc
-    __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]: hp, omzp
-    __host__ __device__ int n_double() const { return d_pi() + 2 * Ic; }
-    // floats (after the doubles)
-    __host__ __device__ int f_tile() const { return 0; }                 // [3][Kc*Oc*Fc]: fi, fm, ffp
-    __host__ __device__ int f_prec() const { return f_tile() + 3 * Kc * Oc * Fc; }  // [2][Ic*Fc]
-    __host__ __device__ int f_tpl() const { return f_prec() + 2 * Ic * Fc; }        // [2][Oc*Fc]
-    __host__ __device__ int f_bp() const { return f_tpl() + 2 * Oc * Fc; }          // [Kc*Fc]
-    __host__ __device__ int f_pk() const { return f_bp() + Kc * Fc; }    // [6][Kc]
-    __host__ __device__ int f_pko() const { return f_pk() + 6 * Kc; }    // [3][Kc*Oc]
-    __host__ __device__ int f_po() const { return f_pko() + 3 * Kc * Oc; }  // [4][Oc]
-    __host__ __device__ int f_pi() const { return f_po() + 4 * Oc; }     // [3][Ic]
-    __host__ __device__ int f_pf() const { return f_pi() + 3 * Ic; }     // [3][Fc]
-    __host__ __device__ int f_feat() const { return f_pf() + 3 * Fc; }
+    __host__ __device__ int d_pk() const { return d_ohe() + Kc * Oc; }   // [4][Kc]
+    __host__ __device__ int d_po() const { return d_pk() + 4 * Kc; }     // [2][Oc]
+    __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]
+    __host__ __device__ int d_frt() const { return d_pi() + 2 * Ic; }    // [Fc] frame rt (float64)
+    __host__ __device__ int n_double() const { return d_frt() + Fc; }
+    // floats
+    __host__ __device__ int f_tile() const { return 0; }                          // [2][Kc*Oc*Sc*Fc]
+    __host__ __device__ int f_ffp() const { return 2 * Kc * Oc * Sc * Fc; }       // [Kc*Oc*Fc]
+    __host__ __device__ int f_fsp() const { return f_ffp() + Kc * Oc * Fc; }      // [2][Kc*Oc*Sc] raw, env
+    __host__ __device__ int f_prec() const { return f_fsp() + 2 * Kc * Oc * Sc; } // [2][Ic*Sc*Fc]
+    __host__ __device__ int f_tpl() const { return f_prec() + 2 * Ic * Sc * Fc; } // [Oc*Sc*Fc]
+    __host__ __device__ int f_tfp() const { return f_tpl() + Oc * Sc * Fc; }      // [Oc*Fc]
+    __host__ __device__ int f_tsp() const { return f_tfp() + 2 * Oc * Fc; }       // [2][Oc*Sc] (tfp: raw, env)
+    __host__ __device__ int f_qm() const { return f_tsp() + 2 * Oc * Sc; }        // [Oc*Sc] qtf mask
+    __host__ __device__ int f_bp() const { return f_qm() + Oc * Sc; }             // [Kc*Fc]
+    __host__ __device__ int f_pk() const { return f_bp() + Kc * Fc; }             // [8][Kc]
+    __host__ __device__ int f_pko() const { return f_pk() + 8 * Kc; }             // [4][Kc*Oc]
+    __host__ __device__ int f_po() const { return f_pko() + 4 * Kc * Oc; }        // [4][Oc]
+    __host__ __device__ int f_pi() const { return f_po() + 4 * Oc; }              // [3][Ic]
+    __host__ __device__ int f_pf() const { return f_pi() + 3 * Ic; }              // [2][Fc]
+    __host__ __device__ int f_feat() const { return f_pf() + 2 * Fc; }
     __host__ __device__ int n_float() const { return f_feat() + ADH_NUM_FEATURES; }
-    // ints (after the floats)
-    __host__ __device__ int i_pk() const { return 0; }                   // [3][Kc]: present, kmap, ord
-    __host__ __device__ int i_pko() const { return i_pk() + 3 * Kc; }    // [Kc*Oc]: fpeak
+    // ints
+    __host__ __device__ int i_pk() const { return 0; }                   // [4][Kc]
+    __host__ __device__ int i_pko() const { return i_pk() + 4 * Kc; }    // [Kc*Oc]
     __host__ __device__ int i_obs() const { return i_pko() + Kc * Oc; }  // [Oc]
     __host__ __device__ int n_int() const { return i_obs() + Oc; }
-    // bytes (after the ints): [5][Kc]
     __host__ __device__ int n_byte() const { return ((5 * Kc + 7) / 8) * 8; }
     __host__ __device__ size_t bytes() const {
         size_t b = (size_t)n_double() * 8;
@@ -82,18 +80,18 @@ struct Layout {
     }
 };
 
-}  // namespace feat
+}  // namespace featim
 
-size_t adh_feature_lds_bytes(const Caps &c) { return feat::Layout(c).bytes(); }
+size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
 
-__global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
-    DevRun run, const CandRec *__restrict__ plan, const float *__restrict__ iso_table,
+__global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
     int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
     DevOut out, Caps caps) {
-    using namespace feat;
+    using namespace featim;
     extern __shared__ __align__(16) unsigned char smem[];
     const Layout lay(caps);
-    const int Kc = lay.Kc, Oc = lay.Oc, Fc = lay.Fc, Ic = lay.Ic;
+    const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
     float *const Fl = reinterpret_cast<float *>(smem + (size_t)lay.n_double() * 8);
     int *const In = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(Fl) +
@@ -101,70 +99,81 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     uint8_t *const By = reinterpret_cast<uint8_t *>(In) + ((size_t)lay.n_int() * 4 + 7) / 8 * 8;
 
     const int lane = threadIdx.x;
-    const CandRec &r = plan[blockIdx.x];
+    const CandRecIM &r = plan[blockIdx.x];
     if (r.flags & ADH_FLAG_SKIP) return;
     const unsigned char *block = scratch + r.scratch_off;
     const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
     const int K0 = (int)header[0];
-    if (K0 == 0) return;  // failed before / in the gather kernel
+    if (K0 == 0) return;
     const uint32_t row = r.row;
-    const int L = run.cycle_len;
-    const int c0 = r.frame_start / L;
-    const int F = r.frame_stop / L - c0;
-    const int O = r.n_obs;
+    const int L = run.cycle_len, z = run.zeroth;
+    const int c0 = (r.frame_start - z) / L;
+    const int F = (r.frame_stop - z) / L - c0;
+    const int S = r.scan_stop - r.scan_start;
+    const int O = r.n_obs, Op = r.n_ms1;
     const int I = min(n_iso_cols, (int)cfg.top_k_isotopes);
-    const int OF = O * F;
+    const int SF = S * F, OSF = O * SF;
     const int top_k = out.top_k;
     if (lane == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
 
-    // tiles
     float *const fi = Fl + lay.f_tile();
-    float *const fm = fi + Kc * Oc * Fc;
-    float *const ffp = fm + Kc * Oc * Fc;
+    float *const fm = fi + Kc * Oc * Sc * Fc;
+    float *const ffp = Fl + lay.f_ffp();
+    float *const fsp_raw = Fl + lay.f_fsp();
+    float *const fsp = fsp_raw + Kc * Oc * Sc;
     float *const pi = Fl + lay.f_prec();
-    float *const pm = pi + Ic * Fc;
+    float *const pm = pi + Ic * Sc * Fc;
     float *const tpl = Fl + lay.f_tpl();
-    float *const tfp = tpl + Oc * Fc;
+    float *const tfp_raw = Fl + lay.f_tfp();
+    float *const tfp = tfp_raw + Oc * Fc;
+    float *const tsp_raw = Fl + lay.f_tsp();
+    float *const tsp = tsp_raw + Oc * Sc;
+    float *const qmask = Fl + lay.f_qm();
     float *const bp = Fl + lay.f_bp();
-    // per-o / per-i / per-f floats
     float *const oi = Fl + lay.f_po();
     float *const tsum = oi + Oc;
-    float *const qmask = tsum + Oc;
-    float *const medpk = qmask + Oc;
+    float *const medpk = tsum + Oc;
     float *const iso_mz = Fl + lay.f_pi();
     float *const iso_int = iso_mz + Ic;
     float *const spi = iso_int + Ic;
-    float *const frame_rt = Fl + lay.f_pf();
-    float *const med = frame_rt + Fc;
+    float *const med = Fl + lay.f_pf();
     float *const xm = med + Fc;
     float *const featv = Fl + lay.f_feat();
     int *const present = In + lay.i_pk();
     int *const kmap = present + Kc;
     int *const ord = kmap + Kc;
+    int *const mkeep = ord + Kc;
     int *const fpeak = In + lay.i_pko();
     int *const obs = In + lay.i_obs();
     double *const qtf = D + lay.d_qtf();
+    double *const frame_rt = D + lay.d_frt();
 
-    // ---- load the tile: scratch cell ((o*F + f)*K0 + k) -> LDS [k][o][f]
+    // ---- load the tile [k][o][s][f]; collapse the MS1 observations (candidate.py:248-269)
     {
         const float2 *fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(r.k_cap));
-        const int n_fc = K0 * OF;
-        for (int c = lane; c < n_fc; c += ADH_WAVE) {
+        for (int c = lane; c < K0 * OSF; c += ADH_WAVE) {
             float2 v = fcells[c];
-            int k = c % K0, of = c / K0;
-            fi[k * OF + of] = v.x;
-            fm[k * OF + of] = v.y;
+            fi[c] = v.x;
+            fm[c] = v.y;
         }
-        const float2 *pcells =
-            reinterpret_cast<const float2 *>(block + adh_scratch_prec_off(r.k_cap, O, F));
-        for (int c = lane; c < I * F; c += ADH_WAVE) {
-            float2 v = pcells[c];
-            pi[c] = v.x;
-            pm[c] = v.y;
+        const float2 *pcells = reinterpret_cast<const float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
+        for (int c = lane; c < I * SF; c += ADH_WAVE) {
+            int i = c / SF, sf = c - i * SF;
+            float acc = 0.0f;
+            double sum = 0.0;
+            int count = 0;
+            for (int j = 0; j < Op; ++j) {
+                float2 v = pcells[(i * Op + j) * SF + sf];
+                acc += v.x;
+                sum += (double)v.y;
+                count += v.y > 0.0f;
+            }
+            pi[c] = acc;
+            pm[c] = (float)(sum / ((double)count + 1e-6));
         }
         if (lane < I) {
             iso_int[lane] = iso_table[(int64_t)row * n_iso_cols + lane];
-            double off = (double)lane * 1.0033548350700006 / (double)r.charge;  // candidate.py:158-163
+            double off = (double)lane * 1.0033548350700006 / (double)r.charge;
             iso_mz[lane] = (float)off + r.precursor_mz;
         }
         if (lane < O) obs[lane] = r.obs[lane];
@@ -172,51 +181,60 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     }
     __syncthreads();
 
-    // ---- quadrupole transfer function (quadrupole.py:261-301), n_scans == 1 (non-IM)
-    for (int c = lane; c < I * O; c += ADH_WAVE) {
-        int i = c / O, o = c - i * O;
-        const double *cy = run.cycle + 2 * ((int64_t)obs[o] * run.cycle_scans + r.scan_start);
+    // ---- quadrupole transfer function per (isotope, observation, scan) (quadrupole.py:261-301)
+    for (int c = lane; c < I * O * S; c += ADH_WAVE) {
+        int i = c / (O * S), rem = c - i * O * S;
+        int o = rem / S, sc = rem - o * S;
+        const double *cy = run.cycle + 2 * ((int64_t)obs[o] * run.scan_max + (r.scan_start + sc));
         double x = (double)iso_mz[i];
         qtf[c] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
     }
     __syncthreads();
-    if (lane < O) {
+    for (int c = lane; c < O * S; c += ADH_WAVE) {
         double sum = 0;
-        for (int i = 0; i < I; ++i) sum += qtf[i * O + lane];
-        qmask[lane] = (float)(sum / (double)I);  // candidate.py:287-289
+        for (int i = 0; i < I; ++i) sum += qtf[i * O * S + c];
+        qmask[c] = (float)(sum / (double)I);  // candidate.py:287-289
     }
     __syncthreads();
-    for (int c = lane; c < K0 * OF; c += ADH_WAVE) {
-        int o = (c % OF) / F;
-        fi[c] = fi[c] * qmask[o];  // candidate.py:290
+    for (int c = lane; c < K0 * OSF; c += ADH_WAVE) {
+        int os = (c % OSF) / F;  // o * S + s
+        fi[c] = fi[c] * qmask[os];
     }
-    // template (quadrupole.py:304-324); both scan slots are identical for non-IM data
-    for (int c = lane; c < OF; c += ADH_WAVE) {
-        int o = c / F, f = c - o * F;
+    // template (O, S, F) (quadrupole.py:304-324)
+    for (int c = lane; c < OSF; c += ADH_WAVE) {
+        int o = c / SF, sf = c - o * SF, sc = sf / F;
         double acc = 0;
         for (int i = 0; i < I; ++i) {
-            float a = pi[i * F + f] * iso_int[i];
-            acc += (double)a * qtf[i * O + o];
+            float a = pi[i * SF + sf] * iso_int[i];
+            acc += (double)a * qtf[(i * O + o) * S + sc];
         }
         tpl[c] = (float)acc;
     }
     __syncthreads();
 
-    // ---- observation importance (quadrupole.py:327-335) and fragment presence (candidate.py:319-329)
+    // ---- observation importance (quadrupole.py:327-335), fragment presence (candidate.py:319-329)
     float *const rowsum = Fl + lay.f_pko();
     float *const fw = rowsum + Kc * Oc;
     float *const ftc = fw + Kc * Oc;
+    float *const mfw = ftc + Kc * Oc;
     if (lane < O) {
-        float sf = 0;
-        for (int f = 0; f < F; ++f) sf += tpl[lane * F + f];
-        tsum[lane] = sf + sf;  // sum over the two identical scan slots
+        float so = 0;
+        for (int sc = 0; sc < S; ++sc) {
+            float sf = 0;
+            for (int f = 0; f < F; ++f) sf += tpl[(lane * S + sc) * F + f];
+            so += sf;
+        }
+        tsum[lane] = so;
     }
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
         for (int o = 0; o < O; ++o) {
-            float sf = 0;
-            for (int f = 0; f < F; ++f) sf += fi[(k * O + o) * F + f];
-            float ss = sf + sf;
+            float ss = 0;
+            for (int sc = 0; sc < S; ++sc) {
+                float sf = 0;
+                for (int f = 0; f < F; ++f) sf += fi[((k * O + o) * S + sc) * F + f];
+                ss += sf;
+            }
             rowsum[k * O + o] = ss;
             so += ss;
         }
@@ -239,13 +257,14 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     const int n_present = K;
     __syncthreads();
 
-    // ---- surviving fragments (fragment_container.py:104-120)
     float *const g_mzlib = Fl + lay.f_pk();
     float *const g_mz = g_mzlib + Kc;
     float *const g_int = g_mz + Kc;
     float *const g_fin = g_int + Kc;
     float *const obs_int = g_fin + Kc;
     float *const corr = obs_int + Kc;
+    float *const mnorm = corr + Kc;
+    float *const mlist = mnorm + Kc;
     uint8_t *const g_type = By;
     uint8_t *const g_loss = g_type + Kc;
     uint8_t *const g_charge = g_loss + Kc;
@@ -267,8 +286,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     }
     __syncthreads();
     {
-        // apply_mask renormalisation, then the second normalisation of
-        // fragment_features (fragment_features.py:218)
         float sum1 = 0;
         for (int k = 0; k < K; ++k) sum1 += g_int[k];
         __syncthreads();
@@ -279,29 +296,64 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         for (int k = lane; k < K; k += ADH_WAVE) g_fin[k] = g_int[k] / sum2;
     }
 
-    // ---- profiles (candidate.py:333-347; scoring/utils.py:26-66)
-    for (int c = lane; c < K * OF; c += ADH_WAVE) {
-        int k = c / OF, rem = c - k * OF;
-        float v = fi[kmap[k] * OF + rem];
-        ffp[c] = v + v;
+    // ---- profiles (candidate.py:333-347; scoring/utils.py:26-66); k is the compacted index
+    for (int c = lane; c < K * O * F; c += ADH_WAVE) {
+        int k = c / (O * F), rem = c - k * O * F;
+        int o = rem / F, f = rem - o * F;
+        const float *p = fi + ((kmap[k] * O + o) * S) * F + f;
+        float a = 0;
+        for (int sc = 0; sc < S; ++sc) a += p[sc * F];
+        ffp[c] = a;
     }
-    for (int c = lane; c < OF; c += ADH_WAVE) {
+    for (int c = lane; c < K * O * S; c += ADH_WAVE) {
+        int k = c / (O * S), rem = c - k * O * S;
+        const float *p = fi + (kmap[k] * O * S + rem) * F;
+        float a = 0;
+        for (int f = 0; f < F; ++f) a += p[f];
+        fsp_raw[c] = a;
+    }
+    for (int c = lane; c < O * F; c += ADH_WAVE) {
+        int o = c / F, f = c - o * F;
+        float a = 0;
+        for (int sc = 0; sc < S; ++sc) a += tpl[(o * S + sc) * F + f];
+        tfp_raw[c] = a;
+    }
+    for (int c = lane; c < O * S; c += ADH_WAVE) {
+        float a = 0;
+        for (int f = 0; f < F; ++f) a += tpl[c * F + f];
+        tsp_raw[c] = a;
+    }
+    for (int f = lane; f < F; f += ADH_WAVE) frame_rt[f] = run.rt[r.frame_start + f * L];
+    __syncthreads();
+    // OR-envelopes: interior points lower than a neighbour become the neighbours' mean
+    for (int c = lane; c < O * F; c += ADH_WAVE) {
         int f = c % F;
-        float x = tpl[c] + tpl[c];
-        float rr = x;
-        if (f >= 1 && f < F - 1) {
-            float xl = tpl[c - 1] + tpl[c - 1];
-            float xr = tpl[c + 1] + tpl[c + 1];
-            if (x < xl || x < xr) {
-                float sm = xl + xr;
-                rr = (float)((double)sm / 2.0);
-            }
+        float x = tfp_raw[c], rr = x;
+        if (f >= 1 && f < F - 1 && (x < tfp_raw[c - 1] || x < tfp_raw[c + 1])) {
+            float sm = tfp_raw[c - 1] + tfp_raw[c + 1];
+            rr = (float)((double)sm / 2.0);
         }
         tfp[c] = rr;
     }
-    const int n_frame_rt = F;  // frame_stop - frame_start is a multiple of the cycle length
-    for (int f = lane; f < F; f += ADH_WAVE) frame_rt[f] = run.rt[r.frame_start + f * L];
-    if (caps.stop_phase == 3) return;
+    for (int c = lane; c < K * O * S; c += ADH_WAVE) {
+        int sc = c % S;
+        float x = fsp_raw[c], rr = x;
+        if (sc >= 1 && sc < S - 1 && (x < fsp_raw[c - 1] || x < fsp_raw[c + 1])) {
+            float sm = fsp_raw[c - 1] + fsp_raw[c + 1];
+            rr = (float)((double)sm / 2.0);
+        }
+        fsp[c] = rr;
+    }
+    for (int c = lane; c < O * S; c += ADH_WAVE) {
+        int sc = c % S;
+        float x = tsp_raw[c], rr = x;
+        if (sc >= 1 && sc < S - 1 && (x < tsp_raw[c - 1] || x < tsp_raw[c + 1])) {
+            float sm = tsp_raw[c - 1] + tsp_raw[c + 1];
+            rr = (float)((double)sm / 2.0);
+        }
+        tsp[c] = rr;
+    }
+    __syncthreads();
 
     // =========================== features ===========================
     double *const wt = D + lay.d_wt();
@@ -310,21 +362,18 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     double *const efc = esc + Oc;
     double *const hp = D + lay.d_pi();
     double *const omzp = hp + Ic;
-    // precursor weight table around (scan, frame) = (S, 1) = (2, 1)
-    // (precursor_features.py:52-57, features_utils.py:9-25)
-    for (int c = lane; c < 2 * F; c += ADH_WAVE) {
+    // precursor weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
+    for (int c = lane; c < SF; c += ADH_WAVE) {
         int sc = c / F, f = c - sc * F;
-        double ds = (double)(sc - 2), df = (double)(f - 1);
-        double dist = sqrt(ds * ds + df * df);
-        wtp[c] = exp(-0.1 * dist);
+        double ds = (double)(sc - S), df = (double)(f - 1);
+        wtp[c] = exp(-0.1 * sqrt(ds * ds + df * df));
     }
-    // template centre of mass per observation (fragment_features.py:20-68)
     if (lane < O) {
         double isum = 0, ssum = 0, fsum = 0;
         bool any = false;
-        for (int sc = 0; sc < 2; ++sc)
+        for (int sc = 0; sc < S; ++sc)
             for (int f = 0; f < F; ++f) {
-                float v = tpl[lane * F + f];
+                float v = tpl[(lane * S + sc) * F + f];
                 if (v > 0.0f) {
                     any = true;
                     isum += (double)v;
@@ -336,44 +385,40 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         efc[lane] = (any && isum > 0) ? fsum / isum : 0.0;
     }
     if (lane < I) {
-        float sf = 0;
-        for (int f = 0; f < F; ++f) sf += pi[lane * F + f];
-        spi[lane] = sf + sf;
+        float ss = 0;
+        for (int sc = 0; sc < S; ++sc) {
+            float sf = 0;
+            for (int f = 0; f < F; ++f) sf += pi[(lane * S + sc) * F + f];
+            ss += sf;
+        }
+        spi[lane] = ss;
     }
     __syncthreads();
-    for (int c = lane; c < O * 2 * F; c += ADH_WAVE) {
-        int o = c / (2 * F), rem = c - o * 2 * F;
-        int sc = rem / F, f = rem - sc * F;
+    for (int c = lane; c < OSF; c += ADH_WAVE) {
+        int o = c / SF, sf = c - o * SF;
+        int sc = sf / F, f = sf - sc * F;
         double ds = (double)sc - esc[o], df = (double)f - efc[o];
-        double dist = sqrt(ds * ds + df * df);
-        wt[c] = exp(-0.1 * dist);
+        wt[c] = exp(-0.1 * sqrt(ds * ds + df * df));
     }
-    // precursor heights / observed m/z
     for (int c = lane; c < 2 * I; c += ADH_WAVE) {
         int i = c >> 1, plane = c & 1;
-        const float *p = (plane ? pm : pi) + i * F;
+        const float *p = (plane ? pm : pi) + i * SF;
         double values = 0, weights = 0;
         bool any = false;
-        for (int sc = 0; sc < 2; ++sc)
-            for (int f = 0; f < F; ++f) {
-                float v = p[f];
-                if (v > 0.0f) {
-                    any = true;
-                    double w = wtp[sc * F + f];
-                    values += (double)v * w;
-                    weights += w;
-                }
+        for (int sf = 0; sf < SF; ++sf) {
+            float v = p[sf];
+            if (v > 0.0f) {
+                any = true;
+                double w = wtp[sf];
+                values += (double)v * w;
+                weights += w;
             }
+        }
         double res = (any && weights > 0) ? values / weights : 0.0;
-        if (plane)
-            omzp[i] = res;
-        else
-            hp[i] = res;
+        if (plane) omzp[i] = res; else hp[i] = res;
     }
     __syncthreads();
-    if (caps.stop_phase == 4) return;
 
-    // ---- best profile + centre envelope (fragment_features.py:240-250)
     double *const omz = D + lay.d_omz();
     double *const ohe = D + lay.d_ohe();
     double *const mzmean = D + lay.d_pk();
@@ -394,9 +439,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
                 x[f] = a;
             }
         } else {
-            x = ffp + (k * O + best_obs) * F;  // a VIEW in the reference: mutated in place
+            x = ffp + (k * O + best_obs) * F;
         }
-        // center_envelope_1d (fragment_features.py:71-159)
         const int n = F;
         if (n >= 2) {
             if (n % 2 == 0) {
@@ -422,52 +466,42 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         }
         if (!cfg.quant_all)
             for (int f = 0; f < F; ++f) bp[k * F + f] = x[f];
-        // quantification window, trapezoid area (fragment_features.py:252-273)
         int qw = min(F / 2 - 1, (int)cfg.quant_window);
         int center = F / 2;
-        int a, b, ra, rb;
+        int a, b;
         py_slice(center - qw, center + qw + 1, F, a, b);
-        py_slice(center - qw, center + qw + 1, n_frame_rt, ra, rb);
         const float *p = bp + k * F + a;
         int W = b - a;
         double ar = 0;
-        for (int i = 0; i + 1 < W && ra + i + 1 < rb; ++i) {
+        for (int i = 0; i + 1 < W; ++i) {
             float sm = p[i + 1] + p[i];
-            float drt = frame_rt[ra + i + 1] - frame_rt[ra + i];
-            float m = sm * drt;
-            ar += (double)m * 0.5;
+            double drt = frame_rt[a + i + 1] - frame_rt[a + i];  // float64 rt_values
+            ar += (double)sm * drt * 0.5;                         // f32 * f64 -> f64
         }
         area[k] = ar * (double)qw;
         float t = 0;
         for (int i = 0; i < W; ++i) t += p[i];
         obs_int[k] = t;
     }
-    // ---- per (fragment, observation) weighted centre means (features_utils.py:9-37)
     for (int c = lane; c < 2 * K * O; c += ADH_WAVE) {
         int plane = c & 1, ko = c >> 1;
         int k = ko / O, o = ko - k * O;
-        const float *p = (plane ? fm : fi) + (kmap[k] * O + o) * F;
-        const double *w = wt + o * 2 * F;
+        const float *p = (plane ? fm : fi) + (kmap[k] * O + o) * SF;
+        const double *w = wt + o * SF;
         double values = 0, weights = 0;
         bool any = false;
-        for (int sc = 0; sc < 2; ++sc)
-            for (int f = 0; f < F; ++f) {
-                float v = p[f];
-                if (v > 0.0f) {
-                    any = true;
-                    double ww = w[sc * F + f];
-                    values += (double)v * ww;
-                    weights += ww;
-                }
+        for (int sf = 0; sf < SF; ++sf) {
+            float v = p[sf];
+            if (v > 0.0f) {
+                any = true;
+                values += (double)v * w[sf];
+                weights += w[sf];
             }
+        }
         double res = (any && weights > 0) ? values / weights : 0.0;
-        if (plane)
-            omz[ko] = res;
-        else
-            ohe[ko] = res;
+        if (plane) omz[ko] = res; else ohe[ko] = res;
     }
     __syncthreads();
-    // importance-weighted means over observations (fragment_features.py:311-336)
     for (int k = lane; k < K; k += ADH_WAVE) {
         float ws = 0;
         for (int o = 0; o < O; ++o) {
@@ -500,8 +534,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             }
         mzmean[k] = m1;
         height[k] = m2;
-        merr[k] = (m1 - (double)g_mz[k]) / (double)g_mz[k] * 1e6;  // fragment_features.py:387
-        // position of k in argsort(intensity)[::-1]
+        merr[k] = (m1 - (double)g_mz[k]) / (double)g_mz[k] * 1e6;
         int rk = 0;
         float ia = g_int[k];
         for (int b = 0; b < K; ++b) {
@@ -511,12 +544,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         ord[rk] = k;
     }
     __syncthreads();
-    if (caps.stop_phase == 5) return;
 
-    // ---- scalar feature assembly by lane 0 (short sequential float sums)
     Assemble asmv;
-    asmv.run = &run;
-    asmv.rec = &r;
+    asmv.run = nullptr;  // location features are float64 here, filled below
+    asmv.rec = nullptr;
     asmv.featv = featv;
     asmv.iso_int = iso_int; asmv.iso_mz = iso_mz; asmv.spi = spi; asmv.oi = oi; asmv.tsum = tsum;
     asmv.rowsum = rowsum; asmv.g_fin = g_fin; asmv.g_int = g_int; asmv.obs_int = obs_int;
@@ -524,14 +555,106 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     asmv.omzp = omzp; asmv.hp = hp; asmv.ohe = ohe; asmv.area = area; asmv.height = height;
     asmv.merr = merr; asmv.kmap = kmap; asmv.ord = ord; asmv.g_type = g_type; asmv.g_pos = g_pos;
     asmv.n_present = n_present; asmv.K0 = K0; asmv.top3 = 0.0f;
-    if (lane == 0) assemble_part1(asmv, I, O, K);
-    if (caps.stop_phase == 6) return;
+    if (lane == 0) {
+        feat::assemble_part1(asmv, I, O, K);
+        // location_features.py:8-33 with float64 mobility / rt arrays
+        featv[0] = (float)(run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1]);
+        featv[1] = (float)(run.rt[r.frame_stop - 1] - run.rt[r.frame_start]);
+        featv[2] = (float)run.rt[r.frame_center];
+        featv[3] = (float)run.mobility[r.scan_center];
+    }
+
+    // =========================== fragment_mobility_correlation (fragment_features.py:430-480)
+    // fi / fm are dead from here on: centred scan profiles go to fm, centred frame profiles later
+    __syncthreads();
+    float *cen = fm;
+    {
+        int Km = 0;
+        for (int k = 0; k < K; ++k) {
+            float so = 0;
+            for (int o = 0; o < O; ++o) {
+                float ss = 0;
+                for (int sc = 0; sc < S; ++sc) ss += fsp[(k * O + o) * S + sc];
+                so += ss;
+            }
+            if (so > 0.0f) {
+                if (lane == 0) mkeep[Km] = k;
+                ++Km;
+            }
+        }
+        __syncthreads();
+        if (Km >= 3) {
+            float isum = 0;
+            for (int a = 0; a < Km; ++a) isum += g_int[mkeep[a]];
+            for (int a = lane; a < Km; a += ADH_WAVE) mnorm[a] = g_int[mkeep[a]] / isum;
+            // centred rows + std per (a, o) over the scan axis (scoring/utils.py:545-559)
+            for (int c = lane; c < Km * O; c += ADH_WAVE) {
+                int a = c / O, o = c - a * O;
+                const float *p = fsp + (mkeep[a] * O + o) * S;
+                float sm = 0;
+                for (int sc = 0; sc < S; ++sc) sm += p[sc];
+                float mean = sm / (float)S;
+                float q = 0;
+                for (int sc = 0; sc < S; ++sc) cen[c * S + sc] = p[sc] - mean;
+                for (int sc = 0; sc < S; ++sc) q += cen[c * S + sc] * cen[c * S + sc];
+                mfw[c] = sqrtf(q / (float)S);
+            }
+            __syncthreads();
+            for (int a = lane; a < Km; a += ADH_WAVE) {
+                float acc = 0;
+                for (int b = 0; b < Km; ++b) {
+                    float red = 0;
+                    for (int o = 0; o < O; ++o) {
+                        float dot = 0;
+                        for (int sc = 0; sc < S; ++sc)
+                            dot += cen[(a * O + o) * S + sc] * cen[(b * O + o) * S + sc];
+                        float cov = dot / (float)S;
+                        float sm = mfw[a * O + o] * mfw[b * O + o];
+                        float cm = (float)((double)cov / ((double)sm + 1e-12));
+                        red += cm * oi[o];
+                    }
+                    acc += red * mnorm[b];
+                }
+                mlist[a] = acc;
+            }
+            // fragment vs template scan correlation (scoring/utils.py:574-647)
+            for (int c = lane; c < Km * O; c += ADH_WAVE) {
+                int a = c / O, o = c - a * O;
+                const float *py = tsp + o * S;
+                float sy = 0;
+                for (int sc = 0; sc < S; ++sc) sy += py[sc];
+                float ym = sy / (float)S;
+                float qy = 0;
+                for (int sc = 0; sc < S; ++sc) {
+                    float d = py[sc] - ym;
+                    qy += d * d;
+                }
+                float ysd = sqrtf(qy / (float)S);
+                float dot = 0;
+                for (int sc = 0; sc < S; ++sc) dot += cen[c * S + sc] * (py[sc] - ym);
+                float cov = dot / (float)S;
+                float sm = mfw[c] * ysd;
+                ftc[o * Km + a] = (float)((double)cov / ((double)sm + 1e-12));
+            }
+            __syncthreads();
+            if (lane == 0) {
+                float lsum = 0;
+                for (int a = 0; a < Km; ++a) lsum += mlist[a];
+                featv[29] = (float)((double)lsum / (double)Km);
+                float dot = 0;
+                for (int a = 0; a < Km; ++a) {
+                    float rr = 0;
+                    for (int o = 0; o < O; ++o) rr += ftc[o * Km + a] * oi[o];
+                    dot += rr * mnorm[a];
+                }
+                featv[30] = dot;
+            }
+        }
+    }
+    __syncthreads();
 
     // =========================== profile features (profile_features.py:18-206)
-    // fi / fm are dead from here on: reuse them as isl[K][F] and nrm[K][F]
-    __syncthreads();
-    float *isl = fi, *nrm = fm;
-    float *cen = fm;  // non-xic path: centred profiles [K][O][F] (nrm unused there)
+    float *isl = fi, *nrm = fm;  // fm is free again once the scan correlation is done
     if (cfg.experimental_xic) {
         for (int c = lane; c < K * F; c += ADH_WAVE) {
             int k = c / F, f = c - k * F;
@@ -540,7 +663,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             isl[c] = a;
         }
         __syncthreads();
-        // normalize_profiles (scoring_utils.py:71-117)
         int cidx = F / 2, wa, wb;
         py_slice(cidx - 1, cidx + 2, F, wa, wb);
         for (int k = lane; k < K; k += ADH_WAVE) {
@@ -551,7 +673,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
                 nrm[k * F + f] = (ci > 0) ? (float)((double)isl[k * F + f] / ci) : 0.0f;
         }
         __syncthreads();
-        // median over fragments per cycle (scoring_utils.py:120-152) by rank selection
         for (int f = lane; f < F; f += ADH_WAVE) {
             float lo_v = 0, hi_v = 0;
             int r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -566,16 +687,15 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
                 if (rk == r_hi) hi_v = va;
             }
             float m;
-            if (K & 1)
+            if (K & 1) {
                 m = hi_v;
-            else {
+            } else {
                 float sm = lo_v + hi_v;
                 m = (float)((double)sm / 2.0);
             }
             med[f] = m;
         }
         __syncthreads();
-        // correlation_coefficient (scoring_utils.py:14-68)
         float sx = 0;
         for (int f = 0; f < F; ++f) sx += med[f];
         float mx = (float)((double)sx / (double)F);
@@ -600,7 +720,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             corr[k] = (var_xy == 0) ? 0.0f : (float)(cov / sqrt(var_xy));
         }
     } else {
-        // fragment_correlation (scoring/utils.py:513-571): centred rows + std per (k, o)
         for (int c = lane; c < K * O; c += ADH_WAVE) {
             const float *p = ffp + c * F;
             float sm = 0;
@@ -609,10 +728,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             float q = 0;
             for (int f = 0; f < F; ++f) cen[c * F + f] = p[f] - mean;
             for (int f = 0; f < F; ++f) q += cen[c * F + f] * cen[c * F + f];
-            fw[c] = sqrtf(q / (float)F);  // std, parked in fw until the FWHM step
+            fw[c] = sqrtf(q / (float)F);
         }
         __syncthreads();
-        // list[a] = sum_b red[a][b] * intensity[b]; red = sum_o corr_o * importance_o
         for (int a = lane; a < K; a += ADH_WAVE) {
             float acc = 0;
             for (int b = 0; b < K; ++b) {
@@ -660,8 +778,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         }
     }
     __syncthreads();
-    // fragment-vs-template frame correlation (scoring/utils.py:574-647), FWHM and apex
-    const float rt_width = run.rt[r.frame_stop - 1] - run.rt[r.frame_start];
+    const double rt_width = run.rt[r.frame_stop - 1] - run.rt[r.frame_start];
+    const double mob_width = run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1];
     for (int c = lane; c < K * O; c += ADH_WAVE) {
         int k = c / O, o = c - k * O;
         const float *px = ffp + c * F;
@@ -689,7 +807,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         float cov = dot / (float)F;
         float sm = xsd * ysd;
         ftc[o * K + k] = (float)((double)cov / ((double)sm + 1e-12));
-        // FWHM in RT (profile_features.py:117-146) and apex (profile_features.py:192-193)
         float mxv = px[0];
         int am = 0;
         for (int f = 1; f < F; ++f)
@@ -702,11 +819,19 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         for (int f = 0; f < F; ++f) n_above += ((double)px[f] > half);
         double frac = (double)n_above / (double)F;
         fpeak[c] = am;
-        fw[c] = (float)(frac * (double)rt_width);  // std values parked here are dead by now
+        fw[c] = (float)(frac * rt_width);
+        // mobility FWHM (profile_features.py:151-188)
+        const float *ps = fsp + c * S;
+        float mxs = ps[0];
+        for (int sc = 1; sc < S; ++sc) mxs = ps[sc] > mxs ? ps[sc] : mxs;
+        double halfs = (double)mxs / 2.0;
+        int n_ab = 0;
+        for (int sc = 0; sc < S; ++sc) n_ab += ((double)ps[sc] > halfs);
+        double fracs = (double)n_ab / (double)S;
+        mfw[c] = (float)(fracs * mob_width);
     }
     __syncthreads();
     if (lane < O) {
-        // median of the apex index over fragments (profile_features.py:196-198)
         int o = lane;
         int lo_v = 0, hi_v = 0, r_lo = (K - 1) / 2, r_hi = K / 2;
         for (int a = 0; a < K; ++a) {
@@ -725,11 +850,17 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     __syncthreads();
     if (lane == 0) {
         asmv.top3 = top3;
-        assemble_part2(asmv, O, K, F);
+        feat::assemble_part2(asmv, O, K, F);
+        float agg = 0;
+        for (int k = 0; k < K; ++k) {
+            float ml = 0;
+            for (int o = 0; o < O; ++o) ml += mfw[k * O + o] * oi[o];
+            agg += ml * g_int[k];
+        }
+        featv[39] = agg;
     }
     __syncthreads();
 
-    // ---- write the row: features, fragment table, valid flag (candidate.py:403-481)
     if (lane < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + lane] = featv[lane];
     if (cfg.collect_fragments) {
         const int n = min(K, top_k);

@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "adh_create",
     "adh_destroy",
     "adh_stage_alpharaw",
+    "adh_stage_timstof",
     "adh_stage_fragments",
     "adh_score_candidates",
     "adh_upload_candidates",
@@ -96,6 +97,15 @@ class Context:
 
     def stage_run(self, dia, force: bool = False) -> bool:
         """Copy the run to HBM unless this very run is already staged."""
+        if hasattr(dia, "tof_indptr"):  # TimsTOFTransposeJIT layout (bruker_jit.py:22-137)
+            key = self._key(dia.mz_values, dia.intensity_values, dia.push_indices, dia.tof_indptr)
+            if not force and key == self._run_key:
+                return False
+            m = _abi.pack_timstof(dia)
+            _check(lib.adh_stage_timstof(self._h, m.ref()), "adh_stage_timstof")
+            self._run_key = key
+            self._run_keepalive = (dia.push_indices, dia.intensity_values)
+            return True
         key = self._key(dia.mz_values, dia.intensity_values, dia.peak_start_idx_list, dia.rt_values)
         if not force and key == self._run_key:
             return False

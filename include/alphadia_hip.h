@@ -187,6 +187,13 @@ int adh_destroy(adh_handle_t *handle);
  */
 int adh_stage_alpharaw(adh_handle_t *handle, const adh_alpharaw_t *dia);
 
+/*
+ * Stage an ion-mobility run (replaces TimsTOFTranspose.to_jitclass(),
+ * raw_data/bruker.py:119-152).  A handle holds ONE run: staging either layout
+ * replaces the previous one.
+ */
+int adh_stage_timstof(adh_handle_t *handle, const adh_timstof_t *dia);
+
 /* Stage the flat fragment library (replaces assemble_fragments, scoring.py:355-392). */
 int adh_stage_fragments(adh_handle_t *handle, const adh_fragments_t *fragments);
 

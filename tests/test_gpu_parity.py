@@ -284,3 +284,72 @@ def test_config2_scale_properties(ctx, oracle_lib):
     r0 = planted & (soa["rank"] == 0)
     assert got["valid"][r0].mean() > 0.99
     assert np.nanmean(got["features"][r0][:, 20]) > 0.9 > np.nanmean(got["features"][~planted][:, 20])
+
+
+# ---- ion-mobility (timsTOF) layout ---------------------------------------------------
+
+def _tims_case_from_golden():
+    import pandas as pd
+
+    z = np.load(H.golden_path("scoring_timstof.npz"))
+    dia = syn.TimsTOFArrays(
+        cycle=z["tims_cycle"], dia_precursor_cycle=z["tims_dia_precursor_cycle"],
+        rt_values=z["tims_rt_values"], mobility_values=z["tims_mobility_values"],
+        mz_values=z["tims_mz_values"], tof_indptr=z["tims_tof_indptr"],
+        push_indices=z["tims_push_indices"], intensity_values=z["tims_intensity_values"],
+        scan_max_index=int(z["tims_scan_max_index"]), zeroth_frame=bool(z["tims_zeroth_frame"]),
+    )
+    fragment_df = pd.DataFrame({c: z["frag_" + c] for c in H.FRAG_COLS})
+    precursor_df = pd.DataFrame({c: z["prec_" + c] for c in H.PREC_COLS})
+    cand = pd.DataFrame({c: z["cand_" + c] for c in H.CAND_COLS})
+    cfg = CandidateScoringConfig()
+    cfg.update({k: z["cfg_" + k].item() for k in H.CFG_KEYS})
+    return z, dia, fragment_df, precursor_df, cand, cfg
+
+
+def _hip_score_tims(ctx, dia, fragment_df, soa, cfg, with_stats=False):
+    ctx.stage_run(dia, force=True)
+    ctx.stage_fragments(*fragment_columns(fragment_df, "mz_library"), force=True)
+    return ctx.score_host(pack_assembled(soa), cfg.to_jitclass(), with_stats=with_stats)
+
+
+def test_timstof_golden_inputs(ctx, oracle_lib):
+    from alphadia_amd.scoring import assemble_candidates
+
+    z, dia, fragment_df, precursor_df, cand, cfg = _tims_case_from_golden()
+    soa = assemble_candidates(cand, precursor_df, "mz_library")
+    got = _hip_score_tims(ctx, dia, fragment_df, soa, cfg, with_stats=True)
+    exp = oracle_lib.score_timstof(dia, fragment_columns(fragment_df, "mz_library"), pack_assembled(soa),
+                                   cfg.to_jitclass(), with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"])
+    golden = {n: z["out_" + n] for n in H.OUT_NAMES}
+    compare(got, golden, PPM_ABS_TOL_GOLDEN, rel_tol=1e-3, corr_abs=2e-3)
+    v = got["valid"].astype(bool)
+    assert v.sum() > 100 and (got["features"][v][:, 29] != 0).sum() > 50
+
+
+def test_timstof_larger_case_all_configs(ctx, oracle_lib):
+    from alphadia_amd.scoring import assemble_candidates
+
+    case = syn.make_timstof_case(n_precursors=400, n_cycles=60, config_id=44, per_precursor=3,
+                                 n_ms2_frames=6, windows_per_frame=3, scan_max_index=96)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    for upd in (dict(quant_all=True, experimental_xic=True, top_k_isotopes=3, precursor_mz_tolerance=10,
+                     fragment_mz_tolerance=15),
+                dict(quant_all=False, experimental_xic=False),
+                dict(quant_all=True, experimental_xic=True, top_k_fragments=6, fragment_mz_tolerance=40)):
+        cfg = CandidateScoringConfig()
+        cfg.update(upd)
+        got = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg)
+        exp = oracle_lib.score_timstof(case.dia, fragment_columns(case.library.fragment_df, "mz_library"),
+                                       pack_assembled(soa), cfg.to_jitclass(), n_threads=8)
+        compare(got, exp, PPM_ABS_TOL_ORACLE)
+        assert got["valid"].sum() > 100
+
+
+def test_switching_run_layouts_on_one_handle(ctx, oracle_lib):
+    g = H.load_scoring_golden("handler_default")
+    got, soa = hip_score(ctx, g, g.config)
+    exp, _ = H.oracle_score(oracle_lib, g, g.config, soa=soa)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
