@@ -638,8 +638,8 @@ int build_plan_im(adh_handle *h, const adh_scoring_config_t *cfg) {
                         return fail(ADH_ERR_UNSUPPORTED, "a precursor overlaps more than 8 cycle rows");
                     r.obs[cnt] = (uint16_t)v;
                 } else {
-                    if (cnt >= ADH_MAX_OBS)
-                        return fail(ADH_ERR_UNSUPPORTED, "more than 8 unfragmented cycle rows in the scan range");
+                    if (cnt >= ADH_MAX_MS1_OBS)
+                        return fail(ADH_ERR_UNSUPPORTED, "more than 16 unfragmented cycle rows in the scan range");
                     r.ms1_obs[cnt] = (uint16_t)v;
                 }
                 ++cnt;

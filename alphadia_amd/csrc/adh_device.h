@@ -20,6 +20,7 @@
 
 #define ADH_WAVE 64
 #define ADH_MAX_OBS 8
+#define ADH_MAX_MS1_OBS 16
 
 struct DevRun {
     const float2 *peaks;      // [n_peaks] (mz, intensity)
@@ -103,11 +104,10 @@ struct __attribute__((aligned(16))) CandRecIM {
     uint8_t charge, rank, flags, n_obs;
     uint16_t obs[ADH_MAX_OBS];   // sorted unique dia_precursor_cycle values hit by the fragment quad range
     uint8_t n_ms1, pad8[3];
-    uint16_t ms1_obs[ADH_MAX_OBS];  // the same for the (-1, -1) precursor query
+    uint16_t ms1_obs[ADH_MAX_MS1_OBS];  // the same for the (-1, -1) precursor query
     uint32_t row, k_cap;
-    uint32_t pad32;
     uint64_t scratch_off;
-    uint64_t pad64[2];
+    uint64_t pad64;
 };
 static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 

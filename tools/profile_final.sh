@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-1 final profiling recipe (GPU box, from the repo root via gpurun).
+export TMPDIR=/tmp
+REPO=$PWD
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp
+for d in prof_stats prof_pmc1 prof_pmc2 prof_pmc3 prof_pmc4; do rm -rf $OUT/$d; done
+CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o r1 -- $CMD > $OUT/prof_stats.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM -d $OUT/prof_pmc1 -o r1 -- $CMD > $OUT/prof_pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA -d $OUT/prof_pmc2 -o r1 -- $CMD > $OUT/prof_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_pmc3 -o r1 -- $CMD > $OUT/prof_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/prof_pmc4 -o r1 -- $CMD > $OUT/prof_pmc4.log 2>&1
+python $REPO/tools/rocpd_summary.py $OUT/prof_stats/r1_results.db | cut -c1-70,110-400 | grep -v "at::native" | head -14
