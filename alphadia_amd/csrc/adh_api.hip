@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "adh_gather.hip"
 #include "adh_features.hip"
 #include "adh_features_fast.hip"
@@ -199,6 +201,69 @@ int adh_destroy(adh_handle_t *h) {
     return ADH_OK;
 }
 
+namespace {
+
+inline uint32_t float_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+// sort the peaks of the run into the transposed order and build entries + bin table
+int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, int64_t n_ref,
+                     int64_t n_tab, uint2 *entries, uint32_t *tab, DeviceBuffers &tmp) {
+    hipStream_t st = h->stream;
+    const int64_t n = d->n_peaks;
+    if (n_ref == 0 || d->n_spectra == 0) {
+        HIP_TRY(hipMemsetAsync(tab, 0, (size_t)n_tab * sizeof(uint32_t), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return ADH_OK;
+    }
+    const float *d_mz = nullptr, *d_int = nullptr;
+    const int64_t *d_ps = nullptr, *d_pe = nullptr;
+    int rc = upload(tmp, d->mz_values, n, &d_mz, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->intensity_values, n, &d_int, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_start_idx, d->n_spectra, &d_ps, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_stop_idx, d->n_spectra, &d_pe, st);
+    if (rc != ADH_OK) return rc;
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    uint32_t *v_in = nullptr, *v_out = nullptr;
+    int *d_bad = nullptr;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(p, bytes));
+        tmp.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    if ((rc = dev_alloc((void **)&k_in, (size_t)n * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&k_out, (size_t)n * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_in, (size_t)n * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_out, (size_t)n * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_bad, 4)) != ADH_OK) return rc;
+    // peaks no spectrum refers to keep the all-ones key and sort to the end
+    HIP_TRY(hipMemsetAsync(k_in, 0xFF, (size_t)n * 8, st));
+    HIP_TRY(hipMemsetAsync(v_in, 0, (size_t)n * 4, st));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+    hipLaunchKernelGGL(adh_peak_key_kernel, dim3((unsigned)d->n_spectra), dim3(256), 0, st, d_mz, d_ps,
+                       d_pe, d->n_spectra, (int)d->cycle_len, (int)r.block_shift, (int)r.bin0,
+                       (int)r.n_bins, k_in, v_in, d_bad);
+    HIP_TRY(hipGetLastError());
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
+    void *sort_tmp = nullptr;
+    if ((rc = dev_alloc(&sort_tmp, std::max<size_t>(sort_bytes, 16))) != ADH_OK) return rc;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
+    hipLaunchKernelGGL(adh_entries_kernel, dim3(8192), dim3(256), 0, st, k_out, v_out, d_int, n_ref,
+                       entries, tab, n_tab);
+    HIP_TRY(hipGetLastError());
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(ADH_ERR_INVALID_ARGUMENT, "m/z values are not ascending inside every spectrum");
+    return ADH_OK;
+}
+
+}  // namespace
+
 int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (d->cycle_len <= 0 || d->cycle_scans <= 0 || d->n_spectra < 0 || d->n_peaks < 0)
@@ -221,17 +286,24 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     // validate the CSR on the host: kernels index with it unchecked
     float mz_lo = 0.f, mz_hi = 0.f;
     bool any = false;
+    int64_t n_ref = 0, prev_stop = 0;
     for (int64_t s = 0; s < d->n_spectra; ++s) {
         int64_t a = d->peak_start_idx[s], b = d->peak_stop_idx[s];
         if (a < 0 || b < a || b > d->n_peaks)
             return fail(ADH_ERR_INVALID_ARGUMENT, "peak_start/stop_idx out of range");
         if (b > a) {
+            if (a < prev_stop)
+                return fail(ADH_ERR_INVALID_ARGUMENT, "spectra must not share peaks (peak_start_idx < previous peak_stop_idx)");
+            prev_stop = b;
+            n_ref += b - a;
             float lo = d->mz_values[a], hi = d->mz_values[b - 1];
             if (!any || lo < mz_lo) mz_lo = lo;
             if (!any || hi > mz_hi) mz_hi = hi;
             any = true;
         }
     }
+    if (any && !(mz_lo > 0.f && mz_hi >= mz_lo && mz_hi < INFINITY))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "m/z values must be positive, finite and ascending inside a spectrum");
     std::vector<int32_t> ms1;
     for (int r = 0; r < d->cycle_len * d->cycle_scans; ++r)
         if (-1.0 <= d->cycle[2 * r + 1] && -1.0 >= d->cycle[2 * r]) ms1.push_back(r);
@@ -248,55 +320,47 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     UP(h->run_buf, ms1.data(), (int64_t)ms1.size(), &r.ms1_obs);
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)d->cycle_len * d->cycle_scans * 2);
 
-    // peaks as (m/z, intensity) pairs
-    float2 *peaks = nullptr;
-    HIP_TRY(hipMalloc((void **)&peaks, (size_t)std::max<int64_t>(d->n_peaks, 1) * sizeof(float2)));
-    h->run_buf.ptrs.push_back(peaks);
-    r.peaks = peaks;
-    DeviceBuffers tmp;
-    const float *d_mz = nullptr, *d_int = nullptr;
-    const int64_t *d_ps = nullptr, *d_pe = nullptr;
-    int rc = upload(tmp, d->mz_values, d->n_peaks, &d_mz, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, d->intensity_values, d->n_peaks, &d_int, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, d->peak_start_idx, d->n_spectra, &d_ps, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, d->peak_stop_idx, d->n_spectra, &d_pe, h->stream);
-    if (rc != ADH_OK) {
-        tmp.release();
-        return rc;
+    // ---- transposed run (see adh_gather.hip): bins, block size, table size
+    if (!any) mz_lo = mz_hi = 1.0f;
+    r.mz_min = mz_lo;
+    r.mz_max = mz_hi;
+    r.bin0 = (int32_t)(float_bits(mz_lo) >> ADH_BIN_SHIFT);
+    r.n_bins = (int32_t)(float_bits(mz_hi) >> ADH_BIN_SHIFT) - r.bin0 + 1;
+    const int64_t L = d->cycle_len;
+    const int64_t n_cycles = (d->n_spectra + L - 1) / L;
+    // about two entries per (block, row, bin): B ~ 2 * n_bins / peaks per spectrum
+    int64_t avg = d->n_spectra > 0 ? std::max<int64_t>(n_ref / d->n_spectra, 1) : 1;
+    int64_t want = 2 * (int64_t)r.n_bins / avg;
+    if (const char *env = getenv("ADH_BLOCK_CYCLES")) want = atoll(env);
+    int bs = 3;
+    while (bs < 20 && (1ll << (bs + 1)) <= want) ++bs;
+    // the table must stay addressable with 32-bit bin ids and should not dwarf the peaks
+    for (;; ++bs) {
+        int64_t nblk = std::max<int64_t>((n_cycles + (1ll << bs) - 1) >> bs, 1);
+        int64_t n_tab = nblk * L * (int64_t)r.n_bins + 1;
+        if (bs >= 20 || (n_tab < (int64_t)0xFFFFFFF0ll && n_tab * 4 <= std::max<int64_t>(2 * n_ref * 8, 64ll << 20))) {
+            r.n_blocks = (int32_t)nblk;
+            break;
+        }
     }
-    if (d->n_peaks > 0) {
-        hipLaunchKernelGGL(adh_interleave_kernel, dim3(4096), dim3(256), 0, h->stream, d_mz, d_int,
-                           d->n_peaks, peaks);
-    }
+    r.block_shift = bs;
+    const int64_t n_tab = (int64_t)r.n_blocks * L * (int64_t)r.n_bins + 1;
+    if (n_tab >= (int64_t)0xFFFFFFF0ll)
+        return fail(ADH_ERR_UNSUPPORTED, "m/z range x cycle positions too large for the bin table");
 
-    // m/z bucket table: about two buckets per peak of an average spectrum
-    int64_t avg = d->n_spectra > 0 ? d->n_peaks / d->n_spectra : 0;
-    int64_t want = 2 * avg;
-    if (const char *env = getenv("ADH_BUCKETS")) want = atoll(env);
-    int nb = (int)std::min<int64_t>(std::max<int64_t>(want, 64), 16384);
-    float span = mz_hi - mz_lo;
-    if (!(span > 0.f)) span = 1.0f;
-    r.n_buckets = nb;
-    r.bucket_min = mz_lo;
-    r.bucket_inv_width = (float)nb / span;
-    uint2 *tab = nullptr;
-    size_t tbytes = (size_t)std::max<int64_t>(d->n_spectra, 1) * (size_t)(nb + 2) * sizeof(uint2);
-    hipError_t e = hipMalloc((void **)&tab, tbytes);
-    if (e != hipSuccess) {
-        tmp.release();
-        return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(bucket table): ") + hipGetErrorString(e));
-    }
+    uint2 *entries = nullptr;
+    uint32_t *tab = nullptr;
+    HIP_TRY(hipMalloc((void **)&entries, (size_t)std::max<int64_t>(n_ref, 1) * sizeof(uint2)));
+    h->run_buf.ptrs.push_back(entries);
+    HIP_TRY(hipMalloc((void **)&tab, (size_t)n_tab * sizeof(uint32_t)));
     h->run_buf.ptrs.push_back(tab);
+    r.entries = entries;
     r.tab = tab;
-    if (d->n_spectra > 0) {
-        hipLaunchKernelGGL(adh_bucket_build_kernel, dim3((unsigned)d->n_spectra), dim3(256), 0,
-                           h->stream, r.peaks, d_ps, d_pe, r.n_spectra, tab, nb, r.bucket_min,
-                           r.bucket_inv_width);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+
+    DeviceBuffers tmp;
+    int rc = stage_transposed(h, d, r, n_ref, n_tab, entries, tab, tmp);
     tmp.release();
-    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("staging kernels: ") + hipGetErrorString(e));
+    if (rc != ADH_OK) return rc;
     h->run = r;
     h->run_staged = true;
     return ADH_OK;
@@ -748,7 +812,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     if (const char *dbg = getenv("ADH_DEBUG_STOP_PHASE")) stop_phase = atoi(dbg);  // developer switch
 
     Caps gcaps = p.caps_all;
-    const size_t g_lds = adh_gather_lds_bytes(gcaps);
+    const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
     p.caps_generic.stop_phase = stop_phase;
     const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
     if (p.n_class[3] > 0 && f_lds > 160 * 1024) {
@@ -758,7 +822,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
                  p.caps_generic.k, p.caps_generic.o, p.caps_generic.f);
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
-    if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice too long for the gather kernel");
+    if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice / MS1 tile too large for the gather kernel");
 
     adh_handle::Timed t;
     rc = get_event(h, &t.e0);

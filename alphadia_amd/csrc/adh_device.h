@@ -22,9 +22,15 @@
 #define ADH_MAX_OBS 8
 #define ADH_MAX_MS1_OBS 16
 
+// m/z bin of the transposed run = float32 bit pattern >> ADH_BIN_SHIFT: exactly monotone,
+// relative width 2^-14 (30.5 .. 61 ppm)
+#define ADH_BIN_SHIFT 9
+
 struct DevRun {
-    const float2 *peaks;      // [n_peaks] (mz, intensity)
-    const uint2 *tab;         // [n_spectra][n_buckets + 2]: (peak offset, m/z bits of that peak)
+    // peaks sorted by (block of 2^block_shift cycles, cycle row, m/z bin, cycle, m/z):
+    // .x = (cycle inside the block << ADH_BIN_SHIFT) | low m/z bits, .y = intensity bits
+    const uint2 *entries;
+    const uint32_t *tab;      // [(n_blocks * cycle_len) * n_bins + 1] first entry of every bin
     const float *rt;          // [n_spectra]
     const float *mobility;    // [n_mobility]
     const double *cycle;      // [cycle_len * cycle_scans * 2]
@@ -34,9 +40,11 @@ struct DevRun {
     int32_t cycle_len;
     int32_t cycle_scans;
     int32_t n_ms1_obs;
-    int32_t n_buckets;
-    float bucket_min;         // m/z of bucket 0
-    float bucket_inv_width;   // 1 / width
+    int32_t n_bins;           // m/z bins per (block, row)
+    int32_t bin0;             // bit pattern >> ADH_BIN_SHIFT of the smallest m/z
+    int32_t block_shift;      // log2(cycles per block)
+    int32_t n_blocks;
+    float mz_min, mz_max;     // smallest / largest m/z of the run
 };
 
 // one library fragment (fragment_container.py:11-46), 32 bytes
@@ -135,10 +143,3 @@ struct Caps {
     int32_t op;      // MS1 observations (ion-mobility kernels only)
 };
 
-// monotone bucket function shared by index build and lookup
-__host__ __device__ inline int adh_bucket_of(float mz, float bmin, float binv, int nb) {
-    float t = (mz - bmin) * binv;
-    if (!(t > 0.0f)) return 0;
-    if (t >= (float)nb) return nb;
-    return (int)t;
-}

@@ -6,19 +6,21 @@
 //   AlphaRawJIT.get_dense (x2)    alphadia/search/jitclasses/alpharaw_jit.py:208-337
 //   MS1 observation collapse      alphadia/search/scoring/containers/candidate.py:248-269
 //
-// This kernel is the latency-/HBM-bound half of the path, so it is kept free of
-// large LDS tiles (high occupancy) and is written for memory-level parallelism:
-//   * the reference walks the K sorted m/z windows of a spectrum with one monotone
-//     cursor and a binary search per window (alpharaw_jit.py:290-297).  The cursor
-//     after window k is "first peak with m/z > max(hi_0..hi_k)", so every
-//     (fragment, observation, cycle) cell is independent: start at the first peak
-//     with m/z >= lo_k and m/z > max(hi_j, j < k)
-//   * the window start comes from a per-spectrum m/z bucket table (one 4-byte load
-//     with an absolute peak offset) followed by a short forward scan; peaks are
-//     (m/z, intensity) pairs so a hit costs no extra dependent load
-//   * each lane keeps four cells in flight: the four table loads are issued
-//     together, then the four first-peak loads, then the scans are resolved
-//   * lanes that are adjacent in k read the same spectrum (same sectors)
+// The reference answers "which peaks of spectrum s fall into m/z window k" with one binary
+// search per (window, spectrum): a candidate of F cycles costs F random probes per
+// fragment.  A chromatogram is contiguous in time, so the run is staged TRANSPOSED:
+// peaks are sorted by (cycle row, block of B consecutive cycles, m/z bin, cycle, m/z), the
+// m/z bin being the upper bits of the float32 pattern (exactly monotone, ~30-60 ppm
+// wide).  The XIC of one fragment over F cycles is then one or two short contiguous
+// runs of 8-byte entries, found through one table lookup each:
+//   * the reference's monotone cursor (alpharaw_jit.py:290-297) makes window k start at
+//     the first peak with m/z >= lo_k and m/z > max(hi_j, j < k); every peak is tested
+//     against exactly these float32 bounds, so the same peaks are selected
+//   * the entries of a cell (same cycle) are visited in ascending m/z (bins ascending,
+//     m/z ascending inside a bin, equal m/z in input order), so the running
+//     intensity-weighted m/z (alpharaw_jit.py:299-335) is reproduced bit for bit
+//   * one lane owns one (window, observation, block) task; its cells are private, so
+//     continuing a cell across bins is a plain load of the cell's state
 // Results (selected fragments + the two-channel tile) go to a per-candidate scratch
 // block in HBM that the feature kernel reads back coalesced.
 #include "adh_device.h"
@@ -26,64 +28,93 @@
 namespace gather {
 
 constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
-constexpr int UNROLL = 4;
 
-struct Cell {
-    uint32_t idx, pe;
-    float2 p;
-    float lo, hi, excl, first_mz;
-    bool live;
+struct Window {
+    float lo, hi, excl;
+    int b_lo, b_hi;  // bin range relative to run.bin0; b_hi < b_lo: nothing can match
 };
 
-// accumulate one window starting at (idx, p): alpharaw_jit.py:299-335, absolute_masses=True
-__device__ __forceinline__ void resolve(const DevRun &run, Cell &c, float &acc_i, float &acc_m,
-                                        uint32_t &hits) {
-    acc_i = 0.0f;
-    acc_m = 0.0f;
-    if (!c.live) return;
-    uint32_t idx = c.idx;
-    float2 p = c.p;
-    while (idx < c.pe && !(p.x >= c.lo && p.x > c.excl)) {
-        ++idx;
-        if (idx < c.pe) p = run.peaks[idx];
-    }
-    while (idx < c.pe && p.x <= c.hi) {
-        float ni = p.y;
-        ni = ((double)ni > 1e-26) ? ni : ni * 0.0f;
-        float a = acc_m * acc_i;
-        float b = ni * p.x;
-        float n32 = a + b;
-        float d32 = acc_i + ni;
-        acc_m = (float)(((double)n32 + 1e-36) / ((double)d32 + 1e-36));
-        acc_i = d32;
-        ++hits;
-        ++idx;
-        if (idx < c.pe) p = run.peaks[idx];
-    }
+__device__ __forceinline__ void bins_of(const DevRun &run, Window &w) {
+    const int nb = run.n_bins;
+    int lo = 0, hi = nb - 1;
+    if (w.lo > run.mz_min) lo = (int)(__float_as_uint(w.lo) >> ADH_BIN_SHIFT) - run.bin0;
+    if (w.hi < run.mz_max) hi = (int)(__float_as_uint(w.hi) >> ADH_BIN_SHIFT) - run.bin0;
+    if (!(w.hi >= run.mz_min) || !(w.lo <= run.mz_max)) hi = -1, lo = 0;  // also NaN windows
+    w.b_lo = min(max(lo, 0), nb);
+    w.b_hi = min(hi, nb - 1);
 }
 
-__device__ __forceinline__ void issue_tab(const DevRun &run, Cell &c, int64_t spec) {
-    const uint2 *t = run.tab + spec * (int64_t)(run.n_buckets + 2);
-    const int b = adh_bucket_of(c.lo, run.bucket_min, run.bucket_inv_width, run.n_buckets);
-    const uint2 e = t[b];
-    c.idx = e.x;
-    c.first_mz = __uint_as_float(e.y);  // +inf when no peak at/after this bucket
-    c.pe = t[run.n_buckets + 1].x;
+// one step of the running sums, alpharaw_jit.py:299-335 with absolute_masses=True
+__device__ __forceinline__ void fold(float &acc_i, float &acc_m, float mz, float ni) {
+    ni = ((double)ni > 1e-26) ? ni : ni * 0.0f;
+    float a = acc_m * acc_i;
+    float b = ni * mz;
+    float n32 = a + b;
+    float d32 = acc_i + ni;
+    acc_m = (float)(((double)n32 + 1e-36) / ((double)d32 + 1e-36));
+    acc_i = d32;
 }
 
-__device__ __forceinline__ void issue_peak(const DevRun &run, Cell &c) {
-    c.p = make_float2(INFINITY, 0.0f);
-    // the table already knows the m/z of peaks[idx]: beyond the window -> nothing to gather,
-    // and no second sector has to be fetched
-    if (c.first_mz > c.hi) c.live = false;
-    if (c.live && c.idx < c.pe) c.p = run.peaks[c.idx];
+// Gather one (window, cycle row, block) task.  `cells` is indexed cells[f * stride] for
+// f = cycle - c0; the cells must be zero on entry.
+template <typename CellPtr>
+__device__ __forceinline__ void gather_task(const DevRun &run, const Window &w, int row, int blk,
+                                            int c0, int F, CellPtr cells, int stride,
+                                            uint32_t &hits) {
+    if (w.b_hi < w.b_lo) return;
+    const int bs = run.block_shift;
+    const int cyc_base = blk << bs;
+    const int f_lo = max(c0, cyc_base) - cyc_base;              // block-relative cycle range
+    const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - cyc_base;
+    const uint32_t *t = run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
+    uint32_t idx = t[w.b_lo];
+    const uint32_t end = t[w.b_hi + 1];
+    if (idx >= end) return;
+    int b = w.b_lo;
+    uint32_t b_end = (w.b_hi > w.b_lo) ? t[b + 1] : end;
+    int cur = -1;  // open cell (block-relative cycle), -1: none
+    float acc_i = 0.0f, acc_m = 0.0f;
+    while (idx < end) {
+        // four entries in flight; the tail repeats the last one (harmless, skipped below)
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = idx + (uint32_t)u;
+            if (i >= end) break;
+            while (i >= b_end) {  // next bin: cycles start over
+                ++b;
+                b_end = (b < w.b_hi) ? t[b + 1] : end;
+            }
+            const int cyc = (int)(e[u].x >> ADH_BIN_SHIFT);
+            if (cyc < f_lo || cyc >= f_hi) continue;
+            const float mz = __uint_as_float(((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) |
+                                             (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u)));
+            if (!(mz >= w.lo && mz > w.excl) || !(mz <= w.hi)) continue;
+            if (cyc != cur) {
+                if (cur >= 0) cells[(cur + cyc_base - c0) * stride] = make_float2(acc_i, acc_m);
+                float2 v = make_float2(0.0f, 0.0f);
+                if (b > w.b_lo) v = cells[(cyc + cyc_base - c0) * stride];  // continue from an earlier bin
+                acc_i = v.x;
+                acc_m = v.y;
+                cur = cyc;
+            }
+            fold(acc_i, acc_m, mz, __uint_as_float(e[u].y));
+            ++hits;
+        }
+        idx += 4;
+    }
+    if (cur >= 0) cells[(cur + cyc_base - c0) * stride] = make_float2(acc_i, acc_m);
 }
 
 }  // namespace gather
 
-size_t adh_gather_lds_bytes(const Caps &c) {
-    size_t b = (size_t)c.n_lib * (4 + 4 + 4 + 4);  // l_int, l_mz, l_rank, l_ok (as int)
-    b += (size_t)(c.k + c.i) * 3 * 4;               // lo, hi, excl for fragments and isotopes
+size_t adh_gather_lds_bytes(const Caps &c, int n_ms1_obs) {
+    size_t b = (size_t)c.n_lib * (4 + 4 + 4 + 4);        // l_int, l_mz, l_rank, l_ok (as int)
+    b += (size_t)(c.k + c.i) * sizeof(gather::Window);     // windows of fragments and isotopes
+    b = (b + 7) / 8 * 8;
+    b += (size_t)c.i * (size_t)std::max(n_ms1_obs, 1) * (size_t)c.f * sizeof(float2);  // raw MS1 cells
     return (b + 15) / 16 * 16;
 }
 
@@ -97,9 +128,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
     float *l_mz = l_int + caps.n_lib;
     int *l_rank = reinterpret_cast<int *>(l_mz + caps.n_lib);
     int *l_ok = l_rank + caps.n_lib;
-    float *w_lo = reinterpret_cast<float *>(l_ok + caps.n_lib);
-    float *w_hi = w_lo + caps.k + caps.i;
-    float *w_ex = w_hi + caps.k + caps.i;
+    Window *win = reinterpret_cast<Window *>(l_ok + caps.n_lib);
+    float2 *raw1 = reinterpret_cast<float2 *>(
+        smem + ((size_t)caps.n_lib * 16 + (size_t)(caps.k + caps.i) * sizeof(Window) + 7) / 8 * 8);
 
     const int lane = threadIdx.x;
     const CandRec &r = plan[blockIdx.x];
@@ -166,8 +197,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
         // mass_range (jitclasses/utils.py:15-20): float32 throughout
         float t = cfg.fragment_mz_tolerance * ma;
         float q = t / 1000000.0f;
-        w_lo[slot] = ma - q;
-        w_hi[slot] = ma + q;
+        win[slot].lo = ma - q;
+        win[slot].hi = ma + q;
     }
     // isotope m/z (candidate.py:151-163) and their windows
     const int I = min(n_iso_cols, (int)cfg.top_k_isotopes);
@@ -176,54 +207,53 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
         float mzq = (float)off + r.precursor_mz;
         float t = cfg.precursor_mz_tolerance * mzq;
         float q = t / 1000000.0f;
-        w_lo[caps.k + lane] = mzq - q;
-        w_hi[caps.k + lane] = mzq + q;
+        win[caps.k + lane].lo = mzq - q;
+        win[caps.k + lane].hi = mzq + q;
     }
     __syncthreads();
     if (lane == 0) {
         float e = -INFINITY;
         for (int k = 0; k < K; ++k) {
-            w_ex[k] = e;
-            e = fmaxf(e, w_hi[k]);
+            win[k].excl = e;
+            e = fmaxf(e, win[k].hi);
         }
         e = -INFINITY;
         for (int i = 0; i < I; ++i) {
-            w_ex[caps.k + i] = e;
-            e = fmaxf(e, w_hi[caps.k + i]);
+            win[caps.k + i].excl = e;
+            e = fmaxf(e, win[caps.k + i].hi);
+        }
+    }
+    for (int w = lane; w < K + I; w += ADH_WAVE) bins_of(run, win[w < K ? w : caps.k + (w - K)]);
+
+    // ---- zero the tile: fragment cells ((o * F + f) * K + k) in scratch, raw MS1 cells in LDS
+    float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
+    const int n_fc = K * O * F;
+    const int M1 = run.n_ms1_obs;
+    for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
+    for (int c = lane; c < I * M1 * F; c += ADH_WAVE) raw1[c] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+
+    // ---- (window, observation, block) tasks
+    uint32_t hits = 0;
+    const int bs = run.block_shift;
+    const int blk0 = c0 >> bs;
+    const int n_blk = ((c0 + F - 1) >> bs) - blk0 + 1;
+    const int n_ft = K * O * n_blk;
+    const int n_tasks = n_ft + I * M1 * n_blk;
+    for (int t = lane; t < n_tasks; t += ADH_WAVE) {
+        if (t < n_ft) {
+            const int bi = t % n_blk, ko = t / n_blk;
+            const int k = ko % K, o = ko / K;
+            gather_task(run, win[k], (int)r.obs[o], blk0 + bi, c0, F, fcells + (o * F) * K + k, K, hits);
+        } else {
+            const int u = t - n_ft;
+            const int bi = u % n_blk, ij = u / n_blk;
+            const int i = ij / M1, j = ij - i * M1;
+            gather_task(run, win[caps.k + i], run.ms1_obs[j], blk0 + bi, c0, F, raw1 + (i * M1 + j) * F, 1, hits);
         }
     }
     __syncthreads();
-
-    // ---- fragment cells, index ((o * F + f) * K + k): k fastest
-    uint32_t hits = 0;
-    float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
-    const int n_fc = K * O * F;
-    for (int base = 0; base < n_fc; base += ADH_WAVE * UNROLL) {
-        Cell cell[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            int c = base + u * ADH_WAVE + lane;
-            cell[u].live = c < n_fc;
-            int cc = cell[u].live ? c : 0;
-            int k = cc % K, of = cc / K;
-            int o = of / F, f = of - o * F;
-            cell[u].lo = w_lo[k];
-            cell[u].hi = w_hi[k];
-            cell[u].excl = w_ex[k];
-            int64_t spec = (int64_t)r.obs[o] + (int64_t)(c0 + f) * L;
-            issue_tab(run, cell[u], spec);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) issue_peak(run, cell[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            float ai, am;
-            resolve(run, cell[u], ai, am, hits);
-            int c = base + u * ADH_WAVE + lane;
-            if (c < n_fc) fcells[c] = make_float2(ai, am);
-        }
-    }
-    // ---- precursor cells (i * F + f), MS1 observations collapsed (candidate.py:248-269)
+    // ---- precursor cells (i * F + f): MS1 observations collapsed (candidate.py:248-269)
     float2 *pcells = reinterpret_cast<float2 *>(block + adh_scratch_prec_off(r.k_cap, O, F));
     const int n_pc = I * F;
     for (int c = lane; c < n_pc; c += ADH_WAVE) {
@@ -231,20 +261,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
         float acc = 0.0f;
         double sum = 0.0;
         int count = 0;
-        for (int j = 0; j < run.n_ms1_obs; ++j) {
-            Cell cell;
-            cell.live = true;
-            cell.lo = w_lo[caps.k + i];
-            cell.hi = w_hi[caps.k + i];
-            cell.excl = w_ex[caps.k + i];
-            int64_t spec = (int64_t)run.ms1_obs[j] + (int64_t)(c0 + f) * L;
-            issue_tab(run, cell, spec);
-            issue_peak(run, cell);
-            float ai, am;
-            resolve(run, cell, ai, am, hits);
-            acc += ai;
-            sum += (double)am;
-            count += am > 0.0f;
+        for (int j = 0; j < M1; ++j) {
+            const float2 v = raw1[(i * M1 + j) * F + f];
+            acc += v.x;
+            sum += (double)v.y;
+            count += v.y > 0.0f;
         }
         pcells[c] = make_float2(acc, (float)(sum / ((double)count + 1e-6)));
     }
@@ -256,31 +277,45 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
 }
 
 // ------------------------------------------------------------------ staging kernels
-// (m/z, intensity) -> float2 pairs
-__global__ void adh_interleave_kernel(const float *__restrict__ mz, const float *__restrict__ inten,
-                                      int64_t n, float2 *__restrict__ peaks) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) peaks[i] = make_float2(mz[i], inten[i]);
+// sort key of every peak: high word = ((block * L + row) * n_bins + bin), low word =
+// (cycle inside the block << ADH_BIN_SHIFT) | low m/z bits.  One workgroup per spectrum.
+__global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t *__restrict__ pstart,
+                                    const int64_t *__restrict__ pstop, int64_t n_spectra, int L,
+                                    int block_shift, int bin0, int n_bins,
+                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                    int *__restrict__ bad) {
+    const int64_t spec = blockIdx.x;
+    if (spec >= n_spectra) return;
+    const int64_t cyc = spec / L;
+    const int row = (int)(spec - cyc * L);
+    const int64_t blk = cyc >> block_shift;
+    const uint32_t cin = (uint32_t)(cyc - (blk << block_shift));
+    const uint64_t seg = (uint64_t)(blk * L + row) * (uint64_t)n_bins;
+    const int64_t ps = pstart[spec], pe = pstop[spec];
+    for (int64_t j = ps + threadIdx.x; j < pe; j += blockDim.x) {
+        const uint32_t bits = __float_as_uint(mz[j]);
+        const int b = (int)(bits >> ADH_BIN_SHIFT) - bin0;
+        if (b < 0 || b >= n_bins) {  // outside [first, last] peak of some spectrum: not sorted
+            *bad = 1;
+            continue;
+        }
+        keys[j] = ((seg + (uint64_t)b) << 32) |
+                  (uint64_t)((cin << ADH_BIN_SHIFT) | (bits & ((1u << ADH_BIN_SHIFT) - 1u)));
+        vals[j] = (uint32_t)j;
+    }
 }
 
-// bucket table of one spectrum per block: tab[b] = absolute index of the first peak whose
-// bucket is >= b (b = 0..nb), tab[nb + 1] = end of the spectrum
-__global__ void adh_bucket_build_kernel(const float2 *__restrict__ peaks,
-                                        const int64_t *__restrict__ pstart,
-                                        const int64_t *__restrict__ pstop, int64_t n_spectra,
-                                        uint2 *__restrict__ tab, int nb, float bmin, float binv) {
-    int64_t spec = blockIdx.x;
-    if (spec >= n_spectra) return;
-    const int64_t ps = pstart[spec], pe = pstop[spec];
-    uint2 *t = tab + spec * (int64_t)(nb + 2);
-    const int64_t n = pe - ps;
-    for (int64_t j = threadIdx.x; j <= n; j += blockDim.x) {
-        int b_prev = (j == 0) ? -1 : adh_bucket_of(peaks[ps + j - 1].x, bmin, binv, nb);
-        int b_cur = (j == n) ? nb : adh_bucket_of(peaks[ps + j].x, bmin, binv, nb);
-        const float mzj = (j == n) ? INFINITY : peaks[ps + j].x;
-        for (int b = b_prev + 1; b <= b_cur; ++b)
-            t[b] = make_uint2((uint32_t)(ps + j), __float_as_uint(mzj));
+// sorted keys -> 8-byte entries (low key word, intensity) + the bin table:
+// tab[g] = index of the first entry whose global bin is >= g, for g = 0..n_tab-1
+__global__ void adh_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                   const float *__restrict__ inten, int64_t n, uint2 *__restrict__ entries,
+                                   uint32_t *__restrict__ tab, int64_t n_tab) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i <= n; i += stride) {
+        const int64_t g_prev = (i == 0) ? -1 : (int64_t)(keys[i - 1] >> 32);
+        const int64_t g_cur = (i == n) ? n_tab - 1 : (int64_t)(keys[i] >> 32);
+        for (int64_t g = g_prev + 1; g <= g_cur; ++g) tab[g] = (uint32_t)i;
+        if (i < n) entries[i] = make_uint2((uint32_t)keys[i], __float_as_uint(inten[vals[i]]));
     }
-    if (threadIdx.x == 0) t[nb + 1] = make_uint2((uint32_t)pe, __float_as_uint(INFINITY));
 }
