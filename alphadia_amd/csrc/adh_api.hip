@@ -68,7 +68,9 @@ struct Plan {
     unsigned char *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // classes 0..2: register kernels for F <= 16 / 24 / 32; class 3: generic LDS kernel
-    int64_t n_class[4] = {0, 0, 0, 0};
+    // classes 0..5: register kernels, index = (observations - 1) * 3 + cycle class; 6: generic
+    int64_t n_class[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool quant_all = false;
     Caps caps_generic;
     Caps caps_all;
 };
@@ -328,9 +330,10 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     r.n_bins = (int32_t)(float_bits(mz_hi) >> ADH_BIN_SHIFT) - r.bin0 + 1;
     const int64_t L = d->cycle_len;
     const int64_t n_cycles = (d->n_spectra + L - 1) / L;
-    // about two entries per (block, row, bin): B ~ 2 * n_bins / peaks per spectrum
+    // about one entry per two (block, row, bin) cells: B ~ n_bins / (2 * peaks per spectrum).
+    // Measured on the bench run: gather 0.88 / 0.92 / 1.06 / 1.34 ms for B = 16 / 32 / 64 / 128.
     int64_t avg = d->n_spectra > 0 ? std::max<int64_t>(n_ref / d->n_spectra, 1) : 1;
-    int64_t want = 2 * (int64_t)r.n_bins / avg;
+    int64_t want = (int64_t)r.n_bins / (2 * avg);
     if (const char *env = getenv("ADH_BLOCK_CYCLES")) want = atoll(env);
     int bs = 3;
     while (bs < 20 && (1ll << (bs + 1)) <= want) ++bs;
@@ -522,7 +525,8 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     Plan &p = h->plan;
     const bool fast_cfg = cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST");
     if (p.ready && p.top_k_fragments == cfg->top_k_fragments &&
-        p.top_k_isotopes == cfg->top_k_isotopes && p.fast_ok == fast_cfg)
+        p.top_k_isotopes == cfg->top_k_isotopes && p.fast_ok == fast_cfg &&
+        p.quant_all == (cfg->quant_all != 0))
         return ADH_OK;
     h->plan_buf.release();
     p = Plan();
@@ -537,7 +541,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     std::vector<CandRec> recs((size_t)n);
     std::vector<uint8_t> cls((size_t)n, 0);
     const int64_t n_cyc = h->run.n_spectra / L + 2;
-    const int NCLS = 4;
+    const int NCLS = 7, GENERIC = 6;
     std::vector<uint32_t> head[NCLS];
     for (int c = 0; c < NCLS; ++c) head[c].assign((size_t)n_cyc + 1, 0);
     for (int64_t i = 0; i < n; ++i) {
@@ -558,8 +562,8 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         r.flags = hc.flags[i];
         r.row = (uint32_t)i;
         if (r.flags & ADH_FLAG_SKIP) {
-            cls[(size_t)i] = 3;
-            ++head[3][1];  // parked in cycle bin 0 of the generic class; the kernels return at once
+            cls[(size_t)i] = GENERIC;
+            ++head[GENERIC][1];  // parked in cycle bin 0 of the generic class; the kernels return at once
             continue;
         }
         // isotope m/z range exactly as the kernels compute it (candidate.py:151-163,203-205)
@@ -585,8 +589,10 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         {
             // shape handled by the register-resident kernel (adh_features_fast.hip)
             const int F = r.frame_stop / L - r.frame_start / L;
-            const bool fast = fast_cfg && O == 1 && F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
-            cls[(size_t)i] = !fast ? 3 : (F <= 16 ? 0 : (F <= 24 ? 1 : 2));
+            // (several observations: only with quant_all, see adh_features_fast.hip)
+            const bool fast = fast_cfg && O >= 1 && O <= ADH_FAST_OMAX && (O == 1 || cfg->quant_all) &&
+                              F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
+            cls[(size_t)i] = !fast ? GENERIC : (O - 1) * 3 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2));
         }
         ++head[cls[(size_t)i]][(size_t)(r.frame_start / L) + 1];
     }
@@ -616,7 +622,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         const int O = r.n_obs;
         r.scratch_off = off;
         off += adh_scratch_bytes(r.k_cap, O, std::max(F, 0), I);
-        for (Caps *cc : {&p.caps_all, (size_t)j >= class_first[3] ? &p.caps_generic : (Caps *)nullptr}) {
+        for (Caps *cc : {&p.caps_all, (size_t)j >= class_first[GENERIC] ? &p.caps_generic : (Caps *)nullptr}) {
             if (!cc) continue;
             cc->k = std::max<int32_t>(cc->k, (int32_t)r.k_cap);
             cc->o = std::max<int32_t>(cc->o, O);
@@ -635,6 +641,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     p.top_k_fragments = cfg->top_k_fragments;
     p.top_k_isotopes = cfg->top_k_isotopes;
     p.fast_ok = fast_cfg;
+    p.quant_all = cfg->quant_all != 0;
     p.ready = true;
     return ADH_OK;
 }
@@ -740,7 +747,7 @@ int build_plan_im(adh_handle *h, const adh_scoring_config_t *cfg) {
         cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
     }
     p.caps_generic = p.caps_all;
-    p.n_class[3] = n;
+    p.n_class[6] = n;
     p.scratch_bytes = std::max<uint64_t>(off, 32);
     const CandRecIM *d_recs = nullptr;
     UP(h->plan_buf, ordered.data(), n, &d_recs);
@@ -815,7 +822,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
     p.caps_generic.stop_phase = stop_phase;
     const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
-    if (p.n_class[3] > 0 && f_lds > 160 * 1024) {
+    if (p.n_class[6] > 0 && f_lds > 160 * 1024) {
         char buf[256];
         snprintf(buf, sizeof(buf),
                  "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", f_lds,
@@ -836,42 +843,45 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(t.e1, st));
     if (stop_phase != 2) {
-        const int64_t first3 = p.n_class[0] + p.n_class[1] + p.n_class[2];
+        int64_t n_fast = 0;
+        for (int c = 0; c < 6; ++c) n_fast += p.n_class[c];
         bool forked = false;
-        if (p.n_class[3] > 0) {
+        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic"
+        const bool run_generic = !(only && only[0] == 'f'), run_fast = !(only && only[0] == 'g');
+        if (p.n_class[6] > 0 && run_generic) {
             // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
             hipStream_t gs = st;
-            if (first3 > 0) {
+            if (n_fast > 0) {
                 HIP_TRY(hipEventRecord(h->ev_fork, st));
                 HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
                 gs = h->side_stream;
                 forked = true;
             }
-            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[3]), dim3(ADH_WAVE), f_lds,
-                               gs, h->run, p.d_recs + first3, h->d_iso, n_iso, *cfg, p.d_scratch, *out,
+            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[6]), dim3(ADH_WAVE), f_lds,
+                               gs, h->run, p.d_recs + n_fast, h->d_iso, n_iso, *cfg, p.d_scratch, *out,
                                p.caps_generic);
             HIP_TRY(hipGetLastError());
             if (forked) HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
         }
         const unsigned per_block = ADH_WAVE / ADH_GS;
         int64_t first = 0;
-        for (int c = 0; c < 3; ++c) {
-            if (p.n_class[c] > 0) {
+        for (int c = 0; c < 6; ++c) {
+            if (p.n_class[c] > 0 && run_fast) {
                 const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                 const CandRec *recs = p.d_recs + first;
                 const int32_t nc = (int32_t)p.n_class[c];
-                if (c == 0)
-                    hipLaunchKernelGGL(adh_feature_fast_kernel<16>, dim3(blocks), dim3(ADH_WAVE), 0, st,
-                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
-                                       *out, (int32_t)stop_phase);
-                else if (c == 1)
-                    hipLaunchKernelGGL(adh_feature_fast_kernel<24>, dim3(blocks), dim3(ADH_WAVE), 0, st,
-                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
-                                       *out, (int32_t)stop_phase);
-                else
-                    hipLaunchKernelGGL(adh_feature_fast_kernel<32>, dim3(blocks), dim3(ADH_WAVE), 0, st,
-                                       h->run, recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp,
-                                       *out, (int32_t)stop_phase);
+#define ADH_LAUNCH_FAST(FM, NO)                                                                      \
+    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, \
+                       recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
+                switch (c) {
+                    case 0: ADH_LAUNCH_FAST(16, 1); break;
+                    case 1: ADH_LAUNCH_FAST(24, 1); break;
+                    case 2: ADH_LAUNCH_FAST(32, 1); break;
+                    case 3: ADH_LAUNCH_FAST(16, 2); break;
+                    case 4: ADH_LAUNCH_FAST(24, 2); break;
+                    default: ADH_LAUNCH_FAST(32, 2); break;
+                }
+#undef ADH_LAUNCH_FAST
                 HIP_TRY(hipGetLastError());
             }
             first += p.n_class[c];

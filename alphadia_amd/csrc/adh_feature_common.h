@@ -46,8 +46,8 @@ struct Assemble {
     float top3;
 };
 
-// features 0-28, 41-45
-__device__ __forceinline__ void assemble_part1(const Assemble &q, int I, int O, int K) {
+// features 0-16, 28
+__device__ __forceinline__ void assemble_precursor(const Assemble &q, int I, int O) {
         float *ft = q.featv;
         ft[28] = (float)((double)q.n_present / (double)q.K0);  // candidate.py:362
         // location_features.py:8-33
@@ -114,8 +114,11 @@ __device__ __forceinline__ void assemble_part1(const Assemble &q, int I, int O, 
             double dend = sqrt((double)sxx * shh);
             ft[16] = (float)(numd / (dend + 1e-12));
         }
+}
 
-        // fragment_features.py:198-427
+// features 17-27, 41-45 (fragment_features.py:198-427)
+__device__ __forceinline__ void assemble_fragments(const Assemble &q, int O, int K) {
+        float *ft = q.featv;
         ft[17] = (float)O;
         int n_height_rows = 0;
         for (int k = 0; k < K; ++k) {
@@ -215,6 +218,12 @@ __device__ __forceinline__ void assemble_part1(const Assemble &q, int I, int O, 
                 ft[45] = 15.0f;
             }
         }
+}
+
+// features 0-28, 41-45
+__device__ __forceinline__ void assemble_part1(const Assemble &q, int I, int O, int K) {
+    assemble_precursor(q, I, O);
+    assemble_fragments(q, O, K);
 }
 
 // features 31-38, 40
