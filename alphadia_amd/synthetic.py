@@ -481,6 +481,59 @@ def make_case(
     return SyntheticCase(dia, lib, cands, planted.apex_cycle)
 
 
+def multiplex_library(
+    library: SyntheticLibrary,
+    channels: tuple = (0, 4, 8, 12),
+    label_mass: float = 1.0018,
+    seed: int = 0,
+) -> SyntheticLibrary:
+    """Channel-multiplexed copy of a library.
+
+    Every precursor of ``library`` becomes one precursor per channel in the same elution
+    group: precursor m/z shifted by ``channel * (1 + n_K) / charge * label_mass``, y-ions
+    (type 121) shifted by ``channel * label_mass``, b-ions (type 98) shared by all channels
+    and therefore flagged with ``cardinality = len(channels)``.
+    """
+    rng = np.random.default_rng([seed, 7])
+    pdf, fdf = library.precursor_df, library.fragment_df
+    n, C = len(pdf), len(channels)
+    n_k = rng.integers(0, 2, n)
+    start = pdf["flat_frag_start_idx"].values.astype(np.int64)
+    stop = pdf["flat_frag_stop_idx"].values.astype(np.int64)
+    nf = stop - start
+    prec_parts, frag_parts = [], []
+    offset = 0
+    total = int(nf.sum())
+    owner = np.repeat(np.arange(n), nf)
+    for ci, ch in enumerate(channels):
+        pp = pdf.copy()
+        pp["channel"] = np.uint32(ch)
+        pp["precursor_idx"] = (pdf["precursor_idx"].values.astype(np.int64) * C + ci).astype(np.uint32)
+        pp["mz_library"] = (
+            pdf["mz_library"].values.astype(np.float64)
+            + ch * (1 + n_k) / pdf["charge"].values.astype(np.float64) * label_mass
+        ).astype(np.float32)
+        new_stop = np.cumsum(nf) + offset
+        pp["flat_frag_start_idx"] = (new_stop - nf).astype(np.uint32)
+        pp["flat_frag_stop_idx"] = new_stop.astype(np.uint32)
+        ff = fdf.iloc[np.concatenate([np.arange(a, b) for a, b in zip(start, stop)])].copy() if total else fdf.copy()
+        is_y = ff["type"].values == 121
+        mz = ff["mz_library"].values.astype(np.float64)
+        mz = np.where(is_y, mz + ch * label_mass, mz)
+        ff["mz_library"] = mz.astype(np.float32)
+        ff["cardinality"] = np.where(is_y, 1, C).astype(np.uint8)
+        prec_parts.append(pp)
+        frag_parts.append(ff)
+        offset += total
+    del owner
+    precursor_df = pd.concat(prec_parts, ignore_index=True)
+    # interleave: all channels of an elution group next to each other, as a real library has them
+    order = np.argsort(precursor_df["precursor_idx"].values, kind="stable")
+    precursor_df = precursor_df.iloc[order].reset_index(drop=True)
+    fragment_df = pd.concat(frag_parts, ignore_index=True)
+    return SyntheticLibrary(precursor_df, fragment_df)
+
+
 # --------------------------------------------------------------------------- timsTOF-style run
 @dataclass
 class TimsTOFArrays:

@@ -299,6 +299,74 @@ def golden_scoring():
         )
 
 
+def multiplex_case(n_base: int = 120, n_cycles: int = 60):
+    """Config 5 in small: 4 label channels per elution group, y-ions shifted, b-ions shared."""
+    seed = syn.BASE_SEED + 105
+    cycle = syn.make_cycle(n_ms2=8, mz_lo=400, mz_hi=480)
+    base = syn.make_library(n_base, seed, mz_lo=400, mz_hi=465, rt_max=n_cycles * 1.5,
+                            frag_mz_lo=200, frag_mz_hi=340)
+    lib = syn.multiplex_library(base, channels=(0, 4, 8, 12), seed=seed)
+    planted = syn.plant_peptides(lib, cycle, n_cycles, seed, fraction=0.6)
+    dia = syn.make_thermo_run(n_cycles, seed, cycle=cycle, ms1_peaks=400, ms2_peaks=150,
+                              planted=planted, threads=1, ms1_mz_range=(395, 500),
+                              ms2_mz_range=(195, 355))
+    # reference-channel candidates (one per target precursor of channel 0) ...
+    pdf = lib.precursor_df
+    ref = pdf[(pdf["channel"] == 0) & (pdf["decoy"] == 0)]
+    ref_lib = syn.SyntheticLibrary(ref.reset_index(drop=True), lib.fragment_df)
+    apex = planted.apex_cycle[ref.index.values]
+    cands = syn.make_candidates(ref_lib, n_cycles, cycle.shape[1], seed, per_precursor=1,
+                                apex_cycle=apex, even_fraction=0.3)
+    cands["proba"] = np.linspace(0.0, 0.5, len(cands)).astype(np.float32)
+    cands["decoy"] = np.uint8(0)
+    # ... expanded to all channels by the reference (scoring/utils.py:114-200), as the
+    # multiplexing handler does (multiplexing_requantification_handler.py:94-131)
+    from alphadia.search.scoring.utils import multiplex_candidates
+
+    mult = multiplex_candidates(cands, pdf, channels=[0, 4, 8, 12])
+    mult["rank"] = np.uint8(0)
+    # a few elution groups lose their reference channel: ScoreGroup.process skips them
+    # (score_group.py:50-65)
+    egs = np.unique(mult["elution_group_idx"].values)
+    lost = egs[::7]
+    mult = mult[~((mult["channel"] == 0) & mult["elution_group_idx"].isin(lost))].reset_index(drop=True)
+    for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center"):
+        mult[c] = mult[c].astype(np.int64)
+    mult["elution_group_idx"] = mult["elution_group_idx"].astype(np.uint32)
+    mult["precursor_idx"] = mult["precursor_idx"].astype(np.uint32)
+    return syn.SyntheticCase(dia, lib, mult[CAND_COLS].copy(), planted.apex_cycle)
+
+
+def golden_multiplex():
+    case = multiplex_case()
+    upd = dict(score_grouped=True, exclude_shared_ions=True, reference_channel=0, experimental_xic=True)
+    out, fdf, frdf, opidx, orank, cfg = run_scoring(case, upd)
+    d = case_to_dict(case)
+    d.update(out_to_dict(out))
+    d["order_precursor_idx"] = opidx
+    d["order_rank"] = orank
+    cfgj = cfg.to_jitclass()
+    for k in (
+        "collect_fragments score_grouped exclude_shared_ions top_k_fragments top_k_isotopes "
+        "reference_channel quant_window quant_all precursor_mz_tolerance "
+        "fragment_mz_tolerance experimental_xic"
+    ).split():
+        d["cfg_" + k] = np.asarray(getattr(cfgj, k))
+    d["features_df_columns"] = np.array(list(fdf.columns), dtype="U")
+    d["fragments_df_columns"] = np.array(list(frdf.columns), dtype="U")
+    d["features_df_precursor_idx"] = fdf["precursor_idx"].values
+    d["features_df_rank"] = fdf["rank"].values
+    d["features_df_delta_rt"] = fdf["delta_rt"].values
+    d["fragments_df_precursor_idx"] = frdf["precursor_idx"].values
+    d["fragments_df_mz_observed"] = frdf["mz_observed"].values
+    d["fragments_df_n"] = np.asarray(len(frdf))
+    d["caveat"] = np.asarray(CAVEAT)
+    path = os.path.join(HERE, "scoring_multiplex.npz")
+    np.savez_compressed(path, **d)
+    v = np.asarray(out.valid)
+    print(f"{path}: {v.sum()}/{len(v)} valid, {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def golden_get_dense():
     """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
     case = small_case(102, n_precursors=40)
@@ -537,7 +605,11 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--multiplex-only" in sys.argv:
+        golden_multiplex()
+        sys.exit(0)
     golden_get_dense()
     golden_fragcomp()
     golden_scoring()
+    golden_multiplex()
     golden_timstof()
