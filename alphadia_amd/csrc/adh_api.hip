@@ -819,6 +819,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     if (const char *dbg = getenv("ADH_DEBUG_STOP_PHASE")) stop_phase = atoi(dbg);  // developer switch
 
     Caps gcaps = p.caps_all;
+    if (const char *dbg = getenv("ADH_DEBUG_GATHER")) gcaps.stop_phase = atoi(dbg);
     const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
     p.caps_generic.stop_phase = stop_phase;
     const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);

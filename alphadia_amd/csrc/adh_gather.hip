@@ -224,6 +224,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
         }
     }
     for (int w = lane; w < K + I; w += ADH_WAVE) bins_of(run, win[w < K ? w : caps.k + (w - K)]);
+    if (caps.stop_phase == 1) return;  // developer ablation switches (ADH_DEBUG_GATHER)
 
     // ---- zero the tile: fragment cells ((o * F + f) * K + k) in scratch, raw MS1 cells in LDS
     float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
     for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
     for (int c = lane; c < I * M1 * F; c += ADH_WAVE) raw1[c] = make_float2(0.0f, 0.0f);
     __syncthreads();
+    if (caps.stop_phase == 2) return;
 
     // ---- (window, observation, block) tasks
     uint32_t hits = 0;

@@ -245,7 +245,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "adh_gather_kernel + adh_feature_kernel (the hot path; sum of both)",
+            "kernel": "adh_gather_kernel + feature kernels (adh_feature_fast_kernel<FM,NO>, adh_feature_kernel): the hot path, sum of both",
             "kernel_ms": kernel_ms,
             "gather_kernel_ms": gather_ms,
             "feature_kernel_ms": feature_ms,
