@@ -367,6 +367,88 @@ def golden_multiplex():
     print(f"{path}: {v.sum()}/{len(v)} valid, {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def edges_case():
+    """Hand-made edge cases on top of a small run: precursors at the edge of the isolation scheme,
+    windows of 1-4 cycles, boxes at the first / last cycle, libraries of 0-4 fragments,
+    fragments outside the m/z range of the run, precursors on a window boundary."""
+    case = small_case(103, n_precursors=60, per_precursor=1, few_fragment_fraction=0.0,
+                      even_fraction=0.0, planted_fraction=0.8)
+    pdf = case.library.precursor_df.copy()
+    fdf = case.library.fragment_df.copy()
+    L = case.dia.cycle_len
+    n_cycles = case.dia.n_cycles
+    cands = case.candidates_df.copy().reset_index(drop=True)
+    n = len(pdf)
+    mz = pdf["mz_library"].values.copy()
+    # (a precursor outside EVERY window makes the reference raise inside
+    # quadrupole_transfer_function_single; that case is implementation-defined, see DESIGN.md)
+    mz[0] = 400.2   # isotope range starts below the first window
+    mz[1] = 479.4   # ... and ends above the last one
+    mz[2] = 410.0   # exactly on a window boundary (windows are 10 Th wide from 400)
+    mz[3] = 409.6   # isotopes straddle the boundary -> two observations
+    pdf["mz_library"] = mz.astype(np.float32)
+    # fragment counts 0..4 for precursors 4..8
+    start = pdf["flat_frag_start_idx"].values.astype(np.int64).copy()
+    stop = pdf["flat_frag_stop_idx"].values.astype(np.int64).copy()
+    for j, cnt in zip(range(4, 9), (0, 1, 2, 3, 4)):
+        stop[j] = start[j] + cnt
+    pdf["flat_frag_stop_idx"] = stop.astype(np.uint32)
+    # precursor 9: all fragments outside the acquired m/z range
+    f = fdf["mz_library"].values.copy()
+    f[start[9]:stop[9]] = np.linspace(50.0, 60.0, stop[9] - start[9], dtype=np.float32)
+    # precursor 10: half of them above it
+    f[start[10]:start[10] + 6] = np.linspace(2000.0, 2100.0, 6, dtype=np.float32)
+    fdf["mz_library"] = f.astype(np.float32)
+
+    def box(i, c, h_lo, h_hi):
+        cands.loc[i, "frame_start"] = (c - h_lo) * L
+        cands.loc[i, "frame_stop"] = (c + h_hi + 1) * L
+        cands.loc[i, "frame_center"] = c * L
+
+    box(11, 20, 0, 0)   # one cycle
+    box(12, 20, 0, 1)   # two cycles
+    box(13, 20, 1, 1)   # three
+    box(14, 20, 1, 2)   # four
+    box(15, 3, 3, 3)    # touches the first cycle
+    box(16, n_cycles - 4, 3, 3)  # touches the last cycle
+    box(17, 30, 14, 14)  # 29 cycles
+    box(18, 30, 16, 17)  # 34 cycles: beyond the register kernels
+    case.library.precursor_df = pdf
+    case.library.fragment_df = fdf
+    case.candidates_df = cands
+    return case
+
+
+def golden_edges():
+    case = edges_case()
+    out, fdf, frdf, opidx, orank, cfg = run_scoring(case, SCORING_CONFIGS["handler_default"])
+    d = case_to_dict(case)
+    d.update(out_to_dict(out))
+    d["order_precursor_idx"] = opidx
+    d["order_rank"] = orank
+    cfgj = cfg.to_jitclass()
+    for k in (
+        "collect_fragments score_grouped exclude_shared_ions top_k_fragments top_k_isotopes "
+        "reference_channel quant_window quant_all precursor_mz_tolerance "
+        "fragment_mz_tolerance experimental_xic"
+    ).split():
+        d["cfg_" + k] = np.asarray(getattr(cfgj, k))
+    d["features_df_columns"] = np.array(list(fdf.columns), dtype="U")
+    d["fragments_df_columns"] = np.array(list(frdf.columns), dtype="U")
+    d["features_df_precursor_idx"] = fdf["precursor_idx"].values
+    d["features_df_rank"] = fdf["rank"].values
+    d["features_df_delta_rt"] = fdf["delta_rt"].values
+    d["fragments_df_precursor_idx"] = frdf["precursor_idx"].values
+    d["fragments_df_mz_observed"] = frdf["mz_observed"].values
+    d["fragments_df_n"] = np.asarray(len(frdf))
+    d["caveat"] = np.asarray(CAVEAT)
+    path = os.path.join(HERE, "scoring_edges.npz")
+    np.savez_compressed(path, **d)
+    v = np.asarray(out.valid)
+    print(f"{path}: {v.sum()}/{len(v)} valid; first 20 valid flags {v[:20].astype(int)}; "
+          f"n_obs of 0..3: {np.asarray(out.features)[:4, 17]}")
+
+
 def golden_get_dense():
     """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
     case = small_case(102, n_precursors=40)
@@ -605,6 +687,9 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--edges-only" in sys.argv:
+        golden_edges()
+        sys.exit(0)
     if "--multiplex-only" in sys.argv:
         golden_multiplex()
         sys.exit(0)
@@ -612,4 +697,5 @@ if __name__ == "__main__":
     golden_fragcomp()
     golden_scoring()
     golden_multiplex()
+    golden_edges()
     golden_timstof()

@@ -68,7 +68,7 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     return worst
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges"])
 def test_hip_matches_oracle_on_golden_inputs(ctx, oracle_lib, name):
     g = H.load_scoring_golden(name)
     got, soa = hip_score(ctx, g, g.config)
@@ -76,7 +76,7 @@ def test_hip_matches_oracle_on_golden_inputs(ctx, oracle_lib, name):
     compare(got, exp, PPM_ABS_TOL_ORACLE)
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges"])
 def test_hip_matches_reference_goldens(ctx, name):
     g = H.load_scoring_golden(name)
     got, _ = hip_score(ctx, g, g.config)

@@ -38,7 +38,7 @@ def _compare(got, exp, ppm_tol, rel_tol, corr_abs):
     assert d.max() <= ppm_tol
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges"])
 def test_oracle_numba_typing_vs_reference_goldens(oracle_lib, name):
     """Production (Numba) typing vs goldens captured under NumPy typing: validity, every
     integer table and the row order are exact; float features within 1e-4 relative except the
@@ -51,7 +51,7 @@ def test_oracle_numba_typing_vs_reference_goldens(oracle_lib, name):
     _compare(got, g.expected, ppm_tol=0.15, rel_tol=1e-4, corr_abs=1e-3)
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges"])
 def test_oracle_numpy_typing_pins_precursor_mass_errors(oracle_lib, name):
     """With the three promotion sites switched to what the shim executed, the MS1 mass
     error features agree to 1e-4 relative: the restatement itself is pinned."""
