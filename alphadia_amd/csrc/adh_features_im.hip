@@ -2,7 +2,11 @@
 //
 // Same phases as adh_features.hip (the restatement of Candidate.process after get_dense,
 // alphadia/search/scoring/containers/candidate.py:248-481) with a REAL scan axis:
-//   * tiles are [K][O][S][F] in LDS; rt / mobility arrays are float64
+//   * the fragment tile [K][O][S][F] stays in the HBM scratch block and is streamed ONCE, one
+//     lane per (fragment, observation, channel) plane: scan profile, frame profile, row sum
+//     and weighted centre means are all folded in that pass in the reference's order; LDS
+//     holds profiles, the precursor tile, the template and the weight tables only
+//   * rt / mobility arrays are float64
 //     (TimsTOFTransposeJIT, alphadia/search/jitclasses/bruker_jit.py:35,45), which changes
 //     the typing of the quantification area and of the location / FWHM features
 //   * the quadrupole transfer function is evaluated per scan (quadrupole.py:261-301)
@@ -43,14 +47,20 @@ struct Layout {
     __host__ __device__ int d_qtf() const { return d_wtp() + Sc * Fc; }      // [Ic][Oc][Sc]
     __host__ __device__ int d_omz() const { return d_qtf() + Ic * Oc * Sc; }
     __host__ __device__ int d_ohe() const { return d_omz() + Kc * Oc; }
-    __host__ __device__ int d_pk() const { return d_ohe() + Kc * Oc; }   // [4][Kc]
+    __host__ __device__ int d_omzu() const { return d_ohe() + Kc * Oc; }  // per selected fragment,
+    __host__ __device__ int d_oheu() const { return d_omzu() + Kc * Oc; } // before the presence mask
+    __host__ __device__ int d_pk() const { return d_oheu() + Kc * Oc; }   // [4][Kc]
     __host__ __device__ int d_po() const { return d_pk() + 4 * Kc; }     // [2][Oc]
     __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]
     __host__ __device__ int d_frt() const { return d_pi() + 2 * Ic; }    // [Fc] frame rt (float64)
     __host__ __device__ int n_double() const { return d_frt() + Fc; }
     // floats
-    __host__ __device__ int f_tile() const { return 0; }                          // [2][Kc*Oc*Sc*Fc]
-    __host__ __device__ int f_ffp() const { return 2 * Kc * Oc * Sc * Fc; }       // [Kc*Oc*Fc]
+    __host__ __device__ int smax() const { return Sc > Fc ? Sc : Fc; }
+    __host__ __device__ int f_wa() const { return 0; }                            // work [Kc*Fc]
+    __host__ __device__ int f_wb() const { return Kc * Fc; }                      // work [Kc*Oc*max(Sc,Fc)]
+    __host__ __device__ int f_ffpu() const { return f_wb() + Kc * Oc * smax(); }  // [Kc*Oc*Fc] before the mask
+    __host__ __device__ int f_fspu() const { return f_ffpu() + Kc * Oc * Fc; }    // [Kc*Oc*Sc] before the mask
+    __host__ __device__ int f_ffp() const { return f_fspu() + Kc * Oc * Sc; }     // [Kc*Oc*Fc]
     __host__ __device__ int f_fsp() const { return f_ffp() + Kc * Oc * Fc; }      // [2][Kc*Oc*Sc] raw, env
     __host__ __device__ int f_prec() const { return f_fsp() + 2 * Kc * Oc * Sc; } // [2][Ic*Sc*Fc]
     __host__ __device__ int f_tpl() const { return f_prec() + 2 * Ic * Sc * Fc; } // [Oc*Sc*Fc]
@@ -116,8 +126,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     const int top_k = out.top_k;
     if (lane == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
 
-    float *const fi = Fl + lay.f_tile();
-    float *const fm = fi + Kc * Oc * Sc * Fc;
+    float *const work_a = Fl + lay.f_wa();
+    float *const work_b = Fl + lay.f_wb();
+    float *const ffp_u = Fl + lay.f_ffpu();
+    float *const fsp_u = Fl + lay.f_fspu();
     float *const ffp = Fl + lay.f_ffp();
     float *const fsp_raw = Fl + lay.f_fsp();
     float *const fsp = fsp_raw + Kc * Oc * Sc;
@@ -148,14 +160,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     double *const qtf = D + lay.d_qtf();
     double *const frame_rt = D + lay.d_frt();
 
-    // ---- load the tile [k][o][s][f]; collapse the MS1 observations (candidate.py:248-269)
+    // ---- collapse the MS1 observations (candidate.py:248-269); the fragment tile
+    // [k][o][s][f] stays in the scratch block
+    const float2 *const fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(r.k_cap));
     {
-        const float2 *fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(r.k_cap));
-        for (int c = lane; c < K0 * OSF; c += ADH_WAVE) {
-            float2 v = fcells[c];
-            fi[c] = v.x;
-            fm[c] = v.y;
-        }
         const float2 *pcells = reinterpret_cast<const float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
         for (int c = lane; c < I * SF; c += ADH_WAVE) {
             int i = c / SF, sf = c - i * SF;
@@ -196,10 +204,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         qmask[c] = (float)(sum / (double)I);  // candidate.py:287-289
     }
     __syncthreads();
-    for (int c = lane; c < K0 * OSF; c += ADH_WAVE) {
-        int os = (c % OSF) / F;  // o * S + s
-        fi[c] = fi[c] * qmask[os];
-    }
+    // (the qtf mask of candidate.py:290 is applied while the fragment tile is streamed)
     // template (O, S, F) (quadrupole.py:304-324)
     for (int c = lane; c < OSF; c += ADH_WAVE) {
         int o = c / SF, sf = c - o * SF, sc = sf / F;
@@ -226,15 +231,115 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         tsum[lane] = so;
     }
+    // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
+    // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
+    // over the fragment tile
+    double *const wt = D + lay.d_wt();
+    double *const wtp = D + lay.d_wtp();
+    double *const esc = D + lay.d_po();
+    double *const efc = esc + Oc;
+    double *const hp = D + lay.d_pi();
+    double *const omzp = hp + Ic;
+    double *const omz = D + lay.d_omz();
+    double *const ohe = D + lay.d_ohe();
+    double *const omz_u = D + lay.d_omzu();
+    double *const ohe_u = D + lay.d_oheu();
+    // precursor weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
+    for (int c = lane; c < SF; c += ADH_WAVE) {
+        int sc = c / F, f = c - sc * F;
+        double ds = (double)(sc - S), df = (double)(f - 1);
+        wtp[c] = exp(-0.1 * sqrt(ds * ds + df * df));
+    }
+    if (lane < O) {
+        double isum = 0, ssum = 0, fsum = 0;
+        bool any = false;
+        for (int sc = 0; sc < S; ++sc)
+            for (int f = 0; f < F; ++f) {
+                float v = tpl[(lane * S + sc) * F + f];
+                if (v > 0.0f) {
+                    any = true;
+                    isum += (double)v;
+                    ssum += (double)sc * (double)v;
+                    fsum += (double)f * (double)v;
+                }
+            }
+        esc[lane] = (any && isum > 0) ? ssum / isum : 0.0;
+        efc[lane] = (any && isum > 0) ? fsum / isum : 0.0;
+    }
+    for (int c = lane; c < K0 * O * F; c += ADH_WAVE) ffp_u[c] = 0.0f;
+    __syncthreads();
+    for (int c = lane; c < OSF; c += ADH_WAVE) {
+        int o = c / SF, sf = c - o * SF;
+        int sc = sf / F, f = sf - sc * F;
+        double ds = (double)sc - esc[o], df = (double)f - efc[o];
+        wt[c] = exp(-0.1 * sqrt(ds * ds + df * df));
+    }
+    __syncthreads();
+    // ---- ONE pass over the fragment tile, a lane per (fragment, observation, channel):
+    //   scan profile  fsp[s] = sum_f x[s][f]            (scoring/utils.py:56-66 input)
+    //   frame profile ffp[f] = sum_s x[s][f]            (scoring/utils.py:26-53 input)
+    //   weighted centre mean of the channel            (features_utils.py:9-37)
+    // each in the reference's summation order (s outer, f inner)
+    for (int c = lane; c < 2 * K0 * O; c += ADH_WAVE) {
+        const int plane = c & 1, ko = c >> 1;
+        const int o = ko % O;
+        const float2 *p = fcells + (size_t)ko * SF;
+        const double *w = wt + o * SF;
+        const float *qm = qmask + o * S;
+        double values = 0, weights = 0;
+        bool any = false;
+        constexpr int NB = 8;  // cells in flight per lane
+        if (plane == 0) {
+            for (int sc = 0; sc < S; ++sc) {
+                const float q = qm[sc];
+                float sf = 0;
+                for (int f0 = 0; f0 < F; f0 += NB) {
+                    float2 buf[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) buf[u] = p[sc * F + min(f0 + u, F - 1)];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int f = f0 + u;
+                        if (f < F) {
+                            const float v = buf[u].x * q;  // candidate.py:290
+                            sf += v;
+                            ffp_u[ko * F + f] += v;
+                            if (v > 0.0f) {
+                                any = true;
+                                values += (double)v * w[sc * F + f];
+                                weights += w[sc * F + f];
+                            }
+                        }
+                    }
+                }
+                fsp_u[ko * S + sc] = sf;
+            }
+            ohe_u[ko] = (any && weights > 0) ? values / weights : 0.0;
+        } else {
+            for (int s0 = 0; s0 < SF; s0 += NB) {
+                float2 buf[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) buf[u] = p[min(s0 + u, SF - 1)];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int sf = s0 + u;
+                    const float v = buf[u].y;
+                    if (sf < SF && v > 0.0f) {
+                        any = true;
+                        values += (double)v * w[sf];
+                        weights += w[sf];
+                    }
+                }
+            }
+            omz_u[ko] = (any && weights > 0) ? values / weights : 0.0;
+        }
+    }
+    __syncthreads();
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
         for (int o = 0; o < O; ++o) {
             float ss = 0;
-            for (int sc = 0; sc < S; ++sc) {
-                float sf = 0;
-                for (int f = 0; f < F; ++f) sf += fi[((k * O + o) * S + sc) * F + f];
-                ss += sf;
-            }
+            for (int sc = 0; sc < S; ++sc) ss += fsp_u[(k * O + o) * S + sc];  // sum of the per-scan sums
             rowsum[k * O + o] = ss;
             so += ss;
         }
@@ -299,18 +404,16 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // ---- profiles (candidate.py:333-347; scoring/utils.py:26-66); k is the compacted index
     for (int c = lane; c < K * O * F; c += ADH_WAVE) {
         int k = c / (O * F), rem = c - k * O * F;
-        int o = rem / F, f = rem - o * F;
-        const float *p = fi + ((kmap[k] * O + o) * S) * F + f;
-        float a = 0;
-        for (int sc = 0; sc < S; ++sc) a += p[sc * F];
-        ffp[c] = a;
+        ffp[c] = ffp_u[kmap[k] * O * F + rem];
     }
     for (int c = lane; c < K * O * S; c += ADH_WAVE) {
         int k = c / (O * S), rem = c - k * O * S;
-        const float *p = fi + (kmap[k] * O * S + rem) * F;
-        float a = 0;
-        for (int f = 0; f < F; ++f) a += p[f];
-        fsp_raw[c] = a;
+        fsp_raw[c] = fsp_u[kmap[k] * O * S + rem];
+    }
+    for (int c = lane; c < K * O; c += ADH_WAVE) {
+        int k = c / O, o = c - k * O;
+        ohe[c] = ohe_u[kmap[k] * O + o];
+        omz[c] = omz_u[kmap[k] * O + o];
     }
     for (int c = lane; c < O * F; c += ADH_WAVE) {
         int o = c / F, f = c - o * F;
@@ -356,34 +459,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     __syncthreads();
 
     // =========================== features ===========================
-    double *const wt = D + lay.d_wt();
-    double *const wtp = D + lay.d_wtp();
-    double *const esc = D + lay.d_po();
-    double *const efc = esc + Oc;
-    double *const hp = D + lay.d_pi();
-    double *const omzp = hp + Ic;
-    // precursor weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
-    for (int c = lane; c < SF; c += ADH_WAVE) {
-        int sc = c / F, f = c - sc * F;
-        double ds = (double)(sc - S), df = (double)(f - 1);
-        wtp[c] = exp(-0.1 * sqrt(ds * ds + df * df));
-    }
-    if (lane < O) {
-        double isum = 0, ssum = 0, fsum = 0;
-        bool any = false;
-        for (int sc = 0; sc < S; ++sc)
-            for (int f = 0; f < F; ++f) {
-                float v = tpl[(lane * S + sc) * F + f];
-                if (v > 0.0f) {
-                    any = true;
-                    isum += (double)v;
-                    ssum += (double)sc * (double)v;
-                    fsum += (double)f * (double)v;
-                }
-            }
-        esc[lane] = (any && isum > 0) ? ssum / isum : 0.0;
-        efc[lane] = (any && isum > 0) ? fsum / isum : 0.0;
-    }
     if (lane < I) {
         float ss = 0;
         for (int sc = 0; sc < S; ++sc) {
@@ -392,13 +467,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             ss += sf;
         }
         spi[lane] = ss;
-    }
-    __syncthreads();
-    for (int c = lane; c < OSF; c += ADH_WAVE) {
-        int o = c / SF, sf = c - o * SF;
-        int sc = sf / F, f = sf - sc * F;
-        double ds = (double)sc - esc[o], df = (double)f - efc[o];
-        wt[c] = exp(-0.1 * sqrt(ds * ds + df * df));
     }
     for (int c = lane; c < 2 * I; c += ADH_WAVE) {
         int i = c >> 1, plane = c & 1;
@@ -419,8 +487,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     __syncthreads();
 
-    double *const omz = D + lay.d_omz();
-    double *const ohe = D + lay.d_ohe();
     double *const mzmean = D + lay.d_pk();
     double *const height = mzmean + Kc;
     double *const area = height + Kc;
@@ -482,24 +548,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         float t = 0;
         for (int i = 0; i < W; ++i) t += p[i];
         obs_int[k] = t;
-    }
-    for (int c = lane; c < 2 * K * O; c += ADH_WAVE) {
-        int plane = c & 1, ko = c >> 1;
-        int k = ko / O, o = ko - k * O;
-        const float *p = (plane ? fm : fi) + (kmap[k] * O + o) * SF;
-        const double *w = wt + o * SF;
-        double values = 0, weights = 0;
-        bool any = false;
-        for (int sf = 0; sf < SF; ++sf) {
-            float v = p[sf];
-            if (v > 0.0f) {
-                any = true;
-                values += (double)v * w[sf];
-                weights += w[sf];
-            }
-        }
-        double res = (any && weights > 0) ? values / weights : 0.0;
-        if (plane) omz[ko] = res; else ohe[ko] = res;
     }
     __syncthreads();
     for (int k = lane; k < K; k += ADH_WAVE) {
@@ -565,9 +613,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
 
     // =========================== fragment_mobility_correlation (fragment_features.py:430-480)
-    // fi / fm are dead from here on: centred scan profiles go to fm, centred frame profiles later
+    // centred scan profiles go to the second work buffer, centred frame profiles later
     __syncthreads();
-    float *cen = fm;
+    float *cen = work_b;
     {
         int Km = 0;
         for (int k = 0; k < K; ++k) {
@@ -654,7 +702,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     __syncthreads();
 
     // =========================== profile features (profile_features.py:18-206)
-    float *isl = fi, *nrm = fm;  // fm is free again once the scan correlation is done
+    float *isl = work_a, *nrm = work_b;  // free again once the scan correlation is done
     if (cfg.experimental_xic) {
         for (int c = lane; c < K * F; c += ADH_WAVE) {
             int k = c / F, f = c - k * F;
