@@ -172,10 +172,12 @@ int adh_create(adh_handle_t **handle, int device) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)adh_gather_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (this kernel also has ADH_IM_STATIC_LDS bytes of static LDS)
     (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
     *handle = h;
     return ADH_OK;
 }
@@ -768,9 +770,11 @@ int score_uploaded_im(adh_handle *h, const adh_scoring_config_t *cfg, adh_output
     Plan &p = h->plan;
     if (cfg->collect_fragments && p.caps_all.k > out->top_k)
         return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
+    p.caps_all.stop_phase = 0;
+    if (const char *dbg = getenv("ADH_DEBUG_IM")) p.caps_all.stop_phase = atoi(dbg);
     const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all);
     const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all);
-    if (f_lds > 160 * 1024 || g_lds > 160 * 1024) {
+    if (f_lds > 160 * 1024 - ADH_IM_STATIC_LDS || g_lds > 160 * 1024) {
         char buf[256];
         snprintf(buf, sizeof(buf),
                  "ion-mobility tile needs %zu bytes of LDS (K=%d O=%d S=%d F=%d): exceeds 160 KiB", f_lds,

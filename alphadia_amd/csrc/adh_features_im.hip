@@ -42,14 +42,13 @@ struct Layout {
     int Kc, Oc, Sc, Fc, Ic;
     __host__ __device__ Layout(const Caps &c) : Kc(c.k), Oc(c.o), Sc(c.s), Fc(c.f), Ic(c.i) {}
     // doubles
-    __host__ __device__ int d_wt() const { return 0; }                       // [Oc][Sc][Fc]
-    __host__ __device__ int d_wtp() const { return d_wt() + Oc * Sc * Fc; }  // [Sc][Fc]
-    __host__ __device__ int d_qtf() const { return d_wtp() + Sc * Fc; }      // [Ic][Oc][Sc]
+    __host__ __device__ int d_qtf() const { return 0; }                      // [Ic][Oc][Sc]
     __host__ __device__ int d_omz() const { return d_qtf() + Ic * Oc * Sc; }
     __host__ __device__ int d_ohe() const { return d_omz() + Kc * Oc; }
     __host__ __device__ int d_omzu() const { return d_ohe() + Kc * Oc; }  // per selected fragment,
     __host__ __device__ int d_oheu() const { return d_omzu() + Kc * Oc; } // before the presence mask
-    __host__ __device__ int d_pk() const { return d_oheu() + Kc * Oc; }   // [4][Kc]
+    __host__ __device__ int d_accw() const { return d_oheu() + Kc * Oc; } // [2][Kc*Oc] weight sums
+    __host__ __device__ int d_pk() const { return d_accw() + 2 * Kc * Oc; }   // [4][Kc]
     __host__ __device__ int d_po() const { return d_pk() + 4 * Kc; }     // [2][Oc]
     __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]
     __host__ __device__ int d_frt() const { return d_pi() + 2 * Ic; }    // [Fc] frame rt (float64)
@@ -92,6 +91,7 @@ struct Layout {
 
 }  // namespace featim
 
+#define ADH_IM_STATIC_LDS 4096  // static LDS of adh_feature_im_kernel (the chunk list), rounded up
 size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
 
 __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     DevOut out, Caps caps) {
     using namespace featim;
     extern __shared__ __align__(16) unsigned char smem[];
+    // ordered list of the non-zero cells of one 64-cell chunk (see the tile passes below)
+    __shared__ double l_ti[ADH_WAVE], l_tm[ADH_WAVE], l_w[ADH_WAVE];
+    __shared__ float l_v[ADH_WAVE];
+    __shared__ int l_cell[ADH_WAVE];
     const Layout lay(caps);
     const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     __syncthreads();
 
+    if (caps.stop_phase == 1) return;  // developer ablation switches (ADH_DEBUG_IM)
     // ---- observation importance (quadrupole.py:327-335), fragment presence (candidate.py:319-329)
     float *const rowsum = Fl + lay.f_pko();
     float *const fw = rowsum + Kc * Oc;
@@ -234,8 +239,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
     // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
     // over the fragment tile
-    double *const wt = D + lay.d_wt();
-    double *const wtp = D + lay.d_wtp();
     double *const esc = D + lay.d_po();
     double *const efc = esc + Oc;
     double *const hp = D + lay.d_pi();
@@ -244,97 +247,134 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     double *const ohe = D + lay.d_ohe();
     double *const omz_u = D + lay.d_omzu();
     double *const ohe_u = D + lay.d_oheu();
-    // precursor weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
-    for (int c = lane; c < SF; c += ADH_WAVE) {
-        int sc = c / F, f = c - sc * F;
-        double ds = (double)(sc - S), df = (double)(f - 1);
-        wtp[c] = exp(-0.1 * sqrt(ds * ds + df * df));
-    }
-    if (lane < O) {
-        double isum = 0, ssum = 0, fsum = 0;
-        bool any = false;
-        for (int sc = 0; sc < S; ++sc)
-            for (int f = 0; f < F; ++f) {
-                float v = tpl[(lane * S + sc) * F + f];
-                if (v > 0.0f) {
-                    any = true;
-                    isum += (double)v;
-                    ssum += (double)sc * (double)v;
-                    fsum += (double)f * (double)v;
-                }
+    // sequential float64 sums over the non-zero template cells (s outer, f inner); the terms are
+    // computed by all lanes, compacted in order, and lanes 0..2 add up one sum each
+    for (int o = 0; o < O; ++o) {
+        double acc = 0.0;  // lane 0: sum v, lane 1: sum scan * v, lane 2: sum frame * v
+        for (int base = 0; base < SF; base += ADH_WAVE) {
+            const int ci = base + lane;
+            const float v = (ci < SF) ? tpl[o * SF + ci] : 0.0f;
+            const bool nz = v > 0.0f;
+            const unsigned long long mask = __ballot(nz);
+            if (mask == 0ull) continue;
+            if (nz) {
+                const int sc = ci / F, f = ci - sc * F;
+                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                l_w[pos] = (double)v;
+                l_ti[pos] = (double)sc * (double)v;
+                l_tm[pos] = (double)f * (double)v;
             }
-        esc[lane] = (any && isum > 0) ? ssum / isum : 0.0;
-        efc[lane] = (any && isum > 0) ? fsum / isum : 0.0;
+            __syncthreads();
+            const int n_ent = __popcll(mask);
+            if (lane < 3) {
+                const double *src = lane == 0 ? l_w : (lane == 1 ? l_ti : l_tm);
+                for (int e = 0; e < n_ent; ++e) acc += src[e];
+            }
+            __syncthreads();
+        }
+        const double isum = __shfl(acc, 0), ssum = __shfl(acc, 1), fsum = __shfl(acc, 2);
+        if (lane == 0) {
+            esc[o] = (isum > 0) ? ssum / isum : 0.0;
+            efc[o] = (isum > 0) ? fsum / isum : 0.0;
+        }
     }
     for (int c = lane; c < K0 * O * F; c += ADH_WAVE) ffp_u[c] = 0.0f;
+    for (int c = lane; c < K0 * O * S; c += ADH_WAVE) fsp_u[c] = 0.0f;
     __syncthreads();
-    for (int c = lane; c < OSF; c += ADH_WAVE) {
-        int o = c / SF, sf = c - o * SF;
-        int sc = sf / F, f = sf - sc * F;
-        double ds = (double)sc - esc[o], df = (double)f - efc[o];
-        wt[c] = exp(-0.1 * sqrt(ds * ds + df * df));
-    }
-    __syncthreads();
-    // ---- ONE pass over the fragment tile, a lane per (fragment, observation, channel):
+    if (caps.stop_phase == 2) return;
+    // ---- ONE pass over the fragment tile [k][o][s][f] (kept in the HBM scratch block):
     //   scan profile  fsp[s] = sum_f x[s][f]            (scoring/utils.py:56-66 input)
     //   frame profile ffp[f] = sum_s x[s][f]            (scoring/utils.py:26-53 input)
-    //   weighted centre mean of the channel            (features_utils.py:9-37)
-    // each in the reference's summation order (s outer, f inner)
-    for (int c = lane; c < 2 * K0 * O; c += ADH_WAVE) {
-        const int plane = c & 1, ko = c >> 1;
-        const int o = ko % O;
-        const float2 *p = fcells + (size_t)ko * SF;
-        const double *w = wt + o * SF;
-        const float *qm = qmask + o * S;
-        double values = 0, weights = 0;
-        bool any = false;
-        constexpr int NB = 8;  // cells in flight per lane
-        if (plane == 0) {
-            for (int sc = 0; sc < S; ++sc) {
-                const float q = qm[sc];
-                float sf = 0;
-                for (int f0 = 0; f0 < F; f0 += NB) {
-                    float2 buf[NB];
+    //   weighted centre means of both channels         (features_utils.py:9-37)
+    // Ion-mobility tiles are sparse, and adding a zero leaves every one of these sums unchanged,
+    // so only non-zero cells do work.  The 64 lanes read 64 consecutive cells (coalesced); the
+    // non-zero ones compute their weight exp(-0.1 * distance to the template centre) and their
+    // float64 products in parallel and are compacted IN ORDER into a small LDS list; one lane per
+    // (fragment, observation) plane touched by the chunk then folds its entries sequentially,
+    // which keeps the reference's summation order (s outer, f inner).
+    {
+        double *const acc_vi = ohe_u, *const acc_vm = omz_u;   // value sums; turned into the means below
+        double *const acc_wi = D + lay.d_accw(), *const acc_wm = acc_wi + Kc * Oc;
+        for (int c = lane; c < K0 * O; c += ADH_WAVE) {
+            acc_vi[c] = 0.0;
+            acc_vm[c] = 0.0;
+            acc_wi[c] = 0.0;
+            acc_wm[c] = 0.0;
+        }
+        __syncthreads();
+        const int n_cells = K0 * OSF;
+        constexpr int PF = 4;  // chunks in flight
+        for (int base0 = 0; base0 < n_cells; base0 += PF * ADH_WAVE) {
+          float2 rawv[PF];
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) buf[u] = p[sc * F + min(f0 + u, F - 1)];
+          for (int u = 0; u < PF; ++u) {
+              const int cu = base0 + u * ADH_WAVE + lane;
+              rawv[u] = fcells[min(cu, n_cells - 1)];
+          }
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const int f = f0 + u;
-                        if (f < F) {
-                            const float v = buf[u].x * q;  // candidate.py:290
-                            sf += v;
-                            ffp_u[ko * F + f] += v;
-                            if (v > 0.0f) {
-                                any = true;
-                                values += (double)v * w[sc * F + f];
-                                weights += w[sc * F + f];
-                            }
-                        }
+          for (int u = 0; u < PF; ++u) {
+            const int base = base0 + u * ADH_WAVE;
+            if (base >= n_cells) break;
+            const int ci = base + lane;
+            float2 raw = rawv[u];
+            if (ci >= n_cells) raw = make_float2(0.0f, 0.0f);
+            const bool nz = raw.x > 0.0f || raw.y > 0.0f;
+            const unsigned long long mask = __ballot(nz);
+            if (mask == 0ull) continue;
+            if (nz) {
+                const int ko = ci / SF, rem = ci - ko * SF;
+                const int sc = rem / F, f = rem - sc * F;
+                const int o = ko % O;
+                const float v = raw.x * qmask[o * S + sc];  // candidate.py:290
+                const double ds = (double)sc - esc[o], df = (double)f - efc[o];
+                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
+                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                l_cell[pos] = ci;
+                l_v[pos] = v;
+                l_w[pos] = w;
+                l_ti[pos] = (double)v * w;
+                l_tm[pos] = (double)raw.y * w;
+            }
+            __syncthreads();
+            const int n_ent = __popcll(mask);
+            const int ko_lo = base / SF;
+            const int ko_hi = (min(base + ADH_WAVE, n_cells) - 1) / SF;
+            const int ko = ko_lo + lane;
+            if (ko <= ko_hi) {
+                double vi = acc_vi[ko], wi = acc_wi[ko], vm = acc_vm[ko], wm = acc_wm[ko];
+                for (int e = 0; e < n_ent; ++e) {
+                    const int cell = l_cell[e];
+                    const int rem = cell - ko * SF;
+                    if (rem < 0 || rem >= SF) continue;
+                    const int sc = rem / F, f = rem - sc * F;
+                    const float v = l_v[e];
+                    fsp_u[ko * S + sc] += v;
+                    ffp_u[ko * F + f] += v;
+                    if (v > 0.0f) {
+                        vi += l_ti[e];
+                        wi += l_w[e];
+                    }
+                    if (l_tm[e] > 0.0) {  // m/z channel of the cell is > 0
+                        vm += l_tm[e];
+                        wm += l_w[e];
                     }
                 }
-                fsp_u[ko * S + sc] = sf;
+                acc_vi[ko] = vi;
+                acc_wi[ko] = wi;
+                acc_vm[ko] = vm;
+                acc_wm[ko] = wm;
             }
-            ohe_u[ko] = (any && weights > 0) ? values / weights : 0.0;
-        } else {
-            for (int s0 = 0; s0 < SF; s0 += NB) {
-                float2 buf[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) buf[u] = p[min(s0 + u, SF - 1)];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int sf = s0 + u;
-                    const float v = buf[u].y;
-                    if (sf < SF && v > 0.0f) {
-                        any = true;
-                        values += (double)v * w[sf];
-                        weights += w[sf];
-                    }
-                }
-            }
-            omz_u[ko] = (any && weights > 0) ? values / weights : 0.0;
+            __syncthreads();
+          }
+        }
+        for (int c = lane; c < K0 * O; c += ADH_WAVE) {
+            const double vi = acc_vi[c], wi = acc_wi[c], vm = acc_vm[c], wm = acc_wm[c];
+            ohe_u[c] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
+            omz_u[c] = (wm > 0) ? vm / wm : 0.0;
         }
     }
     __syncthreads();
+    if (caps.stop_phase == 3) return;
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
         for (int o = 0; o < O; ++o) {
@@ -458,6 +498,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     __syncthreads();
 
+    if (caps.stop_phase == 4) return;
     // =========================== features ===========================
     if (lane < I) {
         float ss = 0;
@@ -477,7 +518,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             float v = p[sf];
             if (v > 0.0f) {
                 any = true;
-                double w = wtp[sf];
+                // weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
+                const int sc = sf / F, f = sf - sc * F;
+                const double ds = (double)(sc - S), df = (double)(f - 1);
+                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
                 values += (double)v * w;
                 weights += w;
             }
@@ -612,6 +656,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         featv[3] = (float)run.mobility[r.scan_center];
     }
 
+    if (caps.stop_phase == 5) return;
     // =========================== fragment_mobility_correlation (fragment_features.py:430-480)
     // centred scan profiles go to the second work buffer, centred frame profiles later
     __syncthreads();
@@ -701,6 +746,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     __syncthreads();
 
+    if (caps.stop_phase == 6) return;
     // =========================== profile features (profile_features.py:18-206)
     float *isl = work_a, *nrm = work_b;  // free again once the scan correlation is done
     if (cfg.experimental_xic) {
