@@ -102,8 +102,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     extern __shared__ __align__(16) unsigned char smem[];
     // ordered list of the non-zero cells of one 64-cell chunk (see the tile passes below)
     __shared__ double l_ti[ADH_WAVE], l_tm[ADH_WAVE], l_w[ADH_WAVE];
-    __shared__ float l_v[ADH_WAVE];
-    __shared__ int l_cell[ADH_WAVE];
+    __shared__ float l_v[ADH_WAVE], l_rx[3 * ADH_WAVE], l_ry[3 * ADH_WAVE];
+    __shared__ int l_cell[3 * ADH_WAVE];
     const Layout lay(caps);
     const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
@@ -287,11 +287,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     //   frame profile ffp[f] = sum_s x[s][f]            (scoring/utils.py:26-53 input)
     //   weighted centre means of both channels         (features_utils.py:9-37)
     // Ion-mobility tiles are sparse, and adding a zero leaves every one of these sums unchanged,
-    // so only non-zero cells do work.  The 64 lanes read 64 consecutive cells (coalesced); the
-    // non-zero ones compute their weight exp(-0.1 * distance to the template centre) and their
-    // float64 products in parallel and are compacted IN ORDER into a small LDS list; one lane per
-    // (fragment, observation) plane touched by the chunk then folds its entries sequentially,
-    // which keeps the reference's summation order (s outer, f inner).
+    // so only non-zero cells do work.  The 64 lanes read 64 consecutive cells (coalesced) and
+    // compact the non-zero ones IN ORDER into a small LDS list.  Whenever 64 entries are waiting,
+    // every lane computes the weight exp(-0.1 * distance to the template centre) and the float64
+    // products of one entry, and one lane per (fragment, observation) plane then folds its entries
+    // sequentially, which keeps the reference's summation order (s outer, f inner).
     {
         double *const acc_vi = ohe_u, *const acc_vm = omz_u;   // value sums; turned into the means below
         double *const acc_wi = D + lay.d_accw(), *const acc_wm = acc_wi + Kc * Oc;
@@ -303,48 +303,29 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         __syncthreads();
         const int n_cells = K0 * OSF;
-        constexpr int PF = 4;  // chunks in flight
-        for (int base0 = 0; base0 < n_cells; base0 += PF * ADH_WAVE) {
-          float2 rawv[PF];
-#pragma unroll
-          for (int u = 0; u < PF; ++u) {
-              const int cu = base0 + u * ADH_WAVE + lane;
-              rawv[u] = fcells[min(cu, n_cells - 1)];
-          }
-#pragma unroll
-          for (int u = 0; u < PF; ++u) {
-            const int base = base0 + u * ADH_WAVE;
-            if (base >= n_cells) break;
-            const int ci = base + lane;
-            float2 raw = rawv[u];
-            if (ci >= n_cells) raw = make_float2(0.0f, 0.0f);
-            const bool nz = raw.x > 0.0f || raw.y > 0.0f;
-            const unsigned long long mask = __ballot(nz);
-            if (mask == 0ull) continue;
-            if (nz) {
+        // fold the first `count` list entries: weights and products by all lanes, then one lane per
+        // plane adds up its entries in list (= cell) order
+        auto flush = [&](int count) {
+            if (lane < count) {
+                const int ci = l_cell[lane];
+                const float rx = l_rx[lane], ry = l_ry[lane];
                 const int ko = ci / SF, rem = ci - ko * SF;
                 const int sc = rem / F, f = rem - sc * F;
                 const int o = ko % O;
-                const float v = raw.x * qmask[o * S + sc];  // candidate.py:290
+                const float v = rx * qmask[o * S + sc];  // candidate.py:290
                 const double ds = (double)sc - esc[o], df = (double)f - efc[o];
                 const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-                l_cell[pos] = ci;
-                l_v[pos] = v;
-                l_w[pos] = w;
-                l_ti[pos] = (double)v * w;
-                l_tm[pos] = (double)raw.y * w;
+                l_v[lane] = v;
+                l_w[lane] = w;
+                l_ti[lane] = (double)v * w;
+                l_tm[lane] = (double)ry * w;
             }
             __syncthreads();
-            const int n_ent = __popcll(mask);
-            const int ko_lo = base / SF;
-            const int ko_hi = (min(base + ADH_WAVE, n_cells) - 1) / SF;
-            const int ko = ko_lo + lane;
-            if (ko <= ko_hi) {
+            const int ko_lo = l_cell[0] / SF, ko_hi = l_cell[count - 1] / SF;
+            for (int ko = ko_lo + lane; ko <= ko_hi; ko += ADH_WAVE) {
                 double vi = acc_vi[ko], wi = acc_wi[ko], vm = acc_vm[ko], wm = acc_wm[ko];
-                for (int e = 0; e < n_ent; ++e) {
-                    const int cell = l_cell[e];
-                    const int rem = cell - ko * SF;
+                for (int e = 0; e < count; ++e) {
+                    const int rem = l_cell[e] - ko * SF;
                     if (rem < 0 || rem >= SF) continue;
                     const int sc = rem / F, f = rem - sc * F;
                     const float v = l_v[e];
@@ -365,8 +346,73 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 acc_wm[ko] = wm;
             }
             __syncthreads();
-          }
+        };
+        int n_list = 0;        // entries waiting in the list (wave-uniform)
+        constexpr int PF = 4;  // 128-cell chunks in flight (a lane reads two neighbouring cells)
+        const float4 *cells4 = reinterpret_cast<const float4 *>(fcells);  // 16-byte aligned block
+        const int n_pairs = (n_cells + 1) / 2;  // (an odd tile reads 8 bytes of the next array: masked)
+        for (int base0 = 0; base0 < n_pairs; base0 += PF * ADH_WAVE) {
+            float4 rawv[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int pu = base0 + u * ADH_WAVE + lane;
+                rawv[u] = cells4[min(pu, n_pairs - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int pu = base0 + u * ADH_WAVE + lane;
+                const int ci = 2 * pu;
+                const float4 raw = rawv[u];
+                const bool nz0 = pu < n_pairs && (raw.x > 0.0f || raw.y > 0.0f);
+                const bool nz1 = pu < n_pairs && ci + 1 < n_cells && (raw.z > 0.0f || raw.w > 0.0f);
+                const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
+                if ((m0 | m1) == 0ull) continue;
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int pos = n_list + __popcll(m0 & lt) + __popcll(m1 & lt);
+                if (nz0) {
+                    l_cell[pos] = ci;
+                    l_rx[pos] = raw.x;
+                    l_ry[pos] = raw.y;
+                    ++pos;
+                }
+                if (nz1) {
+                    l_cell[pos] = ci + 1;
+                    l_rx[pos] = raw.z;
+                    l_ry[pos] = raw.w;
+                }
+                n_list += __popcll(m0) + __popcll(m1);
+                while (n_list >= ADH_WAVE) {
+                    __syncthreads();
+                    flush(ADH_WAVE);
+                    // move the remainder (< 128 entries) to the front
+                    const int rest = n_list - ADH_WAVE;
+                    int c_t[2] = {0, 0};
+                    float x_t[2] = {0.0f, 0.0f}, y_t[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int e = lane + j * ADH_WAVE;
+                        if (e < rest) {
+                            c_t[j] = l_cell[ADH_WAVE + e];
+                            x_t[j] = l_rx[ADH_WAVE + e];
+                            y_t[j] = l_ry[ADH_WAVE + e];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int e = lane + j * ADH_WAVE;
+                        if (e < rest) {
+                            l_cell[e] = c_t[j];
+                            l_rx[e] = x_t[j];
+                            l_ry[e] = y_t[j];
+                        }
+                    }
+                    n_list = rest;
+                }
+            }
         }
+        __syncthreads();
+        if (n_list > 0) flush(n_list);
         for (int c = lane; c < K0 * O; c += ADH_WAVE) {
             const double vi = acc_vi[c], wi = acc_wi[c], vm = acc_vm[c], wm = acc_wm[c];
             ohe_u[c] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
