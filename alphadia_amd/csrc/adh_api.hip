@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -34,7 +37,8 @@ int fail(int code, const std::string &msg) {
         if (_e != hipSuccess) {                                                             \
             (void)hipGetLastError();                                                        \
             return fail(_e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP,   \
-                        std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+                        std::string(#expr) + " (adh_api.hip:" + std::to_string(__LINE__) + "): " +   \
+                            hipGetErrorString(_e));                                         \
         }                                                                                   \
     } while (0)
 
@@ -89,6 +93,10 @@ struct adh_handle {
     int64_t n_lib = 0;
     const float *d_iso = nullptr;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
+    void *scratch_slab = nullptr;   // per-candidate scratch blocks of the AlphaRaw plan
+    uint64_t scratch_slab_bytes = 0;
+    void *out_slab = nullptr;       // device copy of the output tables of adh_score_candidates
+    size_t out_slab_bytes = 0;
     HostCands hc;
     Plan plan;
     bool run_staged = false, lib_staged = false, cands_uploaded = false;
@@ -197,6 +205,8 @@ int adh_destroy(adh_handle_t *h) {
     }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->d_wtp) (void)hipFree(h->d_wtp);
+    if (h->out_slab) (void)hipFree(h->out_slab);
+    if (h->scratch_slab) (void)hipFree(h->scratch_slab);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -546,7 +556,9 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     const int NCLS = 7, GENERIC = 6;
     std::vector<uint32_t> head[NCLS];
     for (int c = 0; c < NCLS; ++c) head[c].assign((size_t)n_cyc + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
+    std::atomic<int> too_many{0};
+    auto build_range = [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i) {
         CandRec &r = recs[(size_t)i];
         memset(&r, 0, sizeof(r));
         r.precursor_idx = hc.precursor_idx[i];
@@ -564,8 +576,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         r.flags = hc.flags[i];
         r.row = (uint32_t)i;
         if (r.flags & ADH_FLAG_SKIP) {
-            cls[(size_t)i] = GENERIC;
-            ++head[GENERIC][1];  // parked in cycle bin 0 of the generic class; the kernels return at once
+            cls[(size_t)i] = GENERIC;  // parked in cycle bin 0 of the generic class; the kernels return at once
             continue;
         }
         // isotope m/z range exactly as the kernels compute it (candidate.py:151-163,203-205)
@@ -579,9 +590,10 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
         int O = 0;
         for (int row = 0; row < rows; ++row) {
             if ((double)q_lo <= cyc[2 * row + 1] && (double)q_hi >= cyc[2 * row]) {
-                if (O >= ADH_MAX_OBS)
-                    return fail(ADH_ERR_UNSUPPORTED,
-                                "a precursor overlaps more than 8 isolation windows");
+                if (O >= ADH_MAX_OBS) {
+                    too_many = 1;
+                    break;
+                }
                 r.obs[O++] = (uint16_t)row;
             }
         }
@@ -596,7 +608,23 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
                               F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
             cls[(size_t)i] = !fast ? GENERIC : (O - 1) * 3 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2));
         }
-        ++head[cls[(size_t)i]][(size_t)(r.frame_start / L) + 1];
+      }
+    };
+    {
+        // the records are independent: build them on a few host threads
+        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 4096}));
+        std::vector<std::thread> pool;
+        const int64_t per = (n + n_thr - 1) / n_thr;
+        for (int t = 1; t < n_thr; ++t)
+            pool.emplace_back(build_range, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+        build_range(0, std::min<int64_t>(n, per));
+        for (auto &th : pool) th.join();
+    }
+    if (too_many) return fail(ADH_ERR_UNSUPPORTED, "a precursor overlaps more than 8 isolation windows");
+    for (int64_t i = 0; i < n; ++i) {
+        const CandRec &r = recs[(size_t)i];
+        const size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)(r.frame_start / L);
+        ++head[cls[(size_t)i]][bin + 1];
     }
     // counting sort by (class, first cycle)
     size_t class_first[NCLS + 1] = {0};
@@ -636,10 +664,16 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     const CandRec *d_recs = nullptr;
     UP(h->plan_buf, ordered.data(), n, &d_recs);
     p.d_recs = const_cast<CandRec *>(d_recs);
-    void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, p.scratch_bytes));
-    h->plan_buf.ptrs.push_back(sp);
-    p.d_scratch = static_cast<unsigned char *>(sp);
+    // the scratch slab outlives the plan (grow-only): a new candidate table of similar size reuses it
+    if (h->scratch_slab_bytes < p.scratch_bytes) {
+        if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+        h->scratch_slab = nullptr;
+        h->scratch_slab_bytes = 0;
+        const uint64_t want = p.scratch_bytes + p.scratch_bytes / 8;
+        HIP_TRY(hipMalloc(&h->scratch_slab, want));
+        h->scratch_slab_bytes = want;
+    }
+    p.d_scratch = static_cast<unsigned char *>(h->scratch_slab);
     p.top_k_fragments = cfg->top_k_fragments;
     p.top_k_isotopes = cfg->top_k_isotopes;
     p.fast_ok = fast_cfg;
@@ -946,8 +980,12 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     if (!h || !c || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (out->n != c->n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
     if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
+    const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;  // developer switch: stage times to stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
     int rc = adh_upload_candidates(h, c);
     if (rc != ADH_OK) return rc;
+    const double t_1 = now();
     const int64_t n = c->n;
     const size_t tk = (size_t)out->top_k;
     struct Field {
@@ -986,40 +1024,54 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         (void **)&dev.fragment_number, (void **)&dev.fragment_type, (void **)&dev.fragment_charge,
         (void **)&dev.fragment_loss_type, (void **)&dev.stat_matched_peaks};
     const int NF = (int)(sizeof(fields) / sizeof(fields[0]));
-    DeviceBuffers tmp;
+    // one device slab for all tables, kept in the handle between calls
+    size_t total = 0;
     rc = ADH_OK;
-    for (int i = 0; i < NF && rc == ADH_OK; ++i) {
-        if (*fields[i].host == nullptr) {
-            if (i == NF - 1) {  // stats are optional
-                *dev_slots[i] = nullptr;
-                continue;
-            }
+    for (int i = 0; i < NF; ++i) {
+        if (*fields[i].host == nullptr && i != NF - 1) {
             rc = fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
             break;
         }
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(fields[i].bytes, 1));
-        if (e != hipSuccess) {
-            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
-            break;
+        total += (fields[i].bytes + 255) / 256 * 256;
+    }
+    if (rc == ADH_OK && h->out_slab_bytes < total) {
+        if (h->out_slab) (void)hipFree(h->out_slab);
+        h->out_slab = nullptr;
+        h->out_slab_bytes = 0;
+        hipError_t e = hipMalloc(&h->out_slab, std::max<size_t>(total, 256));
+        if (e != hipSuccess)
+            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(output tables): ") + hipGetErrorString(e));
+        else
+            h->out_slab_bytes = std::max<size_t>(total, 256);
+    }
+    if (rc == ADH_OK) {
+        size_t off = 0;
+        for (int i = 0; i < NF; ++i) {
+            *dev_slots[i] = (*fields[i].host == nullptr) ? nullptr : (void *)((unsigned char *)h->out_slab + off);
+            off += (fields[i].bytes + 255) / 256 * 256;
         }
-        tmp.ptrs.push_back(p);
-        *dev_slots[i] = p;
-        e = hipMemsetAsync(p, 0, std::max<size_t>(fields[i].bytes, 1), h->stream);
+        hipError_t e = hipMemsetAsync(h->out_slab, 0, std::max<size_t>(total, 256), h->stream);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
     }
+    const double t_2 = now();
     if (rc == ADH_OK) rc = adh_score_uploaded(h, cfg, &dev, (void *)h->stream);
+    const double t_3 = now();
     if (rc == ADH_OK) {
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess)
             rc = fail(ADH_ERR_HIP, std::string("scoring kernel: ") + hipGetErrorString(e));
     }
+    const double t_4 = now();
     for (int i = 0; i < NF && rc == ADH_OK; ++i) {
         if (*dev_slots[i] == nullptr || fields[i].bytes == 0) continue;
         hipError_t e = hipMemcpy(*fields[i].host, *dev_slots[i], fields[i].bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
     }
-    tmp.release();
+    const double t_5 = now();
+    if (timing)
+        fprintf(stderr, "[adh] score_candidates n=%lld: upload %.2f ms, output alloc+memset %.2f, plan+launch %.2f, "
+                        "kernels %.2f, D2H %.2f, free %.2f\n", (long long)n, t_1 - t_0, t_2 - t_1, t_3 - t_2,
+                t_4 - t_3, t_5 - t_4, now() - t_5);
     return rc;
 }
 

@@ -263,6 +263,21 @@ def main():
         except Exception:
             pass
 
+    # ---------------- the same batch through host buffers (PCIe both ways): reported, never `value` ----
+    if rank == 0 and world == 1:
+        try:
+            packed_all = pack_assembled(soa)
+            ctx.score_host(packed_all, cfgj)  # first call builds the plan
+            t0 = time.perf_counter()
+            reps_h = 3
+            for _ in range(reps_h):
+                ctx.score_host(packed_all, cfgj)
+            th = (time.perf_counter() - t0) / reps_h
+            result["config"]["host_buffers_ms_per_step"] = th * 1e3
+            result["config"]["host_buffers_precursors_per_s"] = n_prec_local / th
+        except Exception as exc:  # the metric does not depend on this leg
+            log(f"[bench] host-buffer leg skipped: {exc}")
+
     # ---------------- CPU baseline: the oracle on this host's cores ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
@@ -283,6 +298,14 @@ def main():
             if rate > best[0]:
                 best = (rate, th)
         rate, cores = best
+        # single-thread rate (the reference's pjit loop at thread_count = 1), short sample
+        probe1 = min(1500, n_local)
+        packed1 = pack_assembled(slice_soa(soa, 0, probe1))
+        oracle.score(case.dia, cols, packed1, cfgj, n_threads=1)
+        t0 = time.perf_counter()
+        oracle.score(case.dia, cols, packed1, cfgj, n_threads=1, reuse=oracle.score.last_buffers)
+        rate_1 = probe1 / (time.perf_counter() - t0)
+        all_rate = None
         sample = int(min(n_local, max(2000, rate * args.cpu_seconds)))
         sub = slice_soa(soa, 0, sample)
         packed = pack_assembled(sub)
@@ -312,6 +335,7 @@ def main():
             "sample": f"first {sample} candidates ({cpu_prec} precursors) of the same batch, "
                       f"{reps} x {dt:.2f}s, OpenMP over {cores} threads (fastest of the thread counts tried "
                       f"on this {ncpu}-thread host)",
+            "candidates_per_s_1_thread": rate_1,
             "valid_identical_to_gpu": same_valid,
             "max_rel_feature_diff_vs_gpu": max_rel,
         }

@@ -456,7 +456,7 @@ def golden_get_dense():
     rng = np.random.default_rng(11)
     L = case.dia.cycle_len
     d = dia_to_dict(case.dia)
-    n_cases = 24
+    n_cases = 32
     for i in range(n_cases):
         c0 = int(rng.integers(0, 40))
         nc = int(rng.integers(1, 18))
@@ -510,7 +510,7 @@ def golden_get_dense():
 def golden_fragcomp():
     """G6: FragmentCompetition.__call__ on a synthetic PSM / fragment table."""
     rng = np.random.default_rng(13)
-    n_psm = 1500
+    n_psm = 5000
     cycle = syn.make_cycle(n_ms2=8, mz_lo=400, mz_hi=480)
     precursor_idx = rng.permutation(n_psm).astype(np.uint32)
     rank = rng.integers(0, 2, n_psm).astype(np.uint8)
@@ -627,7 +627,7 @@ def golden_timstof():
     jit = timstof_to_jit(case.dia)
     rng = np.random.default_rng(17)
     L, S = case.dia.cycle_len, case.dia.scan_max_index
-    n_cases = 12
+    n_cases = 16
     for i in range(n_cases):
         c0 = int(rng.integers(0, 20)); nc = int(rng.integers(3, 12))
         s0 = int(rng.integers(0, S - 24)); ns = int(rng.integers(4, 24))
@@ -685,6 +685,11 @@ def golden_timstof():
 
 if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
+        golden_timstof()
+        sys.exit(0)
+    if "--small-only" in sys.argv:
+        golden_get_dense()
+        golden_fragcomp()
         golden_timstof()
         sys.exit(0)
     if "--edges-only" in sys.argv:
