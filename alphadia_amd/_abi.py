@@ -364,3 +364,113 @@ def pack_config(cfg) -> ScoringConfig:
         float(cfg.fragment_mz_tolerance),
         int(bool(cfg.experimental_xic)),
     )
+
+
+# ---------------------------------------------------------------------------
+# candidate selection (include/alphadia_hip.h: adh_precursors_t, adh_selection_config_t,
+# adh_candidate_table_t)
+
+
+class Precursors(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("precursor_idx", C.POINTER(C.c_uint32)),
+        ("frag_start_idx", C.POINTER(C.c_uint32)),
+        ("frag_stop_idx", C.POINTER(C.c_uint32)),
+        ("charge", C.POINTER(C.c_uint8)),
+        ("rt", C.POINTER(C.c_float)),
+        ("mobility", C.POINTER(C.c_float)),
+        ("mz", C.POINTER(C.c_float)),
+        ("isotope_intensity", C.POINTER(C.c_float)),
+        ("n_isotope_cols", C.c_int32),
+    ]
+
+
+class SelectionConfig(C.Structure):
+    _fields_ = [
+        ("rt_tolerance", C.c_double),
+        ("precursor_mz_tolerance", C.c_double),
+        ("fragment_mz_tolerance", C.c_double),
+        ("candidate_count", C.c_int64),
+        ("top_k_precursors", C.c_int64),
+        ("kernel_size", C.c_int64),
+        ("f_mobility", C.c_double),
+        ("f_rt", C.c_double),
+        ("center_fraction", C.c_double),
+        ("min_size_mobility", C.c_int64),
+        ("min_size_rt", C.c_int64),
+        ("max_size_mobility", C.c_int64),
+        ("max_size_rt", C.c_int64),
+        ("join_close_candidates_scan_threshold", C.c_double),
+        ("join_close_candidates_cycle_threshold", C.c_double),
+        ("feature_mean", C.c_double),
+        ("feature_std", C.c_double),
+        ("feature_weight", C.c_double),
+        ("exclude_shared_ions", C.c_uint8),
+        ("use_weighted_score", C.c_uint8),
+        ("join_close_candidates", C.c_uint8),
+        ("pad0", C.c_uint8),
+    ]
+
+
+CANDIDATE_TABLE_FIELDS = [
+    ("precursor_idx", np.uint32),
+    ("rank", np.uint8),
+    ("score", np.float32),
+    ("scan_center", np.uint32),
+    ("scan_start", np.uint32),
+    ("scan_stop", np.uint32),
+    ("frame_center", np.uint32),
+    ("frame_start", np.uint32),
+    ("frame_stop", np.uint32),
+]
+
+
+class CandidateTable(C.Structure):
+    _fields_ = [("n", C.c_int64)] + [
+        (name, C.POINTER(_CT[np.dtype(dt)])) for name, dt in CANDIDATE_TABLE_FIELDS
+    ]
+
+
+def pack_precursors(precursor_idx, frag_start_idx, frag_stop_idx, charge, rt, mobility, mz,
+                    isotope_intensity) -> Marshalled:
+    """The columns of PrecursorFlatContainer (selection.py:712-737), sorted by precursor_idx."""
+    iso = as_c(isotope_intensity, np.float32)
+    if iso.ndim != 2:
+        raise ValueError("isotope_intensity must be 2-D (precursors x isotopes)")
+    u32 = [as_c(a, np.uint32) for a in (precursor_idx, frag_start_idx, frag_stop_idx)]
+    ch = as_c(charge, np.uint8)
+    f32 = [as_c(a, np.float32) for a in (rt, mobility, mz)]
+    n = u32[0].shape[0]
+    if any(a.shape != (n,) for a in u32 + [ch] + f32) or iso.shape[0] != n:
+        raise ValueError("precursor columns differ in length")
+    s = Precursors(n, *[_ptr(a, C.c_uint32) for a in u32], _ptr(ch, C.c_uint8),
+                   *[_ptr(a, C.c_float) for a in f32], _ptr(iso, C.c_float), iso.shape[1])
+    return Marshalled(s, u32 + [ch] + f32 + [iso])
+
+
+def pack_selection_config(cfg) -> SelectionConfig:
+    """``cfg`` exposes the CandidateSelectionConfigJIT fields (config_df.py:15-110)."""
+
+    def first(x):
+        a = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        if a.size != 1:
+            raise ValueError("only the single-feature score of the reference is supported")
+        return float(a[0])
+
+    return SelectionConfig(
+        float(cfg.rt_tolerance), float(cfg.precursor_mz_tolerance), float(cfg.fragment_mz_tolerance),
+        int(cfg.candidate_count), int(cfg.top_k_precursors), int(cfg.kernel_size),
+        float(cfg.f_mobility), float(cfg.f_rt), float(cfg.center_fraction),
+        int(cfg.min_size_mobility), int(cfg.min_size_rt), int(cfg.max_size_mobility), int(cfg.max_size_rt),
+        float(cfg.join_close_candidates_scan_threshold), float(cfg.join_close_candidates_cycle_threshold),
+        first(cfg.feature_mean), first(cfg.feature_std), first(cfg.feature_weight),
+        int(bool(cfg.exclude_shared_ions)), int(bool(cfg.use_weighted_score)),
+        int(bool(cfg.join_close_candidates)), 0,
+    )
+
+
+def alloc_candidate_table(n_rows: int):
+    arrays = {name: np.zeros(n_rows, dtype=dt) for name, dt in CANDIDATE_TABLE_FIELDS}
+    s = CandidateTable(n_rows, *[_ptr(arrays[name], _CT[np.dtype(dt)]) for name, dt in CANDIDATE_TABLE_FIELDS])
+    return Marshalled(s, arrays), arrays

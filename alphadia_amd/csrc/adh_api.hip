@@ -21,6 +21,7 @@
 #include "adh_gather_im.hip"
 #include "adh_features_im.hip"
 #include "adh_fragcomp.hip"
+#include "adh_select.hip"
 
 namespace {
 
@@ -93,6 +94,8 @@ struct adh_handle {
     int64_t n_lib = 0;
     const float *d_iso = nullptr;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
+    std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
+    double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
     void *scratch_slab = nullptr;   // per-candidate scratch blocks of the AlphaRaw plan
     uint64_t scratch_slab_bytes = 0;
     void *out_slab = nullptr;       // device copy of the output tables of adh_score_candidates
@@ -333,6 +336,7 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     UP(h->run_buf, d->cycle, (int64_t)d->cycle_len * d->cycle_scans * 2, &r.cycle);
     UP(h->run_buf, ms1.data(), (int64_t)ms1.size(), &r.ms1_obs);
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)d->cycle_len * d->cycle_scans * 2);
+    h->h_rt.assign(d->rt_values, d->rt_values + d->n_spectra);
 
     // ---- transposed run (see adh_gather.hip): bins, block size, table size
     if (!any) mz_lo = mz_hi = 1.0f;
@@ -1073,6 +1077,119 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
                         "kernels %.2f, D2H %.2f, free %.2f\n", (long long)n, t_1 - t_0, t_2 - t_1, t_3 - t_2,
                 t_4 - t_3, t_5 - t_4, now() - t_5);
     return rc;
+}
+
+int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh_selection_config_t *cfg,
+                          const float *kernel, int32_t k_rows, int32_t k_cols, adh_candidate_table_t *out) {
+    if (!h || !pc || !cfg || !kernel || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!h->run_staged) return fail(ADH_ERR_NOT_STAGED, "no AlphaRaw run staged (candidate selection supports AlphaRaw runs)");
+    if (!h->d_lib) return fail(ADH_ERR_NOT_STAGED, "no fragment library staged");
+    if (pc->n < 0 || cfg->candidate_count <= 0 || cfg->candidate_count > sel::MAX_CAND)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "candidate_count must be in 1..16");
+    if (out->n != pc->n * cfg->candidate_count)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "candidate table rows != precursors x candidate_count");
+    if (k_rows <= 0 || k_cols <= 0 || cfg->top_k_precursors <= 0 || pc->n_isotope_cols <= 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "kernel / isotope dimensions must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t n = pc->n;
+    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
+                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
+    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
+    for (int f = 0; f < 9; ++f) {
+        if (!host_out[f]) return fail(ADH_ERR_INVALID_ARGUMENT, "candidate table buffer is NULL");
+        memset(host_out[f], 0, (size_t)out->n * width[f]);
+    }
+    if (n == 0) return ADH_OK;
+    // validate the fragment slices, size the LDS: longest slice, largest tile (the frame limits
+    // of get_frame_indices, jitclasses/utils.py:24-88, depend on the tolerance only through the
+    // number of cycles)
+    sel::SelCaps caps{};
+    caps.n_iso = (int32_t)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
+    caps.k_rows = k_rows;
+    caps.k_cols = k_cols;
+    const int L = h->run.cycle_len;
+    const int64_t cmax = h->run.n_spectra / L;
+    const std::vector<float> &rtv = h->h_rt;
+    for (int64_t i = 0; i < n; ++i) {
+        if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+        if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+        caps.n_lib = std::max<int32_t>(caps.n_lib, (int32_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]));
+        const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
+        const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), lo) - rtv.begin();
+        const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), hi) - rtv.begin();
+        int64_t len = std::max<int64_t>(f_hi / L - f_lo / L, cfg->kernel_size);
+        len = 16 * ((len + 15) / 16);
+        caps.f = std::max<int32_t>(caps.f, (int32_t)std::min<int64_t>(len, std::max<int64_t>(cmax, 1)));
+    }
+    caps.n_lib = std::max(caps.n_lib, 1);
+    caps.f = std::max(caps.f, 1);
+    const size_t lds = sel::lds_bytes(caps);
+    if (lds > 150 * 1024) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "selection tile needs %zu bytes of LDS (%d cycles, %d fragments): exceeds 150 KiB",
+                 lds, caps.f, caps.n_lib);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    DeviceBuffers tmp;
+    DevPrecursors dp{};
+    dp.n_iso_cols = pc->n_isotope_cols;
+    int rc = upload(tmp, pc->precursor_idx, n, &dp.precursor_idx, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->frag_start_idx, n, &dp.frag_start, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->frag_stop_idx, n, &dp.frag_stop, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->charge, n, &dp.charge, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->rt, n, &dp.rt, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->mz, n, &dp.mz, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->isotope_intensity, n * pc->n_isotope_cols, &dp.iso, h->stream);
+    const float *d_kernel = nullptr;
+    if (rc == ADH_OK) rc = upload(tmp, kernel, (int64_t)k_rows * k_cols, &d_kernel, h->stream);
+    DevCandTable dt{};
+    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
+                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
+                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (size_t)out->n * width[f]);
+        if (e != hipSuccess) {
+            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
+            break;
+        }
+        tmp.ptrs.push_back(p);
+        *dev_out[f] = p;
+        e = hipMemsetAsync(p, 0, (size_t)out->n * width[f], h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    if (rc == ADH_OK) {
+        (void)hipFuncSetAttribute((const void *)adh_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipGetLastError();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream, h->run, h->d_lib,
+                           dp, n, *cfg, d_kernel, caps, dt);
+        hipError_t e = hipGetLastError();
+        (void)hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("selection kernel: ") + hipGetErrorString(e));
+        float ms = 0.0f;
+        if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) h->last_select_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    tmp.release();
+    return rc;
+}
+
+int adh_select_time_ms(adh_handle_t *h, double *kernel_ms) {
+    if (!h || !kernel_ms) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *kernel_ms = h->last_select_ms;
+    return ADH_OK;
 }
 
 int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start,

@@ -31,6 +31,8 @@ EXPORTED_SYMBOLS = [
     "adh_synchronize",
     "adh_kernel_time_ms",
     "adh_fragcomp",
+    "adh_select_candidates",
+    "adh_select_time_ms",
 ]
 
 
@@ -173,6 +175,29 @@ class Context:
         return g.value, f.value, n.value
 
     # -- fragment competition -------------------------------------------
+    def select_candidates(self, precursors: _abi.Marshalled, cfg, kernel) -> dict:
+        """Candidate selection on the staged AlphaRaw run and library: packed precursor table in,
+        the CandidateContainer arrays out (rows without a candidate keep score 0)."""
+        c = _abi.pack_selection_config(cfg)
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        if k.ndim != 2:
+            raise ValueError("kernel must be 2-D (scan, cycle)")
+        n = int(precursors.struct.n) * int(c.candidate_count)
+        m_out, arrays = _abi.alloc_candidate_table(n)
+        _check(
+            lib.adh_select_candidates(
+                self._h, precursors.ref(), C.byref(c), k.ctypes.data_as(C.POINTER(C.c_float)),
+                C.c_int32(k.shape[0]), C.c_int32(k.shape[1]), m_out.ref(),
+            ),
+            "adh_select_candidates",
+        )
+        return arrays
+
+    def select_time_ms(self) -> float:
+        ms = C.c_double(0.0)
+        _check(lib.adh_select_time_ms(self._h, C.byref(ms)), "adh_select_time_ms")
+        return float(ms.value)
+
     def fragcomp(self, window_start, window_stop, rt, frag_start, frag_stop, fragment_mz,
                  rt_tol_seconds: float, mass_tol_ppm: float) -> np.ndarray:
         ws = _abi.as_c(window_start, np.int64)

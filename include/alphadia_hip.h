@@ -249,6 +249,80 @@ int adh_fragcomp(adh_handle_t *handle, int64_t n_windows, const int64_t *window_
                  int64_t n_frag, const float *fragment_mz, double rt_tol_seconds,
                  double mass_tol_ppm, uint8_t *valid);
 
+/* ------------------------------------------------------------------------
+ * Candidate selection - the step before scoring.
+ * Non-ion-mobility (AlphaRaw) runs.
+ * ---------------------------------------------------------------------- */
+
+/*
+ * Precursor table of the selection step: the columns of PrecursorFlatContainer
+ * (search/selection/config_df.py; filled by
+ * CandidateSelection._assemble_precursor_container, selection.py:712-737),
+ * sorted by precursor_idx.
+ */
+typedef struct adh_precursors {
+    int64_t n;
+    const uint32_t *precursor_idx;
+    const uint32_t *frag_start_idx;
+    const uint32_t *frag_stop_idx;
+    const uint8_t *charge;
+    const float *rt;                 /* the configured rt column, seconds */
+    const float *mobility;           /* unused for AlphaRaw runs */
+    const float *mz;                 /* the configured precursor m/z column */
+    const float *isotope_intensity;  /* [n][n_isotope_cols], row-major (columns i_0, i_1, ...) */
+    int32_t n_isotope_cols;
+} adh_precursors_t;
+
+/* CandidateSelectionConfigJIT (search/selection/config_df.py:15-110), single score feature. */
+typedef struct adh_selection_config {
+    double rt_tolerance;
+    double precursor_mz_tolerance;
+    double fragment_mz_tolerance;
+    int64_t candidate_count;
+    int64_t top_k_precursors;        /* isotopes used */
+    int64_t kernel_size;
+    double f_mobility, f_rt, center_fraction;
+    int64_t min_size_mobility, min_size_rt, max_size_mobility, max_size_rt;
+    double join_close_candidates_scan_threshold;
+    double join_close_candidates_cycle_threshold;
+    double feature_mean, feature_std, feature_weight;  /* used when use_weighted_score */
+    uint8_t exclude_shared_ions;
+    uint8_t use_weighted_score;
+    uint8_t join_close_candidates;
+    uint8_t pad0;
+} adh_selection_config_t;
+
+/*
+ * CandidateContainer (search/selection/config_df.py:227-254): n = precursors x
+ * candidate_count rows, row (i * candidate_count + rank); rows that hold no
+ * candidate keep score = 0 (candidate_container_to_df drops them, :270-298).
+ */
+typedef struct adh_candidate_table {
+    int64_t n;
+    uint32_t *precursor_idx;
+    uint8_t *rank;
+    float *score;
+    uint32_t *scan_center, *scan_start, *scan_stop;
+    uint32_t *frame_center, *frame_start, *frame_stop;
+} adh_candidate_table_t;
+
+/*
+ * Select up to candidate_count (rt) boxes per precursor on the staged AlphaRaw
+ * run and fragment library.  Replaces the pjit loop `_select_candidates_pjit`
+ * (search/selection/selection.py:78-203): dense XICs of isotopes and fragments
+ * over rt +- rt_tolerance, circular convolution with `kernel`
+ * (GaussianKernel.get_dense_matrix, selection/kernel.py:141-218; the reference
+ * does it by FFT, selection/fft.py:119-212), log-sum score, peak picking and
+ * symmetric limits (selection/utils.py:46-312).  Host buffers in and out; `out`
+ * is zero-filled by the call.
+ */
+int adh_select_candidates(adh_handle_t *handle, const adh_precursors_t *precursors,
+                          const adh_selection_config_t *config, const float *kernel,
+                          int32_t kernel_rows, int32_t kernel_cols, adh_candidate_table_t *out);
+
+/* Duration (ms, HIP events) of the selection kernel of the last adh_select_candidates call. */
+int adh_select_time_ms(adh_handle_t *handle, double *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

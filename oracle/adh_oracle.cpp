@@ -1306,6 +1306,284 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
 } /* namespace */
 
 /* =============================================================== C entry points */
+/* =====================================================================================
+ * Candidate selection: restatement of _select_candidates_pjit /
+ * _build_candidates, alphadia/search/selection/selection.py:78-526, for AlphaRaw runs.
+ * The reference smooths with an FFT (selection/fft.py:119-212, float32 pocketfft, fastmath);
+ * this restatement evaluates the same circular convolution directly in float64 and rounds to
+ * float32, so scores agree to ~1e-5 relative, not bitwise.
+ * ===================================================================================== */
+namespace select_oracle {
+
+struct Box {
+    int scan, cycle;
+    double score;
+    int scan_lim[2], cycle_lim[2];
+};
+
+/* selection/utils.py:218-280 */
+static void symetric_limits_1d(const std::vector<double> &a, int center, double f, double center_fraction,
+                               int64_t min_size, int64_t max_size, int out[2]) {
+    const int n = (int)a.size();
+    if (n == 0 || center < 0 || center >= n) {
+        out[0] = out[1] = center;
+        return;
+    }
+    const double center_intensity = a[center];
+    double trailing = center_intensity;
+    int64_t limit = min_size;
+    for (int64_t s = min_size + 1; s < max_size; ++s) {
+        const double intensity =
+            (a[std::max<int64_t>(center - s, 0)] + a[std::min<int64_t>(center + s, n - 1)]) / 2;
+        if (intensity < f * trailing) {
+            if (intensity > center_intensity * center_fraction) {
+                limit = s;
+                trailing = intensity;
+            } else {
+                break;
+            }
+        } else {
+            break;
+        }
+    }
+    out[0] = (int)std::max<int64_t>(center - limit, 0);
+    out[1] = (int)std::min<int64_t>(center + limit + 1, n);
+}
+
+static void select_one(const adh_alpharaw_t &d, const adh_fragments_t &fr, const adh_precursors_t &pc,
+                       const adh_selection_config_t &cfg, const float *kernel, int k0, int k1,
+                       int64_t i, adh_candidate_table_t &out) {
+    const int L = d.cycle_len;
+    /* isotopes: assemble_isotope_mz (selection/utils.py:24-46): float32 array += float64 offsets */
+    const int n_iso = (int)std::min<int64_t>(cfg.top_k_precursors, pc.n_isotope_cols);
+    std::vector<float> iso_mz(n_iso);
+    for (int j = 0; j < n_iso; ++j) {
+        const double off = (double)j * 1.0033548350700006 / (double)pc.charge[i];
+        iso_mz[j] = (float)((double)pc.mz[i] + off);
+    }
+    /* fragments: slice, cardinality filter, sort by m/z (selection.py:124-139); no top-k here */
+    std::vector<float> fmz;
+    for (uint32_t j = pc.frag_start_idx[i]; j < pc.frag_stop_idx[i]; ++j)
+        if (!(cfg.exclude_shared_ions && fr.cardinality[j] > 1)) fmz.push_back(fr.mz[j]);
+    std::stable_sort(fmz.begin(), fmz.end());
+    if (fmz.size() <= 3) return;
+
+    /* get_frame_indices_tolerance -> get_frame_indices (jitclasses/utils.py:24-88) */
+    const float rt_lo = (float)((double)pc.rt[i] - cfg.rt_tolerance);
+    const float rt_hi = (float)((double)pc.rt[i] + cfg.rt_tolerance);
+    const float *rtv = d.rt_values;
+    const int64_t f_lo = std::lower_bound(rtv, rtv + d.n_spectra, rt_lo) - rtv;
+    const int64_t f_hi = std::lower_bound(rtv, rtv + d.n_spectra, rt_hi) - rtv;
+    const int64_t cmax = d.n_spectra / L; /* precursor_cycle_max_index, alpharaw_jit.py */
+    int64_t c_lo = f_lo / L, c_hi = f_hi / L;
+    int64_t len = std::max<int64_t>(c_hi - c_lo, cfg.kernel_size);
+    len = 16 * (int64_t)std::ceil((double)len / 16.0);
+    int64_t cs = c_lo, ce = c_lo + len;
+    if (ce > cmax) {
+        ce = cmax;
+        cs = cmax - len;
+        if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+    }
+    const int F = (int)(ce - cs);
+    if (F <= 0) return;
+
+    /* get_dense_intensity (alpharaw_jit.py:339-425): intensities of all valid scans are summed */
+    auto dense = [&](const std::vector<float> &mzq, double tol, double q_lo, double q_hi,
+                     std::vector<float> &tile) {
+        const int K = (int)mzq.size();
+        tile.assign((size_t)K * F, 0.0f);
+        std::vector<float> lo(K), hi(K);
+        for (int k = 0; k < K; ++k) { /* mass_range, jitclasses/utils.py:15-20 (float32) */
+            float t = (float)tol * mzq[k];
+            float q = t / 1000000.0f;
+            lo[k] = mzq[k] - q;
+            hi[k] = mzq[k] + q;
+        }
+        for (int f = 0; f < F; ++f) {
+            for (int row = 0; row < L; ++row) {
+                if (!(q_lo <= d.cycle[2 * row + 1] && q_hi >= d.cycle[2 * row])) continue;
+                const int64_t spec = row + (cs + f) * L;
+                if (spec >= d.n_spectra) continue;
+                int64_t idx = d.peak_start_idx[spec];
+                const int64_t pe = d.peak_stop_idx[spec];
+                for (int k = 0; k < K; ++k) {
+                    idx = std::lower_bound(d.mz_values + idx, d.mz_values + pe, lo[k]) - d.mz_values;
+                    while (idx < pe && d.mz_values[idx] <= hi[k]) {
+                        tile[(size_t)k * F + f] = tile[(size_t)k * F + f] + d.intensity_values[idx];
+                        ++idx;
+                    }
+                }
+            }
+        }
+    };
+    std::vector<float> tp, tf;
+    dense(iso_mz, cfg.precursor_mz_tolerance, -1.0, -1.0, tp);
+    dense(fmz, cfg.fragment_mz_tolerance, (double)iso_mz[0], (double)iso_mz[n_iso - 1], tf);
+    /* _is_valid (selection.py:40-75): S = 2 here */
+    if (n_iso == 0 || 2 < k0 || F < k1) return;
+
+    /* circular convolution with the kernel centred at (k0/2, k1/2) (selection/fft.py:163-212);
+       both scan slots of an AlphaRaw tile are identical (alpharaw_jit.py:417-418) */
+    const int d0 = k0 / 2, d1 = k1 / 2;
+    auto smooth_row = [&](const float *row, int s, std::vector<float> &outrow) {
+        outrow.resize(F);
+        for (int f = 0; f < F; ++f) {
+            double acc = 0.0;
+            for (int a = 0; a < k0 && a < 2; ++a) {
+                (void)s; /* dense[(s + d0 - a) mod 2] is the same row for every a */
+                for (int b = 0; b < k1 && b < F; ++b) {
+                    int src = (f + d1 - b) % F;
+                    if (src < 0) src += F;
+                    acc += (double)kernel[a * k1 + b] * (double)row[src];
+                }
+            }
+            outrow[f] = (float)acc;
+        }
+    };
+    (void)d0;
+    /* _build_features (selection.py:206-226): sum of log(smooth + 1) over fragments and isotopes.
+       The float32 log is taken as the rounded float64 log so that a second implementation can
+       reproduce it bit for bit. */
+    std::vector<float> feat(F, 0.0f), tmp;
+    {
+        std::vector<float> lf(F, 0.0f), lp(F, 0.0f);
+        const int K = (int)fmz.size();
+        for (int k = 0; k < K; ++k) {
+            smooth_row(&tf[(size_t)k * F], 0, tmp);
+            for (int f = 0; f < F; ++f) lf[f] += (float)std::log((double)(tmp[f] + 1.0f));
+        }
+        for (int k = 0; k < n_iso; ++k) {
+            smooth_row(&tp[(size_t)k * F], 0, tmp);
+            for (int f = 0; f < F; ++f) lp[f] += (float)std::log((double)(tmp[f] + 1.0f));
+        }
+        for (int f = 0; f < F; ++f) feat[f] = lf[f] + lp[f];
+    }
+    /* normalisation (selection.py:396-421) */
+    double mean, sd, weight;
+    if (cfg.use_weighted_score) {
+        mean = cfg.feature_mean;
+        sd = cfg.feature_std;
+        weight = cfg.feature_weight;
+    } else {
+        double m = 0;
+        for (int f = 0; f < F; ++f) m += 2.0 * (double)feat[f];
+        m /= (2.0 * F);
+        double v = 0;
+        for (int f = 0; f < F; ++f) v += 2.0 * ((double)feat[f] - m) * ((double)feat[f] - m);
+        mean = m;
+        sd = std::sqrt(v / (2.0 * F));
+        weight = 1.0;
+    }
+    std::vector<double> score(F);
+    for (int f = 0; f < F; ++f) score[f] = weight * ((double)feat[f] - mean) / (sd + 1e-6);
+
+    /* find_peaks_1d (selection/utils.py:49-77) on scan row 0 */
+    std::vector<Box> peaks;
+    for (int p = 2; p < F - 2; ++p)
+        if (score[p - 2] < score[p - 1] && score[p - 1] < score[p] && score[p] > score[p + 1] &&
+            score[p + 1] > score[p + 2]) {
+            Box b{};
+            b.scan = 0;
+            b.cycle = p;
+            b.score = score[p];
+            peaks.push_back(b);
+        }
+    /* argsort(intensity)[::-1][:top_n]: descending; equal scores in reversed index order */
+    std::stable_sort(peaks.begin(), peaks.end(), [](const Box &a, const Box &b) {
+        if (a.score != b.score) return a.score > b.score;
+        return a.cycle > b.cycle;
+    });
+    if ((int64_t)peaks.size() > cfg.candidate_count) peaks.resize((size_t)cfg.candidate_count);
+    /* _join_close_peaks (selection.py:229-278), scan and cycle tolerance 3 */
+    {
+        const int n = (int)peaks.size();
+        std::vector<char> mask(n, 1);
+        for (int a = 0; a < n; ++a) {
+            if (!mask[a]) continue;
+            for (int b = a + 1; b < n; ++b) {
+                if (!mask[b]) continue;
+                if (std::abs(peaks[a].scan - peaks[b].scan) <= 3 && std::abs(peaks[a].cycle - peaks[b].cycle) <= 3) {
+                    if (peaks[a].score > peaks[b].score)
+                        mask[b] = 0;
+                    else
+                        mask[a] = 0;
+                }
+            }
+        }
+        std::vector<Box> kept;
+        for (int a = 0; a < n; ++a)
+            if (mask[a]) kept.push_back(peaks[a]);
+        peaks.swap(kept);
+    }
+    /* symetric_limits_2d (selection/utils.py:283-312) on the (2, F) score matrix */
+    for (Box &b : peaks) {
+        const int mob_lower = (int)std::max<int64_t>(0, b.scan - cfg.min_size_mobility);
+        const int mob_upper = (int)std::min<int64_t>(2, b.scan + cfg.min_size_mobility);
+        const int cyc_lower = (int)std::max<int64_t>(0, b.cycle - cfg.min_size_rt);
+        const int cyc_upper = (int)std::min<int64_t>(F, b.cycle + cfg.min_size_rt);
+        std::vector<double> mob(2, 0.0), cyc(F, 0.0);
+        for (int s = 0; s < 2; ++s)
+            for (int f = cyc_lower; f < cyc_upper; ++f) mob[s] += score[f];
+        for (int f = 0; f < F; ++f)
+            for (int s = mob_lower; s < mob_upper; ++s) cyc[f] += score[f];
+        symetric_limits_1d(mob, b.scan, cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
+                           cfg.max_size_mobility, b.scan_lim);
+        symetric_limits_1d(cyc, b.cycle, cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt,
+                           b.cycle_lim);
+    }
+    /* _join_overlapping_candidates (selection.py:281-345) */
+    if (cfg.join_close_candidates) {
+        const int n = (int)peaks.size();
+        std::vector<char> mask(n, 1);
+        for (int a = 0; a < n; ++a) {
+            if (!mask[a]) continue;
+            for (int b = a + 1; b < n; ++b) {
+                if (!mask[b]) continue;
+                Box &A = peaks[a];
+                const Box &B = peaks[b];
+                const double cyc_len = (double)(A.cycle_lim[1] - A.cycle_lim[0]);
+                const double cyc_ov = (double)(std::min(A.cycle_lim[1], B.cycle_lim[1]) -
+                                               std::max(A.cycle_lim[0], B.cycle_lim[0])) / cyc_len;
+                const double scan_len = (double)(A.scan_lim[1] - A.scan_lim[0]);
+                const double scan_ov = (double)(std::min(A.scan_lim[1], B.scan_lim[1]) -
+                                                std::max(A.scan_lim[0], B.scan_lim[0])) / scan_len;
+                if (scan_ov < 0 || cyc_ov < 0) continue;
+                if (cyc_ov > cfg.join_close_candidates_cycle_threshold &&
+                    scan_ov > cfg.join_close_candidates_scan_threshold) {
+                    A.scan_lim[0] = std::min(A.scan_lim[0], B.scan_lim[0]);
+                    A.scan_lim[1] = std::max(A.scan_lim[1], B.scan_lim[1]);
+                    A.cycle_lim[0] = std::min(A.cycle_lim[0], B.cycle_lim[0]);
+                    A.cycle_lim[1] = std::max(A.cycle_lim[1], B.cycle_lim[1]);
+                    mask[b] = 0;
+                }
+            }
+        }
+        std::vector<Box> kept;
+        for (int a = 0; a < n; ++a)
+            if (mask[a]) kept.push_back(peaks[a]);
+        peaks.swap(kept);
+    }
+    /* absolute coordinates (selection.py:480-526); AlphaRaw: scan_max_index = 1,
+       frame_max_index = n_spectra - 1, scan_limits = [0, 2), frame_limits[0] = cs * L */
+    auto wrap0 = [](int64_t v, int64_t limit) { return v < 0 ? (int64_t)0 : std::min(v, limit); };
+    const int64_t scan_max = 1, frame_max = d.n_spectra - 1, frame0 = cs * L;
+    for (size_t r = 0; r < peaks.size(); ++r) {
+        const Box &b = peaks[r];
+        const int64_t row = i * cfg.candidate_count + (int64_t)r;
+        out.precursor_idx[row] = pc.precursor_idx[i];
+        out.rank[row] = (uint8_t)r;
+        out.score[row] = (float)b.score;
+        out.scan_center[row] = (uint32_t)wrap0(b.scan + 0, scan_max);
+        out.scan_start[row] = (uint32_t)wrap0(b.scan_lim[0] + 0, scan_max);
+        out.scan_stop[row] = (uint32_t)wrap0(b.scan_lim[1] + 0, scan_max);
+        out.frame_center[row] = (uint32_t)wrap0((int64_t)b.cycle * L + frame0, frame_max);
+        out.frame_start[row] = (uint32_t)wrap0((int64_t)b.cycle_lim[0] * L + frame0, frame_max);
+        out.frame_stop[row] = (uint32_t)wrap0((int64_t)b.cycle_lim[1] * L + frame0, frame_max);
+    }
+}
+
+}  // namespace select_oracle
+
 extern "C" {
 
 /*
@@ -1458,6 +1736,20 @@ int adh_oracle_fragcomp(int64_t n_windows, const int64_t *window_start, const in
         }
     }
     return ADH_OK;
+}
+
+/* Candidate selection for every precursor (selection.py:620-660); `out` must be zeroed. */
+int adh_oracle_select(const adh_alpharaw_t *run, const adh_fragments_t *fragments,
+                      const adh_precursors_t *precursors, const adh_selection_config_t *config,
+                      const float *kernel, int32_t kernel_rows, int32_t kernel_cols,
+                      adh_candidate_table_t *out, int32_t n_threads) {
+    if (!run || !fragments || !precursors || !config || !kernel || !out) return -1;
+    if (out->n != precursors->n * config->candidate_count) return -1;
+    const int64_t n = precursors->n;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int64_t i = 0; i < n; ++i)
+        select_oracle::select_one(*run, *fragments, *precursors, *config, kernel, kernel_rows, kernel_cols, i, *out);
+    return 0;
 }
 
 } /* extern "C" */

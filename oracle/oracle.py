@@ -38,6 +38,7 @@ def lib():
         _lib.adh_oracle_search_sorted_left.restype = C.c_int64
         _lib.adh_oracle_save_corrcoeff.restype = C.c_double
         _lib.adh_oracle_fragcomp.restype = C.c_int
+        _lib.adh_oracle_select.restype = C.c_int
     return _lib
 
 
@@ -236,3 +237,23 @@ def fragcomp(window_start, window_stop, rt, frag_start, frag_stop, fragment_mz, 
     if rc != 0:
         raise RuntimeError(f"adh_oracle_fragcomp failed: {rc}")
     return valid.view(np.bool_)
+
+
+def select(dia, fragment_cols, precursors_marshalled, cfg, kernel, n_threads: int = 1) -> dict:
+    """Restated ``_select_candidates_pjit`` (selection.py:78-203) over a packed precursor table.
+
+    Returns the full CandidateContainer arrays (rows without a candidate keep score 0)."""
+    m_dia = _abi.pack_alpharaw(dia)
+    m_frag = _abi.pack_fragments(*fragment_cols)
+    c = _abi.pack_selection_config(cfg)
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    n = int(precursors_marshalled.struct.n) * int(c.candidate_count)
+    m_out, arrays = _abi.alloc_candidate_table(n)
+    rc = lib().adh_oracle_select(
+        m_dia.ref(), m_frag.ref(), precursors_marshalled.ref(), C.byref(c),
+        k.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(k.shape[0]), C.c_int32(k.shape[1]),
+        m_out.ref(), C.c_int32(n_threads),
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_select failed ({rc})")
+    return arrays

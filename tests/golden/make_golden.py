@@ -449,6 +449,58 @@ def golden_edges():
           f"n_obs of 0..3: {np.asarray(out.features)[:4, 17]}")
 
 
+def golden_selection():
+    """Next-row golden: CandidateSelection.__call__ on a small AlphaRaw run.
+
+    Produced with the FFT stand-in of ref_shim.install_selection_glue (np.fft instead of
+    rocket_fft/pocketfft; float32 results): scores agree with any other exact convolution to
+    ~1e-5 relative, so a candidate whose score ties another one within that margin may swap or
+    move by a cycle.  The golden stores the smoothed score row of every precursor as well."""
+    import ref_shim
+
+    ref_shim.install_selection_glue()
+    from alphadia.search.selection import selection as ref_sel
+    from alphadia.search.selection.config_df import CandidateSelectionConfig
+
+    case = small_case(104, n_precursors=240, n_cycles=120, per_precursor=1, planted_fraction=0.7)
+    cfgs = {
+        "default": dict(rt_tolerance=30.0, candidate_count=3, min_size_rt=3),
+        "wide": dict(rt_tolerance=70.0, candidate_count=5, min_size_rt=2, exclude_shared_ions=False,
+                     join_close_candidates=False, precursor_mz_tolerance=20.0, fragment_mz_tolerance=30.0),
+    }
+    d = case_to_dict(case)
+    d["caveat"] = np.asarray(CAVEAT)
+    for name, upd in cfgs.items():
+        cfg = CandidateSelectionConfig()
+        cfg.update(upd)
+        dia = DuckDia(case.dia)
+        cs = ref_sel.CandidateSelection(
+            dia, case.library.precursor_df.copy(), case.library.fragment_df.copy(), cfg,
+            rt_column="rt_library", mobility_column="mobility_library",
+            precursor_mz_column="mz_library", fragment_mz_column="mz_library",
+            fwhm_rt=cfg.peak_len_rt, fwhm_mobility=cfg.peak_len_mobility,
+        )
+        df = cs(thread_count=1)
+        d[f"{name}_kernel"] = np.asarray(cs.kernel, dtype=np.float32)
+        cj = cs.config_jit
+        for k in ("rt_tolerance precursor_mz_tolerance fragment_mz_tolerance candidate_count "
+                  "top_k_precursors exclude_shared_ions kernel_size f_mobility f_rt center_fraction "
+                  "min_size_mobility min_size_rt max_size_mobility max_size_rt use_weighted_score "
+                  "join_close_candidates join_close_candidates_scan_threshold "
+                  "join_close_candidates_cycle_threshold").split():
+            d[f"{name}_cfg_{k}"] = np.asarray(getattr(cj, k))
+        for k in ("feature_mean", "feature_std", "feature_weight"):
+            d[f"{name}_cfg_{k}"] = np.asarray(getattr(cj, k), dtype=np.float64)
+        for c in ("precursor_idx rank score scan_center scan_start scan_stop frame_center frame_start "
+                  "frame_stop elution_group_idx decoy").split():
+            d[f"{name}_out_{c}"] = df[c].values
+        print(name, len(df), "candidates for", df["precursor_idx"].nunique(), "precursors;",
+              "ranks", np.bincount(df["rank"].values))
+    path = os.path.join(HERE, "selection.npz")
+    np.savez_compressed(path, **d)
+    print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
 def golden_get_dense():
     """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
     case = small_case(102, n_precursors=40)
@@ -687,6 +739,9 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--selection-only" in sys.argv:
+        golden_selection()
+        sys.exit(0)
     if "--small-only" in sys.argv:
         golden_get_dense()
         golden_fragcomp()
@@ -703,4 +758,5 @@ if __name__ == "__main__":
     golden_scoring()
     golden_multiplex()
     golden_edges()
+    golden_selection()
     golden_timstof()

@@ -138,6 +138,17 @@ def install(reference_root: str = REFERENCE_ROOT) -> None:
         sys.modules[m] = mod
     sys.modules["alpharaw"] = types.ModuleType("alpharaw")
 
+    # rocket_fft (pocketfft bindings for numba) is only needed by candidate selection; its
+    # functions are reached through numba overloads, which do not exist here (see
+    # install_selection_glue)
+    rf = types.ModuleType("rocket_fft")
+    rf.pocketfft = types.SimpleNamespace()
+    rfo = types.ModuleType("rocket_fft.overloads")
+    for n in "decrease_shape get_fct increase_shape ndshape_and_axes resize zeropad_or_crop".split():
+        setattr(rfo, n, None)
+    rf.overloads = rfo
+    sys.modules.update({"rocket_fft": rf, "rocket_fft.overloads": rfo})
+
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
 
@@ -146,3 +157,44 @@ def install(reference_root: str = REFERENCE_ROOT) -> None:
     from alphadia.search.scoring import utils as su
 
     FragmentContainer.slice = su.slice(FragmentContainer, None)
+
+
+def install_selection_glue() -> None:
+    """Bind plain-NumPy stand-ins for the three numba overloads candidate selection calls.
+
+    In the reference these are ``@overload`` implementations compiled by Numba
+    (selection/fft.py:119-212, selection/utils.py:24-46); without Numba the module-level names
+    raise ``NumbaContextOnly``.  The stand-ins do what the overload bodies do with NumPy:
+    ``rfft2`` / ``irfft2`` from ``np.fft`` replace pocketfft (the reference's own test equates the
+    two at 1e-3, tests/unit_tests/search/selection/test_fft.py), results cast to float32.
+    """
+    install()
+    from alphadia.search.selection import fft, selection
+
+    def convolve_fourier(dense, kernel):
+        k0, k1 = kernel.shape
+        delta0, delta1 = -k0 // 2, -k1 // 2
+        out = np.zeros_like(dense)
+        shape = dense.shape[-2:]
+        fourier_filter = np.fft.rfft2(kernel.astype(np.float32), shape).astype(np.complex64)
+        flat_in = dense.reshape((-1,) + shape)
+        flat_out = out.reshape((-1,) + shape)
+        for i in range(flat_in.shape[0]):
+            spec = np.fft.rfft2(flat_in[i]).astype(np.complex64)
+            layer = np.fft.irfft2(spec * fourier_filter, shape).astype(np.float32)
+            o = flat_out[i]
+            o[delta0:, delta1:] = layer[:-delta0, :-delta1]
+            o[:delta0, delta1:] = layer[-delta0:, :-delta1]
+            o[delta0:, :delta1] = layer[:-delta0, -delta1:]
+            o[:delta0, :delta1] = layer[-delta0:, -delta1:]
+        return out
+
+    def assemble_isotope_mz(mono_mz, charge, isotope_intensity):
+        offset = np.arange(len(isotope_intensity)) * 1.0033548350700006 / charge
+        isotope_mz = np.zeros(len(isotope_intensity), dtype=np.float32)
+        isotope_mz[:] = mono_mz
+        isotope_mz += offset
+        return isotope_mz
+
+    fft.convolve_fourier = convolve_fourier
+    selection.assemble_isotope_mz = assemble_isotope_mz
