@@ -489,9 +489,10 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
         int64_t fs = c->frame_start[i], fe = c->frame_stop[i], fc = c->frame_center[i];
         if (fs < zf || fe < fs || fe > n_fr + (im ? 0 : 0) || fc < 0 || fc >= n_fr)
             return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
-        if ((fs - zf) % L != 0 || (fe - zf) % L != 0)
-            return fail(ADH_ERR_INVALID_ARGUMENT,
-                        "frame_start / frame_stop must sit on cycle boundaries");
+        // frame_stop may be clipped to the last frame of the run by the selection step
+        // (selection.py:488-491); the cycle count is a floor division as in get_dense
+        if ((fs - zf) % L != 0)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "frame_start must sit on a cycle boundary");
         int64_t ss = c->scan_start[i], se = c->scan_stop[i], sc = c->scan_center[i];
         if (im) {
             if (ss < 0 || se < ss || se > h->tims.scan_max || sc < 0 || sc >= h->tims.scan_max)
@@ -1110,17 +1111,28 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
     const int L = h->run.cycle_len;
     const int64_t cmax = h->run.n_spectra / L;
     const std::vector<float> &rtv = h->h_rt;
+    std::vector<int32_t> cyc_start((size_t)n), cyc_count((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
             return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
         if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
         caps.n_lib = std::max<int32_t>(caps.n_lib, (int32_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]));
+        // get_frame_indices_tolerance -> get_frame_indices (alpharaw_jit.py:172-203, jitclasses/utils.py:24-88)
         const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
         const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), lo) - rtv.begin();
         const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), hi) - rtv.begin();
-        int64_t len = std::max<int64_t>(f_hi / L - f_lo / L, cfg->kernel_size);
-        len = 16 * ((len + 15) / 16);
-        caps.f = std::max<int32_t>(caps.f, (int32_t)std::min<int64_t>(len, std::max<int64_t>(cmax, 1)));
+        const int64_t c_lo = f_lo / L, c_hi = f_hi / L;
+        int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
+        len = 16 * (int64_t)std::ceil((double)len / 16.0);
+        int64_t cs = c_lo, ce = c_lo + len;
+        if (ce > cmax) {
+            ce = cmax;
+            cs = cmax - len;
+            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+        }
+        cyc_start[(size_t)i] = (int32_t)cs;
+        cyc_count[(size_t)i] = (int32_t)(ce - cs);
+        caps.f = std::max<int32_t>(caps.f, (int32_t)(ce - cs));
     }
     caps.n_lib = std::max(caps.n_lib, 1);
     caps.f = std::max(caps.f, 1);
@@ -1141,6 +1153,8 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
     if (rc == ADH_OK) rc = upload(tmp, pc->rt, n, &dp.rt, h->stream);
     if (rc == ADH_OK) rc = upload(tmp, pc->mz, n, &dp.mz, h->stream);
     if (rc == ADH_OK) rc = upload(tmp, pc->isotope_intensity, n * pc->n_isotope_cols, &dp.iso, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, cyc_start.data(), n, &dp.cycle_start, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, cyc_count.data(), n, &dp.cycle_count, h->stream);
     const float *d_kernel = nullptr;
     if (rc == ADH_OK) rc = upload(tmp, kernel, (int64_t)k_rows * k_cols, &d_kernel, h->stream);
     DevCandTable dt{};

@@ -106,7 +106,8 @@ __host__ __device__ inline size_t lds_bytes(const SelCaps &c) {
     b = (b + 7) / 8 * 8;
     b += (size_t)((c.n_lib + 1) & ~1) * 4;         // raw fragment m/z (even count: keeps 8-byte alignment)
     b += (size_t)WB * c.f * 4;                     // tile of one batch (>= one float64 row)
-    b += (size_t)c.f * 4 * 3;                      // lf, lp, row buffer
+    b += (size_t)c.f * 4 * 2;                      // lf, lp
+    b += (size_t)(c.f + 2 * c.k_cols) * 4;         // row buffer with wrap-around margins
     b += (size_t)c.k_rows * c.k_cols * 4;          // kernel
     return (b + 15) / 16 * 16;
 }
@@ -117,6 +118,7 @@ struct DevPrecursors {
     const uint32_t *precursor_idx, *frag_start, *frag_stop;
     const uint8_t *charge;
     const float *rt, *mz, *iso;
+    const int32_t *cycle_start, *cycle_count;  // first cycle / number of cycles of every tile
     int32_t n_iso_cols;
 };
 
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
     float *lf = tile + (size_t)WB * caps.f;
     float *lp = lf + caps.f;
     float *rowbuf = lp + caps.f;
-    float *kern = rowbuf + caps.f;
+    float *kern = rowbuf + caps.f + 2 * caps.k_cols;
     __shared__ int s_rows[MAX_ROWS];
     __shared__ int s_misc[8];
 
@@ -204,31 +206,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
             win[W0 + k].excl = e;
             e = fmaxf(e, win[W0 + k].hi);
         }
-        // ---- frame limits (get_frame_indices, jitclasses/utils.py:24-88)
-        const float rt_lo = (float)((double)pc.rt[i] - cfg.rt_tolerance);
-        const float rt_hi = (float)((double)pc.rt[i] + cfg.rt_tolerance);
-        int64_t lim[2];
-        for (int q = 0; q < 2; ++q) {
-            const float v = q ? rt_hi : rt_lo;
-            int64_t a = 0, b = run.n_spectra;
-            while (a < b) {
-                int64_t m = (a + b) >> 1;
-                if (run.rt[m] < v) a = m + 1; else b = m;
-            }
-            lim[q] = a;
-        }
-        const int64_t cmax = run.n_spectra / L;
-        const int64_t c_lo = lim[0] / L, c_hi = lim[1] / L;
-        int64_t len = max(c_hi - c_lo, (int64_t)cfg.kernel_size);
-        len = 16 * (int64_t)ceil((double)len / 16.0);
-        int64_t cs = c_lo, ce = c_lo + len;
-        if (ce > cmax) {
-            ce = cmax;
-            cs = cmax - len;
-            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
-        }
-        s_misc[2] = (int)cs;
-        s_misc[3] = (int)(ce - cs);
+        // frame limits (get_frame_indices, jitclasses/utils.py:24-88): searched on the host, which
+        // needs them anyway to size the tiles (adh_select_candidates)
+        s_misc[2] = pc.cycle_start[i];
+        s_misc[3] = pc.cycle_count[i];
     }
     __syncthreads();
     for (int w = lane; w < K + n_iso; w += ADH_WAVE) gather::bins_of(run, win[w < K ? w : W0 + (w - K)]);
@@ -275,17 +256,19 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
             }
             __syncthreads();
             for (int w = 0; w < wb; ++w) {
-                for (int f = lane; f < F; f += ADH_WAVE) rowbuf[f] = tile[w * F + f];
+                // the row with k1 wrap-around cells on either side: rowbuf[k1 + j] = row[j mod F]
+                for (int j = lane; j < F + 2 * k1; j += ADH_WAVE) {
+                    int src = (j - k1) % F;
+                    if (src < 0) src += F;
+                    rowbuf[j] = tile[w * F + src];
+                }
                 __syncthreads();
                 // circular convolution, kernel centred at column k1 / 2 (selection/fft.py:163-212)
                 for (int f = lane; f < F; f += ADH_WAVE) {
                     double acc = 0.0;
+                    const float *rp = rowbuf + k1 + f + k1 / 2;  // rp[-b] = row[(f + k1/2 - b) mod F]
                     for (int a = 0; a < k0; ++a)
-                        for (int b = 0; b < k1; ++b) {
-                            int src = (f + k1 / 2 - b) % F;
-                            if (src < 0) src += F;
-                            acc += (double)kern[a * k1 + b] * (double)rowbuf[src];
-                        }
+                        for (int b = 0; b < k1; ++b) acc += (double)kern[a * k1 + b] * (double)rp[-b];
                     const float sm = (float)acc;
                     const float x1 = sm + 1.0f;  // _build_features (selection.py:206-226)
                     lsum[f] += (float)log((double)x1);

@@ -7,10 +7,11 @@ comment "add implementations for other backends here" at :114).
 ``HipExtractionHandler`` has the interface of ``ClassicExtractionHandler``
 (extraction_handler.py:344-507): the same constructor arguments and the three
 methods ``select_candidates`` / ``score_and_quantify_candidates`` /
-``quantify_candidates``.  Scoring and quantification run on the GPU; candidate
-selection is delegated to a selection handler passed in by the integration
-(the reference's own ``ClassicExtractionHandler``), because selection is
-outside this repository's scope.
+``quantify_candidates``.  Scoring and quantification run on the GPU, and so does
+candidate selection for runs without ion mobility (``HipCandidateSelection``,
+SURVEY.md section 8f-1); for ion-mobility runs selection is delegated to a
+selection handler passed in by the integration (the reference's own
+``ClassicExtractionHandler``).
 
 INTEGRATION.md shows the three-line patch that registers the backend.
 """
@@ -20,10 +21,33 @@ from __future__ import annotations
 import pandas as pd
 
 from alphadia_amd.scoring import CandidateScoringConfig, HipCandidateScoring
+from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelection
 
 
 class HipExtractionHandler:
     """MI355X backend with the ``ClassicExtractionHandler`` method surface."""
+
+    # extraction_handler.py:348-368
+    _base_selection_config = {
+        "peak_len_rt": 10.0,
+        "sigma_scale_rt": 0.5,
+        "peak_len_mobility": 0.01,
+        "sigma_scale_mobility": 1.0,
+        "top_k_precursors": 3,
+        "kernel_size": 30,
+        "f_mobility": 1.0,
+        "f_rt": 0.99,
+        "center_fraction": 0.5,
+        "min_size_mobility": 8,
+        "min_size_rt": 3,
+        "max_size_mobility": 20,
+        "max_size_rt": 15,
+        "group_channels": False,
+        "use_weighted_score": True,
+        "join_close_candidates": False,
+        "join_close_candidates_scan_threshold": 0.6,
+        "join_close_candidates_cycle_threshold": 0.6,
+    }
 
     # extraction_handler.py:370-376
     _base_scoring_config = {
@@ -43,6 +67,16 @@ class HipExtractionHandler:
         self._column_name_handler = column_name_handler
         self._selection_handler = selection_handler
         self._device = device
+        # extraction_handler.py:390-398
+        self._selection_config = CandidateSelectionConfig()
+        self._selection_config.update(
+            {
+                **self._base_selection_config,
+                "top_k_fragments": config["search"]["top_k_fragments_selection"],
+                "exclude_shared_ions": config["search"]["exclude_shared_ions"],
+                "min_size_rt": config["search"]["quant_window"],
+            }
+        )
         # extraction_handler.py:400-409
         self._scoring_config = CandidateScoringConfig()
         self._scoring_config.update(
@@ -55,14 +89,60 @@ class HipExtractionHandler:
             }
         )
 
+    def _select_candidates(self, dia_data, spectral_library) -> pd.DataFrame:
+        """extraction_handler.py:411-446 with ``CandidateSelection`` replaced by the GPU operator."""
+        om = self._optimization_manager
+        self._selection_config.update(
+            {
+                "rt_tolerance": om.rt_error,
+                "mobility_tolerance": om.mobility_error,
+                "candidate_count": om.num_candidates,
+                "precursor_mz_tolerance": om.ms1_error,
+                "fragment_mz_tolerance": om.ms2_error,
+            }
+        )
+        selection = HipCandidateSelection(
+            dia_data,
+            spectral_library.precursor_df,
+            spectral_library.fragment_df,
+            self._selection_config,
+            rt_column=self._column_name_handler.get_rt_column(),
+            mobility_column=self._column_name_handler.get_mobility_column(),
+            precursor_mz_column=self._column_name_handler.get_precursor_mz_column(),
+            fragment_mz_column=self._column_name_handler.get_fragment_mz_column(),
+            fwhm_rt=om.fwhm_rt,
+            fwhm_mobility=om.fwhm_mobility,
+            device=self._device or 0,
+        )
+        return selection(thread_count=self._config["general"]["thread_count"])
+
     def select_candidates(self, dia_data, spectral_library, apply_cutoff: bool = False) -> pd.DataFrame:
-        """Candidate selection (extraction_handler.py:121-154) stays with the reference."""
-        if self._selection_handler is None:
-            raise NotImplementedError(
-                "candidate selection is not part of the hip backend; construct the handler with "
-                "selection_handler=ClassicExtractionHandler(...) (see INTEGRATION.md)"
+        """extraction_handler.py:121-154.  Runs without ion mobility are selected on the GPU; an
+        ion-mobility run goes to the selection handler passed in by the integration."""
+        jit = dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
+        if getattr(jit, "has_mobility", False):
+            if self._selection_handler is None:
+                raise NotImplementedError(
+                    "candidate selection on ion-mobility runs is not part of the hip backend; construct "
+                    "the handler with selection_handler=ClassicExtractionHandler(...) (see INTEGRATION.md)"
+                )
+            return self._selection_handler.select_candidates(dia_data, spectral_library, apply_cutoff)
+        self._reporter.log_string(
+            f"Extracting batch of {len(spectral_library.precursor_df)} precursors", verbosity="progress"
+        )
+        candidates_df = self._select_candidates(dia_data, spectral_library)
+        if apply_cutoff:
+            # extraction_handler.py:177-203 ("filter 1")
+            num_before = len(candidates_df)
+            candidates_df = candidates_df[candidates_df["score"] > self._optimization_manager.score_cutoff]
+            num_after = len(candidates_df)
+            num_removed = num_before - num_after
+            self._reporter.log_string(
+                f"Removed {num_removed} precursors with score below cutoff "
+                f"{self._optimization_manager.score_cutoff}. {num_after} precursors remain.",
+                verbosity="info",
             )
-        return self._selection_handler.select_candidates(dia_data, spectral_library, apply_cutoff)
+        return candidates_df
 
     def score_and_quantify_candidates(self, candidates_df, dia_data, spectral_library,
                                       top_k_fragments: int | None = None):

@@ -217,9 +217,11 @@ def test_operator_and_handler_dataframes(ctx):
     assert np.abs(frdf["mz_observed"].values - g.z["fragments_df_mz_observed"]).max() < 1e-4
 
     config = {"search": {"extraction_backend": "hip", "exclude_shared_ions": True, "quant_window": 3,
-                         "quant_all": True, "experimental_xic": True, "top_k_fragments_scoring": 12},
+                         "quant_all": True, "experimental_xic": True, "top_k_fragments_scoring": 12,
+                         "top_k_fragments_selection": 12},
               "general": {"thread_count": 4}}
-    opt = SimpleNamespace(ms1_error=10, ms2_error=15)
+    opt = SimpleNamespace(ms1_error=10, ms2_error=15, rt_error=30.0, mobility_error=0.1, num_candidates=2,
+                          fwhm_rt=5.0, fwhm_mobility=0.01, score_cutoff=1.0)
     names = SimpleNamespace(get_rt_column=lambda: "rt_library", get_mobility_column=lambda: "mobility_library",
                             get_precursor_mz_column=lambda: "mz_library",
                             get_fragment_mz_column=lambda: "mz_library")
@@ -232,10 +234,34 @@ def test_operator_and_handler_dataframes(ctx):
     assert np.array_equal(pd_equal, fdf[DEFAULT_FEATURE_COLUMNS].to_numpy(), equal_nan=True)
     none, fr3 = handler.quantify_candidates(g.candidates_df, None, g.dia, lib, top_k_fragments=9999)
     assert none is None and len(fr3) >= len(fr2)
-    with pytest.raises(NotImplementedError):
-        handler.select_candidates(g.dia, lib)
+    # selection -> scoring through the handler, all on the GPU (a run without ion mobility)
+    cands = handler.select_candidates(g.dia, lib, apply_cutoff=True)
+    assert {"precursor_idx", "rank", "score", "frame_start", "frame_stop", "elution_group_idx", "decoy"} <= set(cands.columns)
+    assert len(cands) > 200 and (cands["score"] > 1.0).all() and cands["rank"].max() <= 1
+    f4, _ = handler.score_and_quantify_candidates(cands, g.dia, lib)
+    assert len(f4) > 100
     with pytest.raises(ValueError):
         create_handler({"search": {"extraction_backend": "python"}}, opt, None, reporter, names)
+
+
+def test_frame_stop_clipped_to_the_last_frame(ctx, oracle_lib):
+    """The selection step clips frame_stop to frame_max_index (selection.py:488-491): scoring takes
+    the floor of the cycle count like get_dense does."""
+    g = H.load_scoring_golden("handler_default")
+    cand = g.candidates_df.copy()
+    last = g.dia.n_spectra - 1
+    L = g.dia.cycle_len
+    late = np.argsort(cand["frame_stop"].values)[-40:]
+    width = (cand["frame_stop"].values - cand["frame_start"].values)[late]
+    cand.loc[cand.index[late], "frame_stop"] = last
+    cand.loc[cand.index[late], "frame_start"] = ((last + 1) // L) * L - width
+    cand.loc[cand.index[late], "frame_center"] = cand["frame_start"].values[late] + (width // (2 * L)) * L
+    case = type("Case", (), {})()
+    case.dia, case.library, case.candidates_df = g.dia, g.library, cand
+    got, soa = hip_score(ctx, case, g.config)
+    exp, _ = H.oracle_score(oracle_lib, case, g.config, soa=soa, n_threads=4)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert got["valid"].sum() > 100
 
 
 def test_invalid_inputs_fail_loudly(ctx):

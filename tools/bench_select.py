@@ -1,0 +1,67 @@
+"""Throughput of candidate selection on the bench run: 100k-precursor library vs
+the 2 h synthetic run, rt tolerance 60 s, 3 candidates per precursor.
+
+Not the driver's bench (bench.py measures the scoring metric); records how the selection kernel
+performs next to the CPU oracle on the same inputs.  Run on the GPU box from the repo root."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from alphadia_amd import _abi, runtime, synthetic as syn  # noqa: E402
+from alphadia_amd.scoring import fragment_columns  # noqa: E402
+from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel  # noqa: E402
+
+n_prec = int(os.environ.get("N_PREC", 100000))
+cycles = int(os.environ.get("N_CYCLES", 4800))
+case = syn.make_case(n_prec, cycles, config_id=2, per_precursor=1, threads=os.cpu_count() or 8)
+cfg = CandidateSelectionConfig()
+cfg.update(dict(rt_tolerance=float(os.environ.get("RT_TOL", 60.0)), candidate_count=3))
+kern = gaussian_kernel(case.dia, cfg.peak_len_rt, cfg.sigma_scale_rt, cfg.kernel_size)
+pdf = case.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+iso = pdf[[c for c in pdf.columns if c.startswith("i_")]].values
+pm = _abi.pack_precursors(pdf.precursor_idx.values, pdf.flat_frag_start_idx.values, pdf.flat_frag_stop_idx.values,
+                          pdf.charge.values, pdf.rt_library.values, pdf.mobility_library.values,
+                          pdf.mz_library.values, iso)
+ctx = runtime.get_context(0)
+ctx.stage_run(case.dia)
+cols = fragment_columns(case.library.fragment_df, "mz_library")
+ctx.stage_fragments(*cols)
+got = ctx.select_candidates(pm, cfg, kern)
+reps, t0, k_ms = 3, time.perf_counter(), 0.0
+for _ in range(reps):
+    got = ctx.select_candidates(pm, cfg, kern)
+    k_ms += ctx.select_time_ms()
+wall = (time.perf_counter() - t0) / reps
+k_ms /= reps
+res = {
+    "workload": f"{n_prec} precursors (12 fragments, 3 isotopes) vs {cycles} cycles x 61 spectra, rt tolerance "
+                f"{cfg.rt_tolerance} s, {cfg.candidate_count} candidates",
+    "candidates_found": int((got["score"] > 0).sum()),
+    "kernel_ms": k_ms,
+    "precursors_per_s_kernel": n_prec / (k_ms * 1e-3),
+    "host_call_ms": wall * 1e3,
+}
+if not os.environ.get("ADH_BENCH_NO_CPU"):
+    from oracle import oracle
+
+    sample = min(n_prec, 8000)
+    sub = pdf.iloc[:sample]
+    pm_s = _abi.pack_precursors(sub.precursor_idx.values, sub.flat_frag_start_idx.values, sub.flat_frag_stop_idx.values,
+                                sub.charge.values, sub.rt_library.values, sub.mobility_library.values,
+                                sub.mz_library.values, iso[:sample])
+    th = min(64, os.cpu_count() or 1)
+    oracle.select(case.dia, cols, pm_s, cfg, kern, n_threads=th)
+    t0 = time.perf_counter()
+    exp = oracle.select(case.dia, cols, pm_s, cfg, kern, n_threads=th)
+    dt = time.perf_counter() - t0
+    n_rows = sample * cfg.candidate_count
+    same = all(np.array_equal(got[c][:n_rows], exp[c]) for c in got if c != "score")
+    res["cpu_oracle"] = {"precursors_per_s": sample / dt, "threads": th, "sample": sample,
+                         "boxes_identical_to_gpu": bool(same),
+                         "max_rel_score_diff": float(np.max(np.abs(got["score"][:n_rows] - exp["score"]) /
+                                                            np.maximum(np.abs(exp["score"]), 1e-6)))}
+print(json.dumps(res))
