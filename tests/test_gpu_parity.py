@@ -264,6 +264,57 @@ def test_frame_stop_clipped_to_the_last_frame(ctx, oracle_lib):
     assert got["valid"].sum() > 100
 
 
+def test_multiplex_requantification_handler(ctx):
+    """HipMultiplexingRequantificationHandler.requantify: reference-channel PSMs in, the feature
+    table handed to the FDR manager equals what the reference computed for the same candidates
+    (multiplex golden; groups that kept their reference channel)."""
+    from types import SimpleNamespace
+
+    from alphadia_amd.multiplexing import HipMultiplexingRequantificationHandler
+    from alphadia_amd.scoring import DEFAULT_FEATURE_COLUMNS
+
+    g = H.load_scoring_golden("multiplex")
+    pdf = g.library.precursor_df
+    cand = g.candidates_df.merge(pdf[["precursor_idx", "channel", "decoy"]], on="precursor_idx")
+    # one reference-channel PSM per elution group (boxes are shared by the channels of a group)
+    ref = cand.sort_values("channel").groupby("elution_group_idx").first().reset_index()
+    ref["precursor_idx"] = ((ref["precursor_idx"] // 4) * 4).astype(np.uint32)
+    ref["channel"] = np.uint32(0)
+    ref["proba"] = np.linspace(0.0, 0.5, len(ref)).astype(np.float32)
+    seen = {}
+
+    def fit_predict(features, **kw):
+        seen["features"], seen["kw"] = features, kw
+        return features
+
+    cfg = {"multiplexing": {"reference_channel": 0, "target_channels": "4,8,12", "decoy_channel": -1,
+                            "competitive_scoring": True},
+           "search": {"experimental_xic": True}}
+    names = SimpleNamespace(get_rt_column=lambda: "rt_library", get_mobility_column=lambda: "mobility_library",
+                            get_precursor_mz_column=lambda: "mz_library",
+                            get_fragment_mz_column=lambda: "mz_library")
+    lib = SimpleNamespace(precursor_df_unfiltered=pdf, fragment_df=g.library.fragment_df,
+                          _fragment_df=g.library.fragment_df)
+    handler = HipMultiplexingRequantificationHandler(
+        cfg, None, SimpleNamespace(fit_predict=fit_predict), SimpleNamespace(log_string=lambda *a, **k: None),
+        names, lib, device=0)
+    handler._dia = None
+    out = handler.requantify(g.dia, ref)
+    assert out is seen["features"]
+    assert seen["kw"] == dict(decoy_strategy="channel", competitive=True, decoy_channel=-1)
+    feats = seen["features"].set_index("precursor_idx")
+    exp_valid = g.expected["valid"].astype(bool)
+    exp_pidx = g.expected["precursor_idx"][exp_valid]
+    exp_feat = g.expected["features"][exp_valid]
+    assert set(exp_pidx) <= set(feats.index), "a candidate the reference scored is missing"
+    got = feats.loc[exp_pidx, DEFAULT_FEATURE_COLUMNS].to_numpy()
+    keep = [j for j in range(46) if j not in (8, 9, 10, 41, 42, 45)]  # ppm columns: see PPM_ABS_TOL_GOLDEN
+    err = H.rel_err(got[:, keep], exp_feat[:, keep])
+    assert np.quantile(err, 0.999) < 2e-3
+    # groups that lost their reference channel in the golden are scored here (their PSM exists)
+    assert len(feats) > exp_valid.sum()
+
+
 def test_invalid_inputs_fail_loudly(ctx):
     from alphadia_amd.runtime import HipBackendError
 
