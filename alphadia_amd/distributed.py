@@ -124,3 +124,44 @@ def merge_gathered(tables_per_rank: list[dict], rows_per_rank: list[int]) -> dic
             [t[name][:r] for t, r in zip(tables_per_rank, rows_per_rank, strict=True)], axis=0
         )
     return out
+
+
+# ---------------------------------------------------------------------------
+# the two other stages of the path shard without any exchange beyond one gather
+
+
+def precursor_bounds(n_precursors: int, rank: int, world: int) -> tuple[int, int]:
+    """Candidate selection is independent per precursor (selection.py:620-660): contiguous,
+    balanced ranges of the precursor table sorted by precursor_idx."""
+    base, rem = divmod(int(n_precursors), int(world))
+    a = rank * base + min(rank, rem)
+    return a, a + base + (1 if rank < rem else 0)
+
+
+def window_owner(n_windows: int, world: int) -> np.ndarray:
+    """Fragment competition is independent per DIA window (fragcomp.py:204-229,278): windows are
+    dealt round-robin, rank r owns the windows w with ``owner[w] == r``."""
+    return (np.arange(int(n_windows)) % int(world)).astype(np.int32)
+
+
+def all_gather_rows(local_rows: np.ndarray, n_rows_per_rank: list[int], group=None) -> np.ndarray:
+    """Gather variable-length row blocks (any dtype, any trailing shape) from all ranks in rank
+    order with ONE collective: blocks are padded to the longest one."""
+    import torch
+    import torch.distributed as dist
+
+    world = len(n_rows_per_rank)
+    width = int(max(n_rows_per_rank)) if n_rows_per_rank else 0
+    local_rows = np.ascontiguousarray(local_rows)
+    trailing = local_rows.shape[1:]
+    row_bytes = int(np.prod(trailing, dtype=np.int64)) * local_rows.dtype.itemsize
+    buf = np.zeros(width * row_bytes, dtype=np.uint8)
+    raw = local_rows.view(np.uint8).reshape(-1)
+    buf[: raw.shape[0]] = raw
+    t = torch.from_numpy(buf)
+    gathered = all_gather_tables(t, world, group=group).numpy()
+    parts = [
+        gathered[r, : n_rows_per_rank[r] * row_bytes].view(local_rows.dtype).reshape((n_rows_per_rank[r],) + trailing)
+        for r in range(world)
+    ]
+    return np.concatenate(parts, axis=0)

@@ -15,11 +15,14 @@ import torch.multiprocessing as mp
 import helpers as H
 from alphadia_amd.distributed import (
     DeviceTables,
+    all_gather_rows,
     all_gather_tables,
     merge_gathered,
     packed_layout,
+    precursor_bounds,
     shard_bounds,
     slice_soa,
+    window_owner,
 )
 
 
@@ -75,3 +78,54 @@ def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib):
         z = np.load(tmp_path / f"rank{r}.npz")
         for k, v in full.items():
             assert np.array_equal(z[k], v, equal_nan=True), (r, k)
+
+
+def test_precursor_and_window_partitions_cover_everything():
+    for n, world in ((0, 2), (1, 2), (7, 3), (100, 8), (100001, 8)):
+        cuts = [precursor_bounds(n, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(b0 == a1 for (_, b0), (a1, _) in zip(cuts[:-1], cuts[1:]))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    own = window_owner(61, 8)
+    assert own.shape == (61,) and set(own) == set(range(8)) and np.bincount(own).max() - np.bincount(own).min() <= 1
+
+
+def _select_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_selection as TS
+    from alphadia_amd.scoring import fragment_columns
+    from oracle import oracle
+
+    z, dia, fdf, pdf = TS._load()
+    pdf = pdf.sort_values("precursor_idx").reset_index(drop=True)
+    cfg = TS._cfg(z, "default")
+    a, b = precursor_bounds(len(pdf), rank, world)
+    local = oracle.select(dia, fragment_columns(fdf, "mz_library"), TS._pack(pdf.iloc[a:b]), cfg,
+                          z["default_kernel"], n_threads=2)
+    cc = int(cfg.candidate_count)
+    rows = [(precursor_bounds(len(pdf), r, world)[1] - precursor_bounds(len(pdf), r, world)[0]) * cc
+            for r in range(world)]
+    merged = {k: all_gather_rows(v, rows) for k, v in local.items()}
+    np.savez(os.path.join(tmpdir, f"sel{rank}.npz"), **merged)
+    dist.destroy_process_group()
+
+
+def test_two_rank_selection_sharding(tmp_path, oracle_lib):
+    """Candidate selection sharded by precursor + one gather per column == the unsharded table."""
+    import test_selection as TS
+    from alphadia_amd.scoring import fragment_columns
+
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_select_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z, dia, fdf, pdf = TS._load()
+    full = oracle_lib.select(dia, fragment_columns(fdf, "mz_library"), TS._pack(pdf), TS._cfg(z, "default"),
+                             z["default_kernel"], n_threads=2)
+    for r in range(world):
+        got = np.load(tmp_path / f"sel{r}.npz")
+        for k, v in full.items():
+            assert np.array_equal(got[k], v), (r, k)
