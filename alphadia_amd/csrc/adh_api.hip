@@ -22,6 +22,7 @@
 #include "adh_features_im.hip"
 #include "adh_fragcomp.hip"
 #include "adh_select.hip"
+#include "adh_transpose.hip"
 
 namespace {
 
@@ -1195,6 +1196,80 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
     for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
         hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    tmp.release();
+    return rc;
+}
+
+int adh_transpose_timstof(adh_handle_t *h, const uint32_t *tof_indices, const int64_t *push_indptr,
+                          int64_t n_push, int64_t n_tof, const uint16_t *values, int64_t n,
+                          uint32_t *push_out, int64_t *tof_indptr_out, uint16_t *values_out) {
+    if (!h || !push_indptr || !tof_indptr_out || (n > 0 && (!tof_indices || !values || !push_out || !values_out)))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_push < 0 || n_tof < 0 || n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative size");
+    if (n >= (int64_t)0x7FFFFFFFll || n_push >= (int64_t)0xFFFFFFFFll || n_tof >= (int64_t)0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 - 1 detector events per call are not supported");
+    if (push_indptr[0] != 0 || push_indptr[n_push] != n)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "push_indptr does not span the event arrays");
+    for (int64_t p = 0; p < n_push; ++p)
+        if (push_indptr[p + 1] < push_indptr[p]) return fail(ADH_ERR_INVALID_ARGUMENT, "push_indptr is not monotone");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n == 0) {
+        for (int64_t t = 0; t <= n_tof; ++t) tof_indptr_out[t] = 0;
+        return ADH_OK;
+    }
+    hipStream_t st = h->stream;
+    DeviceBuffers tmp;
+    const uint32_t *d_tof = nullptr;
+    const int64_t *d_ptr = nullptr;
+    const uint16_t *d_val = nullptr;
+    int rc = upload(tmp, tof_indices, n, &d_tof, st);
+    if (rc == ADH_OK) rc = upload(tmp, push_indptr, n_push + 1, &d_ptr, st);
+    if (rc == ADH_OK) rc = upload(tmp, values, n, &d_val, st);
+    uint32_t *d_push_of = nullptr, *d_ev_in = nullptr, *d_ev_out = nullptr, *d_tof_out = nullptr, *d_push_out = nullptr;
+    uint16_t *d_val_out = nullptr;
+    int64_t *d_indptr = nullptr;
+    int *d_bad = nullptr;
+    void *sort_tmp = nullptr;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        tmp.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_of, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_in, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_tof_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_val_out, (size_t)n * 2);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_indptr, (size_t)(n_tof + 1) * 8);
+    (void)d_bad;
+    hipError_t e = hipSuccess;
+    if (rc == ADH_OK) {
+        hipLaunchKernelGGL(adh_expand_push_kernel, dim3(4096), dim3(256), 0, st, d_ptr, n_push, d_push_of);
+        hipLaunchKernelGGL(adh_iota_kernel, dim3(4096), dim3(256), 0, st, d_ev_in, n);
+        int end_bit = 1;
+        while (end_bit < 32 && ((int64_t)1 << end_bit) < std::max<int64_t>(n_tof, 2)) ++end_bit;
+        size_t sort_bytes = 0;
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)n, 0,
+                                               end_bit, st);
+        if (e == hipSuccess) rc = dev_alloc(&sort_tmp, sort_bytes);
+        if (e == hipSuccess && rc == ADH_OK)
+            e = hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)n, 0,
+                                                   end_bit, st);
+        if (e == hipSuccess && rc == ADH_OK) {
+            hipLaunchKernelGGL(adh_transpose_gather_kernel, dim3(8192), dim3(256), 0, st, d_ev_out, d_push_of, d_val, n,
+                               d_push_out, d_val_out);
+            hipLaunchKernelGGL(adh_tof_indptr_kernel, dim3(1024), dim3(256), 0, st, d_tof_out, n, n_tof, d_indptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(push_out, d_push_out, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(values_out, d_val_out, (size_t)n * 2, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK)
+            e = hipMemcpyAsync(tof_indptr_out, d_indptr, (size_t)(n_tof + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK) e = hipStreamSynchronize(st);
+        if (e != hipSuccess && rc == ADH_OK) rc = fail(ADH_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e));
     }
     tmp.release();
     return rc;

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "adh_fragcomp",
     "adh_select_candidates",
     "adh_select_time_ms",
+    "adh_transpose_timstof",
 ]
 
 
@@ -197,6 +198,29 @@ class Context:
         ms = C.c_double(0.0)
         _check(lib.adh_select_time_ms(self._h, C.byref(ms)), "adh_select_time_ms")
         return float(ms.value)
+
+    def transpose_timstof(self, tof_indices, push_indptr, n_tof_indices: int, values):
+        """Drop-in for ``_transpose`` (alphadia/raw_data/bruker.py:201-280): returns
+        ``(push_indices, tof_indptr, new_values)`` in the TOF-major layout."""
+        tof = _abi.as_c(tof_indices, np.uint32)
+        ptr = _abi.as_c(push_indptr, np.int64)
+        val = np.ascontiguousarray(values, dtype=np.uint16)
+        n = tof.shape[0]
+        if val.shape[0] != n or ptr.shape[0] < 1:
+            raise ValueError("tof_indices / values / push_indptr have inconsistent lengths")
+        push_out = np.zeros(n, dtype=np.uint32)
+        val_out = np.zeros(n, dtype=np.uint16)
+        indptr_out = np.zeros(int(n_tof_indices) + 1, dtype=np.int64)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        _check(
+            lib.adh_transpose_timstof(
+                self._h, p(tof, C.c_uint32), p(ptr, C.c_int64), C.c_int64(ptr.shape[0] - 1),
+                C.c_int64(int(n_tof_indices)), p(val, C.c_uint16), C.c_int64(n),
+                p(push_out, C.c_uint32), p(indptr_out, C.c_int64), p(val_out, C.c_uint16),
+            ),
+            "adh_transpose_timstof",
+        )
+        return push_out, indptr_out, val_out
 
     def fragcomp(self, window_start, window_stop, rt, frag_start, frag_stop, fragment_mz,
                  rt_tol_seconds: float, mass_tol_ppm: float) -> np.ndarray:

@@ -320,6 +320,17 @@ int adh_select_candidates(adh_handle_t *handle, const adh_precursors_t *precurso
                           const adh_selection_config_t *config, const float *kernel,
                           int32_t kernel_rows, int32_t kernel_cols, adh_candidate_table_t *out);
 
+/*
+ * Transpose timsTOF detector events from the frame-major alphatims layout (rows = pushes:
+ * push_indptr[n_push + 1], tof_indices[n], values[n]) into the TOF-major layout the scoring and
+ * selection operators read (tof_indptr[n_tof + 1], push_indices[n], values[n]; pushes ascending
+ * inside a TOF bin).  Drop-in for `_transpose` (alphadia/raw_data/bruker.py:201-280), which does
+ * this on 20 CPU threads when a run is loaded.  Host buffers in and out; n < 2^31.
+ */
+int adh_transpose_timstof(adh_handle_t *handle, const uint32_t *tof_indices, const int64_t *push_indptr,
+                          int64_t n_push, int64_t n_tof, const uint16_t *values, int64_t n_events,
+                          uint32_t *push_indices_out, int64_t *tof_indptr_out, uint16_t *values_out);
+
 /* Duration (ms, HIP events) of the selection kernel of the last adh_select_candidates call. */
 int adh_select_time_ms(adh_handle_t *handle, double *kernel_ms);
 

@@ -501,6 +501,27 @@ def golden_selection():
     print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
 
 
+def golden_transpose():
+    """Staging-format golden: the reference's `_transpose`
+    (alphadia/raw_data/bruker.py:201-280) on a small frame-major event list."""
+    from alphadia.raw_data.bruker import _transpose
+
+    rng = np.random.default_rng(17)
+    n_push, n_tof = 3000, 700
+    counts = rng.poisson(12, n_push)
+    counts[rng.random(n_push) < 0.1] = 0  # empty pushes
+    push_indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(push_indptr[-1])
+    # inside a push the tof indices are ascending and may repeat across pushes
+    tof = np.concatenate([np.sort(rng.integers(0, n_tof, c)) for c in counts]).astype(np.uint32)
+    values = rng.integers(1, 4000, n).astype(np.uint16)
+    push_indices, tof_indptr, new_values = _transpose(tof, push_indptr, n_tof, values)
+    path = os.path.join(HERE, "transpose.npz")
+    np.savez_compressed(path, tof_indices=tof, push_indptr=push_indptr, n_tof=np.asarray(n_tof), values=values,
+                        out_push_indices=push_indices, out_tof_indptr=tof_indptr, out_values=new_values)
+    print(path, n, "events", f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
 def golden_get_dense():
     """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
     case = small_case(102, n_precursors=40)
@@ -739,6 +760,9 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--transpose-only" in sys.argv:
+        golden_transpose()
+        sys.exit(0)
     if "--selection-only" in sys.argv:
         golden_selection()
         sys.exit(0)
@@ -759,4 +783,5 @@ if __name__ == "__main__":
     golden_multiplex()
     golden_edges()
     golden_selection()
+    golden_transpose()
     golden_timstof()
