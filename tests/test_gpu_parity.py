@@ -1,6 +1,8 @@
 """GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and vs the
 golden vectors captured from the reference.  Run with ``-m gpu`` on an MI355X."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -315,6 +317,40 @@ def test_multiplex_requantification_handler(ctx):
     assert len(feats) > exp_valid.sum()
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS", "10")))))
+def test_randomized_shapes_and_settings(ctx, oracle_lib, seed):
+    """Differential test: random run geometry, library shape and scoring settings, HIP vs oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_ms2 = int(rng.integers(3, 14))
+    mz_lo = 400.0
+    mz_hi = mz_lo + 10.0 * n_ms2
+    case = syn.make_case(
+        int(rng.integers(80, 260)), int(rng.integers(40, 110)), config_id=300 + seed,
+        per_precursor=int(rng.integers(1, 4)), n_ms2=n_ms2, ms1_peaks=int(rng.integers(100, 900)),
+        ms2_peaks=int(rng.integers(40, 400)), mz_lo=mz_lo, mz_hi=mz_hi, frag_mz_lo=200,
+        frag_mz_hi=float(rng.choice([320.0, 500.0])), ms1_mz_range=(395, mz_hi + 25),
+        ms2_mz_range=(195, 520), few_fragment_fraction=float(rng.choice([0.0, 0.15])),
+        even_fraction=float(rng.choice([0.0, 0.5])), planted_fraction=float(rng.uniform(0.2, 0.9)), threads=1,
+    )
+    if rng.random() < 0.5:  # shared fragments
+        card = case.library.fragment_df["cardinality"].values.copy()
+        card[rng.random(card.size) < 0.2] = 2
+        case.library.fragment_df["cardinality"] = card
+    upd = dict(
+        top_k_fragments=int(rng.choice([4, 6, 12, 16, 20])), top_k_isotopes=int(rng.integers(1, 5)),
+        precursor_mz_tolerance=float(rng.choice([5, 10, 40, 150])),
+        fragment_mz_tolerance=float(rng.choice([7, 15, 60, 200])),
+        exclude_shared_ions=bool(rng.integers(0, 2)), quant_window=int(rng.integers(1, 6)),
+        quant_all=bool(rng.integers(0, 2)), experimental_xic=bool(rng.integers(0, 2)),
+    )
+    cfg = CandidateScoringConfig()
+    cfg.update(upd)
+    got, soa = hip_score(ctx, case, cfg, with_stats=True)
+    exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=soa, n_threads=4, with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"]), upd
+
+
 def test_invalid_inputs_fail_loudly(ctx):
     from alphadia_amd.runtime import HipBackendError
 
@@ -423,6 +459,34 @@ def test_timstof_larger_case_all_configs(ctx, oracle_lib):
                                        pack_assembled(soa), cfg.to_jitclass(), n_threads=8)
         compare(got, exp, PPM_ABS_TOL_ORACLE)
         assert got["valid"].sum() > 100
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_IM", "6")))))
+def test_timstof_randomized(ctx, oracle_lib, seed):
+    """Differential test on the ion-mobility layout: random geometry and settings, HIP vs oracle."""
+    from alphadia_amd.scoring import assemble_candidates
+
+    rng = np.random.default_rng(2000 + seed)
+    case = syn.make_timstof_case(
+        n_precursors=int(rng.integers(60, 200)), n_cycles=int(rng.integers(25, 60)), config_id=500 + seed,
+        per_precursor=int(rng.integers(1, 4)), n_ms2_frames=int(rng.integers(2, 7)),
+        windows_per_frame=int(rng.integers(1, 4)), scan_max_index=int(rng.choice([48, 64, 96])),
+        events_per_push=float(rng.choice([15.0, 40.0, 80.0])), planted_fraction=float(rng.uniform(0.2, 0.8)),
+    )
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    upd = dict(
+        top_k_fragments=int(rng.choice([5, 12, 16])), top_k_isotopes=int(rng.integers(1, 5)),
+        precursor_mz_tolerance=float(rng.choice([10, 40])), fragment_mz_tolerance=float(rng.choice([15, 60])),
+        quant_window=int(rng.integers(1, 5)), quant_all=bool(rng.integers(0, 2)),
+        experimental_xic=bool(rng.integers(0, 2)),
+    )
+    cfg = CandidateScoringConfig()
+    cfg.update(upd)
+    got = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
+    exp = oracle_lib.score_timstof(case.dia, fragment_columns(case.library.fragment_df, "mz_library"),
+                                   pack_assembled(soa), cfg.to_jitclass(), n_threads=8, with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"]), upd
 
 
 def test_switching_run_layouts_on_one_handle(ctx, oracle_lib):

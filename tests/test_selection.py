@@ -165,3 +165,46 @@ def test_hip_selection_at_bench_density(ctx, oracle_lib):
         else:
             assert np.array_equal(got[c], exp[c]), c
     assert (got["score"] > 0).sum() > 3000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_hip_selection_randomized(ctx, oracle_lib, seed):
+    """Differential test: random run geometry and selection settings, HIP == oracle."""
+    from alphadia_amd import synthetic as syn
+
+    rng = np.random.default_rng(3000 + seed)
+    n_ms2 = int(rng.integers(3, 12))
+    case = syn.make_case(
+        int(rng.integers(100, 400)), int(rng.integers(50, 200)), config_id=700 + seed, per_precursor=1,
+        n_ms2=n_ms2, ms1_peaks=int(rng.integers(100, 900)), ms2_peaks=int(rng.integers(40, 400)),
+        mz_lo=400.0, mz_hi=400.0 + 10.0 * n_ms2, frag_mz_lo=200, frag_mz_hi=450,
+        ms1_mz_range=(395, 430 + 10.0 * n_ms2), ms2_mz_range=(195, 470),
+        few_fragment_fraction=float(rng.choice([0.0, 0.2])), planted_fraction=float(rng.uniform(0.2, 0.9)), threads=1,
+    )
+    if rng.random() < 0.5:
+        card = case.library.fragment_df["cardinality"].values.copy()
+        card[rng.random(card.size) < 0.2] = 2
+        case.library.fragment_df["cardinality"] = card
+    cfg = CandidateSelectionConfig()
+    cfg.update(dict(
+        rt_tolerance=float(rng.choice([5.0, 20.0, 45.0, 400.0])), candidate_count=int(rng.integers(1, 8)),
+        top_k_precursors=int(rng.integers(1, 5)), exclude_shared_ions=bool(rng.integers(0, 2)),
+        precursor_mz_tolerance=float(rng.choice([5, 15, 60])), fragment_mz_tolerance=float(rng.choice([7, 15, 80])),
+        min_size_rt=int(rng.integers(1, 5)), max_size_rt=int(rng.integers(6, 20)),
+        f_rt=float(rng.choice([0.9, 0.99])), center_fraction=float(rng.choice([0.2, 0.5])),
+        join_close_candidates=bool(rng.integers(0, 2)), use_weighted_score=bool(rng.integers(0, 2)),
+        sigma_scale_rt=float(rng.choice([0.1, 0.5])),
+    ))
+    cols = fragment_columns(case.library.fragment_df, "mz_library")
+    ctx.stage_run(case.dia, force=True)
+    ctx.stage_fragments(*cols, force=True)
+    kern = gaussian_kernel(case.dia, cfg.peak_len_rt, cfg.sigma_scale_rt, cfg.kernel_size)
+    pm = _pack(case.library.precursor_df)
+    got = ctx.select_candidates(pm, cfg, kern)
+    exp = oracle_lib.select(case.dia, cols, pm, cfg, kern, n_threads=4)
+    for c in CANDIDATE_COLUMNS:
+        if c == "score":
+            assert np.allclose(got[c], exp[c], rtol=1e-6, atol=0), c
+        else:
+            assert np.array_equal(got[c], exp[c]), c
