@@ -64,6 +64,28 @@ __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window 
     }
 }
 
+// one output of the smoothing: sum over kernel rows a (outer) and columns b (inner) of
+// kernel[a][b] * row[(f + k1/2 - b) mod F], float64, in this order (the oracle's order)
+template <int K1>
+__device__ __forceinline__ double conv_fixed(const float *rp, const double *kd, int k0) {
+    double win[K1];  // the K1 row values this output touches, converted once
+#pragma unroll
+    for (int b = 0; b < K1; ++b) win[b] = (double)rp[-b];
+    double acc = 0.0;
+    for (int a = 0; a < k0; ++a) {
+#pragma unroll
+        for (int b = 0; b < K1; ++b) acc += kd[a * K1 + b] * win[b];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ double conv_any(const float *rp, const double *kd, int k0, int k1) {
+    double acc = 0.0;
+    for (int a = 0; a < k0; ++a)
+        for (int b = 0; b < k1; ++b) acc += kd[a * k1 + b] * (double)rp[-b];
+    return acc;
+}
+
 // selection/utils.py:218-280
 __device__ inline void symetric_limits_1d(const double *a, int n, int center, double f, double center_fraction,
                                           int64_t min_size, int64_t max_size, int out[2]) {
@@ -107,8 +129,9 @@ __host__ __device__ inline size_t lds_bytes(const SelCaps &c) {
     b += (size_t)((c.n_lib + 1) & ~1) * 4;         // raw fragment m/z (even count: keeps 8-byte alignment)
     b += (size_t)WB * c.f * 4;                     // tile of one batch (>= one float64 row)
     b += (size_t)c.f * 4 * 2;                      // lf, lp
-    b += (size_t)(c.f + 2 * c.k_cols) * 4;         // row buffer with wrap-around margins
-    b += (size_t)c.k_rows * c.k_cols * 4;          // kernel
+    b += (size_t)WB * (c.f + 2 * c.k_cols) * 4;    // rows of one batch with wrap-around margins
+    b = (b + 7) / 8 * 8;
+    b += (size_t)c.k_rows * c.k_cols * 8;          // kernel (float64)
     return (b + 15) / 16 * 16;
 }
 
@@ -144,7 +167,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
     float *lf = tile + (size_t)WB * caps.f;
     float *lp = lf + caps.f;
     float *rowbuf = lp + caps.f;
-    float *kern = rowbuf + caps.f + 2 * caps.k_cols;
+    const int row_stride = caps.f + 2 * caps.k_cols;
+    double *kern = reinterpret_cast<double *>(
+        smem + ((size_t)(reinterpret_cast<unsigned char *>(rowbuf + (size_t)WB * row_stride) - smem) + 7) / 8 * 8);
     __shared__ int s_rows[MAX_ROWS];
     __shared__ int s_misc[8];
 
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
     if (i >= n_prec) return;
     const int L = run.cycle_len;
     const int k0 = caps.k_rows, k1 = caps.k_cols;
-    for (int c = lane; c < k0 * k1; c += ADH_WAVE) kern[c] = kernel_g[c];
+    for (int c = lane; c < k0 * k1; c += ADH_WAVE) kern[c] = (double)kernel_g[c];
 
     // ---- isotopes (assemble_isotope_mz, selection/utils.py:24-46): float32 array += float64 offsets
     const int n_iso = caps.n_iso;
@@ -255,26 +280,31 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
                     gather_sum_task(run, ww, s_rows[r], blk0 + bi, cs, F, tile + w * F);
             }
             __syncthreads();
-            for (int w = 0; w < wb; ++w) {
-                // the row with k1 wrap-around cells on either side: rowbuf[k1 + j] = row[j mod F]
-                for (int j = lane; j < F + 2 * k1; j += ADH_WAVE) {
-                    int src = (j - k1) % F;
-                    if (src < 0) src += F;
-                    rowbuf[j] = tile[w * F + src];
-                }
-                __syncthreads();
-                // circular convolution, kernel centred at column k1 / 2 (selection/fft.py:163-212)
-                for (int f = lane; f < F; f += ADH_WAVE) {
-                    double acc = 0.0;
-                    const float *rp = rowbuf + k1 + f + k1 / 2;  // rp[-b] = row[(f + k1/2 - b) mod F]
-                    for (int a = 0; a < k0; ++a)
-                        for (int b = 0; b < k1; ++b) acc += (double)kern[a * k1 + b] * (double)rp[-b];
-                    const float sm = (float)acc;
-                    const float x1 = sm + 1.0f;  // _build_features (selection.py:206-226)
-                    lsum[f] += (float)log((double)x1);
-                }
-                __syncthreads();
+            // the rows with k1 wrap-around cells on either side: rowbuf[w][k1 + j] = row_w[j mod F]
+            for (int c = lane; c < wb * (F + 2 * k1); c += ADH_WAVE) {
+                const int w = c / (F + 2 * k1), j = c - w * (F + 2 * k1);
+                int src = (j - k1) % F;
+                if (src < 0) src += F;
+                rowbuf[w * row_stride + j] = tile[w * F + src];
             }
+            __syncthreads();
+            // circular convolution, kernel centred at column k1 / 2 (selection/fft.py:163-212), for
+            // all (window, cycle) outputs of the batch; log(smooth + 1) replaces the tile value
+            for (int o = lane; o < wb * F; o += ADH_WAVE) {
+                const int w = o / F, f = o - w * F;
+                const float *rp = rowbuf + w * row_stride + k1 + f + k1 / 2;  // rp[-b] = row[(f + k1/2 - b) mod F]
+                const double acc = (k1 == 30) ? conv_fixed<30>(rp, kern, k0) : conv_any(rp, kern, k0, k1);
+                const float sm = (float)acc;
+                const float x1 = sm + 1.0f;  // _build_features (selection.py:206-226)
+                tile[o] = (float)log((double)x1);
+            }
+            __syncthreads();
+            for (int f = lane; f < F; f += ADH_WAVE) {
+                float a = lsum[f];
+                for (int w = 0; w < wb; ++w) a += tile[w * F + f];  // np.sum over the windows, in order
+                lsum[f] = a;
+            }
+            __syncthreads();
         }
     }
     __syncthreads();
