@@ -27,36 +27,17 @@ from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelecti
 class HipExtractionHandler:
     """MI355X backend with the ``ClassicExtractionHandler`` method surface."""
 
-    # extraction_handler.py:348-368
-    _base_selection_config = {
-        "peak_len_rt": 10.0,
-        "sigma_scale_rt": 0.5,
-        "peak_len_mobility": 0.01,
-        "sigma_scale_mobility": 1.0,
-        "top_k_precursors": 3,
-        "kernel_size": 30,
-        "f_mobility": 1.0,
-        "f_rt": 0.99,
-        "center_fraction": 0.5,
-        "min_size_mobility": 8,
-        "min_size_rt": 3,
-        "max_size_mobility": 20,
-        "max_size_rt": 15,
-        "group_channels": False,
-        "use_weighted_score": True,
-        "join_close_candidates": False,
-        "join_close_candidates_scan_threshold": 0.6,
-        "join_close_candidates_cycle_threshold": 0.6,
-    }
-
-    # extraction_handler.py:370-376
-    _base_scoring_config = {
-        "score_grouped": False,
-        "top_k_isotopes": 3,
-        "reference_channel": -1,
-        "precursor_mz_tolerance": 10,
-        "fragment_mz_tolerance": 15,
-    }
+    # the values ClassicExtractionHandler passes to the two config classes
+    # (extraction_handler.py:348-376)
+    _base_selection_config = dict(
+        peak_len_rt=10.0, sigma_scale_rt=0.5, peak_len_mobility=0.01, sigma_scale_mobility=1.0,
+        top_k_precursors=3, kernel_size=30, f_mobility=1.0, f_rt=0.99, center_fraction=0.5,
+        min_size_mobility=8, min_size_rt=3, max_size_mobility=20, max_size_rt=15, group_channels=False,
+        use_weighted_score=True, join_close_candidates=False, join_close_candidates_scan_threshold=0.6,
+        join_close_candidates_cycle_threshold=0.6,
+    )
+    _base_scoring_config = dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1,
+                                precursor_mz_tolerance=10, fragment_mz_tolerance=15)
 
     def __init__(self, config, optimization_manager, fdr_manager, reporter, column_name_handler,
                  selection_handler=None, device: int | None = None):
@@ -69,38 +50,23 @@ class HipExtractionHandler:
         self._device = device
         # extraction_handler.py:390-398
         self._selection_config = CandidateSelectionConfig()
-        self._selection_config.update(
-            {
-                **self._base_selection_config,
-                "top_k_fragments": config["search"]["top_k_fragments_selection"],
-                "exclude_shared_ions": config["search"]["exclude_shared_ions"],
-                "min_size_rt": config["search"]["quant_window"],
-            }
-        )
+        search = config["search"]
+        self._selection_config.update(dict(
+            self._base_selection_config, top_k_fragments=search["top_k_fragments_selection"],
+            exclude_shared_ions=search["exclude_shared_ions"], min_size_rt=search["quant_window"]))
         # extraction_handler.py:400-409
         self._scoring_config = CandidateScoringConfig()
-        self._scoring_config.update(
-            {
-                **self._base_scoring_config,
-                "exclude_shared_ions": config["search"]["exclude_shared_ions"],
-                "quant_window": config["search"]["quant_window"],
-                "quant_all": config["search"]["quant_all"],
-                "experimental_xic": config["search"]["experimental_xic"],
-            }
-        )
+        self._scoring_config.update(dict(
+            self._base_scoring_config, exclude_shared_ions=search["exclude_shared_ions"],
+            quant_window=search["quant_window"], quant_all=search["quant_all"],
+            experimental_xic=search["experimental_xic"]))
 
     def _select_candidates(self, dia_data, spectral_library) -> pd.DataFrame:
         """extraction_handler.py:411-446 with ``CandidateSelection`` replaced by the GPU operator."""
         om = self._optimization_manager
-        self._selection_config.update(
-            {
-                "rt_tolerance": om.rt_error,
-                "mobility_tolerance": om.mobility_error,
-                "candidate_count": om.num_candidates,
-                "precursor_mz_tolerance": om.ms1_error,
-                "fragment_mz_tolerance": om.ms2_error,
-            }
-        )
+        self._selection_config.update(dict(
+            rt_tolerance=om.rt_error, mobility_tolerance=om.mobility_error, candidate_count=om.num_candidates,
+            precursor_mz_tolerance=om.ms1_error, fragment_mz_tolerance=om.ms2_error))
         selection = HipCandidateSelection(
             dia_data,
             spectral_library.precursor_df,
@@ -147,15 +113,10 @@ class HipExtractionHandler:
     def score_and_quantify_candidates(self, candidates_df, dia_data, spectral_library,
                                       top_k_fragments: int | None = None):
         """extraction_handler.py:449-486 with ``CandidateScoring`` replaced by the GPU operator."""
-        self._scoring_config.update(
-            {
-                "precursor_mz_tolerance": self._optimization_manager.ms1_error,
-                "fragment_mz_tolerance": self._optimization_manager.ms2_error,
-                "top_k_fragments": top_k_fragments
-                if top_k_fragments is not None
-                else self._config["search"]["top_k_fragments_scoring"],
-            }
-        )
+        om = self._optimization_manager
+        k = top_k_fragments if top_k_fragments is not None else self._config["search"]["top_k_fragments_scoring"]
+        self._scoring_config.update(dict(precursor_mz_tolerance=om.ms1_error, fragment_mz_tolerance=om.ms2_error,
+                                         top_k_fragments=k))
         candidate_scoring = HipCandidateScoring(
             dia_data=dia_data,
             precursors_flat=spectral_library.precursor_df,
