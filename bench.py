@@ -278,6 +278,29 @@ def main():
         except Exception as exc:  # the metric does not depend on this leg
             log(f"[bench] host-buffer leg skipped: {exc}")
 
+    # ---------------- the step before scoring (candidate selection), reported next to the metric ----
+    if rank == 0 and world == 1:
+        try:
+            from alphadia_amd import _abi
+            from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel
+
+            scfg = CandidateSelectionConfig()
+            scfg.update(dict(rt_tolerance=60.0, candidate_count=3))
+            kern = gaussian_kernel(case.dia, scfg.peak_len_rt, scfg.sigma_scale_rt, scfg.kernel_size)
+            pdf = case.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+            iso_cols = [c for c in pdf.columns if c.startswith("i_")]
+            pm = _abi.pack_precursors(pdf.precursor_idx.values, pdf.flat_frag_start_idx.values,
+                                      pdf.flat_frag_stop_idx.values, pdf.charge.values, pdf.rt_library.values,
+                                      pdf.mobility_library.values, pdf.mz_library.values, pdf[iso_cols].values)
+            ctx.select_candidates(pm, scfg, kern)
+            sel = ctx.select_candidates(pm, scfg, kern)
+            sel_ms = ctx.select_time_ms()
+            result["config"]["selection_kernel_ms"] = sel_ms
+            result["config"]["selection_precursors_per_s"] = len(pdf) / (sel_ms * 1e-3)
+            result["config"]["selection_candidates_found"] = int((sel["score"] > 0).sum())
+        except Exception as exc:  # the metric does not depend on this leg
+            log(f"[bench] selection leg skipped: {exc}")
+
     # ---------------- CPU baseline: the oracle on this host's cores ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
