@@ -116,6 +116,63 @@ def all_gather_tables(local, world: int, group=None):
     return gathered
 
 
+class PipelinedGather:
+    """Double-buffered all-gather of the packed tables: the collective of batch i runs while the
+    kernels of batch i+1 fill the other buffer (RCCL works on its own stream; the score kernels
+    are bound by VALU / HBM latency, the gather by xGMI links, so the two overlap well).
+
+        pg = PipelinedGather(n_rows, top_k, device, world)
+        for batch in batches:
+            tables = pg.begin()            # waits until the gather that last read this slot is done
+            ... enqueue zero_() + scoring into `tables` on the current stream ...
+            pg.end()                       # starts the gather of this slot, returns immediately
+        gathered = pg.finish()             # [world, nbytes] of the last batch, all work complete
+    """
+
+    def __init__(self, n_rows: int, top_k: int, device, world: int, with_stats: bool = True, group=None):
+        import torch
+
+        self.world = int(world)
+        self.group = group
+        self.tables = [DeviceTables(n_rows, top_k, device, with_stats) for _ in range(2)]
+        self.gathered = [
+            torch.empty((self.world, self.tables[0].buffer.shape[0]), dtype=torch.uint8, device=device)
+            for _ in range(2)
+        ]
+        self.pending = [None, None]
+        self.slot = 1
+        self.overlap = True
+
+    def begin(self) -> DeviceTables:
+        self.slot ^= 1
+        w = self.pending[self.slot]
+        if w is not None:
+            w.wait()  # orders the current stream after that collective
+            self.pending[self.slot] = None
+        return self.tables[self.slot]
+
+    def end(self):
+        import torch.distributed as dist
+
+        if self.world <= 1:
+            return
+        local, out = self.tables[self.slot].buffer, self.gathered[self.slot]
+        if self.overlap:
+            try:
+                self.pending[self.slot] = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+                return
+            except (RuntimeError, NotImplementedError):
+                self.overlap = False  # e.g. a backend without the flat variant: synchronous path below
+        out.copy_(all_gather_tables(local, self.world, group=self.group))
+
+    def finish(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+        return self.gathered[self.slot] if self.world > 1 else self.tables[self.slot].buffer
+
+
 def merge_gathered(tables_per_rank: list[dict], rows_per_rank: list[int]) -> dict:
     """Concatenate the live rows of every rank's tables in rank order."""
     out = {}

@@ -159,25 +159,33 @@ def main():
     log(f"[bench] staged run+library in {t_stage:.2f}s, candidates uploaded in {t_upload:.3f}s")
 
     n_rows = -(-len(soa_all["precursor_idx"]) // world)  # pad to the largest shard
-    tables = DeviceTables(n_rows, int(cfgj.top_k_fragments), device, with_stats=True)
-    out_struct = tables.as_output(n_local)
-    # one explicit (non-default) torch stream carries the memset, the kernels and the collective
+    # one explicit (non-default) torch stream carries the memset and the kernels; with N > 1 the
+    # all-gather of step i (RCCL, its own stream) overlaps the kernels of step i+1 through two
+    # table buffers (alphadia_amd.distributed.PipelinedGather)
+    from alphadia_amd.distributed import PipelinedGather
+
+    pg = PipelinedGather(n_rows, int(cfgj.top_k_fragments), device, world, with_stats=True)
+    if os.environ.get("ADH_BENCH_NO_OVERLAP"):
+        pg.overlap = False
+    outs = [t.as_output(n_local) for t in pg.tables]
     work_stream = torch.cuda.Stream(device=device)
     stream = work_stream.cuda_stream
 
     def step():
         with torch.cuda.stream(work_stream):
+            tables = pg.begin()
             tables.zero_()
-            ctx.score_uploaded(cfgj, out_struct, stream)
-            if world > 1:
-                return all_gather_tables(tables.buffer, world)
-            return tables.buffer
+            ctx.score_uploaded(cfgj, outs[pg.slot], stream)
+            pg.end()
 
     def fence():
+        with torch.cuda.stream(work_stream):
+            out = pg.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -185,9 +193,10 @@ def main():
     ctx.kernel_time_ms(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gathered = step()
-    fence()
+        step()
+    gathered = fence()
     elapsed = time.perf_counter() - t0
+    tables = pg.tables[pg.slot]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,7 +241,9 @@ def main():
             "candidates_per_gpu": int(n_local),
             "cycles": args.cycles,
             "peaks": int(case.dia.mz_values.size),
-            "parallelism": f"candidate-sharded x{world}, tables all-gathered" if world > 1 else "single GPU",
+            "parallelism": (f"candidate-sharded x{world}, tables all-gathered "
+                            f"({'overlapped with the next step' if pg.overlap else 'synchronous'})")
+            if world > 1 else "single GPU",
             "valid_fraction": float(valid.mean()) if n_local else 0.0,
             "candidates_per_s": float(len(soa_all["precursor_idx"]) * args.steps / elapsed),
             "stage_seconds": t_stage,

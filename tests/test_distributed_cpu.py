@@ -15,6 +15,7 @@ import torch.multiprocessing as mp
 import helpers as H
 from alphadia_amd.distributed import (
     DeviceTables,
+    PipelinedGather,
     all_gather_rows,
     all_gather_tables,
     merge_gathered,
@@ -129,3 +130,36 @@ def test_two_rank_selection_sharding(tmp_path, oracle_lib):
         got = np.load(tmp_path / f"sel{r}.npz")
         for k, v in full.items():
             assert np.array_equal(got[k], v), (r, k)
+
+
+def _pipeline_worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = PipelinedGather(50, 4, "cpu", world, with_stats=False)
+    seen = []
+    for batch in range(5):
+        tables = pg.begin()
+        tables.zero_()
+        tables.buffer[:16] = batch * 10 + rank  # stands in for the kernels filling the tables
+        pg.end()
+        if batch >= 2:  # the slot about to be reused must already hold its complete gather
+            prev = pg.gathered[pg.slot ^ 1]
+            w = pg.pending[pg.slot ^ 1]
+            if w is not None:
+                w.wait()
+            seen.append(prev[:, 0].clone().numpy())
+    last = pg.finish()
+    np.savez(os.path.join(tmpdir, f"pipe{rank}.npz"), last=last[:, :16].numpy(), seen=np.stack(seen))
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_two_ranks(tmp_path):
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"pipe{r}.npz")
+        assert np.array_equal(z["last"], np.array([[40] * 16, [41] * 16], dtype=np.uint8))
+        # while batch b is being filled, the other slot holds the gather of batch b - 1
+        assert np.array_equal(z["seen"], np.array([[10, 11], [20, 21], [30, 31]], dtype=np.uint8))
