@@ -1738,6 +1738,39 @@ int adh_oracle_fragcomp(int64_t n_windows, const int64_t *window_start, const in
     return ADH_OK;
 }
 
+/* ---- known-answer helpers of the selection restatement (tests only) ---- */
+void adh_oracle_symetric_limits_1d(const double *a, int32_t n, int32_t center, double f, double center_fraction,
+                                   int64_t min_size, int64_t max_size, int32_t *out2) {
+    std::vector<double> v(a, a + n);
+    int o[2];
+    select_oracle::symetric_limits_1d(v, center, f, center_fraction, min_size, max_size, o);
+    out2[0] = o[0];
+    out2[1] = o[1];
+}
+
+/* find_peaks_1d (selection/utils.py:49-77) on one score row: returns the number of peaks written */
+int32_t adh_oracle_find_peaks_1d(const double *score, int32_t n, int32_t top_n, int32_t *cycle_out, double *score_out) {
+    std::vector<select_oracle::Box> peaks;
+    for (int p = 2; p < n - 2; ++p)
+        if (score[p - 2] < score[p - 1] && score[p - 1] < score[p] && score[p] > score[p + 1] &&
+            score[p + 1] > score[p + 2]) {
+            select_oracle::Box b{};
+            b.cycle = p;
+            b.score = score[p];
+            peaks.push_back(b);
+        }
+    std::stable_sort(peaks.begin(), peaks.end(), [](const select_oracle::Box &a, const select_oracle::Box &b) {
+        if (a.score != b.score) return a.score > b.score;
+        return a.cycle > b.cycle;
+    });
+    if ((int32_t)peaks.size() > top_n) peaks.resize((size_t)top_n);
+    for (size_t i = 0; i < peaks.size(); ++i) {
+        cycle_out[i] = peaks[i].cycle;
+        score_out[i] = peaks[i].score;
+    }
+    return (int32_t)peaks.size();
+}
+
 /* Candidate selection for every precursor (selection.py:620-660); `out` must be zeroed. */
 int adh_oracle_select(const adh_alpharaw_t *run, const adh_fragments_t *fragments,
                       const adh_precursors_t *precursors, const adh_selection_config_t *config,

@@ -39,6 +39,8 @@ def lib():
         _lib.adh_oracle_save_corrcoeff.restype = C.c_double
         _lib.adh_oracle_fragcomp.restype = C.c_int
         _lib.adh_oracle_select.restype = C.c_int
+        _lib.adh_oracle_find_peaks_1d.restype = C.c_int32
+        _lib.adh_oracle_symetric_limits_1d.restype = None
     return _lib
 
 
@@ -257,3 +259,23 @@ def select(dia, fragment_cols, precursors_marshalled, cfg, kernel, n_threads: in
     if rc != 0:
         raise RuntimeError(f"adh_oracle_select failed ({rc})")
     return arrays
+
+
+def symetric_limits_1d(a, center, f, center_fraction, min_size, max_size):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.zeros(2, dtype=np.int32)
+    lib().adh_oracle_symetric_limits_1d(
+        a.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(a.shape[0]), C.c_int32(int(center)), C.c_double(f),
+        C.c_double(center_fraction), C.c_int64(int(min_size)), C.c_int64(int(max_size)),
+        out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def find_peaks_1d(score_row, top_n):
+    a = np.ascontiguousarray(score_row, dtype=np.float64)
+    cyc = np.zeros(max(a.shape[0], 1), dtype=np.int32)
+    val = np.zeros(max(a.shape[0], 1), dtype=np.float64)
+    n = lib().adh_oracle_find_peaks_1d(a.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(a.shape[0]),
+                                       C.c_int32(int(top_n)), cyc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       val.ctypes.data_as(C.POINTER(C.c_double)))
+    return cyc[:n], val[:n]

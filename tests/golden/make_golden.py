@@ -522,6 +522,54 @@ def golden_transpose():
     print(path, n, "events", f"{os.path.getsize(path)/1e6:.2f} MB")
 
 
+def golden_selection_kats():
+    """Known answers of the small selection functions, produced by the reference functions
+    (selection/utils.py:49-77,218-280): random inputs -> outputs."""
+    import ref_shim
+
+    ref_shim.install_selection_glue()
+    from alphadia.search.selection.utils import _symetric_limits_1d, find_peaks_1d
+
+    rng = np.random.default_rng(23)
+    lim_in, lim_out = [], []
+    for _ in range(400):
+        n = int(rng.integers(0, 40))
+        x = rng.random(n)
+        if n and rng.random() < 0.5:  # a real peak shape
+            c0 = rng.integers(0, n)
+            x = np.exp(-0.5 * ((np.arange(n) - c0) / rng.uniform(1, 6)) ** 2) + 0.05 * rng.random(n)
+        center = int(rng.integers(-2, 42))
+        f, cf = float(rng.random() * 1.5), float(rng.random())
+        mn, mx = int(rng.integers(0, 12)), int(rng.integers(0, 25))
+        out = _symetric_limits_1d(x, center, f=f, center_fraction=cf, min_size=mn, max_size=mx)
+        pad = np.full(40, np.nan)
+        pad[:n] = x
+        lim_in.append(np.concatenate([pad, [n, center, f, cf, mn, mx]]))
+        lim_out.append(np.asarray(out, dtype=np.int32))
+    pk_in, pk_cyc, pk_val, pk_n = [], [], [], []
+    for _ in range(200):
+        n = int(rng.integers(3, 60))
+        row = np.cumsum(rng.normal(size=n))  # random walk: plenty of strict 5-point maxima
+        if rng.random() < 0.3:
+            row = np.round(row, 1)  # ties
+        top_n = int(rng.integers(1, 7))
+        scan, cyc, val = find_peaks_1d(np.stack([row, row]), top_n=top_n)
+        pad = np.full(60, np.nan)
+        pad[:n] = row
+        pk_in.append(np.concatenate([pad, [n, top_n]]))
+        c = np.full(6, -1, dtype=np.int32)
+        v = np.full(6, np.nan)
+        c[: len(cyc)] = cyc
+        v[: len(val)] = val
+        pk_cyc.append(c)
+        pk_val.append(v)
+        pk_n.append(len(cyc))
+    path = os.path.join(HERE, "selection_kats.npz")
+    np.savez_compressed(path, limits_in=np.stack(lim_in), limits_out=np.stack(lim_out), peaks_in=np.stack(pk_in),
+                        peaks_cycle=np.stack(pk_cyc), peaks_score=np.stack(pk_val), peaks_n=np.asarray(pk_n))
+    print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
 def golden_get_dense():
     """G1: AlphaRawJIT.get_dense on hand-picked query lists (incl. overlapping windows)."""
     case = small_case(102, n_precursors=40)
@@ -760,6 +808,9 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--selection-kats-only" in sys.argv:
+        golden_selection_kats()
+        sys.exit(0)
     if "--transpose-only" in sys.argv:
         golden_transpose()
         sys.exit(0)
@@ -783,5 +834,6 @@ if __name__ == "__main__":
     golden_multiplex()
     golden_edges()
     golden_selection()
+    golden_selection_kats()
     golden_transpose()
     golden_timstof()

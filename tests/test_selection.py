@@ -99,6 +99,35 @@ def test_selection_config_defaults_match_reference_golden():
         assert getattr(c, k) == getattr(ref, k).item(), k
 
 
+def test_symetric_limits_1d_matches_reference_function(oracle_lib):
+    """400 random inputs through the reference's `_symetric_limits_1d` (selection/utils.py:218-280;
+    its own test, tests/unit_tests/search/selection/test_search_utils.py:9-33, checks the same
+    properties): the restatement returns the same limits."""
+    z = np.load(H.golden_path("selection_kats.npz"))
+    for row, exp in zip(z["limits_in"], z["limits_out"]):
+        n, center, f, cf, mn, mx = int(row[40]), int(row[41]), row[42], row[43], int(row[44]), int(row[45])
+        got = oracle_lib.symetric_limits_1d(row[:n], center, f, cf, mn, mx)
+        assert np.array_equal(got, exp), (n, center, f, cf, mn, mx)
+        if n > 0 and 0 <= center < n:
+            assert got[0] <= center <= got[1] and got[0] >= 0 and got[1] <= n
+
+
+def test_find_peaks_1d_matches_reference_function(oracle_lib):
+    """200 random score rows (with ties) through the reference's `find_peaks_1d`
+    (selection/utils.py:49-77).  Ties between equal scores are broken by an unstable sort there:
+    compared as sets in that case."""
+    z = np.load(H.golden_path("selection_kats.npz"))
+    for row, cyc, val, n_exp in zip(z["peaks_in"], z["peaks_cycle"], z["peaks_score"], z["peaks_n"]):
+        n, top_n = int(row[60]), int(row[61])
+        got_c, got_v = oracle_lib.find_peaks_1d(row[:n], top_n)
+        assert len(got_c) == n_exp
+        assert np.array_equal(got_v, val[:n_exp])
+        if len(np.unique(val[:n_exp])) == n_exp:
+            assert np.array_equal(got_c, cyc[:n_exp])
+        else:
+            assert sorted(got_v) == sorted(val[:n_exp])
+
+
 # ---------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def ctx():
