@@ -410,6 +410,8 @@ class SelectionConfig(C.Structure):
         ("use_weighted_score", C.c_uint8),
         ("join_close_candidates", C.c_uint8),
         ("pad0", C.c_uint8),
+        ("pad1", C.c_uint8 * 4),
+        ("mobility_tolerance", C.c_double),
     ]
 
 
@@ -466,7 +468,8 @@ def pack_selection_config(cfg) -> SelectionConfig:
         float(cfg.join_close_candidates_scan_threshold), float(cfg.join_close_candidates_cycle_threshold),
         first(cfg.feature_mean), first(cfg.feature_std), first(cfg.feature_weight),
         int(bool(cfg.exclude_shared_ions)), int(bool(cfg.use_weighted_score)),
-        int(bool(cfg.join_close_candidates)), 0,
+        int(bool(cfg.join_close_candidates)), 0, (C.c_uint8 * 4)(),
+        float(getattr(cfg, "mobility_tolerance", 0.0)),
     )
 
 

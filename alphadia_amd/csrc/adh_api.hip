@@ -22,6 +22,7 @@
 #include "adh_features_im.hip"
 #include "adh_fragcomp.hip"
 #include "adh_select.hip"
+#include "adh_select_im.hip"
 #include "adh_transpose.hip"
 
 namespace {
@@ -96,6 +97,7 @@ struct adh_handle {
     const float *d_iso = nullptr;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
+    std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
     void *scratch_slab = nullptr;   // per-candidate scratch blocks of the AlphaRaw plan
     uint64_t scratch_slab_bytes = 0;
@@ -431,6 +433,8 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     UP(h->run_buf, d->rt_values, d->n_frames, &t.rt);
     UP(h->run_buf, d->mobility_values, (int64_t)d->scan_max_index, &t.mobility);
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
+    h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);
+    h->h_mobility_im.assign(d->mobility_values, d->mobility_values + d->scan_max_index);
     h->h_dpc = dpc;
     h->tims = t;
     h->tims_staged = true;
@@ -1081,10 +1085,210 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     return rc;
 }
 
+namespace {
+
+// Candidate selection on the staged ion-mobility run (see adh_select_im.hip); the caller has
+// validated the arguments and zero-filled the host table.
+int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_selection_config_t *cfg,
+                         const float *kernel, int32_t k0, int32_t k1, adh_candidate_table_t *out) {
+    const int64_t n = pc->n;
+    const DevTims &T = h->tims;
+    const int L = T.cycle_len, SM = T.scan_max, z = T.zeroth;
+    if (!pc->mobility) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor mobility column is NULL");
+    // rank-1 factors of the kernel (it is an outer product up to float32 rounding of its entries)
+    std::vector<double> ku((size_t)k0), kv((size_t)k1);
+    {
+        const int a0 = k0 / 2, b0 = k1 / 2;
+        const double c = (double)kernel[a0 * k1 + b0];
+        if (!(c > 0)) return fail(ADH_ERR_UNSUPPORTED, "smoothing kernel without a positive centre");
+        for (int a = 0; a < k0; ++a) ku[(size_t)a] = (double)kernel[a * k1 + b0] / c;
+        for (int b = 0; b < k1; ++b) kv[(size_t)b] = (double)kernel[a0 * k1 + b];
+        for (int a = 0; a < k0; ++a)
+            for (int b = 0; b < k1; ++b)
+                if (std::fabs(ku[(size_t)a] * kv[(size_t)b] - (double)kernel[a * k1 + b]) > 1e-5 * c + 1e-30)
+                    return fail(ADH_ERR_UNSUPPORTED, "smoothing kernel is not separable (not an outer product)");
+    }
+    const int n_iso = (int)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
+    const std::vector<double> &rtv = h->h_rt_im, &mobv = h->h_mobility_im;
+    const double *cyc = h->h_cycle.data();
+    const int64_t cmax = (T.n_frames - 1) / L;  // precursor_cycle_max_index (bruker_jit.py:131)
+    std::vector<selim::PrecRec> recs((size_t)n);
+    int32_t cap_cells = 1;
+    auto rev_upper = [&](float v) {  // searchsorted(mobility_values[::-1], v, "right")
+        int64_t a = 0, b = SM;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if (mobv[(size_t)(SM - 1 - m)] <= (double)v) a = m + 1; else b = m;
+        }
+        return a;
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        selim::PrecRec &r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+        if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+        if ((int64_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]) + n_iso > selim::MAX_W)
+            return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
+        r.precursor_idx = pc->precursor_idx[i];
+        r.frag_start = pc->frag_start_idx[i];
+        r.frag_stop = pc->frag_stop_idx[i];
+        r.mz = pc->mz[i];
+        r.charge = pc->charge[i];
+        // frame limits: get_frame_indices (jitclasses/utils.py:24-88) with the zeroth frame
+        const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
+        const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), (double)lo) - rtv.begin();
+        const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), (double)hi) - rtv.begin();
+        const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
+        int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
+        len = 16 * (int64_t)std::ceil((double)len / 16.0);
+        int64_t cs = c_lo, ce = c_lo + len;
+        if (ce > cmax) {
+            ce = cmax;
+            cs = cmax - len;
+            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+        }
+        // scan limits: _get_scan_indices (bruker_jit.py:204-245); ceil of a negative quotient
+        const float m_hi = (float)((double)pc->mobility[i] + cfg->mobility_tolerance);
+        const float m_lo = (float)((double)pc->mobility[i] - cfg->mobility_tolerance);
+        const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
+        const int64_t opt_len = 16 * (int64_t)std::ceil((double)(s_first - s_second) / 16.0);
+        int64_t ss = s_first, se = s_first - opt_len;
+        if (se < 0) {
+            se = 0;
+            ss = std::min<int64_t>(opt_len, SM);
+        }
+        const int64_t S = std::max<int64_t>(se - ss, 0), F = ce - cs;
+        r.cycle_start = (int32_t)cs;
+        r.n_cycles = (int32_t)std::max<int64_t>(F, 0);
+        r.scan_start = (int32_t)ss;
+        r.n_scans = (int32_t)S;
+        bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
+        if (ok) {
+            // an empty push query ends the precursor (bruker_jit.py:516-519, selection.py:40-49)
+            const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc->charge[i];
+            const double q_lo = (double)(float)((double)pc->mz[i] + 0.0), q_hi = (double)(float)((double)pc->mz[i] + off);
+            bool any_f = false, any_p = false;
+            for (int row = 0; row < L && !(any_f && any_p); ++row)
+                for (int64_t sc = ss; sc < ss + S; ++sc) {
+                    const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
+                    any_f = any_f || (q_lo <= wh && q_hi >= wl);
+                    any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
+                }
+            ok = any_f && any_p;
+        }
+        r.ok = ok ? 1 : 0;
+        if (ok) cap_cells = std::max<int32_t>(cap_cells, (int32_t)(S * F));
+    }
+    const size_t lds = (size_t)cap_cells * 4 * 4 + (size_t)(k0 + k1) * 8 + (size_t)cap_cells + 64;
+    if (lds > 150 * 1024) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "selection tile of %d cells (scans x cycles) needs %zu bytes of LDS: exceeds 150 KiB",
+                 cap_cells, lds);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    // batches of precursors whose tiles fit a bounded scratch slab
+    const uint64_t budget = 2ull << 30;
+    DeviceBuffers tmp;
+    const double *d_ku = nullptr, *d_kv = nullptr;
+    int rc = upload(tmp, ku.data(), k0, &d_ku, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, kv.data(), k1, &d_kv, h->stream);
+    DevCandTable dt{};
+    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
+                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
+    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
+    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
+                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
+                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>((size_t)out->n * width[f], 16));
+        if (e != hipSuccess) {
+            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
+            break;
+        }
+        tmp.ptrs.push_back(p);
+        *dev_out[f] = p;
+        e = hipMemsetAsync(p, 0, std::max<size_t>((size_t)out->n * width[f], 16), h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    unsigned char *d_scratch = nullptr;
+    selim::PrecRec *d_recs = nullptr;
+    if (rc == ADH_OK) {
+        hipError_t e = hipMalloc((void **)&d_scratch, budget);
+        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
+        else tmp.ptrs.push_back(d_scratch);
+    }
+    if (rc == ADH_OK) {
+        hipError_t e = hipMalloc((void **)&d_recs, std::max<size_t>((size_t)n * sizeof(selim::PrecRec), 16));
+        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection plan): ") + hipGetErrorString(e));
+        else tmp.ptrs.push_back(d_recs);
+    }
+    double total_ms = 0.0;
+    if (rc == ADH_OK) {
+        (void)hipFuncSetAttribute((const void *)adh_select_score_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipGetLastError();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        int64_t first = 0;
+        while (first < n && rc == ADH_OK) {
+            uint64_t off = 0;
+            int64_t last = first;
+            while (last < n) {
+                selim::PrecRec &r = recs[(size_t)last];
+                const uint64_t need = 32 + (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso) * r.n_scans * r.n_cycles * 4 : 0);
+                const uint64_t aligned = (need + 255) / 256 * 256;
+                if (off + aligned > budget) break;
+                r.scratch_off = off;
+                off += aligned;
+                ++last;
+            }
+            if (last == first) {
+                rc = fail(ADH_ERR_UNSUPPORTED, "one precursor's tiles exceed the selection scratch budget");
+                break;
+            }
+            const int32_t cnt = (int32_t)(last - first);
+            hipError_t e = hipMemcpyAsync(d_recs + first, recs.data() + first, (size_t)cnt * sizeof(selim::PrecRec),
+                                          hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
+                                   h->d_lib, d_recs + first, cnt, *cfg, (int32_t)n_iso, d_scratch);
+                hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
+                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells,
+                                   d_scratch, dt);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the host plan of the next batch reuses the slab
+            if (e != hipSuccess) {
+                rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
+                break;
+            }
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
+            first = last;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    if (rc == ADH_OK) h->last_select_ms = total_ms;
+    tmp.release();
+    return rc;
+}
+
+}  // namespace
+
 int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh_selection_config_t *cfg,
                           const float *kernel, int32_t k_rows, int32_t k_cols, adh_candidate_table_t *out) {
     if (!h || !pc || !cfg || !kernel || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!h->run_staged) return fail(ADH_ERR_NOT_STAGED, "no AlphaRaw run staged (candidate selection supports AlphaRaw runs)");
+    if (!h->run_staged && !h->tims_staged) return fail(ADH_ERR_NOT_STAGED, "no run staged");
     if (!h->d_lib) return fail(ADH_ERR_NOT_STAGED, "no fragment library staged");
     if (pc->n < 0 || cfg->candidate_count <= 0 || cfg->candidate_count > sel::MAX_CAND)
         return fail(ADH_ERR_INVALID_ARGUMENT, "candidate_count must be in 1..16");
@@ -1102,6 +1306,7 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         memset(host_out[f], 0, (size_t)out->n * width[f]);
     }
     if (n == 0) return ADH_OK;
+    if (h->tims_staged) return select_candidates_im(h, pc, cfg, kernel, k_rows, k_cols, out);
     // validate the fragment slices, size the LDS: longest slice, largest tile (the frame limits
     // of get_frame_indices, jitclasses/utils.py:24-88, depend on the tolerance only through the
     // number of cycles)

@@ -3,7 +3,7 @@
 ``HipCandidateSelection`` has the constructor and call signature of
 ``alphadia.search.selection.selection.CandidateSelection`` (selection.py:529-660) and returns the
 same candidate DataFrame; the per-precursor work runs in ``adh_select_kernel`` behind the C ABI
-(``adh_select_candidates``).  AlphaRaw (non-ion-mobility) runs only.
+(``adh_select_candidates``), for AlphaRaw runs and for ion-mobility (timsTOF) runs.
 """
 
 from __future__ import annotations
@@ -57,9 +57,10 @@ class CandidateSelectionConfig:
         return self
 
 
-def gaussian_kernel(dia, fwhm_rt: float, sigma_scale_rt: float, kernel_size: int) -> np.ndarray:
-    """The smoothing kernel of ``GaussianKernel.get_dense_matrix`` (selection/kernel.py:37-218)
-    for a run without ion mobility: float32, shape (kernel_height, kernel_width).
+def gaussian_kernel(dia, fwhm_rt: float, sigma_scale_rt: float, kernel_size: int,
+                    fwhm_mobility: float = 0.012, sigma_scale_mobility: float = 1.0) -> np.ndarray:
+    """The smoothing kernel of ``GaussianKernel.get_dense_matrix`` (selection/kernel.py:37-218):
+    float32, shape (kernel_height, kernel_width).
 
     Restated literally, including the reference's use of sigma (not sigma squared) on the
     diagonal of the covariance matrix and its normalisation constant."""
@@ -68,7 +69,11 @@ def gaussian_kernel(dia, fwhm_rt: float, sigma_scale_rt: float, kernel_size: int
     rt_values = np.asarray(dia.rt_values)
     rt_resolution = np.mean(np.diff(rt_values[::rt_datapoints]))
     sigma_rt = fwhm_rt / 2.3548 * sigma_scale_rt / rt_resolution
-    sigma_mob = 1.0  # determine_mobility_sigma without a mobility dimension (kernel.py:126-128)
+    if getattr(dia, "has_mobility", False):
+        mobility_resolution = np.mean(np.diff(np.asarray(dia.mobility_values)[::-1]))
+        sigma_mob = fwhm_mobility / 2.3548 * sigma_scale_mobility / mobility_resolution
+    else:
+        sigma_mob = 1.0  # determine_mobility_sigma without a mobility dimension (kernel.py:126-128)
     width = int(np.ceil(kernel_size / 2) * 2)
     height = int(np.ceil(min(kernel_size, int(dia.scan_max_index) + 1) / 2) * 2)
     x, y = np.meshgrid(np.arange(-width // 2, width // 2), np.arange(-height // 2, height // 2))
@@ -96,8 +101,6 @@ class HipCandidateSelection:
                  precursor_mz_column: str, fragment_mz_column: str, fwhm_rt: float = 5.0,
                  fwhm_mobility: float = 0.012, device: int = 0) -> None:
         self.dia_data = dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
-        if getattr(self.dia_data, "has_mobility", False):
-            raise NotImplementedError("candidate selection on the HIP backend supports AlphaRaw runs only")
         self.precursors_flat = precursors_flat.sort_values("precursor_idx").reset_index(drop=True)
         self.fragments_flat = fragments_flat
         self.config = config
@@ -107,7 +110,8 @@ class HipCandidateSelection:
         self.precursor_mz_column = precursor_mz_column
         self.fragment_mz_column = fragment_mz_column
         self.kernel = gaussian_kernel(self.dia_data, fwhm_rt, self.config_jit.sigma_scale_rt,
-                                      self.config_jit.kernel_size)
+                                      self.config_jit.kernel_size, fwhm_mobility,
+                                      self.config_jit.sigma_scale_mobility)
         self._device = device
 
     def _pack_precursors(self) -> _abi.Marshalled:

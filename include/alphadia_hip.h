@@ -182,8 +182,9 @@ int adh_destroy(adh_handle_t *handle);
 /*
  * Stage the run in HBM once (replaces DiaData.to_jitclass(),
  * raw_data/alpharaw_wrapper.py:124-142, as consumed at scoring.py:639).
- * Also builds the per-spectrum m/z bucket index used instead of the
- * reference's binary search (alpharaw_jit.py:53-64,293-297).
+ * The run is kept as a time-major transposed copy (sorted by cycle block, cycle
+ * row, m/z bin, cycle, m/z) that replaces the reference's per-spectrum binary
+ * search (alpharaw_jit.py:53-64,293-297): the XIC of a fragment is contiguous.
  */
 int adh_stage_alpharaw(adh_handle_t *handle, const adh_alpharaw_t *dia);
 
@@ -290,6 +291,8 @@ typedef struct adh_selection_config {
     uint8_t use_weighted_score;
     uint8_t join_close_candidates;
     uint8_t pad0;
+    uint8_t pad1[4];
+    double mobility_tolerance;       /* ion-mobility runs only */
 } adh_selection_config_t;
 
 /*

@@ -1582,6 +1582,288 @@ static void select_one(const adh_alpharaw_t &d, const adh_fragments_t &fr, const
     }
 }
 
+/* ---- ion-mobility runs (TimsTOFTransposeJIT): 2-D tiles (scan, cycle) ------------------------ */
+
+/* candidates of one precursor from its (S, F) score matrix: find_peaks_2d, _join_close_peaks,
+   symetric_limits_2d, _join_overlapping_candidates (selection.py:229-345,423-526;
+   selection/utils.py:80-115,283-312) */
+static void candidates_from_score(const std::vector<double> &score, int S, int F, const adh_selection_config_t &cfg,
+                                  std::vector<Box> &peaks) {
+    auto A = [&](int s, int f) { return score[(size_t)s * F + f]; };
+    peaks.clear();
+    if (S <= 2) { /* _find_peaks: no real ion-mobility dimension */
+        for (int p = 2; p < F - 2; ++p)
+            if (A(0, p - 2) < A(0, p - 1) && A(0, p - 1) < A(0, p) && A(0, p) > A(0, p + 1) && A(0, p + 1) > A(0, p + 2)) {
+                Box b{};
+                b.scan = 0;
+                b.cycle = p;
+                b.score = A(0, p);
+                peaks.push_back(b);
+            }
+    } else {
+        for (int s = 2; s < S - 2; ++s)
+            for (int p = 2; p < F - 2; ++p) {
+                bool pk = A(s - 2, p) < A(s - 1, p) && A(s - 1, p) < A(s, p) && A(s, p) > A(s + 1, p) && A(s + 1, p) > A(s + 2, p);
+                pk = pk && A(s, p - 2) < A(s, p - 1) && A(s, p - 1) < A(s, p) && A(s, p) > A(s, p + 1) && A(s, p + 1) > A(s, p + 2);
+                if (pk) {
+                    Box b{};
+                    b.scan = s;
+                    b.cycle = p;
+                    b.score = A(s, p);
+                    peaks.push_back(b);
+                }
+            }
+    }
+    /* argsort(intensity)[::-1][:top_n]: equal scores in reversed (scan-major) order */
+    {
+        std::vector<int> order(peaks.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (peaks[a].score != peaks[b].score) return peaks[a].score > peaks[b].score;
+            return a > b;
+        });
+        std::vector<Box> sorted;
+        for (int i : order) sorted.push_back(peaks[i]);
+        if ((int64_t)sorted.size() > cfg.candidate_count) sorted.resize((size_t)cfg.candidate_count);
+        peaks.swap(sorted);
+    }
+    {
+        const int n = (int)peaks.size();
+        std::vector<char> mask(n, 1);
+        for (int a = 0; a < n; ++a) {
+            if (!mask[a]) continue;
+            for (int b = a + 1; b < n; ++b) {
+                if (!mask[b]) continue;
+                if (std::abs(peaks[a].scan - peaks[b].scan) <= 3 && std::abs(peaks[a].cycle - peaks[b].cycle) <= 3) {
+                    if (peaks[a].score > peaks[b].score) mask[b] = 0; else mask[a] = 0;
+                }
+            }
+        }
+        std::vector<Box> kept;
+        for (int a = 0; a < n; ++a)
+            if (mask[a]) kept.push_back(peaks[a]);
+        peaks.swap(kept);
+    }
+    for (Box &b : peaks) {
+        const int mob_lower = (int)std::max<int64_t>(0, b.scan - cfg.min_size_mobility);
+        const int mob_upper = (int)std::min<int64_t>(S, b.scan + cfg.min_size_mobility);
+        const int cyc_lower = (int)std::max<int64_t>(0, b.cycle - cfg.min_size_rt);
+        const int cyc_upper = (int)std::min<int64_t>(F, b.cycle + cfg.min_size_rt);
+        std::vector<double> mob(S, 0.0), cyc(F, 0.0);
+        for (int s = 0; s < S; ++s)
+            for (int f = cyc_lower; f < cyc_upper; ++f) mob[s] += A(s, f);
+        for (int s = mob_lower; s < mob_upper; ++s)
+            for (int f = 0; f < F; ++f) cyc[f] += A(s, f);
+        symetric_limits_1d(mob, b.scan, cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
+                           cfg.max_size_mobility, b.scan_lim);
+        symetric_limits_1d(cyc, b.cycle, cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt,
+                           b.cycle_lim);
+    }
+    if (cfg.join_close_candidates) {
+        const int n = (int)peaks.size();
+        std::vector<char> mask(n, 1);
+        for (int a = 0; a < n; ++a) {
+            if (!mask[a]) continue;
+            for (int b = a + 1; b < n; ++b) {
+                if (!mask[b]) continue;
+                Box &P = peaks[a];
+                const Box &Q = peaks[b];
+                const double cyc_ov = (double)(std::min(P.cycle_lim[1], Q.cycle_lim[1]) - std::max(P.cycle_lim[0], Q.cycle_lim[0])) /
+                                      (double)(P.cycle_lim[1] - P.cycle_lim[0]);
+                const double scan_ov = (double)(std::min(P.scan_lim[1], Q.scan_lim[1]) - std::max(P.scan_lim[0], Q.scan_lim[0])) /
+                                       (double)(P.scan_lim[1] - P.scan_lim[0]);
+                if (scan_ov < 0 || cyc_ov < 0) continue;
+                if (cyc_ov > cfg.join_close_candidates_cycle_threshold && scan_ov > cfg.join_close_candidates_scan_threshold) {
+                    P.scan_lim[0] = std::min(P.scan_lim[0], Q.scan_lim[0]);
+                    P.scan_lim[1] = std::max(P.scan_lim[1], Q.scan_lim[1]);
+                    P.cycle_lim[0] = std::min(P.cycle_lim[0], Q.cycle_lim[0]);
+                    P.cycle_lim[1] = std::max(P.cycle_lim[1], Q.cycle_lim[1]);
+                    mask[b] = 0;
+                }
+            }
+        }
+        std::vector<Box> kept;
+        for (int a = 0; a < n; ++a)
+            if (mask[a]) kept.push_back(peaks[a]);
+        peaks.swap(kept);
+    }
+}
+
+/* rank-1 factors of the Gaussian kernel (it is an outer product up to float32 rounding of its
+   entries): k[a][b] ~ u[a] * v[b], u[a] = k[a][b0] / k[a0][b0], v[b] = k[a0][b] */
+static bool kernel_factors(const float *kernel, int k0, int k1, std::vector<double> &u, std::vector<double> &v) {
+    const int a0 = k0 / 2, b0 = k1 / 2;
+    const double c = (double)kernel[a0 * k1 + b0];
+    if (!(c > 0)) return false;
+    u.resize(k0);
+    v.resize(k1);
+    for (int a = 0; a < k0; ++a) u[a] = (double)kernel[a * k1 + b0] / c;
+    for (int b = 0; b < k1; ++b) v[b] = (double)kernel[a0 * k1 + b];
+    for (int a = 0; a < k0; ++a)
+        for (int b = 0; b < k1; ++b) {
+            const double k = (double)kernel[a * k1 + b];
+            if (std::fabs(u[a] * v[b] - k) > 1e-5 * c + 1e-30) return false;
+        }
+    return true;
+}
+
+static void select_one_im(const adh_timstof_t &d, const adh_fragments_t &fr, const adh_precursors_t &pc,
+                          const adh_selection_config_t &cfg, const std::vector<double> &ku, const std::vector<double> &kv,
+                          int64_t i, adh_candidate_table_t &out) {
+    const int L = d.cycle_len, SM = d.scan_max_index, z = d.zeroth_frame ? 1 : 0;
+    const int k0 = (int)ku.size(), k1 = (int)kv.size();
+    const int n_iso = (int)std::min<int64_t>(cfg.top_k_precursors, pc.n_isotope_cols);
+    std::vector<float> iso_mz(n_iso);
+    for (int j = 0; j < n_iso; ++j)
+        iso_mz[j] = (float)((double)pc.mz[i] + (double)j * 1.0033548350700006 / (double)pc.charge[i]);
+    std::vector<float> fmz;
+    for (uint32_t j = pc.frag_start_idx[i]; j < pc.frag_stop_idx[i]; ++j)
+        if (!(cfg.exclude_shared_ions && fr.cardinality[j] > 1)) fmz.push_back(fr.mz[j]);
+    std::stable_sort(fmz.begin(), fmz.end());
+    if (fmz.size() <= 3 || n_iso == 0) return;
+    /* frame limits (bruker_jit.py:139-203 -> jitclasses/utils.py:24-88), zeroth frame aware */
+    const float rt_lo = (float)((double)pc.rt[i] - cfg.rt_tolerance), rt_hi = (float)((double)pc.rt[i] + cfg.rt_tolerance);
+    const double *rtv = d.rt_values;
+    const int64_t f_lo = std::lower_bound(rtv, rtv + d.n_frames, (double)rt_lo) - rtv;
+    const int64_t f_hi = std::lower_bound(rtv, rtv + d.n_frames, (double)rt_hi) - rtv;
+    const int64_t cmax = (d.n_frames - 1) / L; /* precursor_cycle_max_index = frame_max_index // cycle_len */
+    const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
+    int64_t len = std::max<int64_t>(c_hi - c_lo, cfg.kernel_size);
+    len = 16 * (int64_t)std::ceil((double)len / 16.0);
+    int64_t cs = c_lo, ce = c_lo + len;
+    if (ce > cmax) {
+        ce = cmax;
+        cs = cmax - len;
+        if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+    }
+    const int F = (int)(ce - cs);
+    /* scan limits (bruker_jit.py:204-271): searchsorted on the reversed mobility axis; the length
+       is rounded with ceil of a NEGATIVE quotient, i.e. towards zero */
+    const float m_hi = (float)((double)pc.mobility[i] + cfg.mobility_tolerance);
+    const float m_lo = (float)((double)pc.mobility[i] - cfg.mobility_tolerance);
+    auto rev_upper = [&](float v) { /* searchsorted(mobility_values[::-1], v, "right") */
+        int64_t a = 0, b = SM;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if (d.mobility_values[SM - 1 - m] <= (double)v) a = m + 1; else b = m;
+        }
+        return a;
+    };
+    const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
+    const int64_t scan_len = s_first - s_second;
+    const int64_t opt_len = 16 * (int64_t)std::ceil((double)scan_len / 16.0);
+    int64_t ss = s_first, se = s_first - opt_len;
+    if (se < 0) {
+        se = 0;
+        ss = std::min<int64_t>(opt_len, SM);
+    }
+    /* make_slice_1d([ss, se]) is iterated as range(ss, se): empty unless ss < se */
+    const int S = (int)std::max<int64_t>(se - ss, 0);
+    if (F <= 0 || S <= 0) return;
+    /* _is_valid (selection.py:40-75) */
+    if (S % 2 != 0 || S < k0 || F < k1) return;
+
+    /* get_dense_intensity (bruker_jit.py:506-645): every push of the box whose quadrupole window
+       overlaps the range contributes; events are added in (TOF index, push) order */
+    auto dense = [&](const std::vector<float> &mzq, double tol, double q_lo, double q_hi, int k, std::vector<float> &tile) {
+        tile.assign((size_t)S * F, 0.0f);
+        float t = (float)tol * mzq[k];
+        float q = t / 1000000.0f;
+        const double lo = (double)(mzq[k] - q), hi = (double)(mzq[k] + q);
+        const int64_t t_lo = std::lower_bound(d.mz_values, d.mz_values + d.n_tof, lo) - d.mz_values;
+        const int64_t t_hi = std::lower_bound(d.mz_values, d.mz_values + d.n_tof, hi) - d.mz_values;
+        const int64_t frame_start = cs * L + z, frame_stop = ce * L + z;
+        for (int64_t tof = t_lo; tof < t_hi; ++tof)
+            for (int64_t e = d.tof_indptr[tof]; e < d.tof_indptr[tof + 1]; ++e) {
+                const uint32_t p = d.push_indices[e];
+                const int64_t frame = p / SM, scan = p % SM;
+                if (frame < frame_start || frame >= frame_stop || scan < ss || scan >= se) continue;
+                const int64_t crow = ((frame - z) % L) * SM + scan; /* row of the cycle table */
+                if (!(q_lo <= d.cycle[2 * crow + 1] && q_hi >= d.cycle[2 * crow])) continue;
+                const int64_t cyc = (frame - z) / L - cs;
+                float &c = tile[(size_t)(scan - ss) * F + cyc];
+                c = c + (float)d.intensity_values[e];
+            }
+    };
+    /* separable circular smoothing, kernel centred at (k0/2, k1/2): first along the cycles, then
+       along the scans; each pass accumulates in float64 and rounds to float32 once */
+    auto smooth_add_log = [&](const std::vector<float> &tile, std::vector<float> &lsum) {
+        std::vector<float> tmp((size_t)S * F);
+        for (int s = 0; s < S; ++s)
+            for (int f = 0; f < F; ++f) {
+                double acc = 0.0;
+                for (int b = 0; b < k1; ++b) {
+                    int src = (f + k1 / 2 - b) % F;
+                    if (src < 0) src += F;
+                    acc += kv[b] * (double)tile[(size_t)s * F + src];
+                }
+                tmp[(size_t)s * F + f] = (float)acc;
+            }
+        for (int s = 0; s < S; ++s)
+            for (int f = 0; f < F; ++f) {
+                double acc = 0.0;
+                for (int a = 0; a < k0; ++a) {
+                    int src = (s + k0 / 2 - a) % S;
+                    if (src < 0) src += S;
+                    acc += ku[a] * (double)tmp[(size_t)src * F + f];
+                }
+                const float sm = (float)acc;
+                lsum[(size_t)s * F + f] += (float)std::log((double)(sm + 1.0f));
+            }
+    };
+    /* an empty push query (no push of the box is isolated for the range) gives an empty dense
+       matrix and ends the precursor (bruker_jit.py:516-519, selection.py:40-49); the box spans
+       whole cycles, so every cycle row occurs */
+    auto any_push = [&](double q_lo, double q_hi) {
+        for (int row = 0; row < L; ++row)
+            for (int64_t scan = ss; scan < se; ++scan) {
+                const int64_t crow = (int64_t)row * SM + scan;
+                if (q_lo <= d.cycle[2 * crow + 1] && q_hi >= d.cycle[2 * crow]) return true;
+            }
+        return false;
+    };
+    if (!any_push((double)iso_mz[0], (double)iso_mz[n_iso - 1]) || !any_push(-1.0, -1.0)) return;
+    std::vector<float> lf((size_t)S * F, 0.0f), lp((size_t)S * F, 0.0f), tile;
+    for (int k = 0; k < (int)fmz.size(); ++k) {
+        dense(fmz, cfg.fragment_mz_tolerance, (double)iso_mz[0], (double)iso_mz[n_iso - 1], k, tile);
+        smooth_add_log(tile, lf);
+    }
+    for (int k = 0; k < n_iso; ++k) {
+        dense(iso_mz, cfg.precursor_mz_tolerance, -1.0, -1.0, k, tile);
+        smooth_add_log(tile, lp);
+    }
+    double mean = cfg.feature_mean, sd = cfg.feature_std, weight = cfg.feature_weight;
+    if (!cfg.use_weighted_score) {
+        double m = 0;
+        for (size_t c = 0; c < lf.size(); ++c) m += (double)(lf[c] + lp[c]);
+        m /= (double)lf.size();
+        double v = 0;
+        for (size_t c = 0; c < lf.size(); ++c) v += ((double)(lf[c] + lp[c]) - m) * ((double)(lf[c] + lp[c]) - m);
+        mean = m;
+        sd = std::sqrt(v / (double)lf.size());
+        weight = 1.0;
+    }
+    std::vector<double> score((size_t)S * F);
+    for (size_t c = 0; c < score.size(); ++c) score[c] = weight * ((double)(lf[c] + lp[c]) - mean) / (sd + 1e-6);
+    std::vector<Box> peaks;
+    candidates_from_score(score, S, F, cfg, peaks);
+    auto wrap0 = [](int64_t v, int64_t limit) { return v < 0 ? (int64_t)0 : std::min(v, limit); };
+    const int64_t frame_max = d.n_frames - 1, frame0 = cs * L + z;
+    for (size_t r = 0; r < peaks.size(); ++r) {
+        const Box &b = peaks[r];
+        const int64_t row = i * cfg.candidate_count + (int64_t)r;
+        out.precursor_idx[row] = pc.precursor_idx[i];
+        out.rank[row] = (uint8_t)r;
+        out.score[row] = (float)b.score;
+        out.scan_center[row] = (uint32_t)wrap0(b.scan + ss, SM);
+        out.scan_start[row] = (uint32_t)wrap0(b.scan_lim[0] + ss, SM);
+        out.scan_stop[row] = (uint32_t)wrap0(b.scan_lim[1] + ss, SM);
+        out.frame_center[row] = (uint32_t)wrap0((int64_t)b.cycle * L + frame0, frame_max);
+        out.frame_start[row] = (uint32_t)wrap0((int64_t)b.cycle_lim[0] * L + frame0, frame_max);
+        out.frame_stop[row] = (uint32_t)wrap0((int64_t)b.cycle_lim[1] * L + frame0, frame_max);
+    }
+}
+
 }  // namespace select_oracle
 
 extern "C" {
@@ -1736,6 +2018,22 @@ int adh_oracle_fragcomp(int64_t n_windows, const int64_t *window_start, const in
         }
     }
     return ADH_OK;
+}
+
+/* Candidate selection on an ion-mobility run; `out` must be zeroed.  Returns -2 when the kernel is
+   not an outer product (the smoothing is evaluated separably). */
+int adh_oracle_select_timstof(const adh_timstof_t *run, const adh_fragments_t *fragments,
+                              const adh_precursors_t *precursors, const adh_selection_config_t *config,
+                              const float *kernel, int32_t kernel_rows, int32_t kernel_cols,
+                              adh_candidate_table_t *out, int32_t n_threads) {
+    if (!run || !fragments || !precursors || !config || !kernel || !out) return -1;
+    if (out->n != precursors->n * config->candidate_count) return -1;
+    std::vector<double> ku, kv;
+    if (!select_oracle::kernel_factors(kernel, kernel_rows, kernel_cols, ku, kv)) return -2;
+    const int64_t n = precursors->n;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int64_t i = 0; i < n; ++i) select_oracle::select_one_im(*run, *fragments, *precursors, *config, ku, kv, i, *out);
+    return 0;
 }
 
 /* ---- known-answer helpers of the selection restatement (tests only) ---- */

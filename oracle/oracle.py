@@ -39,6 +39,7 @@ def lib():
         _lib.adh_oracle_save_corrcoeff.restype = C.c_double
         _lib.adh_oracle_fragcomp.restype = C.c_int
         _lib.adh_oracle_select.restype = C.c_int
+        _lib.adh_oracle_select_timstof.restype = C.c_int
         _lib.adh_oracle_find_peaks_1d.restype = C.c_int32
         _lib.adh_oracle_symetric_limits_1d.restype = None
     return _lib
@@ -279,3 +280,21 @@ def find_peaks_1d(score_row, top_n):
                                        C.c_int32(int(top_n)), cyc.ctypes.data_as(C.POINTER(C.c_int32)),
                                        val.ctypes.data_as(C.POINTER(C.c_double)))
     return cyc[:n], val[:n]
+
+
+def select_timstof(dia, fragment_cols, precursors_marshalled, cfg, kernel, n_threads: int = 1) -> dict:
+    """Restated candidate selection on an ion-mobility run (TimsTOFTransposeJIT fields)."""
+    m_dia = _abi.pack_timstof(dia)
+    m_frag = _abi.pack_fragments(*fragment_cols)
+    c = _abi.pack_selection_config(cfg)
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    n = int(precursors_marshalled.struct.n) * int(c.candidate_count)
+    m_out, arrays = _abi.alloc_candidate_table(n)
+    rc = lib().adh_oracle_select_timstof(
+        m_dia.ref(), m_frag.ref(), precursors_marshalled.ref(), C.byref(c),
+        k.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(k.shape[0]), C.c_int32(k.shape[1]),
+        m_out.ref(), C.c_int32(n_threads),
+    )
+    if rc != 0:
+        raise RuntimeError(f"adh_oracle_select_timstof failed ({rc})")
+    return arrays

@@ -731,6 +731,59 @@ TIMS_COLS = ["cycle", "dia_precursor_cycle", "rt_values", "mobility_values", "mz
              "tof_indptr", "push_indices", "intensity_values"]
 
 
+def golden_selection_timstof():
+    """CandidateSelection.__call__ on a small ion-mobility run (2-D tiles, find_peaks_2d); same FFT
+    stand-in and caveats as golden_selection."""
+    import ref_shim
+
+    ref_shim.install_selection_glue()
+    from alphadia.search.selection import selection as ref_sel
+    from alphadia.search.selection.config_df import CandidateSelectionConfig
+
+    case = syn.make_timstof_case(n_precursors=90, n_cycles=70, config_id=46, per_precursor=1,
+                                 scan_max_index=96, planted_fraction=0.7)
+    d = {"tims_" + c: getattr(case.dia, c) for c in TIMS_COLS}
+    d["tims_scan_max_index"] = np.asarray(case.dia.scan_max_index)
+    d["tims_zeroth_frame"] = np.asarray(case.dia.zeroth_frame)
+    for c in FRAG_COLS:
+        d["frag_" + c] = case.library.fragment_df[c].values
+    for c in PREC_NUM_COLS:
+        d["prec_" + c] = case.library.precursor_df[c].values
+    d["caveat"] = np.asarray(CAVEAT)
+    cfg = CandidateSelectionConfig()
+    cfg.update(dict(rt_tolerance=2.0, mobility_tolerance=0.22, candidate_count=3, min_size_rt=2,
+                    peak_len_rt=1.5, sigma_scale_rt=0.5, peak_len_mobility=0.06, sigma_scale_mobility=1.0,
+                    max_size_mobility=20))
+    dia = DuckTims(case.dia)
+    dia.has_mobility = True
+    cs = ref_sel.CandidateSelection(
+        dia, case.library.precursor_df.copy(), case.library.fragment_df.copy(), cfg,
+        rt_column="rt_library", mobility_column="mobility_library",
+        precursor_mz_column="mz_library", fragment_mz_column="mz_library",
+        fwhm_rt=cfg.peak_len_rt, fwhm_mobility=cfg.peak_len_mobility,
+    )
+    df = cs(thread_count=1)
+    d["kernel"] = np.asarray(cs.kernel, dtype=np.float32)
+    cj = cs.config_jit
+    for k in ("rt_tolerance mobility_tolerance precursor_mz_tolerance fragment_mz_tolerance candidate_count "
+              "top_k_precursors exclude_shared_ions kernel_size f_mobility f_rt center_fraction "
+              "min_size_mobility min_size_rt max_size_mobility max_size_rt use_weighted_score "
+              "join_close_candidates join_close_candidates_scan_threshold "
+              "join_close_candidates_cycle_threshold sigma_scale_rt sigma_scale_mobility peak_len_rt "
+              "peak_len_mobility").split():
+        d[f"cfg_{k}"] = np.asarray(getattr(cj, k))
+    for k in ("feature_mean", "feature_std", "feature_weight"):
+        d[f"cfg_{k}"] = np.asarray(getattr(cj, k), dtype=np.float64)
+    for c in ("precursor_idx rank score scan_center scan_start scan_stop frame_center frame_start "
+              "frame_stop elution_group_idx decoy").split():
+        d[f"out_{c}"] = df[c].values
+    print(len(df), "candidates for", df["precursor_idx"].nunique(), "precursors; ranks", np.bincount(df["rank"].values),
+          "kernel", cs.kernel.shape, "scan width", np.unique(df["scan_stop"] - df["scan_start"]))
+    path = os.path.join(HERE, "selection_timstof.npz")
+    np.savez_compressed(path, **d)
+    print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
 def golden_timstof():
     """G2 + G4 for ion-mobility data: TimsTOFTransposeJIT.get_dense and full scoring."""
     case = syn.make_timstof_case(n_precursors=160, n_cycles=36)
@@ -808,6 +861,9 @@ if __name__ == "__main__":
     if "--timstof-only" in sys.argv:
         golden_timstof()
         sys.exit(0)
+    if "--selection-timstof-only" in sys.argv:
+        golden_selection_timstof()
+        sys.exit(0)
     if "--selection-kats-only" in sys.argv:
         golden_selection_kats()
         sys.exit(0)
@@ -835,5 +891,6 @@ if __name__ == "__main__":
     golden_edges()
     golden_selection()
     golden_selection_kats()
+    golden_selection_timstof()
     golden_transpose()
     golden_timstof()
