@@ -7,11 +7,10 @@ comment "add implementations for other backends here" at :114).
 ``HipExtractionHandler`` has the interface of ``ClassicExtractionHandler``
 (extraction_handler.py:344-507): the same constructor arguments and the three
 methods ``select_candidates`` / ``score_and_quantify_candidates`` /
-``quantify_candidates``.  Scoring and quantification run on the GPU, and so does
-candidate selection for runs without ion mobility (``HipCandidateSelection``,
-SURVEY.md section 8f-1); for ion-mobility runs selection is delegated to a
-selection handler passed in by the integration (the reference's own
-``ClassicExtractionHandler``).
+``quantify_candidates``.  Candidate selection (``HipCandidateSelection``,
+SURVEY.md section 8f-1), scoring and quantification all run on the GPU, for runs
+with and without ion mobility; an optional ``selection_handler`` (e.g. the
+reference's own ``ClassicExtractionHandler``) can take over the selection step.
 
 INTEGRATION.md shows the three-line patch that registers the backend.
 """
@@ -83,15 +82,9 @@ class HipExtractionHandler:
         return selection(thread_count=self._config["general"]["thread_count"])
 
     def select_candidates(self, dia_data, spectral_library, apply_cutoff: bool = False) -> pd.DataFrame:
-        """extraction_handler.py:121-154.  Runs without ion mobility are selected on the GPU; an
-        ion-mobility run goes to the selection handler passed in by the integration."""
-        jit = dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
-        if getattr(jit, "has_mobility", False):
-            if self._selection_handler is None:
-                raise NotImplementedError(
-                    "candidate selection on ion-mobility runs is not part of the hip backend; construct "
-                    "the handler with selection_handler=ClassicExtractionHandler(...) (see INTEGRATION.md)"
-                )
+        """extraction_handler.py:121-154; both run layouts are selected on the GPU.  A selection
+        handler passed in by the integration (``selection_handler=``) takes precedence."""
+        if self._selection_handler is not None:
             return self._selection_handler.select_candidates(dia_data, spectral_library, apply_cutoff)
         self._reporter.log_string(
             f"Extracting batch of {len(spectral_library.precursor_df)} precursors", verbosity="progress"

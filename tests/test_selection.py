@@ -299,3 +299,42 @@ def test_hip_timstof_selection_matches_oracle_and_golden(ctx, oracle_lib):
         else:
             assert np.array_equal(got[c], exp[c]), c
     _compare_tims_with_golden(_frame(got), z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(5)))
+def test_hip_timstof_selection_randomized(ctx, oracle_lib, seed):
+    """Differential test on ion-mobility runs: random geometry and settings, HIP == oracle."""
+    from alphadia_amd import synthetic as syn
+
+    rng = np.random.default_rng(4000 + seed)
+    sm = int(rng.choice([64, 96, 128]))
+    case = syn.make_timstof_case(
+        n_precursors=int(rng.integers(40, 120)), n_cycles=int(rng.integers(50, 90)), config_id=800 + seed,
+        per_precursor=1, n_ms2_frames=int(rng.integers(2, 6)), windows_per_frame=int(rng.integers(1, 4)),
+        scan_max_index=sm, events_per_push=float(rng.choice([15.0, 40.0])), planted_fraction=float(rng.uniform(0.3, 0.8)),
+    )
+    cfg = CandidateSelectionConfig()
+    cfg.update(dict(
+        rt_tolerance=float(rng.choice([1.0, 2.5])), mobility_tolerance=float(rng.choice([0.2, 0.3, 0.45])),
+        candidate_count=int(rng.integers(1, 6)), top_k_precursors=int(rng.integers(1, 5)),
+        exclude_shared_ions=bool(rng.integers(0, 2)), min_size_rt=int(rng.integers(1, 4)),
+        min_size_mobility=int(rng.integers(2, 9)), max_size_mobility=int(rng.integers(10, 25)),
+        join_close_candidates=bool(rng.integers(0, 2)), use_weighted_score=bool(rng.integers(0, 2)),
+        peak_len_rt=1.5, sigma_scale_rt=0.5, peak_len_mobility=0.06,
+        kernel_size=int(rng.choice([20, 30])),
+    ))
+    case.dia.has_mobility = True
+    kern = gaussian_kernel(case.dia, cfg.peak_len_rt, cfg.sigma_scale_rt, cfg.kernel_size, cfg.peak_len_mobility,
+                           cfg.sigma_scale_mobility)
+    cols = fragment_columns(case.library.fragment_df, "mz_library")
+    ctx.stage_run(case.dia, force=True)
+    ctx.stage_fragments(*cols, force=True)
+    pm = _pack(case.library.precursor_df)
+    got = ctx.select_candidates(pm, cfg, kern)
+    exp = oracle_lib.select_timstof(case.dia, cols, pm, cfg, kern, n_threads=4)
+    for c in CANDIDATE_COLUMNS:
+        if c == "score":
+            assert np.allclose(got[c], exp[c], rtol=1e-6, atol=0), c
+        else:
+            assert np.array_equal(got[c], exp[c]), c
