@@ -181,10 +181,12 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
         for (int c = tid; c < SF; c += SCORE_THREADS) {
             const int s = c / F, f = c - s * F;
             double acc = 0.0;
+            const float *trow = tile + s * F;
             for (int b = 0; b < k1; ++b) {
-                int src = (f + k1 / 2 - b) % F;
-                if (src < 0) src += F;
-                acc += kv[b] * (double)tile[s * F + src];
+                int src = f + k1 / 2 - b;  // one wrap suffices: F >= k1 (_is_valid)
+                src += (src < 0) ? F : 0;
+                src -= (src >= F) ? F : 0;
+                acc += kv[b] * (double)trow[src];
             }
             tmp[c] = (float)acc;
         }
@@ -195,8 +197,9 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
             const int s = c / F, f = c - s * F;
             double acc = 0.0;
             for (int a = 0; a < k0; ++a) {
-                int src = (s + k0 / 2 - a) % S;
-                if (src < 0) src += S;
+                int src = s + k0 / 2 - a;  // one wrap suffices: S >= k0 (_is_valid)
+                src += (src < 0) ? S : 0;
+                src -= (src >= S) ? S : 0;
                 acc += ku[a] * (double)tmp[src * F + f];
             }
             const float sm = (float)acc;
