@@ -40,20 +40,56 @@ def slice_soa(soa: dict, a: int, b: int) -> dict:
             for k, v in soa.items()}
 
 
+# columns every rank can rebuild from the candidate table it already holds: they stay out of the
+# all-gather (65 of 646 bytes per candidate at top_k = 12)
+LOCAL_COLUMNS = ("precursor_idx", "rank", "fragment_precursor_idx", "fragment_rank", "stat_matched_peaks")
+
+
 def packed_layout(n_rows: int, top_k: int, with_stats: bool = True):
-    """Byte offsets of every OutputPsmDF table inside one packed buffer of ``n_rows`` rows."""
-    shapes = _abi.output_shapes(n_rows, top_k)
+    """Byte offsets of every OutputPsmDF table inside one packed buffer of ``n_rows`` rows.
+
+    The computed tables come first (the "wire" prefix that is all-gathered); ``LOCAL_COLUMNS``
+    follow.  ``wire_bytes`` gives the length of the prefix."""
+    shapes = dict(_abi.output_shapes(n_rows, top_k))
+    if with_stats:
+        shapes["stat_matched_peaks"] = ((n_rows,), np.uint32)
+    order = [k for k in shapes if k not in LOCAL_COLUMNS] + [k for k in shapes if k in LOCAL_COLUMNS]
     offsets = {}
     off = 0
-    for name, (shape, dt) in shapes.items():
+    for name in order:
+        shape, dt = shapes[name]
         offsets[name] = (off, shape, np.dtype(dt))
         off += int(np.prod(shape)) * np.dtype(dt).itemsize
         off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
-    if with_stats:
-        offsets["stat_matched_peaks"] = (off, (n_rows,), np.dtype(np.uint32))
-        off += n_rows * 4
-        off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
     return offsets, off
+
+
+def wire_bytes(offsets: dict) -> int:
+    """Length of the all-gathered prefix of a packed buffer."""
+    return min(off for name, (off, _, _) in offsets.items() if name in LOCAL_COLUMNS)
+
+
+def rebuild_local_columns(tables: dict, precursor_idx: np.ndarray, rank: np.ndarray, flags: np.ndarray | None = None,
+                          matched_peaks: np.ndarray | None = None) -> dict:
+    """Complete gathered wire tables with the columns that did not travel: candidate ids from the
+    candidate table (zero for skipped score groups, score_group.py:50-64), and their copies in
+    the filled rows of the fragment tables (candidate.py:403-481)."""
+    n = tables["valid"].shape[0]
+    pi = np.asarray(precursor_idx, dtype=np.uint32)[:n].copy()
+    rk = np.asarray(rank, dtype=np.uint8)[:n].copy()
+    if flags is not None:
+        skip = (np.asarray(flags)[:n] & _abi.FLAG_SKIP) != 0
+        pi[skip] = 0
+        rk[skip] = 0
+    filled = tables["fragment_type"] != 0  # ion types are ASCII codes, never 0
+    out = dict(tables)
+    out["precursor_idx"] = pi
+    out["rank"] = rk
+    out["fragment_precursor_idx"] = np.where(filled, pi[:, None], 0).astype(np.uint32)
+    out["fragment_rank"] = np.where(filled, rk[:, None], 0).astype(np.uint8)
+    if matched_peaks is not None:
+        out["stat_matched_peaks"] = np.asarray(matched_peaks, dtype=np.uint32)[:n]
+    return out
 
 
 class DeviceTables:
@@ -65,6 +101,7 @@ class DeviceTables:
         self.n_rows = int(n_rows)
         self.top_k = int(top_k)
         self.offsets, self.nbytes = packed_layout(self.n_rows, self.top_k, with_stats)
+        self.wire_nbytes = wire_bytes(self.offsets)
         self.buffer = torch.zeros(max(self.nbytes, 1), dtype=torch.uint8, device=device)
         self._with_stats = with_stats
 
@@ -93,12 +130,20 @@ class DeviceTables:
             raw[off : off + flat.size] = flat
         self.buffer.copy_(torch.from_numpy(raw).to(self.buffer.device))
 
+    @property
+    def wire(self):
+        """The prefix of the packed buffer that is all-gathered (computed tables only)."""
+        return self.buffer[: self.wire_nbytes]
+
     def to_host(self, buffer=None) -> dict:
-        """Unpack a packed buffer (this rank's, or one gathered slice) into numpy tables."""
+        """Unpack a packed buffer (this rank's, or one gathered slice) into numpy tables; a
+        wire-only slice yields the computed tables (see ``rebuild_local_columns``)."""
         raw = (self.buffer if buffer is None else buffer).cpu().numpy()
         out = {}
         for name, (off, shape, dt) in self.offsets.items():
             cnt = int(np.prod(shape))
+            if off + cnt * dt.itemsize > raw.shape[0]:
+                continue
             out[name] = raw[off : off + cnt * dt.itemsize].view(dt).reshape(shape).copy()
         return out
 
@@ -126,7 +171,7 @@ class PipelinedGather:
             tables = pg.begin()            # waits until the gather that last read this slot is done
             ... enqueue zero_() + scoring into `tables` on the current stream ...
             pg.end()                       # starts the gather of this slot, returns immediately
-        gathered = pg.finish()             # [world, nbytes] of the last batch, all work complete
+        gathered = pg.finish()             # [world, wire_nbytes] of the last batch, all work complete
     """
 
     def __init__(self, n_rows: int, top_k: int, device, world: int, with_stats: bool = True, group=None):
@@ -136,7 +181,7 @@ class PipelinedGather:
         self.group = group
         self.tables = [DeviceTables(n_rows, top_k, device, with_stats) for _ in range(2)]
         self.gathered = [
-            torch.empty((self.world, self.tables[0].buffer.shape[0]), dtype=torch.uint8, device=device)
+            torch.empty((self.world, self.tables[0].wire_nbytes), dtype=torch.uint8, device=device)
             for _ in range(2)
         ]
         self.pending = [None, None]
@@ -156,7 +201,7 @@ class PipelinedGather:
 
         if self.world <= 1:
             return
-        local, out = self.tables[self.slot].buffer, self.gathered[self.slot]
+        local, out = self.tables[self.slot].wire, self.gathered[self.slot]
         if self.overlap:
             try:
                 self.pending[self.slot] = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)

@@ -210,8 +210,12 @@ def main():
     print(f"[bench] rank {rank}: {int(valid.sum())}/{n_local} candidates valid", file=sys.stderr, flush=True)
     matched = host["stat_matched_peaks"][:n_local]
     if world > 1:
-        first = tables.to_host(gathered[0])
-        assert first["valid"].shape[0] == n_rows
+        # every rank must now hold every rank's tables: compare the valid counts
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        counts[rank] = int(valid.sum())
+        dist.all_reduce(counts)
+        got = [int(tables.to_host(gathered[r])["valid"].sum()) for r in range(world)]
+        assert got == [int(c) for c in counts.tolist()], (got, counts.tolist())
 
     lib_len = (soa["frag_stop_idx"].astype(np.int64) - soa["frag_start_idx"].astype(np.int64))
     per_cand_bytes = algorithmic_bytes(case.dia, soa, cfgj, matched, lib_len)
@@ -246,6 +250,7 @@ def main():
             if world > 1 else "single GPU",
             "valid_fraction": float(valid.mean()) if n_local else 0.0,
             "candidates_per_s": float(len(soa_all["precursor_idx"]) * args.steps / elapsed),
+            "gathered_bytes_per_candidate": pg.tables[0].wire_nbytes / max(n_rows, 1),
             "stage_seconds": t_stage,
             "candidate_upload_seconds": t_upload,
         },

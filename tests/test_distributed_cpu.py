@@ -21,6 +21,7 @@ from alphadia_amd.distributed import (
     merge_gathered,
     packed_layout,
     precursor_bounds,
+    rebuild_local_columns,
     shard_bounds,
     slice_soa,
     window_owner,
@@ -48,32 +49,36 @@ def test_packed_layout_is_aligned_and_disjoint():
     assert all(off % 256 == 0 for off, _, _ in offsets.values()) and spans[-1][1] <= nbytes
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, golden="handler_default"):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
 
-    g = H.load_scoring_golden("handler_default")
+    g = H.load_scoring_golden(golden)
     soa_all = H.soa_for(g, g.config)
     a, b = shard_bounds(soa_all["score_group_idx"], rank, world)
     local, _ = H.oracle_score(oracle, g, g.config, soa=slice_soa(soa_all, a, b))
     n_rows = -(-len(soa_all["precursor_idx"]) // world) + 3
     tables = DeviceTables(n_rows, int(g.config.top_k_fragments), "cpu", with_stats=False)
     tables.load_host(local)
-    gathered = all_gather_tables(tables.buffer, world)
+    # only the computed tables travel; candidate ids are rebuilt from the candidate table
+    gathered = all_gather_tables(tables.wire, world)
     rows = [shard_bounds(soa_all["score_group_idx"], r, world) for r in range(world)]
     merged = merge_gathered([tables.to_host(gathered[r]) for r in range(world)], [e - s for s, e in rows])
+    assert "precursor_idx" not in merged and "fragment_rank" not in merged
+    merged = rebuild_local_columns(merged, soa_all["precursor_idx"], soa_all["rank"], soa_all["flags"])
     np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **merged)
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib):
+@pytest.mark.parametrize("golden", ["handler_default", "multiplex"])
+def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib, golden):
     world = 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    g = H.load_scoring_golden("handler_default")
+    port = 29500 + (os.getpid() % 2000) + (7 if golden == "multiplex" else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), golden), nprocs=world, join=True)
+    g = H.load_scoring_golden(golden)
     full, _ = H.oracle_score(oracle_lib, g, g.config)
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
