@@ -214,15 +214,19 @@ class OutputPsmDF:
         self.__dict__.update(arrays)
         self.valid = self.valid.view(np.bool_)
 
-    def to_fragment_df(self):
-        mask = self.fragment_mz_library.reshape(-1) > 0
+    def fragment_rows(self):
+        """Flat positions (candidate row * top_k + slot) of the filled fragment rows."""
+        return np.flatnonzero(self.fragment_mz_library.reshape(-1) > 0)
+
+    def to_fragment_df(self, idx=None):
+        idx = self.fragment_rows() if idx is None else idx
         cols = (
             "fragment_precursor_idx fragment_rank fragment_mz_library fragment_mz "
             "fragment_mz_observed fragment_height fragment_intensity fragment_mass_error "
             "fragment_correlation fragment_position fragment_number fragment_type "
             "fragment_charge fragment_loss_type"
         ).split()
-        return tuple(getattr(self, c).reshape(-1)[mask] for c in cols)
+        return tuple(getattr(self, c).reshape(-1).take(idx) for c in cols)
 
     def to_precursor_df(self):
         v = self.valid
@@ -305,9 +309,10 @@ def assemble_candidates(
         cols["rank"] = np.zeros(n, dtype=np.uint8)
 
     lib_pidx = precursors_flat_df["precursor_idx"].values
+    lib_rows = None  # row in the caller's table of every row of the sorted one
     if len(lib_pidx) > 1 and not np.all(lib_pidx[1:] > lib_pidx[:-1]):
-        order = np.argsort(lib_pidx, kind="stable")
-        precursors_flat_df = precursors_flat_df.iloc[order]
+        lib_rows = np.argsort(lib_pidx, kind="stable")
+        precursors_flat_df = precursors_flat_df.iloc[lib_rows]
         lib_pidx = precursors_flat_df["precursor_idx"].values
     pos = np.searchsorted(lib_pidx, cols["precursor_idx"])
     pos_c = np.minimum(pos, max(len(lib_pidx) - 1, 0))
@@ -364,6 +369,8 @@ def assemble_candidates(
 
     out = {
         "order": order,
+        # row of every candidate in the caller's precursor table
+        "prec_row": (pos_c if lib_rows is None else lib_rows[pos_c])[order],
         "score_group_idx": score_group_idx,
         "elution_group_idx": eg,
         "decoy": dc,
@@ -421,6 +428,18 @@ def fragment_columns(fragments_flat: pd.DataFrame, fragment_mz_column: str) -> t
     )
 
 
+def _take_missing_columns(left_df, right_df, right_columns, rows):
+    """``merge_missing_columns`` when the matching right row of every left row is known already:
+    same columns, order and dtypes as the left merge on a unique key, without the hash join."""
+    missing = [c for c in dict.fromkeys(right_columns) if c not in left_df.columns]
+    absent = [c for c in missing if c not in right_df.columns]
+    if absent:
+        raise ValueError(f"Columns {absent} must be present in right_df")
+    for c in missing:
+        left_df[c] = right_df[c].values[rows]
+    return left_df
+
+
 def collect_candidates(
     candidates_df: pd.DataFrame,
     psm_proto_df: OutputPsmDF,
@@ -428,8 +447,14 @@ def collect_candidates(
     rt_column: str,
     mobility_column: str,
     precursor_mz_column: str,
+    row_maps=None,
+    sequence_counts=None,
 ) -> pd.DataFrame:
-    """scoring.py:394-467 (column names, order and merges)."""
+    """scoring.py:394-467 (column names, order and merges).
+
+    ``row_maps = (candidate_row, precursor_row)`` of every row of ``psm_proto_df`` (known from
+    ``assemble_candidates``) replaces the two hash joins by gathers; ``sequence_counts`` are the
+    per-precursor K / R / P counts (constant per library)."""
     precursor_idx, rank, features = psm_proto_df.to_precursor_df()
     df = pd.DataFrame(features, columns=DEFAULT_FEATURE_COLUMNS)
     df["precursor_idx"] = precursor_idx
@@ -439,32 +464,46 @@ def collect_candidates(
     candidate_columns += ["score"] if "score" in candidates_df.columns else []
     if "rank" not in candidates_df.columns:
         candidates_df = candidates_df.assign(rank=np.zeros(len(candidates_df), dtype=np.uint8))
-    df = merge_missing_columns(
-        df, candidates_df, candidate_columns, on=["precursor_idx", "rank"], how="left"
-    )
-
     precursor_df_columns = DEFAULT_PRECURSOR_COLUMNS + get_isotope_column_names(
         precursors_flat_df.columns
     )
     for col in [rt_column, mobility_column, precursor_mz_column]:
         if col not in precursor_df_columns:
             precursor_df_columns.append(col)
-    df = merge_missing_columns(
-        df, precursors_flat_df, precursor_df_columns, on=["precursor_idx"], how="left"
-    )
+    if row_maps is not None:
+        v = np.asarray(psm_proto_df.valid, dtype=bool)
+        cand_rows, prec_rows = row_maps[0][v], row_maps[1][v]
+        df = _take_missing_columns(df, candidates_df, candidate_columns, cand_rows)
+        df = _take_missing_columns(df, precursors_flat_df, precursor_df_columns, prec_rows)
+    else:
+        df = merge_missing_columns(
+            df, candidates_df, candidate_columns, on=["precursor_idx", "rank"], how="left"
+        )
+        df = merge_missing_columns(
+            df, precursors_flat_df, precursor_df_columns, on=["precursor_idx"], how="left"
+        )
     df["delta_rt"] = df["rt_observed"] - df[rt_column]
-    df["n_K"] = df["sequence"].str.count("K")
-    df["n_R"] = df["sequence"].str.count("R")
-    df["n_P"] = df["sequence"].str.count("P")
+    if row_maps is not None and sequence_counts is not None:
+        for name, counts in zip(("n_K", "n_R", "n_P"), sequence_counts, strict=True):
+            df[name] = counts[prec_rows]
+    else:
+        df["n_K"] = df["sequence"].str.count("K")
+        df["n_R"] = df["sequence"].str.count("R")
+        df["n_P"] = df["sequence"].str.count("P")
     return df
 
 
-def collect_fragments(psm_proto_df: OutputPsmDF, precursors_flat_df: pd.DataFrame) -> pd.DataFrame:
-    """scoring.py:520-580"""
-    df = pd.DataFrame(dict(zip(FRAGMENT_DF_COLUMNS, psm_proto_df.to_fragment_df(), strict=True)))
-    return merge_missing_columns(
-        df, precursors_flat_df, ["elution_group_idx", "decoy"], on=["precursor_idx"], how="left"
-    )
+def collect_fragments(psm_proto_df: OutputPsmDF, precursors_flat_df: pd.DataFrame, prec_rows=None) -> pd.DataFrame:
+    """scoring.py:520-580; ``prec_rows`` (precursor row of every row of ``psm_proto_df``) replaces the
+    hash join by a gather."""
+    idx = psm_proto_df.fragment_rows()
+    df = pd.DataFrame(dict(zip(FRAGMENT_DF_COLUMNS, psm_proto_df.to_fragment_df(idx), strict=True)))
+    if prec_rows is None:
+        return merge_missing_columns(
+            df, precursors_flat_df, ["elution_group_idx", "decoy"], on=["precursor_idx"], how="left"
+        )
+    rows = np.asarray(prec_rows).take(idx // psm_proto_df.fragment_mz_library.shape[1])
+    return _take_missing_columns(df, precursors_flat_df, ["elution_group_idx", "decoy"], rows)
 
 
 def _jit_view(dia_data):
@@ -533,6 +572,13 @@ class HipCandidateScoring:
         )
         return OutputPsmDF(arrays)
 
+    def _sequence_counts(self):
+        """K / R / P counts of every library precursor (scoring.py:462-464), computed once."""
+        if getattr(self, "_seq_counts", None) is None:
+            seq = self.precursors_flat_df["sequence"]
+            self._seq_counts = tuple(seq.str.count(a).values for a in ("K", "R", "P"))
+        return self._seq_counts
+
     def __call__(
         self,
         candidates_df: pd.DataFrame,
@@ -561,9 +607,11 @@ class HipCandidateScoring:
             self.rt_column,
             self.mobility_column,
             self.precursor_mz_column,
+            row_maps=(soa["order"], soa["prec_row"]),
+            sequence_counts=self._sequence_counts(),
         )
         logger.info("Collecting fragment features")
-        fragments_df = collect_fragments(psm_proto_df, self.precursors_flat_df)
+        fragments_df = collect_fragments(psm_proto_df, self.precursors_flat_df, prec_rows=soa["prec_row"])
         logger.info("Finished candidate scoring")
         return features_df, fragments_df
 

@@ -184,3 +184,30 @@ def test_abi_struct_sizes():
     assert C.sizeof(_abi.Output) == 8 + 8 + 19 * 8  # n, top_k(+pad), 19 pointers
     assert C.sizeof(_abi.Candidates) == 8 + 14 * 8 + 8
     assert C.sizeof(_abi.AlphaRaw) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_gather_based_collection_equals_the_merges():
+    """collect_candidates / collect_fragments with the row maps of assemble_candidates give the
+    same frames as the reference's hash joins (scoring.py:394-580), also for a shuffled library."""
+    from alphadia_amd.scoring import (OutputPsmDF, assemble_candidates, collect_candidates, collect_fragments)
+
+    g = H.load_scoring_golden("multiplex")
+    rng = np.random.default_rng(3)
+    pdf = g.library.precursor_df.sample(frac=1.0, random_state=5).reset_index(drop=True)  # unsorted on purpose
+    pdf["sequence"] = rng.choice(np.array(["PEPTIDEK", "KRPKRP", "AAAA", "PRK"], dtype=object), len(pdf))
+    cand = g.candidates_df.copy()
+    cand["score"] = rng.random(len(cand)).astype(np.float32)
+    soa = assemble_candidates(cand, pdf, "mz_library", score_grouped=True, reference_channel=0)
+    out = OutputPsmDF(dict(g.expected))
+    slow_f = collect_candidates(cand, out, pdf, "rt_library", "mobility_library", "mz_library")
+    seq = pdf["sequence"]
+    fast_f = collect_candidates(cand, out, pdf, "rt_library", "mobility_library", "mz_library",
+                                row_maps=(soa["order"], soa["prec_row"]),
+                                sequence_counts=tuple(seq.str.count(a).values for a in ("K", "R", "P")))
+    assert list(slow_f.columns) == list(fast_f.columns)
+    assert (slow_f.dtypes == fast_f.dtypes).all()
+    pd.testing.assert_frame_equal(slow_f, fast_f)
+    slow_r = collect_fragments(out, pdf)
+    fast_r = collect_fragments(out, pdf, prec_rows=soa["prec_row"])
+    pd.testing.assert_frame_equal(slow_r, fast_r)
+    assert len(fast_f) > 100 and len(fast_r) > 500
