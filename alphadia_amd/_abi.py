@@ -325,10 +325,12 @@ def output_shapes(n: int, top_k: int):
     return shapes
 
 
-def alloc_output(n: int, top_k: int, with_stats: bool = False):
-    """Zeroed host OutputPsmDF buffers (output.py:44-70) and the ctypes view of them."""
-    arrays = {k: np.zeros(shape, dtype=dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
-    stats = np.zeros(n, dtype=np.uint32) if with_stats else None
+def alloc_output(n: int, top_k: int, with_stats: bool = False, zero: bool = True):
+    """Host OutputPsmDF buffers (output.py:44-70) and the ctypes view of them; ``zero=False`` skips the
+    fill for callers that overwrite every byte (``adh_score_candidates`` copies whole tables back)."""
+    new = np.zeros if zero else np.empty
+    arrays = {k: new(shape, dtype=dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
+    stats = new(n, dtype=np.uint32) if with_stats else None
     s = Output(
         n,
         top_k,

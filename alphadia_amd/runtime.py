@@ -132,7 +132,8 @@ class Context:
     def score_host(self, cands: _abi.Marshalled, cfg_jit, with_stats: bool = False) -> dict:
         """Host table in, host OutputPsmDF arrays out."""
         n = int(cands.struct.n)
-        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+        # the call copies every table back completely: no need to clear the host buffers first
+        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats, zero=False)
         cfg = _abi.pack_config(cfg_jit)
         _check(
             lib.adh_score_candidates(self._h, cands.ref(), C.byref(cfg), m_out.ref()),
