@@ -741,7 +741,7 @@ def golden_selection_timstof():
     from alphadia.search.selection.config_df import CandidateSelectionConfig
 
     case = syn.make_timstof_case(n_precursors=90, n_cycles=70, config_id=46, per_precursor=1,
-                                 scan_max_index=96, planted_fraction=0.7)
+                                 scan_max_index=96, planted_fraction=0.7, n_tof=24000, events_per_push=20.0)
     d = {"tims_" + c: getattr(case.dia, c) for c in TIMS_COLS}
     d["tims_scan_max_index"] = np.asarray(case.dia.scan_max_index)
     d["tims_zeroth_frame"] = np.asarray(case.dia.zeroth_frame)
