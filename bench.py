@@ -238,8 +238,9 @@ def main():
         "dtype": "f32/f64",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1] per GPU: 100k-precursor predicted library x 3 candidates vs "
-                        "2h synthetic Thermo-style DIA run T120 (4800 cycles x 61 spectra)",
+            "workload": f"configs[1] per GPU: {args.precursors_per_gpu // 1000}k-precursor predicted library x 3 "
+                        f"candidates vs {'2h ' if args.cycles == 4800 else ''}synthetic Thermo-style DIA run "
+                        f"({args.cycles} cycles x 61 spectra)",
             "precursors_total": total_prec,
             "candidates_total": int(len(soa_all["precursor_idx"])),
             "candidates_per_gpu": int(n_local),
