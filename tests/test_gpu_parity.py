@@ -332,6 +332,14 @@ def test_randomized_shapes_and_settings(ctx, oracle_lib, seed):
         ms2_mz_range=(195, 520), few_fragment_fraction=float(rng.choice([0.0, 0.15])),
         even_fraction=float(rng.choice([0.0, 0.5])), planted_fraction=float(rng.uniform(0.2, 0.9)), threads=1,
     )
+    if rng.random() < 0.4:  # a run that ends inside a cycle
+        k = int(rng.integers(1, case.dia.cycle_len))
+        d = case.dia
+        d.rt_values = d.rt_values[:-k]
+        d.peak_start_idx_list = d.peak_start_idx_list[:-k]
+        d.peak_stop_idx_list = d.peak_stop_idx_list[:-k]
+        keep = case.candidates_df["frame_stop"].values <= d.rt_values.shape[0]
+        case.candidates_df = case.candidates_df[keep].reset_index(drop=True)
     if rng.random() < 0.5:  # shared fragments
         card = case.library.fragment_df["cardinality"].values.copy()
         card[rng.random(card.size) < 0.2] = 2
