@@ -532,6 +532,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
     __syncthreads();
     float *isl = fi, *nrm = fm;
     float *cen = fm;  // non-xic path: centred profiles [K][O][F] (nrm unused there)
+    float top3_nonxic = 0.0f;
     if (cfg.experimental_xic) {
         for (int c = lane; c < K * F; c += ADH_WAVE) {
             int k = c / F, f = c - k * F;
@@ -612,23 +613,88 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             fw[c] = sqrtf(q / (float)F);  // std, parked in fw until the FWHM step
         }
         __syncthreads();
-        // list[a] = sum_b red[a][b] * intensity[b]; red = sum_o corr_o * importance_o
-        for (int a = lane; a < K; a += ADH_WAVE) {
-            float acc = 0;
-            for (int b = 0; b < K; ++b) {
-                float red = 0;
-                for (int o = 0; o < O; ++o) {
-                    float dot = 0;
-                    for (int f = 0; f < F; ++f)
-                        dot += cen[(a * O + o) * F + f] * cen[(b * O + o) * F + f];
-                    float cov = dot / (float)F;
-                    float sm = fw[a * O + o] * fw[b * O + o];
-                    float cm = (float)((double)cov / ((double)sm + 1e-12));
-                    red += cm * oi[o];
+        // covariance_matrix = np.dot(profile_centered, profile_centered.T) (scoring/utils.py:559): the
+        // one dense contraction of the AlphaRaw path, a K x F x K product per observation.  The
+        // reference hands it to BLAS (SGEMM, summation order implementation defined); here it is
+        // one MFMA tile: v_mfma_f32_16x16x4_f32 accumulates the 16 x 16 Gram matrix over 4 cycles
+        // per instruction (lane l supplies row l % 16, cycle l / 16 of the centred profiles as both
+        // operands).  More than 16 fragments fall back to ordered scalar dot products.
+        // red = sum_o corr_o * importance_o, list[a] = sum_b red[a][b] * intensity[b]
+        __shared__ float gram[16][17], redm[16][17];
+        const bool use_mfma = K <= 16;
+        if (use_mfma) {
+            for (int c = lane; c < 16 * 16; c += ADH_WAVE) redm[c / 16][c % 16] = 0.0f;
+            for (int o = 0; o < O; ++o) {
+                typedef float floatx4 __attribute__((ext_vector_type(4)));
+                floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int i = lane & 15, kq = lane >> 4;
+                for (int f0 = 0; f0 < F; f0 += 4) {
+                    const int f = f0 + kq;
+                    const float v = (i < K && f < F) ? cen[(i * O + o) * F + f] : 0.0f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
                 }
-                acc += red * g_int[b];
+                __syncthreads();  // the previous observation's Gram matrix was consumed
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) gram[4 * kq + rr][i] = d[rr];
+                __syncthreads();
+                for (int a = lane; a < K; a += ADH_WAVE)
+                    for (int b = 0; b < K; ++b) {
+                        float cov = gram[a][b] / (float)F;
+                        float sm = fw[a * O + o] * fw[b * O + o];
+                        float cm = (float)((double)cov / ((double)sm + 1e-12));
+                        redm[a][b] += cm * oi[o];
+                    }
             }
-            corr[a] = acc;
+            __syncthreads();
+            for (int a = lane; a < K; a += ADH_WAVE) {
+                float acc = 0;
+                for (int b = 0; b < K; ++b) acc += redm[a][b] * g_int[b];
+                corr[a] = acc;
+            }
+        } else {
+            for (int a = lane; a < K; a += ADH_WAVE) {
+                float acc = 0;
+                for (int b = 0; b < K; ++b) {
+                    float red = 0;
+                    for (int o = 0; o < O; ++o) {
+                        float dot = 0;
+                        for (int f = 0; f < F; ++f)
+                            dot += cen[(a * O + o) * F + f] * cen[(b * O + o) * F + f];
+                        float cov = dot / (float)F;
+                        float sm = fw[a * O + o] * fw[b * O + o];
+                        float cm = (float)((double)cov / ((double)sm + 1e-12));
+                        red += cm * oi[o];
+                    }
+                    acc += red * g_int[b];
+                }
+                corr[a] = acc;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            // mean correlation of the three most intense fragments (profile_features.py:70-92)
+            int n3 = min(K, 3);
+            float sm = 0;
+            for (int i = 0; i < n3; ++i)
+                for (int j = 0; j < n3; ++j) {
+                    int a = ord[i], b = ord[j];
+                    float red = 0;
+                    if (use_mfma) {
+                        red = redm[a][b];
+                    } else {
+                        for (int o = 0; o < O; ++o) {
+                            float dot = 0;
+                            for (int f = 0; f < F; ++f)
+                                dot += cen[(a * O + o) * F + f] * cen[(b * O + o) * F + f];
+                            float cov = dot / (float)F;
+                            float sd = fw[a * O + o] * fw[b * O + o];
+                            float cm = (float)((double)cov / ((double)sd + 1e-12));
+                            red += cm * oi[o];
+                        }
+                    }
+                    sm += red;
+                }
+            top3_nonxic = (float)((double)sm / (double)(n3 * n3));
         }
     }
     __syncthreads();
@@ -640,23 +706,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             for (int i = 0; i < n3; ++i) sm += corr[ord[i]];
             top3 = (float)((double)sm / (double)n3);
         } else {
-            float sm = 0;
-            for (int i = 0; i < n3; ++i)
-                for (int j = 0; j < n3; ++j) {
-                    int a = ord[i], b = ord[j];
-                    float red = 0;
-                    for (int o = 0; o < O; ++o) {
-                        float dot = 0;
-                        for (int f = 0; f < F; ++f)
-                            dot += cen[(a * O + o) * F + f] * cen[(b * O + o) * F + f];
-                        float cov = dot / (float)F;
-                        float sd = fw[a * O + o] * fw[b * O + o];
-                        float cm = (float)((double)cov / ((double)sd + 1e-12));
-                        red += cm * oi[o];
-                    }
-                    sm += red;
-                }
-            top3 = (float)((double)sm / (double)(n3 * n3));
+            top3 = top3_nonxic;
         }
     }
     __syncthreads();
