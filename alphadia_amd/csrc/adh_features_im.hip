@@ -15,10 +15,8 @@
 //     (fragment_features.py:430-480 -> features 29, 30) and mobility FWHM
 //     (profile_features.py:151-188 -> feature 39)
 // One 64-lane wavefront per candidate; float32 reductions keep the reference's order.
-// The K x K scan-profile correlation is the one dense contraction of the path
-// (12 x 12 x S per candidate); it is computed with ordered float32 sums here to stay
-// bit-comparable with the CPU restatement - an MFMA (v_mfma_f32_16x16x4_f32) variant
-// is the planned follow-up once a tolerance-based check replaces the bitwise one.
+// The K x K scan-profile correlation is a small dense contraction (12 x 12 x S per candidate,
+// BLAS SGEMM in the reference): one v_mfma_f32_16x16x4_f32 tile per observation.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
@@ -91,7 +89,7 @@ struct Layout {
 
 }  // namespace featim
 
-#define ADH_IM_STATIC_LDS 4096  // static LDS of adh_feature_im_kernel (the chunk list), rounded up
+#define ADH_IM_STATIC_LDS 8192  // static LDS of adh_feature_im_kernel (the chunk list), rounded up
 size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
 
 __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
@@ -739,22 +737,57 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 mfw[c] = sqrtf(q / (float)S);
             }
             __syncthreads();
-            for (int a = lane; a < Km; a += ADH_WAVE) {
-                float acc = 0;
-                for (int b = 0; b < Km; ++b) {
-                    float red = 0;
-                    for (int o = 0; o < O; ++o) {
-                        float dot = 0;
-                        for (int sc = 0; sc < S; ++sc)
-                            dot += cen[(a * O + o) * S + sc] * cen[(b * O + o) * S + sc];
-                        float cov = dot / (float)S;
-                        float sm = mfw[a * O + o] * mfw[b * O + o];
-                        float cm = (float)((double)cov / ((double)sm + 1e-12));
-                        red += cm * oi[o];
+            // np.dot(profile_centered, profile_centered.T) over the scan axis (scoring/utils.py:559, BLAS
+            // SGEMM in the reference): one MFMA tile per observation, as in adh_feature_kernel; more
+            // than 16 fragments use ordered dot products
+            if (Km <= 16) {
+                __shared__ float gram[16][17], redm[16][17];
+                for (int c = lane; c < 16 * 16; c += ADH_WAVE) redm[c / 16][c % 16] = 0.0f;
+                for (int o = 0; o < O; ++o) {
+                    typedef float floatx4 __attribute__((ext_vector_type(4)));
+                    floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const int i = lane & 15, kq = lane >> 4;
+                    for (int s0 = 0; s0 < S; s0 += 4) {
+                        const int sc = s0 + kq;
+                        const float v = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
                     }
-                    acc += red * mnorm[b];
+                    __syncthreads();
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) gram[4 * kq + rr][i] = d[rr];
+                    __syncthreads();
+                    for (int a = lane; a < Km; a += ADH_WAVE)
+                        for (int b = 0; b < Km; ++b) {
+                            float cov = gram[a][b] / (float)S;
+                            float sm = mfw[a * O + o] * mfw[b * O + o];
+                            float cm = (float)((double)cov / ((double)sm + 1e-12));
+                            redm[a][b] += cm * oi[o];
+                        }
                 }
-                mlist[a] = acc;
+                __syncthreads();
+                for (int a = lane; a < Km; a += ADH_WAVE) {
+                    float acc = 0;
+                    for (int b = 0; b < Km; ++b) acc += redm[a][b] * mnorm[b];
+                    mlist[a] = acc;
+                }
+            } else {
+                for (int a = lane; a < Km; a += ADH_WAVE) {
+                    float acc = 0;
+                    for (int b = 0; b < Km; ++b) {
+                        float red = 0;
+                        for (int o = 0; o < O; ++o) {
+                            float dot = 0;
+                            for (int sc = 0; sc < S; ++sc)
+                                dot += cen[(a * O + o) * S + sc] * cen[(b * O + o) * S + sc];
+                            float cov = dot / (float)S;
+                            float sm = mfw[a * O + o] * mfw[b * O + o];
+                            float cm = (float)((double)cov / ((double)sm + 1e-12));
+                            red += cm * oi[o];
+                        }
+                        acc += red * mnorm[b];
+                    }
+                    mlist[a] = acc;
+                }
             }
             // fragment vs template scan correlation (scoring/utils.py:574-647)
             for (int c = lane; c < Km * O; c += ADH_WAVE) {
