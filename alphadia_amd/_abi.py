@@ -479,3 +479,47 @@ def alloc_candidate_table(n_rows: int):
     arrays = {name: np.zeros(n_rows, dtype=dt) for name, dt in CANDIDATE_TABLE_FIELDS}
     s = CandidateTable(n_rows, *[_ptr(arrays[name], _CT[np.dtype(dt)]) for name, dt in CANDIDATE_TABLE_FIELDS])
     return Marshalled(s, arrays), arrays
+
+
+# ---- FDR stage (include/alphadia_hip.h: adh_mlp_arch_t, adh_mlp_fit_t) ----------------------
+MLP_MAX_LINEAR = 8
+
+
+class MlpArch(C.Structure):
+    _fields_ = [
+        ("n_linear", C.c_int32),
+        ("dims", C.c_int32 * (MLP_MAX_LINEAR + 1)),
+        ("bn_eps", C.c_float),
+        ("bn_momentum", C.c_float),
+    ]
+
+
+class MlpFit(C.Structure):
+    _fields_ = [
+        ("train_rows", _i64p),
+        ("n_train", C.c_int64),
+        ("batch_start", _i64p),
+        ("n_steps", C.c_int64),
+        ("batch_size", C.c_int32),
+        ("learning_rate", C.c_float),
+        ("weight_decay", C.c_float),
+        ("dropout", C.c_float),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("eps", C.c_float),
+        ("seed", C.c_uint64),
+        ("first_step", C.c_int64),
+    ]
+
+
+def pack_mlp_arch(input_dim: int, layers, output_dim: int, bn_eps: float = 1e-5, bn_momentum: float = 0.1) -> MlpArch:
+    dims = [int(input_dim), *[int(x) for x in layers], int(output_dim)]
+    if len(dims) - 1 > MLP_MAX_LINEAR:
+        raise ValueError(f"at most {MLP_MAX_LINEAR - 1} hidden layers")
+    a = MlpArch()
+    a.n_linear = len(dims) - 1
+    for i, v in enumerate(dims):
+        a.dims[i] = v
+    a.bn_eps = bn_eps
+    a.bn_momentum = bn_momentum
+    return a

@@ -1537,3 +1537,6 @@ int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start
 }
 
 }  // extern "C"
+
+#include "adh_fdr.hip"
+#include "adh_mlp.hip"

@@ -34,6 +34,17 @@ EXPORTED_SYMBOLS = [
     "adh_select_candidates",
     "adh_select_time_ms",
     "adh_transpose_timstof",
+    "adh_fdr_q_values",
+    "adh_fdr_keep_best",
+    "adh_mlp_create",
+    "adh_mlp_destroy",
+    "adh_mlp_param_count",
+    "adh_mlp_set_state",
+    "adh_mlp_get_state",
+    "adh_mlp_stage_rows",
+    "adh_mlp_fit",
+    "adh_mlp_predict",
+    "adh_mlp_time_ms",
 ]
 
 
@@ -252,6 +263,141 @@ class Context:
             "adh_fragcomp",
         )
         return valid.view(np.bool_)
+
+
+    # -- FDR stage ---------------------------------------------------------
+    def fdr_q_values(self, score, decoy, tiebreak=None):
+        """``get_q_values`` (alphadia/fdr/fdr.py:232-297): returns ``(order, qval)``, the input row
+        at every sorted position and its q-value."""
+        sc = _abi.as_c(score, np.float64)
+        de = _abi.as_c(np.asarray(decoy) != 0, np.uint8)
+        n = sc.shape[0]
+        if de.shape[0] != n:
+            raise ValueError("score and decoy differ in length")
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        tb = None
+        if tiebreak is not None:
+            tb = _abi.as_c(tiebreak, np.int64)
+            if tb.shape[0] != n:
+                raise ValueError("score and tiebreak differ in length")
+        order = np.zeros(n, dtype=np.int64)
+        qval = np.zeros(n, dtype=np.float64)
+        _check(
+            lib.adh_fdr_q_values(self._h, C.c_int64(n), p(sc, C.c_double), p(de, C.c_uint8),
+                                 p(tb, C.c_int64) if tb is not None else None, p(order, C.c_int64),
+                                 p(qval, C.c_double)),
+            "adh_fdr_q_values",
+        )
+        return order, qval
+
+    def fdr_keep_best(self, score, group_a, group_b=None) -> np.ndarray:
+        """``keep_best`` (alphadia/fdr/fdr.py:181-213) as a mask over the input rows."""
+        sc = _abi.as_c(score, np.float64)
+        ga = _abi.as_c(group_a, np.int64)
+        gb = _abi.as_c(group_b, np.int64) if group_b is not None else None
+        n = sc.shape[0]
+        if ga.shape[0] != n or (gb is not None and gb.shape[0] != n):
+            raise ValueError("score and group columns differ in length")
+        keep = np.zeros(n, dtype=np.uint8)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        _check(
+            lib.adh_fdr_keep_best(self._h, C.c_int64(n), p(sc, C.c_double), p(ga, C.c_int64),
+                                  p(gb, C.c_int64) if gb is not None else None, p(keep, C.c_uint8)),
+            "adh_fdr_keep_best",
+        )
+        return keep.view(np.bool_)
+
+
+class DeviceMlp:
+    """An ``adh_mlp_t``: the classifier network with its parameters, optimiser moments and the
+    staged feature matrix in HBM."""
+
+    def __init__(self, ctx: Context, input_dim: int, layers, output_dim: int = 2):
+        self._ctx = ctx  # keeps the handle alive
+        self.arch = _abi.pack_mlp_arch(input_dim, layers, output_dim)
+        self.input_dim, self.layers, self.output_dim = int(input_dim), [int(x) for x in layers], int(output_dim)
+        n = C.c_int64(0)
+        _check(lib.adh_mlp_param_count(C.byref(self.arch), C.byref(n)), "adh_mlp_param_count")
+        self.n_params = int(n.value)
+        self._m = C.c_void_p()
+        _check(lib.adh_mlp_create(ctx._h, C.byref(self.arch), C.byref(self._m)), "adh_mlp_create")
+        self.n_rows = 0
+
+    def close(self):
+        if self._m:
+            lib.adh_mlp_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(a, t):
+        return a.ctypes.data_as(C.POINTER(t))
+
+    def set_state(self, params, running_mean, running_var, num_batches_tracked: int = 0):
+        pa = _abi.as_c(params, np.float32)
+        rm = _abi.as_c(running_mean, np.float32)
+        rv = _abi.as_c(running_var, np.float32)
+        if pa.shape != (self.n_params,) or rm.shape != (self.input_dim,) or rv.shape != (self.input_dim,):
+            raise ValueError("state arrays do not match the architecture")
+        _check(lib.adh_mlp_set_state(self._m, self._p(pa, C.c_float), self._p(rm, C.c_float), self._p(rv, C.c_float),
+                                     C.c_int64(int(num_batches_tracked))), "adh_mlp_set_state")
+
+    def get_state(self):
+        pa = np.zeros(self.n_params, dtype=np.float32)
+        rm = np.zeros(self.input_dim, dtype=np.float32)
+        rv = np.zeros(self.input_dim, dtype=np.float32)
+        nbt = C.c_int64(0)
+        _check(lib.adh_mlp_get_state(self._m, self._p(pa, C.c_float), self._p(rm, C.c_float), self._p(rv, C.c_float),
+                                     C.byref(nbt)), "adh_mlp_get_state")
+        return pa, rm, rv, int(nbt.value)
+
+    def stage_rows(self, x, y=None):
+        xa = _abi.as_c(x, np.float32)
+        if xa.ndim != 2:
+            raise ValueError("x must be (n_samples, n_features)")
+        ya = None
+        if y is not None:
+            ya = _abi.as_c(y, np.float32)
+            if ya.shape != (xa.shape[0],):
+                raise ValueError("y must hold one target per row")
+        _check(lib.adh_mlp_stage_rows(self._m, self._p(xa, C.c_float), C.c_int64(xa.shape[0]), C.c_int32(xa.shape[1]),
+                                      self._p(ya, C.c_float) if ya is not None else None), "adh_mlp_stage_rows")
+        self.n_rows = xa.shape[0]
+
+    def fit(self, train_rows, batch_start, batch_size: int, learning_rate: float, weight_decay: float,
+            dropout: float, seed: int = 0, first_step: int = 0, betas=(0.9, 0.999), eps: float = 1e-8) -> np.ndarray:
+        tr = _abi.as_c(train_rows, np.int64)
+        bs = _abi.as_c(batch_start, np.int64)
+        f = _abi.MlpFit()
+        f.train_rows, f.n_train = self._p(tr, C.c_int64), tr.shape[0]
+        f.batch_start, f.n_steps = self._p(bs, C.c_int64), bs.shape[0]
+        f.batch_size = int(batch_size)
+        f.learning_rate, f.weight_decay, f.dropout = float(learning_rate), float(weight_decay), float(dropout)
+        f.beta1, f.beta2, f.eps = float(betas[0]), float(betas[1]), float(eps)
+        f.seed, f.first_step = int(seed) & (2**64 - 1), int(first_step)
+        loss = np.zeros(bs.shape[0], dtype=np.float32)
+        _check(lib.adh_mlp_fit(self._m, C.byref(f), self._p(loss, C.c_float)), "adh_mlp_fit")
+        return loss
+
+    def predict(self, rows=None) -> np.ndarray:
+        if rows is None:
+            n, rp = self.n_rows, None
+        else:
+            ra = _abi.as_c(rows, np.int64)
+            n, rp = ra.shape[0], self._p(ra, C.c_int64)
+        out = np.zeros((n, self.output_dim), dtype=np.float32)
+        _check(lib.adh_mlp_predict(self._m, rp, C.c_int64(n), self._p(out, C.c_float)), "adh_mlp_predict")
+        return out
+
+    def time_ms(self):
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        _check(lib.adh_mlp_time_ms(self._m, C.byref(a), C.byref(b)), "adh_mlp_time_ms")
+        return float(a.value), float(b.value)
 
 
 _contexts: dict[int, Context] = {}

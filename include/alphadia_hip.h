@@ -337,6 +337,73 @@ int adh_transpose_timstof(adh_handle_t *handle, const uint32_t *tof_indices, con
 /* Duration (ms, HIP events) of the selection kernel of the last adh_select_candidates call. */
 int adh_select_time_ms(adh_handle_t *handle, double *kernel_ms);
 
+/* ------------------------------------------------------------------------------------------
+ * FDR stage: alphadia/fdr/fdr.py + alphadia/fdr/classifiers.py.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * q-values of n rows.  Replaces `get_q_values` + `_fdr_to_q_values` (fdr/fdr.py:215-297): rows are
+ * ordered by (score, decoy, tiebreak) ascending (stable; NaN scores last), fdr = cumulative decoys /
+ * cumulative targets (float64, 1/0 = inf as in numpy), q = running minimum of fdr from the back.
+ * `order_out[i]` = input row at sorted position i, `qval_out[i]` = its q-value (sorted order, as
+ * the reference returns the frame).  `tiebreak` (the reference's precursor_idx) may be NULL.
+ */
+int adh_fdr_q_values(adh_handle_t *handle, int64_t n, const double *score, const uint8_t *decoy,
+                     const int64_t *tiebreak, int64_t *order_out, double *qval_out);
+
+/*
+ * Best row per group.  Replaces `keep_best` (fdr/fdr.py:181-213): of the rows sharing
+ * (group_a[, group_b]) the one with the LOWEST score stays (score = decoy probability), the
+ * earliest row on ties; keep[i] = 1 for the rows that stay, rows keep their input order.
+ */
+int adh_fdr_keep_best(adh_handle_t *handle, int64_t n, const double *score, const int64_t *group_a,
+                      const int64_t *group_b, uint8_t *keep);
+
+/*
+ * The target/decoy classifier: BatchNorm1d -> (Linear -> ReLU -> Dropout) x hidden -> Linear ->
+ * Softmax trained with BCELoss and Adam (`FeedForwardNN`, fdr/classifiers.py:497-532;
+ * `BinaryClassifierLegacyNewBatching.fit/predict_proba`, :316-495).  The feature matrix is staged
+ * once and stays in HBM; a training step is three kernels (batch statistics, fused
+ * forward/backward per 16-row tile, gradient reduction + Adam) with no host round trip.
+ */
+#define ADH_MLP_MAX_LINEAR 8
+typedef struct adh_mlp adh_mlp_t;
+
+typedef struct adh_mlp_arch {
+    int32_t n_linear;                       /* Linear layers: hidden layers + the output layer */
+    int32_t dims[ADH_MLP_MAX_LINEAR + 1];   /* input_dim, hidden sizes ..., output_dim */
+    float bn_eps, bn_momentum;              /* torch.nn.BatchNorm1d defaults: 1e-5, 0.1 */
+} adh_mlp_arch_t;
+
+typedef struct adh_mlp_fit {
+    const int64_t *train_rows;   /* rows of the staged matrix in training order (x_train) */
+    int64_t n_train;
+    const int64_t *batch_start;  /* per optimiser step: first position of its batch in train_rows */
+    int64_t n_steps;
+    int32_t batch_size;
+    float learning_rate, weight_decay, dropout;
+    float beta1, beta2, eps;     /* torch.optim.Adam defaults: 0.9, 0.999, 1e-8 */
+    uint64_t seed;               /* dropout masks */
+    int64_t first_step;          /* optimiser steps taken before this call; 0 resets the Adam moments */
+} adh_mlp_fit_t;
+
+int adh_mlp_create(adh_handle_t *handle, const adh_mlp_arch_t *arch, adh_mlp_t **mlp);
+int adh_mlp_destroy(adh_mlp_t *mlp);
+/* floats in the trainable parameter vector: bn weight[d], bn bias[d], then per Linear weight[out][in], bias[out] */
+int adh_mlp_param_count(const adh_mlp_arch_t *arch, int64_t *n_params);
+int adh_mlp_set_state(adh_mlp_t *mlp, const float *params, const float *running_mean, const float *running_var,
+                      int64_t num_batches_tracked);
+int adh_mlp_get_state(adh_mlp_t *mlp, float *params, float *running_mean, float *running_var,
+                      int64_t *num_batches_tracked);
+/* copy x[n][d] (row-major float32) and, if not NULL, the class-1 target of every row to HBM */
+int adh_mlp_stage_rows(adh_mlp_t *mlp, const float *x, int64_t n, int32_t d, const float *y);
+/* n_steps training steps (network.train() semantics); train_loss[n_steps] may be NULL */
+int adh_mlp_fit(adh_mlp_t *mlp, const adh_mlp_fit_t *fit, float *train_loss);
+/* network.eval() forward of `rows` (NULL = all staged rows): proba[n][output_dim] */
+int adh_mlp_predict(adh_mlp_t *mlp, const int64_t *rows, int64_t n, float *proba);
+/* HIP-event time (ms) of the kernels of the last adh_mlp_fit / adh_mlp_predict call */
+int adh_mlp_time_ms(adh_mlp_t *mlp, double *fit_ms, double *predict_ms);
+
 #ifdef __cplusplus
 }
 #endif
