@@ -2,29 +2,39 @@
 // Network and training loop: FeedForwardNN (fdr/classifiers.py:497-532) and
 // BinaryClassifierLegacyNewBatching.fit / predict_proba (fdr/classifiers.py:316-495):
 //   BatchNorm1d(d) -> [Linear -> ReLU -> Dropout] x hidden -> Linear -> Softmax, BCELoss, Adam.
-// The whole model is 11 k parameters (43 KB): every workgroup keeps a copy in LDS and pushes a
-// 16-row tile of the batch through forward and backward without touching HBM in between.  One
-// training step = adh_mlp_bn_kernel (batch statistics, last block reduces) ->
-// adh_mlp_train_kernel (one tile per workgroup, per-tile gradients) -> adh_mlp_adam_kernel
-// (ordered reduction over the tiles + Adam).  Launches are queued back to back on the handle's
-// stream; the host never waits inside an epoch.  Results are deterministic for a given seed.
-// Included by adh_api.hip.
+// The whole model is 11 k parameters: every workgroup keeps a padded copy in LDS and pushes a 16-row
+// tile of the batch through forward and backward without touching HBM in between.  Every product
+// of the tile (X W^T forward, delta W and delta^T A backward) is a chain of v_mfma_f32_16x16x4_f32
+// instructions on 16 x 16 output blocks, operands read straight from LDS in the MFMA lane layout
+// (row strides are 4 * odd floats, so the 16 x 4 operand reads are bank-conflict free).
+// A fit call = adh_mlp_bn_kernel once (batch statistics of every distinct batch: they depend on the
+// rows only, not on the parameters), then per step adh_mlp_train_kernel (one tile per workgroup,
+// per-tile gradients) -> adh_mlp_adam_kernel (ordered reduction over the tiles + Adam).  Launches
+// are queued back to back on the handle's stream; the host never waits inside a fit.  Results are
+// deterministic for a given seed.  Included by adh_api.hip.
 
 #define ADH_MLP_TR 16
-#define ADH_MLP_THREADS 256
+#define ADH_MLP_THREADS 512
+#define ADH_MLP_WAVES (ADH_MLP_THREADS / 64)
 #define ADH_MLP_BN_ROWS 64
 
 struct MlpArch {
     int n_linear;
     int dims[ADH_MLP_MAX_LINEAR + 1];
     int w_off[ADH_MLP_MAX_LINEAR], b_off[ADH_MLP_MAX_LINEAR];  // into the parameter vector
+    int w_lds[ADH_MLP_MAX_LINEAR], b_lds[ADH_MLP_MAX_LINEAR];  // into the LDS copy (zero padded)
+    int in_s[ADH_MLP_MAX_LINEAR];                              // LDS row stride of W_l (4 * odd)
     int a_off[ADH_MLP_MAX_LINEAR + 1];                          // layer columns inside a tile row
-    int a_stride;                                               // floats per tile row (odd)
+    int a_stride;                                               // floats per tile row (4 * odd)
+    int x_stride;                                               // floats per row of the normalised input
     int n_params;
+    int lds_params;                                             // floats of the LDS parameter copy
     float bn_eps;
 };
 
 namespace mlp {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t step, uint32_t row, uint32_t layer, uint32_t j) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)step + 1);
@@ -36,43 +46,96 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t step, uint32_
 }
 
 struct Lds {
-    float *w, *act, *xh, *mean, *rstd, *y;
+    float *w, *act, *xh, *mean, *rstd, *y, *g;
 };
 
 __device__ __forceinline__ Lds carve(float *lds, const MlpArch &A) {
     Lds L;
-    const int d = A.dims[0];
-    L.w = lds;
-    L.act = L.w + A.n_params;
+    L.w = lds;  // [gamma d][beta d] then per layer W[out16][in_s], b[out16]
+    L.act = L.w + A.lds_params;
     L.xh = L.act + ADH_MLP_TR * A.a_stride;
-    L.mean = L.xh + ADH_MLP_TR * d;
-    L.rstd = L.mean + d;
-    L.y = L.rstd + d;
+    L.mean = L.xh + ADH_MLP_TR * A.x_stride;
+    L.rstd = L.mean + A.dims[0];
+    L.y = L.rstd + A.dims[0];
+    L.g = L.y + ADH_MLP_TR;  // per-tile gradient of every parameter (training only)
     return L;
 }
 
-// Linear layers of one tile; TRAIN adds dropout (classifiers.py:520-524)
+// padded parameter image (maintained by the Adam kernel) -> LDS, straight 16-byte copies
+__device__ __forceinline__ void load_params(const MlpArch &A, const Lds &L, const float *__restrict__ img) {
+    const float4 *src = reinterpret_cast<const float4 *>(img);
+    float4 *dst = reinterpret_cast<float4 *>(L.w);
+    const int n4 = A.lds_params / 4;
+    for (int base = threadIdx.x; base < n4; base += 8 * ADH_MLP_THREADS) {
+        float4 t[8];  // eight loads in flight per lane before the first LDS write
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u * ADH_MLP_THREADS < n4) t[u] = src[base + u * ADH_MLP_THREADS];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u * ADH_MLP_THREADS < n4) dst[base + u * ADH_MLP_THREADS] = t[u];
+    }
+}
+
+// one 16 x 16 output block: acc += sum_k A[.][k] B[k][.] over kp (a multiple of 16) columns; the two
+// operand streams advance by a_step / b_step floats per k.  Eight LDS reads are issued ahead of four
+// MFMAs on two independent accumulators.
+__device__ __forceinline__ floatx4 mfma_chain(const float *__restrict__ a, int a_step, const float *__restrict__ b,
+                                              int b_step, int kp) {
+    floatx4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float a0 = a[0], a1 = a[4 * a_step], a2 = a[8 * a_step], a3 = a[12 * a_step];
+    float b0 = b[0], b1 = b[4 * b_step], b2 = b[8 * b_step], b3 = b[12 * b_step];
+    for (int k0 = 16; k0 < kp; k0 += 16) {  // the next operands are in flight while these multiply
+        const float na0 = a[(k0 + 0) * a_step], na1 = a[(k0 + 4) * a_step], na2 = a[(k0 + 8) * a_step],
+                    na3 = a[(k0 + 12) * a_step];
+        const float nb0 = b[(k0 + 0) * b_step], nb1 = b[(k0 + 4) * b_step], nb2 = b[(k0 + 8) * b_step],
+                    nb3 = b[(k0 + 12) * b_step];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        a0 = na0, a1 = na1, a2 = na2, a3 = na3;
+        b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+    return acc0 + acc1;
+}
+
+// Linear layers of one tile: out[16 x N] = act[16 x K] W^T + b, one 16 x 16 block per wave and
+// round.  MFMA operands: lane (i = lane % 16, q = lane / 16) supplies A[i][k0 + q] = act[row i]
+// and B[k0 + q][i] = W[j0 + i]; D[4 q + rr][i] comes back in acc[rr].  TRAIN adds dropout
+// (classifiers.py:520-524).
 template <bool TRAIN>
 __device__ __forceinline__ void forward_layers(const MlpArch &A, const Lds &L, float drop_p, float keep_scale,
                                                uint64_t seed, uint32_t step, uint32_t row0) {
-    const int tid = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int S = A.a_stride;
     for (int l = 0; l < A.n_linear; ++l) {
-        const int in = A.dims[l], out = A.dims[l + 1];
-        const float *W = L.w + A.w_off[l], *b = L.w + A.b_off[l];
-        const float *ap = L.act + A.a_off[l];
+        const int in = A.dims[l], out = A.dims[l + 1], in_s = A.in_s[l];
+        const int kp = (in + 15) & ~15, n_blocks = (out + 15) >> 4;
+        const float *W = L.w + A.w_lds[l], *b = L.w + A.b_lds[l];
+        const float *ap = L.act + i * S + A.a_off[l] + q;
         float *an = L.act + A.a_off[l + 1];
         const bool hidden = l + 1 < A.n_linear;
-        for (int i = tid; i < ADH_MLP_TR * out; i += ADH_MLP_THREADS) {
-            const int r = i % ADH_MLP_TR, j = i / ADH_MLP_TR;
-            const float *a = ap + r * A.a_stride, *wj = W + j * in;
-            float acc = b[j];
-            for (int k = 0; k < in; ++k) acc = fmaf(a[k], wj[k], acc);
-            if (hidden) {
-                acc = acc > 0.0f ? acc : 0.0f;
-                if (TRAIN && drop_p > 0.0f && acc > 0.0f)
-                    acc = uniform01(seed, step, row0 + r, l, j) < drop_p ? 0.0f : acc * keep_scale;
+        for (int blk = wave; blk < n_blocks; blk += ADH_MLP_WAVES) {
+            const int j = blk * 16 + i;
+            const float *wp = W + j * in_s + q;
+            const floatx4 acc = mfma_chain(ap, 1, wp, 1, kp);
+            const float bias = b[j];  // zero in the padding
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * q + rr;
+                float v = acc[rr] + bias;
+                if (hidden) {
+                    v = v > 0.0f ? v : 0.0f;
+                    if (TRAIN && drop_p > 0.0f && v > 0.0f)
+                        v = uniform01(seed, step, row0 + r, l, j) < drop_p ? 0.0f : v * keep_scale;
+                }
+                an[r * S + j] = j < out ? v : 0.0f;
             }
-            an[r * A.a_stride + j] = acc;
         }
         __syncthreads();
     }
@@ -93,19 +156,23 @@ __device__ __forceinline__ void softmax_row(const MlpArch &A, float *z) {
 
 }  // namespace mlp
 
-// Batch statistics of BatchNorm1d in training mode.  Every block sums ADH_MLP_BN_ROWS rows
-// (shifted by the first row of the batch, in float64); the last block to finish adds the partial
-// sums in block order and writes mean, biased variance and 1/sqrt(var + eps).
-__global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_bn_kernel(
-    const float *__restrict__ X, int d, const int64_t *__restrict__ rows, int64_t b0, int B, double *__restrict__ part,
-    unsigned *__restrict__ ticket, double bn_eps, float *__restrict__ stats /* mean[d], var[d], rstd[d] */) {
-    __shared__ double red[2][ADH_MLP_THREADS];
+// Batch statistics of BatchNorm1d in training mode for every distinct batch of a fit call:
+// blockIdx.y = batch, blockIdx.x = chunk of ADH_MLP_BN_ROWS rows.  Every block sums its rows (shifted
+// by the first row of the batch, in float64); the last block of a batch to finish adds the partial
+// sums in chunk order and writes mean, biased variance and 1/sqrt(var + eps).
+__global__ __launch_bounds__(256) void adh_mlp_bn_kernel(
+    const float *__restrict__ X, int d, const int64_t *__restrict__ batch_start, int B, double *__restrict__ part, unsigned *__restrict__ ticket, double bn_eps,
+    float *__restrict__ stats /* per batch: mean[d], var[d], rstd[d] */) {
+    __shared__ double red[2][256];
     __shared__ bool last;
     const int tid = threadIdx.x;
-    const int groups = ADH_MLP_THREADS / 64;
+    const int groups = 256 / 64;
     const int g = tid / 64, lane = tid % 64;
+    const int batch = blockIdx.y, n_chunks = gridDim.x;
+    const int64_t b0 = batch_start[batch];
     const int r0 = blockIdx.x * ADH_MLP_BN_ROWS, r1 = min(B, r0 + ADH_MLP_BN_ROWS);
-    const int64_t pivot_row = rows[b0];
+    const int64_t pivot_row = b0;
+    double *bpart = part + (int64_t)batch * n_chunks * 2 * d;
     for (int c0 = 0; c0 < d; c0 += 64) {
         const int c = c0 + lane;
         double s = 0.0, ss = 0.0;
@@ -113,7 +180,7 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_bn_kernel(
             const double pivot = (double)X[pivot_row * d + c];
 #pragma unroll 8
             for (int r = r0 + g; r < r1; r += groups) {
-                const double v = (double)X[rows[b0 + r] * d + c] - pivot;
+                const double v = (double)X[(b0 + r) * d + c] - pivot;
                 s += v;
                 ss += v * v;
             }
@@ -122,64 +189,92 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_bn_kernel(
         red[1][tid] = ss;
         __syncthreads();
         if (g == 0 && c < d) {
-            for (int q = 1; q < groups; ++q) {
-                s += red[0][q * 64 + lane];
-                ss += red[1][q * 64 + lane];
+            for (int qg = 1; qg < groups; ++qg) {
+                s += red[0][qg * 64 + lane];
+                ss += red[1][qg * 64 + lane];
             }
-            part[((int64_t)blockIdx.x * 2 + 0) * d + c] = s;
-            part[((int64_t)blockIdx.x * 2 + 1) * d + c] = ss;
+            bpart[((int64_t)blockIdx.x * 2 + 0) * d + c] = s;
+            bpart[((int64_t)blockIdx.x * 2 + 1) * d + c] = ss;
         }
         __syncthreads();
     }
     __threadfence();
-    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (tid == 0) last = atomicAdd(ticket + batch, 1u) == (unsigned)n_chunks - 1;
     __syncthreads();
     if (!last) return;
     __threadfence();
-    for (int c = tid; c < d; c += ADH_MLP_THREADS) {
+    float *bstats = stats + (int64_t)batch * 3 * d;
+    for (int c = tid; c < d; c += 256) {
         double s = 0.0, ss = 0.0;
-        for (unsigned q = 0; q < gridDim.x; ++q) {
-            s += part[((int64_t)q * 2 + 0) * d + c];
-            ss += part[((int64_t)q * 2 + 1) * d + c];
+#pragma unroll 4
+        for (int qc = 0; qc < n_chunks; ++qc) {
+            s += bpart[((int64_t)qc * 2 + 0) * d + c];
+            ss += bpart[((int64_t)qc * 2 + 1) * d + c];
         }
         const double ms = s / (double)B;
         double var = ss / (double)B - ms * ms;
         if (var < 0.0) var = 0.0;
-        stats[c] = (float)((double)X[pivot_row * d + c] + ms);
-        stats[d + c] = (float)var;
-        stats[2 * d + c] = (float)(1.0 / sqrt(var + bn_eps));
+        bstats[c] = (float)((double)X[pivot_row * d + c] + ms);
+        bstats[d + c] = (float)var;
+        bstats[2 * d + c] = (float)(1.0 / sqrt(var + bn_eps));
     }
-    if (tid == 0) *ticket = 0;
+    if (tid == 0) ticket[batch] = 0;
+}
+
+// x_train / y_train of a fit call as contiguous copies: batches become plain row ranges
+__global__ void adh_mlp_take_rows_kernel(const float *__restrict__ X, const float *__restrict__ Y, int d,
+                                         const int64_t *__restrict__ rows, int64_t n, float *__restrict__ Xt,
+                                         float *__restrict__ Yt) {
+    const int64_t total = n * d;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / d;
+        const int c = (int)(idx - r * d);
+        Xt[idx] = X[rows[r] * d + c];
+        if (c == 0) Yt[r] = Y[rows[r]];
+    }
 }
 
 // Forward + backward of one 16-row tile; writes this tile's gradient of every parameter.
 __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
-    MlpArch A, const float *__restrict__ P, const float *__restrict__ X, const float *__restrict__ Y,
-    const int64_t *__restrict__ rows, int64_t b0, int B, const float *__restrict__ stats, float drop_p,
+    MlpArch A, const float *__restrict__ P, const float *__restrict__ X, const float *__restrict__ Y, int64_t b0,
+    int B, const float *__restrict__ stats, float drop_p,
     float keep_scale, uint64_t seed, uint32_t step, float *__restrict__ gpart, float *__restrict__ loss_part) {
     extern __shared__ float lds_mlp[];
     const mlp::Lds L = mlp::carve(lds_mlp, A);
     const int tid = threadIdx.x, tile = blockIdx.x;
-    const int d = A.dims[0], S = A.a_stride;
+    const int wave = tid >> 6, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int d = A.dims[0], S = A.a_stride, XS = A.x_stride;
     const int row0 = tile * ADH_MLP_TR;
     const int rows_here = min(ADH_MLP_TR, B - row0);
-    for (int i = tid; i < A.n_params; i += ADH_MLP_THREADS) L.w[i] = P[i];
+    // the tile's rows are requested first, the parameter image streams in behind them
+    const int dp = A.a_off[1];
+    const bool x_in_regs = ADH_MLP_TR * dp <= 2 * ADH_MLP_THREADS;
+    float xr[2] = {0.0f, 0.0f};
+    if (x_in_regs) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * ADH_MLP_THREADS, r = idx / dp, c = idx % dp;
+            if (r < rows_here && c < d) xr[u] = X[(b0 + row0 + r) * d + c];
+        }
+    }
+    mlp::load_params(A, L, P);
     for (int c = tid; c < d; c += ADH_MLP_THREADS) {
         L.mean[c] = stats[c];
         L.rstd[c] = stats[2 * d + c];
     }
-    if (tid < ADH_MLP_TR) L.y[tid] = tid < rows_here ? Y[rows[b0 + row0 + tid]] : 0.0f;
+    if (tid < ADH_MLP_TR) L.y[tid] = tid < rows_here ? Y[b0 + row0 + tid] : 0.0f;
     __syncthreads();
-    // BatchNorm1d, training mode (classifiers.py:519)
-    for (int i = tid; i < ADH_MLP_TR * d; i += ADH_MLP_THREADS) {
-        const int r = i / d, c = i % d;
+    // BatchNorm1d, training mode (classifiers.py:519); the padding columns of the tile stay zero
+    for (int idx = tid, u = 0; idx < ADH_MLP_TR * dp; idx += ADH_MLP_THREADS, ++u) {
+        const int r = idx / dp, c = idx % dp;
         float xn = 0.0f, a0 = 0.0f;
-        if (r < rows_here) {
-            const float x = X[rows[b0 + row0 + r] * d + c];
+        if (r < rows_here && c < d) {
+            const float x = x_in_regs ? (u == 0 ? xr[0] : xr[1]) : X[(b0 + row0 + r) * d + c];
             xn = (x - L.mean[c]) * L.rstd[c];
             a0 = fmaf(xn, L.w[c], L.w[d + c]);
         }
-        L.xh[r * d + c] = xn;
+        if (c < d) L.xh[r * XS + c] = xn;
         L.act[r * S + c] = a0;
     }
     __syncthreads();
@@ -212,33 +307,46 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
         if (tid == 0) loss_part[tile] = loss;
     }
     __syncthreads();
-
-    float *gt = gpart + (int64_t)tile * A.n_params;
     for (int l = A.n_linear - 1; l >= 0; --l) {
-        const int in = A.dims[l], out = A.dims[l + 1];
-        const float *W = L.w + A.w_off[l];
+        const int in = A.dims[l], out = A.dims[l + 1], in_s = A.in_s[l];
+        const float *W = L.w + A.w_lds[l];
         const float *delta = L.act + A.a_off[l + 1];
         float *ap = L.act + A.a_off[l];
-        for (int i = tid; i < out * in; i += ADH_MLP_THREADS) {
-            const int j = i / in, k = i % in;
-            float s = 0.0f;
+        // dW[n][k] = sum_r delta[r][n] a[r][k]: A operand = delta^T, B operand = a, 4 MFMAs over the 16 rows
+        const int nb = (out + 15) >> 4, kb = (in + 15) >> 4;
+        for (int blk = wave; blk < nb * kb; blk += ADH_MLP_WAVES) {
+            const int n0 = (blk / kb) * 16, k0 = (blk % kb) * 16;
+            mlp::floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < ADH_MLP_TR; ++r) s = fmaf(delta[r * S + j], ap[r * S + k], s);
-            gt[A.w_off[l] + i] = s;
+            for (int r0 = 0; r0 < ADH_MLP_TR; r0 += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(delta[(r0 + q) * S + n0 + i], ap[(r0 + q) * S + k0 + i], acc,
+                                                           0, 0, 0);
+            const int k = k0 + i;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = n0 + 4 * q + rr;
+                if (n < out && k < in) L.g[A.w_off[l] + n * in + k] = acc[rr];
+            }
         }
         for (int j = tid; j < out; j += ADH_MLP_THREADS) {
             float s = 0.0f;
 #pragma unroll
             for (int r = 0; r < ADH_MLP_TR; ++r) s += delta[r * S + j];
-            gt[A.b_off[l] + j] = s;
+            L.g[A.b_off[l] + j] = s;
         }
         __syncthreads();
-        for (int i = tid; i < ADH_MLP_TR * in; i += ADH_MLP_THREADS) {
-            const int r = i % ADH_MLP_TR, k = i / ADH_MLP_TR;
-            float s = 0.0f;
-            for (int j = 0; j < out; ++j) s = fmaf(delta[r * S + j], W[j * in + k], s);
-            if (l > 0) s = ap[r * S + k] > 0.0f ? s * keep_scale : 0.0f;  // ReLU and dropout of layer l - 1
-            ap[r * S + k] = s;
+        // d a[r][k] = sum_n delta[r][n] W[n][k], times the ReLU/dropout mask of layer l - 1; in place
+        const int np16 = (out + 15) & ~15;
+        for (int blk = wave; blk < kb; blk += ADH_MLP_WAVES) {
+            const int k = blk * 16 + i;
+            const mlp::floatx4 acc = mlp::mfma_chain(delta + i * S + q, 1, W + q * in_s + k, in_s, np16);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * q + rr;
+                float v = acc[rr];
+                if (l > 0) v = ap[r * S + k] > 0.0f ? v * keep_scale : 0.0f;
+                ap[r * S + k] = k < in ? v : 0.0f;
+            }
         }
         __syncthreads();
     }
@@ -248,27 +356,46 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
 #pragma unroll
         for (int r = 0; r < ADH_MLP_TR; ++r) {
             const float g = L.act[r * S + c];
-            sg = fmaf(g, L.xh[r * d + c], sg);
+            sg = fmaf(g, L.xh[r * XS + c], sg);
             sb += g;
         }
-        gt[c] = sg;
-        gt[d + c] = sb;
+        L.g[c] = sg;
+        L.g[d + c] = sb;
     }
+    __syncthreads();
+    // one coalesced write of the tile's gradient
+    float *gt = gpart + (int64_t)tile * A.n_params;
+    for (int idx = tid; idx < A.n_params; idx += ADH_MLP_THREADS) gt[idx] = L.g[idx];
 }
 
-// Sum the tile gradients in tile order, then torch.optim.Adam (weight decay added to the gradient,
-// classifiers.py:356-360); block 0 also updates the BatchNorm running statistics and the loss.
-__global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_adam_kernel(
-    int n_params, int n_tiles, const float *__restrict__ gpart, float *__restrict__ P, float *__restrict__ m,
+// Sum the tile gradients (8 tile groups per parameter in parallel, fixed order), then
+// torch.optim.Adam (weight decay added to the gradient, classifiers.py:356-360); block 0 also
+// updates the BatchNorm running statistics and the loss.
+#define ADH_MLP_ADAM_PARAMS 32
+__global__ __launch_bounds__(256) void adh_mlp_adam_kernel(
+    int n_params, int n_tiles, const float *__restrict__ gpart, float *__restrict__ P /* padded image */,
+    const int *__restrict__ pos /* parameter -> image position */, float *__restrict__ m,
     float *__restrict__ v, float weight_decay, float one_minus_beta1, float beta2, float one_minus_beta2,
     float step_size, float bc2_sqrt, float eps, int d, const float *__restrict__ stats, float *__restrict__ rm,
     float *__restrict__ rv, float momentum, float unbias, const float *__restrict__ loss_part, float loss_scale,
     float *__restrict__ loss_out) {
-    const int i = blockIdx.x * ADH_MLP_THREADS + threadIdx.x;
+    __shared__ float red[8][ADH_MLP_ADAM_PARAMS];
+    const int lp = threadIdx.x % ADH_MLP_ADAM_PARAMS, grp = threadIdx.x / ADH_MLP_ADAM_PARAMS;
+    const int i = blockIdx.x * ADH_MLP_ADAM_PARAMS + lp;
+    float g = 0.0f;
     if (i < n_params) {
-        float g = 0.0f;
-        for (int t = 0; t < n_tiles; ++t) g += gpart[(int64_t)t * n_params + i];
-        const float p = P[i];
+        const int per = (n_tiles + 7) / 8;
+        const int t1 = min(n_tiles, (grp + 1) * per);
+#pragma unroll 8
+        for (int t = grp * per; t < t1; ++t) g += gpart[(int64_t)t * n_params + i];
+    }
+    red[grp][lp] = g;
+    __syncthreads();
+    if (grp == 0 && i < n_params) {
+#pragma unroll
+        for (int qg = 1; qg < 8; ++qg) g += red[qg][lp];
+        const int ip = pos[i];
+        const float p = P[ip];
         g = fmaf(weight_decay, p, g);
         float mi = m[i], vi = v[i];
         mi = fmaf(g - mi, one_minus_beta1, mi);
@@ -276,30 +403,31 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_adam_kernel(
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         m[i] = mi;
         v[i] = vi;
-        P[i] = p - step_size * (mi / denom);
+        P[ip] = p - step_size * (mi / denom);
     }
     if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < d; c += ADH_MLP_THREADS) {
+        for (int c = threadIdx.x; c < d; c += 256) {
             rm[c] = fmaf(momentum, stats[c] - rm[c], rm[c]);
             rv[c] = fmaf(momentum, stats[d + c] * unbias - rv[c], rv[c]);
         }
-        if (threadIdx.x == 0 && loss_out) {
+        if (threadIdx.x < 64 && loss_out) {
             float s = 0.0f;
-            for (int t = 0; t < n_tiles; ++t) s += loss_part[t];
-            *loss_out = s * loss_scale;
+            for (int t = threadIdx.x; t < n_tiles; t += 64) s += loss_part[t];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (threadIdx.x == 0) *loss_out = s * loss_scale;
         }
     }
 }
 
-// network.eval() forward: running statistics, no dropout; one tile per workgroup
+// network.eval() forward: running statistics, no dropout; tiles strided over the workgroups
 __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_predict_kernel(
     MlpArch A, const float *__restrict__ P, const float *__restrict__ rm, const float *__restrict__ rv,
     const float *__restrict__ X, const int64_t *__restrict__ rows, int64_t n, float *__restrict__ proba) {
     extern __shared__ float lds_mlp[];
     const mlp::Lds L = mlp::carve(lds_mlp, A);
     const int tid = threadIdx.x;
-    const int d = A.dims[0], S = A.a_stride, out_dim = A.dims[A.n_linear];
-    for (int i = tid; i < A.n_params; i += ADH_MLP_THREADS) L.w[i] = P[i];
+    const int d = A.dims[0], S = A.a_stride, out_dim = A.dims[A.n_linear], dp = A.a_off[1];
+    mlp::load_params(A, L, P);
     for (int c = tid; c < d; c += ADH_MLP_THREADS) {
         L.mean[c] = rm[c];
         L.rstd[c] = (float)(1.0 / sqrt((double)rv[c] + (double)A.bn_eps));
@@ -309,10 +437,10 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_predict_kernel(
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t row0 = tile * ADH_MLP_TR;
         const int rows_here = (int)min((int64_t)ADH_MLP_TR, n - row0);
-        for (int i = tid; i < ADH_MLP_TR * d; i += ADH_MLP_THREADS) {
-            const int r = i / d, c = i % d;
+        for (int idx = tid; idx < ADH_MLP_TR * dp; idx += ADH_MLP_THREADS) {
+            const int r = idx / dp, c = idx % dp;
             float a0 = 0.0f;
-            if (r < rows_here) {
+            if (r < rows_here && c < d) {
                 const int64_t src = rows ? rows[row0 + r] : row0 + r;
                 a0 = fmaf((X[src * d + c] - L.mean[c]) * L.rstd[c], L.w[c], L.w[d + c]);
             }
@@ -348,6 +476,12 @@ struct adh_mlp {
     double *d_bn_part = nullptr;
     int64_t bn_cap = 0;
     unsigned *d_ticket = nullptr;
+    int64_t *d_batch_start = nullptr;
+    int64_t ticket_cap = 0, stats_cap = 0, batch_cap = 0;
+    int *d_pos = nullptr;           // parameter -> position in the padded image (d_P)
+    std::vector<int> pos;
+    float *d_Xt = nullptr, *d_Yt = nullptr;  // x_train / y_train of the current fit call
+    int64_t xt_cap = 0, yt_cap = 0;
     size_t lds_bytes = 0;
     double fit_ms = 0.0, predict_ms = 0.0;
 };
@@ -359,31 +493,44 @@ int mlp_layout(const adh_mlp_arch_t *a, MlpArch &A) {
         return fail(ADH_ERR_INVALID_ARGUMENT, "n_linear must be 1.." + std::to_string(ADH_MLP_MAX_LINEAR));
     A = MlpArch{};
     A.n_linear = a->n_linear;
-    int off = 0, col = 0;
+    auto odd4 = [](int n) {  // round up to 4 * odd: rows of 16 x 4 MFMA operands then hit distinct banks
+        n = (n + 3) & ~3;
+        return (n / 4) % 2 ? n : n + 4;
+    };
+    int col = 0;
     for (int l = 0; l <= a->n_linear; ++l) {
         if (a->dims[l] < 1 || a->dims[l] > 1024) return fail(ADH_ERR_INVALID_ARGUMENT, "layer sizes must be 1..1024");
         A.dims[l] = a->dims[l];
         A.a_off[l] = col;
-        col += a->dims[l];
+        col += (a->dims[l] + 15) & ~15;
     }
     if (a->dims[a->n_linear] > ADH_MLP_MAX_LINEAR || a->dims[a->n_linear] < 2)
         return fail(ADH_ERR_UNSUPPORTED, "output_dim must be 2.." + std::to_string(ADH_MLP_MAX_LINEAR));
-    A.a_stride = col | 1;
-    off = 2 * a->dims[0];
+    A.a_stride = odd4(col);
+    A.x_stride = a->dims[0] | 1;
+    int off = 2 * a->dims[0], lds = 2 * a->dims[0];
+    lds = (lds + 3) & ~3;
     for (int l = 0; l < a->n_linear; ++l) {
+        const int in = a->dims[l], out = a->dims[l + 1], out16 = (out + 15) & ~15;
         A.w_off[l] = off;
-        off += a->dims[l] * a->dims[l + 1];
+        off += in * out;
         A.b_off[l] = off;
-        off += a->dims[l + 1];
+        off += out;
+        A.in_s[l] = odd4((in + 15) & ~15);
+        A.w_lds[l] = lds;
+        lds += out16 * A.in_s[l];
+        A.b_lds[l] = lds;
+        lds += out16;
     }
     A.n_params = off;
+    A.lds_params = (lds + 16 + 3) & ~3;  // slack: the last operand rows may be read 16 floats past their end
     A.bn_eps = a->bn_eps;
     return ADH_OK;
 }
 
 size_t mlp_lds_bytes(const MlpArch &A) {
-    return sizeof(float) * ((size_t)A.n_params + (size_t)ADH_MLP_TR * A.a_stride + (size_t)ADH_MLP_TR * A.dims[0] +
-                            2 * (size_t)A.dims[0] + ADH_MLP_TR);
+    return sizeof(float) * ((size_t)A.lds_params + (size_t)ADH_MLP_TR * A.a_stride +
+                            (size_t)ADH_MLP_TR * A.x_stride + 2 * (size_t)A.dims[0] + ADH_MLP_TR + (size_t)A.n_params);
 }
 
 template <typename T>
@@ -412,7 +559,7 @@ int adh_mlp_destroy(adh_mlp_t *m) {
     if (!m) return ADH_OK;
     (void)hipSetDevice(m->h->device);
     void *ptrs[] = {m->d_P, m->d_m, m->d_v, m->d_rm, m->d_rv, m->d_stats, m->d_X, m->d_Y, m->d_rows, m->d_gpart,
-                    m->d_loss_part, m->d_loss, m->d_bn_part, m->d_ticket};
+                    m->d_loss_part, m->d_loss, m->d_bn_part, m->d_ticket, m->d_batch_start, m->d_pos, m->d_Xt, m->d_Yt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -438,13 +585,23 @@ int adh_mlp_create(adh_handle_t *h, const adh_mlp_arch_t *arch, adh_mlp_t **out)
         if (e == hipSuccess) e = hipMalloc(p, bytes);
         if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, h->stream);
     };
-    alloc((void **)&m->d_P, (size_t)A.n_params * 4);
+    alloc((void **)&m->d_P, (size_t)A.lds_params * 4);
+    alloc((void **)&m->d_pos, (size_t)A.n_params * 4);
+    m->pos.resize((size_t)A.n_params);
+    for (int c = 0; c < 2 * d; ++c) m->pos[(size_t)c] = c;
+    for (int l = 0; l < A.n_linear; ++l) {
+        const int in = A.dims[l], out = A.dims[l + 1];
+        for (int j = 0; j < out; ++j) {
+            for (int k = 0; k < in; ++k) m->pos[(size_t)(A.w_off[l] + j * in + k)] = A.w_lds[l] + j * A.in_s[l] + k;
+            m->pos[(size_t)(A.b_off[l] + j)] = A.b_lds[l] + j;
+        }
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->d_pos, m->pos.data(), (size_t)A.n_params * 4, hipMemcpyHostToDevice, h->stream);
     alloc((void **)&m->d_m, (size_t)A.n_params * 4);
     alloc((void **)&m->d_v, (size_t)A.n_params * 4);
     alloc((void **)&m->d_rm, (size_t)d * 4);
     alloc((void **)&m->d_rv, (size_t)d * 4);
-    alloc((void **)&m->d_stats, (size_t)3 * d * 4);
-    alloc((void **)&m->d_ticket, 4);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         adh_mlp_destroy(m);
@@ -466,7 +623,9 @@ int adh_mlp_set_state(adh_mlp_t *m, const float *params, const float *running_me
     HIP_TRY(hipSetDevice(m->h->device));
     hipStream_t st = m->h->stream;
     const int d = m->A.dims[0];
-    HIP_TRY(hipMemcpyAsync(m->d_P, params, (size_t)m->A.n_params * 4, hipMemcpyHostToDevice, st));
+    std::vector<float> img((size_t)m->A.lds_params, 0.0f);
+    for (int i = 0; i < m->A.n_params; ++i) img[(size_t)m->pos[(size_t)i]] = params[i];
+    HIP_TRY(hipMemcpyAsync(m->d_P, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_rm, running_mean, (size_t)d * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_rv, running_var, (size_t)d * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -479,10 +638,12 @@ int adh_mlp_get_state(adh_mlp_t *m, float *params, float *running_mean, float *r
     HIP_TRY(hipSetDevice(m->h->device));
     hipStream_t st = m->h->stream;
     const int d = m->A.dims[0];
-    HIP_TRY(hipMemcpyAsync(params, m->d_P, (size_t)m->A.n_params * 4, hipMemcpyDeviceToHost, st));
+    std::vector<float> img((size_t)m->A.lds_params, 0.0f);
+    HIP_TRY(hipMemcpyAsync(img.data(), m->d_P, img.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(running_mean, m->d_rm, (size_t)d * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(running_var, m->d_rv, (size_t)d * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < m->A.n_params; ++i) params[i] = img[(size_t)m->pos[(size_t)i]];
     if (nbt) *nbt = m->nbt;
     return ADH_OK;
 }
@@ -544,8 +705,22 @@ int adh_mlp_fit(adh_mlp_t *m, const adh_mlp_fit_t *f, float *train_loss) {
         m->tiles_cap = n_tiles;
     }
     if ((rc = mlp_reserve(&m->d_loss, &m->loss_cap, f->n_steps)) != ADH_OK) return rc;
-    if ((rc = mlp_reserve(&m->d_bn_part, &m->bn_cap, (int64_t)n_chunks * 2 * d)) != ADH_OK) return rc;
+    // distinct batches of this call: their statistics depend on the rows only
+    std::vector<int64_t> uniq(f->batch_start, f->batch_start + f->n_steps);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const int64_t n_uniq = (int64_t)uniq.size();
+    if ((rc = mlp_reserve(&m->d_bn_part, &m->bn_cap, n_uniq * n_chunks * 2 * d)) != ADH_OK) return rc;
+    if ((rc = mlp_reserve(&m->d_stats, &m->stats_cap, n_uniq * 3 * d)) != ADH_OK) return rc;
+    if ((rc = mlp_reserve(&m->d_batch_start, &m->batch_cap, n_uniq)) != ADH_OK) return rc;
+    if (n_uniq > m->ticket_cap) {
+        if ((rc = mlp_reserve(&m->d_ticket, &m->ticket_cap, n_uniq)) != ADH_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_ticket, 0, (size_t)n_uniq * 4, st));
+    }
+    if ((rc = mlp_reserve(&m->d_Xt, &m->xt_cap, f->n_train * d)) != ADH_OK) return rc;
+    if ((rc = mlp_reserve(&m->d_Yt, &m->yt_cap, f->n_train)) != ADH_OK) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_rows, f->train_rows, (size_t)f->n_train * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_batch_start, uniq.data(), (size_t)n_uniq * 8, hipMemcpyHostToDevice, st));
     if (f->first_step == 0) {
         HIP_TRY(hipMemsetAsync(m->d_m, 0, (size_t)A.n_params * 4, st));
         HIP_TRY(hipMemsetAsync(m->d_v, 0, (size_t)A.n_params * 4, st));
@@ -554,22 +729,30 @@ int adh_mlp_fit(adh_mlp_t *m, const adh_mlp_fit_t *f, float *train_loss) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(adh_mlp_take_rows_kernel, dim3(2048), dim3(256), 0, st, m->d_X, m->d_Y, d, m->d_rows,
+                       f->n_train, m->d_Xt, m->d_Yt);
+    for (int64_t u0 = 0; u0 < n_uniq; u0 += 32768) {
+        const int64_t nu = std::min<int64_t>(32768, n_uniq - u0);
+        hipLaunchKernelGGL(adh_mlp_bn_kernel, dim3(n_chunks, (unsigned)nu), dim3(256), 0, st, m->d_Xt, d,
+                           m->d_batch_start + u0, B, m->d_bn_part + u0 * n_chunks * 2 * d, m->d_ticket + u0,
+                           (double)A.bn_eps, m->d_stats + u0 * 3 * d);
+    }
     const float keep_scale = 1.0f / (1.0f - f->dropout);
     const float unbias = (float)((double)B / (double)(B - 1));
-    const int adam_blocks = (A.n_params + ADH_MLP_THREADS - 1) / ADH_MLP_THREADS;
+    const int adam_blocks = (A.n_params + ADH_MLP_ADAM_PARAMS - 1) / ADH_MLP_ADAM_PARAMS;
     for (int64_t s = 0; s < f->n_steps; ++s) {
         const int64_t t = f->first_step + s + 1;
         const double bc1 = 1.0 - pow((double)f->beta1, (double)t);
         const double bc2 = 1.0 - pow((double)f->beta2, (double)t);
-        hipLaunchKernelGGL(adh_mlp_bn_kernel, dim3(n_chunks), dim3(ADH_MLP_THREADS), 0, st, m->d_X, d, m->d_rows,
-                           f->batch_start[s], B, m->d_bn_part, m->d_ticket, (double)A.bn_eps, m->d_stats);
+        const int64_t slot = std::lower_bound(uniq.begin(), uniq.end(), f->batch_start[s]) - uniq.begin();
+        const float *stats = m->d_stats + slot * 3 * d;
         hipLaunchKernelGGL(adh_mlp_train_kernel, dim3(n_tiles), dim3(ADH_MLP_THREADS), m->lds_bytes, st, A, m->d_P,
-                           m->d_X, m->d_Y, m->d_rows, f->batch_start[s], B, m->d_stats, f->dropout, keep_scale,
-                           f->seed, (uint32_t)(t - 1), m->d_gpart, m->d_loss_part);
-        hipLaunchKernelGGL(adh_mlp_adam_kernel, dim3(adam_blocks), dim3(ADH_MLP_THREADS), 0, st, A.n_params, n_tiles,
-                           m->d_gpart, m->d_P, m->d_m, m->d_v, f->weight_decay, 1.0f - f->beta1, f->beta2,
-                           1.0f - f->beta2, (float)((double)f->learning_rate / bc1), (float)sqrt(bc2), f->eps, d,
-                           m->d_stats, m->d_rm, m->d_rv, m->bn_momentum, unbias, m->d_loss_part,
+                           m->d_Xt, m->d_Yt, f->batch_start[s], B, stats, f->dropout, keep_scale, f->seed,
+                           (uint32_t)(t - 1), m->d_gpart, m->d_loss_part);
+        hipLaunchKernelGGL(adh_mlp_adam_kernel, dim3(adam_blocks), dim3(256), 0, st, A.n_params, n_tiles, m->d_gpart,
+                           m->d_P, m->d_pos, m->d_m, m->d_v, f->weight_decay, 1.0f - f->beta1, f->beta2, 1.0f - f->beta2,
+                           (float)((double)f->learning_rate / bc1), (float)sqrt(bc2), f->eps, d, stats, m->d_rm,
+                           m->d_rv, m->bn_momentum, unbias, m->d_loss_part,
                            1.0f / ((float)B * (float)A.dims[A.n_linear]), m->d_loss + s);
     }
     HIP_TRY(hipGetLastError());
