@@ -478,3 +478,63 @@ def test_hip_fdr_manager_strategies(g):
         mgr.fit_predict(tab, "channel", competitive=False)
     with pytest.raises(ValueError):
         mgr.fit_predict(tab.drop(columns=cols), "precursor", competitive=False)
+
+
+@pytest.mark.gpu
+def test_hip_fdr_invalid_inputs_fail_loudly(ctx):
+    from alphadia_amd import runtime
+
+    with pytest.raises(ValueError):
+        ctx.fdr_q_values(np.zeros(4), np.zeros(3))
+    with pytest.raises(ValueError):
+        ctx.fdr_keep_best(np.zeros(4), np.zeros(4, np.int64), np.zeros(5, np.int64))
+    with pytest.raises(ValueError):
+        runtime.DeviceMlp(ctx, 4, [8] * 9, 2)  # more hidden layers than the ABI carries
+    with pytest.raises(runtime.HipBackendError):
+        runtime.DeviceMlp(ctx, 4, [8], 1)  # output_dim must be at least 2
+    mlp = runtime.DeviceMlp(ctx, 4, [8], 2)
+    x = np.zeros((10, 4), np.float32)
+    with pytest.raises(runtime.HipBackendError):  # nothing staged
+        mlp.fit(np.arange(10), np.zeros(1, np.int64), 4, 1e-3, 0.0, 0.0)
+    with pytest.raises(runtime.HipBackendError):  # wrong feature count
+        mlp.stage_rows(np.zeros((10, 5), np.float32), np.zeros(10))
+    mlp.stage_rows(x)
+    with pytest.raises(runtime.HipBackendError):  # rows staged without targets
+        mlp.fit(np.arange(10), np.zeros(1, np.int64), 4, 1e-3, 0.0, 0.0)
+    mlp.stage_rows(x, np.zeros(10))
+    for kw in (dict(train_rows=np.arange(11)), dict(batch_start=np.array([8])), dict(batch_size=1), dict(dropout=1.0)):
+        args = dict(train_rows=np.arange(10), batch_start=np.zeros(1, np.int64), batch_size=4, learning_rate=1e-3,
+                    weight_decay=0.0, dropout=0.0)
+        args.update(kw)
+        with pytest.raises(runtime.HipBackendError):
+            mlp.fit(**args)
+    with pytest.raises(runtime.HipBackendError):
+        mlp.predict(np.array([10]))
+    assert mlp.predict(np.zeros(0, np.int64)).shape == (0, 2)
+    mlp.close()
+
+
+@pytest.mark.gpu
+def test_hip_fdr_full_size_properties(ctx):
+    """3e6 rows (1e6 precursors x 3 candidates): properties that hold at any size."""
+    n = 3_000_000
+    rng = np.random.default_rng(3)
+    score = rng.random(n).astype(np.float32).astype(np.float64)
+    decoy = rng.random(n) < 0.3 + 0.4 * score
+    pidx = rng.integers(0, n // 3, size=n)
+    order, q = ctx.fdr_q_values(score, decoy, pidx)
+    assert np.array_equal(np.sort(order), np.arange(n))              # a permutation
+    s = score[order]
+    assert np.all(np.diff(s) >= 0) and np.all(np.diff(q) >= 0)        # sorted by score, q-values monotone
+    ties = np.flatnonzero(np.diff(s) == 0)
+    assert np.all(decoy[order][ties] <= decoy[order][ties + 1])      # targets before decoys inside a tie
+    dec = decoy[order].astype(np.float64)
+    with np.errstate(divide="ignore"):
+        fdr_last = np.cumsum(dec)[-1] / np.cumsum(1 - dec)[-1]
+    assert q[-1] == fdr_last
+    keep = ctx.fdr_keep_best(score, pidx)
+    assert keep.sum() == len(np.unique(pidx))                         # one row per group
+    best = np.full(n // 3, np.inf)
+    np.minimum.at(best, pidx, score)
+    assert np.array_equal(score[keep], best[pidx[keep]])              # and it is the group's minimum
+    assert np.array_equal(ctx.fdr_keep_best(score, pidx), keep)      # idempotent / deterministic
