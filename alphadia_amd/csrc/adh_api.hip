@@ -66,6 +66,8 @@ struct HostCands {
 };
 
 // one processing plan = CandRec table + scratch, for a given (top_k_fragments, top_k_isotopes)
+#define ADH_CLASS_GENERIC 10
+#define ADH_N_CLASSES 11
 struct Plan {
     bool ready = false;
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
@@ -74,9 +76,10 @@ struct Plan {
     CandRecIM *d_recs_im = nullptr;
     unsigned char *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
-    // classes 0..2: register kernels for F <= 16 / 24 / 32; class 3: generic LDS kernel
-    // classes 0..5: register kernels, index = (observations - 1) * 3 + cycle class; 6: generic
-    int64_t n_class[7] = {0, 0, 0, 0, 0, 0, 0};
+    // classes 0..6: register kernels for one observation, F <= 8 / 12 / ... / 32 (a kernel per four
+    // cycles: every cycle loop is unrolled to the class size); 7..9: two observations, F <= 16 /
+    // 24 / 32; ADH_CLASS_GENERIC: the LDS kernel
+    int64_t n_class[ADH_N_CLASSES] = {0};
     bool quant_all = false;
     Caps caps_generic;
     Caps caps_all;
@@ -563,7 +566,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
     std::vector<CandRec> recs((size_t)n);
     std::vector<uint8_t> cls((size_t)n, 0);
     const int64_t n_cyc = h->run.n_spectra / L + 2;
-    const int NCLS = 7, GENERIC = 6;
+    const int NCLS = ADH_N_CLASSES, GENERIC = ADH_CLASS_GENERIC;
     std::vector<uint32_t> head[NCLS];
     for (int c = 0; c < NCLS; ++c) head[c].assign((size_t)n_cyc + 1, 0);
     std::atomic<int> too_many{0};
@@ -616,7 +619,7 @@ int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
             // (several observations: only with quant_all, see adh_features_fast.hip)
             const bool fast = fast_cfg && O >= 1 && O <= ADH_FAST_OMAX && (O == 1 || cfg->quant_all) &&
                               F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
-            cls[(size_t)i] = !fast ? GENERIC : (O - 1) * 3 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2));
+            cls[(size_t)i] = !fast ? GENERIC : (O == 1 ? std::max(F - 5, 0) / 4 : 7 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)));
         }
       }
     };
@@ -793,7 +796,7 @@ int build_plan_im(adh_handle *h, const adh_scoring_config_t *cfg) {
         cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
     }
     p.caps_generic = p.caps_all;
-    p.n_class[6] = n;
+    p.n_class[ADH_CLASS_GENERIC] = n;
     p.scratch_bytes = std::max<uint64_t>(off, 32);
     const CandRecIM *d_recs = nullptr;
     UP(h->plan_buf, ordered.data(), n, &d_recs);
@@ -871,7 +874,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
     p.caps_generic.stop_phase = stop_phase;
     const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
-    if (p.n_class[6] > 0 && f_lds > 160 * 1024) {
+    if (p.n_class[ADH_CLASS_GENERIC] > 0 && f_lds > 160 * 1024) {
         char buf[256];
         snprintf(buf, sizeof(buf),
                  "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", f_lds,
@@ -893,11 +896,11 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     HIP_TRY(hipEventRecord(t.e1, st));
     if (stop_phase != 2) {
         int64_t n_fast = 0;
-        for (int c = 0; c < 6; ++c) n_fast += p.n_class[c];
+        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) n_fast += p.n_class[c];
         bool forked = false;
         const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic"
         const bool run_generic = !(only && only[0] == 'f'), run_fast = !(only && only[0] == 'g');
-        if (p.n_class[6] > 0 && run_generic) {
+        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic) {
             // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
             hipStream_t gs = st;
             if (n_fast > 0) {
@@ -906,7 +909,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
                 gs = h->side_stream;
                 forked = true;
             }
-            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[6]), dim3(ADH_WAVE), f_lds,
+            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[ADH_CLASS_GENERIC]), dim3(ADH_WAVE), f_lds,
                                gs, h->run, p.d_recs + n_fast, h->d_iso, n_iso, *cfg, p.d_scratch, *out,
                                p.caps_generic);
             HIP_TRY(hipGetLastError());
@@ -914,7 +917,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
         }
         const unsigned per_block = ADH_WAVE / ADH_GS;
         int64_t first = 0;
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) {
             if (p.n_class[c] > 0 && run_fast) {
                 const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                 const CandRec *recs = p.d_recs + first;
@@ -923,11 +926,15 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, \
                        recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
                 switch (c) {
-                    case 0: ADH_LAUNCH_FAST(16, 1); break;
-                    case 1: ADH_LAUNCH_FAST(24, 1); break;
-                    case 2: ADH_LAUNCH_FAST(32, 1); break;
-                    case 3: ADH_LAUNCH_FAST(16, 2); break;
-                    case 4: ADH_LAUNCH_FAST(24, 2); break;
+                    case 0: ADH_LAUNCH_FAST(8, 1); break;
+                    case 1: ADH_LAUNCH_FAST(12, 1); break;
+                    case 2: ADH_LAUNCH_FAST(16, 1); break;
+                    case 3: ADH_LAUNCH_FAST(20, 1); break;
+                    case 4: ADH_LAUNCH_FAST(24, 1); break;
+                    case 5: ADH_LAUNCH_FAST(28, 1); break;
+                    case 6: ADH_LAUNCH_FAST(32, 1); break;
+                    case 7: ADH_LAUNCH_FAST(16, 2); break;
+                    case 8: ADH_LAUNCH_FAST(24, 2); break;
                     default: ADH_LAUNCH_FAST(32, 2); break;
                 }
 #undef ADH_LAUNCH_FAST

@@ -6,9 +6,10 @@
 //
 //   * four candidates per 64-lane wavefront, 16 lanes each; lane = fragment (K <= 16)
 //   * a lane keeps the XIC row of its fragment in VGPRs, *centred*: register r holds cycle
-//     f = r - 16 + F/2, so the apex sits in register 16 for every F <= 32 and all loops over
+//     f = r - FM/2 + F/2, so the apex sits in register FM/2 for every F <= FM and all loops over
 //     cycles are fully unrolled with constant register indices; cells outside [0, F) hold 0,
-//     which leaves float32 sums unchanged, so most reductions need no predication
+//     which leaves float32 sums unchanged, so most reductions need no predication.  The kernel
+//     is instantiated for FM = 8, 12, ..., 32 (one observation) and 16, 24, 32 (two)
 //   * the three isotope rows use the same registers in an earlier phase
 //   * LDS carries only what crosses lanes (template, weight tables, per-fragment results,
 //     a 16x16 transpose buffer for the per-cycle median): 3.8 KB per candidate
