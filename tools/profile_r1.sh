@@ -16,6 +16,7 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_pmc3 -o r1 -- $CMD > $OUT/prof_pmc3.log 
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/prof_pmc4 -o r1 -- $CMD > $OUT/prof_pmc4.log 2>&1
 python $REPO/tools/rocpd_summary.py $OUT/prof_stats/r1_results.db > $OUT/kernel_stats.csv
 for i in 1 2 3 4; do python $REPO/tools/rocpd_summary.py $OUT/prof_pmc$i/r1_results.db; done > $OUT/pmc.csv
+for d in prof_stats prof_pmc1 prof_pmc2 prof_pmc3 prof_pmc4; do rm -rf $OUT/$d; done  # keep the summaries only (gpurun_out is capped at 64 MiB)
 cd $REPO
 python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-400
