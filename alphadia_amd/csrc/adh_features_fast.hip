@@ -51,21 +51,20 @@ struct __attribute__((aligned(16))) GroupLds {
         } at;
     } u;
     double wt[2][FM];        // exp weights around the template centre of one observation, centred index
-    double mzmean[16], height[16], area[16], merr[16];
+    double merr[16];
     double ohe[16][NO], omz[16][NO];  // [fragment lane][observation]
     double hp[4], omzp[4], qtf[4][NO];
     double red64[12];        // results of the float64 sums
     float tpl[NO][FM], tfp[FM], frt[FM], med[FM];  // centred index
-    float g_mzlib[16], g_mz[16], g_int[16], g_fin[16], obs_int[16], corr[16];
+    float g_int[16], g_fin[16], corr[16];
     float rowsum[16][NO], ftc[16][NO], fw[16][NO];  // [fragment lane][o]
     int fpeak[16][NO];
     float iso_mz[4], iso_int[4], spi[4];
     float oi[NO], tsum[NO], qmask[NO];
     float red32[8];          // results of the float32 sums
     float feat[ADH_NUM_FEATURES + 2];
-    int ord[16], lane_of[16];  // lane_of[kk]: fragment lane of the kk-th present fragment
+    int ord[16];
     int medlo[NO], medhi[NO];
-    uint8_t g_type[16], g_loss[16], g_charge[16], g_number[16], g_pos[16];
 };
 
 // Make a register value opaque to the optimiser (no instruction is emitted): stops LICM from
@@ -221,12 +220,14 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     constexpr int RC = FM / 2;
     constexpr int O = NO;  // every candidate of this launch has NO observations (host plan)
     __shared__ GroupLds<FM, NO> lds[ADH_WAVE / ADH_GS];
-    __shared__ double wtp_s[2][64];
+    __shared__ double wtp_s[2][FM];
     const int lane = threadIdx.x;
-    // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)): the "expected centre"
-    // (S, 1) of precursor_features.py:52-57 does not depend on the candidate
-    wtp_s[0][lane] = wtp_table[lane];
-    wtp_s[1][lane] = wtp_table[64 + lane];
+    // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), f < F <= FM: the "expected
+    // centre" (S, 1) of precursor_features.py:52-57 does not depend on the candidate
+    if (lane < FM) {
+        wtp_s[0][lane] = wtp_table[lane];
+        wtp_s[1][lane] = wtp_table[64 + lane];
+    }
     __syncthreads();
     const int g = lane / ADH_GS, sub = lane % ADH_GS;
     const unsigned gsh = (unsigned)(g * ADH_GS);
@@ -513,14 +514,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         K = 0;
     }
     if (present) {
-        L.g_mzlib[kk] = lrec.mz_library;
-        L.g_mz[kk] = lrec.mz;
         L.g_fin[kk] = lrec.intensity;  // raw intensity, normalised below
-        L.g_type[kk] = lrec.type;
-        L.g_loss[kk] = lrec.loss_type;
-        L.g_charge[kk] = lrec.charge;
-        L.g_number[kk] = lrec.number;
-        L.g_pos[kk] = lrec.position;
     }
     __syncthreads();
     // fragment intensities: apply_mask renormalisation + the second one of fragment_features.py:218
@@ -568,7 +562,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
         }
     }
-    double m2 = 0.0, merr_l = 0.0;
+    double m1 = 0.0, m2 = 0.0, merr_l = 0.0;
     bool hrow = false;
     if (present) {
         // importance-weighted means over observations (fragment_features.py:311-336)
@@ -592,7 +586,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
                 ++nm;
             }
         }
-        double m1 = 0;
         if (nm > 0) {
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
@@ -607,11 +600,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             }
         }
         merr_l = (m1 - (double)lrec.mz) / (double)lrec.mz * 1e6;  // fragment_features.py:387
-        L.mzmean[kk] = m1;
-        L.height[kk] = m2;
         L.merr[kk] = merr_l;
-        L.area[kk] = area;
-        L.obs_int[kk] = obs_int;
         int rk = 0;
         for (int j = 0; j < K; ++j) {
             float ib = L.g_int[j];
@@ -937,10 +926,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             out.fragment_rank[o] = rec.rank;
             out.fragment_mz_library[o] = lrec.mz_library;
             out.fragment_mz[o] = lrec.mz;
-            out.fragment_mz_observed[o] = (float)L.mzmean[kk];
-            out.fragment_height[o] = (float)L.height[kk];
+            out.fragment_mz_observed[o] = (float)m1;
+            out.fragment_height[o] = (float)m2;
             out.fragment_intensity[o] = (float)area;
-            out.fragment_mass_error[o] = (float)L.merr[kk];
+            out.fragment_mass_error[o] = (float)merr_l;
             out.fragment_correlation[o] = corr_l;
             out.fragment_position[o] = lrec.position;
             out.fragment_number[o] = lrec.number;
