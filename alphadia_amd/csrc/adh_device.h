@@ -23,7 +23,9 @@
 
 // m/z bin of the transposed run = float32 bit pattern >> ADH_BIN_SHIFT: exactly monotone,
 // relative width 2^-14 (30.5 .. 61 ppm)
+#ifndef ADH_BIN_SHIFT
 #define ADH_BIN_SHIFT 9
+#endif
 
 struct DevRun {
     // peaks sorted by (block of 2^block_shift cycles, cycle row, m/z bin, cycle, m/z):
