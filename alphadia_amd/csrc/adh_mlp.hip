@@ -46,7 +46,7 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t step, uint32_
 }
 
 struct Lds {
-    float *w, *act, *xh, *mean, *rstd, *y, *g;
+    float *w, *act, *xh, *mean, *rstd, *y, *dl, *g;
 };
 
 __device__ __forceinline__ Lds carve(float *lds, const MlpArch &A) {
@@ -57,7 +57,8 @@ __device__ __forceinline__ Lds carve(float *lds, const MlpArch &A) {
     L.mean = L.xh + ADH_MLP_TR * A.x_stride;
     L.rstd = L.mean + A.dims[0];
     L.y = L.rstd + A.dims[0];
-    L.g = L.y + ADH_MLP_TR;  // per-tile gradient of every parameter (training only)
+    L.dl = L.y + ADH_MLP_TR;             // d loss / d (layer outputs) of the tile, laid out like act (training only)
+    L.g = L.dl + ADH_MLP_TR * A.a_stride;  // per-tile gradient of every parameter (training only)
     return L;
 }
 
@@ -66,13 +67,13 @@ __device__ __forceinline__ void load_params(const MlpArch &A, const Lds &L, cons
     const float4 *src = reinterpret_cast<const float4 *>(img);
     float4 *dst = reinterpret_cast<float4 *>(L.w);
     const int n4 = A.lds_params / 4;
-    for (int base = threadIdx.x; base < n4; base += 8 * ADH_MLP_THREADS) {
-        float4 t[8];  // eight loads in flight per lane before the first LDS write
+    for (int base = threadIdx.x; base < n4; base += 10 * ADH_MLP_THREADS) {
+        float4 t[10];  // all loads of a lane in flight before the first LDS write (one round for 80 KB)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 10; ++u)
             if (base + u * ADH_MLP_THREADS < n4) t[u] = src[base + u * ADH_MLP_THREADS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 10; ++u)
             if (base + u * ADH_MLP_THREADS < n4) dst[base + u * ADH_MLP_THREADS] = t[u];
     }
 }
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
     // Softmax, nn.BCELoss (mean over B * out elements, log clamped at -100) and d loss / d logits
     const int out_dim = A.dims[A.n_linear];
     float *zl = L.act + A.a_off[A.n_linear];
+    float *dzl = L.dl + A.a_off[A.n_linear];
     if (tid < 64) {
         float loss = 0.0f;
         if (tid < rows_here) {
@@ -299,9 +301,9 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
                 g[c] = (p[c] - t) / fmaxf((1.0f - p[c]) * p[c], 1e-12f) * inv_n;
                 dot = fmaf(g[c], p[c], dot);
             }
-            for (int c = 0; c < out_dim; ++c) p[c] = p[c] * (g[c] - dot);
+            for (int c = 0; c < 16; ++c) dzl[tid * S + c] = c < out_dim ? p[c] * (g[c] - dot) : 0.0f;
         } else if (tid < ADH_MLP_TR) {
-            for (int c = 0; c < out_dim; ++c) zl[tid * S + c] = 0.0f;
+            for (int c = 0; c < 16; ++c) dzl[tid * S + c] = 0.0f;
         }
         for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o, 64);
         if (tid == 0) loss_part[tile] = loss;
@@ -310,22 +312,38 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
     for (int l = A.n_linear - 1; l >= 0; --l) {
         const int in = A.dims[l], out = A.dims[l + 1], in_s = A.in_s[l];
         const float *W = L.w + A.w_lds[l];
-        const float *delta = L.act + A.a_off[l + 1];
-        float *ap = L.act + A.a_off[l];
-        // dW[n][k] = sum_r delta[r][n] a[r][k]: A operand = delta^T, B operand = a, 4 MFMAs over the 16 rows
-        const int nb = (out + 15) >> 4, kb = (in + 15) >> 4;
-        for (int blk = wave; blk < nb * kb; blk += ADH_MLP_WAVES) {
-            const int n0 = (blk / kb) * 16, k0 = (blk % kb) * 16;
-            mlp::floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *delta = L.dl + A.a_off[l + 1];  // d loss / d (outputs of layer l)
+        const float *ap = L.act + A.a_off[l];        // inputs of layer l (read only from here on)
+        float *dprev = L.dl + A.a_off[l];
+        const int nb = (out + 15) >> 4, kb = (in + 15) >> 4, np16 = (out + 15) & ~15;
+        // one phase per layer: the first kb blocks are d loss / d inputs, the others the weight gradient
+        for (int blk = wave; blk < kb + nb * kb; blk += ADH_MLP_WAVES) {
+            if (blk < kb) {
+                // d a[r][k] = sum_n delta[r][n] W[n][k], times the ReLU/dropout mask of layer l - 1
+                const int k = blk * 16 + i;
+                const mlp::floatx4 acc = mlp::mfma_chain(delta + i * S + q, 1, W + q * in_s + k, in_s, np16);
 #pragma unroll
-            for (int r0 = 0; r0 < ADH_MLP_TR; r0 += 4)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(delta[(r0 + q) * S + n0 + i], ap[(r0 + q) * S + k0 + i], acc,
-                                                           0, 0, 0);
-            const int k = k0 + i;
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * q + rr;
+                    float v = acc[rr];
+                    if (l > 0) v = ap[r * S + k] > 0.0f ? v * keep_scale : 0.0f;
+                    dprev[r * S + k] = k < in ? v : 0.0f;
+                }
+            } else {
+                // dW[n][k] = sum_r delta[r][n] a[r][k]: A operand = delta^T, B operand = a, 4 MFMAs over the rows
+                const int wb = blk - kb;
+                const int n0 = (wb / kb) * 16, k0 = (wb % kb) * 16;
+                mlp::floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int n = n0 + 4 * q + rr;
-                if (n < out && k < in) L.g[A.w_off[l] + n * in + k] = acc[rr];
+                for (int r0 = 0; r0 < ADH_MLP_TR; r0 += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(delta[(r0 + q) * S + n0 + i], ap[(r0 + q) * S + k0 + i],
+                                                               acc, 0, 0, 0);
+                const int k = k0 + i;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int n = n0 + 4 * q + rr;
+                    if (n < out && k < in) L.g[A.w_off[l] + n * in + k] = acc[rr];
+                }
             }
         }
         for (int j = tid; j < out; j += ADH_MLP_THREADS) {
@@ -335,27 +353,13 @@ __global__ __launch_bounds__(ADH_MLP_THREADS) void adh_mlp_train_kernel(
             L.g[A.b_off[l] + j] = s;
         }
         __syncthreads();
-        // d a[r][k] = sum_n delta[r][n] W[n][k], times the ReLU/dropout mask of layer l - 1; in place
-        const int np16 = (out + 15) & ~15;
-        for (int blk = wave; blk < kb; blk += ADH_MLP_WAVES) {
-            const int k = blk * 16 + i;
-            const mlp::floatx4 acc = mlp::mfma_chain(delta + i * S + q, 1, W + q * in_s + k, in_s, np16);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * q + rr;
-                float v = acc[rr];
-                if (l > 0) v = ap[r * S + k] > 0.0f ? v * keep_scale : 0.0f;
-                ap[r * S + k] = k < in ? v : 0.0f;
-            }
-        }
-        __syncthreads();
     }
     // BatchNorm affine parameters
     for (int c = tid; c < d; c += ADH_MLP_THREADS) {
         float sg = 0.0f, sb = 0.0f;
 #pragma unroll
         for (int r = 0; r < ADH_MLP_TR; ++r) {
-            const float g = L.act[r * S + c];
+            const float g = L.dl[r * S + c];
             sg = fmaf(g, L.xh[r * XS + c], sg);
             sb += g;
         }
@@ -529,7 +533,7 @@ int mlp_layout(const adh_mlp_arch_t *a, MlpArch &A) {
 }
 
 size_t mlp_lds_bytes(const MlpArch &A) {
-    return sizeof(float) * ((size_t)A.lds_params + (size_t)ADH_MLP_TR * A.a_stride +
+    return sizeof(float) * ((size_t)A.lds_params + 2 * (size_t)ADH_MLP_TR * A.a_stride +
                             (size_t)ADH_MLP_TR * A.x_stride + 2 * (size_t)A.dims[0] + ADH_MLP_TR + (size_t)A.n_params);
 }
 
