@@ -130,6 +130,7 @@ class Output(C.Structure):
         ("fragment_charge", _u8p),
         ("fragment_loss_type", _u8p),
         ("stat_matched_peaks", _u32p),
+        ("fragment_lib_slot", C.POINTER(C.c_uint16)),
     ]
 
 
@@ -327,28 +328,33 @@ def output_shapes(n: int, top_k: int):
 
 def alloc_output(n: int, top_k: int, with_stats: bool = False, zero: bool = True):
     """Host OutputPsmDF buffers (output.py:44-70) and the ctypes view of them; ``zero=False`` skips the
-    fill for callers that overwrite every byte (``adh_score_candidates`` copies whole tables back)."""
+    fill for callers that overwrite every byte (``adh_score_candidates`` copies whole tables back).
+    ``fragment_lib_slot`` (1 + position of a slot's fragment in the library slice) rides along."""
     new = np.zeros if zero else np.empty
     arrays = {k: new(shape, dtype=dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
     stats = new(n, dtype=np.uint32) if with_stats else None
+    slots = new((n, top_k), dtype=np.uint16)
     s = Output(
         n,
         top_k,
         *[_ptr(arrays[name], _CT[np.dtype(dt)]) for name, dt, _ in OUTPUT_FIELDS],
         _ptr(stats, C.c_uint32) if stats is not None else None,
+        _ptr(slots, C.c_uint16),
     )
     if stats is not None:
         arrays["stat_matched_peaks"] = stats
+    arrays["fragment_lib_slot"] = slots
     return Marshalled(s, arrays), arrays
 
 
-def output_from_device_pointers(n: int, top_k: int, ptrs: dict, stats_ptr: int = 0) -> Output:
+def output_from_device_pointers(n: int, top_k: int, ptrs: dict, stats_ptr: int = 0, slot_ptr: int = 0) -> Output:
     """Build an ``adh_output_t`` from raw device addresses (ints)."""
     vals = []
     for name, dt, _ in OUTPUT_FIELDS:
         vals.append(C.cast(C.c_void_p(ptrs[name]), C.POINTER(_CT[np.dtype(dt)])))
     st = C.cast(C.c_void_p(stats_ptr), C.POINTER(C.c_uint32)) if stats_ptr else None
-    return Output(n, top_k, *vals, st)
+    sl = C.cast(C.c_void_p(slot_ptr), C.POINTER(C.c_uint16)) if slot_ptr else None
+    return Output(n, top_k, *vals, st, sl)
 
 
 def pack_config(cfg) -> ScoringConfig:

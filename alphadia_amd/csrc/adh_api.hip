@@ -1030,7 +1030,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         {(void **)&out->fragment_charge, (size_t)n * tk},
         {(void **)&out->fragment_loss_type, (size_t)n * tk},
         {(void **)&out->stat_matched_peaks, (size_t)n * 4},
+        {(void **)&out->fragment_lib_slot, (size_t)n * tk * 2},
     };
+    const int n_optional = 2;  // the last two tables may be NULL
     void **dev_slots[] = {
         (void **)&dev.valid, (void **)&dev.precursor_idx, (void **)&dev.rank, (void **)&dev.features,
         (void **)&dev.fragment_precursor_idx, (void **)&dev.fragment_rank,
@@ -1039,13 +1041,13 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         (void **)&dev.fragment_intensity, (void **)&dev.fragment_mass_error,
         (void **)&dev.fragment_correlation, (void **)&dev.fragment_position,
         (void **)&dev.fragment_number, (void **)&dev.fragment_type, (void **)&dev.fragment_charge,
-        (void **)&dev.fragment_loss_type, (void **)&dev.stat_matched_peaks};
+        (void **)&dev.fragment_loss_type, (void **)&dev.stat_matched_peaks, (void **)&dev.fragment_lib_slot};
     const int NF = (int)(sizeof(fields) / sizeof(fields[0]));
     // one device slab for all tables, kept in the handle between calls
     size_t total = 0;
     rc = ADH_OK;
     for (int i = 0; i < NF; ++i) {
-        if (*fields[i].host == nullptr && i != NF - 1) {
+        if (*fields[i].host == nullptr && i < NF - n_optional) {
             rc = fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
             break;
         }

@@ -799,6 +799,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
             out.fragment_type[base + k] = g_type[k];
             out.fragment_charge[base + k] = g_charge[k];
             out.fragment_loss_type[base + k] = g_loss[k];
+            if (out.fragment_lib_slot) {
+                const LibRec pick = reinterpret_cast<const LibRec *>(block + 32)[kmap[k]];
+                out.fragment_lib_slot[base + k] = (uint16_t)(1 + pick.pad0 + 256 * pick.pad1);
+            }
         }
     }
     if (lane == 0) out.valid[row] = 1;

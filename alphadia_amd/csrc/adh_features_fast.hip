@@ -936,6 +936,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             out.fragment_type[o] = lrec.type;
             out.fragment_charge[o] = lrec.charge;
             out.fragment_loss_type[o] = lrec.loss_type;
+            if (out.fragment_lib_slot) out.fragment_lib_slot[o] = (uint16_t)(1 + lrec.pad0 + 256 * lrec.pad1);
         }
         if (sub == 0) out.valid[row] = 1;
     }

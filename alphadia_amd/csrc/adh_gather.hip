@@ -193,7 +193,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
             float mb = l_mz[b];
             slot += (mb < ma) || (mb == ma && rb < ra);  // stable argsort(mz) of the top-k list
         }
-        sel[slot] = lib[frag_start + a];
+        LibRec pick = lib[frag_start + a];
+        pick.pad0 = (uint8_t)(a & 0xFF);  // position inside the library slice (adh_output_t.fragment_lib_slot)
+        pick.pad1 = (uint8_t)(a >> 8);
+        sel[slot] = pick;
         // mass_range (jitclasses/utils.py:15-20): float32 throughout
         float t = cfg.fragment_mz_tolerance * ma;
         float q = t / 1000000.0f;

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             float mb = l_mz[b];
             slot += (mb < ma) || (mb == ma && rb < ra);
         }
-        sel[slot] = lib[frag_start + a];
+        LibRec pick = lib[frag_start + a];
+        pick.pad0 = (uint8_t)(a & 0xFF);  // position inside the library slice (adh_output_t.fragment_lib_slot)
+        pick.pad1 = (uint8_t)(a >> 8);
+        sel[slot] = pick;
         w_mz[slot] = ma;
     }
     if (lane < I) {

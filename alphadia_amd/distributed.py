@@ -40,9 +40,14 @@ def slice_soa(soa: dict, a: int, b: int) -> dict:
             for k, v in soa.items()}
 
 
-# columns every rank can rebuild from the candidate table it already holds: they stay out of the
-# all-gather (65 of 646 bytes per candidate at top_k = 12)
-LOCAL_COLUMNS = ("precursor_idx", "rank", "fragment_precursor_idx", "fragment_rank", "stat_matched_peaks")
+# Columns every rank can rebuild from what it already holds stay out of the all-gather: candidate ids
+# (from the candidate table) and the library columns of the fragment tables (from the staged library
+# and ``fragment_lib_slot``, 2 bytes per slot instead of 13): 449 of 646 bytes per candidate travel
+# at top_k = 12.
+LIBRARY_COLUMNS = ("fragment_mz_library", "fragment_mz", "fragment_position", "fragment_number", "fragment_type",
+                   "fragment_charge", "fragment_loss_type")
+LOCAL_COLUMNS = ("precursor_idx", "rank", "fragment_precursor_idx", "fragment_rank", *LIBRARY_COLUMNS,
+                 "stat_matched_peaks")
 
 
 def packed_layout(n_rows: int, top_k: int, with_stats: bool = True):
@@ -51,6 +56,7 @@ def packed_layout(n_rows: int, top_k: int, with_stats: bool = True):
     The computed tables come first (the "wire" prefix that is all-gathered); ``LOCAL_COLUMNS``
     follow.  ``wire_bytes`` gives the length of the prefix."""
     shapes = dict(_abi.output_shapes(n_rows, top_k))
+    shapes["fragment_lib_slot"] = ((n_rows, top_k), np.uint16)
     if with_stats:
         shapes["stat_matched_peaks"] = ((n_rows,), np.uint32)
     order = [k for k in shapes if k not in LOCAL_COLUMNS] + [k for k in shapes if k in LOCAL_COLUMNS]
@@ -70,10 +76,13 @@ def wire_bytes(offsets: dict) -> int:
 
 
 def rebuild_local_columns(tables: dict, precursor_idx: np.ndarray, rank: np.ndarray, flags: np.ndarray | None = None,
-                          matched_peaks: np.ndarray | None = None) -> dict:
+                          matched_peaks: np.ndarray | None = None, frag_start: np.ndarray | None = None,
+                          fragment_cols: tuple | None = None) -> dict:
     """Complete gathered wire tables with the columns that did not travel: candidate ids from the
-    candidate table (zero for skipped score groups, score_group.py:50-64), and their copies in
-    the filled rows of the fragment tables (candidate.py:403-481)."""
+    candidate table (zero for skipped score groups, score_group.py:50-64), their copies in the
+    filled rows of the fragment tables (candidate.py:403-481), and the library columns of the
+    filled slots from the library (``fragment_cols`` = ``scoring.fragment_columns``, ``frag_start``
+    = first library row of every candidate)."""
     n = tables["valid"].shape[0]
     pi = np.asarray(precursor_idx, dtype=np.uint32)[:n].copy()
     rk = np.asarray(rank, dtype=np.uint8)[:n].copy()
@@ -81,12 +90,27 @@ def rebuild_local_columns(tables: dict, precursor_idx: np.ndarray, rank: np.ndar
         skip = (np.asarray(flags)[:n] & _abi.FLAG_SKIP) != 0
         pi[skip] = 0
         rk[skip] = 0
-    filled = tables["fragment_type"] != 0  # ion types are ASCII codes, never 0
+    slot = tables["fragment_lib_slot"]
+    filled = slot != 0
     out = dict(tables)
     out["precursor_idx"] = pi
     out["rank"] = rk
     out["fragment_precursor_idx"] = np.where(filled, pi[:, None], 0).astype(np.uint32)
     out["fragment_rank"] = np.where(filled, rk[:, None], 0).astype(np.uint8)
+    if any(c not in tables for c in LIBRARY_COLUMNS):
+        if frag_start is None or fragment_cols is None:
+            raise ValueError("the library columns did not travel: pass frag_start and fragment_cols")
+        mz_library, mz, _, type_, loss_type, charge, number, position, _ = fragment_cols
+        src = dict(fragment_mz_library=(mz_library, np.float32), fragment_mz=(mz, np.float32),
+                   fragment_position=(position, np.uint8), fragment_number=(number, np.uint8),
+                   fragment_type=(type_, np.uint8), fragment_charge=(charge, np.uint8),
+                   fragment_loss_type=(loss_type, np.uint8))
+        lib_row = np.asarray(frag_start, dtype=np.int64)[:n, None] + slot.astype(np.int64) - 1
+        lib_row = np.where(filled, lib_row, 0)
+        for name, (col, dt) in src.items():
+            col = np.asarray(col)
+            vals = col[lib_row] if len(col) else np.zeros(lib_row.shape, dt)
+            out[name] = np.where(filled, vals, 0).astype(dt)
     if matched_peaks is not None:
         out["stat_matched_peaks"] = np.asarray(matched_peaks, dtype=np.uint32)[:n]
     return out
@@ -113,8 +137,9 @@ class DeviceTables:
         base = self.buffer.data_ptr()
         ptrs = {k: base + off for k, (off, _, _) in self.offsets.items()}
         stats = ptrs.pop("stat_matched_peaks", 0)
+        slots = ptrs.pop("fragment_lib_slot", 0)
         return _abi.output_from_device_pointers(
-            self.n_rows if n is None else int(n), self.top_k, ptrs, stats_ptr=stats
+            self.n_rows if n is None else int(n), self.top_k, ptrs, stats_ptr=stats, slot_ptr=slots
         )
 
     def load_host(self, arrays: dict) -> None:

@@ -165,6 +165,11 @@ typedef struct adh_output {
     uint8_t *fragment_charge;
     uint8_t *fragment_loss_type;
     uint32_t *stat_matched_peaks;  /* optional [n]: peaks accumulated by get_dense, or NULL */
+    /* optional [n, top_k], or NULL: 1 + position of the slot's fragment inside the candidate's library
+     * slice [frag_start_idx, frag_stop_idx), 0 for an empty slot.  With it the library columns of the
+     * fragment tables (mz_library, mz, position, number, type, charge, loss_type) can be rebuilt from
+     * the staged library, so they need not travel in the all-gather (alphadia_amd/distributed.py). */
+    uint16_t *fragment_lib_slot;
 } adh_output_t;
 
 typedef struct adh_handle adh_handle_t;

@@ -504,6 +504,7 @@ inline double logistic(double x, double mu, double sigma) {
 struct Frags {
     std::vector<float> mz_library, mz, intensity;
     std::vector<uint8_t> type, loss_type, charge, number, position, cardinality;
+    std::vector<uint16_t> slot;  /* 1 + position inside the candidate's library slice */
     size_t size() const { return mz.size(); }
     void take(const std::vector<int64_t> &idx) {
         auto g = [&](auto &v) {
@@ -512,7 +513,7 @@ struct Frags {
             v.swap(t);
         };
         g(mz_library); g(mz); g(intensity); g(type); g(loss_type);
-        g(charge); g(number); g(position); g(cardinality);
+        g(charge); g(number); g(position); g(cardinality); g(slot);
     }
 };
 
@@ -552,6 +553,7 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
         fr.number.push_back(lib.number[j]);
         fr.position.push_back(lib.position[j]);
         fr.cardinality.push_back(lib.cardinality[j]);
+        fr.slot.push_back((uint16_t)(1 + j - c.frag_start));
     }
     {
         std::vector<int64_t> ord = argsort(fr.intensity);
@@ -1073,6 +1075,7 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
             out.fragment_type[base + k] = fr.type[k];
             out.fragment_charge[base + k] = fr.charge[k];
             out.fragment_loss_type[base + k] = fr.loss_type[k];
+            if (out.fragment_lib_slot) out.fragment_lib_slot[base + k] = fr.slot[k];
         }
     }
 

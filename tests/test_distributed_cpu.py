@@ -67,8 +67,12 @@ def _worker(rank, world, port, tmpdir, golden="handler_default"):
     gathered = all_gather_tables(tables.wire, world)
     rows = [shard_bounds(soa_all["score_group_idx"], r, world) for r in range(world)]
     merged = merge_gathered([tables.to_host(gathered[r]) for r in range(world)], [e - s for s, e in rows])
-    assert "precursor_idx" not in merged and "fragment_rank" not in merged
-    merged = rebuild_local_columns(merged, soa_all["precursor_idx"], soa_all["rank"], soa_all["flags"])
+    assert "precursor_idx" not in merged and "fragment_rank" not in merged and "fragment_mz" not in merged
+    from alphadia_amd.scoring import fragment_columns
+
+    merged = rebuild_local_columns(merged, soa_all["precursor_idx"], soa_all["rank"], soa_all["flags"],
+                                   frag_start=soa_all["frag_start_idx"],
+                                   fragment_cols=fragment_columns(g.library.fragment_df, "mz_library"))
     np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **merged)
     dist.destroy_process_group()
 

@@ -46,6 +46,8 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
         assert np.array_equal(got[name][v], exp[name][v]), name
     for name in ("fragment_mz_library", "fragment_mz"):
         assert np.array_equal(got[name][v], exp[name][v]), name
+    if "fragment_lib_slot" in got and "fragment_lib_slot" in exp:  # (the reference goldens have no such column)
+        assert np.array_equal(got["fragment_lib_slot"][v], exp["fragment_lib_slot"][v]), "fragment_lib_slot"
     gf, ef = got["features"][v], exp["features"][v]
     assert np.array_equal(np.isnan(gf), np.isnan(ef)), "NaN pattern differs"
     for f in EXACT_FEATURES:
@@ -76,6 +78,23 @@ def test_hip_matches_oracle_on_golden_inputs(ctx, oracle_lib, name):
     got, soa = hip_score(ctx, g, g.config)
     exp, _ = H.oracle_score(oracle_lib, g, g.config, soa=soa)
     compare(got, exp, PPM_ABS_TOL_ORACLE)
+
+
+@pytest.mark.parametrize("name", ["handler_default", "topk6", "multiplex", "edges"])
+def test_library_columns_rebuilt_from_slots(ctx, name):
+    """The library columns of the fragment tables stay out of the all-gather: fragment_lib_slot and
+    the staged library give them back bit for bit (all three feature kernels write the slot)."""
+    from alphadia_amd.distributed import LIBRARY_COLUMNS, rebuild_local_columns
+
+    g = H.load_scoring_golden(name)
+    got, soa = hip_score(ctx, g, g.config)
+    wire = {k: v for k, v in got.items() if k not in LIBRARY_COLUMNS}
+    cols = fragment_columns(g.library.fragment_df, "mz_library")
+    back = rebuild_local_columns(wire, soa["precursor_idx"], soa["rank"], soa["flags"],
+                                 frag_start=soa["frag_start_idx"], fragment_cols=cols)
+    assert (got["fragment_lib_slot"] != 0).sum() == (got["fragment_type"] != 0).sum() > 0
+    for k in LIBRARY_COLUMNS + ("precursor_idx", "rank", "fragment_precursor_idx", "fragment_rank"):
+        assert np.array_equal(back[k], got[k]), k
 
 
 @pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges"])

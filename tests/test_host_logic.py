@@ -181,7 +181,7 @@ def test_abi_struct_sizes():
     import ctypes as C
 
     assert C.sizeof(_abi.ScoringConfig) == 44
-    assert C.sizeof(_abi.Output) == 8 + 8 + 19 * 8  # n, top_k(+pad), 19 pointers
+    assert C.sizeof(_abi.Output) == 8 + 8 + 20 * 8  # n, top_k(+pad), 20 pointers
     assert C.sizeof(_abi.Candidates) == 8 + 14 * 8 + 8
     assert C.sizeof(_abi.AlphaRaw) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
