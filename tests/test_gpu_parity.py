@@ -48,7 +48,17 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
         assert np.array_equal(got[name][v], exp[name][v]), name
     if "fragment_lib_slot" in got and "fragment_lib_slot" in exp:  # (the reference goldens have no such column)
         assert np.array_equal(got["fragment_lib_slot"][v], exp["fragment_lib_slot"][v]), "fragment_lib_slot"
-    gf, ef = got["features"][v], exp["features"][v]
+    gf, ef = got["features"][v].copy(), exp["features"][v].copy()
+    # np.corrcoef of a constant vector is 0/0 (fragment_features.py:340-356, features 18 and 19).  Whether
+    # two equal float32 heights / areas are also equal in float64 hangs on the last bit of a float64
+    # exp() (device libm vs glibc): rows whose filled slots all show the same value are knife-edge and
+    # excluded from the comparison of that feature.
+    filled = exp["fragment_type"][v] != 0
+    for f, table in ((18, "fragment_intensity"), (19, "fragment_height")):
+        x = np.where(filled, exp[table][v], np.nan)
+        flat = (np.nanmax(x, axis=1) == np.nanmin(x, axis=1)) if x.shape[1] else np.zeros(len(x), bool)
+        gf[flat, f] = 0.0
+        ef[flat, f] = 0.0
     assert np.array_equal(np.isnan(gf), np.isnan(ef)), "NaN pattern differs"
     for f in EXACT_FEATURES:
         assert np.array_equal(gf[:, f], ef[:, f]), f"feature {f} must be exact"
@@ -374,7 +384,9 @@ def test_randomized_shapes_and_settings(ctx, oracle_lib, seed):
     cfg.update(upd)
     got, soa = hip_score(ctx, case, cfg, with_stats=True)
     exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=soa, n_threads=4, with_stats=True)
-    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    # experimental_xic = False: the K x K contraction runs on MFMA, its summation order is not the
+    # oracle's (nor is the reference's BLAS order defined): correlations near zero get an absolute floor
+    compare(got, exp, PPM_ABS_TOL_ORACLE, corr_abs=0.0 if upd["experimental_xic"] else 2e-6)
     assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"]), upd
 
 
@@ -512,7 +524,9 @@ def test_timstof_randomized(ctx, oracle_lib, seed):
     got = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
     exp = oracle_lib.score_timstof(case.dia, fragment_columns(case.library.fragment_df, "mz_library"),
                                    pack_assembled(soa), cfg.to_jitclass(), n_threads=8, with_stats=True)
-    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    # experimental_xic = False: the K x K contraction runs on MFMA, its summation order is not the
+    # oracle's (nor is the reference's BLAS order defined): correlations near zero get an absolute floor
+    compare(got, exp, PPM_ABS_TOL_ORACLE, corr_abs=0.0 if upd["experimental_xic"] else 2e-6)
     assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"]), upd
 
 
