@@ -9,6 +9,7 @@ the oracle / HIP kernel has neither, so the comparison with the golden is:
 every produced row exists in the golden with identical boxes (a few near-tie rank swaps
 allowed), scores within 5e-3 relative, and the golden rows that are not reproduced are few and
 never a precursor's best candidate.  HIP vs oracle is exact."""
+import os
 import types
 
 import numpy as np
@@ -197,7 +198,7 @@ def test_hip_selection_at_bench_density(ctx, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(6)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT", "6")))))
 def test_hip_selection_randomized(ctx, oracle_lib, seed):
     """Differential test: random run geometry and selection settings, HIP == oracle."""
     from alphadia_amd import synthetic as syn
@@ -302,7 +303,7 @@ def test_hip_timstof_selection_matches_oracle_and_golden(ctx, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(5)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT_IM", "5")))))
 def test_hip_timstof_selection_randomized(ctx, oracle_lib, seed):
     """Differential test on ion-mobility runs: random geometry and settings, HIP == oracle."""
     from alphadia_amd import synthetic as syn
