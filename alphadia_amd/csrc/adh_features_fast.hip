@@ -253,6 +253,15 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j)
         if (sub + 16 * j < ADH_NUM_FEATURES + 2) L.feat[sub + 16 * j] = 0.0f;
+    // location features (location_features.py:8-33) right away: their four table look-ups would
+    // otherwise sit, exposed, in the middle of the single-lane feature assembly
+    float loc = 0.0f;
+    if (alive && sub < 4) {
+        loc = sub == 0   ? run.mobility[rec.scan_start] - run.mobility[rec.scan_stop - 1]
+              : sub == 1 ? rt_width
+              : sub == 2 ? run.rt[rec.frame_center]
+                         : run.mobility[rec.scan_center];
+    }
 
     float A[FM], B[FM];
 
@@ -611,9 +620,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     __syncthreads();
     if (stop_phase == 5) return;
 
+    if (alive && sub < 4) L.feat[sub] = loc;
     if (alive && sub == 0) {
         Assemble asmv;
-        asmv.run = &run;
+        asmv.run = nullptr;  // features 0-3 are in place
         asmv.rec = &rec;
         asmv.featv = L.feat;
         asmv.iso_int = L.iso_int; asmv.iso_mz = L.iso_mz; asmv.spi = L.spi; asmv.oi = L.oi;
