@@ -14,8 +14,9 @@ from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel  # 
 
 n_prec = int(os.environ.get("N_PREC", 20000))
 case = syn.make_timstof_case(
-    n_precursors=n_prec, n_cycles=300, config_id=4, per_precursor=1, n_ms2_frames=8, windows_per_frame=3,
-    scan_max_index=256, n_tof=200000, events_per_push=25.0, mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
+    n_precursors=n_prec, n_cycles=int(os.environ.get("N_CYCLES", 300)), config_id=4, per_precursor=1, n_ms2_frames=8,
+    windows_per_frame=3, scan_max_index=int(os.environ.get("SCAN_MAX", 256)), n_tof=int(os.environ.get("N_TOF", 200000)),
+    events_per_push=float(os.environ.get("EVENTS_PER_PUSH", 25.0)), mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
     frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0, planted_fraction=0.3,
 )
 case.dia.has_mobility = True
@@ -46,7 +47,7 @@ wall = time.perf_counter() - t0
 k_ms = ctx.select_time_ms()
 found = got["score"] > 0
 res = {
-    "workload": f"timsTOF-style run ({case.dia.push_indices.size/1e6:.1f}M events, 256 scans, 300 cycles), {n_prec} "
+    "workload": f"timsTOF-style run ({case.dia.push_indices.size/1e6:.1f}M events, {int(case.dia.scan_max_index)} scans, {int(os.environ.get('N_CYCLES', 300))} cycles), {n_prec} "
                 f"precursors, rt tolerance {cfg.rt_tolerance} s, mobility tolerance {cfg.mobility_tolerance}, kernel "
                 f"{kern.shape[0]}x{kern.shape[1]}",
     "candidates_found": int(found.sum()),

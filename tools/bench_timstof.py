@@ -20,9 +20,11 @@ from oracle import oracle  # noqa: E402
 
 n_prec = int(os.environ.get("N_PREC", 20000))
 t0 = time.time()
+# BASELINE config 4 at full scale: N_PREC=200000 N_CYCLES=2000 SCAN_MAX=918 N_TOF=400000 EVENTS_PER_PUSH=30
 case = syn.make_timstof_case(
-    n_precursors=n_prec, n_cycles=300, config_id=4, per_precursor=3, n_ms2_frames=8,
-    windows_per_frame=3, scan_max_index=256, n_tof=200000, events_per_push=25.0, mz_lo=400.0,
+    n_precursors=n_prec, n_cycles=int(os.environ.get("N_CYCLES", 300)), config_id=4, per_precursor=3, n_ms2_frames=8,
+    windows_per_frame=3, scan_max_index=int(os.environ.get("SCAN_MAX", 256)), n_tof=int(os.environ.get("N_TOF", 200000)),
+    events_per_push=float(os.environ.get("EVENTS_PER_PUSH", 25.0)), mz_lo=400.0,
     mz_hi=1000.0, frag_mz_lo=200.0, frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0,
     planted_fraction=0.02,
 )
@@ -70,8 +72,9 @@ same = bool(np.array_equal(exp["valid"], host["valid"][:sample])
 F = (soa["frame_stop"] - soa["frame_start"]) // case.dia.cycle_len
 S = soa["scan_stop"] - soa["scan_start"]
 print(json.dumps({
-    "workload": f"timsTOF-style synthetic run: {case.dia.push_indices.size/1e6:.1f}M events, 256 scans, "
-                f"9 frames/cycle, 300 cycles; {n_prec} precursors x 3 candidates, "
+    "workload": f"timsTOF-style synthetic run: {case.dia.push_indices.size/1e6:.1f}M events, "
+                f"{int(case.dia.scan_max_index)} scans, {int(case.dia.cycle.shape[1])} frames/cycle, "
+                f"{int(os.environ.get('N_CYCLES', 300))} cycles; {n_prec} precursors x 3 candidates, "
                 f"S in [{int(S.min())},{int(S.max())}], F in [{int(F.min())},{int(F.max())}]",
     "candidates": n, "precursors_per_s": n_prec / dt, "candidates_per_s": n / dt, "ms_per_step": dt * 1e3,
     "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms, "valid_fraction": float(host["valid"].mean()),
