@@ -1122,7 +1122,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
     const double *cyc = h->h_cycle.data();
     const int64_t cmax = (T.n_frames - 1) / L;  // precursor_cycle_max_index (bruker_jit.py:131)
     std::vector<selim::PrecRec> recs((size_t)n);
-    int32_t cap_cells = 1;
+    int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1;  // LDS capacities of the score kernel (adh_select_im.hip)
     auto rev_upper = [&](float v) {  // searchsorted(mobility_values[::-1], v, "right")
         int64_t a = 0, b = SM;
         while (a < b) {
@@ -1187,9 +1187,19 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
             ok = any_f && any_p;
         }
         r.ok = ok ? 1 : 0;
-        if (ok) cap_cells = std::max<int32_t>(cap_cells, (int32_t)(S * F));
+        if (ok) {
+            cap_cells = std::max<int32_t>(cap_cells, (int32_t)(S * F));
+            cap_tp = std::max<int32_t>(cap_tp, (int32_t)(S * (F + k1)));
+            cap_mp = std::max<int32_t>(cap_mp, (int32_t)((S + k0) * F));
+            cap_s = std::max<int32_t>(cap_s, (int32_t)S);
+            cap_f = std::max<int32_t>(cap_f, (int32_t)F);
+        }
     }
-    const size_t lds = (size_t)cap_cells * 4 * 4 + (size_t)(k0 + k1) * 8 + (size_t)cap_cells + 64;
+    cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
+    cap_tp = (cap_tp + 1) & ~1;
+    cap_mp = (cap_mp + 1) & ~1;
+    const size_t lds = ((size_t)cap_tp + (size_t)cap_mp + (size_t)cap_cells) * 4 + (size_t)(k0 + k1 + cap_s + cap_f) * 8 +
+                       (size_t)cap_cells + 64;
     if (lds > 150 * 1024) {
         char buf[200];
         snprintf(buf, sizeof(buf), "selection tile of %d cells (scans x cycles) needs %zu bytes of LDS: exceeds 150 KiB",
@@ -1266,7 +1276,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
                                    h->d_lib, d_recs + first, cnt, *cfg, (int32_t)n_iso, d_scratch);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
-                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells,
+                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_tp, cap_mp, cap_s, cap_f,
                                    d_scratch, dt);
                 e = hipGetLastError();
             }

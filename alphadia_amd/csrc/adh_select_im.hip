@@ -6,8 +6,8 @@
 // selection/utils.py:80-115).  Two kernels per batch of precursors:
 //
 //   adh_select_gather_im_kernel   one wavefront per precursor, little LDS, many resident waves:
-//       isotope / fragment windows, then one lane per (window, cycle) walks the TOF bins of the
-//       window and adds the detector events of its cycle that fall into the scan range and whose
+//       isotope / fragment windows, then one lane per window walks the TOF bins of the window
+//       and adds the detector events of the tile's cycles that fall into the scan range and whose
 //       quadrupole window overlaps the precursor - TimsTOFTransposeJIT.get_dense_intensity
 //       (alphadia/search/jitclasses/bruker_jit.py:506-645) - into a float32 tile in HBM scratch.
 //       A cell is touched by exactly one lane in (TOF index, push) order, so its running float32
@@ -110,15 +110,17 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     }
     __syncthreads();
     const double q_lo = (double)s_mz[K], q_hi = (double)s_mz[K + n_iso - 1];
-    // ---- (window, cycle) tasks
-    for (int t = lane; t < W * F; t += ADH_WAVE) {
-        const int w = t / F, f = t - w * F;
+    // ---- one lane per window: per TOF bin ONE binary search for the first push of the tile's first
+    // cycle, then the bin's events of all F cycles in storage order (they are contiguous: pushes
+    // ascend with the frame).  A lane per (window, cycle) would repeat the search F times - 7e9
+    // dependent HBM probes for 200 000 precursors on the full-size run.  A cell is still touched by
+    // exactly one lane in (TOF index, push) order, so its running float32 sum is the reference's.
+    const uint32_t push_lo = (uint32_t)(r.cycle_start * L + z) * (uint32_t)SM;
+    const uint32_t push_hi = (uint32_t)((r.cycle_start + F) * L + z) * (uint32_t)SM;
+    for (int w = lane; w < W; w += ADH_WAVE) {
         const bool prec = w >= K;
         const double ql = prec ? -1.0 : q_lo, qh = prec ? -1.0 : q_hi;
-        const int frame_lo = (r.cycle_start + f) * L + z;
-        const uint32_t push_lo = (uint32_t)frame_lo * (uint32_t)SM;
-        const uint32_t push_hi = (uint32_t)(frame_lo + L) * (uint32_t)SM;
-        float *cells = tiles + (size_t)w * S * F + f;
+        float *cells = tiles + (size_t)w * S * F;
         for (int tof = s_tlo[w]; tof < s_thi[w]; ++tof) {
             const int64_t b = run.tof_indptr[tof + 1];
             int64_t lo = run.tof_indptr[tof], hi = b;
@@ -131,9 +133,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
                 if (p >= push_hi) break;
                 const int frame = (int)(p / (uint32_t)SM), scan = (int)(p % (uint32_t)SM);
                 if (scan < r.scan_start || scan >= r.scan_start + S) continue;
-                const int crow = (frame - frame_lo) * SM + scan;
+                const int fr = frame - z;
+                const int cyc = fr / L;
+                const int crow = (fr - cyc * L) * SM + scan;
                 if (!(ql <= run.cycle[2 * crow + 1] && qh >= run.cycle[2 * crow])) continue;
-                float *c = cells + (size_t)(scan - r.scan_start) * F;
+                float *c = cells + (size_t)(scan - r.scan_start) * F + (cyc - r.cycle_start);
                 *c = *c + (float)run.inten[e];  // bruker_jit.py:575-580: float32 running sum
             }
         }
@@ -143,16 +147,19 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
 __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kernel(
     DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
     adh_selection_config_t cfg, const double *__restrict__ ku_g, const double *__restrict__ kv_g, int32_t k0,
-    int32_t k1, int32_t cap_cells, const unsigned char *__restrict__ scratch, DevCandTable out) {
+    int32_t k1, int32_t cap_cells, int32_t cap_tp, int32_t cap_mp, int32_t cap_s, int32_t cap_f,
+    unsigned char *__restrict__ scratch, DevCandTable out) {
     using namespace selim;
     extern __shared__ __align__(16) unsigned char smem[];
+    // tile padded along the cycles / pass-1 result padded along the scans (circular copies in the
+    // pads, so the convolution loops carry no wrap-around logic), then the two log-sum tiles
     float *tile = reinterpret_cast<float *>(smem);
-    float *tmp = tile + cap_cells;
-    float *lf = tmp + cap_cells;
-    float *lp = lf + cap_cells;
-    double *ku = reinterpret_cast<double *>(lp + cap_cells);
+    float *tmp = tile + cap_tp;
+    float *ls = tmp + cap_mp;  // log-sum tile: fragments first (parked in HBM when done), then isotopes
+    double *ku = reinterpret_cast<double *>(ls + cap_cells);
     double *kv = ku + k0;
-    unsigned char *flag = reinterpret_cast<unsigned char *>(kv + k1);
+    double *mob = kv + k1, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
+    unsigned char *flag = reinterpret_cast<unsigned char *>(cyc + cap_f);
     __shared__ double red_v[SCORE_THREADS];
     __shared__ int red_i[SCORE_THREADS];
     __shared__ int pk_idx[MAX_CAND];
@@ -166,57 +173,99 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
     const int K = (int)header[0], W = (int)header[1];
     if (!r.ok || K == 0) return;
     const float *tiles = reinterpret_cast<const float *>(scratch + r.scratch_off + 32);
+    float *park = reinterpret_cast<float *>(scratch + r.scratch_off + 32);  // tile 0, free once smoothed
     const int S = r.n_scans, F = r.n_cycles, SF = S * F;
     for (int c = tid; c < k0; c += SCORE_THREADS) ku[c] = ku_g[c];
     for (int c = tid; c < k1; c += SCORE_THREADS) kv[c] = kv_g[c];
     for (int c = tid; c < SF; c += SCORE_THREADS) {
-        lf[c] = 0.0f;
-        lp[c] = 0.0f;
+        ls[c] = 0.0f;
     }
     __syncthreads();
+    // circular convolution, separable: out(s, f) = sum_a ku[a] * (sum_b kv[b] * x[(s + k0/2 - a) mod S][(f + k1/2 - b) mod F]),
+    // float64 accumulation in tap order, one rounding to float32 per pass
+    const int h0 = k0 / 2, h1 = k1 / 2;
+    const int padl = k1 - h1 - 1, FP = F + k1;   // padded row: column j holds cycle (j - padl) mod F
+    const int padt = k0 - h0 - 1;                // padded pass-1 tile: row j holds scan (j - padt) mod S
+    const bool fast = k0 == 30 && k1 == 30;      // the default kernel: taps in registers, loops unrolled
     for (int w = 0; w < W; ++w) {
-        for (int c = tid; c < SF; c += SCORE_THREADS) tile[c] = tiles[(size_t)w * SF + c];
+        for (int c = tid; c < S * FP; c += SCORE_THREADS) {
+            const int sc = c / FP, j = c - sc * FP;
+            int src = j - padl;  // one wrap suffices: F >= k1 (_is_valid)
+            src += (src < 0) ? F : 0;
+            src -= (src >= F) ? F : 0;
+            tile[c] = tiles[(size_t)w * SF + sc * F + src];
+        }
         __syncthreads();
-        // pass 1: along the cycles, kernel centred at column k1 / 2
-        for (int c = tid; c < SF; c += SCORE_THREADS) {
-            const int s = c / F, f = c - s * F;
-            double acc = 0.0;
-            const float *trow = tile + s * F;
-            for (int b = 0; b < k1; ++b) {
-                int src = f + k1 / 2 - b;  // one wrap suffices: F >= k1 (_is_valid)
-                src += (src < 0) ? F : 0;
-                src -= (src >= F) ? F : 0;
-                acc += kv[b] * (double)trow[src];
+        // pass 1: along the cycles, kernel centred at column k1 / 2 (default kernel: taps in registers,
+        // loop unrolled; four outputs per thread sharing one converted window measured no faster)
+        {
+            double kr[30];
+            if (fast) {
+#pragma unroll
+                for (int b = 0; b < 30; ++b) kr[b] = kv[b];
             }
-            tmp[c] = (float)acc;
+            for (int c = tid; c < SF; c += SCORE_THREADS) {
+                const int sc = c / F, f = c - sc * F;
+                const float *rp = tile + sc * FP + padl + f + h1;  // rp[-b] = x[sc][(f + h1 - b) mod F]
+                double acc = 0.0;
+                if (fast) {
+#pragma unroll
+                    for (int b = 0; b < 30; ++b) acc += kr[b] * (double)rp[-b];
+                } else {
+                    for (int b = 0; b < k1; ++b) acc += kv[b] * (double)rp[-b];
+                }
+                const float v = (float)acc;
+                tmp[(padt + sc) * F + f] = v;
+                if (sc < h0) tmp[(padt + S + sc) * F + f] = v;            // copy below the last scan
+                if (sc >= S - padt) tmp[(sc - (S - padt)) * F + f] = v;  // copy above the first (S >= k0, _is_valid)
+            }
         }
         __syncthreads();
         // pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group
-        float *lsum = w < K ? lf : lp;
-        for (int c = tid; c < SF; c += SCORE_THREADS) {
-            const int s = c / F, f = c - s * F;
-            double acc = 0.0;
-            for (int a = 0; a < k0; ++a) {
-                int src = s + k0 / 2 - a;  // one wrap suffices: S >= k0 (_is_valid)
-                src += (src < 0) ? S : 0;
-                src -= (src >= S) ? S : 0;
-                acc += ku[a] * (double)tmp[src * F + f];
+        {
+            float *lsum = ls;
+            double kr[30];
+            if (fast) {
+#pragma unroll
+                for (int a = 0; a < 30; ++a) kr[a] = ku[a];
             }
-            const float sm = (float)acc;
-            lsum[c] += (float)log((double)(sm + 1.0f));  // _build_features (selection.py:206-226)
+            for (int c = tid; c < SF; c += SCORE_THREADS) {
+                const int sc = c / F, f = c - sc * F;
+                const float *cp = tmp + (padt + sc + h0) * F + f;  // cp[-a * F] = pass1[(sc + h0 - a) mod S][f]
+                double acc = 0.0;
+                if (fast) {
+#pragma unroll
+                    for (int a = 0; a < 30; ++a) acc += kr[a] * (double)cp[-a * F];
+                } else {
+                    for (int a = 0; a < k0; ++a) acc += ku[a] * (double)cp[-a * F];
+                }
+                const float sm = (float)acc;
+                lsum[c] += (float)log((double)(sm + 1.0f));  // _build_features (selection.py:206-226)
+            }
+            if (w == K - 1) {
+                // fragment sum complete: park it in the (consumed) first tile of the scratch block, the
+                // LDS array starts over for the isotopes (every thread owns the same cells in both loops)
+                for (int c = tid; c < SF; c += SCORE_THREADS) {
+                    park[c] = ls[c];
+                    ls[c] = 0.0f;
+                }
+            }
         }
         __syncthreads();
     }
+    // feature = fragment sum + isotope sum (float32), in place
+    for (int c = tid; c < SF; c += SCORE_THREADS) ls[c] = park[c] + ls[c];
+    __syncthreads();
     // ---- score (selection.py:396-421): kept as the float32 feature + the affine map
     double mean = cfg.feature_mean, sd = cfg.feature_std, weight = cfg.feature_weight;
     if (!cfg.use_weighted_score) {
         if (tid == 0) {  // amean1 / astd1 (selection/utils.py:118-133), sequential
             double m = 0;
-            for (int c = 0; c < SF; ++c) m += (double)(lf[c] + lp[c]);
+            for (int c = 0; c < SF; ++c) m += (double)ls[c];
             m /= (double)SF;
             double v = 0;
             for (int c = 0; c < SF; ++c) {
-                const double d = (double)(lf[c] + lp[c]) - m;
+                const double d = (double)ls[c] - m;
                 v += d * d;
             }
             s_norm[0] = m;
@@ -229,7 +278,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
     }
     double *score = reinterpret_cast<double *>(tile);  // tile + tmp hold SF doubles
     for (int c = tid; c < SF; c += SCORE_THREADS) {
-        const float ft = lf[c] + lp[c];
+        const float ft = ls[c];
         score[c] = weight * ((double)ft - mean) / (sd + 1e-6);
     }
     __syncthreads();
@@ -320,8 +369,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
             }
         n_pk = m;
     }
-    // symetric_limits_2d (selection/utils.py:283-312); the two profiles go to the (free) log-sum rows
-    double *mob = reinterpret_cast<double *>(lf), *cyc = reinterpret_cast<double *>(lp);
+    // symetric_limits_2d (selection/utils.py:283-312)
     for (int a = 0; a < n_pk; ++a) {
         const int mob_lower = (int)max((int64_t)0, (int64_t)p_scan[a] - cfg.min_size_mobility);
         const int mob_upper = (int)min((int64_t)S, (int64_t)p_scan[a] + cfg.min_size_mobility);
