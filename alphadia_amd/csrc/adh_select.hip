@@ -65,7 +65,7 @@ __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window 
 }
 
 // one output of the smoothing: sum over kernel rows a (outer) and columns b (inner) of
-// kernel[a][b] * row[(f + k1/2 - b) mod F], float64, in this order (the oracle's order)
+// kernel[a][b] * row[(f + k1/2 - b) mod F], float64 fused multiply-adds, in this order (the oracle's)
 template <int K1>
 __device__ __forceinline__ double conv_fixed(const float *rp, const double *kd, int k0) {
     double win[K1];  // the K1 row values this output touches, converted once
@@ -74,7 +74,7 @@ __device__ __forceinline__ double conv_fixed(const float *rp, const double *kd, 
     double acc = 0.0;
     for (int a = 0; a < k0; ++a) {
 #pragma unroll
-        for (int b = 0; b < K1; ++b) acc += kd[a * K1 + b] * win[b];
+        for (int b = 0; b < K1; ++b) acc = fma(kd[a * K1 + b], win[b], acc);
     }
     return acc;
 }
@@ -82,7 +82,7 @@ __device__ __forceinline__ double conv_fixed(const float *rp, const double *kd, 
 __device__ __forceinline__ double conv_any(const float *rp, const double *kd, int k0, int k1) {
     double acc = 0.0;
     for (int a = 0; a < k0; ++a)
-        for (int b = 0; b < k1; ++b) acc += kd[a * k1 + b] * (double)rp[-b];
+        for (int b = 0; b < k1; ++b) acc = fma(kd[a * k1 + b], (double)rp[-b], acc);
     return acc;
 }
 

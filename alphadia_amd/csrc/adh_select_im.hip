@@ -182,7 +182,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
     }
     __syncthreads();
     // circular convolution, separable: out(s, f) = sum_a ku[a] * (sum_b kv[b] * x[(s + k0/2 - a) mod S][(f + k1/2 - b) mod F]),
-    // float64 accumulation in tap order, one rounding to float32 per pass
+    // float64 fused multiply-adds in tap order (as in the oracle), one rounding to float32 per pass
     const int h0 = k0 / 2, h1 = k1 / 2;
     const int padl = k1 - h1 - 1, FP = F + k1;   // padded row: column j holds cycle (j - padl) mod F
     const int padt = k0 - h0 - 1;                // padded pass-1 tile: row j holds scan (j - padt) mod S
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
                 double acc = 0.0;
                 if (fast) {
 #pragma unroll
-                    for (int b = 0; b < 30; ++b) acc += kr[b] * (double)rp[-b];
+                    for (int b = 0; b < 30; ++b) acc = fma(kr[b], (double)rp[-b], acc);
                 } else {
-                    for (int b = 0; b < k1; ++b) acc += kv[b] * (double)rp[-b];
+                    for (int b = 0; b < k1; ++b) acc = fma(kv[b], (double)rp[-b], acc);
                 }
                 const float v = (float)acc;
                 tmp[(padt + sc) * F + f] = v;
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
                 double acc = 0.0;
                 if (fast) {
 #pragma unroll
-                    for (int a = 0; a < 30; ++a) acc += kr[a] * (double)cp[-a * F];
+                    for (int a = 0; a < 30; ++a) acc = fma(kr[a], (double)cp[-a * F], acc);
                 } else {
-                    for (int a = 0; a < k0; ++a) acc += ku[a] * (double)cp[-a * F];
+                    for (int a = 0; a < k0; ++a) acc = fma(ku[a], (double)cp[-a * F], acc);
                 }
                 const float sm = (float)acc;
                 lsum[c] += (float)log((double)(sm + 1.0f));  // _build_features (selection.py:206-226)

@@ -1437,7 +1437,7 @@ static void select_one(const adh_alpharaw_t &d, const adh_fragments_t &fr, const
                 for (int b = 0; b < k1 && b < F; ++b) {
                     int src = (f + d1 - b) % F;
                     if (src < 0) src += F;
-                    acc += (double)kernel[a * k1 + b] * (double)row[src];
+                    acc = std::fma((double)kernel[a * k1 + b], (double)row[src], acc);  /* fused, as on the device */
                 }
             }
             outrow[f] = (float)acc;
@@ -1798,7 +1798,7 @@ static void select_one_im(const adh_timstof_t &d, const adh_fragments_t &fr, con
                 for (int b = 0; b < k1; ++b) {
                     int src = (f + k1 / 2 - b) % F;
                     if (src < 0) src += F;
-                    acc += kv[b] * (double)tile[(size_t)s * F + src];
+                    acc = std::fma(kv[b], (double)tile[(size_t)s * F + src], acc);  /* fused, as on the device */
                 }
                 tmp[(size_t)s * F + f] = (float)acc;
             }
@@ -1808,7 +1808,7 @@ static void select_one_im(const adh_timstof_t &d, const adh_fragments_t &fr, con
                 for (int a = 0; a < k0; ++a) {
                     int src = (s + k0 / 2 - a) % S;
                     if (src < 0) src += S;
-                    acc += ku[a] * (double)tmp[(size_t)src * F + f];
+                    acc = std::fma(ku[a], (double)tmp[(size_t)src * F + f], acc);
                 }
                 const float sm = (float)acc;
                 lsum[(size_t)s * F + f] += (float)std::log((double)(sm + 1.0f));
