@@ -89,7 +89,7 @@ struct Layout {
 
 }  // namespace featim
 
-#define ADH_IM_STATIC_LDS 8192  // static LDS of adh_feature_im_kernel (the chunk list), rounded up
+#define ADH_IM_STATIC_LDS 4096  // static LDS of adh_feature_im_kernel (chunk lists / Gram matrices)
 size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
 
 __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
@@ -99,9 +99,17 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     using namespace featim;
     extern __shared__ __align__(16) unsigned char smem[];
     // ordered list of the non-zero cells of one 64-cell chunk (see the tile passes below)
-    __shared__ double l_ti[ADH_WAVE], l_tm[ADH_WAVE], l_w[ADH_WAVE];
-    __shared__ float l_v[ADH_WAVE], l_rx[3 * ADH_WAVE], l_ry[3 * ADH_WAVE];
-    __shared__ int l_cell[3 * ADH_WAVE];
+    // static LDS: the chunk lists of the tile pass; the two 16 x 17 matrices of the scan
+    // correlation reuse the same bytes later (an extra 2 KB of LDS per wavefront cost 22 % of the
+    // kernel's throughput in resident waves)
+    __shared__ __align__(16) unsigned char pool[ADH_IM_STATIC_LDS];
+    double *const l_ti = reinterpret_cast<double *>(pool);
+    double *const l_tm = l_ti + ADH_WAVE;
+    double *const l_w = l_tm + ADH_WAVE;
+    float *const l_v = reinterpret_cast<float *>(l_w + ADH_WAVE);
+    float *const l_rx = l_v + ADH_WAVE;
+    float *const l_ry = l_rx + 3 * ADH_WAVE;
+    int *const l_cell = reinterpret_cast<int *>(l_ry + 3 * ADH_WAVE);
     const Layout lay(caps);
     const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
@@ -741,7 +749,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             // SGEMM in the reference): one MFMA tile per observation, as in adh_feature_kernel; more
             // than 16 fragments use ordered dot products
             if (Km <= 16) {
-                __shared__ float gram[16][17], redm[16][17];
+                float(*gram)[17] = reinterpret_cast<float(*)[17]>(pool);  // the chunk lists are idle here
+                float(*redm)[17] = gram + 16;
                 for (int c = lane; c < 16 * 16; c += ADH_WAVE) redm[c / 16][c % 16] = 0.0f;
                 for (int o = 0; o < O; ++o) {
                     typedef float floatx4 __attribute__((ext_vector_type(4)));
