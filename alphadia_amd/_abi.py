@@ -167,6 +167,7 @@ _CT = {
     np.dtype(np.int64): C.c_int64,
     np.dtype(np.uint32): C.c_uint32,
     np.dtype(np.uint8): C.c_uint8,
+    np.dtype(np.uint16): C.c_uint16,
 }
 
 
@@ -314,7 +315,7 @@ def pack_candidates(
     return Marshalled(s, [pi, rk, fl, fs, fe, *i64, ch, pm, iso])
 
 
-def output_shapes(n: int, top_k: int):
+def output_shapes(n: int, top_k: int, extras: bool = False):
     shapes = {}
     for name, dt, w in OUTPUT_FIELDS:
         if w == 1:
@@ -323,27 +324,35 @@ def output_shapes(n: int, top_k: int):
             shapes[name] = ((n, NUM_FEATURES), dt)
         else:
             shapes[name] = ((n, top_k), dt)
+    if extras:
+        shapes["stat_matched_peaks"] = ((n,), np.uint32)
+        shapes["fragment_lib_slot"] = ((n, top_k), np.uint16)
     return shapes
 
 
-def alloc_output(n: int, top_k: int, with_stats: bool = False, zero: bool = True):
+def alloc_output(n: int, top_k: int, with_stats: bool = False, zero: bool = True, alloc=None,
+                 with_slots: bool = True):
     """Host OutputPsmDF buffers (output.py:44-70) and the ctypes view of them; ``zero=False`` skips the
     fill for callers that overwrite every byte (``adh_score_candidates`` copies whole tables back).
-    ``fragment_lib_slot`` (1 + position of a slot's fragment in the library slice) rides along."""
-    new = np.zeros if zero else np.empty
-    arrays = {k: new(shape, dtype=dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
-    stats = new(n, dtype=np.uint32) if with_stats else None
-    slots = new((n, top_k), dtype=np.uint16)
+    ``fragment_lib_slot`` (1 + position of a slot's fragment in the library slice) rides along.
+    ``alloc(name, shape, dtype)`` supplies the buffers (e.g. page-locked ones) instead of numpy."""
+    if alloc is None:
+        new = np.zeros if zero else np.empty
+        alloc = lambda name, shape, dt: new(shape, dtype=dt)  # noqa: E731
+    arrays = {k: alloc(k, shape, dt) for k, (shape, dt) in output_shapes(n, top_k).items()}
+    stats = alloc("stat_matched_peaks", (n,), np.uint32) if with_stats else None
+    slots = alloc("fragment_lib_slot", (n, top_k), np.uint16) if with_slots else None
     s = Output(
         n,
         top_k,
         *[_ptr(arrays[name], _CT[np.dtype(dt)]) for name, dt, _ in OUTPUT_FIELDS],
         _ptr(stats, C.c_uint32) if stats is not None else None,
-        _ptr(slots, C.c_uint16),
+        _ptr(slots, C.c_uint16) if slots is not None else None,
     )
     if stats is not None:
         arrays["stat_matched_peaks"] = stats
-    arrays["fragment_lib_slot"] = slots
+    if slots is not None:
+        arrays["fragment_lib_slot"] = slots
     return Marshalled(s, arrays), arrays
 
 

@@ -15,6 +15,10 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "adh_plan.hip"
 #include "adh_gather.hip"
 #include "adh_features.hip"
 #include "adh_features_fast.hip"
@@ -55,66 +59,99 @@ struct DeviceBuffers {
 
 }  // namespace
 
-// host copy of the candidate columns the plan needs
-struct HostCands {
+// device copies of the candidate columns (adh_candidates_t): one grow-only slab
+struct CandSlab {
+    void *base = nullptr;
+    size_t bytes = 0;
+    DevCands d{};
+    float *iso = nullptr;
+    uint8_t *flags = nullptr;   // storage of the flags column (d.flags stays NULL when the caller passes none)
     int64_t n = 0;
     int32_t n_iso_cols = 0;
-    std::vector<uint32_t> precursor_idx, frag_start, frag_stop;
-    std::vector<uint8_t> rank, flags, charge;
-    std::vector<int32_t> scan_start, scan_stop, scan_center, frame_start, frame_stop, frame_center;
-    std::vector<float> precursor_mz;
 };
 
-// one processing plan = CandRec table + scratch, for a given (top_k_fragments, top_k_isotopes)
-#define ADH_CLASS_GENERIC 10
-#define ADH_N_CLASSES 11
+// device buffers of one plan under construction (adh_plan.hip); two slots alternate between the
+// chunks of adh_score_candidates
+struct PlanSlot {
+    int64_t cap = 0;
+    size_t rec_bytes = 0;
+    void *recs = nullptr, *ordered = nullptr;
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+    uint64_t *bytes = nullptr, *sorted_bytes = nullptr, *offs = nullptr;
+    void *cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+    PlanMeta *d_meta = nullptr, *h_meta = nullptr;  // device / pinned host
+    hipEvent_t done = nullptr;
+    DeviceBuffers buf;
+};
+
+// one processing plan = CandRec table in processing order, for a given (top_k_fragments,
+// top_k_isotopes, kernel family) and row range
 struct Plan {
     bool ready = false;
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
-    bool fast_ok = false;          // class 0 runs through adh_feature_fast_kernel
+    bool fast_ok = false;          // register kernels enabled (experimental_xic)
+    bool quant_all = false;
+    int64_t row0 = 0, n = 0;
     CandRec *d_recs = nullptr;
     CandRecIM *d_recs_im = nullptr;
-    unsigned char *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // classes 0..6: register kernels for one observation, F <= 8 / 12 / ... / 32 (a kernel per four
     // cycles: every cycle loop is unrolled to the class size); 7..9: two observations, F <= 16 /
     // 24 / 32; ADH_CLASS_GENERIC: the LDS kernel
     int64_t n_class[ADH_N_CLASSES] = {0};
-    bool quant_all = false;
     Caps caps_generic;
     Caps caps_all;
 };
 
+// the OutputPsmDF tables of one call as ONE packed device buffer (computed tables first)
+struct DevTables {
+    void *base = nullptr;
+    size_t bytes = 0, used = 0, wire_bytes = 0;
+    int64_t rows = 0;
+    int top_k = 0;
+    adh_output_t view{};
+};
+
+struct adh_comm_state;
+
 struct adh_handle {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // compute
     hipStream_t side_stream = nullptr;   // the generic feature kernel overlaps the register kernels
+    hipStream_t stream_in = nullptr, stream_out = nullptr;  // H2D + plan / D2H of adh_score_candidates
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_k[2] = {nullptr, nullptr};  // kernels of the chunk that used plan slot s are done
     DevRun run{};
     DevTims tims{};
     bool tims_staged = false;
-    std::vector<int32_t> h_dpc;     // host copy of dia_precursor_cycle (ion-mobility plan)
-    std::vector<double> h_cycle;    // host copy for planning
+    std::vector<double> h_cycle;    // host copy (candidate selection sizes its tiles on the host)
     const LibRec *d_lib = nullptr;
     int64_t n_lib = 0;
-    const float *d_iso = nullptr;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
     std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
-    void *scratch_slab = nullptr;   // per-candidate scratch blocks of the AlphaRaw plan
+    void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
     uint64_t scratch_slab_bytes = 0;
-    void *out_slab = nullptr;       // device copy of the output tables of adh_score_candidates
-    size_t out_slab_bytes = 0;
-    HostCands hc;
-    Plan plan;
+    DevTables tables[2];            // slot 1 only with a communicator (double-buffered all-gather)
+    int table_slot = 1, last_tables = -1;
+    int64_t last_rows = 0;
+    CandSlab cs;
+    PlanSlot slots[2];
+    Plan plan;                      // plan of the resident table (adh_upload_candidates / adh_score_uploaded)
     bool run_staged = false, lib_staged = false, cands_uploaded = false;
-    DeviceBuffers run_buf, lib_buf, cand_buf, plan_buf;
+    DeviceBuffers run_buf, lib_buf;
+    adh_comm_state *comm = nullptr;
+    int64_t comm_rows = 0;          // rows of the largest shard (table layout under a communicator)
+    bool comm_attached() const { return comm != nullptr; }
     struct Timed {
         hipEvent_t e0, e1, e2;
     };
-    std::vector<Timed> timed;  // per step: before gather, between, after features
+    std::vector<Timed> timed;  // per launch: before gather, between, after features
     std::vector<hipEvent_t> free_events;
+    double sum_gather_ms = 0.0, sum_feature_ms = 0.0;
+    int64_t n_timed = 0;
 };
 
 namespace {
@@ -169,21 +206,31 @@ int adh_create(adh_handle_t **handle, int device) {
     HIP_TRY(hipSetDevice(device));
     adh_handle *h = new adh_handle();
     h->device = device;
+    const char *what = "hipStreamCreate";
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(ADH_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking);
+    if (e == hipSuccess) what = "hipEventCreate";
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k[1], hipEventDisableTiming);
+    if (e == hipSuccess) what = "hipMalloc(weight table)";
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_wtp, 2 * 64 * sizeof(double));
-    if (e != hipSuccess) {
-        (void)hipStreamDestroy(h->stream);
-        delete h;
-        return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e == hipSuccess) {
+        what = "adh_wtp_table_kernel";
+        hipLaunchKernelGGL(adh_wtp_table_kernel, dim3(1), dim3(128), 0, h->stream, h->d_wtp);
+        e = hipGetLastError();
+        // callers may score on a stream of their own: the table must be complete before the handle is used
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
-    hipLaunchKernelGGL(adh_wtp_table_kernel, dim3(1), dim3(128), 0, h->stream, h->d_wtp);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        adh_destroy(h);  // releases whatever was created so far
+        return fail(e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP, msg);
+    }
     // the kernels may need more than the default 64 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)adh_feature_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -202,11 +249,15 @@ int adh_create(adh_handle_t **handle, int device) {
 int adh_destroy(adh_handle_t *h) {
     if (!h) return ADH_OK;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();
+    (void)adh_comm_destroy(h);
     h->run_buf.release();
     h->lib_buf.release();
-    h->cand_buf.release();
-    h->plan_buf.release();
+    for (PlanSlot &s : h->slots) {
+        s.buf.release();
+        if (s.h_meta) (void)hipHostFree(s.h_meta);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
     for (auto &p : h->timed) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
@@ -214,12 +265,19 @@ int adh_destroy(adh_handle_t *h) {
     }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->d_wtp) (void)hipFree(h->d_wtp);
-    if (h->out_slab) (void)hipFree(h->out_slab);
+    for (DevTables &t : h->tables)
+        if (t.base) (void)hipFree(t.base);
+    if (h->cs.base) (void)hipFree(h->cs.base);
     if (h->scratch_slab) (void)hipFree(h->scratch_slab);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t e : h->ev_k)
+        if (e) (void)hipEventDestroy(e);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    (void)hipStreamDestroy(h->stream);
+    if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
+    if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    (void)hipGetLastError();
     delete h;
     return ADH_OK;
 }
@@ -300,9 +358,10 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     if (d->n_spectra >= (int64_t)0x7FFFFFFFll || d->cycle_len > 65535)
         return fail(ADH_ERR_UNSUPPORTED, "too many spectra / cycle positions");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
     h->run_buf.release();
-    h->plan_buf.release();
     h->plan = Plan();
+    h->cands_uploaded = false;  // the resident table was planned against the previous run
     h->run_staged = false;
     h->tims_staged = false;
 
@@ -399,9 +458,10 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
         d->n_frames * (int64_t)d->scan_max_index >= 0xFFFFFFFFll)
         return fail(ADH_ERR_UNSUPPORTED, "run too large for 32-bit push / TOF indices");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
     h->run_buf.release();
-    h->plan_buf.release();
     h->plan = Plan();
+    h->cands_uploaded = false;  // the resident table was planned against the previous run
     h->run_staged = false;
     h->tims_staged = false;
     // validate the index arrays on the host: kernels use them unchecked
@@ -438,7 +498,6 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
     h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);
     h->h_mobility_im.assign(d->mobility_values, d->mobility_values + d->scan_max_index);
-    h->h_dpc = dpc;
     h->tims = t;
     h->tims_staged = true;
     return ADH_OK;
@@ -449,8 +508,11 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     if (f->n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative fragment count");
     if (f->n >= (int64_t)0xFFFFFFFFll) return fail(ADH_ERR_UNSUPPORTED, "too many fragments");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
     h->lib_buf.release();
     h->lib_staged = false;
+    h->plan = Plan();
+    h->cands_uploaded = false;  // fragment slices of the resident table refer to the previous library
     std::vector<LibRec> recs((size_t)f->n);
     for (int64_t i = 0; i < f->n; ++i) {
         LibRec &r = recs[(size_t)i];
@@ -471,628 +533,8 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     return ADH_OK;
 }
 
-int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
-    if (!h || !c) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!(h->run_staged || h->tims_staged) || !h->lib_staged)
-        return fail(ADH_ERR_NOT_STAGED, "stage the run and the fragment library first");
-    if (c->n < 0 || c->n_isotope_cols < 1)
-        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid candidate table dimensions");
-    if (c->n > 0x7FFFFFFFll)
-        return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 candidates in one batch");
-    HIP_TRY(hipSetDevice(h->device));
-    h->cand_buf.release();
-    h->plan_buf.release();
-    h->plan = Plan();
-    h->cands_uploaded = false;
-
-    // bounds the kernels rely on
-    const bool im = h->tims_staged;
-    const int64_t L = im ? h->tims.cycle_len : h->run.cycle_len;
-    const int64_t zf = im ? h->tims.zeroth : 0;
-    const int64_t n_fr = im ? h->tims.n_frames : h->run.n_spectra;
-    for (int64_t i = 0; i < c->n; ++i) {
-        if (c->flags && (c->flags[i] & ADH_FLAG_SKIP)) continue;
-        if (c->frag_stop_idx[i] < c->frag_start_idx[i] || (int64_t)c->frag_stop_idx[i] > h->n_lib)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
-        int64_t fs = c->frame_start[i], fe = c->frame_stop[i], fc = c->frame_center[i];
-        if (fs < zf || fe < fs || fe > n_fr + (im ? 0 : 0) || fc < 0 || fc >= n_fr)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
-        // frame_stop may be clipped to the last frame of the run by the selection step
-        // (selection.py:488-491); the cycle count is a floor division as in get_dense
-        if ((fs - zf) % L != 0)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "frame_start must sit on a cycle boundary");
-        int64_t ss = c->scan_start[i], se = c->scan_stop[i], sc = c->scan_center[i];
-        if (im) {
-            if (ss < 0 || se < ss || se > h->tims.scan_max || sc < 0 || sc >= h->tims.scan_max)
-                return fail(ADH_ERR_INVALID_ARGUMENT, "scan limits outside the staged run");
-            if (fe - 1 >= n_fr) return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
-        } else if (se - ss != 1 || ss != 0 || sc != 0) {
-            return fail(ADH_ERR_UNSUPPORTED,
-                        "AlphaRaw candidates must have scan_start=0, scan_stop=1, scan_center=0");
-        }
-        if (c->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge is 0");
-    }
-    HostCands &hc = h->hc;
-    hc.n = c->n;
-    hc.n_iso_cols = c->n_isotope_cols;
-    const size_t n = (size_t)c->n;
-    hc.precursor_idx.assign(c->precursor_idx, c->precursor_idx + n);
-    hc.frag_start.assign(c->frag_start_idx, c->frag_start_idx + n);
-    hc.frag_stop.assign(c->frag_stop_idx, c->frag_stop_idx + n);
-    hc.rank.assign(c->rank, c->rank + n);
-    if (c->flags)
-        hc.flags.assign(c->flags, c->flags + n);
-    else
-        hc.flags.assign(n, 0);
-    hc.charge.assign(c->charge, c->charge + n);
-    hc.precursor_mz.assign(c->precursor_mz, c->precursor_mz + n);
-    auto narrow = [n](const int64_t *src, std::vector<int32_t> &dst) {
-        dst.resize(n);
-        for (size_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i];
-    };
-    narrow(c->scan_start, hc.scan_start);
-    narrow(c->scan_stop, hc.scan_stop);
-    narrow(c->scan_center, hc.scan_center);
-    narrow(c->frame_start, hc.frame_start);
-    narrow(c->frame_stop, hc.frame_stop);
-    narrow(c->frame_center, hc.frame_center);
-    UP(h->cand_buf, c->isotope_intensity, c->n * c->n_isotope_cols, &h->d_iso);
-    h->cands_uploaded = true;
-    return ADH_OK;
-}
-
-namespace {
-
-// Build the processing plan for (top_k_fragments, top_k_isotopes): observation lists,
-// tile sizes, scratch offsets, and a processing order by (observation class, first cycle) so
-// that concurrently resident wavefronts gather from the same few spectra.
-int build_plan(adh_handle *h, const adh_scoring_config_t *cfg) {
-    Plan &p = h->plan;
-    const bool fast_cfg = cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST");
-    if (p.ready && p.top_k_fragments == cfg->top_k_fragments &&
-        p.top_k_isotopes == cfg->top_k_isotopes && p.fast_ok == fast_cfg &&
-        p.quant_all == (cfg->quant_all != 0))
-        return ADH_OK;
-    h->plan_buf.release();
-    p = Plan();
-    const HostCands &hc = h->hc;
-    const int64_t n = hc.n;
-    const int L = h->run.cycle_len;
-    const int rows = h->run.cycle_len * h->run.cycle_scans;
-    const int I = (int)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)hc.n_iso_cols);
-    const double *cyc = h->h_cycle.data();
-    const double ISOTOPE_DELTA = 1.0033548350700006;
-
-    std::vector<CandRec> recs((size_t)n);
-    std::vector<uint8_t> cls((size_t)n, 0);
-    const int64_t n_cyc = h->run.n_spectra / L + 2;
-    const int NCLS = ADH_N_CLASSES, GENERIC = ADH_CLASS_GENERIC;
-    std::vector<uint32_t> head[NCLS];
-    for (int c = 0; c < NCLS; ++c) head[c].assign((size_t)n_cyc + 1, 0);
-    std::atomic<int> too_many{0};
-    auto build_range = [&](int64_t i0, int64_t i1) {
-      for (int64_t i = i0; i < i1; ++i) {
-        CandRec &r = recs[(size_t)i];
-        memset(&r, 0, sizeof(r));
-        r.precursor_idx = hc.precursor_idx[i];
-        r.frag_start = hc.frag_start[i];
-        r.frag_stop = hc.frag_stop[i];
-        r.frame_start = hc.frame_start[i];
-        r.frame_stop = hc.frame_stop[i];
-        r.frame_center = hc.frame_center[i];
-        r.scan_start = hc.scan_start[i];
-        r.scan_stop = hc.scan_stop[i];
-        r.scan_center = hc.scan_center[i];
-        r.precursor_mz = hc.precursor_mz[i];
-        r.charge = hc.charge[i];
-        r.rank = hc.rank[i];
-        r.flags = hc.flags[i];
-        r.row = (uint32_t)i;
-        if (r.flags & ADH_FLAG_SKIP) {
-            cls[(size_t)i] = GENERIC;  // parked in cycle bin 0 of the generic class; the kernels return at once
-            continue;
-        }
-        // isotope m/z range exactly as the kernels compute it (candidate.py:151-163,203-205)
-        float mn = 0.f, mx = 0.f;
-        for (int k = 0; k < I; ++k) {
-            float m = (float)((double)k * ISOTOPE_DELTA / (double)r.charge) + r.precursor_mz;
-            if (k == 0 || m < mn) mn = m;
-            if (k == 0 || m > mx) mx = m;
-        }
-        const float q_lo = (float)((double)mn - 0.5), q_hi = (float)((double)mx + 0.5);
-        int O = 0;
-        for (int row = 0; row < rows; ++row) {
-            if ((double)q_lo <= cyc[2 * row + 1] && (double)q_hi >= cyc[2 * row]) {
-                if (O >= ADH_MAX_OBS) {
-                    too_many = 1;
-                    break;
-                }
-                r.obs[O++] = (uint16_t)row;
-            }
-        }
-        r.n_obs = (uint8_t)O;
-        r.k_cap = (uint32_t)std::min<int64_t>((int64_t)cfg->top_k_fragments,
-                                              (int64_t)r.frag_stop - (int64_t)r.frag_start);
-        {
-            // shape handled by the register-resident kernel (adh_features_fast.hip)
-            const int F = r.frame_stop / L - r.frame_start / L;
-            // (several observations: only with quant_all, see adh_features_fast.hip)
-            const bool fast = fast_cfg && O >= 1 && O <= ADH_FAST_OMAX && (O == 1 || cfg->quant_all) &&
-                              F >= 3 && F <= ADH_FMAX && r.k_cap <= 16 && I <= 4;
-            cls[(size_t)i] = !fast ? GENERIC : (O == 1 ? std::max(F - 5, 0) / 4 : 7 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)));
-        }
-      }
-    };
-    {
-        // the records are independent: build them on a few host threads
-        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 4096}));
-        std::vector<std::thread> pool;
-        const int64_t per = (n + n_thr - 1) / n_thr;
-        for (int t = 1; t < n_thr; ++t)
-            pool.emplace_back(build_range, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
-        build_range(0, std::min<int64_t>(n, per));
-        for (auto &th : pool) th.join();
-    }
-    if (too_many) return fail(ADH_ERR_UNSUPPORTED, "a precursor overlaps more than 8 isolation windows");
-    for (int64_t i = 0; i < n; ++i) {
-        const CandRec &r = recs[(size_t)i];
-        const size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)(r.frame_start / L);
-        ++head[cls[(size_t)i]][bin + 1];
-    }
-    // counting sort by (class, first cycle)
-    size_t class_first[NCLS + 1] = {0};
-    for (int c = 0; c < NCLS; ++c) {
-        for (int64_t k = 0; k < n_cyc; ++k) head[c][(size_t)k + 1] += head[c][(size_t)k];
-        p.n_class[c] = head[c][(size_t)n_cyc];
-        class_first[c + 1] = class_first[c] + (size_t)p.n_class[c];
-    }
-    std::vector<CandRec> ordered((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        const CandRec &r = recs[(size_t)i];
-        int c = cls[(size_t)i];
-        size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)(r.frame_start / L);
-        size_t pos = (size_t)head[c][bin]++ + class_first[c];
-        ordered[pos] = r;
-    }
-    // scratch offsets + capacities
-    Caps zero{1, 1, 1, std::max(I, 1), 1, 0};
-    p.caps_generic = p.caps_all = zero;
-    uint64_t off = 0;
-    for (int64_t j = 0; j < n; ++j) {
-        CandRec &r = ordered[(size_t)j];
-        if (r.flags & ADH_FLAG_SKIP) continue;
-        const int F = r.frame_stop / L - r.frame_start / L;
-        const int O = r.n_obs;
-        r.scratch_off = off;
-        off += adh_scratch_bytes(r.k_cap, O, std::max(F, 0), I);
-        for (Caps *cc : {&p.caps_all, (size_t)j >= class_first[GENERIC] ? &p.caps_generic : (Caps *)nullptr}) {
-            if (!cc) continue;
-            cc->k = std::max<int32_t>(cc->k, (int32_t)r.k_cap);
-            cc->o = std::max<int32_t>(cc->o, O);
-            cc->f = std::max<int32_t>(cc->f, F);
-            cc->n_lib = std::max<int32_t>(cc->n_lib, (int32_t)(r.frag_stop - r.frag_start));
-        }
-    }
-    p.scratch_bytes = std::max<uint64_t>(off, 32);
-    const CandRec *d_recs = nullptr;
-    UP(h->plan_buf, ordered.data(), n, &d_recs);
-    p.d_recs = const_cast<CandRec *>(d_recs);
-    // the scratch slab outlives the plan (grow-only): a new candidate table of similar size reuses it
-    if (h->scratch_slab_bytes < p.scratch_bytes) {
-        if (h->scratch_slab) (void)hipFree(h->scratch_slab);
-        h->scratch_slab = nullptr;
-        h->scratch_slab_bytes = 0;
-        const uint64_t want = p.scratch_bytes + p.scratch_bytes / 8;
-        HIP_TRY(hipMalloc(&h->scratch_slab, want));
-        h->scratch_slab_bytes = want;
-    }
-    p.d_scratch = static_cast<unsigned char *>(h->scratch_slab);
-    p.top_k_fragments = cfg->top_k_fragments;
-    p.top_k_isotopes = cfg->top_k_isotopes;
-    p.fast_ok = fast_cfg;
-    p.quant_all = cfg->quant_all != 0;
-    p.ready = true;
-    return ADH_OK;
-}
-
-
-// Ion-mobility plan: observation lists (sorted unique dia_precursor_cycle values of the cycle
-// rows inside the scan range that overlap the quadrupole range), tile sizes, scratch offsets.
-int build_plan_im(adh_handle *h, const adh_scoring_config_t *cfg) {
-    Plan &p = h->plan;
-    if (p.ready && p.top_k_fragments == cfg->top_k_fragments && p.top_k_isotopes == cfg->top_k_isotopes)
-        return ADH_OK;
-    h->plan_buf.release();
-    p = Plan();
-    const HostCands &hc = h->hc;
-    const int64_t n = hc.n;
-    const int L = h->tims.cycle_len, S_max = h->tims.scan_max, z = h->tims.zeroth;
-    const int I = (int)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)hc.n_iso_cols);
-    const double *cyc = h->h_cycle.data();
-    const double ISOTOPE_DELTA = 1.0033548350700006;
-    const int64_t n_cyc = h->tims.n_frames / L + 2;
-    std::vector<uint32_t> head((size_t)n_cyc + 1, 0);
-    std::vector<CandRecIM> recs((size_t)n);
-    std::vector<uint8_t> seen((size_t)L);
-    for (int64_t i = 0; i < n; ++i) {
-        CandRecIM &r = recs[(size_t)i];
-        memset(&r, 0, sizeof(r));
-        r.precursor_idx = hc.precursor_idx[i];
-        r.frag_start = hc.frag_start[i];
-        r.frag_stop = hc.frag_stop[i];
-        r.frame_start = hc.frame_start[i];
-        r.frame_stop = hc.frame_stop[i];
-        r.frame_center = hc.frame_center[i];
-        r.scan_start = hc.scan_start[i];
-        r.scan_stop = hc.scan_stop[i];
-        r.scan_center = hc.scan_center[i];
-        r.precursor_mz = hc.precursor_mz[i];
-        r.charge = hc.charge[i];
-        r.rank = hc.rank[i];
-        r.flags = hc.flags[i];
-        r.row = (uint32_t)i;
-        if (r.flags & ADH_FLAG_SKIP) {
-            ++head[1];
-            continue;
-        }
-        float mn = 0.f, mx = 0.f;
-        for (int k = 0; k < I; ++k) {
-            float m = (float)((double)k * ISOTOPE_DELTA / (double)r.charge) + r.precursor_mz;
-            if (k == 0 || m < mn) mn = m;
-            if (k == 0 || m > mx) mx = m;
-        }
-        const double q_lo = (double)(float)((double)mn - 0.5), q_hi = (double)(float)((double)mx + 0.5);
-        for (int pass = 0; pass < 2; ++pass) {
-            const double lo = pass ? -1.0 : q_lo, hi = pass ? -1.0 : q_hi;
-            std::fill(seen.begin(), seen.end(), 0);
-            for (int fr = 0; fr < L; ++fr)
-                for (int sc = r.scan_start; sc < r.scan_stop; ++sc) {
-                    const int64_t rowi = (int64_t)fr * S_max + sc;
-                    if (lo <= cyc[2 * rowi + 1] && hi >= cyc[2 * rowi]) seen[(size_t)h->h_dpc[(size_t)rowi]] = 1;
-                }
-            int cnt = 0;
-            for (int v = 0; v < L; ++v) {
-                if (!seen[(size_t)v]) continue;
-                if (pass == 0) {
-                    if (cnt >= ADH_MAX_OBS)
-                        return fail(ADH_ERR_UNSUPPORTED, "a precursor overlaps more than 8 cycle rows");
-                    r.obs[cnt] = (uint16_t)v;
-                } else {
-                    if (cnt >= ADH_MAX_MS1_OBS)
-                        return fail(ADH_ERR_UNSUPPORTED, "more than 16 unfragmented cycle rows in the scan range");
-                    r.ms1_obs[cnt] = (uint16_t)v;
-                }
-                ++cnt;
-            }
-            if (pass == 0) r.n_obs = (uint8_t)cnt; else r.n_ms1 = (uint8_t)cnt;
-        }
-        r.k_cap = (uint32_t)std::min<int64_t>((int64_t)cfg->top_k_fragments,
-                                              (int64_t)r.frag_stop - (int64_t)r.frag_start);
-        ++head[(size_t)((r.frame_start - z) / L) + 1];
-    }
-    for (int64_t k = 0; k < n_cyc; ++k) head[(size_t)k + 1] += head[(size_t)k];
-    std::vector<CandRecIM> ordered((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        const CandRecIM &r = recs[(size_t)i];
-        size_t bin = (r.flags & ADH_FLAG_SKIP) ? 0 : (size_t)((r.frame_start - z) / L);
-        ordered[(size_t)head[bin]++] = r;
-    }
-    Caps zero{1, 1, 1, std::max(I, 1), 1, 0, 1, 1};
-    p.caps_generic = p.caps_all = zero;
-    uint64_t off = 0;
-    for (int64_t j = 0; j < n; ++j) {
-        CandRecIM &r = ordered[(size_t)j];
-        if (r.flags & ADH_FLAG_SKIP) continue;
-        const int F = std::max((r.frame_stop - z) / L - (r.frame_start - z) / L, 0);
-        const int S = std::max(r.scan_stop - r.scan_start, 0);
-        r.scratch_off = off;
-        off += adh_im_scratch_bytes(r.k_cap, r.n_obs, S, F, I, r.n_ms1);
-        Caps &cc = p.caps_all;
-        cc.k = std::max<int32_t>(cc.k, (int32_t)r.k_cap);
-        cc.o = std::max<int32_t>(cc.o, (int32_t)r.n_obs);
-        cc.f = std::max<int32_t>(cc.f, F);
-        cc.s = std::max<int32_t>(cc.s, S);
-        cc.op = std::max<int32_t>(cc.op, (int32_t)r.n_ms1);
-        cc.n_lib = std::max<int32_t>(cc.n_lib, (int32_t)(r.frag_stop - r.frag_start));
-    }
-    p.caps_generic = p.caps_all;
-    p.n_class[ADH_CLASS_GENERIC] = n;
-    p.scratch_bytes = std::max<uint64_t>(off, 32);
-    const CandRecIM *d_recs = nullptr;
-    UP(h->plan_buf, ordered.data(), n, &d_recs);
-    p.d_recs_im = const_cast<CandRecIM *>(d_recs);
-    void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, p.scratch_bytes));
-    h->plan_buf.ptrs.push_back(sp);
-    p.d_scratch = static_cast<unsigned char *>(sp);
-    p.top_k_fragments = cfg->top_k_fragments;
-    p.top_k_isotopes = cfg->top_k_isotopes;
-    p.ready = true;
-    return ADH_OK;
-}
-
-int score_uploaded_im(adh_handle *h, const adh_scoring_config_t *cfg, adh_output_t *out, hipStream_t st) {
-    int rc = build_plan_im(h, cfg);
-    if (rc != ADH_OK) return rc;
-    Plan &p = h->plan;
-    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
-        return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
-    p.caps_all.stop_phase = 0;
-    if (const char *dbg = getenv("ADH_DEBUG_IM")) p.caps_all.stop_phase = atoi(dbg);
-    const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all);
-    const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all);
-    if (f_lds > 160 * 1024 - ADH_IM_STATIC_LDS || g_lds > 160 * 1024) {
-        char buf[256];
-        snprintf(buf, sizeof(buf),
-                 "ion-mobility tile needs %zu bytes of LDS (K=%d O=%d S=%d F=%d): exceeds 160 KiB", f_lds,
-                 p.caps_all.k, p.caps_all.o, p.caps_all.s, p.caps_all.f);
-        return fail(ADH_ERR_UNSUPPORTED, buf);
-    }
-    adh_handle::Timed t;
-    rc = get_event(h, &t.e0);
-    if (rc == ADH_OK) rc = get_event(h, &t.e1);
-    if (rc == ADH_OK) rc = get_event(h, &t.e2);
-    if (rc != ADH_OK) return rc;
-    const int32_t n_iso = h->hc.n_iso_cols;
-    HIP_TRY(hipEventRecord(t.e0, st));
-    hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), g_lds, st, h->tims,
-                       h->d_lib, p.d_recs_im, *cfg, n_iso, p.d_scratch, *out, p.caps_all);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(t.e1, st));
-    hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), f_lds, st, h->tims,
-                       p.d_recs_im, h->d_iso, n_iso, *cfg, p.d_scratch, *out, p.caps_all);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(t.e2, st));
-    h->timed.push_back(t);
-    return ADH_OK;
-}
-
-}  // namespace
-
-int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_output_t *out,
-                       void *hip_stream) {
-    if (!h || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!h->cands_uploaded) return fail(ADH_ERR_NOT_STAGED, "no candidate table uploaded");
-    if (out->n != h->hc.n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
-    if (cfg->top_k_fragments == 0 || cfg->top_k_isotopes == 0)
-        return fail(ADH_ERR_INVALID_ARGUMENT, "top_k_fragments / top_k_isotopes must be > 0");
-    if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
-    HIP_TRY(hipSetDevice(h->device));
-    if (h->hc.n == 0) return ADH_OK;
-    hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's default stream, taken literally
-    if (h->tims_staged) return score_uploaded_im(h, cfg, out, st);
-    int rc = build_plan(h, cfg);
-    if (rc != ADH_OK) return rc;
-    Plan &p = h->plan;
-    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
-        return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
-    int stop_phase = 0;
-    if (const char *dbg = getenv("ADH_DEBUG_STOP_PHASE")) stop_phase = atoi(dbg);  // developer switch
-
-    Caps gcaps = p.caps_all;
-    if (const char *dbg = getenv("ADH_DEBUG_GATHER")) gcaps.stop_phase = atoi(dbg);
-    const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
-    p.caps_generic.stop_phase = stop_phase;
-    const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
-    if (p.n_class[ADH_CLASS_GENERIC] > 0 && f_lds > 160 * 1024) {
-        char buf[256];
-        snprintf(buf, sizeof(buf),
-                 "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", f_lds,
-                 p.caps_generic.k, p.caps_generic.o, p.caps_generic.f);
-        return fail(ADH_ERR_UNSUPPORTED, buf);
-    }
-    if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice / MS1 tile too large for the gather kernel");
-
-    adh_handle::Timed t;
-    rc = get_event(h, &t.e0);
-    if (rc == ADH_OK) rc = get_event(h, &t.e1);
-    if (rc == ADH_OK) rc = get_event(h, &t.e2);
-    if (rc != ADH_OK) return rc;
-    const int32_t n_iso = h->hc.n_iso_cols;
-    HIP_TRY(hipEventRecord(t.e0, st));
-    hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)h->hc.n), dim3(ADH_WAVE), g_lds, st, h->run,
-                       h->d_lib, p.d_recs, *cfg, n_iso, p.d_scratch, *out, gcaps);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(t.e1, st));
-    if (stop_phase != 2) {
-        int64_t n_fast = 0;
-        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) n_fast += p.n_class[c];
-        bool forked = false;
-        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic"
-        const bool run_generic = !(only && only[0] == 'f'), run_fast = !(only && only[0] == 'g');
-        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic) {
-            // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
-            hipStream_t gs = st;
-            if (n_fast > 0) {
-                HIP_TRY(hipEventRecord(h->ev_fork, st));
-                HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-                gs = h->side_stream;
-                forked = true;
-            }
-            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[ADH_CLASS_GENERIC]), dim3(ADH_WAVE), f_lds,
-                               gs, h->run, p.d_recs + n_fast, h->d_iso, n_iso, *cfg, p.d_scratch, *out,
-                               p.caps_generic);
-            HIP_TRY(hipGetLastError());
-            if (forked) HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
-        }
-        const unsigned per_block = ADH_WAVE / ADH_GS;
-        int64_t first = 0;
-        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) {
-            if (p.n_class[c] > 0 && run_fast) {
-                const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
-                const CandRec *recs = p.d_recs + first;
-                const int32_t nc = (int32_t)p.n_class[c];
-#define ADH_LAUNCH_FAST(FM, NO)                                                                      \
-    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, \
-                       recs, nc, h->d_iso, n_iso, *cfg, p.d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
-                switch (c) {
-                    case 0: ADH_LAUNCH_FAST(8, 1); break;
-                    case 1: ADH_LAUNCH_FAST(12, 1); break;
-                    case 2: ADH_LAUNCH_FAST(16, 1); break;
-                    case 3: ADH_LAUNCH_FAST(20, 1); break;
-                    case 4: ADH_LAUNCH_FAST(24, 1); break;
-                    case 5: ADH_LAUNCH_FAST(28, 1); break;
-                    case 6: ADH_LAUNCH_FAST(32, 1); break;
-                    case 7: ADH_LAUNCH_FAST(16, 2); break;
-                    case 8: ADH_LAUNCH_FAST(24, 2); break;
-                    default: ADH_LAUNCH_FAST(32, 2); break;
-                }
-#undef ADH_LAUNCH_FAST
-                HIP_TRY(hipGetLastError());
-            }
-            first += p.n_class[c];
-        }
-        if (forked) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-    }
-    HIP_TRY(hipEventRecord(t.e2, st));
-    h->timed.push_back(t);
-    return ADH_OK;
-}
-
-int adh_get_stream(adh_handle_t *h, void **hip_stream) {
-    if (!h || !hip_stream) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    *hip_stream = (void *)h->stream;
-    return ADH_OK;
-}
-
-int adh_synchronize(adh_handle_t *h) {
-    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return ADH_OK;
-}
-
-int adh_kernel_time_ms(adh_handle_t *h, double *gather_ms, double *feature_ms, int64_t *launches,
-                       int reset) {
-    if (!h || !gather_ms || !feature_ms || !launches)
-        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
-    double sg = 0, sf = 0;
-    int64_t n = 0;
-    for (auto &t : h->timed) {
-        HIP_TRY(hipEventSynchronize(t.e2));
-        float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, t.e0, t.e1));
-        HIP_TRY(hipEventElapsedTime(&b, t.e1, t.e2));
-        sg += a;
-        sf += b;
-        ++n;
-    }
-    *gather_ms = n ? sg / (double)n : 0.0;
-    *feature_ms = n ? sf / (double)n : 0.0;
-    *launches = n;
-    if (reset) {
-        for (auto &t : h->timed) {
-            h->free_events.push_back(t.e0);
-            h->free_events.push_back(t.e1);
-            h->free_events.push_back(t.e2);
-        }
-        h->timed.clear();
-    }
-    return ADH_OK;
-}
-
-int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
-                         adh_output_t *out) {
-    if (!h || !c || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (out->n != c->n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
-    if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
-    const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;  // developer switch: stage times to stderr
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_0 = now();
-    int rc = adh_upload_candidates(h, c);
-    if (rc != ADH_OK) return rc;
-    const double t_1 = now();
-    const int64_t n = c->n;
-    const size_t tk = (size_t)out->top_k;
-    struct Field {
-        void **host;
-        size_t bytes;
-    };
-    adh_output_t dev = *out;
-    Field fields[] = {
-        {(void **)&out->valid, (size_t)n},
-        {(void **)&out->precursor_idx, (size_t)n * 4},
-        {(void **)&out->rank, (size_t)n},
-        {(void **)&out->features, (size_t)n * ADH_NUM_FEATURES * 4},
-        {(void **)&out->fragment_precursor_idx, (size_t)n * tk * 4},
-        {(void **)&out->fragment_rank, (size_t)n * tk},
-        {(void **)&out->fragment_mz_library, (size_t)n * tk * 4},
-        {(void **)&out->fragment_mz, (size_t)n * tk * 4},
-        {(void **)&out->fragment_mz_observed, (size_t)n * tk * 4},
-        {(void **)&out->fragment_height, (size_t)n * tk * 4},
-        {(void **)&out->fragment_intensity, (size_t)n * tk * 4},
-        {(void **)&out->fragment_mass_error, (size_t)n * tk * 4},
-        {(void **)&out->fragment_correlation, (size_t)n * tk * 4},
-        {(void **)&out->fragment_position, (size_t)n * tk},
-        {(void **)&out->fragment_number, (size_t)n * tk},
-        {(void **)&out->fragment_type, (size_t)n * tk},
-        {(void **)&out->fragment_charge, (size_t)n * tk},
-        {(void **)&out->fragment_loss_type, (size_t)n * tk},
-        {(void **)&out->stat_matched_peaks, (size_t)n * 4},
-        {(void **)&out->fragment_lib_slot, (size_t)n * tk * 2},
-    };
-    const int n_optional = 2;  // the last two tables may be NULL
-    void **dev_slots[] = {
-        (void **)&dev.valid, (void **)&dev.precursor_idx, (void **)&dev.rank, (void **)&dev.features,
-        (void **)&dev.fragment_precursor_idx, (void **)&dev.fragment_rank,
-        (void **)&dev.fragment_mz_library, (void **)&dev.fragment_mz,
-        (void **)&dev.fragment_mz_observed, (void **)&dev.fragment_height,
-        (void **)&dev.fragment_intensity, (void **)&dev.fragment_mass_error,
-        (void **)&dev.fragment_correlation, (void **)&dev.fragment_position,
-        (void **)&dev.fragment_number, (void **)&dev.fragment_type, (void **)&dev.fragment_charge,
-        (void **)&dev.fragment_loss_type, (void **)&dev.stat_matched_peaks, (void **)&dev.fragment_lib_slot};
-    const int NF = (int)(sizeof(fields) / sizeof(fields[0]));
-    // one device slab for all tables, kept in the handle between calls
-    size_t total = 0;
-    rc = ADH_OK;
-    for (int i = 0; i < NF; ++i) {
-        if (*fields[i].host == nullptr && i < NF - n_optional) {
-            rc = fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
-            break;
-        }
-        total += (fields[i].bytes + 255) / 256 * 256;
-    }
-    if (rc == ADH_OK && h->out_slab_bytes < total) {
-        if (h->out_slab) (void)hipFree(h->out_slab);
-        h->out_slab = nullptr;
-        h->out_slab_bytes = 0;
-        hipError_t e = hipMalloc(&h->out_slab, std::max<size_t>(total, 256));
-        if (e != hipSuccess)
-            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(output tables): ") + hipGetErrorString(e));
-        else
-            h->out_slab_bytes = std::max<size_t>(total, 256);
-    }
-    if (rc == ADH_OK) {
-        size_t off = 0;
-        for (int i = 0; i < NF; ++i) {
-            *dev_slots[i] = (*fields[i].host == nullptr) ? nullptr : (void *)((unsigned char *)h->out_slab + off);
-            off += (fields[i].bytes + 255) / 256 * 256;
-        }
-        hipError_t e = hipMemsetAsync(h->out_slab, 0, std::max<size_t>(total, 256), h->stream);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
-    }
-    const double t_2 = now();
-    if (rc == ADH_OK) rc = adh_score_uploaded(h, cfg, &dev, (void *)h->stream);
-    const double t_3 = now();
-    if (rc == ADH_OK) {
-        hipError_t e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess)
-            rc = fail(ADH_ERR_HIP, std::string("scoring kernel: ") + hipGetErrorString(e));
-    }
-    const double t_4 = now();
-    for (int i = 0; i < NF && rc == ADH_OK; ++i) {
-        if (*dev_slots[i] == nullptr || fields[i].bytes == 0) continue;
-        hipError_t e = hipMemcpy(*fields[i].host, *dev_slots[i], fields[i].bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
-    }
-    const double t_5 = now();
-    if (timing)
-        fprintf(stderr, "[adh] score_candidates n=%lld: upload %.2f ms, output alloc+memset %.2f, plan+launch %.2f, "
-                        "kernels %.2f, D2H %.2f, free %.2f\n", (long long)n, t_1 - t_0, t_2 - t_1, t_3 - t_2,
-                t_4 - t_3, t_5 - t_4, now() - t_5);
-    return rc;
-}
+#include "adh_score_host.hip"
+#include "adh_comm.hip"
 
 namespace {
 

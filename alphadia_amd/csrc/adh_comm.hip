@@ -1,0 +1,217 @@
+// adh_comm.hip - the one collective of the path: an RCCL all-gather of the packed score/feature
+// tables over xGMI, behind the C ABI (included by adh_api.hip inside its extern "C" block).
+//
+// Score groups are independent (alphadia/search/scoring/containers/score_group.py:66-75: disjoint
+// output rows), so every rank scores a contiguous shard of the candidate table and ONE all-gather
+// reassembles the computed tables on every GPU.  librccl is opened with dlopen() when a
+// communicator is created: a single-GPU process never loads it.  One communicator per handle
+// (= per GPU = per process); the collective runs on its own stream so that it overlaps the D2H
+// copies of the same call and the kernels of the next one (two table slots).
+struct adh_comm_state {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;           // the collective's stream
+    hipEvent_t ready = nullptr;             // kernels of the call that feeds the gather
+    hipEvent_t done[2] = {nullptr, nullptr};  // gather of table slot s finished
+    bool pending[2] = {false, false};
+    void *gathered[2] = {nullptr, nullptr};   // [world][wire_bytes] per slot
+    size_t gathered_bytes[2] = {0, 0};
+    size_t wire_bytes[2] = {0, 0};
+    double *d_scalar = nullptr;             // all-reduce scratch
+};
+
+namespace {
+
+int rccl_open(adh_comm_state &c) {
+    if (c.lib) return ADH_OK;
+    const char *names[] = {getenv("ADH_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        if (!nm || !nm[0]) continue;
+        c.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (c.lib) break;
+    }
+    if (!c.lib) return fail(ADH_ERR_UNSUPPORTED, std::string("librccl not found: ") + (dlerror() ? dlerror() : ""));
+#define ADH_RCCL_SYM(field, name)                                                         \
+    c.field = reinterpret_cast<decltype(c.field)>(dlsym(c.lib, name));                    \
+    if (!c.field) return fail(ADH_ERR_UNSUPPORTED, std::string("librccl lacks ") + name)
+    ADH_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    ADH_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    ADH_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    ADH_RCCL_SYM(AllGather, "ncclAllGather");
+    ADH_RCCL_SYM(AllReduce, "ncclAllReduce");
+    ADH_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef ADH_RCCL_SYM
+    return ADH_OK;
+}
+
+#define RCCL_TRY(c, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t _r = (expr);                                                                      \
+        if (_r != ncclSuccess)                                                                         \
+            return fail(ADH_ERR_HIP, std::string(#expr) + ": " + ((c).GetErrorString ? (c).GetErrorString(_r) : "?")); \
+    } while (0)
+
+// before table slot `slot` is overwritten: its previous gather must have read it
+int comm_wait_slot(adh_handle *h, int slot) {
+    adh_comm_state *c = h->comm;
+    if (!c || !c->pending[slot]) return ADH_OK;
+    HIP_TRY(hipEventSynchronize(c->done[slot]));
+    c->pending[slot] = false;
+    return ADH_OK;
+}
+
+// enqueue the all-gather of the wire prefix of table slot `slot` (after everything on the compute stream)
+int comm_gather_slot(adh_handle *h, int slot) {
+    adh_comm_state *c = h->comm;
+    if (!c) return ADH_OK;
+    DevTables &t = h->tables[slot];
+    const size_t need = t.wire_bytes * (size_t)c->world;
+    if (c->gathered_bytes[slot] < need) {
+        if (c->gathered[slot]) (void)hipFree(c->gathered[slot]);
+        c->gathered[slot] = nullptr;
+        c->gathered_bytes[slot] = 0;
+        HIP_TRY(hipMalloc(&c->gathered[slot], std::max<size_t>(need, 256)));
+        c->gathered_bytes[slot] = std::max<size_t>(need, 256);
+    }
+    c->wire_bytes[slot] = t.wire_bytes;
+    HIP_TRY(hipEventRecord(c->ready, h->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
+    RCCL_TRY(*c, c->AllGather(t.base, c->gathered[slot], t.wire_bytes, ncclUint8, c->comm, c->stream));
+    HIP_TRY(hipEventRecord(c->done[slot], c->stream));
+    c->pending[slot] = true;
+    return ADH_OK;
+}
+
+}  // namespace
+
+int adh_comm_unique_id(void *id128) {
+    if (!id128) return fail(ADH_ERR_INVALID_ARGUMENT, "id buffer is NULL");
+    adh_comm_state tmp;
+    int rc = rccl_open(tmp);
+    if (rc != ADH_OK) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(tmp, tmp.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return ADH_OK;  // the library stays loaded (a later adh_comm_init reuses the mapping)
+}
+
+int adh_comm_init(adh_handle_t *h, int rank, int world, const void *id128, int64_t max_rows_per_rank) {
+    if (!h || !id128) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world || max_rows_per_rank < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid rank / world size / row count");
+    if (h->comm) return fail(ADH_ERR_INVALID_ARGUMENT, "the handle already has a communicator");
+    HIP_TRY(hipSetDevice(h->device));
+    adh_comm_state *c = new adh_comm_state();
+    int rc = rccl_open(*c);
+    if (rc != ADH_OK) {
+        delete c;
+        return rc;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = c->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        std::string msg = std::string("ncclCommInitRank: ") + c->GetErrorString(r);
+        delete c;
+        return fail(ADH_ERR_HIP, msg);
+    }
+    c->rank = rank;
+    c->world = world;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_scalar, 2 * sizeof(double));
+    h->comm = c;
+    h->comm_rows = max_rows_per_rank;
+    if (e != hipSuccess) {
+        adh_comm_destroy(h);
+        return fail(ADH_ERR_HIP, std::string("communicator resources: ") + hipGetErrorString(e));
+    }
+    return ADH_OK;
+}
+
+int adh_comm_destroy(adh_handle_t *h) {
+    if (!h || !h->comm) return ADH_OK;
+    adh_comm_state *c = h->comm;
+    (void)hipSetDevice(h->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)c->CommDestroy(c->comm);
+    for (int s = 0; s < 2; ++s) {
+        if (c->gathered[s]) (void)hipFree(c->gathered[s]);
+        if (c->done[s]) (void)hipEventDestroy(c->done[s]);
+    }
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    h->comm = nullptr;
+    h->comm_rows = 0;
+    return ADH_OK;
+}
+
+int adh_comm_wait(adh_handle_t *h) {
+    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!h->comm) return ADH_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    for (int s = 0; s < 2; ++s) {
+        int rc = comm_wait_slot(h, s);
+        if (rc != ADH_OK) return rc;
+    }
+    return ADH_OK;
+}
+
+int adh_comm_gathered(adh_handle_t *h, int rank, adh_output_t *device_view, int64_t *rows) {
+    if (!h || !device_view) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    adh_comm_state *c = h->comm;
+    if (!c || h->last_tables < 0) return fail(ADH_ERR_NOT_STAGED, "no gathered tables");
+    if (rank < 0 || rank >= c->world) return fail(ADH_ERR_INVALID_ARGUMENT, "rank out of range");
+    const int slot = h->last_tables;
+    int rc = comm_wait_slot(h, slot);
+    if (rc != ADH_OK) return rc;
+    const DevTables &t = h->tables[slot];
+    adh_output_t view;
+    memset(&view, 0, sizeof(view));
+    unsigned char *base = static_cast<unsigned char *>(c->gathered[slot]) + (size_t)rank * c->wire_bytes[slot];
+    adh_output_t full;
+    memset(&full, 0, sizeof(full));
+    layout_tables(base, t.rows, t.top_k, &full, nullptr);
+    for (int i = 0; i < kNumOutFields; ++i)
+        if (kOutFields[i].wire) out_member(&view, kOutFields[i]) = out_member(&full, kOutFields[i]);
+    view.n = t.rows;
+    view.top_k = t.top_k;
+    *device_view = view;
+    if (rows) *rows = t.rows;
+    return ADH_OK;
+}
+
+int adh_comm_all_reduce_max(adh_handle_t *h, double *value) {
+    if (!h || !value) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    adh_comm_state *c = h->comm;
+    if (!c) return ADH_OK;  // a single rank: the value is its own maximum
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(*c, c->AllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclFloat64, ncclMax, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ADH_OK;
+}
+
+int adh_comm_barrier(adh_handle_t *h) {
+    double v = 0.0;
+    return adh_comm_all_reduce_max(h, &v);
+}
+
+int adh_device_synchronize(adh_handle_t *h) {
+    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return ADH_OK;
+}

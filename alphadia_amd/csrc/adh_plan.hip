@@ -1,0 +1,295 @@
+// adh_plan.hip - the processing plan of a candidate batch, built ON THE DEVICE.
+//
+// Replaces, together with the host function assemble_candidates (alphadia_amd/scoring.py),
+//   assemble_score_group_container   alphadia/search/scoring/scoring.py:273-353
+//   ScoreGroupContainer.build_from_df alphadia/search/scoring/containers/score_group.py:145-229
+//   the quadrupole overlap test of get_dense  alphadia/search/jitclasses/alpharaw_jit.py:19-50
+//                                             alphadia/search/jitclasses/bruker_jit.py:315-350
+// The reference creates one jitclass object per candidate on the host.  Here the candidate
+// columns are uploaded as they are (struct of arrays, the dtypes of the reference) and one thread
+// per candidate
+//   * checks every bound the scoring kernels rely on (an offending row sets an error code; the
+//     host refuses the batch before any scoring kernel runs),
+//   * finds the cycle rows whose isolation window overlaps the precursor ("observations"),
+//   * picks the kernel class (register kernels by cycle count / observation count, or the
+//     generic LDS kernel) and the size of the candidate's scratch block,
+//   * emits a sort key (class, first cycle).
+// A stable radix sort of (key, row) pairs, an exclusive scan of the scratch sizes in sorted order
+// and one scatter produce the CandRec table in processing order; class boundaries, LDS capacities
+// and the scratch size come back to the host in one 128-byte record.  Nothing of this depends on
+// the order of candidates in the input, and the output rows are the input rows.
+#pragma once
+#include "adh_device.h"
+
+#define ADH_CLASS_GENERIC 10
+#define ADH_N_CLASSES 11
+
+// mirrors of the register-kernel limits (adh_features_fast.hip)
+#define ADH_PLAN_FMAX 32
+#define ADH_PLAN_FAST_OMAX 2
+
+// candidate columns in HBM (adh_candidates_t, device copies)
+struct DevCands {
+    const uint32_t *precursor_idx, *frag_start, *frag_stop;
+    const uint8_t *rank, *flags, *charge;  // flags may be NULL
+    const int64_t *scan_start, *scan_stop, *scan_center, *frame_start, *frame_stop, *frame_center;
+    const float *precursor_mz;
+};
+
+// error codes of the validation (first row that shows the highest code is reported)
+enum {
+    ADH_PLAN_OK = 0,
+    ADH_PLAN_ERR_FRAG_SLICE = 1,
+    ADH_PLAN_ERR_FRAME_LIMITS = 2,
+    ADH_PLAN_ERR_CYCLE_BOUNDARY = 3,
+    ADH_PLAN_ERR_SCAN_LIMITS = 4,
+    ADH_PLAN_ERR_ALPHARAW_SCANS = 5,
+    ADH_PLAN_ERR_CHARGE = 6,
+    ADH_PLAN_ERR_TOO_MANY_OBS = 7,
+    ADH_PLAN_ERR_TOO_MANY_MS1 = 8,
+};
+
+struct PlanMeta {
+    int32_t err, pad;
+    int32_t all_k, all_o, all_f, all_n_lib, all_s, all_op;  // maxima over the batch
+    int32_t gen_k, gen_o, gen_f, gen_n_lib;                 // maxima over the generic class
+    uint32_t class_first[ADH_N_CLASSES + 1];                // first processing position of every class
+    uint64_t scratch_bytes;
+};
+
+struct PlanArgs {
+    int64_t row0, n;        // first candidate row of the batch, rows in it
+    int64_t n_frames;       // spectra (AlphaRaw) / frames (ion mobility) of the run
+    int64_t n_lib;          // fragments of the staged library
+    int32_t L;              // cycle length
+    int32_t rows;           // cycle rows (AlphaRaw: L * cycle_scans)
+    int32_t scan_max;       // ion mobility: scans per frame
+    int32_t zeroth;         // ion mobility: 1 when frame 0 is the empty alphatims frame
+    int32_t I;              // isotopes used
+    uint32_t top_k;
+    int32_t fast_cfg, quant_all;
+    int32_t n_cyc_bins;     // first-cycle bins per class in the sort key
+};
+
+namespace plan {
+
+constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
+
+__device__ __forceinline__ void raise_max(int32_t *slot, int32_t v) {
+    if (v > *reinterpret_cast<volatile int32_t *>(slot)) atomicMax(slot, v);
+}
+
+// isotope m/z range -> quadrupole query range exactly as the kernels compute it
+// (candidate.py:151-163,203-205)
+__device__ __forceinline__ void quad_range(float precursor_mz, uint8_t charge, int I, float &q_lo, float &q_hi) {
+    float mn = 0.f, mx = 0.f;
+    for (int k = 0; k < I; ++k) {
+        float m = (float)((double)k * ISOTOPE_DELTA / (double)charge) + precursor_mz;
+        if (k == 0 || m < mn) mn = m;
+        if (k == 0 || m > mx) mx = m;
+    }
+    q_lo = (float)((double)mn - 0.5);
+    q_hi = (float)((double)mx + 0.5);
+}
+
+}  // namespace plan
+
+__global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const double *__restrict__ cyc, PlanArgs p,
+                                                           CandRec *__restrict__ recs, uint32_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ idx, uint64_t *__restrict__ bytes,
+                                                           PlanMeta *__restrict__ meta) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.n) return;
+    const int64_t i = p.row0 + j;
+    CandRec r;
+    memset(&r, 0, sizeof(r));
+    r.precursor_idx = c.precursor_idx[i];
+    r.frag_start = c.frag_start[i];
+    r.frag_stop = c.frag_stop[i];
+    const int64_t fs = c.frame_start[i], fe = c.frame_stop[i], fc = c.frame_center[i];
+    const int64_t ss = c.scan_start[i], se = c.scan_stop[i], sc = c.scan_center[i];
+    r.frame_start = (int32_t)fs;
+    r.frame_stop = (int32_t)fe;
+    r.frame_center = (int32_t)fc;
+    r.scan_start = (int32_t)ss;
+    r.scan_stop = (int32_t)se;
+    r.scan_center = (int32_t)sc;
+    r.precursor_mz = c.precursor_mz[i];
+    r.charge = c.charge[i];
+    r.rank = c.rank[i];
+    r.flags = c.flags ? c.flags[i] : (uint8_t)0;
+    r.row = (uint32_t)i;
+    idx[j] = (uint32_t)j;
+    int cls = ADH_CLASS_GENERIC;
+    uint32_t bin = 0;
+    uint64_t nbytes = 0;
+    if (!(r.flags & ADH_FLAG_SKIP)) {
+        int err = 0;
+        if (r.frag_stop < r.frag_start || (int64_t)r.frag_stop > p.n_lib) err = ADH_PLAN_ERR_FRAG_SLICE;
+        else if (fs < 0 || fe < fs || fe > p.n_frames || fc < 0 || fc >= p.n_frames) err = ADH_PLAN_ERR_FRAME_LIMITS;
+        else if (fs % p.L != 0) err = ADH_PLAN_ERR_CYCLE_BOUNDARY;
+        else if (se - ss != 1 || ss != 0 || sc != 0) err = ADH_PLAN_ERR_ALPHARAW_SCANS;
+        else if (r.charge == 0) err = ADH_PLAN_ERR_CHARGE;
+        int O = 0;
+        if (!err) {
+            float q_lo, q_hi;
+            plan::quad_range(r.precursor_mz, r.charge, p.I, q_lo, q_hi);
+            for (int row = 0; row < p.rows; ++row) {
+                if ((double)q_lo <= cyc[2 * row + 1] && (double)q_hi >= cyc[2 * row]) {
+                    if (O >= ADH_MAX_OBS) {
+                        err = ADH_PLAN_ERR_TOO_MANY_OBS;
+                        break;
+                    }
+                    r.obs[O++] = (uint16_t)row;
+                }
+            }
+        }
+        if (err) {
+            atomicMax(&meta->err, err);
+            r.flags |= ADH_FLAG_SKIP;  // never reaches a scoring kernel: the host refuses the batch
+        } else {
+            r.n_obs = (uint8_t)O;
+            const int64_t nl = (int64_t)r.frag_stop - (int64_t)r.frag_start;
+            r.k_cap = (uint32_t)min((int64_t)p.top_k, nl);
+            const int F = r.frame_stop / p.L - r.frame_start / p.L;
+            // shape handled by the register-resident kernels (adh_features_fast.hip); several
+            // observations only with quant_all
+            const bool fast = p.fast_cfg && O >= 1 && O <= ADH_PLAN_FAST_OMAX && (O == 1 || p.quant_all) && F >= 3 &&
+                              F <= ADH_PLAN_FMAX && r.k_cap <= 16 && p.I <= 4;
+            cls = !fast ? ADH_CLASS_GENERIC : (O == 1 ? max(F - 5, 0) / 4 : 7 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)));
+            bin = (uint32_t)(r.frame_start / p.L);
+            nbytes = adh_scratch_bytes(r.k_cap, O, max(F, 0), p.I);
+            plan::raise_max(&meta->all_k, (int32_t)r.k_cap);
+            plan::raise_max(&meta->all_o, O);
+            plan::raise_max(&meta->all_f, F);
+            plan::raise_max(&meta->all_n_lib, (int32_t)nl);
+            if (cls == ADH_CLASS_GENERIC) {
+                plan::raise_max(&meta->gen_k, (int32_t)r.k_cap);
+                plan::raise_max(&meta->gen_o, O);
+                plan::raise_max(&meta->gen_f, F);
+                plan::raise_max(&meta->gen_n_lib, (int32_t)nl);
+            }
+        }
+    }
+    recs[j] = r;
+    keys[j] = (uint32_t)cls * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
+    bytes[j] = nbytes;
+}
+
+// Ion-mobility plan: observation lists = sorted unique dia_precursor_cycle values of the cycle rows
+// inside the scan range that overlap the fragment / the (-1, -1) precursor quadrupole range.
+__global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const double *__restrict__ cyc,
+                                                              const int32_t *__restrict__ dpc, PlanArgs p,
+                                                              CandRecIM *__restrict__ recs, uint32_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ idx, uint64_t *__restrict__ bytes,
+                                                              PlanMeta *__restrict__ meta) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.n) return;
+    const int64_t i = p.row0 + j;
+    CandRecIM r;
+    memset(&r, 0, sizeof(r));
+    r.precursor_idx = c.precursor_idx[i];
+    r.frag_start = c.frag_start[i];
+    r.frag_stop = c.frag_stop[i];
+    const int64_t fs = c.frame_start[i], fe = c.frame_stop[i], fc = c.frame_center[i];
+    const int64_t ss = c.scan_start[i], se = c.scan_stop[i], sc = c.scan_center[i];
+    r.frame_start = (int32_t)fs;
+    r.frame_stop = (int32_t)fe;
+    r.frame_center = (int32_t)fc;
+    r.scan_start = (int32_t)ss;
+    r.scan_stop = (int32_t)se;
+    r.scan_center = (int32_t)sc;
+    r.precursor_mz = c.precursor_mz[i];
+    r.charge = c.charge[i];
+    r.rank = c.rank[i];
+    r.flags = c.flags ? c.flags[i] : (uint8_t)0;
+    r.row = (uint32_t)i;
+    idx[j] = (uint32_t)j;
+    uint32_t bin = 0;
+    uint64_t nbytes = 0;
+    if (!(r.flags & ADH_FLAG_SKIP)) {
+        int err = 0;
+        const int64_t z = p.zeroth;
+        if (r.frag_stop < r.frag_start || (int64_t)r.frag_stop > p.n_lib) err = ADH_PLAN_ERR_FRAG_SLICE;
+        else if (fs < z || fe < fs || fe > p.n_frames || fc < 0 || fc >= p.n_frames) err = ADH_PLAN_ERR_FRAME_LIMITS;
+        else if ((fs - z) % p.L != 0) err = ADH_PLAN_ERR_CYCLE_BOUNDARY;
+        else if (ss < 0 || se < ss || se > p.scan_max || sc < 0 || sc >= p.scan_max) err = ADH_PLAN_ERR_SCAN_LIMITS;
+        else if (r.charge == 0) err = ADH_PLAN_ERR_CHARGE;
+        if (!err) {
+            float qf_lo, qf_hi;
+            plan::quad_range(r.precursor_mz, r.charge, p.I, qf_lo, qf_hi);
+            const double q_lo = (double)qf_lo, q_hi = (double)qf_hi;
+            uint32_t seen_f[32], seen_p[32];  // bit v: cycle row value v was hit (L <= 1024, checked by the host)
+            for (int w = 0; w < 32; ++w) seen_f[w] = seen_p[w] = 0u;
+            for (int fr = 0; fr < p.L; ++fr)
+                for (int s = (int)ss; s < (int)se; ++s) {
+                    const int64_t rowi = (int64_t)fr * p.scan_max + s;
+                    const double wl = cyc[2 * rowi], wh = cyc[2 * rowi + 1];
+                    const int v = dpc[rowi];
+                    if (q_lo <= wh && q_hi >= wl) seen_f[v >> 5] |= 1u << (v & 31);
+                    if (-1.0 <= wh && -1.0 >= wl) seen_p[v >> 5] |= 1u << (v & 31);
+                }
+            int nf = 0, np = 0;
+            for (int v = 0; v < p.L && !err; ++v) {
+                if (seen_f[v >> 5] >> (v & 31) & 1u) {
+                    if (nf >= ADH_MAX_OBS) err = ADH_PLAN_ERR_TOO_MANY_OBS;
+                    else r.obs[nf++] = (uint16_t)v;
+                }
+                if (seen_p[v >> 5] >> (v & 31) & 1u) {
+                    if (np >= ADH_MAX_MS1_OBS) err = ADH_PLAN_ERR_TOO_MANY_MS1;
+                    else r.ms1_obs[np++] = (uint16_t)v;
+                }
+            }
+            r.n_obs = (uint8_t)nf;
+            r.n_ms1 = (uint8_t)np;
+        }
+        if (err) {
+            atomicMax(&meta->err, err);
+            r.flags |= ADH_FLAG_SKIP;
+            r.n_obs = r.n_ms1 = 0;
+        } else {
+            const int64_t nl = (int64_t)r.frag_stop - (int64_t)r.frag_start;
+            r.k_cap = (uint32_t)min((int64_t)p.top_k, nl);
+            const int z32 = p.zeroth;
+            const int F = max((r.frame_stop - z32) / p.L - (r.frame_start - z32) / p.L, 0);
+            const int S = max(r.scan_stop - r.scan_start, 0);
+            bin = (uint32_t)((r.frame_start - z32) / p.L);
+            nbytes = adh_im_scratch_bytes(r.k_cap, r.n_obs, S, F, p.I, r.n_ms1);
+            plan::raise_max(&meta->all_k, (int32_t)r.k_cap);
+            plan::raise_max(&meta->all_o, (int32_t)r.n_obs);
+            plan::raise_max(&meta->all_f, F);
+            plan::raise_max(&meta->all_s, S);
+            plan::raise_max(&meta->all_op, (int32_t)r.n_ms1);
+            plan::raise_max(&meta->all_n_lib, (int32_t)nl);
+        }
+    }
+    recs[j] = r;
+    keys[j] = (uint32_t)ADH_CLASS_GENERIC * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
+    bytes[j] = nbytes;
+}
+
+__global__ void adh_plan_take_bytes_kernel(const uint64_t *__restrict__ bytes, const uint32_t *__restrict__ idx,
+                                           int64_t n, uint64_t *__restrict__ sorted_bytes) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) sorted_bytes[j] = bytes[idx[j]];
+}
+
+// records into processing order with their scratch offsets; class boundaries; scratch size
+template <typename Rec>
+__global__ void adh_plan_order_kernel(const Rec *__restrict__ recs, const uint32_t *__restrict__ sorted_keys,
+                                      const uint32_t *__restrict__ idx, const uint64_t *__restrict__ offs,
+                                      const uint64_t *__restrict__ sorted_bytes, int64_t n, uint32_t n_cyc_bins,
+                                      Rec *__restrict__ ordered, PlanMeta *__restrict__ meta) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Rec r = recs[idx[j]];
+    r.scratch_off = offs[j];
+    ordered[j] = r;
+    const int cj = (int)(sorted_keys[j] / n_cyc_bins);
+    const int cp = j > 0 ? (int)(sorted_keys[j - 1] / n_cyc_bins) : -1;
+    for (int c = cp + 1; c <= cj; ++c) meta->class_first[c] = (uint32_t)j;
+    if (j == n - 1) {
+        for (int c = cj + 1; c <= ADH_N_CLASSES; ++c) meta->class_first[c] = (uint32_t)n;
+        meta->scratch_bytes = offs[j] + sorted_bytes[j];
+    }
+}

@@ -1,0 +1,738 @@
+// adh_score_host.hip - host side of the scoring entry points (included by adh_api.hip inside
+// its extern "C" block): candidate upload, the device-built plan (adh_plan.hip), kernel
+// launches and the chunked host -> host pipeline of adh_score_candidates.
+//
+// Replaces the harness around the reference's pjit loop:
+//   CandidateScoring.__call__            alphadia/search/scoring/scoring.py:582-661
+//   assemble_score_group_container       alphadia/search/scoring/scoring.py:273-353
+//   _process_score_groups                alphadia/search/scoring/scoring.py:114-137
+// Timeline of one adh_score_candidates call (three HIP streams, two plan slots):
+//   copy-in : H2D columns(c+1) | plan(c+1)                    (while the kernels of chunk c run)
+//   compute : zero tables | gather(c) features(c) | gather(c+1) ...
+//   copy-out:                  D2H tables(c) | D2H tables(c+1) ...
+// The host only waits for the 128-byte plan record of a chunk (class sizes, LDS capacities,
+// validation result) before it launches that chunk's kernels.
+
+namespace {
+
+// adh_comm.hip
+int comm_wait_slot(adh_handle *h, int slot);
+int comm_gather_slot(adh_handle *h, int slot);
+
+struct OutFieldDesc {
+    size_t member;   // offsetof the pointer inside adh_output_t
+    int per_row;     // 1, ADH_NUM_FEATURES, or -1 = top_k
+    int elem;        // bytes per element
+    bool wire;       // travels in the all-gather (computed tables); the others are rebuilt locally
+    bool optional;   // the caller's host pointer may be NULL
+};
+
+// computed tables first: they form the contiguous "wire" prefix of the packed device buffer
+const OutFieldDesc kOutFields[] = {
+    {offsetof(adh_output_t, valid), 1, 1, true, false},
+    {offsetof(adh_output_t, features), ADH_NUM_FEATURES, 4, true, false},
+    {offsetof(adh_output_t, fragment_mz_observed), -1, 4, true, false},
+    {offsetof(adh_output_t, fragment_height), -1, 4, true, false},
+    {offsetof(adh_output_t, fragment_intensity), -1, 4, true, false},
+    {offsetof(adh_output_t, fragment_mass_error), -1, 4, true, false},
+    {offsetof(adh_output_t, fragment_correlation), -1, 4, true, false},
+    {offsetof(adh_output_t, fragment_lib_slot), -1, 2, true, true},
+    {offsetof(adh_output_t, precursor_idx), 1, 4, false, false},
+    {offsetof(adh_output_t, rank), 1, 1, false, false},
+    {offsetof(adh_output_t, fragment_precursor_idx), -1, 4, false, false},
+    {offsetof(adh_output_t, fragment_rank), -1, 1, false, false},
+    {offsetof(adh_output_t, fragment_mz_library), -1, 4, false, false},
+    {offsetof(adh_output_t, fragment_mz), -1, 4, false, false},
+    {offsetof(adh_output_t, fragment_position), -1, 1, false, false},
+    {offsetof(adh_output_t, fragment_number), -1, 1, false, false},
+    {offsetof(adh_output_t, fragment_type), -1, 1, false, false},
+    {offsetof(adh_output_t, fragment_charge), -1, 1, false, false},
+    {offsetof(adh_output_t, fragment_loss_type), -1, 1, false, false},
+    {offsetof(adh_output_t, stat_matched_peaks), 1, 4, false, true},
+};
+constexpr int kNumOutFields = (int)(sizeof(kOutFields) / sizeof(kOutFields[0]));
+
+inline void *&out_member(adh_output_t *o, const OutFieldDesc &f) {
+    return *reinterpret_cast<void **>(reinterpret_cast<unsigned char *>(o) + f.member);
+}
+inline size_t out_row_bytes(const OutFieldDesc &f, int top_k) {
+    return (size_t)(f.per_row < 0 ? top_k : f.per_row) * (size_t)f.elem;
+}
+
+// layout of the packed device tables for `rows` rows: view->... = base + offset; returns total bytes
+size_t layout_tables(unsigned char *base, int64_t rows, int top_k, adh_output_t *view, size_t *wire_bytes) {
+    size_t off = 0, wire = 0;
+    for (int i = 0; i < kNumOutFields; ++i) {
+        const OutFieldDesc &f = kOutFields[i];
+        if (view) out_member(view, f) = base ? (void *)(base + off) : nullptr;
+        off += ((size_t)rows * out_row_bytes(f, top_k) + 255) / 256 * 256;
+        if (f.wire) wire = off;
+    }
+    if (wire_bytes) *wire_bytes = wire;
+    if (view) {
+        view->n = rows;
+        view->top_k = top_k;
+    }
+    return std::max<size_t>(off, 256);
+}
+
+int ensure_tables(adh_handle *h, int slot, int64_t rows, int top_k) {
+    DevTables &t = h->tables[slot];
+    const size_t need = layout_tables(nullptr, rows, top_k, nullptr, nullptr);
+    if (t.bytes < need) {
+        if (t.base) (void)hipFree(t.base);
+        t.base = nullptr;
+        t.bytes = 0;
+        hipError_t e = hipMalloc(&t.base, need);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(output tables): ") + hipGetErrorString(e));
+        }
+        t.bytes = need;
+    }
+    t.used = layout_tables(static_cast<unsigned char *>(t.base), rows, top_k, &t.view, &t.wire_bytes);
+    t.rows = rows;
+    t.top_k = top_k;
+    return ADH_OK;
+}
+
+// ---------------------------------------------------------------- candidate columns in HBM
+struct CandColumn {
+    const void *host;
+    void **dev;
+    size_t elem;
+};
+
+int cand_reserve(adh_handle *h, int64_t n, int32_t n_iso) {
+    CandSlab &s = h->cs;
+    const int64_t rows = std::max<int64_t>(n, 1);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t need = 3 * al((size_t)rows * 4) + 3 * al((size_t)rows) + 6 * al((size_t)rows * 8) +
+                        al((size_t)rows * 4) + al((size_t)rows * (size_t)n_iso * 4);
+    if (s.bytes < need) {
+        HIP_TRY(hipDeviceSynchronize());  // nothing may still read the old slab
+        if (s.base) (void)hipFree(s.base);
+        s.base = nullptr;
+        s.bytes = 0;
+        HIP_TRY(hipMalloc(&s.base, need + need / 8));
+        s.bytes = need + need / 8;
+    }
+    unsigned char *p = static_cast<unsigned char *>(s.base);
+    auto take = [&](size_t b) {
+        unsigned char *q = p;
+        p += al(b);
+        return q;
+    };
+    s.d.precursor_idx = (const uint32_t *)take((size_t)rows * 4);
+    s.d.frag_start = (const uint32_t *)take((size_t)rows * 4);
+    s.d.frag_stop = (const uint32_t *)take((size_t)rows * 4);
+    s.d.rank = (const uint8_t *)take((size_t)rows);
+    s.flags = (uint8_t *)take((size_t)rows);
+    s.d.charge = (const uint8_t *)take((size_t)rows);
+    s.d.scan_start = (const int64_t *)take((size_t)rows * 8);
+    s.d.scan_stop = (const int64_t *)take((size_t)rows * 8);
+    s.d.scan_center = (const int64_t *)take((size_t)rows * 8);
+    s.d.frame_start = (const int64_t *)take((size_t)rows * 8);
+    s.d.frame_stop = (const int64_t *)take((size_t)rows * 8);
+    s.d.frame_center = (const int64_t *)take((size_t)rows * 8);
+    s.d.precursor_mz = (const float *)take((size_t)rows * 4);
+    s.iso = (float *)take((size_t)rows * (size_t)n_iso * 4);
+    s.d.flags = nullptr;
+    s.n = n;
+    s.n_iso_cols = n_iso;
+    return ADH_OK;
+}
+
+// H2D of rows [a, b) of every candidate column, asynchronous on `st`
+int cand_upload_range(adh_handle *h, const adh_candidates_t *c, int64_t a, int64_t b, hipStream_t st) {
+    CandSlab &s = h->cs;
+    if (b <= a) return ADH_OK;
+    s.d.flags = c->flags ? s.flags : nullptr;
+    const size_t iso_w = (size_t)c->n_isotope_cols * 4;
+    const CandColumn cols[] = {
+        {c->precursor_idx, (void **)&s.d.precursor_idx, 4}, {c->frag_start_idx, (void **)&s.d.frag_start, 4},
+        {c->frag_stop_idx, (void **)&s.d.frag_stop, 4},     {c->rank, (void **)&s.d.rank, 1},
+        {c->flags, (void **)&s.flags, 1},                   {c->charge, (void **)&s.d.charge, 1},
+        {c->scan_start, (void **)&s.d.scan_start, 8},       {c->scan_stop, (void **)&s.d.scan_stop, 8},
+        {c->scan_center, (void **)&s.d.scan_center, 8},     {c->frame_start, (void **)&s.d.frame_start, 8},
+        {c->frame_stop, (void **)&s.d.frame_stop, 8},       {c->frame_center, (void **)&s.d.frame_center, 8},
+        {c->precursor_mz, (void **)&s.d.precursor_mz, 4},   {c->isotope_intensity, (void **)&s.iso, iso_w},
+    };
+    for (const CandColumn &col : cols) {
+        if (!col.host) continue;
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(*col.dev) + (size_t)a * col.elem,
+                               static_cast<const unsigned char *>(col.host) + (size_t)a * col.elem,
+                               (size_t)(b - a) * col.elem, hipMemcpyHostToDevice, st));
+    }
+    return ADH_OK;
+}
+
+int check_candidate_args(adh_handle *h, const adh_candidates_t *c) {
+    if (!(h->run_staged || h->tims_staged) || !h->lib_staged)
+        return fail(ADH_ERR_NOT_STAGED, "stage the run and the fragment library first");
+    if (c->n < 0 || c->n_isotope_cols < 1)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid candidate table dimensions");
+    if (c->n > 0x7FFFFFFFll) return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 candidates in one batch");
+    if (c->n > 0 && (!c->precursor_idx || !c->rank || !c->frag_start_idx || !c->frag_stop_idx || !c->scan_start ||
+                     !c->scan_stop || !c->scan_center || !c->frame_start || !c->frame_stop || !c->frame_center ||
+                     !c->charge || !c->precursor_mz || !c->isotope_intensity))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "candidate column is NULL");
+    return ADH_OK;
+}
+
+// ---------------------------------------------------------------- the plan (adh_plan.hip)
+__global__ void adh_plan_init_kernel(PlanMeta *meta, int32_t I) {
+    PlanMeta m;
+    memset(&m, 0, sizeof(m));
+    m.all_k = m.all_o = m.all_f = m.all_n_lib = m.all_s = m.all_op = 1;
+    m.gen_k = m.gen_o = m.gen_f = m.gen_n_lib = 1;
+    (void)I;
+    *meta = m;
+}
+
+int plan_reserve(adh_handle *h, PlanSlot &s, int64_t n, bool im) {
+    if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (!s.h_meta) HIP_TRY(hipHostMalloc((void **)&s.h_meta, sizeof(PlanMeta), hipHostMallocDefault));
+    const size_t rec = im ? sizeof(CandRecIM) : sizeof(CandRec);
+    if (s.cap >= n && s.rec_bytes >= rec) return ADH_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    s.buf.release();
+    s.cap = 0;
+    const int64_t cap = n + n / 8 + 64;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+        s.buf.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    int rc;
+    if ((rc = dev_alloc(&s.recs, (size_t)cap * rec)) != ADH_OK) return rc;
+    if ((rc = dev_alloc(&s.ordered, (size_t)cap * rec)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.keys_in, (size_t)cap * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.keys_out, (size_t)cap * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.idx_in, (size_t)cap * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.idx_out, (size_t)cap * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.bytes, (size_t)cap * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.sorted_bytes, (size_t)cap * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.offs, (size_t)cap * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&s.d_meta, sizeof(PlanMeta))) != ADH_OK) return rc;
+    size_t b_sort = 0, b_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b_sort, s.keys_in, s.keys_out, s.idx_in, s.idx_out, (int)cap, 0, 32,
+                                               h->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b_scan, s.sorted_bytes, s.offs, (int)cap, h->stream));
+    s.cub_bytes = std::max(b_sort, b_scan);
+    if ((rc = dev_alloc(&s.cub_tmp, s.cub_bytes)) != ADH_OK) return rc;
+    s.cap = cap;
+    s.rec_bytes = rec;
+    return ADH_OK;
+}
+
+struct PlanKey {
+    uint32_t top_k_fragments, top_k_isotopes;
+    bool fast_cfg, quant_all;
+};
+
+PlanKey plan_key(const adh_scoring_config_t *cfg) {
+    return PlanKey{cfg->top_k_fragments, cfg->top_k_isotopes,
+                   cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST"), cfg->quant_all != 0};
+}
+
+// enqueue the plan of rows [row0, row0 + n) on `st`; plan_finish() waits for it
+int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int64_t row0, int64_t n, hipStream_t st) {
+    const bool im = h->tims_staged;
+    int rc = plan_reserve(h, s, n, im);
+    if (rc != ADH_OK) return rc;
+    const PlanKey key = plan_key(cfg);
+    PlanArgs p{};
+    p.row0 = row0;
+    p.n = n;
+    p.n_lib = h->n_lib;
+    p.I = (int32_t)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)h->cs.n_iso_cols);
+    p.top_k = cfg->top_k_fragments;
+    p.fast_cfg = key.fast_cfg ? 1 : 0;
+    p.quant_all = key.quant_all ? 1 : 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(adh_plan_init_kernel, dim3(1), dim3(1), 0, st, s.d_meta, p.I);
+    if (im) {
+        p.L = h->tims.cycle_len;
+        p.rows = h->tims.cycle_len;
+        p.scan_max = h->tims.scan_max;
+        p.zeroth = h->tims.zeroth;
+        p.n_frames = h->tims.n_frames;
+        p.n_cyc_bins = (int32_t)std::min<int64_t>(h->tims.n_frames / p.L + 2, 1 << 26);
+        hipLaunchKernelGGL(adh_plan_rec_im_kernel, dim3(blocks), dim3(256), 0, st, h->cs.d, h->tims.cycle, h->tims.dpc, p,
+                           static_cast<CandRecIM *>(s.recs), s.keys_in, s.idx_in, s.bytes, s.d_meta);
+    } else {
+        p.L = h->run.cycle_len;
+        p.rows = h->run.cycle_len * h->run.cycle_scans;
+        p.n_frames = h->run.n_spectra;
+        p.n_cyc_bins = (int32_t)std::min<int64_t>(h->run.n_spectra / p.L + 2, 1 << 26);
+        hipLaunchKernelGGL(adh_plan_rec_kernel, dim3(blocks), dim3(256), 0, st, h->cs.d, h->run.cycle, p,
+                           static_cast<CandRec *>(s.recs), s.keys_in, s.idx_in, s.bytes, s.d_meta);
+    }
+    HIP_TRY(hipGetLastError());
+    int end_bit = 1;
+    while (end_bit < 32 && (1ull << end_bit) < (uint64_t)ADH_N_CLASSES * (uint64_t)p.n_cyc_bins) ++end_bit;
+    size_t tb = s.cub_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s.cub_tmp, tb, s.keys_in, s.keys_out, s.idx_in, s.idx_out, (int)n, 0, end_bit,
+                                               st));
+    hipLaunchKernelGGL(adh_plan_take_bytes_kernel, dim3(blocks), dim3(256), 0, st, s.bytes, s.idx_out, n, s.sorted_bytes);
+    tb = s.cub_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(s.cub_tmp, tb, s.sorted_bytes, s.offs, (int)n, st));
+    if (im)
+        hipLaunchKernelGGL((adh_plan_order_kernel<CandRecIM>), dim3(blocks), dim3(256), 0, st,
+                           static_cast<const CandRecIM *>(s.recs), s.keys_out, s.idx_out, s.offs, s.sorted_bytes, n,
+                           (uint32_t)p.n_cyc_bins, static_cast<CandRecIM *>(s.ordered), s.d_meta);
+    else
+        hipLaunchKernelGGL((adh_plan_order_kernel<CandRec>), dim3(blocks), dim3(256), 0, st,
+                           static_cast<const CandRec *>(s.recs), s.keys_out, s.idx_out, s.offs, s.sorted_bytes, n,
+                           (uint32_t)p.n_cyc_bins, static_cast<CandRec *>(s.ordered), s.d_meta);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s.h_meta, s.d_meta, sizeof(PlanMeta), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s.done, st));
+    return ADH_OK;
+}
+
+int plan_finish(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int64_t row0, int64_t n, Plan &p) {
+    HIP_TRY(hipEventSynchronize(s.done));
+    const PlanMeta &m = *s.h_meta;
+    switch (m.err) {
+        case ADH_PLAN_OK: break;
+        case ADH_PLAN_ERR_FRAG_SLICE: return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+        case ADH_PLAN_ERR_FRAME_LIMITS: return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run");
+        case ADH_PLAN_ERR_CYCLE_BOUNDARY: return fail(ADH_ERR_INVALID_ARGUMENT, "frame_start must sit on a cycle boundary");
+        case ADH_PLAN_ERR_SCAN_LIMITS: return fail(ADH_ERR_INVALID_ARGUMENT, "scan limits outside the staged run");
+        case ADH_PLAN_ERR_ALPHARAW_SCANS:
+            return fail(ADH_ERR_UNSUPPORTED, "AlphaRaw candidates must have scan_start=0, scan_stop=1, scan_center=0");
+        case ADH_PLAN_ERR_CHARGE: return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge is 0");
+        case ADH_PLAN_ERR_TOO_MANY_OBS:
+            return fail(ADH_ERR_UNSUPPORTED, h->tims_staged ? "a precursor overlaps more than 8 cycle rows"
+                                                            : "a precursor overlaps more than 8 isolation windows");
+        default: return fail(ADH_ERR_UNSUPPORTED, "more than 16 unfragmented cycle rows in the scan range");
+    }
+    const PlanKey key = plan_key(cfg);
+    const int I = (int)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)h->cs.n_iso_cols);
+    p = Plan();
+    p.row0 = row0;
+    p.n = n;
+    p.d_recs = h->tims_staged ? nullptr : static_cast<CandRec *>(s.ordered);
+    p.d_recs_im = h->tims_staged ? static_cast<CandRecIM *>(s.ordered) : nullptr;
+    for (int c = 0; c < ADH_N_CLASSES; ++c) p.n_class[c] = (int64_t)m.class_first[c + 1] - (int64_t)m.class_first[c];
+    p.caps_all = Caps{m.all_k, m.all_o, m.all_f, std::max(I, 1), m.all_n_lib, 0, m.all_s, m.all_op};
+    p.caps_generic = h->tims_staged ? p.caps_all : Caps{m.gen_k, m.gen_o, m.gen_f, std::max(I, 1), m.gen_n_lib, 0, 1, 1};
+    p.scratch_bytes = std::max<uint64_t>(m.scratch_bytes, 32);
+    p.top_k_fragments = key.top_k_fragments;
+    p.top_k_isotopes = key.top_k_isotopes;
+    p.fast_ok = key.fast_cfg;
+    p.quant_all = key.quant_all;
+    p.ready = true;
+    return ADH_OK;
+}
+
+// the scratch slab is grow-only and shared by all chunks (their kernels are serialised on one stream)
+int ensure_scratch(adh_handle *h, uint64_t bytes) {
+    if (h->scratch_slab_bytes >= bytes) return ADH_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+    h->scratch_slab = nullptr;
+    h->scratch_slab_bytes = 0;
+    const uint64_t want = bytes + bytes / 4;
+    HIP_TRY(hipMalloc(&h->scratch_slab, want));
+    h->scratch_slab_bytes = want;
+    return ADH_OK;
+}
+
+// fold finished timing triples into the running sums so that the event list stays short
+void fold_timed(adh_handle *h, bool wait) {
+    size_t keep = 0;
+    for (size_t i = 0; i < h->timed.size(); ++i) {
+        adh_handle::Timed &t = h->timed[i];
+        bool done = wait ? (hipEventSynchronize(t.e2) == hipSuccess) : (hipEventQuery(t.e2) == hipSuccess);
+        float a = 0, b = 0;
+        if (done && hipEventElapsedTime(&a, t.e0, t.e1) == hipSuccess && hipEventElapsedTime(&b, t.e1, t.e2) == hipSuccess) {
+            h->sum_gather_ms += a;
+            h->sum_feature_ms += b;
+            ++h->n_timed;
+            h->free_events.push_back(t.e0);
+            h->free_events.push_back(t.e1);
+            h->free_events.push_back(t.e2);
+        } else {
+            h->timed[keep++] = t;
+        }
+    }
+    (void)hipGetLastError();
+    h->timed.resize(keep);
+}
+
+int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_output_t *out, hipStream_t st) {
+    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
+    p.caps_all.stop_phase = 0;
+    if (const char *dbg = getenv("ADH_DEBUG_IM")) p.caps_all.stop_phase = atoi(dbg);
+    const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all);
+    const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all);
+    if (f_lds > 160 * 1024 - ADH_IM_STATIC_LDS || g_lds > 160 * 1024) {
+        char buf[256];
+        snprintf(buf, sizeof(buf),
+                 "ion-mobility tile needs %zu bytes of LDS (K=%d O=%d S=%d F=%d): exceeds 160 KiB", f_lds,
+                 p.caps_all.k, p.caps_all.o, p.caps_all.s, p.caps_all.f);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    int rc = ensure_scratch(h, p.scratch_bytes);
+    if (rc != ADH_OK) return rc;
+    unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
+    adh_handle::Timed t;
+    rc = get_event(h, &t.e0);
+    if (rc == ADH_OK) rc = get_event(h, &t.e1);
+    if (rc == ADH_OK) rc = get_event(h, &t.e2);
+    if (rc != ADH_OK) return rc;
+    const int32_t n_iso = h->cs.n_iso_cols;
+    HIP_TRY(hipEventRecord(t.e0, st));
+    hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, h->tims, h->d_lib,
+                       p.d_recs_im, *cfg, n_iso, d_scratch, *out, p.caps_all);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.e1, st));
+    hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), f_lds, st, h->tims, p.d_recs_im,
+                       h->cs.iso, n_iso, *cfg, d_scratch, *out, p.caps_all);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.e2, st));
+    h->timed.push_back(t);
+    return ADH_OK;
+}
+
+// enqueue gather + feature kernels of one planned batch on `st`
+int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_output_t *out, hipStream_t st) {
+    if (h->timed.size() > 48) fold_timed(h, false);
+    if (p.n == 0) return ADH_OK;
+    if (h->tims_staged) return launch_scoring_im(h, p, cfg, out, st);
+    if (cfg->collect_fragments && p.caps_all.k > out->top_k)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
+    int stop_phase = 0;
+    if (const char *dbg = getenv("ADH_DEBUG_STOP_PHASE")) stop_phase = atoi(dbg);  // developer switch
+
+    Caps gcaps = p.caps_all;
+    if (const char *dbg = getenv("ADH_DEBUG_GATHER")) gcaps.stop_phase = atoi(dbg);
+    const size_t g_lds = adh_gather_lds_bytes(gcaps, h->run.n_ms1_obs);
+    p.caps_generic.stop_phase = stop_phase;
+    const size_t f_lds = adh_feature_lds_bytes(p.caps_generic);
+    if (p.n_class[ADH_CLASS_GENERIC] > 0 && f_lds > 160 * 1024) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "candidate tile needs %zu bytes of LDS (K=%d O=%d F=%d): exceeds 160 KiB", f_lds,
+                 p.caps_generic.k, p.caps_generic.o, p.caps_generic.f);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    if (g_lds > 160 * 1024) return fail(ADH_ERR_UNSUPPORTED, "library slice / MS1 tile too large for the gather kernel");
+    int rc = ensure_scratch(h, p.scratch_bytes);
+    if (rc != ADH_OK) return rc;
+    unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
+
+    adh_handle::Timed t;
+    rc = get_event(h, &t.e0);
+    if (rc == ADH_OK) rc = get_event(h, &t.e1);
+    if (rc == ADH_OK) rc = get_event(h, &t.e2);
+    if (rc != ADH_OK) return rc;
+    const int32_t n_iso = h->cs.n_iso_cols;
+    HIP_TRY(hipEventRecord(t.e0, st));
+    hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, h->run, h->d_lib, p.d_recs, *cfg,
+                       n_iso, d_scratch, *out, gcaps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.e1, st));
+    if (stop_phase != 2) {
+        int64_t n_fast = 0;
+        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) n_fast += p.n_class[c];
+        bool forked = false;
+        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic"
+        const bool run_generic = !(only && only[0] == 'f'), run_fast = !(only && only[0] == 'g');
+        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic) {
+            // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
+            hipStream_t gs = st;
+            if (n_fast > 0) {
+                HIP_TRY(hipEventRecord(h->ev_fork, st));
+                HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                gs = h->side_stream;
+                forked = true;
+            }
+            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[ADH_CLASS_GENERIC]), dim3(ADH_WAVE), f_lds, gs,
+                               h->run, p.d_recs + n_fast, h->cs.iso, n_iso, *cfg, d_scratch, *out, p.caps_generic);
+            HIP_TRY(hipGetLastError());
+            if (forked) HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+        }
+        const unsigned per_block = ADH_WAVE / ADH_GS;
+        int64_t first = 0;
+        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) {
+            if (p.n_class[c] > 0 && run_fast) {
+                const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
+                const CandRec *recs = p.d_recs + first;
+                const int32_t nc = (int32_t)p.n_class[c];
+#define ADH_LAUNCH_FAST(FM, NO)                                                                              \
+    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
+                       nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
+                switch (c) {
+                    case 0: ADH_LAUNCH_FAST(8, 1); break;
+                    case 1: ADH_LAUNCH_FAST(12, 1); break;
+                    case 2: ADH_LAUNCH_FAST(16, 1); break;
+                    case 3: ADH_LAUNCH_FAST(20, 1); break;
+                    case 4: ADH_LAUNCH_FAST(24, 1); break;
+                    case 5: ADH_LAUNCH_FAST(28, 1); break;
+                    case 6: ADH_LAUNCH_FAST(32, 1); break;
+                    case 7: ADH_LAUNCH_FAST(16, 2); break;
+                    case 8: ADH_LAUNCH_FAST(24, 2); break;
+                    default: ADH_LAUNCH_FAST(32, 2); break;
+                }
+#undef ADH_LAUNCH_FAST
+                HIP_TRY(hipGetLastError());
+            }
+            first += p.n_class[c];
+        }
+        if (forked) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    HIP_TRY(hipEventRecord(t.e2, st));
+    h->timed.push_back(t);
+    return ADH_OK;
+}
+
+int check_score_args(adh_handle *h, const adh_scoring_config_t *cfg, const adh_output_t *out) {
+    if (cfg->top_k_fragments == 0 || cfg->top_k_isotopes == 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "top_k_fragments / top_k_isotopes must be > 0");
+    if (out->top_k <= 0) return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k must be > 0");
+    if (h->tims_staged && h->tims.cycle_len > 1024)
+        return fail(ADH_ERR_UNSUPPORTED, "ion-mobility cycles of more than 1024 frames are not supported");
+    return ADH_OK;
+}
+
+int64_t pick_chunk(int64_t n) {
+    // rows per pipeline chunk: large enough to fill the GPU and amortise ~30 launches, small
+    // enough that the first H2D / last D2H (not overlapped) stay short
+    int64_t target = 262144;
+    if (const char *env = getenv("ADH_CHUNK")) target = std::max<int64_t>(atoll(env), 1024);
+    if (n <= target + target / 2) return std::max<int64_t>(n, 1);
+    const int64_t parts = (n + target - 1) / target;
+    return (n + parts - 1) / parts;
+}
+
+}  // namespace
+
+int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
+    if (!h || !c) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_candidate_args(h, c);
+    if (rc != ADH_OK) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    h->plan = Plan();
+    h->cands_uploaded = false;
+    rc = cand_reserve(h, c->n, c->n_isotope_cols);
+    if (rc != ADH_OK) return rc;
+    rc = cand_upload_range(h, c, 0, c->n, h->stream);
+    if (rc != ADH_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->cands_uploaded = true;
+    return ADH_OK;
+}
+
+int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_output_t *out, void *hip_stream) {
+    if (!h || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!h->cands_uploaded) return fail(ADH_ERR_NOT_STAGED, "no candidate table uploaded");
+    if (out->n != h->cs.n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
+    int rc = check_score_args(h, cfg, out);
+    if (rc != ADH_OK) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->cs.n == 0) return ADH_OK;
+    hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's default stream, taken literally
+    // the plan of the uploaded table is kept until the table or the plan-relevant settings change
+    Plan &p = h->plan;
+    const PlanKey key = plan_key(cfg);
+    if (!(p.ready && p.top_k_fragments == key.top_k_fragments && p.top_k_isotopes == key.top_k_isotopes &&
+          p.fast_ok == key.fast_cfg && p.quant_all == key.quant_all)) {
+        p = Plan();
+        rc = plan_enqueue(h, h->slots[0], cfg, 0, h->cs.n, st);
+        if (rc == ADH_OK) rc = plan_finish(h, h->slots[0], cfg, 0, h->cs.n, p);
+        if (rc != ADH_OK) return rc;
+    }
+    return launch_scoring(h, p, cfg, out, st);
+}
+
+int adh_get_stream(adh_handle_t *h, void **hip_stream) {
+    if (!h || !hip_stream) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *hip_stream = (void *)h->stream;
+    return ADH_OK;
+}
+
+int adh_synchronize(adh_handle_t *h) {
+    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ADH_OK;
+}
+
+int adh_kernel_time_ms(adh_handle_t *h, double *gather_ms, double *feature_ms, int64_t *launches, int reset) {
+    if (!h || !gather_ms || !feature_ms || !launches) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    fold_timed(h, true);
+    const int64_t n = h->n_timed;
+    *gather_ms = n ? h->sum_gather_ms / (double)n : 0.0;
+    *feature_ms = n ? h->sum_feature_ms / (double)n : 0.0;
+    *launches = n;
+    if (reset) {
+        h->sum_gather_ms = h->sum_feature_ms = 0.0;
+        h->n_timed = 0;
+    }
+    return ADH_OK;
+}
+
+int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
+                         adh_output_t *out) {
+    if (!h || !c || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (out->n != c->n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
+    int rc = check_candidate_args(h, c);
+    if (rc == ADH_OK) rc = check_score_args(h, cfg, out);
+    if (rc != ADH_OK) return rc;
+    for (int i = 0; i < kNumOutFields; ++i)
+        if (!kOutFields[i].optional && out_member(out, kOutFields[i]) == nullptr)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;  // developer switch: stage times to stderr
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t_0 = now();
+    const int64_t n = c->n;
+    const int top_k = out->top_k;
+    h->plan = Plan();            // the resident table (adh_upload_candidates) is replaced
+    h->cands_uploaded = false;
+    rc = cand_reserve(h, n, c->n_isotope_cols);
+    if (rc != ADH_OK) return rc;
+    // device tables: with a communicator attached the layout is padded to the largest shard and
+    // double-buffered (the all-gather of call i overlaps call i + 1)
+    const int slot = h->comm_attached() ? (h->table_slot ^= 1) : 0;
+    rc = comm_wait_slot(h, slot);
+    if (rc != ADH_OK) return rc;
+    rc = ensure_tables(h, slot, std::max<int64_t>(n, h->comm_attached() ? h->comm_rows : 0), top_k);
+    if (rc != ADH_OK) return rc;
+    DevTables &tab = h->tables[slot];
+    h->last_tables = slot;
+    h->last_rows = n;
+    if (n == 0) return comm_gather_slot(h, slot);
+    adh_output_t dev = tab.view;
+    dev.n = n;
+    hipStream_t sk = h->stream, si = h->stream_in, so = h->stream_out;
+    HIP_TRY(hipMemsetAsync(tab.base, 0, tab.used, sk));
+
+    // chunk boundaries: a short first chunk (its H2D, plan and kernels are the un-overlapped ramp
+    // of the D2H-bound pipeline), then equal chunks
+    const int64_t chunk = pick_chunk(n);
+    std::vector<int64_t> cut{0};
+    if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
+    while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
+    const int64_t n_chunks = (int64_t)cut.size() - 1;
+    const double t_1 = now();
+    const bool dbg_events = timing && atoi(getenv("ADH_DEBUG_TIMING")) >= 2;  // per-chunk D2H spans
+    std::vector<hipEvent_t> dbg;
+    auto fail_sync = [&](int code) {
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        return code;
+    };
+    // Chunk 0: its columns + plan on the copy-in stream.  The columns of ALL later chunks follow in
+    // one go right behind it (one H2D per column): H2D copies issued while the D2H copies of earlier
+    // chunks are in flight slowed those down four-fold for two chunks on MI355X (measured; the
+    // copy engines are shared), whereas one early burst overlaps only the kernels of chunk 0.
+    rc = cand_upload_range(h, c, 0, cut[1], si);
+    if (rc == ADH_OK) rc = plan_enqueue(h, h->slots[0], cfg, 0, cut[1], si);
+    if (rc == ADH_OK && n_chunks > 1) rc = cand_upload_range(h, c, cut[1], n, si);
+    if (rc != ADH_OK) return fail_sync(rc);
+    for (int64_t ci = 0; ci < n_chunks; ++ci) {
+        const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
+        const int ps = (int)(ci & 1);
+        if (ci + 1 < n_chunks) {
+            // plan of the next chunk: the other plan slot is free once the kernels of chunk ci - 1 are done
+            const int64_t a2 = b, b2 = cut[(size_t)ci + 2];
+            if (ci >= 1) HIP_TRY(hipStreamWaitEvent(si, h->ev_k[ps ^ 1], 0));
+            rc = plan_enqueue(h, h->slots[ps ^ 1], cfg, a2, b2 - a2, si);
+            if (rc != ADH_OK) return fail_sync(rc);
+        }
+        Plan p;
+        rc = plan_finish(h, h->slots[ps], cfg, a, b - a, p);
+        if (rc == ADH_OK) rc = launch_scoring(h, p, cfg, &dev, sk);
+        if (rc != ADH_OK) return fail_sync(rc);
+        HIP_TRY(hipEventRecord(h->ev_k[ps], sk));
+        HIP_TRY(hipStreamWaitEvent(so, h->ev_k[ps], 0));
+        if (dbg_events) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, so);
+            dbg.push_back(e0);
+            dbg.push_back(e1);
+        }
+        for (int i = 0; i < kNumOutFields; ++i) {
+            const OutFieldDesc &f = kOutFields[i];
+            void *host = out_member(out, f);
+            if (!host) continue;
+            const size_t rb = out_row_bytes(f, top_k);
+            hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(host) + (size_t)a * rb,
+                                          static_cast<unsigned char *>(out_member(&dev, f)) + (size_t)a * rb,
+                                          (size_t)(b - a) * rb, hipMemcpyDeviceToHost, so);
+            if (e != hipSuccess) {
+                fail(ADH_ERR_HIP, std::string("hipMemcpyAsync D2H: ") + hipGetErrorString(e));
+                return fail_sync(ADH_ERR_HIP);
+            }
+        }
+        if (dbg_events) (void)hipEventRecord(dbg.back(), so);
+    }
+    const double t_2 = now();
+    rc = comm_gather_slot(h, slot);  // after the last chunk's kernels; overlaps the remaining D2H
+    if (rc != ADH_OK) return fail_sync(rc);
+    hipError_t e = hipStreamSynchronize(sk);
+    if (e == hipSuccess) e = hipStreamSynchronize(so);
+    if (e != hipSuccess) {
+        fail(ADH_ERR_HIP, std::string("scoring pipeline: ") + hipGetErrorString(e));
+        return fail_sync(ADH_ERR_HIP);
+    }
+    if (timing)
+        fprintf(stderr, "[adh] score_candidates n=%lld in %lld chunks: setup %.2f ms, enqueue %.2f, drain %.2f\n",
+                (long long)n, (long long)n_chunks, t_1 - t_0, t_2 - t_1, now() - t_2);
+    if (dbg_events) {
+        for (size_t i = 0; i + 1 < dbg.size(); i += 2) {
+            float ms = 0.f, since = 0.f;
+            (void)hipEventElapsedTime(&ms, dbg[i], dbg[i + 1]);
+            (void)hipEventElapsedTime(&since, dbg[0], dbg[i]);
+            fprintf(stderr, "[adh]   chunk %zu: D2H starts %.2f ms after the first, lasts %.2f ms\n", i / 2, since, ms);
+        }
+        for (hipEvent_t e : dbg) (void)hipEventDestroy(e);
+    }
+    return ADH_OK;
+}
+
+int adh_get_device_tables(adh_handle_t *h, adh_output_t *device_view) {
+    if (!h || !device_view) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (h->last_tables < 0) return fail(ADH_ERR_NOT_STAGED, "no adh_score_candidates call has filled the device tables");
+    *device_view = h->tables[h->last_tables].view;
+    device_view->n = h->last_rows;
+    return ADH_OK;
+}
+
+int adh_zero_device_tables(adh_handle_t *h, void *hip_stream) {
+    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (h->last_tables < 0) return fail(ADH_ERR_NOT_STAGED, "no device tables yet");
+    HIP_TRY(hipSetDevice(h->device));
+    DevTables &t = h->tables[h->last_tables];
+    HIP_TRY(hipMemsetAsync(t.base, 0, t.used, (hipStream_t)hip_stream));
+    return ADH_OK;
+}
+
+int adh_copy_to_host(adh_handle_t *h, void *dst, const void *src_device, uint64_t bytes) {
+    if (!h || (bytes > 0 && (!dst || !src_device))) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (bytes > 0) HIP_TRY(hipMemcpy(dst, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
+    return ADH_OK;
+}
+
+int adh_host_alloc(void **ptr, uint64_t bytes) {
+    if (!ptr) return fail(ADH_ERR_INVALID_ARGUMENT, "ptr is NULL");
+    *ptr = nullptr;
+    HIP_TRY(hipHostMalloc(ptr, std::max<size_t>((size_t)bytes, 64), hipHostMallocPortable));
+    return ADH_OK;
+}
+
+int adh_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return ADH_OK;
+}

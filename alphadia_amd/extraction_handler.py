@@ -77,7 +77,7 @@ class HipExtractionHandler:
             fragment_mz_column=self._column_name_handler.get_fragment_mz_column(),
             fwhm_rt=om.fwhm_rt,
             fwhm_mobility=om.fwhm_mobility,
-            device=self._device or 0,
+            device=self._device,
         )
         return selection(thread_count=self._config["general"]["thread_count"])
 
@@ -138,7 +138,7 @@ class HipExtractionHandler:
 
 
 def create_handler(config, optimization_manager, fdr_manager, reporter, column_name_handler,
-                   selection_handler=None):
+                   selection_handler=None, device: int | None = None):
     """What ``ExtractionHandler.create_handler`` returns for ``extraction_backend: hip``."""
     backend = config["search"]["extraction_backend"].lower()
     if backend != "hip":
@@ -148,5 +148,5 @@ def create_handler(config, optimization_manager, fdr_manager, reporter, column_n
     reporter.log_string(f"Using {backend} extraction backend", verbosity="info")
     return HipExtractionHandler(
         config, optimization_manager, fdr_manager, reporter, column_name_handler,
-        selection_handler=selection_handler,
+        selection_handler=selection_handler, device=device,
     )

@@ -386,6 +386,8 @@ def perform_fdr(classifier, available_columns: list[str], df_target: pd.DataFram
         psm_df["proba"] = 1.0
         return psm_df
 
+    if device is not None and getattr(classifier, "device", device) is None:
+        classifier.device = device  # one FDR call stays on one GPU
     classifier.fit(X[train_rows], y[train_rows])
     psm_df["_decoy"] = y
     if competitive:
@@ -401,7 +403,7 @@ def perform_fdr(classifier, available_columns: list[str], df_target: pd.DataFram
         if start_idx == 0:
             start_idx = len(psm_df)
         if df_fragments is not None:
-            psm_df = FragmentCompetition()(psm_df.iloc[:start_idx].copy(), df_fragments, dia_cycle)
+            psm_df = FragmentCompetition(device=device)(psm_df.iloc[:start_idx].copy(), df_fragments, dia_cycle)
 
     psm_df = keep_best(psm_df, group_columns=group_columns, device=device)
     return get_q_values(psm_df, "proba", "_decoy", device=device)

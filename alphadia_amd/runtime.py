@@ -45,6 +45,19 @@ EXPORTED_SYMBOLS = [
     "adh_mlp_fit",
     "adh_mlp_predict",
     "adh_mlp_time_ms",
+    "adh_get_device_tables",
+    "adh_zero_device_tables",
+    "adh_host_alloc",
+    "adh_host_free",
+    "adh_copy_to_host",
+    "adh_comm_unique_id",
+    "adh_comm_init",
+    "adh_comm_destroy",
+    "adh_comm_wait",
+    "adh_comm_gathered",
+    "adh_comm_all_reduce_max",
+    "adh_comm_barrier",
+    "adh_device_synchronize",
 ]
 
 
@@ -80,6 +93,86 @@ def device_count() -> int:
     return n.value
 
 
+class PinnedPool:
+    """Page-locked host buffers (``adh_host_alloc``) handed out as numpy arrays and reused by tag.
+
+    H2D / D2H copies from page-locked memory run asynchronously at the full PCIe rate; allocating
+    it is slow (it pins pages), hence the pool: a buffer is grown, never shrunk, and the array
+    returned for a tag is only valid until the same tag is requested again."""
+
+    def __init__(self):
+        self._bufs: dict[str, tuple[int, int]] = {}
+
+    def empty(self, tag: str, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr, cap = self._bufs.get(tag, (0, 0))
+        if cap < nbytes or ptr == 0:
+            if ptr:
+                lib.adh_host_free(C.c_void_p(ptr))
+                self._bufs.pop(tag, None)
+            want = max(nbytes + nbytes // 8, 64)
+            p = C.c_void_p()
+            _check(lib.adh_host_alloc(C.byref(p), C.c_uint64(want)), "adh_host_alloc")
+            ptr, cap = int(p.value), want
+            self._bufs[tag] = (ptr, cap)
+        if nbytes == 0:
+            return np.empty(shape, dtype=dtype)
+        raw = (C.c_uint8 * nbytes).from_address(ptr)
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def take(self, tag: str, src: np.ndarray, order: np.ndarray | None = None, dtype=None) -> np.ndarray:
+        """``src[order]`` (or a copy of ``src``) written straight into the pooled buffer of ``tag``."""
+        src = np.asarray(src)
+        dtype = np.dtype(dtype or src.dtype)
+        if order is None:
+            out = self.empty(tag, src.shape, dtype)
+            out[...] = src
+            return out
+        out = self.empty(tag, (len(order),) + src.shape[1:], dtype)
+        if src.dtype == dtype and out.size:
+            np.take(src, order, axis=0, out=out)
+        elif out.size:
+            out[...] = src[order]
+        return out
+
+    def close(self):
+        for ptr, _ in self._bufs.values():
+            lib.adh_host_free(C.c_void_p(ptr))
+        self._bufs.clear()
+
+
+def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0) -> bytes:
+    """Hand rank 0's RCCL unique id to the other ranks of this node through a file in /dev/shm
+    (all ranks of a launch share MASTER_PORT and their parent, the launcher)."""
+    import time
+
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.environ.get("ADH_RENDEZVOUS_FILE", os.path.join(base, f"adh_rccl_id_{tag}"))
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        _check(lib.adh_comm_unique_id(buf), "adh_comm_unique_id")
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(buf.raw)
+        os.replace(tmp, path)  # atomic: readers see all 128 bytes or nothing
+        return buf.raw
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) == 128:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise HipBackendError(f"rank {rank}: no RCCL unique id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
 class Context:
     """One GPU: staged run + library + candidate table (an ``adh_handle_t``)."""
 
@@ -90,11 +183,78 @@ class Context:
         self._run_key = None
         self._lib_key = None
         self.n_candidates = 0
+        self.pinned = PinnedPool()
+        self.comm_world = 1
+        self.comm_rank = 0
+        self._rdv_file = None
 
     def close(self):
         if self._h:
             lib.adh_destroy(self._h)
             self._h = C.c_void_p()
+            self.pinned.close()
+
+    # -- multi-GPU (one process per GPU; RCCL behind the C ABI) -------------
+    def comm_init(self, rank: int, world: int, max_rows_per_rank: int, unique_id: bytes | None = None) -> None:
+        """Attach an RCCL communicator: every later ``score_host`` also all-gathers the computed
+        tables of all ranks into HBM (``gathered_tables``)."""
+        uid = unique_id if unique_id is not None else rendezvous_unique_id(rank, world)
+        buf = C.create_string_buffer(bytes(uid), 128)
+        _check(lib.adh_comm_init(self._h, C.c_int(rank), C.c_int(world), buf, C.c_int64(int(max_rows_per_rank))),
+               "adh_comm_init")
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self) -> None:
+        _check(lib.adh_comm_destroy(self._h), "adh_comm_destroy")
+        self.comm_rank, self.comm_world = 0, 1
+
+    def comm_wait(self) -> None:
+        _check(lib.adh_comm_wait(self._h), "adh_comm_wait")
+
+    def barrier(self) -> None:
+        _check(lib.adh_comm_barrier(self._h), "adh_comm_barrier")
+
+    def all_reduce_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        _check(lib.adh_comm_all_reduce_max(self._h, C.byref(v)), "adh_comm_all_reduce_max")
+        return float(v.value)
+
+    def device_synchronize(self) -> None:
+        _check(lib.adh_device_synchronize(self._h), "adh_device_synchronize")
+
+    def _view_to_host(self, view: _abi.Output, rows: int, names=None) -> dict:
+        out = {}
+        for name, (shape, dt) in _abi.output_shapes(rows, int(view.top_k), extras=True).items():
+            if names is not None and name not in names:
+                continue
+            ptr = C.cast(getattr(view, name), C.c_void_p).value
+            if not ptr:
+                continue
+            a = np.empty(shape, dtype=dt)
+            _check(lib.adh_copy_to_host(self._h, a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_uint64(a.nbytes)),
+                   "adh_copy_to_host")
+            out[name] = a
+        return out
+
+    def device_tables(self) -> _abi.Output:
+        """Device view of the tables of the last ``score_host`` call (they stay in HBM)."""
+        view = _abi.Output()
+        _check(lib.adh_get_device_tables(self._h, C.byref(view)), "adh_get_device_tables")
+        return view
+
+    def zero_device_tables(self, stream: int = 0) -> None:
+        _check(lib.adh_zero_device_tables(self._h, C.c_void_p(stream)), "adh_zero_device_tables")
+
+    def device_tables_to_host(self, names=None) -> dict:
+        view = self.device_tables()
+        return self._view_to_host(view, int(view.n), names)
+
+    def gathered_tables(self, rank: int, rows: int | None = None) -> dict:
+        """Host copy of the computed ("wire") tables rank ``rank`` contributed to the last all-gather."""
+        view = _abi.Output()
+        n = C.c_int64(0)
+        _check(lib.adh_comm_gathered(self._h, C.c_int(rank), C.byref(view), C.byref(n)), "adh_comm_gathered")
+        return self._view_to_host(view, int(n.value) if rows is None else int(rows))
 
     def __del__(self):
         try:
@@ -140,11 +300,19 @@ class Context:
         return True
 
     # -- scoring ---------------------------------------------------------
-    def score_host(self, cands: _abi.Marshalled, cfg_jit, with_stats: bool = False) -> dict:
-        """Host table in, host OutputPsmDF arrays out."""
+    def score_host(self, cands: _abi.Marshalled, cfg_jit, with_stats: bool = False,
+                   reuse_buffers: bool = False) -> dict:
+        """Host table in, host OutputPsmDF arrays out (chunked, pipelined H2D / kernels / D2H).
+
+        ``reuse_buffers=True`` writes into this context's page-locked output buffers (full PCIe
+        rate, no allocation): the returned arrays are then only valid until the next such call."""
         n = int(cands.struct.n)
         # the call copies every table back completely: no need to clear the host buffers first
-        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats, zero=False)
+        alloc = (lambda name, shape, dt: self.pinned.empty("out:" + name, shape, dt)) if reuse_buffers else None
+        # production calls (reuse_buffers) fetch exactly the OutputPsmDF tables; the diagnostic columns
+        # (matched-peak counts, library slots) stay in HBM unless asked for
+        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats, zero=False,
+                                          alloc=alloc, with_slots=with_stats or not reuse_buffers)
         cfg = _abi.pack_config(cfg_jit)
         _check(
             lib.adh_score_candidates(self._h, cands.ref(), C.byref(cfg), m_out.ref()),

@@ -287,8 +287,13 @@ def assemble_candidates(
     precursor_mz_column: str,
     score_grouped: bool = False,
     reference_channel: int = -1,
+    pool=None,
 ) -> dict:
     """Candidate table -> struct of arrays in score-group order.
+
+    ``pool`` (a ``runtime.PinnedPool``) places the columns that are uploaded to the GPU in
+    page-locked memory, written directly by the final gather (no extra copy): they are then valid
+    until the next call with the same pool.
 
     Does the work of ``assemble_score_group_container`` (scoring.py:273-353),
     ``calculate_score_groups`` (scoring/utils.py:269-410) and
@@ -343,11 +348,16 @@ def assemble_candidates(
         iso = np.ones((n, 1), dtype=np.float32)  # scoring.py:322-323
 
     order = np.lexsort((cols["precursor_idx"], cols["rank"], decoy, cols["elution_group_idx"]))
+
+    def ordered(name, col):
+        """``col[order]``, in page-locked memory when a pool is given"""
+        return col[order] if pool is None else pool.take("cand:" + name, col, order)
+
     eg, dc, rk, pi = (
         cols["elution_group_idx"][order],
         decoy[order],
-        cols["rank"][order],
-        cols["precursor_idx"][order],
+        ordered("rank", cols["rank"]),
+        ordered("precursor_idx", cols["precursor_idx"]),
     )
     if score_grouped and n:
         change = np.ones(n, dtype=bool)
@@ -361,7 +371,8 @@ def assemble_candidates(
             raise ValueError("precursor_idx must be unique within a score group")
 
     ch = channel[order]
-    flags = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8) if pool is None else pool.empty("cand:flags", (n,), np.uint8)
+    flags[...] = 0
     if reference_channel >= 0 and n:
         has_ref = np.zeros(int(score_group_idx[-1]) + 1, dtype=bool)
         has_ref[score_group_idx[ch == reference_channel]] = True
@@ -378,14 +389,14 @@ def assemble_candidates(
         "precursor_idx": pi,
         "rank": rk,
         "flags": flags,
-        "frag_start_idx": frag_start[order],
-        "frag_stop_idx": frag_stop[order],
-        "charge": charge[order],
-        "precursor_mz": prec_mz[order],
-        "isotope_intensity": np.ascontiguousarray(iso[order]),
+        "frag_start_idx": ordered("frag_start_idx", frag_start),
+        "frag_stop_idx": ordered("frag_stop_idx", frag_stop),
+        "charge": ordered("charge", charge),
+        "precursor_mz": ordered("precursor_mz", prec_mz),
+        "isotope_intensity": ordered("isotope_intensity", np.ascontiguousarray(iso)),
     }
     for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center"):
-        out[c] = cols[c][order]
+        out[c] = ordered(c, cols[c])
     return out
 
 
@@ -565,10 +576,11 @@ class HipCandidateScoring:
     def dia_data(self):
         return self._dia_data
 
-    def score_soa(self, soa: dict, with_stats: bool = False) -> OutputPsmDF:
-        """Run the kernels on an assembled candidate SoA; returns host OutputPsmDF."""
+    def score_soa(self, soa: dict, with_stats: bool = False, reuse_buffers: bool = False) -> OutputPsmDF:
+        """Run the kernels on an assembled candidate SoA; returns host OutputPsmDF.
+        ``reuse_buffers``: results live in the context's page-locked buffers until the next call."""
         arrays = self._ctx.score_host(
-            pack_assembled(soa), self.config.to_jitclass(), with_stats=with_stats
+            pack_assembled(soa), self.config.to_jitclass(), with_stats=with_stats, reuse_buffers=reuse_buffers
         )
         return OutputPsmDF(arrays)
 
@@ -594,11 +606,13 @@ class HipCandidateScoring:
             self.precursor_mz_column,
             score_grouped=self.config.score_grouped,
             reference_channel=self.config.reference_channel,
+            pool=self._ctx.pinned,
         )
         if debug:  # scoring.py:628-631: first 10 score groups only
             keep = soa["score_group_idx"] < 10
             soa["flags"] = np.where(keep, soa["flags"], _abi.FLAG_SKIP).astype(np.uint8)
-        psm_proto_df = self.score_soa(soa)
+        # the frames below copy what they need out of the pooled page-locked tables
+        psm_proto_df = self.score_soa(soa, reuse_buffers=True)
         logger.info("Collecting candidate features")
         features_df = collect_candidates(
             candidates_df,

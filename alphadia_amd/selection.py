@@ -99,7 +99,7 @@ class HipCandidateSelection:
     def __init__(self, dia_data, precursors_flat: pd.DataFrame, fragments_flat: pd.DataFrame,
                  config: CandidateSelectionConfig, rt_column: str, mobility_column: str,
                  precursor_mz_column: str, fragment_mz_column: str, fwhm_rt: float = 5.0,
-                 fwhm_mobility: float = 0.012, device: int = 0) -> None:
+                 fwhm_mobility: float = 0.012, device: int | None = None) -> None:
         self.dia_data = dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
         self.precursors_flat = precursors_flat.sort_values("precursor_idx").reset_index(drop=True)
         self.fragments_flat = fragments_flat

@@ -2,21 +2,34 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): precursors scored / s.  A "step" is one pass of the hot
-path over the rank's candidate batch: zero the output tables, run the scoring
-kernel on the candidate table that is already resident in HBM and - for N > 1 -
-reassemble the tables with ONE RCCL all-gather.  Workload at N = 1 is
-BASELINE.json configs[1] (100k-precursor predicted library x 3 candidates vs the
-2 h synthetic run T120); with N GPUs every rank keeps that amount of work
-(weak scaling: N x 100k precursors, run and library replicated per GPU).
+Metric (BASELINE.json): precursors scored / s on the 1e6-precursor predicted library (3 candidates
+per precursor = 3e6 candidates) against the 2 h synthetic DIA run (4800 cycles x 61 spectra, 4.9e8
+peaks).  N = 1 scores the whole library on one GPU; N > 1 shards THE SAME library by contiguous
+score-group ranges over the ranks (strong scaling) and reassembles the computed tables in HBM with
+ONE RCCL all-gather over xGMI per step.
+
+A "step" is one pass of the hot path over the rank's candidate shard in the region SURVEY.md
+section 8(d) / BASELINE.md section 2 define (the reference's region is CandidateScoring.__call__
+between assembling the SoA and collecting DataFrames, search/scoring/scoring.py:634-643):
+
+    host candidate SoA -> H2D -> plan (on the device) -> gather + feature kernels
+                       -> [all-gather of the computed tables] -> D2H -> host OutputPsmDF SoA
+
+through ONE C-ABI call (adh_score_candidates: chunked, H2D / kernels / D2H overlap on three
+streams).  The run and the fragment library are staged in HBM once (reported, excluded).  No torch
+anywhere in this file: device memory, streams and the communicator live behind the C ABI.
 
 The JSON line also carries
-  roofline     - algorithmic bytes (SURVEY.md section 8d formula) / average kernel
-                 duration (HIP events on the launch stream) vs the 8 TB/s HBM peak
-  cpu_baseline - the CPU oracle (oracle/, a C++ restatement of the reference's
-                 Numba path) timed on this host's cores on a bounded sample of the
-                 same candidates (rank 0, N = 1 only).  Checker code is used here
-                 only as the thing timed beside the GPU, never in the GPU path.
+  resident      - the same step with the candidate table and its plan already resident in HBM and
+                  the tables left in HBM (kernels + zero fill only)
+  roofline      - algorithmic bytes (SURVEY.md section 8d formula) / kernel time per step (HIP
+                  events on the launch stream) vs the 8 TB/s HBM peak
+  cpu_baseline  - the CPU oracle (oracle/, a C++ restatement of the reference's Numba path) timed on
+                  this host's cores over the same host -> host region on a bounded sample of the
+                  same candidates (rank 0, N = 1 only), at 1 thread and at the fastest thread count.
+                  Checker code is used here only as the thing timed beside the GPU.
+  small_batches - host -> host latency at the batch sizes of the reference's optimisation loop
+                  (optimization_lock.py:72-108: 8 000 elution groups, doubling)
 """
 
 from __future__ import annotations
@@ -76,47 +89,40 @@ def algorithmic_bytes(dia, soa, cfg, matched_peaks, lib_slice_len):
     return per
 
 
+def pinned_shard(ctx, soa: dict, a: int, b: int) -> dict:
+    """Rows [a, b) of the assembled SoA with the uploaded columns in page-locked memory."""
+    n = len(soa["precursor_idx"])
+    out = {}
+    for k, v in soa.items():
+        if isinstance(v, np.ndarray) and v.shape[:1] == (n,):
+            out[k] = ctx.pinned.take("cand:" + k, v[a:b])
+        else:
+            out[k] = v
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precursors-per-gpu", type=int, default=100_000)
+    ap.add_argument("--precursors", type=int, default=1_000_000,
+                    help="library size (total, sharded over the ranks); BASELINE headline = 1e6")
     ap.add_argument("--cycles", type=int, default=4800)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="debug: every rank uses cuda:0 (smoke-test the N>1 path on a 1-GPU box; "
-                         "needs --backend gloo)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch / selection legs")
+    ap.add_argument("--pageable", action="store_true", help="host buffers in pageable memory (for comparison)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    import torch
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` for N > 1")
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    from alphadia_amd import runtime, synthetic as syn
-    from alphadia_amd.distributed import DeviceTables, all_gather_tables, shard_bounds, slice_soa
+    from alphadia_amd import _abi, runtime, synthetic as syn
+    from alphadia_amd.distributed import shard_bounds
     from alphadia_amd.scoring import (
         CandidateScoringConfig,
         assemble_candidates,
@@ -124,17 +130,17 @@ def main():
         pack_assembled,
     )
 
-    # ---------------- workload: configs[1] per GPU ----------------
-    n_prec_total = args.precursors_per_gpu * world
+    if runtime.device_count() <= local_rank:
+        raise SystemExit(f"bench.py needs an MI355X for local rank {local_rank}")
+    ctx = runtime.get_context(local_rank)
+
+    # ---------------- workload: the 1e6-precursor library, sharded over the ranks ----------------
+    n_prec_total = args.precursors
     t0 = time.time()
     threads = max(1, (os.cpu_count() or 8) // max(world, 1))
     case = syn.make_case(n_prec_total, args.cycles, config_id=2, per_precursor=3, threads=threads)
     log(f"[bench] synthetic run: {case.dia.n_spectra} spectra, {case.dia.mz_values.size/1e6:.1f}M peaks, "
         f"{len(case.candidates_df)} candidates, generated in {time.time()-t0:.1f}s ({threads} threads)")
-    if os.environ.get("ADH_BENCH_DEBUG"):
-        print(f"[debug] rank {rank} mz checksum {float(case.dia.mz_values[::1000].astype(np.float64).sum())} "
-              f"int checksum {float(case.dia.intensity_values[::1000].astype(np.float64).sum())} "
-              f"cand checksum {int(case.candidates_df['frame_start'].sum())}", file=sys.stderr, flush=True)
     cfg = CandidateScoringConfig()
     # ClassicExtractionHandler defaults (extraction_handler.py:370-376,400-409; default.yaml:158-199)
     cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1,
@@ -142,50 +148,39 @@ def main():
                     quant_window=3, quant_all=True, experimental_xic=True, top_k_fragments=12))
     cfgj = cfg.to_jitclass()
     soa_all = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
-    a, b = shard_bounds(soa_all["score_group_idx"], rank, world)
-    soa = slice_soa(soa_all, a, b)
+    n_all = len(soa_all["precursor_idx"])
+    bounds = [shard_bounds(soa_all["score_group_idx"], r, world) for r in range(world)]
+    a, b = bounds[rank]
     n_local = b - a
+    max_rows = max(e - s for s, e in bounds)
+    if args.pageable:
+        from alphadia_amd.distributed import slice_soa
+
+        soa = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in slice_soa(soa_all, a, b).items()}
+    else:
+        soa = pinned_shard(ctx, soa_all, a, b)
     n_prec_local = len(np.unique(soa["precursor_idx"]))
 
     # ---------------- staging (one-time, excluded from the metric) ----------------
-    ctx = runtime.get_context(local_rank)
     t0 = time.time()
     ctx.stage_run(case.dia)
     ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"))
     t_stage = time.time() - t0
-    t0 = time.time()
-    ctx.upload_candidates(pack_assembled(soa))
-    t_upload = time.time() - t0
-    log(f"[bench] staged run+library in {t_stage:.2f}s, candidates uploaded in {t_upload:.3f}s")
+    log(f"[bench] staged run+library in {t_stage:.2f}s")
+    if world > 1:
+        ctx.comm_init(rank, world, max_rows)
 
-    n_rows = -(-len(soa_all["precursor_idx"]) // world)  # pad to the largest shard
-    # one explicit (non-default) torch stream carries the memset and the kernels; with N > 1 the
-    # all-gather of step i (RCCL, its own stream) overlaps the kernels of step i+1 through two
-    # table buffers (alphadia_amd.distributed.PipelinedGather)
-    from alphadia_amd.distributed import PipelinedGather
-
-    pg = PipelinedGather(n_rows, int(cfgj.top_k_fragments), device, world, with_stats=True)
-    if os.environ.get("ADH_BENCH_NO_OVERLAP"):
-        pg.overlap = False
-    outs = [t.as_output(n_local) for t in pg.tables]
-    work_stream = torch.cuda.Stream(device=device)
-    stream = work_stream.cuda_stream
+    packed = pack_assembled(soa)
+    reuse = not args.pageable
 
     def step():
-        with torch.cuda.stream(work_stream):
-            tables = pg.begin()
-            tables.zero_()
-            ctx.score_uploaded(cfgj, outs[pg.slot], stream)
-            pg.end()
+        return ctx.score_host(packed, cfgj, reuse_buffers=reuse)
 
     def fence():
-        with torch.cuda.stream(work_stream):
-            out = pg.finish()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return out
+        ctx.comm_wait()           # the all-gather of the last step
+        ctx.device_synchronize()
+        ctx.barrier()
+        ctx.device_synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -193,37 +188,56 @@ def main():
     ctx.kernel_time_ms(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    gathered = fence()
+        host = step()
+    fence()
     elapsed = time.perf_counter() - t0
-    tables = pg.tables[pg.slot]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctx.all_reduce_max(elapsed)
     gather_ms, feature_ms, launches = ctx.kernel_time_ms(reset=True)
+    per_step = launches / max(args.steps, 1)
+    gather_ms, feature_ms = gather_ms * per_step, feature_ms * per_step
     kernel_ms = gather_ms + feature_ms
 
     # ---------------- results of the last step (sanity + roofline inputs) ----------------
-    host = tables.to_host()
     valid = host["valid"][:n_local].astype(bool)
     print(f"[bench] rank {rank}: {int(valid.sum())}/{n_local} candidates valid", file=sys.stderr, flush=True)
-    matched = host["stat_matched_peaks"][:n_local]
+    matched = ctx.device_tables_to_host(names=["stat_matched_peaks"])["stat_matched_peaks"][:n_local]
+    features_last = host["features"].copy() if world == 1 else None
     if world > 1:
-        # every rank must now hold every rank's tables: compare the valid counts
-        counts = torch.zeros(world, dtype=torch.int64, device=device)
-        counts[rank] = int(valid.sum())
-        dist.all_reduce(counts)
-        got = [int(tables.to_host(gathered[r])["valid"].sum()) for r in range(world)]
-        assert got == [int(c) for c in counts.tolist()], (got, counts.tolist())
+        # every rank must now hold every rank's computed tables: its own slice must equal its host tables
+        mine = ctx.gathered_tables(rank, rows=n_local)
+        assert np.array_equal(mine["valid"], host["valid"]), "gathered tables differ from the local ones"
+        assert np.array_equal(mine["features"], host["features"], equal_nan=True)
+        peer = (rank + 1) % world
+        got = ctx.gathered_tables(peer, rows=bounds[peer][1] - bounds[peer][0])
+        assert got["valid"].any(), f"rank {rank}: the tables gathered from rank {peer} are empty"
 
     lib_len = (soa["frag_stop_idx"].astype(np.int64) - soa["frag_start_idx"].astype(np.int64))
     per_cand_bytes = algorithmic_bytes(case.dia, soa, cfgj, matched, lib_len)
     bytes_per_launch = float(per_cand_bytes.sum())
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
-    total_prec = n_prec_total
-    value = total_prec * args.steps / elapsed
+    # ---------------- the same step with table and plan resident in HBM, outputs left in HBM ----------------
+    ctx.upload_candidates(packed)
+    view = ctx.device_tables()
+    stream = ctx.stream_handle()
+    resident_ms = None
+    try:
+        for _ in range(2):
+            ctx.zero_device_tables(stream)
+            ctx.score_uploaded(cfgj, view, stream)
+        ctx.synchronize()
+        reps_r = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(reps_r):
+            ctx.zero_device_tables(stream)
+            ctx.score_uploaded(cfgj, view, stream)
+        ctx.synchronize()
+        resident_ms = (time.perf_counter() - t0) / reps_r * 1e3
+        ctx.kernel_time_ms(reset=True)
+    except runtime.HipBackendError as exc:
+        log(f"[bench] resident leg skipped: {exc}")
+
+    value = n_prec_total * args.steps / elapsed
     result = {
         "metric": "precursors scored/sec",
         "value": value,
@@ -233,27 +247,35 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32/f64",
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1] per GPU: {args.precursors_per_gpu // 1000}k-precursor predicted library x 3 "
-                        f"candidates vs {'2h ' if args.cycles == 4800 else ''}synthetic Thermo-style DIA run "
-                        f"({args.cycles} cycles x 61 spectra)",
-            "precursors_total": total_prec,
-            "candidates_total": int(len(soa_all["precursor_idx"])),
+            "workload": f"{n_prec_total}-precursor predicted library x 3 candidates vs "
+                        f"{'2h ' if args.cycles == 4800 else ''}synthetic Thermo-style DIA run "
+                        f"({args.cycles} cycles x 61 spectra); BASELINE configs[2] "
+                        f"{'on one GPU' if world == 1 else f'sharded over {world} GPUs'}",
+            "timed_region": "host candidate SoA -> H2D -> device plan -> gather + feature kernels -> "
+                            + ("RCCL all-gather of the computed tables -> " if world > 1 else "")
+                            + "D2H -> host OutputPsmDF SoA (one adh_score_candidates call per step)",
+            "host_buffers": "pageable" if args.pageable else "page-locked (adh_host_alloc)",
+            "precursors_total": n_prec_total,
+            "candidates_total": int(n_all),
             "candidates_per_gpu": int(n_local),
             "cycles": args.cycles,
             "peaks": int(case.dia.mz_values.size),
-            "parallelism": (f"candidate-sharded x{world}, tables all-gathered "
-                            f"({'overlapped with the next step' if pg.overlap else 'synchronous'})")
-            if world > 1 else "single GPU",
+            "parallelism": (f"score-group shards x{world}, computed tables all-gathered over RCCL "
+                            f"(overlaps the D2H of the same step and the next step)") if world > 1 else "single GPU",
             "valid_fraction": float(valid.mean()) if n_local else 0.0,
-            "candidates_per_s": float(len(soa_all["precursor_idx"]) * args.steps / elapsed),
-            "gathered_bytes_per_candidate": pg.tables[0].wire_nbytes / max(n_rows, 1),
+            "candidates_per_s": float(n_all * args.steps / elapsed),
             "stage_seconds": t_stage,
-            "candidate_upload_seconds": t_upload,
+        },
+        "resident": None if resident_ms is None else {
+            "ms_per_step": resident_ms,
+            "value": n_prec_local / (resident_ms * 1e-3) * (world if world > 1 else 1),
+            "unit": "precursors/s",
+            "region": "candidate table + plan resident in HBM -> zero tables + kernels -> tables stay in HBM",
         },
         "roofline": {
             "bound": "hbm",
@@ -262,11 +284,12 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "adh_gather_kernel + feature kernels (adh_feature_fast_kernel<FM,NO>, adh_feature_kernel): the hot path, sum of both",
+            "kernel": "adh_gather_kernel + feature kernels (adh_feature_fast_kernel<FM,NO>, adh_feature_kernel): "
+                      "the hot path, summed over the chunks of one step",
             "kernel_ms": kernel_ms,
             "gather_kernel_ms": gather_ms,
             "feature_kernel_ms": feature_ms,
-            "launches": int(launches),
+            "launches_per_step": per_step,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_per_candidate": bytes_per_launch / max(n_local, 1),
         },
@@ -280,25 +303,31 @@ def main():
         except Exception:
             pass
 
-    # ---------------- the same batch through host buffers (PCIe both ways): reported, never `value` ----
-    if rank == 0 and world == 1:
+    extras = rank == 0 and world == 1 and not args.no_extras
+    # ---------------- small batches: the optimisation loop of the reference ----------------
+    if extras:
         try:
-            packed_all = pack_assembled(soa)
-            ctx.score_host(packed_all, cfgj)  # first call builds the plan
-            t0 = time.perf_counter()
-            reps_h = 3
-            for _ in range(reps_h):
-                ctx.score_host(packed_all, cfgj)
-            th = (time.perf_counter() - t0) / reps_h
-            result["config"]["host_buffers_ms_per_step"] = th * 1e3
-            result["config"]["host_buffers_precursors_per_s"] = n_prec_local / th
+            table = {}
+            from alphadia_amd.distributed import slice_soa
+
+            for n_prec in (8_000, 16_000, 32_000, 64_000, 100_000):
+                m = min(n_local, 3 * n_prec)
+                sub = pack_assembled(slice_soa(soa, 0, m))
+                ctx.score_host(sub, cfgj, reuse_buffers=reuse)
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.score_host(sub, cfgj, reuse_buffers=reuse)
+                table[str(n_prec)] = (time.perf_counter() - t0) / reps * 1e3
+                g, f, nl = ctx.kernel_time_ms(reset=True)
+                table[str(n_prec) + "_kernel_ms"] = (g + f) * nl / (reps + 1)
+            result["config"]["small_batch_host_to_host_ms"] = table
         except Exception as exc:  # the metric does not depend on this leg
-            log(f"[bench] host-buffer leg skipped: {exc}")
+            log(f"[bench] small-batch leg skipped: {exc}")
 
     # ---------------- the step before scoring (candidate selection), reported next to the metric ----
-    if rank == 0 and world == 1:
+    if extras:
         try:
-            from alphadia_amd import _abi
             from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel
 
             scfg = CandidateSelectionConfig()
@@ -318,50 +347,52 @@ def main():
         except Exception as exc:  # the metric does not depend on this leg
             log(f"[bench] selection leg skipped: {exc}")
 
-    # ---------------- CPU baseline: the oracle on this host's cores ----------------
+    # ---------------- CPU baseline: the oracle on this host's cores, same host -> host region ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from alphadia_amd.distributed import slice_soa
         from oracle import oracle
 
         ncpu = os.cpu_count() or 1
         cols = fragment_columns(case.library.fragment_df, "mz_library")
-        # pick the thread count that is fastest on this host (memory-latency bound: more
-        # threads than memory channels x a few does not help)
+        # pick the thread count that is fastest on this host
         best = (0.0, 1)
+        tried = {}
         for th in sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)}):
             probe = min(400 * th, n_local)
-            packed = pack_assembled(slice_soa(soa, 0, probe))
-            oracle.score(case.dia, cols, packed, cfgj, n_threads=th)
+            pk = pack_assembled(slice_soa(soa, 0, probe))
+            oracle.score(case.dia, cols, pk, cfgj, n_threads=th)
             t0 = time.perf_counter()
-            oracle.score(case.dia, cols, packed, cfgj, n_threads=th, reuse=oracle.score.last_buffers)
+            oracle.score(case.dia, cols, pk, cfgj, n_threads=th, reuse=oracle.score.last_buffers)
             rate = probe / (time.perf_counter() - t0)
+            tried[th] = rate
             log(f"[bench] cpu oracle {th:4d} threads: {rate:,.0f} candidates/s")
             if rate > best[0]:
                 best = (rate, th)
         rate, cores = best
         # single-thread rate (the reference's pjit loop at thread_count = 1), short sample
         probe1 = min(1500, n_local)
-        packed1 = pack_assembled(slice_soa(soa, 0, probe1))
-        oracle.score(case.dia, cols, packed1, cfgj, n_threads=1)
+        pk1 = pack_assembled(slice_soa(soa, 0, probe1))
+        oracle.score(case.dia, cols, pk1, cfgj, n_threads=1)
         t0 = time.perf_counter()
-        oracle.score(case.dia, cols, packed1, cfgj, n_threads=1, reuse=oracle.score.last_buffers)
+        oracle.score(case.dia, cols, pk1, cfgj, n_threads=1, reuse=oracle.score.last_buffers)
         rate_1 = probe1 / (time.perf_counter() - t0)
-        all_rate = None
         sample = int(min(n_local, max(2000, rate * args.cpu_seconds)))
         sub = slice_soa(soa, 0, sample)
-        packed = pack_assembled(sub)
-        oracle.score(case.dia, cols, packed, cfgj, n_threads=cores)  # touches the output pages
+        pk = pack_assembled(sub)
+        oracle.score(case.dia, cols, pk, cfgj, n_threads=cores)  # touches the output pages
         reps, dt = 0, 0.0
         while dt < min(args.cpu_seconds, 10.0) or reps == 0:  # repeat the sample for a stable rate
             t0 = time.perf_counter()
-            exp = oracle.score(case.dia, cols, packed, cfgj, n_threads=cores, reuse=oracle.score.last_buffers)
+            exp = oracle.score(case.dia, cols, pk, cfgj, n_threads=cores, reuse=oracle.score.last_buffers)
             dt += time.perf_counter() - t0
             reps += 1
         dt /= reps
         cpu_prec = len(np.unique(sub["precursor_idx"]))
         same_valid = bool(np.array_equal(exp["valid"].astype(bool), valid[:sample]))
-        fe, fg = exp["features"][exp["valid"].astype(bool)], host["features"][:sample][valid[:sample]] if same_valid else None
         max_rel = None
-        if same_valid and fe.size:
+        if same_valid and exp["valid"].any():
+            fe = exp["features"][exp["valid"].astype(bool)]
+            fg = features_last[:sample][valid[:sample]]
             keep = [f for f in range(46) if f not in (8, 9, 41, 42, 45)]  # ppm errors: absolute metric
             fe, fg = fe[:, keep], fg[:, keep]
             d = np.abs(fe.astype(np.float64) - fg) / np.maximum(np.maximum(np.abs(fe), np.abs(fg)), 1e-6)
@@ -372,10 +403,12 @@ def main():
             "unit": "precursors/s",
             "cores": cores,
             "kind": "port",
+            "region": "host candidate SoA -> host OutputPsmDF SoA (the region `value` is timed on)",
             "sample": f"first {sample} candidates ({cpu_prec} precursors) of the same batch, "
-                      f"{reps} x {dt:.2f}s, OpenMP over {cores} threads (fastest of the thread counts tried "
-                      f"on this {ncpu}-thread host)",
-            "candidates_per_s_1_thread": rate_1,
+                      f"{reps} x {dt:.2f}s, static-stride threads over {cores} threads (fastest of the thread "
+                      f"counts tried on this {ncpu}-thread host)",
+            "precursors_per_s_1_thread": rate_1 * cpu_prec / sample,
+            "candidates_per_s_by_threads": {str(k): v for k, v in tried.items()},
             "valid_identical_to_gpu": same_valid,
             "max_rel_feature_diff_vs_gpu": max_rel,
         }
@@ -384,7 +417,8 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
-        dist.destroy_process_group()
+        ctx.comm_wait()
+        ctx.comm_destroy()
 
 
 if __name__ == "__main__":

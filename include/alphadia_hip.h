@@ -228,6 +228,26 @@ int adh_upload_candidates(adh_handle_t *handle, const adh_candidates_t *candidat
 int adh_score_uploaded(adh_handle_t *handle, const adh_scoring_config_t *config,
                        adh_output_t *out_device, void *hip_stream);
 
+/*
+ * Device view of the tables the last adh_score_candidates call filled (they stay in HBM until the
+ * next call): the hand-over to a following on-device stage (classifier, q-values, fragment
+ * competition; alphadia/workflow/peptidecentric/peptidecentric.py:219-243 hands DataFrames over
+ * on the host).  device_view->n is the number of live rows.
+ */
+int adh_get_device_tables(adh_handle_t *handle, adh_output_t *device_view);
+/* zero those tables on `hip_stream` (for callers that refill them with adh_score_uploaded) */
+int adh_zero_device_tables(adh_handle_t *handle, void *hip_stream);
+
+/*
+ * Page-locked host memory for candidate columns and output tables: with it the H2D / D2H copies
+ * of adh_score_candidates run asynchronously at full PCIe rate and overlap the kernels.  Pageable
+ * buffers are accepted everywhere, they are just slower.
+ */
+int adh_host_alloc(void **ptr, uint64_t bytes);
+/* blocking copy of `bytes` bytes from a device pointer of one of the views above to host memory */
+int adh_copy_to_host(adh_handle_t *handle, void *dst, const void *src_device, uint64_t bytes);
+int adh_host_free(void *ptr);
+
 /* The handle's own (non-blocking) stream as a hipStream_t. */
 int adh_get_stream(adh_handle_t *handle, void **hip_stream);
 
@@ -241,6 +261,32 @@ int adh_synchronize(adh_handle_t *handle);
  */
 int adh_kernel_time_ms(adh_handle_t *handle, double *gather_ms, double *feature_ms,
                        int64_t *launches, int reset);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, candidates sharded by contiguous score-group ranges
+ * (score groups are independent, search/scoring/containers/score_group.py:66-75), ONE RCCL
+ * all-gather of the computed tables over xGMI.  librccl is loaded on first use.
+ * ---------------------------------------------------------------------- */
+
+/* 128-byte RCCL unique id (rank 0 creates it; the caller hands it to every rank). */
+int adh_comm_unique_id(void *id128);
+/*
+ * Attach a communicator to the handle.  From now on every adh_score_candidates call lays its
+ * device tables out for `max_rows_per_rank` rows (the largest shard, so that all ranks agree on the
+ * layout) and, once its kernels are enqueued, all-gathers the computed tables of all ranks into
+ * HBM on a stream of its own.  The call returns when the host tables are complete; the gather may
+ * still run and overlaps the next call (two table slots).  adh_comm_wait blocks until it is done.
+ */
+int adh_comm_init(adh_handle_t *handle, int rank, int world, const void *id128, int64_t max_rows_per_rank);
+int adh_comm_destroy(adh_handle_t *handle);
+int adh_comm_wait(adh_handle_t *handle);
+/* Device view of rank `rank`'s computed tables after the last call's gather (waits for it). */
+int adh_comm_gathered(adh_handle_t *handle, int rank, adh_output_t *device_view, int64_t *rows);
+/* max over ranks of *value (in place); also the barrier of the benchmark.  No-op without a communicator. */
+int adh_comm_all_reduce_max(adh_handle_t *handle, double *value);
+int adh_comm_barrier(adh_handle_t *handle);
+/* hipDeviceSynchronize on the handle's GPU. */
+int adh_device_synchronize(adh_handle_t *handle);
 
 /*
  * Fragment competition inside one run (replaces `_compete_for_fragments`,

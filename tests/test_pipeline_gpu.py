@@ -1,0 +1,165 @@
+"""GPU tests of the host -> host pipeline behind ``adh_score_candidates``: chunking, page-locked
+buffers, the plan built on the device, tables left in HBM, the RCCL all-gather (one rank) and the
+invalidation rules of the resident candidate table."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from alphadia_amd import synthetic as syn
+from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
+
+pytestmark = pytest.mark.gpu
+
+TABLES = list(H.OUT_NAMES) + ["stat_matched_peaks", "fragment_lib_slot"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from alphadia_amd import runtime
+
+    return runtime.get_context(0)
+
+
+@pytest.fixture(scope="module")
+def case():
+    return syn.make_case(2500, 400, config_id=2, per_precursor=3, threads=8)
+
+
+def _cfg(**kw):
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True,
+                         experimental_xic=True), **kw))
+    return cfg
+
+
+def _stage(ctx, case):
+    ctx.stage_run(case.dia, force=True)
+    ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"), force=True)
+
+
+def _same(a: dict, b: dict, names=TABLES):
+    for k in names:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("experimental_xic", [True, False])
+def test_chunked_pipeline_is_bitwise_the_single_pass(ctx, case, monkeypatch, experimental_xic):
+    """Chunk boundaries (short first chunk, ragged last one), page-locked or pageable host buffers:
+    every table identical to the one-chunk result."""
+    cfg = _cfg(experimental_xic=experimental_xic).to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    n = len(soa["precursor_idx"])
+    monkeypatch.setenv("ADH_CHUNK", str(10 * n))
+    ref = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+    assert ref["valid"].sum() > n // 4
+    for chunk in (1024, 1777, 4096):
+        monkeypatch.setenv("ADH_CHUNK", str(chunk))
+        got = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+        _same(got, ref)
+        pinned_soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
+        got = ctx.score_host(pack_assembled(pinned_soa), cfg, with_stats=True, reuse_buffers=True)
+        _same(got, ref)
+
+
+def test_device_plan_matches_oracle_on_mixed_classes(ctx, oracle_lib, monkeypatch):
+    """Candidates of every kernel class (cycle counts 3..40, one and two observations, short library
+    slices, skipped score groups) in one table, several chunks: the device-built plan routes each
+    to its kernel and the rows come back in input order."""
+    g = H.load_scoring_golden("edges")
+    monkeypatch.setenv("ADH_CHUNK", "1024")
+    cfg = g.config
+    soa = H.soa_for(g, cfg)
+    _stage(ctx, g)
+    got = ctx.score_host(pack_assembled(soa), cfg.to_jitclass(), with_stats=True)
+    exp, _ = H.oracle_score(oracle_lib, g, cfg, soa=soa, with_stats=True)
+    assert np.array_equal(got["valid"], exp["valid"])
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"])
+    v = exp["valid"].astype(bool)
+    assert H.rel_err(got["features"][v][:, [0, 1, 2, 3, 17, 20, 28]], exp["features"][v][:, [0, 1, 2, 3, 17, 20, 28]]).max() == 0
+
+
+def test_tables_stay_in_hbm_and_gather_with_one_rank(ctx, case):
+    """``device_tables`` is the hand-over to an on-device stage; with a communicator attached the
+    computed tables are all-gathered (world = 1: the gathered slice is the rank's own)."""
+    cfg = _cfg().to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    n = len(soa["precursor_idx"])
+    host = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+    dev = ctx.device_tables_to_host()
+    _same(dev, host)
+    from alphadia_amd import runtime
+
+    uid = C.create_string_buffer(128)
+    runtime._check(runtime.lib.adh_comm_unique_id(uid), "adh_comm_unique_id")
+    ctx.comm_init(0, 1, n + 100, unique_id=uid.raw)
+    try:
+        for _ in range(3):  # both table slots, gather of call i overlapping call i + 1
+            host2 = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+        _same(host2, host)
+        ctx.comm_wait()
+        wire = ctx.gathered_tables(0, rows=n)
+        for k in ("valid", "features", "fragment_mz_observed", "fragment_height", "fragment_intensity",
+                  "fragment_mass_error", "fragment_correlation", "fragment_lib_slot"):
+            assert np.array_equal(wire[k], host[k], equal_nan=True), k
+        assert "precursor_idx" not in wire and "fragment_mz" not in wire  # rebuilt locally, never on the wire
+        assert ctx.all_reduce_max(3.5) == 3.5
+        ctx.barrier()
+    finally:
+        ctx.comm_destroy()
+    # the columns that did not travel come back from the candidate table and the staged library
+    from alphadia_amd.distributed import rebuild_local_columns
+
+    full = rebuild_local_columns(wire, soa["precursor_idx"], soa["rank"], soa["flags"], frag_start=soa["frag_start_idx"],
+                                 fragment_cols=fragment_columns(case.library.fragment_df, "mz_library"))
+    _same(full, host, names=H.OUT_NAMES)
+
+
+def test_restaging_invalidates_the_resident_table(ctx, case):
+    """A candidate table uploaded for one run / library must not be scored against another one
+    (its bounds were checked against the old arrays)."""
+    from alphadia_amd.runtime import HipBackendError
+
+    cfg = _cfg().to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    host = ctx.score_host(pack_assembled(soa), cfg)
+    view = ctx.device_tables()
+    ctx.upload_candidates(pack_assembled(soa))
+    ctx.zero_device_tables(ctx.stream_handle())
+    ctx.score_uploaded(cfg, view, ctx.stream_handle())
+    ctx.synchronize()
+    _same(ctx.device_tables_to_host(), host, names=H.OUT_NAMES)
+    small = case.library.fragment_df.iloc[: len(case.library.fragment_df) // 2]
+    ctx.stage_fragments(*fragment_columns(small, "mz_library"), force=True)
+    with pytest.raises(HipBackendError, match="no candidate table uploaded"):
+        ctx.score_uploaded(cfg, view, ctx.stream_handle())
+    ctx.upload_candidates(pack_assembled(soa))
+    with pytest.raises(HipBackendError, match="fragment slice"):  # the plan re-validates against the new library
+        ctx.score_uploaded(cfg, view, ctx.stream_handle())
+    _stage(ctx, case)
+    ctx.upload_candidates(pack_assembled(soa))
+    ctx.stage_run(case.dia, force=True)
+    with pytest.raises(HipBackendError, match="no candidate table uploaded"):
+        ctx.score_uploaded(cfg, view, ctx.stream_handle())
+
+
+def test_event_list_stays_bounded(ctx, case):
+    """Timing events are folded into running sums: many calls without reading the timers do not
+    accumulate events."""
+    cfg = _cfg().to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    sub = {k: (v[:600] if isinstance(v, np.ndarray) and v.shape[:1] == (len(soa["precursor_idx"]),) else v)
+           for k, v in soa.items()}
+    packed = pack_assembled(sub)
+    ctx.kernel_time_ms(reset=True)
+    for _ in range(300):
+        ctx.score_host(packed, cfg, reuse_buffers=True)
+    g, f, n = ctx.kernel_time_ms(reset=True)
+    assert n == 300 and g > 0 and f > 0
