@@ -315,6 +315,22 @@ def pack_candidates(
     return Marshalled(s, [pi, rk, fl, fs, fe, *i64, ch, pm, iso])
 
 
+def output_width(cands: "Marshalled", top_k: int) -> int:
+    """Columns the fragment tables need: ``top_k_fragments`` clamped to the longest library slice
+    of the table.  The reference allocates ``top_k_fragments`` columns literally (output.py:44-70),
+    9999 of them in transfer-library requantification
+    (transfer_library_requantification_handler.py:117-124); the columns beyond the longest slice
+    can never be filled (fragment_container.py:75-90), so the frames built from them are the same."""
+    st = cands.struct
+    n = int(st.n)
+    if n == 0:
+        return max(1, min(int(top_k), 1))
+    start = np.ctypeslib.as_array(st.frag_start_idx, shape=(n,))
+    stop = np.ctypeslib.as_array(st.frag_stop_idx, shape=(n,))
+    longest = int((stop.astype(np.int64) - start.astype(np.int64)).max())
+    return max(1, min(int(top_k), max(longest, 1)))
+
+
 def output_shapes(n: int, top_k: int, extras: bool = False):
     shapes = {}
     for name, dt, w in OUTPUT_FIELDS:

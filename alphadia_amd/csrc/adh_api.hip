@@ -126,6 +126,7 @@ struct adh_handle {
     DevTims tims{};
     bool tims_staged = false;
     std::vector<double> h_cycle;    // host copy (candidate selection sizes its tiles on the host)
+    std::vector<int32_t> h_dpc;     // host copy of dia_precursor_cycle (adh_debug_get_dense)
     const LibRec *d_lib = nullptr;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
@@ -498,6 +499,7 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
     h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);
     h->h_mobility_im.assign(d->mobility_values, d->mobility_values + d->scan_max_index);
+    h->h_dpc = dpc;
     h->tims = t;
     h->tims_staged = true;
     return ADH_OK;

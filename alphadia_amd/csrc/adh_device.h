@@ -142,5 +142,9 @@ struct Caps {
     int32_t stop_phase;  // developer ablation switch (0 = run everything)
     int32_t s;       // scans (ion-mobility kernels only)
     int32_t op;      // MS1 observations (ion-mobility kernels only)
+    // adh_debug_get_dense only (stop_phase == ADH_DEBUG_DENSE): explicit quadrupole range of the
+    // query instead of the one derived from the precursor isotopes; no "<= 3 fragments" exit
+    float dbg_q_lo, dbg_q_hi;
 };
+#define ADH_DEBUG_DENSE 9
 

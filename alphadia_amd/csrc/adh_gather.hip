@@ -175,7 +175,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
     const int c0 = r.frame_start / L, c1 = r.frame_stop / L;
     const int F = c1 - c0;
     const int O = r.n_obs;
-    if (K <= 3 || F <= 0 || O <= 0) {  // candidate.py:190,230 / no overlapping window (:323)
+    if ((K <= 3 && caps.stop_phase != ADH_DEBUG_DENSE) || K <= 0 || F <= 0 || O <= 0) {  // candidate.py:190,230 / no overlapping window (:323)
         if (lane == 0) {
             header[0] = 0;
             header[1] = 0;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     const int S = r.scan_stop - r.scan_start;
     const int O = r.n_obs, Op = r.n_ms1;
     const int I = min(n_iso_cols, (int)cfg.top_k_isotopes);
-    if (K <= 3 || F <= 0 || S <= 0 || O <= 0) {  // candidate.py:190,230; no push matches the quadrupole
+    if ((K <= 3 && caps.stop_phase != ADH_DEBUG_DENSE) || K <= 0 || F <= 0 || S <= 0 || O <= 0) {  // candidate.py:190,230; no push matches the quadrupole
         if (lane == 0) {
             header[0] = 0;
             header[1] = 0;
@@ -152,7 +152,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         iso_min = fminf(iso_min, w_mz[caps.k + i]);
         iso_max = fmaxf(iso_max, w_mz[caps.k + i]);
     }
-    const double fq_lo = (double)(float)((double)iso_min - 0.5), fq_hi = (double)(float)((double)iso_max + 0.5);
+    double fq_lo = (double)(float)((double)iso_min - 0.5), fq_hi = (double)(float)((double)iso_max + 0.5);
+    if (caps.stop_phase == ADH_DEBUG_DENSE) {
+        fq_lo = (double)caps.dbg_q_lo;
+        fq_hi = (double)caps.dbg_q_hi;
+    }
 
     // ---- (window, cycle) tasks
     uint32_t hits = 0;

@@ -709,6 +709,160 @@ int adh_get_device_tables(adh_handle_t *h, adh_output_t *device_view) {
     return ADH_OK;
 }
 
+int adh_debug_get_dense(adh_handle_t *h, int64_t frame_start, int64_t frame_stop, int64_t scan_start, int64_t scan_stop,
+                        const float *mz_query, int32_t n_query, float mass_tolerance, float quad_lo, float quad_hi,
+                        float *dense, int64_t dense_capacity, int32_t *obs_out, int32_t *n_obs, int32_t *n_scans,
+                        int32_t *n_cycles) {
+    if (!h || !mz_query || !dense || !obs_out || !n_obs || !n_scans || !n_cycles)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!h->run_staged && !h->tims_staged) return fail(ADH_ERR_NOT_STAGED, "no run staged");
+    if (n_query < 1 || n_query > 4096) return fail(ADH_ERR_INVALID_ARGUMENT, "n_query must be in 1..4096");
+    HIP_TRY(hipSetDevice(h->device));
+    const bool im = h->tims_staged;
+    const int L = im ? h->tims.cycle_len : h->run.cycle_len;
+    const int z = im ? h->tims.zeroth : 0;
+    const int64_t n_fr = im ? h->tims.n_frames : h->run.n_spectra;
+    if (frame_start < z || frame_stop < frame_start || frame_stop > n_fr || (frame_start - z) % L != 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "frame limits outside the staged run / not on a cycle boundary");
+    const int K = n_query;
+    const int F = (int)((frame_stop - z) / L - (frame_start - z) / L);
+    const int S = im ? (int)(scan_stop - scan_start) : 1;
+    if (im && (scan_start < 0 || scan_stop < scan_start || scan_stop > h->tims.scan_max))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "scan limits outside the staged run");
+    // observations: the quadrupole test of get_dense (alpharaw_jit.py:19-50 / bruker_jit.py:315-350)
+    const double *cyc = h->h_cycle.data();
+    std::vector<uint16_t> obs;
+    if (!im) {
+        for (int row = 0; row < L; ++row)
+            if ((double)quad_lo <= cyc[2 * row + 1] && (double)quad_hi >= cyc[2 * row]) obs.push_back((uint16_t)row);
+    } else {
+        std::vector<uint8_t> seen((size_t)L, 0);
+        for (int fr = 0; fr < L; ++fr)
+            for (int64_t sc = scan_start; sc < scan_stop; ++sc) {
+                const int64_t rowi = (int64_t)fr * h->tims.scan_max + sc;
+                if ((double)quad_lo <= cyc[2 * rowi + 1] && (double)quad_hi >= cyc[2 * rowi]) seen[(size_t)h->h_dpc[(size_t)rowi]] = 1;
+            }
+        for (int v = 0; v < L; ++v)
+            if (seen[(size_t)v]) obs.push_back((uint16_t)v);
+    }
+    const int O = (int)obs.size();
+    if (O > ADH_MAX_OBS) return fail(ADH_ERR_UNSUPPORTED, "the query overlaps more than 8 cycle rows");
+    *n_obs = O;
+    *n_scans = S;
+    *n_cycles = std::max(F, 0);
+    for (int o = 0; o < O; ++o) obs_out[o] = obs[(size_t)o];
+    const int64_t need = 2ll * K * O * S * std::max(F, 0);
+    if (need > dense_capacity) return fail(ADH_ERR_INVALID_ARGUMENT, "dense buffer too small");
+    for (int64_t i = 0; i < need; ++i) dense[i] = 0.0f;
+    if (O == 0 || F <= 0 || S <= 0) return ADH_OK;
+
+    // a one-precursor library whose fragments are the query (all kept: distinct descending intensities)
+    std::vector<LibRec> lib((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        memset(&lib[(size_t)k], 0, sizeof(LibRec));
+        lib[(size_t)k].mz_library = lib[(size_t)k].mz = mz_query[k];
+        lib[(size_t)k].intensity = (float)(K - k);
+        lib[(size_t)k].cardinality = 1;
+    }
+    adh_scoring_config_t cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.collect_fragments = 1;
+    cfg.top_k_fragments = (uint32_t)K;
+    cfg.top_k_isotopes = 1;
+    cfg.reference_channel = -1;
+    cfg.quant_window = 3;
+    cfg.precursor_mz_tolerance = 10.0f;
+    cfg.fragment_mz_tolerance = mass_tolerance;
+    Caps caps{K, O, F, 1, K, ADH_DEBUG_DENSE, S, 0, quad_lo, quad_hi};
+    const uint64_t sbytes = im ? adh_im_scratch_bytes((uint32_t)K, O, S, F, 1, 0) : adh_scratch_bytes((uint32_t)K, O, F, 1);
+    DeviceBuffers tmp;
+    const LibRec *d_lib = nullptr;
+    int rc = upload(tmp, lib.data(), (int64_t)K, &d_lib, h->stream);
+    unsigned char *d_scr = nullptr;
+    uint32_t *d_small = nullptr;  // precursor_idx[1] + rank[1] of the kernel's bookkeeping writes
+    if (rc == ADH_OK) {
+        hipError_t e = hipMalloc((void **)&d_scr, sbytes);
+        if (e == hipSuccess) tmp.ptrs.push_back(d_scr);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_small, 64);
+        if (e == hipSuccess) tmp.ptrs.push_back(d_small);
+        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    adh_output_t out;
+    memset(&out, 0, sizeof(out));
+    out.n = 1;
+    out.top_k = K;
+    out.precursor_idx = d_small;
+    out.rank = reinterpret_cast<uint8_t *>(d_small + 4);
+    hipError_t e = hipSuccess;
+    if (rc == ADH_OK && !im) {
+        CandRec r;
+        memset(&r, 0, sizeof(r));
+        r.frag_stop = (uint32_t)K;
+        r.frame_start = (int32_t)frame_start;
+        r.frame_stop = (int32_t)frame_stop;
+        r.frame_center = (int32_t)frame_start;
+        r.scan_stop = 1;
+        r.precursor_mz = 500.0f;
+        r.charge = 1;
+        r.n_obs = (uint8_t)O;
+        for (int o = 0; o < O; ++o) r.obs[o] = obs[(size_t)o];
+        r.k_cap = (uint32_t)K;
+        const CandRec *d_rec = nullptr;
+        rc = upload(tmp, &r, 1, &d_rec, h->stream);
+        const size_t lds = adh_gather_lds_bytes(caps, h->run.n_ms1_obs);
+        if (rc == ADH_OK && lds > 160 * 1024) rc = fail(ADH_ERR_UNSUPPORTED, "query too large for the gather kernel's LDS");
+        if (rc == ADH_OK) {
+            hipLaunchKernelGGL(adh_gather_kernel, dim3(1), dim3(ADH_WAVE), lds, h->stream, h->run, d_lib, d_rec, cfg, 1,
+                               d_scr, out, caps);
+            e = hipGetLastError();
+        }
+    } else if (rc == ADH_OK) {
+        CandRecIM r;
+        memset(&r, 0, sizeof(r));
+        r.frag_stop = (uint32_t)K;
+        r.frame_start = (int32_t)frame_start;
+        r.frame_stop = (int32_t)frame_stop;
+        r.frame_center = (int32_t)frame_start;
+        r.scan_start = (int32_t)scan_start;
+        r.scan_stop = (int32_t)scan_stop;
+        r.scan_center = (int32_t)scan_start;
+        r.precursor_mz = 500.0f;
+        r.charge = 1;
+        r.n_obs = (uint8_t)O;
+        for (int o = 0; o < O; ++o) r.obs[o] = obs[(size_t)o];
+        r.k_cap = (uint32_t)K;
+        const CandRecIM *d_rec = nullptr;
+        rc = upload(tmp, &r, 1, &d_rec, h->stream);
+        const size_t lds = adh_gather_im_lds_bytes(caps);
+        if (rc == ADH_OK && lds > 160 * 1024) rc = fail(ADH_ERR_UNSUPPORTED, "query too large for the gather kernel's LDS");
+        if (rc == ADH_OK) {
+            hipLaunchKernelGGL(adh_gather_im_kernel, dim3(1), dim3(ADH_WAVE), lds, h->stream, h->tims, d_lib, d_rec, cfg, 1,
+                               d_scr, out, caps);
+            e = hipGetLastError();
+        }
+    }
+    std::vector<unsigned char> host((size_t)sbytes);
+    if (rc == ADH_OK && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (rc == ADH_OK && e == hipSuccess) e = hipMemcpy(host.data(), d_scr, sbytes, hipMemcpyDeviceToHost);
+    tmp.release();
+    if (rc != ADH_OK) return rc;
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("adh_debug_get_dense: ") + hipGetErrorString(e));
+    const uint32_t k_sel = *reinterpret_cast<const uint32_t *>(host.data());
+    if ((int)k_sel != K) return fail(ADH_ERR_HIP, "gather kernel did not keep every query fragment");
+    const float2 *cells = reinterpret_cast<const float2 *>(host.data() + adh_scratch_frag_off((uint32_t)K));
+    const int64_t plane = (int64_t)K * O * S * F;
+    for (int k = 0; k < K; ++k)
+        for (int o = 0; o < O; ++o)
+            for (int sc = 0; sc < S; ++sc)
+                for (int f = 0; f < F; ++f) {
+                    const float2 v = im ? cells[(((int64_t)k * O + o) * S + sc) * F + f] : cells[((int64_t)o * F + f) * K + k];
+                    const int64_t at = (((int64_t)k * O + o) * S + sc) * F + f;
+                    dense[at] = v.x;
+                    dense[plane + at] = v.y;
+                }
+    return ADH_OK;
+}
+
 int adh_zero_device_tables(adh_handle_t *h, void *hip_stream) {
     if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
     if (h->last_tables < 0) return fail(ADH_ERR_NOT_STAGED, "no device tables yet");

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "adh_mlp_time_ms",
     "adh_get_device_tables",
     "adh_zero_device_tables",
+    "adh_debug_get_dense",
     "adh_host_alloc",
     "adh_host_free",
     "adh_copy_to_host",
@@ -143,14 +144,18 @@ class PinnedPool:
         self._bufs.clear()
 
 
+def rendezvous_path() -> str:
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    return os.environ.get("ADH_RENDEZVOUS_FILE", os.path.join(base, f"adh_rccl_id_{tag}"))
+
+
 def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0) -> bytes:
     """Hand rank 0's RCCL unique id to the other ranks of this node through a file in /dev/shm
     (all ranks of a launch share MASTER_PORT and their parent, the launcher)."""
     import time
 
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-    path = os.environ.get("ADH_RENDEZVOUS_FILE", os.path.join(base, f"adh_rccl_id_{tag}"))
+    path = rendezvous_path()
     if rank == 0:
         buf = C.create_string_buffer(128)
         _check(lib.adh_comm_unique_id(buf), "adh_comm_unique_id")
@@ -203,6 +208,12 @@ class Context:
         _check(lib.adh_comm_init(self._h, C.c_int(rank), C.c_int(world), buf, C.c_int64(int(max_rows_per_rank))),
                "adh_comm_init")
         self.comm_rank, self.comm_world = int(rank), int(world)
+        if unique_id is None and rank == 0:
+            # communicator creation is collective: every rank has read the id by now
+            try:
+                os.remove(rendezvous_path())
+            except OSError:
+                pass
 
     def comm_destroy(self) -> None:
         _check(lib.adh_comm_destroy(self._h), "adh_comm_destroy")
@@ -241,6 +252,27 @@ class Context:
         view = _abi.Output()
         _check(lib.adh_get_device_tables(self._h, C.byref(view)), "adh_get_device_tables")
         return view
+
+    def debug_get_dense(self, frame_start, frame_stop, mz_query, mass_tolerance, quad_lo, quad_hi,
+                        scan_start: int = 0, scan_stop: int = 1):
+        """The gather kernel's dense tile for one query (test entry): ``(dense[2, K, O, S, F], obs)``
+        as ``get_dense(..., absolute_masses=True)`` returns them (S = 1 for AlphaRaw runs)."""
+        q = _abi.as_c(mz_query, np.float32)
+        cap = 2 * q.shape[0] * 8 * max(int(scan_stop) - int(scan_start), 1) * (int(frame_stop) - int(frame_start) + 1)
+        buf = np.zeros(max(cap, 1), dtype=np.float32)
+        obs = np.zeros(8, dtype=np.int32)
+        n_obs, n_s, n_f = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(
+            lib.adh_debug_get_dense(
+                self._h, C.c_int64(int(frame_start)), C.c_int64(int(frame_stop)), C.c_int64(int(scan_start)),
+                C.c_int64(int(scan_stop)), q.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(q.shape[0]),
+                C.c_float(float(mass_tolerance)), C.c_float(float(quad_lo)), C.c_float(float(quad_hi)),
+                buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(buf.shape[0]),
+                obs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_obs), C.byref(n_s), C.byref(n_f)),
+            "adh_debug_get_dense",
+        )
+        K, O, S, F = q.shape[0], n_obs.value, n_s.value, n_f.value
+        return buf[: 2 * K * O * S * F].reshape(2, K, O, S, F).copy(), obs[:O].astype(np.int64)
 
     def zero_device_tables(self, stream: int = 0) -> None:
         _check(lib.adh_zero_device_tables(self._h, C.c_void_p(stream)), "adh_zero_device_tables")
@@ -311,8 +343,9 @@ class Context:
         alloc = (lambda name, shape, dt: self.pinned.empty("out:" + name, shape, dt)) if reuse_buffers else None
         # production calls (reuse_buffers) fetch exactly the OutputPsmDF tables; the diagnostic columns
         # (matched-peak counts, library slots) stay in HBM unless asked for
-        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats, zero=False,
-                                          alloc=alloc, with_slots=with_stats or not reuse_buffers)
+        m_out, arrays = _abi.alloc_output(n, _abi.output_width(cands, int(cfg_jit.top_k_fragments)),
+                                          with_stats=with_stats, zero=False, alloc=alloc,
+                                          with_slots=with_stats or not reuse_buffers)
         cfg = _abi.pack_config(cfg_jit)
         _check(
             lib.adh_score_candidates(self._h, cands.ref(), C.byref(cfg), m_out.ref()),

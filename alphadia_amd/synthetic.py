@@ -103,7 +103,7 @@ def make_cycle(n_ms2: int = 60, mz_lo: float = 400.0, mz_hi: float = 1000.0) -> 
 def make_library(
     n_precursors: int,
     seed: int,
-    k_fragments: int = 12,
+    k_fragments: int | tuple = 12,
     n_isotopes: int = 4,
     mz_lo: float = 400.0,
     mz_hi: float = 1000.0,
@@ -116,6 +116,9 @@ def make_library(
 
     ``few_fragment_fraction`` > 0 gives that share of precursors only 2-3
     fragments (exercises the "<=3 fragments" early exit, candidate.py:190).
+    ``k_fragments`` = (lo, hi) draws the fragment count of every precursor uniformly from
+    lo..hi (libraries with more than 12 / 16 fragments: transfer-library requantification scores
+    with ``top_k_fragments = 9999``, transfer_library_requantification_handler.py:117-124).
     """
     rng = np.random.default_rng([seed, 1])
     n = int(n_precursors)
@@ -137,7 +140,10 @@ def make_library(
     iso /= iso.sum(axis=1, keepdims=True)
     iso = iso.astype(np.float32)
 
-    n_frag = np.full(n, k_fragments, dtype=np.int64)
+    if isinstance(k_fragments, (tuple, list)):
+        n_frag = np.random.default_rng([seed, 11]).integers(int(k_fragments[0]), int(k_fragments[1]) + 1, n).astype(np.int64)
+    else:
+        n_frag = np.full(n, k_fragments, dtype=np.int64)
     if few_fragment_fraction > 0:
         few = rng.random(n) < few_fragment_fraction
         n_frag[few] = rng.integers(2, 4, few.sum())
@@ -443,6 +449,7 @@ def make_case(
     frag_mz_hi: float = 1800.0,
     ms1_mz_range: tuple = (350.0, 1100.0),
     ms2_mz_range: tuple = (150.0, 1600.0),
+    k_fragments: int | tuple = 12,
 ) -> SyntheticCase:
     """One full synthetic workload (run + library + candidates)."""
     seed = BASE_SEED + config_id if seed is None else seed
@@ -456,6 +463,7 @@ def make_case(
         few_fragment_fraction=few_fragment_fraction,
         frag_mz_lo=frag_mz_lo,
         frag_mz_hi=frag_mz_hi,
+        k_fragments=k_fragments,
     )
     planted = plant_peptides(lib, cycle, n_cycles, seed, fraction=planted_fraction)
     dia = make_thermo_run(

@@ -167,7 +167,8 @@ def main():
     ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"))
     t_stage = time.time() - t0
     log(f"[bench] staged run+library in {t_stage:.2f}s")
-    if world > 1:
+    with_comm = world > 1 or bool(os.environ.get("ADH_BENCH_FORCE_COMM"))  # (debug: the RCCL path on one GPU)
+    if with_comm:
         ctx.comm_init(rank, world, max_rows)
 
     packed = pack_assembled(soa)
@@ -202,7 +203,7 @@ def main():
     print(f"[bench] rank {rank}: {int(valid.sum())}/{n_local} candidates valid", file=sys.stderr, flush=True)
     matched = ctx.device_tables_to_host(names=["stat_matched_peaks"])["stat_matched_peaks"][:n_local]
     features_last = host["features"].copy() if world == 1 else None
-    if world > 1:
+    if with_comm:
         # every rank must now hold every rank's computed tables: its own slice must equal its host tables
         mine = ctx.gathered_tables(rank, rows=n_local)
         assert np.array_equal(mine["valid"], host["valid"]), "gathered tables differ from the local ones"
@@ -416,7 +417,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if with_comm:
         ctx.comm_wait()
         ctx.comm_destroy()
 

@@ -248,6 +248,20 @@ int adh_host_alloc(void **ptr, uint64_t bytes);
 int adh_copy_to_host(adh_handle_t *handle, void *dst, const void *src_device, uint64_t bytes);
 int adh_host_free(void *ptr);
 
+/*
+ * Test entry: the dense tile the gather kernels build for ONE query, i.e. what
+ * AlphaRawJIT.get_dense (search/jitclasses/alpharaw_jit.py:208-337) /
+ * TimsTOFTransposeJIT.get_dense (search/jitclasses/bruker_jit.py:273-504) return with
+ * absolute_masses=True: dense[2][n_query][O][S][F] (intensity plane, then m/z plane; S = 1 for an
+ * AlphaRaw run, whose two scan slots are copies, alpharaw_jit.py:326-333) and the cycle rows
+ * (`precursor_idx_list`) in obs[0..*n_obs).  mz_query must be ascending.  Runs the production
+ * gather kernel on a one-candidate plan built from the query.
+ */
+int adh_debug_get_dense(adh_handle_t *handle, int64_t frame_start, int64_t frame_stop, int64_t scan_start,
+                        int64_t scan_stop, const float *mz_query, int32_t n_query, float mass_tolerance,
+                        float quad_lo, float quad_hi, float *dense, int64_t dense_capacity, int32_t *obs,
+                        int32_t *n_obs, int32_t *n_scans, int32_t *n_cycles);
+
 /* The handle's own (non-blocking) stream as a hipStream_t. */
 int adh_get_stream(adh_handle_t *handle, void **hip_stream);
 

@@ -57,6 +57,27 @@ constexpr double ISOTOPE_DELTA = 1.0033548350700006; /* candidate.py:160 */
  */
 int g_numpy_typing = 0;
 
+/* np.sum of a contiguous float32 vector as NumPy 2.x computes it (pairwise_sum in
+ * numpy/_core/src/umath/loops_utils.h.src): sequential below 8 elements, else 8 running sums over
+ * blocks of 8 combined as a tree, remainder added sequentially (n <= 128: no recursion here).
+ * Only used with g_numpy_typing, to pin the restatement against goldens the shim produced
+ * under NumPy; Numba's np.sum is the plain sequential loop. */
+static float numpy_pairwise_sum(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
 /* ------------------------------------------------------------------ helpers */
 
 /* python slice(start, stop) on a sequence of length n -> [a, b) */
@@ -667,6 +688,7 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
             for (int s = 0; s < S; ++s) {
                 float sf = 0;
                 for (int f = 0; f < F; ++f) sf += T(o, s, f);
+                if (g_numpy_typing) sf = numpy_pairwise_sum(&templ[((size_t)o * S + s) * F], F);
                 so += sf;
             }
             oi[o] = so;

@@ -60,7 +60,8 @@ def score(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int = 1, with
         for a in arrays.values():
             a.fill(0)
     else:
-        m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+        m_out, arrays = _abi.alloc_output(n, _abi.output_width(cand_marshalled, int(cfg_jit.top_k_fragments)),
+                                          with_stats=with_stats)
     score.last_buffers = (m_out, arrays)
     rc = lib().adh_oracle_score(
         m_dia.ref(), m_frag.ref(), cand_marshalled.ref(), C.byref(cfg), m_out.ref(), C.c_int(n_threads)
@@ -76,7 +77,8 @@ def score_timstof(dia, fragment_cols, cand_marshalled, cfg_jit, n_threads: int =
     m_frag = _abi.pack_fragments(*fragment_cols)
     cfg = _abi.pack_config(cfg_jit)
     n = int(cand_marshalled.struct.n)
-    m_out, arrays = _abi.alloc_output(n, int(cfg_jit.top_k_fragments), with_stats=with_stats)
+    m_out, arrays = _abi.alloc_output(n, _abi.output_width(cand_marshalled, int(cfg_jit.top_k_fragments)),
+                                      with_stats=with_stats)
     lib().adh_oracle_score_timstof.restype = C.c_int
     rc = lib().adh_oracle_score_timstof(
         m_dia.ref(), m_frag.ref(), cand_marshalled.ref(), C.byref(cfg), m_out.ref(), C.c_int(n_threads)

@@ -260,9 +260,25 @@ SCORING_CONFIGS = {
 }
 
 
-def golden_scoring():
-    for name, upd in SCORING_CONFIGS.items():
-        case = small_case(101)
+# libraries with 5..40 fragments per precursor (more than the 12 of a predicted library and than
+# the 16 lanes of the register kernels): transfer-library requantification scores every fragment
+# (transfer_library_requantification_handler.py:117-124, top_k_fragments = 9999), and a plain top-k
+# of 24 with the class defaults exercises the K > 16 branch of the K x K contraction
+MANYFRAG_CONFIGS = {
+    "manyfrag": dict(SCORING_CONFIGS["handler_default"], top_k_fragments=9999),
+    "manyfrag_class": dict(top_k_fragments=24),
+}
+
+
+def golden_scoring(which=None):
+    configs = dict(SCORING_CONFIGS, **MANYFRAG_CONFIGS)
+    for name, upd in configs.items():
+        if which is not None and name not in which:
+            continue
+        if name in MANYFRAG_CONFIGS:
+            case = small_case(131, n_precursors=160, k_fragments=(5, 40), frag_mz_hi=500, ms2_mz_range=(195, 505))
+        else:
+            case = small_case(101)
         if name == "topk6":
             # give some fragments cardinality 2 so exclude_shared_ions drops them
             rng = np.random.default_rng(7)
@@ -271,7 +287,17 @@ def golden_scoring():
             case.library.fragment_df["cardinality"] = card
         out, fdf, frdf, opidx, orank, cfg = run_scoring(case, upd)
         d = case_to_dict(case)
-        d.update(out_to_dict(out))
+        od = out_to_dict(out)
+        if name in MANYFRAG_CONFIGS:
+            # the reference allocates top_k_fragments (9999) columns; keep those a library slice can fill
+            lens = (case.library.precursor_df["flat_frag_stop_idx"].values.astype(np.int64)
+                    - case.library.precursor_df["flat_frag_start_idx"].values.astype(np.int64))
+            width = int(min(int(cfg.top_k_fragments), lens.max()))
+            for k, v in od.items():
+                if v.ndim == 2 and k != "out_features":
+                    assert not v[:, width:].any(), k
+                    od[k] = np.ascontiguousarray(v[:, :width])
+        d.update(od)
         d["order_precursor_idx"] = opidx
         d["order_rank"] = orank
         cfgj = cfg.to_jitclass()
@@ -883,6 +909,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--multiplex-only" in sys.argv:
         golden_multiplex()
+        sys.exit(0)
+    if "--manyfrag-only" in sys.argv:
+        golden_scoring(which=MANYFRAG_CONFIGS)
         sys.exit(0)
     golden_get_dense()
     golden_fragcomp()

@@ -163,3 +163,44 @@ def test_event_list_stays_bounded(ctx, case):
         ctx.score_host(packed, cfg, reuse_buffers=True)
     g, f, n = ctx.kernel_time_ms(reset=True)
     assert n == 300 and g > 0 and f > 0
+
+
+def test_hip_dense_tile_matches_reference_alpharaw(ctx):
+    """The tile the production gather kernel builds, dumped through ``adh_debug_get_dense``,
+    against the 32 ``AlphaRawJIT.get_dense`` outputs of the reference: intensity plane bit for
+    bit in all cases, absolute-m/z plane bit for bit where the golden was made with
+    ``absolute_masses=True`` (the only mode the scoring path uses, candidate.py:213-246)."""
+    z = np.load(H.golden_path("get_dense_alpharaw.npz"))
+    ctx.stage_run(H.dia_from_npz(z), force=True)
+    hits = 0
+    for i in range(int(z["n_cases"])):
+        fl, quad, e = z[f"q{i}_frame_limits"], z[f"q{i}_quad"], z[f"q{i}_dense"]
+        dense, obs = ctx.debug_get_dense(fl[0, 0], fl[0, 1], z[f"q{i}_mz"], z[f"q{i}_tol"], quad[0, 0], quad[0, 1])
+        assert np.array_equal(obs, z[f"q{i}_pidx"]), i
+        assert dense.shape == e.shape[:3] + (1,) + e.shape[4:], (dense.shape, e.shape)
+        for slot in (0, 1):  # the reference writes the same value to both scan slots
+            assert np.array_equal(dense[0, :, :, 0, :], e[0, :, :, slot, :]), f"intensity, case {i}"
+            if bool(z[f"q{i}_absolute"]):
+                assert np.array_equal(dense[1, :, :, 0, :], e[1, :, :, slot, :]), f"m/z, case {i}"
+        hits += int((e[0] > 0).sum())
+    assert hits > 100
+
+
+def test_hip_dense_tile_matches_reference_timstof(ctx):
+    """The same for the 16 ``TimsTOFTransposeJIT.get_dense`` goldens (both planes, every scan)."""
+    import test_oracle_golden as TG
+
+    z, dia, *_ = TG._tims_golden()
+    ctx.stage_run(dia, force=True)
+    hits = 0
+    for i in range(int(z["n_cases"])):
+        fl, sl, quad, e = z[f"q{i}_frame_limits"], z[f"q{i}_scan_limits"], z[f"q{i}_quad"], z[f"q{i}_dense"]
+        dense, obs = ctx.debug_get_dense(fl[0, 0], fl[0, 1], z[f"q{i}_mz"], z[f"q{i}_tol"], quad[0, 0], quad[0, 1],
+                                         scan_start=sl[0, 0], scan_stop=sl[0, 1])
+        if e.size == 0:  # no push matches the quadrupole: bruker_jit.py:363-366
+            assert dense.size == 0
+            continue
+        assert np.array_equal(obs, z[f"q{i}_pidx"]), i
+        assert dense.shape == e.shape and np.array_equal(dense, e), f"case {i}"
+        hits += int((e[0] > 0).sum())
+    assert hits > 20
