@@ -1,17 +1,19 @@
 """Fragment competition on the GPU.
 
 Drop-in for ``alphadia.fragcomp.fragcomp.FragmentCompetition``
-(alphadia/fragcomp/fragcomp.py:146-299): same constructor, same ``__call__``
-signature and the same returned ``psm_df[psm_df["valid"]]``.  The pandas
-preparation (hashing, fragment start/stop indices, window index, sort) follows
-the reference line by line; the nested competition loops
-(``_compete_for_fragments``, fragcomp.py:51-143) run in a HIP kernel, one
-workgroup per DIA window.
+(alphadia/fragcomp/fragcomp.py:146-299): same constructor, same ``__call__`` signature, same
+surviving rows in the same order.  The reference prepares the competition with a chain of pandas
+group-bys and merges (fragcomp.py:170-229,268-289; fragcomp/utils.py:11-58); here the whole
+preparation is ONE numpy pass over plain arrays (:func:`competition_plan`): candidate keys, the
+fragment range of every PSM, the DIA window of every PSM, the processing order and the row range
+of every window.  The nested competition loops (``_compete_for_fragments``, fragcomp.py:51-143)
+run in a HIP kernel, one workgroup per DIA window.
 """
 
 from __future__ import annotations
 
 import logging
+from dataclasses import dataclass
 
 import numpy as np
 import pandas as pd
@@ -20,26 +22,74 @@ logger = logging.getLogger(__name__)
 
 
 def candidate_hash(precursor_idx: np.ndarray, rank: np.ndarray) -> np.ndarray:
-    """64-bit hash: precursor_idx in the low 32 bits, rank above (fragcomp/utils.py:48-58)."""
-    return (
-        np.asarray(precursor_idx).astype(np.int64) + (np.asarray(rank).astype(np.int64) << 32)
-    ).astype(np.uint64)
+    """The reference's candidate key (fragcomp/utils.py:48-58): rank << 32 | precursor_idx."""
+    return (np.asarray(rank).astype(np.uint64) << np.uint64(32)) | np.asarray(precursor_idx).astype(np.uint64)
 
 
-def add_frag_start_stop_idx(psm_df: pd.DataFrame, frag_df: pd.DataFrame) -> pd.DataFrame:
-    """fragcomp/utils.py:11-45"""
-    if "_frag_start_idx" in psm_df.columns and "_frag_stop_idx" in psm_df.columns:
-        logger.warning(
-            "Fragment start and stop indices already present in PSM dataframe. Skipping."
-        )
-        return psm_df
-    frag_df["frag_idx"] = np.arange(len(frag_df))
-    index_df = frag_df.groupby("_candidate_idx", as_index=False).agg(
-        _frag_start_idx=pd.NamedAgg("frag_idx", "min"),
-        _frag_stop_idx=pd.NamedAgg("frag_idx", "max"),
-    )
-    index_df["_frag_stop_idx"] += 1
-    return psm_df.merge(index_df, "inner", on="_candidate_idx")
+@dataclass
+class CompetitionPlan:
+    """Everything the competition kernel needs, in processing order."""
+
+    rows: np.ndarray          # PSM rows (positions in the caller's frame) in processing order
+    key: np.ndarray           # candidate key of those rows
+    frag_start: np.ndarray    # [start, stop) into the fragment table, per processed row
+    frag_stop: np.ndarray
+    window: np.ndarray        # DIA window of every processed row (non-decreasing)
+    window_start: np.ndarray  # row range of every occupied window
+    window_stop: np.ndarray
+
+
+def competition_plan(precursor_idx, rank, mz_observed, proba, frag_precursor_idx, frag_rank,
+                     cycle: np.ndarray) -> CompetitionPlan:
+    """What ``FragmentCompetition.__call__`` derives before it competes (fragcomp.py:268-289).
+
+    * a PSM owns the fragment rows that carry its (precursor_idx, rank) key: first such row to last
+      such row + 1 (``add_frag_start_stop_idx``, fragcomp/utils.py:11-45); PSMs without fragment
+      rows leave the competition (the reference's inner merge)
+    * its DIA window is the first cycle row whose [lowest, highest) isolation limit holds its
+      observed m/z, row 0 when none does (``_add_window_idx``, fragcomp.py:170-202)
+    * rows are processed window by window, best (lowest) ``proba`` first, ties by precursor_idx,
+      then by input position (the reference's stable multi-column sort)
+    """
+    key = candidate_hash(precursor_idx, rank)
+    fkey = candidate_hash(frag_precursor_idx, frag_rank)
+    n_frag = fkey.shape[0]
+    # first / last fragment row of every distinct key
+    by_key = np.argsort(fkey, kind="stable")
+    sorted_keys = fkey[by_key]
+    is_first = np.ones(n_frag, dtype=bool)
+    is_first[1:] = sorted_keys[1:] != sorted_keys[:-1]
+    group_first = np.flatnonzero(is_first)
+    uniq = sorted_keys[group_first]
+    # stable sort: inside a group the rows appear in table order -> first is the minimum, last the maximum
+    group_last = np.append(group_first[1:], n_frag) - 1
+    lo = by_key[group_first] if n_frag else np.zeros(0, np.int64)
+    hi = by_key[group_last] + 1 if n_frag else np.zeros(0, np.int64)
+    at = np.searchsorted(uniq, key)
+    at_c = np.minimum(at, max(len(uniq) - 1, 0))
+    has = (uniq[at_c] == key) if len(uniq) else np.zeros(len(key), dtype=bool)
+    rows = np.flatnonzero(has)
+
+    # DIA window: per cycle row the extreme isolation limits over its scans
+    lower = cycle[0, :, :, 0].min(axis=1)
+    upper = cycle[0, :, :, 1].max(axis=1)
+    mz = np.asarray(mz_observed)[rows]
+    window = np.zeros(len(rows), dtype=np.int64)
+    unassigned = np.ones(len(rows), dtype=bool)
+    for w in range(len(lower)):
+        inside = unassigned & (mz >= lower[w]) & (mz < upper[w])
+        window[inside] = w
+        unassigned &= ~inside
+
+    order = np.lexsort((np.asarray(precursor_idx)[rows], np.asarray(proba)[rows], window))
+    rows = rows[order]
+    window = window[order]
+    occupied, first = np.unique(window, return_index=True)
+    del occupied
+    stop = np.append(first[1:], len(window)) if len(first) else first
+    return CompetitionPlan(rows=rows, key=key[rows], frag_start=lo[at_c[rows]].astype(np.int64),
+                           frag_stop=hi[at_c[rows]].astype(np.int64), window=window,
+                           window_start=first.astype(np.int64), window_stop=stop.astype(np.int64))
 
 
 class FragmentCompetition:
@@ -52,52 +102,22 @@ class FragmentCompetition:
         self.thread_count = thread_count  # CPU knob of the reference; unused on the GPU
         self.device = device
 
-    @staticmethod
-    def _add_window_idx(psm_df: pd.DataFrame, cycle: np.ndarray) -> pd.DataFrame:
-        """fragcomp.py:170-202"""
-        if "window_idx" in psm_df.columns:
-            logger.warning("Window index already present in PSM dataframe. Skipping.")
-            return psm_df
-        lower_limit = np.min(cycle[0, :, :, 0], axis=1, keepdims=True).T
-        upper_limit = np.max(cycle[0, :, :, 1], axis=1, keepdims=True).T
-        mz = np.expand_dims(psm_df["mz_observed"].values, axis=-1)
-        idx = (mz >= lower_limit) & (mz < upper_limit)
-        psm_df["window_idx"] = np.argmax(idx, axis=1)
-        return psm_df
-
-    @staticmethod
-    def _get_thread_plan_df(psm_df: pd.DataFrame) -> pd.DataFrame:
-        """fragcomp.py:204-229"""
-        psm_df["_thread_idx"] = np.arange(len(psm_df))
-        index_df = psm_df.groupby("window_idx", as_index=False).agg(
-            start_idx=pd.NamedAgg("_thread_idx", "min"),
-            stop_idx=pd.NamedAgg("_thread_idx", "max"),
-        )
-        index_df["stop_idx"] += 1
-        psm_df.drop(columns=["_thread_idx"], inplace=True)
-        return index_df
-
     def __call__(self, psm_df: pd.DataFrame, frag_df: pd.DataFrame, cycle: np.ndarray) -> pd.DataFrame:
         from alphadia_amd import runtime  # raises when the HIP library is missing
 
-        psm_df["_candidate_idx"] = candidate_hash(psm_df["precursor_idx"].values, psm_df["rank"].values)
-        frag_df["_candidate_idx"] = candidate_hash(frag_df["precursor_idx"].values, frag_df["rank"].values)
-        psm_df = add_frag_start_stop_idx(psm_df, frag_df)
-        psm_df = self._add_window_idx(psm_df, cycle)
-        # important to sort by window_idx and proba (fragcomp.py:268-270)
-        psm_df.sort_values(by=["window_idx", "proba", "precursor_idx"], inplace=True)
-        thread_plan_df = self._get_thread_plan_df(psm_df)
+        plan = competition_plan(
+            psm_df["precursor_idx"].values, psm_df["rank"].values, psm_df["mz_observed"].values,
+            psm_df["proba"].values, frag_df["precursor_idx"].values, frag_df["rank"].values, cycle,
+        )
         ctx = runtime.get_context(self.device)
         valid = ctx.fragcomp(
-            thread_plan_df["start_idx"].values,
-            thread_plan_df["stop_idx"].values,
-            psm_df["rt_observed"].values,
-            psm_df["_frag_start_idx"].values,
-            psm_df["_frag_stop_idx"].values,
-            frag_df["mz_observed"].values,
-            self.rt_tol_seconds,
-            self.mass_tol_ppm,
+            plan.window_start, plan.window_stop, psm_df["rt_observed"].values[plan.rows],
+            plan.frag_start, plan.frag_stop, frag_df["mz_observed"].values,
+            self.rt_tol_seconds, self.mass_tol_ppm,
         )
-        psm_df["valid"] = valid
-        psm_df.drop(columns=["_frag_start_idx", "_frag_stop_idx", "window_idx"], inplace=True)
-        return psm_df[psm_df["valid"]]
+        # the frame the reference returns: surviving rows in processing order, with the candidate
+        # key and the (all-true) flag column it leaves behind (fragcomp.py:291-299)
+        out = psm_df.iloc[plan.rows[valid]].copy()
+        out["_candidate_idx"] = plan.key[valid]
+        out["valid"] = True
+        return out

@@ -245,27 +245,66 @@ def get_isotope_column_names(colnames) -> list[str]:
     return [f"i_{i}" for i in sorted(iso)]
 
 
+def _row_lookup(right_df: pd.DataFrame, left_df: pd.DataFrame, on: list[str]):
+    """Position in ``right_df`` of the row whose key columns equal those of every ``left_df`` row
+    (-1 where there is none), or None when the right keys are not unique / not integer-like."""
+    keys_r = [right_df[c].values for c in on]
+    keys_l = [left_df[c].values for c in on]
+    if not all(np.issubdtype(k.dtype, np.integer) for k in keys_r + keys_l):
+        return None
+    # composite key: mixed-radix over the value ranges of the right table
+    code_r = np.zeros(len(right_df), dtype=np.int64)
+    code_l = np.zeros(len(left_df), dtype=np.int64)
+    ok_l = np.ones(len(left_df), dtype=bool)
+    radix = 1
+    for kr, kl in zip(keys_r, keys_l, strict=True):
+        lo = int(kr.min()) if len(kr) else 0
+        span = (int(kr.max()) - lo + 1) if len(kr) else 1
+        if radix * span >= 2**62:
+            return None
+        kl64 = kl.astype(np.int64)
+        ok_l &= (kl64 >= lo) & (kl64 < lo + span)
+        code_r += (kr.astype(np.int64) - lo) * radix
+        code_l += (np.clip(kl64, lo, lo + span - 1) - lo) * radix
+        radix *= span
+    order = np.argsort(code_r, kind="stable")
+    sorted_codes = code_r[order]
+    if len(sorted_codes) > 1 and (sorted_codes[1:] == sorted_codes[:-1]).any():
+        return None
+    pos = np.searchsorted(sorted_codes, code_l)
+    pos_c = np.minimum(pos, max(len(sorted_codes) - 1, 0))
+    hit = ok_l & (sorted_codes[pos_c] == code_l) if len(sorted_codes) else np.zeros(len(left_df), dtype=bool)
+    return np.where(hit, order[pos_c] if len(order) else 0, -1)
+
+
 def merge_missing_columns(left_df, right_df, right_columns, on=None, how="left"):
-    """scoring/utils.py:203-266"""
-    if isinstance(on, str):
-        on = [on]
-    if isinstance(right_columns, str):
-        right_columns = [right_columns]
-    missing_from_left = [c for c in dict.fromkeys(right_columns) if c not in left_df.columns]
-    missing_from_right = [c for c in missing_from_left if c not in right_df.columns]
-    if len(missing_from_left) == 0:
+    """Bring the columns of ``right_columns`` that ``left_df`` lacks over from ``right_df``.
+
+    Interface, checks and result of the reference helper (scoring/utils.py:203-266).  The common
+    case (``how="left"``, integer keys, unique on the right) is a sort + searchsorted lookup and a
+    gather per column; anything else is handed to ``DataFrame.merge``."""
+    on = [on] if isinstance(on, str) else on
+    wanted = [right_columns] if isinstance(right_columns, str) else list(right_columns)
+    to_add = [c for c in dict.fromkeys(wanted) if c not in left_df.columns]
+    if not to_add:
         return left_df
-    if missing_from_right:
-        raise ValueError(f"Columns {missing_from_right} must be present in right_df")
+    unknown = [c for c in to_add if c not in right_df.columns]
+    if unknown:
+        raise ValueError(f"Columns {unknown} must be present in right_df")
     if on is None:
         raise ValueError("Parameter on must be specified")
-    if not all(col in left_df.columns for col in on):
-        raise ValueError(f"Columns {on} must be present in left_df")
-    if not all(col in right_df.columns for col in on):
-        raise ValueError(f"Columns {on} must be present in right_df")
-    if how not in ["left", "right", "inner", "outer"]:
+    for name, frame in (("left_df", left_df), ("right_df", right_df)):
+        if any(c not in frame.columns for c in on):
+            raise ValueError(f"Columns {on} must be present in {name}")
+    if how not in ("left", "right", "inner", "outer"):
         raise ValueError("Parameter how must be one of left, right, inner, outer")
-    return left_df.merge(right_df[on + missing_from_left], on=on, how=how)
+    rows = _row_lookup(right_df, left_df, on) if how == "left" else None
+    if rows is None or (rows < 0).any():  # duplicate / non-integer keys, or rows without a partner (NaN fill)
+        return left_df.merge(right_df[on + to_add], on=on, how=how)
+    out = left_df.copy()
+    for c in to_add:
+        out[c] = right_df[c].values[rows]
+    return out
 
 
 _CAND_REQUIRED = {
@@ -631,28 +670,38 @@ class HipCandidateScoring:
 
 
 def calculate_score_groups(input_df: pd.DataFrame, group_channels: bool = False) -> pd.DataFrame:
-    """Score groups for DIA multiplexing (scoring/utils.py:269-410).
+    """``score_group_idx`` for every row (reference: scoring/utils.py:269-410).
 
-    Rows are sorted by (elution_group_idx, decoy, rank, precursor_idx); with
-    ``group_channels`` every change of (elution group, decoy, rank) opens a new
-    group, otherwise each row is its own group.
-    """
-    if "rank" in input_df.columns:
-        input_df = input_df.sort_values(by=["elution_group_idx", "decoy", "rank", "precursor_idx"])
-        rank_values = input_df["rank"].values
-    else:
-        input_df = input_df.sort_values(by=["elution_group_idx", "decoy", "precursor_idx"])
-        rank_values = np.zeros(len(input_df), dtype=np.uint32)
+    Rows come back ordered by (elution group, decoy, rank, precursor); without ``group_channels``
+    every row is its own group, with it one group spans the rows that share elution group, decoy
+    flag and rank (the label channels of one peptide)."""
     n = len(input_df)
+    rank = input_df["rank"].values if "rank" in input_df.columns else np.zeros(n, dtype=np.uint32)
+    eg, dc, pi = (input_df[c].values for c in ("elution_group_idx", "decoy", "precursor_idx"))
+    order = np.lexsort((pi, rank, dc, eg))
+    out = input_df.iloc[order].reset_index(drop=True)
     if group_channels and n:
-        eg = input_df["elution_group_idx"].values
-        dc = input_df["decoy"].values
-        change = np.zeros(n, dtype=bool)
-        change[1:] = (eg[1:] != eg[:-1]) | (dc[1:] != dc[:-1]) | (rank_values[1:] != rank_values[:-1])
-        input_df["score_group_idx"] = np.cumsum(change).astype(np.uint32)
+        key = np.stack([eg[order], dc[order], rank[order]])
+        new_group = np.r_[False, (key[:, 1:] != key[:, :-1]).any(axis=0)]
+        out["score_group_idx"] = np.cumsum(new_group).astype(np.uint32)
     else:
-        input_df["score_group_idx"] = np.arange(n, dtype=np.uint32)
-    return input_df.sort_values(by=["score_group_idx", "precursor_idx"]).reset_index(drop=True)
+        out["score_group_idx"] = np.arange(n, dtype=np.uint32)
+    return out
+
+
+def _first_valid_per_group(values: np.ndarray, group_start: np.ndarray, n: int) -> np.ndarray:
+    """First non-null entry of every group of a grouped-and-ordered column (GroupBy.first)."""
+    null = pd.isnull(values)
+    if not null.any():
+        return values[group_start]
+    pos = np.where(null, n, np.arange(n))
+    first = np.minimum.reduceat(pos, group_start)
+    stop = np.r_[group_start[1:], n]
+    out = values[np.minimum(first, n - 1)].copy()
+    if (first >= stop).any():  # a group without any value keeps the null
+        out = out.astype(object) if out.dtype.kind not in "fO" else out
+        out[first >= stop] = np.nan
+    return out
 
 
 def multiplex_candidates(
@@ -661,29 +710,56 @@ def multiplex_candidates(
     remove_decoys: bool = True,
     channels: list[int] | None = None,
 ) -> pd.DataFrame:
-    """Spread the best candidate of every elution group over all channels
-    (scoring/utils.py:114-200)."""
-    if channels is None:
-        channels = [0, 4, 8, 12]
-    precursors_flat_view = precursors_flat_df.copy()
-    best_candidate_view = candidates_df.copy()
+    """Copy the best candidate of every elution group to all its label channels
+    (reference: scoring/utils.py:114-200).
+
+    The best candidate of a group is the one with the lowest ``proba`` (ties: lowest precursor_idx);
+    it is handed, without its own precursor_idx / channel, to every library precursor of the group
+    whose channel is in ``channels`` (targets only unless ``remove_decoys`` is off).  Rows keep the
+    order of the library table."""
+    channels = [0, 4, 8, 12] if channels is None else channels
+    cand = candidates_df
+    lib = precursors_flat_df
     if remove_decoys:
-        precursors_flat_view = precursors_flat_df[precursors_flat_df["decoy"] == 0]
-        if "decoy" in best_candidate_view.columns:
-            best_candidate_view = best_candidate_view[best_candidate_view["decoy"] == 0]
-    best_candidate_view = (
-        best_candidate_view.sort_values(["proba", "precursor_idx"])
-        .groupby("elution_group_idx")
-        .first()
-        .reset_index()
-    )
-    candidate_elution_group_idxs = best_candidate_view["elution_group_idx"].unique()
-    precursors_flat_view = precursors_flat_view[precursors_flat_view["channel"].isin(channels)]
-    precursors_flat_view = precursors_flat_view[
-        precursors_flat_view["elution_group_idx"].isin(candidate_elution_group_idxs)
-    ]
-    precursors_flat_view = precursors_flat_view[["elution_group_idx", "precursor_idx", "channel"]]
-    best_candidate_view = best_candidate_view.drop(columns=["precursor_idx"])
-    if "channel" in best_candidate_view.columns:
-        best_candidate_view = best_candidate_view.drop(columns=["channel"])
-    return precursors_flat_view.merge(best_candidate_view, on="elution_group_idx", how="left")
+        lib = lib[lib["decoy"].values == 0]
+        if "decoy" in cand.columns:
+            cand = cand[cand["decoy"].values == 0]
+    n = len(cand)
+    eg = cand["elution_group_idx"].values
+    order = np.lexsort((cand["precursor_idx"].values, cand["proba"].values, eg))
+    eg_sorted = eg[order]
+    group_start = np.flatnonzero(np.r_[True, eg_sorted[1:] != eg_sorted[:-1]]) if n else np.zeros(0, np.int64)
+    best_eg = eg_sorted[group_start]
+
+    lib_eg = lib["elution_group_idx"].values
+    at = np.searchsorted(best_eg, lib_eg)
+    at_c = np.minimum(at, max(len(best_eg) - 1, 0))
+    keep = np.isin(lib["channel"].values, channels)
+    keep &= (best_eg[at_c] == lib_eg) if len(best_eg) else False
+    out = pd.DataFrame({c: lib[c].values[keep] for c in ("elution_group_idx", "precursor_idx", "channel")})
+    group_of_row = at_c[keep]
+    for col in cand.columns:
+        if col in ("elution_group_idx", "precursor_idx", "channel"):
+            continue
+        best = _first_valid_per_group(cand[col].values[order], group_start, n) if n else cand[col].values[:0]
+        out[col] = best[group_of_row]
+    return out
+
+
+def requantify_multiplexed(dia_data, psm_df: pd.DataFrame, precursors_flat: pd.DataFrame, fragments_flat: pd.DataFrame,
+                           channels: list[int], reference_channel: int, experimental_xic: bool, column_names: dict,
+                           device: int | None = None):
+    """The scoring half of multiplex requantification
+    (multiplexing_requantification_handler.py:95-140): best candidate of every elution group copied
+    to all ``channels``, the channel copies scored as one score group gated on the reference
+    channel.  Returns ``(features_df, fragments_df)``; the q-values are the FDR manager's business."""
+    cols = ["elution_group_idx", "precursor_idx", "rank", "scan_start", "scan_stop", "scan_center", "frame_start",
+            "frame_stop", "frame_center", "proba"]
+    multiplexed = multiplex_candidates(psm_df[cols], precursors_flat, channels=channels)
+    multiplexed["rank"] = 0
+    config = CandidateScoringConfig()
+    config.update(dict(score_grouped=True, exclude_shared_ions=True, reference_channel=int(reference_channel),
+                       experimental_xic=bool(experimental_xic)))
+    scoring = HipCandidateScoring(dia_data=dia_data, precursors_flat=precursors_flat, fragments_flat=fragments_flat,
+                                  config=config, device=device, **column_names)
+    return scoring(multiplexed)

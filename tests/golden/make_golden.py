@@ -363,6 +363,61 @@ def multiplex_case(n_base: int = 120, n_cycles: int = 60):
     return syn.SyntheticCase(dia, lib, mult[CAND_COLS].copy(), planted.apex_cycle)
 
 
+def golden_host_helpers():
+    """Inputs and outputs of the reference's DataFrame helpers that the host layer restates in
+    numpy: ``multiplex_candidates`` (scoring/utils.py:114-200, three settings) and
+    ``calculate_score_groups`` (scoring/utils.py:269-410, grouped and not)."""
+    from alphadia.search.scoring.utils import calculate_score_groups, multiplex_candidates
+
+    rng = np.random.default_rng(20260928)
+    n_eg, channels_all = 150, np.array([0, 4, 8, 12])
+    rows = []
+    for eg in range(n_eg):
+        for decoy in (0, 1):
+            for ch in channels_all[: rng.integers(2, 5)]:
+                rows.append((eg, decoy, int(ch)))
+    lib = pd.DataFrame(rows, columns=["elution_group_idx", "decoy", "channel"])
+    lib = lib.sample(frac=1.0, random_state=3).reset_index(drop=True)  # library order is arbitrary
+    lib["precursor_idx"] = rng.permutation(len(lib)).astype(np.uint32)
+    lib["elution_group_idx"] = lib["elution_group_idx"].astype(np.uint32)
+    lib["decoy"] = lib["decoy"].astype(np.uint8)
+    lib["channel"] = lib["channel"].astype(np.uint32)
+    # the columns precursors_flat_schema asks for (validation/schemas.py:11-32)
+    for c in ("flat_frag_start_idx", "flat_frag_stop_idx"):
+        lib[c] = np.zeros(len(lib), dtype=np.uint32)
+    lib["charge"] = np.full(len(lib), 2, dtype=np.uint8)
+    for c in ("rt_library", "mobility_library", "mz_library"):
+        lib[c] = rng.random(len(lib)).astype(np.float32)
+    lib["proteins"] = np.full(len(lib), "P", dtype=object)
+    lib["genes"] = np.full(len(lib), "G", dtype=object)
+    # candidates: several per elution group (different precursors, ranks), ties in proba, some groups absent
+    pick = lib[lib["elution_group_idx"] % 5 != 0].sample(frac=0.7, random_state=9)
+    cand = pick[["elution_group_idx", "precursor_idx", "decoy", "channel"]].copy().reset_index(drop=True)
+    cand = pd.concat([cand, cand.iloc[::3]], ignore_index=True)
+    cand["channel"] = cand["channel"].astype(np.uint8)  # candidates_schema: uint8
+    cand["rank"] = rng.integers(0, 3, len(cand)).astype(np.uint8)
+    cand["proba"] = np.round(rng.random(len(cand)), 1).astype(np.float32)  # many ties
+    for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center"):
+        cand[c] = rng.integers(0, 5000, len(cand)).astype(np.int64)
+    cand["score"] = rng.random(len(cand)).astype(np.float32)
+    d = {"lib_" + c: lib[c].values for c in lib.columns if lib[c].dtype != object}
+    d.update({"cand_" + c: cand[c].values for c in cand.columns})
+    settings = {"default": dict(), "with_decoys": dict(remove_decoys=False), "two_channels": dict(channels=[0, 8])}
+    for name, kw in settings.items():
+        out = multiplex_candidates(cand.copy(), lib.copy(), **kw)
+        d[f"mult_{name}_columns"] = np.array(list(out.columns), dtype="U")
+        for c in out.columns:
+            d[f"mult_{name}_{c}"] = out[c].values
+        print(f"multiplex_candidates[{name}]: {len(out)} rows")
+    for name, grouped in (("plain", False), ("grouped", True)):
+        out = calculate_score_groups(cand.copy(), group_channels=grouped)
+        for c in ("precursor_idx", "rank", "score_group_idx"):
+            d[f"groups_{name}_{c}"] = out[c].values
+    path = os.path.join(HERE, "host_helpers.npz")
+    np.savez_compressed(path, **d)
+    print(f"{path}: {os.path.getsize(path)/1e3:.0f} kB")
+
+
 def golden_multiplex():
     case = multiplex_case()
     upd = dict(score_grouped=True, exclude_shared_ions=True, reference_channel=0, experimental_xic=True)
@@ -910,6 +965,9 @@ if __name__ == "__main__":
     if "--multiplex-only" in sys.argv:
         golden_multiplex()
         sys.exit(0)
+    if "--host-helpers-only" in sys.argv:
+        golden_host_helpers()
+        sys.exit(0)
     if "--manyfrag-only" in sys.argv:
         golden_scoring(which=MANYFRAG_CONFIGS)
         sys.exit(0)
@@ -917,6 +975,7 @@ if __name__ == "__main__":
     golden_fragcomp()
     golden_scoring()
     golden_multiplex()
+    golden_host_helpers()
     golden_edges()
     golden_selection()
     golden_selection_kats()

@@ -214,3 +214,34 @@ def test_gather_based_collection_equals_the_merges():
     fast_r = collect_fragments(out, pdf, prec_rows=soa["prec_row"])
     pd.testing.assert_frame_equal(slow_r, fast_r)
     assert len(fast_f) > 100 and len(fast_r) > 500
+
+
+def _helpers_golden():
+    z = np.load(H.golden_path("host_helpers.npz"))
+    lib = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("lib_")})
+    cand = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("cand_")})
+    return z, lib, cand
+
+
+@pytest.mark.parametrize("name, kw", [("default", {}), ("with_decoys", {"remove_decoys": False}),
+                                      ("two_channels", {"channels": [0, 8]})])
+def test_multiplex_candidates_matches_reference(name, kw):
+    """Golden from the reference's ``multiplex_candidates`` (scoring/utils.py:114-200): shuffled
+    library, several candidates per elution group, ties in proba, groups without candidates."""
+    z, lib, cand = _helpers_golden()
+    got = multiplex_candidates(cand, lib, **kw)
+    cols = z[f"mult_{name}_columns"].tolist()
+    assert list(got.columns) == cols
+    assert len(got) == len(z[f"mult_{name}_precursor_idx"]) > 100
+    for c in cols:
+        assert np.array_equal(got[c].values, z[f"mult_{name}_{c}"]), c
+
+
+@pytest.mark.parametrize("name, grouped", [("plain", False), ("grouped", True)])
+def test_score_groups_match_reference(name, grouped):
+    """``calculate_score_groups`` and the grouping inside ``assemble_candidates`` against the
+    reference's own output (scoring/utils.py:269-410)."""
+    z, lib, cand = _helpers_golden()
+    got = calculate_score_groups(cand, group_channels=grouped)
+    for c in ("precursor_idx", "rank", "score_group_idx"):
+        assert np.array_equal(got[c].values, z[f"groups_{name}_{c}"]), c

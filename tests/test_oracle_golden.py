@@ -111,28 +111,45 @@ def test_get_dense_matches_reference(oracle_lib):
 
 
 def test_fragcomp_matches_reference(oracle_lib):
-    import pandas as pd
-
-    from alphadia_amd.fragcomp import FragmentCompetition, add_frag_start_stop_idx, candidate_hash
+    """The numpy preparation (``competition_plan``) + the oracle's competition loop reproduce the
+    reference's surviving PSMs, in the reference's order (golden from FragmentCompetition.__call__)."""
+    from alphadia_amd.fragcomp import competition_plan
 
     z = np.load(H.golden_path("fragcomp.npz"))
-    psm_df = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
-    frag_df = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
-    psm_df["_candidate_idx"] = candidate_hash(psm_df["precursor_idx"].values, psm_df["rank"].values)
-    frag_df["_candidate_idx"] = candidate_hash(frag_df["precursor_idx"].values, frag_df["rank"].values)
-    psm_df = add_frag_start_stop_idx(psm_df, frag_df)
-    psm_df = FragmentCompetition._add_window_idx(psm_df, z["cycle"])
-    psm_df.sort_values(by=["window_idx", "proba", "precursor_idx"], inplace=True)
-    plan = FragmentCompetition._get_thread_plan_df(psm_df)
-    valid = oracle_lib.fragcomp(
-        plan["start_idx"].values, plan["stop_idx"].values, psm_df["rt_observed"].values,
-        psm_df["_frag_start_idx"].values, psm_df["_frag_stop_idx"].values,
-        frag_df["mz_observed"].values, 3, 15,
-    )
-    got = psm_df[valid]
-    assert np.array_equal(got["precursor_idx"].values, z["surviving_precursor_idx"])
-    assert np.array_equal(got["rank"].values, z["surviving_rank"])
-    assert 0 < len(got) < len(psm_df)
+    psm = {k[4:]: z[k] for k in z.files if k.startswith("psm_")}
+    frag = {k[5:]: z[k] for k in z.files if k.startswith("frag_")}
+    plan = competition_plan(psm["precursor_idx"], psm["rank"], psm["mz_observed"], psm["proba"],
+                            frag["precursor_idx"], frag["rank"], z["cycle"])
+    assert np.all(np.diff(plan.window) >= 0) and plan.window_start[0] == 0 and plan.window_stop[-1] == len(plan.rows)
+    valid = oracle_lib.fragcomp(plan.window_start, plan.window_stop, psm["rt_observed"][plan.rows],
+                                plan.frag_start, plan.frag_stop, frag["mz_observed"], 3, 15)
+    keep = plan.rows[valid]
+    assert np.array_equal(psm["precursor_idx"][keep], z["surviving_precursor_idx"])
+    assert np.array_equal(psm["rank"][keep], z["surviving_rank"])
+    assert 0 < len(keep) < len(psm["precursor_idx"])
+
+
+def test_competition_plan_edge_cases():
+    """PSMs without fragment rows leave the competition; m/z outside every window falls into
+    window 0; ties in proba are broken by precursor_idx, then by input position."""
+    from alphadia_amd.fragcomp import competition_plan
+
+    cycle = np.zeros((1, 3, 1, 2))
+    cycle[0, :, 0, 0] = [-1, 400, 500]
+    cycle[0, :, 0, 1] = [-1, 500, 600]
+    pidx = np.array([7, 3, 3, 9, 5], dtype=np.uint32)
+    rank = np.array([0, 0, 1, 0, 0], dtype=np.uint8)
+    mz = np.array([450.0, 550.0, 550.0, 950.0, 420.0], dtype=np.float32)
+    proba = np.array([0.2, 0.1, 0.1, 0.3, 0.2])
+    fp = np.array([3, 3, 7, 7, 7, 3, 9], dtype=np.uint32)   # precursor 5 has no fragment rows
+    fr = np.array([0, 0, 0, 0, 0, 1, 0], dtype=np.uint8)
+    plan = competition_plan(pidx, rank, mz, proba, fp, fr, cycle)
+    assert plan.rows.tolist() == [3, 0, 1, 2]               # window 0: 9 (outside); window 1: 7; window 2: 3/0, 3/1
+    assert plan.window.tolist() == [0, 1, 2, 2]
+    assert plan.frag_start.tolist() == [6, 2, 0, 5] and plan.frag_stop.tolist() == [7, 5, 2, 6]
+    assert plan.window_start.tolist() == [0, 1, 2] and plan.window_stop.tolist() == [1, 2, 4]
+    empty = competition_plan(pidx[:0], rank[:0], mz[:0], proba[:0], fp, fr, cycle)
+    assert len(empty.rows) == 0 and len(empty.window_start) == 0
 
 
 # ---- known-answer tests of the reference, restated against the oracle ----------------
