@@ -627,6 +627,9 @@ def make_timstof_case(
     frag_mz_hi: float = 350.0,
     planted_fraction: float = 0.5,
     seed: int | None = None,
+    h_range: tuple = (2, 10),
+    hs_range: tuple = (3, 12),
+    candidates_on_window: bool = False,
 ) -> TimsTOFCase:
     """Run "B" of SURVEY.md section 8(d) at a configurable (test) scale."""
     seed = BASE_SEED + config_id if seed is None else seed
@@ -653,61 +656,72 @@ def make_timstof_case(
     ev_tof = rng.integers(0, n_tof, n_noise).astype(np.int64)
     ev_int = np.clip(rng.lognormal(3.0, 1.0, n_noise), 1, 60000).astype(np.int64)
 
-    # ---- planted peptides: Gaussian in cycle and in scan
+    # ---- planted peptides: Gaussian in cycle and in scan (vectorised over precursors x cells)
     targets = np.flatnonzero(pdf["decoy"].values == 0)
     chosen = targets[rng.random(targets.size) < planted_fraction]
     apex_cycle = np.full(n_precursors, -1, dtype=np.int64)
     apex_scan = np.full(n_precursors, -1, dtype=np.int64)
+    p_mz_all = pdf["mz_library"].values.astype(np.float64)
+    # a scan at which some MS2 frame isolates the precursor: the home scan of every precursor
+    home_scan = np.full(n_precursors, -1, dtype=np.int64)
+    todo = np.arange(n_precursors)
+    for _ in range(64):  # rejection sampling over scans; windows cover contiguous scan ranges
+        if todo.size == 0:
+            break
+        sc_try = rng.integers(0, S, todo.size)
+        lo = cycle[0, 1:, sc_try, 0]  # (todo, L-1)
+        hi = cycle[0, 1:, sc_try, 1]
+        ok = ((lo <= p_mz_all[todo, None]) & (hi > p_mz_all[todo, None])).any(axis=1)
+        home_scan[todo[ok]] = sc_try[ok]
+        todo = todo[~ok]
+    chosen = chosen[home_scan[chosen] >= 0]
     apex_cycle[chosen] = rng.integers(8, max(9, n_cycles - 8), chosen.size)
-    pp, pt, pi_ = [], [], []
-    flat_cycle = cycle.reshape(-1, 2)
-    for p in chosen:
-        pmz = float(pdf["mz_library"].values[p])
-        charge = float(pdf["charge"].values[p])
-        # a (frame, scan) cell whose window contains the precursor decides the apex scan
-        rows = np.flatnonzero((flat_cycle[:, 0] <= pmz) & (flat_cycle[:, 1] > pmz))
-        if rows.size == 0:
-            apex_cycle[p] = -1
-            continue
-        r0 = int(rng.choice(rows))
-        fr_in_cycle, sc0 = divmod(r0, S)
-        apex_scan[p] = sc0
-        for dc in range(-6, 7):
-            c = int(apex_cycle[p]) + dc
-            if c < 0 or c >= n_cycles:
+    apex_scan[chosen] = home_scan[chosen]
+    if chosen.size:
+        dc = np.arange(-6, 7)
+        ds = np.arange(-5, 6)
+        g_cell = (np.exp(-0.5 * (dc / 2.0) ** 2)[:, None] * np.exp(-0.5 * (ds / 1.8) ** 2)[None, :]).reshape(-1)
+        dc_cell = np.repeat(dc, ds.size)
+        ds_cell = np.tile(ds, dc.size)
+        cell_p = np.repeat(chosen, g_cell.size)
+        cell_c = apex_cycle[cell_p] + np.tile(dc_cell, chosen.size)
+        cell_s = apex_scan[cell_p] + np.tile(ds_cell, chosen.size)
+        cell_g = np.tile(g_cell, chosen.size)
+        inside = (cell_c >= 0) & (cell_c < n_cycles) & (cell_s >= 0) & (cell_s < S)
+        cell_p, cell_c, cell_s, cell_g = cell_p[inside], cell_c[inside], cell_s[inside], cell_g[inside]
+        cell_mz = p_mz_all[cell_p]
+        charge = pdf["charge"].values.astype(np.float64)[cell_p]
+        parts = []
+
+        def emit(push, mz_true, amp):
+            keep = amp >= 1
+            if keep.any():
+                mzv = mz_true[keep] * (1 + rng.normal(2e-6, 1e-6, int(keep.sum())))
+                parts.append((push[keep], np.clip(np.searchsorted(mz_table, mzv), 0, n_tof - 1),
+                              np.clip(amp[keep].astype(np.int64), 1, 60000)))
+
+        push1 = (cell_c * L + 1) * S + cell_s  # the MS1 frame of the cycle (frame 0 is the empty zeroth frame)
+        for i in range(3):
+            emit(push1, cell_mz + i * ISOTOPE_DELTA / charge, 3000.0 * pdf[f"i_{i}"].values.astype(np.float64)[cell_p] * cell_g)
+        f_start = pdf["flat_frag_start_idx"].values.astype(np.int64)
+        f_stop = pdf["flat_frag_stop_idx"].values.astype(np.int64)
+        f_mz = fdf["mz_library"].values.astype(np.float64)
+        f_int = fdf["intensity"].values.astype(np.float64)
+        k_max = int((f_stop - f_start)[chosen].max())
+        for fr in range(1, L):  # fragments in every MS2 frame row of this scan that isolates the precursor
+            sel = (cycle[0, fr, cell_s, 0] <= cell_mz) & (cell_mz < cycle[0, fr, cell_s, 1])
+            if not sel.any():
                 continue
-            gc = np.exp(-0.5 * (dc / 2.0) ** 2)
-            for ds in range(-5, 6):
-                sc = sc0 + ds
-                if sc < 0 or sc >= S:
-                    continue
-                g = gc * np.exp(-0.5 * (ds / 1.8) ** 2)
-                # isotopes in the MS1 frame of the cycle
-                push1 = (c * L + 1) * S + sc
-                for i in range(3):
-                    mzv = (pmz + i * ISOTOPE_DELTA / charge) * (1 + rng.normal(2e-6, 1e-6))
-                    amp = 3000.0 * float(pdf[f"i_{i}"].values[p]) * g
-                    if amp >= 1:
-                        pp.append(push1)
-                        pt.append(int(np.searchsorted(mz_table, mzv)))
-                        pi_.append(int(amp))
-                # fragments in every MS2 frame row of this scan that isolates the precursor
-                for fr in range(1, L):
-                    lo, hi = cycle[0, fr, sc]
-                    if lo <= pmz < hi:
-                        push2 = (c * L + 1 + fr) * S + sc
-                        a, b = int(pdf["flat_frag_start_idx"].values[p]), int(pdf["flat_frag_stop_idx"].values[p])
-                        for k in range(a, b):
-                            mzv = float(fdf["mz_library"].values[k]) * (1 + rng.normal(2e-6, 1e-6))
-                            amp = 1500.0 * float(fdf["intensity"].values[k]) * g
-                            if amp >= 1:
-                                pp.append(push2)
-                                pt.append(int(np.searchsorted(mz_table, mzv)))
-                                pi_.append(int(amp))
-    if pp:
-        ev_push = np.concatenate([ev_push, np.array(pp, dtype=np.int64)])
-        ev_tof = np.concatenate([ev_tof, np.clip(np.array(pt, dtype=np.int64), 0, n_tof - 1)])
-        ev_int = np.concatenate([ev_int, np.clip(np.array(pi_, dtype=np.int64), 1, 60000)])
+            sp, sg = cell_p[sel], cell_g[sel]
+            push2 = (cell_c[sel] * L + 1 + fr) * S + cell_s[sel]
+            for k in range(k_max):
+                has = f_start[sp] + k < f_stop[sp]
+                idx = (f_start[sp] + k)[has]
+                emit(push2[has], f_mz[idx], 1500.0 * f_int[idx] * sg[has])
+        if parts:
+            ev_push = np.concatenate([ev_push] + [x[0] for x in parts])
+            ev_tof = np.concatenate([ev_tof] + [x[1] for x in parts])
+            ev_int = np.concatenate([ev_int] + [x[2] for x in parts])
     order = np.lexsort((ev_push, ev_tof))
     ev_push, ev_tof, ev_int = ev_push[order], ev_tof[order], ev_int[order]
     tof_indptr = np.concatenate([[0], np.cumsum(np.bincount(ev_tof, minlength=n_tof))]).astype(np.int64)
@@ -724,12 +738,15 @@ def make_timstof_case(
         scan_max_index=S,
     )
 
-    # ---- candidates: rank 0 on the planted apex, boxes of 5-21 cycles x 6-24 scans
+    # ---- candidates: rank 0 on the planted apex; boxes of 2h+1 cycles x 2hs scans (defaults 5-21 x 6-24).
+    # ``candidates_on_window``: every box is centred on a scan at which the precursor is isolated (what
+    # candidate selection delivers); otherwise the scan centre of the unplanted boxes is arbitrary and
+    # most of them see no isolation window at all (early exit)
     C = per_precursor
     n = n_precursors * C
     pidx = np.repeat(pdf["precursor_idx"].values.astype(np.uint32), C)
     rank = np.tile(np.arange(C, dtype=np.uint8), n_precursors)
-    h = rng.integers(2, 11, n)
+    h = rng.integers(h_range[0], h_range[1] + 1, n)
     cc = rng.integers(0, n_cycles, n)
     ap = np.repeat(apex_cycle, C)
     use = (ap >= 0) & (rank == 0)
@@ -737,9 +754,12 @@ def make_timstof_case(
     cc = np.clip(cc, h, n_cycles - h - 1)
     even = rng.random(n) < 0.3
     c_stop = cc + h + 1 - even.astype(np.int64)
-    hs = rng.integers(3, 13, n)
+    hs = rng.integers(hs_range[0], hs_range[1] + 1, n)
     sc = rng.integers(0, S, n)
     sc = np.where(use, np.repeat(np.maximum(apex_scan, 0), C), sc)
+    if candidates_on_window:
+        home = np.repeat(home_scan, C)
+        sc = np.where((home >= 0) & ~use, np.clip(home + rng.integers(-2, 3, n), 0, S - 1), sc)
     sc = np.clip(sc, hs, S - hs - 1)
     cands = pd.DataFrame(
         {

@@ -89,6 +89,21 @@ def algorithmic_bytes(dia, soa, cfg, matched_peaks, lib_slice_len):
     return per
 
 
+def cpu_quota_cores() -> float | None:
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def pinned_shard(ctx, soa: dict, a: int, b: int) -> dict:
     """Rows [a, b) of the assembled SoA with the uploaded columns in page-locked memory."""
     n = len(soa["precursor_idx"])
@@ -354,11 +369,17 @@ def main():
         from oracle import oracle
 
         ncpu = os.cpu_count() or 1
+        quota = cpu_quota_cores()
         cols = fragment_columns(case.library.fragment_df, "mz_library")
-        # pick the thread count that is fastest on this host
+        # pick the thread count that is fastest on this host.  The container may be capped by a CFS
+        # quota well below the visible CPUs (the pool's GPU boxes: 16 cores' worth of 256 hardware
+        # threads); more threads than about twice the quota only add throttling
         best = (0.0, 1)
         tried = {}
-        for th in sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)}):
+        cand_threads = {t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}
+        if quota:
+            cand_threads = {t for t in cand_threads if t <= 4 * quota} | {max(1, int(quota))}
+        for th in sorted(cand_threads):
             probe = min(400 * th, n_local)
             pk = pack_assembled(slice_soa(soa, 0, probe))
             oracle.score(case.dia, cols, pk, cfgj, n_threads=th)
@@ -403,11 +424,13 @@ def main():
             "value": cpu_prec / dt,
             "unit": "precursors/s",
             "cores": cores,
+            "cpu_quota_cores": quota,
             "kind": "port",
             "region": "host candidate SoA -> host OutputPsmDF SoA (the region `value` is timed on)",
             "sample": f"first {sample} candidates ({cpu_prec} precursors) of the same batch, "
-                      f"{reps} x {dt:.2f}s, static-stride threads over {cores} threads (fastest of the thread "
-                      f"counts tried on this {ncpu}-thread host)",
+                      f"{reps} x {dt:.2f}s, {cores} OpenMP threads (fastest of the thread counts tried; the host "
+                      f"shows {ncpu} hardware threads, the container's CFS quota is "
+                      f"{'unlimited' if not quota else f'{quota:g} cores'})",
             "precursors_per_s_1_thread": rate_1 * cpu_prec / sample,
             "candidates_per_s_by_threads": {str(k): v for k, v in tried.items()},
             "valid_identical_to_gpu": same_valid,

@@ -1,7 +1,12 @@
-"""Throughput of the ion-mobility path (BASELINE config 4 shape at reduced scale).
+"""BASELINE configs[3]: the ion-mobility (timsTOF-style) path at the specified shape.
 
-Not the driver's bench (bench.py measures configs[1]); this records how the timsTOF-style
-path performs next to the CPU oracle on the same inputs.  Run on the GPU box from the repo root.
+    N_PREC=200000 N_CYCLES=2000 SCAN_MAX=918 N_TOF=400000 EVENTS_PER_PUSH=30 python tools/bench_timstof.py
+
+Run "B" of SURVEY.md section 8(d): 1 MS1 + 8 diaPASEF frames per cycle, candidates of S in [17, 39]
+scans x F in [7, 29] cycles centred where the precursor is isolated (what candidate selection
+delivers), 30 % of the target precursors planted.  Reports, like bench.py, the host -> host step
+(adh_score_candidates), the resident step, the kernel roofline and the CPU oracle on the same
+inputs.  No torch.  Defaults are a reduced run that finishes in a minute.
 """
 import json
 import os
@@ -10,74 +15,129 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from alphadia_amd import runtime, synthetic as syn  # noqa: E402
-from alphadia_amd.distributed import DeviceTables, slice_soa  # noqa: E402
+from alphadia_amd.distributed import slice_soa  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
-from oracle import oracle  # noqa: E402
+from bench import cpu_quota_cores  # noqa: E402
 
 n_prec = int(os.environ.get("N_PREC", 20000))
+n_cycles = int(os.environ.get("N_CYCLES", 300))
 t0 = time.time()
-# BASELINE config 4 at full scale: N_PREC=200000 N_CYCLES=2000 SCAN_MAX=918 N_TOF=400000 EVENTS_PER_PUSH=30
 case = syn.make_timstof_case(
-    n_precursors=n_prec, n_cycles=int(os.environ.get("N_CYCLES", 300)), config_id=4, per_precursor=3, n_ms2_frames=8,
-    windows_per_frame=3, scan_max_index=int(os.environ.get("SCAN_MAX", 256)), n_tof=int(os.environ.get("N_TOF", 200000)),
-    events_per_push=float(os.environ.get("EVENTS_PER_PUSH", 25.0)), mz_lo=400.0,
-    mz_hi=1000.0, frag_mz_lo=200.0, frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0,
-    planted_fraction=0.02,
+    n_precursors=n_prec, n_cycles=n_cycles, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
+    scan_max_index=int(os.environ.get("SCAN_MAX", 256)), n_tof=int(os.environ.get("N_TOF", 200000)),
+    events_per_push=float(os.environ.get("EVENTS_PER_PUSH", 25.0)), mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
+    frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0, planted_fraction=float(os.environ.get("PLANTED", 0.3)),
+    h_range=(3, 14), hs_range=(9, 19), candidates_on_window=True,
 )
-print(f"generated {case.dia.push_indices.size/1e6:.1f}M events in {time.time()-t0:.1f}s", file=sys.stderr)
+dia = case.dia
+print(f"generated {dia.push_indices.size/1e6:.1f}M events in {time.time()-t0:.1f}s", file=sys.stderr, flush=True)
 cfg = CandidateScoringConfig()
-cfg.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True,
-                experimental_xic=True))
+cfg.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True, experimental_xic=True))
 cfgj = cfg.to_jitclass()
-soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
-n = len(soa["precursor_idx"])
 ctx = runtime.get_context(0)
-ctx.stage_run(case.dia)
+soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
+n = len(soa["precursor_idx"])
+t0 = time.time()
+ctx.stage_run(dia)
 cols = fragment_columns(case.library.fragment_df, "mz_library")
 ctx.stage_fragments(*cols)
-ctx.upload_candidates(pack_assembled(soa))
-dev = torch.device("cuda", 0)
-tables = DeviceTables(n, 12, dev, with_stats=True)
-out = tables.as_output(n)
-ws = torch.cuda.Stream(device=dev)
-steps = 5
-with torch.cuda.stream(ws):
-    for it in range(steps + 1):
-        if it == 1:
-            torch.cuda.synchronize()
-            ctx.kernel_time_ms(reset=True)
-            t0 = time.perf_counter()
-        tables.zero_()
-        ctx.score_uploaded(cfgj, out, ws.cuda_stream)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
-g_ms, f_ms, _ = ctx.kernel_time_ms(reset=True)
-host = tables.to_host()
-if os.environ.get("ADH_BENCH_NO_CPU"):
-    print(json.dumps({"gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms, "ms_per_step": dt * 1e3}))
-    sys.exit(0)
-cores = min(64, os.cpu_count() or 1)
-sample = min(n, 6000)
-sub = slice_soa(soa, 0, sample)
-oracle.score_timstof(case.dia, cols, pack_assembled(slice_soa(soa, 0, 500)), cfgj, n_threads=cores)
+t_stage = time.time() - t0
+packed = pack_assembled(soa)
+
+# ---- host -> host steps
+steps, warm = int(os.environ.get("STEPS", 5)), 4
+for _ in range(warm):
+    host = ctx.score_host(packed, cfgj, reuse_buffers=True)
+ctx.kernel_time_ms(reset=True)
 t0 = time.perf_counter()
-exp = oracle.score_timstof(case.dia, cols, pack_assembled(sub), cfgj, n_threads=cores, with_stats=True)
-cdt = time.perf_counter() - t0
-same = bool(np.array_equal(exp["valid"], host["valid"][:sample])
-            and np.array_equal(exp["stat_matched_peaks"], host["stat_matched_peaks"][:sample]))
-F = (soa["frame_stop"] - soa["frame_start"]) // case.dia.cycle_len
+for _ in range(steps):
+    host = ctx.score_host(packed, cfgj, reuse_buffers=True)
+h2h_ms = (time.perf_counter() - t0) / steps * 1e3
+g_ms, f_ms, launches = ctx.kernel_time_ms(reset=True)
+g_ms, f_ms = g_ms * launches / steps, f_ms * launches / steps
+valid = host["valid"].astype(bool).copy()
+matched = ctx.device_tables_to_host(names=["stat_matched_peaks"])["stat_matched_peaks"][:n]
+
+# ---- resident steps (table + plan in HBM, tables stay in HBM)
+ctx.upload_candidates(packed)
+view, st = ctx.device_tables(), ctx.stream_handle()
+for it in range(steps + 1):
+    if it == 1:
+        ctx.synchronize()
+        t0 = time.perf_counter()
+    ctx.zero_device_tables(st)
+    ctx.score_uploaded(cfgj, view, st)
+ctx.synchronize()
+res_ms = (time.perf_counter() - t0) / steps * 1e3
+
+# ---- algorithmic bytes, SURVEY.md section 8(d) with the run-B probe term
+L, S_max = dia.cycle_len, int(dia.scan_max_index)
+mzv = dia.mz_values
+indptr = dia.tof_indptr
+lib_start, lib_stop = soa["frag_start_idx"].astype(np.int64), soa["frag_stop_idx"].astype(np.int64)
+K = np.minimum(lib_stop - lib_start, 12)
+fmz = case.library.fragment_df["mz_library"].values.astype(np.float64)
+
+
+def window_bytes(mz, tol_ppm):
+    lo = np.searchsorted(mzv, mz * (1 - tol_ppm * 1e-6))
+    hi = np.searchsorted(mzv, mz * (1 + tol_ppm * 1e-6))
+    return 8 * (hi - lo) + 6 * (indptr[hi] - indptr[lo])
+
+
+per = np.zeros(n, dtype=np.int64)
+for k in range(int((lib_stop - lib_start).max())):
+    has = lib_start + k < lib_stop
+    per[has] += window_bytes(fmz[(lib_start + k)[has]], 15.0)
+for i in range(3):
+    per += window_bytes(soa["precursor_mz"].astype(np.float64) + i * 1.0033548350700006 / soa["charge"], 10.0)
+F = (soa["frame_stop"] - 1) // L - (soa["frame_start"] - 1) // L
 S = soa["scan_stop"] - soa["scan_start"]
-print(json.dumps({
-    "workload": f"timsTOF-style synthetic run: {case.dia.push_indices.size/1e6:.1f}M events, "
-                f"{int(case.dia.scan_max_index)} scans, {int(case.dia.cycle.shape[1])} frames/cycle, "
-                f"{int(os.environ.get('N_CYCLES', 300))} cycles; {n_prec} precursors x 3 candidates, "
+per += 4 * (F * S * 2)  # the two push queries (fragment frames, MS1 frame), one push per (cycle, scan) each
+per += 18 * (lib_stop - lib_start) + 64 + (46 * 4 + K * 38 + 6)
+alg_bytes = float(per.sum())
+kernel_ms = g_ms + f_ms
+
+result = {
+    "workload": f"BASELINE configs[3]: timsTOF-style synthetic run, {dia.push_indices.size/1e6:.0f}M events, {S_max} scans, "
+                f"{L} frames/cycle, {n_cycles} cycles; {n_prec} precursors x 3 candidates, "
                 f"S in [{int(S.min())},{int(S.max())}], F in [{int(F.min())},{int(F.max())}]",
-    "candidates": n, "precursors_per_s": n_prec / dt, "candidates_per_s": n / dt, "ms_per_step": dt * 1e3,
-    "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms, "valid_fraction": float(host["valid"].mean()),
-    "cpu_oracle": {"candidates_per_s": sample / cdt, "threads": cores, "sample": sample,
-                   "valid_and_matched_peaks_identical_to_gpu": same},
-}))
+    "metric": "precursors scored/sec", "value": n_prec / (h2h_ms * 1e-3), "unit": "precursors/s", "ms_per_step": h2h_ms,
+    "timed_region": "host candidate SoA -> host OutputPsmDF SoA (adh_score_candidates)",
+    "resident": {"ms_per_step": res_ms, "value": n_prec / (res_ms * 1e-3)},
+    "candidates": n, "valid_fraction": float(valid.mean()), "mean_matched_events": float(matched.mean()),
+    "stage_seconds": t_stage,
+    "roofline": {
+        "bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+        "kernel": "adh_gather_im_kernel + adh_feature_im_kernel", "kernel_ms": kernel_ms,
+        "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
+        "algorithmic_bytes_per_candidate": alg_bytes / n,
+        "note": "SURVEY 8(d) run-B formula: the reference merge-joins every TOF bin of a window from the start of "
+                "the bin (bruker_jit.py:415-502), so whole bins count; the kernel binary-searches a bin for the "
+                "candidate's cycles and touches far less, which is why the fraction can exceed 1",
+    },
+}
+if not os.environ.get("ADH_BENCH_NO_CPU"):
+    from oracle import oracle
+
+    quota = cpu_quota_cores()
+    cores = int(min(os.cpu_count() or 1, 2 * quota if quota else 64))
+    sample = min(n, int(os.environ.get("CPU_SAMPLE", 6000)))
+    sub = slice_soa(soa, 0, sample)
+    oracle.score_timstof(dia, cols, pack_assembled(slice_soa(soa, 0, 500)), cfgj, n_threads=cores)
+    t0 = time.perf_counter()
+    exp = oracle.score_timstof(dia, cols, pack_assembled(sub), cfgj, n_threads=cores, with_stats=True)
+    cdt = time.perf_counter() - t0
+    result["cpu_baseline"] = {
+        "value": len(np.unique(sub["precursor_idx"])) / cdt, "unit": "precursors/s", "cores": cores,
+        "cpu_quota_cores": quota, "kind": "port", "sample": f"first {sample} candidates, one pass",
+        "valid_and_matched_events_identical_to_gpu": bool(
+            np.array_equal(exp["valid"].astype(bool), valid[:sample])
+            and np.array_equal(exp["stat_matched_peaks"], matched[:sample])),
+    }
+    result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+print(json.dumps(result))
