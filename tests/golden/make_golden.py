@@ -418,6 +418,82 @@ def golden_host_helpers():
     print(f"{path}: {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def _spectrum_tables(rng, n_cycles, n_windows, prefix, ms1_every_cycle=True, peaks=(3, 9)):
+    """An AlphaRaw-style spectrum_df / peak_df pair: ``prefix`` non-DIA spectra, then cycles of one MS1
+    + ``n_windows`` MS2 spectra (rt in minutes, as alpharaw delivers it)."""
+    edges = np.linspace(400.0, 400.0 + 10.0 * n_windows, n_windows + 1)
+    lower, upper, level, prec = [], [], [], []
+    for _ in range(prefix):  # calibration / settling scans before the method starts cycling
+        lo = float(rng.uniform(300, 900))
+        lower.append(lo)
+        upper.append(lo + float(rng.uniform(1, 30)))
+        level.append(2)
+        prec.append(lo + 1)
+    for c in range(n_cycles):
+        if ms1_every_cycle or c % 3 != 1:
+            lower.append(-1.0)
+            upper.append(-1.0)
+            level.append(1)
+            prec.append(-1.0)
+        for w in range(n_windows):
+            lower.append(edges[w])
+            upper.append(edges[w + 1])
+            level.append(2)
+            prec.append(0.5 * (edges[w] + edges[w + 1]))
+    n = len(lower)
+    counts = rng.integers(peaks[0], peaks[1], n)
+    stop = np.cumsum(counts)
+    spectrum_df = pd.DataFrame({
+        "spec_idx": np.arange(n, dtype=np.int64), "rt": np.cumsum(rng.uniform(0.0008, 0.0012, n)),
+        "ms_level": np.array(level, dtype=np.int64), "precursor_mz": np.array(prec, dtype=np.float64),
+        "isolation_lower_mz": np.array(lower, dtype=np.float64), "isolation_upper_mz": np.array(upper, dtype=np.float64),
+        "peak_start_idx": (stop - counts).astype(np.int64), "peak_stop_idx": stop.astype(np.int64),
+    })
+    mz = np.concatenate([np.sort(rng.uniform(150, 1500, c)) for c in counts])
+    peak_df = pd.DataFrame({"mz": mz, "intensity": rng.lognormal(5, 1, mz.size)})
+    return spectrum_df, peak_df
+
+
+def golden_staging():
+    """f-4: what the reference derives from a spectrum table before anything is scored -
+    ``determine_dia_cycle`` (raw_data/dia_cycle.py:18-82) and ``AlphaRaw._preprocess_raw_data``
+    (raw_data/alpharaw_wrapper.py:72-117) - on tables with a non-DIA prefix and with an MS1 that
+    does not follow the cycle."""
+    import types as _types
+
+    from alphadia.raw_data.alpharaw_wrapper import AlphaRaw
+    from alphadia.raw_data.dia_cycle import determine_dia_cycle
+
+    rng = np.random.default_rng(77)
+    cases = {
+        "plain": dict(n_cycles=40, n_windows=12, prefix=0),
+        "prefix": dict(n_cycles=35, n_windows=9, prefix=7),
+        "irregular_ms1": dict(n_cycles=45, n_windows=6, prefix=0, ms1_every_cycle=False),
+    }
+    d = {}
+    for name, kw in cases.items():
+        sdf, pdf = _spectrum_tables(rng, **kw)
+        for c in sdf.columns:
+            d[f"{name}_spec_{c}"] = sdf[c].values
+        for c in pdf.columns:
+            d[f"{name}_peak_{c}"] = pdf[c].values
+        obj = _types.SimpleNamespace(spectrum_df=sdf.copy(), peak_df=pdf.copy(), has_ms1=True)
+        obj._is_ms1_dia = _types.MethodType(AlphaRaw._is_ms1_dia, obj)
+        AlphaRaw._preprocess_raw_data(obj)
+        cycle, start, length = determine_dia_cycle(obj.spectrum_df if not obj.has_ms1 else sdf)
+        d[f"{name}_cycle_direct"] = cycle
+        for attr in ("cycle", "rt_values", "_peak_start_idx_list", "_peak_stop_idx_list", "_mz_values", "_intensity_values"):
+            d[f"{name}_{attr.lstrip('_')}"] = np.asarray(getattr(obj, attr))
+        for attr in ("_cycle_start", "_cycle_length", "_precursor_cycle_max_index", "_max_mz_value", "_min_mz_value",
+                     "_quad_max_mz_value", "_quad_min_mz_value", "frame_max_index", "has_ms1"):
+            d[f"{name}_{attr.lstrip('_')}"] = np.asarray(getattr(obj, attr))
+        print(name, "cycle length", obj._cycle_length, "start", obj._cycle_start, "has_ms1", obj.has_ms1,
+              "spectra", len(obj.rt_values))
+    path = os.path.join(HERE, "staging.npz")
+    np.savez_compressed(path, **d)
+    print(f"{path}: {os.path.getsize(path)/1e3:.0f} kB")
+
+
 def golden_multiplex():
     case = multiplex_case()
     upd = dict(score_grouped=True, exclude_shared_ions=True, reference_channel=0, experimental_xic=True)
@@ -965,6 +1041,9 @@ if __name__ == "__main__":
     if "--multiplex-only" in sys.argv:
         golden_multiplex()
         sys.exit(0)
+    if "--staging-only" in sys.argv:
+        golden_staging()
+        sys.exit(0)
     if "--host-helpers-only" in sys.argv:
         golden_host_helpers()
         sys.exit(0)
@@ -976,6 +1055,7 @@ if __name__ == "__main__":
     golden_scoring()
     golden_multiplex()
     golden_host_helpers()
+    golden_staging()
     golden_edges()
     golden_selection()
     golden_selection_kats()
