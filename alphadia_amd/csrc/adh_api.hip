@@ -153,6 +153,7 @@ struct adh_handle {
     std::vector<hipEvent_t> free_events;
     double sum_gather_ms = 0.0, sum_feature_ms = 0.0;
     int64_t n_timed = 0;
+    uint64_t d2h_bytes = 0;  // bytes this library copied device -> host (adh_transfer_counters)
 };
 
 namespace {
@@ -1003,3 +1004,4 @@ int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start
 
 #include "adh_fdr.hip"
 #include "adh_mlp.hip"
+#include "adh_fdr_device.hip"

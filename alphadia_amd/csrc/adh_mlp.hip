@@ -488,6 +488,12 @@ struct adh_mlp {
     int64_t xt_cap = 0, yt_cap = 0;
     size_t lds_bytes = 0;
     double fit_ms = 0.0, predict_ms = 0.0;
+    // rows staged straight from the scoring tables in HBM (adh_fdr_device.hip)
+    int64_t *d_rowmap = nullptr;   // [n_rows] candidate row of every staged row
+    uint8_t *d_decoy = nullptr;    // [n_rows]
+    float *d_proba = nullptr;      // [n_rows][out] of adh_mlp_predict_resident
+    int64_t n_table = 0;           // rows of the table the stage came from
+    bool proba_ready = false;
 };
 
 namespace {
@@ -563,7 +569,8 @@ int adh_mlp_destroy(adh_mlp_t *m) {
     if (!m) return ADH_OK;
     (void)hipSetDevice(m->h->device);
     void *ptrs[] = {m->d_P, m->d_m, m->d_v, m->d_rm, m->d_rv, m->d_stats, m->d_X, m->d_Y, m->d_rows, m->d_gpart,
-                    m->d_loss_part, m->d_loss, m->d_bn_part, m->d_ticket, m->d_batch_start, m->d_pos, m->d_Xt, m->d_Yt};
+                    m->d_loss_part, m->d_loss, m->d_bn_part, m->d_ticket, m->d_batch_start, m->d_pos, m->d_Xt, m->d_Yt,
+                    m->d_rowmap, m->d_decoy, m->d_proba};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -810,6 +817,7 @@ int adh_mlp_predict(adh_mlp_t *m, const int64_t *rows, int64_t n, float *proba) 
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("adh_mlp_predict: ") + hipGetErrorString(e));
     m->predict_ms = ms;
+    m->h->d2h_bytes += (uint64_t)n * out_dim * 4;
     return ADH_OK;
 }
 

@@ -674,6 +674,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
                 fail(ADH_ERR_HIP, std::string("hipMemcpyAsync D2H: ") + hipGetErrorString(e));
                 return fail_sync(ADH_ERR_HIP);
             }
+            h->d2h_bytes += (uint64_t)(b - a) * rb;
         }
         if (dbg_events) (void)hipEventRecord(dbg.back(), so);
     }
@@ -876,6 +877,14 @@ int adh_copy_to_host(adh_handle_t *h, void *dst, const void *src_device, uint64_
     if (!h || (bytes > 0 && (!dst || !src_device))) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
     if (bytes > 0) HIP_TRY(hipMemcpy(dst, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
+    h->d2h_bytes += bytes;
+    return ADH_OK;
+}
+
+int adh_transfer_counters(adh_handle_t *h, uint64_t *d2h_bytes, int reset) {
+    if (!h || !d2h_bytes) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *d2h_bytes = h->d2h_bytes;
+    if (reset) h->d2h_bytes = 0;
     return ADH_OK;
 }
 

@@ -231,59 +231,85 @@ class HipBinaryClassifier:
         epoch_of = np.concatenate(epoch_of) if epoch_of else np.zeros(0, np.int64)
         return train_rows, test_rows, schedule, epoch_of
 
+    def _prepare(self, n_features: int) -> None:
+        if self._state is not None and self.input_dim != n_features:
+            warnings.warn("Input dimension of network has changed. Network has been reinitialized.")
+            self._state = None
+        if self._state is None:
+            self.input_dim = n_features
+            self._init_state()
+        if self.output_dim != 2:
+            raise NotImplementedError("the device classifier is binary (output_dim = 2)")
+
+    def _train(self, mlp, y1: np.ndarray, base_rows: np.ndarray | None = None) -> None:
+        """The training loop of classifiers.py:350-433 over rows that are already staged in ``mlp``.
+        ``y1`` holds the class-1 target of the rows the classifier sees; ``base_rows`` maps them to
+        staged rows when the classifier is given a subset (perform_fdr trains on 80 %)."""
+        at = (lambda r: r) if base_rows is None else (lambda r: base_rows[r])
+        if self.experimental_hyperparameter_tuning:
+            self.batch_size, self.learning_rate = scaled_training_params(len(y1))
+            logger.info(f"Estimating optimal hyperparameters - samples: {len(y1):,}, batch_size: "
+                        f"{self.batch_size:,}, learning_rate: {self.learning_rate:.2e}")
+        train_rows, test_rows, schedule, epoch_of = self._plan(len(y1))
+        self.last_fit_ms = 0.0
+        t_test = np.stack([1 - y1[test_rows], y1[test_rows]], axis=1)
+        done = 0
+        n_steps = len(schedule)
+        while done < n_steps:
+            # run up to and including the next step that reports metrics (classifiers.py:395-428)
+            stop = done
+            while stop < n_steps and stop % self.metric_interval != 0:
+                stop += 1
+            stop = min(stop + 1, n_steps)
+            loss = mlp.fit(at(train_rows), schedule[done:stop], self.batch_size, self.learning_rate,
+                           self.weight_decay, self.dropout, seed=self._dropout_seed, first_step=done)
+            self.last_fit_ms += mlp.time_ms()[0]
+            last = stop - 1
+            if last % self.metric_interval == 0:
+                batch_rows = train_rows[schedule[last] : schedule[last] + self.batch_size]
+                p_test = mlp.predict(at(test_rows))
+                p_batch = mlp.predict(at(batch_rows))
+                self.metrics["epoch"].append(int(epoch_of[last]))
+                self.metrics["batch_count"].append(int(last))
+                self.metrics["train_loss"].append(float(loss[-1]))
+                self.metrics["test_loss"].append(_bce(p_test, t_test))
+                self.metrics["train_accuracy"].append(float(np.mean(y1[batch_rows] == np.argmax(p_batch, axis=1))))
+                self.metrics["test_accuracy"].append(float(np.mean(y1[test_rows] == np.argmax(p_test, axis=1)))
+                                                     if len(test_rows) else float("nan"))
+            done = stop
+        self._state = mlp.get_state()
+        self._fitted = True
+
     def fit(self, x: np.ndarray, y: np.ndarray) -> None:
         """classifiers.py:316-433, one optimiser step = three kernels on the device."""
         x = np.asarray(x)
         y = np.asarray(y)
-        if self.experimental_hyperparameter_tuning:
-            self.batch_size, self.learning_rate = scaled_training_params(len(x))
-            logger.info(f"Estimating optimal hyperparameters - samples: {len(x):,}, batch_size: "
-                        f"{self.batch_size:,}, learning_rate: {self.learning_rate:.2e}")
-        if self._state is not None and self.input_dim != x.shape[1]:
-            warnings.warn("Input dimension of network has changed. Network has been reinitialized.")
-            self._state = None
-        if self._state is None:
-            self.input_dim = x.shape[1]
-            self._init_state()
-        if self.output_dim != 2:
-            raise NotImplementedError("the device classifier is binary (output_dim = 2)")
+        self._prepare(x.shape[1])
         y1 = y if y.ndim == 1 else y[:, 1]
-
-        train_rows, test_rows, schedule, epoch_of = self._plan(len(x))
-
         mlp = self._device_mlp()
         try:
             mlp.stage_rows(x, y1)
-            self.last_fit_ms = 0.0
-            t_test = np.stack([1 - y1[test_rows], y1[test_rows]], axis=1)
-            done = 0
-            n_steps = len(schedule)
-            while done < n_steps:
-                # run up to and including the next step that reports metrics (classifiers.py:395-428)
-                stop = done
-                while stop < n_steps and stop % self.metric_interval != 0:
-                    stop += 1
-                stop = min(stop + 1, n_steps)
-                loss = mlp.fit(train_rows, schedule[done:stop], self.batch_size, self.learning_rate,
-                               self.weight_decay, self.dropout, seed=self._dropout_seed, first_step=done)
-                self.last_fit_ms += mlp.time_ms()[0]
-                last = stop - 1
-                if last % self.metric_interval == 0:
-                    batch_rows = train_rows[schedule[last] : schedule[last] + self.batch_size]
-                    p_test = mlp.predict(test_rows)
-                    p_batch = mlp.predict(batch_rows)
-                    self.metrics["epoch"].append(int(epoch_of[last]))
-                    self.metrics["batch_count"].append(int(last))
-                    self.metrics["train_loss"].append(float(loss[-1]))
-                    self.metrics["test_loss"].append(_bce(p_test, t_test))
-                    self.metrics["train_accuracy"].append(float(np.mean(y1[batch_rows] == np.argmax(p_batch, axis=1))))
-                    self.metrics["test_accuracy"].append(float(np.mean(y1[test_rows] == np.argmax(p_test, axis=1)))
-                                                         if len(test_rows) else float("nan"))
-                done = stop
-            self._state = mlp.get_state()
+            self._train(mlp, y1)
         finally:
             mlp.close()
-        self._fitted = True
+
+    def fit_resident(self, src_cols, decoy, extra_cols=(), subset=None):
+        """Train on rows staged straight from the scoring tables in HBM (``adh_mlp_stage_rows_device``).
+        ``subset(n_staged) -> rows`` picks the staged rows the classifier may see (perform_fdr's 80 %
+        split).  Returns ``(mlp, table_rows)``: the live device network (the caller closes it) and the
+        candidate row of every staged row."""
+        self._prepare(len(src_cols))
+        mlp = self._device_mlp()
+        try:
+            mlp.stage_rows_device(src_cols, decoy, extra_cols)
+            table_rows = mlp.staged_rows()
+            y_all = (np.asarray(decoy)[table_rows] != 0).astype(np.float64)
+            base = None if subset is None else np.asarray(subset(len(table_rows)), dtype=np.int64)
+            self._train(mlp, y_all if base is None else y_all[base], base_rows=base)
+        except Exception:
+            mlp.close()
+            raise
+        return mlp, table_rows
 
     def _forward(self, x: np.ndarray) -> np.ndarray:
         if not self.fitted:
@@ -407,6 +433,65 @@ def perform_fdr(classifier, available_columns: list[str], df_target: pd.DataFram
 
     psm_df = keep_best(psm_df, group_columns=group_columns, device=device)
     return get_q_values(psm_df, "proba", "_decoy", device=device)
+
+
+def perform_fdr_resident(classifier, available_columns: list[str], candidates: pd.DataFrame, *, rt_column: str = "rt_library",
+                         competitive: bool = False, group_channels: bool = True, dia_cycle: np.ndarray | None = None,
+                         fdr_heuristic: float = 0.1, random_state: int | None = None,
+                         device: int | None = None) -> pd.DataFrame:
+    """:func:`perform_fdr` for tables that are still in HBM.
+
+    ``candidates`` has ONE ROW PER ROW of the device tables of the last scoring call (the assembled
+    candidate table: ``precursor_idx, rank, decoy, elution_group_idx, channel`` and the library columns
+    a classifier column needs, i.e. ``rt_column`` for ``delta_rt`` and ``mz_library``).  The feature
+    rows are staged for the classifier, scored, ranked, put through fragment competition (fragment
+    m/z from the fragment table in HBM) and reduced to the best row per group on the device; what
+    comes back is the surviving PSMs with ``proba`` and ``qval`` - the frame perform_fdr returns,
+    restricted to the identifying columns."""
+    from alphadia_amd.scoring import DEFAULT_FEATURE_COLUMNS
+
+    ctx = runtime.get_context(device)
+    extras, src_cols = [], []
+    for c in available_columns:
+        if c in DEFAULT_FEATURE_COLUMNS:
+            src_cols.append(DEFAULT_FEATURE_COLUMNS.index(c))
+        elif c == "delta_rt":  # rt_observed - library rt (scoring.py:458)
+            extras.append(candidates[rt_column].to_numpy().astype(np.float32))
+            src_cols.append(-len(extras))
+        elif c in candidates.columns:
+            extras.append(candidates[c].to_numpy().astype(np.float32))
+            src_cols.append(len(DEFAULT_FEATURE_COLUMNS) + len(extras) - 1)
+        else:
+            raise KeyError(f"classifier column {c!r} is neither a scoring feature nor a column of `candidates`")
+    decoy = candidates["decoy"].to_numpy()
+
+    def subset(n_staged):
+        try:
+            return train_test_indices(n_staged, 0.2, random_state)[0]
+        except TooFewPSMError:
+            return np.zeros(0, np.int64)
+
+    if getattr(classifier, "device", device) is None:
+        classifier.device = device
+    mlp, table_rows = classifier.fit_resident(src_cols, decoy, extras, subset=subset)
+    try:
+        mlp.predict_resident()
+        if competitive:
+            ga = candidates["elution_group_idx"].to_numpy()
+            gb = candidates["channel"].to_numpy() if group_channels else None
+        else:
+            ga, gb = candidates["precursor_idx"].to_numpy(), None
+        rows, proba, qval = ctx.fdr_resident(mlp, ga, gb, tiebreak=candidates["precursor_idx"].to_numpy(),
+                                             cycle=dia_cycle, fdr_heuristic=fdr_heuristic)
+    finally:
+        mlp.close()
+    out = candidates.iloc[rows][[c for c in ("precursor_idx", "rank", "elution_group_idx", "channel", "decoy")
+                                 if c in candidates.columns]].copy()
+    out["_decoy"] = out["decoy"].to_numpy().astype(np.float64)
+    out["proba"] = proba
+    out["qval"] = qval
+    out["table_row"] = rows
+    return out
 
 
 class HipFDRManager:

@@ -48,6 +48,11 @@ EXPORTED_SYMBOLS = [
     "adh_get_device_tables",
     "adh_zero_device_tables",
     "adh_debug_get_dense",
+    "adh_mlp_stage_rows_device",
+    "adh_mlp_staged_rows",
+    "adh_mlp_predict_resident",
+    "adh_fdr_resident",
+    "adh_transfer_counters",
     "adh_host_alloc",
     "adh_host_free",
     "adh_copy_to_host",
@@ -270,9 +275,45 @@ class Context:
                 buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(buf.shape[0]),
                 obs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_obs), C.byref(n_s), C.byref(n_f)),
             "adh_debug_get_dense",
+    "adh_mlp_stage_rows_device",
+    "adh_mlp_staged_rows",
+    "adh_mlp_predict_resident",
+    "adh_fdr_resident",
+    "adh_transfer_counters",
         )
         K, O, S, F = q.shape[0], n_obs.value, n_s.value, n_f.value
         return buf[: 2 * K * O * S * F].reshape(2, K, O, S, F).copy(), obs[:O].astype(np.int64)
+
+    def d2h_bytes(self, reset: bool = False) -> int:
+        """Bytes the library copied device -> host on this GPU since the last reset."""
+        v = C.c_uint64(0)
+        _check(lib.adh_transfer_counters(self._h, C.byref(v), C.c_int(int(reset))), "adh_transfer_counters")
+        return int(v.value)
+
+    def fdr_resident(self, mlp: "DeviceMlp", group_a, group_b=None, tiebreak=None, cycle=None,
+                     rt_tol_seconds: float = 3.0, mass_tol_ppm: float = 15.0, fdr_heuristic: float = 0.1):
+        """fdr.py:134-178 on the device for rows staged with ``DeviceMlp.stage_rows_device`` and scored
+        with ``predict_resident``: returns ``(candidate_row, proba, qval)`` of the surviving PSMs."""
+        ga = _abi.as_c(group_a, np.int64)
+        gb = _abi.as_c(group_b, np.int64) if group_b is not None else None
+        tb = _abi.as_c(tiebreak, np.int64) if tiebreak is not None else None
+        cyc = _abi.as_c(cycle, np.float64) if cycle is not None else None
+        if cyc is not None and (cyc.ndim != 4 or cyc.shape[0] != 1 or cyc.shape[3] != 2):
+            raise ValueError("cycle must have shape (1, cycle_len, cycle_scans, 2)")
+        m = mlp.n_rows
+        rows, proba, qval = np.zeros(m, np.int64), np.zeros(m, np.float32), np.zeros(m, np.float64)
+        n_out = C.c_int64(0)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None  # noqa: E731
+        _check(
+            lib.adh_fdr_resident(
+                self._h, mlp._m, p(ga, C.c_int64), p(gb, C.c_int64), p(tb, C.c_int64), p(cyc, C.c_double),
+                C.c_int32(cyc.shape[1] if cyc is not None else 0), C.c_int32(cyc.shape[2] if cyc is not None else 0),
+                C.c_double(float(rt_tol_seconds)), C.c_double(float(mass_tol_ppm)), C.c_double(float(fdr_heuristic)),
+                C.byref(n_out), p(rows, C.c_int64), p(proba, C.c_float), p(qval, C.c_double)),
+            "adh_fdr_resident",
+        )
+        k = int(n_out.value)
+        return rows[:k], proba[:k], qval[:k]
 
     def zero_device_tables(self, stream: int = 0) -> None:
         _check(lib.adh_zero_device_tables(self._h, C.c_void_p(stream)), "adh_zero_device_tables")
@@ -569,6 +610,30 @@ class DeviceMlp:
         _check(lib.adh_mlp_stage_rows(self._m, self._p(xa, C.c_float), C.c_int64(xa.shape[0]), C.c_int32(xa.shape[1]),
                                       self._p(ya, C.c_float) if ya is not None else None), "adh_mlp_stage_rows")
         self.n_rows = xa.shape[0]
+
+    def stage_rows_device(self, src_cols, decoy, extra_cols=()):
+        """Stage the usable rows of the device tables of the last ``score_host`` call (targets first,
+        then decoys); returns ``(n_targets, n_decoys)``.  See ``adh_mlp_stage_rows_device``."""
+        sc = _abi.as_c(src_cols, np.int32)
+        de = _abi.as_c(np.asarray(decoy) != 0, np.uint8)
+        extras = [_abi.as_c(e, np.float32) for e in extra_cols]
+        if any(e.shape != de.shape for e in extras):
+            raise ValueError("extra columns must have one value per candidate row")
+        arr = (C.POINTER(C.c_float) * max(len(extras), 1))(*[self._p(e, C.c_float) for e in extras])
+        nt, nd = C.c_int64(0), C.c_int64(0)
+        _check(lib.adh_mlp_stage_rows_device(self._m, self._p(sc, C.c_int32), C.c_int32(sc.shape[0]), arr,
+                                             C.c_int32(len(extras)), self._p(de, C.c_uint8), C.c_int64(de.shape[0]),
+                                             C.byref(nt), C.byref(nd)), "adh_mlp_stage_rows_device")
+        self.n_rows = int(nt.value) + int(nd.value)
+        return int(nt.value), int(nd.value)
+
+    def staged_rows(self) -> np.ndarray:
+        rows = np.zeros(self.n_rows, dtype=np.int64)
+        _check(lib.adh_mlp_staged_rows(self._m, self._p(rows, C.c_int64), C.c_int64(rows.shape[0])), "adh_mlp_staged_rows")
+        return rows
+
+    def predict_resident(self) -> None:
+        _check(lib.adh_mlp_predict_resident(self._m), "adh_mlp_predict_resident")
 
     def fit(self, train_rows, batch_start, batch_size: int, learning_rate: float, weight_decay: float,
             dropout: float, seed: int = 0, first_step: int = 0, betas=(0.9, 0.999), eps: float = 1e-8) -> np.ndarray:

@@ -469,6 +469,44 @@ int adh_mlp_predict(adh_mlp_t *mlp, const int64_t *rows, int64_t n, float *proba
 /* HIP-event time (ms) of the kernels of the last adh_mlp_fit / adh_mlp_predict call */
 int adh_mlp_time_ms(adh_mlp_t *mlp, double *fit_ms, double *predict_ms);
 
+/* ------------------------------------------------------------------------------------------
+ * The FDR stage fed from the scoring tables that adh_score_candidates left in HBM: the 46-float
+ * feature rows and the fragment tables never cross PCIe between scoring and FDR
+ * (the reference hands DataFrames over on the host: workflow/peptidecentric/peptidecentric.py:219-243
+ * -> fdr/fdr.py:24-178).  Only row-sized metadata travels.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Classifier rows straight from the device tables (fdr.py:86-105): of the `n_rows` candidate rows of
+ * the last adh_score_candidates call, those that are valid and have no NaN in a classifier column are
+ * staged, targets first, then decoys, each in row order (np.concatenate([targets, decoys])).
+ * Column j of the network input is, by src_cols[j]:  0..45 = that feature;  46 + e = extra_cols[e]
+ * (host float[n_rows], e.g. mz_library);  -(1 + e) = rt_observed - extra_cols[e] (delta_rt,
+ * scoring.py:458).  `decoy` is a host uint8[n_rows].  Returns the staged counts.
+ */
+int adh_mlp_stage_rows_device(adh_mlp_t *mlp, const int32_t *src_cols, int32_t d, const float *const *extra_cols,
+                              int32_t n_extra, const uint8_t *decoy, int64_t n_rows, int64_t *n_targets,
+                              int64_t *n_decoys);
+/* candidate row of every staged row (8 bytes per row; the host needs it to label its metrics) */
+int adh_mlp_staged_rows(adh_mlp_t *mlp, int64_t *rows_out, int64_t capacity);
+/* network.eval() forward of all staged rows; the probabilities stay in HBM */
+int adh_mlp_predict_resident(adh_mlp_t *mlp);
+/*
+ * fdr.py:134-178 on the device: q-values of the staged rows (sorted by proba, decoy, tiebreak) ->
+ * if `cycle` is given (float64 [cycle_len][cycle_scans][2], cycle_scans <= 2): the rows below
+ * `fdr_heuristic` compete for fragments (fragcomp/fragcomp.py:231-299; fragment m/z from the
+ * fragment_mz_observed table, rt / m/z from features 2 / 10), the others are dropped -> best row per
+ * (group_a[, group_b]) -> q-values.  group_a / group_b / tiebreak are host int64[n_rows of the
+ * device tables] (e.g. elution_group_idx, channel, precursor_idx).  Out (host, capacity = staged
+ * rows): candidate row, class-1 probability and q-value of the surviving PSMs in the final order.
+ */
+int adh_fdr_resident(adh_handle_t *handle, adh_mlp_t *mlp, const int64_t *group_a, const int64_t *group_b,
+                     const int64_t *tiebreak, const double *cycle, int32_t cycle_len, int32_t cycle_scans,
+                     double rt_tol_seconds, double mass_tol_ppm, double fdr_heuristic, int64_t *n_out,
+                     int64_t *row_out, float *proba_out, double *qval_out);
+/* bytes this library has copied device -> host on the handle's GPU since the last reset */
+int adh_transfer_counters(adh_handle_t *handle, uint64_t *d2h_bytes, int reset);
+
 #ifdef __cplusplus
 }
 #endif
