@@ -338,9 +338,19 @@ class Context:
     # -- staging ---------------------------------------------------------
     @staticmethod
     def _key(*arrays):
-        return tuple(
-            (a.__array_interface__["data"][0], a.shape, str(a.dtype)) for a in map(np.asarray, arrays)
-        )
+        """Identity of host arrays that are staged in HBM: address, shape, dtype and a checksum of a
+        strided sample (<= 64 K elements per array).  The arrays themselves are kept alive while they
+        are staged (``_run_keepalive`` / ``_lib_keepalive``), so an address cannot be handed to a new
+        array; the checksum catches in-place edits."""
+        import zlib
+
+        key = []
+        for a in map(np.asarray, arrays):
+            flat = a.reshape(-1)
+            step = max(1, flat.shape[0] // 65536)
+            crc = zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8)) if flat.shape[0] else 0
+            key.append((a.__array_interface__["data"][0], a.shape, str(a.dtype), crc))
+        return tuple(key)
 
     def stage_run(self, dia, force: bool = False) -> bool:
         """Copy the run to HBM unless this very run is already staged."""
@@ -351,7 +361,7 @@ class Context:
             m = _abi.pack_timstof(dia)
             _check(lib.adh_stage_timstof(self._h, m.ref()), "adh_stage_timstof")
             self._run_key = key
-            self._run_keepalive = (dia.push_indices, dia.intensity_values)
+            self._run_keepalive = (dia.mz_values, dia.intensity_values, dia.push_indices, dia.tof_indptr)
             return True
         key = self._key(dia.mz_values, dia.intensity_values, dia.peak_start_idx_list, dia.rt_values)
         if not force and key == self._run_key:
@@ -359,7 +369,7 @@ class Context:
         m = _abi.pack_alpharaw(dia)
         _check(lib.adh_stage_alpharaw(self._h, m.ref()), "adh_stage_alpharaw")
         self._run_key = key
-        self._run_keepalive = (dia.mz_values, dia.intensity_values)
+        self._run_keepalive = (dia.mz_values, dia.intensity_values, dia.peak_start_idx_list, dia.rt_values)
         return True
 
     def stage_fragments(self, *columns, force: bool = False) -> bool:

@@ -45,6 +45,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))  # the synthetic data generators live with the tests
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -136,7 +138,8 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` for N > 1")
 
-    from alphadia_amd import _abi, runtime, synthetic as syn
+    import synthetic as syn
+    from alphadia_amd import _abi, runtime
     from alphadia_amd.distributed import shard_bounds
     from alphadia_amd.scoring import (
         CandidateScoringConfig,

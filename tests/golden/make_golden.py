@@ -7,7 +7,7 @@ mounted there):
 
 It imports the reference's own modules through ``ref_shim`` (which stubs the
 missing third-party packages numba / alphatims / alpharaw, nothing else), feeds
-them synthetic inputs from ``alphadia_amd.synthetic`` and stores inputs AND
+them synthetic inputs from ``tests/synthetic.py`` and stores inputs AND
 outputs as small ``.npz`` fixtures, so that the tests need neither the
 reference nor bit-reproducible random streams on the GPU box.
 
@@ -26,6 +26,7 @@ import pandas as pd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))  # tests/: the synthetic generators
 sys.path.insert(0, HERE)
 
 import ref_shim  # noqa: E402
@@ -38,7 +39,7 @@ from alphadia.search.scoring import scoring as ref_scoring  # noqa: E402
 from alphadia.search.scoring.config import CandidateScoringConfig  # noqa: E402
 from alphadia.search.scoring.output import OutputPsmDF  # noqa: E402
 
-from alphadia_amd import synthetic as syn  # noqa: E402
+import synthetic as syn  # noqa: E402
 
 CAVEAT = (
     "reference executed as pure Python under a numba stub with NumPy "

@@ -8,7 +8,7 @@ from types import SimpleNamespace
 import numpy as np
 import pandas as pd
 
-from alphadia_amd import synthetic as syn
+import synthetic as syn
 from alphadia_amd.scoring import (
     CandidateScoringConfig,
     assemble_candidates,

@@ -6,7 +6,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from alphadia_amd import synthetic as syn
+import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import helpers as H
-from alphadia_amd import synthetic as syn
+import synthetic as syn
 from alphadia_amd.scoring import FRAGMENT_DF_COLUMNS, CandidateScoringConfig, fragment_columns, pack_assembled
 
 pytestmark = pytest.mark.gpu

@@ -237,7 +237,7 @@ def test_threads_do_not_change_results(oracle_lib):
 def _tims_golden():
     import pandas as pd
 
-    from alphadia_amd import synthetic as syn
+    import synthetic as syn
     from alphadia_amd.scoring import CandidateScoringConfig
 
     z = np.load(H.golden_path("scoring_timstof.npz"))

@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from alphadia_amd import synthetic as syn
+import synthetic as syn
 
 
 @pytest.mark.gpu

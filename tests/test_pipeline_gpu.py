@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import helpers as H
-from alphadia_amd import synthetic as syn
+import synthetic as syn
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
 
 pytestmark = pytest.mark.gpu
@@ -204,3 +204,17 @@ def test_hip_dense_tile_matches_reference_timstof(ctx):
         assert dense.shape == e.shape and np.array_equal(dense, e), f"case {i}"
         hits += int((e[0] > 0).sum())
     assert hits > 20
+
+
+def test_staging_cache_notices_edited_arrays(ctx, case):
+    """``stage_run`` skips the upload when the very same arrays are staged already; an in-place edit
+    of a staged array (same address, same shape) must not be mistaken for "already staged"."""
+    import copy
+
+    dia = copy.copy(case.dia)
+    dia.intensity_values = case.dia.intensity_values.copy()
+    assert ctx.stage_run(dia, force=True) is True
+    assert ctx.stage_run(dia) is False
+    dia.intensity_values[::7] *= 2.0
+    assert ctx.stage_run(dia) is True
+    assert ctx.stage_run(dia) is False

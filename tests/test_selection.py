@@ -177,7 +177,7 @@ def test_hip_selection_operator_dataframe(ctx):
 @pytest.mark.gpu
 def test_hip_selection_at_bench_density(ctx, oracle_lib):
     """A larger run (config-2 density): HIP equals the oracle on every row."""
-    from alphadia_amd import synthetic as syn
+    import synthetic as syn
 
     case = syn.make_case(3000, 400, config_id=2, per_precursor=1, threads=4)
     cols = fragment_columns(case.library.fragment_df, "mz_library")
@@ -201,7 +201,7 @@ def test_hip_selection_at_bench_density(ctx, oracle_lib):
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT", "6")))))
 def test_hip_selection_randomized(ctx, oracle_lib, seed):
     """Differential test: random run geometry and selection settings, HIP == oracle."""
-    from alphadia_amd import synthetic as syn
+    import synthetic as syn
 
     rng = np.random.default_rng(3000 + seed)
     n_ms2 = int(rng.integers(3, 12))
@@ -242,7 +242,7 @@ def test_hip_selection_randomized(ctx, oracle_lib, seed):
 
 # ---------------------------------------------------------------- ion-mobility runs
 def _load_tims():
-    from alphadia_amd import synthetic as syn
+    import synthetic as syn
 
     z = np.load(H.golden_path("selection_timstof.npz"))
     dia = syn.TimsTOFArrays(
@@ -306,7 +306,7 @@ def test_hip_timstof_selection_matches_oracle_and_golden(ctx, oracle_lib):
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT_IM", "5")))))
 def test_hip_timstof_selection_randomized(ctx, oracle_lib, seed):
     """Differential test on ion-mobility runs: random geometry and settings, HIP == oracle."""
-    from alphadia_amd import synthetic as syn
+    import synthetic as syn
 
     rng = np.random.default_rng(4000 + seed)
     sm = int(rng.choice([64, 96, 128]))

@@ -7,7 +7,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphadia_amd import runtime, synthetic as syn  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
+import synthetic as syn
+from alphadia_amd import runtime  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 
 N_PREC = int(os.environ.get("N_PREC", 1_000_000))

@@ -4,9 +4,11 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
 import torch  # noqa: E402
 
-from alphadia_amd import runtime, synthetic as syn  # noqa: E402
+import synthetic as syn
+from alphadia_amd import runtime  # noqa: E402
 from alphadia_amd.distributed import DeviceTables  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 

@@ -11,7 +11,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphadia_amd import _abi, runtime, synthetic as syn  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
+import synthetic as syn
+    from alphadia_amd import _abi, runtime  # noqa: E402
 from alphadia_amd.scoring import fragment_columns  # noqa: E402
 from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel  # noqa: E402
 

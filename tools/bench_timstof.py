@@ -17,7 +17,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from alphadia_amd import runtime, synthetic as syn  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
+import synthetic as syn
+from alphadia_amd import runtime  # noqa: E402
 from alphadia_amd.distributed import slice_soa  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 from bench import cpu_quota_cores  # noqa: E402

@@ -4,7 +4,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphadia_amd import synthetic as syn  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
+import synthetic as syn  # noqa: E402
 from alphadia_amd.distributed import slice_soa  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 from oracle import oracle  # noqa: E402

@@ -1,7 +1,9 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from alphadia_amd import runtime, synthetic as syn
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))  # synthetic data generators
+import synthetic as syn
+from alphadia_amd import runtime
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
 case = syn.make_case(1_000_000, 4800, config_id=2, per_precursor=3, threads=os.cpu_count())
 cfg = CandidateScoringConfig()

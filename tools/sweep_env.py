@@ -11,12 +11,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
 
 
 def main():
     import torch
 
-    from alphadia_amd import runtime, synthetic as syn
+    import synthetic as syn
+from alphadia_amd import runtime
     from alphadia_amd.distributed import DeviceTables
     from alphadia_amd.scoring import (CandidateScoringConfig, assemble_candidates, fragment_columns,
                                       pack_assembled)
