@@ -80,6 +80,8 @@ struct PlanSlot {
     uint64_t *bytes = nullptr, *sorted_bytes = nullptr, *offs = nullptr;
     void *cub_tmp = nullptr;
     size_t cub_bytes = 0;
+    uint32_t *hist = nullptr;       // counting sort: one counter / cursor per (class, first cycle) key
+    int64_t hist_cap = 0;
     PlanMeta *d_meta = nullptr, *h_meta = nullptr;  // device / pinned host
     hipEvent_t done = nullptr;
     DeviceBuffers buf;
@@ -257,6 +259,7 @@ int adh_destroy(adh_handle_t *h) {
     h->lib_buf.release();
     for (PlanSlot &s : h->slots) {
         s.buf.release();
+        if (s.hist) (void)hipFree(s.hist);
         if (s.h_meta) (void)hipHostFree(s.h_meta);
         if (s.done) (void)hipEventDestroy(s.done);
     }

@@ -75,8 +75,12 @@ namespace plan {
 
 constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
 
+// maximum over the wavefront, then ONE atomic per wavefront and slot (a quarter of a million
+// same-address atomics per launch cost 0.3 ms)
 __device__ __forceinline__ void raise_max(int32_t *slot, int32_t v) {
-    if (v > *reinterpret_cast<volatile int32_t *>(slot)) atomicMax(slot, v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0 && v > *reinterpret_cast<volatile int32_t *>(slot)) atomicMax(slot, v);
 }
 
 // isotope m/z range -> quadrupole query range exactly as the kernels compute it
@@ -97,9 +101,10 @@ __device__ __forceinline__ void quad_range(float precursor_mz, uint8_t charge, i
 __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const double *__restrict__ cyc, PlanArgs p,
                                                            CandRec *__restrict__ recs, uint32_t *__restrict__ keys,
                                                            uint32_t *__restrict__ idx, uint64_t *__restrict__ bytes,
-                                                           PlanMeta *__restrict__ meta) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= p.n) return;
+                                                           uint32_t *__restrict__ hist, PlanMeta *__restrict__ meta) {
+    const int64_t j0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j0 < p.n;          // dead lanes of the last block ride along (wave-wide reductions below)
+    const int64_t j = live ? j0 : p.n - 1;
     const int64_t i = p.row0 + j;
     CandRec r;
     memset(&r, 0, sizeof(r));
@@ -119,10 +124,10 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
     r.rank = c.rank[i];
     r.flags = c.flags ? c.flags[i] : (uint8_t)0;
     r.row = (uint32_t)i;
-    idx[j] = (uint32_t)j;
     int cls = ADH_CLASS_GENERIC;
     uint32_t bin = 0;
     uint64_t nbytes = 0;
+    int32_t mx_k = 0, mx_o = 0, mx_f = 0, mx_l = 0, gx_k = 0, gx_o = 0, gx_f = 0, gx_l = 0;
     if (!(r.flags & ADH_FLAG_SKIP)) {
         int err = 0;
         if (r.frag_stop < r.frag_start || (int64_t)r.frag_stop > p.n_lib) err = ADH_PLAN_ERR_FRAG_SLICE;
@@ -159,21 +164,27 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
             cls = !fast ? ADH_CLASS_GENERIC : (O == 1 ? max(F - 5, 0) / 4 : 7 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)));
             bin = (uint32_t)(r.frame_start / p.L);
             nbytes = adh_scratch_bytes(r.k_cap, O, max(F, 0), p.I);
-            plan::raise_max(&meta->all_k, (int32_t)r.k_cap);
-            plan::raise_max(&meta->all_o, O);
-            plan::raise_max(&meta->all_f, F);
-            plan::raise_max(&meta->all_n_lib, (int32_t)nl);
-            if (cls == ADH_CLASS_GENERIC) {
-                plan::raise_max(&meta->gen_k, (int32_t)r.k_cap);
-                plan::raise_max(&meta->gen_o, O);
-                plan::raise_max(&meta->gen_f, F);
-                plan::raise_max(&meta->gen_n_lib, (int32_t)nl);
+            if (live) {
+                mx_k = (int32_t)r.k_cap, mx_o = O, mx_f = F, mx_l = (int32_t)nl;
+                if (cls == ADH_CLASS_GENERIC) gx_k = mx_k, gx_o = mx_o, gx_f = mx_f, gx_l = mx_l;
             }
         }
     }
+    plan::raise_max(&meta->all_k, mx_k);
+    plan::raise_max(&meta->all_o, mx_o);
+    plan::raise_max(&meta->all_f, mx_f);
+    plan::raise_max(&meta->all_n_lib, mx_l);
+    plan::raise_max(&meta->gen_k, gx_k);
+    plan::raise_max(&meta->gen_o, gx_o);
+    plan::raise_max(&meta->gen_f, gx_f);
+    plan::raise_max(&meta->gen_n_lib, gx_l);
+    if (!live) return;
+    const uint32_t key = (uint32_t)cls * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
     recs[j] = r;
-    keys[j] = (uint32_t)cls * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
+    keys[j] = key;
+    idx[j] = (uint32_t)j;
     bytes[j] = nbytes;
+    if (hist) atomicAdd(&hist[key], 1u);  // counting sort by (class, first cycle)
 }
 
 // Ion-mobility plan: observation lists = sorted unique dia_precursor_cycle values of the cycle rows
@@ -182,9 +193,10 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
                                                               const int32_t *__restrict__ dpc, PlanArgs p,
                                                               CandRecIM *__restrict__ recs, uint32_t *__restrict__ keys,
                                                               uint32_t *__restrict__ idx, uint64_t *__restrict__ bytes,
-                                                              PlanMeta *__restrict__ meta) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= p.n) return;
+                                                              uint32_t *__restrict__ hist, PlanMeta *__restrict__ meta) {
+    const int64_t j0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j0 < p.n;
+    const int64_t j = live ? j0 : p.n - 1;
     const int64_t i = p.row0 + j;
     CandRecIM r;
     memset(&r, 0, sizeof(r));
@@ -204,9 +216,9 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
     r.rank = c.rank[i];
     r.flags = c.flags ? c.flags[i] : (uint8_t)0;
     r.row = (uint32_t)i;
-    idx[j] = (uint32_t)j;
     uint32_t bin = 0;
     uint64_t nbytes = 0;
+    int32_t mx_k = 0, mx_o = 0, mx_f = 0, mx_s = 0, mx_p = 0, mx_l = 0;
     if (!(r.flags & ADH_FLAG_SKIP)) {
         int err = 0;
         const int64_t z = p.zeroth;
@@ -255,18 +267,38 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
             const int S = max(r.scan_stop - r.scan_start, 0);
             bin = (uint32_t)((r.frame_start - z32) / p.L);
             nbytes = adh_im_scratch_bytes(r.k_cap, r.n_obs, S, F, p.I, r.n_ms1);
-            plan::raise_max(&meta->all_k, (int32_t)r.k_cap);
-            plan::raise_max(&meta->all_o, (int32_t)r.n_obs);
-            plan::raise_max(&meta->all_f, F);
-            plan::raise_max(&meta->all_s, S);
-            plan::raise_max(&meta->all_op, (int32_t)r.n_ms1);
-            plan::raise_max(&meta->all_n_lib, (int32_t)nl);
+            if (live) mx_k = (int32_t)r.k_cap, mx_o = r.n_obs, mx_f = F, mx_s = S, mx_p = r.n_ms1, mx_l = (int32_t)nl;
         }
     }
+    plan::raise_max(&meta->all_k, mx_k);
+    plan::raise_max(&meta->all_o, mx_o);
+    plan::raise_max(&meta->all_f, mx_f);
+    plan::raise_max(&meta->all_s, mx_s);
+    plan::raise_max(&meta->all_op, mx_p);
+    plan::raise_max(&meta->all_n_lib, mx_l);
+    if (!live) return;
+    const uint32_t key = (uint32_t)ADH_CLASS_GENERIC * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
     recs[j] = r;
-    keys[j] = (uint32_t)ADH_CLASS_GENERIC * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
+    keys[j] = key;
+    idx[j] = (uint32_t)j;
     bytes[j] = nbytes;
+    if (hist) atomicAdd(&hist[key], 1u);
 }
+
+// counting sort, scatter step: position = running cursor of the key (order inside one (class, cycle)
+// bin is arbitrary: results do not depend on the processing order, only the locality does)
+__global__ void adh_plan_scatter_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ bytes, int64_t n,
+                                        uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted_keys,
+                                        uint32_t *__restrict__ idx_out, uint64_t *__restrict__ sorted_bytes) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t key = keys[j];
+    const uint32_t pos = atomicAdd(&cursor[key], 1u);
+    sorted_keys[pos] = key;
+    idx_out[pos] = (uint32_t)j;
+    sorted_bytes[pos] = bytes[j];
+}
+
 
 __global__ void adh_plan_take_bytes_kernel(const uint64_t *__restrict__ bytes, const uint32_t *__restrict__ idx,
                                            int64_t n, uint64_t *__restrict__ sorted_bytes) {

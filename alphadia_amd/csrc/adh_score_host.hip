@@ -252,30 +252,60 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.quant_all = key.quant_all ? 1 : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(adh_plan_init_kernel, dim3(1), dim3(1), 0, st, s.d_meta, p.I);
+    const int64_t n_frames = im ? h->tims.n_frames : h->run.n_spectra;
+    const int L = im ? h->tims.cycle_len : h->run.cycle_len;
+    p.L = L;
+    p.n_frames = n_frames;
+    p.n_cyc_bins = (int32_t)std::min<int64_t>(n_frames / L + 2, 1 << 26);
+    // counting sort when the key space is small next to the batch (the usual case: 11 classes x
+    // cycles of the run); a stable radix sort otherwise
+    const int64_t n_keys = (int64_t)ADH_N_CLASSES * p.n_cyc_bins;
+    const bool counting = n_keys <= (1 << 22) && !getenv("ADH_DEBUG_PLAN_RADIX");
+    if (counting) {
+        if (s.hist_cap < n_keys + 1) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (s.hist) (void)hipFree(s.hist);
+            s.hist = nullptr;
+            s.hist_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s.hist, (size_t)(n_keys + 1) * 4));
+            s.hist_cap = n_keys + 1;
+            size_t b = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b, s.hist, s.hist, (int)(n_keys + 1), st));
+            if (b > s.cub_bytes) {  // (the scratch was sized for the per-candidate scans)
+                void *tmp = nullptr;
+                HIP_TRY(hipMalloc(&tmp, b));
+                s.buf.ptrs.push_back(tmp);
+                s.cub_tmp = tmp;
+                s.cub_bytes = b;
+            }
+        }
+        HIP_TRY(hipMemsetAsync(s.hist, 0, (size_t)(n_keys + 1) * 4, st));
+    }
+    uint32_t *hist = counting ? s.hist : nullptr;
     if (im) {
-        p.L = h->tims.cycle_len;
         p.rows = h->tims.cycle_len;
         p.scan_max = h->tims.scan_max;
         p.zeroth = h->tims.zeroth;
-        p.n_frames = h->tims.n_frames;
-        p.n_cyc_bins = (int32_t)std::min<int64_t>(h->tims.n_frames / p.L + 2, 1 << 26);
         hipLaunchKernelGGL(adh_plan_rec_im_kernel, dim3(blocks), dim3(256), 0, st, h->cs.d, h->tims.cycle, h->tims.dpc, p,
-                           static_cast<CandRecIM *>(s.recs), s.keys_in, s.idx_in, s.bytes, s.d_meta);
+                           static_cast<CandRecIM *>(s.recs), s.keys_in, s.idx_in, s.bytes, hist, s.d_meta);
     } else {
-        p.L = h->run.cycle_len;
         p.rows = h->run.cycle_len * h->run.cycle_scans;
-        p.n_frames = h->run.n_spectra;
-        p.n_cyc_bins = (int32_t)std::min<int64_t>(h->run.n_spectra / p.L + 2, 1 << 26);
         hipLaunchKernelGGL(adh_plan_rec_kernel, dim3(blocks), dim3(256), 0, st, h->cs.d, h->run.cycle, p,
-                           static_cast<CandRec *>(s.recs), s.keys_in, s.idx_in, s.bytes, s.d_meta);
+                           static_cast<CandRec *>(s.recs), s.keys_in, s.idx_in, s.bytes, hist, s.d_meta);
     }
     HIP_TRY(hipGetLastError());
-    int end_bit = 1;
-    while (end_bit < 32 && (1ull << end_bit) < (uint64_t)ADH_N_CLASSES * (uint64_t)p.n_cyc_bins) ++end_bit;
     size_t tb = s.cub_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s.cub_tmp, tb, s.keys_in, s.keys_out, s.idx_in, s.idx_out, (int)n, 0, end_bit,
-                                               st));
-    hipLaunchKernelGGL(adh_plan_take_bytes_kernel, dim3(blocks), dim3(256), 0, st, s.bytes, s.idx_out, n, s.sorted_bytes);
+    if (counting) {
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(s.cub_tmp, tb, s.hist, s.hist, (int)(n_keys + 1), st));
+        hipLaunchKernelGGL(adh_plan_scatter_kernel, dim3(blocks), dim3(256), 0, st, s.keys_in, s.bytes, n, s.hist, s.keys_out,
+                           s.idx_out, s.sorted_bytes);
+    } else {
+        int end_bit = 1;
+        while (end_bit < 32 && (1ull << end_bit) < (uint64_t)n_keys) ++end_bit;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s.cub_tmp, tb, s.keys_in, s.keys_out, s.idx_in, s.idx_out, (int)n, 0,
+                                                   end_bit, st));
+        hipLaunchKernelGGL(adh_plan_take_bytes_kernel, dim3(blocks), dim3(256), 0, st, s.bytes, s.idx_out, n, s.sorted_bytes);
+    }
     tb = s.cub_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(s.cub_tmp, tb, s.sorted_bytes, s.offs, (int)n, st));
     if (im)

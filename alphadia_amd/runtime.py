@@ -275,11 +275,6 @@ class Context:
                 buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(buf.shape[0]),
                 obs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_obs), C.byref(n_s), C.byref(n_f)),
             "adh_debug_get_dense",
-    "adh_mlp_stage_rows_device",
-    "adh_mlp_staged_rows",
-    "adh_mlp_predict_resident",
-    "adh_fdr_resident",
-    "adh_transfer_counters",
         )
         K, O, S, F = q.shape[0], n_obs.value, n_s.value, n_f.value
         return buf[: 2 * K * O * S * F].reshape(2, K, O, S, F).copy(), obs[:O].astype(np.int64)
