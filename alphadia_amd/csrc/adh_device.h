@@ -120,14 +120,21 @@ struct __attribute__((aligned(16))) CandRecIM {
 };
 static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 
-// ion-mobility scratch block: header (32 B), selected fragments (k_cap x 32 B),
-// fragment cells float2[k_cap][O][S][F], precursor cells float2[I][Op][S][F]
+// ion-mobility scratch block: header (32 B; [0] K, [1] hits, [2] touched fragment cells or
+// ADH_IM_TOUCH_OVERFLOW), selected fragments (k_cap x 32 B), fragment cells float2[k_cap][O][S][F],
+// precursor cells float2[I][Op][S][F], then the indices of the fragment cells the gather touched
+// (ion-mobility tiles are ~1 % full: the feature kernel visits the touched cells instead of the tile)
+#define ADH_IM_TOUCH_CAP 1024
+#define ADH_IM_TOUCH_OVERFLOW 0xFFFFFFFFu
 __host__ __device__ inline uint64_t adh_im_prec_off(uint32_t k_cap, int O, int S, int F) {
     return adh_scratch_frag_off(k_cap) + (uint64_t)k_cap * O * S * F * 8;
 }
-__host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
+__host__ __device__ inline uint64_t adh_im_touch_off(uint32_t k_cap, int O, int S, int F, int I, int Op) {
     uint64_t b = adh_im_prec_off(k_cap, O, S, F) + (uint64_t)I * Op * S * F * 8;
     return (b + 31) / 32 * 32;
+}
+__host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
+    return adh_im_touch_off(k_cap, O, S, F, I, Op) + (uint64_t)ADH_IM_TOUCH_CAP * 4;
 }
 
 typedef adh_output_t DevOut;

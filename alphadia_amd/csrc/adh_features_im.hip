@@ -59,8 +59,7 @@ struct Layout {
     __host__ __device__ int f_fspu() const { return f_ffpu() + Kc * Oc * Fc; }    // [Kc*Oc*Sc] before the mask
     __host__ __device__ int f_ffp() const { return f_fspu() + Kc * Oc * Sc; }     // [Kc*Oc*Fc]
     __host__ __device__ int f_fsp() const { return f_ffp() + Kc * Oc * Fc; }      // [2][Kc*Oc*Sc] raw, env
-    __host__ __device__ int f_prec() const { return f_fsp() + 2 * Kc * Oc * Sc; } // [2][Ic*Sc*Fc]
-    __host__ __device__ int f_tpl() const { return f_prec() + 2 * Ic * Sc * Fc; } // [Oc*Sc*Fc]
+    __host__ __device__ int f_tpl() const { return f_fsp() + 2 * Kc * Oc * Sc; }  // [Oc*Sc*Fc]
     __host__ __device__ int f_tfp() const { return f_tpl() + Oc * Sc * Fc; }      // [Oc*Fc]
     __host__ __device__ int f_tsp() const { return f_tfp() + 2 * Oc * Fc; }       // [2][Oc*Sc] (tfp: raw, env)
     __host__ __device__ int f_qm() const { return f_tsp() + 2 * Oc * Sc; }        // [Oc*Sc] qtf mask
@@ -143,8 +142,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     float *const ffp = Fl + lay.f_ffp();
     float *const fsp_raw = Fl + lay.f_fsp();
     float *const fsp = fsp_raw + Kc * Oc * Sc;
-    float *const pi = Fl + lay.f_prec();
-    float *const pm = pi + Ic * Sc * Fc;
     float *const tpl = Fl + lay.f_tpl();
     float *const tfp_raw = Fl + lay.f_tfp();
     float *const tfp = tfp_raw + Oc * Fc;
@@ -170,25 +167,30 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     double *const qtf = D + lay.d_qtf();
     double *const frame_rt = D + lay.d_frt();
 
-    // ---- collapse the MS1 observations (candidate.py:248-269); the fragment tile
-    // [k][o][s][f] stays in the scratch block
+    // ---- the fragment tile [k][o][s][f] and the raw precursor tile [i][Op][s][f] stay in the scratch
+    // block.  The MS1 observations are collapsed (candidate.py:248-269) where a cell is used: with one
+    // unfragmented frame per cycle (the usual acquisition) that is the cell itself, and keeping the
+    // collapsed tile out of LDS (26 KB at 38 scans x 29 cycles) more than doubles the resident waves.
     const float2 *const fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(r.k_cap));
-    {
-        const float2 *pcells = reinterpret_cast<const float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
-        for (int c = lane; c < I * SF; c += ADH_WAVE) {
-            int i = c / SF, sf = c - i * SF;
-            float acc = 0.0f;
-            double sum = 0.0;
-            int count = 0;
-            for (int j = 0; j < Op; ++j) {
-                float2 v = pcells[(i * Op + j) * SF + sf];
-                acc += v.x;
-                sum += (double)v.y;
-                count += v.y > 0.0f;
-            }
-            pi[c] = acc;
-            pm[c] = (float)(sum / ((double)count + 1e-6));
+    const float2 *const pcells = reinterpret_cast<const float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
+    auto prec_cell = [&](int i, int sf) -> float2 {  // (summed intensity, mean m/z of the non-empty observations)
+        float acc = 0.0f;
+        double sum = 0.0;
+        int count = 0;
+        for (int j = 0; j < Op; ++j) {
+            const float2 v = pcells[(i * Op + j) * SF + sf];
+            acc += v.x;
+            sum += (double)v.y;
+            count += v.y > 0.0f;
         }
+        return make_float2(acc, (float)(sum / ((double)count + 1e-6)));
+    };
+    auto prec_int = [&](int i, int sf) -> float {  // the intensity plane only
+        float acc = 0.0f;
+        for (int j = 0; j < Op; ++j) acc += pcells[(i * Op + j) * SF + sf].x;
+        return acc;
+    };
+    {
         if (lane < I) {
             iso_int[lane] = iso_table[(int64_t)row * n_iso_cols + lane];
             double off = (double)lane * 1.0033548350700006 / (double)r.charge;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         int o = c / SF, sf = c - o * SF, sc = sf / F;
         double acc = 0;
         for (int i = 0; i < I; ++i) {
-            float a = pi[i * SF + sf] * iso_int[i];
+            float a = prec_int(i, sf) * iso_int[i];
             acc += (double)a * qtf[(i * O + o) * S + sc];
         }
         tpl[c] = (float)acc;
@@ -233,15 +235,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     float *const fw = rowsum + Kc * Oc;
     float *const ftc = fw + Kc * Oc;
     float *const mfw = ftc + Kc * Oc;
+    // np.sum(np.sum(template, axis=-1), axis=-1): the inner sums (one per scan) are independent, the
+    // outer one adds them in scan order
+    for (int c = lane; c < O * S; c += ADH_WAVE) {
+        float sf = 0;
+        for (int f = 0; f < F; ++f) sf += tpl[c * F + f];
+        work_b[c] = sf;
+    }
+    __syncthreads();
     if (lane < O) {
         float so = 0;
-        for (int sc = 0; sc < S; ++sc) {
-            float sf = 0;
-            for (int f = 0; f < F; ++f) sf += tpl[(lane * S + sc) * F + f];
-            so += sf;
-        }
+        for (int sc = 0; sc < S; ++sc) so += work_b[lane * S + sc];
         tsum[lane] = so;
     }
+    __syncthreads();
     // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
     // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
     // over the fragment tile
@@ -354,6 +361,45 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             __syncthreads();
         };
         int n_list = 0;        // entries waiting in the list (wave-uniform)
+        const uint32_t n_touch = header[2];
+        int n_p_need = ADH_WAVE;
+        while (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need < (int)n_touch) n_p_need <<= 1;
+        const int sorted_cap = lay.f_ffpu();  // floats of work_a + work_b
+        if (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need <= sorted_cap) {
+            // ---- the gather kernel listed the cells it touched (<= ADH_IM_TOUCH_CAP, ~1 % of the
+            // tile): sort the list (cell order = the reference's summation order) and visit those
+            int *const sorted = reinterpret_cast<int *>(work_a);  // work_a + work_b are idle here (>= 1024 + ints)
+            const uint32_t *touched = reinterpret_cast<const uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
+            const int n_p = n_p_need;
+            for (int e = lane; e < n_p; e += ADH_WAVE) sorted[e] = e < (int)n_touch ? (int)touched[e] : 0x7FFFFFFF;
+            __syncthreads();
+            for (int k = 2; k <= n_p; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int e = lane; e < n_p; e += ADH_WAVE) {
+                        const int q = e ^ j;
+                        if (q > e) {
+                            const int a = sorted[e], b = sorted[q];
+                            if ((a > b) == ((e & k) == 0)) {
+                                sorted[e] = b;
+                                sorted[q] = a;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int base = 0; base < (int)n_touch; base += ADH_WAVE) {
+                const int cnt = min(ADH_WAVE, (int)n_touch - base);
+                if (lane < cnt) {
+                    const int ci = sorted[base + lane];
+                    const float2 v = fcells[ci];
+                    l_cell[lane] = ci;
+                    l_rx[lane] = v.x;
+                    l_ry[lane] = v.y;
+                }
+                __syncthreads();
+                flush(cnt);
+            }
+        } else {
         constexpr int PF = 4;  // 128-cell chunks in flight (a lane reads two neighbouring cells)
         const float4 *cells4 = reinterpret_cast<const float4 *>(fcells);  // 16-byte aligned block
         const int n_pairs = (n_cells + 1) / 2;  // (an odd tile reads 8 bytes of the next array: masked)
@@ -419,6 +465,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         __syncthreads();
         if (n_list > 0) flush(n_list);
+        }
         for (int c = lane; c < K0 * O; c += ADH_WAVE) {
             const double vi = acc_vi[c], wi = acc_wi[c], vm = acc_vm[c], wm = acc_wm[c];
             ohe_u[c] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
@@ -552,34 +599,57 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
 
     if (caps.stop_phase == 4) return;
     // =========================== features ===========================
+    // isotope intensity sums: per-scan sums in parallel, then in scan order (as for the template)
+    for (int c = lane; c < I * S; c += ADH_WAVE) {
+        float sf = 0;
+        for (int f = 0; f < F; ++f) sf += prec_int(c / S, (c % S) * F + f);
+        work_b[c] = sf;
+    }
+    __syncthreads();
     if (lane < I) {
         float ss = 0;
-        for (int sc = 0; sc < S; ++sc) {
-            float sf = 0;
-            for (int f = 0; f < F; ++f) sf += pi[(lane * S + sc) * F + f];
-            ss += sf;
-        }
+        for (int sc = 0; sc < S; ++sc) ss += work_b[lane * S + sc];
         spi[lane] = ss;
     }
-    for (int c = lane; c < 2 * I; c += ADH_WAVE) {
-        int i = c >> 1, plane = c & 1;
-        const float *p = (plane ? pm : pi) + i * SF;
-        double values = 0, weights = 0;
-        bool any = false;
-        for (int sf = 0; sf < SF; ++sf) {
-            float v = p[sf];
-            if (v > 0.0f) {
-                any = true;
-                // weights around (scan, frame) = (S, 1) (precursor_features.py:52-57)
-                const int sc = sf / F, f = sf - sc * F;
+    // weighted centre means of the precursor planes around (scan, frame) = (S, 1)
+    // (precursor_features.py:52-66): float64 sums over the non-zero cells in (scan, frame) order.  The
+    // 64 lanes look at 64 cells at once, compact the non-zero ones in order into the chunk lists and
+    // lanes 0..3 fold one of the four sums each (intensity plane: values, weights; m/z plane: the same).
+    for (int i = 0; i < I; ++i) {
+        double acc = 0.0;
+        for (int base = 0; base < SF; base += ADH_WAVE) {
+            const int ci = base + lane;
+            const float2 pc = (ci < SF) ? prec_cell(i, ci) : make_float2(0.0f, 0.0f);
+            const float vi = pc.x, vm = pc.y;
+            const bool nz = vi > 0.0f || vm > 0.0f;
+            const unsigned long long mask = __ballot(nz);
+            if (mask == 0ull) continue;
+            if (nz) {
+                const int sc = ci / F, f = ci - sc * F;
                 const double ds = (double)(sc - S), df = (double)(f - 1);
                 const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                values += (double)v * w;
-                weights += w;
+                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                l_w[pos] = w;
+                l_ti[pos] = (double)vi * w;
+                l_tm[pos] = (double)vm * w;
+                l_rx[pos] = vi;
+                l_ry[pos] = vm;
             }
+            __syncthreads();
+            const int n_ent = __popcll(mask);
+            if (lane < 4) {
+                const float *flag = (lane < 2) ? l_rx : l_ry;
+                const double *src = (lane & 1) ? l_w : (lane == 0 ? l_ti : l_tm);
+                for (int e = 0; e < n_ent; ++e)
+                    if (flag[e] > 0.0f) acc += src[e];
+            }
+            __syncthreads();
         }
-        double res = (any && weights > 0) ? values / weights : 0.0;
-        if (plane) omzp[i] = res; else hp[i] = res;
+        const double vh = __shfl(acc, 0), wh = __shfl(acc, 1), vmz = __shfl(acc, 2), wmz = __shfl(acc, 3);
+        if (lane == 0) {
+            hp[i] = (wh > 0) ? vh / wh : 0.0;      // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
+            omzp[i] = (wmz > 0) ? vmz / wmz : 0.0;
+        }
     }
     __syncthreads();
 

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     Caps caps) {
     using namespace gather_im;
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned n_touched;  // fragment cells that received their first event
     float *l_int = reinterpret_cast<float *>(smem);
     float *l_mz = l_int + caps.n_lib;
     int *l_rank = reinterpret_cast<int *>(l_mz + caps.n_lib);
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     if (lane == 0) {
         out.precursor_idx[row] = r.precursor_idx;  // candidate.py:175-176
         out.rank[row] = r.rank;
+        n_touched = 0u;
     }
     unsigned char *block = scratch + r.scratch_off;
     uint32_t *header = reinterpret_cast<uint32_t *>(block);
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     }
 
     // ---- (window, cycle) tasks
+    uint32_t *touched = reinterpret_cast<uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
     uint32_t hits = 0;
     for (int t = lane; t < (K + I) * F; t += ADH_WAVE) {
         const int w = t / F, f = t - w * F;
@@ -194,6 +197,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 if (o >= n_o) continue;  // cannot happen: the plan lists every overlapping row
                 const int cell = ((j * n_o + o) * S + (scan - r.scan_start)) * F + f;
                 float2 v = cells[cell];
+                if (!prec && v.x == 0.0f && v.y == 0.0f) {  // pristine: after any event the m/z plane is > 0
+                    const unsigned pos = atomicAdd(&n_touched, 1u);
+                    if (pos < ADH_IM_TOUCH_CAP) touched[pos] = (uint32_t)cell;
+                }
                 // bruker_jit.py:440-485 (absolute_masses=True): uint16 intensity, float64 m/z
                 const int64_t ni = run.inten[idx];
                 float am = v.y * v.x;
@@ -207,8 +214,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         }
     }
     for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
+    __syncthreads();
     if (lane == 0) {
         header[0] = (uint32_t)K;
         header[1] = hits;
+        header[2] = n_touched <= ADH_IM_TOUCH_CAP ? n_touched : ADH_IM_TOUCH_OVERFLOW;
     }
 }

@@ -277,7 +277,10 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
     plan::raise_max(&meta->all_op, mx_p);
     plan::raise_max(&meta->all_n_lib, mx_l);
     if (!live) return;
-    const uint32_t key = (uint32_t)ADH_CLASS_GENERIC * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
+    // feature launches by observation count (class 0: one, class 1: two, generic: more): the LDS of
+    // the ion-mobility feature kernel scales with it, and most precursors sit in one isolation window
+    const int cls = (r.flags & ADH_FLAG_SKIP) ? ADH_CLASS_GENERIC : (r.n_obs <= 1 ? 0 : (r.n_obs == 2 ? 1 : ADH_CLASS_GENERIC));
+    const uint32_t key = (uint32_t)cls * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
     recs[j] = r;
     keys[j] = key;
     idx[j] = (uint32_t)j;

@@ -421,9 +421,22 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                        p.d_recs_im, *cfg, n_iso, d_scratch, *out, p.caps_all);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(t.e1, st));
-    hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), f_lds, st, h->tims, p.d_recs_im,
-                       h->cs.iso, n_iso, *cfg, d_scratch, *out, p.caps_all);
-    HIP_TRY(hipGetLastError());
+    {
+        // one feature launch per observation class (adh_plan_rec_im_kernel): 1, 2, more
+        int64_t first = 0;
+        for (int c = 0; c < ADH_N_CLASSES; ++c) {
+            const int64_t cnt = p.n_class[c];
+            if (cnt > 0) {
+                Caps cc = p.caps_all;
+                if (c == 0) cc.o = 1;
+                if (c == 1) cc.o = std::min(cc.o, 2);
+                hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), adh_feature_im_lds_bytes(cc), st,
+                                   h->tims, p.d_recs_im + first, h->cs.iso, n_iso, *cfg, d_scratch, *out, cc);
+                HIP_TRY(hipGetLastError());
+            }
+            first += cnt;
+        }
+    }
     HIP_TRY(hipEventRecord(t.e2, st));
     h->timed.push_back(t);
     return ADH_OK;
