@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include "adh_plan.hip"

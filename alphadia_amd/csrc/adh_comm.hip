@@ -29,6 +29,24 @@ struct adh_comm_state {
 
 namespace {
 
+// RCCL prints a version banner to stdout when the first communicator is created; callers may
+// reserve stdout for their own output (bench.py: one JSON line), so it is sent to stderr
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) {
+            (void)dup2(saved, 1);
+            close(saved);
+        }
+    }
+};
+
 int rccl_open(adh_comm_state &c) {
     if (c.lib) return ADH_OK;
     const char *names[] = {getenv("ADH_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -97,7 +115,10 @@ int adh_comm_unique_id(void *id128) {
     int rc = rccl_open(tmp);
     if (rc != ADH_OK) return rc;
     ncclUniqueId id;
-    RCCL_TRY(tmp, tmp.GetUniqueId(&id));
+    {
+        StdoutToStderr quiet;
+        RCCL_TRY(tmp, tmp.GetUniqueId(&id));
+    }
     memcpy(id128, &id, sizeof(id));
     return ADH_OK;  // the library stays loaded (a later adh_comm_init reuses the mapping)
 }
@@ -116,7 +137,11 @@ int adh_comm_init(adh_handle_t *h, int rank, int world, const void *id128, int64
     }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    ncclResult_t r = c->CommInitRank(&c->comm, world, id, rank);
+    ncclResult_t r;
+    {
+        StdoutToStderr quiet;
+        r = c->CommInitRank(&c->comm, world, id, rank);
+    }
     if (r != ncclSuccess) {
         std::string msg = std::string("ncclCommInitRank: ") + c->GetErrorString(r);
         delete c;
