@@ -218,3 +218,29 @@ def test_staging_cache_notices_edited_arrays(ctx, case):
     dia.intensity_values[::7] *= 2.0
     assert ctx.stage_run(dia) is True
     assert ctx.stage_run(dia) is False
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_score_group_shards_reassemble_to_the_unsharded_tables(ctx, world):
+    """BASELINE configs[4] in small (3-plex + reference channel, channels of one elution group scored
+    as ONE score group, groups without their reference channel skipped) cut into `world` score-group
+    shards the way bench.py / a multi-GPU search does: every shard goes through the production call
+    on its own and the shards, put back in rank order, are the unsharded tables bit for bit - no group
+    is split and no row depends on its neighbours."""
+    from alphadia_amd.distributed import merge_gathered, shard_bounds, slice_soa
+
+    g = H.load_scoring_golden("multiplex")
+    cfg = g.config
+    soa = H.soa_for(g, cfg)
+    _stage(ctx, g)
+    full = ctx.score_host(pack_assembled(soa), cfg.to_jitclass(), with_stats=True)
+    bounds = [shard_bounds(soa["score_group_idx"], r, world) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == len(soa["precursor_idx"])
+    parts = []
+    for a, b in bounds:
+        if a > 0:  # a cut never falls inside a score group
+            assert soa["score_group_idx"][a] != soa["score_group_idx"][a - 1]
+        parts.append(ctx.score_host(pack_assembled(slice_soa(soa, a, b)), cfg.to_jitclass(), with_stats=True))
+    merged = merge_gathered(parts, [b - a for a, b in bounds])
+    _same(merged, full)
+    assert full["valid"].sum() > 50 and (soa["flags"] != 0).sum() > 0
