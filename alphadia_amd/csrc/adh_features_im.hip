@@ -361,6 +361,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             __syncthreads();
         };
         int n_list = 0;        // entries waiting in the list (wave-uniform)
+        if (header[3] == ADH_IM_MODE_COMPACT) {
+            // ---- the gather kernel kept the fragment tile in sparse form: the non-zero cells as
+            // (cell, intensity, m/z) entries sorted by cell, i.e. in the reference's summation order
+            const ImEntry *entries = reinterpret_cast<const ImEntry *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
+            const int total = (int)header[2];
+            for (int base = 0; base < total; base += ADH_WAVE) {
+                const int cnt = min(ADH_WAVE, total - base);
+                if (lane < cnt) {
+                    const ImEntry en = entries[base + lane];
+                    l_cell[lane] = (int)en.cell;
+                    l_rx[lane] = en.x;
+                    l_ry[lane] = en.y;
+                }
+                __syncthreads();
+                flush(cnt);
+            }
+        } else {
         const uint32_t n_touch = header[2];
         int n_p_need = ADH_WAVE;
         while (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need < (int)n_touch) n_p_need <<= 1;
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         __syncthreads();
         if (n_list > 0) flush(n_list);
+        }
         }
         for (int c = lane; c < K0 * O; c += ADH_WAVE) {
             const double vi = acc_vi[c], wi = acc_wi[c], vm = acc_vm[c], wm = acc_wm[c];

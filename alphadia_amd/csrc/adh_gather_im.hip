@@ -34,7 +34,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     Caps caps) {
     using namespace gather_im;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ unsigned n_touched;  // fragment cells that received their first event
+    __shared__ unsigned n_touched;  // dense mode: fragment cells that received their first event
+    __shared__ unsigned n_list;     // compact mode: entries in `list`
+    __shared__ ImEntry list[ADH_IM_LIST_CAP];
     float *l_int = reinterpret_cast<float *>(smem);
     float *l_mz = l_int + caps.n_lib;
     int *l_rank = reinterpret_cast<int *>(l_mz + caps.n_lib);
@@ -144,9 +146,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
     float2 *pcells = reinterpret_cast<float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
     const int n_fc = K * O * S * F, n_pc = I * Op * S * F;
-    for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
-    for (int c = lane; c < n_pc; c += ADH_WAVE) pcells[c] = make_float2(0.0f, 0.0f);
     __syncthreads();
+    if (caps.stop_phase == 7) {  // developer ablation: selection + window limits only
+        if (lane == 0) header[0] = 0;
+        return;
+    }
 
     // quadrupole range of the fragments (candidate.py:203-205)
     float iso_min = w_mz[caps.k], iso_max = w_mz[caps.k];
@@ -160,9 +164,148 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         fq_hi = (double)caps.dbg_q_hi;
     }
 
-    // ---- (window, cycle) tasks
-    uint32_t *touched = reinterpret_cast<uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
+    // one step of the running sums of a cell, bruker_jit.py:440-485 (absolute_masses=True): uint16
+    // intensity, float64 m/z
+    auto fold = [](float &vx, float &vy, int64_t ni, double measured) {
+        float am = vy * vx;
+        double num = (double)am + (double)ni * measured + 1e-36;
+        double den = ((double)vx + (double)ni) + 1e-36;
+        vy = (float)(num / den);
+        vx = (float)((double)vx + (double)ni);
+    };
     uint32_t hits = 0;
+    bool dense = caps.stop_phase == ADH_DEBUG_DENSE || caps.stop_phase == 8;  // (8: developer switch, dense mode only)
+    if (!dense) {
+        // ---- compact mode: the same (window, cycle) tasks, one per lane, but a task keeps the few cells
+        // it touches in registers (a fragment window sees ~0.4 events per cycle) and appends them to an
+        // LDS list when it is done: no tile, no zero fill (116 KB per candidate at 38 scans x 29 cycles),
+        // no read-modify-write traffic.  A cell belongs to exactly one task and receives its events in
+        // (TOF, push) order: the reference's order.  The (small) precursor tile stays dense.
+        for (int c = lane; c < n_pc; c += ADH_WAVE) pcells[c] = make_float2(0.0f, 0.0f);
+        if (lane == 0) n_list = 0u;
+        __syncthreads();
+        bool over = false;
+        for (int t = lane; t < (K + I) * F; t += ADH_WAVE) {
+            const int w = t / F, f = t - w * F;
+            const bool prec = w >= K;
+            const int slot = prec ? caps.k + (w - K) : w;
+            const int j = prec ? (w - K) : w;
+            const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
+            const int n_o = prec ? Op : O;
+            const uint16_t *obs = prec ? r.ms1_obs : r.obs;
+            const int frame_lo = (c0 + f) * L + z;
+            const uint32_t push_lo = (uint32_t)frame_lo * (uint32_t)S_max;
+            const uint32_t push_hi = (uint32_t)(frame_lo + L) * (uint32_t)S_max;
+            uint32_t ec[ADH_IM_TASK_CAP];
+            float ex[ADH_IM_TASK_CAP], ey[ADH_IM_TASK_CAP];
+            int ne = 0;
+            for (int tof = t_lo[slot]; tof < t_hi[slot]; ++tof) {
+                const double measured = run.mz[tof];
+                const int64_t b = run.tof_indptr[tof + 1];
+                int64_t lo = run.tof_indptr[tof], hi = b;
+                while (lo < hi) {
+                    int64_t m = (lo + hi) >> 1;
+                    if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                }
+                for (int64_t idx = lo; idx < b; ++idx) {
+                    const uint32_t p = run.push[idx];
+                    if (p >= push_hi) break;
+                    const int frame = (int)(p / (uint32_t)S_max), scan = (int)(p % (uint32_t)S_max);
+                    if (scan < r.scan_start || scan >= r.scan_stop) continue;
+                    const int crow = (frame - frame_lo) * S_max + scan;
+                    if (!(q_lo <= run.cycle[2 * crow + 1] && q_hi >= run.cycle[2 * crow])) continue;
+                    const int pc = run.dpc[crow];
+                    int o = 0;
+                    while (o < n_o && (int)obs[o] != pc) ++o;
+                    if (o >= n_o) continue;  // cannot happen: the plan lists every overlapping row
+                    const int cell = ((j * n_o + o) * S + (scan - r.scan_start)) * F + f;
+                    const int64_t ni = run.inten[idx];
+                    ++hits;
+                    if (prec) {
+                        float2 v = pcells[cell];
+                        fold(v.x, v.y, ni, measured);
+                        pcells[cell] = v;
+                        continue;
+                    }
+                    int e = -1;
+#pragma unroll
+                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
+                        if (q < ne && ec[q] == (uint32_t)cell) e = q;
+                    if (e < 0) {
+                        if (ne == ADH_IM_TASK_CAP) {
+                            over = true;
+                            break;
+                        }
+                        e = ne++;
+#pragma unroll
+                        for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
+                            if (q == e) ec[q] = (uint32_t)cell, ex[q] = 0.0f, ey[q] = 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
+                        if (q == e) fold(ex[q], ey[q], ni, measured);
+                }
+                if (over) break;
+            }
+            if (ne > 0 && !over) {
+                const unsigned base = atomicAdd(&n_list, (unsigned)ne);
+                if (base + (unsigned)ne > ADH_IM_LIST_CAP) {
+                    over = true;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
+                        if (q < ne) {
+                            ImEntry en;
+                            en.cell = ec[q];
+                            en.x = ex[q];
+                            en.y = ey[q];
+                            list[base + q] = en;
+                        }
+                }
+            }
+        }
+        dense = __ballot(over) != 0ull;  // too many non-zero cells: this candidate takes the dense path below
+        __syncthreads();
+        if (!dense) {
+            // sort the entries by cell (bitonic, padded with the largest key) and write the list out
+            const int n_ent = (int)n_list;
+            int n_p = ADH_WAVE;
+            while (n_p < n_ent) n_p <<= 1;
+            for (int e = n_ent + lane; e < n_p; e += ADH_WAVE) list[e].cell = 0xFFFFFFFFu;
+            __syncthreads();
+            for (int k = 2; k <= n_p; k <<= 1)
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int e = lane; e < n_p; e += ADH_WAVE) {
+                        const int q = e ^ jj;
+                        if (q > e) {
+                            const ImEntry ea = list[e], eb = list[q];
+                            if ((ea.cell > eb.cell) == ((e & k) == 0)) {
+                                list[e] = eb;
+                                list[q] = ea;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
+            for (int e = lane; e < n_ent; e += ADH_WAVE) out_list[e] = list[e];
+            for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
+            if (lane == 0) {
+                header[0] = (uint32_t)K;
+                header[1] = hits;
+                header[2] = (uint32_t)n_ent;
+                header[3] = ADH_IM_MODE_COMPACT;
+            }
+            return;
+        }
+        hits = 0;
+    }
+
+    // ---- dense mode: zero the tile, (window, cycle) tasks, list of the touched fragment cells
+    for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
+    for (int c = lane; c < n_pc; c += ADH_WAVE) pcells[c] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+    uint32_t *touched = reinterpret_cast<uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
     for (int t = lane; t < (K + I) * F; t += ADH_WAVE) {
         const int w = t / F, f = t - w * F;
         const bool prec = w >= K;
@@ -201,13 +344,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     const unsigned pos = atomicAdd(&n_touched, 1u);
                     if (pos < ADH_IM_TOUCH_CAP) touched[pos] = (uint32_t)cell;
                 }
-                // bruker_jit.py:440-485 (absolute_masses=True): uint16 intensity, float64 m/z
-                const int64_t ni = run.inten[idx];
-                float am = v.y * v.x;
-                double num = (double)am + (double)ni * measured + 1e-36;
-                double den = ((double)v.x + (double)ni) + 1e-36;
-                v.y = (float)(num / den);
-                v.x = (float)((double)v.x + (double)ni);
+                fold(v.x, v.y, (int64_t)run.inten[idx], measured);
                 cells[cell] = v;
                 ++hits;
             }
@@ -219,5 +356,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         header[0] = (uint32_t)K;
         header[1] = hits;
         header[2] = n_touched <= ADH_IM_TOUCH_CAP ? n_touched : ADH_IM_TOUCH_OVERFLOW;
+        header[3] = ADH_IM_MODE_DENSE;
     }
 }
