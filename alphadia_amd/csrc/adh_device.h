@@ -120,23 +120,26 @@ struct __attribute__((aligned(16))) CandRecIM {
 };
 static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 
-// ion-mobility scratch block: header (32 B; [0] K, [1] hits, [2] entry count, [3] mode), selected
-// fragments (k_cap x 32 B), fragment cells float2[k_cap][O][S][F], precursor cells float2[I][Op][S][F],
-// then the sparse form of the fragment tile.  Ion-mobility tiles are ~1 % full, so the gather kernel
-// normally never materialises the fragment tile (mode ADH_IM_MODE_COMPACT): the non-zero cells are
-// collected as (cell, intensity, m/z) entries in LDS, sorted by cell - the reference's summation order -
-// and written out as one list of at most ADH_IM_LIST_CAP entries.  A candidate with more non-zero cells
-// (or more than ADH_IM_TASK_CAP in one (window, cycle) task) falls back to the dense tile (zero fill +
-// scatter) with a list of the cells it touched (mode ADH_IM_MODE_DENSE; header[2] =
-// ADH_IM_TOUCH_OVERFLOW when even that list is full and the feature kernel has to stream the tile).
+// ion-mobility scratch block: header (32 B; [0] K, [1] hits, [2] entry count, [3] mode, [4] precursor
+// entry count), selected fragments (k_cap x 32 B), fragment cells float2[k_cap][O][S][F], precursor cells
+// float2[I][Op][S][F], list of the touched fragment cells.  Ion-mobility tiles are ~1 % full, so the
+// gather kernel normally never materialises the tiles (mode ADH_IM_MODE_COMPACT): the non-zero cells
+// leave as (cell, intensity, m/z) entries sorted by cell - the reference's summation order - written
+// where the tiles would be: header[2] fragment entries (cell = ((k * O + o) * S + scan) * F + cycle),
+// then header[4] precursor entries with the MS1 rows already collapsed
+// (cell = (scan * F + cycle) * I + isotope).  A candidate with more than ADH_IM_SORT_CAP events in one
+// window (or in its isotope windows together), or more than ADH_IM_PAIR_CAP TOF bins in all windows,
+// falls back to the dense tiles (zero fill + scatter) with a list of the cells it touched (mode
+// ADH_IM_MODE_DENSE; header[2] = ADH_IM_TOUCH_OVERFLOW when even that list is full and the feature
+// kernel has to stream the tile).
 #define ADH_IM_TOUCH_CAP 1024
 #define ADH_IM_TOUCH_OVERFLOW 0xFFFFFFFFu
-#define ADH_IM_LIST_CAP 256
-#define ADH_IM_TASK_CAP 4
+#define ADH_IM_SORT_CAP 512
+#define ADH_IM_PAIR_CAP 256
 #define ADH_IM_MODE_DENSE 0u
 #define ADH_IM_MODE_COMPACT 1u
 struct ImEntry {
-    uint32_t cell;  // ((k * O + o) * S + scan) * F + cycle
+    uint32_t cell;
     float x, y;     // accumulated intensity, running intensity-weighted m/z
 };
 __host__ __device__ inline uint64_t adh_im_prec_off(uint32_t k_cap, int O, int S, int F) {
@@ -146,12 +149,8 @@ __host__ __device__ inline uint64_t adh_im_touch_off(uint32_t k_cap, int O, int 
     uint64_t b = adh_im_prec_off(k_cap, O, S, F) + (uint64_t)I * Op * S * F * 8;
     return (b + 31) / 32 * 32;
 }
-// (the sorted entry list of the compact mode shares the bytes of the touched-cell list of the dense mode)
 __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
-    const uint64_t list = (uint64_t)ADH_IM_TOUCH_CAP * 4 > (uint64_t)ADH_IM_LIST_CAP * sizeof(ImEntry)
-                              ? (uint64_t)ADH_IM_TOUCH_CAP * 4
-                              : (uint64_t)ADH_IM_LIST_CAP * sizeof(ImEntry);
-    return (adh_im_touch_off(k_cap, O, S, F, I, Op) + list + 31) / 32 * 32;
+    return (adh_im_touch_off(k_cap, O, S, F, I, Op) + (uint64_t)ADH_IM_TOUCH_CAP * 4 + 31) / 32 * 32;
 }
 
 typedef adh_output_t DevOut;

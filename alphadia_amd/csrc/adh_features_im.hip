@@ -102,6 +102,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // correlation reuse the same bytes later (an extra 2 KB of LDS per wavefront cost 22 % of the
     // kernel's throughput in resident waves)
     __shared__ __align__(16) unsigned char pool[ADH_IM_STATIC_LDS];
+    __shared__ int pl_start[ADH_WAVE];  // tile pass: first list entry of every (fragment, observation) plane
     double *const l_ti = reinterpret_cast<double *>(pool);
     double *const l_tm = l_ti + ADH_WAVE;
     double *const l_w = l_tm + ADH_WAVE;
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // collapsed tile out of LDS (26 KB at 38 scans x 29 cycles) more than doubles the resident waves.
     const float2 *const fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(r.k_cap));
     const float2 *const pcells = reinterpret_cast<const float2 *>(block + adh_im_prec_off(r.k_cap, O, S, F));
+    // sparse form of both tiles (see adh_device.h): fragment entries, then the collapsed precursor entries
+    const bool compact = header[3] == ADH_IM_MODE_COMPACT;
+    const ImEntry *const entries = reinterpret_cast<const ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
+    const int n_fe = compact ? (int)header[2] : 0, n_pe = compact ? (int)header[4] : 0;
     auto prec_cell = [&](int i, int sf) -> float2 {  // (summed intensity, mean m/z of the non-empty observations)
         float acc = 0.0f;
         double sum = 0.0;
@@ -217,6 +222,87 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     __syncthreads();
     // (the qtf mask of candidate.py:290 is applied while the fragment tile is streamed)
+    double *const hp = D + lay.d_pi();
+    double *const omzp = hp + Ic;
+    if (compact) {
+        // ---- everything that reads the precursor tile, in ONE pass over its sparse form: the entries are
+        // the non-zero (scan, cycle, isotope) cells in that order, staged 192 at a time in the chunk lists.
+        //   template (O, S, F) (quadrupole.py:304-324): one lane per (scan, cycle) cell with any isotope
+        //   isotope intensity sums (per scan, then over the scans) and the weighted centre means of the
+        //   isotope planes around (scan, frame) = (S, 1) (precursor_features.py:52-66): sequential sums in
+        //   (scan, cycle) order - lanes 0..5I-1 walk the staged entries, one sum each.  Empty cells add
+        //   0 to every one of these sums, so skipping them changes nothing.
+        double *const c_w = reinterpret_cast<double *>(pool);
+        uint32_t *const c_cell = reinterpret_cast<uint32_t *>(c_w + 192);
+        float *const c_x = reinterpret_cast<float *>(c_cell + 192);
+        float *const c_y = c_x + 192;
+        for (int c = lane; c < OSF; c += ADH_WAVE) tpl[c] = 0.0f;
+        const ImEntry *const pent = entries + n_fe;
+        const int role = lane / I, iso = lane - role * I;  // role 0: intensity sum; 1, 2: intensity mean; 3, 4: m/z mean
+        double acc = 0.0;
+        float part = 0.0f, tot = 0.0f;
+        int cur_sc = -1;
+        for (int base = 0; base < n_pe;) {
+            int cnt = min(192, n_pe - base);
+            for (int e = lane; e < cnt; e += ADH_WAVE) {
+                const ImEntry en = pent[base + e];
+                const int sf = (int)en.cell / I, sc = sf / F, f = sf - sc * F;
+                const double ds = (double)(sc - S), df = (double)(f - 1);
+                c_cell[e] = en.cell;
+                c_x[e] = en.x;
+                c_y[e] = en.y;
+                c_w[e] = exp(-0.1 * sqrt(ds * ds + df * df));
+            }
+            __syncthreads();
+            if (base + cnt < n_pe) {  // never cut the isotopes of a cell in two: stop at the last cell start
+                const int e = cnt - ADH_WAVE + lane;
+                const unsigned long long st = __ballot((int)c_cell[e] / I != (int)c_cell[e - 1] / I);
+                cnt = cnt - ADH_WAVE + (63 - __clzll(st));
+            }
+            for (int e = lane; e < cnt; e += ADH_WAVE) {
+                const int sf = (int)c_cell[e] / I;
+                if (e > 0 && (int)c_cell[e - 1] / I == sf) continue;
+                const int sc = sf / F;
+                for (int o = 0; o < O; ++o) {
+                    double a = 0;
+                    for (int q = e; q < cnt && (int)c_cell[q] / I == sf; ++q) {
+                        const int i = (int)c_cell[q] - sf * I;
+                        const float t = c_x[q] * iso_int[i];
+                        a += (double)t * qtf[(i * O + o) * S + sc];
+                    }
+                    tpl[o * SF + sf] = (float)a;
+                }
+            }
+            if (lane < 5 * I) {
+                for (int e = 0; e < cnt; ++e) {
+                    const int cell = (int)c_cell[e], sf = cell / I;
+                    if (cell - sf * I != iso) continue;
+                    if (role == 0) {
+                        const int sc = sf / F;
+                        if (sc != cur_sc) {
+                            tot += part;
+                            part = 0.0f;
+                            cur_sc = sc;
+                        }
+                        part += c_x[e];
+                    } else if ((role <= 2 ? c_x[e] : c_y[e]) > 0.0f) {
+                        const double w = c_w[e];
+                        acc += role == 1 ? (double)c_x[e] * w : (role == 3 ? (double)c_y[e] * w : w);
+                    }
+                }
+            }
+            __syncthreads();
+            base += cnt;
+        }
+        const int il = lane < I ? lane : 0;
+        const double vh = __shfl(acc, I + il), wh = __shfl(acc, 2 * I + il);
+        const double vmz = __shfl(acc, 3 * I + il), wmz = __shfl(acc, 4 * I + il);
+        if (lane < I) {
+            spi[lane] = tot + part;
+            hp[lane] = (wh > 0) ? vh / wh : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
+            omzp[lane] = (wmz > 0) ? vmz / wmz : 0.0;
+        }
+    } else {
     // template (O, S, F) (quadrupole.py:304-324)
     for (int c = lane; c < OSF; c += ADH_WAVE) {
         int o = c / SF, sf = c - o * SF, sc = sf / F;
@@ -226,6 +312,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             acc += (double)a * qtf[(i * O + o) * S + sc];
         }
         tpl[c] = (float)acc;
+    }
     }
     __syncthreads();
 
@@ -254,8 +341,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // over the fragment tile
     double *const esc = D + lay.d_po();
     double *const efc = esc + Oc;
-    double *const hp = D + lay.d_pi();
-    double *const omzp = hp + Ic;
     double *const omz = D + lay.d_omz();
     double *const ohe = D + lay.d_ohe();
     double *const omz_u = D + lay.d_omzu();
@@ -334,12 +419,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 l_tm[lane] = (double)ry * w;
             }
             __syncthreads();
+            // the list is sorted by cell, so the entries of a plane are a contiguous run: mark where
+            // every plane's run starts, then one lane per plane folds its own run only
             const int ko_lo = l_cell[0] / SF, ko_hi = l_cell[count - 1] / SF;
+            for (int p = lane; p <= ko_hi - ko_lo; p += ADH_WAVE) pl_start[p] = -1;
+            __syncthreads();
+            if (lane < count) {
+                const int ko = l_cell[lane] / SF;
+                if (lane == 0 || l_cell[lane - 1] / SF != ko) pl_start[ko - ko_lo] = lane;
+            }
+            __syncthreads();
             for (int ko = ko_lo + lane; ko <= ko_hi; ko += ADH_WAVE) {
+                int e = pl_start[ko - ko_lo];
+                if (e < 0) continue;
                 double vi = acc_vi[ko], wi = acc_wi[ko], vm = acc_vm[ko], wm = acc_wm[ko];
-                for (int e = 0; e < count; ++e) {
+                for (; e < count; ++e) {
                     const int rem = l_cell[e] - ko * SF;
-                    if (rem < 0 || rem >= SF) continue;
+                    if (rem >= SF) break;
                     const int sc = rem / F, f = rem - sc * F;
                     const float v = l_v[e];
                     fsp_u[ko * S + sc] += v;
@@ -361,11 +457,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             __syncthreads();
         };
         int n_list = 0;        // entries waiting in the list (wave-uniform)
-        if (header[3] == ADH_IM_MODE_COMPACT) {
+        if (compact) {
             // ---- the gather kernel kept the fragment tile in sparse form: the non-zero cells as
             // (cell, intensity, m/z) entries sorted by cell, i.e. in the reference's summation order
-            const ImEntry *entries = reinterpret_cast<const ImEntry *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
-            const int total = (int)header[2];
+            const int total = n_fe;
             for (int base = 0; base < total; base += ADH_WAVE) {
                 const int cnt = min(ADH_WAVE, total - base);
                 if (lane < cnt) {
@@ -618,6 +713,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     if (caps.stop_phase == 4) return;
     // =========================== features ===========================
     // isotope intensity sums: per-scan sums in parallel, then in scan order (as for the template)
+    // (sparse form: done with the template above)
+    if (!compact) {
     for (int c = lane; c < I * S; c += ADH_WAVE) {
         float sf = 0;
         for (int f = 0; f < F; ++f) sf += prec_int(c / S, (c % S) * F + f);
@@ -668,6 +765,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             hp[i] = (wh > 0) ? vh / wh : 0.0;      // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
             omzp[i] = (wmz > 0) ? vmz / wmz : 0.0;
         }
+    }
     }
     __syncthreads();
 

@@ -25,6 +25,7 @@ constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
 size_t adh_gather_im_lds_bytes(const Caps &c) {
     size_t b = (size_t)c.n_lib * 16;          // l_int, l_mz, l_rank, l_ok
     b += (size_t)(c.k + c.i) * (4 + 4 + 4);   // window m/z, tof start, tof stop
+    b += (size_t)(c.k + c.i + 1) * 4;         // first pair of every window
     return (b + 15) / 16 * 16;
 }
 
@@ -35,8 +36,12 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     using namespace gather_im;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned n_touched;  // dense mode: fragment cells that received their first event
-    __shared__ unsigned n_list;     // compact mode: entries in `list`
-    __shared__ ImEntry list[ADH_IM_LIST_CAP];
+    // compact mode: event ranges of the (window, TOF bin) pairs, and the list of surviving events
+    __shared__ int64_t p_lo[ADH_IM_PAIR_CAP];
+    __shared__ uint32_t p_off[ADH_IM_PAIR_CAP + 1];
+    __shared__ uint32_t s_key[ADH_IM_SORT_CAP];  // cell << 9 | position in the list
+    __shared__ uint32_t s_tof[ADH_IM_SORT_CAP];
+    __shared__ uint16_t s_int[ADH_IM_SORT_CAP];
     float *l_int = reinterpret_cast<float *>(smem);
     float *l_mz = l_int + caps.n_lib;
     int *l_rank = reinterpret_cast<int *>(l_mz + caps.n_lib);
@@ -44,6 +49,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     float *w_mz = reinterpret_cast<float *>(l_ok + caps.n_lib);
     int *t_lo = reinterpret_cast<int *>(w_mz + caps.k + caps.i);
     int *t_hi = t_lo + caps.k + caps.i;
+    int *w_p0 = t_hi + caps.k + caps.i;  // first (window, bin) pair of every window
 
     const int lane = threadIdx.x;
     const CandRecIM &r = plan[blockIdx.x];
@@ -175,130 +181,224 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     };
     uint32_t hits = 0;
     bool dense = caps.stop_phase == ADH_DEBUG_DENSE || caps.stop_phase == 8;  // (8: developer switch, dense mode only)
+    const int W = K + I;
     if (!dense) {
-        // ---- compact mode: the same (window, cycle) tasks, one per lane, but a task keeps the few cells
-        // it touches in registers (a fragment window sees ~0.4 events per cycle) and appends them to an
-        // LDS list when it is done: no tile, no zero fill (116 KB per candidate at 38 scans x 29 cycles),
-        // no read-modify-write traffic.  A cell belongs to exactly one task and receives its events in
-        // (TOF, push) order: the reference's order.  The (small) precursor tile stays dense.
-        for (int c = lane; c < n_pc; c += ADH_WAVE) pcells[c] = make_float2(0.0f, 0.0f);
-        if (lane == 0) n_list = 0u;
+        // ---- compact mode: the tile is never materialised.
+        //  1. one lane per (window, TOF bin) pair: two binary searches give the events of the bin that lie
+        //     in the candidate's cycles - ONE contiguous range, because a bin's events ascend by push
+        //  2. the ranges of a group of windows form one stream of raw events, 64 per round, one per lane:
+        //     scan / quadrupole tests, survivors compacted in stream order (bin, then push: the order in
+        //     which the reference folds the events of a cell) into an LDS list
+        //  3. the list is sorted by (cell, stream position), one lane per cell folds its events, and the
+        //     non-zero cells leave as (cell, intensity, m/z) entries, already in cell order
+        // The isotope windows form the last group; its cells are keyed (scan, cycle, isotope, MS1 row) and
+        // the MS1 rows are collapsed here (candidate.py:248-269), so the feature kernel finds all isotopes
+        // of a precursor cell next to each other.
+        if (lane == 0) {
+            int acc = 0;
+            for (int w = 0; w < W; ++w) {
+                const int slot = w >= K ? caps.k + (w - K) : w;
+                w_p0[w] = acc;
+                acc += t_hi[slot] - t_lo[slot];
+            }
+            w_p0[W] = acc;
+        }
         __syncthreads();
-        bool over = false;
-        for (int t = lane; t < (K + I) * F; t += ADH_WAVE) {
-            const int w = t / F, f = t - w * F;
-            const bool prec = w >= K;
-            const int slot = prec ? caps.k + (w - K) : w;
-            const int j = prec ? (w - K) : w;
-            const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
-            const int n_o = prec ? Op : O;
-            const uint16_t *obs = prec ? r.ms1_obs : r.obs;
-            const int frame_lo = (c0 + f) * L + z;
-            const uint32_t push_lo = (uint32_t)frame_lo * (uint32_t)S_max;
-            const uint32_t push_hi = (uint32_t)(frame_lo + L) * (uint32_t)S_max;
-            uint32_t ec[ADH_IM_TASK_CAP];
-            float ex[ADH_IM_TASK_CAP], ey[ADH_IM_TASK_CAP];
-            int ne = 0;
-            for (int tof = t_lo[slot]; tof < t_hi[slot]; ++tof) {
-                const double measured = run.mz[tof];
+        const int P = w_p0[W];
+        bool over = P > ADH_IM_PAIR_CAP || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12;
+        const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)S_max;
+        const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
+        const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
+        if (!over) {
+            for (int p = lane; p < P; p += ADH_WAVE) {
+                int w = 0;
+                while (w_p0[w + 1] <= p) ++w;
+                const int slot = w >= K ? caps.k + (w - K) : w;
+                const int tof = t_lo[slot] + (p - w_p0[w]);
                 const int64_t b = run.tof_indptr[tof + 1];
                 int64_t lo = run.tof_indptr[tof], hi = b;
                 while (lo < hi) {
                     int64_t m = (lo + hi) >> 1;
                     if (run.push[m] < push_lo) lo = m + 1; else hi = m;
                 }
-                for (int64_t idx = lo; idx < b; ++idx) {
-                    const uint32_t p = run.push[idx];
-                    if (p >= push_hi) break;
-                    const int frame = (int)(p / (uint32_t)S_max), scan = (int)(p % (uint32_t)S_max);
-                    if (scan < r.scan_start || scan >= r.scan_stop) continue;
-                    const int crow = (frame - frame_lo) * S_max + scan;
-                    if (!(q_lo <= run.cycle[2 * crow + 1] && q_hi >= run.cycle[2 * crow])) continue;
-                    const int pc = run.dpc[crow];
-                    int o = 0;
-                    while (o < n_o && (int)obs[o] != pc) ++o;
-                    if (o >= n_o) continue;  // cannot happen: the plan lists every overlapping row
-                    const int cell = ((j * n_o + o) * S + (scan - r.scan_start)) * F + f;
-                    const int64_t ni = run.inten[idx];
-                    ++hits;
-                    if (prec) {
-                        float2 v = pcells[cell];
-                        fold(v.x, v.y, ni, measured);
-                        pcells[cell] = v;
-                        continue;
-                    }
-                    int e = -1;
-#pragma unroll
-                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
-                        if (q < ne && ec[q] == (uint32_t)cell) e = q;
-                    if (e < 0) {
-                        if (ne == ADH_IM_TASK_CAP) {
-                            over = true;
-                            break;
-                        }
-                        e = ne++;
-#pragma unroll
-                        for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
-                            if (q == e) ec[q] = (uint32_t)cell, ex[q] = 0.0f, ey[q] = 0.0f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
-                        if (q == e) fold(ex[q], ey[q], ni, measured);
+                int64_t lo2 = lo;
+                hi = b;
+                while (lo2 < hi) {
+                    int64_t m = (lo2 + hi) >> 1;
+                    if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
                 }
-                if (over) break;
+                p_lo[p] = lo;
+                p_off[p + 1] = (uint32_t)(lo2 - lo);
             }
-            if (ne > 0 && !over) {
-                const unsigned base = atomicAdd(&n_list, (unsigned)ne);
-                if (base + (unsigned)ne > ADH_IM_LIST_CAP) {
-                    over = true;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < ADH_IM_TASK_CAP; ++q)
-                        if (q < ne) {
-                            ImEntry en;
-                            en.cell = ec[q];
-                            en.x = ex[q];
-                            en.y = ey[q];
-                            list[base + q] = en;
-                        }
-                }
-            }
-        }
-        dense = __ballot(over) != 0ull;  // too many non-zero cells: this candidate takes the dense path below
-        __syncthreads();
-        if (!dense) {
-            // sort the entries by cell (bitonic, padded with the largest key) and write the list out
-            const int n_ent = (int)n_list;
-            int n_p = ADH_WAVE;
-            while (n_p < n_ent) n_p <<= 1;
-            for (int e = n_ent + lane; e < n_p; e += ADH_WAVE) list[e].cell = 0xFFFFFFFFu;
             __syncthreads();
-            for (int k = 2; k <= n_p; k <<= 1)
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int e = lane; e < n_p; e += ADH_WAVE) {
-                        const int q = e ^ jj;
-                        if (q > e) {
-                            const ImEntry ea = list[e], eb = list[q];
-                            if ((ea.cell > eb.cell) == ((e & k) == 0)) {
-                                list[e] = eb;
-                                list[q] = ea;
+            uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
+            for (int base = 0; base < P; base += ADH_WAVE) {
+                uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
+                for (int off = 1; off < ADH_WAVE; off <<= 1) {
+                    const uint32_t u = __shfl_up(v, off);
+                    if (lane >= off) v += u;
+                }
+                if (base + lane < P) p_off[base + lane + 1] = carry + v;
+                carry += __shfl(v, ADH_WAVE - 1);
+            }
+            if (lane == 0) p_off[0] = 0u;
+            __syncthreads();
+        }
+        ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
+        const uint32_t out_cap =
+            (uint32_t)((adh_im_touch_off(r.k_cap, O, S, F, I, Op) - adh_scratch_frag_off(r.k_cap)) / sizeof(ImEntry));
+        uint32_t out_n = 0, n_fe = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int w0 = 0;
+        while (w0 < W && !over) {
+            const bool pgroup = w0 >= K;
+            int w1 = pgroup ? W : w0 + 1;
+            if (!pgroup)
+                while (w1 < K && p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]] <= ADH_IM_SORT_CAP) ++w1;
+            if (pgroup) n_fe = out_n;
+            const int pa0 = w_p0[w0], pb0 = w_p0[w1];
+            const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
+            int m = 0;  // survivors in the list (wave-uniform)
+            for (uint32_t e0 = r0; e0 < r1; e0 += ADH_WAVE) {
+                const uint32_t e = e0 + lane;
+                bool ok = false;
+                uint32_t cell = 0, tofv = 0;
+                uint16_t ni = 0;
+                if (e < r1) {
+                    int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
+                    while (pb - pa > 1) {
+                        const int mid = (pa + pb) >> 1;
+                        if (p_off[mid] <= e) pa = mid; else pb = mid;
+                    }
+                    int w = w0;
+                    while (w_p0[w + 1] <= pa) ++w;
+                    const bool prec = w >= K;
+                    const int slot = prec ? caps.k + (w - K) : w;
+                    const int64_t idx = p_lo[pa] + (int64_t)(e - p_off[pa]);
+                    const uint32_t pv = run.push[idx];
+                    const int frame = (int)(pv / (uint32_t)S_max), scan = (int)(pv % (uint32_t)S_max);
+                    if (scan >= r.scan_start && scan < r.scan_stop) {
+                        const int cyc = (frame - z) / L;
+                        const int f = cyc - c0;
+                        const int crow = (frame - z - cyc * L) * S_max + scan;
+                        const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
+                        if (q_lo <= run.cycle[2 * crow + 1] && q_hi >= run.cycle[2 * crow]) {
+                            const int n_o = prec ? Op : O;
+                            const uint16_t *obs = prec ? r.ms1_obs : r.obs;
+                            const int pc = run.dpc[crow];
+                            int o = 0;
+                            while (o < n_o && (int)obs[o] != pc) ++o;
+                            if (o < n_o) {  // (always: the plan lists every overlapping row)
+                                const int sc = scan - r.scan_start;
+                                cell = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
+                                            : (uint32_t)(((w * O + o) * S + sc) * F + f);
+                                tofv = (uint32_t)(t_lo[slot] + (pa - w_p0[w]));
+                                ni = run.inten[idx];
+                                ok = true;
                             }
                         }
                     }
-                    __syncthreads();
                 }
-            ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
-            for (int e = lane; e < n_ent; e += ADH_WAVE) out_list[e] = list[e];
-            for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
+                const unsigned long long mask = __ballot(ok);
+                if (ok) {
+                    const int pos = m + __popcll(mask & lt);
+                    if (pos < ADH_IM_SORT_CAP) {
+                        s_key[pos] = (cell << 9) | (uint32_t)pos;
+                        s_tof[pos] = tofv;
+                        s_int[pos] = ni;
+                    }
+                }
+                m += __popcll(mask);
+            }
+            if (m > ADH_IM_SORT_CAP) {
+                over = true;
+                break;
+            }
+            hits += (uint32_t)m;
+            int n_p = ADH_WAVE;
+            while (n_p < m) n_p <<= 1;
+            for (int e = m + lane; e < n_p; e += ADH_WAVE) s_key[e] = 0xFFFFFFFFu;
+            __syncthreads();
+            if (m > 1)
+                for (int k = 2; k <= n_p; k <<= 1)
+                    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                        for (int e = lane; e < n_p; e += ADH_WAVE) {
+                            const int q = e ^ jj;
+                            if (q > e) {
+                                const uint32_t ka = s_key[e], kb = s_key[q];
+                                if ((ka > kb) == ((e & k) == 0)) {
+                                    s_key[e] = kb;
+                                    s_key[q] = ka;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+            // one lane per output cell folds the events of the cell in list order
+            for (int e0 = 0; e0 < m; e0 += ADH_WAVE) {
+                const int e = e0 + lane;
+                bool owner = false;
+                ImEntry en;
+                en.cell = 0u, en.x = 0.0f, en.y = 0.0f;
+                if (e < m) {
+                    const uint32_t cell = s_key[e] >> 9;
+                    if (!pgroup) {
+                        owner = e == 0 || (s_key[e - 1] >> 9) != cell;
+                        if (owner) {
+                            float vx = 0.0f, vy = 0.0f;
+                            for (int q = e; q < m && (s_key[q] >> 9) == cell; ++q) {
+                                const int pos = (int)(s_key[q] & 511u);
+                                fold(vx, vy, (int64_t)s_int[pos], run.mz[s_tof[pos]]);
+                            }
+                            en.cell = cell, en.x = vx, en.y = vy;
+                        }
+                    } else {
+                        const uint32_t gid = (cell - (uint32_t)n_fc) / (uint32_t)Op;  // (scan, cycle, isotope)
+                        owner = e == 0 || ((s_key[e - 1] >> 9) - (uint32_t)n_fc) / (uint32_t)Op != gid;
+                        if (owner) {
+                            float acc = 0.0f;  // candidate.py:248-269: sum of the intensities, mean of the non-zero m/z
+                            double sum = 0.0;
+                            int count = 0;
+                            int q = e;
+                            while (q < m && ((s_key[q] >> 9) - (uint32_t)n_fc) / (uint32_t)Op == gid) {
+                                const uint32_t c = s_key[q] >> 9;
+                                float vx = 0.0f, vy = 0.0f;
+                                for (; q < m && (s_key[q] >> 9) == c; ++q) {
+                                    const int pos = (int)(s_key[q] & 511u);
+                                    fold(vx, vy, (int64_t)s_int[pos], run.mz[s_tof[pos]]);
+                                }
+                                acc += vx;
+                                sum += (double)vy;
+                                count += vy > 0.0f;
+                            }
+                            en.cell = gid, en.x = acc, en.y = (float)(sum / ((double)count + 1e-6));
+                        }
+                    }
+                }
+                const unsigned long long mask = __ballot(owner);
+                if (owner) {
+                    const uint32_t at = out_n + (uint32_t)__popcll(mask & lt);
+                    if (at < out_cap) out_list[at] = en;
+                }
+                out_n += (uint32_t)__popcll(mask);
+            }
+            __syncthreads();
+            if (out_n > out_cap) over = true;
+            w0 = w1;
+        }
+        dense = over;  // too many events for the lists: this candidate takes the dense path below
+        if (!dense) {
             if (lane == 0) {
                 header[0] = (uint32_t)K;
                 header[1] = hits;
-                header[2] = (uint32_t)n_ent;
+                header[2] = n_fe;
                 header[3] = ADH_IM_MODE_COMPACT;
+                header[4] = out_n - n_fe;
             }
             return;
         }
         hits = 0;
+        __syncthreads();
     }
 
     // ---- dense mode: zero the tile, (window, cycle) tasks, list of the touched fragment cells
