@@ -460,18 +460,95 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         if (compact) {
             // ---- the gather kernel kept the fragment tile in sparse form: the non-zero cells as
             // (cell, intensity, m/z) entries sorted by cell, i.e. in the reference's summation order
-            const int total = n_fe;
-            for (int base = 0; base < total; base += ADH_WAVE) {
-                const int cnt = min(ADH_WAVE, total - base);
-                if (lane < cnt) {
-                    const ImEntry en = entries[base + lane];
-                    l_cell[lane] = (int)en.cell;
-                    l_rx[lane] = en.x;
-                    l_ry[lane] = en.y;
-                }
-                __syncthreads();
-                flush(cnt);
+            // Every (fragment, observation) plane has its own lane, which folds the plane's entries in list
+            // order with the running sums in registers.  A round stages q = 64 / planes entries of every
+            // plane at once (weights and products by all 64 lanes), so the planes advance in parallel
+            // and a signal-rich candidate (thousands of entries) costs max-plane / q rounds.
+            int *const pl_beg = fpeak;                              // [K0 * O], idle until the peak search
+            int *const pl_end = reinterpret_cast<int *>(rowsum);    // [K0 * O], idle until the pass is over
+            const int n_pl = K0 * O;
+            for (int c = lane; c < n_pl; c += ADH_WAVE) {
+                pl_beg[c] = 0;
+                pl_end[c] = 0;
             }
+            __syncthreads();
+            for (int e = lane; e < n_fe; e += ADH_WAVE) {
+                const int pc = (int)entries[e].cell / SF;
+                const int pp = e > 0 ? (int)entries[e - 1].cell / SF : -1;
+                if (pc != pp) {
+                    pl_beg[pc] = e;
+                    if (pp >= 0) pl_end[pp] = e;
+                }
+                if (e == n_fe - 1) pl_end[pc] = n_fe;
+            }
+            __syncthreads();
+            for (int pbase = 0; pbase < n_pl; pbase += ADH_WAVE) {
+                const int np = min(ADH_WAVE, n_pl - pbase);
+                const int q = ADH_WAVE / np;
+                const int pslot = lane / q, j = lane - pslot * q;
+                const bool active = pslot < np;
+                const int p = pbase + pslot, o = p % O;
+                const int beg = active ? pl_beg[p] : 0, end = active ? pl_end[p] : 0;
+                int R = (end - beg + q - 1) / q;
+                for (int off = 32; off > 0; off >>= 1) R = max(R, __shfl_xor(R, off));
+                double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
+                float fs = 0.0f;
+                int cur_sc = -1;
+                ImEntry nxt;
+                nxt.cell = 0u, nxt.x = 0.0f, nxt.y = 0.0f;
+                if (active && beg + j < end) nxt = entries[beg + j];
+                for (int rr = 0; rr < R; ++rr) {
+                    const int e = beg + rr * q + j;
+                    const ImEntry en = nxt;
+                    if (active && e + q < end) nxt = entries[e + q];
+                    if (active && e < end) {
+                        const int rem = (int)en.cell - p * SF;
+                        const int sc = rem / F, f = rem - sc * F;
+                        const float v = en.x * qmask[o * S + sc];  // candidate.py:290
+                        const double ds = (double)sc - esc[o], df = (double)f - efc[o];
+                        const double w = exp(-0.1 * sqrt(ds * ds + df * df));
+                        l_cell[lane] = rem;
+                        l_v[lane] = v;
+                        l_w[lane] = w;
+                        l_ti[lane] = (double)v * w;
+                        l_tm[lane] = (double)en.y * w;
+                    }
+                    __syncthreads();
+                    if (active && j == 0) {
+                        const int cnt = min(q, end - (beg + rr * q));
+                        for (int t = 0; t < cnt; ++t) {
+                            const int at = lane + t;
+                            const int rem = l_cell[at];
+                            const int sc = rem / F, f = rem - sc * F;
+                            const float v = l_v[at];
+                            if (sc != cur_sc) {  // the cells of a scan are consecutive: its sum is complete
+                                if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
+                                fs = 0.0f;
+                                cur_sc = sc;
+                            }
+                            fs += v;
+                            ffp_u[p * F + f] += v;
+                            if (v > 0.0f) {
+                                vi += l_ti[at];
+                                wi += l_w[at];
+                            }
+                            if (l_tm[at] > 0.0) {  // m/z channel of the cell is > 0
+                                vm += l_tm[at];
+                                wm += l_w[at];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (active && j == 0) {
+                    if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
+                    acc_vi[p] = vi;
+                    acc_wi[p] = wi;
+                    acc_vm[p] = vm;
+                    acc_wm[p] = wm;
+                }
+            }
+            __syncthreads();
         } else {
         const uint32_t n_touch = header[2];
         int n_p_need = ADH_WAVE;
