@@ -135,6 +135,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     const int SF = S * F, OSF = O * SF;
     const int top_k = out.top_k;
     if (lane == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
+    if (caps.stop_phase == 10) return;  // developer ablation switches (ADH_DEBUG_IM)
 
     float *const work_a = Fl + lay.f_wa();
     float *const work_b = Fl + lay.f_wb();
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // (the qtf mask of candidate.py:290 is applied while the fragment tile is streamed)
     double *const hp = D + lay.d_pi();
     double *const omzp = hp + Ic;
+    if (caps.stop_phase == 11) return;
     if (compact) {
         // ---- everything that reads the precursor tile, in ONE pass over its sparse form: the entries are
         // the non-zero (scan, cycle, isotope) cells in that order, staged 192 at a time in the chunk lists.
@@ -242,13 +244,15 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         double acc = 0.0;
         float part = 0.0f, tot = 0.0f;
         int cur_sc = -1;
+        // (a staged cell is packed as scan << 16 | cycle << 4 | isotope: the sequential walks below must
+        // not divide)
         for (int base = 0; base < n_pe;) {
             int cnt = min(192, n_pe - base);
             for (int e = lane; e < cnt; e += ADH_WAVE) {
                 const ImEntry en = pent[base + e];
-                const int sf = (int)en.cell / I, sc = sf / F, f = sf - sc * F;
+                const int sf = (int)en.cell / I, i = (int)en.cell - sf * I, sc = sf / F, f = sf - sc * F;
                 const double ds = (double)(sc - S), df = (double)(f - 1);
-                c_cell[e] = en.cell;
+                c_cell[e] = (uint32_t)(sc << 16 | f << 4 | i);
                 c_x[e] = en.x;
                 c_y[e] = en.y;
                 c_w[e] = exp(-0.1 * sqrt(ds * ds + df * df));
@@ -256,17 +260,17 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             __syncthreads();
             if (base + cnt < n_pe) {  // never cut the isotopes of a cell in two: stop at the last cell start
                 const int e = cnt - ADH_WAVE + lane;
-                const unsigned long long st = __ballot((int)c_cell[e] / I != (int)c_cell[e - 1] / I);
+                const unsigned long long st = __ballot((c_cell[e] >> 4) != (c_cell[e - 1] >> 4));
                 cnt = cnt - ADH_WAVE + (63 - __clzll(st));
             }
             for (int e = lane; e < cnt; e += ADH_WAVE) {
-                const int sf = (int)c_cell[e] / I;
-                if (e > 0 && (int)c_cell[e - 1] / I == sf) continue;
-                const int sc = sf / F;
+                const uint32_t cs = c_cell[e] >> 4;
+                if (e > 0 && (c_cell[e - 1] >> 4) == cs) continue;
+                const int sc = (int)(cs >> 12), sf = sc * F + (int)(cs & 0xFFFu);
                 for (int o = 0; o < O; ++o) {
                     double a = 0;
-                    for (int q = e; q < cnt && (int)c_cell[q] / I == sf; ++q) {
-                        const int i = (int)c_cell[q] - sf * I;
+                    for (int q = e; q < cnt && (c_cell[q] >> 4) == cs; ++q) {
+                        const int i = (int)(c_cell[q] & 15u);
                         const float t = c_x[q] * iso_int[i];
                         a += (double)t * qtf[(i * O + o) * S + sc];
                     }
@@ -275,10 +279,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             }
             if (lane < 5 * I) {
                 for (int e = 0; e < cnt; ++e) {
-                    const int cell = (int)c_cell[e], sf = cell / I;
-                    if (cell - sf * I != iso) continue;
+                    const uint32_t cp = c_cell[e];
+                    if ((int)(cp & 15u) != iso) continue;
                     if (role == 0) {
-                        const int sc = sf / F;
+                        const int sc = (int)(cp >> 16);
                         if (sc != cur_sc) {
                             tot += part;
                             part = 0.0f;
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                         const float v = en.x * qmask[o * S + sc];  // candidate.py:290
                         const double ds = (double)sc - esc[o], df = (double)f - efc[o];
                         const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                        l_cell[lane] = rem;
+                        l_cell[lane] = sc << 16 | f;  // (the serial fold below must not divide)
                         l_v[lane] = v;
                         l_w[lane] = w;
                         l_ti[lane] = (double)v * w;
@@ -518,8 +522,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                         const int cnt = min(q, end - (beg + rr * q));
                         for (int t = 0; t < cnt; ++t) {
                             const int at = lane + t;
-                            const int rem = l_cell[at];
-                            const int sc = rem / F, f = rem - sc * F;
+                            const int sc = l_cell[at] >> 16, f = l_cell[at] & 0xFFFF;
                             const float v = l_v[at];
                             if (sc != cur_sc) {  // the cells of a scan are consecutive: its sum is complete
                                 if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;

@@ -22,10 +22,19 @@ namespace gather_im {
 constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
 }
 
+// LDS of one block: window tables, then ONE region used twice - by the library slice while the
+// fragments are selected, by the pair ranges and the event list of the compact mode afterwards.
+// (Occupancy is what this latency-bound kernel lives on: 10 KB -> 20 KB per block costs 70 %.)
+namespace gather_im {
+constexpr size_t kCompactBytes = (size_t)ADH_IM_PAIR_CAP * 4 + (size_t)(ADH_IM_PAIR_CAP + 1) * 4 + 4 +  // p_lo, p_off
+                                 (size_t)ADH_IM_SORT_CAP * (4 + 2 + 1);                                  // s_key, s_int, s_pair
+}
 size_t adh_gather_im_lds_bytes(const Caps &c) {
-    size_t b = (size_t)c.n_lib * 16;          // l_int, l_mz, l_rank, l_ok
-    b += (size_t)(c.k + c.i) * (4 + 4 + 4);   // window m/z, tof start, tof stop
-    b += (size_t)(c.k + c.i + 1) * 4;         // first pair of every window
+    size_t b = (size_t)(c.k + c.i) * (4 + 4 + 4);  // window m/z, tof start, tof stop
+    b += (size_t)(c.k + c.i + 1) * 4;              // first pair of every window
+    b = (b + 15) / 16 * 16;
+    const size_t lib = (size_t)c.n_lib * 16;       // l_int, l_mz, l_rank, l_ok
+    b += lib > gather_im::kCompactBytes ? lib : gather_im::kCompactBytes;
     return (b + 15) / 16 * 16;
 }
 
@@ -36,20 +45,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     using namespace gather_im;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned n_touched;  // dense mode: fragment cells that received their first event
-    // compact mode: event ranges of the (window, TOF bin) pairs, and the list of surviving events
-    __shared__ int64_t p_lo[ADH_IM_PAIR_CAP];
-    __shared__ uint32_t p_off[ADH_IM_PAIR_CAP + 1];
-    __shared__ uint32_t s_key[ADH_IM_SORT_CAP];  // cell << 9 | position in the list
-    __shared__ uint32_t s_tof[ADH_IM_SORT_CAP];
-    __shared__ uint16_t s_int[ADH_IM_SORT_CAP];
-    float *l_int = reinterpret_cast<float *>(smem);
+    const int n_win = caps.k + caps.i;
+    float *w_mz = reinterpret_cast<float *>(smem);
+    int *t_lo = reinterpret_cast<int *>(w_mz + n_win);
+    int *t_hi = t_lo + n_win;
+    int *w_p0 = t_hi + n_win;  // first (window, bin) pair of every window
+    unsigned char *region = smem + ((size_t)n_win * 12 + (size_t)(n_win + 1) * 4 + 15) / 16 * 16;
+    // fragment selection
+    float *l_int = reinterpret_cast<float *>(region);
     float *l_mz = l_int + caps.n_lib;
     int *l_rank = reinterpret_cast<int *>(l_mz + caps.n_lib);
     int *l_ok = l_rank + caps.n_lib;
-    float *w_mz = reinterpret_cast<float *>(l_ok + caps.n_lib);
-    int *t_lo = reinterpret_cast<int *>(w_mz + caps.k + caps.i);
-    int *t_hi = t_lo + caps.k + caps.i;
-    int *w_p0 = t_hi + caps.k + caps.i;  // first (window, bin) pair of every window
+    // compact mode: event ranges of the (window, TOF bin) pairs, and the list of surviving events
+    uint32_t *p_lo = reinterpret_cast<uint32_t *>(region);   // [ADH_IM_PAIR_CAP] first event of the range
+    uint32_t *p_off = p_lo + ADH_IM_PAIR_CAP;                 // [ADH_IM_PAIR_CAP + 1] events before the pair
+    uint32_t *s_key = p_off + ADH_IM_PAIR_CAP + 2;            // [ADH_IM_SORT_CAP] cell << 9 | position in the list
+    uint16_t *s_int = reinterpret_cast<uint16_t *>(s_key + ADH_IM_SORT_CAP);
+    uint8_t *s_pair = reinterpret_cast<uint8_t *>(s_int + ADH_IM_SORT_CAP);
 
     const int lane = threadIdx.x;
     const CandRecIM &r = plan[blockIdx.x];
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         }
         __syncthreads();
         const int P = w_p0[W];
-        bool over = P > ADH_IM_PAIR_CAP || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12;
+        bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)S_max;
         const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
         const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     int64_t m = (lo2 + hi) >> 1;
                     if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
                 }
-                p_lo[p] = lo;
+                p_lo[p] = (uint32_t)lo;
                 p_off[p + 1] = (uint32_t)(lo2 - lo);
             }
             __syncthreads();
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             if (lane == 0) p_off[0] = 0u;
             __syncthreads();
         }
+        const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
         const uint32_t out_cap =
             (uint32_t)((adh_im_touch_off(r.k_cap, O, S, F, I, Op) - adh_scratch_frag_off(r.k_cap)) / sizeof(ImEntry));
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             for (uint32_t e0 = r0; e0 < r1; e0 += ADH_WAVE) {
                 const uint32_t e = e0 + lane;
                 bool ok = false;
-                uint32_t cell = 0, tofv = 0;
+                uint32_t cell = 0, pair = 0;
                 uint16_t ni = 0;
                 if (e < r1) {
                     int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
@@ -274,11 +287,16 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     while (w_p0[w + 1] <= pa) ++w;
                     const bool prec = w >= K;
                     const int slot = prec ? caps.k + (w - K) : w;
-                    const int64_t idx = p_lo[pa] + (int64_t)(e - p_off[pa]);
+                    const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                     const uint32_t pv = run.push[idx];
-                    const int frame = (int)(pv / (uint32_t)S_max), scan = (int)(pv % (uint32_t)S_max);
+                    // (exact quotients without the integer-division sequence: float64 estimate, one fix-up)
+                    uint32_t fq = (uint32_t)((double)pv * inv_smax);
+                    if (pv - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
+                    const int frame = (int)fq, scan = (int)(pv - fq * (uint32_t)S_max);
                     if (scan >= r.scan_start && scan < r.scan_stop) {
-                        const int cyc = (frame - z) / L;
+                        uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
+                        if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
+                        const int cyc = (int)cq;
                         const int f = cyc - c0;
                         const int crow = (frame - z - cyc * L) * S_max + scan;
                         const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                                 const int sc = scan - r.scan_start;
                                 cell = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
                                             : (uint32_t)(((w * O + o) * S + sc) * F + f);
-                                tofv = (uint32_t)(t_lo[slot] + (pa - w_p0[w]));
+                                pair = (uint32_t)pa;
                                 ni = run.inten[idx];
                                 ok = true;
                             }
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     const int pos = m + __popcll(mask & lt);
                     if (pos < ADH_IM_SORT_CAP) {
                         s_key[pos] = (cell << 9) | (uint32_t)pos;
-                        s_tof[pos] = tofv;
+                        s_pair[pos] = (uint8_t)pair;
                         s_int[pos] = ni;
                     }
                 }
@@ -345,10 +363,12 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     if (!pgroup) {
                         owner = e == 0 || (s_key[e - 1] >> 9) != cell;
                         if (owner) {
+                            const int w = (int)cell / (O * S * F);  // TOF bin of an event: first bin of the window + pair - first pair
+                            const int tof0 = t_lo[w] - w_p0[w];
                             float vx = 0.0f, vy = 0.0f;
                             for (int q = e; q < m && (s_key[q] >> 9) == cell; ++q) {
                                 const int pos = (int)(s_key[q] & 511u);
-                                fold(vx, vy, (int64_t)s_int[pos], run.mz[s_tof[pos]]);
+                                fold(vx, vy, (int64_t)s_int[pos], run.mz[tof0 + (int)s_pair[pos]]);
                             }
                             en.cell = cell, en.x = vx, en.y = vy;
                         }
@@ -356,6 +376,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                         const uint32_t gid = (cell - (uint32_t)n_fc) / (uint32_t)Op;  // (scan, cycle, isotope)
                         owner = e == 0 || ((s_key[e - 1] >> 9) - (uint32_t)n_fc) / (uint32_t)Op != gid;
                         if (owner) {
+                            const int w = K + (int)(gid % (uint32_t)I);
+                            const int tof0 = t_lo[caps.k + (w - K)] - w_p0[w];
                             float acc = 0.0f;  // candidate.py:248-269: sum of the intensities, mean of the non-zero m/z
                             double sum = 0.0;
                             int count = 0;
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                                 float vx = 0.0f, vy = 0.0f;
                                 for (; q < m && (s_key[q] >> 9) == c; ++q) {
                                     const int pos = (int)(s_key[q] & 511u);
-                                    fold(vx, vy, (int64_t)s_int[pos], run.mz[s_tof[pos]]);
+                                    fold(vx, vy, (int64_t)s_int[pos], run.mz[tof0 + (int)s_pair[pos]]);
                                 }
                                 acc += vx;
                                 sum += (double)vy;

@@ -398,8 +398,11 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
         return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
     p.caps_all.stop_phase = 0;
     if (const char *dbg = getenv("ADH_DEBUG_IM")) p.caps_all.stop_phase = atoi(dbg);
-    const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all);
-    const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all);
+    size_t g_pad = 0, f_pad = 0;  // developer switches: extra LDS per block, to see what occupancy is worth
+    if (const char *dbg = getenv("ADH_DEBUG_IM_GATHER_LDS_PAD")) g_pad = (size_t)atoi(dbg);
+    if (const char *dbg = getenv("ADH_DEBUG_IM_FEATURE_LDS_PAD")) f_pad = (size_t)atoi(dbg);
+    const size_t g_lds = adh_gather_im_lds_bytes(p.caps_all) + g_pad;
+    const size_t f_lds = adh_feature_im_lds_bytes(p.caps_all) + f_pad;
     if (f_lds > 160 * 1024 - ADH_IM_STATIC_LDS || g_lds > 160 * 1024) {
         char buf[256];
         snprintf(buf, sizeof(buf),
@@ -430,7 +433,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                 Caps cc = p.caps_all;
                 if (c == 0) cc.o = 1;
                 if (c == 1) cc.o = std::min(cc.o, 2);
-                hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), adh_feature_im_lds_bytes(cc), st,
+                hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), adh_feature_im_lds_bytes(cc) + f_pad, st,
                                    h->tims, p.d_recs_im + first, h->cs.iso, n_iso, *cfg, d_scratch, *out, cc);
                 HIP_TRY(hipGetLastError());
             }
