@@ -55,16 +55,28 @@ struct Layout {
     __host__ __device__ int smax() const { return Sc > Fc ? Sc : Fc; }
     __host__ __device__ int f_wa() const { return 0; }                            // work [Kc*Fc]
     __host__ __device__ int f_wb() const { return Kc * Fc; }                      // work [Kc*Oc*max(Sc,Fc)]
-    __host__ __device__ int f_ffpu() const { return f_wb() + Kc * Oc * smax(); }  // [Kc*Oc*Fc] before the mask
-    __host__ __device__ int f_fspu() const { return f_ffpu() + Kc * Oc * Fc; }    // [Kc*Oc*Sc] before the mask
-    __host__ __device__ int f_ffp() const { return f_fspu() + Kc * Oc * Sc; }     // [Kc*Oc*Fc]
-    __host__ __device__ int f_fsp() const { return f_ffp() + Kc * Oc * Fc; }      // [2][Kc*Oc*Sc] raw, env
-    __host__ __device__ int f_tpl() const { return f_fsp() + 2 * Kc * Oc * Sc; }  // [Oc*Sc*Fc]
-    __host__ __device__ int f_tfp() const { return f_tpl() + Oc * Sc * Fc; }      // [Oc*Fc]
+    // Two regions are used twice.  R1 holds the template until its profiles are taken, then the masked
+    // frame / scan profiles; R2 holds the profiles before the presence mask, then the scan envelopes and
+    // the quantification profiles.  (LDS per block is what bounds the resident waves of this kernel, and
+    // the kernel's time follows them: 26 KB -> 40 KB per block costs 38 %.)
+    __host__ __device__ int f_work_end() const { return f_wb() + Kc * Oc * smax(); }
+    __host__ __device__ int r1_size() const {
+        const int a = Oc * Sc * Fc, b = Kc * Oc * (Fc + Sc);
+        return a > b ? a : b;
+    }
+    __host__ __device__ int f_r1() const { return f_work_end(); }
+    __host__ __device__ int f_r2() const { return f_r1() + r1_size(); }
+    __host__ __device__ int f_tpl() const { return f_r1(); }                      // [Oc*Sc*Fc]       R1, early
+    __host__ __device__ int f_ffp() const { return f_r1(); }                      // [Kc*Oc*Fc]       R1, late
+    __host__ __device__ int f_fspr() const { return f_r1() + Kc * Oc * Fc; }      // [Kc*Oc*Sc] raw   R1, late
+    __host__ __device__ int f_ffpu() const { return f_r2(); }                     // [Kc*Oc*Fc] before the mask  R2, early
+    __host__ __device__ int f_fspu() const { return f_r2() + Kc * Oc * Fc; }      // [Kc*Oc*Sc] before the mask  R2, early
+    __host__ __device__ int f_fspe() const { return f_r2(); }                     // [Kc*Oc*Sc] envelope  R2, late
+    __host__ __device__ int f_bp() const { return f_r2() + Kc * Oc * Sc; }        // [Kc*Fc]          R2, late
+    __host__ __device__ int f_tfp() const { return f_r2() + Kc * Oc * (Fc + Sc); }  // [Oc*Fc]
     __host__ __device__ int f_tsp() const { return f_tfp() + 2 * Oc * Fc; }       // [2][Oc*Sc] (tfp: raw, env)
     __host__ __device__ int f_qm() const { return f_tsp() + 2 * Oc * Sc; }        // [Oc*Sc] qtf mask
-    __host__ __device__ int f_bp() const { return f_qm() + Oc * Sc; }             // [Kc*Fc]
-    __host__ __device__ int f_pk() const { return f_bp() + Kc * Fc; }             // [8][Kc]
+    __host__ __device__ int f_pk() const { return f_qm() + Oc * Sc; }             // [8][Kc]
     __host__ __device__ int f_pko() const { return f_pk() + 8 * Kc; }             // [4][Kc*Oc]
     __host__ __device__ int f_po() const { return f_pko() + 4 * Kc * Oc; }        // [4][Oc]
     __host__ __device__ int f_pi() const { return f_po() + 4 * Oc; }              // [3][Ic]
@@ -142,8 +154,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     float *const ffp_u = Fl + lay.f_ffpu();
     float *const fsp_u = Fl + lay.f_fspu();
     float *const ffp = Fl + lay.f_ffp();
-    float *const fsp_raw = Fl + lay.f_fsp();
-    float *const fsp = fsp_raw + Kc * Oc * Sc;
+    float *const fsp_raw = Fl + lay.f_fspr();
+    float *const fsp = Fl + lay.f_fspe();
     float *const tpl = Fl + lay.f_tpl();
     float *const tfp_raw = Fl + lay.f_tfp();
     float *const tfp = tfp_raw + Oc * Fc;
@@ -556,7 +568,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         const uint32_t n_touch = header[2];
         int n_p_need = ADH_WAVE;
         while (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need < (int)n_touch) n_p_need <<= 1;
-        const int sorted_cap = lay.f_ffpu();  // floats of work_a + work_b
+        const int sorted_cap = lay.f_work_end();  // floats of work_a + work_b
         if (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need <= sorted_cap) {
             // ---- the gather kernel listed the cells it touched (<= ADH_IM_TOUCH_CAP, ~1 % of the
             // tile): sort the list (cell order = the reference's summation order) and visit those
@@ -733,7 +745,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         for (int k = lane; k < K; k += ADH_WAVE) g_fin[k] = g_int[k] / sum2;
     }
 
-    // ---- profiles (candidate.py:333-347; scoring/utils.py:26-66); k is the compacted index
+    // ---- profiles (candidate.py:333-347; scoring/utils.py:26-66); k is the compacted index.
+    // The template's profiles first: the masked fragment profiles then take the template's place.
+    for (int c = lane; c < O * F; c += ADH_WAVE) {
+        int o = c / F, f = c - o * F;
+        float a = 0;
+        for (int sc = 0; sc < S; ++sc) a += tpl[(o * S + sc) * F + f];
+        tfp_raw[c] = a;
+    }
+    for (int c = lane; c < O * S; c += ADH_WAVE) {
+        float a = 0;
+        for (int f = 0; f < F; ++f) a += tpl[c * F + f];
+        tsp_raw[c] = a;
+    }
+    __syncthreads();
     for (int c = lane; c < K * O * F; c += ADH_WAVE) {
         int k = c / (O * F), rem = c - k * O * F;
         ffp[c] = ffp_u[kmap[k] * O * F + rem];
@@ -746,17 +771,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         int k = c / O, o = c - k * O;
         ohe[c] = ohe_u[kmap[k] * O + o];
         omz[c] = omz_u[kmap[k] * O + o];
-    }
-    for (int c = lane; c < O * F; c += ADH_WAVE) {
-        int o = c / F, f = c - o * F;
-        float a = 0;
-        for (int sc = 0; sc < S; ++sc) a += tpl[(o * S + sc) * F + f];
-        tfp_raw[c] = a;
-    }
-    for (int c = lane; c < O * S; c += ADH_WAVE) {
-        float a = 0;
-        for (int f = 0; f < F; ++f) a += tpl[c * F + f];
-        tsp_raw[c] = a;
     }
     for (int f = lane; f < F; f += ADH_WAVE) frame_rt[f] = run.rt[r.frame_start + f * L];
     __syncthreads();
