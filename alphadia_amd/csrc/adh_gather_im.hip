@@ -20,6 +20,48 @@
 
 namespace gather_im {
 constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
+
+// Bitonic sort of the first m keys of an LDS array (m <= 64 * NR) by one wavefront, in registers:
+// element e = r * 64 + lane.  A partner 64 or more elements away lives in the same lane (a register
+// swap), a closer one in lane ^ j (one cross-lane read): no LDS traffic and no barrier between the
+// log^2 stages, which is what the sort costs when it is done in LDS.
+template <int NR>
+__device__ __forceinline__ void sort_keys(uint32_t *keys, int m, int lane) {
+    uint32_t k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) k[r] = r * ADH_WAVE + lane < m ? keys[r * ADH_WAVE + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int kk = 2; kk <= ADH_WAVE * NR; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= ADH_WAVE) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int pr = r ^ (j / ADH_WAVE);
+                    if (pr > r) {
+                        const bool up = ((r * ADH_WAVE) & kk) == 0;  // (kk > 64 here: the lane bits do not matter)
+                        const uint32_t a = k[r], b = k[pr];
+                        if ((a > b) == up) {
+                            k[r] = b;
+                            k[pr] = a;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const uint32_t other = __shfl_xor(k[r], j);
+                    const bool up = ((r * ADH_WAVE + lane) & kk) == 0;
+                    const bool lower = (lane & j) == 0;
+                    k[r] = (lower == up) ? min(k[r], other) : max(k[r], other);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (r * ADH_WAVE + lane < m) keys[r * ADH_WAVE + lane] = k[r];
+}
 }
 
 // LDS of one block: window tables, then ONE region used twice - by the library slice while the
@@ -333,25 +375,14 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 break;
             }
             hits += (uint32_t)m;
-            int n_p = ADH_WAVE;
-            while (n_p < m) n_p <<= 1;
-            for (int e = m + lane; e < n_p; e += ADH_WAVE) s_key[e] = 0xFFFFFFFFu;
             __syncthreads();
-            if (m > 1)
-                for (int k = 2; k <= n_p; k <<= 1)
-                    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                        for (int e = lane; e < n_p; e += ADH_WAVE) {
-                            const int q = e ^ jj;
-                            if (q > e) {
-                                const uint32_t ka = s_key[e], kb = s_key[q];
-                                if ((ka > kb) == ((e & k) == 0)) {
-                                    s_key[e] = kb;
-                                    s_key[q] = ka;
-                                }
-                            }
-                        }
-                        __syncthreads();
-                    }
+            if (m > 1) {  // sort the keys: in registers, element r * 64 + lane
+                if (m <= ADH_WAVE) sort_keys<1>(s_key, m, lane);
+                else if (m <= 2 * ADH_WAVE) sort_keys<2>(s_key, m, lane);
+                else if (m <= 4 * ADH_WAVE) sort_keys<4>(s_key, m, lane);
+                else sort_keys<8>(s_key, m, lane);
+            }
+            __syncthreads();
             // one lane per output cell folds the events of the cell in list order
             for (int e0 = 0; e0 < m; e0 += ADH_WAVE) {
                 const int e = e0 + lane;
