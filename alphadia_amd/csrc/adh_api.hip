@@ -19,6 +19,7 @@
 #include <unistd.h>
 #include <rccl/rccl.h>
 
+#include "adh_index_im.hip"
 #include "adh_plan.hip"
 #include "adh_gather.hip"
 #include "adh_features.hip"
@@ -501,6 +502,55 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     UP(h->run_buf, dpc.data(), rows, &t.dpc);
     UP(h->run_buf, d->rt_values, d->n_frames, &t.rt);
     UP(h->run_buf, d->mobility_values, (int64_t)d->scan_max_index, &t.mobility);
+    {
+        // search indices (DevTims): the m/z table on the host, the (bin, cycle) table on the device
+        t.n_cycles = (int32_t)((d->n_frames - t.zeroth + d->cycle_len - 1) / d->cycle_len);
+        const char *env = getenv("ADH_IM_INDEX");
+        const bool want = !(env && atoi(env) == 0) && d->n_events < 0xFFFFFFFFll && d->n_tof >= 2 && t.n_cycles > 0 &&
+                          d->mz_values[d->n_tof - 1] > d->mz_values[0];
+        if (want) {
+            int64_t nb = 1;
+            while (nb < 4 * d->n_tof) nb <<= 1;
+            const double lo = d->mz_values[0], hi = d->mz_values[d->n_tof - 1];
+            std::vector<uint32_t> lut((size_t)nb + 1);
+            int64_t pos = 0;
+            const double step = (hi - lo) / (double)nb;
+            for (int64_t b = 0; b <= nb; ++b) {
+                const double x = lo + (double)b * step;
+                while (pos < d->n_tof && d->mz_values[pos] < x) ++pos;
+                lut[(size_t)b] = (uint32_t)pos;
+            }
+            UP(h->run_buf, lut.data(), nb + 1, &t.mz_lut);
+            t.lut_min = lo;
+            t.lut_inv_step = 1.0 / step;
+            t.lut_n = (int32_t)nb;
+            // 4 bytes per (bin, cycle block): the finest block that fits an eighth of the device memory
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            size_t budget = std::min(total_b / 8, free_b / 2);
+            if (const char *mb = getenv("ADH_IM_INDEX_MB")) budget = (size_t)atoll(mb) << 20;
+            int shift = 0;
+            int64_t blocks = t.n_cycles;
+            while (shift < 16 && (size_t)d->n_tof * (size_t)(blocks + 1) * 4 > budget) {
+                ++shift;
+                blocks = ((int64_t)t.n_cycles + (1ll << shift) - 1) >> shift;
+            }
+            if ((size_t)d->n_tof * (size_t)(blocks + 1) * 4 <= budget) {
+                uint32_t *idx = nullptr;
+                HIP_TRY(hipMalloc((void **)&idx, (size_t)d->n_tof * (size_t)(blocks + 1) * 4));
+                h->run_buf.ptrs.push_back(idx);
+                const unsigned grid = (unsigned)std::min<int64_t>(d->n_tof, 1 << 20);
+                hipLaunchKernelGGL(adh_index_im_kernel, dim3(grid), dim3(ADH_WAVE), 0, h->stream, t.tof_indptr, t.push,
+                                   t.n_tof, (uint32_t)t.scan_max, (uint32_t)t.cycle_len, (uint32_t)t.zeroth, shift,
+                                   (uint32_t)blocks, idx);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                t.cyc_idx = idx;
+                t.cyc_shift = shift;
+                t.cyc_cols = (int32_t)(blocks + 1);
+            }
+        }
+    }
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
     h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);
     h->h_mobility_im.assign(d->mobility_values, d->mobility_values + d->scan_max_index);

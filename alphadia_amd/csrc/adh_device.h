@@ -102,6 +102,16 @@ struct DevTims {
     const double *mobility;      // [scan_max]
     int64_t n_tof, n_events, n_frames;
     int32_t cycle_len, scan_max, zeroth;
+    // Search indices built when the run is staged (adh_index_im.hip); NULL when they do not fit.
+    //   mz_lut[b]  = first TOF bin with mz >= lut_min + b / lut_inv_step        (lut_n + 1 entries)
+    //   cyc_idx[tof * cyc_cols + cb] = first event of the bin with push >= the first push of cycle
+    //   cb << cyc_shift (cyc_cols = blocks + 1; the last column is the end of the bin's cycles)
+    // They replace the two ~19-step searches over mz and the two ~10-step searches over a bin's pushes,
+    // i.e. most of the dependent-load chain of a candidate, by one load each.
+    const uint32_t *mz_lut;
+    const uint32_t *cyc_idx;
+    double lut_min, lut_inv_step;
+    int32_t lut_n, cyc_shift, cyc_cols, n_cycles;
 };
 
 // candidate record of the ion-mobility plan (processing order)

@@ -69,7 +69,7 @@ __device__ __forceinline__ void sort_keys(uint32_t *keys, int m, int lane) {
 // (Occupancy is what this latency-bound kernel lives on: 10 KB -> 20 KB per block costs 70 %.)
 namespace gather_im {
 constexpr size_t kCompactBytes = (size_t)ADH_IM_PAIR_CAP * 4 + (size_t)(ADH_IM_PAIR_CAP + 1) * 4 + 4 +  // p_lo, p_off
-                                 (size_t)ADH_IM_SORT_CAP * (4 + 2 + 1);                                  // s_key, s_int, s_pair
+                                 (size_t)ADH_IM_SORT_CAP * (4 + 2 + 1) + ADH_IM_PAIR_CAP;                // s_key, s_int, s_pair, p_win
 }
 size_t adh_gather_im_lds_bytes(const Caps &c) {
     size_t b = (size_t)(c.k + c.i) * (4 + 4 + 4);  // window m/z, tof start, tof stop
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     uint32_t *s_key = p_off + ADH_IM_PAIR_CAP + 2;            // [ADH_IM_SORT_CAP] cell << 9 | position in the list
     uint16_t *s_int = reinterpret_cast<uint16_t *>(s_key + ADH_IM_SORT_CAP);
     uint8_t *s_pair = reinterpret_cast<uint8_t *>(s_int + ADH_IM_SORT_CAP);
+    uint8_t *p_win = s_pair + ADH_IM_SORT_CAP;                // [ADH_IM_PAIR_CAP] window of the pair
 
     const int lane = threadIdx.x;
     const CandRecIM &r = plan[blockIdx.x];
@@ -180,7 +181,32 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         w_mz[caps.k + lane] = (float)off + r.precursor_mz;
     }
     __syncthreads();
-    // TOF index limits: searchsorted(mz_values, mass_range(...), "left") (bruker_jit.py:273-278)
+    // TOF index limits: searchsorted(mz_values, mass_range(...), "left") (bruker_jit.py:273-278).  The
+    // staged lookup table brackets the answer to a few bins; a result on the edge of the bracket is
+    // verified and searched again over the whole table if the bracket was wrong.
+    auto tof_lower_bound = [&](double x) -> int {
+        const int n_tof = (int)run.n_tof;
+        int a = 0, b = n_tof;
+        if (run.mz_lut) {
+            const double t = (x - run.lut_min) * run.lut_inv_step;
+            const int bk = !(t >= 0.0) ? 0 : (t >= (double)run.lut_n ? run.lut_n - 1 : (int)t);
+            const int a0 = (int)run.mz_lut[max(bk - 1, 0)], b0 = (int)run.mz_lut[min(bk + 2, run.lut_n)];
+            a = a0, b = b0;
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (run.mz[m] < x) a = m + 1; else b = m;
+            }
+            const bool ok_lo = a > a0 || a == 0 || run.mz[a - 1] < x;
+            const bool ok_hi = a < b0 || a == n_tof || !(run.mz[a] < x);
+            if (ok_lo && ok_hi) return a;
+            a = 0, b = n_tof;
+        }
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (run.mz[m] < x) a = m + 1; else b = m;
+        }
+        return a;
+    };
     for (int w = lane; w < K + I; w += ADH_WAVE) {
         const bool prec = w >= K;
         const int slot = prec ? caps.k + (w - K) : w;
@@ -188,19 +214,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         float tol = prec ? cfg.precursor_mz_tolerance : cfg.fragment_mz_tolerance;
         float t = tol * mzq;
         float q = t / 1000000.0f;
-        double lo = (double)(mzq - q), hi = (double)(mzq + q);
-        int a = 0, b = (int)run.n_tof;
-        while (a < b) {
-            int m = (a + b) >> 1;
-            if (run.mz[m] < lo) a = m + 1; else b = m;
-        }
+        const int a = tof_lower_bound((double)(mzq - q));
+        const int b = tof_lower_bound((double)(mzq + q));
         t_lo[slot] = a;
-        b = (int)run.n_tof;
-        while (a < b) {
-            int m = (a + b) >> 1;
-            if (run.mz[m] < hi) a = m + 1; else b = m;
-        }
-        t_hi[slot] = a;
+        t_hi[slot] = b > a ? b : a;
     }
     // zero the tile
     float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         }
         __syncthreads();
         const int P = w_p0[W];
-        bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
+        bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)S_max;
         const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
         const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
@@ -269,19 +286,45 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 while (w_p0[w + 1] <= p) ++w;
                 const int slot = w >= K ? caps.k + (w - K) : w;
                 const int tof = t_lo[slot] + (p - w_p0[w]);
-                const int64_t b = run.tof_indptr[tof + 1];
-                int64_t lo = run.tof_indptr[tof], hi = b;
-                while (lo < hi) {
-                    int64_t m = (lo + hi) >> 1;
-                    if (run.push[m] < push_lo) lo = m + 1; else hi = m;
-                }
-                int64_t lo2 = lo;
-                hi = b;
-                while (lo2 < hi) {
-                    int64_t m = (lo2 + hi) >> 1;
-                    if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
+                int64_t lo, lo2;
+                if (run.cyc_idx) {
+                    // the (bin, cycle block) index brackets both ends of the range; with one column per
+                    // cycle the brackets ARE the answers
+                    const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
+                    const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
+                    const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
+                    lo = row[ba];
+                    lo2 = row[bb];
+                    if (sh > 0) {
+                        int64_t hi = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
+                        while (lo < hi) {
+                            int64_t m = (lo + hi) >> 1;
+                            if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                        }
+                        hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
+                        if (lo2 < lo) lo2 = lo;
+                        while (lo2 < hi) {
+                            int64_t m = (lo2 + hi) >> 1;
+                            if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
+                        }
+                    }
+                } else {
+                    const int64_t b = run.tof_indptr[tof + 1];
+                    int64_t hi = b;
+                    lo = run.tof_indptr[tof];
+                    while (lo < hi) {
+                        int64_t m = (lo + hi) >> 1;
+                        if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                    }
+                    lo2 = lo;
+                    hi = b;
+                    while (lo2 < hi) {
+                        int64_t m = (lo2 + hi) >> 1;
+                        if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
+                    }
                 }
                 p_lo[p] = (uint32_t)lo;
+                p_win[p] = (uint8_t)w;
                 p_off[p + 1] = (uint32_t)(lo2 - lo);
             }
             __syncthreads();
@@ -314,33 +357,39 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             const int pa0 = w_p0[w0], pb0 = w_p0[w1];
             const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
             int m = 0;  // survivors in the list (wave-uniform)
-            for (uint32_t e0 = r0; e0 < r1; e0 += ADH_WAVE) {
-                const uint32_t e = e0 + lane;
-                bool ok = false;
-                uint32_t cell = 0, pair = 0;
-                uint16_t ni = 0;
-                if (e < r1) {
+            // four raw events per lane and step: the four push loads overlap; the few events inside the
+            // scan range (~3 %) then look up their quadrupole row
+            constexpr int U = 4;
+            for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
+                bool ok[U];
+                uint32_t cell[U], pair[U];
+                uint16_t ni[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+                    const bool in = eu < r1;
+                    const uint32_t e = in ? eu : r0;
                     int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
                     while (pb - pa > 1) {
                         const int mid = (pa + pb) >> 1;
                         if (p_off[mid] <= e) pa = mid; else pb = mid;
                     }
-                    int w = w0;
-                    while (w_p0[w + 1] <= pa) ++w;
+                    const int w = (int)p_win[pa];
                     const bool prec = w >= K;
-                    const int slot = prec ? caps.k + (w - K) : w;
                     const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                     const uint32_t pv = run.push[idx];
                     // (exact quotients without the integer-division sequence: float64 estimate, one fix-up)
                     uint32_t fq = (uint32_t)((double)pv * inv_smax);
                     if (pv - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
                     const int frame = (int)fq, scan = (int)(pv - fq * (uint32_t)S_max);
-                    if (scan >= r.scan_start && scan < r.scan_stop) {
+                    ok[u] = false;
+                    cell[u] = 0u;
+                    ni[u] = 0;
+                    if (in && scan >= r.scan_start && scan < r.scan_stop) {  // ~3 % of the events of the bins
                         uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
                         if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
-                        const int cyc = (int)cq;
-                        const int f = cyc - c0;
-                        const int crow = (frame - z - cyc * L) * S_max + scan;
+                        const int f = (int)cq - c0;
+                        const int crow = (frame - z - (int)cq * L) * S_max + scan;
                         const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
                         if (q_lo <= run.cycle[2 * crow + 1] && q_hi >= run.cycle[2 * crow]) {
                             const int n_o = prec ? Op : O;
@@ -350,25 +399,28 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                             while (o < n_o && (int)obs[o] != pc) ++o;
                             if (o < n_o) {  // (always: the plan lists every overlapping row)
                                 const int sc = scan - r.scan_start;
-                                cell = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
-                                            : (uint32_t)(((w * O + o) * S + sc) * F + f);
-                                pair = (uint32_t)pa;
-                                ni = run.inten[idx];
-                                ok = true;
+                                cell[u] = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
+                                               : (uint32_t)(((w * O + o) * S + sc) * F + f);
+                                ni[u] = run.inten[idx];
+                                ok[u] = true;
                             }
                         }
                     }
+                    pair[u] = (uint32_t)pa;
                 }
-                const unsigned long long mask = __ballot(ok);
-                if (ok) {
-                    const int pos = m + __popcll(mask & lt);
-                    if (pos < ADH_IM_SORT_CAP) {
-                        s_key[pos] = (cell << 9) | (uint32_t)pos;
-                        s_pair[pos] = (uint8_t)pair;
-                        s_int[pos] = ni;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long mask = __ballot(ok[u]);
+                    if (ok[u]) {
+                        const int pos = m + __popcll(mask & lt);
+                        if (pos < ADH_IM_SORT_CAP) {
+                            s_key[pos] = (cell[u] << 9) | (uint32_t)pos;
+                            s_pair[pos] = (uint8_t)pair[u];
+                            s_int[pos] = ni[u];
+                        }
                     }
+                    m += __popcll(mask);
                 }
-                m += __popcll(mask);
             }
             if (m > ADH_IM_SORT_CAP) {
                 over = true;

@@ -505,6 +505,30 @@ def test_timstof_larger_case_all_configs(ctx, oracle_lib):
         assert got["valid"].sum() > 100
 
 
+def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
+    """The staged search indices (m/z lookup table, (TOF bin, cycle) table - one column per cycle or per
+    block of cycles) and the two forms of the tiles (sparse entry lists, dense tiles) are different ways
+    to the same numbers: every output table must come out bit for bit the same."""
+    from alphadia_amd.scoring import assemble_candidates
+
+    case = syn.make_timstof_case(n_precursors=300, n_cycles=70, config_id=45, per_precursor=2, n_ms2_frames=5,
+                                 windows_per_frame=2, scan_max_index=64, planted_fraction=0.6)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(top_k_isotopes=3, quant_all=True, experimental_xic=True))
+    base = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
+    base = {k: np.array(v, copy=True) for k, v in base.items()}
+    assert base["valid"].sum() > 100
+    for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8")):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
+            for name, ref in base.items():
+                assert np.array_equal(np.asarray(got[name]), ref, equal_nan=ref.dtype.kind == "f"), (env, name)
+    ctx.stage_run(case.dia, force=True)  # (leave the handle with the default indices)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_IM", "6")))))
 def test_timstof_randomized(ctx, oracle_lib, seed):
     """Differential test on the ion-mobility layout: random geometry and settings, HIP vs oracle."""
