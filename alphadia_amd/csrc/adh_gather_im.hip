@@ -347,137 +347,56 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             (uint32_t)((adh_im_touch_off(r.k_cap, O, S, F, I, Op) - adh_scratch_frag_off(r.k_cap)) / sizeof(ImEntry));
         uint32_t out_n = 0, n_fe = 0;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        int w0 = 0;
-        while (w0 < W && !over) {
-            const bool pgroup = w0 >= K;
-            int w1 = pgroup ? W : w0 + 1;
-            if (!pgroup)
-                while (w1 < K && p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]] <= ADH_IM_SORT_CAP) ++w1;
-            if (pgroup) n_fe = out_n;
-            const int pa0 = w_p0[w0], pb0 = w_p0[w1];
-            const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
-            int m = 0;  // survivors in the list (wave-uniform)
-            // four raw events per lane and step: the four push loads overlap; the few events inside the
-            // scan range (~3 %) then look up their quadrupole row
-            constexpr int U = 4;
-            for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
-                bool ok[U];
-                uint32_t cell[U], pair[U];
-                uint16_t ni[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-                    const bool in = eu < r1;
-                    const uint32_t e = in ? eu : r0;
-                    int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
-                    while (pb - pa > 1) {
-                        const int mid = (pa + pb) >> 1;
-                        if (p_off[mid] <= e) pa = mid; else pb = mid;
-                    }
-                    const int w = (int)p_win[pa];
-                    const bool prec = w >= K;
-                    const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
-                    const uint32_t pv = run.push[idx];
-                    // (exact quotients without the integer-division sequence: float64 estimate, one fix-up)
-                    uint32_t fq = (uint32_t)((double)pv * inv_smax);
-                    if (pv - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
-                    const int frame = (int)fq, scan = (int)(pv - fq * (uint32_t)S_max);
-                    ok[u] = false;
-                    cell[u] = 0u;
-                    ni[u] = 0;
-                    if (in && scan >= r.scan_start && scan < r.scan_stop) {  // ~3 % of the events of the bins
-                        uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
-                        if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
-                        const int f = (int)cq - c0;
-                        const int crow = (frame - z - (int)cq * L) * S_max + scan;
-                        const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
-                        if (q_lo <= run.cycle[2 * crow + 1] && q_hi >= run.cycle[2 * crow]) {
-                            const int n_o = prec ? Op : O;
-                            const uint16_t *obs = prec ? r.ms1_obs : r.obs;
-                            const int pc = run.dpc[crow];
-                            int o = 0;
-                            while (o < n_o && (int)obs[o] != pc) ++o;
-                            if (o < n_o) {  // (always: the plan lists every overlapping row)
-                                const int sc = scan - r.scan_start;
-                                cell[u] = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
-                                               : (uint32_t)(((w * O + o) * S + sc) * F + f);
-                                ni[u] = run.inten[idx];
-                                ok[u] = true;
-                            }
-                        }
-                    }
-                    pair[u] = (uint32_t)pa;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned long long mask = __ballot(ok[u]);
-                    if (ok[u]) {
-                        const int pos = m + __popcll(mask & lt);
-                        if (pos < ADH_IM_SORT_CAP) {
-                            s_key[pos] = (cell[u] << 9) | (uint32_t)pos;
-                            s_pair[pos] = (uint8_t)pair[u];
-                            s_int[pos] = ni[u];
-                        }
-                    }
-                    m += __popcll(mask);
-                }
-            }
-            if (m > ADH_IM_SORT_CAP) {
-                over = true;
-                break;
-            }
-            hits += (uint32_t)m;
+        int m = 0;  // events in the list (wave-uniform)
+
+        // sort the list by (cell, position) and fold it: one lane per output cell adds up the events of the
+        // cell in list order.  A fragment cell is one tile cell; a precursor cell (scan, cycle, isotope)
+        // collapses its MS1 rows (candidate.py:248-269: sum of the intensities, mean of the non-zero m/z).
+        auto flush = [&]() {
             __syncthreads();
-            if (m > 1) {  // sort the keys: in registers, element r * 64 + lane
+            if (m > 1) {  // in registers, element r * 64 + lane
                 if (m <= ADH_WAVE) sort_keys<1>(s_key, m, lane);
                 else if (m <= 2 * ADH_WAVE) sort_keys<2>(s_key, m, lane);
                 else if (m <= 4 * ADH_WAVE) sort_keys<4>(s_key, m, lane);
                 else sort_keys<8>(s_key, m, lane);
             }
             __syncthreads();
-            // one lane per output cell folds the events of the cell in list order
+            auto group_of = [&](uint32_t cell) -> uint32_t {
+                return cell < (uint32_t)n_fc ? cell : (uint32_t)n_fc + (cell - (uint32_t)n_fc) / (uint32_t)Op;
+            };
             for (int e0 = 0; e0 < m; e0 += ADH_WAVE) {
                 const int e = e0 + lane;
-                bool owner = false;
+                bool owner = false, frag = false;
                 ImEntry en;
                 en.cell = 0u, en.x = 0.0f, en.y = 0.0f;
                 if (e < m) {
                     const uint32_t cell = s_key[e] >> 9;
-                    if (!pgroup) {
-                        owner = e == 0 || (s_key[e - 1] >> 9) != cell;
-                        if (owner) {
-                            const int w = (int)cell / (O * S * F);  // TOF bin of an event: first bin of the window + pair - first pair
-                            const int tof0 = t_lo[w] - w_p0[w];
+                    const uint32_t gid = group_of(cell);
+                    owner = e == 0 || group_of(s_key[e - 1] >> 9) != gid;
+                    frag = cell < (uint32_t)n_fc;
+                    if (owner) {
+                        // TOF bin of an event: first bin of its window + pair - first pair of the window
+                        const int w = frag ? (int)cell / (O * S * F) : K + (int)((gid - (uint32_t)n_fc) % (uint32_t)I);
+                        const int tof0 = t_lo[frag ? w : caps.k + (w - K)] - w_p0[w];
+                        float acc = 0.0f, last_y = 0.0f;
+                        double sum = 0.0;
+                        int count = 0;
+                        int q = e;
+                        while (q < m && group_of(s_key[q] >> 9) == gid) {
+                            const uint32_t c = s_key[q] >> 9;
                             float vx = 0.0f, vy = 0.0f;
-                            for (int q = e; q < m && (s_key[q] >> 9) == cell; ++q) {
+                            for (; q < m && (s_key[q] >> 9) == c; ++q) {
                                 const int pos = (int)(s_key[q] & 511u);
                                 fold(vx, vy, (int64_t)s_int[pos], run.mz[tof0 + (int)s_pair[pos]]);
                             }
-                            en.cell = cell, en.x = vx, en.y = vy;
+                            acc += vx;
+                            sum += (double)vy;
+                            count += vy > 0.0f;
+                            last_y = vy;
                         }
-                    } else {
-                        const uint32_t gid = (cell - (uint32_t)n_fc) / (uint32_t)Op;  // (scan, cycle, isotope)
-                        owner = e == 0 || ((s_key[e - 1] >> 9) - (uint32_t)n_fc) / (uint32_t)Op != gid;
-                        if (owner) {
-                            const int w = K + (int)(gid % (uint32_t)I);
-                            const int tof0 = t_lo[caps.k + (w - K)] - w_p0[w];
-                            float acc = 0.0f;  // candidate.py:248-269: sum of the intensities, mean of the non-zero m/z
-                            double sum = 0.0;
-                            int count = 0;
-                            int q = e;
-                            while (q < m && ((s_key[q] >> 9) - (uint32_t)n_fc) / (uint32_t)Op == gid) {
-                                const uint32_t c = s_key[q] >> 9;
-                                float vx = 0.0f, vy = 0.0f;
-                                for (; q < m && (s_key[q] >> 9) == c; ++q) {
-                                    const int pos = (int)(s_key[q] & 511u);
-                                    fold(vx, vy, (int64_t)s_int[pos], run.mz[tof0 + (int)s_pair[pos]]);
-                                }
-                                acc += vx;
-                                sum += (double)vy;
-                                count += vy > 0.0f;
-                            }
-                            en.cell = gid, en.x = acc, en.y = (float)(sum / ((double)count + 1e-6));
-                        }
+                        en.cell = frag ? cell : gid - (uint32_t)n_fc;
+                        en.x = acc;  // (a fragment cell: 0 + vx)
+                        en.y = frag ? last_y : (float)(sum / ((double)count + 1e-6));
                     }
                 }
                 const unsigned long long mask = __ballot(owner);
@@ -486,11 +405,126 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     if (at < out_cap) out_list[at] = en;
                 }
                 out_n += (uint32_t)__popcll(mask);
+                n_fe += (uint32_t)__popcll(__ballot(owner && frag));
             }
             __syncthreads();
             if (out_n > out_cap) over = true;
+            m = 0;
+        };
+
+        int w0 = 0;
+        while (w0 < W && !over) {
+            // the next batch of windows: as many as are certain to fit the free part of the list (every raw
+            // event might survive); the isotope windows go together, whatever their size
+            const bool pg = w0 >= K;
+            int w1 = pg ? W : w0 + 1;
+            if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > ADH_IM_SORT_CAP) {
+                flush();
+                if (over) break;
+            }
+            if (!pg)
+                while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= ADH_IM_SORT_CAP) ++w1;
+            const int pa0 = w_p0[w0], pb0 = w_p0[w1];
+            const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
+            if (r1 - r0 > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
+                over = true;
+                break;
+            }
+            // ---- stage 1: the raw events, eight per lane and step (eight independent push loads in flight);
+            // those inside the scan range (~3 %) queue up behind the list: (push, raw number, pair)
+            int nq = 0;
+            constexpr int U = 8;
+            for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
+                uint32_t pv[U];
+                int pa_u[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+                    const uint32_t e = eu < r1 ? eu : r0;
+                    int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
+                    while (pb - pa > 1) {
+                        const int mid = (pa + pb) >> 1;
+                        if (p_off[mid] <= e) pa = mid; else pb = mid;
+                    }
+                    pa_u[u] = pa;
+                    pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+                    // (exact quotient without the integer-division sequence: float64 estimate, one fix-up)
+                    uint32_t fq = (uint32_t)((double)pv[u] * inv_smax);
+                    if (pv[u] - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
+                    const int scan = (int)(pv[u] - fq * (uint32_t)S_max);
+                    const bool pass = eu < r1 && scan >= r.scan_start && scan < r.scan_stop;
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) {
+                        const int at = m + nq + __popcll(mask & lt);
+                        if (at < ADH_IM_SORT_CAP) {
+                            s_key[at] = pv[u];
+                            s_int[at] = (uint16_t)(eu - r0);
+                            s_pair[at] = (uint8_t)pa_u[u];
+                        }
+                    }
+                    nq += __popcll(mask);
+                }
+            }
+            if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
+                over = true;
+                break;
+            }
+            __syncthreads();
+            // ---- stage 2: the queued events look up their quadrupole row, MS1 / MS2 observation and
+            // intensity (independent loads) and the survivors take their place in the list, in stream order
+            const int q_base = m;
+            for (int q0 = 0; q0 < nq; q0 += ADH_WAVE) {
+                const int qi = q0 + lane;
+                bool ok = false;
+                uint32_t cell = 0u, pair = 0u;
+                uint16_t ni = 0;
+                if (qi < nq) {
+                    const uint32_t pvq = s_key[q_base + qi];
+                    const int pa = (int)s_pair[q_base + qi];
+                    const uint32_t e = r0 + (uint32_t)s_int[q_base + qi];
+                    const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
+                    const int w = (int)p_win[pa];
+                    const bool prec = w >= K;
+                    uint32_t fq = (uint32_t)((double)pvq * inv_smax);
+                    if (pvq - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
+                    const int frame = (int)fq, scan = (int)(pvq - fq * (uint32_t)S_max);
+                    uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
+                    if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
+                    const int f = (int)cq - c0;
+                    const int crow = (frame - z - (int)cq * L) * S_max + scan;
+                    const double cy0 = run.cycle[2 * crow], cy1 = run.cycle[2 * crow + 1];
+                    const int pc = run.dpc[crow];
+                    ni = run.inten[idx];
+                    const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
+                    const int n_o = prec ? Op : O;
+                    const uint16_t *obs = prec ? r.ms1_obs : r.obs;
+                    int o = 0;
+                    while (o < n_o && (int)obs[o] != pc) ++o;
+                    const int sc = scan - r.scan_start;
+                    ok = q_lo <= cy1 && q_hi >= cy0 && o < n_o;  // (o < n_o always: the plan lists every overlapping row)
+                    cell = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
+                                : (uint32_t)(((w * O + o) * S + sc) * F + f);
+                    pair = (uint32_t)pa;
+                }
+                __syncthreads();  // the queue slots of this step are in registers: the list may grow over them
+                const unsigned long long mask = __ballot(ok);
+                if (ok) {
+                    const int pos = m + __popcll(mask & lt);
+                    s_key[pos] = (cell << 9) | (uint32_t)pos;
+                    s_pair[pos] = (uint8_t)pair;
+                    s_int[pos] = ni;
+                }
+                m += __popcll(mask);
+                hits += (uint32_t)__popcll(mask);
+            }
+            __syncthreads();
             w0 = w1;
         }
+        if (!over && m > 0) flush();
         dense = over;  // too many events for the lists: this candidate takes the dense path below
         if (!dense) {
             if (lane == 0) {
