@@ -132,18 +132,14 @@ static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 
 // ion-mobility scratch block: header (32 B; [0] K, [1] hits, [2] entry count, [3] mode, [4] precursor
 // entry count), selected fragments (k_cap x 32 B), fragment cells float2[k_cap][O][S][F], precursor cells
-// float2[I][Op][S][F], list of the touched fragment cells.  Ion-mobility tiles are ~1 % full, so the
-// gather kernel normally never materialises the tiles (mode ADH_IM_MODE_COMPACT): the non-zero cells
-// leave as (cell, intensity, m/z) entries sorted by cell - the reference's summation order - written
-// where the tiles would be: header[2] fragment entries (cell = ((k * O + o) * S + scan) * F + cycle),
-// then header[4] precursor entries with the MS1 rows already collapsed
-// (cell = (scan * F + cycle) * I + isotope).  A candidate with more than ADH_IM_SORT_CAP events in one
-// window (or in its isotope windows together), or more than ADH_IM_PAIR_CAP TOF bins in all windows,
-// falls back to the dense tiles (zero fill + scatter) with a list of the cells it touched (mode
-// ADH_IM_MODE_DENSE; header[2] = ADH_IM_TOUCH_OVERFLOW when even that list is full and the feature
-// kernel has to stream the tile).
-#define ADH_IM_TOUCH_CAP 1024
-#define ADH_IM_TOUCH_OVERFLOW 0xFFFFFFFFu
+// float2[I][Op][S][F].  Ion-mobility tiles are ~1 % full, so the gather kernel normally never
+// materialises the tiles (mode ADH_IM_MODE_COMPACT): the non-zero cells leave as (cell, intensity, m/z)
+// entries sorted by cell - the reference's summation order - written where the tiles would be:
+// header[2] fragment entries (cell = ((k * O + o) * S + scan) * F + cycle), then header[4] precursor
+// entries with the MS1 rows already collapsed (cell = (scan * F + cycle) * I + isotope).  A candidate
+// with more than ADH_IM_SORT_CAP events in one window (or in its isotope windows together), more than
+// ADH_IM_PAIR_CAP TOF bins in all windows, or more entries than fit where the tiles would be (a small
+// tile full of signal) gets the dense tiles (zero fill + scatter; mode ADH_IM_MODE_DENSE).
 #define ADH_IM_SORT_CAP 512
 #define ADH_IM_PAIR_CAP 256
 #define ADH_IM_MODE_DENSE 0u
@@ -160,7 +156,20 @@ __host__ __device__ inline uint64_t adh_im_touch_off(uint32_t k_cap, int O, int 
     return (b + 31) / 32 * 32;
 }
 __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
-    return (adh_im_touch_off(k_cap, O, S, F, I, Op) + (uint64_t)ADH_IM_TOUCH_CAP * 4 + 31) / 32 * 32;
+    return adh_im_touch_off(k_cap, O, S, F, I, Op);
+}
+
+// Barrier of a ONE-wavefront block whose lanes talk through LDS.  A wavefront issues its LDS
+// instructions in order and the LDS unit completes them in order, so a read that follows a write in
+// program order sees the write, whichever lane made it: nothing has to be waited for.  What is
+// needed is that the compiler keeps the order - the two wavefront-scope fences (no instruction) and the
+// scheduling barrier do that.  __syncthreads() would add s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier:
+// every global load in flight (prefetches!) and every LDS access would have to land at each of the
+// hundreds of hand-over points of a candidate.  NOT for data handed over through global memory.
+__device__ __forceinline__ void adh_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 typedef adh_output_t DevOut;
@@ -178,6 +187,7 @@ struct Caps {
     // adh_debug_get_dense only (stop_phase == ADH_DEBUG_DENSE): explicit quadrupole range of the
     // query instead of the one derived from the precursor isotopes; no "<= 3 fragments" exit
     float dbg_q_lo, dbg_q_hi;
+    int dbg_drop_dense;  // developer ablation (ADH_DEBUG_IM_DROP_DENSE): ion-mobility candidates that overflow the sparse lists are dropped
 };
 #define ADH_DEBUG_DENSE 9
 

@@ -114,7 +114,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // correlation reuse the same bytes later (an extra 2 KB of LDS per wavefront cost 22 % of the
     // kernel's throughput in resident waves)
     __shared__ __align__(16) unsigned char pool[ADH_IM_STATIC_LDS];
-    __shared__ int pl_start[ADH_WAVE];  // tile pass: first list entry of every (fragment, observation) plane
     double *const l_ti = reinterpret_cast<double *>(pool);
     double *const l_tm = l_ti + ADH_WAVE;
     double *const l_w = l_tm + ADH_WAVE;
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         if (lane < O) obs[lane] = r.obs[lane];
         if (lane < ADH_NUM_FEATURES) featv[lane] = 0.0f;
     }
-    __syncthreads();
+    adh_wave_sync();
 
     // ---- quadrupole transfer function per (isotope, observation, scan) (quadrupole.py:261-301)
     for (int c = lane; c < I * O * S; c += ADH_WAVE) {
@@ -227,13 +226,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         double x = (double)iso_mz[i];
         qtf[c] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
     }
-    __syncthreads();
+    adh_wave_sync();
     for (int c = lane; c < O * S; c += ADH_WAVE) {
         double sum = 0;
         for (int i = 0; i < I; ++i) sum += qtf[i * O * S + c];
         qmask[c] = (float)(sum / (double)I);  // candidate.py:287-289
     }
-    __syncthreads();
+    adh_wave_sync();
     // (the qtf mask of candidate.py:290 is applied while the fragment tile is streamed)
     double *const hp = D + lay.d_pi();
     double *const omzp = hp + Ic;
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 c_y[e] = en.y;
                 c_w[e] = exp(-0.1 * sqrt(ds * ds + df * df));
             }
-            __syncthreads();
+            adh_wave_sync();
             if (base + cnt < n_pe) {  // never cut the isotopes of a cell in two: stop at the last cell start
                 const int e = cnt - ADH_WAVE + lane;
                 const unsigned long long st = __ballot((c_cell[e] >> 4) != (c_cell[e - 1] >> 4));
@@ -290,24 +289,36 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 }
             }
             if (lane < 5 * I) {
-                for (int e = 0; e < cnt; ++e) {
-                    const uint32_t cp = c_cell[e];
-                    if ((int)(cp & 15u) != iso) continue;
-                    if (role == 0) {
-                        const int sc = (int)(cp >> 16);
-                        if (sc != cur_sc) {
-                            tot += part;
-                            part = 0.0f;
-                            cur_sc = sc;
-                        }
-                        part += c_x[e];
-                    } else if ((role <= 2 ? c_x[e] : c_y[e]) > 0.0f) {
-                        const double w = c_w[e];
-                        acc += role == 1 ? (double)c_x[e] * w : (role == 3 ? (double)c_y[e] * w : w);
+                // four entries per step, all loads first, no branch: the walk is a chain of LDS latencies
+                // otherwise.  (Adding 0.0 leaves a sum as it is.)
+                for (int e0 = 0; e0 < cnt; e0 += 4) {
+                    uint32_t cp[4];
+                    float xs[4], ys[4];
+                    double ws[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = min(e0 + u, cnt - 1);
+                        cp[u] = c_cell[e];
+                        xs[u] = c_x[e];
+                        ys[u] = c_y[e];
+                        ws[u] = c_w[e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool mine = e0 + u < cnt && (int)(cp[u] & 15u) == iso;
+                        const int sc = (int)(cp[u] >> 16);
+                        const bool fresh = mine && sc != cur_sc;  // role 0: per-scan sums, added up in scan order
+                        tot += fresh ? part : 0.0f;
+                        part = fresh ? 0.0f : part;
+                        cur_sc = fresh ? sc : cur_sc;
+                        part += mine ? xs[u] : 0.0f;
+                        const float flag = role <= 2 ? xs[u] : ys[u];
+                        const double term = role == 1 ? (double)xs[u] * ws[u] : (role == 3 ? (double)ys[u] * ws[u] : ws[u]);
+                        acc += mine && flag > 0.0f ? term : 0.0;
                     }
                 }
             }
-            __syncthreads();
+            adh_wave_sync();
             base += cnt;
         }
         const int il = lane < I ? lane : 0;
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         tpl[c] = (float)acc;
     }
     }
-    __syncthreads();
+    adh_wave_sync();
 
     if (caps.stop_phase == 1) return;  // developer ablation switches (ADH_DEBUG_IM)
     // ---- observation importance (quadrupole.py:327-335), fragment presence (candidate.py:319-329)
@@ -345,13 +356,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         for (int f = 0; f < F; ++f) sf += tpl[c * F + f];
         work_b[c] = sf;
     }
-    __syncthreads();
+    adh_wave_sync();
     if (lane < O) {
         float so = 0;
         for (int sc = 0; sc < S; ++sc) so += work_b[lane * S + sc];
         tsum[lane] = so;
     }
-    __syncthreads();
+    adh_wave_sync();
     // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
     // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
     // over the fragment tile
@@ -378,13 +389,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 l_ti[pos] = (double)sc * (double)v;
                 l_tm[pos] = (double)f * (double)v;
             }
-            __syncthreads();
+            adh_wave_sync();
             const int n_ent = __popcll(mask);
             if (lane < 3) {
                 const double *src = lane == 0 ? l_w : (lane == 1 ? l_ti : l_tm);
                 for (int e = 0; e < n_ent; ++e) acc += src[e];
             }
-            __syncthreads();
+            adh_wave_sync();
         }
         const double isum = __shfl(acc, 0), ssum = __shfl(acc, 1), fsum = __shfl(acc, 2);
         if (lane == 0) {
@@ -394,100 +405,34 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     for (int c = lane; c < K0 * O * F; c += ADH_WAVE) ffp_u[c] = 0.0f;
     for (int c = lane; c < K0 * O * S; c += ADH_WAVE) fsp_u[c] = 0.0f;
-    __syncthreads();
+    adh_wave_sync();
     if (caps.stop_phase == 2) return;
-    // ---- ONE pass over the fragment tile [k][o][s][f] (kept in the HBM scratch block):
+    // ---- ONE pass over the fragment tile [k][o][s][f]:
     //   scan profile  fsp[s] = sum_f x[s][f]            (scoring/utils.py:56-66 input)
     //   frame profile ffp[f] = sum_s x[s][f]            (scoring/utils.py:26-53 input)
     //   weighted centre means of both channels         (features_utils.py:9-37)
-    // Ion-mobility tiles are sparse, and adding a zero leaves every one of these sums unchanged,
-    // so only non-zero cells do work.  The 64 lanes read 64 consecutive cells (coalesced) and
-    // compact the non-zero ones IN ORDER into a small LDS list.  Whenever 64 entries are waiting,
-    // every lane computes the weight exp(-0.1 * distance to the template centre) and the float64
-    // products of one entry, and one lane per (fragment, observation) plane then folds its entries
-    // sequentially, which keeps the reference's summation order (s outer, f inner).
+    // Every (fragment, observation) plane has its own lane, which folds the plane's cells in the
+    // reference's order (scan outer, cycle inner) with the running sums in registers.  A round stages
+    // QT = 192 / planes cells of every plane in the chunk lists (three per lane: the weights
+    // exp(-0.1 * distance to the template centre) are computed by all 64 lanes, and the three loads of the
+    // next round are in flight meanwhile); lane l then folds the QT staged cells of plane l.  The planes
+    // advance in parallel, so a signal-rich candidate costs (cells of its fullest plane) / QT rounds.
+    // Ion-mobility tiles are sparse and adding a zero leaves every one of these sums unchanged: normally
+    // the gather kernel delivers the non-zero cells only, as (cell, intensity, m/z) entries sorted by cell,
+    // and a plane's cells are a range of that list; a candidate whose tile had to be materialised
+    // (ADH_IM_MODE_DENSE) walks all cells of its planes the same way.
     {
         double *const acc_vi = ohe_u, *const acc_vm = omz_u;   // value sums; turned into the means below
         double *const acc_wi = D + lay.d_accw(), *const acc_wm = acc_wi + Kc * Oc;
-        for (int c = lane; c < K0 * O; c += ADH_WAVE) {
-            acc_vi[c] = 0.0;
-            acc_vm[c] = 0.0;
-            acc_wi[c] = 0.0;
-            acc_wm[c] = 0.0;
-        }
-        __syncthreads();
-        const int n_cells = K0 * OSF;
-        // fold the first `count` list entries: weights and products by all lanes, then one lane per
-        // plane adds up its entries in list (= cell) order
-        auto flush = [&](int count) {
-            if (lane < count) {
-                const int ci = l_cell[lane];
-                const float rx = l_rx[lane], ry = l_ry[lane];
-                const int ko = ci / SF, rem = ci - ko * SF;
-                const int sc = rem / F, f = rem - sc * F;
-                const int o = ko % O;
-                const float v = rx * qmask[o * S + sc];  // candidate.py:290
-                const double ds = (double)sc - esc[o], df = (double)f - efc[o];
-                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                l_v[lane] = v;
-                l_w[lane] = w;
-                l_ti[lane] = (double)v * w;
-                l_tm[lane] = (double)ry * w;
-            }
-            __syncthreads();
-            // the list is sorted by cell, so the entries of a plane are a contiguous run: mark where
-            // every plane's run starts, then one lane per plane folds its own run only
-            const int ko_lo = l_cell[0] / SF, ko_hi = l_cell[count - 1] / SF;
-            for (int p = lane; p <= ko_hi - ko_lo; p += ADH_WAVE) pl_start[p] = -1;
-            __syncthreads();
-            if (lane < count) {
-                const int ko = l_cell[lane] / SF;
-                if (lane == 0 || l_cell[lane - 1] / SF != ko) pl_start[ko - ko_lo] = lane;
-            }
-            __syncthreads();
-            for (int ko = ko_lo + lane; ko <= ko_hi; ko += ADH_WAVE) {
-                int e = pl_start[ko - ko_lo];
-                if (e < 0) continue;
-                double vi = acc_vi[ko], wi = acc_wi[ko], vm = acc_vm[ko], wm = acc_wm[ko];
-                for (; e < count; ++e) {
-                    const int rem = l_cell[e] - ko * SF;
-                    if (rem >= SF) break;
-                    const int sc = rem / F, f = rem - sc * F;
-                    const float v = l_v[e];
-                    fsp_u[ko * S + sc] += v;
-                    ffp_u[ko * F + f] += v;
-                    if (v > 0.0f) {
-                        vi += l_ti[e];
-                        wi += l_w[e];
-                    }
-                    if (l_tm[e] > 0.0) {  // m/z channel of the cell is > 0
-                        vm += l_tm[e];
-                        wm += l_w[e];
-                    }
-                }
-                acc_vi[ko] = vi;
-                acc_wi[ko] = wi;
-                acc_vm[ko] = vm;
-                acc_wm[ko] = wm;
-            }
-            __syncthreads();
-        };
-        int n_list = 0;        // entries waiting in the list (wave-uniform)
+        int *const pl_beg = fpeak;                              // [K0 * O], idle until the peak search
+        int *const pl_end = reinterpret_cast<int *>(rowsum);    // [K0 * O], idle until the pass is over
+        const int n_pl = K0 * O;
         if (compact) {
-            // ---- the gather kernel kept the fragment tile in sparse form: the non-zero cells as
-            // (cell, intensity, m/z) entries sorted by cell, i.e. in the reference's summation order
-            // Every (fragment, observation) plane has its own lane, which folds the plane's entries in list
-            // order with the running sums in registers.  A round stages q = 64 / planes entries of every
-            // plane at once (weights and products by all 64 lanes), so the planes advance in parallel
-            // and a signal-rich candidate (thousands of entries) costs max-plane / q rounds.
-            int *const pl_beg = fpeak;                              // [K0 * O], idle until the peak search
-            int *const pl_end = reinterpret_cast<int *>(rowsum);    // [K0 * O], idle until the pass is over
-            const int n_pl = K0 * O;
             for (int c = lane; c < n_pl; c += ADH_WAVE) {
                 pl_beg[c] = 0;
                 pl_end[c] = 0;
             }
-            __syncthreads();
+            adh_wave_sync();
             for (int e = lane; e < n_fe; e += ADH_WAVE) {
                 const int pc = (int)entries[e].cell / SF;
                 const int pp = e > 0 ? (int)entries[e - 1].cell / SF : -1;
@@ -497,187 +442,123 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 }
                 if (e == n_fe - 1) pl_end[pc] = n_fe;
             }
-            __syncthreads();
-            for (int pbase = 0; pbase < n_pl; pbase += ADH_WAVE) {
-                const int np = min(ADH_WAVE, n_pl - pbase);
-                const int q = ADH_WAVE / np;
-                const int pslot = lane / q, j = lane - pslot * q;
-                const bool active = pslot < np;
-                const int p = pbase + pslot, o = p % O;
-                const int beg = active ? pl_beg[p] : 0, end = active ? pl_end[p] : 0;
-                int R = (end - beg + q - 1) / q;
-                for (int off = 32; off > 0; off >>= 1) R = max(R, __shfl_xor(R, off));
-                double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
-                float fs = 0.0f;
-                int cur_sc = -1;
-                ImEntry nxt;
-                nxt.cell = 0u, nxt.x = 0.0f, nxt.y = 0.0f;
-                if (active && beg + j < end) nxt = entries[beg + j];
-                for (int rr = 0; rr < R; ++rr) {
-                    const int e = beg + rr * q + j;
-                    const ImEntry en = nxt;
-                    if (active && e + q < end) nxt = entries[e + q];
-                    if (active && e < end) {
-                        const int rem = (int)en.cell - p * SF;
-                        const int sc = rem / F, f = rem - sc * F;
-                        const float v = en.x * qmask[o * S + sc];  // candidate.py:290
-                        const double ds = (double)sc - esc[o], df = (double)f - efc[o];
-                        const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                        l_cell[lane] = sc << 16 | f;  // (the serial fold below must not divide)
-                        l_v[lane] = v;
-                        l_w[lane] = w;
-                        l_ti[lane] = (double)v * w;
-                        l_tm[lane] = (double)en.y * w;
-                    }
-                    __syncthreads();
-                    if (active && j == 0) {
-                        const int cnt = min(q, end - (beg + rr * q));
-                        for (int t = 0; t < cnt; ++t) {
-                            const int at = lane + t;
-                            const int sc = l_cell[at] >> 16, f = l_cell[at] & 0xFFFF;
-                            const float v = l_v[at];
-                            if (sc != cur_sc) {  // the cells of a scan are consecutive: its sum is complete
-                                if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
-                                fs = 0.0f;
-                                cur_sc = sc;
-                            }
-                            fs += v;
-                            ffp_u[p * F + f] += v;
-                            if (v > 0.0f) {
-                                vi += l_ti[at];
-                                wi += l_w[at];
-                            }
-                            if (l_tm[at] > 0.0) {  // m/z channel of the cell is > 0
-                                vm += l_tm[at];
-                                wm += l_w[at];
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-                if (active && j == 0) {
-                    if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
-                    acc_vi[p] = vi;
-                    acc_wi[p] = wi;
-                    acc_vm[p] = vm;
-                    acc_wm[p] = wm;
-                }
-            }
-            __syncthreads();
         } else {
-        const uint32_t n_touch = header[2];
-        int n_p_need = ADH_WAVE;
-        while (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need < (int)n_touch) n_p_need <<= 1;
-        const int sorted_cap = lay.f_work_end();  // floats of work_a + work_b
-        if (n_touch != ADH_IM_TOUCH_OVERFLOW && n_p_need <= sorted_cap) {
-            // ---- the gather kernel listed the cells it touched (<= ADH_IM_TOUCH_CAP, ~1 % of the
-            // tile): sort the list (cell order = the reference's summation order) and visit those
-            int *const sorted = reinterpret_cast<int *>(work_a);  // work_a + work_b are idle here (>= 1024 + ints)
-            const uint32_t *touched = reinterpret_cast<const uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
-            const int n_p = n_p_need;
-            for (int e = lane; e < n_p; e += ADH_WAVE) sorted[e] = e < (int)n_touch ? (int)touched[e] : 0x7FFFFFFF;
-            __syncthreads();
-            for (int k = 2; k <= n_p; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int e = lane; e < n_p; e += ADH_WAVE) {
-                        const int q = e ^ j;
-                        if (q > e) {
-                            const int a = sorted[e], b = sorted[q];
-                            if ((a > b) == ((e & k) == 0)) {
-                                sorted[e] = b;
-                                sorted[q] = a;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (int base = 0; base < (int)n_touch; base += ADH_WAVE) {
-                const int cnt = min(ADH_WAVE, (int)n_touch - base);
-                if (lane < cnt) {
-                    const int ci = sorted[base + lane];
-                    const float2 v = fcells[ci];
-                    l_cell[lane] = ci;
-                    l_rx[lane] = v.x;
-                    l_ry[lane] = v.y;
-                }
-                __syncthreads();
-                flush(cnt);
-            }
-        } else {
-        constexpr int PF = 4;  // 128-cell chunks in flight (a lane reads two neighbouring cells)
-        const float4 *cells4 = reinterpret_cast<const float4 *>(fcells);  // 16-byte aligned block
-        const int n_pairs = (n_cells + 1) / 2;  // (an odd tile reads 8 bytes of the next array: masked)
-        for (int base0 = 0; base0 < n_pairs; base0 += PF * ADH_WAVE) {
-            float4 rawv[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int pu = base0 + u * ADH_WAVE + lane;
-                rawv[u] = cells4[min(pu, n_pairs - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int pu = base0 + u * ADH_WAVE + lane;
-                const int ci = 2 * pu;
-                const float4 raw = rawv[u];
-                const bool nz0 = pu < n_pairs && (raw.x > 0.0f || raw.y > 0.0f);
-                const bool nz1 = pu < n_pairs && ci + 1 < n_cells && (raw.z > 0.0f || raw.w > 0.0f);
-                const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
-                if ((m0 | m1) == 0ull) continue;
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                int pos = n_list + __popcll(m0 & lt) + __popcll(m1 & lt);
-                if (nz0) {
-                    l_cell[pos] = ci;
-                    l_rx[pos] = raw.x;
-                    l_ry[pos] = raw.y;
-                    ++pos;
-                }
-                if (nz1) {
-                    l_cell[pos] = ci + 1;
-                    l_rx[pos] = raw.z;
-                    l_ry[pos] = raw.w;
-                }
-                n_list += __popcll(m0) + __popcll(m1);
-                while (n_list >= ADH_WAVE) {
-                    __syncthreads();
-                    flush(ADH_WAVE);
-                    // move the remainder (< 128 entries) to the front
-                    const int rest = n_list - ADH_WAVE;
-                    int c_t[2] = {0, 0};
-                    float x_t[2] = {0.0f, 0.0f}, y_t[2] = {0.0f, 0.0f};
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int e = lane + j * ADH_WAVE;
-                        if (e < rest) {
-                            c_t[j] = l_cell[ADH_WAVE + e];
-                            x_t[j] = l_rx[ADH_WAVE + e];
-                            y_t[j] = l_ry[ADH_WAVE + e];
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int e = lane + j * ADH_WAVE;
-                        if (e < rest) {
-                            l_cell[e] = c_t[j];
-                            l_rx[e] = x_t[j];
-                            l_ry[e] = y_t[j];
-                        }
-                    }
-                    n_list = rest;
-                }
+            for (int c = lane; c < n_pl; c += ADH_WAVE) {
+                pl_beg[c] = c * SF;
+                pl_end[c] = (c + 1) * SF;
             }
         }
-        __syncthreads();
-        if (n_list > 0) flush(n_list);
+        adh_wave_sync();
+        // cell e of the list (sparse form) or of the tile (dense form)
+        auto fetch = [&](int e) -> ImEntry {
+            if (compact) return entries[e];
+            const float2 v = fcells[e];
+            ImEntry en;
+            en.cell = (uint32_t)e, en.x = v.x, en.y = v.y;
+            return en;
+        };
+        double *const s_w = reinterpret_cast<double *>(pool);
+        int *const s_c = reinterpret_cast<int *>(s_w + 192);
+        float *const s_v = reinterpret_cast<float *>(s_c + 192);
+        float *const s_y = s_v + 192;
+        const double inv_f = 1.0 / (double)F;
+        for (int pbase = 0; pbase < n_pl; pbase += ADH_WAVE) {
+            const int np = min(ADH_WAVE, n_pl - pbase);
+            const int QT = 192 / np;
+            const bool fl = lane < np;
+            const int p = pbase + lane;
+            const int beg_f = fl ? pl_beg[p] : 0, end_f = fl ? pl_end[p] : 0;
+            int R = (end_f - beg_f + QT - 1) / QT;
+            for (int off = 32; off > 0; off >>= 1) R = max(R, __shfl_xor(R, off));
+            int t_beg[3], t_end[3], t_j[3], t_o[3], t_psf[3];
+            ImEntry nxt[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int slot = lane + t * ADH_WAVE;
+                const int ps = slot / QT;
+                const bool okp = ps < np;
+                const int pp = pbase + (okp ? ps : 0);
+                t_j[t] = slot - ps * QT;
+                t_beg[t] = okp ? pl_beg[pp] : 0;
+                t_end[t] = okp ? pl_end[pp] : 0;
+                t_o[t] = pp % O;
+                t_psf[t] = pp * SF;
+                nxt[t].cell = 0u, nxt[t].x = 0.0f, nxt[t].y = 0.0f;
+                if (t_beg[t] + t_j[t] < t_end[t]) nxt[t] = fetch(t_beg[t] + t_j[t]);
+            }
+            double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
+            float fs = 0.0f;
+            int cur_sc = -1;
+            for (int rr = 0; rr < R; ++rr) {
+                ImEntry cur[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    cur[t] = nxt[t];
+                    const int e2 = t_beg[t] + (rr + 1) * QT + t_j[t];
+                    if (e2 < t_end[t]) nxt[t] = fetch(e2);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int e = t_beg[t] + rr * QT + t_j[t];
+                    if (e < t_end[t]) {
+                        const int rem = (int)cur[t].cell - t_psf[t];
+                        int sc = (int)((double)rem * inv_f);  // exact quotient: float64 estimate, one fix-up
+                        if (rem - sc * F >= F) ++sc;
+                        const int f = rem - sc * F, o = t_o[t];
+                        const int slot = lane + t * ADH_WAVE;
+                        double w = 1.0;
+                        if (cur[t].x > 0.0f || cur[t].y > 0.0f) {  // (an empty cell of a dense tile adds 0 whatever its weight)
+                            const double ds = (double)sc - esc[o], df = (double)f - efc[o];
+                            w = exp(-0.1 * sqrt(ds * ds + df * df));
+                        }
+                        s_c[slot] = sc << 16 | f;  // (the serial fold below must not divide)
+                        s_v[slot] = cur[t].x * qmask[o * S + sc];  // candidate.py:290
+                        s_y[slot] = cur[t].y;
+                        s_w[slot] = w;
+                    }
+                }
+                adh_wave_sync();
+                if (fl) {
+                    const int cnt = min(QT, end_f - (beg_f + rr * QT));
+                    for (int t = 0; t < cnt; ++t) {
+                        const int at = lane * QT + t;
+                        const int cf = s_c[at];
+                        const float v = s_v[at], y = s_y[at];
+                        const double w = s_w[at];
+                        const int sc = cf >> 16, f = cf & 0xFFFF;
+                        const float col = ffp_u[p * F + f];
+                        if (sc != cur_sc) {  // the cells of a scan are consecutive: its sum is complete
+                            if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
+                            fs = 0.0f;
+                            cur_sc = sc;
+                        }
+                        fs += v;
+                        ffp_u[p * F + f] = col + v;
+                        const double tm = (double)y * w;  // (w > 0: the product is > 0 exactly when the m/z channel is)
+                        vi += v > 0.0f ? (double)v * w : 0.0;  // (adding 0.0 leaves a sum as it is)
+                        wi += v > 0.0f ? w : 0.0;
+                        vm += tm > 0.0 ? tm : 0.0;
+                        wm += tm > 0.0 ? w : 0.0;
+                    }
+                }
+                adh_wave_sync();
+            }
+            if (fl) {
+                if (cur_sc >= 0) fsp_u[p * S + cur_sc] = fs;
+                acc_vi[p] = vi;
+                acc_wi[p] = wi;
+                acc_vm[p] = vm;
+                acc_wm[p] = wm;
+            }
         }
-        }
+        adh_wave_sync();
         for (int c = lane; c < K0 * O; c += ADH_WAVE) {
             const double vi = acc_vi[c], wi = acc_wi[c], vm = acc_vm[c], wm = acc_wm[c];
             ohe_u[c] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
             omz_u[c] = (wm > 0) ? vm / wm : 0.0;
         }
     }
-    __syncthreads();
+    adh_wave_sync();
     if (caps.stop_phase == 3) return;
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
@@ -689,7 +570,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         present[k] = so > 0.0f;
     }
-    __syncthreads();
+    adh_wave_sync();
     {
         float tot = 0;
         for (int o = 0; o < O; ++o) tot += tsum[o];
@@ -704,7 +585,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     }
     if (K < 2) return;  // candidate.py:323
     const int n_present = K;
-    __syncthreads();
+    adh_wave_sync();
 
     float *const g_mzlib = Fl + lay.f_pk();
     float *const g_mz = g_mzlib + Kc;
@@ -733,13 +614,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             g_pos[k] = rec.position;
         }
     }
-    __syncthreads();
+    adh_wave_sync();
     {
         float sum1 = 0;
         for (int k = 0; k < K; ++k) sum1 += g_int[k];
-        __syncthreads();
+        adh_wave_sync();
         for (int k = lane; k < K; k += ADH_WAVE) g_int[k] = g_int[k] / sum1;
-        __syncthreads();
+        adh_wave_sync();
         float sum2 = 0;
         for (int k = 0; k < K; ++k) sum2 += g_int[k];
         for (int k = lane; k < K; k += ADH_WAVE) g_fin[k] = g_int[k] / sum2;
@@ -758,7 +639,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         for (int f = 0; f < F; ++f) a += tpl[c * F + f];
         tsp_raw[c] = a;
     }
-    __syncthreads();
+    adh_wave_sync();
     for (int c = lane; c < K * O * F; c += ADH_WAVE) {
         int k = c / (O * F), rem = c - k * O * F;
         ffp[c] = ffp_u[kmap[k] * O * F + rem];
@@ -773,7 +654,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         omz[c] = omz_u[kmap[k] * O + o];
     }
     for (int f = lane; f < F; f += ADH_WAVE) frame_rt[f] = run.rt[r.frame_start + f * L];
-    __syncthreads();
+    adh_wave_sync();
     // OR-envelopes: interior points lower than a neighbour become the neighbours' mean
     for (int c = lane; c < O * F; c += ADH_WAVE) {
         int f = c % F;
@@ -802,7 +683,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         tsp[c] = rr;
     }
-    __syncthreads();
+    adh_wave_sync();
 
     if (caps.stop_phase == 4) return;
     // =========================== features ===========================
@@ -814,7 +695,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         for (int f = 0; f < F; ++f) sf += prec_int(c / S, (c % S) * F + f);
         work_b[c] = sf;
     }
-    __syncthreads();
+    adh_wave_sync();
     if (lane < I) {
         float ss = 0;
         for (int sc = 0; sc < S; ++sc) ss += work_b[lane * S + sc];
@@ -844,7 +725,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 l_rx[pos] = vi;
                 l_ry[pos] = vm;
             }
-            __syncthreads();
+            adh_wave_sync();
             const int n_ent = __popcll(mask);
             if (lane < 4) {
                 const float *flag = (lane < 2) ? l_rx : l_ry;
@@ -852,7 +733,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 for (int e = 0; e < n_ent; ++e)
                     if (flag[e] > 0.0f) acc += src[e];
             }
-            __syncthreads();
+            adh_wave_sync();
         }
         const double vh = __shfl(acc, 0), wh = __shfl(acc, 1), vmz = __shfl(acc, 2), wmz = __shfl(acc, 3);
         if (lane == 0) {
@@ -861,7 +742,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
     }
     }
-    __syncthreads();
+    adh_wave_sync();
 
     double *const mzmean = D + lay.d_pk();
     double *const height = mzmean + Kc;
@@ -925,7 +806,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         for (int i = 0; i < W; ++i) t += p[i];
         obs_int[k] = t;
     }
-    __syncthreads();
+    adh_wave_sync();
     for (int k = lane; k < K; k += ADH_WAVE) {
         float ws = 0;
         for (int o = 0; o < O; ++o) {
@@ -967,7 +848,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         ord[rk] = k;
     }
-    __syncthreads();
+    adh_wave_sync();
 
     Assemble asmv;
     asmv.run = nullptr;  // location features are float64 here, filled below
@@ -991,7 +872,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     if (caps.stop_phase == 5) return;
     // =========================== fragment_mobility_correlation (fragment_features.py:430-480)
     // centred scan profiles go to the second work buffer, centred frame profiles later
-    __syncthreads();
+    adh_wave_sync();
     float *cen = work_b;
     {
         int Km = 0;
@@ -1007,7 +888,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 ++Km;
             }
         }
-        __syncthreads();
+        adh_wave_sync();
         if (Km >= 3) {
             float isum = 0;
             for (int a = 0; a < Km; ++a) isum += g_int[mkeep[a]];
@@ -1024,7 +905,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 for (int sc = 0; sc < S; ++sc) q += cen[c * S + sc] * cen[c * S + sc];
                 mfw[c] = sqrtf(q / (float)S);
             }
-            __syncthreads();
+            adh_wave_sync();
             // np.dot(profile_centered, profile_centered.T) over the scan axis (scoring/utils.py:559, BLAS
             // SGEMM in the reference): one MFMA tile per observation, as in adh_feature_kernel; more
             // than 16 fragments use ordered dot products
@@ -1041,10 +922,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                         const float v = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
                     }
-                    __syncthreads();
+                    adh_wave_sync();
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) gram[4 * kq + rr][i] = d[rr];
-                    __syncthreads();
+                    adh_wave_sync();
                     for (int a = lane; a < Km; a += ADH_WAVE)
                         for (int b = 0; b < Km; ++b) {
                             float cov = gram[a][b] / (float)S;
@@ -1053,7 +934,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                             redm[a][b] += cm * oi[o];
                         }
                 }
-                __syncthreads();
+                adh_wave_sync();
                 for (int a = lane; a < Km; a += ADH_WAVE) {
                     float acc = 0;
                     for (int b = 0; b < Km; ++b) acc += redm[a][b] * mnorm[b];
@@ -1097,7 +978,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 float sm = mfw[c] * ysd;
                 ftc[o * Km + a] = (float)((double)cov / ((double)sm + 1e-12));
             }
-            __syncthreads();
+            adh_wave_sync();
             if (lane == 0) {
                 float lsum = 0;
                 for (int a = 0; a < Km; ++a) lsum += mlist[a];
@@ -1112,7 +993,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             }
         }
     }
-    __syncthreads();
+    adh_wave_sync();
 
     if (caps.stop_phase == 6) return;
     // =========================== profile features (profile_features.py:18-206)
@@ -1124,7 +1005,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             for (int o = 0; o < O; ++o) a += ffp[(k * O + o) * F + f];
             isl[c] = a;
         }
-        __syncthreads();
+        adh_wave_sync();
         int cidx = F / 2, wa, wb;
         py_slice(cidx - 1, cidx + 2, F, wa, wb);
         for (int k = lane; k < K; k += ADH_WAVE) {
@@ -1134,7 +1015,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             for (int f = 0; f < F; ++f)
                 nrm[k * F + f] = (ci > 0) ? (float)((double)isl[k * F + f] / ci) : 0.0f;
         }
-        __syncthreads();
+        adh_wave_sync();
         for (int f = lane; f < F; f += ADH_WAVE) {
             float lo_v = 0, hi_v = 0;
             int r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -1157,12 +1038,12 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             }
             med[f] = m;
         }
-        __syncthreads();
+        adh_wave_sync();
         float sx = 0;
         for (int f = 0; f < F; ++f) sx += med[f];
         float mx = (float)((double)sx / (double)F);
         for (int f = lane; f < F; f += ADH_WAVE) xm[f] = med[f] - mx;
-        __syncthreads();
+        adh_wave_sync();
         float sxx = 0;
         for (int f = 0; f < F; ++f) sxx += xm[f] * xm[f];
         double var_x = (double)sxx / (double)F;
@@ -1192,7 +1073,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             for (int f = 0; f < F; ++f) q += cen[c * F + f] * cen[c * F + f];
             fw[c] = sqrtf(q / (float)F);
         }
-        __syncthreads();
+        adh_wave_sync();
         for (int a = lane; a < K; a += ADH_WAVE) {
             float acc = 0;
             for (int b = 0; b < K; ++b) {
@@ -1211,7 +1092,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             corr[a] = acc;
         }
     }
-    __syncthreads();
+    adh_wave_sync();
     float top3 = 0.0f;
     if (lane == 0) {
         int n3 = min(K, 3);
@@ -1239,7 +1120,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             top3 = (float)((double)sm / (double)(n3 * n3));
         }
     }
-    __syncthreads();
+    adh_wave_sync();
     const double rt_width = run.rt[r.frame_stop - 1] - run.rt[r.frame_start];
     const double mob_width = run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1];
     for (int c = lane; c < K * O; c += ADH_WAVE) {
@@ -1292,7 +1173,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         double fracs = (double)n_ab / (double)S;
         mfw[c] = (float)(fracs * mob_width);
     }
-    __syncthreads();
+    adh_wave_sync();
     if (lane < O) {
         int o = lane;
         int lo_v = 0, hi_v = 0, r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -1309,7 +1190,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         double m = (K & 1) ? (double)hi_v : (double)(lo_v + hi_v) / 2.0;
         medpk[o] = (float)m;
     }
-    __syncthreads();
+    adh_wave_sync();
     if (lane == 0) {
         asmv.top3 = top3;
         feat::assemble_part2(asmv, O, K, F);
@@ -1321,7 +1202,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
         featv[39] = agg;
     }
-    __syncthreads();
+    adh_wave_sync();
 
     if (lane < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + lane] = featv[lane];
     if (cfg.collect_fragments) {

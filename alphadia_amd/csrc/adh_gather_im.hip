@@ -86,7 +86,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     Caps caps) {
     using namespace gather_im;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ unsigned n_touched;  // dense mode: fragment cells that received their first event
     const int n_win = caps.k + caps.i;
     float *w_mz = reinterpret_cast<float *>(smem);
     int *t_lo = reinterpret_cast<int *>(w_mz + n_win);
@@ -113,7 +112,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     if (lane == 0) {
         out.precursor_idx[row] = r.precursor_idx;  // candidate.py:175-176
         out.rank[row] = r.rank;
-        n_touched = 0u;
     }
     unsigned char *block = scratch + r.scratch_off;
     uint32_t *header = reinterpret_cast<uint32_t *>(block);
@@ -536,15 +534,21 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             }
             return;
         }
+        if (caps.stop_phase == 13 || caps.dbg_drop_dense) {  // developer ablation: candidates that overflow the lists are dropped
+            if (lane == 0) header[0] = 0;
+            return;
+        }
         hits = 0;
         __syncthreads();
     }
 
-    // ---- dense mode: zero the tile, (window, cycle) tasks, list of the touched fragment cells
+    // ---- dense mode: zero the tiles; (window, cycle) tasks, one per lane: a task walks the TOF bins of its
+    // window in ascending order and, inside a bin, the events of its cycle.  A tile cell is only ever
+    // touched by one task, in the reference's order (TOF ascending, then push ascending).
     for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
     for (int c = lane; c < n_pc; c += ADH_WAVE) pcells[c] = make_float2(0.0f, 0.0f);
     __syncthreads();
-    uint32_t *touched = reinterpret_cast<uint32_t *>(block + adh_im_touch_off(r.k_cap, O, S, F, I, Op));
+    const bool per_cycle = run.cyc_idx != nullptr && run.cyc_shift == 0;
     for (int t = lane; t < (K + I) * F; t += ADH_WAVE) {
         const int w = t / F, f = t - w * F;
         const bool prec = w >= K;
@@ -559,12 +563,19 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         const uint32_t push_hi = (uint32_t)(frame_lo + L) * (uint32_t)S_max;
         for (int tof = t_lo[slot]; tof < t_hi[slot]; ++tof) {
             const double measured = run.mz[tof];
-            int64_t a = run.tof_indptr[tof];
-            const int64_t b = run.tof_indptr[tof + 1];
-            int64_t lo = a, hi = b;
-            while (lo < hi) {
-                int64_t m = (lo + hi) >> 1;
-                if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+            int64_t lo, b;
+            if (per_cycle) {  // the staged (bin, cycle) index holds both ends
+                const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
+                lo = row[c0 + f];
+                b = row[min(c0 + f + 1, run.cyc_cols - 1)];
+            } else {
+                b = run.tof_indptr[tof + 1];
+                lo = run.tof_indptr[tof];
+                int64_t hi = b;
+                while (lo < hi) {
+                    int64_t m = (lo + hi) >> 1;
+                    if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                }
             }
             for (int64_t idx = lo; idx < b; ++idx) {
                 const uint32_t p = run.push[idx];
@@ -579,10 +590,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 if (o >= n_o) continue;  // cannot happen: the plan lists every overlapping row
                 const int cell = ((j * n_o + o) * S + (scan - r.scan_start)) * F + f;
                 float2 v = cells[cell];
-                if (!prec && v.x == 0.0f && v.y == 0.0f) {  // pristine: after any event the m/z plane is > 0
-                    const unsigned pos = atomicAdd(&n_touched, 1u);
-                    if (pos < ADH_IM_TOUCH_CAP) touched[pos] = (uint32_t)cell;
-                }
                 fold(v.x, v.y, (int64_t)run.inten[idx], measured);
                 cells[cell] = v;
                 ++hits;
@@ -590,11 +597,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         }
     }
     for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
-    __syncthreads();
     if (lane == 0) {
         header[0] = (uint32_t)K;
         header[1] = hits;
-        header[2] = n_touched <= ADH_IM_TOUCH_CAP ? n_touched : ADH_IM_TOUCH_OVERFLOW;
+        header[2] = 0u;
         header[3] = ADH_IM_MODE_DENSE;
+        header[4] = 0u;
     }
 }

@@ -398,6 +398,8 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
         return fail(ADH_ERR_INVALID_ARGUMENT, "output top_k smaller than config.top_k_fragments");
     p.caps_all.stop_phase = 0;
     if (const char *dbg = getenv("ADH_DEBUG_IM")) p.caps_all.stop_phase = atoi(dbg);
+    p.caps_all.dbg_drop_dense = 0;
+    if (const char *dbg = getenv("ADH_DEBUG_IM_DROP_DENSE")) p.caps_all.dbg_drop_dense = atoi(dbg);
     size_t g_pad = 0, f_pad = 0;  // developer switches: extra LDS per block, to see what occupancy is worth
     if (const char *dbg = getenv("ADH_DEBUG_IM_GATHER_LDS_PAD")) g_pad = (size_t)atoi(dbg);
     if (const char *dbg = getenv("ADH_DEBUG_IM_FEATURE_LDS_PAD")) f_pad = (size_t)atoi(dbg);
