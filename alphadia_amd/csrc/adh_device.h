@@ -163,9 +163,11 @@ __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, 
 // instructions in order and the LDS unit completes them in order, so a read that follows a write in
 // program order sees the write, whichever lane made it: nothing has to be waited for.  What is
 // needed is that the compiler keeps the order - the two wavefront-scope fences (no instruction) and the
-// scheduling barrier do that.  __syncthreads() would add s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier:
-// every global load in flight (prefetches!) and every LDS access would have to land at each of the
-// hundreds of hand-over points of a candidate.  NOT for data handed over through global memory.
+// scheduling barrier do that.  __syncthreads() adds s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier, i.e.
+// every global load in flight has to land first: a prefetch issued before a hand-over point would be
+// waited for right there.  (Measured: by itself the swap changes nothing - the kernels are bound by
+// dependent LDS / ALU chains, not by the barriers - it only keeps prefetches alive.)  NOT for data
+// handed over through global memory.
 __device__ __forceinline__ void adh_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
