@@ -240,6 +240,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
     int K0 = alive ? (int)header[0] : 0;
     alive = alive && K0 != 0;
+    if (__ballot(alive) == 0ull) return;  // (every lane of a dead candidate walks the whole kernel masked: four dead ones need not)
     const uint32_t row = rec.row;
     const int Lc = run.cycle_len;
     const int c0 = rec.frame_start / Lc;

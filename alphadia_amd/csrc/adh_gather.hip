@@ -144,6 +144,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
     uint32_t *header = reinterpret_cast<uint32_t *>(block);
     LibRec *sel = reinterpret_cast<LibRec *>(block + 32);
 
+    // ---- zero the tile right away: fragment cells ((o * F + f) * K + k) in scratch - K <= k_cap of them per
+    // (o, f) - and the raw MS1 cells in LDS.  The stores drain while the library slice is loaded and
+    // ranked, so the barrier in front of the gather tasks finds them done.
+    float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
+    const int M1 = run.n_ms1_obs;
+    {
+        const int Lz = run.cycle_len;
+        const int Fz = r.frame_stop / Lz - r.frame_start / Lz;
+        const int n_z = (int)r.k_cap * (int)r.n_obs * max(Fz, 0);
+        for (int c = lane; c < n_z; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
+        const int n_r = min(n_iso_cols, (int)cfg.top_k_isotopes) * M1 * max(Fz, 0);
+        for (int c = lane; c < n_r; c += ADH_WAVE) raw1[c] = make_float2(0.0f, 0.0f);
+    }
+
     // ---- fragments: slice, cardinality filter, top-k by intensity, sort by m/z
     const int64_t frag_start = r.frag_start;
     const int n_lib = (int)(r.frag_stop - r.frag_start);
@@ -227,16 +241,16 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
         }
     }
     for (int w = lane; w < K + I; w += ADH_WAVE) bins_of(run, win[w < K ? w : caps.k + (w - K)]);
-    if (caps.stop_phase == 1) return;  // developer ablation switches (ADH_DEBUG_GATHER)
+    if (caps.stop_phase == 1) {  // developer ablation switches (ADH_DEBUG_GATHER)
+        if (lane == 0) header[0] = 0;
+        return;
+    }
 
-    // ---- zero the tile: fragment cells ((o * F + f) * K + k) in scratch, raw MS1 cells in LDS
-    float2 *fcells = reinterpret_cast<float2 *>(block + adh_scratch_frag_off(r.k_cap));
-    const int n_fc = K * O * F;
-    const int M1 = run.n_ms1_obs;
-    for (int c = lane; c < n_fc; c += ADH_WAVE) fcells[c] = make_float2(0.0f, 0.0f);
-    for (int c = lane; c < I * M1 * F; c += ADH_WAVE) raw1[c] = make_float2(0.0f, 0.0f);
-    __syncthreads();
-    if (caps.stop_phase == 2) return;
+    __syncthreads();  // (the tile was zeroed at the top)
+    if (caps.stop_phase == 2) {
+        if (lane == 0) header[0] = 0;
+        return;
+    }
 
     // ---- (window, observation, block) tasks
     uint32_t hits = 0;
