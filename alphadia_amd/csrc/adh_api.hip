@@ -695,18 +695,23 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         }
     }
     cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
-    cap_tp = (cap_tp + 1) & ~1;
-    cap_mp = (cap_mp + 1) & ~1;
-    const size_t lds = ((size_t)cap_tp + (size_t)cap_mp + (size_t)cap_cells) * 4 + (size_t)(k0 + k1 + cap_s + cap_f) * 8 +
-                       (size_t)cap_cells + 64;
-    if (lds > 150 * 1024) {
+    (void)cap_tp;
+    (void)cap_mp;
+    const size_t lds = adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f, k0, k1);
+    if (lds > 150 * 1024 || cap_f > selim::SCORE_THREADS) {
         char buf[200];
-        snprintf(buf, sizeof(buf), "selection tile of %d cells (scans x cycles) needs %zu bytes of LDS: exceeds 150 KiB",
-                 cap_cells, lds);
+        snprintf(buf, sizeof(buf), "selection tile of %d cells (scans x cycles, %d cycles) needs %zu bytes of LDS: exceeds 150 KiB",
+                 cap_cells, cap_f, lds);
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
     // batches of precursors whose tiles fit a bounded scratch slab
-    const uint64_t budget = 2ull << 30;
+    uint64_t budget = 2ull << 30;
+    {
+        // (the slab is only reserved: a precursor's tiles are normally kept in sparse form and touch a few KB of it)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 4, 32ull << 30));
+        if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
+    }
     DeviceBuffers tmp;
     const double *d_ku = nullptr, *d_kv = nullptr;
     int rc = upload(tmp, ku.data(), k0, &d_ku, h->stream);
@@ -756,7 +761,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
             int64_t last = first;
             while (last < n) {
                 selim::PrecRec &r = recs[(size_t)last];
-                const uint64_t need = 32 + (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso) * r.n_scans * r.n_cycles * 4 : 0);
+                const uint64_t need = selim::SEL_HEADER +
+                                      (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
                 const uint64_t aligned = (need + 255) / 256 * 256;
                 if (off + aligned > budget) break;
                 r.scratch_off = off;
@@ -775,8 +781,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
                                    h->d_lib, d_recs + first, cnt, *cfg, (int32_t)n_iso, d_scratch);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
-                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_tp, cap_mp, cap_s, cap_f,
-                                   d_scratch, dt);
+                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipEventRecord(e1, h->stream);

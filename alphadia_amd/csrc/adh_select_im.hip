@@ -23,6 +23,12 @@ namespace selim {
 constexpr int MAX_W = 64;    // m/z windows (fragments + isotopes) per precursor
 constexpr int MAX_CAND = 16;
 constexpr int SCORE_THREADS = 256;
+constexpr int SEL_HEADER = 32 + 4 * (MAX_W + 2);  // bytes in front of the tiles of a precursor (see below)
+constexpr uint32_t SEL_DENSE = 0u, SEL_COMPACT = 1u;
+struct SelEntry {
+    uint32_t cell;  // (window * S + scan) * F + cycle
+    float x;        // summed intensity
+};
 
 // per-precursor record prepared by the host (frame / scan limits as the reference computes them)
 struct __attribute__((aligned(16))) PrecRec {
@@ -30,13 +36,20 @@ struct __attribute__((aligned(16))) PrecRec {
     float mz;
     int32_t cycle_start, n_cycles;   // first cycle, F
     int32_t scan_start, n_scans;     // first scan, S
-    uint64_t scratch_off;            // bytes: header (32) + [W][S][F] float
+    uint64_t scratch_off;            // bytes: SEL_HEADER + the tiles (W * S * F * 4) + one parked tile (S * F * 4)
     uint8_t charge, ok, pad[6];
 };
 static_assert(sizeof(PrecRec) == 48, "PrecRec must be 48 bytes");
 
 }  // namespace selim
 
+// ------------------------------------------------------------------------------------------------
+// Scratch block of one precursor: header (SEL_HEADER bytes: [0] K, [1] W, [2] mode, [3] entry count,
+// then the first entry of every window, W + 1 values), the tiles - in sparse form (SEL_COMPACT: the
+// non-zero cells of all windows as (cell, intensity) entries sorted by cell,
+// cell = (window * S + scan) * F + cycle) or, when there are too many for that, as float[W][S][F]
+// (SEL_DENSE) - and one float[S][F] tile where the score kernel parks its sums.  The tiles of a
+// precursor are ~0.1 % full (176 scans x 48 cycles x 15 windows, a handful of events per window).
 __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     DevTims run, const LibRec *__restrict__ lib, const selim::PrecRec *__restrict__ recs, int32_t n_prec,
     adh_selection_config_t cfg, int32_t n_iso, unsigned char *__restrict__ scratch) {
@@ -44,6 +57,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     __shared__ float s_mz[MAX_W];       // window centres: fragments ascending, then isotopes
     __shared__ int s_tlo[MAX_W], s_thi[MAX_W];
     __shared__ float s_raw[MAX_W];
+    __shared__ int w_p0[MAX_W + 1];                   // first (window, TOF bin) pair of every window
+    __shared__ uint32_t p_lo[ADH_IM_PAIR_CAP];        // first event of the pair's range
+    __shared__ uint32_t p_off[ADH_IM_PAIR_CAP + 2];   // events before the pair
+    __shared__ uint8_t p_win[ADH_IM_PAIR_CAP];
+    __shared__ uint32_t s_key[ADH_IM_SORT_CAP];       // cell << 9 | position in the list
+    __shared__ uint16_t s_int[ADH_IM_SORT_CAP];
+    __shared__ uint8_t s_pair[ADH_IM_SORT_CAP];
     const int lane = threadIdx.x;
     const int i = blockIdx.x;
     if (i >= n_prec) return;
@@ -80,43 +100,285 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
         s_mz[K + lane] = (float)((double)r.mz + (double)lane * 1.0033548350700006 / (double)r.charge);
     __syncthreads();
     const int W = K + n_iso;
-    // TOF index limits of every window: searchsorted(mz_values, mass_range(...), "left")
+    // TOF index limits of every window: searchsorted(mz_values, mass_range(...), "left"); the staged
+    // lookup table brackets the answer, an answer on the edge of the bracket is verified
+    auto tof_lower_bound = [&](double x) -> int {
+        const int n_tof = (int)run.n_tof;
+        int a = 0, b = n_tof;
+        if (run.mz_lut) {
+            const double t = (x - run.lut_min) * run.lut_inv_step;
+            const int bk = !(t >= 0.0) ? 0 : (t >= (double)run.lut_n ? run.lut_n - 1 : (int)t);
+            const int a0 = (int)run.mz_lut[max(bk - 1, 0)], b0 = (int)run.mz_lut[min(bk + 2, run.lut_n)];
+            a = a0, b = b0;
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (run.mz[m] < x) a = m + 1; else b = m;
+            }
+            const bool ok_lo = a > a0 || a == 0 || run.mz[a - 1] < x;
+            const bool ok_hi = a < b0 || a == n_tof || !(run.mz[a] < x);
+            if (ok_lo && ok_hi) return a;
+            a = 0, b = n_tof;
+        }
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (run.mz[m] < x) a = m + 1; else b = m;
+        }
+        return a;
+    };
     if (lane < W) {
         const float m = s_mz[lane];
         const float tol = (float)(lane < K ? cfg.fragment_mz_tolerance : cfg.precursor_mz_tolerance);
         float t = tol * m;
         float q = t / 1000000.0f;
-        const double lo = (double)(m - q), hi = (double)(m + q);
-        int64_t a = 0, b = run.n_tof;
-        while (a < b) {
-            const int64_t mid = (a + b) >> 1;
-            if (run.mz[mid] < lo) a = mid + 1; else b = mid;
-        }
-        s_tlo[lane] = (int)a;
-        b = run.n_tof;
-        while (a < b) {
-            const int64_t mid = (a + b) >> 1;
-            if (run.mz[mid] < hi) a = mid + 1; else b = mid;
-        }
-        s_thi[lane] = (int)a;
+        const int a = tof_lower_bound((double)(m - q)), b = tof_lower_bound((double)(m + q));
+        s_tlo[lane] = a;
+        s_thi[lane] = b > a ? b : a;
     }
     const int S = r.n_scans, F = r.n_cycles, L = run.cycle_len, SM = run.scan_max, z = run.zeroth;
-    float *tiles = reinterpret_cast<float *>(scratch + r.scratch_off + 32);
-    const int n_cells = W * S * F;
-    for (int c = lane; c < n_cells; c += ADH_WAVE) tiles[c] = 0.0f;
+    const int c0 = r.cycle_start;
+    unsigned char *body = scratch + r.scratch_off + SEL_HEADER;
+    __syncthreads();
+    const double q_lo = (double)s_mz[K], q_hi = (double)s_mz[K + n_iso - 1];
+    const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)SM;
+    const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)SM;
+    const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
+
+    // ---- sparse form (the scheme of adh_gather_im_kernel): (window, TOF bin) pairs -> one range of events
+    // each (the bin's events of the tile's cycles are contiguous) -> one stream of raw events; those in the
+    // scan range queue up, look up their quadrupole row, and the survivors are sorted by (cell, stream
+    // position) and summed per cell in that order: TOF ascending, then push - the reference's order
+    // (bruker_jit.py:575-580: float32 running sum).
+    if (lane == 0) {
+        int acc = 0;
+        for (int w = 0; w < W; ++w) {
+            w_p0[w] = acc;
+            acc += s_thi[w] - s_tlo[w];
+        }
+        w_p0[W] = acc;
+    }
+    __syncthreads();
+    const int P = w_p0[W];
+    const int64_t n_cells = (int64_t)W * S * F;
+    bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || n_cells >= (1 << 23);
+    if (!over) {
+        for (int p = lane; p < P; p += ADH_WAVE) {
+            int w = 0;
+            while (w_p0[w + 1] <= p) ++w;
+            const int tof = s_tlo[w] + (p - w_p0[w]);
+            int64_t lo, lo2;
+            const bool indexed = run.cyc_idx != nullptr;
+            int64_t hi_lo = 0, hi_hi = 0;
+            if (indexed) {
+                const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
+                const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
+                const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
+                lo = row[ba];
+                lo2 = row[bb];
+                hi_lo = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
+                hi_hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
+            } else {
+                lo = run.tof_indptr[tof];
+                hi_lo = hi_hi = run.tof_indptr[tof + 1];
+                lo2 = lo;
+            }
+            if (!indexed || run.cyc_shift > 0) {
+                int64_t hi = hi_lo;
+                while (lo < hi) {
+                    const int64_t m = (lo + hi) >> 1;
+                    if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                }
+                if (lo2 < lo) lo2 = lo;
+                hi = hi_hi;
+                while (lo2 < hi) {
+                    const int64_t m = (lo2 + hi) >> 1;
+                    if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
+                }
+            }
+            p_lo[p] = (uint32_t)lo;
+            p_win[p] = (uint8_t)w;
+            p_off[p + 1] = (uint32_t)(lo2 - lo);
+        }
+        __syncthreads();
+        uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
+        for (int base = 0; base < P; base += ADH_WAVE) {
+            uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
+            for (int off = 1; off < ADH_WAVE; off <<= 1) {
+                const uint32_t u = __shfl_up(v, off);
+                if (lane >= off) v += u;
+            }
+            if (base + lane < P) p_off[base + lane + 1] = carry + v;
+            carry += __shfl(v, ADH_WAVE - 1);
+        }
+        if (lane == 0) p_off[0] = 0u;
+        __syncthreads();
+    }
+    SelEntry *out_list = reinterpret_cast<SelEntry *>(body);
+    const uint32_t out_cap = (uint32_t)(n_cells * 4 / (int64_t)sizeof(SelEntry));
+    uint32_t out_n = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const double inv_sm = 1.0 / (double)SM, inv_l = 1.0 / (double)L;
+    int m = 0;  // events in the list (wave-uniform)
+    auto flush = [&]() {
+        __syncthreads();
+        if (m > 1) {
+            if (m <= ADH_WAVE) gather_im::sort_keys<1>(s_key, m, lane);
+            else if (m <= 2 * ADH_WAVE) gather_im::sort_keys<2>(s_key, m, lane);
+            else if (m <= 4 * ADH_WAVE) gather_im::sort_keys<4>(s_key, m, lane);
+            else gather_im::sort_keys<8>(s_key, m, lane);
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < m; e0 += ADH_WAVE) {
+            const int e = e0 + lane;
+            bool owner = false;
+            SelEntry en;
+            en.cell = 0u, en.x = 0.0f;
+            if (e < m) {
+                const uint32_t cell = s_key[e] >> 9;
+                owner = e == 0 || (s_key[e - 1] >> 9) != cell;
+                if (owner) {
+                    float x = 0.0f;
+                    for (int q = e; q < m && (s_key[q] >> 9) == cell; ++q) x = x + (float)s_int[s_key[q] & 511u];
+                    en.cell = cell, en.x = x;
+                }
+            }
+            const unsigned long long mask = __ballot(owner);
+            if (owner) {
+                const uint32_t at = out_n + (uint32_t)__popcll(mask & lt);
+                if (at < out_cap) out_list[at] = en;
+            }
+            out_n += (uint32_t)__popcll(mask);
+        }
+        __syncthreads();
+        if (out_n > out_cap) over = true;
+        m = 0;
+    };
+    int w0 = 0;
+    while (w0 < W && !over) {
+        int w1 = w0 + 1;
+        if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > ADH_IM_SORT_CAP) {
+            flush();
+            if (over) break;
+        }
+        while (w1 < W && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= ADH_IM_SORT_CAP) ++w1;
+        const int pa0 = w_p0[w0], pb0 = w_p0[w1];
+        const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
+        if (r1 - r0 > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
+            over = true;
+            break;
+        }
+        int nq = 0;
+        constexpr int U = 8;
+        for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
+            uint32_t pv[U];
+            int pa_u[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+                const uint32_t e = eu < r1 ? eu : r0;
+                int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
+                while (pb - pa > 1) {
+                    const int mid = (pa + pb) >> 1;
+                    if (p_off[mid] <= e) pa = mid; else pb = mid;
+                }
+                pa_u[u] = pa;
+                pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+                uint32_t fq = (uint32_t)((double)pv[u] * inv_sm);  // exact quotient: float64 estimate, one fix-up
+                if (pv[u] - fq * (uint32_t)SM >= (uint32_t)SM) ++fq;
+                const int scan = (int)(pv[u] - fq * (uint32_t)SM);
+                const bool pass = eu < r1 && scan >= r.scan_start && scan < r.scan_start + S;
+                const unsigned long long mask = __ballot(pass);
+                if (pass) {
+                    const int at = m + nq + __popcll(mask & lt);
+                    if (at < ADH_IM_SORT_CAP) {
+                        s_key[at] = pv[u];
+                        s_int[at] = (uint16_t)(eu - r0);
+                        s_pair[at] = (uint8_t)pa_u[u];
+                    }
+                }
+                nq += __popcll(mask);
+            }
+        }
+        if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window can be this full)
+            over = true;
+            break;
+        }
+        __syncthreads();
+        const int q_base = m;
+        for (int q0 = 0; q0 < nq; q0 += ADH_WAVE) {
+            const int qi = q0 + lane;
+            bool ok = false;
+            uint32_t cell = 0u;
+            uint16_t ni = 0;
+            if (qi < nq) {
+                const uint32_t pvq = s_key[q_base + qi];
+                const int pa = (int)s_pair[q_base + qi];
+                const uint32_t e = r0 + (uint32_t)s_int[q_base + qi];
+                const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
+                const int w = (int)p_win[pa];
+                const bool prec = w >= K;
+                uint32_t fq = (uint32_t)((double)pvq * inv_sm);
+                if (pvq - fq * (uint32_t)SM >= (uint32_t)SM) ++fq;
+                const int frame = (int)fq, scan = (int)(pvq - fq * (uint32_t)SM);
+                uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
+                if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
+                const int crow = (frame - z - (int)cq * L) * SM + scan;
+                const double cy0 = run.cycle[2 * crow], cy1 = run.cycle[2 * crow + 1];
+                ni = run.inten[idx];
+                const double ql = prec ? -1.0 : q_lo, qh = prec ? -1.0 : q_hi;
+                ok = ql <= cy1 && qh >= cy0;
+                cell = (uint32_t)((w * S + (scan - r.scan_start)) * F + ((int)cq - c0));
+            }
+            __syncthreads();  // the queue slots of this step are in registers: the list may grow over them
+            const unsigned long long mask = __ballot(ok);
+            if (ok) {
+                const int pos = m + __popcll(mask & lt);
+                s_key[pos] = (cell << 9) | (uint32_t)pos;
+                s_int[pos] = ni;
+            }
+            m += __popcll(mask);
+        }
+        __syncthreads();
+        w0 = w1;
+    }
+    if (!over && m > 0) flush();
+    if (!over) {
+        // first entry of every window (the list is sorted by cell)
+        __syncthreads();
+        for (int w = lane; w <= W; w += ADH_WAVE) {
+            const uint32_t target = (uint32_t)((int64_t)w * S * F);
+            uint32_t a = 0, b = out_n;
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (out_list[mid].cell < target) a = mid + 1; else b = mid;
+            }
+            header[4 + w] = a;
+        }
+        if (lane == 0) {
+            header[0] = (uint32_t)K;
+            header[1] = (uint32_t)W;
+            header[2] = SEL_COMPACT;
+            header[3] = out_n;
+        }
+        return;
+    }
+
+    // ---- dense form: zero the tiles, one lane per window walks the TOF bins of the window: the bin's events
+    // of all F cycles are contiguous (pushes ascend with the frame).  A cell is touched by exactly one lane
+    // in (TOF index, push) order, so its running float32 sum is the reference's.
+    __syncthreads();
+    float *tiles = reinterpret_cast<float *>(body);
+    for (int64_t c = lane; c < n_cells; c += ADH_WAVE) tiles[c] = 0.0f;
     if (lane == 0) {
         header[0] = (uint32_t)K;
         header[1] = (uint32_t)W;
+        header[2] = SEL_DENSE;
+        header[3] = 0u;
     }
     __syncthreads();
-    const double q_lo = (double)s_mz[K], q_hi = (double)s_mz[K + n_iso - 1];
-    // ---- one lane per window: per TOF bin ONE binary search for the first push of the tile's first
-    // cycle, then the bin's events of all F cycles in storage order (they are contiguous: pushes
-    // ascend with the frame).  A lane per (window, cycle) would repeat the search F times - 7e9
-    // dependent HBM probes for 200 000 precursors on the full-size run.  A cell is still touched by
-    // exactly one lane in (TOF index, push) order, so its running float32 sum is the reference's.
-    const uint32_t push_lo = (uint32_t)(r.cycle_start * L + z) * (uint32_t)SM;
-    const uint32_t push_hi = (uint32_t)((r.cycle_start + F) * L + z) * (uint32_t)SM;
     for (int w = lane; w < W; w += ADH_WAVE) {
         const bool prec = w >= K;
         const double ql = prec ? -1.0 : q_lo, qh = prec ? -1.0 : q_hi;
@@ -125,8 +387,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
             const int64_t b = run.tof_indptr[tof + 1];
             int64_t lo = run.tof_indptr[tof], hi = b;
             while (lo < hi) {
-                const int64_t m = (lo + hi) >> 1;
-                if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+                const int64_t mm = (lo + hi) >> 1;
+                if (run.push[mm] < push_lo) lo = mm + 1; else hi = mm;
             }
             for (int64_t e = lo; e < b; ++e) {
                 const uint32_t p = run.push[e];
@@ -144,27 +406,44 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     }
 }
 
+// LDS of the score kernel for tiles of at most cap_cells = S * F cells, cap_s scans, cap_f cycles
+size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f, int k0, int k1) {
+    size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile, later the float64 scores
+    b += (size_t)(k0 + k1 + cap_s + cap_f) * 8;          // kernel factors, scan / cycle profiles
+    b += (size_t)((cap_cells + 31) / 32) * 4;            // peak flags, one bit per cell
+    b += (size_t)cap_s * 3 * 2 + 16;                     // row tables
+    return (b + 15) / 16 * 16;
+}
+
 __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kernel(
     DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
     adh_selection_config_t cfg, const double *__restrict__ ku_g, const double *__restrict__ kv_g, int32_t k0,
-    int32_t k1, int32_t cap_cells, int32_t cap_tp, int32_t cap_mp, int32_t cap_s, int32_t cap_f,
-    unsigned char *__restrict__ scratch, DevCandTable out) {
+    int32_t k1, int32_t cap_cells, int32_t cap_s, int32_t cap_f, unsigned char *__restrict__ scratch,
+    DevCandTable out) {
     using namespace selim;
     extern __shared__ __align__(16) unsigned char smem[];
-    // tile padded along the cycles / pass-1 result padded along the scans (circular copies in the
-    // pads, so the convolution loops carry no wrap-around logic), then the two log-sum tiles
-    float *tile = reinterpret_cast<float *>(smem);
-    float *tmp = tile + cap_tp;
-    float *ls = tmp + cap_mp;  // log-sum tile: fragments first (parked in HBM when done), then isotopes
+    // The smoothing is the separable circular convolution
+    //   out(s, f) = sum_a ku[a] * (sum_b kv[b] * x[(s + k0/2 - a) mod S][(f + k1/2 - b) mod F])
+    // with float64 fused multiply-adds in tap order and one rounding to float32 per pass (as in the oracle).
+    // A tile holds a handful of events, and a zero input leaves a running fma sum as it is, so only the
+    // scans WITH events are kept ("rows": compacted, in scan order): pass 1 runs over those rows, and
+    // pass 2 adds, for every output cell, the rows within the kernel's reach in tap order.  What is left
+    // of the dense algorithm is the log per non-zero output cell.
+    float *rows = reinterpret_cast<float *>(smem);      // [n_rows][F] events, then pass-1 result (in place)
+    float *ls = rows + cap_cells;                       // log-sum tile: fragments first (parked in HBM when done), then isotopes
     double *ku = reinterpret_cast<double *>(ls + cap_cells);
     double *kv = ku + k0;
     double *mob = kv + k1, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
-    unsigned char *flag = reinterpret_cast<unsigned char *>(cyc + cap_f);
+    uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + cap_f);   // peak flags, one bit per cell
+    int16_t *row_slot = reinterpret_cast<int16_t *>(flag + (cap_cells + 31) / 32);  // [S] slot of a scan, -1: no event
+    int16_t *row_list = row_slot + cap_s;               // [n_rows] scans with events, ascending
+    int16_t *row_top = row_list + cap_s;                // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
     __shared__ double red_v[SCORE_THREADS];
     __shared__ int red_i[SCORE_THREADS];
     __shared__ int pk_idx[MAX_CAND];
     __shared__ double pk_val[MAX_CAND];
     __shared__ double s_norm[2];
+    __shared__ int wave_rows[SCORE_THREADS / ADH_WAVE + 1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x;
     if (i >= n_prec) return;
@@ -172,100 +451,165 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
     const uint32_t *header = reinterpret_cast<const uint32_t *>(scratch + r.scratch_off);
     const int K = (int)header[0], W = (int)header[1];
     if (!r.ok || K == 0) return;
-    const float *tiles = reinterpret_cast<const float *>(scratch + r.scratch_off + 32);
-    float *park = reinterpret_cast<float *>(scratch + r.scratch_off + 32);  // tile 0, free once smoothed
+    const bool compact = header[2] == SEL_COMPACT;
+    const unsigned char *body = scratch + r.scratch_off + SEL_HEADER;
+    const SelEntry *entries = reinterpret_cast<const SelEntry *>(body);
+    const float *tiles = reinterpret_cast<const float *>(body);
     const int S = r.n_scans, F = r.n_cycles, SF = S * F;
+    float *park = reinterpret_cast<float *>(scratch + r.scratch_off + SEL_HEADER) + (size_t)W * SF;  // the parked tile
     for (int c = tid; c < k0; c += SCORE_THREADS) ku[c] = ku_g[c];
     for (int c = tid; c < k1; c += SCORE_THREADS) kv[c] = kv_g[c];
-    for (int c = tid; c < SF; c += SCORE_THREADS) {
-        ls[c] = 0.0f;
-    }
+    for (int c = tid; c < SF; c += SCORE_THREADS) ls[c] = 0.0f;
     __syncthreads();
-    // circular convolution, separable: out(s, f) = sum_a ku[a] * (sum_b kv[b] * x[(s + k0/2 - a) mod S][(f + k1/2 - b) mod F]),
-    // float64 fused multiply-adds in tap order (as in the oracle), one rounding to float32 per pass
     const int h0 = k0 / 2, h1 = k1 / 2;
-    const int padl = k1 - h1 - 1, FP = F + k1;   // padded row: column j holds cycle (j - padl) mod F
-    const int padt = k0 - h0 - 1;                // padded pass-1 tile: row j holds scan (j - padt) mod S
-    const bool fast = k0 == 30 && k1 == 30;      // the default kernel: taps in registers, loops unrolled
+    const double inv_f = 1.0 / (double)F;
+    const int rows_per_step = max(SCORE_THREADS / F, 1);  // pass 1: whole rows per step (F <= 256: host check)
     for (int w = 0; w < W; ++w) {
-        for (int c = tid; c < S * FP; c += SCORE_THREADS) {
-            const int sc = c / FP, j = c - sc * FP;
-            int src = j - padl;  // one wrap suffices: F >= k1 (_is_valid)
-            src += (src < 0) ? F : 0;
-            src -= (src >= F) ? F : 0;
-            tile[c] = tiles[(size_t)w * SF + sc * F + src];
+        // ---- which scans have events
+        for (int sc = tid; sc < S; sc += SCORE_THREADS) row_slot[sc] = -1;
+        __syncthreads();
+        const int e_lo = compact ? (int)header[4 + w] : 0, e_hi = compact ? (int)header[4 + w + 1] : 0;
+        if (compact) {
+            for (int e = e_lo + tid; e < e_hi; e += SCORE_THREADS) {
+                const int rem = (int)entries[e].cell - w * SF;
+                int sc = (int)((double)rem * inv_f);
+                if (rem - sc * F >= F) ++sc;
+                row_slot[sc] = 0;
+            }
+        } else {
+            for (int c = tid; c < SF; c += SCORE_THREADS)
+                if (tiles[(size_t)w * SF + c] != 0.0f) {
+                    int sc = (int)((double)c * inv_f);
+                    if (c - sc * F >= F) ++sc;
+                    row_slot[sc] = 0;
+                }
         }
         __syncthreads();
-        // pass 1: along the cycles, kernel centred at column k1 / 2 (default kernel: taps in registers,
-        // loop unrolled; four outputs per thread sharing one converted window measured no faster)
-        {
-            double kr[30];
-            if (fast) {
-#pragma unroll
-                for (int b = 0; b < 30; ++b) kr[b] = kv[b];
+        // compact them in scan order (S <= 256 scans per sweep: ballot + per-wavefront offsets)
+        int n_rows = 0;
+        for (int base = 0; base < S; base += SCORE_THREADS) {
+            const int sc = base + tid;
+            const bool has = sc < S && row_slot[sc] == 0;
+            const unsigned long long mask = __ballot(has);
+            const int wv = tid / ADH_WAVE, ln = tid % ADH_WAVE;
+            if (ln == 0) wave_rows[wv] = __popcll(mask);
+            __syncthreads();
+            int before = n_rows;
+            for (int q = 0; q < wv; ++q) before += wave_rows[q];
+            int total = 0;
+            for (int q = 0; q < SCORE_THREADS / ADH_WAVE; ++q) total += wave_rows[q];
+            if (has) {
+                const int slot = before + __popcll(mask & ((1ull << ln) - 1ull));
+                row_slot[sc] = (int16_t)slot;
+                row_list[slot] = (int16_t)sc;
             }
-            for (int c = tid; c < SF; c += SCORE_THREADS) {
-                const int sc = c / F, f = c - sc * F;
-                const float *rp = tile + sc * FP + padl + f + h1;  // rp[-b] = x[sc][(f + h1 - b) mod F]
-                double acc = 0.0;
-                if (fast) {
-#pragma unroll
-                    for (int b = 0; b < 30; ++b) acc = fma(kr[b], (double)rp[-b], acc);
-                } else {
-                    for (int b = 0; b < k1; ++b) acc = fma(kv[b], (double)rp[-b], acc);
-                }
-                const float v = (float)acc;
-                tmp[(padt + sc) * F + f] = v;
-                if (sc < h0) tmp[(padt + S + sc) * F + f] = v;            // copy below the last scan
-                if (sc >= S - padt) tmp[(sc - (S - padt)) * F + f] = v;  // copy above the first (S >= k0, _is_valid)
-            }
+            n_rows += total;
+            __syncthreads();
         }
-        __syncthreads();
-        // pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group
-        {
-            float *lsum = ls;
-            double kr[30];
-            if (fast) {
-#pragma unroll
-                for (int a = 0; a < 30; ++a) kr[a] = ku[a];
-            }
-            for (int c = tid; c < SF; c += SCORE_THREADS) {
-                const int sc = c / F, f = c - sc * F;
-                const float *cp = tmp + (padt + sc + h0) * F + f;  // cp[-a * F] = pass1[(sc + h0 - a) mod S][f]
-                double acc = 0.0;
-                if (fast) {
-#pragma unroll
-                    for (int a = 0; a < 30; ++a) acc = fma(kr[a], (double)cp[-a * F], acc);
-                } else {
-                    for (int a = 0; a < k0; ++a) acc = fma(ku[a], (double)cp[-a * F], acc);
-                }
-                const float sm = (float)acc;
-                lsum[c] += (float)log((double)(sm + 1.0f));  // _build_features (selection.py:206-226)
-            }
+        if (n_rows == 0) {  // an empty tile smooths to zeros: log(0 + 1) = 0 changes nothing
             if (w == K - 1) {
-                // fragment sum complete: park it in the (consumed) first tile of the scratch block, the
-                // LDS array starts over for the isotopes (every thread owns the same cells in both loops)
                 for (int c = tid; c < SF; c += SCORE_THREADS) {
                     park[c] = ls[c];
                     ls[c] = 0.0f;
                 }
             }
+            __syncthreads();
+            continue;
+        }
+        // the rows of the events, dense along the cycles
+        for (int c = tid; c < n_rows * F; c += SCORE_THREADS) rows[c] = 0.0f;
+        __syncthreads();
+        if (compact) {
+            for (int e = e_lo + tid; e < e_hi; e += SCORE_THREADS) {
+                const SelEntry en = entries[e];
+                const int rem = (int)en.cell - w * SF;
+                int sc = (int)((double)rem * inv_f);
+                if (rem - sc * F >= F) ++sc;
+                rows[(int)row_slot[sc] * F + (rem - sc * F)] = en.x;
+            }
+        } else {
+            for (int c = tid; c < n_rows * F; c += SCORE_THREADS) {
+                int slot = (int)((double)c * inv_f);
+                if (c - slot * F >= F) ++slot;
+                rows[c] = tiles[(size_t)w * SF + (int)row_list[slot] * F + (c - slot * F)];
+            }
+        }
+        // for every scan: the last row at or below (s + h0) mod S, circularly
+        for (int sc = tid; sc < S; sc += SCORE_THREADS) {
+            int top = sc + h0;
+            top -= top >= S ? S : 0;
+            int a = 0, b = n_rows;  // number of rows <= top
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if ((int)row_list[mid] <= top) a = mid + 1; else b = mid;
+            }
+            row_top[sc] = (int16_t)(a == 0 ? n_rows - 1 : a - 1);
+        }
+        __syncthreads();
+        // ---- pass 1, in place: along the cycles, kernel centred at column k1 / 2.  A step takes whole rows:
+        // every thread reads the taps of its cell, then all write.
+        for (int base = 0; base < n_rows; base += rows_per_step) {
+            const int lr = tid / F, f = tid - lr * F;
+            const int slot = base + lr;
+            const bool act = lr < rows_per_step && slot < n_rows;
+            float v = 0.0f;
+            if (act) {
+                const float *rp = rows + slot * F;
+                double acc = 0.0;
+                int col = f + h1;  // column of tap b: (f + h1 - b) mod F
+                col -= col >= F ? F : 0;
+                for (int bb = 0; bb < k1; ++bb) {
+                    acc = fma(kv[bb], (double)rp[col], acc);
+                    col = col == 0 ? F - 1 : col - 1;
+                }
+                v = (float)acc;
+            }
+            __syncthreads();
+            if (act) rows[slot * F + f] = v;
+            __syncthreads();
+        }
+        // ---- pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group
+        for (int c = tid; c < SF; c += SCORE_THREADS) {
+            int sc = (int)((double)c * inv_f);
+            if (c - sc * F >= F) ++sc;
+            const int f = c - sc * F;
+            int idx = (int)row_top[sc];
+            double acc = 0.0;
+            for (int t = 0; t < n_rows; ++t) {
+                int a = sc + h0 - (int)row_list[idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
+                a += a < 0 ? S : 0;
+                a -= a >= S ? S : 0;
+                if (a >= k0) break;
+                acc = fma(ku[a], (double)rows[idx * F + f], acc);
+                idx = idx == 0 ? n_rows - 1 : idx - 1;
+            }
+            const float sm = (float)acc;
+            if (sm != 0.0f) ls[c] += (float)log((double)(sm + 1.0f));  // _build_features (selection.py:206-226); log(1) = 0
+        }
+        if (w == K - 1) {
+            // fragment sum complete: park it in the scratch block, the LDS array starts over for the isotopes
+            // (every thread owns the same cells in both loops)
+            for (int c = tid; c < SF; c += SCORE_THREADS) {
+                park[c] = ls[c];
+                ls[c] = 0.0f;
+            }
         }
         __syncthreads();
     }
-    // feature = fragment sum + isotope sum (float32), in place
-    for (int c = tid; c < SF; c += SCORE_THREADS) ls[c] = park[c] + ls[c];
+    // feature = fragment sum + isotope sum (float32); it goes through the parked tile, because the float64
+    // scores take the place of both LDS tiles
+    for (int c = tid; c < SF; c += SCORE_THREADS) park[c] = park[c] + ls[c];
     __syncthreads();
     // ---- score (selection.py:396-421): kept as the float32 feature + the affine map
     double mean = cfg.feature_mean, sd = cfg.feature_std, weight = cfg.feature_weight;
     if (!cfg.use_weighted_score) {
         if (tid == 0) {  // amean1 / astd1 (selection/utils.py:118-133), sequential
             double m = 0;
-            for (int c = 0; c < SF; ++c) m += (double)ls[c];
+            for (int c = 0; c < SF; ++c) m += (double)park[c];
             m /= (double)SF;
             double v = 0;
             for (int c = 0; c < SF; ++c) {
-                const double d = (double)ls[c] - m;
+                const double d = (double)park[c] - m;
                 v += d * d;
             }
             s_norm[0] = m;
@@ -276,11 +620,12 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
         sd = s_norm[1];
         weight = 1.0;
     }
-    double *score = reinterpret_cast<double *>(tile);  // tile + tmp hold SF doubles
+    double *score = reinterpret_cast<double *>(smem);  // the two float tiles hold SF doubles
     for (int c = tid; c < SF; c += SCORE_THREADS) {
-        const float ft = ls[c];
+        const float ft = park[c];
         score[c] = weight * ((double)ft - mean) / (sd + 1e-6);
     }
+    for (int c = tid; c < (SF + 31) / 32; c += SCORE_THREADS) flag[c] = 0u;
     __syncthreads();
     auto A = [&](int s, int f) { return score[s * F + f]; };
     // ---- find_peaks_2d / find_peaks_1d (selection/utils.py:49-115): flag, then top_n rounds of a
@@ -295,7 +640,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
             pk = A(s - 2, p) < A(s - 1, p) && A(s - 1, p) < A(s, p) && A(s, p) > A(s + 1, p) && A(s + 1, p) > A(s + 2, p);
             pk = pk && A(s, p - 2) < A(s, p - 1) && A(s, p - 1) < A(s, p) && A(s, p) > A(s, p + 1) && A(s, p + 1) > A(s, p + 2);
         }
-        flag[c] = pk ? 1 : 0;
+        if (pk) atomicOr(&flag[c >> 5], 1u << (c & 31));
     }
     __syncthreads();
     const int top_n = (int)min((int64_t)MAX_CAND, cfg.candidate_count);
@@ -304,7 +649,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
         double best = -INFINITY;
         int best_i = -1;
         for (int c = tid; c < SF; c += SCORE_THREADS)
-            if (flag[c]) {
+            if ((flag[c >> 5] >> (c & 31)) & 1u) {
                 const double v = score[c];
                 if (best_i < 0 || v > best || (v == best && c > best_i)) {
                     best = v;
@@ -333,7 +678,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kern
         if (tid == 0) {
             pk_idx[n_pk] = win;
             pk_val[n_pk] = red_v[0];
-            flag[win] = 0;
+            flag[win >> 5] &= ~(1u << (win & 31));
         }
         ++n_pk;
         __syncthreads();

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
 import synthetic as syn
-    from alphadia_amd import _abi, runtime  # noqa: E402
+from alphadia_amd import _abi, runtime  # noqa: E402
 from alphadia_amd.scoring import fragment_columns  # noqa: E402
 from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel  # noqa: E402
 
