@@ -705,12 +705,23 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
     // batches of precursors whose tiles fit a bounded scratch slab
-    uint64_t budget = 2ull << 30;
+    // the scratch slab of the handle is used (kept between calls; only reserved memory: a precursor's tiles are
+    // normally kept in sparse form and touch a few KB of their block); batches follow each other on the
+    // stream, so a batch may reuse the slab of the one before without the host waiting
+    uint64_t budget = 8ull << 30;
+    if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
     {
-        // (the slab is only reserved: a precursor's tiles are normally kept in sparse form and touch a few KB of it)
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 4, 32ull << 30));
-        if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
+        uint64_t all = 0, biggest = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const selim::PrecRec &r = recs[(size_t)i];
+            const uint64_t need = selim::SEL_HEADER +
+                                  (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
+            const uint64_t aligned = (need + 255) / 256 * 256;
+            all += aligned;
+            biggest = std::max(biggest, aligned);
+        }
+        budget = std::max(std::min(budget, all), biggest);
+        budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
     }
     DeviceBuffers tmp;
     const double *d_ku = nullptr, *d_kv = nullptr;
@@ -738,9 +749,17 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
     unsigned char *d_scratch = nullptr;
     selim::PrecRec *d_recs = nullptr;
     if (rc == ADH_OK) {
-        hipError_t e = hipMalloc((void **)&d_scratch, budget);
-        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
-        else tmp.ptrs.push_back(d_scratch);
+        if (h->scratch_slab_bytes < budget) {
+            // (exactly the budget: ensure_scratch's head-room is for scoring batches that grow from call to call)
+            hipError_t e = hipDeviceSynchronize();
+            if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+            h->scratch_slab = nullptr;
+            h->scratch_slab_bytes = 0;
+            if (e == hipSuccess) e = hipMalloc(&h->scratch_slab, budget);
+            if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
+            else h->scratch_slab_bytes = budget;
+        }
+        d_scratch = static_cast<unsigned char *>(h->scratch_slab);
     }
     if (rc == ADH_OK) {
         hipError_t e = hipMalloc((void **)&d_recs, std::max<size_t>((size_t)n * sizeof(selim::PrecRec), 16));
@@ -755,6 +774,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
+        // plan every batch on the host, one upload, then the kernels of the batches back to back
+        std::vector<std::pair<int64_t, int64_t>> batches;
         int64_t first = 0;
         while (first < n && rc == ADH_OK) {
             uint64_t off = 0;
@@ -773,26 +794,26 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 rc = fail(ADH_ERR_UNSUPPORTED, "one precursor's tiles exceed the selection scratch budget");
                 break;
             }
-            const int32_t cnt = (int32_t)(last - first);
-            hipError_t e = hipMemcpyAsync(d_recs + first, recs.data() + first, (size_t)cnt * sizeof(selim::PrecRec),
-                                          hipMemcpyHostToDevice, h->stream);
+            batches.emplace_back(first, last);
+            first = last;
+        }
+        if (rc == ADH_OK) {
+            hipError_t e = hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(selim::PrecRec), hipMemcpyHostToDevice, h->stream);
             if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
-            if (e == hipSuccess) {
+            for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) {
+                const int64_t b0 = batches[b].first;
+                const int32_t cnt = (int32_t)(batches[b].second - b0);
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
-                                   h->d_lib, d_recs + first, cnt, *cfg, (int32_t)n_iso, d_scratch);
+                                   h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
-                                   h->stream, T, d_recs + first, cnt, first, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt);
+                                   h->stream, T, d_recs + b0, cnt, b0, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the host plan of the next batch reuses the slab
-            if (e != hipSuccess) {
-                rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
-                break;
-            }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
-            first = last;
+            if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);

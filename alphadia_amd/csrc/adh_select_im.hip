@@ -22,7 +22,7 @@ namespace selim {
 
 constexpr int MAX_W = 64;    // m/z windows (fragments + isotopes) per precursor
 constexpr int MAX_CAND = 16;
-constexpr int SCORE_THREADS = 256;
+constexpr int SCORE_THREADS = 512;
 constexpr int SEL_HEADER = 32 + 4 * (MAX_W + 2);  // bytes in front of the tiles of a precursor (see below)
 constexpr uint32_t SEL_DENSE = 0u, SEL_COMPACT = 1u;
 struct SelEntry {
@@ -415,7 +415,7 @@ size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f, int k0
     return (b + 15) / 16 * 16;
 }
 
-__global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kernel(
+__global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_kernel(
     DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
     adh_selection_config_t cfg, const double *__restrict__ ku_g, const double *__restrict__ kv_g, int32_t k0,
     int32_t k1, int32_t cap_cells, int32_t cap_s, int32_t cap_f, unsigned char *__restrict__ scratch,
