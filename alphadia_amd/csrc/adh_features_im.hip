@@ -2,10 +2,10 @@
 //
 // Same phases as adh_features.hip (the restatement of Candidate.process after get_dense,
 // alphadia/search/scoring/containers/candidate.py:248-481) with a REAL scan axis:
-//   * the fragment tile [K][O][S][F] stays in the HBM scratch block and is streamed ONCE, one
-//     lane per (fragment, observation, channel) plane: scan profile, frame profile, row sum
-//     and weighted centre means are all folded in that pass in the reference's order; LDS
-//     holds profiles, the precursor tile, the template and the weight tables only
+//   * the tiles normally arrive in sparse form (sorted non-zero cells, adh_device.h); the fragment
+//     cells are folded ONCE, one lane per (fragment, observation) plane: scan profile, frame
+//     profile, row sum and weighted centre means in the reference's order; LDS holds profiles,
+//     the template and the weight tables only
 //   * rt / mobility arrays are float64
 //     (TimsTOFTransposeJIT, alphadia/search/jitclasses/bruker_jit.py:35,45), which changes
 //     the typing of the quantification area and of the location / FWHM features

@@ -8,14 +8,15 @@
 // The reference builds, per call, a Python list of every (frame, scan) push of the candidate
 // box whose quadrupole window overlaps, then merge-joins it with the event list of every TOF
 // bin in the m/z window.  Here membership of an event in that list is decided arithmetically
-// (frame range, scan range, quadrupole test on the cycle table), and the work is split into
-// independent (fragment, cycle) tasks, one per lane: a task walks the TOF bins of its fragment
-// in ascending order and, inside a bin, binary-searches the first event of its cycle.  A tile
-// cell (fragment, observation, scan, cycle) is only ever touched by one task, in the same
-// order as in the reference (TOF ascending, then push ascending), so the running
-// intensity-weighted m/z is reproduced exactly.  The TOF-major event lists are read with
-// 4-byte / 2-byte loads; the tile itself lives in the candidate's HBM scratch block
-// (zero-filled first) and is read back coalesced by the feature kernel.
+// (frame range, scan range, quadrupole test on the cycle table).  An ion-mobility tile is ~1 %
+// full, so it is not built: per (window, TOF bin) the bin's events of the candidate's cycles are one
+// contiguous range (found through the staged (bin, cycle) index), the ranges are streamed, the few
+// events that pass the tests are sorted by (cell, stream position) and folded per cell in that
+// order - TOF ascending, then push ascending, the reference's order, so the running
+// intensity-weighted m/z is reproduced exactly - and the non-zero cells leave as sorted
+// (cell, intensity, m/z) entries (adh_device.h: ADH_IM_MODE_COMPACT).  A candidate that does not fit
+// the LDS lists gets the dense tiles in its HBM scratch block instead: zero fill, then independent
+// (window, cycle) tasks, one per lane, each the only one to touch its cells.
 #include "adh_device.h"
 
 namespace gather_im {
