@@ -537,7 +537,11 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
             }
             if ((size_t)d->n_tof * (size_t)(blocks + 1) * 4 <= budget) {
                 uint32_t *idx = nullptr;
-                HIP_TRY(hipMalloc((void **)&idx, (size_t)d->n_tof * (size_t)(blocks + 1) * 4));
+                if (hipMalloc((void **)&idx, (size_t)d->n_tof * (size_t)(blocks + 1) * 4) != hipSuccess) {
+                    (void)hipGetLastError();  // no room for the index: the kernels search instead
+                    idx = nullptr;
+                }
+                if (idx) {
                 h->run_buf.ptrs.push_back(idx);
                 const unsigned grid = (unsigned)std::min<int64_t>(d->n_tof, 1 << 20);
                 hipLaunchKernelGGL(adh_index_im_kernel, dim3(grid), dim3(ADH_WAVE), 0, h->stream, t.tof_indptr, t.push,
@@ -548,6 +552,7 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
                 t.cyc_idx = idx;
                 t.cyc_shift = shift;
                 t.cyc_cols = (int32_t)(blocks + 1);
+                }
             }
         }
     }
@@ -776,6 +781,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         (void)hipEventCreate(&e1);
         // plan every batch on the host, one upload, then the kernels of the batches back to back
         std::vector<std::pair<int64_t, int64_t>> batches;
+        int32_t debug_dense = 0;
+        if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_DENSE")) debug_dense = atoi(dbg);
         int64_t first = 0;
         while (first < n && rc == ADH_OK) {
             uint64_t off = 0;
@@ -804,7 +811,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 const int64_t b0 = batches[b].first;
                 const int32_t cnt = (int32_t)(batches[b].second - b0);
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
-                                   h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch);
+                                   h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
                                    h->stream, T, d_recs + b0, cnt, b0, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt);
                 e = hipGetLastError();

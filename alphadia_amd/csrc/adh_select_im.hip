@@ -52,7 +52,7 @@ static_assert(sizeof(PrecRec) == 48, "PrecRec must be 48 bytes");
 // precursor are ~0.1 % full (176 scans x 48 cycles x 15 windows, a handful of events per window).
 __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     DevTims run, const LibRec *__restrict__ lib, const selim::PrecRec *__restrict__ recs, int32_t n_prec,
-    adh_selection_config_t cfg, int32_t n_iso, unsigned char *__restrict__ scratch) {
+    adh_selection_config_t cfg, int32_t n_iso, unsigned char *__restrict__ scratch, int32_t debug_dense) {
     using namespace selim;
     __shared__ float s_mz[MAX_W];       // window centres: fragments ascending, then isotopes
     __shared__ int s_tlo[MAX_W], s_thi[MAX_W];
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     __syncthreads();
     const int P = w_p0[W];
     const int64_t n_cells = (int64_t)W * S * F;
-    bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || n_cells >= (1 << 23);
+    bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || n_cells >= (1 << 23) ||
+                debug_dense != 0;  // (developer switch ADH_DEBUG_SELECT_IM_DENSE: dense tiles for every precursor)
     if (!over) {
         for (int p = lane; p < P; p += ADH_WAVE) {
             int w = 0;

@@ -303,6 +303,43 @@ def test_hip_timstof_selection_matches_oracle_and_golden(ctx, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_hip_timstof_selection_tile_forms_and_indices_agree(ctx, monkeypatch):
+    """Sparse tiles / dense tiles, search indices on / off / one column per block of cycles: the same
+    candidate table, bit for bit (scores included)."""
+    import synthetic as syn
+    from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel
+
+    case = syn.make_timstof_case(n_precursors=250, n_cycles=90, config_id=46, per_precursor=1, n_ms2_frames=5,
+                                 windows_per_frame=2, scan_max_index=96, planted_fraction=0.6)
+    case.dia.has_mobility = True
+    cfg = CandidateSelectionConfig()
+    cfg.update(dict(rt_tolerance=40.0, mobility_tolerance=0.08, candidate_count=3, peak_len_rt=3.0, sigma_scale_rt=0.5,
+                    peak_len_mobility=0.02))
+    kern = gaussian_kernel(case.dia, cfg.peak_len_rt, cfg.sigma_scale_rt, cfg.kernel_size, cfg.peak_len_mobility,
+                           cfg.sigma_scale_mobility)
+    pdf = case.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+    cols = fragment_columns(case.library.fragment_df, "mz_library")
+    pm = _pack(pdf)
+
+    def run():
+        ctx.stage_run(case.dia, force=True)
+        ctx.stage_fragments(*cols, force=True)
+        got = ctx.select_candidates(pm, cfg, kern)
+        return {c: np.array(got[c], copy=True) for c in CANDIDATE_COLUMNS}
+
+    base = run()
+    assert len(base["precursor_idx"]) > 100
+    for env in (dict(ADH_DEBUG_SELECT_IM_DENSE="1"), dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1")):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = run()
+        for c in CANDIDATE_COLUMNS:
+            assert np.array_equal(got[c], base[c]), (env, c)
+    ctx.stage_run(case.dia, force=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT_IM", "5")))))
 def test_hip_timstof_selection_randomized(ctx, oracle_lib, seed):
     """Differential test on ion-mobility runs: random geometry and settings, HIP == oracle."""
