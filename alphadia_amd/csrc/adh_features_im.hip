@@ -861,7 +861,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     asmv.merr = merr; asmv.kmap = kmap; asmv.ord = ord; asmv.g_type = g_type; asmv.g_pos = g_pos;
     asmv.n_present = n_present; asmv.K0 = K0; asmv.top3 = 0.0f;
     if (lane == 0) {
-        feat::assemble_part1(asmv, I, O, K);
+        if (caps.stop_phase != 20) feat::assemble_part1(asmv, I, O, K);  // (20: developer ablation, no assembly)
         // location_features.py:8-33 with float64 mobility / rt arrays
         featv[0] = (float)(run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1]);
         featv[1] = (float)(run.rt[r.frame_stop - 1] - run.rt[r.frame_start]);
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     adh_wave_sync();
     if (lane == 0) {
         asmv.top3 = top3;
-        feat::assemble_part2(asmv, O, K, F);
+        if (caps.stop_phase != 20) feat::assemble_part2(asmv, O, K, F);
         float agg = 0;
         for (int k = 0; k < K; ++k) {
             float ml = 0;
