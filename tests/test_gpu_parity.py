@@ -59,6 +59,12 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
         flat = (np.nanmax(x, axis=1) == np.nanmin(x, axis=1)) if x.shape[1] else np.zeros(len(x), bool)
         gf[flat, f] = 0.0
         ef[flat, f] = 0.0
+    # feature 16 (correlation of the isotope intensities with the isotope heights, save_corrcoeff) is the
+    # same kind of knife edge: isotope planes of equal height (e.g. one event of 5 counts each) give
+    # numerator / (denominator + 1e-12) with both ~1e-16 or exactly 0, depending on the last bit of exp()
+    knife = ((gf[:, 16] == 0.0) | (ef[:, 16] == 0.0)) & (np.abs(gf[:, 16]) < 1e-3) & (np.abs(ef[:, 16]) < 1e-3)
+    gf[knife, 16] = 0.0
+    ef[knife, 16] = 0.0
     assert np.array_equal(np.isnan(gf), np.isnan(ef)), "NaN pattern differs"
     for f in EXACT_FEATURES:
         assert np.array_equal(gf[:, f], ef[:, f]), f"feature {f} must be exact"
