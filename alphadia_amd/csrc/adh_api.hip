@@ -783,6 +783,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         std::vector<std::pair<int64_t, int64_t>> batches;
         int32_t debug_dense = 0;
         if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_DENSE")) debug_dense = atoi(dbg);
+        int32_t debug_abl = 0;
+        if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_ABL")) debug_abl = atoi(dbg);
         int64_t first = 0;
         while (first < n && rc == ADH_OK) {
             uint64_t off = 0;
@@ -813,7 +815,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
                                    h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS), lds,
-                                   h->stream, T, d_recs + b0, cnt, b0, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt);
+                                   h->stream, T, d_recs + b0, cnt, b0, *cfg, d_ku, d_kv, k0, k1, cap_cells, cap_s, cap_f, d_scratch, dt, debug_abl);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipEventRecord(e1, h->stream);

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
     adh_selection_config_t cfg, const double *__restrict__ ku_g, const double *__restrict__ kv_g, int32_t k0,
     int32_t k1, int32_t cap_cells, int32_t cap_s, int32_t cap_f, unsigned char *__restrict__ scratch,
-    DevCandTable out) {
+    DevCandTable out, int32_t debug_abl) {
     using namespace selim;
     extern __shared__ __align__(16) unsigned char smem[];
     // The smoothing is the separable circular convolution
@@ -597,10 +597,10 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
             __syncthreads();
         }
         // ---- pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group
-        for (int c = tid; c < SF; c += SCORE_THREADS) {
-            int sc = (int)((double)c * inv_f);
-            if (c - sc * F >= F) ++sc;
-            const int f = c - sc * F;
+        // (a thread keeps its column and strides over the scans: no index arithmetic per cell)
+        const int p2_rows = SCORE_THREADS / F, p2_lr = tid / F, p2_f = tid - p2_lr * F;
+        for (int sc = p2_lr; sc < (debug_abl == 2 || p2_lr >= p2_rows ? 0 : S); sc += p2_rows) {  // (2: developer ablation, no pass 2)
+            const int f = p2_f, c = sc * F + f;
             int idx = (int)row_top[sc];
             double acc = 0.0;
             for (int t = 0; t < n_rows; ++t) {
@@ -614,12 +614,13 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
             const float sm = (float)acc;
             if (sm != 0.0f) {  // _build_features (selection.py:206-226); log(1) = 0
                 const float x = sm + 1.0f;
-                ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
+                if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
+                else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
             }
         }
         if (w == K - 1) {
             // fragment sum complete: park it in the scratch block, the LDS array starts over for the isotopes
-            // (every thread owns the same cells in both loops)
+            __syncthreads();  // (the cells are owned by other threads here than in pass 2)
             for (int c = tid; c < SF; c += SCORE_THREADS) {
                 park[c] = ls[c];
                 ls[c] = 0.0f;
