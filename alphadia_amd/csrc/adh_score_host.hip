@@ -144,12 +144,14 @@ int cand_reserve(adh_handle *h, int64_t n, int32_t n_iso) {
 }
 
 // H2D of rows [a, b) of every candidate column, asynchronous on `st`
-// Copy jobs done by a kernel: the candidate columns of a chunk when they sit in page-locked host memory -
-// one launch that reads the 14 host columns over PCIe instead of 14 DMA copies.  Measured: 5-10 % on
-// small batches (8 000 precursors host -> host 1.45 -> 1.33 ms: fewer driver calls), nothing on the
-// 3 M-candidate step (tried because the device-bound DMA copies slow the host-bound ones down when they
-// overlap, see adh_score_candidates; the host-bound stream is the limit either way).  ADH_H2D_KERNEL=0
-// switches back to hipMemcpyAsync, which is also what pageable columns get.
+// Copy jobs done by a kernel: the candidate columns of a SMALL range (<= 131 072 rows: the batches of the
+// optimisation loop, the short first chunk of a large call) when they sit in page-locked host memory - one
+// launch that reads the 14 host columns over PCIe instead of 14 DMA copies.  Measured: 5-10 % on small
+// batches (8 000 precursors host -> host 1.45 -> 1.33 ms: fewer driver calls).  Large ranges stay with the
+// DMA engine: a copy kernel sits on the CUs for the 4-5 ms the 0.2 GB of a 3 M-candidate step take over PCIe
+// and the gather kernel next to it ran 7 % slower, with nothing gained on the step (the host-bound stream
+// is the limit either way).  ADH_H2D_KERNEL=0 switches the kernel off; pageable columns always use
+// hipMemcpyAsync.
 struct CopyJobs {
     const unsigned char *src[16];
     unsigned char *dst[16];
@@ -202,7 +204,7 @@ int cand_upload_range(adh_handle *h, const adh_candidates_t *c, int64_t a, int64
         const unsigned char *src = static_cast<const unsigned char *>(col.host) + (size_t)a * col.elem;
         const size_t bytes = (size_t)(b - a) * col.elem;
         void *dev_view = nullptr;
-        if (by_kernel) {
+        if (by_kernel && b - a <= 131072) {  // (small ranges only: see above)
             hipPointerAttribute_t attr;
             if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
                 hipHostGetDevicePointer(&dev_view, const_cast<unsigned char *>(src), 0) == hipSuccess && dev_view) {
