@@ -635,68 +635,95 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         }
         return a;
     };
-    for (int64_t i = 0; i < n; ++i) {
-        selim::PrecRec &r = recs[(size_t)i];
-        memset(&r, 0, sizeof(r));
-        if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
-        if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
-        if ((int64_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]) + n_iso > selim::MAX_W)
-            return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
-        r.precursor_idx = pc->precursor_idx[i];
-        r.frag_start = pc->frag_start_idx[i];
-        r.frag_stop = pc->frag_stop_idx[i];
-        r.mz = pc->mz[i];
-        r.charge = pc->charge[i];
-        // frame limits: get_frame_indices (jitclasses/utils.py:24-88) with the zeroth frame
-        const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
-        const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), (double)lo) - rtv.begin();
-        const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), (double)hi) - rtv.begin();
-        const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
-        int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
-        len = 16 * (int64_t)std::ceil((double)len / 16.0);
-        int64_t cs = c_lo, ce = c_lo + len;
-        if (ce > cmax) {
-            ce = cmax;
-            cs = cmax - len;
-            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+    // the per-precursor limits (searches over rt / mobility, the "empty push query" test over L x S window
+    // rows) are independent: spread over the host threads (230 ms on one thread for 200 000 precursors)
+    struct Caps5 { int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1; };
+    auto plan_range = [&](int64_t i0, int64_t i1, Caps5 &c, int &err) {
+    for (int64_t i = i0; i < i1; ++i) {
+            selim::PrecRec &r = recs[(size_t)i];
+            memset(&r, 0, sizeof(r));
+            if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
+                { err = 1; return; }
+            if (pc->charge[i] == 0) { err = 2; return; }
+            if ((int64_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]) + n_iso > selim::MAX_W)
+                { err = 3; return; }
+            r.precursor_idx = pc->precursor_idx[i];
+            r.frag_start = pc->frag_start_idx[i];
+            r.frag_stop = pc->frag_stop_idx[i];
+            r.mz = pc->mz[i];
+            r.charge = pc->charge[i];
+            // frame limits: get_frame_indices (jitclasses/utils.py:24-88) with the zeroth frame
+            const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
+            const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), (double)lo) - rtv.begin();
+            const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), (double)hi) - rtv.begin();
+            const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
+            int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
+            len = 16 * (int64_t)std::ceil((double)len / 16.0);
+            int64_t cs = c_lo, ce = c_lo + len;
+            if (ce > cmax) {
+                ce = cmax;
+                cs = cmax - len;
+                if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+            }
+            // scan limits: _get_scan_indices (bruker_jit.py:204-245); ceil of a negative quotient
+            const float m_hi = (float)((double)pc->mobility[i] + cfg->mobility_tolerance);
+            const float m_lo = (float)((double)pc->mobility[i] - cfg->mobility_tolerance);
+            const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
+            const int64_t opt_len = 16 * (int64_t)std::ceil((double)(s_first - s_second) / 16.0);
+            int64_t ss = s_first, se = s_first - opt_len;
+            if (se < 0) {
+                se = 0;
+                ss = std::min<int64_t>(opt_len, SM);
+            }
+            const int64_t S = std::max<int64_t>(se - ss, 0), F = ce - cs;
+            r.cycle_start = (int32_t)cs;
+            r.n_cycles = (int32_t)std::max<int64_t>(F, 0);
+            r.scan_start = (int32_t)ss;
+            r.n_scans = (int32_t)S;
+            bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
+            if (ok) {
+                // an empty push query ends the precursor (bruker_jit.py:516-519, selection.py:40-49)
+                const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc->charge[i];
+                const double q_lo = (double)(float)((double)pc->mz[i] + 0.0), q_hi = (double)(float)((double)pc->mz[i] + off);
+                bool any_f = false, any_p = false;
+                for (int row = 0; row < L && !(any_f && any_p); ++row)
+                    for (int64_t sc = ss; sc < ss + S; ++sc) {
+                        const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
+                        any_f = any_f || (q_lo <= wh && q_hi >= wl);
+                        any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
+                    }
+                ok = any_f && any_p;
+            }
+            r.ok = ok ? 1 : 0;
+            if (ok) {
+                c.cap_cells = std::max<int32_t>(c.cap_cells, (int32_t)(S * F));
+                c.cap_tp = std::max<int32_t>(c.cap_tp, (int32_t)(S * (F + k1)));
+                c.cap_mp = std::max<int32_t>(c.cap_mp, (int32_t)((S + k0) * F));
+                c.cap_s = std::max<int32_t>(c.cap_s, (int32_t)S);
+                c.cap_f = std::max<int32_t>(c.cap_f, (int32_t)F);
+            }
         }
-        // scan limits: _get_scan_indices (bruker_jit.py:204-245); ceil of a negative quotient
-        const float m_hi = (float)((double)pc->mobility[i] + cfg->mobility_tolerance);
-        const float m_lo = (float)((double)pc->mobility[i] - cfg->mobility_tolerance);
-        const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
-        const int64_t opt_len = 16 * (int64_t)std::ceil((double)(s_first - s_second) / 16.0);
-        int64_t ss = s_first, se = s_first - opt_len;
-        if (se < 0) {
-            se = 0;
-            ss = std::min<int64_t>(opt_len, SM);
+    };
+    {
+        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 2048 + 1}));
+        std::vector<Caps5> caps((size_t)n_thr);
+        std::vector<int> errs((size_t)n_thr, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) {
+            const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
+            if (t + 1 < n_thr) pool.emplace_back(plan_range, i0, i1, std::ref(caps[(size_t)t]), std::ref(errs[(size_t)t]));
+            else plan_range(i0, i1, caps[(size_t)t], errs[(size_t)t]);
         }
-        const int64_t S = std::max<int64_t>(se - ss, 0), F = ce - cs;
-        r.cycle_start = (int32_t)cs;
-        r.n_cycles = (int32_t)std::max<int64_t>(F, 0);
-        r.scan_start = (int32_t)ss;
-        r.n_scans = (int32_t)S;
-        bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
-        if (ok) {
-            // an empty push query ends the precursor (bruker_jit.py:516-519, selection.py:40-49)
-            const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc->charge[i];
-            const double q_lo = (double)(float)((double)pc->mz[i] + 0.0), q_hi = (double)(float)((double)pc->mz[i] + off);
-            bool any_f = false, any_p = false;
-            for (int row = 0; row < L && !(any_f && any_p); ++row)
-                for (int64_t sc = ss; sc < ss + S; ++sc) {
-                    const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
-                    any_f = any_f || (q_lo <= wh && q_hi >= wl);
-                    any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
-                }
-            ok = any_f && any_p;
-        }
-        r.ok = ok ? 1 : 0;
-        if (ok) {
-            cap_cells = std::max<int32_t>(cap_cells, (int32_t)(S * F));
-            cap_tp = std::max<int32_t>(cap_tp, (int32_t)(S * (F + k1)));
-            cap_mp = std::max<int32_t>(cap_mp, (int32_t)((S + k0) * F));
-            cap_s = std::max<int32_t>(cap_s, (int32_t)S);
-            cap_f = std::max<int32_t>(cap_f, (int32_t)F);
+        for (std::thread &th : pool) th.join();
+        for (int t = 0; t < n_thr; ++t) {
+            if (errs[(size_t)t] == 1) return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+            if (errs[(size_t)t] == 2) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+            if (errs[(size_t)t] == 3) return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
+            cap_cells = std::max(cap_cells, caps[(size_t)t].cap_cells);
+            cap_tp = std::max(cap_tp, caps[(size_t)t].cap_tp);
+            cap_mp = std::max(cap_mp, caps[(size_t)t].cap_mp);
+            cap_s = std::max(cap_s, caps[(size_t)t].cap_s);
+            cap_f = std::max(cap_f, caps[(size_t)t].cap_f);
         }
     }
     cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
