@@ -603,12 +603,13 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
             const int f = p2_f, c = sc * F + f;
             int idx = (int)row_top[sc];
             double acc = 0.0;
-            for (int t = 0; t < n_rows; ++t) {
+            for (int t = 0; t < (debug_abl == 3 ? 0 : n_rows); ++t) {  // (3: developer ablation, no row walk)
                 int a = sc + h0 - (int)row_list[idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
                 a += a < 0 ? S : 0;
                 a -= a >= S ? S : 0;
                 if (a >= k0) break;
-                acc = fma(ku[a], (double)rows[idx * F + f], acc);
+                if (debug_abl == 4) acc += 1.0;  // (4: developer ablation, the walk without the taps)
+                else acc = fma(ku[a], (double)rows[idx * F + f], acc);
                 idx = idx == 0 ? n_rows - 1 : idx - 1;
             }
             const float sm = (float)acc;
