@@ -100,7 +100,8 @@ struct Layout {
 
 }  // namespace featim
 
-#define ADH_IM_STATIC_LDS 4096  // static LDS of adh_feature_im_kernel (chunk lists / Gram matrices)
+#define ADH_IM_STAGE 128          // cells staged per round of the tile passes (two per lane)
+#define ADH_IM_STATIC_LDS (ADH_IM_STAGE * 20)  // static LDS of adh_feature_im_kernel (chunk lists / Gram matrices: 2 176 B)
 size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
 
 __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
@@ -119,8 +120,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     double *const l_w = l_tm + ADH_WAVE;
     float *const l_v = reinterpret_cast<float *>(l_w + ADH_WAVE);
     float *const l_rx = l_v + ADH_WAVE;
-    float *const l_ry = l_rx + 3 * ADH_WAVE;
-    int *const l_cell = reinterpret_cast<int *>(l_ry + 3 * ADH_WAVE);
+    float *const l_ry = l_rx + ADH_WAVE;
     const Layout lay(caps);
     const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
@@ -239,16 +239,16 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     if (caps.stop_phase == 11) return;
     if (compact) {
         // ---- everything that reads the precursor tile, in ONE pass over its sparse form: the entries are
-        // the non-zero (scan, cycle, isotope) cells in that order, staged 192 at a time in the chunk lists.
+        // the non-zero (scan, cycle, isotope) cells in that order, staged ADH_IM_STAGE at a time in the chunk lists.
         //   template (O, S, F) (quadrupole.py:304-324): one lane per (scan, cycle) cell with any isotope
         //   isotope intensity sums (per scan, then over the scans) and the weighted centre means of the
         //   isotope planes around (scan, frame) = (S, 1) (precursor_features.py:52-66): sequential sums in
         //   (scan, cycle) order - lanes 0..5I-1 walk the staged entries, one sum each.  Empty cells add
         //   0 to every one of these sums, so skipping them changes nothing.
         double *const c_w = reinterpret_cast<double *>(pool);
-        uint32_t *const c_cell = reinterpret_cast<uint32_t *>(c_w + 192);
-        float *const c_x = reinterpret_cast<float *>(c_cell + 192);
-        float *const c_y = c_x + 192;
+        uint32_t *const c_cell = reinterpret_cast<uint32_t *>(c_w + ADH_IM_STAGE);
+        float *const c_x = reinterpret_cast<float *>(c_cell + ADH_IM_STAGE);
+        float *const c_y = c_x + ADH_IM_STAGE;
         for (int c = lane; c < OSF; c += ADH_WAVE) tpl[c] = 0.0f;
         const ImEntry *const pent = entries + n_fe;
         const int role = lane / I, iso = lane - role * I;  // role 0: intensity sum; 1, 2: intensity mean; 3, 4: m/z mean
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         // (a staged cell is packed as scan << 16 | cycle << 4 | isotope: the sequential walks below must
         // not divide)
         for (int base = 0; base < n_pe;) {
-            int cnt = min(192, n_pe - base);
+            int cnt = min(ADH_IM_STAGE, n_pe - base);
             for (int e = lane; e < cnt; e += ADH_WAVE) {
                 const ImEntry en = pent[base + e];
                 const int sf = (int)en.cell / I, i = (int)en.cell - sf * I, sc = sf / F, f = sf - sc * F;
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     //   weighted centre means of both channels         (features_utils.py:9-37)
     // Every (fragment, observation) plane has its own lane, which folds the plane's cells in the
     // reference's order (scan outer, cycle inner) with the running sums in registers.  A round stages
-    // QT = 192 / planes cells of every plane in the chunk lists (three per lane: the weights
-    // exp(-0.1 * distance to the template centre) are computed by all 64 lanes, and the three loads of the
+    // QT = ADH_IM_STAGE / planes cells of every plane in the chunk lists (two per lane: the weights
+    // exp(-0.1 * distance to the template centre) are computed by all 64 lanes, and the loads of the
     // next round are in flight meanwhile); lane l then folds the QT staged cells of plane l.  The planes
     // advance in parallel, so a signal-rich candidate costs (cells of its fullest plane) / QT rounds.
     // Ion-mobility tiles are sparse and adding a zero leaves every one of these sums unchanged: normally
@@ -458,22 +458,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             return en;
         };
         double *const s_w = reinterpret_cast<double *>(pool);
-        int *const s_c = reinterpret_cast<int *>(s_w + 192);
-        float *const s_v = reinterpret_cast<float *>(s_c + 192);
-        float *const s_y = s_v + 192;
+        int *const s_c = reinterpret_cast<int *>(s_w + ADH_IM_STAGE);
+        float *const s_v = reinterpret_cast<float *>(s_c + ADH_IM_STAGE);
+        float *const s_y = s_v + ADH_IM_STAGE;
         const double inv_f = 1.0 / (double)F;
         for (int pbase = 0; pbase < n_pl; pbase += ADH_WAVE) {
             const int np = min(ADH_WAVE, n_pl - pbase);
-            const int QT = 192 / np;
+            const int QT = ADH_IM_STAGE / np;
             const bool fl = lane < np;
             const int p = pbase + lane;
             const int beg_f = fl ? pl_beg[p] : 0, end_f = fl ? pl_end[p] : 0;
             int R = (end_f - beg_f + QT - 1) / QT;
             for (int off = 32; off > 0; off >>= 1) R = max(R, __shfl_xor(R, off));
-            int t_beg[3], t_end[3], t_j[3], t_o[3], t_psf[3];
-            ImEntry nxt[3];
+            int t_beg[ADH_IM_STAGE / ADH_WAVE], t_end[ADH_IM_STAGE / ADH_WAVE], t_j[ADH_IM_STAGE / ADH_WAVE], t_o[ADH_IM_STAGE / ADH_WAVE],
+                t_psf[ADH_IM_STAGE / ADH_WAVE];
+            ImEntry nxt[ADH_IM_STAGE / ADH_WAVE];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < ADH_IM_STAGE / ADH_WAVE; ++t) {
                 const int slot = lane + t * ADH_WAVE;
                 const int ps = slot / QT;
                 const bool okp = ps < np;
@@ -490,15 +491,15 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
             float fs = 0.0f;
             int cur_sc = -1;
             for (int rr = 0; rr < R; ++rr) {
-                ImEntry cur[3];
+                ImEntry cur[ADH_IM_STAGE / ADH_WAVE];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < ADH_IM_STAGE / ADH_WAVE; ++t) {
                     cur[t] = nxt[t];
                     const int e2 = t_beg[t] + (rr + 1) * QT + t_j[t];
                     if (e2 < t_end[t]) nxt[t] = fetch(e2);
                 }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < ADH_IM_STAGE / ADH_WAVE; ++t) {
                     const int e = t_beg[t] + rr * QT + t_j[t];
                     if (e < t_end[t]) {
                         const int rem = (int)cur[t].cell - t_psf[t];
