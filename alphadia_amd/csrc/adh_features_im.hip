@@ -40,21 +40,26 @@ struct Layout {
     int Kc, Oc, Sc, Fc, Ic;
     __host__ __device__ Layout(const Caps &c) : Kc(c.k), Oc(c.o), Sc(c.s), Fc(c.f), Ic(c.i) {}
     // doubles
-    __host__ __device__ int d_qtf() const { return 0; }                      // [Ic][Oc][Sc]
-    __host__ __device__ int d_omz() const { return d_qtf() + Ic * Oc * Sc; }
+    // (the transfer function is dead after the template; the per-fragment results and the frame times,
+    // born later, take its place)
+    __host__ __device__ int d_qtf() const { return 0; }                      // [Ic][Oc][Sc], early
+    __host__ __device__ int qtf_size() const {
+        const int a = Ic * Oc * Sc, b = 4 * Kc + Fc;
+        return a > b ? a : b;
+    }
+    __host__ __device__ int d_pk() const { return d_qtf(); }                 // [4][Kc], late
+    __host__ __device__ int d_frt() const { return d_qtf() + 4 * Kc; }       // [Fc] frame rt (float64), late
+    __host__ __device__ int d_omz() const { return d_qtf() + qtf_size(); }
     __host__ __device__ int d_ohe() const { return d_omz() + Kc * Oc; }
     __host__ __device__ int d_omzu() const { return d_ohe() + Kc * Oc; }  // per selected fragment,
     __host__ __device__ int d_oheu() const { return d_omzu() + Kc * Oc; } // before the presence mask
     __host__ __device__ int d_accw() const { return d_oheu() + Kc * Oc; } // [2][Kc*Oc] weight sums
-    __host__ __device__ int d_pk() const { return d_accw() + 2 * Kc * Oc; }   // [4][Kc]
-    __host__ __device__ int d_po() const { return d_pk() + 4 * Kc; }     // [2][Oc]
+    __host__ __device__ int d_po() const { return d_accw() + 2 * Kc * Oc; }   // [2][Oc]
     __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]
-    __host__ __device__ int d_frt() const { return d_pi() + 2 * Ic; }    // [Fc] frame rt (float64)
-    __host__ __device__ int n_double() const { return d_frt() + Fc; }
+    __host__ __device__ int n_double() const { return d_pi() + 2 * Ic; }
     // floats
     __host__ __device__ int smax() const { return Sc > Fc ? Sc : Fc; }
-    __host__ __device__ int f_wa() const { return 0; }                            // work [Kc*Fc]
-    __host__ __device__ int f_wb() const { return Kc * Fc; }                      // work [Kc*Oc*max(Sc,Fc)]
+    __host__ __device__ int f_wb() const { return 0; }                            // work [Kc*Oc*max(Sc,Fc)]
     // Two regions are used twice.  R1 holds the template until its profiles are taken, then the masked
     // frame / scan profiles; R2 holds the profiles before the presence mask, then the scan envelopes and
     // the quantification profiles.  (LDS per block is what bounds the resident waves of this kernel, and
@@ -148,7 +153,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     if (lane == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
     if (caps.stop_phase == 10) return;  // developer ablation switches (ADH_DEBUG_IM)
 
-    float *const work_a = Fl + lay.f_wa();
     float *const work_b = Fl + lay.f_wb();
     float *const ffp_u = Fl + lay.f_ffpu();
     float *const fsp_u = Fl + lay.f_fspu();
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
 
     if (caps.stop_phase == 6) return;
     // =========================== profile features (profile_features.py:18-206)
-    float *isl = work_a, *nrm = work_b;  // free again once the scan correlation is done
+    float *isl = bp, *nrm = work_b;  // (the quantification profiles are done with; work_b is free again once the scan correlation is done)
     if (cfg.experimental_xic) {
         for (int c = lane; c < K * F; c += ADH_WAVE) {
             int k = c / F, f = c - k * F;
