@@ -50,6 +50,7 @@ namespace selim {
 constexpr int MAX_W = 64;    // m/z windows (fragments + isotopes) per precursor
 constexpr int MAX_CAND = 16;
 constexpr int SCORE_THREADS = 512;
+constexpr int SEL_BATCH = 4;  // windows per batch of the score kernel (<= SCORE_THREADS / 64)
 constexpr int SEL_HEADER = 32 + 4 * (MAX_W + 2);  // bytes in front of the tiles of a precursor (see below)
 constexpr uint32_t SEL_DENSE = 0u, SEL_COMPACT = 1u;
 struct SelEntry {
@@ -439,7 +440,7 @@ size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f, int k0
     size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile, later the float64 scores
     b += (size_t)(k0 + k1 + cap_s + cap_f) * 8;          // kernel factors, scan / cycle profiles
     b += (size_t)((cap_cells + 31) / 32) * 4;            // peak flags, one bit per cell
-    b += (size_t)cap_s * 3 * 2 + 16;                     // row tables
+    b += (size_t)cap_s * 3 * 2 * selim::SEL_BATCH + 16;  // row tables of a batch of windows
     return (b + 15) / 16 * 16;
 }
 
@@ -463,15 +464,16 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     double *kv = ku + k0;
     double *mob = kv + k1, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
     uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + cap_f);   // peak flags, one bit per cell
+    // per window g of a batch, at [g * S ...]:
     int16_t *row_slot = reinterpret_cast<int16_t *>(flag + (cap_cells + 31) / 32);  // [S] slot of a scan, -1: no event
-    int16_t *row_list = row_slot + cap_s;               // [n_rows] scans with events, ascending
-    int16_t *row_top = row_list + cap_s;                // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
+    int16_t *row_list = row_slot + SEL_BATCH * cap_s;   // [n_rows] scans with events, ascending
+    int16_t *row_top = row_list + SEL_BATCH * cap_s;    // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
     __shared__ double red_v[SCORE_THREADS];
     __shared__ int red_i[SCORE_THREADS];
     __shared__ int pk_idx[MAX_CAND];
     __shared__ double pk_val[MAX_CAND];
     __shared__ double s_norm[2];
-    __shared__ int wave_rows[SCORE_THREADS / ADH_WAVE + 1];
+    __shared__ int batch_rows[SEL_BATCH];  // scans with events of every window of the batch
     const int tid = threadIdx.x;
     const int i = blockIdx.x;
     if (i >= n_prec) return;
@@ -492,134 +494,165 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     const int h0 = k0 / 2, h1 = k1 / 2;
     const double inv_f = 1.0 / (double)F;
     const int rows_per_step = max(SCORE_THREADS / F, 1);  // pass 1: whole rows per step (F <= 256: host check)
-    for (int w = 0; w < W; ++w) {
-        // ---- which scans have events
-        for (int sc = tid; sc < S; sc += SCORE_THREADS) row_slot[sc] = -1;
+    // Windows are taken SEL_BATCH at a time: the block-wide phases (row discovery, row fill, pass 1) and
+    // their barriers are paid once per batch; pass 2 then runs window after window without a barrier (a
+    // thread owns its cells, the rows are read-only), which keeps the float32 log sums in window order.
+    const double inv_sf = 1.0 / (double)SF;
+    const int wv = tid / ADH_WAVE, ln = tid % ADH_WAVE;
+    for (int w0 = 0; w0 < W;) {
+        const int gmax = min(SEL_BATCH, (w0 < K ? K : W) - w0);  // (never across the fragment / isotope boundary)
+        // ---- which scans have events, per window of the batch
+        for (int c = tid; c < gmax * S; c += SCORE_THREADS) row_slot[c] = -1;
         __syncthreads();
-        const int e_lo = compact ? (int)header[4 + w] : 0, e_hi = compact ? (int)header[4 + w + 1] : 0;
+        const int e_lo = compact ? (int)header[4 + w0] : 0, e_hi = compact ? (int)header[4 + w0 + gmax] : 0;
         if (compact) {
             for (int e = e_lo + tid; e < e_hi; e += SCORE_THREADS) {
-                const int rem = (int)entries[e].cell - w * SF;
-                int sc = (int)((double)rem * inv_f);
-                if (rem - sc * F >= F) ++sc;
-                row_slot[sc] = 0;
+                const int rem = (int)entries[e].cell - w0 * SF;
+                int g = (int)((double)rem * inv_sf);
+                if (rem - g * SF >= SF) ++g;
+                const int r2 = rem - g * SF;
+                int sc = (int)((double)r2 * inv_f);
+                if (r2 - sc * F >= F) ++sc;
+                row_slot[g * S + sc] = 0;
             }
         } else {
-            for (int c = tid; c < SF; c += SCORE_THREADS)
-                if (tiles[(size_t)w * SF + c] != 0.0f) {
-                    int sc = (int)((double)c * inv_f);
-                    if (c - sc * F >= F) ++sc;
-                    row_slot[sc] = 0;
+            for (int c = tid; c < gmax * SF; c += SCORE_THREADS)
+                if (tiles[(size_t)w0 * SF + c] != 0.0f) {
+                    int g = (int)((double)c * inv_sf);
+                    if (c - g * SF >= SF) ++g;
+                    const int r2 = c - g * SF;
+                    int sc = (int)((double)r2 * inv_f);
+                    if (r2 - sc * F >= F) ++sc;
+                    row_slot[g * S + sc] = 0;
                 }
         }
         __syncthreads();
-        // compact them in scan order (S <= 256 scans per sweep: ballot + per-wavefront offsets)
-        int n_rows = 0;
-        for (int base = 0; base < S; base += SCORE_THREADS) {
-            const int sc = base + tid;
-            const bool has = sc < S && row_slot[sc] == 0;
-            const unsigned long long mask = __ballot(has);
-            const int wv = tid / ADH_WAVE, ln = tid % ADH_WAVE;
-            if (ln == 0) wave_rows[wv] = __popcll(mask);
-            __syncthreads();
-            int before = n_rows;
-            for (int q = 0; q < wv; ++q) before += wave_rows[q];
-            int total = 0;
-            for (int q = 0; q < SCORE_THREADS / ADH_WAVE; ++q) total += wave_rows[q];
-            if (has) {
-                const int slot = before + __popcll(mask & ((1ull << ln) - 1ull));
-                row_slot[sc] = (int16_t)slot;
-                row_list[slot] = (int16_t)sc;
-            }
-            n_rows += total;
-            __syncthreads();
-        }
-        if (n_rows == 0) {  // an empty tile smooths to zeros: log(0 + 1) = 0 changes nothing
-            if (w == K - 1) {
-                for (int c = tid; c < SF; c += SCORE_THREADS) {
-                    park[c] = ls[c];
-                    ls[c] = 0.0f;
+        // compact them in scan order: wavefront g takes window g (ballots, no block barrier)
+        if (wv < gmax) {
+            int cnt = 0;
+            for (int base = 0; base < S; base += ADH_WAVE) {
+                const int sc = base + ln;
+                const bool has = sc < S && row_slot[wv * S + sc] == 0;
+                const unsigned long long mask = __ballot(has);
+                if (has) {
+                    const int slot = cnt + __popcll(mask & ((1ull << ln) - 1ull));
+                    row_slot[wv * S + sc] = (int16_t)slot;
+                    row_list[wv * S + slot] = (int16_t)sc;
                 }
+                cnt += __popcll(mask);
             }
-            __syncthreads();
-            continue;
-        }
-        // the rows of the events, dense along the cycles
-        for (int c = tid; c < n_rows * F; c += SCORE_THREADS) rows[c] = 0.0f;
-        __syncthreads();
-        if (compact) {
-            for (int e = e_lo + tid; e < e_hi; e += SCORE_THREADS) {
-                const SelEntry en = entries[e];
-                const int rem = (int)en.cell - w * SF;
-                int sc = (int)((double)rem * inv_f);
-                if (rem - sc * F >= F) ++sc;
-                rows[(int)row_slot[sc] * F + (rem - sc * F)] = en.x;
-            }
-        } else {
-            for (int c = tid; c < n_rows * F; c += SCORE_THREADS) {
-                int slot = (int)((double)c * inv_f);
-                if (c - slot * F >= F) ++slot;
-                rows[c] = tiles[(size_t)w * SF + (int)row_list[slot] * F + (c - slot * F)];
-            }
-        }
-        // for every scan: the last row at or below (s + h0) mod S, circularly
-        for (int sc = tid; sc < S; sc += SCORE_THREADS) {
-            int top = sc + h0;
-            top -= top >= S ? S : 0;
-            int a = 0, b = n_rows;  // number of rows <= top
-            while (a < b) {
-                const int mid = (a + b) >> 1;
-                if ((int)row_list[mid] <= top) a = mid + 1; else b = mid;
-            }
-            row_top[sc] = (int16_t)(a == 0 ? n_rows - 1 : a - 1);
+            if (ln == 0) batch_rows[wv] = cnt;
         }
         __syncthreads();
-        // ---- pass 1, in place: along the cycles, kernel centred at column k1 / 2.  A step takes whole rows:
-        // every thread reads the taps of its cell, then all write.
-        for (int base = 0; base < n_rows; base += rows_per_step) {
-            const int lr = tid / F, f = tid - lr * F;
-            const int slot = base + lr;
-            const bool act = lr < rows_per_step && slot < n_rows;
-            float v = 0.0f;
-            if (act) {
-                const float *rp = rows + slot * F;
-                double acc = 0.0;
-                int col = f + h1;  // column of tap b: (f + h1 - b) mod F
-                col -= col >= F ? F : 0;
-                for (int bb = 0; bb < k1; ++bb) {
-                    acc = fma(kv[bb], (double)rp[col], acc);
-                    col = col == 0 ? F - 1 : col - 1;
+        // the windows of the batch whose rows fit the row storage together (S rows; one window always fits)
+        int gc = 0, tot = 0, base_r[SEL_BATCH];
+#pragma unroll
+        for (int g = 0; g < SEL_BATCH; ++g) {
+            base_r[g] = tot;
+            if (g < gmax && gc == g && tot + batch_rows[g] <= S) {
+                tot += batch_rows[g];
+                gc = g + 1;
+            }
+        }
+        if (tot > 0) {
+            // the rows of the events, dense along the cycles
+            for (int c = tid; c < tot * F; c += SCORE_THREADS) rows[c] = 0.0f;
+            __syncthreads();
+            if (compact) {
+                const int e_end = (int)header[4 + w0 + gc];
+                for (int e = e_lo + tid; e < e_end; e += SCORE_THREADS) {
+                    const SelEntry en = entries[e];
+                    const int rem = (int)en.cell - w0 * SF;
+                    int g = (int)((double)rem * inv_sf);
+                    if (rem - g * SF >= SF) ++g;
+                    const int r2 = rem - g * SF;
+                    int sc = (int)((double)r2 * inv_f);
+                    if (r2 - sc * F >= F) ++sc;
+                    int br = 0;
+#pragma unroll
+                    for (int q = 0; q < SEL_BATCH; ++q) br = q == g ? base_r[q] : br;
+                    rows[(br + (int)row_slot[g * S + sc]) * F + (r2 - sc * F)] = en.x;
                 }
-                v = (float)acc;
+            } else {
+#pragma unroll
+                for (int g = 0; g < SEL_BATCH; ++g)
+                    if (g < gc)
+                        for (int c = tid; c < batch_rows[g] * F; c += SCORE_THREADS) {
+                            int slot = (int)((double)c * inv_f);
+                            if (c - slot * F >= F) ++slot;
+                            rows[(base_r[g] + slot) * F + (c - slot * F)] =
+                                tiles[(size_t)(w0 + g) * SF + (int)row_list[g * S + slot] * F + (c - slot * F)];
+                        }
+            }
+            // for every scan: the last row at or below (s + h0) mod S, circularly
+            for (int c = tid; c < gc * S; c += SCORE_THREADS) {
+                const int g = c / S, sc = c - g * S;
+                const int nr = batch_rows[g];
+                int top = sc + h0;
+                top -= top >= S ? S : 0;
+                int lo = 0, hi = nr;  // number of rows <= top
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)row_list[g * S + mid] <= top) lo = mid + 1; else hi = mid;
+                }
+                row_top[c] = (int16_t)(lo == 0 ? nr - 1 : lo - 1);
             }
             __syncthreads();
-            if (act) rows[slot * F + f] = v;
-            __syncthreads();
-        }
-        // ---- pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group
-        // (a thread keeps its column and strides over the scans: no index arithmetic per cell)
-        const int p2_rows = SCORE_THREADS / F, p2_lr = tid / F, p2_f = tid - p2_lr * F;
-        for (int sc = p2_lr; sc < (debug_abl == 2 || p2_lr >= p2_rows ? 0 : S); sc += p2_rows) {  // (2: developer ablation, no pass 2)
-            const int f = p2_f, c = sc * F + f;
-            int idx = (int)row_top[sc];
-            double acc = 0.0;
-            for (int t = 0; t < (debug_abl == 3 ? 0 : n_rows); ++t) {  // (3: developer ablation, no row walk)
-                int a = sc + h0 - (int)row_list[idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
-                a += a < 0 ? S : 0;
-                a -= a >= S ? S : 0;
-                if (a >= k0) break;
-                if (debug_abl == 4) acc += 1.0;  // (4: developer ablation, the walk without the taps)
-                else acc = fma(ku[a], (double)rows[idx * F + f], acc);
-                idx = idx == 0 ? n_rows - 1 : idx - 1;
+            // ---- pass 1, in place: along the cycles, kernel centred at column k1 / 2.  A step takes whole rows:
+            // every thread reads the taps of its cell, then all write.
+            for (int base = 0; base < tot; base += rows_per_step) {
+                const int lr = tid / F, f = tid - lr * F;
+                const int slot = base + lr;
+                const bool act = lr < rows_per_step && slot < tot;
+                float v = 0.0f;
+                if (act) {
+                    const float *rp = rows + slot * F;
+                    double acc = 0.0;
+                    int col = f + h1;  // column of tap b: (f + h1 - b) mod F
+                    col -= col >= F ? F : 0;
+                    for (int bb = 0; bb < k1; ++bb) {
+                        acc = fma(kv[bb], (double)rp[col], acc);
+                        col = col == 0 ? F - 1 : col - 1;
+                    }
+                    v = (float)acc;
+                }
+                __syncthreads();
+                if (act) rows[slot * F + f] = v;
+                __syncthreads();
             }
-            const float sm = (float)acc;
-            if (sm != 0.0f) {  // _build_features (selection.py:206-226); log(1) = 0
-                const float x = sm + 1.0f;
-                if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
-                else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
+            // ---- pass 2: along the scans, kernel centred at row k0 / 2; log(smooth + 1) summed per group.
+            // (a thread keeps its column and strides over the scans: no index arithmetic per cell)
+            const int p2_rows = SCORE_THREADS / F, p2_lr = tid / F, p2_f = tid - p2_lr * F;
+#pragma unroll
+            for (int g = 0; g < SEL_BATCH; ++g) {
+                if (g >= gc) continue;
+                const int n_rows = batch_rows[g];
+                if (n_rows == 0) continue;  // an empty tile smooths to zeros: log(0 + 1) = 0 changes nothing
+                const int16_t *rl = row_list + g * S, *rt = row_top + g * S;
+                const float *rw = rows + base_r[g] * F;
+                for (int sc = p2_lr; sc < (debug_abl == 2 || p2_lr >= p2_rows ? 0 : S); sc += p2_rows) {  // (2: developer ablation, no pass 2)
+                    const int f = p2_f, c = sc * F + f;
+                    int idx = (int)rt[sc];
+                    double acc = 0.0;
+                    for (int t = 0; t < (debug_abl == 3 ? 0 : n_rows); ++t) {  // (3: developer ablation, no row walk)
+                        int a = sc + h0 - (int)rl[idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
+                        a += a < 0 ? S : 0;
+                        a -= a >= S ? S : 0;
+                        if (a >= k0) break;
+                        if (debug_abl == 4) acc += 1.0;  // (4: developer ablation, the walk without the taps)
+                        else acc = fma(ku[a], (double)rw[idx * F + f], acc);
+                        idx = idx == 0 ? n_rows - 1 : idx - 1;
+                    }
+                    const float sm = (float)acc;
+                    if (sm != 0.0f) {  // _build_features (selection.py:206-226); log(1) = 0
+                        const float x = sm + 1.0f;
+                        if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
+                        else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
+                    }
+                }
             }
         }
-        if (w == K - 1) {
+        if (w0 + gc == K) {
             // fragment sum complete: park it in the scratch block, the LDS array starts over for the isotopes
             __syncthreads();  // (the cells are owned by other threads here than in pass 2)
             for (int c = tid; c < SF; c += SCORE_THREADS) {
@@ -628,6 +661,7 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
             }
         }
         __syncthreads();
+        w0 += gc;
     }
     // feature = fragment sum + isotope sum (float32); it goes through the parked tile, because the float64
     // scores take the place of both LDS tiles
