@@ -50,7 +50,8 @@ namespace selim {
 constexpr int MAX_W = 64;    // m/z windows (fragments + isotopes) per precursor
 constexpr int MAX_CAND = 16;
 constexpr int SCORE_THREADS = 512;
-constexpr int SEL_BATCH = 4;  // windows per batch of the score kernel (<= SCORE_THREADS / 64)
+constexpr int SMOOTH_THREADS = 1024;  // threads of the smoothing kernel (16 wavefronts)
+constexpr int SEL_BATCH = 4;  // windows per batch of the smoothing kernel (<= SMOOTH_THREADS / 64)
 constexpr int SEL_HEADER = 32 + 4 * (MAX_W + 2);  // bytes in front of the tiles of a precursor (see below)
 constexpr uint32_t SEL_DENSE = 0u, SEL_COMPACT = 1u;
 struct SelEntry {
@@ -435,21 +436,31 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     }
 }
 
-// LDS of the score kernel for tiles of at most cap_cells = S * F cells, cap_s scans, cap_f cycles
-size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f, int k0, int k1) {
-    size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile, later the float64 scores
-    b += (size_t)(k0 + k1 + cap_s + cap_f) * 8;          // kernel factors, scan / cycle profiles
-    b += (size_t)((cap_cells + 31) / 32) * 4;            // peak flags, one bit per cell
+// LDS of the smoothing kernel for tiles of at most cap_cells = S * F cells and cap_s scans
+size_t adh_select_smooth_im_lds_bytes(int cap_cells, int cap_s, int k0, int k1) {
+    size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile
+    b += (size_t)(k0 + k1) * 8;                          // kernel factors
     b += (size_t)cap_s * 3 * 2 * selim::SEL_BATCH + 16;  // row tables of a batch of windows
     return (b + 15) / 16 * 16;
 }
+// LDS of the score kernel
+size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f) {
+    size_t b = (size_t)cap_cells * 8;                    // the float64 scores
+    b += (size_t)(cap_s + cap_f) * 8;                    // scan / cycle profiles
+    b += (size_t)((cap_cells + 31) / 32) * 4;            // peak flags, one bit per cell
+    return (b + 15) / 16 * 16;
+}
 
-__global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_kernel(
-    DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
-    adh_selection_config_t cfg, const double *__restrict__ ku_g, const double *__restrict__ kv_g, int32_t k0,
-    int32_t k1, int32_t cap_cells, int32_t cap_s, int32_t cap_f, unsigned char *__restrict__ scratch,
-    DevCandTable out, int32_t debug_abl) {
+// Kernel 2 of 3: the smoothed log-sum feature tile of every precursor, written to the parked tile of its
+// scratch block.  Separate from the peak search (kernel 3) because it is bound by LDS latency and needs
+// wavefronts: 1024 threads at <= 64 VGPRs, two blocks = 32 wavefronts per CU (the peak search carries
+// per-candidate arrays in registers and would cap the whole at half of that).
+__global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im_kernel(
+    const selim::PrecRec *__restrict__ recs, int32_t n_prec, const double *__restrict__ ku_g,
+    const double *__restrict__ kv_g, int32_t k0, int32_t k1, int32_t cap_cells, int32_t cap_s,
+    unsigned char *__restrict__ scratch, int32_t debug_abl) {
     using namespace selim;
+    constexpr int SCORE_THREADS = SMOOTH_THREADS;  // (this kernel's block size, under the name the loops use)
     extern __shared__ __align__(16) unsigned char smem[];
     // The smoothing is the separable circular convolution
     //   out(s, f) = sum_a ku[a] * (sum_b kv[b] * x[(s + k0/2 - a) mod S][(f + k1/2 - b) mod F])
@@ -462,17 +473,10 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     float *ls = rows + cap_cells;                       // log-sum tile: fragments first (parked in HBM when done), then isotopes
     double *ku = reinterpret_cast<double *>(ls + cap_cells);
     double *kv = ku + k0;
-    double *mob = kv + k1, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
-    uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + cap_f);   // peak flags, one bit per cell
     // per window g of a batch, at [g * S ...]:
-    int16_t *row_slot = reinterpret_cast<int16_t *>(flag + (cap_cells + 31) / 32);  // [S] slot of a scan, -1: no event
+    int16_t *row_slot = reinterpret_cast<int16_t *>(kv + k1);  // [S] slot of a scan, -1: no event
     int16_t *row_list = row_slot + SEL_BATCH * cap_s;   // [n_rows] scans with events, ascending
     int16_t *row_top = row_list + SEL_BATCH * cap_s;    // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
-    __shared__ double red_v[SCORE_THREADS];
-    __shared__ int red_i[SCORE_THREADS];
-    __shared__ int pk_idx[MAX_CAND];
-    __shared__ double pk_val[MAX_CAND];
-    __shared__ double s_norm[2];
     __shared__ int batch_rows[SEL_BATCH];  // scans with events of every window of the batch
     const int tid = threadIdx.x;
     const int i = blockIdx.x;
@@ -663,20 +667,68 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
         __syncthreads();
         w0 += gc;
     }
-    // feature = fragment sum + isotope sum (float32); it goes through the parked tile, because the float64
-    // scores take the place of both LDS tiles
+    // feature = fragment sum + isotope sum (float32), left in the parked tile for the score kernel
     for (int c = tid; c < SF; c += SCORE_THREADS) park[c] = park[c] + ls[c];
-    __syncthreads();
+}
+
+// Kernel 3 of 3: scores, peaks, joins and limits of every precursor from its feature tile.
+__global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kernel(
+    DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
+    adh_selection_config_t cfg, int32_t cap_cells, int32_t cap_s, int32_t cap_f,
+    unsigned char *__restrict__ scratch, DevCandTable out) {
+    using namespace selim;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *mob = reinterpret_cast<double *>(smem) + cap_cells, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
+    uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + cap_f);   // peak flags, one bit per cell
+    __shared__ double red_v[SCORE_THREADS];
+    __shared__ int red_i[SCORE_THREADS];
+    __shared__ int pk_idx[MAX_CAND];
+    __shared__ double pk_val[MAX_CAND];
+    __shared__ double s_norm[2];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= n_prec) return;
+    const PrecRec r = recs[i];
+    const uint32_t *header = reinterpret_cast<const uint32_t *>(scratch + r.scratch_off);
+    const int K = (int)header[0], W = (int)header[1];
+    if (!r.ok || K == 0) return;
+    const int S = r.n_scans, F = r.n_cycles, SF = S * F;
+    const float *park = reinterpret_cast<const float *>(scratch + r.scratch_off + SEL_HEADER) + (size_t)W * SF;  // the feature tile
     // ---- score (selection.py:396-421): kept as the float32 feature + the affine map
     double mean = cfg.feature_mean, sd = cfg.feature_std, weight = cfg.feature_weight;
     if (!cfg.use_weighted_score) {
-        if (tid == 0) {  // amean1 / astd1 (selection/utils.py:118-133), sequential
+        // amean1 / astd1 (selection/utils.py:118-133): sequential float64 sums over the tile, by one thread.
+        // The tile is staged in LDS by all threads first and read eight cells at a time (reads in flight
+        // together, adds in order): from global memory this loop was two thirds of the whole selection.
+        float *ftile = reinterpret_cast<float *>(smem);
+        for (int c = tid; c < SF; c += SCORE_THREADS) ftile[c] = park[c];
+        __syncthreads();
+        if (tid == 0) {
             double m = 0;
-            for (int c = 0; c < SF; ++c) m += (double)park[c];
+            int c = 0;
+            for (; c + 8 <= SF; c += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ftile[c + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m += (double)t[u];
+            }
+            for (; c < SF; ++c) m += (double)ftile[c];
             m /= (double)SF;
             double v = 0;
-            for (int c = 0; c < SF; ++c) {
-                const double d = (double)park[c] - m;
+            c = 0;
+            for (; c + 8 <= SF; c += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ftile[c + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double d = (double)t[u] - m;
+                    v += d * d;
+                }
+            }
+            for (; c < SF; ++c) {
+                const double d = (double)ftile[c] - m;
                 v += d * d;
             }
             s_norm[0] = m;
@@ -750,56 +802,76 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
         ++n_pk;
         __syncthreads();
     }
-    if (tid != 0) return;
-    // ---- joins and limits by one thread (short loops), in the reference's order
+    // ---- joins and limits, in the reference's order.  The joins are short loops for one thread; the scan /
+    // cycle profiles of symetric_limits_2d are sums over S x ~10 and ~10 x F cells per peak and were, on one
+    // thread, two thirds of the whole selection: one thread per scan / per cycle now (the sum of a thread
+    // keeps its order).
+    __shared__ int sh_scan[MAX_CAND], sh_cycle[MAX_CAND], sh_npk;
     int p_scan[MAX_CAND], p_cycle[MAX_CAND], p_sl[MAX_CAND][2], p_cl[MAX_CAND][2];
     double p_score[MAX_CAND];
-    for (int a = 0; a < n_pk; ++a) {
-        p_scan[a] = pk_idx[a] / F;
-        p_cycle[a] = pk_idx[a] - p_scan[a] * F;
-        p_score[a] = pk_val[a];
-    }
-    {  // _join_close_peaks (selection.py:229-278), tolerances 3 / 3
-        bool mask[MAX_CAND];
-        for (int a = 0; a < n_pk; ++a) mask[a] = true;
+    if (tid == 0) {
         for (int a = 0; a < n_pk; ++a) {
-            if (!mask[a]) continue;
-            for (int b = a + 1; b < n_pk; ++b) {
-                if (!mask[b]) continue;
-                if (abs(p_scan[a] - p_scan[b]) <= 3 && abs(p_cycle[a] - p_cycle[b]) <= 3) {
-                    if (p_score[a] > p_score[b]) mask[b] = false; else mask[a] = false;
+            p_scan[a] = pk_idx[a] / F;
+            p_cycle[a] = pk_idx[a] - p_scan[a] * F;
+            p_score[a] = pk_val[a];
+        }
+        {  // _join_close_peaks (selection.py:229-278), tolerances 3 / 3
+            bool mask[MAX_CAND];
+            for (int a = 0; a < n_pk; ++a) mask[a] = true;
+            for (int a = 0; a < n_pk; ++a) {
+                if (!mask[a]) continue;
+                for (int b = a + 1; b < n_pk; ++b) {
+                    if (!mask[b]) continue;
+                    if (abs(p_scan[a] - p_scan[b]) <= 3 && abs(p_cycle[a] - p_cycle[b]) <= 3) {
+                        if (p_score[a] > p_score[b]) mask[b] = false; else mask[a] = false;
+                    }
                 }
             }
+            int m = 0;
+            for (int a = 0; a < n_pk; ++a)
+                if (mask[a]) {
+                    p_scan[m] = p_scan[a];
+                    p_cycle[m] = p_cycle[a];
+                    p_score[m] = p_score[a];
+                    ++m;
+                }
+            n_pk = m;
         }
-        int m = 0;
-        for (int a = 0; a < n_pk; ++a)
-            if (mask[a]) {
-                p_scan[m] = p_scan[a];
-                p_cycle[m] = p_cycle[a];
-                p_score[m] = p_score[a];
-                ++m;
-            }
-        n_pk = m;
+        for (int a = 0; a < n_pk; ++a) {
+            sh_scan[a] = p_scan[a];
+            sh_cycle[a] = p_cycle[a];
+        }
+        sh_npk = n_pk;
     }
+    __syncthreads();
+    n_pk = sh_npk;
     // symetric_limits_2d (selection/utils.py:283-312)
     for (int a = 0; a < n_pk; ++a) {
-        const int mob_lower = (int)max((int64_t)0, (int64_t)p_scan[a] - cfg.min_size_mobility);
-        const int mob_upper = (int)min((int64_t)S, (int64_t)p_scan[a] + cfg.min_size_mobility);
-        const int cyc_lower = (int)max((int64_t)0, (int64_t)p_cycle[a] - cfg.min_size_rt);
-        const int cyc_upper = (int)min((int64_t)F, (int64_t)p_cycle[a] + cfg.min_size_rt);
-        for (int s = 0; s < S; ++s) {
+        const int pa_scan = sh_scan[a], pa_cycle = sh_cycle[a];
+        const int mob_lower = (int)max((int64_t)0, (int64_t)pa_scan - cfg.min_size_mobility);
+        const int mob_upper = (int)min((int64_t)S, (int64_t)pa_scan + cfg.min_size_mobility);
+        const int cyc_lower = (int)max((int64_t)0, (int64_t)pa_cycle - cfg.min_size_rt);
+        const int cyc_upper = (int)min((int64_t)F, (int64_t)pa_cycle + cfg.min_size_rt);
+        for (int sc = tid; sc < S; sc += SCORE_THREADS) {
             double v = 0.0;
-            for (int f = cyc_lower; f < cyc_upper; ++f) v += A(s, f);
-            mob[s] = v;
+            for (int f = cyc_lower; f < cyc_upper; ++f) v += A(sc, f);
+            mob[sc] = v;
         }
-        for (int f = 0; f < F; ++f) cyc[f] = 0.0;
-        for (int s = mob_lower; s < mob_upper; ++s)
-            for (int f = 0; f < F; ++f) cyc[f] += A(s, f);
-        sel::symetric_limits_1d(mob, S, p_scan[a], cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
-                                cfg.max_size_mobility, p_sl[a]);
-        sel::symetric_limits_1d(cyc, F, p_cycle[a], cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt,
-                                p_cl[a]);
+        for (int f = tid; f < F; f += SCORE_THREADS) {
+            double v = 0.0;
+            for (int sc = mob_lower; sc < mob_upper; ++sc) v += A(sc, f);
+            cyc[f] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            sel::symetric_limits_1d(mob, S, pa_scan, cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
+                                    cfg.max_size_mobility, p_sl[a]);
+            sel::symetric_limits_1d(cyc, F, pa_cycle, cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt,
+                                    p_cl[a]);
+        }
+        __syncthreads();
     }
+    if (tid != 0) return;
     if (cfg.join_close_candidates) {  // _join_overlapping_candidates (selection.py:281-345)
         bool mask[MAX_CAND];
         for (int a = 0; a < n_pk; ++a) mask[a] = true;
