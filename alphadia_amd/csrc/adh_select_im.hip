@@ -672,7 +672,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
 }
 
 // Kernel 3 of 3: scores, peaks, joins and limits of every precursor from its feature tile.
-__global__ __launch_bounds__(selim::SCORE_THREADS) void adh_select_score_im_kernel(
+__global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_kernel(
     DevTims run, const selim::PrecRec *__restrict__ recs, int32_t n_prec, int64_t first_prec,
     adh_selection_config_t cfg, int32_t cap_cells, int32_t cap_s, int32_t cap_f,
     unsigned char *__restrict__ scratch, DevCandTable out) {
