@@ -151,12 +151,12 @@ struct ImEntry {
 __host__ __device__ inline uint64_t adh_im_prec_off(uint32_t k_cap, int O, int S, int F) {
     return adh_scratch_frag_off(k_cap) + (uint64_t)k_cap * O * S * F * 8;
 }
-__host__ __device__ inline uint64_t adh_im_touch_off(uint32_t k_cap, int O, int S, int F, int I, int Op) {
+__host__ __device__ inline uint64_t adh_im_tiles_end(uint32_t k_cap, int O, int S, int F, int I, int Op) {
     uint64_t b = adh_im_prec_off(k_cap, O, S, F) + (uint64_t)I * Op * S * F * 8;
     return (b + 31) / 32 * 32;
 }
 __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, int S, int F, int I, int Op) {
-    return adh_im_touch_off(k_cap, O, S, F, I, Op);
+    return adh_im_tiles_end(k_cap, O, S, F, I, Op);
 }
 
 // Barrier of a ONE-wavefront block whose lanes talk through LDS.  A wavefront issues its LDS

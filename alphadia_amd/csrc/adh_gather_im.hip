@@ -343,7 +343,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
         const uint32_t out_cap =
-            (uint32_t)((adh_im_touch_off(r.k_cap, O, S, F, I, Op) - adh_scratch_frag_off(r.k_cap)) / sizeof(ImEntry));
+            (uint32_t)((adh_im_tiles_end(r.k_cap, O, S, F, I, Op) - adh_scratch_frag_off(r.k_cap)) / sizeof(ImEntry));
         uint32_t out_n = 0, n_fe = 0;
         const unsigned long long lt = (1ull << lane) - 1ull;
         int m = 0;  // events in the list (wave-uniform)
