@@ -725,7 +725,29 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
 
     // chunk boundaries: a short first chunk (its H2D, plan and kernels are the un-overlapped ramp
     // of the D2H-bound pipeline), then equal chunks
-    const int64_t chunk = pick_chunk(n);
+    int64_t chunk = pick_chunk(n);
+    if (h->tims_staged && n > 0) {
+        // ion-mobility candidates reserve a scratch block sized for their dense tiles (116 KB at 38 scans x 29
+        // cycles, although ~1 % of it is touched): bound the chunk so that the slab stays within a third of the
+        // free device memory.  Tile sizes from the host columns; K <= top_k fragments, 3 observations assumed.
+        int64_t cells = 1;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t S = std::max<int64_t>(c->scan_stop[i] - c->scan_start[i], 1);
+            const int64_t F = std::max<int64_t>((c->frame_stop[i] - c->frame_start[i]) / std::max(h->tims.cycle_len, 1) + 1, 1);
+            cells = std::max(cells, S * F);
+        }
+        const int64_t k_max = std::max<int64_t>(std::min<int64_t>(cfg->top_k_fragments, 64), 1);
+        const uint64_t block = (uint64_t)cells * 8 * (uint64_t)(k_max * 3 + 4) + 4096;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t budget = std::max<uint64_t>((free_b + h->scratch_slab_bytes) / 3, 1ull << 30);
+            const int64_t fit = (int64_t)std::max<uint64_t>(budget / block, 1024);
+            if (fit < chunk) {
+                const int64_t parts = (n + fit - 1) / fit;
+                chunk = (n + parts - 1) / parts;
+            }
+        }
+    }
     std::vector<int64_t> cut{0};
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
