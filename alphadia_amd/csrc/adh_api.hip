@@ -134,6 +134,7 @@ struct adh_handle {
     const LibRec *d_lib = nullptr;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
+    uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
     std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
     std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
@@ -562,6 +563,7 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     h->h_dpc = dpc;
     h->tims = t;
     h->tims_staged = true;
+    h->im_scratch_budget = 0;
     return ADH_OK;
 }
 

@@ -738,9 +738,13 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         const int64_t k_max = std::max<int64_t>(std::min<int64_t>(cfg->top_k_fragments, 64), 1);
         const uint64_t block = (uint64_t)cells * 8 * (uint64_t)(k_max * 3 + 4) + 4096;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t budget = std::max<uint64_t>((free_b + h->scratch_slab_bytes) / 3, 1ull << 30);
+        if (h->im_scratch_budget == 0) {  // (asked once per staged run: hipMemGetInfo takes ~2 ms)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                h->im_scratch_budget = std::max<uint64_t>((free_b + h->scratch_slab_bytes) / 3, 1ull << 30);
+        }
+        if (h->im_scratch_budget) {
+            const uint64_t budget = h->im_scratch_budget;
             const int64_t fit = (int64_t)std::max<uint64_t>(budget / block, 1024);
             if (fit < chunk) {
                 const int64_t parts = (n + fit - 1) / fit;
