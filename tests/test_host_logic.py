@@ -245,3 +245,50 @@ def test_score_groups_match_reference(name, grouped):
     got = calculate_score_groups(cand, group_channels=grouped)
     for c in ("precursor_idx", "rank", "score_group_idx"):
         assert np.array_equal(got[c].values, z[f"groups_{name}_{c}"]), c
+
+
+def test_log_table_header_matches_its_generator():
+    """adh_log_table.h (table of the float64 log of float32 arguments in the selection kernel) is generated:
+    regenerate the 128 entries and compare with the committed header, and check the algorithm built on the
+    table against an 80-bit log on a sample (<= 1 ulp of float64, identical after rounding to float32)."""
+    import os
+    import re
+    import struct
+    from fractions import Fraction
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "alphadia_amd", "csrc", "adh_log_table.h")).read()
+    rows = re.findall(r"\{(\S+), (\S+)\},", text)
+    assert len(rows) == 128
+    ld = np.longdouble
+    inv, tab = np.empty(128), np.empty(128)
+    for i, (a, b) in enumerate(rows):
+        inv[i], tab[i] = float.fromhex(a), float.fromhex(b)
+        want_inv = float(ld(1) / (ld(1) + ld(i) / ld(128)))
+        assert inv[i] == want_inv
+        assert tab[i] == (float(-np.log(ld(want_inv))) if i else 0.0)
+
+    def fma(a, b, c):  # correctly rounded
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def log_f32(x32):
+        bits = struct.unpack("<I", struct.pack("<f", x32))[0]
+        e, mant = (bits >> 23) - 127, bits & 0x7FFFFF
+        i = mant >> 16
+        m = struct.unpack("<f", struct.pack("<I", mant | 0x3F800000))[0]
+        r = fma(float(m), inv[i], -1.0)
+        q = 1.0 / 9.0
+        for c in (-1 / 8, 1 / 7, -1 / 6, 1 / 5, -1 / 4, 1 / 3, -1 / 2):
+            q = fma(q, r, c)
+        p = fma(r * r, q, r)
+        return e * 6.93147180369123816490e-01 + ((tab[i] + p) + e * 1.90821492927058770002e-10)
+
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([np.float32(1) + rng.random(400, dtype=np.float32) * np.float32(1e-3),
+                         np.float32(1) + rng.random(400, dtype=np.float32),
+                         rng.random(400, dtype=np.float32) * np.float32(60000) + np.float32(1),
+                         np.array([np.nextafter(np.float32(1), np.float32(2))], dtype=np.float32)])
+    for x in xs:
+        mine, ref = log_f32(float(x)), float(np.log(ld(float(x))))
+        assert abs(mine - ref) <= np.spacing(abs(ref)), x
+        assert np.float32(mine) == np.float32(np.log(np.float64(x))), x
