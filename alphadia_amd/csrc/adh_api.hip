@@ -610,6 +610,11 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
     const DevTims &T = h->tims;
     const int L = T.cycle_len, SM = T.scan_max, z = T.zeroth;
     if (!pc->mobility) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor mobility column is NULL");
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;
+    const double t_0 = now();
     // rank-1 factors of the kernel (it is an outer product up to float32 rounding of its entries)
     std::vector<double> ku((size_t)k0), kv((size_t)k1);
     {
@@ -758,6 +763,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         budget = std::max(std::min(budget, all), biggest);
         budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
     }
+    const double t_plan = now();
     DeviceBuffers tmp;
     const double *d_ku = nullptr, *d_kv = nullptr;
     int rc = upload(tmp, ku.data(), k0, &d_ku, h->stream);
@@ -802,6 +808,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         else tmp.ptrs.push_back(d_recs);
     }
     double total_ms = 0.0;
+    const double t_alloc = now();
     if (rc == ADH_OK) {
         (void)hipFuncSetAttribute((const void *)adh_select_score_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024);
@@ -862,12 +869,17 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
+    const double t_kernels = now();
     for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
         hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
     }
     if (rc == ADH_OK) h->last_select_ms = total_ms;
+    const double t_copy = now();
     tmp.release();
+    if (timing)
+        fprintf(stderr, "[adh] select_candidates_im n=%lld: host plan %.2f ms, allocations %.2f, upload + kernels %.2f (kernels %.2f), D2H %.2f, free %.2f\n",
+                (long long)n, t_plan - t_0, t_alloc - t_plan, t_kernels - t_alloc, total_ms, t_copy - t_kernels, now() - t_copy);
     return rc;
 }
 
