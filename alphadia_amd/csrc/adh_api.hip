@@ -698,6 +698,7 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                         const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
                         any_f = any_f || (q_lo <= wh && q_hi >= wl);
                         any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
+                        if (any_f && any_p) break;  // both queries are non-empty: nothing more to learn
                     }
                 ok = any_f && any_p;
             }
