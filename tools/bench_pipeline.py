@@ -14,7 +14,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphadia_amd import fdr, runtime, synthetic as syn  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # synthetic data generators
+import synthetic as syn  # noqa: E402
+from alphadia_amd import fdr, runtime  # noqa: E402
 from alphadia_amd.scoring import DEFAULT_FEATURE_COLUMNS, CandidateScoringConfig, HipCandidateScoring  # noqa: E402
 from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelection  # noqa: E402
 
