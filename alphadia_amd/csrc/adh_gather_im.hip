@@ -180,32 +180,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         w_mz[caps.k + lane] = (float)off + r.precursor_mz;
     }
     __syncthreads();
-    // TOF index limits: searchsorted(mz_values, mass_range(...), "left") (bruker_jit.py:273-278).  The
-    // staged lookup table brackets the answer to a few bins; a result on the edge of the bracket is
-    // verified and searched again over the whole table if the bracket was wrong.
-    auto tof_lower_bound = [&](double x) -> int {
-        const int n_tof = (int)run.n_tof;
-        int a = 0, b = n_tof;
-        if (run.mz_lut) {
-            const double t = (x - run.lut_min) * run.lut_inv_step;
-            const int bk = !(t >= 0.0) ? 0 : (t >= (double)run.lut_n ? run.lut_n - 1 : (int)t);
-            const int a0 = (int)run.mz_lut[max(bk - 1, 0)], b0 = (int)run.mz_lut[min(bk + 2, run.lut_n)];
-            a = a0, b = b0;
-            while (a < b) {
-                const int m = (a + b) >> 1;
-                if (run.mz[m] < x) a = m + 1; else b = m;
-            }
-            const bool ok_lo = a > a0 || a == 0 || run.mz[a - 1] < x;
-            const bool ok_hi = a < b0 || a == n_tof || !(run.mz[a] < x);
-            if (ok_lo && ok_hi) return a;
-            a = 0, b = n_tof;
-        }
-        while (a < b) {
-            const int m = (a + b) >> 1;
-            if (run.mz[m] < x) a = m + 1; else b = m;
-        }
-        return a;
-    };
+    // TOF index limits: searchsorted(mz_values, mass_range(...), "left") (bruker_jit.py:273-278)
     for (int w = lane; w < K + I; w += ADH_WAVE) {
         const bool prec = w >= K;
         const int slot = prec ? caps.k + (w - K) : w;
@@ -213,8 +188,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         float tol = prec ? cfg.precursor_mz_tolerance : cfg.fragment_mz_tolerance;
         float t = tol * mzq;
         float q = t / 1000000.0f;
-        const int a = tof_lower_bound((double)(mzq - q));
-        const int b = tof_lower_bound((double)(mzq + q));
+        const int a = index_im::tof_lower_bound(run, (double)(mzq - q));
+        const int b = index_im::tof_lower_bound(run, (double)(mzq + q));
         t_lo[slot] = a;
         t_hi[slot] = b > a ? b : a;
     }
@@ -286,42 +261,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 const int slot = w >= K ? caps.k + (w - K) : w;
                 const int tof = t_lo[slot] + (p - w_p0[w]);
                 int64_t lo, lo2;
-                if (run.cyc_idx) {
-                    // the (bin, cycle block) index brackets both ends of the range; with one column per
-                    // cycle the brackets ARE the answers
-                    const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
-                    const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
-                    const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
-                    lo = row[ba];
-                    lo2 = row[bb];
-                    if (sh > 0) {
-                        int64_t hi = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
-                        while (lo < hi) {
-                            int64_t m = (lo + hi) >> 1;
-                            if (run.push[m] < push_lo) lo = m + 1; else hi = m;
-                        }
-                        hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
-                        if (lo2 < lo) lo2 = lo;
-                        while (lo2 < hi) {
-                            int64_t m = (lo2 + hi) >> 1;
-                            if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
-                        }
-                    }
-                } else {
-                    const int64_t b = run.tof_indptr[tof + 1];
-                    int64_t hi = b;
-                    lo = run.tof_indptr[tof];
-                    while (lo < hi) {
-                        int64_t m = (lo + hi) >> 1;
-                        if (run.push[m] < push_lo) lo = m + 1; else hi = m;
-                    }
-                    lo2 = lo;
-                    hi = b;
-                    while (lo2 < hi) {
-                        int64_t m = (lo2 + hi) >> 1;
-                        if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
-                    }
-                }
+                index_im::event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
                 p_lo[p] = (uint32_t)lo;
                 p_win[p] = (uint8_t)w;
                 p_off[p + 1] = (uint32_t)(lo2 - lo);

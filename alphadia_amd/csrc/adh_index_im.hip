@@ -19,6 +19,67 @@ __device__ __forceinline__ uint32_t columns_le(uint32_t p, uint32_t S_max, uint3
     return (blk < n_blocks ? blk : n_blocks) + 1u;
 }
 
+// searchsorted(mz_values, x, "left") (bruker_jit.py:273-278): the staged lookup table brackets the answer to
+// a few bins; an answer on the edge of the bracket is verified and searched again over the whole table if
+// the bracket was wrong (it never is unless the table and the arithmetic here disagree in the last bit).
+__device__ __forceinline__ int tof_lower_bound(const DevTims &run, double x) {
+    const int n_tof = (int)run.n_tof;
+    int a = 0, b = n_tof;
+    if (run.mz_lut) {
+        const double t = (x - run.lut_min) * run.lut_inv_step;
+        const int bk = !(t >= 0.0) ? 0 : (t >= (double)run.lut_n ? run.lut_n - 1 : (int)t);
+        const int a0 = (int)run.mz_lut[max(bk - 1, 0)], b0 = (int)run.mz_lut[min(bk + 2, run.lut_n)];
+        a = a0, b = b0;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (run.mz[m] < x) a = m + 1; else b = m;
+        }
+        const bool ok_lo = a > a0 || a == 0 || run.mz[a - 1] < x;
+        const bool ok_hi = a < b0 || a == n_tof || !(run.mz[a] < x);
+        if (ok_lo && ok_hi) return a;
+        a = 0, b = n_tof;
+    }
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (run.mz[m] < x) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+// The events of TOF bin `tof` whose push lies in [push_lo, push_hi) - the pushes of cycles c0 ... c0 + F - 1:
+// one contiguous range [lo, lo2), because a bin's events ascend by push.  With one index column per cycle
+// the two look-ups are the answer; with one column per block of cycles they bracket two short searches;
+// without the index both ends are searched in the whole bin.
+__device__ __forceinline__ void event_range(const DevTims &run, int tof, int c0, int F, uint32_t push_lo,
+                                            uint32_t push_hi, int64_t &lo, int64_t &lo2) {
+    int64_t hi_lo, hi_hi;
+    if (run.cyc_idx) {
+        const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
+        const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
+        const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
+        lo = row[ba];
+        lo2 = row[bb];
+        if (sh == 0) return;
+        hi_lo = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
+        hi_hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
+    } else {
+        lo = run.tof_indptr[tof];
+        hi_lo = hi_hi = run.tof_indptr[tof + 1];
+        lo2 = lo;
+    }
+    int64_t hi = hi_lo;
+    while (lo < hi) {
+        const int64_t m = (lo + hi) >> 1;
+        if (run.push[m] < push_lo) lo = m + 1; else hi = m;
+    }
+    if (lo2 < lo) lo2 = lo;
+    hi = hi_hi;
+    while (lo2 < hi) {
+        const int64_t m = (lo2 + hi) >> 1;
+        if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
+    }
+}
+
 }  // namespace index_im
 
 // one wavefront per TOF bin: the bin's events are read 64 at a time; an event that is the first one at or

@@ -129,37 +129,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
         s_mz[K + lane] = (float)((double)r.mz + (double)lane * 1.0033548350700006 / (double)r.charge);
     __syncthreads();
     const int W = K + n_iso;
-    // TOF index limits of every window: searchsorted(mz_values, mass_range(...), "left"); the staged
-    // lookup table brackets the answer, an answer on the edge of the bracket is verified
-    auto tof_lower_bound = [&](double x) -> int {
-        const int n_tof = (int)run.n_tof;
-        int a = 0, b = n_tof;
-        if (run.mz_lut) {
-            const double t = (x - run.lut_min) * run.lut_inv_step;
-            const int bk = !(t >= 0.0) ? 0 : (t >= (double)run.lut_n ? run.lut_n - 1 : (int)t);
-            const int a0 = (int)run.mz_lut[max(bk - 1, 0)], b0 = (int)run.mz_lut[min(bk + 2, run.lut_n)];
-            a = a0, b = b0;
-            while (a < b) {
-                const int m = (a + b) >> 1;
-                if (run.mz[m] < x) a = m + 1; else b = m;
-            }
-            const bool ok_lo = a > a0 || a == 0 || run.mz[a - 1] < x;
-            const bool ok_hi = a < b0 || a == n_tof || !(run.mz[a] < x);
-            if (ok_lo && ok_hi) return a;
-            a = 0, b = n_tof;
-        }
-        while (a < b) {
-            const int m = (a + b) >> 1;
-            if (run.mz[m] < x) a = m + 1; else b = m;
-        }
-        return a;
-    };
+    // TOF index limits of every window: searchsorted(mz_values, mass_range(...), "left")
     if (lane < W) {
         const float m = s_mz[lane];
         const float tol = (float)(lane < K ? cfg.fragment_mz_tolerance : cfg.precursor_mz_tolerance);
         float t = tol * m;
         float q = t / 1000000.0f;
-        const int a = tof_lower_bound((double)(m - q)), b = tof_lower_bound((double)(m + q));
+        const int a = index_im::tof_lower_bound(run, (double)(m - q)), b = index_im::tof_lower_bound(run, (double)(m + q));
         s_tlo[lane] = a;
         s_thi[lane] = b > a ? b : a;
     }
@@ -196,34 +172,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
             while (w_p0[w + 1] <= p) ++w;
             const int tof = s_tlo[w] + (p - w_p0[w]);
             int64_t lo, lo2;
-            const bool indexed = run.cyc_idx != nullptr;
-            int64_t hi_lo = 0, hi_hi = 0;
-            if (indexed) {
-                const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
-                const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
-                const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
-                lo = row[ba];
-                lo2 = row[bb];
-                hi_lo = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
-                hi_hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
-            } else {
-                lo = run.tof_indptr[tof];
-                hi_lo = hi_hi = run.tof_indptr[tof + 1];
-                lo2 = lo;
-            }
-            if (!indexed || run.cyc_shift > 0) {
-                int64_t hi = hi_lo;
-                while (lo < hi) {
-                    const int64_t m = (lo + hi) >> 1;
-                    if (run.push[m] < push_lo) lo = m + 1; else hi = m;
-                }
-                if (lo2 < lo) lo2 = lo;
-                hi = hi_hi;
-                while (lo2 < hi) {
-                    const int64_t m = (lo2 + hi) >> 1;
-                    if (run.push[m] < push_hi) lo2 = m + 1; else hi = m;
-                }
-            }
+            index_im::event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
             p_lo[p] = (uint32_t)lo;
             p_win[p] = (uint8_t)w;
             p_off[p + 1] = (uint32_t)(lo2 - lo);
