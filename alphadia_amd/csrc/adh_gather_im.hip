@@ -239,47 +239,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         // The isotope windows form the last group; its cells are keyed (scan, cycle, isotope, MS1 row) and
         // the MS1 rows are collapsed here (candidate.py:248-269), so the feature kernel finds all isotopes
         // of a precursor cell next to each other.
-        if (lane == 0) {
-            int acc = 0;
-            for (int w = 0; w < W; ++w) {
-                const int slot = w >= K ? caps.k + (w - K) : w;
-                w_p0[w] = acc;
-                acc += t_hi[slot] - t_lo[slot];
-            }
-            w_p0[W] = acc;
-        }
-        __syncthreads();
-        const int P = w_p0[W];
-        bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)S_max;
         const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
         const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
-        if (!over) {
-            for (int p = lane; p < P; p += ADH_WAVE) {
-                int w = 0;
-                while (w_p0[w + 1] <= p) ++w;
-                const int slot = w >= K ? caps.k + (w - K) : w;
-                const int tof = t_lo[slot] + (p - w_p0[w]);
-                int64_t lo, lo2;
-                index_im::event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
-                p_lo[p] = (uint32_t)lo;
-                p_win[p] = (uint8_t)w;
-                p_off[p + 1] = (uint32_t)(lo2 - lo);
-            }
-            __syncthreads();
-            uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
-            for (int base = 0; base < P; base += ADH_WAVE) {
-                uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
-                for (int off = 1; off < ADH_WAVE; off <<= 1) {
-                    const uint32_t u = __shfl_up(v, off);
-                    if (lane >= off) v += u;
-                }
-                if (base + lane < P) p_off[base + lane + 1] = carry + v;
-                carry += __shfl(v, ADH_WAVE - 1);
-            }
-            if (lane == 0) p_off[0] = 0u;
-            __syncthreads();
-        }
+        const int P = index_im::pair_setup(
+            run, W, t_lo, t_hi, [&](int w) { return w >= K ? caps.k + (w - K) : w; }, c0, F, push_lo, push_hi, w_p0, p_lo,
+            p_off, p_win, lane);
+        bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
         const uint32_t out_cap =
@@ -369,45 +335,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 over = true;
                 break;
             }
-            // ---- stage 1: the raw events, eight per lane and step (eight independent push loads in flight);
-            // those inside the scan range (~3 %) queue up behind the list: (push, raw number, pair)
-            int nq = 0;
-            constexpr int U = 8;
-            for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
-                uint32_t pv[U];
-                int pa_u[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-                    const uint32_t e = eu < r1 ? eu : r0;
-                    int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
-                    while (pb - pa > 1) {
-                        const int mid = (pa + pb) >> 1;
-                        if (p_off[mid] <= e) pa = mid; else pb = mid;
-                    }
-                    pa_u[u] = pa;
-                    pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-                    // (exact quotient without the integer-division sequence: float64 estimate, one fix-up)
-                    uint32_t fq = (uint32_t)((double)pv[u] * inv_smax);
-                    if (pv[u] - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
-                    const int scan = (int)(pv[u] - fq * (uint32_t)S_max);
-                    const bool pass = eu < r1 && scan >= r.scan_start && scan < r.scan_stop;
-                    const unsigned long long mask = __ballot(pass);
-                    if (pass) {
-                        const int at = m + nq + __popcll(mask & lt);
-                        if (at < ADH_IM_SORT_CAP) {
-                            s_key[at] = pv[u];
-                            s_int[at] = (uint16_t)(eu - r0);
-                            s_pair[at] = (uint8_t)pa_u[u];
-                        }
-                    }
-                    nq += __popcll(mask);
-                }
-            }
+            // ---- stage 1: the raw events of the batch; those in the scan range (~3 %) queue up behind the list
+            const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, p_lo, p_off,
+                                                      s_key, s_int, s_pair, lane);
             if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
                 over = true;
                 break;

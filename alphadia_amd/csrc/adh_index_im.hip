@@ -80,6 +80,106 @@ __device__ __forceinline__ void event_range(const DevTims &run, int tof, int c0,
     }
 }
 
+// ---- the event stream of the sparse gathers (adh_gather_im_kernel, adh_select_gather_im_kernel), one wavefront
+// per candidate / precursor.  LDS arrays of the caller: w_p0[W + 1] first (window, TOF bin) pair of every
+// window, p_lo[ADH_IM_PAIR_CAP] first event of a pair's range, p_off[ADH_IM_PAIR_CAP + 1] events before the
+// pair, p_win[ADH_IM_PAIR_CAP] window of the pair.
+
+// Pairs of all W windows (window w covers the TOF bins [t_lo[slot_of(w)], t_hi[slot_of(w)])) and their event
+// ranges.  Returns the number of pairs; more than ADH_IM_PAIR_CAP: nothing else is set up.
+template <typename SlotOf>
+__device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *t_lo, const int *t_hi, SlotOf slot_of,
+                                          int c0, int F, uint32_t push_lo, uint32_t push_hi, int *w_p0,
+                                          uint32_t *p_lo, uint32_t *p_off, uint8_t *p_win, int lane) {
+    if (lane == 0) {
+        int acc = 0;
+        for (int w = 0; w < W; ++w) {
+            const int slot = slot_of(w);
+            w_p0[w] = acc;
+            acc += t_hi[slot] - t_lo[slot];
+        }
+        w_p0[W] = acc;
+    }
+    __syncthreads();
+    const int P = w_p0[W];
+    if (P > ADH_IM_PAIR_CAP) return P;
+    for (int p = lane; p < P; p += ADH_WAVE) {
+        int w = 0;
+        while (w_p0[w + 1] <= p) ++w;
+        const int tof = t_lo[slot_of(w)] + (p - w_p0[w]);
+        int64_t lo, lo2;
+        event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
+        p_lo[p] = (uint32_t)lo;
+        p_win[p] = (uint8_t)w;
+        p_off[p + 1] = (uint32_t)(lo2 - lo);
+    }
+    __syncthreads();
+    uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
+    for (int base = 0; base < P; base += ADH_WAVE) {
+        uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
+        for (int off = 1; off < ADH_WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(v, off);
+            if (lane >= off) v += u;
+        }
+        if (base + lane < P) p_off[base + lane + 1] = carry + v;
+        carry += __shfl(v, ADH_WAVE - 1);
+    }
+    if (lane == 0) p_off[0] = 0u;
+    __syncthreads();
+    return P;
+}
+
+// Stage 1 of a batch of windows (pairs [pa0, pb0), raw events [r0, r1)): eight pushes per lane and step
+// (eight independent loads in flight); the events inside the scan range [scan_lo, scan_hi) - ~3 % - are
+// queued behind the m entries of the list: s_key = push, s_int = raw number - r0, s_pair = pair.  Returns the
+// number of queued events (entries beyond ADH_IM_SORT_CAP are counted, not stored).
+__device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int pb0, uint32_t r0, uint32_t r1,
+                                                int scan_lo, int scan_hi, int m, const uint32_t *p_lo,
+                                                const uint32_t *p_off, uint32_t *s_key, uint16_t *s_int,
+                                                uint8_t *s_pair, int lane) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t S_max = (uint32_t)run.scan_max;
+    const double inv_smax = 1.0 / (double)S_max;
+    int nq = 0;
+    constexpr int U = 8;
+    for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
+        uint32_t pv[U];
+        int pa_u[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+            const uint32_t e = eu < r1 ? eu : r0;
+            int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
+            while (pb - pa > 1) {
+                const int mid = (pa + pb) >> 1;
+                if (p_off[mid] <= e) pa = mid; else pb = mid;
+            }
+            pa_u[u] = pa;
+            pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
+            // (exact quotient without the integer-division sequence: float64 estimate, one fix-up)
+            uint32_t fq = (uint32_t)((double)pv[u] * inv_smax);
+            if (pv[u] - fq * S_max >= S_max) ++fq;
+            const int scan = (int)(pv[u] - fq * S_max);
+            const bool pass = eu < r1 && scan >= scan_lo && scan < scan_hi;
+            const unsigned long long mask = __ballot(pass);
+            if (pass) {
+                const int at = m + nq + __popcll(mask & lt);
+                if (at < ADH_IM_SORT_CAP) {
+                    s_key[at] = pv[u];
+                    s_int[at] = (uint16_t)(eu - r0);
+                    s_pair[at] = (uint8_t)pa_u[u];
+                }
+            }
+            nq += __popcll(mask);
+        }
+    }
+    return nq;
+}
+
 }  // namespace index_im
 
 // one wavefront per TOF bin: the bin's events are read 64 at a time; an event that is the first one at or

@@ -153,44 +153,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     // scan range queue up, look up their quadrupole row, and the survivors are sorted by (cell, stream
     // position) and summed per cell in that order: TOF ascending, then push - the reference's order
     // (bruker_jit.py:575-580: float32 running sum).
-    if (lane == 0) {
-        int acc = 0;
-        for (int w = 0; w < W; ++w) {
-            w_p0[w] = acc;
-            acc += s_thi[w] - s_tlo[w];
-        }
-        w_p0[W] = acc;
-    }
-    __syncthreads();
-    const int P = w_p0[W];
+    const int P = index_im::pair_setup(
+        run, W, s_tlo, s_thi, [](int w) { return w; }, c0, F, push_lo, push_hi, w_p0, p_lo, p_off, p_win, lane);
     const int64_t n_cells = (int64_t)W * S * F;
     bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || n_cells >= (1 << 23) ||
                 debug_dense != 0;  // (developer switch ADH_DEBUG_SELECT_IM_DENSE: dense tiles for every precursor)
-    if (!over) {
-        for (int p = lane; p < P; p += ADH_WAVE) {
-            int w = 0;
-            while (w_p0[w + 1] <= p) ++w;
-            const int tof = s_tlo[w] + (p - w_p0[w]);
-            int64_t lo, lo2;
-            index_im::event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
-            p_lo[p] = (uint32_t)lo;
-            p_win[p] = (uint8_t)w;
-            p_off[p + 1] = (uint32_t)(lo2 - lo);
-        }
-        __syncthreads();
-        uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
-        for (int base = 0; base < P; base += ADH_WAVE) {
-            uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
-            for (int off = 1; off < ADH_WAVE; off <<= 1) {
-                const uint32_t u = __shfl_up(v, off);
-                if (lane >= off) v += u;
-            }
-            if (base + lane < P) p_off[base + lane + 1] = carry + v;
-            carry += __shfl(v, ADH_WAVE - 1);
-        }
-        if (lane == 0) p_off[0] = 0u;
-        __syncthreads();
-    }
     SelEntry *out_list = reinterpret_cast<SelEntry *>(body);
     const uint32_t out_cap = (uint32_t)(n_cells * 4 / (int64_t)sizeof(SelEntry));
     uint32_t out_n = 0;
@@ -245,42 +212,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
             over = true;
             break;
         }
-        int nq = 0;
-        constexpr int U = 8;
-        for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
-            uint32_t pv[U];
-            int pa_u[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-                const uint32_t e = eu < r1 ? eu : r0;
-                int pa = pa0, pb = pb0;  // the pair of raw event e: last pair with p_off <= e
-                while (pb - pa > 1) {
-                    const int mid = (pa + pb) >> 1;
-                    if (p_off[mid] <= e) pa = mid; else pb = mid;
-                }
-                pa_u[u] = pa;
-                pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-                uint32_t fq = (uint32_t)((double)pv[u] * inv_sm);  // exact quotient: float64 estimate, one fix-up
-                if (pv[u] - fq * (uint32_t)SM >= (uint32_t)SM) ++fq;
-                const int scan = (int)(pv[u] - fq * (uint32_t)SM);
-                const bool pass = eu < r1 && scan >= r.scan_start && scan < r.scan_start + S;
-                const unsigned long long mask = __ballot(pass);
-                if (pass) {
-                    const int at = m + nq + __popcll(mask & lt);
-                    if (at < ADH_IM_SORT_CAP) {
-                        s_key[at] = pv[u];
-                        s_int[at] = (uint16_t)(eu - r0);
-                        s_pair[at] = (uint8_t)pa_u[u];
-                    }
-                }
-                nq += __popcll(mask);
-            }
-        }
+        const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_start + S, m, p_lo, p_off,
+                                                  s_key, s_int, s_pair, lane);
         if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window can be this full)
             over = true;
             break;
