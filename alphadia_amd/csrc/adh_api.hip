@@ -719,8 +719,15 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         std::vector<std::thread> pool;
         for (int t = 0; t < n_thr; ++t) {
             const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
-            if (t + 1 < n_thr) pool.emplace_back(plan_range, i0, i1, std::ref(caps[(size_t)t]), std::ref(errs[(size_t)t]));
-            else plan_range(i0, i1, caps[(size_t)t], errs[(size_t)t]);
+            bool started = false;
+            if (t + 1 < n_thr) {
+                try {  // (no exception may cross the C ABI: a range whose thread cannot be started runs here)
+                    pool.emplace_back(plan_range, i0, i1, std::ref(caps[(size_t)t]), std::ref(errs[(size_t)t]));
+                    started = true;
+                } catch (...) {
+                }
+            }
+            if (!started) plan_range(i0, i1, caps[(size_t)t], errs[(size_t)t]);
         }
         for (std::thread &th : pool) th.join();
         for (int t = 0; t < n_thr; ++t) {
