@@ -209,7 +209,7 @@ int adh_comm_gathered(adh_handle_t *h, int rank, adh_output_t *device_view, int6
     memset(&full, 0, sizeof(full));
     layout_tables(base, t.rows, t.top_k, &full, nullptr);
     for (int i = 0; i < kNumOutFields; ++i)
-        if (kOutFields[i].wire) out_member(&view, kOutFields[i]) = out_member(&full, kOutFields[i]);
+        if (kOutFields[i].wire) *out_member(&view, kOutFields[i]) = *out_member(&full, kOutFields[i]);
     view.n = t.rows;
     view.top_k = t.top_k;
     *device_view = view;

@@ -52,8 +52,8 @@ const OutFieldDesc kOutFields[] = {
 };
 constexpr int kNumOutFields = (int)(sizeof(kOutFields) / sizeof(kOutFields[0]));
 
-inline void *&out_member(adh_output_t *o, const OutFieldDesc &f) {
-    return *reinterpret_cast<void **>(reinterpret_cast<unsigned char *>(o) + f.member);
+inline void **out_member(adh_output_t *o, const OutFieldDesc &f) {
+    return reinterpret_cast<void **>(reinterpret_cast<unsigned char *>(o) + f.member);
 }
 inline size_t out_row_bytes(const OutFieldDesc &f, int top_k) {
     return (size_t)(f.per_row < 0 ? top_k : f.per_row) * (size_t)f.elem;
@@ -64,7 +64,7 @@ size_t layout_tables(unsigned char *base, int64_t rows, int top_k, adh_output_t 
     size_t off = 0, wire = 0;
     for (int i = 0; i < kNumOutFields; ++i) {
         const OutFieldDesc &f = kOutFields[i];
-        if (view) out_member(view, f) = base ? (void *)(base + off) : nullptr;
+        if (view) *out_member(view, f) = base ? (void *)(base + off) : nullptr;
         off += ((size_t)rows * out_row_bytes(f, top_k) + 255) / 256 * 256;
         if (f.wire) wire = off;
     }
@@ -693,7 +693,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     if (rc == ADH_OK) rc = check_score_args(h, cfg, out);
     if (rc != ADH_OK) return rc;
     for (int i = 0; i < kNumOutFields; ++i)
-        if (!kOutFields[i].optional && out_member(out, kOutFields[i]) == nullptr)
+        if (!kOutFields[i].optional && *out_member(out, kOutFields[i]) == nullptr)
             return fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
     HIP_TRY(hipSetDevice(h->device));
     const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;  // developer switch: stage times to stderr
@@ -798,11 +798,11 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         for (int i = 0; i < kNumOutFields; ++i) {
             const OutFieldDesc &f = kOutFields[i];
-            void *host = out_member(out, f);
+            void *host = *out_member(out, f);
             if (!host) continue;
             const size_t rb = out_row_bytes(f, top_k);
             hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(host) + (size_t)a * rb,
-                                          static_cast<unsigned char *>(out_member(&dev, f)) + (size_t)a * rb,
+                                          static_cast<unsigned char *>(*out_member(&dev, f)) + (size_t)a * rb,
                                           (size_t)(b - a) * rb, hipMemcpyDeviceToHost, so);
             if (e != hipSuccess) {
                 fail(ADH_ERR_HIP, std::string("hipMemcpyAsync D2H: ") + hipGetErrorString(e));
