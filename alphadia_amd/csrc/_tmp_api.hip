@@ -1,0 +1,1151 @@
+// adh_api.hip - host side of libalphadia_hip.so: the C ABI declared in
+// include/alphadia_hip.h.  Owns the HBM-resident copies of the run, the fragment
+// library and the candidate table, sizes the LDS of the scoring kernel per batch
+// and times the kernel with HIP events on its launch stream.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+#include <dlfcn.h>
+#include <unistd.h>
+#include <rccl/rccl.h>
+
+#include "adh_index_im.hip"
+#include "adh_plan.hip"
+#include "adh_gather.hip"
+#include "adh_features.hip"
+#include "_tmp_fast.hip"
+#include "adh_gather_im.hip"
+#include "adh_features_im.hip"
+#include "adh_fragcomp.hip"
+#include "adh_select.hip"
+#include "adh_select_im.hip"
+#include "adh_transpose.hip"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            (void)hipGetLastError();                                                        \
+            return fail(_e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP,   \
+                        std::string(#expr) + " (adh_api.hip:" + std::to_string(__LINE__) + "): " +   \
+                            hipGetErrorString(_e));                                         \
+        }                                                                                   \
+    } while (0)
+
+struct DeviceBuffers {
+    std::vector<void *> ptrs;
+    void release() {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+}  // namespace
+
+// device copies of the candidate columns (adh_candidates_t): one grow-only slab
+struct CandSlab {
+    void *base = nullptr;
+    size_t bytes = 0;
+    DevCands d{};
+    float *iso = nullptr;
+    uint8_t *flags = nullptr;   // storage of the flags column (d.flags stays NULL when the caller passes none)
+    int64_t n = 0;
+    int32_t n_iso_cols = 0;
+};
+
+// device buffers of one plan under construction (adh_plan.hip); two slots alternate between the
+// chunks of adh_score_candidates
+struct PlanSlot {
+    int64_t cap = 0;
+    size_t rec_bytes = 0;
+    void *recs = nullptr, *ordered = nullptr;
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
+    uint64_t *bytes = nullptr, *sorted_bytes = nullptr, *offs = nullptr;
+    void *cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+    uint32_t *hist = nullptr;       // counting sort: one counter / cursor per (class, first cycle) key
+    int64_t hist_cap = 0;
+    PlanMeta *d_meta = nullptr, *h_meta = nullptr;  // device / pinned host
+    hipEvent_t done = nullptr;
+    DeviceBuffers buf;
+};
+
+// one processing plan = CandRec table in processing order, for a given (top_k_fragments,
+// top_k_isotopes, kernel family) and row range
+struct Plan {
+    bool ready = false;
+    uint32_t top_k_fragments = 0, top_k_isotopes = 0;
+    bool fast_ok = false;          // register kernels enabled (experimental_xic)
+    bool quant_all = false;
+    int64_t row0 = 0, n = 0;
+    CandRec *d_recs = nullptr;
+    CandRecIM *d_recs_im = nullptr;
+    uint64_t scratch_bytes = 0;
+    // classes 0..6: register kernels for one observation, F <= 8 / 12 / ... / 32 (a kernel per four
+    // cycles: every cycle loop is unrolled to the class size); 7..9: two observations, F <= 16 /
+    // 24 / 32; ADH_CLASS_GENERIC: the LDS kernel
+    int64_t n_class[ADH_N_CLASSES] = {0};
+    Caps caps_generic;
+    Caps caps_all;
+};
+
+// the OutputPsmDF tables of one call as ONE packed device buffer (computed tables first)
+struct DevTables {
+    void *base = nullptr;
+    size_t bytes = 0, used = 0, wire_bytes = 0;
+    int64_t rows = 0;
+    int top_k = 0;
+    adh_output_t view{};
+};
+
+struct adh_comm_state;
+
+struct adh_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;        // compute
+    hipStream_t side_stream = nullptr;   // the generic feature kernel overlaps the register kernels
+    hipStream_t stream_in = nullptr, stream_out = nullptr;  // H2D + plan / D2H of adh_score_candidates
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_k[2] = {nullptr, nullptr};  // kernels of the chunk that used plan slot s are done
+    DevRun run{};
+    DevTims tims{};
+    bool tims_staged = false;
+    std::vector<double> h_cycle;    // host copy (candidate selection sizes its tiles on the host)
+    std::vector<int32_t> h_dpc;     // host copy of dia_precursor_cycle (adh_debug_get_dense)
+    const LibRec *d_lib = nullptr;
+    int64_t n_lib = 0;
+    double *d_wtp = nullptr;        // precursor weight table [2][64]
+    uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
+    std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
+    std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
+    double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
+    void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
+    uint64_t scratch_slab_bytes = 0;
+    DevTables tables[2];            // slot 1 only with a communicator (double-buffered all-gather)
+    int table_slot = 1, last_tables = -1;
+    int64_t last_rows = 0;
+    CandSlab cs;
+    PlanSlot slots[2];
+    Plan plan;                      // plan of the resident table (adh_upload_candidates / adh_score_uploaded)
+    bool run_staged = false, lib_staged = false, cands_uploaded = false;
+    DeviceBuffers run_buf, lib_buf;
+    adh_comm_state *comm = nullptr;
+    int64_t comm_rows = 0;          // rows of the largest shard (table layout under a communicator)
+    bool comm_attached() const { return comm != nullptr; }
+    struct Timed {
+        hipEvent_t e0, e1, e2;
+    };
+    std::vector<Timed> timed;  // per launch: before gather, between, after features
+    std::vector<hipEvent_t> free_events;
+    double sum_gather_ms = 0.0, sum_feature_ms = 0.0;
+    int64_t n_timed = 0;
+    uint64_t d2h_bytes = 0;  // bytes this library copied device -> host (adh_transfer_counters)
+};
+
+namespace {
+
+template <typename T>
+int upload(DeviceBuffers &owner, const T *host, int64_t n, const T **dev, hipStream_t) {
+    *dev = nullptr;
+    void *p = nullptr;
+    size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    owner.ptrs.push_back(p);
+    if (n > 0) HIP_TRY(hipMemcpy(p, host, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    return ADH_OK;
+}
+
+#define UP(owner, host, n, dev)                                            \
+    do {                                                                   \
+        int _rc = upload(owner, host, n, dev, h->stream);                  \
+        if (_rc != ADH_OK) return _rc;                                     \
+    } while (0)
+
+int get_event(adh_handle *h, hipEvent_t *e) {
+    if (!h->free_events.empty()) {
+        *e = h->free_events.back();
+        h->free_events.pop_back();
+        return ADH_OK;
+    }
+    HIP_TRY(hipEventCreate(e));
+    return ADH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *adh_last_error(void) { return g_last_error.c_str(); }
+
+int adh_device_count(int *count) {
+    if (!count) return fail(ADH_ERR_INVALID_ARGUMENT, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return ADH_OK;
+}
+
+int adh_create(adh_handle_t **handle, int device) {
+    if (!handle) return fail(ADH_ERR_INVALID_ARGUMENT, "handle is NULL");
+    *handle = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    adh_handle *h = new adh_handle();
+    h->device = device;
+    const char *what = "hipStreamCreate";
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking);
+    if (e == hipSuccess) what = "hipEventCreate";
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k[1], hipEventDisableTiming);
+    if (e == hipSuccess) what = "hipMalloc(weight table)";
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_wtp, 2 * 64 * sizeof(double));
+    if (e == hipSuccess) {
+        what = "adh_wtp_table_kernel";
+        hipLaunchKernelGGL(adh_wtp_table_kernel, dim3(1), dim3(128), 0, h->stream, h->d_wtp);
+        e = hipGetLastError();
+        // callers may score on a stream of their own: the table must be complete before the handle is used
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        adh_destroy(h);  // releases whatever was created so far
+        return fail(e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP, msg);
+    }
+    // the kernels may need more than the default 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void *)adh_feature_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)adh_gather_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (this kernel also has ADH_IM_STATIC_LDS bytes of static LDS)
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
+    (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    *handle = h;
+    return ADH_OK;
+}
+
+int adh_destroy(adh_handle_t *h) {
+    if (!h) return ADH_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)adh_comm_destroy(h);
+    h->run_buf.release();
+    h->lib_buf.release();
+    for (PlanSlot &s : h->slots) {
+        s.buf.release();
+        if (s.hist) (void)hipFree(s.hist);
+        if (s.h_meta) (void)hipHostFree(s.h_meta);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto &p : h->timed) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        (void)hipEventDestroy(p.e2);
+    }
+    for (auto e : h->free_events) (void)hipEventDestroy(e);
+    if (h->d_wtp) (void)hipFree(h->d_wtp);
+    for (DevTables &t : h->tables)
+        if (t.base) (void)hipFree(t.base);
+    if (h->cs.base) (void)hipFree(h->cs.base);
+    if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t e : h->ev_k)
+        if (e) (void)hipEventDestroy(e);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
+    if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    (void)hipGetLastError();
+    delete h;
+    return ADH_OK;
+}
+
+namespace {
+
+inline uint32_t float_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+// sort the peaks of the run into the transposed order and build entries + bin table
+int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, int64_t n_ref,
+                     int64_t n_tab, uint2 *entries, uint32_t *tab, DeviceBuffers &tmp) {
+    hipStream_t st = h->stream;
+    const int64_t n = d->n_peaks;
+    if (n_ref == 0 || d->n_spectra == 0) {
+        HIP_TRY(hipMemsetAsync(tab, 0, (size_t)n_tab * sizeof(uint32_t), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return ADH_OK;
+    }
+    const float *d_mz = nullptr, *d_int = nullptr;
+    const int64_t *d_ps = nullptr, *d_pe = nullptr;
+    int rc = upload(tmp, d->mz_values, n, &d_mz, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->intensity_values, n, &d_int, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_start_idx, d->n_spectra, &d_ps, st);
+    if (rc == ADH_OK) rc = upload(tmp, d->peak_stop_idx, d->n_spectra, &d_pe, st);
+    if (rc != ADH_OK) return rc;
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    uint32_t *v_in = nullptr, *v_out = nullptr;
+    int *d_bad = nullptr;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(p, bytes));
+        tmp.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    if ((rc = dev_alloc((void **)&k_in, (size_t)n * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&k_out, (size_t)n * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_in, (size_t)n * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_out, (size_t)n * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_bad, 4)) != ADH_OK) return rc;
+    // peaks no spectrum refers to keep the all-ones key and sort to the end
+    HIP_TRY(hipMemsetAsync(k_in, 0xFF, (size_t)n * 8, st));
+    HIP_TRY(hipMemsetAsync(v_in, 0, (size_t)n * 4, st));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+    hipLaunchKernelGGL(adh_peak_key_kernel, dim3((unsigned)d->n_spectra), dim3(256), 0, st, d_mz, d_ps,
+                       d_pe, d->n_spectra, (int)d->cycle_len, (int)r.block_shift, (int)r.bin0,
+                       (int)r.n_bins, k_in, v_in, d_bad);
+    HIP_TRY(hipGetLastError());
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
+    void *sort_tmp = nullptr;
+    if ((rc = dev_alloc(&sort_tmp, std::max<size_t>(sort_bytes, 16))) != ADH_OK) return rc;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
+    hipLaunchKernelGGL(adh_entries_kernel, dim3(8192), dim3(256), 0, st, k_out, v_out, d_int, n_ref,
+                       entries, tab, n_tab);
+    HIP_TRY(hipGetLastError());
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(ADH_ERR_INVALID_ARGUMENT, "m/z values are not ascending inside every spectrum");
+    return ADH_OK;
+}
+
+}  // namespace
+
+int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
+    if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->cycle_len <= 0 || d->cycle_scans <= 0 || d->n_spectra < 0 || d->n_peaks < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid run dimensions");
+    if (d->cycle_scans != 1)
+        return fail(ADH_ERR_UNSUPPORTED,
+                    "cycle with a scan axis (ion mobility) is not an AlphaRaw run");
+    if (d->n_mobility < 1) return fail(ADH_ERR_INVALID_ARGUMENT, "mobility_values is empty");
+    if (d->n_peaks >= (int64_t)0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "runs with 2^32 or more peaks are not supported yet");
+    if (d->n_spectra >= (int64_t)0x7FFFFFFFll || d->cycle_len > 65535)
+        return fail(ADH_ERR_UNSUPPORTED, "too many spectra / cycle positions");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->run_buf.release();
+    h->plan = Plan();
+    h->cands_uploaded = false;  // the resident table was planned against the previous run
+    h->run_staged = false;
+    h->tims_staged = false;
+
+    // validate the CSR on the host: kernels index with it unchecked
+    float mz_lo = 0.f, mz_hi = 0.f;
+    bool any = false;
+    int64_t n_ref = 0, prev_stop = 0;
+    for (int64_t s = 0; s < d->n_spectra; ++s) {
+        int64_t a = d->peak_start_idx[s], b = d->peak_stop_idx[s];
+        if (a < 0 || b < a || b > d->n_peaks)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "peak_start/stop_idx out of range");
+        if (b > a) {
+            if (a < prev_stop)
+                return fail(ADH_ERR_INVALID_ARGUMENT, "spectra must not share peaks (peak_start_idx < previous peak_stop_idx)");
+            prev_stop = b;
+            n_ref += b - a;
+            float lo = d->mz_values[a], hi = d->mz_values[b - 1];
+            if (!any || lo < mz_lo) mz_lo = lo;
+            if (!any || hi > mz_hi) mz_hi = hi;
+            any = true;
+        }
+    }
+    if (any && !(mz_lo > 0.f && mz_hi >= mz_lo && mz_hi < INFINITY))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "m/z values must be positive, finite and ascending inside a spectrum");
+    std::vector<int32_t> ms1;
+    for (int r = 0; r < d->cycle_len * d->cycle_scans; ++r)
+        if (-1.0 <= d->cycle[2 * r + 1] && -1.0 >= d->cycle[2 * r]) ms1.push_back(r);
+
+    DevRun r{};
+    r.n_spectra = d->n_spectra;
+    r.n_peaks = d->n_peaks;
+    r.cycle_len = d->cycle_len;
+    r.cycle_scans = d->cycle_scans;
+    r.n_ms1_obs = (int32_t)ms1.size();
+    UP(h->run_buf, d->rt_values, d->n_spectra, &r.rt);
+    UP(h->run_buf, d->mobility_values, d->n_mobility, &r.mobility);
+    UP(h->run_buf, d->cycle, (int64_t)d->cycle_len * d->cycle_scans * 2, &r.cycle);
+    UP(h->run_buf, ms1.data(), (int64_t)ms1.size(), &r.ms1_obs);
+    h->h_cycle.assign(d->cycle, d->cycle + (size_t)d->cycle_len * d->cycle_scans * 2);
+    h->h_rt.assign(d->rt_values, d->rt_values + d->n_spectra);
+
+    // ---- transposed run (see adh_gather.hip): bins, block size, table size
+    if (!any) mz_lo = mz_hi = 1.0f;
+    r.mz_min = mz_lo;
+    r.mz_max = mz_hi;
+    r.bin0 = (int32_t)(float_bits(mz_lo) >> ADH_BIN_SHIFT);
+    r.n_bins = (int32_t)(float_bits(mz_hi) >> ADH_BIN_SHIFT) - r.bin0 + 1;
+    const int64_t L = d->cycle_len;
+    const int64_t n_cycles = (d->n_spectra + L - 1) / L;
+    // about one entry per two (block, row, bin) cells: B ~ n_bins / (2 * peaks per spectrum).
+    // Measured on the bench run: gather 0.88 / 0.92 / 1.06 / 1.34 ms for B = 16 / 32 / 64 / 128.
+    int64_t avg = d->n_spectra > 0 ? std::max<int64_t>(n_ref / d->n_spectra, 1) : 1;
+    int64_t want = (int64_t)r.n_bins / (2 * avg);
+    if (const char *env = getenv("ADH_BLOCK_CYCLES")) want = atoll(env);
+    int bs = 3;
+    while (bs < 20 && (1ll << (bs + 1)) <= want) ++bs;
+    // the table must stay addressable with 32-bit bin ids and should not dwarf the peaks
+    for (;; ++bs) {
+        int64_t nblk = std::max<int64_t>((n_cycles + (1ll << bs) - 1) >> bs, 1);
+        int64_t n_tab = nblk * L * (int64_t)r.n_bins + 1;
+        if (bs >= 20 || (n_tab < (int64_t)0xFFFFFFF0ll && n_tab * 4 <= std::max<int64_t>(2 * n_ref * 8, 64ll << 20))) {
+            r.n_blocks = (int32_t)nblk;
+            break;
+        }
+    }
+    r.block_shift = bs;
+    const int64_t n_tab = (int64_t)r.n_blocks * L * (int64_t)r.n_bins + 1;
+    if (n_tab >= (int64_t)0xFFFFFFF0ll)
+        return fail(ADH_ERR_UNSUPPORTED, "m/z range x cycle positions too large for the bin table");
+
+    uint2 *entries = nullptr;
+    uint32_t *tab = nullptr;
+    HIP_TRY(hipMalloc((void **)&entries, (size_t)std::max<int64_t>(n_ref, 1) * sizeof(uint2)));
+    h->run_buf.ptrs.push_back(entries);
+    HIP_TRY(hipMalloc((void **)&tab, (size_t)n_tab * sizeof(uint32_t)));
+    h->run_buf.ptrs.push_back(tab);
+    r.entries = entries;
+    r.tab = tab;
+
+    DeviceBuffers tmp;
+    int rc = stage_transposed(h, d, r, n_ref, n_tab, entries, tab, tmp);
+    tmp.release();
+    if (rc != ADH_OK) return rc;
+    h->run = r;
+    h->run_staged = true;
+    return ADH_OK;
+}
+
+int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
+    if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->cycle_len <= 0 || d->scan_max_index <= 0 || d->n_frames <= 0 || d->n_tof <= 0 || d->n_events < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "invalid run dimensions");
+    if (d->cycle_len > 65535 || d->n_tof >= 0x7FFFFFFFll ||
+        d->n_frames * (int64_t)d->scan_max_index >= 0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "run too large for 32-bit push / TOF indices");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->run_buf.release();
+    h->plan = Plan();
+    h->cands_uploaded = false;  // the resident table was planned against the previous run
+    h->run_staged = false;
+    h->tims_staged = false;
+    // validate the index arrays on the host: kernels use them unchecked
+    if (d->tof_indptr[0] != 0 || d->tof_indptr[d->n_tof] != d->n_events)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indptr does not span the event arrays");
+    for (int64_t t = 0; t < d->n_tof; ++t) {
+        if (d->tof_indptr[t + 1] < d->tof_indptr[t])
+            return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indptr is not monotone");
+        if (t > 0 && !(d->mz_values[t] >= d->mz_values[t - 1]))
+            return fail(ADH_ERR_INVALID_ARGUMENT, "mz_values must be ascending");
+    }
+    const int64_t rows = (int64_t)d->cycle_len * d->scan_max_index;
+    std::vector<int32_t> dpc((size_t)rows);
+    for (int64_t i = 0; i < rows; ++i) {
+        if (d->dia_precursor_cycle[i] < 0 || d->dia_precursor_cycle[i] >= d->cycle_len)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "dia_precursor_cycle must index the cycle");
+        dpc[(size_t)i] = (int32_t)d->dia_precursor_cycle[i];
+    }
+    DevTims t{};
+    t.n_tof = d->n_tof;
+    t.n_events = d->n_events;
+    t.n_frames = d->n_frames;
+    t.cycle_len = d->cycle_len;
+    t.scan_max = d->scan_max_index;
+    t.zeroth = d->zeroth_frame ? 1 : 0;
+    UP(h->run_buf, d->tof_indptr, d->n_tof + 1, &t.tof_indptr);
+    UP(h->run_buf, d->push_indices, d->n_events, &t.push);
+    UP(h->run_buf, d->intensity_values, d->n_events, &t.inten);
+    UP(h->run_buf, d->mz_values, d->n_tof, &t.mz);
+    UP(h->run_buf, d->cycle, rows * 2, &t.cycle);
+    UP(h->run_buf, dpc.data(), rows, &t.dpc);
+    UP(h->run_buf, d->rt_values, d->n_frames, &t.rt);
+    UP(h->run_buf, d->mobility_values, (int64_t)d->scan_max_index, &t.mobility);
+    {
+        // search indices (DevTims): the m/z table on the host, the (bin, cycle) table on the device
+        t.n_cycles = (int32_t)((d->n_frames - t.zeroth + d->cycle_len - 1) / d->cycle_len);
+        const char *env = getenv("ADH_IM_INDEX");
+        const bool want = !(env && atoi(env) == 0) && d->n_events < 0xFFFFFFFFll && d->n_tof >= 2 && t.n_cycles > 0 &&
+                          d->mz_values[d->n_tof - 1] > d->mz_values[0];
+        if (want) {
+            int64_t nb = 1;
+            while (nb < 4 * d->n_tof) nb <<= 1;
+            const double lo = d->mz_values[0], hi = d->mz_values[d->n_tof - 1];
+            std::vector<uint32_t> lut((size_t)nb + 1);
+            int64_t pos = 0;
+            const double step = (hi - lo) / (double)nb;
+            for (int64_t b = 0; b <= nb; ++b) {
+                const double x = lo + (double)b * step;
+                while (pos < d->n_tof && d->mz_values[pos] < x) ++pos;
+                lut[(size_t)b] = (uint32_t)pos;
+            }
+            UP(h->run_buf, lut.data(), nb + 1, &t.mz_lut);
+            t.lut_min = lo;
+            t.lut_inv_step = 1.0 / step;
+            t.lut_n = (int32_t)nb;
+            // 4 bytes per (bin, cycle block): the finest block that fits an eighth of the device memory
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            size_t budget = std::min(total_b / 8, free_b / 2);
+            if (const char *mb = getenv("ADH_IM_INDEX_MB")) budget = (size_t)atoll(mb) << 20;
+            int shift = 0;
+            int64_t blocks = t.n_cycles;
+            while (shift < 16 && (size_t)d->n_tof * (size_t)(blocks + 1) * 4 > budget) {
+                ++shift;
+                blocks = ((int64_t)t.n_cycles + (1ll << shift) - 1) >> shift;
+            }
+            if ((size_t)d->n_tof * (size_t)(blocks + 1) * 4 <= budget) {
+                uint32_t *idx = nullptr;
+                if (hipMalloc((void **)&idx, (size_t)d->n_tof * (size_t)(blocks + 1) * 4) != hipSuccess) {
+                    (void)hipGetLastError();  // no room for the index: the kernels search instead
+                    idx = nullptr;
+                }
+                if (idx) {
+                h->run_buf.ptrs.push_back(idx);
+                const unsigned grid = (unsigned)std::min<int64_t>(d->n_tof, 1 << 20);
+                hipLaunchKernelGGL(adh_index_im_kernel, dim3(grid), dim3(ADH_WAVE), 0, h->stream, t.tof_indptr, t.push,
+                                   t.n_tof, (uint32_t)t.scan_max, (uint32_t)t.cycle_len, (uint32_t)t.zeroth, shift,
+                                   (uint32_t)blocks, idx);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                t.cyc_idx = idx;
+                t.cyc_shift = shift;
+                t.cyc_cols = (int32_t)(blocks + 1);
+                }
+            }
+        }
+    }
+    h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
+    h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);
+    h->h_mobility_im.assign(d->mobility_values, d->mobility_values + d->scan_max_index);
+    h->h_dpc = dpc;
+    h->tims = t;
+    h->tims_staged = true;
+    h->im_scratch_budget = 0;
+    return ADH_OK;
+}
+
+int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
+    if (!h || !f) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (f->n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative fragment count");
+    if (f->n >= (int64_t)0xFFFFFFFFll) return fail(ADH_ERR_UNSUPPORTED, "too many fragments");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->lib_buf.release();
+    h->lib_staged = false;
+    h->plan = Plan();
+    h->cands_uploaded = false;  // fragment slices of the resident table refer to the previous library
+    std::vector<LibRec> recs((size_t)f->n);
+    for (int64_t i = 0; i < f->n; ++i) {
+        LibRec &r = recs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        r.mz_library = f->mz_library[i];
+        r.mz = f->mz[i];
+        r.intensity = f->intensity[i];
+        r.type = f->type[i];
+        r.loss_type = f->loss_type[i];
+        r.charge = f->charge[i];
+        r.number = f->number[i];
+        r.position = f->position[i];
+        r.cardinality = f->cardinality[i];
+    }
+    UP(h->lib_buf, recs.data(), f->n, &h->d_lib);
+    h->n_lib = f->n;
+    h->lib_staged = true;
+    return ADH_OK;
+}
+
+#include "adh_score_host.hip"
+#include "adh_comm.hip"
+
+namespace {
+
+// Candidate selection on the staged ion-mobility run (see adh_select_im.hip); the caller has
+// validated the arguments and zero-filled the host table.
+int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_selection_config_t *cfg,
+                         const float *kernel, int32_t k0, int32_t k1, adh_candidate_table_t *out) {
+    const int64_t n = pc->n;
+    const DevTims &T = h->tims;
+    const int L = T.cycle_len, SM = T.scan_max, z = T.zeroth;
+    if (!pc->mobility) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor mobility column is NULL");
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const bool timing = getenv("ADH_DEBUG_TIMING") != nullptr;
+    const double t_0 = now();
+    // rank-1 factors of the kernel (it is an outer product up to float32 rounding of its entries)
+    std::vector<double> ku((size_t)k0), kv((size_t)k1);
+    {
+        const int a0 = k0 / 2, b0 = k1 / 2;
+        const double c = (double)kernel[a0 * k1 + b0];
+        if (!(c > 0)) return fail(ADH_ERR_UNSUPPORTED, "smoothing kernel without a positive centre");
+        for (int a = 0; a < k0; ++a) ku[(size_t)a] = (double)kernel[a * k1 + b0] / c;
+        for (int b = 0; b < k1; ++b) kv[(size_t)b] = (double)kernel[a0 * k1 + b];
+        for (int a = 0; a < k0; ++a)
+            for (int b = 0; b < k1; ++b)
+                if (std::fabs(ku[(size_t)a] * kv[(size_t)b] - (double)kernel[a * k1 + b]) > 1e-5 * c + 1e-30)
+                    return fail(ADH_ERR_UNSUPPORTED, "smoothing kernel is not separable (not an outer product)");
+    }
+    const int n_iso = (int)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
+    const std::vector<double> &rtv = h->h_rt_im, &mobv = h->h_mobility_im;
+    const double *cyc = h->h_cycle.data();
+    const int64_t cmax = (T.n_frames - 1) / L;  // precursor_cycle_max_index (bruker_jit.py:131)
+    std::vector<selim::PrecRec> recs((size_t)n);
+    int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1;  // LDS capacities of the score kernel (adh_select_im.hip)
+    auto rev_upper = [&](float v) {  // searchsorted(mobility_values[::-1], v, "right")
+        int64_t a = 0, b = SM;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if (mobv[(size_t)(SM - 1 - m)] <= (double)v) a = m + 1; else b = m;
+        }
+        return a;
+    };
+    // the per-precursor limits (searches over rt / mobility, the "empty push query" test over L x S window
+    // rows) are independent: spread over the host threads (230 ms on one thread for 200 000 precursors)
+    struct Caps5 { int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1; };
+    auto plan_range = [&](int64_t i0, int64_t i1, Caps5 &c, int &err) {
+    for (int64_t i = i0; i < i1; ++i) {
+            selim::PrecRec &r = recs[(size_t)i];
+            memset(&r, 0, sizeof(r));
+            if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
+                { err = 1; return; }
+            if (pc->charge[i] == 0) { err = 2; return; }
+            if ((int64_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]) + n_iso > selim::MAX_W)
+                { err = 3; return; }
+            r.precursor_idx = pc->precursor_idx[i];
+            r.frag_start = pc->frag_start_idx[i];
+            r.frag_stop = pc->frag_stop_idx[i];
+            r.mz = pc->mz[i];
+            r.charge = pc->charge[i];
+            // frame limits: get_frame_indices (jitclasses/utils.py:24-88) with the zeroth frame
+            const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
+            const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), (double)lo) - rtv.begin();
+            const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), (double)hi) - rtv.begin();
+            const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
+            int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
+            len = 16 * (int64_t)std::ceil((double)len / 16.0);
+            int64_t cs = c_lo, ce = c_lo + len;
+            if (ce > cmax) {
+                ce = cmax;
+                cs = cmax - len;
+                if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+            }
+            // scan limits: _get_scan_indices (bruker_jit.py:204-245); ceil of a negative quotient
+            const float m_hi = (float)((double)pc->mobility[i] + cfg->mobility_tolerance);
+            const float m_lo = (float)((double)pc->mobility[i] - cfg->mobility_tolerance);
+            const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
+            const int64_t opt_len = 16 * (int64_t)std::ceil((double)(s_first - s_second) / 16.0);
+            int64_t ss = s_first, se = s_first - opt_len;
+            if (se < 0) {
+                se = 0;
+                ss = std::min<int64_t>(opt_len, SM);
+            }
+            const int64_t S = std::max<int64_t>(se - ss, 0), F = ce - cs;
+            r.cycle_start = (int32_t)cs;
+            r.n_cycles = (int32_t)std::max<int64_t>(F, 0);
+            r.scan_start = (int32_t)ss;
+            r.n_scans = (int32_t)S;
+            bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
+            if (ok) {
+                // an empty push query ends the precursor (bruker_jit.py:516-519, selection.py:40-49)
+                const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc->charge[i];
+                const double q_lo = (double)(float)((double)pc->mz[i] + 0.0), q_hi = (double)(float)((double)pc->mz[i] + off);
+                bool any_f = false, any_p = false;
+                for (int row = 0; row < L && !(any_f && any_p); ++row)
+                    for (int64_t sc = ss; sc < ss + S; ++sc) {
+                        const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
+                        any_f = any_f || (q_lo <= wh && q_hi >= wl);
+                        any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
+                        if (any_f && any_p) break;  // both queries are non-empty: nothing more to learn
+                    }
+                ok = any_f && any_p;
+            }
+            r.ok = ok ? 1 : 0;
+            if (ok) {
+                c.cap_cells = std::max<int32_t>(c.cap_cells, (int32_t)(S * F));
+                c.cap_tp = std::max<int32_t>(c.cap_tp, (int32_t)(S * (F + k1)));
+                c.cap_mp = std::max<int32_t>(c.cap_mp, (int32_t)((S + k0) * F));
+                c.cap_s = std::max<int32_t>(c.cap_s, (int32_t)S);
+                c.cap_f = std::max<int32_t>(c.cap_f, (int32_t)F);
+            }
+        }
+    };
+    {
+        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 2048 + 1}));
+        std::vector<Caps5> caps((size_t)n_thr);
+        std::vector<int> errs((size_t)n_thr, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) {
+            const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
+            bool started = false;
+            if (t + 1 < n_thr) {
+                try {  // (no exception may cross the C ABI: a range whose thread cannot be started runs here)
+                    pool.emplace_back(plan_range, i0, i1, std::ref(caps[(size_t)t]), std::ref(errs[(size_t)t]));
+                    started = true;
+                } catch (...) {
+                }
+            }
+            if (!started) plan_range(i0, i1, caps[(size_t)t], errs[(size_t)t]);
+        }
+        for (std::thread &th : pool) th.join();
+        for (int t = 0; t < n_thr; ++t) {
+            if (errs[(size_t)t] == 1) return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+            if (errs[(size_t)t] == 2) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+            if (errs[(size_t)t] == 3) return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
+            cap_cells = std::max(cap_cells, caps[(size_t)t].cap_cells);
+            cap_tp = std::max(cap_tp, caps[(size_t)t].cap_tp);
+            cap_mp = std::max(cap_mp, caps[(size_t)t].cap_mp);
+            cap_s = std::max(cap_s, caps[(size_t)t].cap_s);
+            cap_f = std::max(cap_f, caps[(size_t)t].cap_f);
+        }
+    }
+    cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
+    (void)cap_tp;
+    (void)cap_mp;
+    const size_t lds_smooth = adh_select_smooth_im_lds_bytes(cap_cells, cap_s, k0, k1);
+    const size_t lds = std::max(lds_smooth, adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f));
+    if (lds > 150 * 1024 || cap_f > selim::SCORE_THREADS) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "selection tile of %d cells (scans x cycles, %d cycles) needs %zu bytes of LDS: exceeds 150 KiB",
+                 cap_cells, cap_f, lds);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    // batches of precursors whose tiles fit a bounded scratch slab
+    // the scratch slab of the handle is used (kept between calls; only reserved memory: a precursor's tiles are
+    // normally kept in sparse form and touch a few KB of their block); batches follow each other on the
+    // stream, so a batch may reuse the slab of the one before without the host waiting
+    uint64_t budget = 8ull << 30;
+    if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
+    {
+        uint64_t all = 0, biggest = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const selim::PrecRec &r = recs[(size_t)i];
+            const uint64_t need = selim::SEL_HEADER +
+                                  (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
+            const uint64_t aligned = (need + 255) / 256 * 256;
+            all += aligned;
+            biggest = std::max(biggest, aligned);
+        }
+        budget = std::max(std::min(budget, all), biggest);
+        budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
+    }
+    const double t_plan = now();
+    DeviceBuffers tmp;
+    const double *d_ku = nullptr, *d_kv = nullptr;
+    int rc = upload(tmp, ku.data(), k0, &d_ku, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, kv.data(), k1, &d_kv, h->stream);
+    DevCandTable dt{};
+    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
+                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
+    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
+    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
+                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
+                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>((size_t)out->n * width[f], 16));
+        if (e != hipSuccess) {
+            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
+            break;
+        }
+        tmp.ptrs.push_back(p);
+        *dev_out[f] = p;
+        e = hipMemsetAsync(p, 0, std::max<size_t>((size_t)out->n * width[f], 16), h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    unsigned char *d_scratch = nullptr;
+    selim::PrecRec *d_recs = nullptr;
+    if (rc == ADH_OK) {
+        if (h->scratch_slab_bytes < budget) {
+            // (exactly the budget: ensure_scratch's head-room is for scoring batches that grow from call to call)
+            hipError_t e = hipDeviceSynchronize();
+            if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+            h->scratch_slab = nullptr;
+            h->scratch_slab_bytes = 0;
+            if (e == hipSuccess) e = hipMalloc(&h->scratch_slab, budget);
+            if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
+            else h->scratch_slab_bytes = budget;
+        }
+        d_scratch = static_cast<unsigned char *>(h->scratch_slab);
+    }
+    if (rc == ADH_OK) {
+        hipError_t e = hipMalloc((void **)&d_recs, std::max<size_t>((size_t)n * sizeof(selim::PrecRec), 16));
+        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection plan): ") + hipGetErrorString(e));
+        else tmp.ptrs.push_back(d_recs);
+    }
+    double total_ms = 0.0;
+    const double t_alloc = now();
+    if (rc == ADH_OK) {
+        (void)hipFuncSetAttribute((const void *)adh_select_score_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipFuncSetAttribute((const void *)adh_select_smooth_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipGetLastError();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        // plan every batch on the host, one upload, then the kernels of the batches back to back
+        std::vector<std::pair<int64_t, int64_t>> batches;
+        int32_t debug_dense = 0;
+        if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_DENSE")) debug_dense = atoi(dbg);
+        int32_t debug_abl = 0;
+        if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_ABL")) debug_abl = atoi(dbg);
+        int64_t first = 0;
+        while (first < n && rc == ADH_OK) {
+            uint64_t off = 0;
+            int64_t last = first;
+            while (last < n) {
+                selim::PrecRec &r = recs[(size_t)last];
+                const uint64_t need = selim::SEL_HEADER +
+                                      (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
+                const uint64_t aligned = (need + 255) / 256 * 256;
+                if (off + aligned > budget) break;
+                r.scratch_off = off;
+                off += aligned;
+                ++last;
+            }
+            if (last == first) {
+                rc = fail(ADH_ERR_UNSUPPORTED, "one precursor's tiles exceed the selection scratch budget");
+                break;
+            }
+            batches.emplace_back(first, last);
+            first = last;
+        }
+        if (rc == ADH_OK) {
+            hipError_t e = hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(selim::PrecRec), hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+            for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) {
+                const int64_t b0 = batches[b].first;
+                const int32_t cnt = (int32_t)(batches[b].second - b0);
+                hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
+                                   h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
+                hipLaunchKernelGGL(adh_select_smooth_im_kernel, dim3((unsigned)cnt), dim3(selim::SMOOTH_THREADS), lds_smooth,
+                                   h->stream, d_recs + b0, cnt, d_ku, d_kv, k0, k1, cap_cells, cap_s, d_scratch, debug_abl);
+                hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS),
+                                   adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f), h->stream, T, d_recs + b0, cnt, b0, *cfg,
+                                   cap_cells, cap_s, cap_f, d_scratch, dt);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
+            float ms = 0.0f;
+            if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    const double t_kernels = now();
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    if (rc == ADH_OK) h->last_select_ms = total_ms;
+    const double t_copy = now();
+    tmp.release();
+    if (timing)
+        fprintf(stderr, "[adh] select_candidates_im n=%lld: host plan %.2f ms, allocations %.2f, upload + kernels %.2f (kernels %.2f), D2H %.2f, free %.2f\n",
+                (long long)n, t_plan - t_0, t_alloc - t_plan, t_kernels - t_alloc, total_ms, t_copy - t_kernels, now() - t_copy);
+    return rc;
+}
+
+}  // namespace
+
+int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh_selection_config_t *cfg,
+                          const float *kernel, int32_t k_rows, int32_t k_cols, adh_candidate_table_t *out) {
+    if (!h || !pc || !cfg || !kernel || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!h->run_staged && !h->tims_staged) return fail(ADH_ERR_NOT_STAGED, "no run staged");
+    if (!h->d_lib) return fail(ADH_ERR_NOT_STAGED, "no fragment library staged");
+    if (pc->n < 0 || cfg->candidate_count <= 0 || cfg->candidate_count > sel::MAX_CAND)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "candidate_count must be in 1..16");
+    if (out->n != pc->n * cfg->candidate_count)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "candidate table rows != precursors x candidate_count");
+    if (k_rows <= 0 || k_cols <= 0 || cfg->top_k_precursors <= 0 || pc->n_isotope_cols <= 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "kernel / isotope dimensions must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t n = pc->n;
+    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
+                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
+    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
+    for (int f = 0; f < 9; ++f) {
+        if (!host_out[f]) return fail(ADH_ERR_INVALID_ARGUMENT, "candidate table buffer is NULL");
+        memset(host_out[f], 0, (size_t)out->n * width[f]);
+    }
+    if (n == 0) return ADH_OK;
+    if (h->tims_staged) return select_candidates_im(h, pc, cfg, kernel, k_rows, k_cols, out);
+    // validate the fragment slices, size the LDS: longest slice, largest tile (the frame limits
+    // of get_frame_indices, jitclasses/utils.py:24-88, depend on the tolerance only through the
+    // number of cycles)
+    sel::SelCaps caps{};
+    caps.n_iso = (int32_t)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
+    caps.k_rows = k_rows;
+    caps.k_cols = k_cols;
+    const int L = h->run.cycle_len;
+    const int64_t cmax = h->run.n_spectra / L;
+    const std::vector<float> &rtv = h->h_rt;
+    std::vector<int32_t> cyc_start((size_t)n), cyc_count((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+        if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+        caps.n_lib = std::max<int32_t>(caps.n_lib, (int32_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]));
+        // get_frame_indices_tolerance -> get_frame_indices (alpharaw_jit.py:172-203, jitclasses/utils.py:24-88)
+        const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
+        const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), lo) - rtv.begin();
+        const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), hi) - rtv.begin();
+        const int64_t c_lo = f_lo / L, c_hi = f_hi / L;
+        int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
+        len = 16 * (int64_t)std::ceil((double)len / 16.0);
+        int64_t cs = c_lo, ce = c_lo + len;
+        if (ce > cmax) {
+            ce = cmax;
+            cs = cmax - len;
+            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+        }
+        cyc_start[(size_t)i] = (int32_t)cs;
+        cyc_count[(size_t)i] = (int32_t)(ce - cs);
+        caps.f = std::max<int32_t>(caps.f, (int32_t)(ce - cs));
+    }
+    caps.n_lib = std::max(caps.n_lib, 1);
+    caps.f = std::max(caps.f, 1);
+    const size_t lds = sel::lds_bytes(caps);
+    if (lds > 150 * 1024) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "selection tile needs %zu bytes of LDS (%d cycles, %d fragments): exceeds 150 KiB",
+                 lds, caps.f, caps.n_lib);
+        return fail(ADH_ERR_UNSUPPORTED, buf);
+    }
+    DeviceBuffers tmp;
+    DevPrecursors dp{};
+    dp.n_iso_cols = pc->n_isotope_cols;
+    int rc = upload(tmp, pc->precursor_idx, n, &dp.precursor_idx, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->frag_start_idx, n, &dp.frag_start, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->frag_stop_idx, n, &dp.frag_stop, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->charge, n, &dp.charge, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->rt, n, &dp.rt, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->mz, n, &dp.mz, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, pc->isotope_intensity, n * pc->n_isotope_cols, &dp.iso, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, cyc_start.data(), n, &dp.cycle_start, h->stream);
+    if (rc == ADH_OK) rc = upload(tmp, cyc_count.data(), n, &dp.cycle_count, h->stream);
+    const float *d_kernel = nullptr;
+    if (rc == ADH_OK) rc = upload(tmp, kernel, (int64_t)k_rows * k_cols, &d_kernel, h->stream);
+    DevCandTable dt{};
+    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
+                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
+                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (size_t)out->n * width[f]);
+        if (e != hipSuccess) {
+            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
+            break;
+        }
+        tmp.ptrs.push_back(p);
+        *dev_out[f] = p;
+        e = hipMemsetAsync(p, 0, (size_t)out->n * width[f], h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    if (rc == ADH_OK) {
+        (void)hipFuncSetAttribute((const void *)adh_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipGetLastError();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream, h->run, h->d_lib,
+                           dp, n, *cfg, d_kernel, caps, dt);
+        hipError_t e = hipGetLastError();
+        (void)hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("selection kernel: ") + hipGetErrorString(e));
+        float ms = 0.0f;
+        if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) h->last_select_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
+        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+    }
+    tmp.release();
+    return rc;
+}
+
+int adh_transpose_timstof(adh_handle_t *h, const uint32_t *tof_indices, const int64_t *push_indptr,
+                          int64_t n_push, int64_t n_tof, const uint16_t *values, int64_t n,
+                          uint32_t *push_out, int64_t *tof_indptr_out, uint16_t *values_out) {
+    if (!h || !push_indptr || !tof_indptr_out || (n > 0 && (!tof_indices || !values || !push_out || !values_out)))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_push < 0 || n_tof < 0 || n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative size");
+    if (n >= (int64_t)0x7FFFFFFFll || n_push >= (int64_t)0xFFFFFFFFll || n_tof >= (int64_t)0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 - 1 detector events per call are not supported");
+    if (push_indptr[0] != 0 || push_indptr[n_push] != n)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "push_indptr does not span the event arrays");
+    for (int64_t p = 0; p < n_push; ++p)
+        if (push_indptr[p + 1] < push_indptr[p]) return fail(ADH_ERR_INVALID_ARGUMENT, "push_indptr is not monotone");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n == 0) {
+        for (int64_t t = 0; t <= n_tof; ++t) tof_indptr_out[t] = 0;
+        return ADH_OK;
+    }
+    hipStream_t st = h->stream;
+    DeviceBuffers tmp;
+    const uint32_t *d_tof = nullptr;
+    const int64_t *d_ptr = nullptr;
+    const uint16_t *d_val = nullptr;
+    int rc = upload(tmp, tof_indices, n, &d_tof, st);
+    if (rc == ADH_OK) rc = upload(tmp, push_indptr, n_push + 1, &d_ptr, st);
+    if (rc == ADH_OK) rc = upload(tmp, values, n, &d_val, st);
+    uint32_t *d_push_of = nullptr, *d_ev_in = nullptr, *d_ev_out = nullptr, *d_tof_out = nullptr, *d_push_out = nullptr;
+    uint16_t *d_val_out = nullptr;
+    int64_t *d_indptr = nullptr;
+    int *d_bad = nullptr;
+    void *sort_tmp = nullptr;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        tmp.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_of, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_in, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_tof_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_val_out, (size_t)n * 2);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_indptr, (size_t)(n_tof + 1) * 8);
+    (void)d_bad;
+    hipError_t e = hipSuccess;
+    if (rc == ADH_OK) {
+        hipLaunchKernelGGL(adh_expand_push_kernel, dim3(4096), dim3(256), 0, st, d_ptr, n_push, d_push_of);
+        hipLaunchKernelGGL(adh_iota_kernel, dim3(4096), dim3(256), 0, st, d_ev_in, n);
+        int end_bit = 1;
+        while (end_bit < 32 && ((int64_t)1 << end_bit) < std::max<int64_t>(n_tof, 2)) ++end_bit;
+        size_t sort_bytes = 0;
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)n, 0,
+                                               end_bit, st);
+        if (e == hipSuccess) rc = dev_alloc(&sort_tmp, sort_bytes);
+        if (e == hipSuccess && rc == ADH_OK)
+            e = hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)n, 0,
+                                                   end_bit, st);
+        if (e == hipSuccess && rc == ADH_OK) {
+            hipLaunchKernelGGL(adh_transpose_gather_kernel, dim3(8192), dim3(256), 0, st, d_ev_out, d_push_of, d_val, n,
+                               d_push_out, d_val_out);
+            hipLaunchKernelGGL(adh_tof_indptr_kernel, dim3(1024), dim3(256), 0, st, d_tof_out, n, n_tof, d_indptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(push_out, d_push_out, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(values_out, d_val_out, (size_t)n * 2, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK)
+            e = hipMemcpyAsync(tof_indptr_out, d_indptr, (size_t)(n_tof + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ADH_OK) e = hipStreamSynchronize(st);
+        if (e != hipSuccess && rc == ADH_OK) rc = fail(ADH_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e));
+    }
+    tmp.release();
+    return rc;
+}
+
+int adh_select_time_ms(adh_handle_t *h, double *kernel_ms) {
+    if (!h || !kernel_ms) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *kernel_ms = h->last_select_ms;
+    return ADH_OK;
+}
+
+int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start,
+                 const int64_t *window_stop, int64_t n_psm, const float *rt,
+                 const int64_t *frag_start_idx, const int64_t *frag_stop_idx, int64_t n_frag,
+                 const float *fragment_mz, double rt_tol_seconds, double mass_tol_ppm,
+                 uint8_t *valid) {
+    if (!h || (n_windows > 0 && (!window_start || !window_stop)) ||
+        (n_psm > 0 && (!rt || !frag_start_idx || !frag_stop_idx || !valid)) ||
+        (n_frag > 0 && !fragment_mz))
+        return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_windows < 0 || n_psm < 0 || n_frag < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "negative size");
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (window_start[w] < 0 || window_stop[w] < window_start[w] || window_stop[w] > n_psm)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "window range outside the PSM table");
+    for (int64_t i = 0; i < n_psm; ++i)
+        if (frag_start_idx[i] < 0 || frag_stop_idx[i] < frag_start_idx[i] || frag_stop_idx[i] > n_frag)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment range outside the fragment table");
+    if (n_windows == 0 || n_psm == 0) return ADH_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    DeviceBuffers tmp;
+    const int64_t *d_ws, *d_we, *d_fs, *d_fe;
+    const float *d_rt, *d_mz;
+    const uint8_t *d_valid_c;
+    int rc;
+#define FC_UP(host, n, dev)                                   \
+    rc = upload(tmp, host, n, dev, h->stream);                \
+    if (rc != ADH_OK) {                                       \
+        tmp.release();                                        \
+        return rc;                                            \
+    }
+    FC_UP(window_start, n_windows, &d_ws);
+    FC_UP(window_stop, n_windows, &d_we);
+    FC_UP(rt, n_psm, &d_rt);
+    FC_UP(frag_start_idx, n_psm, &d_fs);
+    FC_UP(frag_stop_idx, n_psm, &d_fe);
+    FC_UP(fragment_mz, n_frag, &d_mz);
+    FC_UP(valid, n_psm, &d_valid_c);
+#undef FC_UP
+    uint8_t *d_valid = const_cast<uint8_t *>(d_valid_c);
+    hipLaunchKernelGGL(adh_fragcomp_kernel, dim3((unsigned)n_windows), dim3(ADH_FC_THREADS), 0,
+                       h->stream, n_windows, d_ws, d_we, d_rt, d_fs, d_fe, d_mz, rt_tol_seconds,
+                       mass_tol_ppm, d_valid);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(valid, d_valid, (size_t)n_psm, hipMemcpyDeviceToHost);
+    tmp.release();
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("fragcomp: ") + hipGetErrorString(e));
+    return ADH_OK;
+}
+
+}  // extern "C"
+
+#include "adh_fdr.hip"
+#include "adh_mlp.hip"
+#include "adh_fdr_device.hip"

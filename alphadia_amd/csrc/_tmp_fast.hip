@@ -1,0 +1,954 @@
+// adh_features_fast.hip - register-resident feature kernel for the common candidate shape.
+//
+// Same arithmetic as adh_feature_kernel (adh_features.hip) - which in turn restates
+// Candidate.process after get_dense (alphadia/search/scoring/containers/candidate.py:278-481)
+// - but organised around the register file instead of LDS:
+//
+//   * four candidates per 64-lane wavefront, 16 lanes each; lane = fragment (K <= 16)
+//   * a lane keeps the XIC row of its fragment in VGPRs, *centred*: register r holds cycle
+//     f = r - FM/2 + F/2, so the apex sits in register FM/2 for every F <= FM and all loops over
+//     cycles are fully unrolled with constant register indices; cells outside [0, F) hold 0,
+//     which leaves float32 sums unchanged, so most reductions need no predication.  The kernel
+//     is instantiated for FM = 8, 12, ..., 32 (one observation) and 16, 24, 32 (two)
+//   * the three isotope rows use the same registers in an earlier phase
+//   * LDS carries only what crosses lanes (template, weight tables, per-fragment results,
+//     a 16x16 transpose buffer for the per-cycle median): 3.8 KB per candidate
+//   * float32 reductions keep the reference's sequential order -> bit-identical to the
+//     generic kernel and the CPU oracle
+//
+//   * a precursor that overlaps two isolation windows (O == 2) runs the per-observation part
+//     twice over the same registers: rows of observation o are loaded, their row sums,
+//     weighted centre means and frame-profile statistics are parked in LDS ([fragment][o]),
+//     and the rows are added into the fragment's summed profile
+//
+// Eligibility (decided by the host plan): O <= ADH_FAST_OMAX observations (and quant_all when
+// O > 1), 3 <= F <= 32, k_cap <= 16, I <= 4, experimental_xic = True.  Everything else runs
+// through adh_feature_kernel.
+#include "adh_device.h"
+#include "adh_feature_common.h"
+
+#define ADH_FMAX 32  // largest cycle count handled by the register kernels
+#define ADH_GS 16
+#define ADH_FAST_OMAX 2  // observations handled by the register kernels
+
+namespace fast {
+
+using feat::Assemble;
+
+__device__ __forceinline__ double logistic(double x, double mu, double sigma) {
+    double a = (x - mu) / sigma;
+    return 1.0 / (1.0 + exp(-a));
+}
+
+template <int FM, int NO>
+struct __attribute__((aligned(16))) GroupLds {
+    union {
+        double dT[4][FM];    // isotope contributions to the template of one observation
+        float nrmT[16][17];        // transpose buffer for the per-cycle median (padded rows)
+        struct {                   // per-fragment terms of the feature sums: [fragment][sum]
+            double t64[16][6];
+            float t32[16][6];
+        } at;
+    } u;
+    double wt[2][FM];        // exp weights around the template centre of one observation, centred index
+    double merr[16];
+    double ohe[16][NO], omz[16][NO];  // [fragment lane][observation]
+    double hp[4], omzp[4], qtf[4][NO];
+    double red64[12];        // results of the float64 sums
+    float tpl[NO][FM], tfp[FM], frt[FM], med[FM];  // centred index
+    float g_int[16], g_fin[16], corr[16];
+    float rowsum[16][NO], ftc[16][NO], fw[16][NO];  // [fragment lane][o]
+    int fpeak[16][NO];
+    float iso_mz[4], iso_int[4], spi[4];
+    float oi[NO], tsum[NO], qmask[NO];
+    float red32[8];          // results of the float32 sums
+    float feat[ADH_NUM_FEATURES + 2];
+    int ord[16];
+    int medlo[NO], medhi[NO];
+};
+
+// Make a register value opaque to the optimiser (no instruction is emitted): stops LICM from
+// hoisting the 64 float->double conversions of a row out of the two-trip scan loop, which
+// would keep 128 extra VGPRs live.
+#define OPAQUE(x) __asm__ volatile("" : "+v"(x))
+#define FOR_R _Pragma("unroll") for (int r = 0; r < FM; ++r)
+// Compiler-only fence every 8 unrolled iterations: keeps hipcc from hoisting all 32 (or 64)
+// table loads of an unrolled loop to its top, which would double the live register set.
+#define R_FENCE(r)                                        \
+    do {                                                  \
+        if ((((r)) & 7) == 7) __asm__ volatile("" ::: "memory"); \
+    } while (0)
+
+// center_envelope_1d (fragment_features.py:71-159) on a centred register row
+template <int FM>
+__device__ __forceinline__ void center_envelope(float (&x)[FM], int F) {
+    constexpr int RC = FM / 2;
+    const int c = F / 2;
+    if (F & 1) {
+        double left = (double)(x[RC - 1] + x[RC]) * 0.5;
+        double right = (double)(x[RC + 1] + x[RC]) * 0.5;
+#pragma unroll
+        for (int i = 1; i <= RC - 1; ++i) {
+            if (i <= c) {
+                x[RC - i] = (float)fmin(left, (double)x[RC - i]);
+                left = (double)(x[RC - i] + x[RC - i + 1]) * 0.5;
+                x[RC + i] = (float)fmin(right, (double)x[RC + i]);
+                right = (double)(x[RC + i] + x[RC + i - 1]) * 0.5;
+            }
+        }
+    } else {
+        // cl = register 15, cr = register 16
+        double left = x[RC - 1], right = x[RC];
+#pragma unroll
+        for (int i = 1; i <= RC - 1; ++i) {
+            if (i <= c - 1) {
+                x[RC - 1 - i] = (float)fmin(left, (double)x[RC - 1 - i]);
+                left = (double)(x[RC - 1 - i] + x[RC - i]) * 0.5;
+                x[RC + i] = (float)fmin(right, (double)x[RC + i]);
+                right = (double)(x[RC + i] + x[RC + i - 1]) * 0.5;
+            }
+        }
+    }
+}
+
+// ascending bitonic sort of 16 registers
+__device__ __forceinline__ void sort16(float (&v)[16]) {
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int l = i ^ j;
+                if (l > i) {
+                    float a = v[i], b = v[l];
+                    float lo = fminf(a, b), hi = fmaxf(a, b);
+                    bool up = (i & k) == 0;
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+// frame-profile statistics of one (fragment, observation) row against the template frame
+// profile of that observation: fragment-vs-template correlation (scoring/utils.py:574-647),
+// FWHM in RT (profile_features.py:117-146) and apex (profile_features.py:192-193)
+template <int FM>
+__device__ __forceinline__ void profile_stats(const float (&P)[FM], const float *tfp, int F, int shift,
+                                              float rt_width, float &ftc, float &fw, int &fpeak) {
+    float syt = 0.0f;
+    FOR_R {
+        syt += tfp[r];
+        R_FENCE(r);
+    }
+    const float ym = syt / (float)F;
+    float qy = 0.0f;
+    FOR_R {
+        int f = r + shift;
+        bool ok = f >= 0 && f < F;
+        float d = ok ? tfp[r] - ym : 0.0f;
+        qy += d * d;
+        R_FENCE(r);
+    }
+    const float ysd = sqrtf(qy / (float)F);
+    float sy = 0.0f;
+    FOR_R sy += P[r];
+    const float xmn = sy / (float)F;
+    float qx = 0.0f, dot = 0.0f;
+    FOR_R {
+        int f = r + shift;
+        bool ok = f >= 0 && f < F;
+        float d = ok ? P[r] - xmn : 0.0f;
+        qx += d * d;
+    }
+    const float xsd = sqrtf(qx / (float)F);
+    FOR_R {
+        int f = r + shift;
+        bool ok = f >= 0 && f < F;
+        float dx = ok ? P[r] - xmn : 0.0f;
+        float dy = ok ? tfp[r] - ym : 0.0f;
+        dot += dx * dy;
+        R_FENCE(r);
+    }
+    const float cv = dot / (float)F;
+    const float smm = xsd * ysd;
+    ftc = (float)((double)cv / ((double)smm + 1e-12));
+    float mxv = 0.0f;
+    int am = 0;
+    bool first = true;
+    FOR_R {
+        int f = r + shift;
+        bool ok = f >= 0 && f < F;
+        if (ok && (first || P[r] > mxv)) {
+            mxv = P[r];
+            am = f;
+            first = false;
+        }
+    }
+    const double half_max = (double)mxv / 2.0;
+    int n_above = 0;
+    FOR_R {
+        int f = r + shift;
+        bool ok = f >= 0 && f < F;
+        n_above += (ok && (double)P[r] > half_max);
+    }
+    const double frac = (double)n_above / (double)F;
+    fw = (float)(frac * (double)rt_width);
+    fpeak = am;
+}
+
+}  // namespace fast
+
+// precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), s in {0,1}, f < 64:
+// the "expected centre" (S, 1) of precursor_features.py:52-57 does not depend on the candidate
+__global__ void adh_wtp_table_kernel(double *table) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * 64) return;
+    int sc = i / 64, f = i - sc * 64;
+    double ds = (double)(sc - 2), df = (double)(f - 1);
+    table[i] = exp(-0.1 * sqrt(ds * ds + df * df));
+}
+
+template <int FM, int NO>
+__global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
+    DevRun run, const CandRec *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
+    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    using namespace fast;
+    constexpr int RC = FM / 2;
+    constexpr int O = NO;  // every candidate of this launch has NO observations (host plan)
+    __shared__ GroupLds<FM, NO> lds[ADH_WAVE / ADH_GS];
+    __shared__ double wtp_s[2][FM];
+    const int lane = threadIdx.x;
+    // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), f < F <= FM: the "expected
+    // centre" (S, 1) of precursor_features.py:52-57 does not depend on the candidate
+    if (lane < FM) {
+        wtp_s[0][lane] = wtp_table[lane];
+        wtp_s[1][lane] = wtp_table[64 + lane];
+    }
+    __syncthreads();
+    const int g = lane / ADH_GS, sub = lane % ADH_GS;
+    const unsigned gsh = (unsigned)(g * ADH_GS);
+    GroupLds<FM, NO> &L = lds[g];
+    const int ci = blockIdx.x * (ADH_WAVE / ADH_GS) + g;
+    bool alive = ci < n_cand;
+    const CandRec &rec = plan[alive ? ci : 0];
+    alive = alive && !(rec.flags & ADH_FLAG_SKIP);
+    const unsigned char *block = scratch + rec.scratch_off;
+    const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
+    int K0 = alive ? (int)header[0] : 0;
+    alive = alive && K0 != 0;
+    if (__ballot(alive) == 0ull) return;  // (every lane of a dead candidate walks the whole kernel masked: four dead ones need not)
+    const uint32_t row = rec.row;
+    const int Lc = run.cycle_len;
+    const int c0 = rec.frame_start / Lc;
+    const int F = alive ? rec.frame_stop / Lc - c0 : 0;
+    const int c = F / 2;
+    const int shift = c - RC;  // f = r + shift
+    const int I = alive ? min(n_iso_cols, (int)cfg.top_k_isotopes) : 0;
+    const int top_k = out.top_k;
+    const float rt_width = alive ? run.rt[rec.frame_stop - 1] - run.rt[rec.frame_start] : 0.0f;
+    if (alive && sub == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (sub + 16 * j < ADH_NUM_FEATURES + 2) L.feat[sub + 16 * j] = 0.0f;
+    // location features (location_features.py:8-33) right away: their four table look-ups would
+    // otherwise sit, exposed, in the middle of the single-lane feature assembly
+    float loc = 0.0f;
+    if (alive && sub < 4) {
+        loc = sub == 0   ? run.mobility[rec.scan_start] - run.mobility[rec.scan_stop - 1]
+              : sub == 1 ? rt_width
+              : sub == 2 ? run.rt[rec.frame_center]
+                         : run.mobility[rec.scan_center];
+    }
+
+    float A[FM], B[FM];
+
+    // ================= precursor phase: lanes 0..I-1 hold one isotope row each =================
+    const bool iso_lane = alive && sub < I;
+    {
+        const float2 *pcells =
+            reinterpret_cast<const float2 *>(block + adh_scratch_prec_off(rec.k_cap, O, F));
+        FOR_R {
+            int f = r + shift;
+            bool ok = iso_lane && f >= 0 && f < F;
+            float2 v = pcells[ok ? sub * F + f : 0];  // branch-free: clamp the index, mask the value
+            A[r] = ok ? v.x : 0.0f;
+            B[r] = ok ? v.y : 0.0f;
+        }
+        float iso_int_l = 0.0f, iso_mz_l = 0.0f;
+        double q[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) q[o] = 0.0;
+        if (iso_lane) {
+            iso_int_l = iso_table[(int64_t)row * n_iso_cols + sub];
+            double off = (double)sub * 1.0033548350700006 / (double)rec.charge;  // candidate.py:158-163
+            iso_mz_l = (float)off + rec.precursor_mz;
+            // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1
+            double x = (double)iso_mz_l;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const double *cy = run.cycle + 2 * ((int64_t)rec.obs[o] * run.cycle_scans + rec.scan_start);
+                q[o] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+                L.qtf[sub][o] = q[o];
+            }
+            L.iso_mz[sub] = iso_mz_l;
+            L.iso_int[sub] = iso_int_l;
+        }
+        float sf = 0.0f;
+        FOR_R sf += A[r];
+        // weighted centre means around (S, 1) (precursor_features.py:52-66)
+        double vh = 0, wh = 0, vm = 0, wm = 0;
+        bool anyh = false, anym = false;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+        for (int sc = 0; sc < 2; ++sc) {
+            FOR_R {
+                int f = r + shift;
+                bool ok = iso_lane && f >= 0 && f < F;
+                double w = ok ? wtp_s[sc][f] : 0.0;
+                float a = A[r], b = B[r];
+                OPAQUE(a);
+                OPAQUE(b);
+                if (ok && a > 0.0f) {
+                    anyh = true;
+                    vh += (double)a * w;
+                    wh += w;
+                }
+                if (ok && b > 0.0f) {
+                    anym = true;
+                    vm += (double)b * w;
+                    wm += w;
+                }
+                R_FENCE(r);
+            }
+        }
+        if (iso_lane) {
+            L.spi[sub] = sf + sf;
+            L.hp[sub] = (anyh && wh > 0) ? vh / wh : 0.0;
+            L.omzp[sub] = (anym && wm > 0) ? vm / wm : 0.0;
+        }
+        // template rows of every observation (quadrupole.py:304-324) and the qtf mask
+        // (candidate.py:287-289)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            __syncthreads();  // the previous observation's contributions were consumed
+            FOR_R {
+                float a = A[r] * iso_int_l;
+                if (iso_lane) L.u.dT[sub][r] = (double)a * q[o];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+                int r = sub + 16 * pass;
+                if (r < FM) {
+                    double acc = 0;
+                    for (int i = 0; i < I; ++i) acc += L.u.dT[i][r];
+                    L.tpl[o][r] = (float)acc;  // zero outside [0, F)
+                }
+            }
+            if (sub == 0) {
+                double qs = 0;
+                for (int i = 0; i < I; ++i) qs += L.qtf[i][o];
+                L.qmask[o] = (I > 0) ? (float)(qs / (double)I) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_phase == 31) return;
+    // observation importance (quadrupole.py:327-335)
+    if (sub < O) {
+        float st = 0.0f;
+        FOR_R {
+            st += L.tpl[sub][r];
+            R_FENCE(r);
+        }
+        L.tsum[sub] = st + st;
+    }
+    // frame RTs
+#pragma unroll
+    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+        int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+        int f = r + shift;
+        bool ok = alive && f >= 0 && f < F;
+        L.frt[r] = ok ? run.rt[rec.frame_start + f * Lc] : 0.0f;
+    }
+    __syncthreads();
+    {
+        float tot = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) tot += L.tsum[o];
+        if (sub < O) L.oi[sub] = (tot == 0.0f) ? 1.0f / (float)O : L.tsum[sub] / tot;
+    }
+    if (stop_phase == 32) return;
+
+    // ================= fragment phase: lane = fragment, one pass per observation =================
+    const bool frag_lane0 = alive && sub < K0;
+    float P[FM];  // frame profile summed over observations (frame_profile_2d + sum over o)
+    FOR_R P[r] = 0.0f;
+    float so = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        // ---- tables of this observation: template centre of mass (fragment_features.py:20-68;
+        // every lane computes it), template frame profile, weights around the centre
+        double esc, efc;
+        {
+            double isum = 0, ssum = 0, fsum = 0;
+            bool any = false;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+            for (int sc = 0; sc < 2; ++sc) {
+                FOR_R {
+                    float v = L.tpl[o][r];
+                    if (v > 0.0f) {
+                        any = true;
+                        isum += (double)v;
+                        ssum += (double)sc * (double)v;
+                        fsum += (double)(r + shift) * (double)v;
+                    }
+                    R_FENCE(r);
+                }
+            }
+            esc = (any && isum > 0) ? ssum / isum : 0.0;
+            efc = (any && isum > 0) ? fsum / isum : 0.0;
+        }
+        __syncthreads();  // the previous observation's tables were consumed
+        // template frame profile with or_envelope (scoring/utils.py:46-53)
+#pragma unroll
+        for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+            int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+            int f = r + shift;
+            bool ok = alive && f >= 0 && f < F;
+            float x = L.tpl[o][r] + L.tpl[o][r];
+            float rr = x;
+            if (ok && f >= 1 && f < F - 1) {
+                float xl = L.tpl[o][r - 1] + L.tpl[o][r - 1];
+                float xr = L.tpl[o][r + 1] + L.tpl[o][r + 1];
+                if (x < xl || x < xr) {
+                    float sm = xl + xr;
+                    rr = (float)((double)sm / 2.0);
+                }
+            }
+            L.tfp[r] = ok ? rr : 0.0f;
+        }
+        // weight table around the template centre (features_utils.py:9-25), centred index
+#pragma unroll
+        for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
+            int idx = min(sub + 16 * pass, 2 * FM - 1);
+            int sc = idx / FM, r = idx - sc * FM;
+            int f = r + shift;
+            bool ok = alive && f >= 0 && f < F;
+            double w = 0.0;
+            if (ok) {
+                double ds = (double)sc - esc, df = (double)f - efc;
+                w = exp(-0.1 * sqrt(ds * ds + df * df));
+            }
+            L.wt[sc][r] = w;
+        }
+        __syncthreads();
+
+        // ---- rows of this observation
+        {
+            const float2 *fcells =
+                reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(rec.k_cap));
+            const float qmask = L.qmask[o];
+            FOR_R {
+                int f = r + shift;
+                bool ok = frag_lane0 && f >= 0 && f < F;
+                float2 v = fcells[ok ? (o * F + f) * K0 + sub : 0];
+                A[r] = ok ? v.x * qmask : 0.0f;  // candidate.py:290
+                B[r] = ok ? v.y : 0.0f;
+            }
+        }
+        // presence (candidate.py:319-329): row sum over the two identical scan slots
+        float sf = 0.0f;
+        FOR_R sf += A[r];
+        const float ss = sf + sf;
+        L.rowsum[sub][o] = ss;
+        so += ss;
+        // weighted centre means of both channels (features_utils.py:9-37)
+        {
+            double vo = 0, wo = 0, vm = 0, wm = 0;
+            bool anyo = false, anym = false;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+            for (int sc = 0; sc < 2; ++sc) {
+                FOR_R {
+                    double w = L.wt[sc][r];
+                    float a = A[r], b = B[r];
+                    OPAQUE(a);
+                    OPAQUE(b);
+                    if (a > 0.0f) {
+                        anyo = true;
+                        vo += (double)a * w;
+                        wo += w;
+                    }
+                    if (b > 0.0f) {
+                        anym = true;
+                        vm += (double)b * w;
+                        wm += w;
+                    }
+                    R_FENCE(r);
+                }
+            }
+            L.ohe[sub][o] = (anyo && wo > 0) ? vo / wo : 0.0;
+            L.omz[sub][o] = (anym && wm > 0) ? vm / wm : 0.0;
+        }
+        if (NO > 1) {
+            // per-observation frame profile (frame_profile_2d): statistics against this
+            // observation's template.  With one observation they are taken after the envelope
+            // step, whose in-place edit they must see when quant_all is off.
+            FOR_R A[r] = A[r] + A[r];
+            float ftc_o, fw_o;
+            int fpeak_o;
+            profile_stats<FM>(A, L.tfp, F, shift, rt_width, ftc_o, fw_o, fpeak_o);
+            L.ftc[sub][o] = ftc_o;
+            L.fw[sub][o] = fw_o;
+            L.fpeak[sub][o] = fpeak_o;
+            FOR_R P[r] += A[r];
+        } else {
+            FOR_R P[r] += A[r] + A[r];
+        }
+    }
+    if (stop_phase == 33) return;
+    LibRec lrec;
+    if (frag_lane0) lrec = reinterpret_cast<const LibRec *>(block + 32)[sub];
+    bool present = frag_lane0 && so > 0.0f;
+    const unsigned long long bal = __ballot(present);
+    const unsigned gm = (unsigned)((bal >> gsh) & 0xFFFFull);
+    int K = __popc(gm);
+    const int kk = __popc(gm & ((1u << sub) - 1u));
+    const int n_present = K;
+    if (K < 2) {  // candidate.py:323
+        alive = false;
+        present = false;
+        K = 0;
+    }
+    if (present) {
+        L.g_fin[kk] = lrec.intensity;  // raw intensity, normalised below
+    }
+    __syncthreads();
+    // fragment intensities: apply_mask renormalisation + the second one of fragment_features.py:218
+    float g_int_l = 0.0f, g_fin_l = 0.0f;
+    {
+        float sum1 = 0.0f;
+        for (int j = 0; j < K; ++j) sum1 += L.g_fin[j];
+        if (present) {
+            g_int_l = lrec.intensity / sum1;
+            L.g_int[kk] = g_int_l;
+        }
+    }
+    __syncthreads();
+    {
+        float sum2 = 0.0f;
+        for (int j = 0; j < K; ++j) sum2 += L.g_int[j];
+        if (present) g_fin_l = g_int_l / sum2;
+    }
+    if (present) L.g_fin[kk] = g_fin_l;  // raw values were consumed before the last barrier
+    if (stop_phase == 3 || stop_phase == 4) return;
+
+    // ---- envelope, quantification (fragment_features.py:240-273)
+    double area = 0.0;
+    float obs_int = 0.0f;
+    {
+        float E[FM];  // np.sum(axis=1) made a copy: with quant_all the profile itself is untouched
+        FOR_R E[r] = P[r];
+        center_envelope<FM>(E, F);
+        const int qw = min(c - 1, (int)cfg.quant_window);
+        double ar = 0.0;
+#pragma unroll
+        for (int r = 1; r < FM - 1; ++r) {
+            if (r >= RC - qw && r + 1 <= RC + qw) {
+                float sm = E[r + 1] + E[r];
+                float drt = L.frt[r + 1] - L.frt[r];
+                float m = sm * drt;
+                ar += (double)m * 0.5;
+            }
+        }
+        area = ar * (double)qw;
+        FOR_R {
+            if (r >= RC - qw && r <= RC + qw) obs_int += E[r];
+        }
+        if (NO == 1 && !cfg.quant_all) {
+            FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
+        }
+    }
+    double m1 = 0.0, m2 = 0.0, merr_l = 0.0;
+    bool hrow = false;
+    if (present) {
+        // importance-weighted means over observations (fragment_features.py:311-336)
+        float ws = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            bool m = L.ohe[sub][o] > 0;
+            hrow = hrow || m;
+            float w32 = m ? L.oi[o] : L.oi[o] * 0.0f;
+            ws += w32;
+        }
+        double msum = 0.0;
+        int nm = 0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            bool m = L.ohe[sub][o] > 0;
+            float w32 = m ? L.oi[o] : L.oi[o] * 0.0f;
+            double w = (double)w32 / ((double)ws + 1e-20);
+            if (w > 0) {
+                msum += w;
+                ++nm;
+            }
+        }
+        if (nm > 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                bool m = L.ohe[sub][o] > 0;
+                float w32 = m ? L.oi[o] : L.oi[o] * 0.0f;
+                double w = (double)w32 / ((double)ws + 1e-20);
+                if (w > 0) {
+                    double lw = w / msum;
+                    m1 += L.omz[sub][o] * lw;
+                    m2 += L.ohe[sub][o] * lw;
+                }
+            }
+        }
+        merr_l = (m1 - (double)lrec.mz) / (double)lrec.mz * 1e6;  // fragment_features.py:387
+        L.merr[kk] = merr_l;
+        int rk = 0;
+        for (int j = 0; j < K; ++j) {
+            float ib = L.g_int[j];
+            rk += (ib > g_int_l) || (ib == g_int_l && j > kk);
+        }
+        L.ord[rk] = kk;  // position in argsort(intensity)[::-1]
+    }
+    __syncthreads();
+    if (stop_phase == 5) return;
+
+    if (alive && sub < 4) L.feat[sub] = loc;
+    if (alive && sub == 0) {
+        Assemble asmv;
+        asmv.run = nullptr;  // features 0-3 are in place
+        asmv.rec = &rec;
+        asmv.featv = L.feat;
+        asmv.iso_int = L.iso_int; asmv.iso_mz = L.iso_mz; asmv.spi = L.spi; asmv.oi = L.oi;
+        asmv.omzp = L.omzp; asmv.hp = L.hp;
+        asmv.n_present = n_present; asmv.K0 = K0;
+        feat::assemble_precursor(asmv, I, O);
+    }
+    // ---- fragment features 17-27, 41-45 (fragment_features.py:198-427; the scalar form is
+    // feat::assemble_fragments).  Every sum over fragments keeps the reference's order
+    // (k ascending) but all sums advance together: lane k provides its term of every sum,
+    // then lane j adds up sum j.  Skipped terms are added as +0, which leaves a sum unchanged.
+    const bool ipos = present && obs_int > 0.0f;
+    const bool hpos = present && m2 > 0.0;
+    const bool isb = present && lrec.type == 98, isy = present && lrec.type == 121;
+    const unsigned b_isb = (unsigned)((__ballot(isb) >> gsh) & 0xFFFFull);
+    const unsigned b_isy = (unsigned)((__ballot(isy) >> gsh) & 0xFFFFull);
+    const int n_int = __popc((unsigned)((__ballot(ipos) >> gsh) & 0xFFFFull));
+    const int n_hei = __popc((unsigned)((__ballot(hpos) >> gsh) & 0xFFFFull));
+    const int n_hrows = __popc((unsigned)((__ballot(present && hrow) >> gsh) & 0xFFFFull));
+    const int nb = __popc(b_isb), ny = __popc(b_isy);
+    int min_y = isy ? (int)lrec.position : 255, max_b = isb ? (int)lrec.position : 0;
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) {
+        min_y = min(min_y, __shfl_xor(min_y, m, ADH_GS));
+        max_b = max(max_b, __shfl_xor(max_b, m, ADH_GS));
+    }
+    const bool ov = (isy && (int)lrec.position < max_b) || (isb && (int)lrec.position > min_y);
+    const int n_ov = __popc((unsigned)((__ballot(ov) >> gsh) & 0xFFFFull));
+    const int n3 = min(K, 3);
+    if (present) {
+        double *t = L.u.at.t64[kk];
+        t[0] = area;
+        t[1] = m2;
+        t[2] = (double)g_fin_l;
+        t[3] = merr_l;
+        t[4] = ov ? area : 0.0;
+        t[5] = ov ? merr_l : 0.0;
+        // cosine_similarity_a1 (features_utils.py:40-47) of the observation sums
+        float tn = 0.0f, fn = 0.0f, dot = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) tn += L.tsum[o] * L.tsum[o];
+        tn = sqrtf(tn);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) fn += L.rowsum[sub][o] * L.rowsum[sub][o];
+        fn = sqrtf(fn);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) dot += L.rowsum[sub][o] * L.tsum[o];
+        const float pr = fn * tn;
+        const float score = (float)((double)dot / ((double)pr + 0.0001));
+        float *u = L.u.at.t32[kk];
+        u[0] = ipos ? g_fin_l : 0.0f;
+        u[1] = hpos ? g_fin_l : 0.0f;
+        u[2] = ipos ? score : 0.0f;
+        u[3] = isb ? obs_int : 0.0f;
+        u[4] = isy ? obs_int : 0.0f;
+    }
+    __syncthreads();
+    {
+        double s64 = 0.0;
+        float s32 = 0.0f;
+        if (sub < 6) {
+            for (int k = 0; k < K; ++k) s64 += L.u.at.t64[k][sub];
+            L.red64[sub] = s64;
+        } else if (sub < 11) {
+            for (int k = 0; k < K; ++k) s32 += L.u.at.t32[k][sub - 6];
+            L.red32[sub - 6] = s32;
+        } else if (sub == 11) {
+            for (int i = 0; i < n3; ++i) s64 += L.merr[L.ord[i]];  // mean_top3 mass error, by rank
+            L.red64[6] = s64;
+        }
+    }
+    __syncthreads();
+    {
+        // np.corrcoef terms (feat::corrcoef01): area vs intensity, height vs intensity
+        const double mx_a = L.red64[0] / (double)K, mx_h = L.red64[1] / (double)K;
+        const double my = L.red64[2] / (double)K;
+        if (present) {
+            const double a = area - mx_a, h = m2 - mx_h, b = (double)g_fin_l - my;
+            double *t = L.u.at.t64[kk];
+            t[0] = a * a;
+            t[1] = b * b;
+            t[2] = a * b;
+            t[3] = h * h;
+            t[4] = h * b;
+        }
+    }
+    __syncthreads();
+    if (sub < 5) {
+        double s64 = 0.0;
+        for (int k = 0; k < K; ++k) s64 += L.u.at.t64[k][sub];
+        L.red64[7 + sub] = s64;
+    }
+    __syncthreads();
+    if (alive && sub < 2) {
+        // lane 0: feature 18 (areas), lane 1: feature 19 (heights)
+        const double fact = fmax((double)K - 1.0, 0.0);
+        const double inv = 1.0 / fact;
+        const double cxx = L.red64[sub ? 10 : 7] * inv, cyy = L.red64[8] * inv;
+        const double cxy = L.red64[sub ? 11 : 9] * inv;
+        const double s0 = sqrt(cxx), s1 = sqrt(cyy);
+        double cc = cxy / s1 / s0;
+        if (fabs(cc) > 1.0) cc = (cc > 0) ? 1.0 : -1.0;
+        const bool on = sub ? (L.red64[1] > 0.0) : (n_hrows > 0);
+        if (on) L.feat[18 + sub] = (float)cc;
+    }
+    if (alive && sub == 0) {
+        float *ft = L.feat;
+        ft[17] = (float)O;
+        ft[20] = (float)((double)n_int / (double)K);
+        ft[21] = (float)((double)n_hei / (double)K);
+        ft[22] = L.red32[0];
+        ft[23] = L.red32[1];
+        if (n_int > 0) ft[24] = (float)((double)L.red32[2] / (double)n_int);
+        ft[25] = nb > 0 ? (float)log((double)L.red32[3] + 1.0) : 0.0f;
+        ft[26] = ny > 0 ? (float)log((double)L.red32[4] + 1.0) : 0.0f;
+        ft[27] = ft[25] - ft[26];
+        ft[41] = (float)(L.red64[6] / (double)n3);
+        ft[42] = (float)(L.red64[3] / (double)K);
+        if (nb > 0 && ny > 0) {
+            ft[43] = (float)n_ov;
+            if (n_ov > 0) {
+                ft[44] = (float)(L.red64[4] / (double)n_ov);
+                ft[45] = (float)(L.red64[5] / (double)n_ov);
+            } else {
+                ft[44] = 0.0f;
+                ft[45] = 15.0f;
+            }
+        }
+    }
+    if (stop_phase == 6) return;
+
+    // ================= profile features (profile_features.py:18-206), experimental_xic =======
+    // intensity_slice = frame profile summed over the observations = P
+    {
+        // normalize_profiles (scoring_utils.py:71-117): centre +- 1 are registers RC-1, RC, RC+1
+        float sm = 0.0f;
+        sm += P[RC - 1];
+        sm += P[RC];
+        sm += P[RC + 1];
+        const double cn = (double)sm / 3.0;
+        // median over fragments per cycle (scoring_utils.py:120-152): 16x16 transposes via LDS
+#pragma unroll
+        for (int half = 0; half < (FM + 15) / 16; ++half) {
+            __syncthreads();  // previous users of the union are done
+            if (present) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (half * 16 + t >= FM) break;
+                    float x = P[half * 16 + t];
+                    L.u.nrmT[t][kk] = (cn > 0) ? (float)((double)x / cn) : 0.0f;
+                    if ((t & 3) == 3) __asm__ volatile("" ::: "memory");  // bound the in-flight divisions
+                }
+            }
+            __syncthreads();
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (j < K) ? L.u.nrmT[sub][j] : INFINITY;
+            sort16(v);
+            const int r_lo = (K - 1) / 2, r_hi = K / 2;
+            float lo_v = 0.0f, hi_v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                lo_v = (j == r_lo) ? v[j] : lo_v;
+                hi_v = (j == r_hi) ? v[j] : hi_v;
+            }
+            float m;
+            if (K & 1) {
+                m = hi_v;
+            } else {
+                float s2 = lo_v + hi_v;
+                m = (float)((double)s2 / 2.0);
+            }
+            const int r = half * 16 + sub;
+            const int f = r + shift;
+            if (r < FM) L.med[r] = (alive && f >= 0 && f < F) ? m : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (stop_phase == 61) return;
+    float corr_l = 0.0f;
+    {
+        // correlation_coefficient (scoring_utils.py:14-68)
+        float sx = 0.0f;
+        FOR_R {
+            sx += L.med[r];
+            R_FENCE(r);
+        }
+        const float mx = (float)((double)sx / (double)F);
+        float sxx = 0.0f, sy = 0.0f;
+        FOR_R {
+            int f = r + shift;
+            bool ok = f >= 0 && f < F;
+            float xm = ok ? L.med[r] - mx : 0.0f;
+            sxx += xm * xm;
+            R_FENCE(r);
+        }
+        const double var_x = (double)sxx / (double)F;
+        FOR_R sy += P[r];
+        const float my = (float)((double)sy / (double)F);
+        float sxy = 0.0f, syy = 0.0f;
+        FOR_R {
+            int f = r + shift;
+            bool ok = f >= 0 && f < F;
+            float xm = ok ? L.med[r] - mx : 0.0f;
+            float ym = ok ? P[r] - my : 0.0f;
+            sxy += xm * ym;
+            R_FENCE(r);
+        }
+        FOR_R {
+            int f = r + shift;
+            bool ok = f >= 0 && f < F;
+            float ym = ok ? P[r] - my : 0.0f;
+            syy += ym * ym;
+        }
+        const double cov = (double)sxy / (double)F;
+        const double var_y = (double)syy / (double)F;
+        const double var_xy = var_x * var_y;
+        corr_l = (var_xy == 0) ? 0.0f : (float)(cov / sqrt(var_xy));
+    }
+    if (NO == 1) {
+        float ftc_o, fw_o;
+        int fpeak_o;
+        profile_stats<FM>(P, L.tfp, F, shift, rt_width, ftc_o, fw_o, fpeak_o);
+        L.ftc[sub][0] = ftc_o;
+        L.fw[sub][0] = fw_o;
+        L.fpeak[sub][0] = fpeak_o;
+    }
+    if (stop_phase == 62) return;
+    if (present) L.corr[kk] = corr_l;
+    __syncthreads();
+    // ---- features 31-38, 40 (profile_features.py:70-113,141-146,196-204; the scalar form is
+    // feat::assemble_part2), sums organised as above
+    {
+        const int r_lo = (K - 1) / 2, r_hi = K / 2;
+        if (present) {
+            // median apex per observation (profile_features.py:196-198): rank of this fragment's apex
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const int va = L.fpeak[sub][o];
+                int rk = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (!((gm >> b) & 1u)) continue;
+                    int vb = L.fpeak[b][o];
+                    rk += (vb < va) || (vb == va && b < sub);
+                }
+                if (rk == r_lo) L.medlo[o] = va;
+                if (rk == r_hi) L.medhi[o] = va;
+            }
+            const float cr = L.corr[L.ord[kk]];  // correlation of the fragment with intensity rank kk
+            // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
+            const bool b3 = isb && __popc(b_isb & ((1u << sub) - 1u)) < 3;
+            const bool y3 = isy && __popc(b_isy & ((1u << sub) - 1u)) < 3;
+            float rr = 0.0f, ml = 0.0f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) rr += L.ftc[sub][o] * L.oi[o];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) ml += L.fw[sub][o] * L.oi[o];
+            float *u = L.u.at.t32[kk];
+            u[0] = corr_l;
+            u[1] = rr * g_int_l;
+            u[2] = ml * g_int_l;
+            u[3] = b3 ? cr : 0.0f;
+            u[4] = y3 ? cr : 0.0f;
+            u[5] = (kk < n3) ? cr : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (sub < 6) {
+        float s32 = 0.0f;
+        for (int k = 0; k < K; ++k) s32 += L.u.at.t32[k][sub];
+        L.red32[sub] = s32;
+    }
+    __syncthreads();
+    if (alive && sub == 0) {
+        float *ft = L.feat;
+        ft[31] = (float)((double)L.red32[0] / (double)K);
+        ft[32] = (float)((double)L.red32[5] / (double)n3);
+        ft[33] = L.red32[1];
+        if (nb > 0) {
+            ft[34] = (float)((double)L.red32[3] / (double)min(nb, 3));
+            ft[35] = (float)nb;
+        }
+        if (ny > 0) {
+            ft[36] = (float)((double)L.red32[4] / (double)min(ny, 3));
+            ft[37] = (float)ny;
+        }
+        ft[38] = L.red32[2];
+        double acc = 0.0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const double med = (K & 1) ? (double)L.medhi[o] : (double)(L.medlo[o] + L.medhi[o]) / 2.0;
+            const float medpk = (float)med;
+            acc += ((double)medpk - floor((double)F / 2.0)) * (double)L.oi[o];
+        }
+        ft[40] = (float)acc;
+    }
+    __syncthreads();
+
+    // ---- output row (candidate.py:403-481)
+    if (alive) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int idx = sub + 16 * j;
+            if (idx < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + idx] = L.feat[idx];
+        }
+        if (cfg.collect_fragments && present && kk < top_k) {
+            const int64_t o = (int64_t)row * top_k + kk;
+            out.fragment_precursor_idx[o] = rec.precursor_idx;
+            out.fragment_rank[o] = rec.rank;
+            out.fragment_mz_library[o] = lrec.mz_library;
+            out.fragment_mz[o] = lrec.mz;
+            out.fragment_mz_observed[o] = (float)m1;
+            out.fragment_height[o] = (float)m2;
+            out.fragment_intensity[o] = (float)area;
+            out.fragment_mass_error[o] = (float)merr_l;
+            out.fragment_correlation[o] = corr_l;
+            out.fragment_position[o] = lrec.position;
+            out.fragment_number[o] = lrec.number;
+            out.fragment_type[o] = lrec.type;
+            out.fragment_charge[o] = lrec.charge;
+            out.fragment_loss_type[o] = lrec.loss_type;
+            if (out.fragment_lib_slot) out.fragment_lib_slot[o] = (uint16_t)(1 + lrec.pad0 + 256 * lrec.pad1);
+        }
+        if (sub == 0) out.valid[row] = 1;
+    }
+}
