@@ -24,6 +24,7 @@
 #include "adh_gather.hip"
 #include "adh_features.hip"
 #include "adh_features_fast.hip"
+#include "adh_fused.hip"
 #include "adh_gather_im.hip"
 #include "adh_features_im.hip"
 #include "adh_fragcomp.hip"
@@ -95,14 +96,14 @@ struct Plan {
     bool ready = false;
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
     bool fast_ok = false;          // register kernels enabled (experimental_xic)
+    bool fused_ok = false;         // fused gather + feature kernel enabled
     bool quant_all = false;
     int64_t row0 = 0, n = 0;
     CandRec *d_recs = nullptr;
     CandRecIM *d_recs_im = nullptr;
     uint64_t scratch_bytes = 0;
-    // classes 0..6: register kernels for one observation, F <= 8 / 12 / ... / 32 (a kernel per four
-    // cycles: every cycle loop is unrolled to the class size); 7..9: two observations, F <= 16 /
-    // 24 / 32; ADH_CLASS_GENERIC: the LDS kernel
+    // candidates per kernel class (adh_plan.hip): fused kernel / register kernels by cycle count (a
+    // kernel per four cycles: every cycle loop is unrolled to the class size) / the LDS kernel
     int64_t n_class[ADH_N_CLASSES] = {0};
     Caps caps_generic;
     Caps caps_all;
@@ -442,9 +443,9 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
 
     uint2 *entries = nullptr;
     uint32_t *tab = nullptr;
-    HIP_TRY(hipMalloc((void **)&entries, (size_t)std::max<int64_t>(n_ref, 1) * sizeof(uint2)));
+    HIP_TRY(hipMalloc((void **)&entries, (size_t)(std::max<int64_t>(n_ref, 1) + 4) * sizeof(uint2)));  // (+4: the fused kernel reads entries in pairs and table words in fours, see adh_fused.hip)
     h->run_buf.ptrs.push_back(entries);
-    HIP_TRY(hipMalloc((void **)&tab, (size_t)n_tab * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&tab, (size_t)(n_tab + 4) * sizeof(uint32_t)));
     h->run_buf.ptrs.push_back(tab);
     r.entries = entries;
     r.tab = tab;

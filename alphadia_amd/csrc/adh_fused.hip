@@ -1,0 +1,1229 @@
+// adh_fused.hip - gather + features in ONE kernel for the common candidate shape.
+//
+// The two-kernel path (adh_gather_kernel -> scratch block in HBM -> adh_feature_fast_kernel) writes
+// every XIC tile to HBM (zero fill + cells) and reads it back: half of the traffic of a scoring pass
+// existed only because gather and features were two kernels.  Here a candidate never leaves the
+// compute unit between
+//   FragmentContainer.slice / filter / sort   alphadia/search/jitclasses/fragment_container.py:56-102
+//   AlphaRawJIT.get_dense (x2)                alphadia/search/jitclasses/alpharaw_jit.py:208-337
+//   MS1 observation collapse                  alphadia/search/scoring/containers/candidate.py:248-269
+// and Candidate.process after get_dense       alphadia/search/scoring/containers/candidate.py:278-481
+//
+//   * four candidates per 64-lane wavefront, 16 lanes each.  Lane k < 12 owns fragment k (ascending
+//     m/z), lane 12 + i owns isotope i: all K + I m/z windows of a candidate are gathered at once and
+//     the per-row work of the precursor features runs in the same instructions as the fragments'
+//   * a lane folds the peaks of its window into a private column of an LDS tile [FM][16] (the
+//     reference's running intensity-weighted m/z, alpharaw_jit.py:299-335, in the reference's order:
+//     see adh_gather.hip), stored CENTRED - row r holds cycle f = r - FM/2 + F/2 - so that the
+//     rows then move into VGPRs with constant offsets and no masks; cells outside [0, F) stay zero
+//   * from there on the arithmetic is that of adh_feature_fast_kernel (same summation order, float64
+//     where Numba types the expression as float64): bit-identical rows.  Differences are of form
+//     only: branch-free envelope recurrences (a min with an untouched zero cell is a no-op), cycle
+//     masks only on the outer registers of a class (3 <= FM - F < 4 for every candidate of a launch),
+//     float64 divisions by a common divisor through one shared reciprocal refinement
+//   * LDS is one union per candidate: selection scratch -> tile -> feature arrays
+//
+// Eligibility (adh_plan_rec_kernel): one observation, 3 <= F <= 32, k_cap <= 12, I <= 3, library slice
+// of at most 64 fragments, experimental_xic = True, a single MS1 row per cycle.  Everything else runs
+// through the two-kernel path.
+#include "adh_device.h"
+#include "adh_feature_common.h"
+
+#define ADH_FUSED_ISO0 12      // first isotope lane of a 16-lane group
+#define ADH_FUSED_NLIB 64      // longest library slice handled here
+
+namespace fused {
+
+constexpr int GS = 16;
+constexpr int TW = 15;  // tile columns: 12 fragment lanes + at most 3 isotope lanes
+constexpr int ISO0 = ADH_FUSED_ISO0;
+constexpr int NLIB = ADH_FUSED_NLIB;
+
+// cycles F of a launch with FM registers: FMIN <= F <= FM; registers [R0, R1) hold a valid cycle for
+// every such F (f = r - FM/2 + F/2)
+template <int FM>
+struct Rng {
+    static constexpr int FMIN = FM == 8 ? 3 : FM - 3;
+    static constexpr int R0 = FM / 2 - FMIN / 2;
+    static constexpr int R1 = FM / 2 + (FMIN + 1) / 2;
+};
+
+// a library record (LibRec, 32 bytes) as the registers it travels in: a = (mz_library, mz, intensity,
+// type | loss_type << 8 | charge << 16 | number << 24), b = position | cardinality << 8 | (index inside the
+// library slice) << 16
+struct __attribute__((aligned(16))) RawRec {
+    uint4 a;
+    uint32_t b, pad[3];
+};
+static_assert(sizeof(RawRec) == sizeof(LibRec), "RawRec mirrors LibRec");
+__device__ __forceinline__ RawRec load_rec(const LibRec *p) {
+    RawRec r;
+    r.a = *reinterpret_cast<const uint4 *>(p);
+    r.b = reinterpret_cast<const uint32_t *>(p)[4] & 0xFFFFu;
+    return r;
+}
+__device__ __forceinline__ float rec_mz(const RawRec &r) { return __uint_as_float(r.a.y); }
+__device__ __forceinline__ float rec_intensity(const RawRec &r) { return __uint_as_float(r.a.z); }
+__device__ __forceinline__ int rec_type(const RawRec &r) { return (int)(r.a.w & 0xFFu); }
+__device__ __forceinline__ int rec_position(const RawRec &r) { return (int)(r.b & 0xFFu); }
+__device__ __forceinline__ int rec_cardinality(const RawRec &r) { return (int)((r.b >> 8) & 0xFFu); }
+
+template <int FM>
+struct __attribute__((aligned(16))) GroupLds {
+    union {
+        struct {  // fragment selection
+            float l_int[NLIB], l_mz[NLIB];
+            int l_ok[NLIB], l_rank[NLIB];
+            RawRec sel[ISO0];
+        } s;
+        float2 tile[FM][TW];  // gathered cells, [centred cycle][lane]
+        struct {
+            union {
+                double dT[4][FM];    // isotope contributions to the template
+                double wti[2][FM];   // precursor weights (centred, masked); written once dT is consumed
+                float nrmT[16][17];  // transpose buffer for the per-cycle median (padded rows)
+                struct {             // per-fragment terms of the feature sums: [fragment][sum]
+                    double t64[16][6];
+                    float t32[16][6];
+                } at;
+            } u;
+            double wt[2][FM];  // [scan slot][centred cycle]: exp weights around the template centre
+            double merr[16];
+            double hp[4], omzp[4], qtf[4];
+            double red64[12];
+            float tpl[FM], tfp[FM], frt[FM], med[FM];
+            float g_int[16], g_fin[16], corr[16];
+            float ftc[16], fw[16];
+            int fpeak[16];
+            float iso_mz[4], iso_int[4], spi[4];
+            float oi[1], tsum[1];
+            float red32[8];
+            float feat[ADH_NUM_FEATURES + 2];
+            int ord[16];
+            int medlo, medhi;
+        } f;
+    } u;
+};
+
+#define FU_OPAQUE(x) __asm__ volatile("" : "+v"(x))
+#define FU_FOR_R _Pragma("unroll") for (int r = 0; r < FM; ++r)
+#define FU_FENCE(r)                                               \
+    do {                                                          \
+        if ((((r)) & 7) == 7) __asm__ volatile("" ::: "memory"); \
+    } while (0)
+// does register r hold a cycle of this candidate?  (compile-time true for the inner registers)
+#define FU_OK(r) (((r) >= Rng<FM>::R0 && (r) < Rng<FM>::R1) ? true : ((unsigned)((r) + shift) < (unsigned)F))
+
+// value of the lane `n` lanes down in the same 16-lane row; `fill` where there is none
+template <int N>
+__device__ __forceinline__ float row_shr(float fill, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x110 + N, 0xF, 0xF, false));
+}
+// maximum over all lower lanes of the row (-inf for lane 0)
+__device__ __forceinline__ float row_prefix_max_excl(float x) {
+    float v = row_shr<1>(-INFINITY, x);
+    v = fmaxf(v, row_shr<1>(-INFINITY, v));
+    v = fmaxf(v, row_shr<2>(-INFINITY, v));
+    v = fmaxf(v, row_shr<4>(-INFINITY, v));
+    v = fmaxf(v, row_shr<8>(-INFINITY, v));
+    return v;
+}
+
+// value of another lane of the same 16-lane row: rotation by N lanes (whichever lane it is, the lane
+// index travels with it, so callers never depend on the direction)
+template <int N>
+__device__ __forceinline__ int row_ror(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
+}
+#define FU_FOR_OTHER_LANES(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+__device__ __forceinline__ double logistic(double x, double mu, double sigma) {
+    double a = (x - mu) / sigma;
+    return 1.0 / (1.0 + exp(-a));
+}
+
+// x / d for many x and one d > 0: the reciprocal refinement of the IEEE division sequence
+// (v_rcp_f64 + two Newton steps) is shared, the per-quotient part (q0 = x r, e = x - d q0,
+// q = q0 + e r) is what the compiler emits for x / d when no operand needs rescaling
+struct Recip {
+    double d, r;
+    __device__ __forceinline__ explicit Recip(double dd) : d(dd) {
+        double y = __builtin_amdgcn_rcp(dd);
+        double e = __builtin_fma(-dd, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-dd, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        r = y;
+    }
+    __device__ __forceinline__ double div(double x) const {
+        double q = x * r;
+        double e = __builtin_fma(-d, q, x);
+        return __builtin_fma(e, r, q);
+    }
+};
+
+// center_envelope_1d (fragment_features.py:71-159) on a centred register row of non-negative
+// values.  (a) every step is min(x, mean of the two inner neighbours): float32 additions of the
+// reference, the halving and the float64 minimum are exact, so float32 arithmetic gives the same
+// bits; (b) a step on a register outside [0, F) is min(0, >= 0) = 0: no predicate is needed beyond
+// the parity of F, which decides where the left chain starts.
+template <int FM>
+__device__ __forceinline__ void center_envelope(float (&x)[FM], int F) {
+    constexpr int RC = FM / 2;
+    const bool odd = F & 1;
+    // right chain: registers RC + i, i >= 1, seeded with (x[RC + 1] + x[RC]) / 2 (odd) or x[RC] (even)
+    {
+        float right = odd ? (x[RC + 1] + x[RC]) * 0.5f : x[RC];
+#pragma unroll
+        for (int i = 1; RC + i < FM; ++i) {
+            x[RC + i] = fminf(right, x[RC + i]);
+            right = (x[RC + i] + x[RC + i - 1]) * 0.5f;
+        }
+    }
+    // left chain: odd F walks RC - i from the centre register RC, even F walks RC - 1 - i from RC - 1
+    {
+        float y[RC + 1];  // y[i] = the chain's i-th register, y[0] its seed register
+#pragma unroll
+        for (int i = 0; i <= RC; ++i) {
+            const float xo = x[RC - i];
+            const float xe = (RC - 1 - i >= 0) ? x[RC - 1 - i > 0 ? RC - 1 - i : 0] : 0.0f;
+            y[i] = odd ? xo : xe;
+        }
+        // odd: left = (x[RC - 1] + x[RC]) / 2 = (y[1] + y[0]) / 2; even: left = x[RC - 1] = y[0]
+        float left = odd ? (y[1] + y[0]) * 0.5f : y[0];
+#pragma unroll
+        for (int i = 1; i <= RC; ++i) {
+            y[i] = fminf(left, y[i]);
+            left = (y[i] + y[i - 1]) * 0.5f;
+        }
+#pragma unroll
+        for (int i = 1; i <= RC; ++i) {
+            if (RC - i >= 0) x[RC - i] = odd ? y[i] : ((i >= 2) ? y[i - 1] : x[RC - i]);
+        }
+    }
+}
+
+// frame-profile statistics of one fragment row against the template frame profile: fragment-vs-
+// template correlation (scoring/utils.py:574-647), FWHM in RT (profile_features.py:117-146) and apex
+// (profile_features.py:192-193)
+template <int FM>
+__device__ __forceinline__ void profile_stats(const float (&P)[FM], const float *tfp, int F, int shift,
+                                              float rt_width, float &ftc, float &fw, int &fpeak) {
+    const float Ff = (float)F;
+    float syt = 0.0f;
+    FU_FOR_R {
+        syt += tfp[r];
+        FU_FENCE(r);
+    }
+    const float ym = syt / Ff;
+    float qy = 0.0f;
+    FU_FOR_R {
+        float d = tfp[r] - ym;
+        d = FU_OK(r) ? d : 0.0f;
+        qy += d * d;
+        FU_FENCE(r);
+    }
+    const float ysd = sqrtf(qy / Ff);
+    float sy = 0.0f;
+    FU_FOR_R sy += P[r];
+    const float xmn = sy / Ff;
+    float qx = 0.0f, dot = 0.0f;
+    FU_FOR_R {
+        float d = P[r] - xmn;
+        d = FU_OK(r) ? d : 0.0f;
+        qx += d * d;
+    }
+    const float xsd = sqrtf(qx / Ff);
+    FU_FOR_R {
+        float dx = P[r] - xmn;
+        float dy = tfp[r] - ym;
+        dx = FU_OK(r) ? dx : 0.0f;  // (one zero factor is enough)
+        dot += dx * dy;
+        FU_FENCE(r);
+    }
+    const float cv = dot / Ff;
+    const float smm = xsd * ysd;
+    ftc = (float)((double)cv / ((double)smm + 1e-12));
+    // first maximum over the valid cycles; values are non-negative and cells outside [0, F) are 0,
+    // so "first strictly greater" started from the first valid cycle is all that is needed
+    float mxv = -1.0f;
+    int am = 0;
+    FU_FOR_R {
+        const bool up = FU_OK(r) && P[r] > mxv;
+        mxv = up ? P[r] : mxv;
+        am = up ? r : am;
+    }
+    const float half_max = mxv * 0.5f;  // exact halving; (double)P > (double)mxv / 2 is the same comparison
+    int n_above = 0;
+    FU_FOR_R n_above += (FU_OK(r) && P[r] > half_max) ? 1 : 0;
+    const double frac = (double)n_above / (double)F;
+    fw = (float)(frac * (double)rt_width);
+    fpeak = am + shift;
+}
+
+// one (window, cycle row, block) gather task, split in three so that the table words and the first
+// entries of ALL tasks of a lane are in flight before the first one is consumed: a candidate's gather is
+// a chain of dependent round trips (record -> library slice -> bin table -> entries), and with the
+// registers of the feature phase only three wavefronts share a SIMD, so every link that can be removed
+// counts.  Four table words and two entries travel per load (they are neighbours in memory: 4- and 8-byte
+// aligned vector loads), and a lane only asks for entries it has: a scattered load costs the L1 one tag
+// look-up per lane and line, which is what this phase is bound by.
+constexpr int EB = 4;  // entries fetched per step
+constexpr int NT = 3;  // tasks (cycle blocks) of a lane in flight
+struct __attribute__((packed, aligned(4))) Tab4 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(8))) Ent2 {
+    uint2 a, b;
+};
+struct Task {
+    const uint32_t *t;
+    uint32_t idx, end, b_end, b_end2;
+    int cyc_base;
+    uint32_t f_lo, nf;        // block-relative cycles [f_lo, f_lo + nf)
+    uint2 e[EB], n[EB];       // entries of the current and of the next step
+};
+// the window as the gather sees it: bins and the float32 bounds as bit patterns (positive floats order
+// like their patterns; m/z > excl is pattern >= pattern(excl) + 1)
+struct WinBits {
+    int b_lo, b_hi;
+    uint32_t lo_u, hi_u;
+};
+__device__ __forceinline__ WinBits win_bits(const gather::Window &w) {
+    WinBits q;
+    q.b_lo = w.b_lo;
+    q.b_hi = w.b_hi;
+    const uint32_t lo = (w.lo > 0.0f) ? __float_as_uint(w.lo) : 0u;
+    const uint32_t ex = (w.excl > 0.0f) ? __float_as_uint(w.excl) + 1u : 0u;  // (-inf: no earlier window)
+    q.lo_u = max(lo, ex);
+    q.hi_u = (w.hi > 0.0f) ? __float_as_uint(w.hi) : 0u;
+    return q;
+}
+
+__device__ __forceinline__ void task_begin(const DevRun &run, const WinBits &w, bool on, int row, int blk, int c0,
+                                           int F, Task &k) {
+    const int bs = run.block_shift;
+    k.cyc_base = blk << bs;
+    const int f_lo = max(c0, k.cyc_base) - k.cyc_base;
+    const int f_hi = min(c0 + F, k.cyc_base + (1 << bs)) - k.cyc_base;
+    k.f_lo = (uint32_t)f_lo;
+    k.nf = (uint32_t)max(f_hi - f_lo, 0);
+    k.t = run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
+    k.idx = 0;
+    k.end = 0;
+    k.b_end = 0;
+    k.b_end2 = 0;
+    if (on) {
+        const Tab4 v = *reinterpret_cast<const Tab4 *>(k.t + w.b_lo);  // first entry of bins b_lo .. b_lo + 3
+        const int nb = w.b_hi - w.b_lo;
+        k.idx = v.x;
+        k.end = nb == 0 ? v.y : (nb == 1 ? v.z : v.w);
+        if (nb > 2) k.end = k.t[w.b_hi + 1];  // (a window rarely spans more than three bins)
+        k.b_end = nb == 0 ? k.end : v.y;
+        k.b_end2 = nb <= 1 ? k.end : v.z;
+    }
+}
+
+__device__ __forceinline__ void load2(const DevRun &run, uint32_t i, uint2 &a, uint2 &b) {
+    const Ent2 p = *reinterpret_cast<const Ent2 *>(run.entries + i);
+    a = p.a;
+    b = p.b;
+}
+
+__device__ __forceinline__ void task_fetch(const DevRun &run, Task &k) {
+    const uint32_t n = k.end - k.idx;  // (idx <= end)
+    if (n > 0) load2(run, k.idx, k.e[0], k.e[1]);
+    if (n > 2) load2(run, k.idx + 2, k.e[2], k.e[3]);
+    if (n > 4) load2(run, k.idx + 4, k.n[0], k.n[1]);
+    if (n > 6) load2(run, k.idx + 6, k.n[2], k.n[3]);
+}
+
+// cells: the lane's column of the tile, cells[r * TW] = centred row r; roff = FM/2 - F/2 - c0
+__device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Task &k, float2 *cells, int roff,
+                                         uint32_t &hits) {
+    uint32_t idx = k.idx;
+    const uint32_t end = k.end;
+    if (idx >= end) return;
+    const uint32_t *t = k.t;
+    uint32_t b_end = k.b_end;
+    int b = w.b_lo;
+    int cur = -1;  // open cell (block-relative cycle), -1: none
+    float acc_i = 0.0f, acc_m = 0.0f;
+    while (idx < end) {
+        // this step's entries were requested two steps ago; the step after next is requested now
+        uint2 e[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            e[u] = k.e[u];
+            k.e[u] = k.n[u];
+        }
+        {
+            const uint32_t left = end - idx;
+            if (left > 2 * EB) load2(run, idx + 2 * EB, k.n[0], k.n[1]);
+            if (left > 2 * EB + 2) load2(run, idx + 2 * EB + 2, k.n[2], k.n[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const uint32_t i = idx + (uint32_t)u;
+            if (i >= end) break;
+            while (i >= b_end) {  // next bin: cycles start over
+                ++b;
+                b_end = (b >= w.b_hi) ? end : (b == w.b_lo + 1 ? k.b_end2 : t[b + 1]);
+            }
+            const uint32_t cyc = e[u].x >> ADH_BIN_SHIFT;
+            const uint32_t bits = ((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) | (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u));
+            if (cyc - k.f_lo >= k.nf || bits < w.lo_u || bits > w.hi_u) continue;
+            if ((int)cyc != cur) {
+                if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
+                float2 v = make_float2(0.0f, 0.0f);
+                if (b > w.b_lo) v = cells[((int)cyc + k.cyc_base + roff) * TW];  // continue from an earlier bin
+                acc_i = v.x;
+                acc_m = v.y;
+                cur = (int)cyc;
+            }
+            gather::fold(acc_i, acc_m, __uint_as_float(bits), __uint_as_float(e[u].y));
+            ++hits;
+        }
+        idx += EB;
+    }
+    if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
+}
+
+}  // namespace fused
+
+template <int FM>
+__global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
+    DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, int32_t n_cand,
+    const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
+    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    using namespace fused;
+    using feat::Assemble;
+    constexpr int RC = FM / 2;
+    __shared__ GroupLds<FM> lds[ADH_WAVE / GS];
+    const int lane = threadIdx.x;
+    const int g = lane / GS, sub = lane % GS;
+    const unsigned gsh = (unsigned)(g * GS);
+    GroupLds<FM> &L = lds[g];
+    const int ci = blockIdx.x * (ADH_WAVE / GS) + g;
+    bool alive = ci < n_cand;
+    const CandRec &rec = plan[alive ? ci : 0];
+    alive = alive && !(rec.flags & ADH_FLAG_SKIP);
+    const uint32_t row = rec.row;
+    if (alive && sub == 0) {
+        out.precursor_idx[row] = rec.precursor_idx;  // candidate.py:175-176
+        out.rank[row] = rec.rank;
+    }
+    const int Lc = run.cycle_len;
+    const int c0 = rec.frame_start / Lc;
+    const int F = alive ? rec.frame_stop / Lc - c0 : 0;
+    const int c = F / 2;
+    const int shift = c - RC;  // f = r + shift
+    const int I = alive ? min(n_iso_cols, (int)cfg.top_k_isotopes) : 0;
+    const int top_k = out.top_k;
+
+    // ================= fragments: slice, cardinality filter, top-k by intensity, sort by m/z =========
+    // (fragment_container.py:56-102; the tie rules of argsort()[::-1][:k] and of the stable argsort(mz))
+    const int64_t frag_start = rec.frag_start;
+    const int n_lib = alive ? (int)(rec.frag_stop - rec.frag_start) : 0;
+    RawRec mine;
+    mine.a = make_uint4(0u, 0u, 0u, 0u);
+    mine.b = 0u;
+    if (sub < n_lib) mine = load_rec(lib + frag_start + sub);
+    const float mine_int = rec_intensity(mine), mine_mz = rec_mz(mine);
+    // loads that do not depend on the selection: issued now, consumed after the gather
+    const float rt_first = alive ? run.rt[rec.frame_start] : 0.0f;
+    const float rt_last = alive ? run.rt[max(rec.frame_stop - 1, 0)] : 0.0f;
+    float loc = 0.0f;  // location features (location_features.py:8-33)
+    if (alive && (sub == 0 || sub == 2 || sub == 3)) {
+        loc = sub == 0   ? run.mobility[rec.scan_start] - run.mobility[rec.scan_stop - 1]
+              : sub == 2 ? run.rt[rec.frame_center]
+                         : run.mobility[rec.scan_center];
+    }
+    float frt_l[(FM + 15) / 16];  // frame RTs of the registers sub, sub + 16
+#pragma unroll
+    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+        const int r = min(sub + 16 * pass, FM - 1);
+        const int f = r + shift;
+        const bool ok = alive && f >= 0 && f < F;
+        frt_l[pass] = ok ? run.rt[rec.frame_start + f * Lc] : 0.0f;
+    }
+    const bool iso_lane = alive && sub >= ISO0 && sub - ISO0 < I;
+    const int il = iso_lane ? sub - ISO0 : 0;
+    float iso_int_l = 0.0f;
+    double cy0 = 0.0, cy1 = 1.0;
+    if (iso_lane) {
+        iso_int_l = iso_table[(int64_t)row * n_iso_cols + il];
+        const double *cy = run.cycle + 2 * ((int64_t)rec.obs[0] * run.cycle_scans + rec.scan_start);
+        cy0 = cy[0];
+        cy1 = cy[1];
+    }
+    const int ms1_row = run.ms1_obs[0];
+    int K0 = 0;
+    if (!__any(n_lib > GS)) {
+        // ---- every fragment of the slice has its lane: ranks by comparison with the 15 other lanes of
+        // the row, values moved by DPP rotations (no LDS round trips in the dependency chain)
+        const bool ok_l = sub < n_lib && !(cfg.exclude_shared_ions && rec_cardinality(mine) > 1);
+        const unsigned okm = (unsigned)((__ballot(ok_l) >> gsh) & 0xFFFFull);
+        const int ia = __float_as_int(mine_int);
+        int rk = 0;
+#define FU_RANK_STEP(N)                                                                                \
+    {                                                                                                  \
+        const int b = row_ror<N>(sub);                                                                 \
+        const float ib = __int_as_float(row_ror<N>(ia));                                               \
+        rk += (((okm >> b) & 1u) != 0u) && ((ib > mine_int) || (ib == mine_int && b > sub)); \
+    }
+        FU_FOR_OTHER_LANES(FU_RANK_STEP)  // position in argsort()[::-1]
+#undef FU_RANK_STEP
+        if (!ok_l || rk >= (int)cfg.top_k_fragments) rk = -1;
+        const unsigned selm = (unsigned)((__ballot(rk >= 0) >> gsh) & 0xFFFFull);
+        K0 = __popc(selm);
+        if (K0 <= 3) {  // candidate.py:190,230
+            K0 = 0;
+            alive = false;
+        }
+        if (__ballot(alive) == 0ull) return;
+        int slot = 0;
+        const int ma = __float_as_int(mine_mz);
+#define FU_SLOT_STEP(N)                                                                           \
+    {                                                                                             \
+        const int rb = row_ror<N>(rk);                                                            \
+        const float mb = __int_as_float(row_ror<N>(ma));                                          \
+        slot += (rb >= 0) && ((mb < mine_mz) || (mb == mine_mz && rb < rk));                      \
+    }
+        FU_FOR_OTHER_LANES(FU_SLOT_STEP)  // stable argsort(mz) of the top-k list
+#undef FU_SLOT_STEP
+        if (rk >= 0 && alive) {
+            L.u.s.sel[slot].a = mine.a;
+            L.u.s.sel[slot].b = mine.b | ((uint32_t)sub << 16);  // position inside the library slice (adh_output_t.fragment_lib_slot)
+        }
+    } else {
+        // ---- longer slices (up to 64): the same counting through LDS
+        for (int j = sub; j < n_lib; j += GS) {
+            RawRec lr = mine;
+            if (j != sub) lr = load_rec(lib + frag_start + j);
+            L.u.s.l_int[j] = rec_intensity(lr);
+            L.u.s.l_mz[j] = rec_mz(lr);
+            L.u.s.l_ok[j] = !(cfg.exclude_shared_ions && rec_cardinality(lr) > 1);
+        }
+        adh_wave_sync();
+        for (int a = sub; a < n_lib; a += GS) {
+            int rk = -1;
+            if (L.u.s.l_ok[a]) {
+                rk = 0;
+                const float ia = L.u.s.l_int[a];
+                for (int b = 0; b < n_lib; ++b) {
+                    const float ib = L.u.s.l_int[b];
+                    rk += (L.u.s.l_ok[b] != 0) && ((ib > ia) || (ib == ia && b > a));  // position in argsort()[::-1]
+                }
+                if (rk >= (int)cfg.top_k_fragments) rk = -1;
+            }
+            L.u.s.l_rank[a] = rk;
+        }
+        adh_wave_sync();
+        for (int a = 0; a < n_lib; ++a) K0 += L.u.s.l_rank[a] >= 0;
+        if (K0 <= 3) {  // candidate.py:190,230
+            K0 = 0;
+            alive = false;
+        }
+        if (__ballot(alive) == 0ull) return;
+        for (int a = sub; a < n_lib; a += GS) {
+            const int ra = L.u.s.l_rank[a];
+            if (ra < 0 || !alive) continue;
+            const float ma = L.u.s.l_mz[a];
+            int slot = 0;
+            for (int b = 0; b < n_lib; ++b) {
+                const int rb = L.u.s.l_rank[b];
+                const float mb = L.u.s.l_mz[b];
+                slot += (rb >= 0) && ((mb < ma) || (mb == ma && rb < ra));  // stable argsort(mz) of the top-k list
+            }
+            RawRec pick = mine;
+            if (a != sub) pick = load_rec(lib + frag_start + a);
+            L.u.s.sel[slot].a = pick.a;
+            L.u.s.sel[slot].b = pick.b | ((uint32_t)a << 16);  // position inside the library slice (adh_output_t.fragment_lib_slot)
+        }
+    }
+    adh_wave_sync();
+    const bool frag_lane0 = alive && sub < K0;
+    RawRec lrec;
+    lrec.a = make_uint4(0u, 0u, 0u, 0u);
+    lrec.b = 0u;
+    if (frag_lane0) {
+        lrec.a = L.u.s.sel[sub].a;
+        lrec.b = L.u.s.sel[sub].b;
+    }
+    const float lrec_mz = rec_mz(lrec), lrec_int = rec_intensity(lrec);
+    adh_wave_sync();  // the selection arrays are dead: the tile takes their place
+    if (stop_phase == 21) {
+        if (lrec_mz == -1.5f) out.valid[row] = 2;
+        return;
+    }
+
+    // ================= windows (jitclasses/utils.py:15-20: float32 throughout) =================
+    gather::Window w;
+    w.lo = 0.0f;
+    w.hi = -INFINITY;
+    float iso_mz_l = 0.0f;
+    if (frag_lane0) {
+        const float ma = lrec_mz;
+        const float t = cfg.fragment_mz_tolerance * ma;
+        const float q = t / 1000000.0f;
+        w.lo = ma - q;
+        w.hi = ma + q;
+    }
+    if (iso_lane) {  // isotope m/z (candidate.py:151-163)
+        const double off = (double)il * 1.0033548350700006 / (double)rec.charge;
+        iso_mz_l = (float)off + rec.precursor_mz;
+        const float t = cfg.precursor_mz_tolerance * iso_mz_l;
+        const float q = t / 1000000.0f;
+        w.lo = iso_mz_l - q;
+        w.hi = iso_mz_l + q;
+    }
+    const bool win_lane = frag_lane0 || iso_lane;
+    {
+        // the reference's monotone cursor: window k starts above max(hi_j, j < k) (adh_gather.hip)
+        const float ef = row_prefix_max_excl(frag_lane0 ? w.hi : -INFINITY);
+        const float ei = row_prefix_max_excl(iso_lane ? w.hi : -INFINITY);
+        w.excl = iso_lane ? ei : ef;
+    }
+    gather::bins_of(run, w);
+    const bool task_on = win_lane && w.b_hi >= w.b_lo;
+    const int task_row = iso_lane ? ms1_row : (int)rec.obs[0];
+    const WinBits wb = win_bits(w);
+
+    // ================= gather: every lane its window, into its column of the tile =================
+    {
+        float4 *z = reinterpret_cast<float4 *>(&L.u.tile[0][0]);
+        constexpr int N4 = FM * TW / 2;
+#pragma unroll
+        for (int j = 0; j < (N4 + GS - 1) / GS; ++j)
+            if (j * GS + sub < N4) z[j * GS + sub] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    uint32_t hits = 0;
+    {
+        const int bs = run.block_shift;
+        const int blk0 = c0 >> bs;
+        const int n_blk = alive ? ((c0 + F - 1) >> bs) - blk0 + 1 : 0;
+        float2 *cells = &L.u.tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
+        const int roff = RC - c - c0;  // centred row of absolute cycle x: x + roff
+        for (int bb = 0; __any(bb < n_blk); bb += NT) {
+            Task t[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, t[u]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) task_fetch(run, t[u]);
+            if (stop_phase == 22) {  // developer ablation: table and first entry loads only
+                uint32_t x = 0;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) x += t[u].e[0].x + t[u].e[EB - 1].y;
+                if (x == 0xFFFFFFF1u) out.valid[row] = 2;
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) task_run(run, wb, t[u], cells, roff, hits);
+        }
+    }
+    if (stop_phase == 22) return;
+    // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1; the isotope lanes
+    double qtf_l = 0.0;
+    if (iso_lane) {
+        const double x = (double)iso_mz_l;
+        qtf_l = logistic(x, cy0, 0.2) - logistic(x, cy1, 0.2);
+    }
+    // qtf mask of the fragment tile (candidate.py:287-289): mean over the isotopes, in order
+    float qmask;
+    {
+        double qs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double qi = __shfl(qtf_l, (int)gsh + ISO0 + i);
+            if (i < I) qs += qi;
+        }
+        qmask = (I > 0) ? (float)(qs / (double)I) : 0.0f;
+    }
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) hits += __shfl_xor(hits, m, GS);
+    if (alive && sub == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = hits;
+    if (stop_phase == 2) return;
+
+    // ================= rows into registers (the tile is dead afterwards) =================
+    float A[FM], B[FM];
+    {
+        const float2 *col = &L.u.tile[0][min(sub, TW - 1)];
+        const float mq = iso_lane ? 1.0f : qmask;  // candidate.py:290 (fragments only)
+        FU_FOR_R {
+            const float2 v = col[r * TW];
+            A[r] = v.x * mq;
+            B[r] = v.y;
+        }
+        if (iso_lane) {
+            // MS1 observation collapse (candidate.py:248-269) with ONE MS1 row per cycle: the sum over the
+            // single observation is the value itself, the mean m/z is y / (count + 1e-6) with count = 1
+            // where y > 0 (y is a weighted mean of m/z values: positive or an untouched 0 = 0 / 1e-6)
+            const Recip one(1.0 + 1e-6);
+            FU_FOR_R {
+                const float b = B[r];
+                B[r] = (b > 0.0f) ? (float)one.div((double)b) : b;
+            }
+        }
+    }
+    adh_wave_sync();
+    auto &Q = L.u.f;
+    const float rt_width = rt_last - rt_first;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (sub + 16 * j < ADH_NUM_FEATURES + 2) Q.feat[sub + 16 * j] = 0.0f;
+    if (sub == 1) loc = rt_width;
+#pragma unroll
+    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+        const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+        Q.frt[r] = frt_l[pass];
+    }
+    // ---- isotope lanes: template contributions (quadrupole.py:304-324), precursor weights around the
+    // expected centre (S, 1) of precursor_features.py:52-57
+    if (iso_lane) {
+        Q.qtf[il] = qtf_l;
+        Q.iso_mz[il] = iso_mz_l;
+        Q.iso_int[il] = iso_int_l;
+        FU_FOR_R {
+            const float a = A[r] * iso_int_l;
+            Q.u.dT[il][r] = (double)a * qtf_l;
+        }
+    }
+    adh_wave_sync();
+#pragma unroll
+    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+        const int r = sub + 16 * pass;
+        if (r < FM) {
+            double acc = 0;
+            for (int i = 0; i < I; ++i) acc += Q.u.dT[i][r];
+            Q.tpl[r] = (float)acc;  // zero outside [0, F)
+        }
+    }
+    adh_wave_sync();
+    // precursor weights exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)) around the expected centre (S, 1) of
+    // precursor_features.py:52-57, centred and masked like the fragments' table below
+#pragma unroll
+    for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
+        const int idx = min(sub + 16 * pass, 2 * FM - 1);
+        const int sc = idx / FM, r = idx - sc * FM;
+        const int f = r + shift;
+        const bool ok = alive && f >= 0 && f < F;
+        Q.u.wti[sc][r] = ok ? wtp_table[sc * 64 + f] : 0.0;
+    }
+    if (stop_phase == 31) return;
+    // observation importance (quadrupole.py:327-335)
+    {
+        float st = 0.0f;
+        FU_FOR_R {
+            st += Q.tpl[r];
+            FU_FENCE(r);
+        }
+        const float ts = st + st;
+        const float tot = 0.0f + ts;
+        if (sub == 0) {
+            Q.tsum[0] = ts;
+            Q.oi[0] = (tot == 0.0f) ? 1.0f / 1.0f : ts / tot;
+        }
+    }
+    // ---- template centre of mass (fragment_features.py:20-68; every lane computes it), template frame
+    // profile, weights around the centre
+    double esc, efc;
+    {
+        double isum = 0, ssum = 0, fsum = 0;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+        for (int sc = 0; sc < 2; ++sc) {
+            const double scd = (double)sc;
+            FU_FOR_R {
+                float v = Q.tpl[r];
+                v = (v > 0.0f) ? v : 0.0f;  // the reference skips v <= 0; adding +0 is the same
+                const double vd = (double)v;
+                isum += vd;
+                ssum += scd * vd;
+                fsum += (double)(r + shift) * vd;
+                FU_FENCE(r);
+            }
+        }
+        esc = (isum > 0) ? ssum / isum : 0.0;
+        efc = (isum > 0) ? fsum / isum : 0.0;
+    }
+    // template frame profile with or_envelope (scoring/utils.py:46-53)
+#pragma unroll
+    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+        const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+        const int f = r + shift;
+        const bool ok = alive && f >= 0 && f < F;
+        const float x = Q.tpl[r] + Q.tpl[r];
+        float rr = x;
+        if (ok && f >= 1 && f < F - 1) {
+            const float xl = Q.tpl[r - 1] + Q.tpl[r - 1];
+            const float xr = Q.tpl[r + 1] + Q.tpl[r + 1];
+            if (x < xl || x < xr) {
+                const float sm = xl + xr;
+                rr = sm * 0.5f;  // (float)((double)sm / 2): exact either way
+            }
+        }
+        Q.tfp[r] = ok ? rr : 0.0f;
+    }
+    // weight table around the template centre (features_utils.py:9-25), centred index
+#pragma unroll
+    for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
+        const int idx = min(sub + 16 * pass, 2 * FM - 1);
+        const int sc = idx / FM, r = idx - sc * FM;
+        const int f = r + shift;
+        const bool ok = alive && f >= 0 && f < F;
+        double wv = 0.0;
+        if (ok) {
+            const double ds = (double)sc - esc, df = (double)f - efc;
+            wv = exp(-0.1 * sqrt(ds * ds + df * df));
+        }
+        Q.wt[sc][r] = wv;
+    }
+    adh_wave_sync();
+    if (stop_phase == 32) return;
+
+    // ================= row sums and weighted centre means: fragments and isotopes together =========
+    // presence (candidate.py:319-329) / sum_precursor_intensity: row sum over the two identical scan slots
+    float sf = 0.0f;
+    FU_FOR_R sf += A[r];
+    const float ss = sf + sf;
+    // weighted centre means of both channels (features_utils.py:9-37; precursor_features.py:52-66).
+    // A skipped cell (value <= 0) adds nothing: its product is +0, only its weight has to stay out.
+    double m_int, m_mz;
+    {
+        const double *wrow = iso_lane ? &Q.u.wti[0][0] : &Q.wt[0][0];
+        double vo = 0, wo = 0, vm = 0, wm = 0;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+        for (int sc = 0; sc < 2; ++sc) {
+            FU_FOR_R {
+                const double wv = wrow[sc * FM + r];
+                float a = A[r], b = B[r];
+                FU_OPAQUE(a);
+                FU_OPAQUE(b);
+                vo += (double)a * wv;
+                if (a > 0.0f) wo += wv;
+                vm += (double)b * wv;
+                if (b > 0.0f) wm += wv;
+                FU_FENCE(r);
+            }
+        }
+        m_int = (wo > 0) ? vo / wo : 0.0;
+        m_mz = (wm > 0) ? vm / wm : 0.0;
+    }
+    if (iso_lane) {
+        Q.spi[il] = ss;
+        Q.hp[il] = m_int;
+        Q.omzp[il] = m_mz;
+    }
+    const double ohe_l = frag_lane0 ? m_int : 0.0, omz_l = frag_lane0 ? m_mz : 0.0;
+    const float rowsum_l = frag_lane0 ? ss : 0.0f;
+    float P[FM];  // frame profile (frame_profile_2d: sum over the two scan slots)
+    FU_FOR_R P[r] = frag_lane0 ? A[r] + A[r] : 0.0f;
+    if (stop_phase == 33) return;
+    bool present = frag_lane0 && rowsum_l > 0.0f;
+    const unsigned long long bal = __ballot(present);
+    const unsigned gm = (unsigned)((bal >> gsh) & 0xFFFFull);
+    int K = __popc(gm);
+    const int kk = __popc(gm & ((1u << sub) - 1u));
+    const int n_present = K;
+    if (K < 2) {  // candidate.py:323
+        alive = false;
+        present = false;
+        K = 0;
+    }
+    if (present) Q.g_fin[kk] = lrec_int;  // raw intensity, normalised below
+    adh_wave_sync();
+    // fragment intensities: apply_mask renormalisation + the second one of fragment_features.py:218
+    float g_int_l = 0.0f, g_fin_l = 0.0f;
+    {
+        float sum1 = 0.0f;
+        for (int j = 0; j < K; ++j) sum1 += Q.g_fin[j];
+        if (present) {
+            g_int_l = lrec_int / sum1;
+            Q.g_int[kk] = g_int_l;
+        }
+    }
+    adh_wave_sync();
+    {
+        float sum2 = 0.0f;
+        for (int j = 0; j < K; ++j) sum2 += Q.g_int[j];
+        if (present) g_fin_l = g_int_l / sum2;
+    }
+    adh_wave_sync();
+    if (present) Q.g_fin[kk] = g_fin_l;
+    if (stop_phase == 3 || stop_phase == 4) return;
+
+    // ---- envelope, quantification (fragment_features.py:240-273)
+    double area = 0.0;
+    float obs_int = 0.0f;
+    {
+        float E[FM];  // np.sum(axis=1) made a copy: with quant_all the profile itself is untouched
+        FU_FOR_R E[r] = P[r];
+        center_envelope<FM>(E, F);
+        const int qw = min(c - 1, (int)cfg.quant_window);
+        double ar = 0.0;
+#pragma unroll
+        for (int r = 1; r < FM - 1; ++r) {
+            const bool in = r >= RC - qw && r + 1 <= RC + qw;
+            const float sm = E[r + 1] + E[r];
+            const float drt = Q.frt[r + 1] - Q.frt[r];
+            const float m = sm * drt;
+            ar += in ? (double)m * 0.5 : 0.0;
+        }
+        area = ar * (double)qw;
+        FU_FOR_R obs_int += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
+        if (!cfg.quant_all) {
+            FU_FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
+        }
+    }
+    double m1 = 0.0, m2 = 0.0, merr_l = 0.0;
+    bool hrow = false;
+    if (present) {
+        // importance-weighted means over observations (fragment_features.py:311-336), one observation
+        const float oi0 = Q.oi[0];
+        const bool m = ohe_l > 0;
+        hrow = m;
+        const float w32 = m ? oi0 : oi0 * 0.0f;
+        const float ws = 0.0f + w32;
+        const double wd = (double)w32 / ((double)ws + 1e-20);
+        if (wd > 0) {
+            const double msum = 0.0 + wd;
+            const double lw = wd / msum;
+            m1 += omz_l * lw;
+            m2 += ohe_l * lw;
+        }
+        merr_l = (m1 - (double)lrec_mz) / (double)lrec_mz * 1e6;  // fragment_features.py:387
+        Q.merr[kk] = merr_l;
+        int rk = 0;
+        for (int j = 0; j < K; ++j) {
+            const float ib = Q.g_int[j];
+            rk += (ib > g_int_l) || (ib == g_int_l && j > kk);
+        }
+        Q.ord[rk] = kk;  // position in argsort(intensity)[::-1]
+    }
+    adh_wave_sync();
+    if (stop_phase == 5) return;
+
+    if (alive && sub < 4) Q.feat[sub] = loc;
+    adh_wave_sync();
+    if (alive && sub == 0) {
+        Assemble asmv;
+        asmv.run = nullptr;  // features 0-3 are in place
+        asmv.rec = &rec;
+        asmv.featv = Q.feat;
+        asmv.iso_int = Q.iso_int; asmv.iso_mz = Q.iso_mz; asmv.spi = Q.spi; asmv.oi = Q.oi;
+        asmv.omzp = Q.omzp; asmv.hp = Q.hp;
+        asmv.n_present = n_present; asmv.K0 = K0;
+        feat::assemble_precursor(asmv, I, 1);
+    }
+    // ---- fragment features 17-27, 41-45 (fragment_features.py:198-427; the scalar form is
+    // feat::assemble_fragments).  Every sum over fragments keeps the reference's order
+    // (k ascending) but all sums advance together: lane k provides its term of every sum,
+    // then lane j adds up sum j.  Skipped terms are added as +0, which leaves a sum unchanged.
+    const bool ipos = present && obs_int > 0.0f;
+    const bool hpos = present && m2 > 0.0;
+    const bool isb = present && rec_type(lrec) == 98, isy = present && rec_type(lrec) == 121;
+    const unsigned b_isb = (unsigned)((__ballot(isb) >> gsh) & 0xFFFFull);
+    const unsigned b_isy = (unsigned)((__ballot(isy) >> gsh) & 0xFFFFull);
+    const int n_int = __popc((unsigned)((__ballot(ipos) >> gsh) & 0xFFFFull));
+    const int n_hei = __popc((unsigned)((__ballot(hpos) >> gsh) & 0xFFFFull));
+    const int n_hrows = __popc((unsigned)((__ballot(present && hrow) >> gsh) & 0xFFFFull));
+    const int nb = __popc(b_isb), ny = __popc(b_isy);
+    const int lpos = rec_position(lrec);
+    int min_y = isy ? lpos : 255, max_b = isb ? lpos : 0;
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) {
+        min_y = min(min_y, __shfl_xor(min_y, m, GS));
+        max_b = max(max_b, __shfl_xor(max_b, m, GS));
+    }
+    const bool ov = (isy && lpos < max_b) || (isb && lpos > min_y);
+    const int n_ov = __popc((unsigned)((__ballot(ov) >> gsh) & 0xFFFFull));
+    const int n3 = min(K, 3);
+    if (present) {
+        double *t = Q.u.at.t64[kk];
+        t[0] = area;
+        t[1] = m2;
+        t[2] = (double)g_fin_l;
+        t[3] = merr_l;
+        t[4] = ov ? area : 0.0;
+        t[5] = ov ? merr_l : 0.0;
+        // cosine_similarity_a1 (features_utils.py:40-47) of the observation sums
+        const float ts0 = Q.tsum[0];
+        float tn = 0.0f, fn = 0.0f, dot = 0.0f;
+        tn += ts0 * ts0;
+        tn = sqrtf(tn);
+        fn += rowsum_l * rowsum_l;
+        fn = sqrtf(fn);
+        dot += rowsum_l * ts0;
+        const float pr = fn * tn;
+        const float score = (float)((double)dot / ((double)pr + 0.0001));
+        float *u = Q.u.at.t32[kk];
+        u[0] = ipos ? g_fin_l : 0.0f;
+        u[1] = hpos ? g_fin_l : 0.0f;
+        u[2] = ipos ? score : 0.0f;
+        u[3] = isb ? obs_int : 0.0f;
+        u[4] = isy ? obs_int : 0.0f;
+    }
+    adh_wave_sync();
+    {
+        double s64 = 0.0;
+        float s32 = 0.0f;
+        if (sub < 6) {
+            for (int k = 0; k < K; ++k) s64 += Q.u.at.t64[k][sub];
+            Q.red64[sub] = s64;
+        } else if (sub < 11) {
+            for (int k = 0; k < K; ++k) s32 += Q.u.at.t32[k][sub - 6];
+            Q.red32[sub - 6] = s32;
+        } else if (sub == 11) {
+            for (int i = 0; i < n3; ++i) s64 += Q.merr[Q.ord[i]];  // mean_top3 mass error, by rank
+            Q.red64[6] = s64;
+        }
+    }
+    adh_wave_sync();
+    {
+        // np.corrcoef terms (feat::corrcoef01): area vs intensity, height vs intensity
+        const double mx_a = Q.red64[0] / (double)K, mx_h = Q.red64[1] / (double)K;
+        const double my = Q.red64[2] / (double)K;
+        adh_wave_sync();
+        if (present) {
+            const double a = area - mx_a, h = m2 - mx_h, b = (double)g_fin_l - my;
+            double *t = Q.u.at.t64[kk];
+            t[0] = a * a;
+            t[1] = b * b;
+            t[2] = a * b;
+            t[3] = h * h;
+            t[4] = h * b;
+        }
+    }
+    adh_wave_sync();
+    if (sub < 5) {
+        double s64 = 0.0;
+        for (int k = 0; k < K; ++k) s64 += Q.u.at.t64[k][sub];
+        Q.red64[7 + sub] = s64;
+    }
+    adh_wave_sync();
+    if (alive && sub < 2) {
+        // lane 0: feature 18 (areas), lane 1: feature 19 (heights)
+        const double fact = fmax((double)K - 1.0, 0.0);
+        const double inv = 1.0 / fact;
+        const double cxx = Q.red64[sub ? 10 : 7] * inv, cyy = Q.red64[8] * inv;
+        const double cxy = Q.red64[sub ? 11 : 9] * inv;
+        const double s0 = sqrt(cxx), s1 = sqrt(cyy);
+        double cc = cxy / s1 / s0;
+        if (fabs(cc) > 1.0) cc = (cc > 0) ? 1.0 : -1.0;
+        const bool on = sub ? (Q.red64[1] > 0.0) : (n_hrows > 0);
+        if (on) Q.feat[18 + sub] = (float)cc;
+    }
+    if (alive && sub == 0) {
+        float *ft = Q.feat;
+        ft[17] = (float)1;
+        ft[20] = (float)((double)n_int / (double)K);
+        ft[21] = (float)((double)n_hei / (double)K);
+        ft[22] = Q.red32[0];
+        ft[23] = Q.red32[1];
+        if (n_int > 0) ft[24] = (float)((double)Q.red32[2] / (double)n_int);
+        ft[25] = nb > 0 ? (float)log((double)Q.red32[3] + 1.0) : 0.0f;
+        ft[26] = ny > 0 ? (float)log((double)Q.red32[4] + 1.0) : 0.0f;
+        ft[27] = ft[25] - ft[26];
+        ft[41] = (float)(Q.red64[6] / (double)n3);
+        ft[42] = (float)(Q.red64[3] / (double)K);
+        if (nb > 0 && ny > 0) {
+            ft[43] = (float)n_ov;
+            if (n_ov > 0) {
+                ft[44] = (float)(Q.red64[4] / (double)n_ov);
+                ft[45] = (float)(Q.red64[5] / (double)n_ov);
+            } else {
+                ft[44] = 0.0f;
+                ft[45] = 15.0f;
+            }
+        }
+    }
+    if (stop_phase == 6) return;
+
+    // ================= profile features (profile_features.py:18-206), experimental_xic =======
+    {
+        // normalize_profiles (scoring_utils.py:71-117): centre +- 1 are registers RC-1, RC, RC+1
+        float sm = 0.0f;
+        sm += P[RC - 1];
+        sm += P[RC];
+        sm += P[RC + 1];
+        const double cn = (double)sm / 3.0;
+        const bool cpos = cn > 0;
+        const Recip rcn(cpos ? cn : 1.0);
+        // median over fragments per cycle (scoring_utils.py:120-152): 16x16 transposes via LDS
+#pragma unroll
+        for (int half = 0; half < (FM + 15) / 16; ++half) {
+            adh_wave_sync();  // previous users of the union are done
+            if (present) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (half * 16 + t >= FM) break;
+                    const float x = P[half * 16 + t];
+                    Q.u.nrmT[t][kk] = cpos ? (float)rcn.div((double)x) : 0.0f;
+                }
+            }
+            adh_wave_sync();
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (j < K) ? Q.u.nrmT[sub][j] : INFINITY;
+            fast::sort16(v);
+            const int r_lo = (K - 1) / 2, r_hi = K / 2;
+            float lo_v = 0.0f, hi_v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                lo_v = (j == r_lo) ? v[j] : lo_v;
+                hi_v = (j == r_hi) ? v[j] : hi_v;
+            }
+            float m;
+            if (K & 1) {
+                m = hi_v;
+            } else {
+                const float s2 = lo_v + hi_v;
+                m = (float)((double)s2 / 2.0);
+            }
+            const int r = half * 16 + sub;
+            const int f = r + shift;
+            if (r < FM) Q.med[r] = (alive && f >= 0 && f < F) ? m : 0.0f;
+        }
+    }
+    adh_wave_sync();
+    if (stop_phase == 61) return;
+    float corr_l = 0.0f;
+    {
+        // correlation_coefficient (scoring_utils.py:14-68)
+        float sx = 0.0f;
+        FU_FOR_R {
+            sx += Q.med[r];
+            FU_FENCE(r);
+        }
+        const float mx = (float)((double)sx / (double)F);
+        float sxx = 0.0f, sy = 0.0f;
+        FU_FOR_R {
+            float xm = Q.med[r] - mx;
+            xm = FU_OK(r) ? xm : 0.0f;
+            sxx += xm * xm;
+            FU_FENCE(r);
+        }
+        const double var_x = (double)sxx / (double)F;
+        FU_FOR_R sy += P[r];
+        const float my = (float)((double)sy / (double)F);
+        float sxy = 0.0f, syy = 0.0f;
+        FU_FOR_R {
+            float xm = Q.med[r] - mx;
+            const float ym = P[r] - my;
+            xm = FU_OK(r) ? xm : 0.0f;  // (one zero factor is enough)
+            sxy += xm * ym;
+            FU_FENCE(r);
+        }
+        FU_FOR_R {
+            float ym = P[r] - my;
+            ym = FU_OK(r) ? ym : 0.0f;
+            syy += ym * ym;
+        }
+        const double cov = (double)sxy / (double)F;
+        const double var_y = (double)syy / (double)F;
+        const double var_xy = var_x * var_y;
+        corr_l = (var_xy == 0) ? 0.0f : (float)(cov / sqrt(var_xy));
+    }
+    {
+        float ftc_o, fw_o;
+        int fpeak_o;
+        profile_stats<FM>(P, Q.tfp, F, shift, rt_width, ftc_o, fw_o, fpeak_o);
+        Q.ftc[sub] = ftc_o;
+        Q.fw[sub] = fw_o;
+        Q.fpeak[sub] = fpeak_o;
+    }
+    if (stop_phase == 62) return;
+    if (present) Q.corr[kk] = corr_l;
+    adh_wave_sync();
+    // ---- features 31-38, 40 (profile_features.py:70-113,141-146,196-204; the scalar form is
+    // feat::assemble_part2), sums organised as above
+    {
+        const int r_lo = (K - 1) / 2, r_hi = K / 2;
+        if (present) {
+            // median apex (profile_features.py:196-198): rank of this fragment's apex
+            const int va = Q.fpeak[sub];
+            int rk = 0;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                if (!((gm >> b) & 1u)) continue;
+                const int vb = Q.fpeak[b];
+                rk += (vb < va) || (vb == va && b < sub);
+            }
+            if (rk == r_lo) Q.medlo = va;
+            if (rk == r_hi) Q.medhi = va;
+            const float cr = Q.corr[Q.ord[kk]];  // correlation of the fragment with intensity rank kk
+            // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
+            const bool b3 = isb && __popc(b_isb & ((1u << sub) - 1u)) < 3;
+            const bool y3 = isy && __popc(b_isy & ((1u << sub) - 1u)) < 3;
+            const float oi0 = Q.oi[0];
+            float rr = 0.0f, ml = 0.0f;
+            rr += Q.ftc[sub] * oi0;
+            ml += Q.fw[sub] * oi0;
+            float *u = Q.u.at.t32[kk];
+            u[0] = corr_l;
+            u[1] = rr * g_int_l;
+            u[2] = ml * g_int_l;
+            u[3] = b3 ? cr : 0.0f;
+            u[4] = y3 ? cr : 0.0f;
+            u[5] = (kk < n3) ? cr : 0.0f;
+        }
+    }
+    adh_wave_sync();
+    if (sub < 6) {
+        float s32 = 0.0f;
+        for (int k = 0; k < K; ++k) s32 += Q.u.at.t32[k][sub];
+        Q.red32[sub] = s32;
+    }
+    adh_wave_sync();
+    if (alive && sub == 0) {
+        float *ft = Q.feat;
+        ft[31] = (float)((double)Q.red32[0] / (double)K);
+        ft[32] = (float)((double)Q.red32[5] / (double)n3);
+        ft[33] = Q.red32[1];
+        if (nb > 0) {
+            ft[34] = (float)((double)Q.red32[3] / (double)min(nb, 3));
+            ft[35] = (float)nb;
+        }
+        if (ny > 0) {
+            ft[36] = (float)((double)Q.red32[4] / (double)min(ny, 3));
+            ft[37] = (float)ny;
+        }
+        ft[38] = Q.red32[2];
+        double acc = 0.0;
+        {
+            const double med = (K & 1) ? (double)Q.medhi : (double)(Q.medlo + Q.medhi) / 2.0;
+            const float medpk = (float)med;
+            acc += ((double)medpk - floor((double)F / 2.0)) * (double)Q.oi[0];
+        }
+        ft[40] = (float)acc;
+    }
+    adh_wave_sync();
+
+    // ---- output row (candidate.py:403-481)
+    if (alive) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = sub + 16 * j;
+            if (idx < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + idx] = Q.feat[idx];
+        }
+        if (cfg.collect_fragments && present && kk < top_k) {
+            const int64_t o = (int64_t)row * top_k + kk;
+            out.fragment_precursor_idx[o] = rec.precursor_idx;
+            out.fragment_rank[o] = rec.rank;
+            out.fragment_mz_library[o] = __uint_as_float(lrec.a.x);
+            out.fragment_mz[o] = lrec_mz;
+            out.fragment_mz_observed[o] = (float)m1;
+            out.fragment_height[o] = (float)m2;
+            out.fragment_intensity[o] = (float)area;
+            out.fragment_mass_error[o] = (float)merr_l;
+            out.fragment_correlation[o] = corr_l;
+            out.fragment_position[o] = (uint8_t)lpos;
+            out.fragment_number[o] = (uint8_t)(lrec.a.w >> 24);
+            out.fragment_type[o] = (uint8_t)(lrec.a.w & 0xFFu);
+            out.fragment_charge[o] = (uint8_t)((lrec.a.w >> 16) & 0xFFu);
+            out.fragment_loss_type[o] = (uint8_t)((lrec.a.w >> 8) & 0xFFu);
+            if (out.fragment_lib_slot) out.fragment_lib_slot[o] = (uint16_t)(1u + (lrec.b >> 16));
+        }
+        if (sub == 0) out.valid[row] = 1;
+    }
+}

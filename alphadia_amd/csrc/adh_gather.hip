@@ -51,7 +51,14 @@ __device__ __forceinline__ void fold(float &acc_i, float &acc_m, float mz, float
     float b = ni * mz;
     float n32 = a + b;
     float d32 = acc_i + ni;
-    acc_m = (float)(((double)n32 + 1e-36) / ((double)d32 + 1e-36));
+    // (float)(((double)n32 + 1e-36) / ((double)d32 + 1e-36)).  Above 1e-20 the float64 sums are the operands
+    // themselves (1e-36 is below half an ulp of their 53-bit form), and a float64 quotient of two float32
+    // values rounded to float32 is the correctly rounded float32 quotient (53 >= 2 * 24 + 2): one float32
+    // division (IEEE, hipcc's default) instead of a float64 one.
+    if (n32 > 1e-20f && d32 > 1e-20f)
+        acc_m = n32 / d32;
+    else
+        acc_m = (float)(((double)n32 + 1e-36) / ((double)d32 + 1e-36));
     acc_i = d32;
 }
 

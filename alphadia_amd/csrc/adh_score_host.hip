@@ -288,12 +288,13 @@ int plan_reserve(adh_handle *h, PlanSlot &s, int64_t n, bool im) {
 
 struct PlanKey {
     uint32_t top_k_fragments, top_k_isotopes;
-    bool fast_cfg, quant_all;
+    bool fast_cfg, quant_all, fused_cfg;
 };
 
 PlanKey plan_key(const adh_scoring_config_t *cfg) {
-    return PlanKey{cfg->top_k_fragments, cfg->top_k_isotopes,
-                   cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST"), cfg->quant_all != 0};
+    const bool fast = cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST");
+    return PlanKey{cfg->top_k_fragments, cfg->top_k_isotopes, fast, cfg->quant_all != 0,
+                   fast && !getenv("ADH_DEBUG_NO_FUSED")};  // developer switches: two-kernel path only
 }
 
 // enqueue the plan of rows [row0, row0 + n) on `st`; plan_finish() waits for it
@@ -310,6 +311,7 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.top_k = cfg->top_k_fragments;
     p.fast_cfg = key.fast_cfg ? 1 : 0;
     p.quant_all = key.quant_all ? 1 : 0;
+    p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 3) ? 1 : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(adh_plan_init_kernel, dim3(1), dim3(1), 0, st, s.d_meta, p.I);
     const int64_t n_frames = im ? h->tims.n_frames : h->run.n_spectra;
@@ -317,7 +319,7 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.L = L;
     p.n_frames = n_frames;
     p.n_cyc_bins = (int32_t)std::min<int64_t>(n_frames / L + 2, 1 << 26);
-    // counting sort when the key space is small next to the batch (the usual case: 11 classes x
+    // counting sort when the key space is small next to the batch (the usual case: 18 classes x
     // cycles of the run); a stable radix sort otherwise
     const int64_t n_keys = (int64_t)ADH_N_CLASSES * p.n_cyc_bins;
     const bool counting = n_keys <= (1 << 22) && !getenv("ADH_DEBUG_PLAN_RADIX");
@@ -413,6 +415,7 @@ int plan_finish(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int
     p.top_k_fragments = key.top_k_fragments;
     p.top_k_isotopes = key.top_k_isotopes;
     p.fast_ok = key.fast_cfg;
+    p.fused_ok = key.fused_cfg;
     p.quant_all = key.quant_all;
     p.ready = true;
     return ADH_OK;
@@ -539,18 +542,23 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
     if (rc == ADH_OK) rc = get_event(h, &t.e2);
     if (rc != ADH_OK) return rc;
     const int32_t n_iso = h->cs.n_iso_cols;
+    int64_t n_fused = 0;  // classes of the fused kernel come first in processing order
+    for (int c = ADH_CLASS_FUSED0; c < ADH_CLASS_FAST2; ++c) n_fused += p.n_class[c];
     HIP_TRY(hipEventRecord(t.e0, st));
-    hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, h->run, h->d_lib, p.d_recs, *cfg,
-                       n_iso, d_scratch, *out, gcaps);
-    HIP_TRY(hipGetLastError());
+    if (p.n > n_fused) {
+        hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)(p.n - n_fused)), dim3(ADH_WAVE), g_lds, st, h->run, h->d_lib,
+                           p.d_recs + n_fused, *cfg, n_iso, d_scratch, *out, gcaps);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(t.e1, st));
-    if (stop_phase != 2) {
+    if (stop_phase != 2 || n_fused > 0) {
         int64_t n_fast = 0;
         for (int c = 0; c < ADH_CLASS_GENERIC; ++c) n_fast += p.n_class[c];
         bool forked = false;
-        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic"
-        const bool run_generic = !(only && only[0] == 'f'), run_fast = !(only && only[0] == 'g');
-        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic) {
+        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic" / "u" = fused kernels only
+        const bool run_generic = !(only && (only[0] == 'f' || only[0] == 'u')), run_fast = !(only && only[0] == 'g');
+        const bool fused_only = only && only[0] == 'u';
+        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic && stop_phase != 2) {
             // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
             hipStream_t gs = st;
             if (n_fast > 0) {
@@ -567,26 +575,37 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         const unsigned per_block = ADH_WAVE / ADH_GS;
         int64_t first = 0;
         for (int c = 0; c < ADH_CLASS_GENERIC; ++c) {
-            if (p.n_class[c] > 0 && run_fast) {
+            if (p.n_class[c] > 0 && run_fast && (c < ADH_CLASS_FAST2 || (stop_phase != 2 && !fused_only))) {
                 const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                 const CandRec *recs = p.d_recs + first;
                 const int32_t nc = (int32_t)p.n_class[c];
+#define ADH_LAUNCH_FUSED(FM)                                                                                  \
+    hipLaunchKernelGGL((adh_fused_kernel<FM>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, recs, nc, \
+                       h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
 #define ADH_LAUNCH_FAST(FM, NO)                                                                              \
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
                        nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
                 switch (c) {
-                    case 0: ADH_LAUNCH_FAST(8, 1); break;
-                    case 1: ADH_LAUNCH_FAST(12, 1); break;
-                    case 2: ADH_LAUNCH_FAST(16, 1); break;
-                    case 3: ADH_LAUNCH_FAST(20, 1); break;
-                    case 4: ADH_LAUNCH_FAST(24, 1); break;
-                    case 5: ADH_LAUNCH_FAST(28, 1); break;
-                    case 6: ADH_LAUNCH_FAST(32, 1); break;
-                    case 7: ADH_LAUNCH_FAST(16, 2); break;
-                    case 8: ADH_LAUNCH_FAST(24, 2); break;
-                    default: ADH_LAUNCH_FAST(32, 2); break;
+                    case ADH_CLASS_FUSED0 + 0: ADH_LAUNCH_FUSED(8); break;
+                    case ADH_CLASS_FUSED0 + 1: ADH_LAUNCH_FUSED(12); break;
+                    case ADH_CLASS_FUSED0 + 2: ADH_LAUNCH_FUSED(16); break;
+                    case ADH_CLASS_FUSED0 + 3: ADH_LAUNCH_FUSED(20); break;
+                    case ADH_CLASS_FUSED0 + 4: ADH_LAUNCH_FUSED(24); break;
+                    case ADH_CLASS_FUSED0 + 5: ADH_LAUNCH_FUSED(28); break;
+                    case ADH_CLASS_FUSED0 + 6: ADH_LAUNCH_FUSED(32); break;
+                    case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
+                    case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
+                    case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
+                    case ADH_CLASS_FAST1 + 0: ADH_LAUNCH_FAST(8, 1); break;
+                    case ADH_CLASS_FAST1 + 1: ADH_LAUNCH_FAST(12, 1); break;
+                    case ADH_CLASS_FAST1 + 2: ADH_LAUNCH_FAST(16, 1); break;
+                    case ADH_CLASS_FAST1 + 3: ADH_LAUNCH_FAST(20, 1); break;
+                    case ADH_CLASS_FAST1 + 4: ADH_LAUNCH_FAST(24, 1); break;
+                    case ADH_CLASS_FAST1 + 5: ADH_LAUNCH_FAST(28, 1); break;
+                    default: ADH_LAUNCH_FAST(32, 1); break;
                 }
 #undef ADH_LAUNCH_FAST
+#undef ADH_LAUNCH_FUSED
                 HIP_TRY(hipGetLastError());
             }
             first += p.n_class[c];
@@ -648,7 +667,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     Plan &p = h->plan;
     const PlanKey key = plan_key(cfg);
     if (!(p.ready && p.top_k_fragments == key.top_k_fragments && p.top_k_isotopes == key.top_k_isotopes &&
-          p.fast_ok == key.fast_cfg && p.quant_all == key.quant_all)) {
+          p.fast_ok == key.fast_cfg && p.fused_ok == key.fused_cfg && p.quant_all == key.quant_all)) {
         p = Plan();
         rc = plan_enqueue(h, h->slots[0], cfg, 0, h->cs.n, st);
         if (rc == ADH_OK) rc = plan_finish(h, h->slots[0], cfg, 0, h->cs.n, p);

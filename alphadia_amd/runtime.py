@@ -14,7 +14,7 @@ import numpy as np
 from alphadia_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalphadia_hip.so")
+LIB_PATH = os.environ.get("ADH_LIB_PATH") or os.path.join(_HERE, "libalphadia_hip.so")  # (developer switch: an experimental build)
 
 EXPORTED_SYMBOLS = [
     "adh_last_error",

@@ -1,0 +1,16 @@
+#!/bin/bash
+# instruction-cache and issue counters of the scoring kernels (gpurun, from the repo root)
+export TMPDIR=/tmp
+REPO=$PWD
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+rm -rf $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM -d $OUT/prof_pmc1 -o r3 -- $CMD > $OUT/prof_pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA -d $OUT/prof_pmc2 -o r3 -- $CMD > $OUT/prof_pmc2.log 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD -d $OUT/prof_pmc3 -o r3 -- $CMD > $OUT/prof_pmc3.log 2>&1
+for i in 1 2 3; do python $REPO/tools/rocpd_summary.py $OUT/prof_pmc$i/r3_results.db; done > $OUT/r3_pmc.csv
+tail -3 $OUT/prof_pmc3.log
+rm -rf $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3
+grep "fused_kernel<28>" $OUT/r3_pmc.csv | sed 's/(DevRun[^)]*)//; s/void //' | cut -c1-140
