@@ -123,7 +123,6 @@ struct adh_comm_state;
 struct adh_handle {
     int device = 0;
     hipStream_t stream = nullptr;        // compute
-    hipStream_t side_stream = nullptr;   // the generic feature kernel overlaps the register kernels
     hipStream_t stream_in = nullptr, stream_out = nullptr;  // H2D + plan / D2H of adh_score_candidates
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_k[2] = {nullptr, nullptr};  // kernels of the chunk that used plan slot s are done
@@ -216,7 +215,6 @@ int adh_create(adh_handle_t **handle, int device) {
     h->device = device;
     const char *what = "hipStreamCreate";
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking);
     if (e == hipSuccess) what = "hipEventCreate";
@@ -282,7 +280,6 @@ int adh_destroy(adh_handle_t *h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t e : h->ev_k)
         if (e) (void)hipEventDestroy(e);
-    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
     if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);

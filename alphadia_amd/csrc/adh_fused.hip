@@ -31,6 +31,19 @@
 
 #define ADH_FUSED_ISO0 12      // first isotope lane of a 16-lane group
 #define ADH_FUSED_NLIB 64      // longest library slice handled here
+#ifndef ADH_FUSED_WAVES
+#define ADH_FUSED_WAVES 3      // wavefronts per SIMD the register budget is held to
+#endif
+#ifndef ADH_FUSED_NT
+#define ADH_FUSED_NT 1         // gather tasks (cycle blocks) of a lane in flight (same-box A/B, fused kernels per 3 M
+                               // candidates: 1 -> 14.0 ms, 2 -> 14.9 ms, 3 -> 17.8 ms: registers, not loads in flight)
+#endif
+#ifndef ADH_FUSED_SCALAR
+#define ADH_FUSED_SCALAR 1     // developer switch: 0 skips the one-lane feature assembly (wrong results; what it costs)
+#endif
+#ifndef ADH_FUSED_EB
+#define ADH_FUSED_EB 4         // entries per step of a gather task (even)
+#endif
 
 namespace fused {
 
@@ -268,8 +281,8 @@ __device__ __forceinline__ void profile_stats(const float (&P)[FM], const float 
 // counts.  Four table words and two entries travel per load (they are neighbours in memory: 4- and 8-byte
 // aligned vector loads), and a lane only asks for entries it has: a scattered load costs the L1 one tag
 // look-up per lane and line, which is what this phase is bound by.
-constexpr int EB = 4;  // entries fetched per step
-constexpr int NT = 3;  // tasks (cycle blocks) of a lane in flight
+constexpr int EB = ADH_FUSED_EB;  // entries fetched per step
+constexpr int NT = ADH_FUSED_NT;  // tasks (cycle blocks) of a lane in flight
 struct __attribute__((packed, aligned(4))) Tab4 {
     uint32_t x, y, z, w;
 };
@@ -332,10 +345,14 @@ __device__ __forceinline__ void load2(const DevRun &run, uint32_t i, uint2 &a, u
 
 __device__ __forceinline__ void task_fetch(const DevRun &run, Task &k) {
     const uint32_t n = k.end - k.idx;  // (idx <= end)
-    if (n > 0) load2(run, k.idx, k.e[0], k.e[1]);
-    if (n > 2) load2(run, k.idx + 2, k.e[2], k.e[3]);
-    if (n > 4) load2(run, k.idx + 4, k.n[0], k.n[1]);
-    if (n > 6) load2(run, k.idx + 6, k.n[2], k.n[3]);
+#pragma unroll
+    for (int u = 0; u < EB; u += 2) {
+        if (n > (uint32_t)u) load2(run, k.idx + u, k.e[u], k.e[u + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < EB; u += 2) {
+        if (n > (uint32_t)(EB + u)) load2(run, k.idx + EB + u, k.n[u], k.n[u + 1]);
+    }
 }
 
 // cells: the lane's column of the tile, cells[r * TW] = centred row r; roff = FM/2 - F/2 - c0
@@ -359,8 +376,10 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
         }
         {
             const uint32_t left = end - idx;
-            if (left > 2 * EB) load2(run, idx + 2 * EB, k.n[0], k.n[1]);
-            if (left > 2 * EB + 2) load2(run, idx + 2 * EB + 2, k.n[2], k.n[3]);
+#pragma unroll
+            for (int u = 0; u < EB; u += 2) {
+                if (left > (uint32_t)(2 * EB + u)) load2(run, idx + 2 * EB + u, k.n[u], k.n[u + 1]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
@@ -391,20 +410,22 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
 
 }  // namespace fused
 
+// one wavefront = four candidates of a class with FM registers; `block` counts the wavefronts of the class
 template <int FM>
-__global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
-    DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, int32_t n_cand,
-    const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
-    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+__device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan,
+                                           int32_t n_cand, int32_t block, const float *__restrict__ iso_table,
+                                           int32_t n_iso_cols, const adh_scoring_config_t &cfg,
+                                           const double *__restrict__ wtp_table, const DevOut &out, int32_t stop_phase,
+                                           unsigned char *smem) {
     using namespace fused;
     using feat::Assemble;
     constexpr int RC = FM / 2;
-    __shared__ GroupLds<FM> lds[ADH_WAVE / GS];
+    GroupLds<FM> *lds = reinterpret_cast<GroupLds<FM> *>(smem);
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
     GroupLds<FM> &L = lds[g];
-    const int ci = blockIdx.x * (ADH_WAVE / GS) + g;
+    const int ci = block * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
     const CandRec &rec = plan[alive ? ci : 0];
     alive = alive && !(rec.flags & ADH_FLAG_SKIP);
@@ -420,6 +441,10 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
     const int shift = c - RC;  // f = r + shift
     const int I = alive ? min(n_iso_cols, (int)cfg.top_k_isotopes) : 0;
     const int top_k = out.top_k;
+    if (stop_phase == 19) {  // developer ablation (ADH_DEBUG_STOP_PHASE): launch + candidate record only
+        if (F == -12345) out.valid[row] = 2;
+        return;
+    }
 
     // ================= fragments: slice, cardinality filter, top-k by intensity, sort by m/z =========
     // (fragment_container.py:56-102; the tie rules of argsort()[::-1][:k] and of the stable argsort(mz))
@@ -458,6 +483,10 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
         cy1 = cy[1];
     }
     const int ms1_row = run.ms1_obs[0];
+    if (stop_phase == 20) {  // ... + library records and the other first-round loads
+        if (mine_int + rt_first + rt_last + loc + frt_l[0] + iso_int_l + (float)(cy0 + cy1) + (float)ms1_row == -12345.5f) out.valid[row] = 2;
+        return;
+    }
     int K0 = 0;
     if (!__any(n_lib > GS)) {
         // ---- every fragment of the slice has its lane: ranks by comparison with the 15 other lanes of
@@ -905,7 +934,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
 
     if (alive && sub < 4) Q.feat[sub] = loc;
     adh_wave_sync();
-    if (alive && sub == 0) {
+    if (ADH_FUSED_SCALAR && alive && sub == 0) {
         Assemble asmv;
         asmv.run = nullptr;  // features 0-3 are in place
         asmv.rec = &rec;
@@ -1001,7 +1030,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
         Q.red64[7 + sub] = s64;
     }
     adh_wave_sync();
-    if (alive && sub < 2) {
+    if (ADH_FUSED_SCALAR && alive && sub < 2) {
         // lane 0: feature 18 (areas), lane 1: feature 19 (heights)
         const double fact = fmax((double)K - 1.0, 0.0);
         const double inv = 1.0 / fact;
@@ -1013,7 +1042,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
         const bool on = sub ? (Q.red64[1] > 0.0) : (n_hrows > 0);
         if (on) Q.feat[18 + sub] = (float)cc;
     }
-    if (alive && sub == 0) {
+    if (ADH_FUSED_SCALAR && alive && sub == 0) {
         float *ft = Q.feat;
         ft[17] = (float)1;
         ft[20] = (float)((double)n_int / (double)K);
@@ -1175,7 +1204,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
         Q.red32[sub] = s32;
     }
     adh_wave_sync();
-    if (alive && sub == 0) {
+    if (ADH_FUSED_SCALAR && alive && sub == 0) {
         float *ft = Q.feat;
         ft[31] = (float)((double)Q.red32[0] / (double)K);
         ft[32] = (float)((double)Q.red32[5] / (double)n3);
@@ -1226,4 +1255,48 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_fused_kernel(
         }
         if (sub == 0) out.valid[row] = 1;
     }
+}
+
+// The classes of one batch in ONE launch: a launch drains the GPU at its end (a wavefront lives ~70 us) and
+// costs ~10 us to start, and a chunk of the host -> host pipeline has seven classes.  Wavefronts are ordered
+// by class (the plan is), so a compute unit runs one class at a time except at the six seams.
+struct FusedClasses {
+    int32_t first_block[8];  // first wavefront of class c (FM = 8 + 4 c); [7] = all
+    int32_t first_cand[7];   // first candidate of the class in the plan
+    int32_t n_cand[7];
+};
+constexpr size_t adh_fused_lds_bytes(int fm_max) {
+    return (fm_max > 28 ? sizeof(fused::GroupLds<32>) : sizeof(fused::GroupLds<28>)) * (ADH_WAVE / 16);
+}
+
+template <int FM_MAX>
+__global__ __launch_bounds__(ADH_WAVE, ADH_FUSED_WAVES) void adh_fused_kernel(
+    DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, FusedClasses fc,
+    const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
+    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes(FM_MAX)];
+    const int32_t b = (int32_t)blockIdx.x;
+    int c = 0;
+    while (c < 6 && b >= fc.first_block[c + 1]) ++c;
+    const CandRec *recs = plan + fc.first_cand[c];
+    const int32_t n = fc.n_cand[c], blk = b - fc.first_block[c];
+#define ADH_FUSED_CASE(C, FM)                                                                                  \
+    case C:                                                                                                    \
+        fused_body<FM>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
+        break;
+    if (FM_MAX > 28) {
+        fused_body<32>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
+    } else {
+        switch (c) {
+            ADH_FUSED_CASE(0, 8)
+            ADH_FUSED_CASE(1, 12)
+            ADH_FUSED_CASE(2, 16)
+            ADH_FUSED_CASE(3, 20)
+            ADH_FUSED_CASE(4, 24)
+            default:
+                fused_body<28>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
+                break;
+        }
+    }
+#undef ADH_FUSED_CASE
 }

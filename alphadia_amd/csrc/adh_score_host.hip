@@ -544,6 +544,9 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
     const int32_t n_iso = h->cs.n_iso_cols;
     int64_t n_fused = 0;  // classes of the fused kernel come first in processing order
     for (int c = ADH_CLASS_FUSED0; c < ADH_CLASS_FAST2; ++c) n_fused += p.n_class[c];
+    const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic" / "u" = fused kernels only
+    const bool run_generic = !(only && (only[0] == 'f' || only[0] == 'u')), run_fast = !(only && only[0] == 'g');
+    const bool fused_only = only && only[0] == 'u';
     HIP_TRY(hipEventRecord(t.e0, st));
     if (p.n > n_fused) {
         hipLaunchKernelGGL(adh_gather_kernel, dim3((unsigned)(p.n - n_fused)), dim3(ADH_WAVE), g_lds, st, h->run, h->d_lib,
@@ -551,66 +554,68 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(t.e1, st));
-    if (stop_phase != 2 || n_fused > 0) {
-        int64_t n_fast = 0;
-        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) n_fast += p.n_class[c];
-        bool forked = false;
-        const char *only = getenv("ADH_DEBUG_ONLY");  // developer switch: "fast" / "generic" / "u" = fused kernels only
-        const bool run_generic = !(only && (only[0] == 'f' || only[0] == 'u')), run_fast = !(only && only[0] == 'g');
-        const bool fused_only = only && only[0] == 'u';
-        if (p.n_class[ADH_CLASS_GENERIC] > 0 && run_generic && stop_phase != 2) {
-            // the generic kernel (rare shapes, LDS heavy) runs beside the register kernels
-            hipStream_t gs = st;
-            if (n_fast > 0) {
-                HIP_TRY(hipEventRecord(h->ev_fork, st));
-                HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-                gs = h->side_stream;
-                forked = true;
-            }
-            hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[ADH_CLASS_GENERIC]), dim3(ADH_WAVE), f_lds, gs,
-                               h->run, p.d_recs + n_fast, h->cs.iso, n_iso, *cfg, d_scratch, *out, p.caps_generic);
-            HIP_TRY(hipGetLastError());
-            if (forked) HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+    const unsigned per_block = ADH_WAVE / ADH_GS;
+    if (n_fused > 0 && run_fast) {
+        // the fused classes FM = 8 ... 28 in one launch, FM = 32 (more LDS) in a second one
+        FusedClasses fc{};
+        int64_t first = 0, blocks = 0;
+        for (int c = 0; c < 6; ++c) {
+            fc.first_block[c] = (int32_t)blocks;
+            fc.first_cand[c] = (int32_t)first;
+            fc.n_cand[c] = (int32_t)p.n_class[ADH_CLASS_FUSED0 + c];
+            blocks += (p.n_class[ADH_CLASS_FUSED0 + c] + per_block - 1) / per_block;
+            first += p.n_class[ADH_CLASS_FUSED0 + c];
         }
-        const unsigned per_block = ADH_WAVE / ADH_GS;
-        int64_t first = 0;
-        for (int c = 0; c < ADH_CLASS_GENERIC; ++c) {
-            if (p.n_class[c] > 0 && run_fast && (c < ADH_CLASS_FAST2 || (stop_phase != 2 && !fused_only))) {
-                const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
+        fc.first_block[6] = fc.first_block[7] = (int32_t)blocks;
+        if (blocks > 0) {
+            hipLaunchKernelGGL((adh_fused_kernel<28>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, p.d_recs,
+                               fc, h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);
+            HIP_TRY(hipGetLastError());
+        }
+        const int64_t n32 = p.n_class[ADH_CLASS_FUSED0 + 6];
+        if (n32 > 0) {
+            FusedClasses f32c{};
+            const int64_t b32 = (n32 + per_block - 1) / per_block;
+            for (int c = 1; c < 8; ++c) f32c.first_block[c] = (int32_t)b32;
+            f32c.first_cand[0] = (int32_t)first;
+            f32c.n_cand[0] = (int32_t)n32;
+            hipLaunchKernelGGL((adh_fused_kernel<32>), dim3((unsigned)b32), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, p.d_recs,
+                               f32c, h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (stop_phase != 2 && !fused_only) {
+        int64_t first = n_fused;
+        for (int c = ADH_CLASS_FAST2; c <= ADH_CLASS_GENERIC; ++c) {
+            if (p.n_class[c] > 0 && (c == ADH_CLASS_GENERIC ? run_generic : run_fast)) {
                 const CandRec *recs = p.d_recs + first;
-                const int32_t nc = (int32_t)p.n_class[c];
-#define ADH_LAUNCH_FUSED(FM)                                                                                  \
-    hipLaunchKernelGGL((adh_fused_kernel<FM>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, recs, nc, \
-                       h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
+                if (c == ADH_CLASS_GENERIC) {
+                    hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[c]), dim3(ADH_WAVE), f_lds, st, h->run, recs,
+                                       h->cs.iso, n_iso, *cfg, d_scratch, *out, p.caps_generic);
+                } else {
+                    const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
+                    const int32_t nc = (int32_t)p.n_class[c];
 #define ADH_LAUNCH_FAST(FM, NO)                                                                              \
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
                        nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
-                switch (c) {
-                    case ADH_CLASS_FUSED0 + 0: ADH_LAUNCH_FUSED(8); break;
-                    case ADH_CLASS_FUSED0 + 1: ADH_LAUNCH_FUSED(12); break;
-                    case ADH_CLASS_FUSED0 + 2: ADH_LAUNCH_FUSED(16); break;
-                    case ADH_CLASS_FUSED0 + 3: ADH_LAUNCH_FUSED(20); break;
-                    case ADH_CLASS_FUSED0 + 4: ADH_LAUNCH_FUSED(24); break;
-                    case ADH_CLASS_FUSED0 + 5: ADH_LAUNCH_FUSED(28); break;
-                    case ADH_CLASS_FUSED0 + 6: ADH_LAUNCH_FUSED(32); break;
-                    case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
-                    case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
-                    case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
-                    case ADH_CLASS_FAST1 + 0: ADH_LAUNCH_FAST(8, 1); break;
-                    case ADH_CLASS_FAST1 + 1: ADH_LAUNCH_FAST(12, 1); break;
-                    case ADH_CLASS_FAST1 + 2: ADH_LAUNCH_FAST(16, 1); break;
-                    case ADH_CLASS_FAST1 + 3: ADH_LAUNCH_FAST(20, 1); break;
-                    case ADH_CLASS_FAST1 + 4: ADH_LAUNCH_FAST(24, 1); break;
-                    case ADH_CLASS_FAST1 + 5: ADH_LAUNCH_FAST(28, 1); break;
-                    default: ADH_LAUNCH_FAST(32, 1); break;
-                }
+                    switch (c) {
+                        case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
+                        case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
+                        case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
+                        case ADH_CLASS_FAST1 + 0: ADH_LAUNCH_FAST(8, 1); break;
+                        case ADH_CLASS_FAST1 + 1: ADH_LAUNCH_FAST(12, 1); break;
+                        case ADH_CLASS_FAST1 + 2: ADH_LAUNCH_FAST(16, 1); break;
+                        case ADH_CLASS_FAST1 + 3: ADH_LAUNCH_FAST(20, 1); break;
+                        case ADH_CLASS_FAST1 + 4: ADH_LAUNCH_FAST(24, 1); break;
+                        case ADH_CLASS_FAST1 + 5: ADH_LAUNCH_FAST(28, 1); break;
+                        default: ADH_LAUNCH_FAST(32, 1); break;
+                    }
 #undef ADH_LAUNCH_FAST
-#undef ADH_LAUNCH_FUSED
+                }
                 HIP_TRY(hipGetLastError());
             }
             first += p.n_class[c];
         }
-        if (forked) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     }
     HIP_TRY(hipEventRecord(t.e2, st));
     h->timed.push_back(t);
