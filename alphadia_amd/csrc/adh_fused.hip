@@ -23,16 +23,21 @@
 //     float64 divisions by a common divisor through one shared reciprocal refinement
 //   * LDS is one union per candidate: selection scratch -> tile -> feature arrays
 //
-// Eligibility (adh_plan_rec_kernel): one observation, 3 <= F <= 32, k_cap <= 12, I <= 3, library slice
+// Eligibility (adh_plan_rec_kernel): one or two observations, 3 <= F <= 32, k_cap <= 12, I <= 3, library slice
 // of at most 64 fragments, experimental_xic = True, a single MS1 row per cycle.  Everything else runs
 // through the two-kernel path.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
+#include <type_traits>
+
 #define ADH_FUSED_ISO0 12      // first isotope lane of a 16-lane group
 #define ADH_FUSED_NLIB 64      // longest library slice handled here
 #ifndef ADH_FUSED_WAVES
 #define ADH_FUSED_WAVES 3      // wavefronts per SIMD the register budget is held to
+#endif
+#ifndef ADH_FUSED_WAVES2
+#define ADH_FUSED_WAVES2 3     // ... of the two-observation kernels
 #endif
 #ifndef ADH_FUSED_NT
 #define ADH_FUSED_NT 1         // gather tasks (cycle blocks) of a lane in flight (same-box A/B, fused kernels per 3 M
@@ -81,7 +86,18 @@ __device__ __forceinline__ int rec_type(const RawRec &r) { return (int)(r.a.w & 
 __device__ __forceinline__ int rec_position(const RawRec &r) { return (int)(r.b & 0xFFu); }
 __device__ __forceinline__ int rec_cardinality(const RawRec &r) { return (int)((r.b >> 8) & 0xFFu); }
 
-template <int FM>
+// What a candidate keeps in LDS across the gather of its second observation (which takes the tile = the
+// union below): with one observation these arrays live inside the union's feature part, at no cost
+template <int FM, int NO>
+struct __attribute__((aligned(16))) Keep {
+    double hp[4], omzp[4];
+    float frt[FM];             // frame RTs, centred
+    float tpl_next[FM];        // template row of the observation still to come
+    float iso_mz[4], iso_int[4], spi[4];
+};
+struct __attribute__((aligned(16))) NoKeep {};
+
+template <int FM, int NO>
 struct __attribute__((aligned(16))) GroupLds {
     union {
         struct {  // fragment selection
@@ -102,20 +118,23 @@ struct __attribute__((aligned(16))) GroupLds {
             } u;
             double wt[2][FM];  // [scan slot][centred cycle]: exp weights around the template centre
             double merr[16];
-            double hp[4], omzp[4], qtf[4];
             double red64[12];
-            float tpl[FM], tfp[FM], frt[FM], med[FM];
+            float tpl[FM], tfp[FM], med[FM];
             float g_int[16], g_fin[16], corr[16];
-            float ftc[16], fw[16];
-            int fpeak[16];
-            float iso_mz[4], iso_int[4], spi[4];
-            float oi[1], tsum[1];
+            int fpeak[16][NO];
+            float oi[NO];
             float red32[8];
             float feat[ADH_NUM_FEATURES + 2];
             int ord[16];
-            int medlo, medhi;
+            int medlo[NO], medhi[NO];
+            typename std::conditional<NO == 1, Keep<FM, NO>, NoKeep>::type keep1;
         } f;
     } u;
+    typename std::conditional<NO == 1, NoKeep, Keep<FM, NO>>::type keep2;
+    __device__ __forceinline__ Keep<FM, NO> &keep() {
+        if constexpr (NO == 1) return u.f.keep1;
+        else return keep2;
+    }
 };
 
 #define FU_OPAQUE(x) __asm__ volatile("" : "+v"(x))
@@ -408,10 +427,38 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
     if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
 }
 
+// one gather pass of a candidate: every lane with a window folds the peaks of its (window, cycle row) into
+// its column of the zeroed tile, cycle block after cycle block
+template <int FM>
+__device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb, bool task_on, int task_row, bool alive,
+                                            int c0, int F, float2 (*tile)[TW], int sub, uint32_t &hits) {
+    {
+        float4 *z = reinterpret_cast<float4 *>(&tile[0][0]);
+        constexpr int N4 = FM * TW / 2;
+#pragma unroll
+        for (int j = 0; j < (N4 + GS - 1) / GS; ++j)
+            if (j * GS + sub < N4) z[j * GS + sub] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const int bs = run.block_shift;
+    const int blk0 = c0 >> bs;
+    const int n_blk = alive ? ((c0 + F - 1) >> bs) - blk0 + 1 : 0;
+    float2 *cells = &tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
+    const int roff = FM / 2 - F / 2 - c0;       // centred row of absolute cycle x: x + roff
+    for (int bb = 0; __any(bb < n_blk); bb += NT) {
+        Task t[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, t[u]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) task_fetch(run, t[u]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) task_run(run, wb, t[u], cells, roff, hits);
+    }
+}
+
 }  // namespace fused
 
 // one wavefront = four candidates of a class with FM registers; `block` counts the wavefronts of the class
-template <int FM>
+template <int FM, int NO>
 __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan,
                                            int32_t n_cand, int32_t block, const float *__restrict__ iso_table,
                                            int32_t n_iso_cols, const adh_scoring_config_t &cfg,
@@ -420,11 +467,12 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     using namespace fused;
     using feat::Assemble;
     constexpr int RC = FM / 2;
-    GroupLds<FM> *lds = reinterpret_cast<GroupLds<FM> *>(smem);
+    GroupLds<FM, NO> *lds = reinterpret_cast<GroupLds<FM, NO> *>(smem);
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
-    GroupLds<FM> &L = lds[g];
+    GroupLds<FM, NO> &L = lds[g];
+    Keep<FM, NO> &KP = L.keep();
     const int ci = block * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
     const CandRec &rec = plan[alive ? ci : 0];
@@ -475,16 +523,21 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     const bool iso_lane = alive && sub >= ISO0 && sub - ISO0 < I;
     const int il = iso_lane ? sub - ISO0 : 0;
     float iso_int_l = 0.0f;
-    double cy0 = 0.0, cy1 = 1.0;
+    double cy0[NO], cy1[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) cy0[o] = 0.0, cy1[o] = 1.0;
     if (iso_lane) {
         iso_int_l = iso_table[(int64_t)row * n_iso_cols + il];
-        const double *cy = run.cycle + 2 * ((int64_t)rec.obs[0] * run.cycle_scans + rec.scan_start);
-        cy0 = cy[0];
-        cy1 = cy[1];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const double *cy = run.cycle + 2 * ((int64_t)rec.obs[o] * run.cycle_scans + rec.scan_start);
+            cy0[o] = cy[0];
+            cy1[o] = cy[1];
+        }
     }
     const int ms1_row = run.ms1_obs[0];
     if (stop_phase == 20) {  // ... + library records and the other first-round loads
-        if (mine_int + rt_first + rt_last + loc + frt_l[0] + iso_int_l + (float)(cy0 + cy1) + (float)ms1_row == -12345.5f) out.valid[row] = 2;
+        if (mine_int + rt_first + rt_last + loc + frt_l[0] + iso_int_l + (float)(cy0[0] + cy1[0]) + (float)ms1_row == -12345.5f) out.valid[row] = 2;
         return;
     }
     int K0 = 0;
@@ -620,235 +673,260 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     const WinBits wb = win_bits(w);
 
     // ================= gather: every lane its window, into its column of the tile =================
-    {
-        float4 *z = reinterpret_cast<float4 *>(&L.u.tile[0][0]);
-        constexpr int N4 = FM * TW / 2;
-#pragma unroll
-        for (int j = 0; j < (N4 + GS - 1) / GS; ++j)
-            if (j * GS + sub < N4) z[j * GS + sub] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
     uint32_t hits = 0;
-    {
-        const int bs = run.block_shift;
-        const int blk0 = c0 >> bs;
-        const int n_blk = alive ? ((c0 + F - 1) >> bs) - blk0 + 1 : 0;
-        float2 *cells = &L.u.tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
-        const int roff = RC - c - c0;  // centred row of absolute cycle x: x + roff
-        for (int bb = 0; __any(bb < n_blk); bb += NT) {
-            Task t[NT];
+    gather_pass<FM>(run, wb, task_on, task_row, alive, c0, F, L.u.tile, sub, hits);
+    // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1; the isotope lanes
+    double qtf_l[NO];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, t[u]);
-#pragma unroll
-            for (int u = 0; u < NT; ++u) task_fetch(run, t[u]);
-            if (stop_phase == 22) {  // developer ablation: table and first entry loads only
-                uint32_t x = 0;
-#pragma unroll
-                for (int u = 0; u < NT; ++u) x += t[u].e[0].x + t[u].e[EB - 1].y;
-                if (x == 0xFFFFFFF1u) out.valid[row] = 2;
-                continue;
-            }
-#pragma unroll
-            for (int u = 0; u < NT; ++u) task_run(run, wb, t[u], cells, roff, hits);
+    for (int o = 0; o < NO; ++o) {
+        qtf_l[o] = 0.0;
+        if (iso_lane) {
+            const double x = (double)iso_mz_l;
+            qtf_l[o] = logistic(x, cy0[o], 0.2) - logistic(x, cy1[o], 0.2);
         }
     }
-    if (stop_phase == 22) return;
-    // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1; the isotope lanes
-    double qtf_l = 0.0;
-    if (iso_lane) {
-        const double x = (double)iso_mz_l;
-        qtf_l = logistic(x, cy0, 0.2) - logistic(x, cy1, 0.2);
-    }
     // qtf mask of the fragment tile (candidate.py:287-289): mean over the isotopes, in order
-    float qmask;
-    {
+    float qmask[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
         double qs = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const double qi = __shfl(qtf_l, (int)gsh + ISO0 + i);
+            const double qi = __shfl(qtf_l[o], (int)gsh + ISO0 + i);
             if (i < I) qs += qi;
         }
-        qmask = (I > 0) ? (float)(qs / (double)I) : 0.0f;
+        qmask[o] = (I > 0) ? (float)(qs / (double)I) : 0.0f;
     }
+    if (stop_phase == 2) return;
+
+    float A[FM], B[FM];
+    float P[FM];  // frame profile summed over the observations (frame_profile_2d + sum over o)
+    auto &Q = L.u.f;
+    const float rt_width = rt_last - rt_first;
+    if (sub == 1) loc = rt_width;
+    float tsum[NO], rowsum_l[NO], ftc_l[NO], fw_l[NO];
+    double ohe_l[NO], omz_l[NO];
+    int fpeak_l[NO];
+    float so = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        if (o > 0) {
+            // the next observation: only the fragment lanes gather (cycle row obs[o]); the tile takes the
+            // place of the feature arrays, what has to survive sits in KP
+            adh_wave_sync();
+            gather_pass<FM>(run, wb, task_on && !iso_lane, (int)rec.obs[o], alive, c0, F, L.u.tile, sub, hits);
+        }
+        // ================= rows into registers (the tile is dead afterwards) =================
+        {
+            const float2 *col = &L.u.tile[0][min(sub, TW - 1)];
+            const float mq = iso_lane ? 1.0f : qmask[o];  // candidate.py:290 (fragments only)
+            FU_FOR_R {
+                const float2 v = col[r * TW];
+                A[r] = v.x * mq;
+                B[r] = v.y;
+            }
+            if (o == 0 && iso_lane) {
+                // MS1 observation collapse (candidate.py:248-269) with ONE MS1 row per cycle: the sum over the
+                // single observation is the value itself, the mean m/z is y / (count + 1e-6) with count = 1
+                // where y > 0 (y is a weighted mean of m/z values: positive or an untouched 0 = 0 / 1e-6)
+                const Recip one(1.0 + 1e-6);
+                FU_FOR_R {
+                    const float b = B[r];
+                    B[r] = (b > 0.0f) ? (float)one.div((double)b) : b;
+                }
+            }
+        }
+        adh_wave_sync();
+        if (o == 0) {
+#pragma unroll
+            for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+                const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+                KP.frt[r] = frt_l[pass];
+            }
+            // ---- isotope lanes: template rows of every observation (quadrupole.py:304-324)
+            if (iso_lane) {
+                KP.iso_mz[il] = iso_mz_l;
+                KP.iso_int[il] = iso_int_l;
+            }
+#pragma unroll
+            for (int oo = 0; oo < NO; ++oo) {
+                if (iso_lane) {
+                    FU_FOR_R {
+                        const float a = A[r] * iso_int_l;
+                        Q.u.dT[il][r] = (double)a * qtf_l[oo];
+                    }
+                }
+                adh_wave_sync();
+#pragma unroll
+                for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+                    const int r = sub + 16 * pass;
+                    if (r < FM) {
+                        double acc = 0;
+                        for (int i = 0; i < I; ++i) acc += Q.u.dT[i][r];
+                        if (oo == 0) Q.tpl[r] = (float)acc;  // zero outside [0, F)
+                        else KP.tpl_next[r] = (float)acc;
+                    }
+                }
+                adh_wave_sync();
+            }
+            // precursor weights exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)) around the expected centre (S, 1) of
+            // precursor_features.py:52-57, centred and masked like the fragments' table below
+#pragma unroll
+            for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
+                const int idx = min(sub + 16 * pass, 2 * FM - 1);
+                const int sc = idx / FM, r = idx - sc * FM;
+                const int f = r + shift;
+                const bool ok = alive && f >= 0 && f < F;
+                Q.u.wti[sc][r] = ok ? wtp_table[sc * 64 + f] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+                const int r = min(sub + 16 * pass, FM - 1);
+                Q.tpl[r] = KP.tpl_next[r];
+            }
+            adh_wave_sync();
+        }
+        if (stop_phase == 31) return;
+        // observation importance (quadrupole.py:327-335): template sum of this observation
+        {
+            float st = 0.0f;
+            FU_FOR_R {
+                st += Q.tpl[r];
+                FU_FENCE(r);
+            }
+            tsum[o] = st + st;
+        }
+        // ---- template centre of mass (fragment_features.py:20-68; every lane computes it), template frame
+        // profile, weights around the centre
+        double esc, efc;
+        {
+            double isum = 0, ssum = 0, fsum = 0;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+            for (int sc = 0; sc < 2; ++sc) {
+                const double scd = (double)sc;
+                FU_FOR_R {
+                    float v = Q.tpl[r];
+                    v = (v > 0.0f) ? v : 0.0f;  // the reference skips v <= 0; adding +0 is the same
+                    const double vd = (double)v;
+                    isum += vd;
+                    ssum += scd * vd;
+                    fsum += (double)(r + shift) * vd;
+                    FU_FENCE(r);
+                }
+            }
+            esc = (isum > 0) ? ssum / isum : 0.0;
+            efc = (isum > 0) ? fsum / isum : 0.0;
+        }
+        // template frame profile with or_envelope (scoring/utils.py:46-53)
+#pragma unroll
+        for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+            const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+            const int f = r + shift;
+            const bool ok = alive && f >= 0 && f < F;
+            const float x = Q.tpl[r] + Q.tpl[r];
+            float rr = x;
+            if (ok && f >= 1 && f < F - 1) {
+                const float xl = Q.tpl[r - 1] + Q.tpl[r - 1];
+                const float xr = Q.tpl[r + 1] + Q.tpl[r + 1];
+                if (x < xl || x < xr) {
+                    const float sm = xl + xr;
+                    rr = sm * 0.5f;  // (float)((double)sm / 2): exact either way
+                }
+            }
+            Q.tfp[r] = ok ? rr : 0.0f;
+        }
+        // weight table around the template centre (features_utils.py:9-25), centred index
+#pragma unroll
+        for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
+            const int idx = min(sub + 16 * pass, 2 * FM - 1);
+            const int sc = idx / FM, r = idx - sc * FM;
+            const int f = r + shift;
+            const bool ok = alive && f >= 0 && f < F;
+            double wv = 0.0;
+            if (ok) {
+                const double ds = (double)sc - esc, df = (double)f - efc;
+                wv = exp(-0.1 * sqrt(ds * ds + df * df));
+            }
+            Q.wt[sc][r] = wv;
+        }
+        adh_wave_sync();
+        if (stop_phase == 32) return;
+
+        // ================= row sums and weighted centre means: fragments and isotopes together =========
+        // presence (candidate.py:319-329) / sum_precursor_intensity: row sum over the two identical scan slots
+        float sf = 0.0f;
+        FU_FOR_R sf += A[r];
+        const float ss = sf + sf;
+        // weighted centre means of both channels (features_utils.py:9-37; precursor_features.py:52-66).
+        // A skipped cell (value <= 0) adds nothing: its product is +0, only its weight has to stay out.
+        double m_int, m_mz;
+        {
+            const double *wrow = (o == 0 && iso_lane) ? &Q.u.wti[0][0] : &Q.wt[0][0];
+            double vo = 0, wo = 0, vm = 0, wm = 0;
+#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
+            for (int sc = 0; sc < 2; ++sc) {
+                FU_FOR_R {
+                    const double wv = wrow[sc * FM + r];
+                    float a = A[r], b = B[r];
+                    FU_OPAQUE(a);
+                    FU_OPAQUE(b);
+                    vo += (double)a * wv;
+                    if (a > 0.0f) wo += wv;
+                    vm += (double)b * wv;
+                    if (b > 0.0f) wm += wv;
+                    FU_FENCE(r);
+                }
+            }
+            m_int = (wo > 0) ? vo / wo : 0.0;
+            m_mz = (wm > 0) ? vm / wm : 0.0;
+        }
+        if (o == 0 && iso_lane) {
+            KP.spi[il] = ss;
+            KP.hp[il] = m_int;
+            KP.omzp[il] = m_mz;
+        }
+        ohe_l[o] = frag_lane0 ? m_int : 0.0;
+        omz_l[o] = frag_lane0 ? m_mz : 0.0;
+        rowsum_l[o] = frag_lane0 ? ss : 0.0f;
+        so += rowsum_l[o];
+        if (NO > 1) {
+            // per-observation frame profile (frame_profile_2d): statistics against this observation's
+            // template.  With one observation they are taken after the envelope step, whose in-place edit
+            // they must see when quant_all is off.
+            FU_FOR_R A[r] = frag_lane0 ? A[r] + A[r] : 0.0f;
+            profile_stats<FM>(A, Q.tfp, F, shift, rt_width, ftc_l[o], fw_l[o], fpeak_l[o]);
+            if (o == 0) {
+                FU_FOR_R P[r] = A[r];  // (0 + x for x >= +0)
+            } else {
+                FU_FOR_R P[r] += A[r];
+            }
+        } else {
+            FU_FOR_R P[r] = frag_lane0 ? A[r] + A[r] : 0.0f;
+        }
+    }
+    // (nothing of Q written above is read below: from here on the feature arrays are rebuilt)
 #pragma unroll
     for (int m = 8; m > 0; m >>= 1) hits += __shfl_xor(hits, m, GS);
     if (alive && sub == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = hits;
-    if (stop_phase == 2) return;
-
-    // ================= rows into registers (the tile is dead afterwards) =================
-    float A[FM], B[FM];
-    {
-        const float2 *col = &L.u.tile[0][min(sub, TW - 1)];
-        const float mq = iso_lane ? 1.0f : qmask;  // candidate.py:290 (fragments only)
-        FU_FOR_R {
-            const float2 v = col[r * TW];
-            A[r] = v.x * mq;
-            B[r] = v.y;
-        }
-        if (iso_lane) {
-            // MS1 observation collapse (candidate.py:248-269) with ONE MS1 row per cycle: the sum over the
-            // single observation is the value itself, the mean m/z is y / (count + 1e-6) with count = 1
-            // where y > 0 (y is a weighted mean of m/z values: positive or an untouched 0 = 0 / 1e-6)
-            const Recip one(1.0 + 1e-6);
-            FU_FOR_R {
-                const float b = B[r];
-                B[r] = (b > 0.0f) ? (float)one.div((double)b) : b;
-            }
-        }
-    }
     adh_wave_sync();
-    auto &Q = L.u.f;
-    const float rt_width = rt_last - rt_first;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
         if (sub + 16 * j < ADH_NUM_FEATURES + 2) Q.feat[sub + 16 * j] = 0.0f;
-    if (sub == 1) loc = rt_width;
-#pragma unroll
-    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-        const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
-        Q.frt[r] = frt_l[pass];
-    }
-    // ---- isotope lanes: template contributions (quadrupole.py:304-324), precursor weights around the
-    // expected centre (S, 1) of precursor_features.py:52-57
-    if (iso_lane) {
-        Q.qtf[il] = qtf_l;
-        Q.iso_mz[il] = iso_mz_l;
-        Q.iso_int[il] = iso_int_l;
-        FU_FOR_R {
-            const float a = A[r] * iso_int_l;
-            Q.u.dT[il][r] = (double)a * qtf_l;
-        }
-    }
-    adh_wave_sync();
-#pragma unroll
-    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-        const int r = sub + 16 * pass;
-        if (r < FM) {
-            double acc = 0;
-            for (int i = 0; i < I; ++i) acc += Q.u.dT[i][r];
-            Q.tpl[r] = (float)acc;  // zero outside [0, F)
-        }
-    }
-    adh_wave_sync();
-    // precursor weights exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)) around the expected centre (S, 1) of
-    // precursor_features.py:52-57, centred and masked like the fragments' table below
-#pragma unroll
-    for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
-        const int idx = min(sub + 16 * pass, 2 * FM - 1);
-        const int sc = idx / FM, r = idx - sc * FM;
-        const int f = r + shift;
-        const bool ok = alive && f >= 0 && f < F;
-        Q.u.wti[sc][r] = ok ? wtp_table[sc * 64 + f] : 0.0;
-    }
-    if (stop_phase == 31) return;
     // observation importance (quadrupole.py:327-335)
+    float oi[NO];
     {
-        float st = 0.0f;
-        FU_FOR_R {
-            st += Q.tpl[r];
-            FU_FENCE(r);
-        }
-        const float ts = st + st;
-        const float tot = 0.0f + ts;
-        if (sub == 0) {
-            Q.tsum[0] = ts;
-            Q.oi[0] = (tot == 0.0f) ? 1.0f / 1.0f : ts / tot;
-        }
-    }
-    // ---- template centre of mass (fragment_features.py:20-68; every lane computes it), template frame
-    // profile, weights around the centre
-    double esc, efc;
-    {
-        double isum = 0, ssum = 0, fsum = 0;
-#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
-        for (int sc = 0; sc < 2; ++sc) {
-            const double scd = (double)sc;
-            FU_FOR_R {
-                float v = Q.tpl[r];
-                v = (v > 0.0f) ? v : 0.0f;  // the reference skips v <= 0; adding +0 is the same
-                const double vd = (double)v;
-                isum += vd;
-                ssum += scd * vd;
-                fsum += (double)(r + shift) * vd;
-                FU_FENCE(r);
-            }
-        }
-        esc = (isum > 0) ? ssum / isum : 0.0;
-        efc = (isum > 0) ? fsum / isum : 0.0;
-    }
-    // template frame profile with or_envelope (scoring/utils.py:46-53)
+        float tot = 0.0f;
 #pragma unroll
-    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-        const int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
-        const int f = r + shift;
-        const bool ok = alive && f >= 0 && f < F;
-        const float x = Q.tpl[r] + Q.tpl[r];
-        float rr = x;
-        if (ok && f >= 1 && f < F - 1) {
-            const float xl = Q.tpl[r - 1] + Q.tpl[r - 1];
-            const float xr = Q.tpl[r + 1] + Q.tpl[r + 1];
-            if (x < xl || x < xr) {
-                const float sm = xl + xr;
-                rr = sm * 0.5f;  // (float)((double)sm / 2): exact either way
-            }
-        }
-        Q.tfp[r] = ok ? rr : 0.0f;
-    }
-    // weight table around the template centre (features_utils.py:9-25), centred index
+        for (int o = 0; o < NO; ++o) tot += tsum[o];
 #pragma unroll
-    for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
-        const int idx = min(sub + 16 * pass, 2 * FM - 1);
-        const int sc = idx / FM, r = idx - sc * FM;
-        const int f = r + shift;
-        const bool ok = alive && f >= 0 && f < F;
-        double wv = 0.0;
-        if (ok) {
-            const double ds = (double)sc - esc, df = (double)f - efc;
-            wv = exp(-0.1 * sqrt(ds * ds + df * df));
+        for (int o = 0; o < NO; ++o) {
+            oi[o] = (tot == 0.0f) ? 1.0f / (float)NO : tsum[o] / tot;
+            if (sub == 0) Q.oi[o] = oi[o];
         }
-        Q.wt[sc][r] = wv;
     }
-    adh_wave_sync();
-    if (stop_phase == 32) return;
-
-    // ================= row sums and weighted centre means: fragments and isotopes together =========
-    // presence (candidate.py:319-329) / sum_precursor_intensity: row sum over the two identical scan slots
-    float sf = 0.0f;
-    FU_FOR_R sf += A[r];
-    const float ss = sf + sf;
-    // weighted centre means of both channels (features_utils.py:9-37; precursor_features.py:52-66).
-    // A skipped cell (value <= 0) adds nothing: its product is +0, only its weight has to stay out.
-    double m_int, m_mz;
-    {
-        const double *wrow = iso_lane ? &Q.u.wti[0][0] : &Q.wt[0][0];
-        double vo = 0, wo = 0, vm = 0, wm = 0;
-#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
-        for (int sc = 0; sc < 2; ++sc) {
-            FU_FOR_R {
-                const double wv = wrow[sc * FM + r];
-                float a = A[r], b = B[r];
-                FU_OPAQUE(a);
-                FU_OPAQUE(b);
-                vo += (double)a * wv;
-                if (a > 0.0f) wo += wv;
-                vm += (double)b * wv;
-                if (b > 0.0f) wm += wv;
-                FU_FENCE(r);
-            }
-        }
-        m_int = (wo > 0) ? vo / wo : 0.0;
-        m_mz = (wm > 0) ? vm / wm : 0.0;
-    }
-    if (iso_lane) {
-        Q.spi[il] = ss;
-        Q.hp[il] = m_int;
-        Q.omzp[il] = m_mz;
-    }
-    const double ohe_l = frag_lane0 ? m_int : 0.0, omz_l = frag_lane0 ? m_mz : 0.0;
-    const float rowsum_l = frag_lane0 ? ss : 0.0f;
-    float P[FM];  // frame profile (frame_profile_2d: sum over the two scan slots)
-    FU_FOR_R P[r] = frag_lane0 ? A[r] + A[r] : 0.0f;
     if (stop_phase == 33) return;
-    bool present = frag_lane0 && rowsum_l > 0.0f;
+    bool present = frag_lane0 && so > 0.0f;
     const unsigned long long bal = __ballot(present);
     const unsigned gm = (unsigned)((bal >> gsh) & 0xFFFFull);
     int K = __popc(gm);
@@ -894,31 +972,52 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         for (int r = 1; r < FM - 1; ++r) {
             const bool in = r >= RC - qw && r + 1 <= RC + qw;
             const float sm = E[r + 1] + E[r];
-            const float drt = Q.frt[r + 1] - Q.frt[r];
+            const float drt = KP.frt[r + 1] - KP.frt[r];
             const float m = sm * drt;
             ar += in ? (double)m * 0.5 : 0.0;
         }
         area = ar * (double)qw;
         FU_FOR_R obs_int += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
-        if (!cfg.quant_all) {
+        if (NO == 1 && !cfg.quant_all) {
             FU_FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
         }
     }
     double m1 = 0.0, m2 = 0.0, merr_l = 0.0;
     bool hrow = false;
     if (present) {
-        // importance-weighted means over observations (fragment_features.py:311-336), one observation
-        const float oi0 = Q.oi[0];
-        const bool m = ohe_l > 0;
-        hrow = m;
-        const float w32 = m ? oi0 : oi0 * 0.0f;
-        const float ws = 0.0f + w32;
-        const double wd = (double)w32 / ((double)ws + 1e-20);
-        if (wd > 0) {
-            const double msum = 0.0 + wd;
-            const double lw = wd / msum;
-            m1 += omz_l * lw;
-            m2 += ohe_l * lw;
+        // importance-weighted means over observations (fragment_features.py:311-336)
+        float ws = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const bool m = ohe_l[o] > 0;
+            hrow = hrow || m;
+            const float w32 = m ? oi[o] : oi[o] * 0.0f;
+            ws += w32;
+        }
+        double msum = 0.0;
+        int nm = 0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const bool m = ohe_l[o] > 0;
+            const float w32 = m ? oi[o] : oi[o] * 0.0f;
+            const double wd = (double)w32 / ((double)ws + 1e-20);
+            if (wd > 0) {
+                msum += wd;
+                ++nm;
+            }
+        }
+        if (nm > 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const bool m = ohe_l[o] > 0;
+                const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                const double wd = (double)w32 / ((double)ws + 1e-20);
+                if (wd > 0) {
+                    const double lw = wd / msum;
+                    m1 += omz_l[o] * lw;
+                    m2 += ohe_l[o] * lw;
+                }
+            }
         }
         merr_l = (m1 - (double)lrec_mz) / (double)lrec_mz * 1e6;  // fragment_features.py:387
         Q.merr[kk] = merr_l;
@@ -939,10 +1038,10 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         asmv.run = nullptr;  // features 0-3 are in place
         asmv.rec = &rec;
         asmv.featv = Q.feat;
-        asmv.iso_int = Q.iso_int; asmv.iso_mz = Q.iso_mz; asmv.spi = Q.spi; asmv.oi = Q.oi;
-        asmv.omzp = Q.omzp; asmv.hp = Q.hp;
+        asmv.iso_int = KP.iso_int; asmv.iso_mz = KP.iso_mz; asmv.spi = KP.spi; asmv.oi = Q.oi;
+        asmv.omzp = KP.omzp; asmv.hp = KP.hp;
         asmv.n_present = n_present; asmv.K0 = K0;
-        feat::assemble_precursor(asmv, I, 1);
+        feat::assemble_precursor(asmv, I, NO);
     }
     // ---- fragment features 17-27, 41-45 (fragment_features.py:198-427; the scalar form is
     // feat::assemble_fragments).  Every sum over fragments keeps the reference's order
@@ -976,13 +1075,15 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         t[4] = ov ? area : 0.0;
         t[5] = ov ? merr_l : 0.0;
         // cosine_similarity_a1 (features_utils.py:40-47) of the observation sums
-        const float ts0 = Q.tsum[0];
         float tn = 0.0f, fn = 0.0f, dot = 0.0f;
-        tn += ts0 * ts0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) tn += tsum[o] * tsum[o];
         tn = sqrtf(tn);
-        fn += rowsum_l * rowsum_l;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) fn += rowsum_l[o] * rowsum_l[o];
         fn = sqrtf(fn);
-        dot += rowsum_l * ts0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) dot += rowsum_l[o] * tsum[o];
         const float pr = fn * tn;
         const float score = (float)((double)dot / ((double)pr + 0.0001));
         float *u = Q.u.at.t32[kk];
@@ -1044,7 +1145,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     }
     if (ADH_FUSED_SCALAR && alive && sub == 0) {
         float *ft = Q.feat;
-        ft[17] = (float)1;
+        ft[17] = (float)NO;
         ft[20] = (float)((double)n_int / (double)K);
         ft[21] = (float)((double)n_hei / (double)K);
         ft[22] = Q.red32[0];
@@ -1153,14 +1254,9 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         const double var_xy = var_x * var_y;
         corr_l = (var_xy == 0) ? 0.0f : (float)(cov / sqrt(var_xy));
     }
-    {
-        float ftc_o, fw_o;
-        int fpeak_o;
-        profile_stats<FM>(P, Q.tfp, F, shift, rt_width, ftc_o, fw_o, fpeak_o);
-        Q.ftc[sub] = ftc_o;
-        Q.fw[sub] = fw_o;
-        Q.fpeak[sub] = fpeak_o;
-    }
+    if (NO == 1) profile_stats<FM>(P, Q.tfp, F, shift, rt_width, ftc_l[0], fw_l[0], fpeak_l[0]);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) Q.fpeak[sub][o] = fpeak_l[o];
     if (stop_phase == 62) return;
     if (present) Q.corr[kk] = corr_l;
     adh_wave_sync();
@@ -1169,25 +1265,29 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     {
         const int r_lo = (K - 1) / 2, r_hi = K / 2;
         if (present) {
-            // median apex (profile_features.py:196-198): rank of this fragment's apex
-            const int va = Q.fpeak[sub];
-            int rk = 0;
+            // median apex per observation (profile_features.py:196-198): rank of this fragment's apex
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if (!((gm >> b) & 1u)) continue;
-                const int vb = Q.fpeak[b];
-                rk += (vb < va) || (vb == va && b < sub);
+            for (int o = 0; o < NO; ++o) {
+                const int va = fpeak_l[o];
+                int rk = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (!((gm >> b) & 1u)) continue;
+                    const int vb = Q.fpeak[b][o];
+                    rk += (vb < va) || (vb == va && b < sub);
+                }
+                if (rk == r_lo) Q.medlo[o] = va;
+                if (rk == r_hi) Q.medhi[o] = va;
             }
-            if (rk == r_lo) Q.medlo = va;
-            if (rk == r_hi) Q.medhi = va;
             const float cr = Q.corr[Q.ord[kk]];  // correlation of the fragment with intensity rank kk
             // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
             const bool b3 = isb && __popc(b_isb & ((1u << sub) - 1u)) < 3;
             const bool y3 = isy && __popc(b_isy & ((1u << sub) - 1u)) < 3;
-            const float oi0 = Q.oi[0];
             float rr = 0.0f, ml = 0.0f;
-            rr += Q.ftc[sub] * oi0;
-            ml += Q.fw[sub] * oi0;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) rr += ftc_l[o] * oi[o];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) ml += fw_l[o] * oi[o];
             float *u = Q.u.at.t32[kk];
             u[0] = corr_l;
             u[1] = rr * g_int_l;
@@ -1219,10 +1319,11 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
         ft[38] = Q.red32[2];
         double acc = 0.0;
-        {
-            const double med = (K & 1) ? (double)Q.medhi : (double)(Q.medlo + Q.medhi) / 2.0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const double med = (K & 1) ? (double)Q.medhi[o] : (double)(Q.medlo[o] + Q.medhi[o]) / 2.0;
             const float medpk = (float)med;
-            acc += ((double)medpk - floor((double)F / 2.0)) * (double)Q.oi[0];
+            acc += ((double)medpk - floor((double)F / 2.0)) * (double)Q.oi[o];
         }
         ft[40] = (float)acc;
     }
@@ -1258,43 +1359,51 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 }
 
 // The classes of one batch in ONE launch: a launch drains the GPU at its end (a wavefront lives ~70 us) and
-// costs ~10 us to start, and a chunk of the host -> host pipeline has seven classes.  Wavefronts are ordered
-// by class (the plan is), so a compute unit runs one class at a time except at the six seams.
+// costs ~10 us to start, and a chunk of the host -> host pipeline has up to fourteen classes of them.  Wavefronts are
+// ordered by class (the plan is), so a compute unit runs one class at a time except at the seams.
+#define ADH_FUSED_MAX_CLASSES 6
 struct FusedClasses {
-    int32_t first_block[8];  // first wavefront of class c (FM = 8 + 4 c); [7] = all
-    int32_t first_cand[7];   // first candidate of the class in the plan
-    int32_t n_cand[7];
+    int32_t n;                                       // classes in this launch
+    int32_t first_block[ADH_FUSED_MAX_CLASSES + 1];  // first wavefront of class i; [n] = all
+    int32_t first_cand[ADH_FUSED_MAX_CLASSES];       // first candidate of the class in the plan
+    int32_t n_cand[ADH_FUSED_MAX_CLASSES];
+    int32_t kind[ADH_FUSED_MAX_CLASSES];             // (FM - 8) / 4 + 7 * (observations - 1)
 };
-constexpr size_t adh_fused_lds_bytes(int fm_max) {
-    return (fm_max > 28 ? sizeof(fused::GroupLds<32>) : sizeof(fused::GroupLds<28>)) * (ADH_WAVE / 16);
+constexpr size_t adh_fused_lds_bytes(int fm_max, int no) {
+    return (fm_max > 28 ? (no > 1 ? sizeof(fused::GroupLds<32, 2>) : sizeof(fused::GroupLds<32, 1>))
+                        : (no > 1 ? sizeof(fused::GroupLds<28, 2>) : sizeof(fused::GroupLds<28, 1>))) *
+           (ADH_WAVE / 16);
 }
 
-template <int FM_MAX>
-__global__ __launch_bounds__(ADH_WAVE, ADH_FUSED_WAVES) void adh_fused_kernel(
+// One launch per observation count (and one more each for FM = 32, which needs more LDS): with the bodies of
+// both in one kernel every wavefront pays the larger LDS block and spill area of the two-observation code
+// (measured: 3 ms of the 13.5 ms of the one-observation candidates of the bench).
+template <int FM_MAX, int NO>
+__global__ __launch_bounds__(ADH_WAVE, NO == 1 ? ADH_FUSED_WAVES : ADH_FUSED_WAVES2) void adh_fused_kernel(
     DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, FusedClasses fc,
     const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
     const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
-    __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes(FM_MAX)];
+    __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes(FM_MAX, NO)];
     const int32_t b = (int32_t)blockIdx.x;
     int c = 0;
-    while (c < 6 && b >= fc.first_block[c + 1]) ++c;
+    while (c + 1 < fc.n && b >= fc.first_block[c + 1]) ++c;
     const CandRec *recs = plan + fc.first_cand[c];
     const int32_t n = fc.n_cand[c], blk = b - fc.first_block[c];
-#define ADH_FUSED_CASE(C, FM)                                                                                  \
-    case C:                                                                                                    \
-        fused_body<FM>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
+#define ADH_FUSED_CASE(KIND, FM)                                                                                   \
+    case KIND:                                                                                                     \
+        fused_body<FM, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
         break;
     if (FM_MAX > 28) {
-        fused_body<32>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
+        fused_body<32, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
     } else {
-        switch (c) {
+        switch (fc.kind[c] % 7) {
             ADH_FUSED_CASE(0, 8)
             ADH_FUSED_CASE(1, 12)
             ADH_FUSED_CASE(2, 16)
             ADH_FUSED_CASE(3, 20)
             ADH_FUSED_CASE(4, 24)
             default:
-                fused_body<28>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
+                fused_body<28, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
                 break;
         }
     }

@@ -23,15 +23,17 @@
 
 // kernel classes, in processing order:
 //   0 ..  6  fused gather + feature kernel (adh_fused.hip), one observation, FM = 8, 12, ..., 32 registers
-//   7 ..  9  register kernels for two observations (FM = 16, 24, 32) behind the gather kernel
-//  10 .. 16  register kernels for one observation (FM = 8 ... 32) behind the gather kernel: shapes the
+//   7 .. 13  the same for two observations
+//  14 .. 16  register kernels for two observations (FM = 16, 24, 32) behind the gather kernel: shapes the
 //            fused kernel does not take (more than 12 fragments kept, library slices beyond 64)
-//  17        the generic LDS kernel behind the gather kernel
+//  17 .. 23  register kernels for one observation (FM = 8 ... 32) behind the gather kernel, likewise
+//  24        the generic LDS kernel behind the gather kernel
 #define ADH_CLASS_FUSED0 0
-#define ADH_CLASS_FAST2 7
-#define ADH_CLASS_FAST1 10
-#define ADH_CLASS_GENERIC 17
-#define ADH_N_CLASSES 18
+#define ADH_CLASS_FUSED2 7
+#define ADH_CLASS_FAST2 14
+#define ADH_CLASS_FAST1 17
+#define ADH_CLASS_GENERIC 24
+#define ADH_N_CLASSES 25
 
 // mirrors of the register-kernel limits (adh_features_fast.hip)
 #define ADH_PLAN_FMAX 32
@@ -77,7 +79,7 @@ struct PlanArgs {
     int32_t I;              // isotopes used
     uint32_t top_k;
     int32_t fast_cfg, quant_all;
-    int32_t fused_cfg;      // the fused kernel may be used (one MS1 row per cycle, <= 3 isotopes)
+    int32_t fused_cfg;      // the fused kernel may be used (one MS1 row per cycle, <= 3 isotopes): bit 0 for one, bit 1 for two observations
     int32_t n_cyc_bins;     // first-cycle bins per class in the sort key
 };
 
@@ -172,10 +174,11 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
             const bool fast = p.fast_cfg && O >= 1 && O <= ADH_PLAN_FAST_OMAX && (O == 1 || p.quant_all) && F >= 3 &&
                               F <= ADH_PLAN_FMAX && r.k_cap <= 16 && p.I <= 4;
             // gather and features in one kernel (adh_fused.hip): lanes 12..15 of a 16-lane group carry the isotopes
-            const bool fused = fast && p.fused_cfg && O == 1 && r.k_cap <= 12 && nl <= 64;  // (p.I <= 3 is part of fused_cfg)
+            const bool fused = fast && ((p.fused_cfg >> (O - 1)) & 1) && r.k_cap <= 12 && nl <= 64;  // (p.I <= 3 is part of fused_cfg)
             cls = !fast ? ADH_CLASS_GENERIC
-                        : (O == 1 ? (fused ? ADH_CLASS_FUSED0 : ADH_CLASS_FAST1) + max(F - 5, 0) / 4
-                                  : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)));
+                        : (fused ? (O == 1 ? ADH_CLASS_FUSED0 : ADH_CLASS_FUSED2) + max(F - 5, 0) / 4
+                                 : (O == 1 ? ADH_CLASS_FAST1 + max(F - 5, 0) / 4
+                                           : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2))));
             bin = (uint32_t)(r.frame_start / p.L);
             nbytes = fused ? 0 : adh_scratch_bytes(r.k_cap, O, max(F, 0), p.I);  // nothing leaves the CU there
             if (live) {

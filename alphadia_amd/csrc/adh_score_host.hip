@@ -311,7 +311,7 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.top_k = cfg->top_k_fragments;
     p.fast_cfg = key.fast_cfg ? 1 : 0;
     p.quant_all = key.quant_all ? 1 : 0;
-    p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 3) ? 1 : 0;
+    p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 3) ? (getenv("ADH_DEBUG_NO_FUSED2") ? 1 : 3) : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(adh_plan_init_kernel, dim3(1), dim3(1), 0, st, s.d_meta, p.I);
     const int64_t n_frames = im ? h->tims.n_frames : h->run.n_spectra;
@@ -556,33 +556,36 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
     HIP_TRY(hipEventRecord(t.e1, st));
     const unsigned per_block = ADH_WAVE / ADH_GS;
     if (n_fused > 0 && run_fast) {
-        // the fused classes FM = 8 ... 28 in one launch, FM = 32 (more LDS) in a second one
-        FusedClasses fc{};
-        int64_t first = 0, blocks = 0;
-        for (int c = 0; c < 6; ++c) {
-            fc.first_block[c] = (int32_t)blocks;
-            fc.first_cand[c] = (int32_t)first;
-            fc.n_cand[c] = (int32_t)p.n_class[ADH_CLASS_FUSED0 + c];
-            blocks += (p.n_class[ADH_CLASS_FUSED0 + c] + per_block - 1) / per_block;
-            first += p.n_class[ADH_CLASS_FUSED0 + c];
+        // per observation count: the classes with FM <= 28 in one launch, FM = 32 (more LDS) in a second one
+        FusedClasses fcs[4] = {};  // [2 * (observations - 1) + (FM == 32)]
+        int64_t fblocks[4] = {0, 0, 0, 0};
+        int64_t first = 0;
+        for (int c = ADH_CLASS_FUSED0; c < ADH_CLASS_FAST2; ++c) {
+            const int64_t nc = p.n_class[c];
+            const int which = 2 * ((c - ADH_CLASS_FUSED0) / 7) + ((c - ADH_CLASS_FUSED0) % 7 == 6 ? 1 : 0);
+            FusedClasses &fc = fcs[which];
+            if (nc > 0) {
+                fc.first_block[fc.n] = (int32_t)fblocks[which];
+                fc.first_cand[fc.n] = (int32_t)first;
+                fc.n_cand[fc.n] = (int32_t)nc;
+                fc.kind[fc.n] = c - ADH_CLASS_FUSED0;
+                ++fc.n;
+                fblocks[which] += (nc + per_block - 1) / per_block;
+                fc.first_block[fc.n] = (int32_t)fblocks[which];
+            }
+            first += nc;
         }
-        fc.first_block[6] = fc.first_block[7] = (int32_t)blocks;
-        if (blocks > 0) {
-            hipLaunchKernelGGL((adh_fused_kernel<28>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, p.d_recs,
-                               fc, h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);
-            HIP_TRY(hipGetLastError());
-        }
-        const int64_t n32 = p.n_class[ADH_CLASS_FUSED0 + 6];
-        if (n32 > 0) {
-            FusedClasses f32c{};
-            const int64_t b32 = (n32 + per_block - 1) / per_block;
-            for (int c = 1; c < 8; ++c) f32c.first_block[c] = (int32_t)b32;
-            f32c.first_cand[0] = (int32_t)first;
-            f32c.n_cand[0] = (int32_t)n32;
-            hipLaunchKernelGGL((adh_fused_kernel<32>), dim3((unsigned)b32), dim3(ADH_WAVE), 0, st, h->run, h->d_lib, p.d_recs,
-                               f32c, h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);
-            HIP_TRY(hipGetLastError());
-        }
+#define ADH_LAUNCH_FUSED(W, FM_MAX, NO)                                                                               \
+    if (fblocks[W] > 0) {                                                                                             \
+        hipLaunchKernelGGL((adh_fused_kernel<FM_MAX, NO>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, h->run, \
+                           h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);  \
+        HIP_TRY(hipGetLastError());                                                                                   \
+    }
+        ADH_LAUNCH_FUSED(0, 28, 1)
+        ADH_LAUNCH_FUSED(1, 32, 1)
+        ADH_LAUNCH_FUSED(2, 28, 2)
+        ADH_LAUNCH_FUSED(3, 32, 2)
+#undef ADH_LAUNCH_FUSED
     }
     if (stop_phase != 2 && !fused_only) {
         int64_t first = n_fused;
