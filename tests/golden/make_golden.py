@@ -25,6 +25,8 @@ import numpy as np
 import pandas as pd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# fixtures go to tests/golden/ unless --out DIR is given (tests/test_golden_regenerate.py writes to a temp dir)
+OUT_DIR = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))  # tests/: the synthetic generators
 sys.path.insert(0, HERE)
@@ -317,7 +319,7 @@ def golden_scoring(which=None):
         d["fragments_df_mz_observed"] = frdf["mz_observed"].values
         d["fragments_df_n"] = np.asarray(len(frdf))
         d["caveat"] = np.asarray(CAVEAT)
-        path = os.path.join(HERE, f"scoring_{name}.npz")
+        path = os.path.join(OUT_DIR, f"scoring_{name}.npz")
         np.savez_compressed(path, **d)
         v = np.asarray(out.valid)
         print(
@@ -414,7 +416,7 @@ def golden_host_helpers():
         out = calculate_score_groups(cand.copy(), group_channels=grouped)
         for c in ("precursor_idx", "rank", "score_group_idx"):
             d[f"groups_{name}_{c}"] = out[c].values
-    path = os.path.join(HERE, "host_helpers.npz")
+    path = os.path.join(OUT_DIR, "host_helpers.npz")
     np.savez_compressed(path, **d)
     print(f"{path}: {os.path.getsize(path)/1e3:.0f} kB")
 
@@ -490,7 +492,7 @@ def golden_staging():
             d[f"{name}_{attr.lstrip('_')}"] = np.asarray(getattr(obj, attr))
         print(name, "cycle length", obj._cycle_length, "start", obj._cycle_start, "has_ms1", obj.has_ms1,
               "spectra", len(obj.rt_values))
-    path = os.path.join(HERE, "staging.npz")
+    path = os.path.join(OUT_DIR, "staging.npz")
     np.savez_compressed(path, **d)
     print(f"{path}: {os.path.getsize(path)/1e3:.0f} kB")
 
@@ -519,7 +521,7 @@ def golden_multiplex():
     d["fragments_df_mz_observed"] = frdf["mz_observed"].values
     d["fragments_df_n"] = np.asarray(len(frdf))
     d["caveat"] = np.asarray(CAVEAT)
-    path = os.path.join(HERE, "scoring_multiplex.npz")
+    path = os.path.join(OUT_DIR, "scoring_multiplex.npz")
     np.savez_compressed(path, **d)
     v = np.asarray(out.valid)
     print(f"{path}: {v.sum()}/{len(v)} valid, {os.path.getsize(path)/1e6:.2f} MB")
@@ -600,7 +602,7 @@ def golden_edges():
     d["fragments_df_mz_observed"] = frdf["mz_observed"].values
     d["fragments_df_n"] = np.asarray(len(frdf))
     d["caveat"] = np.asarray(CAVEAT)
-    path = os.path.join(HERE, "scoring_edges.npz")
+    path = os.path.join(OUT_DIR, "scoring_edges.npz")
     np.savez_compressed(path, **d)
     v = np.asarray(out.valid)
     print(f"{path}: {v.sum()}/{len(v)} valid; first 20 valid flags {v[:20].astype(int)}; "
@@ -654,7 +656,7 @@ def golden_selection():
             d[f"{name}_out_{c}"] = df[c].values
         print(name, len(df), "candidates for", df["precursor_idx"].nunique(), "precursors;",
               "ranks", np.bincount(df["rank"].values))
-    path = os.path.join(HERE, "selection.npz")
+    path = os.path.join(OUT_DIR, "selection.npz")
     np.savez_compressed(path, **d)
     print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
 
@@ -674,7 +676,7 @@ def golden_transpose():
     tof = np.concatenate([np.sort(rng.integers(0, n_tof, c)) for c in counts]).astype(np.uint32)
     values = rng.integers(1, 4000, n).astype(np.uint16)
     push_indices, tof_indptr, new_values = _transpose(tof, push_indptr, n_tof, values)
-    path = os.path.join(HERE, "transpose.npz")
+    path = os.path.join(OUT_DIR, "transpose.npz")
     np.savez_compressed(path, tof_indices=tof, push_indptr=push_indptr, n_tof=np.asarray(n_tof), values=values,
                         out_push_indices=push_indices, out_tof_indptr=tof_indptr, out_values=new_values)
     print(path, n, "events", f"{os.path.getsize(path)/1e6:.2f} MB")
@@ -722,7 +724,7 @@ def golden_selection_kats():
         pk_cyc.append(c)
         pk_val.append(v)
         pk_n.append(len(cyc))
-    path = os.path.join(HERE, "selection_kats.npz")
+    path = os.path.join(OUT_DIR, "selection_kats.npz")
     np.savez_compressed(path, limits_in=np.stack(lim_in), limits_out=np.stack(lim_out), peaks_in=np.stack(pk_in),
                         peaks_cycle=np.stack(pk_cyc), peaks_score=np.stack(pk_val), peaks_n=np.asarray(pk_n))
     print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
@@ -781,7 +783,7 @@ def golden_get_dense():
         d[f"q{i}_pidx"] = np.asarray(pidx, dtype=np.int64)
     d["n_cases"] = np.asarray(n_cases)
     d["caveat"] = np.asarray(CAVEAT)
-    path = os.path.join(HERE, "get_dense_alpharaw.npz")
+    path = os.path.join(OUT_DIR, "get_dense_alpharaw.npz")
     np.savez_compressed(path, **d)
     print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
 
@@ -839,7 +841,7 @@ def golden_fragcomp():
     d["surviving_precursor_idx"] = res["precursor_idx"].values
     d["surviving_rank"] = res["rank"].values
     d["caveat"] = np.asarray(CAVEAT)
-    path = os.path.join(HERE, "fragcomp.npz")
+    path = os.path.join(OUT_DIR, "fragcomp.npz")
     np.savez_compressed(path, **d)
     print(path, f"{len(res)}/{n_psm} survive, {os.path.getsize(path)/1e6:.2f} MB")
 
@@ -937,7 +939,7 @@ def golden_selection_timstof():
         d[f"out_{c}"] = df[c].values
     print(len(df), "candidates for", df["precursor_idx"].nunique(), "precursors; ranks", np.bincount(df["rank"].values),
           "kernel", cs.kernel.shape, "scan width", np.unique(df["scan_stop"] - df["scan_start"]))
-    path = os.path.join(HERE, "selection_timstof.npz")
+    path = os.path.join(OUT_DIR, "selection_timstof.npz")
     np.savez_compressed(path, **d)
     print(path, f"{os.path.getsize(path)/1e6:.2f} MB")
 
@@ -1008,7 +1010,7 @@ def golden_timstof():
                "fragment_mz_tolerance experimental_xic").split():
         d["cfg_" + kk] = np.asarray(getattr(cfgj, kk))
     d["caveat"] = np.asarray(CAVEAT)
-    path = os.path.join(HERE, "scoring_timstof.npz")
+    path = os.path.join(OUT_DIR, "scoring_timstof.npz")
     np.savez_compressed(path, **d)
     v = np.asarray(out.valid)
     print(f"{path}: {v.sum()}/{len(v)} valid, {os.path.getsize(path)/1e6:.2f} MB, "

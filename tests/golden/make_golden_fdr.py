@@ -19,6 +19,8 @@ import numpy as np
 import pandas as pd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# fixtures go to tests/golden/ unless --out DIR is given (tests/test_golden_regenerate.py writes to a temp dir)
+OUT_DIR = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
@@ -160,7 +162,7 @@ def main():
 
     d["caveat"] = np.asarray("reference fdr.py / classifiers.py executed with torch " + torch.__version__ +
                              ", numpy " + np.__version__ + ", pandas " + pd.__version__ + " on CPU")
-    path = os.path.join(HERE, "fdr.npz")
+    path = os.path.join(OUT_DIR, "fdr.npz")
     np.savez_compressed(path, **d)
     print(f"{path}: {os.path.getsize(path) / 1e6:.2f} MB; q<=0.01 targets end to end: "
           f"{int(((res['qval'] <= 0.01) & (res['decoy'] == 0)).sum())}")
