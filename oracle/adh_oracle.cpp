@@ -683,14 +683,18 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
     std::vector<float> oi(O);
     {
         float tot = 0;
+        std::vector<float> per_scan(S);
         for (int o = 0; o < O; ++o) {
             float so = 0;
             for (int s = 0; s < S; ++s) {
                 float sf = 0;
                 for (int f = 0; f < F; ++f) sf += T(o, s, f);
                 if (g_numpy_typing) sf = numpy_pairwise_sum(&templ[((size_t)o * S + s) * F], F);
+                per_scan[s] = sf;
                 so += sf;
             }
+            /* np.sum(np.sum(template, axis=-1), axis=-1): the outer sum runs over a contiguous axis too */
+            if (g_numpy_typing) so = numpy_pairwise_sum(per_scan.data(), S);
             oi[o] = so;
         }
         for (int o = 0; o < O; ++o) tot += oi[o];

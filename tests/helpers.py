@@ -102,6 +102,12 @@ def oracle_score(oracle, case_like, cfg: CandidateScoringConfig, n_threads=1, so
     ), soa
 
 
+# correlation-type features (differences of nearly equal sums: a relative bound means nothing near zero):
+# isotope correlations 15/16, fragment-vs-library correlations 18/19, scan correlations 29/30, the
+# profile correlations 31-34 and 36.  Only these get an absolute floor next to the relative tolerance.
+CORR_FEATURES = (15, 16, 18, 19, 29, 30, 31, 32, 33, 34, 36)
+
+
 def rel_err(a, b, floor=1e-6):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

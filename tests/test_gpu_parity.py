@@ -74,13 +74,16 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     rest = [f for f in range(46) if f not in PPM_FEATURES]
     err = H.rel_err(gf[:, rest], ef[:, rest])
     if corr_abs > 0:
+        # an absolute floor only where a relative bound means nothing near zero: the correlation features
+        # (H.CORR_FEATURES) and the fragment_correlation table
+        floor = np.array([corr_abs if f in H.CORR_FEATURES else 0.0 for f in rest])
         ad = np.abs(gf[:, rest].astype(np.float64) - ef[:, rest])
-        err = np.where(ad <= corr_abs, 0.0, err)
+        err = np.where(ad <= floor[None, :], 0.0, err)
     worst = float(err.max()) if err.size else 0.0
     assert worst <= rel_tol, f"feature rel err {worst} at {np.unravel_index(err.argmax(), err.shape)}"
     for name in ("fragment_mz_observed", "fragment_height", "fragment_intensity", "fragment_correlation"):
         e = H.rel_err(got[name][v], exp[name][v])
-        if corr_abs > 0:
+        if corr_abs > 0 and name == "fragment_correlation":
             e = np.where(np.abs(got[name][v].astype(np.float64) - exp[name][v]) <= corr_abs, 0.0, e)
         assert e.max() <= rel_tol, f"{name}: {e.max()}"
     d = np.abs(got["fragment_mass_error"][v].astype(np.float64) - exp["fragment_mass_error"][v]).max()
@@ -487,7 +490,7 @@ def test_timstof_golden_inputs(ctx, oracle_lib):
     compare(got, exp, PPM_ABS_TOL_ORACLE)
     assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"])
     golden = {n: z["out_" + n] for n in H.OUT_NAMES}
-    compare(got, golden, PPM_ABS_TOL_GOLDEN, rel_tol=1e-3, corr_abs=2e-3)
+    compare(got, golden, PPM_ABS_TOL_GOLDEN, rel_tol=REL_TOL, corr_abs=1e-3)  # the north-star bar, as for the AlphaRaw layout
     v = got["valid"].astype(bool)
     assert v.sum() > 100 and (got["features"][v][:, 29] != 0).sum() > 50
 
