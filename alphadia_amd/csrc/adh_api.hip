@@ -132,6 +132,10 @@ struct adh_handle {
     std::vector<double> h_cycle;    // host copy (candidate selection sizes its tiles on the host)
     std::vector<int32_t> h_dpc;     // host copy of dia_precursor_cycle (adh_debug_get_dense)
     const LibRec *d_lib = nullptr;
+    std::vector<LibRec> h_lib;            // host copy of the staged library: the library columns of the fragment
+                                          // tables are rebuilt from it on the host instead of crossing PCIe
+    void *slot_stage = nullptr;           // page-locked fragment_lib_slot staging when the caller passes none
+    size_t slot_stage_bytes = 0;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
@@ -272,6 +276,7 @@ int adh_destroy(adh_handle_t *h) {
     }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->d_wtp) (void)hipFree(h->d_wtp);
+    if (h->slot_stage) (void)hipHostFree(h->slot_stage);
     for (DevTables &t : h->tables)
         if (t.base) (void)hipFree(t.base);
     if (h->cs.base) (void)hipFree(h->cs.base);
@@ -590,6 +595,7 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
         r.cardinality = f->cardinality[i];
     }
     UP(h->lib_buf, recs.data(), f->n, &h->d_lib);
+    h->h_lib.swap(recs);
     h->n_lib = f->n;
     h->lib_staged = true;
     return ADH_OK;

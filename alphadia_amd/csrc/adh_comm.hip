@@ -15,6 +15,8 @@ struct adh_comm_state {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;           // the collective's stream
@@ -65,6 +67,8 @@ int rccl_open(adh_comm_state &c) {
     ADH_RCCL_SYM(AllGather, "ncclAllGather");
     ADH_RCCL_SYM(AllReduce, "ncclAllReduce");
     ADH_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    ADH_RCCL_SYM(CommCount, "ncclCommCount");
+    ADH_RCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef ADH_RCCL_SYM
     return ADH_OK;
 }
@@ -232,6 +236,20 @@ int adh_comm_all_reduce_max(adh_handle_t *h, double *value) {
 int adh_comm_barrier(adh_handle_t *h) {
     double v = 0.0;
     return adh_comm_all_reduce_max(h, &v);
+}
+
+int adh_comm_info(adh_handle_t *h, int *rank, int *world) {
+    if (!h || !rank || !world) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *rank = 0;
+    *world = 1;
+    if (!h->comm) return ADH_OK;
+    adh_comm_state &c = *h->comm;
+    int n = 0, r = 0;
+    RCCL_TRY(c, c.CommCount(c.comm, &n));
+    RCCL_TRY(c, c.CommUserRank(c.comm, &r));
+    *rank = r;
+    *world = n;
+    return ADH_OK;
 }
 
 int adh_device_synchronize(adh_handle_t *h) {

@@ -20,35 +20,41 @@ int comm_wait_slot(adh_handle *h, int slot);
 int comm_gather_slot(adh_handle *h, int slot);
 
 struct OutFieldDesc {
+    const char *name;  // the OutputPsmDF column (adh_table_layout)
     size_t member;   // offsetof the pointer inside adh_output_t
     int per_row;     // 1, ADH_NUM_FEATURES, or -1 = top_k
     int elem;        // bytes per element
-    bool wire;       // travels in the all-gather (computed tables); the others are rebuilt locally
+    bool wire;       // travels in the all-gather and over PCIe (computed tables); the others are rebuilt locally
     bool optional;   // the caller's host pointer may be NULL
 };
+// The columns that are not `wire` are copies of the candidate table (precursor_idx, rank) and of the library
+// (per fragment slot): adh_score_candidates does not copy them back, it rebuilds them in the caller's host
+// buffers from fragment_lib_slot with host threads while the D2H copies of later chunks are in flight
+// (216 of the 646 bytes per candidate; the link is what bounds the host -> host step).
+// stat_matched_peaks is the exception: computed, optional, copied when asked for.
 
 // computed tables first: they form the contiguous "wire" prefix of the packed device buffer
 const OutFieldDesc kOutFields[] = {
-    {offsetof(adh_output_t, valid), 1, 1, true, false},
-    {offsetof(adh_output_t, features), ADH_NUM_FEATURES, 4, true, false},
-    {offsetof(adh_output_t, fragment_mz_observed), -1, 4, true, false},
-    {offsetof(adh_output_t, fragment_height), -1, 4, true, false},
-    {offsetof(adh_output_t, fragment_intensity), -1, 4, true, false},
-    {offsetof(adh_output_t, fragment_mass_error), -1, 4, true, false},
-    {offsetof(adh_output_t, fragment_correlation), -1, 4, true, false},
-    {offsetof(adh_output_t, fragment_lib_slot), -1, 2, true, true},
-    {offsetof(adh_output_t, precursor_idx), 1, 4, false, false},
-    {offsetof(adh_output_t, rank), 1, 1, false, false},
-    {offsetof(adh_output_t, fragment_precursor_idx), -1, 4, false, false},
-    {offsetof(adh_output_t, fragment_rank), -1, 1, false, false},
-    {offsetof(adh_output_t, fragment_mz_library), -1, 4, false, false},
-    {offsetof(adh_output_t, fragment_mz), -1, 4, false, false},
-    {offsetof(adh_output_t, fragment_position), -1, 1, false, false},
-    {offsetof(adh_output_t, fragment_number), -1, 1, false, false},
-    {offsetof(adh_output_t, fragment_type), -1, 1, false, false},
-    {offsetof(adh_output_t, fragment_charge), -1, 1, false, false},
-    {offsetof(adh_output_t, fragment_loss_type), -1, 1, false, false},
-    {offsetof(adh_output_t, stat_matched_peaks), 1, 4, false, true},
+    {"valid", offsetof(adh_output_t, valid), 1, 1, true, false},
+    {"features", offsetof(adh_output_t, features), ADH_NUM_FEATURES, 4, true, false},
+    {"fragment_mz_observed", offsetof(adh_output_t, fragment_mz_observed), -1, 4, true, false},
+    {"fragment_height", offsetof(adh_output_t, fragment_height), -1, 4, true, false},
+    {"fragment_intensity", offsetof(adh_output_t, fragment_intensity), -1, 4, true, false},
+    {"fragment_mass_error", offsetof(adh_output_t, fragment_mass_error), -1, 4, true, false},
+    {"fragment_correlation", offsetof(adh_output_t, fragment_correlation), -1, 4, true, false},
+    {"fragment_lib_slot", offsetof(adh_output_t, fragment_lib_slot), -1, 2, true, true},
+    {"precursor_idx", offsetof(adh_output_t, precursor_idx), 1, 4, false, false},
+    {"rank", offsetof(adh_output_t, rank), 1, 1, false, false},
+    {"fragment_precursor_idx", offsetof(adh_output_t, fragment_precursor_idx), -1, 4, false, false},
+    {"fragment_rank", offsetof(adh_output_t, fragment_rank), -1, 1, false, false},
+    {"fragment_mz_library", offsetof(adh_output_t, fragment_mz_library), -1, 4, false, false},
+    {"fragment_mz", offsetof(adh_output_t, fragment_mz), -1, 4, false, false},
+    {"fragment_position", offsetof(adh_output_t, fragment_position), -1, 1, false, false},
+    {"fragment_number", offsetof(adh_output_t, fragment_number), -1, 1, false, false},
+    {"fragment_type", offsetof(adh_output_t, fragment_type), -1, 1, false, false},
+    {"fragment_charge", offsetof(adh_output_t, fragment_charge), -1, 1, false, false},
+    {"fragment_loss_type", offsetof(adh_output_t, fragment_loss_type), -1, 1, false, false},
+    {"stat_matched_peaks", offsetof(adh_output_t, stat_matched_peaks), 1, 4, false, true},
 };
 constexpr int kNumOutFields = (int)(sizeof(kOutFields) / sizeof(kOutFields[0]));
 
@@ -712,6 +718,61 @@ int adh_kernel_time_ms(adh_handle_t *h, double *gather_ms, double *feature_ms, i
     return ADH_OK;
 }
 
+namespace {
+
+// rows [a, b) of the rebuildable host columns (OutputPsmDF columns that repeat the candidate table / the library,
+// alphadia/search/scoring/output.py:17-97; written by the kernels as candidate.py:175-176, 403-481)
+void rebuild_host_rows(const adh_handle *h, const adh_candidates_t *c, adh_output_t *out, const uint16_t *slots,
+                       int64_t a, int64_t b) {
+    const int top_k = out->top_k;
+    const LibRec *lib = h->h_lib.data();
+    for (int64_t i = a; i < b; ++i) {
+        const bool skip = c->flags && (c->flags[i] & ADH_FLAG_SKIP);
+        const uint32_t p = skip ? 0u : c->precursor_idx[i];
+        const uint8_t r = skip ? (uint8_t)0 : c->rank[i];
+        out->precursor_idx[i] = p;
+        out->rank[i] = r;
+        const LibRec *base = lib + c->frag_start_idx[i];
+        for (int j = 0; j < top_k; ++j) {
+            const size_t o = (size_t)i * (size_t)top_k + (size_t)j;
+            const uint16_t s = slots[o];
+            if (s) {
+                const LibRec &l = base[s - 1];
+                out->fragment_precursor_idx[o] = p;
+                out->fragment_rank[o] = r;
+                out->fragment_mz_library[o] = l.mz_library;
+                out->fragment_mz[o] = l.mz;
+                out->fragment_position[o] = l.position;
+                out->fragment_number[o] = l.number;
+                out->fragment_type[o] = l.type;
+                out->fragment_charge[o] = l.charge;
+                out->fragment_loss_type[o] = l.loss_type;
+            } else {
+                out->fragment_precursor_idx[o] = 0;
+                out->fragment_rank[o] = 0;
+                out->fragment_mz_library[o] = 0.0f;
+                out->fragment_mz[o] = 0.0f;
+                out->fragment_position[o] = 0;
+                out->fragment_number[o] = 0;
+                out->fragment_type[o] = 0;
+                out->fragment_charge[o] = 0;
+                out->fragment_loss_type[o] = 0;
+            }
+        }
+    }
+}
+
+int host_threads_for(int64_t n) {
+    int t = 16;
+    if (const char *env = getenv("ADH_HOST_THREADS")) t = atoi(env);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0) t = std::min<int>(t, (int)hw);
+    t = (int)std::min<int64_t>(t, n / 16384);  // (a thread per 16 k rows at least: starting one costs ~20 us)
+    return std::max(t, 1);
+}
+
+}  // namespace
+
 int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
                          adh_output_t *out) {
     if (!h || !c || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -736,6 +797,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     if (rc != ADH_OK) return rc;
     // device tables: with a communicator attached the layout is padded to the largest shard and
     // double-buffered (the all-gather of call i overlaps call i + 1)
+    if (h->comm_attached() && n > h->comm_rows)
+        return fail(ADH_ERR_INVALID_ARGUMENT,
+                    "more candidates than max_rows_per_rank of adh_comm_init: the ranks would disagree on the table layout");
     const int slot = h->comm_attached() ? (h->table_slot ^= 1) : 0;
     rc = comm_wait_slot(h, slot);
     if (rc != ADH_OK) return rc;
@@ -779,6 +843,21 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             }
         }
     }
+    // rebuildable columns: not copied back, rebuilt on the host from fragment_lib_slot (see kOutFields)
+    const bool rebuild = h->h_lib.size() == (size_t)h->n_lib && !getenv("ADH_DEBUG_COPY_ALL");
+    uint16_t *slot_host = out->fragment_lib_slot;
+    if (rebuild && !slot_host) {
+        const size_t need = (size_t)n * (size_t)top_k * sizeof(uint16_t);
+        if (h->slot_stage_bytes < need) {
+            if (h->slot_stage) (void)hipHostFree(h->slot_stage);
+            h->slot_stage = nullptr;
+            h->slot_stage_bytes = 0;
+            HIP_TRY(hipHostMalloc(&h->slot_stage, need + need / 8, hipHostMallocDefault));
+            h->slot_stage_bytes = need + need / 8;
+        }
+        slot_host = static_cast<uint16_t *>(h->slot_stage);
+    }
+    std::vector<hipEvent_t> chunk_done;
     std::vector<int64_t> cut{0};
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
@@ -826,7 +905,11 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         for (int i = 0; i < kNumOutFields; ++i) {
             const OutFieldDesc &f = kOutFields[i];
             void *host = *out_member(out, f);
+            const bool is_slot = f.member == offsetof(adh_output_t, fragment_lib_slot);
+            const bool is_stat = f.member == offsetof(adh_output_t, stat_matched_peaks);
+            if (is_slot && !host && rebuild) host = slot_host;
             if (!host) continue;
+            if (rebuild && !f.wire && !is_stat) continue;  // rebuilt on the host below
             const size_t rb = out_row_bytes(f, top_k);
             hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(host) + (size_t)a * rb,
                                           static_cast<unsigned char *>(*out_member(&dev, f)) + (size_t)a * rb,
@@ -837,11 +920,59 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             }
             h->d2h_bytes += (uint64_t)(b - a) * rb;
         }
+        if (rebuild) {
+            hipEvent_t ev = nullptr;
+            rc = get_event(h, &ev);
+            if (rc != ADH_OK) return fail_sync(rc);
+            HIP_TRY(hipEventRecord(ev, so));
+            chunk_done.push_back(ev);
+        }
         if (dbg_events) (void)hipEventRecord(dbg.back(), so);
     }
     const double t_2 = now();
     rc = comm_gather_slot(h, slot);  // after the last chunk's kernels; overlaps the remaining D2H
     if (rc != ADH_OK) return fail_sync(rc);
+    if (rebuild) {
+        // host threads follow the copy-out stream chunk by chunk: thread w takes the w-th stripe of every chunk
+        const int T = host_threads_for(n);
+        std::atomic<int64_t> ready{0};
+        std::atomic<bool> abort{false};
+        auto worker = [&](int w) {
+            for (int64_t ci = 0; ci < n_chunks; ++ci) {
+                while (ready.load(std::memory_order_acquire) <= ci) {
+                    if (abort.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
+                rebuild_host_rows(h, c, out, slot_host, a + (b - a) * w / T, a + (b - a) * (w + 1) / T);
+            }
+        };
+        std::vector<std::thread> team;
+        for (int w = 1; w < T; ++w) {
+            try {
+                team.emplace_back(worker, w);
+            } catch (const std::system_error &) {
+                break;  // (the calling thread takes the stripes that have no thread)
+            }
+        }
+        const int started = (int)team.size() + 1;
+        hipError_t ee = hipSuccess;
+        for (int64_t ci = 0; ci < n_chunks && ee == hipSuccess; ++ci) {
+            ee = hipEventSynchronize(chunk_done[(size_t)ci]);
+            if (ee != hipSuccess) break;
+            ready.store(ci + 1, std::memory_order_release);
+            const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
+            rebuild_host_rows(h, c, out, slot_host, a, a + (b - a) / T);  // stripe 0
+            for (int w = started; w < T; ++w) rebuild_host_rows(h, c, out, slot_host, a + (b - a) * w / T, a + (b - a) * (w + 1) / T);
+        }
+        if (ee != hipSuccess) abort.store(true);
+        for (std::thread &t : team) t.join();
+        for (hipEvent_t ev : chunk_done) h->free_events.push_back(ev);
+        if (ee != hipSuccess) {
+            fail(ADH_ERR_HIP, std::string("scoring pipeline (copy-out): ") + hipGetErrorString(ee));
+            return fail_sync(ADH_ERR_HIP);
+        }
+    }
     hipError_t e = hipStreamSynchronize(sk);
     if (e == hipSuccess) e = hipStreamSynchronize(so);
     if (e != hipSuccess) {
@@ -859,6 +990,31 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             fprintf(stderr, "[adh]   chunk %zu: D2H starts %.2f ms after the first, lasts %.2f ms\n", i / 2, since, ms);
         }
         for (hipEvent_t e : dbg) (void)hipEventDestroy(e);
+    }
+    return ADH_OK;
+}
+
+int adh_table_layout(int64_t rows, int32_t top_k, int32_t capacity, adh_table_field_t *fields, int32_t *n_fields,
+                     uint64_t *total_bytes, uint64_t *wire_bytes) {
+    if (rows < 0 || top_k <= 0 || !n_fields) return fail(ADH_ERR_INVALID_ARGUMENT, "adh_table_layout: bad argument");
+    *n_fields = kNumOutFields;
+    size_t wire = 0;
+    const size_t total = layout_tables(nullptr, rows, top_k, nullptr, &wire);
+    if (total_bytes) *total_bytes = total;
+    if (wire_bytes) *wire_bytes = wire;
+    if (!fields) return ADH_OK;
+    if (capacity < kNumOutFields) return fail(ADH_ERR_INVALID_ARGUMENT, "adh_table_layout: field array too short");
+    size_t off = 0;
+    for (int i = 0; i < kNumOutFields; ++i) {
+        const OutFieldDesc &f = kOutFields[i];
+        adh_table_field_t &o = fields[i];
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", f.name);
+        o.offset = off;
+        o.row_elems = (uint32_t)(f.per_row < 0 ? top_k : f.per_row);
+        o.elem_bytes = (uint32_t)f.elem;
+        o.wire = f.wire ? 1 : 0;
+        off += ((size_t)rows * out_row_bytes(f, top_k) + 255) / 256 * 256;
     }
     return ADH_OK;
 }

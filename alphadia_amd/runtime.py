@@ -63,6 +63,8 @@ EXPORTED_SYMBOLS = [
     "adh_comm_gathered",
     "adh_comm_all_reduce_max",
     "adh_comm_barrier",
+    "adh_comm_info",
+    "adh_table_layout",
     "adh_device_synchronize",
 ]
 
@@ -91,6 +93,26 @@ def _check(rc: int, what: str):
     if rc != 0:
         msg = lib.adh_last_error()
         raise HipBackendError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class _TableField(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("offset", C.c_uint64), ("row_elems", C.c_uint32), ("elem_bytes", C.c_uint32),
+                ("wire", C.c_int32), ("reserved", C.c_int32)]
+
+
+def table_layout(rows: int, top_k: int) -> tuple[list[dict], int, int]:
+    """``adh_table_layout``: the packed device buffer of ``rows`` candidates as the library lays it out -
+    (fields in buffer order, total bytes, bytes of the wire prefix).  Needs no GPU."""
+    n = C.c_int32(0)
+    total, wire = C.c_uint64(0), C.c_uint64(0)
+    _check(lib.adh_table_layout(C.c_int64(int(rows)), C.c_int32(int(top_k)), C.c_int32(0), None, C.byref(n),
+                                C.byref(total), C.byref(wire)), "adh_table_layout")
+    arr = (_TableField * n.value)()
+    _check(lib.adh_table_layout(C.c_int64(int(rows)), C.c_int32(int(top_k)), C.c_int32(n.value), arr, C.byref(n),
+                                C.byref(total), C.byref(wire)), "adh_table_layout")
+    fields = [dict(name=f.name.decode(), offset=int(f.offset), row_elems=int(f.row_elems), elem_bytes=int(f.elem_bytes),
+                   wire=bool(f.wire)) for f in arr]
+    return fields, int(total.value), int(wire.value)
 
 
 def device_count() -> int:
@@ -149,33 +171,76 @@ class PinnedPool:
         self._bufs.clear()
 
 
+def _launch_nonce() -> bytes:
+    """What all ranks of ONE launch share and a later launch does not: the launcher process (parent of every
+    rank) and its start time, plus whatever the launcher exports.  ``ADH_RUN_NONCE`` overrides (ranks started
+    by hand from one shell share a parent that outlives the run)."""
+    import hashlib
+
+    ppid = os.getppid()
+    start = ""
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time of the process
+    except (OSError, IndexError):
+        pass
+    tag = "|".join([os.environ.get("ADH_RUN_NONCE", ""), os.environ.get("MASTER_PORT", "0"),
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(ppid), start])
+    return hashlib.sha256(tag.encode()).digest()
+
+
 def rendezvous_path() -> str:
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    if os.environ.get("ADH_RENDEZVOUS_FILE"):
+        return os.environ["ADH_RENDEZVOUS_FILE"]
     base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-    return os.environ.get("ADH_RENDEZVOUS_FILE", os.path.join(base, f"adh_rccl_id_{tag}"))
+    folder = os.path.join(base, f"adh_{os.getuid()}")  # a directory of this user only: nobody else can pre-create
+    os.makedirs(folder, mode=0o700, exist_ok=True)      # or redirect the id file
+    st = os.stat(folder)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise HipBackendError(f"{folder} is not a private directory of this user")
+    return os.path.join(folder, f"rccl_id_{_launch_nonce().hex()[:24]}")
 
 
-def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0) -> bytes:
-    """Hand rank 0's RCCL unique id to the other ranks of this node through a file in /dev/shm
-    (all ranks of a launch share MASTER_PORT and their parent, the launcher)."""
+def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0, make_id=None) -> bytes:
+    """Hand rank 0's RCCL unique id to the other ranks of THIS NODE through a file in /dev/shm.
+
+    The file is named after a per-launch nonce (launcher pid + start time, MASTER_PORT, run id) and starts
+    with that nonce; rank 0 removes whatever a crashed earlier launch left under the name, creates the file
+    exclusively (0600, inside a 0700 directory of this user) and removes it again once the communicator exists
+    (``Context.comm_init``); readers only accept a file that carries their own nonce.  Single node: the ranks
+    must share a file system and a launcher (checked through LOCAL_WORLD_SIZE)."""
     import time
 
+    local_world = os.environ.get("LOCAL_WORLD_SIZE")
+    if local_world is not None and int(local_world) != int(world):
+        raise HipBackendError("the RCCL id rendezvous goes through a node-local file: all ranks must run on one node "
+                              f"(WORLD_SIZE {world}, LOCAL_WORLD_SIZE {local_world})")
     path = rendezvous_path()
+    nonce = _launch_nonce()
     if rank == 0:
-        buf = C.create_string_buffer(128)
-        _check(lib.adh_comm_unique_id(buf), "adh_comm_unique_id")
+        if make_id is None:
+            buf = C.create_string_buffer(128)
+            _check(lib.adh_comm_unique_id(buf), "adh_comm_unique_id")
+            uid = buf.raw
+        else:
+            uid = bytes(make_id())
+        try:
+            os.unlink(path)  # a stale file of a crashed launch with the same nonce inputs
+        except FileNotFoundError:
+            pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(buf.raw)
-        os.replace(tmp, path)  # atomic: readers see all 128 bytes or nothing
-        return buf.raw
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(nonce + uid)
+        os.replace(tmp, path)  # atomic: readers see all of it or nothing
+        return uid
     t0 = time.time()
     while True:
         try:
             with open(path, "rb") as f:
                 data = f.read()
-            if len(data) == 128:
-                return data
+            if len(data) == len(nonce) + 128 and data[: len(nonce)] == nonce:
+                return data[len(nonce):]
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
@@ -196,7 +261,6 @@ class Context:
         self.pinned = PinnedPool()
         self.comm_world = 1
         self.comm_rank = 0
-        self._rdv_file = None
 
     def close(self):
         if self._h:
@@ -205,13 +269,30 @@ class Context:
             self.pinned.close()
 
     # -- multi-GPU (one process per GPU; RCCL behind the C ABI) -------------
-    def comm_init(self, rank: int, world: int, max_rows_per_rank: int, unique_id: bytes | None = None) -> None:
+    def comm_init(self, rank: int, world: int, max_rows_per_rank: int, unique_id: bytes | None = None,
+                  timeout: float = 600.0) -> None:
         """Attach an RCCL communicator: every later ``score_host`` also all-gathers the computed
-        tables of all ranks into HBM (``gathered_tables``)."""
+        tables of all ranks into HBM (``gathered_tables``).  Creating the communicator is collective; a rank
+        whose peers never arrive (e.g. a stale unique id) fails after ``timeout`` seconds instead of hanging."""
+        import threading
+
         uid = unique_id if unique_id is not None else rendezvous_unique_id(rank, world)
         buf = C.create_string_buffer(bytes(uid), 128)
-        _check(lib.adh_comm_init(self._h, C.c_int(rank), C.c_int(world), buf, C.c_int64(int(max_rows_per_rank))),
-               "adh_comm_init")
+        result: list = []
+
+        def call():
+            result.append(lib.adh_comm_init(self._h, C.c_int(rank), C.c_int(world), buf, C.c_int64(int(max_rows_per_rank))))
+            msg = lib.adh_last_error()  # (thread-local: fetched on the thread that made the call)
+            result.append(msg.decode() if msg else "")
+
+        t = threading.Thread(target=call, name="adh_comm_init", daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            raise HipBackendError(f"adh_comm_init: rank {rank} of {world} still waits for its peers after {timeout:.0f} s "
+                                  "(ncclCommInitRank is collective: did every rank start, with the same unique id?)")
+        if result[0] != 0:
+            raise HipBackendError(f"adh_comm_init failed ({result[0]}): {result[1]}")
         self.comm_rank, self.comm_world = int(rank), int(world)
         if unique_id is None and rank == 0:
             # communicator creation is collective: every rank has read the id by now
@@ -234,6 +315,12 @@ class Context:
         v = C.c_double(float(value))
         _check(lib.adh_comm_all_reduce_max(self._h, C.byref(v)), "adh_comm_all_reduce_max")
         return float(v.value)
+
+    def comm_info(self) -> tuple[int, int]:
+        """(rank, world) as RCCL reports them for the attached communicator; (0, 1) without one."""
+        r, w = C.c_int(0), C.c_int(1)
+        _check(lib.adh_comm_info(self._h, C.byref(r), C.byref(w)), "adh_comm_info")
+        return int(r.value), int(w.value)
 
     def device_synchronize(self) -> None:
         _check(lib.adh_device_synchronize(self._h), "adh_device_synchronize")
@@ -389,7 +476,11 @@ class Context:
         alloc = (lambda name, shape, dt: self.pinned.empty("out:" + name, shape, dt)) if reuse_buffers else None
         # production calls (reuse_buffers) fetch exactly the OutputPsmDF tables; the diagnostic columns
         # (matched-peak counts, library slots) stay in HBM unless asked for
-        m_out, arrays = _abi.alloc_output(n, _abi.output_width(cands, int(cfg_jit.top_k_fragments)),
+        width = _abi.output_width(cands, int(cfg_jit.top_k_fragments))
+        if self.comm_world > 1:
+            # the all-gather needs ONE table layout on all ranks: the widest shard decides (a collective)
+            width = int(round(self.all_reduce_max(float(width))))
+        m_out, arrays = _abi.alloc_output(n, width,
                                           with_stats=with_stats, zero=False, alloc=alloc,
                                           with_slots=with_stats or not reuse_buffers)
         cfg = _abi.pack_config(cfg_jit)

@@ -235,6 +235,26 @@ int adh_score_uploaded(adh_handle_t *handle, const adh_scoring_config_t *config,
  * on the host).  device_view->n is the number of live rows.
  */
 int adh_get_device_tables(adh_handle_t *handle, adh_output_t *device_view);
+
+/*
+ * Layout of the packed device buffer that holds the tables of `rows` candidates (the buffer
+ * adh_get_device_tables / adh_comm_gathered give views of): one entry per OutputPsmDF column
+ * (alphadia/search/scoring/output.py:17-97) in buffer order, every table 256-byte aligned.  The computed
+ * tables come first and form the contiguous "wire" prefix of `wire_bytes` bytes - what the all-gather of
+ * adh_comm_init and the D2H copies of adh_score_candidates move; the columns behind it (wire = 0) repeat the
+ * candidate table or the staged library and are rebuilt where they are needed.  Pure function: needs no
+ * GPU.  fields may be NULL to query n_fields / the sizes only.
+ */
+typedef struct adh_table_field {
+    char name[40];
+    uint64_t offset;      /* bytes from the start of the buffer */
+    uint32_t row_elems;   /* elements per candidate row: 1, 46 or top_k */
+    uint32_t elem_bytes;
+    int32_t wire;
+    int32_t reserved;
+} adh_table_field_t;
+int adh_table_layout(int64_t rows, int32_t top_k, int32_t capacity, adh_table_field_t *fields, int32_t *n_fields,
+                     uint64_t *total_bytes, uint64_t *wire_bytes);
 /* zero those tables on `hip_stream` (for callers that refill them with adh_score_uploaded) */
 int adh_zero_device_tables(adh_handle_t *handle, void *hip_stream);
 
@@ -299,6 +319,9 @@ int adh_comm_gathered(adh_handle_t *handle, int rank, adh_output_t *device_view,
 /* max over ranks of *value (in place); also the barrier of the benchmark.  No-op without a communicator. */
 int adh_comm_all_reduce_max(adh_handle_t *handle, double *value);
 int adh_comm_barrier(adh_handle_t *handle);
+/* What RCCL itself reports for the attached communicator (ncclCommUserRank / ncclCommCount): rank 0 of 1
+ * without one.  bench.py prints it, so that a run on N GPUs shows that N ranks met. */
+int adh_comm_info(adh_handle_t *handle, int *rank, int *world);
 /* hipDeviceSynchronize on the handle's GPU. */
 int adh_device_synchronize(adh_handle_t *handle);
 

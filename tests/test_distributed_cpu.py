@@ -14,10 +14,6 @@ import torch.multiprocessing as mp
 
 import helpers as H
 from alphadia_amd.distributed import (
-    DeviceTables,
-    PipelinedGather,
-    all_gather_rows,
-    all_gather_tables,
     merge_gathered,
     packed_layout,
     precursor_bounds,
@@ -26,6 +22,7 @@ from alphadia_amd.distributed import (
     slice_soa,
     window_owner,
 )
+from torch_transport import DeviceTables, PipelinedGather, all_gather_rows, all_gather_tables
 
 
 def test_shard_bounds_keep_score_groups_intact():

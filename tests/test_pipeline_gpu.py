@@ -66,6 +66,39 @@ def test_chunked_pipeline_is_bitwise_the_single_pass(ctx, case, monkeypatch, exp
         _same(got, ref)
 
 
+def test_host_rebuilt_columns_equal_the_copied_ones(ctx, case, monkeypatch):
+    """adh_score_candidates copies only the computed tables back; ids and library columns are rebuilt in the
+    caller's buffers from fragment_lib_slot by host threads while later chunks are in flight.  Byte-identical
+    to copying every table (ADH_DEBUG_COPY_ALL), for chunked calls, skipped rows, with and without a host
+    buffer for the slots, at any thread count; and a third of the bytes stay off the link."""
+    from alphadia_amd import _abi
+
+    cfg = _cfg().to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    n = len(soa["precursor_idx"])
+    soa["flags"] = soa["flags"].copy()
+    soa["flags"][::17] |= 1  # ADH_FLAG_SKIP: such rows stay zero everywhere
+    monkeypatch.setenv("ADH_DEBUG_COPY_ALL", "1")
+    monkeypatch.setenv("ADH_CHUNK", "1500")
+    ctx.d2h_bytes(reset=True)
+    ref = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+    copied = ctx.d2h_bytes(reset=True)
+    monkeypatch.delenv("ADH_DEBUG_COPY_ALL")
+    assert ref["valid"].sum() > n // 4 and (ref["precursor_idx"][::17] == 0).all()
+    for threads, chunk in (("1", "1500"), ("3", "1777"), ("16", str(10 * n))):
+        monkeypatch.setenv("ADH_HOST_THREADS", threads)
+        monkeypatch.setenv("ADH_CHUNK", chunk)
+        ctx.d2h_bytes(reset=True)
+        got = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+        rebuilt = ctx.d2h_bytes(reset=True)
+        _same(got, ref)
+        assert rebuilt < 0.75 * copied
+        # production form: page-locked buffers, no host table for the slots (an internal staging buffer is used)
+        got = ctx.score_host(pack_assembled(soa), cfg, reuse_buffers=True)
+        _same(got, ref, [k for k in TABLES if k in got])
+
+
 def test_device_plan_matches_oracle_on_mixed_classes(ctx, oracle_lib, monkeypatch):
     """Candidates of every kernel class (cycle counts 3..40, one and two observations, short library
     slices, skipped score groups) in one table, several chunks: the device-built plan routes each

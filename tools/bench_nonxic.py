@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 import synthetic as syn
 from alphadia_amd import runtime  # noqa: E402
-from alphadia_amd.distributed import DeviceTables  # noqa: E402
+from torch_transport import DeviceTables  # noqa: E402  (tests/: the torch-side packed buffer)
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 
 case = syn.make_case(int(os.environ.get("N_PREC", 50000)), 2400, config_id=2, per_precursor=3, threads=os.cpu_count() or 8)
