@@ -189,8 +189,13 @@ def main():
     t_stage = time.time() - t0
     log(f"[bench] staged run+library in {t_stage:.2f}s")
     with_comm = world > 1 or bool(os.environ.get("ADH_BENCH_FORCE_COMM"))  # (debug: the RCCL path on one GPU)
+    ranks_seen = [1, 1]
     if with_comm:
         ctx.comm_init(rank, world, max_rows)
+        # what RCCL itself says about the communicator (ncclCommCount), smallest and largest answer over the
+        # ranks: a run on N GPUs shows here that N ranks met
+        _, w_seen = ctx.comm_info()
+        ranks_seen = [int(round(-ctx.all_reduce_max(-float(w_seen)))), int(round(ctx.all_reduce_max(float(w_seen))))]
 
     packed = pack_assembled(soa)
     reuse = not args.pageable
@@ -294,6 +299,7 @@ def main():
             "peaks": int(case.dia.mz_values.size),
             "parallelism": (f"score-group shards x{world}, computed tables all-gathered over RCCL "
                             f"(overlaps the D2H of the same step and the next step)") if world > 1 else "single GPU",
+            "rccl_ranks_seen": ranks_seen[1] if ranks_seen[0] == ranks_seen[1] else ranks_seen,
             "valid_fraction": float(valid.mean()) if n_local else 0.0,
             "priming_steps_before_warmup": PRIME,
             "candidates_per_s": float(n_all * args.steps / elapsed),
@@ -312,8 +318,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "adh_gather_kernel + feature kernels (adh_feature_fast_kernel<FM,NO>, adh_feature_kernel): "
-                      "the hot path, summed over the chunks of one step",
+            "kernel": "adh_fused_kernel<FM_MAX, observations> (gather + features in one kernel; every candidate of this "
+                      "workload takes it) + the two-kernel fallback classes: the hot path, summed over the chunks of one step",
             "kernel_ms": kernel_ms,
             "gather_kernel_ms": gather_ms,
             "feature_kernel_ms": feature_ms,

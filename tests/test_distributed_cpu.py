@@ -169,3 +169,83 @@ def test_pipelined_gather_two_ranks(tmp_path):
         assert np.array_equal(z["last"], np.array([[40] * 16, [41] * 16], dtype=np.uint8))
         # while batch b is being filled, the other slot holds the gather of batch b - 1
         assert np.array_equal(z["seen"], np.array([[10, 11], [20, 21], [30, 31]], dtype=np.uint8))
+
+
+def test_packed_layout_is_the_librarys(tmp_path):
+    """``packed_layout`` (what the gloo tests pack and unpack with) IS ``adh_table_layout``: computed tables
+    first, 256-byte aligned, the wire prefix ends where the first rebuildable column starts."""
+    from alphadia_amd import _abi, runtime
+    from alphadia_amd.distributed import LOCAL_COLUMNS, wire_bytes
+
+    fields, total, wire = runtime.table_layout(1000, 12)
+    names = [f["name"] for f in fields]
+    assert set(names) == set(dict(_abi.output_shapes(1, 1))) | {"fragment_lib_slot", "stat_matched_peaks"}
+    seen_local = False
+    for f in fields:
+        assert f["offset"] % 256 == 0
+        seen_local = seen_local or not f["wire"]
+        assert f["wire"] != seen_local  # wire columns first, then only local ones
+        assert (f["name"] in LOCAL_COLUMNS) == (not f["wire"])
+    offsets, nbytes = packed_layout(1000, 12)
+    assert nbytes == total and wire_bytes(offsets) == wire
+    assert wire == sum((1000 * f["row_elems"] * f["elem_bytes"] + 255) // 256 * 256 for f in fields if f["wire"])
+    per_row = sum(f["row_elems"] * f["elem_bytes"] for f in fields if f["wire"])
+    assert per_row == 449  # bytes per candidate on the wire and over PCIe at top_k = 12
+
+
+def _rendezvous_worker(rank, world, path_env, out_dir, nonce):
+    os.environ["ADH_RUN_NONCE"] = nonce
+    os.environ["MASTER_PORT"] = "29555"
+    os.environ.pop("LOCAL_WORLD_SIZE", None)
+    if path_env:
+        os.environ["ADH_RENDEZVOUS_FILE"] = path_env
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from alphadia_amd import runtime
+
+    uid = runtime.rendezvous_unique_id(rank, world, timeout=30.0, make_id=lambda: bytes([7 + rank]) * 128)
+    with open(os.path.join(out_dir, f"id_{rank}"), "wb") as f:
+        f.write(uid)
+
+
+def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
+    """The RCCL id travels through a node-local file: every rank ends up with rank 0's 128 bytes, a stale file
+    of another launch (other nonce) or a truncated one is never accepted, the file is private to the user."""
+    import stat
+
+    from alphadia_amd import runtime
+
+    # (a) default location: a 0700 directory of this user, the name carries the launch nonce
+    os.environ["ADH_RUN_NONCE"] = "launch-A"
+    os.environ.pop("ADH_RENDEZVOUS_FILE", None)
+    p_a = runtime.rendezvous_path()
+    assert stat.S_IMODE(os.stat(os.path.dirname(p_a)).st_mode) == 0o700
+    os.environ["ADH_RUN_NONCE"] = "launch-B"
+    assert runtime.rendezvous_path() != p_a
+    # (b) a stale file of an earlier launch sits where this launch will look: same path (forced), other nonce
+    path = str(tmp_path / "rccl_id")
+    with open(path, "wb") as f:
+        f.write(b"\0" * 32 + b"\x55" * 128)
+    procs = [mp.get_context("spawn").Process(target=_rendezvous_worker, args=(r, 3, path, str(tmp_path), "launch-C"))
+             for r in (1, 2)]
+    for p in procs:
+        p.start()
+    import time
+
+    time.sleep(1.0)  # the readers are polling: they must not have taken the stale id
+    assert not os.path.exists(tmp_path / "id_1") and not os.path.exists(tmp_path / "id_2")
+    p0 = mp.get_context("spawn").Process(target=_rendezvous_worker, args=(0, 3, path, str(tmp_path), "launch-C"))
+    p0.start()
+    for p in procs + [p0]:
+        p.join(60)
+        assert p.exitcode == 0
+    ids = [open(tmp_path / f"id_{r}", "rb").read() for r in range(3)]
+    assert ids[0] == bytes([7]) * 128 and ids[1] == ids[0] and ids[2] == ids[0]
+    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    # (c) more than one node is refused (the file is node-local)
+    os.environ["LOCAL_WORLD_SIZE"] = "4"
+    try:
+        with pytest.raises(runtime.HipBackendError, match="one node"):
+            runtime.rendezvous_unique_id(1, 8, timeout=0.1)
+    finally:
+        os.environ.pop("LOCAL_WORLD_SIZE", None)
+        os.environ.pop("ADH_RUN_NONCE", None)

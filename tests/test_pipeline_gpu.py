@@ -153,6 +153,44 @@ def test_tables_stay_in_hbm_and_gather_with_one_rank(ctx, case):
     _same(full, host, names=H.OUT_NAMES)
 
 
+def test_uneven_shards_share_one_layout_under_a_communicator(ctx, case):
+    """All ranks must lay their tables out alike (the all-gather moves equal byte counts): the layout follows
+    ``max_rows_per_rank`` and the agreed table width, not the shard.  A short shard scored through a
+    communicator sized for a longer one gives the rows of the unsharded call; RCCL itself reports the ranks it
+    sees; more rows than the communicator was sized for are refused (mismatched counts are undefined)."""
+    from alphadia_amd import runtime
+    from alphadia_amd.distributed import shard_bounds, slice_soa
+
+    cfg = _cfg().to_jitclass()
+    _stage(ctx, case)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    n = len(soa["precursor_idx"])
+    full = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+    sg = np.cumsum(np.r_[0, np.diff(soa["precursor_idx"].astype(np.int64)) != 0])
+    bounds = [shard_bounds(sg, r, 3) for r in range(3)]
+    longest = max(b - a for a, b in bounds)
+    a, b = bounds[1][0], bounds[1][0] + (bounds[1][1] - bounds[1][0]) // 2  # a shard half as long as the longest
+    uid = C.create_string_buffer(128)
+    runtime._check(runtime.lib.adh_comm_unique_id(uid), "adh_comm_unique_id")
+    ctx.comm_init(0, 1, longest, unique_id=uid.raw)
+    try:
+        assert ctx.comm_info() == (0, 1)
+        part = ctx.score_host(pack_assembled(slice_soa(soa, a, b)), cfg, with_stats=True)
+        for k in TABLES:
+            assert np.array_equal(part[k], full[k][a:b], equal_nan=True), k
+        ctx.comm_wait()
+        wire = ctx.gathered_tables(0, rows=b - a)
+        assert np.array_equal(wire["features"], full["features"][a:b], equal_nan=True)
+        # the gathered slice of a rank is as long as the layout of the LONGEST shard says
+        _, _, wire_bytes = runtime.table_layout(longest, part["fragment_mz"].shape[1])
+        assert wire_bytes % 256 == 0 and wire_bytes > (b - a) * 449
+        with pytest.raises(runtime.HipBackendError, match="max_rows_per_rank"):
+            ctx.score_host(pack_assembled(soa), cfg)  # n > longest
+    finally:
+        ctx.comm_destroy()
+    assert ctx.comm_info() == (0, 1)
+
+
 def test_restaging_invalidates_the_resident_table(ctx, case):
     """A candidate table uploaded for one run / library must not be scored against another one
     (its bounds were checked against the old arrays)."""
