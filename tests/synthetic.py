@@ -609,6 +609,35 @@ class TimsTOFCase:
     candidates_df: pd.DataFrame
 
 
+def _sorted_noise(seed: int, n_tof: int, n_push: int, S: int, events_per_push: float, threads: int):
+    """Uniform (TOF, push) noise events in (TOF, push) order without a sort: the TOF axis is cut into ranges,
+    every range draws its Poisson count and the order statistics of that many uniform keys over
+    range x pushes (normalised cumulative exponential gaps).  -> (push uint32, tof int32, intensity uint16)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    width = n_push - S  # (the S pushes of the empty zeroth frame carry nothing)
+    n_parts = max(1, min(n_tof, 4 * max(threads, 1), int(events_per_push * width // 2_000_000) + 1))
+    cuts = np.linspace(0, n_tof, n_parts + 1).astype(np.int64)
+
+    def part(i):
+        t0, t1 = int(cuts[i]), int(cuts[i + 1])
+        r = np.random.default_rng([seed, 11, i])
+        space = float(t1 - t0) * float(width)
+        n = int(r.poisson(events_per_push * width * (t1 - t0) / n_tof))
+        g = r.standard_exponential(n + 1)
+        np.cumsum(g, out=g)
+        keys = np.minimum((g[:-1] * (space / g[-1])).astype(np.int64), int(space) - 1)
+        tof = (keys // width + t0).astype(np.int32)
+        push = (keys % width + S).astype(np.uint32)
+        inten = np.clip(r.lognormal(3.0, 1.0, n), 1, 60000).astype(np.uint16)
+        return push, tof, inten
+
+    with ThreadPoolExecutor(max_workers=max(threads, 1)) as ex:
+        parts = list(ex.map(part, range(n_parts)))
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+            np.concatenate([p[2] for p in parts]))
+
+
 def make_timstof_case(
     n_precursors: int = 200,
     n_cycles: int = 40,
@@ -630,8 +659,15 @@ def make_timstof_case(
     h_range: tuple = (2, 10),
     hs_range: tuple = (3, 12),
     candidates_on_window: bool = False,
+    sorted_noise: bool = False,
+    threads: int = 16,
 ) -> TimsTOFCase:
-    """Run "B" of SURVEY.md section 8(d) at a configurable (test) scale."""
+    """Run "B" of SURVEY.md section 8(d) at a configurable (test) scale.
+
+    ``sorted_noise``: draw the noise events already in (TOF, push) order - order statistics of uniform keys
+    as cumulative sums of exponential gaps, TOF range by TOF range on ``threads`` threads - instead of
+    drawing and lexsorting them: the full-size run (5e8 events) in seconds instead of minutes.  Another
+    random stream, hence another run: the committed fixtures use the default."""
     seed = BASE_SEED + config_id if seed is None else seed
     rng = np.random.default_rng([seed, 7])
     cycle = make_timstof_cycle(n_ms2_frames, windows_per_frame, scan_max_index, mz_lo, mz_hi)
@@ -651,10 +687,13 @@ def make_timstof_case(
 
     # ---- noise events
     n_push = n_frames * S
-    n_noise = rng.poisson(events_per_push * (n_push - S))
-    ev_push = rng.integers(S, n_push, n_noise).astype(np.int64)
-    ev_tof = rng.integers(0, n_tof, n_noise).astype(np.int64)
-    ev_int = np.clip(rng.lognormal(3.0, 1.0, n_noise), 1, 60000).astype(np.int64)
+    if sorted_noise:
+        ev_push, ev_tof, ev_int = _sorted_noise(seed, n_tof, n_push, S, events_per_push, threads)
+    else:
+        n_noise = rng.poisson(events_per_push * (n_push - S))
+        ev_push = rng.integers(S, n_push, n_noise).astype(np.int64)
+        ev_tof = rng.integers(0, n_tof, n_noise).astype(np.int64)
+        ev_int = np.clip(rng.lognormal(3.0, 1.0, n_noise), 1, 60000).astype(np.int64)
 
     # ---- planted peptides: Gaussian in cycle and in scan (vectorised over precursors x cells)
     targets = np.flatnonzero(pdf["decoy"].values == 0)
@@ -718,12 +757,24 @@ def make_timstof_case(
                 has = f_start[sp] + k < f_stop[sp]
                 idx = (f_start[sp] + k)[has]
                 emit(push2[has], f_mz[idx], 1500.0 * f_int[idx] * sg[has])
-        if parts:
+        if parts and sorted_noise:
+            # the planted events (a few million) are sorted and merged into the sorted noise
+            pp = np.concatenate([x[0] for x in parts]).astype(np.int64)
+            pt = np.concatenate([x[1] for x in parts]).astype(np.int64)
+            pi = np.concatenate([x[2] for x in parts]).astype(np.uint16)
+            o = np.lexsort((pp, pt))
+            pp, pt, pi = pp[o], pt[o], pi[o]
+            at = np.searchsorted(ev_tof.astype(np.int64) * n_push + ev_push, pt * n_push + pp, side="right")
+            ev_push = np.insert(ev_push, at, pp.astype(ev_push.dtype))
+            ev_tof = np.insert(ev_tof, at, pt.astype(ev_tof.dtype))
+            ev_int = np.insert(ev_int, at, pi)
+        elif parts:
             ev_push = np.concatenate([ev_push] + [x[0] for x in parts])
             ev_tof = np.concatenate([ev_tof] + [x[1] for x in parts])
             ev_int = np.concatenate([ev_int] + [x[2] for x in parts])
-    order = np.lexsort((ev_push, ev_tof))
-    ev_push, ev_tof, ev_int = ev_push[order], ev_tof[order], ev_int[order]
+    if not sorted_noise:
+        order = np.lexsort((ev_push, ev_tof))
+        ev_push, ev_tof, ev_int = ev_push[order], ev_tof[order], ev_int[order]
     tof_indptr = np.concatenate([[0], np.cumsum(np.bincount(ev_tof, minlength=n_tof))]).astype(np.int64)
 
     dia = TimsTOFArrays(
@@ -733,8 +784,8 @@ def make_timstof_case(
         mobility_values=mobility,
         mz_values=mz_table,
         tof_indptr=tof_indptr,
-        push_indices=ev_push.astype(np.uint32),
-        intensity_values=ev_int.astype(np.uint16),
+        push_indices=ev_push.astype(np.uint32, copy=False),
+        intensity_values=ev_int.astype(np.uint16, copy=False),
         scan_max_index=S,
     )
 

@@ -1,0 +1,123 @@
+"""BASELINE.json's configurations at their full sizes, inside the GPU suite.
+
+configs[2] (1e6-precursor library x 3 candidates vs the 2 h run, on one GPU) and configs[1] (its first
+100 000 precursors: the same run, the 100k library) through size-independent properties - permutation
+invariance, sub-table == rows of the full table, planted precursors found - and a strided oracle sample that
+includes the ppm features; configs[3] (918 scans x 2 000 cycles, ion mobility) with 20 000 precursors and an
+oracle sample.  The run generators are the bench's (tests/synthetic.py); generation dominates the time.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import synthetic as syn
+from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
+from test_gpu_parity import PPM_ABS_TOL_ORACLE, compare
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(1, min(32, os.cpu_count() or 8))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from alphadia_amd import runtime
+
+    return runtime.get_context(0)
+
+
+def _cfg():
+    cfg = CandidateScoringConfig()
+    # ClassicExtractionHandler defaults (extraction_handler.py:370-376,400-409), as bench.py
+    cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
+                    fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=True,
+                    experimental_xic=True, top_k_fragments=12))
+    return cfg
+
+
+def _rows(soa: dict, idx) -> dict:
+    n = len(soa["precursor_idx"])
+    return {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in soa.items()}
+
+
+@pytest.fixture(scope="module")
+def headline(ctx):
+    """The bench workload: 1e6 precursors x 3 candidates against 4 800 cycles x 61 spectra (4.9e8 peaks)."""
+    case = syn.make_case(1_000_000, 4800, config_id=2, per_precursor=3, threads=THREADS)
+    cfg = _cfg()
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    ctx.stage_run(case.dia, force=True)
+    ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"), force=True)
+    got = ctx.score_host(pack_assembled(soa), cfg.to_jitclass(), with_stats=True)
+    return case, cfg, soa, got
+
+
+def test_config2_full_size_one_gpu(ctx, oracle_lib, headline):
+    """configs[2] on one GPU: all 3 000 000 candidates; every 150th row against the oracle (all 46 features
+    incl. the ppm ones, every fragment table, matched-peak counts); planted precursors are found."""
+    case, cfg, soa, got = headline
+    n = len(soa["precursor_idx"])
+    assert n == 3_000_000 and case.dia.mz_values.size > 4.5e8
+    assert 0.85 < got["valid"].mean() <= 1.0
+    idx = np.arange(0, n, 150)
+    exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=_rows(soa, idx), n_threads=THREADS, with_stats=True)
+    compare({k: v[idx] for k, v in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
+    planted = case.apex_cycle[soa["precursor_idx"]] >= 0
+    r0 = planted & (soa["rank"] == 0)
+    assert got["valid"][r0].mean() > 0.99
+    assert np.nanmean(got["features"][r0][:, 20]) > 0.9 > np.nanmean(got["features"][~planted][:, 20])
+    # two observations (precursor on an isolation-window boundary) are part of the workload
+    assert 0.05 < (got["features"][got["valid"].astype(bool)][:, 17] == 2).mean() < 0.4
+
+
+def test_config1_full_size(ctx, headline):
+    """configs[1]: the 100 000-precursor library (the first 100 000 precursors) against the same 2 h run.
+    Scored on its own it gives the rows of the big table, in any order (other chunk cuts, other plan)."""
+    case, cfg, soa, got = headline
+    n1 = 300_000
+    assert len(np.unique(soa["precursor_idx"][:n1])) == 100_000
+    sub = _rows(soa, np.arange(n1))
+    alone = ctx.score_host(pack_assembled(sub), cfg.to_jitclass(), with_stats=True)
+    for k in got:
+        assert np.array_equal(alone[k], got[k][:n1], equal_nan=True), k
+    perm = np.random.default_rng(1).permutation(n1)
+    shuffled = ctx.score_host(pack_assembled(_rows(sub, perm)), cfg.to_jitclass(), with_stats=True)
+    for k in got:
+        assert np.array_equal(shuffled[k], got[k][:n1][perm], equal_nan=True), k
+
+
+def test_config3_full_size_ion_mobility(ctx, oracle_lib):
+    """configs[3]: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 20 000 precursors x 3
+    candidates of 17-39 scans x 7-29 cycles; every 30th candidate against the oracle; permutation invariance."""
+    case = syn.make_timstof_case(
+        n_precursors=20_000, n_cycles=2000, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
+        scan_max_index=918, n_tof=400_000, events_per_push=30.0, mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
+        frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0, planted_fraction=0.3, h_range=(3, 14), hs_range=(9, 19),
+        candidates_on_window=True, sorted_noise=True, threads=THREADS,
+    )
+    assert case.dia.push_indices.size > 4e8 and case.dia.scan_max_index == 918
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True,
+                    experimental_xic=True))
+    cfgj = cfg.to_jitclass()
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    n = len(soa["precursor_idx"])
+    ctx.stage_run(case.dia, force=True)
+    cols = fragment_columns(case.library.fragment_df, "mz_library")
+    ctx.stage_fragments(*cols, force=True)
+    got = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
+    v = got["valid"].astype(bool)
+    assert n == 60_000 and v.mean() > 0.5 and (got["features"][v][:, 29] != 0).mean() > 0.3
+    idx = np.arange(0, n, 30)
+    exp = oracle_lib.score_timstof(case.dia, cols, pack_assembled(_rows(soa, idx)), cfgj, n_threads=THREADS,
+                                   with_stats=True)
+    compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
+    perm = np.random.default_rng(2).permutation(n)
+    shuffled = ctx.score_host(pack_assembled(_rows(soa, perm)), cfgj, with_stats=True)
+    for k in got:
+        assert np.array_equal(shuffled[k], got[k][perm], equal_nan=True), k

@@ -33,6 +33,7 @@ case = syn.make_timstof_case(
     events_per_push=float(os.environ.get("EVENTS_PER_PUSH", 25.0)), mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
     frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0, planted_fraction=float(os.environ.get("PLANTED", 0.3)),
     h_range=(3, 14), hs_range=(9, 19), candidates_on_window=True,
+    sorted_noise=bool(int(os.environ.get("SORTED_NOISE", "1"))), threads=min(32, os.cpu_count() or 8),
 )
 dia = case.dia
 print(f"generated {dia.push_indices.size/1e6:.1f}M events in {time.time()-t0:.1f}s", file=sys.stderr, flush=True)
