@@ -200,7 +200,10 @@ int adh_mlp_stage_rows_device(adh_mlp_t *m, const int32_t *src_cols, int32_t d, 
     m->has_y = false;
     m->proba_ready = false;
     m->n_table = n;
-    if (n == 0) return ADH_OK;
+    if (n == 0) {  // an empty table is staged, with no rows (adh_mlp_staged_rows then succeeds and returns none)
+        HIP_TRY(hipMalloc((void **)&m->d_rowmap, 8));
+        return ADH_OK;
+    }
     const adh_output_t &tab = h->tables[h->last_tables].view;
     Scratch s;
     uint8_t *d_decoy_all = nullptr;
@@ -229,10 +232,11 @@ int adh_mlp_stage_rows_device(adh_mlp_t *m, const int32_t *src_cols, int32_t d, 
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, flag_d, pos_d, (int)n, st));
     }
     // upper bound of the staged rows is n: allocate once, the live count comes back with the scatter
-    HIP_TRY(hipMalloc((void **)&m->d_X, (size_t)n * d * 4));
-    HIP_TRY(hipMalloc((void **)&m->d_Y, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&m->d_rowmap, (size_t)n * 8));
-    HIP_TRY(hipMalloc((void **)&m->d_decoy, (size_t)n));
+    // (at least one element each: an empty table must still count as staged, adh_mlp_staged_rows)
+    HIP_TRY(hipMalloc((void **)&m->d_X, std::max<size_t>((size_t)n * d * 4, 4)));
+    HIP_TRY(hipMalloc((void **)&m->d_Y, std::max<size_t>((size_t)n * 4, 4)));
+    HIP_TRY(hipMalloc((void **)&m->d_rowmap, std::max<size_t>((size_t)n * 8, 8)));
+    HIP_TRY(hipMalloc((void **)&m->d_decoy, std::max<size_t>((size_t)n, 1)));
     hipLaunchKernelGGL(stage_kernel, grid_for(n), dim3(256), 0, st, spec, tab.features, d_decoy_all, flag_t, flag_d, pos_t,
                        pos_d, n, m->d_X, m->d_Y, m->d_rowmap, m->d_decoy, d_counts);
     HIP_TRY(hipGetLastError());

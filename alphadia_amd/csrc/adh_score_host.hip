@@ -836,7 +836,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         if (h->im_scratch_budget) {
             const uint64_t budget = h->im_scratch_budget;
-            const int64_t fit = (int64_t)std::max<uint64_t>(budget / block, 1024);
+            if (block > budget)
+                return fail(ADH_ERR_UNSUPPORTED, "one ion-mobility candidate's tiles exceed a third of the free device memory");
+            const int64_t fit = (int64_t)std::max<uint64_t>(budget / block, 64);  // (the budget holds, down to 64 rows per chunk)
             if (fit < chunk) {
                 const int64_t parts = (n + fit - 1) / fit;
                 chunk = (n + parts - 1) / parts;

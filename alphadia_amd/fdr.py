@@ -304,7 +304,11 @@ class HipBinaryClassifier:
             mlp.stage_rows_device(src_cols, decoy, extra_cols)
             table_rows = mlp.staged_rows()
             y_all = (np.asarray(decoy)[table_rows] != 0).astype(np.float64)
-            base = None if subset is None else np.asarray(subset(len(table_rows)), dtype=np.int64)
+            try:
+                base = None if subset is None else np.asarray(subset(len(table_rows)), dtype=np.int64)
+            except TooFewPSMError as exc:
+                exc.table_rows = table_rows  # the caller answers as perform_fdr does: every staged row, qval 1
+                raise
             self._train(mlp, y_all if base is None else y_all[base], base_rows=base)
         except Exception:
             mlp.close()
@@ -466,14 +470,23 @@ def perform_fdr_resident(classifier, available_columns: list[str], candidates: p
     decoy = candidates["decoy"].to_numpy()
 
     def subset(n_staged):
-        try:
-            return train_test_indices(n_staged, 0.2, random_state)[0]
-        except TooFewPSMError:
-            return np.zeros(0, np.int64)
+        return train_test_indices(n_staged, 0.2, random_state)[0]
 
+    id_columns = [c for c in ("precursor_idx", "rank", "elution_group_idx", "channel", "decoy") if c in candidates.columns]
     if getattr(classifier, "device", device) is None:
         classifier.device = device
-    mlp, table_rows = classifier.fit_resident(src_cols, decoy, extras, subset=subset)
+    try:
+        mlp, table_rows = classifier.fit_resident(src_cols, decoy, extras, subset=subset)
+    except TooFewPSMError as exc:
+        # fdr.py:125-137: too few PSMs for a train / test split -> every usable PSM with qval = proba = 1
+        logger.warning("Too few PSMs for FDR classification, assigning qval=1.0 and proba=1.0 to all PSMs.")
+        rows = np.asarray(getattr(exc, "table_rows", np.zeros(0, np.int64)), dtype=np.int64)
+        out = candidates.iloc[rows][id_columns].copy()
+        out["_decoy"] = out["decoy"].to_numpy().astype(np.float64)
+        out["proba"] = 1.0
+        out["qval"] = 1.0
+        out["table_row"] = rows
+        return out
     try:
         mlp.predict_resident()
         if competitive:
@@ -485,8 +498,7 @@ def perform_fdr_resident(classifier, available_columns: list[str], candidates: p
                                              cycle=dia_cycle, fdr_heuristic=fdr_heuristic)
     finally:
         mlp.close()
-    out = candidates.iloc[rows][[c for c in ("precursor_idx", "rank", "elution_group_idx", "channel", "decoy")
-                                 if c in candidates.columns]].copy()
+    out = candidates.iloc[rows][id_columns].copy()
     out["_decoy"] = out["decoy"].to_numpy().astype(np.float64)
     out["proba"] = proba
     out["qval"] = qval

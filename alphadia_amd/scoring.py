@@ -301,7 +301,7 @@ def merge_missing_columns(left_df, right_df, right_columns, on=None, how="left")
     rows = _row_lookup(right_df, left_df, on) if how == "left" else None
     if rows is None or (rows < 0).any():  # duplicate / non-integer keys, or rows without a partner (NaN fill)
         return left_df.merge(right_df[on + to_add], on=on, how=how)
-    out = left_df.copy()
+    out = left_df.reset_index(drop=True)  # (a fresh RangeIndex, as DataFrame.merge returns)
     for c in to_add:
         out[c] = right_df[c].values[rows]
     return out

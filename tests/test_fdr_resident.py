@@ -80,3 +80,37 @@ def test_resident_fdr_needs_the_tables_it_was_staged_from():
     finally:
         mlp.close()
     assert fdr.perform_fdr_resident is not None
+
+
+def test_resident_fdr_with_too_few_psms_answers_like_the_host_stage():
+    """fdr.py:125-137: when the train / test split would be empty, perform_fdr returns every usable PSM with
+    qval = proba = 1 instead of failing; so does the device-resident stage, also for an empty table."""
+    from alphadia_amd import fdr, runtime
+    from alphadia_amd.scoring import (DEFAULT_FEATURE_COLUMNS, CandidateScoringConfig, HipCandidateScoring,
+                                      assemble_candidates)
+
+    case = syn.make_case(40, 80, config_id=79, per_precursor=1, n_ms2=8, ms1_peaks=400, ms2_peaks=150, mz_lo=400, mz_hi=480,
+                         frag_mz_lo=200, frag_mz_hi=350, ms1_mz_range=(395, 500), ms2_mz_range=(195, 355),
+                         planted_fraction=1.0, threads=1)
+    pdf, fdf = case.library.precursor_df, case.library.fragment_df
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True,
+                    experimental_xic=True))
+    scorer = HipCandidateScoring(dia_data=case.dia, precursors_flat=pdf, fragments_flat=fdf, config=cfg, device=0,
+                                 rt_column="rt_library", mobility_column="mobility_library",
+                                 precursor_mz_column="mz_library", fragment_mz_column="mz_library")
+    cols = [c for c in DEFAULT_FEATURE_COLUMNS if c not in ("mobility_observed", "base_width_mobility")]
+    for keep in (1, 0):  # one candidate: its train split is empty; none at all
+        cands = case.candidates_df.iloc[:keep]
+        features_df, _ = scorer(cands, thread_count=1)
+        soa = assemble_candidates(cands, scorer.precursors_flat_df, "mz_library")
+        meta = pd.DataFrame({"precursor_idx": soa["precursor_idx"], "rank": soa["rank"], "decoy": soa["decoy"],
+                             "elution_group_idx": soa["elution_group_idx"], "channel": soa["channel"]})
+        res = fdr.perform_fdr_resident(fdr.HipBinaryClassifier(epochs=1, random_state=1), cols, meta, random_state=5, device=0)
+        host = fdr.perform_fdr(fdr.HipBinaryClassifier(epochs=1, random_state=1), cols,
+                               features_df[features_df["decoy"] == 0].copy(), features_df[features_df["decoy"] == 1].copy(),
+                               random_state=5, device=0)
+        assert len(res) == len(host) == len(features_df) <= keep
+        assert (res["qval"] == 1.0).all() and (res["proba"] == 1.0).all()
+        assert (host["qval"] == 1.0).all() and (host["proba"] == 1.0).all()
+        assert np.array_equal(res["precursor_idx"].to_numpy(), host["precursor_idx"].to_numpy())

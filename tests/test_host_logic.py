@@ -84,6 +84,15 @@ def test_merge_missing_columns_kat():
         merge_missing_columns(left, right, ["col_5"], on="idx")
     df = merge_missing_columns(left, right, ["col_3"], on="idx")
     assert list(df.columns) == ["idx", "col_1", "col_2", "col_3"]
+    # both code paths (lookup / DataFrame.merge fallback) return a fresh RangeIndex, like DataFrame.merge
+    left = pd.DataFrame({"idx": [3, 1, 2], "a": [30, 10, 20]}, index=[7, 5, 9])
+    right = pd.DataFrame({"idx": [1, 2, 3], "b": [1.5, 2.5, 3.5]})
+    fast = merge_missing_columns(left, right, ["b"], on="idx")
+    slow = left.merge(right[["idx", "b"]], on="idx", how="left")
+    pd.testing.assert_frame_equal(fast, slow)
+    assert list(fast.index) == [0, 1, 2] and list(left.index) == [7, 5, 9]
+    dup = pd.DataFrame({"idx": [1, 1, 2, 3], "b": [1.0, 1.1, 2.0, 3.0]})  # duplicate keys: the merge path
+    assert list(merge_missing_columns(left, dup, ["b"], on="idx").index) == [0, 1, 2, 3]
 
 
 def test_assemble_candidates_order_matches_reference():
