@@ -46,6 +46,9 @@
 #ifndef ADH_FUSED_SCALAR
 #define ADH_FUSED_SCALAR 1     // developer switch: 0 skips the one-lane feature assembly (wrong results; what it costs)
 #endif
+#ifndef ADH_FUSED_NTAB
+#define ADH_FUSED_NTAB 1       // cycle blocks whose bin-table words are requested together (3: one round trip less, 2 % slower)
+#endif
 #ifndef ADH_FUSED_EB
 #define ADH_FUSED_EB 4         // entries per step of a gather task (even)
 #endif
@@ -332,27 +335,43 @@ __device__ __forceinline__ WinBits win_bits(const gather::Window &w) {
     return q;
 }
 
+// the table words of a task: first entry of the bins b_lo .. b_lo + 3 of (block, cycle row), and the end of the
+// window's last bin when it lies further out (a window rarely spans more than three bins)
+struct TabWords {
+    Tab4 v;
+    uint32_t far_end;
+};
+__device__ __forceinline__ const uint32_t *tab_row(const DevRun &run, int row, int blk) {
+    return run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
+}
+__device__ __forceinline__ void task_tab(const DevRun &run, const WinBits &w, bool on, int row, int blk, TabWords &tw) {
+    tw.v.x = tw.v.y = tw.v.z = tw.v.w = 0u;
+    tw.far_end = 0u;
+    if (on) {
+        const uint32_t *t = tab_row(run, row, blk);
+        tw.v = *reinterpret_cast<const Tab4 *>(t + w.b_lo);
+        if (w.b_hi - w.b_lo > 2) tw.far_end = t[w.b_hi + 1];
+    }
+}
 __device__ __forceinline__ void task_begin(const DevRun &run, const WinBits &w, bool on, int row, int blk, int c0,
-                                           int F, Task &k) {
+                                           int F, const TabWords &tw, Task &k) {
     const int bs = run.block_shift;
     k.cyc_base = blk << bs;
     const int f_lo = max(c0, k.cyc_base) - k.cyc_base;
     const int f_hi = min(c0 + F, k.cyc_base + (1 << bs)) - k.cyc_base;
     k.f_lo = (uint32_t)f_lo;
     k.nf = (uint32_t)max(f_hi - f_lo, 0);
-    k.t = run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
+    k.t = tab_row(run, row, blk);
     k.idx = 0;
     k.end = 0;
     k.b_end = 0;
     k.b_end2 = 0;
     if (on) {
-        const Tab4 v = *reinterpret_cast<const Tab4 *>(k.t + w.b_lo);  // first entry of bins b_lo .. b_lo + 3
         const int nb = w.b_hi - w.b_lo;
-        k.idx = v.x;
-        k.end = nb == 0 ? v.y : (nb == 1 ? v.z : v.w);
-        if (nb > 2) k.end = k.t[w.b_hi + 1];  // (a window rarely spans more than three bins)
-        k.b_end = nb == 0 ? k.end : v.y;
-        k.b_end2 = nb <= 1 ? k.end : v.z;
+        k.idx = tw.v.x;
+        k.end = nb == 0 ? tw.v.y : (nb == 1 ? tw.v.z : (nb == 2 ? tw.v.w : tw.far_end));
+        k.b_end = nb == 0 ? k.end : tw.v.y;
+        k.b_end2 = nb <= 1 ? k.end : tw.v.z;
     }
 }
 
@@ -427,6 +446,105 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
     if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
 }
 
+// Precursor features 4-16 (precursor_features.py:13-102; feat::assemble_precursor is the scalar form over LDS
+// arrays): the per-isotope values are read once, every loop over the (at most three) isotopes is unrolled
+// with `i < I` masks - same terms, same order.  wme_term[i] = mass error of isotope i x its intensity, or 0
+// where the isotope was not observed (computed by the isotope's own lane).
+template <int NO>
+__device__ __forceinline__ void precursor_features(float *ft, int I, const float *iso_int_p, const float *iso_mz_p,
+                                                   const float *spi_p, const double *hp_p, const double *wme_term_p,
+                                                   const float (&oi)[NO]) {
+    float ii[3], mz[3], spi[3];
+    double hp[3], wt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ii[i] = iso_int_p[i];
+        mz[i] = iso_mz_p[i];
+        spi[i] = spi_p[i];
+        hp[i] = hp_p[i];
+        wt[i] = wme_term_p[i];
+    }
+    int amax = 0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+        if (i < I && ii[i] > ii[amax == 0 ? 0 : (amax == 1 ? 1 : 2)]) amax = i;
+    float w4 = 0, w5 = 0, f6 = 0, f7 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < I) {
+            float a = 0;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) a += spi[i] * oi[o];
+            if (i == 0) w4 = a;
+            if (i == amax) w5 = a;
+            f6 += a;
+            f7 += a * ii[i];
+        }
+    }
+    ft[4] = w4;
+    ft[5] = w5;
+    ft[6] = f6;
+    ft[7] = f7;
+    double wme = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < I) wme += wt[i];
+    ft[8] = (float)wme;
+    ft[9] = (float)fabs(wme);
+    ft[10] = (float)((double)mz[0] + wme * 1e-6 * (double)mz[0]);
+    ft[11] = (float)hp[0];
+    ft[12] = (float)(amax == 0 ? hp[0] : (amax == 1 ? hp[1] : hp[2]));
+    {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) a += hp[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) b += hp[i] * (double)ii[i];
+        ft[13] = (float)a;
+        ft[14] = (float)b;
+    }
+    {
+        // save_corrcoeff (scoring/utils.py:478-510): (f32, f32) and (f32, f64)
+        float sx = 0, sy = 0;
+        double sh = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sx += ii[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sy += spi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sh += hp[i];
+        const Recip rI((double)max(I, 1));
+        const float xb = (float)rI.div((double)sx), yb = (float)rI.div((double)sy);
+        const double hb = rI.div(sh);
+        float num = 0, sxx = 0, syy = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) num += (ii[i] - xb) * (spi[i] - yb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sxx += (ii[i] - xb) * (ii[i] - xb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) syy += (spi[i] - yb) * (spi[i] - yb);
+        const float den = sqrtf(sxx * syy);
+        ft[15] = (float)((double)num / ((double)den + 1e-12));
+        double numd = 0, shh = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) numd += (double)(ii[i] - xb) * (hp[i] - hb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) shh += (hp[i] - hb) * (hp[i] - hb);
+        const double dend = sqrt((double)sxx * shh);
+        ft[16] = (float)(numd / (dend + 1e-12));
+    }
+}
+
 // one gather pass of a candidate: every lane with a window folds the peaks of its (window, cycle row) into
 // its column of the zeroed tile, cycle block after cycle block
 template <int FM>
@@ -444,14 +562,27 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
     const int n_blk = alive ? ((c0 + F - 1) >> bs) - blk0 + 1 : 0;
     float2 *cells = &tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
     const int roff = FM / 2 - F / 2 - c0;       // centred row of absolute cycle x: x + roff
-    for (int bb = 0; __any(bb < n_blk); bb += NT) {
-        Task t[NT];
+    // the table words of up to NTAB cycle blocks are requested together (one round trip), then block after
+    // block: entries, fold.  (More than one block's ENTRIES in flight costs registers the feature phase needs:
+    // spills, 20 % slower; the table words are 4-5 registers per block.)
+    constexpr int NTAB = ADH_FUSED_NTAB;
+    for (int bb = 0; __any(bb < n_blk); bb += NTAB) {
+        TabWords tw[NTAB];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, t[u]);
+        for (int u = 0; u < NTAB; ++u) task_tab(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, tw[u]);
+#pragma unroll 1
+        for (int u = 0; u < NTAB; ++u) {
+            if (!__any(bb + u < n_blk)) break;
+            TabWords cur = tw[0];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) task_fetch(run, t[u]);
-#pragma unroll
-        for (int u = 0; u < NT; ++u) task_run(run, wb, t[u], cells, roff, hits);
+            for (int j = 1; j < NTAB; ++j) {
+                if (u == j) cur = tw[j];
+            }
+            Task t;
+            task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, cur, t);
+            task_fetch(run, t);
+            task_run(run, wb, t, cells, roff, hits);
+        }
     }
 }
 
@@ -467,6 +598,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     using namespace fused;
     using feat::Assemble;
     constexpr int RC = FM / 2;
+    constexpr int KMAX = ISO0;  // fragments a candidate of this kernel keeps at most
     GroupLds<FM, NO> *lds = reinterpret_cast<GroupLds<FM, NO> *>(smem);
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
@@ -943,7 +1075,8 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     float g_int_l = 0.0f, g_fin_l = 0.0f;
     {
         float sum1 = 0.0f;
-        for (int j = 0; j < K; ++j) sum1 += Q.g_fin[j];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) sum1 += (j < K) ? Q.g_fin[j] : 0.0f;
         if (present) {
             g_int_l = lrec_int / sum1;
             Q.g_int[kk] = g_int_l;
@@ -952,7 +1085,8 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     adh_wave_sync();
     {
         float sum2 = 0.0f;
-        for (int j = 0; j < K; ++j) sum2 += Q.g_int[j];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) sum2 += (j < K) ? Q.g_int[j] : 0.0f;
         if (present) g_fin_l = g_int_l / sum2;
     }
     adh_wave_sync();
@@ -986,45 +1120,56 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     bool hrow = false;
     if (present) {
         // importance-weighted means over observations (fragment_features.py:311-336)
-        float ws = 0.0f;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const bool m = ohe_l[o] > 0;
-            hrow = hrow || m;
-            const float w32 = m ? oi[o] : oi[o] * 0.0f;
-            ws += w32;
-        }
-        double msum = 0.0;
-        int nm = 0;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const bool m = ohe_l[o] > 0;
-            const float w32 = m ? oi[o] : oi[o] * 0.0f;
-            const double wd = (double)w32 / ((double)ws + 1e-20);
-            if (wd > 0) {
-                msum += wd;
-                ++nm;
+        if (NO == 1 && oi[0] == 1.0f) {
+            // one observation of importance 1: w = 1 / (1 + 1e-20) = 1, local weight 1 / 1: the means are the
+            // observation's own values (x * 1.0 and 0.0 + x are exact)
+            hrow = ohe_l[0] > 0;
+            if (hrow) {
+                m1 = omz_l[0];
+                m2 = ohe_l[0];
             }
-        }
-        if (nm > 0) {
+        } else {
+            float ws = 0.0f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const bool m = ohe_l[o] > 0;
+                hrow = hrow || m;
+                const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                ws += w32;
+            }
+            double msum = 0.0;
+            int nm = 0;
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
                 const bool m = ohe_l[o] > 0;
                 const float w32 = m ? oi[o] : oi[o] * 0.0f;
                 const double wd = (double)w32 / ((double)ws + 1e-20);
                 if (wd > 0) {
-                    const double lw = wd / msum;
-                    m1 += omz_l[o] * lw;
-                    m2 += ohe_l[o] * lw;
+                    msum += wd;
+                    ++nm;
+                }
+            }
+            if (nm > 0) {
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const bool m = ohe_l[o] > 0;
+                    const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                    const double wd = (double)w32 / ((double)ws + 1e-20);
+                    if (wd > 0) {
+                        const double lw = wd / msum;
+                        m1 += omz_l[o] * lw;
+                        m2 += ohe_l[o] * lw;
+                    }
                 }
             }
         }
         merr_l = (m1 - (double)lrec_mz) / (double)lrec_mz * 1e6;  // fragment_features.py:387
         Q.merr[kk] = merr_l;
         int rk = 0;
-        for (int j = 0; j < K; ++j) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {  // (all reads first: one LDS round trip, not K)
             const float ib = Q.g_int[j];
-            rk += (ib > g_int_l) || (ib == g_int_l && j > kk);
+            rk += (j < K) && ((ib > g_int_l) || (ib == g_int_l && j > kk));
         }
         Q.ord[rk] = kk;  // position in argsort(intensity)[::-1]
     }
@@ -1032,21 +1177,12 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     if (stop_phase == 5) return;
 
     if (alive && sub < 4) Q.feat[sub] = loc;
-    adh_wave_sync();
-    if (ADH_FUSED_SCALAR && alive && sub == 0) {
-        Assemble asmv;
-        asmv.run = nullptr;  // features 0-3 are in place
-        asmv.rec = &rec;
-        asmv.featv = Q.feat;
-        asmv.iso_int = KP.iso_int; asmv.iso_mz = KP.iso_mz; asmv.spi = KP.spi; asmv.oi = Q.oi;
-        asmv.omzp = KP.omzp; asmv.hp = KP.hp;
-        asmv.n_present = n_present; asmv.K0 = K0;
-        feat::assemble_precursor(asmv, I, NO);
-    }
     // ---- fragment features 17-27, 41-45 (fragment_features.py:198-427; the scalar form is
-    // feat::assemble_fragments).  Every sum over fragments keeps the reference's order
-    // (k ascending) but all sums advance together: lane k provides its term of every sum,
-    // then lane j adds up sum j.  Skipped terms are added as +0, which leaves a sum unchanged.
+    // feat::assemble_fragments) and precursor features 4-16, 28 (precursor_features.py:13-102).  Every sum
+    // over fragments keeps the reference's order (k ascending) but all sums advance together: lane k provides
+    // its term of every sum, then lane j adds up sum j (skipped terms are added as +0, which leaves a sum
+    // unchanged) and finishes the features that hang on it: one float64 division and one log for the whole
+    // candidate, each lane dividing its own operands.
     const bool ipos = present && obs_int > 0.0f;
     const bool hpos = present && m2 > 0.0;
     const bool isb = present && rec_type(lrec) == 98, isy = present && rec_type(lrec) == 121;
@@ -1095,25 +1231,77 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     }
     adh_wave_sync();
     {
+        // lane j < 6: float64 sum j; 6 <= j < 11: float32 sum j - 6; lane 11: mean_top3 mass error, by rank
         double s64 = 0.0;
         float s32 = 0.0f;
-        if (sub < 6) {
-            for (int k = 0; k < K; ++k) s64 += Q.u.at.t64[k][sub];
-            Q.red64[sub] = s64;
-        } else if (sub < 11) {
-            for (int k = 0; k < K; ++k) s32 += Q.u.at.t32[k][sub - 6];
-            Q.red32[sub - 6] = s32;
-        } else if (sub == 11) {
-            for (int i = 0; i < n3; ++i) s64 += Q.merr[Q.ord[i]];  // mean_top3 mass error, by rank
-            Q.red64[6] = s64;
+        {
+            double v64[KMAX];
+            float v32[KMAX];
+            const int c64 = min(sub, 5), c32 = min(max(sub - 6, 0), 5);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                v64[k] = Q.u.at.t64[k][c64];
+                v32[k] = Q.u.at.t32[k][c32];
+            }
+            if (sub == 11) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v64[i] = Q.merr[i < n3 ? Q.ord[i] : 0];
+            }
+            const int n64 = sub == 11 ? n3 : K;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                s64 += (k < n64) ? v64[k] : 0.0;
+                s32 += (k < K) ? v32[k] : 0.0f;
+            }
+        }
+        // ---- the quotients: lane -> (numerator, denominator)
+        //   0-2 sums of area / height / intensity over K (np.corrcoef means), 3 mass error / K (42),
+        //   4, 5 overlap area / mass error over n_ov (44, 45), 6 n_int / K (20), 7 n_hei / K (21),
+        //   8 cosine sum / n_int (24), 11 top-3 mass error / n3 (41), 12 + i the mass error of isotope i
+        //   (precursor_features.py:40-50), 15 n_present / K0 (28, candidate.py:362)
+        double num = s64, den = (double)K;
+        if (sub == 4 || sub == 5) den = (double)n_ov;
+        if (sub == 6) num = (double)n_int;
+        if (sub == 7) num = (double)n_hei;
+        if (sub == 8) num = (double)s32, den = (double)n_int;
+        if (sub == 11) den = (double)n3;
+        double omzp_i = 0.0;
+        if (sub >= ISO0 && sub < 15) {
+            const int i = sub - ISO0;
+            omzp_i = KP.omzp[i];
+            num = omzp_i - (double)KP.iso_mz[i];
+            den = (double)KP.iso_mz[i];
+        }
+        if (sub == 15) num = (double)n_present, den = (double)K0;
+        const double quo = num / den;
+        if (sub < 3) Q.red64[sub] = quo;
+        if (sub == 1) Q.red64[3] = s64;  // (the sum of the heights decides whether feature 19 is taken)
+        if (sub >= ISO0 && sub < 15) {
+            const double me = quo * 1e6;
+            Q.red64[4 + sub - ISO0] = (omzp_i > 0) ? me * (double)KP.iso_int[sub - ISO0] : 0.0;
+        }
+        if (ADH_FUSED_SCALAR && alive) {
+            float *ft = Q.feat;
+            if (sub == 3) ft[42] = (float)quo;
+            if ((sub == 4 || sub == 5) && nb > 0 && ny > 0) {
+                if (sub == 4) ft[43] = (float)n_ov;
+                ft[40 + sub] = n_ov > 0 ? (float)quo : (sub == 4 ? 0.0f : 15.0f);
+            }
+            if (sub == 6) ft[22] = s32, ft[20] = (float)quo;
+            if (sub == 7) ft[23] = s32, ft[21] = (float)quo;
+            if (sub == 8 && n_int > 0) ft[24] = (float)quo;
+            if (sub == 9 || sub == 10) {
+                const float lg = (float)log((double)s32 + 1.0);
+                ft[16 + sub] = ((sub == 9 ? nb : ny) > 0) ? lg : 0.0f;
+            }
+            if (sub == 11) ft[41] = (float)quo;
+            if (sub == 15) ft[28] = (float)quo, ft[17] = (float)NO;
         }
     }
     adh_wave_sync();
     {
         // np.corrcoef terms (feat::corrcoef01): area vs intensity, height vs intensity
-        const double mx_a = Q.red64[0] / (double)K, mx_h = Q.red64[1] / (double)K;
-        const double my = Q.red64[2] / (double)K;
-        adh_wave_sync();
+        const double mx_a = Q.red64[0], mx_h = Q.red64[1], my = Q.red64[2];
         if (present) {
             const double a = area - mx_a, h = m2 - mx_h, b = (double)g_fin_l - my;
             double *t = Q.u.at.t64[kk];
@@ -1125,10 +1313,14 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
     }
     adh_wave_sync();
-    if (sub < 5) {
-        double s64 = 0.0;
-        for (int k = 0; k < K; ++k) s64 += Q.u.at.t64[k][sub];
-        Q.red64[7 + sub] = s64;
+    {
+        double v64[KMAX], s64 = 0.0;
+        const int c64 = min(sub, 4);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v64[k] = Q.u.at.t64[k][c64];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) s64 += (k < K) ? v64[k] : 0.0;
+        if (sub < 5) Q.red64[7 + sub] = s64;
     }
     adh_wave_sync();
     if (ADH_FUSED_SCALAR && alive && sub < 2) {
@@ -1140,33 +1332,12 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         const double s0 = sqrt(cxx), s1 = sqrt(cyy);
         double cc = cxy / s1 / s0;
         if (fabs(cc) > 1.0) cc = (cc > 0) ? 1.0 : -1.0;
-        const bool on = sub ? (Q.red64[1] > 0.0) : (n_hrows > 0);
+        const bool on = sub ? (Q.red64[3] > 0.0) : (n_hrows > 0);
         if (on) Q.feat[18 + sub] = (float)cc;
     }
-    if (ADH_FUSED_SCALAR && alive && sub == 0) {
-        float *ft = Q.feat;
-        ft[17] = (float)NO;
-        ft[20] = (float)((double)n_int / (double)K);
-        ft[21] = (float)((double)n_hei / (double)K);
-        ft[22] = Q.red32[0];
-        ft[23] = Q.red32[1];
-        if (n_int > 0) ft[24] = (float)((double)Q.red32[2] / (double)n_int);
-        ft[25] = nb > 0 ? (float)log((double)Q.red32[3] + 1.0) : 0.0f;
-        ft[26] = ny > 0 ? (float)log((double)Q.red32[4] + 1.0) : 0.0f;
-        ft[27] = ft[25] - ft[26];
-        ft[41] = (float)(Q.red64[6] / (double)n3);
-        ft[42] = (float)(Q.red64[3] / (double)K);
-        if (nb > 0 && ny > 0) {
-            ft[43] = (float)n_ov;
-            if (n_ov > 0) {
-                ft[44] = (float)(Q.red64[4] / (double)n_ov);
-                ft[45] = (float)(Q.red64[5] / (double)n_ov);
-            } else {
-                ft[44] = 0.0f;
-                ft[45] = 15.0f;
-            }
-        }
-    }
+    if (ADH_FUSED_SCALAR && alive && sub == 2) Q.feat[27] = Q.feat[25] - Q.feat[26];
+    if (ADH_FUSED_SCALAR && alive && sub == 3)
+        precursor_features<NO>(Q.feat, I, KP.iso_int, KP.iso_mz, KP.spi, KP.hp, &Q.red64[4], oi);
     if (stop_phase == 6) return;
 
     // ================= profile features (profile_features.py:18-206), experimental_xic =======
