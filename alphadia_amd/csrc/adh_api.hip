@@ -116,6 +116,9 @@ struct DevTables {
     int64_t rows = 0;
     int top_k = 0;
     adh_output_t view{};
+    // the last call left the columns that repeat ids / the library unwritten (adh_score_candidates rebuilds them
+    // on the host): a reader of the device tables has them filled in first (materialise_tables)
+    bool partial = false;
 };
 
 struct adh_comm_state;

@@ -302,6 +302,10 @@ int adh_fdr_resident(adh_handle_t *h, adh_mlp_t *m, const int64_t *group_a, cons
     const int out_dim = m->A.dims[m->A.n_linear];
     *n_out = 0;
     if (n0 == 0) return ADH_OK;
+    {
+        const int rc_m = materialise_tables(h);  // (fragment competition reads fragment_mz_library)
+        if (rc_m != ADH_OK) return rc_m;
+    }
     const adh_output_t &tab = h->tables[h->last_tables].view;
     Scratch s;
     // per-candidate keys (host, one int64 each) -> device

@@ -785,20 +785,22 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         const int n = min(K, top_k);
         const int64_t base = (int64_t)row * top_k;
         for (int k = lane; k < n; k += ADH_WAVE) {
-            out.fragment_precursor_idx[base + k] = r.precursor_idx;
-            out.fragment_rank[base + k] = r.rank;
-            out.fragment_mz_library[base + k] = g_mzlib[k];
-            out.fragment_mz[base + k] = g_mz[k];
+            if (out.fragment_precursor_idx) {  // (NULL: the columns that repeat ids / the library are rebuilt later)
+                out.fragment_precursor_idx[base + k] = r.precursor_idx;
+                out.fragment_rank[base + k] = r.rank;
+                out.fragment_mz_library[base + k] = g_mzlib[k];
+                out.fragment_mz[base + k] = g_mz[k];
+                out.fragment_position[base + k] = g_pos[k];
+                out.fragment_number[base + k] = g_number[k];
+                out.fragment_type[base + k] = g_type[k];
+                out.fragment_charge[base + k] = g_charge[k];
+                out.fragment_loss_type[base + k] = g_loss[k];
+            }
             out.fragment_mz_observed[base + k] = (float)mzmean[k];
             out.fragment_height[base + k] = (float)height[k];
             out.fragment_intensity[base + k] = (float)area[k];
             out.fragment_mass_error[base + k] = (float)merr[k];
             out.fragment_correlation[base + k] = corr[k];
-            out.fragment_position[base + k] = g_pos[k];
-            out.fragment_number[base + k] = g_number[k];
-            out.fragment_type[base + k] = g_type[k];
-            out.fragment_charge[base + k] = g_charge[k];
-            out.fragment_loss_type[base + k] = g_loss[k];
             if (out.fragment_lib_slot) {
                 const LibRec pick = reinterpret_cast<const LibRec *>(block + 32)[kmap[k]];
                 out.fragment_lib_slot[base + k] = (uint16_t)(1 + pick.pad0 + 256 * pick.pad1);

@@ -933,20 +933,22 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         }
         if (cfg.collect_fragments && present && kk < top_k) {
             const int64_t o = (int64_t)row * top_k + kk;
-            out.fragment_precursor_idx[o] = rec.precursor_idx;
-            out.fragment_rank[o] = rec.rank;
-            out.fragment_mz_library[o] = lrec.mz_library;
-            out.fragment_mz[o] = lrec.mz;
+            if (out.fragment_precursor_idx) {  // (NULL: the columns that repeat ids / the library are rebuilt later)
+                out.fragment_precursor_idx[o] = rec.precursor_idx;
+                out.fragment_rank[o] = rec.rank;
+                out.fragment_mz_library[o] = lrec.mz_library;
+                out.fragment_mz[o] = lrec.mz;
+                out.fragment_position[o] = lrec.position;
+                out.fragment_number[o] = lrec.number;
+                out.fragment_type[o] = lrec.type;
+                out.fragment_charge[o] = lrec.charge;
+                out.fragment_loss_type[o] = lrec.loss_type;
+            }
             out.fragment_mz_observed[o] = (float)m1;
             out.fragment_height[o] = (float)m2;
             out.fragment_intensity[o] = (float)area;
             out.fragment_mass_error[o] = (float)merr_l;
             out.fragment_correlation[o] = corr_l;
-            out.fragment_position[o] = lrec.position;
-            out.fragment_number[o] = lrec.number;
-            out.fragment_type[o] = lrec.type;
-            out.fragment_charge[o] = lrec.charge;
-            out.fragment_loss_type[o] = lrec.loss_type;
             if (out.fragment_lib_slot) out.fragment_lib_slot[o] = (uint16_t)(1 + lrec.pad0 + 256 * lrec.pad1);
         }
         if (sub == 0) out.valid[row] = 1;

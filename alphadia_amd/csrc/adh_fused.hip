@@ -610,7 +610,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     const CandRec &rec = plan[alive ? ci : 0];
     alive = alive && !(rec.flags & ADH_FLAG_SKIP);
     const uint32_t row = rec.row;
-    if (alive && sub == 0) {
+    if (alive && sub == 0 && out.precursor_idx) {
         out.precursor_idx[row] = rec.precursor_idx;  // candidate.py:175-176
         out.rank[row] = rec.rank;
     }
@@ -1469,34 +1469,35 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
     }
     adh_wave_sync();
-    if (sub < 6) {
-        float s32 = 0.0f;
-        for (int k = 0; k < K; ++k) s32 += Q.u.at.t32[k][sub];
-        Q.red32[sub] = s32;
-    }
-    adh_wave_sync();
-    if (ADH_FUSED_SCALAR && alive && sub == 0) {
-        float *ft = Q.feat;
-        ft[31] = (float)((double)Q.red32[0] / (double)K);
-        ft[32] = (float)((double)Q.red32[5] / (double)n3);
-        ft[33] = Q.red32[1];
-        if (nb > 0) {
-            ft[34] = (float)((double)Q.red32[3] / (double)min(nb, 3));
-            ft[35] = (float)nb;
-        }
-        if (ny > 0) {
-            ft[36] = (float)((double)Q.red32[4] / (double)min(ny, 3));
-            ft[37] = (float)ny;
-        }
-        ft[38] = Q.red32[2];
-        double acc = 0.0;
+    {
+        // lane j < 6 adds up sum j and finishes its feature (one division for all of them); lane 6: feature 40
+        float v32[KMAX], s32 = 0.0f;
+        const int c32 = min(sub, 5);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const double med = (K & 1) ? (double)Q.medhi[o] : (double)(Q.medlo[o] + Q.medhi[o]) / 2.0;
-            const float medpk = (float)med;
-            acc += ((double)medpk - floor((double)F / 2.0)) * (double)Q.oi[o];
+        for (int k = 0; k < KMAX; ++k) v32[k] = Q.u.at.t32[k][c32];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) s32 += (k < K) ? v32[k] : 0.0f;
+        const int dn = sub == 0 ? K : (sub == 5 ? n3 : (sub == 3 ? min(nb, 3) : min(ny, 3)));
+        const double quo = (double)s32 / (double)dn;
+        if (ADH_FUSED_SCALAR && alive) {
+            float *ft = Q.feat;
+            if (sub == 0) ft[31] = (float)quo;
+            if (sub == 5) ft[32] = (float)quo;
+            if (sub == 1) ft[33] = s32;
+            if (sub == 2) ft[38] = s32;
+            if (sub == 3 && nb > 0) ft[34] = (float)quo, ft[35] = (float)nb;
+            if (sub == 4 && ny > 0) ft[36] = (float)quo, ft[37] = (float)ny;
+            if (sub == 6) {
+                double acc = 0.0;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const double med = (K & 1) ? (double)Q.medhi[o] : (double)(Q.medlo[o] + Q.medhi[o]) / 2.0;
+                    const float medpk = (float)med;
+                    acc += ((double)medpk - floor((double)F / 2.0)) * (double)oi[o];
+                }
+                ft[40] = (float)acc;
+            }
         }
-        ft[40] = (float)acc;
     }
     adh_wave_sync();
 
@@ -1509,20 +1510,22 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
         if (cfg.collect_fragments && present && kk < top_k) {
             const int64_t o = (int64_t)row * top_k + kk;
-            out.fragment_precursor_idx[o] = rec.precursor_idx;
-            out.fragment_rank[o] = rec.rank;
-            out.fragment_mz_library[o] = __uint_as_float(lrec.a.x);
-            out.fragment_mz[o] = lrec_mz;
+            if (out.fragment_precursor_idx) {  // (NULL: the columns that repeat ids / the library are rebuilt later)
+                out.fragment_precursor_idx[o] = rec.precursor_idx;
+                out.fragment_rank[o] = rec.rank;
+                out.fragment_mz_library[o] = __uint_as_float(lrec.a.x);
+                out.fragment_mz[o] = lrec_mz;
+                out.fragment_position[o] = (uint8_t)lpos;
+                out.fragment_number[o] = (uint8_t)(lrec.a.w >> 24);
+                out.fragment_type[o] = (uint8_t)(lrec.a.w & 0xFFu);
+                out.fragment_charge[o] = (uint8_t)((lrec.a.w >> 16) & 0xFFu);
+                out.fragment_loss_type[o] = (uint8_t)((lrec.a.w >> 8) & 0xFFu);
+            }
             out.fragment_mz_observed[o] = (float)m1;
             out.fragment_height[o] = (float)m2;
             out.fragment_intensity[o] = (float)area;
             out.fragment_mass_error[o] = (float)merr_l;
             out.fragment_correlation[o] = corr_l;
-            out.fragment_position[o] = (uint8_t)lpos;
-            out.fragment_number[o] = (uint8_t)(lrec.a.w >> 24);
-            out.fragment_type[o] = (uint8_t)(lrec.a.w & 0xFFu);
-            out.fragment_charge[o] = (uint8_t)((lrec.a.w >> 16) & 0xFFu);
-            out.fragment_loss_type[o] = (uint8_t)((lrec.a.w >> 8) & 0xFFu);
             if (out.fragment_lib_slot) out.fragment_lib_slot[o] = (uint16_t)(1u + (lrec.b >> 16));
         }
         if (sub == 0) out.valid[row] = 1;

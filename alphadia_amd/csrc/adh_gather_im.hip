@@ -110,7 +110,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     const CandRecIM &r = plan[blockIdx.x];
     if (r.flags & ADH_FLAG_SKIP) return;
     const uint32_t row = r.row;
-    if (lane == 0) {
+    if (lane == 0 && out.precursor_idx) {
         out.precursor_idx[row] = r.precursor_idx;  // candidate.py:175-176
         out.rank[row] = r.rank;
     }

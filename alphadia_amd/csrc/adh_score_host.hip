@@ -652,6 +652,63 @@ int64_t pick_chunk(int64_t n) {
 
 }  // namespace
 
+}  // extern "C"
+
+// The columns of the device tables that repeat the candidate table (precursor_idx, rank) or the library (per
+// fragment slot) from fragment_lib_slot: the device-side twin of rebuild_host_rows, one thread per slot.
+__global__ void adh_rebuild_columns_kernel(DevCands c, const LibRec *__restrict__ lib, DevOut out, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int top_k = out.top_k;
+    if (t >= n * top_k) return;
+    const int64_t i = t / top_k;
+    const int j = (int)(t - i * top_k);
+    const bool skip = c.flags && (c.flags[i] & ADH_FLAG_SKIP);
+    const uint32_t p = skip ? 0u : c.precursor_idx[i];
+    const uint8_t r = skip ? (uint8_t)0 : c.rank[i];
+    if (j == 0) {
+        out.precursor_idx[i] = p;
+        out.rank[i] = r;
+    }
+    const uint16_t s = out.fragment_lib_slot[t];
+    if (!s) return;  // (the tables were zeroed before the kernels ran)
+    const LibRec l = lib[c.frag_start[i] + s - 1];
+    out.fragment_precursor_idx[t] = p;
+    out.fragment_rank[t] = r;
+    out.fragment_mz_library[t] = l.mz_library;
+    out.fragment_mz[t] = l.mz;
+    out.fragment_position[t] = l.position;
+    out.fragment_number[t] = l.number;
+    out.fragment_type[t] = l.type;
+    out.fragment_charge[t] = l.charge;
+    out.fragment_loss_type[t] = l.loss_type;
+}
+
+extern "C" {
+
+namespace {
+
+// fill in what a host -> host call left out of the device tables (DevTables::partial) before somebody reads them
+int materialise_tables(adh_handle *h) {
+    if (h->last_tables < 0) return ADH_OK;
+    DevTables &t = h->tables[h->last_tables];
+    if (!t.partial) return ADH_OK;
+    const int64_t n = h->last_rows;
+    if (n > 0) {
+        HIP_TRY(hipSetDevice(h->device));
+        adh_output_t view = t.view;
+        view.n = n;
+        const int64_t threads = n * (int64_t)view.top_k;
+        hipLaunchKernelGGL(adh_rebuild_columns_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, h->cs.d,
+                           h->d_lib, view, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    t.partial = false;
+    return ADH_OK;
+}
+
+}  // namespace
+
 int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
     if (!h || !c) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     int rc = check_candidate_args(h, c);
@@ -813,6 +870,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     dev.n = n;
     hipStream_t sk = h->stream, si = h->stream_in, so = h->stream_out;
     HIP_TRY(hipMemsetAsync(tab.base, 0, tab.used, sk));
+    tab.partial = false;
 
     // chunk boundaries: a short first chunk (its H2D, plan and kernels are the un-overlapped ramp
     // of the D2H-bound pipeline), then equal chunks
@@ -859,6 +917,16 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         slot_host = static_cast<uint16_t *>(h->slot_stage);
     }
+    adh_output_t dev_k = dev;  // what the kernels write
+    if (rebuild && !getenv("ADH_DEBUG_WRITE_ALL")) {
+        // ... and the kernels need not write them either: nobody on the host waits for them, and a reader of the
+        // device tables (adh_get_device_tables, the resident FDR stage) gets them filled in on demand
+        for (int i = 0; i < kNumOutFields; ++i) {
+            const OutFieldDesc &f = kOutFields[i];
+            if (!f.wire && f.member != offsetof(adh_output_t, stat_matched_peaks)) *out_member(&dev_k, f) = nullptr;
+        }
+        tab.partial = true;
+    }
     std::vector<hipEvent_t> chunk_done;
     std::vector<int64_t> cut{0};
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
@@ -892,7 +960,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         Plan p;
         rc = plan_finish(h, h->slots[ps], cfg, a, b - a, p);
-        if (rc == ADH_OK) rc = launch_scoring(h, p, cfg, &dev, sk);
+        if (rc == ADH_OK) rc = launch_scoring(h, p, cfg, &dev_k, sk);
         if (rc != ADH_OK) return fail_sync(rc);
         HIP_TRY(hipEventRecord(h->ev_k[ps], sk));
         HIP_TRY(hipStreamWaitEvent(so, h->ev_k[ps], 0));
@@ -1024,6 +1092,8 @@ int adh_table_layout(int64_t rows, int32_t top_k, int32_t capacity, adh_table_fi
 int adh_get_device_tables(adh_handle_t *h, adh_output_t *device_view) {
     if (!h || !device_view) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (h->last_tables < 0) return fail(ADH_ERR_NOT_STAGED, "no adh_score_candidates call has filled the device tables");
+    const int rc = materialise_tables(h);
+    if (rc != ADH_OK) return rc;
     *device_view = h->tables[h->last_tables].view;
     device_view->n = h->last_rows;
     return ADH_OK;
