@@ -348,7 +348,7 @@ int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, in
     if ((rc = dev_alloc(&sort_tmp, std::max<size_t>(sort_bytes, 16))) != ADH_OK) return rc;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
     hipLaunchKernelGGL(adh_entries_kernel, dim3(8192), dim3(256), 0, st, k_out, v_out, d_int, n_ref,
-                       entries, tab, n_tab);
+                       entries, tab, n_tab, (int)r.block_shift);
     HIP_TRY(hipGetLastError());
     int bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
@@ -435,6 +435,7 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     // the table must stay addressable with 32-bit bin ids and should not dwarf the peaks
     for (;; ++bs) {
         int64_t nblk = std::max<int64_t>((n_cycles + (1ll << bs) - 1) >> bs, 1);
+        nblk = (nblk + ADH_SUB - 1) / ADH_SUB * ADH_SUB;  // whole groups of blocks (adh_device.h)
         int64_t n_tab = nblk * L * (int64_t)r.n_bins + 1;
         if (bs >= 20 || (n_tab < (int64_t)0xFFFFFFF0ll && n_tab * 4 <= std::max<int64_t>(2 * n_ref * 8, 64ll << 20))) {
             r.n_blocks = (int32_t)nblk;

@@ -26,12 +26,22 @@
 #ifndef ADH_BIN_SHIFT
 #define ADH_BIN_SHIFT 9
 #endif
+// Cycles are cut into blocks of 2^block_shift cycles (the granularity of the bin table) and blocks into
+// groups of ADH_SUB blocks (the granularity of the sort): inside a (group, cycle row, m/z bin) the entries
+// of consecutive blocks follow each other, so the two or three blocks a candidate spans are ONE run of
+// entries per bin and their table words are neighbours - half the random line fetches of a layout sorted
+// block by block (what bounds the gather).
+#define ADH_SUB_SHIFT 3
+#define ADH_SUB (1 << ADH_SUB_SHIFT)
 
 struct DevRun {
-    // peaks sorted by (block of 2^block_shift cycles, cycle row, m/z bin, cycle, m/z):
-    // .x = (cycle inside the block << ADH_BIN_SHIFT) | low m/z bits, .y = intensity bits
+    // peaks sorted by (group of ADH_SUB blocks, cycle row, m/z bin, cycle, m/z):
+    // .x = (cycle inside the GROUP << ADH_BIN_SHIFT) | low m/z bits, .y = intensity bits
     const uint2 *entries;
-    const uint32_t *tab;      // [(n_blocks * cycle_len) * n_bins + 1] first entry of every bin
+    // [((n_blocks / ADH_SUB * cycle_len + row) * n_bins + bin) * ADH_SUB + block in group] (+ 1): first entry of
+    // the (group, row, bin) that lies in that block or a later one; the word after a bin's last block is the
+    // next bin's first, so entries of blocks sb0 .. sb1 of a bin are [t[bin * ADH_SUB + sb0], t[bin * ADH_SUB + sb1 + 1])
+    const uint32_t *tab;
     const float *rt;          // [n_spectra]
     const float *mobility;    // [n_mobility]
     const double *cycle;      // [cycle_len * cycle_scans * 2]
@@ -44,7 +54,7 @@ struct DevRun {
     int32_t n_bins;           // m/z bins per (block, row)
     int32_t bin0;             // bit pattern >> ADH_BIN_SHIFT of the smallest m/z
     int32_t block_shift;      // log2(cycles per block)
-    int32_t n_blocks;
+    int32_t n_blocks;         // blocks, padded to whole groups
     float mz_min, mz_max;     // smallest / largest m/z of the run
 };
 
@@ -172,6 +182,11 @@ __device__ __forceinline__ void adh_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// table row of (group of blocks, cycle row): index it with bin * ADH_SUB + block inside the group
+__device__ __forceinline__ const uint32_t *adh_tab_row(const DevRun &run, int row, int blk) {
+    return run.tab + (((int64_t)(blk >> ADH_SUB_SHIFT) * run.cycle_len + row) * (int64_t)run.n_bins << ADH_SUB_SHIFT);
 }
 
 typedef adh_output_t DevOut;

@@ -37,17 +37,13 @@
 #define ADH_FUSED_WAVES 3      // wavefronts per SIMD the register budget is held to
 #endif
 #ifndef ADH_FUSED_WAVES2
-#define ADH_FUSED_WAVES2 3     // ... of the two-observation kernels
-#endif
-#ifndef ADH_FUSED_NT
-#define ADH_FUSED_NT 1         // gather tasks (cycle blocks) of a lane in flight (same-box A/B, fused kernels per 3 M
-                               // candidates: 1 -> 14.0 ms, 2 -> 14.9 ms, 3 -> 17.8 ms: registers, not loads in flight)
+#define ADH_FUSED_WAVES2 2     // ... of the two-observation kernels (3: spills, 15 % slower; same-box A/B)
 #endif
 #ifndef ADH_FUSED_SCALAR
-#define ADH_FUSED_SCALAR 1     // developer switch: 0 skips the one-lane feature assembly (wrong results; what it costs)
+#define ADH_FUSED_SCALAR 1     // developer switch: 0 skips the feature assembly of single lanes (wrong results; what it costs)
 #endif
-#ifndef ADH_FUSED_NTAB
-#define ADH_FUSED_NTAB 1       // cycle blocks whose bin-table words are requested together (3: one round trip less, 2 % slower)
+#ifndef ADH_FUSED_AHEAD
+#define ADH_FUSED_AHEAD 1      // 1: the entries of the step after next are requested while a step is folded; 0: step by step
 #endif
 #ifndef ADH_FUSED_EB
 #define ADH_FUSED_EB 4         // entries per step of a gather task (even)
@@ -296,15 +292,14 @@ __device__ __forceinline__ void profile_stats(const float (&P)[FM], const float 
     fpeak = am + shift;
 }
 
-// one (window, cycle row, block) gather task, split in three so that the table words and the first
-// entries of ALL tasks of a lane are in flight before the first one is consumed: a candidate's gather is
-// a chain of dependent round trips (record -> library slice -> bin table -> entries), and with the
-// registers of the feature phase only three wavefronts share a SIMD, so every link that can be removed
-// counts.  Four table words and two entries travel per load (they are neighbours in memory: 4- and 8-byte
-// aligned vector loads), and a lane only asks for entries it has: a scattered load costs the L1 one tag
-// look-up per lane and line, which is what this phase is bound by.
+// One gather task = one m/z bin of a window inside one GROUP of cycle blocks (adh_device.h): the entries of
+// the blocks a candidate spans are one contiguous run there, sorted by (cycle, m/z), and their first / last
+// table words sit next to each other.  A candidate of up to 32 cycles meets one or two groups, a window one or
+// two bins (rarely more): per window ~2 table lines and ~2 entry lines travel, where the block-by-block
+// layout needed ~5.  A scattered load costs the memory system one line per lane: that, not arithmetic or the
+// length of the dependency chain, is what bounds the gather (measured: coarser bins, larger blocks, more
+// loads in flight and fewer instructions all left its time where it was or made it worse).
 constexpr int EB = ADH_FUSED_EB;  // entries fetched per step
-constexpr int NT = ADH_FUSED_NT;  // tasks (cycle blocks) of a lane in flight
 struct __attribute__((packed, aligned(4))) Tab4 {
     uint32_t x, y, z, w;
 };
@@ -312,10 +307,11 @@ struct __attribute__((packed, aligned(8))) Ent2 {
     uint2 a, b;
 };
 struct Task {
-    const uint32_t *t;
-    uint32_t idx, end, b_end, b_end2;
-    int cyc_base;
-    uint32_t f_lo, nf;        // block-relative cycles [f_lo, f_lo + nf)
+    uint32_t idx, end;
+    uint32_t bin_bits;        // (bin0 + bin) << ADH_BIN_SHIFT: the upper bits of every m/z of the bin
+    int grp_base;             // first cycle of the group
+    uint32_t f_lo, nf;        // group-relative cycles [f_lo, f_lo + nf)
+    bool first_bin;           // no earlier bin of the window has touched the cells
     uint2 e[EB], n[EB];       // entries of the current and of the next step
 };
 // the window as the gather sees it: bins and the float32 bounds as bit patterns (positive floats order
@@ -335,43 +331,30 @@ __device__ __forceinline__ WinBits win_bits(const gather::Window &w) {
     return q;
 }
 
-// the table words of a task: first entry of the bins b_lo .. b_lo + 3 of (block, cycle row), and the end of the
-// window's last bin when it lies further out (a window rarely spans more than three bins)
-struct TabWords {
-    Tab4 v;
-    uint32_t far_end;
-};
-__device__ __forceinline__ const uint32_t *tab_row(const DevRun &run, int row, int blk) {
-    return run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
-}
-__device__ __forceinline__ void task_tab(const DevRun &run, const WinBits &w, bool on, int row, int blk, TabWords &tw) {
-    tw.v.x = tw.v.y = tw.v.z = tw.v.w = 0u;
-    tw.far_end = 0u;
-    if (on) {
-        const uint32_t *t = tab_row(run, row, blk);
-        tw.v = *reinterpret_cast<const Tab4 *>(t + w.b_lo);
-        if (w.b_hi - w.b_lo > 2) tw.far_end = t[w.b_hi + 1];
-    }
-}
-__device__ __forceinline__ void task_begin(const DevRun &run, const WinBits &w, bool on, int row, int blk, int c0,
-                                           int F, const TabWords &tw, Task &k) {
-    const int bs = run.block_shift;
-    k.cyc_base = blk << bs;
-    const int f_lo = max(c0, k.cyc_base) - k.cyc_base;
-    const int f_hi = min(c0 + F, k.cyc_base + (1 << bs)) - k.cyc_base;
+// entries of the blocks sb0 .. sb1 of bin b of (group, row): [t[b * ADH_SUB + sb0], t[b * ADH_SUB + sb1 + 1])
+__device__ __forceinline__ void task_begin(const DevRun &run, bool on, int row, int grp, int sb0, int sb1, int b,
+                                           int b_lo, int c0, int F, Task &k) {
+    const int gs = run.block_shift + ADH_SUB_SHIFT;
+    k.grp_base = grp << gs;
+    const int f_lo = max(c0, k.grp_base) - k.grp_base;
+    const int f_hi = min(c0 + F, k.grp_base + (1 << gs)) - k.grp_base;
     k.f_lo = (uint32_t)f_lo;
     k.nf = (uint32_t)max(f_hi - f_lo, 0);
-    k.t = tab_row(run, row, blk);
+    k.bin_bits = (uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT;
+    k.first_bin = b == b_lo;
     k.idx = 0;
     k.end = 0;
-    k.b_end = 0;
-    k.b_end2 = 0;
     if (on) {
-        const int nb = w.b_hi - w.b_lo;
-        k.idx = tw.v.x;
-        k.end = nb == 0 ? tw.v.y : (nb == 1 ? tw.v.z : (nb == 2 ? tw.v.w : tw.far_end));
-        k.b_end = nb == 0 ? k.end : tw.v.y;
-        k.b_end2 = nb <= 1 ? k.end : tw.v.z;
+        const uint32_t *t = adh_tab_row(run, row, grp << ADH_SUB_SHIFT) + (int64_t)b * ADH_SUB + sb0;
+        const int d = sb1 + 1 - sb0;  // 1 .. ADH_SUB
+        if (d <= 3) {
+            const Tab4 v = *reinterpret_cast<const Tab4 *>(t);  // words sb0 .. sb0 + 3 (the table has 4 spare words)
+            k.idx = v.x;
+            k.end = d == 1 ? v.y : (d == 2 ? v.z : v.w);
+        } else {
+            k.idx = t[0];
+            k.end = t[d];
+        }
     }
 }
 
@@ -387,10 +370,12 @@ __device__ __forceinline__ void task_fetch(const DevRun &run, Task &k) {
     for (int u = 0; u < EB; u += 2) {
         if (n > (uint32_t)u) load2(run, k.idx + u, k.e[u], k.e[u + 1]);
     }
+#if ADH_FUSED_AHEAD
 #pragma unroll
     for (int u = 0; u < EB; u += 2) {
         if (n > (uint32_t)(EB + u)) load2(run, k.idx + EB + u, k.n[u], k.n[u + 1]);
     }
+#endif
 }
 
 // cells: the lane's column of the tile, cells[r * TW] = centred row r; roff = FM/2 - F/2 - c0
@@ -399,12 +384,10 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
     uint32_t idx = k.idx;
     const uint32_t end = k.end;
     if (idx >= end) return;
-    const uint32_t *t = k.t;
-    uint32_t b_end = k.b_end;
-    int b = w.b_lo;
-    int cur = -1;  // open cell (block-relative cycle), -1: none
+    int cur = -1;  // open cell (group-relative cycle), -1: none
     float acc_i = 0.0f, acc_m = 0.0f;
     while (idx < end) {
+#if ADH_FUSED_AHEAD
         // this step's entries were requested two steps ago; the step after next is requested now
         uint2 e[EB];
 #pragma unroll
@@ -419,21 +402,29 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
                 if (left > (uint32_t)(2 * EB + u)) load2(run, idx + 2 * EB + u, k.n[u], k.n[u + 1]);
             }
         }
+#else
+        uint2 e[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) e[u] = k.e[u];
+        {
+            const uint32_t left = end - idx;
+#pragma unroll
+            for (int u = 0; u < EB; u += 2) {
+                if (left > (uint32_t)(EB + u)) load2(run, idx + EB + u, k.e[u], k.e[u + 1]);
+            }
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
             const uint32_t i = idx + (uint32_t)u;
             if (i >= end) break;
-            while (i >= b_end) {  // next bin: cycles start over
-                ++b;
-                b_end = (b >= w.b_hi) ? end : (b == w.b_lo + 1 ? k.b_end2 : t[b + 1]);
-            }
             const uint32_t cyc = e[u].x >> ADH_BIN_SHIFT;
-            const uint32_t bits = ((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) | (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u));
+            const uint32_t bits = k.bin_bits | (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u));
             if (cyc - k.f_lo >= k.nf || bits < w.lo_u || bits > w.hi_u) continue;
             if ((int)cyc != cur) {
-                if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
+                if (cur >= 0) cells[(cur + k.grp_base + roff) * TW] = make_float2(acc_i, acc_m);
                 float2 v = make_float2(0.0f, 0.0f);
-                if (b > w.b_lo) v = cells[((int)cyc + k.cyc_base + roff) * TW];  // continue from an earlier bin
+                if (!k.first_bin) v = cells[((int)cyc + k.grp_base + roff) * TW];  // continue from an earlier bin
                 acc_i = v.x;
                 acc_m = v.y;
                 cur = (int)cyc;
@@ -443,7 +434,7 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
         }
         idx += EB;
     }
-    if (cur >= 0) cells[(cur + k.cyc_base + roff) * TW] = make_float2(acc_i, acc_m);
+    if (cur >= 0) cells[(cur + k.grp_base + roff) * TW] = make_float2(acc_i, acc_m);
 }
 
 // Precursor features 4-16 (precursor_features.py:13-102; feat::assemble_precursor is the scalar form over LDS
@@ -558,28 +549,16 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
             if (j * GS + sub < N4) z[j * GS + sub] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const int bs = run.block_shift;
-    const int blk0 = c0 >> bs;
-    const int n_blk = alive ? ((c0 + F - 1) >> bs) - blk0 + 1 : 0;
+    const int blk0 = c0 >> bs, blk1 = alive ? (c0 + F - 1) >> bs : blk0 - 1;  // first / last cycle block
     float2 *cells = &tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
     const int roff = FM / 2 - F / 2 - c0;       // centred row of absolute cycle x: x + roff
-    // the table words of up to NTAB cycle blocks are requested together (one round trip), then block after
-    // block: entries, fold.  (More than one block's ENTRIES in flight costs registers the feature phase needs:
-    // spills, 20 % slower; the table words are 4-5 registers per block.)
-    constexpr int NTAB = ADH_FUSED_NTAB;
-    for (int bb = 0; __any(bb < n_blk); bb += NTAB) {
-        TabWords tw[NTAB];
-#pragma unroll
-        for (int u = 0; u < NTAB; ++u) task_tab(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, tw[u]);
-#pragma unroll 1
-        for (int u = 0; u < NTAB; ++u) {
-            if (!__any(bb + u < n_blk)) break;
-            TabWords cur = tw[0];
-#pragma unroll
-            for (int j = 1; j < NTAB; ++j) {
-                if (u == j) cur = tw[j];
-            }
+    const int n_bins_l = task_on ? wb.b_hi - wb.b_lo + 1 : 0;
+    for (int grp = blk0 >> ADH_SUB_SHIFT; grp <= (blk1 >> ADH_SUB_SHIFT); ++grp) {  // (wave-uniform only per group of lanes:
+        // lanes of a candidate that has no such group idle, see `on`)
+        const int sb0 = max(blk0 - (grp << ADH_SUB_SHIFT), 0), sb1 = min(blk1 - (grp << ADH_SUB_SHIFT), ADH_SUB - 1);
+        for (int j = 0; __any(j < n_bins_l); ++j) {
             Task t;
-            task_begin(run, wb, task_on && bb + u < n_blk, task_row, blk0 + bb + u, c0, F, cur, t);
+            task_begin(run, j < n_bins_l && sb1 >= sb0, task_row, grp, sb0, max(sb1, sb0), wb.b_lo + j, wb.b_lo, c0, F, t);
             task_fetch(run, t);
             task_run(run, wb, t, cells, roff, hits);
         }
@@ -655,21 +634,17 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     const bool iso_lane = alive && sub >= ISO0 && sub - ISO0 < I;
     const int il = iso_lane ? sub - ISO0 : 0;
     float iso_int_l = 0.0f;
-    double cy0[NO], cy1[NO];
-#pragma unroll
-    for (int o = 0; o < NO; ++o) cy0[o] = 0.0, cy1[o] = 1.0;
-    if (iso_lane) {
-        iso_int_l = iso_table[(int64_t)row * n_iso_cols + il];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const double *cy = run.cycle + 2 * ((int64_t)rec.obs[o] * run.cycle_scans + rec.scan_start);
-            cy0[o] = cy[0];
-            cy1[o] = cy[1];
-        }
-    }
+    if (iso_lane) iso_int_l = iso_table[(int64_t)row * n_iso_cols + il];
+    // quadrupole transfer function (quadrupole.py:261-301, n_scans == 1): a logistic term per (isotope,
+    // observation, window edge) - at most 4 x 2 x 2 = 16: lane e = i + 4 o + 4 NO edge evaluates one, so that the
+    // candidate costs ONE float64 exp and division instead of two per observation on three lanes
+    const int q_i = sub & 3, q_o = (sub >> 2) % NO, q_edge = sub / (4 * NO);
+    const bool q_lane = alive && sub < 8 * NO && q_i < I;
+    double q_mu = 0.0;
+    if (q_lane) q_mu = run.cycle[2 * ((int64_t)rec.obs[q_o] * run.cycle_scans + rec.scan_start) + q_edge];
     const int ms1_row = run.ms1_obs[0];
     if (stop_phase == 20) {  // ... + library records and the other first-round loads
-        if (mine_int + rt_first + rt_last + loc + frt_l[0] + iso_int_l + (float)(cy0[0] + cy1[0]) + (float)ms1_row == -12345.5f) out.valid[row] = 2;
+        if (mine_int + rt_first + rt_last + loc + frt_l[0] + iso_int_l + (float)q_mu + (float)ms1_row == -12345.5f) out.valid[row] = 2;
         return;
     }
     int K0 = 0;
@@ -807,24 +782,31 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     // ================= gather: every lane its window, into its column of the tile =================
     uint32_t hits = 0;
     gather_pass<FM>(run, wb, task_on, task_row, alive, c0, F, L.u.tile, sub, hits);
-    // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1; the isotope lanes
-    double qtf_l[NO];
-#pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        qtf_l[o] = 0.0;
-        if (iso_lane) {
-            const double x = (double)iso_mz_l;
-            qtf_l[o] = logistic(x, cy0[o], 0.2) - logistic(x, cy1[o], 0.2);
-        }
+    // quadrupole_transfer_function_single (quadrupole.py:261-301): logistic(x, lower edge) - logistic(x, upper edge)
+    double q_term = 0.0;
+    {
+        // isotope m/z of this lane's term (candidate.py:151-163), as the isotope lane computes it
+        const double off = (double)q_i * 1.0033548350700006 / (double)rec.charge;
+        const float mzq = (float)off + rec.precursor_mz;
+        if (q_lane) q_term = logistic((double)mzq, q_mu, 0.2);
     }
-    // qtf mask of the fragment tile (candidate.py:287-289): mean over the isotopes, in order
+    double q_io;  // lanes i + 4 o: the transfer function of (isotope i, observation o)
+    {
+        const double upper = __shfl(q_term, (int)gsh + ((sub + 4 * NO) & 15));
+        q_io = q_term - upper;
+    }
+    // the isotope lanes take theirs; qtf mask of the fragment tile (candidate.py:287-289): mean over the
+    // isotopes, in order
+    double qtf_l[NO];
     float qmask[NO];
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
+        const double mine_q = __shfl(q_io, (int)gsh + 4 * o + (il & 3));
+        qtf_l[o] = iso_lane ? mine_q : 0.0;
         double qs = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const double qi = __shfl(qtf_l[o], (int)gsh + ISO0 + i);
+            const double qi = __shfl(q_io, (int)gsh + 4 * o + i);
             if (i < I) qs += qi;
         }
         qmask[o] = (I > 0) ? (float)(qs / (double)I) : 0.0f;

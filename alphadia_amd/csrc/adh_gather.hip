@@ -71,48 +71,44 @@ __device__ __forceinline__ void gather_task(const DevRun &run, const Window &w, 
     if (w.b_hi < w.b_lo) return;
     const int bs = run.block_shift;
     const int cyc_base = blk << bs;
-    const int f_lo = max(c0, cyc_base) - cyc_base;              // block-relative cycle range
-    const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - cyc_base;
-    const uint32_t *t = run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
-    uint32_t idx = t[w.b_lo];
-    const uint32_t end = t[w.b_hi + 1];
-    if (idx >= end) return;
-    int b = w.b_lo;
-    uint32_t b_end = (w.b_hi > w.b_lo) ? t[b + 1] : end;
-    int cur = -1;  // open cell (block-relative cycle), -1: none
-    float acc_i = 0.0f, acc_m = 0.0f;
-    while (idx < end) {
-        // four entries in flight; the tail repeats the last one (harmless, skipped below)
-        uint2 e[4];
+    const int grp_base = (blk >> ADH_SUB_SHIFT) << (bs + ADH_SUB_SHIFT);
+    const int f_lo = max(c0, cyc_base) - grp_base;              // group-relative cycle range inside the block
+    const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - grp_base;
+    const uint32_t *t = adh_tab_row(run, row, blk) + (blk & (ADH_SUB - 1));
+    for (int b = w.b_lo; b <= w.b_hi; ++b) {  // bin after bin: a cell keeps ascending m/z
+        uint32_t idx = t[b * ADH_SUB];
+        const uint32_t end = t[b * ADH_SUB + 1];
+        int cur = -1;  // open cell (group-relative cycle), -1: none
+        float acc_i = 0.0f, acc_m = 0.0f;
+        while (idx < end) {
+            // four entries in flight; the tail repeats the last one (harmless, skipped below)
+            uint2 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
+            for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = idx + (uint32_t)u;
-            if (i >= end) break;
-            while (i >= b_end) {  // next bin: cycles start over
-                ++b;
-                b_end = (b < w.b_hi) ? t[b + 1] : end;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = idx + (uint32_t)u;
+                if (i >= end) break;
+                const int cyc = (int)(e[u].x >> ADH_BIN_SHIFT);
+                if (cyc < f_lo || cyc >= f_hi) continue;
+                const float mz = __uint_as_float(((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) |
+                                                 (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u)));
+                if (!(mz >= w.lo && mz > w.excl) || !(mz <= w.hi)) continue;
+                if (cyc != cur) {
+                    if (cur >= 0) cells[(cur + grp_base - c0) * stride] = make_float2(acc_i, acc_m);
+                    float2 v = make_float2(0.0f, 0.0f);
+                    if (b > w.b_lo) v = cells[(cyc + grp_base - c0) * stride];  // continue from an earlier bin
+                    acc_i = v.x;
+                    acc_m = v.y;
+                    cur = cyc;
+                }
+                fold(acc_i, acc_m, mz, __uint_as_float(e[u].y));
+                ++hits;
             }
-            const int cyc = (int)(e[u].x >> ADH_BIN_SHIFT);
-            if (cyc < f_lo || cyc >= f_hi) continue;
-            const float mz = __uint_as_float(((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) |
-                                             (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u)));
-            if (!(mz >= w.lo && mz > w.excl) || !(mz <= w.hi)) continue;
-            if (cyc != cur) {
-                if (cur >= 0) cells[(cur + cyc_base - c0) * stride] = make_float2(acc_i, acc_m);
-                float2 v = make_float2(0.0f, 0.0f);
-                if (b > w.b_lo) v = cells[(cyc + cyc_base - c0) * stride];  // continue from an earlier bin
-                acc_i = v.x;
-                acc_m = v.y;
-                cur = cyc;
-            }
-            fold(acc_i, acc_m, mz, __uint_as_float(e[u].y));
-            ++hits;
+            idx += 4;
         }
-        idx += 4;
+        if (cur >= 0) cells[(cur + grp_base - c0) * stride] = make_float2(acc_i, acc_m);
     }
-    if (cur >= 0) cells[(cur + cyc_base - c0) * stride] = make_float2(acc_i, acc_m);
 }
 
 }  // namespace gather
@@ -303,8 +299,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
 }
 
 // ------------------------------------------------------------------ staging kernels
-// sort key of every peak: high word = ((block * L + row) * n_bins + bin), low word =
-// (cycle inside the block << ADH_BIN_SHIFT) | low m/z bits.  One workgroup per spectrum.
+// sort key of every peak: high word = ((group * L + row) * n_bins + bin), low word =
+// (cycle inside the group << ADH_BIN_SHIFT) | low m/z bits.  One workgroup per spectrum.
 __global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t *__restrict__ pstart,
                                     const int64_t *__restrict__ pstop, int64_t n_spectra, int L,
                                     int block_shift, int bin0, int n_bins,
@@ -314,9 +310,10 @@ __global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t 
     if (spec >= n_spectra) return;
     const int64_t cyc = spec / L;
     const int row = (int)(spec - cyc * L);
-    const int64_t blk = cyc >> block_shift;
-    const uint32_t cin = (uint32_t)(cyc - (blk << block_shift));
-    const uint64_t seg = (uint64_t)(blk * L + row) * (uint64_t)n_bins;
+    const int gs = block_shift + ADH_SUB_SHIFT;
+    const int64_t grp = cyc >> gs;
+    const uint32_t cin = (uint32_t)(cyc - (grp << gs));
+    const uint64_t seg = (uint64_t)(grp * L + row) * (uint64_t)n_bins;
     const int64_t ps = pstart[spec], pe = pstop[spec];
     for (int64_t j = ps + threadIdx.x; j < pe; j += blockDim.x) {
         const uint32_t bits = __float_as_uint(mz[j]);
@@ -331,16 +328,21 @@ __global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t 
     }
 }
 
-// sorted keys -> 8-byte entries (low key word, intensity) + the bin table:
-// tab[g] = index of the first entry whose global bin is >= g, for g = 0..n_tab-1
+// sorted keys -> 8-byte entries (low key word, intensity) + the bin table: with the fine key
+// g = (group, row, bin) * ADH_SUB + block inside the group, tab[g] = index of the first entry whose fine key
+// is >= g, for g = 0..n_tab-1
 __global__ void adh_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                    const float *__restrict__ inten, int64_t n, uint2 *__restrict__ entries,
-                                   uint32_t *__restrict__ tab, int64_t n_tab) {
+                                   uint32_t *__restrict__ tab, int64_t n_tab, int block_shift) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto fine = [block_shift](uint64_t key) -> int64_t {
+        const uint32_t cin = (uint32_t)key >> ADH_BIN_SHIFT;
+        return (int64_t)((key >> 32) << ADH_SUB_SHIFT) + (int64_t)(cin >> block_shift);
+    };
     for (; i <= n; i += stride) {
-        const int64_t g_prev = (i == 0) ? -1 : (int64_t)(keys[i - 1] >> 32);
-        const int64_t g_cur = (i == n) ? n_tab - 1 : (int64_t)(keys[i] >> 32);
+        const int64_t g_prev = (i == 0) ? -1 : fine(keys[i - 1]);
+        const int64_t g_cur = (i == n) ? n_tab - 1 : fine(keys[i]);
         for (int64_t g = g_prev + 1; g <= g_cur; ++g) tab[g] = (uint32_t)i;
         if (i < n) entries[i] = make_uint2((uint32_t)keys[i], __float_as_uint(inten[vals[i]]));
     }

@@ -31,36 +31,32 @@ __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window 
     if (w.b_hi < w.b_lo) return;
     const int bs = run.block_shift;
     const int cyc_base = blk << bs;
-    const int f_lo = max(c0, cyc_base) - cyc_base;
-    const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - cyc_base;
-    const uint32_t *t = run.tab + ((int64_t)blk * run.cycle_len + row) * (int64_t)run.n_bins;
-    uint32_t idx = t[w.b_lo];
-    const uint32_t end = t[w.b_hi + 1];
-    if (idx >= end) return;
-    int b = w.b_lo;
-    uint32_t b_end = (w.b_hi > w.b_lo) ? t[b + 1] : end;
-    while (idx < end) {
-        uint2 e[4];
+    const int grp_base = (blk >> ADH_SUB_SHIFT) << (bs + ADH_SUB_SHIFT);
+    const int f_lo = max(c0, cyc_base) - grp_base;
+    const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - grp_base;
+    const uint32_t *t = adh_tab_row(run, row, blk) + (blk & (ADH_SUB - 1));
+    for (int b = w.b_lo; b <= w.b_hi; ++b) {  // bin after bin: a cell keeps ascending m/z
+        uint32_t idx = t[b * ADH_SUB];
+        const uint32_t end = t[b * ADH_SUB + 1];
+        while (idx < end) {
+            uint2 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
+            for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = idx + (uint32_t)u;
-            if (i >= end) break;
-            while (i >= b_end) {
-                ++b;
-                b_end = (b < w.b_hi) ? t[b + 1] : end;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = idx + (uint32_t)u;
+                if (i >= end) break;
+                const int cyc = (int)(e[u].x >> ADH_BIN_SHIFT);
+                if (cyc < f_lo || cyc >= f_hi) continue;
+                const float mz = __uint_as_float(((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) |
+                                                 (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u)));
+                if (!(mz >= w.lo && mz > w.excl) || !(mz <= w.hi)) continue;
+                // alpharaw_jit.py:405-420: float32 running sum in ascending m/z
+                float *c = cells + (cyc + grp_base - c0);
+                *c = *c + __uint_as_float(e[u].y);
             }
-            const int cyc = (int)(e[u].x >> ADH_BIN_SHIFT);
-            if (cyc < f_lo || cyc >= f_hi) continue;
-            const float mz = __uint_as_float(((uint32_t)(run.bin0 + b) << ADH_BIN_SHIFT) |
-                                             (e[u].x & ((1u << ADH_BIN_SHIFT) - 1u)));
-            if (!(mz >= w.lo && mz > w.excl) || !(mz <= w.hi)) continue;
-            // alpharaw_jit.py:405-420: float32 running sum in ascending m/z
-            float *c = cells + (cyc + cyc_base - c0);
-            *c = *c + __uint_as_float(e[u].y);
+            idx += 4;
         }
-        idx += 4;
     }
 }
 
