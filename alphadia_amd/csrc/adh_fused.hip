@@ -43,7 +43,10 @@
 #define ADH_FUSED_SCALAR 1     // developer switch: 0 skips the feature assembly of single lanes (wrong results; what it costs)
 #endif
 #ifndef ADH_FUSED_AHEAD
-#define ADH_FUSED_AHEAD 1      // 1: the entries of the step after next are requested while a step is folded; 0: step by step
+#define ADH_FUSED_AHEAD 0      // 1: the entries of the step after next are requested while a step is folded; 0: step by step
+#endif
+#ifndef ADH_FUSED_NPAIR
+#define ADH_FUSED_NPAIR 2      // m/z bins of a window whose table words and entries are requested together
 #endif
 #ifndef ADH_FUSED_EB
 #define ADH_FUSED_EB 4         // entries per step of a gather task (even)
@@ -300,6 +303,7 @@ __device__ __forceinline__ void profile_stats(const float (&P)[FM], const float 
 // length of the dependency chain, is what bounds the gather (measured: coarser bins, larger blocks, more
 // loads in flight and fewer instructions all left its time where it was or made it worse).
 constexpr int EB = ADH_FUSED_EB;  // entries fetched per step
+constexpr int NPAIR = ADH_FUSED_NPAIR;  // bins of a window in flight together
 struct __attribute__((packed, aligned(4))) Tab4 {
     uint32_t x, y, z, w;
 };
@@ -556,11 +560,18 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
     for (int grp = blk0 >> ADH_SUB_SHIFT; grp <= (blk1 >> ADH_SUB_SHIFT); ++grp) {  // (wave-uniform only per group of lanes:
         // lanes of a candidate that has no such group idle, see `on`)
         const int sb0 = max(blk0 - (grp << ADH_SUB_SHIFT), 0), sb1 = min(blk1 - (grp << ADH_SUB_SHIFT), ADH_SUB - 1);
-        for (int j = 0; __any(j < n_bins_l); ++j) {
-            Task t;
-            task_begin(run, j < n_bins_l && sb1 >= sb0, task_row, grp, sb0, max(sb1, sb0), wb.b_lo + j, wb.b_lo, c0, F, t);
-            task_fetch(run, t);
-            task_run(run, wb, t, cells, roff, hits);
+        // two bins of the window at a time: their table words, then their entries, are in flight together
+        // (one dependent round trip per pair instead of per bin; a window rarely has a third bin)
+        for (int j = 0; __any(j < n_bins_l); j += NPAIR) {
+            Task t[NPAIR];
+#pragma unroll
+            for (int u = 0; u < NPAIR; ++u)
+                task_begin(run, j + u < n_bins_l && sb1 >= sb0, task_row, grp, sb0, max(sb1, sb0), wb.b_lo + j + u, wb.b_lo, c0,
+                           F, t[u]);
+#pragma unroll
+            for (int u = 0; u < NPAIR; ++u) task_fetch(run, t[u]);
+#pragma unroll
+            for (int u = 0; u < NPAIR; ++u) task_run(run, wb, t[u], cells, roff, hits);
         }
     }
 }
