@@ -210,29 +210,24 @@ __device__ __forceinline__ void center_envelope(float (&x)[FM], int F) {
         float right = odd ? (x[RC + 1] + x[RC]) * 0.5f : x[RC];
 #pragma unroll
         for (int i = 1; RC + i < FM; ++i) {
-            x[RC + i] = fminf(right, x[RC + i]);
+            x[RC + i] = (right < x[RC + i]) ? right : x[RC + i];  // (min of two non-negative numbers: no NaN to quiet)
             right = (x[RC + i] + x[RC + i - 1]) * 0.5f;
         }
     }
-    // left chain: odd F walks RC - i from the centre register RC, even F walks RC - 1 - i from RC - 1
+    // left chain: odd F walks RC - i from the centre register RC, even F walks RC - 1 - i from RC - 1.  In place:
+    // step i reads and writes the register of the lane's parity, the other parity's register passes through
     {
-        float y[RC + 1];  // y[i] = the chain's i-th register, y[0] its seed register
+        float prev = odd ? x[RC] : x[RC - 1];
+        float left = odd ? (x[RC - 1] + x[RC]) * 0.5f : x[RC - 1];
 #pragma unroll
-        for (int i = 0; i <= RC; ++i) {
-            const float xo = x[RC - i];
+        for (int i = 1; i <= RC; ++i) {
             const float xe = (RC - 1 - i >= 0) ? x[RC - 1 - i > 0 ? RC - 1 - i : 0] : 0.0f;
-            y[i] = odd ? xo : xe;
-        }
-        // odd: left = (x[RC - 1] + x[RC]) / 2 = (y[1] + y[0]) / 2; even: left = x[RC - 1] = y[0]
-        float left = odd ? (y[1] + y[0]) * 0.5f : y[0];
-#pragma unroll
-        for (int i = 1; i <= RC; ++i) {
-            y[i] = fminf(left, y[i]);
-            left = (y[i] + y[i - 1]) * 0.5f;
-        }
-#pragma unroll
-        for (int i = 1; i <= RC; ++i) {
-            if (RC - i >= 0) x[RC - i] = odd ? y[i] : ((i >= 2) ? y[i - 1] : x[RC - i]);
+            const float cur = odd ? x[RC - i] : xe;
+            const float nv = (left < cur) ? left : cur;
+            left = (nv + prev) * 0.5f;
+            prev = nv;
+            x[RC - i] = odd ? nv : x[RC - i];
+            if (RC - 1 - i >= 0) x[RC - 1 - i] = odd ? x[RC - 1 - i] : nv;
         }
     }
 }
@@ -930,13 +925,19 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 #pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
             for (int sc = 0; sc < 2; ++sc) {
                 const double scd = (double)sc;
+                // the cycle coordinate f = r + shift as a running float64 (exact) that starts from a value the
+                // optimiser cannot see through: left to itself it converts all FM coordinates ahead of the two-trip
+                // loop and keeps them in 2 FM registers next to the rows
+                double fd = (double)shift;
+                __asm__ volatile("" : "+v"(fd));
                 FU_FOR_R {
                     float v = Q.tpl[r];
                     v = (v > 0.0f) ? v : 0.0f;  // the reference skips v <= 0; adding +0 is the same
                     const double vd = (double)v;
                     isum += vd;
                     ssum += scd * vd;
-                    fsum += (double)(r + shift) * vd;
+                    fsum += fd * vd;
+                    fd += 1.0;
                     FU_FENCE(r);
                 }
             }
@@ -962,7 +963,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             Q.tfp[r] = ok ? rr : 0.0f;
         }
         // weight table around the template centre (features_utils.py:9-25), centred index
-#pragma unroll
+#pragma unroll 1  // (pass after pass: interleaved float64 exp() evaluations cost registers the rows need)
         for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
             const int idx = min(sub + 16 * pass, 2 * FM - 1);
             const int sc = idx / FM, r = idx - sc * FM;
