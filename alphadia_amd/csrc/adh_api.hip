@@ -514,7 +514,13 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
         // search indices (DevTims): the m/z table on the host, the (bin, cycle) table on the device
         t.n_cycles = (int32_t)((d->n_frames - t.zeroth + d->cycle_len - 1) / d->cycle_len);
         const char *env = getenv("ADH_IM_INDEX");
-        const bool want = !(env && atoi(env) == 0) && d->n_events < 0xFFFFFFFFll && d->n_tof >= 2 && t.n_cycles > 0 &&
+        // (event numbers are 64-bit everywhere; the index columns and the pair ranges of the kernels count from the
+        // first event of a TOF bin / of a window's first bin in 32 bits: a single bin must stay below 2^32 events)
+        int64_t widest = 0;
+        for (int64_t b = 0; b < d->n_tof; ++b) widest = std::max(widest, d->tof_indptr[b + 1] - d->tof_indptr[b]);
+        if (widest >= (int64_t)0xFFFFFFFFll)
+            return fail(ADH_ERR_UNSUPPORTED, "a TOF bin with 2^32 or more events");
+        const bool want = !(env && atoi(env) == 0) && d->n_tof >= 2 && t.n_cycles > 0 &&
                           d->mz_values[d->n_tof - 1] > d->mz_values[0];
         if (want) {
             int64_t nb = 1;

@@ -76,6 +76,8 @@ size_t adh_gather_im_lds_bytes(const Caps &c) {
     size_t b = (size_t)(c.k + c.i) * (4 + 4 + 4);  // window m/z, tof start, tof stop
     b += (size_t)(c.k + c.i + 1) * 4;              // first pair of every window
     b = (b + 15) / 16 * 16;
+    b += (size_t)(c.k + c.i) * 8;                  // first event of every window's first TOF bin
+    b = (b + 15) / 16 * 16;
     const size_t lib = (size_t)c.n_lib * 16;       // l_int, l_mz, l_rank, l_ok
     b += lib > gather_im::kCompactBytes ? lib : gather_im::kCompactBytes;
     return (b + 15) / 16 * 16;
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     int *t_lo = reinterpret_cast<int *>(w_mz + n_win);
     int *t_hi = t_lo + n_win;
     int *w_p0 = t_hi + n_win;  // first (window, bin) pair of every window
-    unsigned char *region = smem + ((size_t)n_win * 12 + (size_t)(n_win + 1) * 4 + 15) / 16 * 16;
+    int64_t *w_base = reinterpret_cast<int64_t *>(smem + ((size_t)n_win * 12 + (size_t)(n_win + 1) * 4 + 15) / 16 * 16);
+    unsigned char *region = reinterpret_cast<unsigned char *>(w_base) + ((size_t)n_win * 8 + 15) / 16 * 16;
     // fragment selection
     float *l_int = reinterpret_cast<float *>(region);
     float *l_mz = l_int + caps.n_lib;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
         const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
         const int P = index_im::pair_setup(
-            run, W, t_lo, t_hi, [&](int w) { return w >= K ? caps.k + (w - K) : w; }, c0, F, push_lo, push_hi, w_p0, p_lo,
+            run, W, t_lo, t_hi, [&](int w) { return w >= K ? caps.k + (w - K) : w; }, c0, F, push_lo, push_hi, w_p0, w_base, p_lo,
             p_off, p_win, lane);
         bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 break;
             }
             // ---- stage 1: the raw events of the batch; those in the scan range (~3 %) queue up behind the list
-            const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, p_lo, p_off,
+            const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo, p_off,
                                                       s_key, s_int, s_pair, lane);
             if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
                 over = true;
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     const uint32_t pvq = s_key[q_base + qi];
                     const int pa = (int)s_pair[q_base + qi];
                     const uint32_t e = r0 + (uint32_t)s_int[q_base + qi];
-                    const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                     const int w = (int)p_win[pa];
+                    const int64_t idx = w_base[w] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                     const bool prec = w >= K;
                     uint32_t fq = (uint32_t)((double)pvq * inv_smax);
                     if (pvq - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
@@ -437,8 +440,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             int64_t lo, b;
             if (per_cycle) {  // the staged (bin, cycle) index holds both ends
                 const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
-                lo = row[c0 + f];
-                b = row[min(c0 + f + 1, run.cyc_cols - 1)];
+                const int64_t first = run.tof_indptr[tof];  // (the columns count from the bin's first event)
+                lo = first + (int64_t)row[c0 + f];
+                b = first + (int64_t)row[min(c0 + f + 1, run.cyc_cols - 1)];
             } else {
                 b = run.tof_indptr[tof + 1];
                 lo = run.tof_indptr[tof];

@@ -54,14 +54,16 @@ __device__ __forceinline__ void event_range(const DevTims &run, int tof, int c0,
                                             uint32_t push_hi, int64_t &lo, int64_t &lo2) {
     int64_t hi_lo, hi_hi;
     if (run.cyc_idx) {
+        // (the columns count from the bin's first event: 32 bits per column whatever the size of the run)
         const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
+        const int64_t first = run.tof_indptr[tof];
         const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
         const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
-        lo = row[ba];
-        lo2 = row[bb];
+        lo = first + (int64_t)row[ba];
+        lo2 = first + (int64_t)row[bb];
         if (sh == 0) return;
-        hi_lo = ba < nb ? (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
-        hi_hi = bb < nb ? (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
+        hi_lo = ba < nb ? first + (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
+        hi_hi = bb < nb ? first + (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
     } else {
         lo = run.tof_indptr[tof];
         hi_lo = hi_hi = run.tof_indptr[tof + 1];
@@ -82,15 +84,18 @@ __device__ __forceinline__ void event_range(const DevTims &run, int tof, int c0,
 
 // ---- the event stream of the sparse gathers (adh_gather_im_kernel, adh_select_gather_im_kernel), one wavefront
 // per candidate / precursor.  LDS arrays of the caller: w_p0[W + 1] first (window, TOF bin) pair of every
-// window, p_lo[ADH_IM_PAIR_CAP] first event of a pair's range, p_off[ADH_IM_PAIR_CAP + 1] events before the
-// pair, p_win[ADH_IM_PAIR_CAP] window of the pair.
+// window, w_base[W] first event of the window's first TOF bin (64 bits: a run may hold more than 2^32 events),
+// p_lo[ADH_IM_PAIR_CAP] first event of a pair's range COUNTED FROM w_base of its window (the bins of a window are
+// neighbours, so 32 bits do), p_off[ADH_IM_PAIR_CAP + 1] events before the pair, p_win[ADH_IM_PAIR_CAP] window
+// of the pair.
 
 // Pairs of all W windows (window w covers the TOF bins [t_lo[slot_of(w)], t_hi[slot_of(w)])) and their event
 // ranges.  Returns the number of pairs; more than ADH_IM_PAIR_CAP: nothing else is set up.
 template <typename SlotOf>
 __device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *t_lo, const int *t_hi, SlotOf slot_of,
                                           int c0, int F, uint32_t push_lo, uint32_t push_hi, int *w_p0,
-                                          uint32_t *p_lo, uint32_t *p_off, uint8_t *p_win, int lane) {
+                                          int64_t *w_base, uint32_t *p_lo, uint32_t *p_off, uint8_t *p_win, int lane) {
+    for (int w = lane; w < W; w += ADH_WAVE) w_base[w] = run.tof_indptr[max(min(t_lo[slot_of(w)], (int)run.n_tof), 0)];
     if (lane == 0) {
         int acc = 0;
         for (int w = 0; w < W; ++w) {
@@ -109,7 +114,7 @@ __device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *
         const int tof = t_lo[slot_of(w)] + (p - w_p0[w]);
         int64_t lo, lo2;
         event_range(run, tof, c0, F, push_lo, push_hi, lo, lo2);
-        p_lo[p] = (uint32_t)lo;
+        p_lo[p] = (uint32_t)(lo - w_base[w]);
         p_win[p] = (uint8_t)w;
         p_off[p + 1] = (uint32_t)(lo2 - lo);
     }
@@ -134,9 +139,9 @@ __device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *
 // queued behind the m entries of the list: s_key = push, s_int = raw number - r0, s_pair = pair.  Returns the
 // number of queued events (entries beyond ADH_IM_SORT_CAP are counted, not stored).
 __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int pb0, uint32_t r0, uint32_t r1,
-                                                int scan_lo, int scan_hi, int m, const uint32_t *p_lo,
-                                                const uint32_t *p_off, uint32_t *s_key, uint16_t *s_int,
-                                                uint8_t *s_pair, int lane) {
+                                                int scan_lo, int scan_hi, int m, const int64_t *w_base,
+                                                const uint8_t *p_win, const uint32_t *p_lo, const uint32_t *p_off,
+                                                uint32_t *s_key, uint16_t *s_int, uint8_t *s_pair, int lane) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t S_max = (uint32_t)run.scan_max;
     const double inv_smax = 1.0 / (double)S_max;
@@ -155,7 +160,7 @@ __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int
                 if (p_off[mid] <= e) pa = mid; else pb = mid;
             }
             pa_u[u] = pa;
-            pv[u] = run.push[(int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+            pv[u] = run.push[w_base[p_win[pa]] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -202,10 +207,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_index_im_kernel(const int64_t *_
             uint32_t g_prev = __shfl_up(g, 1);
             if (lane == 0) g_prev = done;
             if (in)
-                for (uint32_t cb = g_prev; cb < g; ++cb) row[cb] = (uint32_t)e;
+                for (uint32_t cb = g_prev; cb < g; ++cb) row[cb] = (uint32_t)(e - a);  // (counted from the bin's first event)
             const int last = (int)min((int64_t)ADH_WAVE, b - base) - 1;
             done = __shfl(g, last);
         }
-        for (uint32_t cb = done + lane; cb < cols; cb += ADH_WAVE) row[cb] = (uint32_t)b;
+        for (uint32_t cb = done + lane; cb < cols; cb += ADH_WAVE) row[cb] = (uint32_t)(b - a);
     }
 }

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     __shared__ int s_tlo[MAX_W], s_thi[MAX_W];
     __shared__ float s_raw[MAX_W];
     __shared__ int w_p0[MAX_W + 1];                   // first (window, TOF bin) pair of every window
-    __shared__ uint32_t p_lo[ADH_IM_PAIR_CAP];        // first event of the pair's range
+    __shared__ int64_t w_base[MAX_W];                 // first event of every window's first TOF bin
+    __shared__ uint32_t p_lo[ADH_IM_PAIR_CAP];        // first event of the pair's range, counted from w_base
     __shared__ uint32_t p_off[ADH_IM_PAIR_CAP + 2];   // events before the pair
     __shared__ uint8_t p_win[ADH_IM_PAIR_CAP];
     __shared__ uint32_t s_key[ADH_IM_SORT_CAP];       // cell << 9 | position in the list
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     // position) and summed per cell in that order: TOF ascending, then push - the reference's order
     // (bruker_jit.py:575-580: float32 running sum).
     const int P = index_im::pair_setup(
-        run, W, s_tlo, s_thi, [](int w) { return w; }, c0, F, push_lo, push_hi, w_p0, p_lo, p_off, p_win, lane);
+        run, W, s_tlo, s_thi, [](int w) { return w; }, c0, F, push_lo, push_hi, w_p0, w_base, p_lo, p_off, p_win, lane);
     const int64_t n_cells = (int64_t)W * S * F;
     bool over = P > ADH_IM_PAIR_CAP || run.n_events >= 0xFFFFFFFFll || n_cells >= (1 << 23) ||
                 debug_dense != 0;  // (developer switch ADH_DEBUG_SELECT_IM_DENSE: dense tiles for every precursor)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
             over = true;
             break;
         }
-        const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_start + S, m, p_lo, p_off,
+        const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_start + S, m, w_base, p_win, p_lo, p_off,
                                                   s_key, s_int, s_pair, lane);
         if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window can be this full)
             over = true;
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
                 const uint32_t pvq = s_key[q_base + qi];
                 const int pa = (int)s_pair[q_base + qi];
                 const uint32_t e = r0 + (uint32_t)s_int[q_base + qi];
-                const int64_t idx = (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                 const int w = (int)p_win[pa];
+                const int64_t idx = w_base[w] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                 const bool prec = w >= K;
                 uint32_t fq = (uint32_t)((double)pvq * inv_sm);
                 if (pvq - fq * (uint32_t)SM >= (uint32_t)SM) ++fq;

@@ -104,6 +104,45 @@ per += 18 * (lib_stop - lib_start) + 64 + (46 * 4 + K * 38 + 6)
 alg_bytes = float(per.sum())
 kernel_ms = g_ms + f_ms
 
+# ---- second yardstick: the bytes the candidates' (TOF bin, cycle range) ranges actually hold.  The run-B
+# formula above charges whole TOF bins (the reference merge-joins a bin from its first event), ~100x what
+# these kernels read through their indices, so its "fraction" says nothing about them.  Here, per candidate:
+# events of every (window, TOF bin) inside the candidate's frames x 6 B (push + intensity), two index words +
+# the bin's tof_indptr and m/z per (window, bin), two m/z look-ups per window, the library slice, the plan
+# record and the 646-byte output row.  Exact on a sample of candidates, scaled to all of them.
+def touched_bytes(sample_rows):
+    push = dia.push_indices
+    out = np.zeros(len(sample_rows), dtype=np.int64)
+    for j, i in enumerate(sample_rows):
+        p_lo = np.uint32(int(soa["frame_start"][i]) * S_max)
+        p_hi = np.uint32(int(soa["frame_stop"][i]) * S_max)
+        mzs = [fmz[a] for a in range(lib_start[i], lib_stop[i])]
+        tol = [15.0] * len(mzs)
+        mzs += [float(soa["precursor_mz"][i]) + k * 1.0033548350700006 / float(soa["charge"][i]) for k in range(3)]
+        tol += [10.0] * 3
+        b = 128 + 32 * (lib_stop[i] - lib_start[i]) + 646
+        for m, t in zip(mzs, tol):
+            lo = np.searchsorted(mzv, m * (1 - t * 1e-6))
+            hi = np.searchsorted(mzv, m * (1 + t * 1e-6))
+            b += 8 + (hi - lo) * (8 + 8 + 8)
+            for tof in range(lo, hi):
+                a0, a1 = indptr[tof], indptr[tof + 1]
+                e0 = a0 + np.searchsorted(push[a0:a1], p_lo)
+                e1 = a0 + np.searchsorted(push[a0:a1], p_hi)
+                b += 6 * int(e1 - e0)
+        out[j] = b
+    return out
+
+
+rows = np.linspace(0, n - 1, int(os.environ.get("TOUCHED_SAMPLE", 400))).astype(np.int64)
+touched = float(touched_bytes(rows).mean()) * n
+traffic = None
+tfile = os.environ.get("ADH_IM_TRAFFIC_JSON")  # {"fetch_bytes_per_pass": ..., "write_bytes_per_pass": ...} from tools/profile_r3_im.sh
+if tfile and os.path.exists(tfile):
+    tj = json.load(open(tfile))
+    if tj.get("candidates") == n:
+        traffic = tj.get("hbm_bytes_per_pass")
+
 result = {
     "workload": f"BASELINE configs[3]: timsTOF-style synthetic run, {dia.push_indices.size/1e6:.0f}M events, {S_max} scans, "
                 f"{L} frames/cycle, {n_cycles} cycles; {n_prec} precursors x 3 candidates, "
@@ -114,14 +153,20 @@ result = {
     "candidates": n, "valid_fraction": float(valid.mean()), "mean_matched_events": float(matched.mean()),
     "stage_seconds": t_stage,
     "roofline": {
-        "bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-        "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+        "bound": "hbm", "achieved": touched / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        "frac": touched / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
         "kernel": "adh_gather_im_kernel + adh_feature_im_kernel", "kernel_ms": kernel_ms,
         "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
-        "algorithmic_bytes_per_candidate": alg_bytes / n,
-        "note": "SURVEY 8(d) run-B formula: the reference merge-joins every TOF bin of a window from the start of "
-                "the bin (bruker_jit.py:415-502), so whole bins count; the kernel binary-searches a bin for the "
-                "candidate's cycles and touches far less, which is why the fraction can exceed 1",
+        "yardstick": "bytes the candidates' (window, TOF bin, frame range) ranges hold: events x 6 B + index words + "
+                     "library slice + plan record + 646 B output row (exact on a strided sample of candidates)",
+        "touched_bytes_per_candidate": touched / n,
+        "survey_8d_run_b": {
+            "algorithmic_bytes_per_candidate": alg_bytes / n,
+            "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0,
+            "note": "SURVEY 8(d) run-B formula: the reference merge-joins every TOF bin of a window from the start of "
+                    "the bin (bruker_jit.py:415-502), so whole bins count; the kernels read the candidate's cycles of "
+                    "a bin through their indices, which is why this fraction exceeds 1 and is not the one reported",
+        },
     },
 }
 if not os.environ.get("ADH_BENCH_NO_CPU"):
