@@ -1,15 +1,20 @@
-"""profiles/pmc_traffic.json from a PMC summary (tools/rocpd_summary.py output of the FETCH_SIZE and
-WRITE_SIZE passes of tools/profile_r2.sh): HBM bytes of one scoring step of the headline bench =
-everything adh_gather_kernel and the feature kernels moved, divided by the number of passes over the
-candidate table the profiled command made (each kernel name is launched once per chunk and pass).
+"""profiles/pmc_traffic.json from a PMC summary (tools/rocpd_summary.py output of the FETCH_SIZE and WRITE_SIZE
+passes of tools/profile_r3.sh): HBM-side bytes of one scoring step of the headline bench = everything the
+scoring kernels (adh_fused_kernel, and the two-kernel fallback: adh_gather_kernel, adh_feature*) moved, divided
+by the number of passes over the candidate table the profiled command made.
 
-    python tools/pmc_traffic.py gpurun_out/r02_pmc.csv <passes> <candidates_per_pass>
+    python tools/pmc_traffic.py gpurun_out/r03_pmc.csv <passes> <candidates_per_pass>
+
+FETCH_SIZE counts read requests at 64 B each while a request fills a 128-byte line, for a wide coalesced stream
+(MI355X_MICROARCH.md) and for the gather's pattern alike - one narrow load per lane, every load its own line
+(tools/probes/fetch_probe.hip, profiles/r03_fetch_probe.txt: 64.0 B per load): the read side is doubled.
 """
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCORING = ("adh_fused_kernel", "adh_gather_kernel", "adh_feature")
 
 
 def main(path, passes, n_cand):
@@ -19,30 +24,30 @@ def main(path, passes, n_cand):
         if len(parts) != 5 or parts[1] not in per:
             continue
         name = parts[0].replace("void ", "").split("(")[0]
-        if name.startswith("adh_gather_kernel") or name.startswith("adh_feature"):
+        if name.startswith(SCORING):
             per[parts[1]][name] = per[parts[1]].get(name, 0.0) + float(parts[4]) * 1024.0 / passes  # KB summed -> bytes per pass
-    fetch, write = sum(per["FETCH_SIZE"].values()), sum(per["WRITE_SIZE"].values())
-    feat = lambda d: sum(v for k, v in d.items() if k.startswith("adh_feature"))  # noqa: E731
+    fetch_counter, write = sum(per["FETCH_SIZE"].values()), sum(per["WRITE_SIZE"].values())
+    fetch = 2.0 * fetch_counter
     out = {
         "candidates_per_gpu": n_cand,
         "hbm_bytes_per_launch": fetch + write,
         "hbm_bytes_per_candidate": (fetch + write) / n_cand,
         "fetch_bytes": fetch,
+        "fetch_size_counter_bytes": fetch_counter,
         "write_bytes": write,
-        "per_kernel_fetch_bytes": {"adh_gather_kernel": per["FETCH_SIZE"].get("adh_gather_kernel", 0.0),
-                                   "feature kernels": feat(per["FETCH_SIZE"])},
-        "per_kernel_write_bytes": {"adh_gather_kernel": per["WRITE_SIZE"].get("adh_gather_kernel", 0.0),
-                                   "feature kernels": feat(per["WRITE_SIZE"])},
+        "per_kernel_fetch_bytes": {k: 2.0 * v for k, v in sorted(per["FETCH_SIZE"].items())},
+        "per_kernel_write_bytes": dict(sorted(per["WRITE_SIZE"].items())),
         "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {os.path.basename(path)}), KB -> bytes, summed "
-                f"over all launches of adh_gather_kernel and the feature kernels and divided by the {passes} passes over "
-                "the candidate table the profiled command made (one step = all chunks of one adh_score_candidates call). "
-                "WRITE_SIZE was calibrated exact on a streaming kernel; FETCH_SIZE reads half of a wide coalesced stream "
-                "on gfx950 (MI355X_MICROARCH.md) and is uncorrected here for the gather's narrow random loads: the read "
-                "side is a lower bound, at most 2x higher.",
+                f"over all launches of the scoring kernels and divided by the {passes:g} passes over the candidate table the "
+                "profiled command made (one pass = all chunks of one adh_score_candidates call, or one resident step). "
+                "Read side = 2 x FETCH_SIZE: the counter tallies a request at 64 B, the request fills a 128-byte line - "
+                "calibrated on a coalesced stream and on scattered 4/8/16-byte loads, one line each "
+                "(profiles/r03_fetch_probe.txt).  WRITE_SIZE as reported; it includes the register spills of the "
+                "fused kernels (scratch memory), which are most of it.",
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps(out)[:400])
+    print(json.dumps(out)[:600])
 
 
 if __name__ == "__main__":
