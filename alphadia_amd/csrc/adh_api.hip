@@ -250,7 +250,9 @@ int adh_create(adh_handle_t **handle, int device) {
     (void)hipFuncSetAttribute((const void *)adh_gather_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // (this kernel also has ADH_IM_STATIC_LDS bytes of static LDS)
-    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel,
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::Layout>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutCommon>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -36,64 +36,229 @@ __device__ __forceinline__ double logistic(double x, double mu, double sigma) {
     return 1.0 / (1.0 + exp(-a));
 }
 
-struct Layout {
-    int Kc, Oc, Sc, Fc, Ic;
-    __host__ __device__ Layout(const Caps &c) : Kc(c.k), Oc(c.o), Sc(c.s), Fc(c.f), Ic(c.i) {}
+// Register rows.  A loop `for (i < n) s += p[i]` over an LDS row with a run-time bound is a chain of LDS
+// latencies (load, add, load, add ...) on a wavefront that has nothing else to do; with the row in
+// registers - all loads issued together, compile-time indices, the tail beyond n filled with +0 - the chain
+// is the additions alone.  Adding +0 leaves a float sum as it is (sums start at +0), so the order and the
+// bits of the reference's sequential sums are kept.  FR cycles / SR scans fit; longer rows take the loops.
+constexpr int FR = 32;
+constexpr int SR = 40;
+constexpr int KR = 16;
+
+template <int N>
+__device__ __forceinline__ void load_row(float (&x)[N], const float *p, int stride, int n) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = (i < n) ? p[i * stride] : 0.0f;
+}
+// p[0] + p[stride] + ... (n terms, in order)
+template <int N>
+__device__ __forceinline__ float osum(const float *p, int stride, int n) {
+    float s = 0.0f;
+    if (n <= N) {
+        float v[N];
+        load_row<N>(v, p, stride, n);
+#pragma unroll
+        for (int i = 0; i < N; ++i) s += v[i];
+    } else {
+        for (int i = 0; i < n; ++i) s += p[i * stride];
+    }
+    return s;
+}
+// Pearson statistics of a register row against a second one, as scoring/utils.py:574-647 takes them:
+// means, population standard deviations and the covariance, float32 sums in index order
+template <int N>
+__device__ __forceinline__ void row_moments(const float (&x)[N], int n, float &mean, float &sd) {
+    float sx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) sx += x[i];
+    mean = sx / (float)n;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float d = x[i] - mean;
+        d = (i < n) ? d : 0.0f;
+        q += d * d;
+    }
+    sd = sqrtf(q / (float)n);
+}
+
+// Precursor features 4-16 (precursor_features.py:13-102; feat::assemble_precursor is the loop form) for up to
+// three isotopes and four observations: inputs to registers first, every loop unrolled, so that the one lane
+// that runs this waits for no LDS load in the middle of a sum
+__device__ __forceinline__ void precursor_features_rows(float *ft, int I, int O, const float *iso_int_p,
+                                                        const float *iso_mz_p, const float *spi_p, const double *hp_p,
+                                                        const double *omzp_p, const float *oi_p) {
+    float ii[3], mz[3], spi[3], oi[4];
+    double hp[3], omzp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i < I ? i : 0;
+        ii[i] = iso_int_p[j];
+        mz[i] = iso_mz_p[j];
+        spi[i] = spi_p[j];
+        hp[i] = hp_p[j];
+        omzp[i] = omzp_p[j];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) oi[o] = oi_p[o < O ? o : 0];
+    int amax = 0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+        if (i < I && ii[i] > (amax == 0 ? ii[0] : (amax == 1 ? ii[1] : ii[2]))) amax = i;
+    float w4 = 0, w5 = 0, f6 = 0, f7 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < I) {
+            float a = 0;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < O) a += spi[i] * oi[o];
+            if (i == 0) w4 = a;
+            if (i == amax) w5 = a;
+            f6 += a;
+            f7 += a * ii[i];
+        }
+    }
+    ft[4] = w4;
+    ft[5] = w5;
+    ft[6] = f6;
+    ft[7] = f7;
+    double wme = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < I && omzp[i] > 0) {
+            const double me = (omzp[i] - (double)mz[i]) / (double)mz[i] * 1e6;
+            wme += me * (double)ii[i];
+        }
+    ft[8] = (float)wme;
+    ft[9] = (float)fabs(wme);
+    ft[10] = (float)((double)mz[0] + wme * 1e-6 * (double)mz[0]);
+    ft[11] = (float)hp[0];
+    ft[12] = (float)(amax == 0 ? hp[0] : (amax == 1 ? hp[1] : hp[2]));
+    {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) a += hp[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) b += hp[i] * (double)ii[i];
+        ft[13] = (float)a;
+        ft[14] = (float)b;
+    }
+    {
+        // save_corrcoeff (scoring/utils.py:478-510): (f32, f32) and (f32, f64)
+        float sx = 0, sy = 0;
+        double sh = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sx += ii[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sy += spi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sh += hp[i];
+        const float xb = (float)((double)sx / (double)I), yb = (float)((double)sy / (double)I);
+        const double hb = sh / (double)I;
+        float num = 0, sxx = 0, syy = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) num += (ii[i] - xb) * (spi[i] - yb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) sxx += (ii[i] - xb) * (ii[i] - xb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) syy += (spi[i] - yb) * (spi[i] - yb);
+        const float den = sqrtf(sxx * syy);
+        ft[15] = (float)((double)num / ((double)den + 1e-12));
+        double numd = 0, shh = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) numd += (double)(ii[i] - xb) * (hp[i] - hb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < I) shh += (hp[i] - hb) * (hp[i] - hb);
+        const double dend = sqrt((double)sxx * shh);
+        ft[16] = (float)(numd / (dend + 1e-12));
+    }
+}
+
+// LDS capacities of a launch: taken from the launch's Caps (DimsDyn) or fixed at compile time (DimsFix), which
+// turns every array address below into an instruction offset - with run-time capacities the ~60 array bases
+// are scalar registers, more than there are, and the kernel spends a sixth of its instructions moving
+// them between scalar registers and the lanes of spill registers
+struct DimsDyn {
+    int Kc, Oc, Sc, Fc, Ic, SFc;  // SFc: cells of one (scan, cycle) plane
+    __host__ __device__ DimsDyn(const Caps &c) : Kc(c.k), Oc(c.o), Sc(c.s), Fc(c.f), Ic(c.i), SFc(c.s * c.f) {}
+};
+template <int K, int O, int S, int F, int I, int SF>
+struct DimsFix {
+    static constexpr int Kc = K, Oc = O, Sc = S, Fc = F, Ic = I, SFc = SF;
+    __host__ __device__ DimsFix(const Caps &) {}
+    __host__ __device__ static bool holds(const Caps &c) {
+        return c.k <= K && c.o <= O && c.s <= S && c.f <= F && c.i <= I && c.s * c.f <= SF;
+    }
+};
+template <class D>
+struct LayoutT : D {
+    __host__ __device__ LayoutT(const Caps &c) : D(c) {}
     // doubles
     // (the transfer function is dead after the template; the per-fragment results and the frame times,
     // born later, take its place)
     __host__ __device__ int d_qtf() const { return 0; }                      // [Ic][Oc][Sc], early
     __host__ __device__ int qtf_size() const {
-        const int a = Ic * Oc * Sc, b = 4 * Kc + Fc;
+        const int a = D::Ic * D::Oc * D::Sc, b = 4 * D::Kc + D::Fc;
         return a > b ? a : b;
     }
     __host__ __device__ int d_pk() const { return d_qtf(); }                 // [4][Kc], late
-    __host__ __device__ int d_frt() const { return d_qtf() + 4 * Kc; }       // [Fc] frame rt (float64), late
+    __host__ __device__ int d_frt() const { return d_qtf() + 4 * D::Kc; }       // [Fc] frame rt (float64), late
     __host__ __device__ int d_omz() const { return d_qtf() + qtf_size(); }
-    __host__ __device__ int d_ohe() const { return d_omz() + Kc * Oc; }
-    __host__ __device__ int d_omzu() const { return d_ohe() + Kc * Oc; }  // per selected fragment,
-    __host__ __device__ int d_oheu() const { return d_omzu() + Kc * Oc; } // before the presence mask
-    __host__ __device__ int d_accw() const { return d_oheu() + Kc * Oc; } // [2][Kc*Oc] weight sums
-    __host__ __device__ int d_po() const { return d_accw() + 2 * Kc * Oc; }   // [2][Oc]
-    __host__ __device__ int d_pi() const { return d_po() + 2 * Oc; }     // [2][Ic]
-    __host__ __device__ int n_double() const { return d_pi() + 2 * Ic; }
+    __host__ __device__ int d_ohe() const { return d_omz() + D::Kc * D::Oc; }
+    __host__ __device__ int d_omzu() const { return d_ohe() + D::Kc * D::Oc; }  // per selected fragment,
+    __host__ __device__ int d_oheu() const { return d_omzu() + D::Kc * D::Oc; } // before the presence mask
+    __host__ __device__ int d_accw() const { return d_oheu() + D::Kc * D::Oc; } // [2][Kc*Oc] weight sums
+    __host__ __device__ int d_po() const { return d_accw() + 2 * D::Kc * D::Oc; }   // [2][Oc]
+    __host__ __device__ int d_pi() const { return d_po() + 2 * D::Oc; }     // [2][Ic]
+    __host__ __device__ int n_double() const { return d_pi() + 2 * D::Ic; }
     // floats
-    __host__ __device__ int smax() const { return Sc > Fc ? Sc : Fc; }
+    __host__ __device__ int smax() const { return D::Sc > D::Fc ? D::Sc : D::Fc; }
     __host__ __device__ int f_wb() const { return 0; }                            // work [Kc*Oc*max(Sc,Fc)]
     // Two regions are used twice.  R1 holds the template until its profiles are taken, then the masked
     // frame / scan profiles; R2 holds the profiles before the presence mask, then the scan envelopes and
     // the quantification profiles.  (LDS per block is what bounds the resident waves of this kernel, and
     // the kernel's time follows them: 26 KB -> 40 KB per block costs 38 %.)
-    __host__ __device__ int f_work_end() const { return f_wb() + Kc * Oc * smax(); }
+    __host__ __device__ int f_work_end() const { return f_wb() + D::Kc * D::Oc * smax(); }
     __host__ __device__ int r1_size() const {
-        const int a = Oc * Sc * Fc, b = Kc * Oc * (Fc + Sc);
+        const int a = D::Oc * D::SFc, b = D::Kc * D::Oc * (D::Fc + D::Sc);
         return a > b ? a : b;
     }
     __host__ __device__ int f_r1() const { return f_work_end(); }
     __host__ __device__ int f_r2() const { return f_r1() + r1_size(); }
     __host__ __device__ int f_tpl() const { return f_r1(); }                      // [Oc*Sc*Fc]       R1, early
     __host__ __device__ int f_ffp() const { return f_r1(); }                      // [Kc*Oc*Fc]       R1, late
-    __host__ __device__ int f_fspr() const { return f_r1() + Kc * Oc * Fc; }      // [Kc*Oc*Sc] raw   R1, late
+    __host__ __device__ int f_fspr() const { return f_r1() + D::Kc * D::Oc * D::Fc; }      // [Kc*Oc*Sc] raw   R1, late
     __host__ __device__ int f_ffpu() const { return f_r2(); }                     // [Kc*Oc*Fc] before the mask  R2, early
-    __host__ __device__ int f_fspu() const { return f_r2() + Kc * Oc * Fc; }      // [Kc*Oc*Sc] before the mask  R2, early
+    __host__ __device__ int f_fspu() const { return f_r2() + D::Kc * D::Oc * D::Fc; }      // [Kc*Oc*Sc] before the mask  R2, early
     __host__ __device__ int f_fspe() const { return f_r2(); }                     // [Kc*Oc*Sc] envelope  R2, late
-    __host__ __device__ int f_bp() const { return f_r2() + Kc * Oc * Sc; }        // [Kc*Fc]          R2, late
-    __host__ __device__ int f_tfp() const { return f_r2() + Kc * Oc * (Fc + Sc); }  // [Oc*Fc]
-    __host__ __device__ int f_tsp() const { return f_tfp() + 2 * Oc * Fc; }       // [2][Oc*Sc] (tfp: raw, env)
-    __host__ __device__ int f_qm() const { return f_tsp() + 2 * Oc * Sc; }        // [Oc*Sc] qtf mask
-    __host__ __device__ int f_pk() const { return f_qm() + Oc * Sc; }             // [8][Kc]
-    __host__ __device__ int f_pko() const { return f_pk() + 8 * Kc; }             // [4][Kc*Oc]
-    __host__ __device__ int f_po() const { return f_pko() + 4 * Kc * Oc; }        // [4][Oc]
-    __host__ __device__ int f_pi() const { return f_po() + 4 * Oc; }              // [3][Ic]
-    __host__ __device__ int f_pf() const { return f_pi() + 3 * Ic; }              // [2][Fc]
-    __host__ __device__ int f_feat() const { return f_pf() + 2 * Fc; }
+    __host__ __device__ int f_bp() const { return f_r2() + D::Kc * D::Oc * D::Sc; }        // [Kc*Fc]          R2, late
+    __host__ __device__ int f_tfp() const { return f_r2() + D::Kc * D::Oc * (D::Fc + D::Sc); }  // [Oc*Fc]
+    __host__ __device__ int f_tsp() const { return f_tfp() + 2 * D::Oc * D::Fc; }       // [2][Oc*Sc] (tfp: raw, env)
+    __host__ __device__ int f_qm() const { return f_tsp() + 2 * D::Oc * D::Sc; }        // [Oc*Sc] qtf mask
+    __host__ __device__ int f_pk() const { return f_qm() + D::Oc * D::Sc; }             // [8][Kc]
+    __host__ __device__ int f_pko() const { return f_pk() + 8 * D::Kc; }             // [4][Kc*Oc]
+    __host__ __device__ int f_po() const { return f_pko() + 4 * D::Kc * D::Oc; }        // [4][Oc]
+    __host__ __device__ int f_pi() const { return f_po() + 4 * D::Oc; }              // [3][Ic]
+    __host__ __device__ int f_pf() const { return f_pi() + 3 * D::Ic; }              // [2][Fc]
+    __host__ __device__ int f_feat() const { return f_pf() + 2 * D::Fc; }
     __host__ __device__ int n_float() const { return f_feat() + ADH_NUM_FEATURES; }
     // ints
     __host__ __device__ int i_pk() const { return 0; }                   // [4][Kc]
-    __host__ __device__ int i_pko() const { return i_pk() + 4 * Kc; }    // [Kc*Oc]
-    __host__ __device__ int i_obs() const { return i_pko() + Kc * Oc; }  // [Oc]
-    __host__ __device__ int n_int() const { return i_obs() + Oc; }
-    __host__ __device__ int n_byte() const { return ((5 * Kc + 7) / 8) * 8; }
+    __host__ __device__ int i_pko() const { return i_pk() + 4 * D::Kc; }    // [Kc*Oc]
+    __host__ __device__ int i_obs() const { return i_pko() + D::Kc * D::Oc; }  // [Oc]
+    __host__ __device__ int n_int() const { return i_obs() + D::Oc; }
+    __host__ __device__ int n_byte() const { return ((5 * D::Kc + 7) / 8) * 8; }
     __host__ __device__ size_t bytes() const {
         size_t b = (size_t)n_double() * 8;
         b += ((size_t)n_float() * 4 + 7) / 8 * 8;
@@ -102,14 +267,22 @@ struct Layout {
         return b;
     }
 };
+using Layout = LayoutT<DimsDyn>;
+// the common shape: up to 12 fragments, one observation, 40 scans, 32 cycles, 1152 cells per plane, 3 isotopes
+// (13 704 + 2 560 static bytes: ten blocks per CU, as the specified 38 x 29 tiles get with run-time capacities)
+using DimsCommon = DimsFix<12, 1, 40, 32, 3, 1152>;
+using LayoutCommon = LayoutT<DimsCommon>;
 
 }  // namespace featim
 
 #define ADH_IM_STAGE 128          // cells staged per round of the tile passes (two per lane)
 #define ADH_IM_STATIC_LDS (ADH_IM_STAGE * 20)  // static LDS of adh_feature_im_kernel (chunk lists / Gram matrices: 2 176 B)
-size_t adh_feature_im_lds_bytes(const Caps &c) { return featim::Layout(c).bytes(); }
+size_t adh_feature_im_lds_bytes(const Caps &c) {
+    return featim::DimsCommon::holds(c) ? featim::LayoutCommon(c).bytes() : featim::Layout(c).bytes();
+}
 
-__global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
+template <class LAY>
+__global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
     int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
     DevOut out, Caps caps) {
@@ -126,7 +299,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     float *const l_v = reinterpret_cast<float *>(l_w + ADH_WAVE);
     float *const l_rx = l_v + ADH_WAVE;
     float *const l_ry = l_rx + ADH_WAVE;
-    const Layout lay(caps);
+    const LAY lay(caps);
     const int Kc = lay.Kc, Oc = lay.Oc, Sc = lay.Sc, Fc = lay.Fc, Ic = lay.Ic;
     double *const D = reinterpret_cast<double *>(smem);
     float *const Fl = reinterpret_cast<float *>(smem + (size_t)lay.n_double() * 8);
@@ -146,7 +319,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     const int c0 = (r.frame_start - z) / L;
     const int F = (r.frame_stop - z) / L - c0;
     const int S = r.scan_stop - r.scan_start;
-    const int O = r.n_obs, Op = r.n_ms1;
+    // (a candidate that gets this far has at least one observation - the gather kernel leaves K0 = 0 otherwise -
+    // so a launch whose capacity is one observation has exactly one: a compile-time 1 in the fixed layout)
+    const int O = (lay.Oc == 1) ? 1 : r.n_obs, Op = r.n_ms1;
     const int I = min(n_iso_cols, (int)cfg.top_k_isotopes);
     const int SF = S * F, OSF = O * SF;
     const int top_k = out.top_k;
@@ -355,17 +530,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     float *const mfw = ftc + Kc * Oc;
     // np.sum(np.sum(template, axis=-1), axis=-1): the inner sums (one per scan) are independent, the
     // outer one adds them in scan order
-    for (int c = lane; c < O * S; c += ADH_WAVE) {
-        float sf = 0;
-        for (int f = 0; f < F; ++f) sf += tpl[c * F + f];
-        work_b[c] = sf;
-    }
+    // (the per-scan sums are the template's scan profile: tsp_raw keeps them)
+    for (int c = lane; c < O * S; c += ADH_WAVE) tsp_raw[c] = osum<FR>(tpl + c * F, 1, F);
     adh_wave_sync();
-    if (lane < O) {
-        float so = 0;
-        for (int sc = 0; sc < S; ++sc) so += work_b[lane * S + sc];
-        tsum[lane] = so;
-    }
+    if (lane < O) tsum[lane] = osum<SR>(tsp_raw + lane * S, 1, S);
     adh_wave_sync();
     // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
     // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
@@ -568,8 +736,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
         for (int o = 0; o < O; ++o) {
-            float ss = 0;
-            for (int sc = 0; sc < S; ++sc) ss += fsp_u[(k * O + o) * S + sc];  // sum of the per-scan sums
+            const float ss = osum<SR>(fsp_u + (k * O + o) * S, 1, S);  // sum of the per-scan sums
             rowsum[k * O + o] = ss;
             so += ss;
         }
@@ -635,15 +802,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     // The template's profiles first: the masked fragment profiles then take the template's place.
     for (int c = lane; c < O * F; c += ADH_WAVE) {
         int o = c / F, f = c - o * F;
-        float a = 0;
-        for (int sc = 0; sc < S; ++sc) a += tpl[(o * S + sc) * F + f];
-        tfp_raw[c] = a;
+        tfp_raw[c] = osum<SR>(tpl + o * S * F + f, F, S);
     }
-    for (int c = lane; c < O * S; c += ADH_WAVE) {
-        float a = 0;
-        for (int f = 0; f < F; ++f) a += tpl[c * F + f];
-        tsp_raw[c] = a;
-    }
+    // (tsp_raw: the per-scan sums taken for the observation importance above)
     adh_wave_sync();
     for (int c = lane; c < K * O * F; c += ADH_WAVE) {
         int k = c / (O * F), rem = c - k * O * F;
@@ -812,6 +973,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         obs_int[k] = t;
     }
     adh_wave_sync();
+    if (caps.stop_phase == 45) return;
     for (int k = lane; k < K; k += ADH_WAVE) {
         float ws = 0;
         for (int o = 0; o < O; ++o) {
@@ -854,6 +1016,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         ord[rk] = k;
     }
     adh_wave_sync();
+    if (caps.stop_phase == 46) return;
 
     Assemble asmv;
     asmv.run = nullptr;  // location features are float64 here, filled below
@@ -865,8 +1028,161 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     asmv.omzp = omzp; asmv.hp = hp; asmv.ohe = ohe; asmv.area = area; asmv.height = height;
     asmv.merr = merr; asmv.kmap = kmap; asmv.ord = ord; asmv.g_type = g_type; asmv.g_pos = g_pos;
     asmv.n_present = n_present; asmv.K0 = K0; asmv.top3 = 0.0f;
+    // Feature assembly.  The loop form (feat::assemble_*) is ~45 short sequential sums over fragments on one
+    // lane, every term an LDS load away: a third of a millisecond per 60 000 candidates.  Up to 16 fragments:
+    // lane k provides its term of every sum (a skipped term is +0, which leaves a sum as it is), lane j adds
+    // up sum j in fragment order from registers and finishes the features that hang on it.
+    const bool lanes_ok = K <= KR && I <= 3 && O <= 4 && caps.stop_phase != 21;
+    double(*const t64)[6] = reinterpret_cast<double(*)[6]>(pool);                   // [KR][6]; the chunk lists are idle
+    float(*const t32)[8] = reinterpret_cast<float(*)[8]>(pool + KR * 6 * 8);        // [KR][8]
+    double *const red64 = reinterpret_cast<double *>(pool + KR * 6 * 8 + KR * 8 * 4);  // [16]
+    static_assert(KR * 6 * 8 + KR * 8 * 4 + 16 * 8 <= ADH_IM_STATIC_LDS, "term matrices fit the chunk lists");
+    if (lanes_ok && caps.stop_phase != 20) {
+        const bool kl = lane < K;
+        const int k = kl ? lane : 0;
+        const double area_k = area[k], m2 = height[k], merr_k = merr[k];
+        const float gfin = g_fin[k], oint = obs_int[k];
+        const int type = g_type[k], pos = g_pos[k];
+        bool hrow = false;
+        for (int o = 0; o < O; ++o) hrow = hrow || ohe[k * O + o] > 0;
+        const bool ipos = kl && oint > 0.0f, hpos = kl && m2 > 0.0;
+        const bool isb = kl && type == 98, isy = kl && type == 121;
+        const int n_int = __popcll(__ballot(ipos)), n_hei = __popcll(__ballot(hpos));
+        const int n_hrows = __popcll(__ballot(kl && hrow));
+        const int nb = __popcll(__ballot(isb)), ny = __popcll(__ballot(isy));
+        int min_y = isy ? pos : 255, max_b = isb ? pos : 0;
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {  // (fragments sit in lanes 0..15)
+            min_y = min(min_y, __shfl_xor(min_y, m));
+            max_b = max(max_b, __shfl_xor(max_b, m));
+        }
+        min_y = __shfl(min_y, 0);
+        max_b = __shfl(max_b, 0);
+        const bool ov = (isy && pos < max_b) || (isb && pos > min_y);
+        const int n_ov = __popcll(__ballot(ov));
+        const int n3 = min(K, 3);
+        if (kl) {
+            double *t = t64[k];
+            t[0] = area_k;
+            t[1] = m2;
+            t[2] = (double)gfin;
+            t[3] = merr_k;
+            t[4] = ov ? area_k : 0.0;
+            t[5] = ov ? merr_k : 0.0;
+            // cosine_similarity_a1 (features_utils.py:40-47) of the observation sums
+            float tn = 0.0f, fn = 0.0f, dot = 0.0f;
+            const float *rs = rowsum + kmap[k] * O;
+            for (int o = 0; o < O; ++o) tn += tsum[o] * tsum[o];
+            tn = sqrtf(tn);
+            for (int o = 0; o < O; ++o) fn += rs[o] * rs[o];
+            fn = sqrtf(fn);
+            for (int o = 0; o < O; ++o) dot += rs[o] * tsum[o];
+            const float pr = fn * tn;
+            const float score = (float)((double)dot / ((double)pr + 0.0001));
+            float *u = t32[k];
+            u[0] = ipos ? gfin : 0.0f;
+            u[1] = hpos ? gfin : 0.0f;
+            u[2] = ipos ? score : 0.0f;
+            u[3] = isb ? oint : 0.0f;
+            u[4] = isy ? oint : 0.0f;
+        }
+        adh_wave_sync();
+        {
+            // lane j < 6: float64 sum j; 6 <= j < 11: float32 sum j - 6; lane 11: mean_top3 mass error, by rank
+            double s64 = 0.0;
+            float s32 = 0.0f;
+            {
+                double v64[KR];
+                float v32[KR];
+                const int c64 = min(lane, 5), c32 = min(max(lane - 6, 0), 4);
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    v64[j] = t64[j][c64];
+                    v32[j] = t32[j][c32];
+                }
+                if (lane == 11) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v64[i] = merr[i < n3 ? ord[i] : 0];
+                }
+                const int n64 = lane == 11 ? n3 : K;
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    s64 += (j < n64) ? v64[j] : 0.0;
+                    s32 += (j < K) ? v32[j] : 0.0f;
+                }
+            }
+            // the quotients: lane -> (numerator, denominator)
+            //   0-2 sums of area / height / intensity over K (np.corrcoef means), 3 mass error / K (42),
+            //   4, 5 overlap area / mass error over n_ov (44, 45), 6 n_int / K (20), 7 n_hei / K (21),
+            //   8 cosine sum / n_int (24), 11 top-3 mass error / n3 (41), 15 n_present / K0 (28, candidate.py:362)
+            double num = s64, den = (double)K;
+            if (lane == 4 || lane == 5) den = (double)n_ov;
+            if (lane == 6) num = (double)n_int;
+            if (lane == 7) num = (double)n_hei;
+            if (lane == 8) num = (double)s32, den = (double)n_int;
+            if (lane == 11) den = (double)n3;
+            if (lane == 15) num = (double)n_present, den = (double)K0;
+            const double quo = num / den;
+            if (lane < 3) red64[lane] = quo;
+            if (lane == 1) red64[3] = s64;  // (the sum of the heights decides whether feature 19 is taken)
+            float *ft = featv;
+            if (lane == 3) ft[42] = (float)quo;
+            if ((lane == 4 || lane == 5) && nb > 0 && ny > 0) {
+                if (lane == 4) ft[43] = (float)n_ov;
+                ft[40 + lane] = n_ov > 0 ? (float)quo : (lane == 4 ? 0.0f : 15.0f);
+            }
+            if (lane == 6) ft[22] = s32, ft[20] = (float)quo;
+            if (lane == 7) ft[23] = s32, ft[21] = (float)quo;
+            if (lane == 8 && n_int > 0) ft[24] = (float)quo;
+            if (lane == 9 || lane == 10) {
+                const float lg = (float)log((double)s32 + 1.0);
+                ft[16 + lane] = ((lane == 9 ? nb : ny) > 0) ? lg : 0.0f;
+            }
+            if (lane == 11) ft[41] = (float)quo;
+            if (lane == 15) ft[28] = (float)quo, ft[17] = (float)O;
+        }
+        adh_wave_sync();
+        {
+            // np.corrcoef terms (feat::corrcoef01): area vs intensity, height vs intensity
+            const double mx_a = red64[0], mx_h = red64[1], my = red64[2];
+            if (kl) {
+                const double a = area_k - mx_a, h = m2 - mx_h, b = (double)gfin - my;
+                double *t = t64[k];
+                t[0] = a * a;
+                t[1] = b * b;
+                t[2] = a * b;
+                t[3] = h * h;
+                t[4] = h * b;
+            }
+        }
+        adh_wave_sync();
+        {
+            double v64[KR], s64 = 0.0;
+            const int c64 = min(lane, 4);
+#pragma unroll
+            for (int j = 0; j < KR; ++j) v64[j] = t64[j][c64];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) s64 += (j < K) ? v64[j] : 0.0;
+            if (lane < 5) red64[7 + lane] = s64;
+        }
+        adh_wave_sync();
+        if (lane < 2) {
+            // lane 0: feature 18 (areas), lane 1: feature 19 (heights)
+            const double fact = fmax((double)K - 1.0, 0.0);
+            const double inv = 1.0 / fact;
+            const double cxx = red64[lane ? 10 : 7] * inv, cyy = red64[8] * inv;
+            const double cxy = red64[lane ? 11 : 9] * inv;
+            const double s0 = sqrt(cxx), s1 = sqrt(cyy);
+            double cc = cxy / s1 / s0;
+            if (fabs(cc) > 1.0) cc = (cc > 0) ? 1.0 : -1.0;
+            const bool on = lane ? (red64[3] > 0.0) : (n_hrows > 0);
+            if (on) featv[18 + lane] = (float)cc;
+        }
+        if (lane == 2) featv[27] = featv[25] - featv[26];
+        if (lane == 3) precursor_features_rows(featv, I, O, iso_int, iso_mz, spi, hp, omzp, oi);
+    }
     if (lane == 0) {
-        if (caps.stop_phase != 20) feat::assemble_part1(asmv, I, O, K);  // (20: developer ablation, no assembly)
+        if (caps.stop_phase != 20 && !lanes_ok) feat::assemble_part1(asmv, I, O, K);  // (20: developer ablation, no assembly)
         // location_features.py:8-33 with float64 mobility / rt arrays
         featv[0] = (float)(run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1]);
         featv[1] = (float)(run.rt[r.frame_stop - 1] - run.rt[r.frame_start]);
@@ -880,25 +1196,61 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     adh_wave_sync();
     float *cen = work_b;
     {
+        // fragments whose scan profiles hold any signal (fragment_features.py:447-452), in order
         int Km = 0;
-        for (int k = 0; k < K; ++k) {
+        if (K <= ADH_WAVE) {  // one fragment per lane
             float so = 0;
-            for (int o = 0; o < O; ++o) {
-                float ss = 0;
-                for (int sc = 0; sc < S; ++sc) ss += fsp[(k * O + o) * S + sc];
-                so += ss;
-            }
-            if (so > 0.0f) {
-                if (lane == 0) mkeep[Km] = k;
-                ++Km;
+            if (lane < K)
+                for (int o = 0; o < O; ++o) so += osum<SR>(fsp + (lane * O + o) * S, 1, S);
+            const unsigned long long keep = __ballot(lane < K && so > 0.0f);
+            Km = __popcll(keep);
+            if (lane < K && so > 0.0f) mkeep[__popcll(keep & ((1ull << lane) - 1ull))] = lane;
+        } else {
+            for (int k = 0; k < K; ++k) {
+                float so = 0;
+                for (int o = 0; o < O; ++o) {
+                    float ss = 0;
+                    for (int sc = 0; sc < S; ++sc) ss += fsp[(k * O + o) * S + sc];
+                    so += ss;
+                }
+                if (so > 0.0f) {
+                    if (lane == 0) mkeep[Km] = k;
+                    ++Km;
+                }
             }
         }
         adh_wave_sync();
+        const bool rows = S <= SR;  // scan rows fit the registers
         if (Km >= 3) {
             float isum = 0;
             for (int a = 0; a < Km; ++a) isum += g_int[mkeep[a]];
             for (int a = lane; a < Km; a += ADH_WAVE) mnorm[a] = g_int[mkeep[a]] / isum;
             // centred rows + std per (a, o) over the scan axis (scoring/utils.py:545-559)
+            if (rows) {
+                // ... and, with the centred row still in registers, its correlation with the template's
+                // scan profile (scoring/utils.py:574-647)
+                for (int c = lane; c < Km * O; c += ADH_WAVE) {
+                    const int a = c / O, o = c - a * O;
+                    float pr[SR], py[SR];
+                    load_row<SR>(pr, fsp + (mkeep[a] * O + o) * S, 1, S);
+                    load_row<SR>(py, tsp + o * S, 1, S);
+                    float mean, sd, ym, ysd;
+                    row_moments<SR>(pr, S, mean, sd);
+                    row_moments<SR>(py, S, ym, ysd);
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < SR; ++i) {
+                        float d = pr[i] - mean;
+                        d = (i < S) ? d : 0.0f;
+                        if (i < S) cen[c * S + i] = d;
+                        dot += d * (py[i] - ym);
+                    }
+                    mfw[c] = sd;
+                    const float cov = dot / (float)S;
+                    const float sm = sd * ysd;
+                    ftc[o * Km + a] = (float)((double)cov / ((double)sm + 1e-12));
+                }
+            } else {
             for (int c = lane; c < Km * O; c += ADH_WAVE) {
                 int a = c / O, o = c - a * O;
                 const float *p = fsp + (mkeep[a] * O + o) * S;
@@ -909,6 +1261,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 for (int sc = 0; sc < S; ++sc) cen[c * S + sc] = p[sc] - mean;
                 for (int sc = 0; sc < S; ++sc) q += cen[c * S + sc] * cen[c * S + sc];
                 mfw[c] = sqrtf(q / (float)S);
+            }
             }
             adh_wave_sync();
             // np.dot(profile_centered, profile_centered.T) over the scan axis (scoring/utils.py:559, BLAS
@@ -922,27 +1275,45 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                     typedef float floatx4 __attribute__((ext_vector_type(4)));
                     floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
                     const int i = lane & 15, kq = lane >> 4;
+                    if (rows) {  // all loads first (a step of all-zero operands adds nothing to the tile)
+                        float v[SR / 4];
+#pragma unroll
+                        for (int j = 0; j < SR / 4; ++j) {
+                            const int sc = 4 * j + kq;
+                            v[j] = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < SR / 4; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], v[j], d, 0, 0, 0);
+                    } else {
                     for (int s0 = 0; s0 < S; s0 += 4) {
                         const int sc = s0 + kq;
                         const float v = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
                     }
+                    }
                     adh_wave_sync();
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) gram[4 * kq + rr][i] = d[rr];
                     adh_wave_sync();
-                    for (int a = lane; a < Km; a += ADH_WAVE)
-                        for (int b = 0; b < Km; ++b) {
-                            float cov = gram[a][b] / (float)S;
-                            float sm = mfw[a * O + o] * mfw[b * O + o];
-                            float cm = (float)((double)cov / ((double)sm + 1e-12));
-                            redm[a][b] += cm * oi[o];
-                        }
+                    // one (a, b) pair per lane and round: every pair has its own float64 division
+                    for (int pr = lane; pr < Km * Km; pr += ADH_WAVE) {
+                        const int a = pr / Km, b = pr - a * Km;
+                        float cov = gram[a][b] / (float)S;
+                        float sm = mfw[a * O + o] * mfw[b * O + o];
+                        float cm = (float)((double)cov / ((double)sm + 1e-12));
+                        redm[a][b] += cm * oi[o];
+                    }
                 }
                 adh_wave_sync();
                 for (int a = lane; a < Km; a += ADH_WAVE) {
-                    float acc = 0;
-                    for (int b = 0; b < Km; ++b) acc += redm[a][b] * mnorm[b];
+                    float ra[KR], rb[KR], acc = 0;
+#pragma unroll
+                    for (int b = 0; b < KR; ++b) {
+                        ra[b] = redm[a][b];
+                        rb[b] = (b < Km) ? mnorm[b] : 0.0f;
+                    }
+#pragma unroll
+                    for (int b = 0; b < KR; ++b) acc += (b < Km) ? ra[b] * rb[b] : 0.0f;
                     mlist[a] = acc;
                 }
             } else {
@@ -965,6 +1336,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
                 }
             }
             // fragment vs template scan correlation (scoring/utils.py:574-647)
+            if (!rows)
             for (int c = lane; c < Km * O; c += ADH_WAVE) {
                 int a = c / O, o = c - a * O;
                 const float *py = tsp + o * S;
@@ -1098,6 +1470,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         }
     }
     adh_wave_sync();
+    if (caps.stop_phase == 71) return;
     float top3 = 0.0f;
     if (lane == 0) {
         int n3 = min(K, 3);
@@ -1128,6 +1501,56 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
     adh_wave_sync();
     const double rt_width = run.rt[r.frame_stop - 1] - run.rt[r.frame_start];
     const double mob_width = run.mobility[r.scan_start] - run.mobility[r.scan_stop - 1];
+    const bool reg_rows = F <= FR && S <= SR;
+    if (reg_rows) {
+        // the same statistics with the rows in registers (see load_row)
+        for (int c = lane; c < K * O; c += ADH_WAVE) {
+            const int k = c / O, o = c - k * O;
+            float px[FR], py[FR];
+            load_row<FR>(px, ffp + c * F, 1, F);
+            load_row<FR>(py, tfp + o * F, 1, F);
+            float ym, ysd, xmn, xsd;
+            row_moments<FR>(py, F, ym, ysd);
+            row_moments<FR>(px, F, xmn, xsd);
+            float dot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < FR; ++i) {
+                float dx = px[i] - xmn;
+                dx = (i < F) ? dx : 0.0f;  // (one zero factor is enough)
+                dot += dx * (py[i] - ym);
+            }
+            const float cov = dot / (float)F;
+            const float sm = xsd * ysd;
+            ftc[o * K + k] = (float)((double)cov / ((double)sm + 1e-12));
+            float mxv = px[0];
+            int am = 0;
+#pragma unroll
+            for (int i = 1; i < FR; ++i) {
+                const bool up = i < F && px[i] > mxv;
+                mxv = up ? px[i] : mxv;
+                am = up ? i : am;
+            }
+            const double half = (double)mxv / 2.0;
+            int n_above = 0;
+#pragma unroll
+            for (int i = 0; i < FR; ++i) n_above += (i < F && (double)px[i] > half) ? 1 : 0;
+            const double frac = (double)n_above / (double)F;
+            fpeak[c] = am;
+            fw[c] = (float)(frac * rt_width);
+            // mobility FWHM (profile_features.py:151-188)
+            float ps[SR];
+            load_row<SR>(ps, fsp + c * S, 1, S);
+            float mxs = ps[0];
+#pragma unroll
+            for (int i = 1; i < SR; ++i) mxs = (i < S && ps[i] > mxs) ? ps[i] : mxs;
+            const double halfs = (double)mxs / 2.0;
+            int n_ab = 0;
+#pragma unroll
+            for (int i = 0; i < SR; ++i) n_ab += (i < S && (double)ps[i] > halfs) ? 1 : 0;
+            const double fracs = (double)n_ab / (double)S;
+            mfw[c] = (float)(fracs * mob_width);
+        }
+    } else
     for (int c = lane; c < K * O; c += ADH_WAVE) {
         int k = c / O, o = c - k * O;
         const float *px = ffp + c * F;
@@ -1179,6 +1602,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         mfw[c] = (float)(fracs * mob_width);
     }
     adh_wave_sync();
+    if (caps.stop_phase == 72) return;
     if (lane < O) {
         int o = lane;
         int lo_v = 0, hi_v = 0, r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -1196,7 +1620,56 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         medpk[o] = (float)m;
     }
     adh_wave_sync();
-    if (lane == 0) {
+    if (lanes_ok) {
+        // features 31-40 (feat::assemble_part2 is the loop form), lane-parallel as above
+        const bool kl = lane < K;
+        const int k = kl ? lane : 0;
+        const int type = g_type[k];
+        const bool isb = kl && type == 98, isy = kl && type == 121;
+        const unsigned long long bb = __ballot(isb), by = __ballot(isy), below = (1ull << lane) - 1ull;
+        const int nbi = __popcll(bb), nyi = __popcll(by);
+        if (kl) {
+            float rr = 0, ml = 0, mm = 0;
+            for (int o = 0; o < O; ++o) rr += ftc[o * K + k] * oi[o];
+            for (int o = 0; o < O; ++o) ml += fw[k * O + o] * oi[o];
+            for (int o = 0; o < O; ++o) mm += mfw[k * O + o] * oi[o];
+            const float gi = g_int[k], co = corr[ord[k]];
+            float *u = t32[k];
+            u[0] = corr[k];
+            u[1] = rr * gi;
+            u[2] = ml * gi;
+            u[3] = mm * gi;
+            // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
+            u[4] = (isb && __popcll(bb & below) < 3) ? co : 0.0f;
+            u[5] = (isy && __popcll(by & below) < 3) ? co : 0.0f;
+        }
+        adh_wave_sync();
+        {
+            float v32[KR], s32 = 0.0f;
+            const int c32 = min(lane, 5);
+#pragma unroll
+            for (int j = 0; j < KR; ++j) v32[j] = t32[j][c32];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) s32 += (j < K) ? v32[j] : 0.0f;
+            float *ft = featv;
+            if (caps.stop_phase != 20) {
+                if (lane == 0) ft[31] = (float)((double)s32 / (double)K), ft[32] = top3;
+                if (lane == 1) ft[33] = s32;
+                if (lane == 2) ft[38] = s32;
+                if (lane == 4 && nbi > 0) ft[34] = (float)((double)s32 / (double)min(nbi, 3)), ft[35] = (float)nbi;
+                if (lane == 5 && nyi > 0) ft[36] = (float)((double)s32 / (double)min(nyi, 3)), ft[37] = (float)nyi;
+                if (lane == 6) {
+                    double acc = 0;
+                    for (int o = 0; o < O; ++o) {
+                        double delta = (double)medpk[o] - floor((double)F / 2.0);
+                        acc += delta * (double)oi[o];
+                    }
+                    ft[40] = (float)acc;
+                }
+            }
+            if (lane == 3) ft[39] = s32;
+        }
+    } else if (lane == 0) {
         asmv.top3 = top3;
         if (caps.stop_phase != 20) feat::assemble_part2(asmv, O, K, F);
         float agg = 0;
@@ -1208,6 +1681,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_im_kernel(
         featv[39] = agg;
     }
     adh_wave_sync();
+    if (caps.stop_phase == 73) return;
 
     if (lane < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + lane] = featv[lane];
     if (cfg.collect_fragments) {

@@ -504,8 +504,16 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                 Caps cc = p.caps_all;
                 if (c == 0) cc.o = 1;
                 if (c == 1) cc.o = std::min(cc.o, 2);
-                hipLaunchKernelGGL(adh_feature_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), adh_feature_im_lds_bytes(cc) + f_pad, st,
-                                   h->tims, p.d_recs_im + first, h->cs.iso, n_iso, *cfg, d_scratch, *out, cc);
+                // (capacities fixed at compile time for the common shape: adh_features_im.hip, DimsFix)
+                const bool common = featim::DimsCommon::holds(cc) && !getenv("ADH_DEBUG_IM_DYNAMIC_LAYOUT");
+                if (common)
+                    hipLaunchKernelGGL(adh_feature_im_kernel<featim::LayoutCommon>, dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                       *cfg, d_scratch, *out, cc);
+                else
+                    hipLaunchKernelGGL(adh_feature_im_kernel<featim::Layout>, dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::Layout(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso, *cfg,
+                                       d_scratch, *out, cc);
                 HIP_TRY(hipGetLastError());
             }
             first += cnt;

@@ -516,8 +516,9 @@ def test_timstof_larger_case_all_configs(ctx, oracle_lib):
 
 def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     """The staged search indices (m/z lookup table, (TOF bin, cycle) table - one column per cycle or per
-    block of cycles) and the two forms of the tiles (sparse entry lists, dense tiles) are different ways
-    to the same numbers: every output table must come out bit for bit the same."""
+    block of cycles), the two forms of the tiles (sparse entry lists, dense tiles) and the two forms of the
+    feature assembly (lane-parallel sums, one-lane loops) are different ways to the same numbers: every output
+    table must come out bit for bit the same."""
     from alphadia_amd.scoring import assemble_candidates
 
     case = syn.make_timstof_case(n_precursors=300, n_cycles=70, config_id=45, per_precursor=2, n_ms2_frames=5,
@@ -528,7 +529,8 @@ def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     base = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
     base = {k: np.array(v, copy=True) for k, v in base.items()}
     assert base["valid"].sum() > 100
-    for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8")):
+    for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8"),
+                dict(ADH_DEBUG_IM="21")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
