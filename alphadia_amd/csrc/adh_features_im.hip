@@ -1275,21 +1275,13 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
                     typedef float floatx4 __attribute__((ext_vector_type(4)));
                     floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
                     const int i = lane & 15, kq = lane >> 4;
-                    if (rows) {  // all loads first (a step of all-zero operands adds nothing to the tile)
-                        float v[SR / 4];
-#pragma unroll
-                        for (int j = 0; j < SR / 4; ++j) {
-                            const int sc = 4 * j + kq;
-                            v[j] = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
-                        }
-#pragma unroll
-                        for (int j = 0; j < SR / 4; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], v[j], d, 0, 0, 0);
-                    } else {
+                    // (NOT unrolled with the operands loaded ahead: hipcc 7.2 then gives an MFMA of the chain a
+                    // destination that overlaps the operand register of a later one - v_mfma v[2:5], v5, v5, v[16:19]
+                    // - and the tile comes out different from run to run on ~1 of 2 000 candidates)
                     for (int s0 = 0; s0 < S; s0 += 4) {
                         const int sc = s0 + kq;
                         const float v = (i < Km && sc < S) ? cen[(i * O + o) * S + sc] : 0.0f;
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
-                    }
                     }
                     adh_wave_sync();
 #pragma unroll
@@ -1303,6 +1295,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
                         float cm = (float)((double)cov / ((double)sm + 1e-12));
                         redm[a][b] += cm * oi[o];
                     }
+
                 }
                 adh_wave_sync();
                 for (int a = lane; a < Km; a += ADH_WAVE) {

@@ -36,6 +36,9 @@
 #ifndef ADH_FUSED_WAVES
 #define ADH_FUSED_WAVES 3      // wavefronts per SIMD the register budget is held to
 #endif
+#ifndef ADH_FUSED_FM3
+#define ADH_FUSED_FM3 24       // longest one-observation rows that run at ADH_FUSED_WAVES; longer ones at ADH_FUSED_WAVES2
+#endif
 #ifndef ADH_FUSED_WAVES2
 #define ADH_FUSED_WAVES2 2     // ... of the two-observation kernels (3: spills, 15 % slower; same-box A/B)
 #endif
@@ -1543,11 +1546,14 @@ constexpr size_t adh_fused_lds_bytes(int fm_max, int no) {
            (ADH_WAVE / 16);
 }
 
-// One launch per observation count (and one more each for FM = 32, which needs more LDS): with the bodies of
-// both in one kernel every wavefront pays the larger LDS block and spill area of the two-observation code
-// (measured: 3 ms of the 13.5 ms of the one-observation candidates of the bench).
-template <int FM_MAX, int NO>
-__global__ __launch_bounds__(ADH_WAVE, NO == 1 ? ADH_FUSED_WAVES : ADH_FUSED_WAVES2) void adh_fused_kernel(
+// One launch per observation count: with the bodies of both in one kernel every wavefront pays the larger LDS
+// block and spill area of the two-observation code (measured: 3 ms of the 13.5 ms of the one-observation
+// candidates of the bench).  And one more each for the longest rows - FM = 32 needs more LDS, and with one
+// observation the bodies for 28 and 32 cycles are the only ones that do not fit the registers of three
+// wavefronts per SIMD (120 / 252 bytes of scratch per lane, 2.5 GB of spill stores per 3 M candidates):
+// they run at two, without a spill, in a launch of their own.
+template <int FM_MIN, int FM_MAX, int NO>
+__global__ __launch_bounds__(ADH_WAVE, (NO == 1 && FM_MAX <= ADH_FUSED_FM3) ? ADH_FUSED_WAVES : ADH_FUSED_WAVES2) void adh_fused_kernel(
     DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, FusedClasses fc,
     const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
     const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
@@ -1557,23 +1563,20 @@ __global__ __launch_bounds__(ADH_WAVE, NO == 1 ? ADH_FUSED_WAVES : ADH_FUSED_WAV
     while (c + 1 < fc.n && b >= fc.first_block[c + 1]) ++c;
     const CandRec *recs = plan + fc.first_cand[c];
     const int32_t n = fc.n_cand[c], blk = b - fc.first_block[c];
-#define ADH_FUSED_CASE(KIND, FM)                                                                                   \
-    case KIND:                                                                                                     \
-        fused_body<FM, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
-        break;
-    if (FM_MAX > 28) {
-        fused_body<32, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
-    } else {
-        switch (fc.kind[c] % 7) {
-            ADH_FUSED_CASE(0, 8)
-            ADH_FUSED_CASE(1, 12)
-            ADH_FUSED_CASE(2, 16)
-            ADH_FUSED_CASE(3, 20)
-            ADH_FUSED_CASE(4, 24)
-            default:
-                fused_body<28, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem);
-                break;
-        }
+    const int kind = fc.kind[c] % 7;
+#define ADH_FUSED_CASE(KIND, FM)                                                                                       \
+    if constexpr (FM >= FM_MIN && FM <= FM_MAX) {                                                                      \
+        if (kind == KIND) {                                                                                            \
+            fused_body<FM, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
+            return;                                                                                                    \
+        }                                                                                                              \
     }
+    ADH_FUSED_CASE(0, 8)
+    ADH_FUSED_CASE(1, 12)
+    ADH_FUSED_CASE(2, 16)
+    ADH_FUSED_CASE(3, 20)
+    ADH_FUSED_CASE(4, 24)
+    ADH_FUSED_CASE(5, 28)
+    ADH_FUSED_CASE(6, 32)
 #undef ADH_FUSED_CASE
 }

@@ -570,13 +570,15 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
     HIP_TRY(hipEventRecord(t.e1, st));
     const unsigned per_block = ADH_WAVE / ADH_GS;
     if (n_fused > 0 && run_fast) {
-        // per observation count: the classes with FM <= 28 in one launch, FM = 32 (more LDS) in a second one
-        FusedClasses fcs[4] = {};  // [2 * (observations - 1) + (FM == 32)]
+        // per observation count: the shorter rows in one launch, the longest (more LDS; with one observation also
+        // more registers than three wavefronts per SIMD leave: adh_fused.hip) in a second one
+        FusedClasses fcs[4] = {};  // [2 * (observations - 1) + (long rows)]
         int64_t fblocks[4] = {0, 0, 0, 0};
         int64_t first = 0;
         for (int c = ADH_CLASS_FUSED0; c < ADH_CLASS_FAST2; ++c) {
             const int64_t nc = p.n_class[c];
-            const int which = 2 * ((c - ADH_CLASS_FUSED0) / 7) + ((c - ADH_CLASS_FUSED0) % 7 == 6 ? 1 : 0);
+            const int obs = (c - ADH_CLASS_FUSED0) / 7, fm = 8 + 4 * ((c - ADH_CLASS_FUSED0) % 7);
+            const int which = 2 * obs + (fm > (obs == 0 ? ADH_FUSED_FM3 : 28) ? 1 : 0);
             FusedClasses &fc = fcs[which];
             if (nc > 0) {
                 fc.first_block[fc.n] = (int32_t)fblocks[which];
@@ -589,16 +591,17 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
             }
             first += nc;
         }
-#define ADH_LAUNCH_FUSED(W, FM_MAX, NO)                                                                               \
+#define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                                                                       \
     if (fblocks[W] > 0) {                                                                                             \
-        hipLaunchKernelGGL((adh_fused_kernel<FM_MAX, NO>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, h->run, \
-                           h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase);  \
+        hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, \
+                           h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out,                \
+                           (int32_t)stop_phase);                                                                      \
         HIP_TRY(hipGetLastError());                                                                                   \
     }
-        ADH_LAUNCH_FUSED(0, 28, 1)
-        ADH_LAUNCH_FUSED(1, 32, 1)
-        ADH_LAUNCH_FUSED(2, 28, 2)
-        ADH_LAUNCH_FUSED(3, 32, 2)
+        ADH_LAUNCH_FUSED(0, 8, ADH_FUSED_FM3, 1)
+        ADH_LAUNCH_FUSED(1, ADH_FUSED_FM3 + 4, 32, 1)
+        ADH_LAUNCH_FUSED(2, 8, 28, 2)
+        ADH_LAUNCH_FUSED(3, 32, 32, 2)
 #undef ADH_LAUNCH_FUSED
     }
     if (stop_phase != 2 && !fused_only) {

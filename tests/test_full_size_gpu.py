@@ -92,7 +92,8 @@ def test_config1_full_size(ctx, headline):
 
 def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     """configs[3]: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 20 000 precursors x 3
-    candidates of 17-39 scans x 7-29 cycles; every 30th candidate against the oracle; permutation invariance."""
+    candidates of 17-39 scans x 7-29 cycles; every 30th candidate against the oracle; repeated runs identical;
+    permutation invariance."""
     case = syn.make_timstof_case(
         n_precursors=20_000, n_cycles=2000, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
         scan_max_index=918, n_tof=400_000, events_per_push=30.0, mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
@@ -117,6 +118,11 @@ def test_config3_full_size_ion_mobility(ctx, oracle_lib):
                                    with_stats=True)
     compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
     assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
+    got = {k: np.array(x, copy=True) for k, x in got.items()}
+    for _ in range(3):  # run-to-run identical (a register hazard in an unrolled MFMA chain once broke this for feature 29)
+        again = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
+        for k in got:
+            assert np.array_equal(again[k], got[k], equal_nan=True), k
     perm = np.random.default_rng(2).permutation(n)
     shuffled = ctx.score_host(pack_assembled(_rows(soa, perm)), cfgj, with_stats=True)
     for k in got:
