@@ -42,8 +42,9 @@ def main(path, passes, n_cand):
                 "profiled command made (one pass = all chunks of one adh_score_candidates call, or one resident step). "
                 "Read side = 2 x FETCH_SIZE: the counter tallies a request at 64 B, the request fills a 128-byte line - "
                 "calibrated on a coalesced stream and on scattered 4/8/16-byte loads, one line each "
-                "(profiles/r03_fetch_probe.txt).  WRITE_SIZE as reported; it includes the register spills of the "
-                "fused kernels (scratch memory), which are most of it.",
+                "(profiles/r03_fetch_probe.txt).  WRITE_SIZE as reported: the output rows (449 B per candidate) in "
+                "partial lines; no fused kernel spills registers any more (the launch that held the 28- and "
+                "32-cycle bodies to three wavefronts per SIMD wrote 2.5 GB of scratch per step).",
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
