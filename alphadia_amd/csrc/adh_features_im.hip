@@ -197,8 +197,10 @@ template <int K, int O, int S, int F, int I, int SF>
 struct DimsFix {
     static constexpr int Kc = K, Oc = O, Sc = S, Fc = F, Ic = I, SFc = SF;
     __host__ __device__ DimsFix(const Caps &) {}
-    __host__ __device__ static bool holds(const Caps &c) {
-        return c.k <= K && c.o <= O && c.s <= S && c.f <= F && c.i <= I && c.s * c.f <= SF;
+    __host__ __device__ static bool holds(const Caps &c) { return holds_axes(c) && c.s * c.f <= SF; }
+    // (without the plane size: for a launch whose candidates were admitted one by one, plan class ADH_CLASS_IM_SMALL)
+    __host__ __device__ static bool holds_axes(const Caps &c) {
+        return c.k <= K && c.o <= O && c.s <= S && c.f <= F && c.i <= I;
     }
 };
 template <class D>
@@ -272,13 +274,18 @@ using Layout = LayoutT<DimsDyn>;
 // (13 704 + 2 560 static bytes: ten blocks per CU, as the specified 38 x 29 tiles get with run-time capacities)
 using DimsCommon = DimsFix<12, 1, 40, 32, 3, 1152>;
 using LayoutCommon = LayoutT<DimsCommon>;
+// small tiles (plan class ADH_CLASS_IM_SMALL): 10 248 + 2 560 bytes, twelve blocks per CU
+using DimsSmall = DimsFix<ADH_IM_SMALL_K, 1, ADH_IM_SMALL_S, ADH_IM_SMALL_F, 3, ADH_IM_SMALL_SF>;
+using LayoutSmall = LayoutT<DimsSmall>;
 
 }  // namespace featim
 
 #define ADH_IM_STAGE 128          // cells staged per round of the tile passes (two per lane)
 #define ADH_IM_STATIC_LDS (ADH_IM_STAGE * 20)  // static LDS of adh_feature_im_kernel (chunk lists / Gram matrices: 2 176 B)
 size_t adh_feature_im_lds_bytes(const Caps &c) {
-    return featim::DimsCommon::holds(c) ? featim::LayoutCommon(c).bytes() : featim::Layout(c).bytes();
+    return featim::DimsSmall::holds(c)    ? featim::LayoutSmall(c).bytes()
+           : featim::DimsCommon::holds(c) ? featim::LayoutCommon(c).bytes()
+                                          : featim::Layout(c).bytes();
 }
 
 template <class LAY>

@@ -28,6 +28,13 @@
 //            fused kernel does not take (more than 12 fragments kept, library slices beyond 64)
 //  17 .. 23  register kernels for one observation (FM = 8 ... 32) behind the gather kernel, likewise
 //  24        the generic LDS kernel behind the gather kernel
+// ion-mobility plans use classes 0 (one observation), 1 (two), ADH_CLASS_IM_SMALL (one observation, a tile
+// within the limits below: a feature-kernel instantiation with 12.8 KB of LDS instead of 16.3) and the generic one
+#define ADH_CLASS_IM_SMALL 2
+#define ADH_IM_SMALL_K 12
+#define ADH_IM_SMALL_S 32
+#define ADH_IM_SMALL_F 24
+#define ADH_IM_SMALL_SF 640
 #define ADH_CLASS_FUSED0 0
 #define ADH_CLASS_FUSED2 7
 #define ADH_CLASS_FAST2 14
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
     uint32_t bin = 0;
     uint64_t nbytes = 0;
     int32_t mx_k = 0, mx_o = 0, mx_f = 0, mx_s = 0, mx_p = 0, mx_l = 0;
+    bool small_tile = false;
     if (!(r.flags & ADH_FLAG_SKIP)) {
         int err = 0;
         const int64_t z = p.zeroth;
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
             bin = (uint32_t)((r.frame_start - z32) / p.L);
             nbytes = adh_im_scratch_bytes(r.k_cap, r.n_obs, S, F, p.I, r.n_ms1);
             if (live) mx_k = (int32_t)r.k_cap, mx_o = r.n_obs, mx_f = F, mx_s = S, mx_p = r.n_ms1, mx_l = (int32_t)nl;
+            small_tile = r.k_cap <= ADH_IM_SMALL_K && S <= ADH_IM_SMALL_S && F <= ADH_IM_SMALL_F && S * F <= ADH_IM_SMALL_SF;
         }
     }
     plan::raise_max(&meta->all_k, mx_k);
@@ -294,9 +303,11 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
     plan::raise_max(&meta->all_op, mx_p);
     plan::raise_max(&meta->all_n_lib, mx_l);
     if (!live) return;
-    // feature launches by observation count (class 0: one, class 1: two, generic: more): the LDS of
-    // the ion-mobility feature kernel scales with it, and most precursors sit in one isolation window
-    const int cls = (r.flags & ADH_FLAG_SKIP) ? ADH_CLASS_GENERIC : (r.n_obs <= 1 ? 0 : (r.n_obs == 2 ? 1 : ADH_CLASS_GENERIC));
+    // feature launches by observation count (class 0: one, class 1: two, generic: more) and, with one observation,
+    // by tile size (class ADH_CLASS_IM_SMALL): the LDS of the ion-mobility feature kernel scales with both, its
+    // resident blocks with the LDS and its time with the resident blocks; most precursors sit in one isolation window
+    const int cls = (r.flags & ADH_FLAG_SKIP) ? ADH_CLASS_GENERIC
+                    : (r.n_obs <= 1 ? (small_tile ? ADH_CLASS_IM_SMALL : 0) : (r.n_obs == 2 ? 1 : ADH_CLASS_GENERIC));
     const uint32_t key = (uint32_t)cls * (uint32_t)p.n_cyc_bins + min(bin, (uint32_t)p.n_cyc_bins - 1u);
     recs[j] = r;
     keys[j] = key;

@@ -502,11 +502,21 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
             const int64_t cnt = p.n_class[c];
             if (cnt > 0) {
                 Caps cc = p.caps_all;
-                if (c == 0) cc.o = 1;
+                if (c == 0 || c == ADH_CLASS_IM_SMALL) cc.o = 1;
                 if (c == 1) cc.o = std::min(cc.o, 2);
+                if (c == ADH_CLASS_IM_SMALL) {  // (what the plan admitted to the class: adh_plan_rec_im_kernel)
+                    cc.k = std::min(cc.k, ADH_IM_SMALL_K);
+                    cc.s = std::min(cc.s, ADH_IM_SMALL_S);
+                    cc.f = std::min(cc.f, ADH_IM_SMALL_F);
+                }
                 // (capacities fixed at compile time for the common shape: adh_features_im.hip, DimsFix)
-                const bool common = featim::DimsCommon::holds(cc) && !getenv("ADH_DEBUG_IM_DYNAMIC_LAYOUT");
-                if (common)
+                const bool fixed_ok = !getenv("ADH_DEBUG_IM_DYNAMIC_LAYOUT");
+                const bool common = featim::DimsCommon::holds(cc) && fixed_ok;
+                if (c == ADH_CLASS_IM_SMALL && featim::DimsSmall::holds_axes(cc) && fixed_ok)
+                    hipLaunchKernelGGL(adh_feature_im_kernel<featim::LayoutSmall>, dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                       *cfg, d_scratch, *out, cc);
+                else if (common)
                     hipLaunchKernelGGL(adh_feature_im_kernel<featim::LayoutCommon>, dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc);

@@ -416,17 +416,29 @@ def main():
         t0 = time.perf_counter()
         oracle.score(case.dia, cols, pk1, cfgj, n_threads=1, reuse=oracle.score.last_buffers)
         rate_1 = probe1 / (time.perf_counter() - t0)
-        sample = int(min(n_local, max(2000, rate * args.cpu_seconds)))
-        sub = slice_soa(soa, 0, sample)
-        pk = pack_assembled(sub)
-        oracle.score(case.dia, cols, pk, cfgj, n_threads=cores)  # touches the output pages
-        reps, dt = 0, 0.0
-        while dt < min(args.cpu_seconds, 10.0) or reps == 0:  # repeat the sample for a stable rate
-            t0 = time.perf_counter()
-            exp = oracle.score(case.dia, cols, pk, cfgj, n_threads=cores, reuse=oracle.score.last_buffers)
-            dt += time.perf_counter() - t0
-            reps += 1
-        dt /= reps
+        # sustained rate per thread count: the probes above are bursts of a fraction of a second, which a CFS quota
+        # lets run ahead of the sustained rate; the record is the rate over seconds, at the quota's thread count and
+        # at the fastest probed one, and `value` is the better of the two
+        sustained = {}
+        best_s = None
+        counts = sorted({cores} | ({max(1, int(quota))} if quota else set()))
+        budget = min(args.cpu_seconds, 10.0) * 2.0 / len(counts)
+        for th in counts:
+            sample_t = int(min(n_local, max(2000, tried.get(th, rate) * budget * 0.6)))
+            sub_t = slice_soa(soa, 0, sample_t)
+            pk_t = pack_assembled(sub_t)
+            oracle.score(case.dia, cols, pk_t, cfgj, n_threads=th)  # touches the output pages
+            reps_t, dt_t = 0, 0.0
+            while dt_t < budget or reps_t == 0:  # repeat the sample for a stable rate
+                t0 = time.perf_counter()
+                exp_t = oracle.score(case.dia, cols, pk_t, cfgj, n_threads=th, reuse=oracle.score.last_buffers)
+                dt_t += time.perf_counter() - t0
+                reps_t += 1
+            sustained[th] = sample_t * reps_t / dt_t
+            log(f"[bench] cpu oracle {th:4d} threads sustained: {sustained[th]:,.0f} candidates/s ({reps_t} x {dt_t / reps_t:.2f} s)")
+            if best_s is None or sustained[th] > sustained[best_s[0]]:
+                best_s = (th, sample_t, sub_t, reps_t, dt_t / reps_t, {k: np.array(v, copy=True) for k, v in exp_t.items() if k in ("valid", "features")})
+        cores, sample, sub, reps, dt, exp = best_s
         cpu_prec = len(np.unique(sub["precursor_idx"]))
         same_valid = bool(np.array_equal(exp["valid"].astype(bool), valid[:sample]))
         max_rel = None
@@ -446,11 +458,12 @@ def main():
             "kind": "port",
             "region": "host candidate SoA -> host OutputPsmDF SoA (the region `value` is timed on)",
             "sample": f"first {sample} candidates ({cpu_prec} precursors) of the same batch, "
-                      f"{reps} x {dt:.2f}s, {cores} OpenMP threads (fastest of the thread counts tried; the host "
+                      f"{reps} x {dt:.2f}s, {cores} OpenMP threads (the faster of the sustained runs; the host "
                       f"shows {ncpu} hardware threads, the container's CFS quota is "
                       f"{'unlimited' if not quota else f'{quota:g} cores'})",
             "precursors_per_s_1_thread": rate_1 * cpu_prec / sample,
-            "candidates_per_s_by_threads": {str(k): v for k, v in tried.items()},
+            "sustained_candidates_per_s_by_threads": {str(k): v for k, v in sustained.items()},
+            "burst_candidates_per_s_by_threads": {str(k): v for k, v in tried.items()},
             "valid_identical_to_gpu": same_valid,
             "max_rel_feature_diff_vs_gpu": max_rel,
         }

@@ -90,6 +90,24 @@ def test_config1_full_size(ctx, headline):
         assert np.array_equal(shuffled[k], got[k][:n1][perm], equal_nan=True), k
 
 
+def test_config2_score_group_shards_reassemble(ctx, headline):
+    """The 3 000 000-row table cut into score-group shards as `bench.py --gpus N` cuts it (N = 3: uneven), every
+    shard scored on its own - its own chunk cuts of the host -> host pipeline, its own plan - gives the rows of
+    the one-GPU table bit for bit: sharding and chunking at a size where both are in play."""
+    from alphadia_amd.distributed import shard_bounds, slice_soa
+
+    case, cfg, soa, got = headline
+    n, world, pos = len(soa["precursor_idx"]), 3, 0
+    for rank in range(world):
+        a, b = shard_bounds(soa["score_group_idx"], rank, world)
+        assert a == pos and b > a
+        pos = b
+        part = ctx.score_host(pack_assembled(slice_soa(soa, a, b)), cfg.to_jitclass(), with_stats=True)
+        for k in got:
+            assert np.array_equal(part[k], got[k][a:b], equal_nan=True), (rank, k)
+    assert pos == n
+
+
 def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     """configs[3]: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 20 000 precursors x 3
     candidates of 17-39 scans x 7-29 cycles; every 30th candidate against the oracle; repeated runs identical;
