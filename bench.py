@@ -318,7 +318,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "adh_fused_kernel<FM_MAX, observations> (gather + features in one kernel; every candidate of this "
+            "kernel": "adh_fused_kernel<FM_MIN, FM_MAX, observations> (gather + features in one kernel; every candidate of this "
                       "workload takes it) + the two-kernel fallback classes: the hot path, summed over the chunks of one step",
             "kernel_ms": kernel_ms,
             "gather_kernel_ms": gather_ms,
