@@ -114,14 +114,19 @@ struct DevTims {
     int32_t cycle_len, scan_max, zeroth;
     // Search indices built when the run is staged (adh_index_im.hip); NULL when they do not fit.
     //   mz_lut[b]  = first TOF bin with mz >= lut_min + b / lut_inv_step        (lut_n + 1 entries)
-    //   cyc_idx[tof * cyc_cols + cb] = first event of the bin with push >= the first push of cycle
-    //   cb << cyc_shift (cyc_cols = blocks + 1; the last column is the end of the bin's cycles)
+    //   cyc_idx[cb * n_tof + tof] = first event of the bin with push >= the first push of cycle
+    //   cb << cyc_shift, counted from the bin's first event (cyc_cols = blocks + 1; the last column is the end of
+    //   the bin's cycles).  Column-major since round 3: the TOF bins of an m/z window are neighbours and the
+    //   lanes that look them up take ONE 128-byte line per column, where the row-major table cost a line per bin
+    //   (the ion-mobility gather is bound by the lines it makes HBM fill: 35 GB per 600 000 candidates at
+    //   4.8 TB/s, for 8 GB of events, index words and rows it needs)
     // They replace the two ~19-step searches over mz and the two ~10-step searches over a bin's pushes,
     // i.e. most of the dependent-load chain of a candidate, by one load each.
     const uint32_t *mz_lut;
     const uint32_t *cyc_idx;
     double lut_min, lut_inv_step;
     int32_t lut_n, cyc_shift, cyc_cols, n_cycles;
+    __device__ __forceinline__ uint32_t cyc_word(int tof, int col) const { return cyc_idx[(size_t)col * (size_t)n_tof + (size_t)tof]; }
 };
 
 // candidate record of the ion-mobility plan (processing order)

@@ -439,10 +439,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             const double measured = run.mz[tof];
             int64_t lo, b;
             if (per_cycle) {  // the staged (bin, cycle) index holds both ends
-                const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
                 const int64_t first = run.tof_indptr[tof];  // (the columns count from the bin's first event)
-                lo = first + (int64_t)row[c0 + f];
-                b = first + (int64_t)row[min(c0 + f + 1, run.cyc_cols - 1)];
+                lo = first + (int64_t)run.cyc_word(tof, c0 + f);
+                b = first + (int64_t)run.cyc_word(tof, min(c0 + f + 1, run.cyc_cols - 1));
             } else {
                 b = run.tof_indptr[tof + 1];
                 lo = run.tof_indptr[tof];

@@ -55,15 +55,14 @@ __device__ __forceinline__ void event_range(const DevTims &run, int tof, int c0,
     int64_t hi_lo, hi_hi;
     if (run.cyc_idx) {
         // (the columns count from the bin's first event: 32 bits per column whatever the size of the run)
-        const uint32_t *row = run.cyc_idx + (size_t)tof * (size_t)run.cyc_cols;
         const int64_t first = run.tof_indptr[tof];
         const int sh = run.cyc_shift, nb = run.cyc_cols - 1;
         const int ba = min(c0 >> sh, nb), bb = min((c0 + F) >> sh, nb);
-        lo = first + (int64_t)row[ba];
-        lo2 = first + (int64_t)row[bb];
+        lo = first + (int64_t)run.cyc_word(tof, ba);
+        lo2 = first + (int64_t)run.cyc_word(tof, bb);
         if (sh == 0) return;
-        hi_lo = ba < nb ? first + (int64_t)row[ba + 1] : run.tof_indptr[tof + 1];
-        hi_hi = bb < nb ? first + (int64_t)row[bb + 1] : run.tof_indptr[tof + 1];
+        hi_lo = ba < nb ? first + (int64_t)run.cyc_word(tof, ba + 1) : run.tof_indptr[tof + 1];
+        hi_hi = bb < nb ? first + (int64_t)run.cyc_word(tof, bb + 1) : run.tof_indptr[tof + 1];
     } else {
         lo = run.tof_indptr[tof];
         hi_lo = hi_hi = run.tof_indptr[tof + 1];
@@ -198,7 +197,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_index_im_kernel(const int64_t *_
     const uint32_t cols = n_blocks + 1u;
     for (int64_t tof = blockIdx.x; tof < n_tof; tof += gridDim.x) {
         const int64_t a = tof_indptr[tof], b = tof_indptr[tof + 1];
-        uint32_t *row = idx + (size_t)tof * cols;
+        // (column-major: word (cb, tof) at cb * n_tof + tof.  Neighbouring bins are written by neighbouring
+        // blocks at about the same time, so the stores of a column meet in the L2 line they share.)
+        uint32_t *row = idx + (size_t)tof;
+        const size_t cs = (size_t)n_tof;  // stride of a column
         uint32_t done = 0u;  // columns written so far (wave-uniform)
         for (int64_t base = a; base < b; base += ADH_WAVE) {
             const int64_t e = base + lane;
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_index_im_kernel(const int64_t *_
             uint32_t g_prev = __shfl_up(g, 1);
             if (lane == 0) g_prev = done;
             if (in)
-                for (uint32_t cb = g_prev; cb < g; ++cb) row[cb] = (uint32_t)(e - a);  // (counted from the bin's first event)
+                for (uint32_t cb = g_prev; cb < g; ++cb) row[cb * cs] = (uint32_t)(e - a);  // (counted from the bin's first event)
             const int last = (int)min((int64_t)ADH_WAVE, b - base) - 1;
             done = __shfl(g, last);
         }
-        for (uint32_t cb = done + lane; cb < cols; cb += ADH_WAVE) row[cb] = (uint32_t)(b - a);
+        for (uint32_t cb = done + lane; cb < cols; cb += ADH_WAVE) row[cb * cs] = (uint32_t)(b - a);
     }
 }

@@ -664,9 +664,10 @@ int check_score_args(adh_handle *h, const adh_scoring_config_t *cfg, const adh_o
 int64_t pick_chunk(int64_t n) {
     // rows per pipeline chunk: large enough to fill the GPU and amortise its launches (every launch drains the GPU
     // at its end: ~50 us per kernel), small enough that the first H2D / last D2H (not overlapped) stay short.
-    // 3 M candidates, host -> host / kernels: 262144 rows 36.3 / 16.6 ms, 393216 36.0 / 15.8, 524288 36.8 / 15.3,
-    // 1048576 38.8 / 14.7
-    int64_t target = 393216;
+    // 3 M candidates, host -> host / kernels (final kernels of round 3, two sweeps on one box): 196608 rows
+    // 37.9, 36.6 / 16.9 ms, 262144 35.0, 36.0 / 16.1, 393216 36.7, 35.9 / 15.2, 524288 35.5, 36.0 / 14.7; 1048576 cost
+    // 2 ms of host -> host time earlier in the round (the un-overlapped first and last copies)
+    int64_t target = 524288;
     if (const char *env = getenv("ADH_CHUNK")) target = std::max<int64_t>(atoll(env), 1024);
     if (n <= target + target / 2) return std::max<int64_t>(n, 1);
     const int64_t parts = (n + target - 1) / target;
