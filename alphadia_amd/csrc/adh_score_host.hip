@@ -669,8 +669,13 @@ int64_t pick_chunk(int64_t n) {
     // 2 ms of host -> host time earlier in the round (the un-overlapped first and last copies)
     int64_t target = 524288;
     if (const char *env = getenv("ADH_CHUNK")) target = std::max<int64_t>(atoll(env), 1024);
-    if (n <= target + target / 2) return std::max<int64_t>(n, 1);
-    const int64_t parts = (n + target - 1) / target;
+    // A table of at least ADH_SPLIT_ROWS rows is cut in two at least, however large the target: with one chunk
+    // the copy-out (4-5 ms per 375 000 rows) starts only when the last kernel has ended - the shards of a
+    // multi-GPU run (375 000 rows per GPU at N = 8) are in this range
+    const int64_t split_rows = 196608;
+    int64_t parts = (n + target - 1) / target;
+    if (parts < 2 && n >= split_rows && !getenv("ADH_CHUNK")) parts = 2;
+    if (parts <= 1) return std::max<int64_t>(n, 1);
     return (n + parts - 1) / parts;
 }
 

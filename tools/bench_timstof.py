@@ -136,12 +136,13 @@ def touched_bytes(sample_rows):
 
 rows = np.linspace(0, n - 1, int(os.environ.get("TOUCHED_SAMPLE", 400))).astype(np.int64)
 touched = float(touched_bytes(rows).mean()) * n
-traffic = None
+traffic = gather_traffic = None
 tfile = os.environ.get("ADH_IM_TRAFFIC_JSON")  # {"fetch_bytes_per_pass": ..., "write_bytes_per_pass": ...} from tools/profile_r3_im.sh
 if tfile and os.path.exists(tfile):
     tj = json.load(open(tfile))
     if tj.get("candidates") == n:
         traffic = tj.get("hbm_bytes_per_pass")
+        gather_traffic = tj.get("gather_kernel_hbm_bytes_per_pass")
 
 result = {
     "workload": f"BASELINE configs[3]: timsTOF-style synthetic run, {dia.push_indices.size/1e6:.0f}M events, {S_max} scans, "
@@ -157,6 +158,9 @@ result = {
         "frac": touched / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
         "kernel": "adh_gather_im_kernel + adh_feature_im_kernel", "kernel_ms": kernel_ms,
         "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
+        # the gather kernel against the lines it makes HBM fill (PMC traffic of that kernel / its duration)
+        "gather_kernel_traffic": gather_traffic,
+        "gather_kernel_line_fill_rate_GBps": (gather_traffic / (g_ms * 1e-3) / 1e9) if gather_traffic else None,
         "yardstick": "bytes the candidates' (window, TOF bin, frame range) ranges hold: events x 6 B + index words + "
                      "library slice + plan record + 646 B output row (exact on a strided sample of candidates)",
         "touched_bytes_per_candidate": touched / n,

@@ -19,14 +19,20 @@ for d in f w; do python $REPO/tools/rocpd_summary.py /tmp/im_$d/p_results.db | g
 python - <<PY
 import json
 passes = 4 + 3 + 3 + 1
-f = w = 0.0
+f = w = gf = gw = 0.0
 for line in open("$OUT/r03_timstof_pmc.csv"):
     parts = line.rstrip("\n").rsplit(",", 4)
     if len(parts) == 5 and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
         v = float(parts[4]) * 1024.0 / passes
-        if parts[1] == "FETCH_SIZE": f += 2.0 * v   # requests are tallied at 64 B, the lines they fill are 128 B (tools/probes/fetch_probe.hip)
-        else: w += v
-json.dump({"candidates": 600000, "passes": passes, "fetch_bytes_per_pass": f, "write_bytes_per_pass": w, "hbm_bytes_per_pass": f + w},
+        gather = parts[0].startswith("adh_gather_im")
+        if parts[1] == "FETCH_SIZE":
+            f += 2.0 * v   # requests are tallied at 64 B, the lines they fill are 128 B (tools/probes/fetch_probe.hip)
+            gf += 2.0 * v if gather else 0.0
+        else:
+            w += v
+            gw += v if gather else 0.0
+json.dump({"candidates": 600000, "passes": passes, "fetch_bytes_per_pass": f, "write_bytes_per_pass": w, "hbm_bytes_per_pass": f + w,
+           "gather_kernel_hbm_bytes_per_pass": gf + gw},
           open("$OUT/r03_timstof_traffic.json", "w"), indent=1)
 print(open("$OUT/r03_timstof_traffic.json").read())
 PY
