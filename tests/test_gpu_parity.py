@@ -516,9 +516,10 @@ def test_timstof_larger_case_all_configs(ctx, oracle_lib):
 
 def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     """The staged search indices (m/z lookup table, (TOF bin, cycle) table - one column per cycle or per
-    block of cycles), the two forms of the tiles (sparse entry lists, dense tiles) and the two forms of the
-    feature assembly (lane-parallel sums, one-lane loops) are different ways to the same numbers: every output
-    table must come out bit for bit the same."""
+    block of cycles), the two forms of the tiles (sparse entry lists, dense tiles), the two forms of the
+    feature assembly (lane-parallel sums, one-lane loops) and the feature kernel's instantiations (capacities
+    fixed at compile time, capacities of the launch) are different ways to the same numbers: every output table
+    must come out bit for bit the same."""
     from alphadia_amd.scoring import assemble_candidates
 
     case = syn.make_timstof_case(n_precursors=300, n_cycles=70, config_id=45, per_precursor=2, n_ms2_frames=5,
@@ -530,7 +531,7 @@ def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     base = {k: np.array(v, copy=True) for k, v in base.items()}
     assert base["valid"].sum() > 100
     for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8"),
-                dict(ADH_DEBUG_IM="21")):
+                dict(ADH_DEBUG_IM="21"), dict(ADH_DEBUG_IM_DYNAMIC_LAYOUT="1")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
