@@ -104,6 +104,8 @@ class ScoringConfig(C.Structure):
         ("precursor_mz_tolerance", C.c_float),
         ("fragment_mz_tolerance", C.c_float),
         ("experimental_xic", C.c_int32),
+        ("quadrupole_sigma", C.c_double * 2),
+        ("quadrupole_delta_mu", C.c_double * 2),
     ]
 
 
@@ -396,7 +398,16 @@ def pack_config(cfg) -> ScoringConfig:
         float(cfg.precursor_mz_tolerance),
         float(cfg.fragment_mz_tolerance),
         int(bool(cfg.experimental_xic)),
+        _pair(getattr(cfg, "quadrupole_sigma", None), 0.0),  # (0: the class defaults, sigma 0.2 / delta_mu 0)
+        _pair(getattr(cfg, "quadrupole_delta_mu", None), 0.0),
     )
+
+
+def _pair(values, default: float):
+    out = (C.c_double * 2)(default, default)
+    if values is not None:
+        out[0], out[1] = float(values[0]), float(values[1])
+    return out
 
 
 # ---------------------------------------------------------------------------

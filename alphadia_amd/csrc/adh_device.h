@@ -196,6 +196,20 @@ __device__ __forceinline__ const uint32_t *adh_tab_row(const DevRun &run, int ro
 
 typedef adh_output_t DevOut;
 
+// parameters of the quadrupole transfer function (SimpleQuadrupoleJit.predict, quadrupole.py:94-113)
+struct QuadParams {
+    double sigma_lo, sigma_hi, delta_lo, delta_hi;
+};
+__host__ __device__ inline QuadParams adh_quad_params(const adh_scoring_config_t &c) {
+    QuadParams q;
+    const bool set = c.quadrupole_sigma[0] > 0.0 && c.quadrupole_sigma[1] > 0.0;
+    q.sigma_lo = set ? c.quadrupole_sigma[0] : 0.2;
+    q.sigma_hi = set ? c.quadrupole_sigma[1] : 0.2;
+    q.delta_lo = set ? c.quadrupole_delta_mu[0] : 0.0;
+    q.delta_hi = set ? c.quadrupole_delta_mu[1] : 0.0;
+    return q;
+}
+
 // LDS capacities of one launch (maxima over the launch's candidates)
 struct Caps {
     int32_t k;       // fragments kept (<= top_k)

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_kernel(
         int i = c / O, o = c - i * O;
         const double *cy = run.cycle + 2 * ((int64_t)obs[o] * run.cycle_scans + r.scan_start);
         double x = (double)iso_mz[i];
-        qtf[c] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+        const QuadParams qp = adh_quad_params(cfg);
+        qtf[c] = logistic(x, cy[0] + qp.delta_lo, qp.sigma_lo) - logistic(x, cy[1] + qp.delta_hi, qp.sigma_hi);
     }
     __syncthreads();
     if (lane < O) {

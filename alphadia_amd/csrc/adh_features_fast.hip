@@ -291,7 +291,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
                 const double *cy = run.cycle + 2 * ((int64_t)rec.obs[o] * run.cycle_scans + rec.scan_start);
-                q[o] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+                const QuadParams qp = adh_quad_params(cfg);
+                q[o] = logistic(x, cy[0] + qp.delta_lo, qp.sigma_lo) - logistic(x, cy[1] + qp.delta_hi, qp.sigma_hi);
                 L.qtf[sub][o] = q[o];
             }
             L.iso_mz[sub] = iso_mz_l;

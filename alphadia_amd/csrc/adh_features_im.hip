@@ -410,7 +410,8 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
         int o = rem / S, sc = rem - o * S;
         const double *cy = run.cycle + 2 * ((int64_t)obs[o] * run.scan_max + (r.scan_start + sc));
         double x = (double)iso_mz[i];
-        qtf[c] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+        const QuadParams qp = adh_quad_params(cfg);
+        qtf[c] = logistic(x, cy[0] + qp.delta_lo, qp.sigma_lo) - logistic(x, cy[1] + qp.delta_hi, qp.sigma_hi);
     }
     adh_wave_sync();
     for (int c = lane; c < O * S; c += ADH_WAVE) {

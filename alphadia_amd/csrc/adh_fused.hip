@@ -797,7 +797,9 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         // isotope m/z of this lane's term (candidate.py:151-163), as the isotope lane computes it
         const double off = (double)q_i * 1.0033548350700006 / (double)rec.charge;
         const float mzq = (float)off + rec.precursor_mz;
-        if (q_lane) q_term = logistic((double)mzq, q_mu, 0.2);
+        // (a fitted calibration shifts the edges and has its own widths: SimpleQuadrupoleJit.predict, quadrupole.py:94-113)
+        const QuadParams qp = adh_quad_params(cfg);
+        if (q_lane) q_term = logistic((double)mzq, q_mu + (q_edge ? qp.delta_hi : qp.delta_lo), q_edge ? qp.sigma_hi : qp.sigma_lo);
     }
     double q_io;  // lanes i + 4 o: the transfer function of (isotope i, observation o)
     {

@@ -151,6 +151,11 @@ class CandidateScoringConfig:
         self.precursor_mz_tolerance = 15
         self.fragment_mz_tolerance = 15
         self.experimental_xic = False
+        # not fields of the reference's config: the parameters of a FITTED quadrupole calibration
+        # (SimpleQuadrupoleJit.sigma / .delta_mu, quadrupole.py:72-76); None = the class defaults (0.2, 0.0).
+        # HipCandidateScoring sets them from its ``quadrupole_calibration`` argument.
+        self.quadrupole_sigma = None
+        self.quadrupole_delta_mu = None
 
     def update(self, input_dict: dict) -> None:
         """Type-checked update (jit_config.py:69-138)."""
@@ -199,6 +204,9 @@ class CandidateScoringConfig:
             precursor_mz_tolerance=np.float32(self.precursor_mz_tolerance),
             fragment_mz_tolerance=np.float32(self.fragment_mz_tolerance),
             experimental_xic=bool(self.experimental_xic),
+            quadrupole_sigma=None if self.quadrupole_sigma is None else tuple(float(x) for x in self.quadrupole_sigma),
+            quadrupole_delta_mu=None if self.quadrupole_delta_mu is None
+            else tuple(float(x) for x in self.quadrupole_delta_mu),
         )
 
     def __repr__(self) -> str:
@@ -587,21 +595,27 @@ class HipCandidateScoring:
         self._dia_data = dia_data
         self.precursors_flat_df = precursors_flat.sort_values(by="precursor_idx")
         self.fragments_flat = fragments_flat
+        self.config = config if config is not None else CandidateScoringConfig()
+        self.config.validate()
         if quadrupole_calibration is not None:
+            # SimpleQuadrupole (quadrupole.py:116-259): the transfer function of candidate scoring is
+            # jit.predict = logistic_rectangle(cycle + delta_mu, sigma) (quadrupole.py:94-113); a fitted
+            # calibration differs from the default one in sigma and delta_mu only (its calibrated cycle is
+            # used for plots, candidate.py:207-214)
             jit = getattr(quadrupole_calibration, "jit", None)
             if jit is None:
                 raise AttributeError("quadrupole_calibration must have a jit method")
-            if not (
-                np.allclose(jit.sigma, 0.2)
-                and np.allclose(jit.delta_mu, 0.0)
-                and np.array_equal(jit.cycle, _jit_view(dia_data).cycle)
-            ):
+            if not np.array_equal(jit.cycle, _jit_view(dia_data).cycle):
                 raise NotImplementedError(
-                    "fitted quadrupole calibrations are not supported by the HIP backend "
-                    "(the reference workflow never fits one: scoring.py:209-212)"
+                    "the quadrupole calibration was built for another cycle than the run's "
+                    "(SimpleQuadrupole(dia_data.cycle), scoring.py:209-212)"
                 )
-        self.config = config if config is not None else CandidateScoringConfig()
-        self.config.validate()
+            sigma, delta_mu = np.asarray(jit.sigma, dtype=np.float64), np.asarray(jit.delta_mu, dtype=np.float64)
+            if sigma.shape != (2,) or delta_mu.shape != (2,) or not (sigma > 0).all():
+                raise ValueError("quadrupole calibration: sigma and delta_mu must hold two values, sigma > 0")
+            if not (np.array_equal(sigma, [0.2, 0.2]) and np.array_equal(delta_mu, [0.0, 0.0])):
+                self.config.quadrupole_sigma = (float(sigma[0]), float(sigma[1]))
+                self.config.quadrupole_delta_mu = (float(delta_mu[0]), float(delta_mu[1]))
         self.rt_column = rt_column
         self.mobility_column = mobility_column
         self.precursor_mz_column = precursor_mz_column

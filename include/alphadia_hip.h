@@ -135,6 +135,12 @@ typedef struct adh_scoring_config {
     float precursor_mz_tolerance;
     float fragment_mz_tolerance;
     int32_t experimental_xic;
+    /* SimpleQuadrupoleJit.sigma / .delta_mu (search/scoring/quadrupole.py:72-76,110-113): the quadrupole
+     * transfer function of a fitted calibration, logistic(x, lower + delta_mu[0], sigma[0]) -
+     * logistic(x, upper + delta_mu[1], sigma[1]).  sigma[0] <= 0 (a zeroed struct) stands for the class
+     * defaults the reference workflow runs with: sigma 0.2, delta_mu 0. */
+    double quadrupole_sigma[2];
+    double quadrupole_delta_mu[2];
 } adh_scoring_config_t;
 
 /*

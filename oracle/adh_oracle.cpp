@@ -649,7 +649,11 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
                 int64_t scan = c.scan_start + s;
                 const double *cy = rv.cycle() + 2 * (obs * rv.cycle_scans() + scan);
                 double x = (double)iso_mz[i];
-                qtf[((size_t)i * O + o) * n_scans + s] = logistic(x, cy[0], 0.2) - logistic(x, cy[1], 0.2);
+                /* SimpleQuadrupoleJit.predict (quadrupole.py:94-113): sigma / delta_mu of a fitted calibration */
+                const bool qset = cfg.quadrupole_sigma[0] > 0.0 && cfg.quadrupole_sigma[1] > 0.0;
+                const double s_lo = qset ? cfg.quadrupole_sigma[0] : 0.2, s_hi = qset ? cfg.quadrupole_sigma[1] : 0.2;
+                const double d_lo = qset ? cfg.quadrupole_delta_mu[0] : 0.0, d_hi = qset ? cfg.quadrupole_delta_mu[1] : 0.0;
+                qtf[((size_t)i * O + o) * n_scans + s] = logistic(x, cy[0] + d_lo, s_lo) - logistic(x, cy[1] + d_hi, s_hi);
             }
     /* broadcasting of a size-1 scan axis against S (non-IM data: n_scans = 1, S = 2) */
     auto qs = [&](int s) { return n_scans == 1 ? 0 : s; };

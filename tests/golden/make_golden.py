@@ -133,7 +133,12 @@ CAND_COLS = [
 ]
 
 
-def run_scoring(case: syn.SyntheticCase, cfg_updates: dict):
+# parameters of the fitted quadrupole calibration of the "fitted_quadrupole" golden (what SimpleQuadrupole.fit
+# leaves in jit.sigma / jit.delta_mu, quadrupole.py:195-204)
+FITTED_QUADRUPOLE = dict(sigma=(0.35, 0.12), delta_mu=(0.4, -0.25))
+
+
+def run_scoring(case: syn.SyntheticCase, cfg_updates: dict, quadrupole: dict | None = None):
     cfg = CandidateScoringConfig()
     cfg.update(cfg_updates)
     dia = DuckDia(case.dia)
@@ -148,6 +153,9 @@ def run_scoring(case: syn.SyntheticCase, cfg_updates: dict):
         config=cfg,
     )
     cands = case.candidates_df.copy()
+    if quadrupole is not None:  # a fitted calibration: sigma / delta_mu as SimpleQuadrupole.fit sets them
+        cs.quadrupole_calibration.jit.sigma = np.array(quadrupole["sigma"], dtype=np.float64)
+        cs.quadrupole_calibration.jit.delta_mu = np.array(quadrupole["delta_mu"], dtype=np.float64)
     fragment_container = cs.assemble_fragments()
     sgc = cs.assemble_score_group_container(cands)
     n = sgc.get_candidate_count()
@@ -248,6 +256,19 @@ SCORING_CONFIGS = {
         experimental_xic=True,
         top_k_fragments=12,
     ),
+    # the handler's settings with a FITTED quadrupole calibration (FITTED_QUADRUPOLE above)
+    "fitted_quadrupole": dict(
+        score_grouped=False,
+        top_k_isotopes=3,
+        reference_channel=-1,
+        precursor_mz_tolerance=10,
+        fragment_mz_tolerance=15,
+        exclude_shared_ions=True,
+        quant_window=3,
+        quant_all=True,
+        experimental_xic=True,
+        top_k_fragments=12,
+    ),
     # CandidateScoringConfig() defaults (config.py:73-85); used by multiplex requant
     "class_default": dict(),
     # top-k filtering active + narrow tolerances
@@ -288,9 +309,12 @@ def golden_scoring(which=None):
             card = case.library.fragment_df["cardinality"].values.copy()
             card[rng.random(card.size) < 0.15] = 2
             case.library.fragment_df["cardinality"] = card
-        out, fdf, frdf, opidx, orank, cfg = run_scoring(case, upd)
+        out, fdf, frdf, opidx, orank, cfg = run_scoring(case, upd, FITTED_QUADRUPOLE if name == "fitted_quadrupole" else None)
         d = case_to_dict(case)
         od = out_to_dict(out)
+        if name == "fitted_quadrupole":
+            d["cfg_quadrupole_sigma"] = np.asarray(FITTED_QUADRUPOLE["sigma"], dtype=np.float64)
+            d["cfg_quadrupole_delta_mu"] = np.asarray(FITTED_QUADRUPOLE["delta_mu"], dtype=np.float64)
         if name in MANYFRAG_CONFIGS:
             # the reference allocates top_k_fragments (9999) columns; keep those a library slice can fill
             lens = (case.library.precursor_df["flat_frag_stop_idx"].values.astype(np.int64)

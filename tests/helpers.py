@@ -72,6 +72,9 @@ def load_scoring_golden(name: str):
         v = z["cfg_" + k].item()
         upd[k] = v
     cfg.update(upd)
+    if "cfg_quadrupole_sigma" in z.files:  # a fitted quadrupole calibration (golden "fitted_quadrupole")
+        cfg.quadrupole_sigma = tuple(float(x) for x in z["cfg_quadrupole_sigma"])
+        cfg.quadrupole_delta_mu = tuple(float(x) for x in z["cfg_quadrupole_delta_mu"])
     expected = {n_: z["out_" + n_] for n_ in OUT_NAMES}
     return SimpleNamespace(
         dia=dia,

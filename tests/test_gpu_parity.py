@@ -91,7 +91,8 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     return worst
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class",
+                                  "fitted_quadrupole"])
 def test_hip_matches_oracle_on_golden_inputs(ctx, oracle_lib, name):
     g = H.load_scoring_golden(name)
     got, soa = hip_score(ctx, g, g.config)
@@ -116,7 +117,8 @@ def test_library_columns_rebuilt_from_slots(ctx, name):
         assert np.array_equal(back[k], got[k]), k
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class",
+                                  "fitted_quadrupole"])
 def test_hip_matches_reference_goldens(ctx, name):
     g = H.load_scoring_golden(name)
     got, _ = hip_score(ctx, g, g.config)
@@ -124,6 +126,64 @@ def test_hip_matches_reference_goldens(ctx, name):
     # moves the ppm errors by up to one float32 ulp of m/z (0.15 ppm; pinned exactly by
     # test_oracle_numpy_typing_pins_every_table) and cancellation-prone correlations by <= 1e-3 absolute
     compare(got, g.expected, PPM_ABS_TOL_GOLDEN, rel_tol=REL_TOL, corr_abs=1e-3)
+
+
+def test_fitted_quadrupole_on_every_kernel(ctx, oracle_lib, monkeypatch):
+    """A fitted quadrupole calibration (SimpleQuadrupoleJit.sigma / .delta_mu, quadrupole.py:72-113) reaches all
+    four places the transfer function is evaluated: the fused kernel, the two-kernel register path
+    (ADH_DEBUG_NO_FUSED), the generic kernel (class defaults) and the ion-mobility kernel - each against the
+    oracle, which the reference's own run with these parameters pins (golden "fitted_quadrupole"); and the
+    features must differ from those of the default calibration."""
+    from alphadia_amd.scoring import assemble_candidates
+
+    g = H.load_scoring_golden("fitted_quadrupole")
+    assert g.config.quadrupole_sigma == (0.35, 0.12)
+    got, soa = hip_score(ctx, g, g.config)
+    exp, _ = H.oracle_score(oracle_lib, g, g.config, soa=soa)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    plain = CandidateScoringConfig()
+    plain.update({k: getattr(g.config, k) for k in H.CFG_KEYS})
+    base, _ = hip_score(ctx, g, plain)
+    v = got["valid"].astype(bool) & base["valid"].astype(bool)
+    assert v.sum() > 100 and not np.array_equal(got["features"][v], base["features"][v])
+    with monkeypatch.context() as mp:
+        mp.setenv("ADH_DEBUG_NO_FUSED", "1")
+        two_kernel, _ = hip_score(ctx, g, g.config)
+    for k in got:
+        assert np.array_equal(two_kernel[k], got[k], equal_nan=True), k
+    generic = CandidateScoringConfig()  # class defaults: quant_all / experimental_xic off -> adh_feature_kernel
+    generic.quadrupole_sigma, generic.quadrupole_delta_mu = g.config.quadrupole_sigma, g.config.quadrupole_delta_mu
+    got_g, soa_g = hip_score(ctx, g, generic)
+    exp_g, _ = H.oracle_score(oracle_lib, g, generic, soa=soa_g)
+    compare(got_g, exp_g, PPM_ABS_TOL_ORACLE)
+    # the operator takes the calibration object the reference's operator takes (scoring.py:154,209-212)
+    from types import SimpleNamespace
+
+    from alphadia_amd.scoring import HipCandidateScoring
+
+    calibration = SimpleNamespace(jit=SimpleNamespace(sigma=np.array(g.config.quadrupole_sigma),
+                                                      delta_mu=np.array(g.config.quadrupole_delta_mu), cycle=g.dia.cycle))
+    scorer = HipCandidateScoring(
+        dia_data=g.dia, precursors_flat=g.library.precursor_df, fragments_flat=g.library.fragment_df,
+        quadrupole_calibration=calibration, rt_column="rt_library", mobility_column="mobility_library",
+        precursor_mz_column="mz_library", fragment_mz_column="mz_library", config=plain, device=0,
+    )
+    assert scorer.config.quadrupole_sigma == g.config.quadrupole_sigma
+    fdf, frdf = scorer(g.candidates_df, thread_count=4)
+    assert np.array_equal(fdf["precursor_idx"].values, g.z["features_df_precursor_idx"])
+    assert np.abs(frdf["mz_observed"].values - g.z["fragments_df_mz_observed"]).max() < 1e-4
+    # ion mobility
+    case = syn.make_timstof_case(n_precursors=300, n_cycles=60, config_id=46, per_precursor=2, n_ms2_frames=6,
+                                 windows_per_frame=3, scan_max_index=96)
+    soa_t = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(quant_all=True, experimental_xic=True, top_k_isotopes=3))
+    cfg.quadrupole_sigma, cfg.quadrupole_delta_mu = (0.5, 0.3), (-0.6, 0.8)
+    got_t = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa_t, cfg)
+    exp_t = oracle_lib.score_timstof(case.dia, fragment_columns(case.library.fragment_df, "mz_library"),
+                                     pack_assembled(soa_t), cfg.to_jitclass(), n_threads=8)
+    compare(got_t, exp_t, PPM_ABS_TOL_ORACLE)
+    assert got_t["valid"].sum() > 50
 
 
 def test_config1_full_size_parity(ctx, oracle_lib):

@@ -192,7 +192,7 @@ def test_abi_header_symbols_are_exported():
 def test_abi_struct_sizes():
     import ctypes as C
 
-    assert C.sizeof(_abi.ScoringConfig) == 44
+    assert C.sizeof(_abi.ScoringConfig) == 80  # 11 x 4 bytes, padding, sigma[2] + delta_mu[2] of the quadrupole (doubles)
     assert C.sizeof(_abi.Output) == 8 + 8 + 20 * 8  # n, top_k(+pad), 20 pointers
     assert C.sizeof(_abi.Candidates) == 8 + 14 * 8 + 8
     assert C.sizeof(_abi.AlphaRaw) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8

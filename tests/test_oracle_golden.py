@@ -41,7 +41,8 @@ def _compare(got, exp, ppm_tol, rel_tol, corr_abs):
     assert d.max() <= ppm_tol
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class",
+                                  "fitted_quadrupole"])
 def test_oracle_numba_typing_vs_reference_goldens(oracle_lib, name):
     """Production (Numba) typing vs goldens captured under NumPy typing: validity, every
     integer table and the row order are exact; float features within 1e-4 relative except the
@@ -54,7 +55,8 @@ def test_oracle_numba_typing_vs_reference_goldens(oracle_lib, name):
     _compare(got, g.expected, ppm_tol=0.15, rel_tol=1e-4, corr_abs=1e-3)
 
 
-@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class"])
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "topk6", "multiplex", "edges", "manyfrag", "manyfrag_class",
+                                  "fitted_quadrupole"])
 def test_oracle_numpy_typing_pins_every_table(oracle_lib, name):
     """The goldens were produced by the reference running under NumPy (the shim), whose typing
     differs from Numba's at four places: the float32 MS1 collapse, the float32 normalisation of
