@@ -762,7 +762,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
     cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
     (void)cap_tp;
     (void)cap_mp;
-    const size_t lds_smooth = adh_select_smooth_im_lds_bytes(cap_cells, cap_s, k0, k1);
+    const int tap_budget = adh_select_tap_budget(cap_cells, cap_s, k0, k1);
+    const size_t lds_smooth = adh_select_smooth_im_lds_bytes(cap_cells, cap_s, k0, k1, tap_budget);
     const size_t lds = std::max(lds_smooth, adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f));
     if (lds > 150 * 1024 || cap_f > selim::SCORE_THREADS) {
         char buf[200];
@@ -880,7 +881,8 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                 hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
                                    h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
                 hipLaunchKernelGGL(adh_select_smooth_im_kernel, dim3((unsigned)cnt), dim3(selim::SMOOTH_THREADS), lds_smooth,
-                                   h->stream, d_recs + b0, cnt, d_ku, d_kv, k0, k1, cap_cells, cap_s, d_scratch, debug_abl);
+                                   h->stream, d_recs + b0, cnt, d_ku, d_kv, k0, k1, cap_cells, cap_s, d_scratch, debug_abl,
+                                   (int32_t)tap_budget);
                 hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS),
                                    adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f), h->stream, T, d_recs + b0, cnt, b0, *cfg,
                                    cap_cells, cap_s, cap_f, d_scratch, dt);

@@ -320,11 +320,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
 }
 
 // LDS of the smoothing kernel for tiles of at most cap_cells = S * F cells and cap_s scans
-size_t adh_select_smooth_im_lds_bytes(int cap_cells, int cap_s, int k0, int k1) {
+size_t adh_select_smooth_im_lds_bytes(int cap_cells, int cap_s, int k0, int k1, int tap_budget) {
     size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile
     b += (size_t)(k0 + k1) * 8;                          // kernel factors
-    b += (size_t)cap_s * 3 * 2 * selim::SEL_BATCH + 16;  // row tables of a batch of windows
+    b += (size_t)cap_s * 4 * 2 * selim::SEL_BATCH + 16;  // row tables and tap counts of a batch of windows
+    b += (size_t)tap_budget * 2 + 8;                     // tap lists of pass 2 (uint16 entries)
     return (b + 15) / 16 * 16;
+}
+// Entries of the tap lists a launch can afford: the lists take LDS, and the kernel wants two blocks per CU
+// (80 KB each) more than it wants the lists; with one block per CU anyway they may fill what is left.
+// 0: no lists (kernels of more than 64 taps or tiles of more than 1023 scans do not fit the 16-bit entries).
+int adh_select_tap_budget(int cap_cells, int cap_s, int k0, int k1) {
+    if (k0 > 64 || cap_s > 1023) return 0;
+    const size_t base = adh_select_smooth_im_lds_bytes(cap_cells, cap_s, k0, k1, 0);
+    const size_t two_blocks = 80 * 1024, one_block = 150 * 1024;
+    const size_t room = base + 2048 <= two_blocks ? two_blocks - base : (base + 2048 <= one_block ? one_block - base : 0);
+    const size_t want = (size_t)selim::SEL_BATCH * cap_s * (size_t)std::min(cap_s, k0) * 2;  // every list at its longest
+    return (int)(std::min(room > 64 ? room - 64 : 0, want) / 2);
 }
 // LDS of the score kernel
 size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f) {
@@ -341,7 +353,7 @@ size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f) {
 __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im_kernel(
     const selim::PrecRec *__restrict__ recs, int32_t n_prec, const double *__restrict__ ku_g,
     const double *__restrict__ kv_g, int32_t k0, int32_t k1, int32_t cap_cells, int32_t cap_s,
-    unsigned char *__restrict__ scratch, int32_t debug_abl) {
+    unsigned char *__restrict__ scratch, int32_t debug_abl, int32_t tap_budget) {
     using namespace selim;
     constexpr int SCORE_THREADS = SMOOTH_THREADS;  // (this kernel's block size, under the name the loops use)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -360,6 +372,13 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
     int16_t *row_slot = reinterpret_cast<int16_t *>(kv + k1);  // [S] slot of a scan, -1: no event
     int16_t *row_list = row_slot + SEL_BATCH * cap_s;   // [n_rows] scans with events, ascending
     int16_t *row_top = row_list + SEL_BATCH * cap_s;    // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
+    // Tap lists of pass 2, per (window of the batch, scan): the rows within the kernel's reach in tap order, as
+    // (row slot << 6 | tap).  The walk that finds them depends on the scan only; done by every thread of a row
+    // of cells it was 40 % of this kernel (index arithmetic, wrap-arounds and the break: 16 instructions per
+    // tap).  A window's lists are min(rows of the window, k0) entries per scan; a batch whose lists exceed the
+    // launch's budget (dense tiles) walks as before.
+    int16_t *tap_cnt = row_top + SEL_BATCH * cap_s;  // [S] per window
+    uint16_t *tap_tab = reinterpret_cast<uint16_t *>(tap_cnt + SEL_BATCH * cap_s);
     __shared__ int batch_rows[SEL_BATCH];  // scans with events of every window of the batch
     const int tid = threadIdx.x;
     const int i = blockIdx.x;
@@ -484,6 +503,39 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                 }
                 row_top[c] = (int16_t)(lo == 0 ? nr - 1 : lo - 1);
             }
+            // tap lists, if those of the batch fit: window g gets S lists of tap_len[g] entries at tap_base[g]
+            int tap_len[SEL_BATCH], tap_base[SEL_BATCH], tap_total = 0;
+#pragma unroll
+            for (int g = 0; g < SEL_BATCH; ++g) {
+                tap_len[g] = g < gc ? min(batch_rows[g], k0) : 0;
+                tap_base[g] = tap_total;
+                tap_total += S * tap_len[g];
+            }
+            const bool use_taps = tap_total <= tap_budget && debug_abl != 5;  // (5: developer switch, always walk)
+            if (use_taps) {
+                for (int c = tid; c < gc * S; c += SCORE_THREADS) {
+                    const int g = c / S, sc = c - g * S;
+                    const int nr = batch_rows[g];
+                    int tb = 0, tl = 0;
+#pragma unroll
+                    for (int q = 0; q < SEL_BATCH; ++q) {
+                        tb = q == g ? tap_base[q] : tb;
+                        tl = q == g ? tap_len[q] : tl;
+                    }
+                    uint16_t *tp = tap_tab + tb + sc * tl;
+                    // (row_top[c] is this thread's own write of the loop above)
+                    int idx = (int)row_top[c], cnt = 0;
+                    for (int t = 0; t < nr; ++t) {
+                        int a = sc + h0 - (int)row_list[g * S + idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
+                        a += a < 0 ? S : 0;
+                        a -= a >= S ? S : 0;
+                        if (a >= k0) break;
+                        tp[cnt++] = (uint16_t)(idx << 6 | a);
+                        idx = idx == 0 ? nr - 1 : idx - 1;
+                    }
+                    tap_cnt[c] = (int16_t)cnt;
+                }
+            }
             __syncthreads();
             // ---- pass 1, in place: along the cycles, kernel centred at column k1 / 2.  A step takes whole rows:
             // every thread reads the taps of its cell, then all write.
@@ -521,6 +573,14 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                     const int f = p2_f, c = sc * F + f;
                     int idx = (int)rt[sc];
                     double acc = 0.0;
+                    if (use_taps) {
+                        const uint16_t *tp = tap_tab + tap_base[g] + sc * tap_len[g];
+                        const int cnt = debug_abl == 3 ? 0 : (int)tap_cnt[g * S + sc];
+                        for (int t = 0; t < cnt; ++t) {
+                            const int u = (int)tp[t];
+                            acc = fma(ku[u & 63], (double)rw[(u >> 6) * F + f], acc);
+                        }
+                    } else
                     for (int t = 0; t < (debug_abl == 3 ? 0 : n_rows); ++t) {  // (3: developer ablation, no row walk)
                         int a = sc + h0 - (int)rl[idx];  // tap of this row: (sc + h0 - row) mod S, ascending along the walk
                         a += a < 0 ? S : 0;

@@ -329,7 +329,9 @@ def test_hip_timstof_selection_tile_forms_and_indices_agree(ctx, monkeypatch):
 
     base = run()
     assert len(base["precursor_idx"]) > 100
-    for env in (dict(ADH_DEBUG_SELECT_IM_DENSE="1"), dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1")):
+    # (ADH_DEBUG_SELECT_IM_ABL=5: pass 2 of the smoothing walks the rows per cell instead of reading its tap lists)
+    for env in (dict(ADH_DEBUG_SELECT_IM_DENSE="1"), dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"),
+                dict(ADH_DEBUG_SELECT_IM_ABL="5")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
