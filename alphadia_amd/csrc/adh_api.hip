@@ -145,6 +145,7 @@ struct adh_handle {
     std::vector<float> h_rt;        // host copy of the run's rt_values (selection sizes its tiles with it)
     std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
+    fragcomp::Stats last_fragcomp;  // of the last adh_fragcomp / adh_fdr_resident call
     void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
     uint64_t scratch_slab_bytes = 0;
     DevTables tables[2];            // slot 1 only with a communicator (double-buffered all-gather)
@@ -201,6 +202,13 @@ int get_event(adh_handle *h, hipEvent_t *e) {
 }  // namespace
 
 extern "C" {
+
+namespace {
+// adh_score_host.hip: fills the columns a host -> host call left out of the device tables.  They are rebuilt
+// from the candidate table and the library that are in HBM at that moment, so every entry point that
+// replaces either (or the run) settles the tables of the previous call first.
+int materialise_tables(adh_handle *h);
+}  // namespace
 
 const char *adh_last_error(void) { return g_last_error.c_str(); }
 
@@ -376,6 +384,10 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     if (d->n_spectra >= (int64_t)0x7FFFFFFFll || d->cycle_len > 65535)
         return fail(ADH_ERR_UNSUPPORTED, "too many spectra / cycle positions");
     HIP_TRY(hipSetDevice(h->device));
+    {
+        const int rc_m = materialise_tables(h);  // while the candidate table the last call scored is still the resident one
+        if (rc_m != ADH_OK) return rc_m;
+    }
     HIP_TRY(hipDeviceSynchronize());
     h->run_buf.release();
     h->plan = Plan();
@@ -477,6 +489,10 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
         d->n_frames * (int64_t)d->scan_max_index >= 0xFFFFFFFFll)
         return fail(ADH_ERR_UNSUPPORTED, "run too large for 32-bit push / TOF indices");
     HIP_TRY(hipSetDevice(h->device));
+    {
+        const int rc_m = materialise_tables(h);  // while the candidate table the last call scored is still the resident one
+        if (rc_m != ADH_OK) return rc_m;
+    }
     HIP_TRY(hipDeviceSynchronize());
     h->run_buf.release();
     h->plan = Plan();
@@ -589,6 +605,10 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     if (f->n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative fragment count");
     if (f->n >= (int64_t)0xFFFFFFFFll) return fail(ADH_ERR_UNSUPPORTED, "too many fragments");
     HIP_TRY(hipSetDevice(h->device));
+    {
+        const int rc_m = materialise_tables(h);  // the last call's tables refer to the library that goes away
+        if (rc_m != ADH_OK) return rc_m;
+    }
     HIP_TRY(hipDeviceSynchronize());
     h->lib_buf.release();
     h->lib_staged = false;
@@ -1128,6 +1148,15 @@ int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start
     for (int64_t w = 0; w < n_windows; ++w)
         if (window_start[w] < 0 || window_stop[w] < window_start[w] || window_stop[w] > n_psm)
             return fail(ADH_ERR_INVALID_ARGUMENT, "window range outside the PSM table");
+    {  // a PSM belongs to one window (the reference hands every window to its own thread)
+        std::vector<std::pair<int64_t, int64_t>> ranges;
+        for (int64_t w = 0; w < n_windows; ++w)
+            if (window_stop[w] > window_start[w]) ranges.emplace_back(window_start[w], window_stop[w]);
+        std::sort(ranges.begin(), ranges.end());
+        for (size_t r = 1; r < ranges.size(); ++r)
+            if (ranges[r].first < ranges[r - 1].second)
+                return fail(ADH_ERR_INVALID_ARGUMENT, "window ranges overlap");
+    }
     for (int64_t i = 0; i < n_psm; ++i)
         if (frag_start_idx[i] < 0 || frag_stop_idx[i] < frag_start_idx[i] || frag_stop_idx[i] > n_frag)
             return fail(ADH_ERR_INVALID_ARGUMENT, "fragment range outside the fragment table");
@@ -1153,14 +1182,28 @@ int adh_fragcomp(adh_handle_t *h, int64_t n_windows, const int64_t *window_start
     FC_UP(valid, n_psm, &d_valid_c);
 #undef FC_UP
     uint8_t *d_valid = const_cast<uint8_t *>(d_valid_c);
-    hipLaunchKernelGGL(adh_fragcomp_kernel, dim3((unsigned)n_windows), dim3(ADH_FC_THREADS), 0,
-                       h->stream, n_windows, d_ws, d_we, d_rt, d_fs, d_fe, d_mz, rt_tol_seconds,
-                       mass_tol_ppm, d_valid);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    fragcomp::Stats stats;
+    hipError_t e = fragcomp::compete(h->stream, n_windows, d_ws, d_we, n_psm, d_rt, d_fs, d_fe, d_mz, rt_tol_seconds,
+                                     mass_tol_ppm, d_valid, &stats);
     if (e == hipSuccess) e = hipMemcpy(valid, d_valid, (size_t)n_psm, hipMemcpyDeviceToHost);
     tmp.release();
-    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("fragcomp: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP,
+                    std::string("fragcomp: ") + hipGetErrorString(e));
+    }
+    h->last_fragcomp = stats;
+    return ADH_OK;
+}
+
+int adh_fragcomp_stats(adh_handle_t *h, double *kernel_ms, int64_t *pairs, int64_t *waiting, int32_t *rounds,
+                       int32_t *serial) {
+    if (!h) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (kernel_ms) *kernel_ms = h->last_fragcomp.kernel_ms;
+    if (pairs) *pairs = h->last_fragcomp.pairs;
+    if (waiting) *waiting = h->last_fragcomp.unknown;
+    if (rounds) *rounds = h->last_fragcomp.rounds;
+    if (serial) *serial = h->last_fragcomp.serial;
     return ADH_OK;
 }
 

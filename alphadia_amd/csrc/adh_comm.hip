@@ -51,7 +51,26 @@ struct StdoutToStderr {
 
 int rccl_open(adh_comm_state &c) {
     if (c.lib) return ADH_OK;
-    const char *names[] = {getenv("ADH_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // The RCCL that belongs to the HIP runtime THIS library runs on: the one in the same directory, by absolute
+    // path.  A bare soname is not enough: a process that also imports torch holds the wheel's private ROCm
+    // copies (its own libamdhip64 / libhsa-runtime64 / librccl), dlopen("librccl.so.1") then returns the
+    // wheel's RCCL, which talks to the wheel's second, device-less HSA runtime ("no ROCm-capable device is
+    // detected" from ncclCommInitRank; tools/probes/rccl_with_torch_probe.py).
+    std::string beside[2];
+    {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                beside[0] = dir + "librccl.so.1";
+                beside[1] = dir + "librccl.so";
+            }
+        }
+    }
+    const char *names[] = {getenv("ADH_RCCL_LIBRARY"), beside[0].c_str(), beside[1].c_str(), "librccl.so.1", "librccl.so",
+                           "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
         if (!nm || !nm[0]) continue;
         c.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);

@@ -418,9 +418,9 @@ int adh_fdr_resident(adh_handle_t *h, adh_mlp_t *m, const int64_t *group_a, cons
         HIP_TRY(hipMemsetAsync(we, 0, (size_t)cycle_len * 8, st));
         hipLaunchKernelGGL(window_bounds_kernel, grid_for(nc), dim3(256), 0, st, w_sorted, nc, cycle_len, ws, we);
         hipLaunchKernelGGL(fill_u8_kernel, grid_for(nc), dim3(256), 0, st, alive, nc, (uint8_t)1);
-        hipLaunchKernelGGL(adh_fragcomp_kernel, dim3((unsigned)cycle_len), dim3(ADH_FC_THREADS), 0, st, (int64_t)cycle_len, ws,
-                           we, rt_sorted, fs_sorted, fe_sorted, tab.fragment_mz_observed, rt_tol_seconds, mass_tol_ppm, alive);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(fragcomp::compete(st, (int64_t)cycle_len, ws, we, nc, rt_sorted, fs_sorted, fe_sorted, tab.fragment_mz_observed,
+                                  rt_tol_seconds, mass_tol_ppm, alive, &h->last_fragcomp));
         // survivors, in processing order (FragmentCompetition.__call__ returns psm_df[valid])
         rc = compact_ids(h, s, ids_sorted, alive, nc, &cur, &n_cur);
         if (rc != ADH_OK) return rc;

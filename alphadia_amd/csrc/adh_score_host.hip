@@ -722,6 +722,8 @@ int materialise_tables(adh_handle *h) {
     DevTables &t = h->tables[h->last_tables];
     if (!t.partial) return ADH_OK;
     const int64_t n = h->last_rows;
+    if (n > h->cs.n || !h->lib_staged)  // cannot happen through the ABI (replacing either settles the tables first)
+        return fail(ADH_ERR_NOT_STAGED, "the candidate table / library the device tables were scored from is gone");
     if (n > 0) {
         HIP_TRY(hipSetDevice(h->device));
         adh_output_t view = t.view;
@@ -743,6 +745,8 @@ int adh_upload_candidates(adh_handle_t *h, const adh_candidates_t *c) {
     int rc = check_candidate_args(h, c);
     if (rc != ADH_OK) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    rc = materialise_tables(h);  // the last call's tables are rebuilt from the candidate columns that go away now
+    if (rc != ADH_OK) return rc;
     h->plan = Plan();
     h->cands_uploaded = false;
     rc = cand_reserve(h, c->n, c->n_isotope_cols);
@@ -895,6 +899,26 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     h->last_tables = slot;
     h->last_rows = n;
     if (n == 0) return comm_gather_slot(h, slot);
+    std::vector<hipEvent_t> chunk_done;
+    // a call that fails half way leaves no tables behind (a reader would rebuild columns of a half-filled
+    // table), and its events go back to the pool
+    struct Unwind {
+        adh_handle *h;
+        DevTables &tab;
+        std::vector<hipEvent_t> &events;
+        bool ok = false;
+        ~Unwind() {
+            for (hipEvent_t ev : events) h->free_events.push_back(ev);
+            events.clear();
+            if (!ok) {
+                (void)hipDeviceSynchronize();
+                (void)hipGetLastError();
+                h->last_tables = -1;
+                h->last_rows = 0;
+                tab.partial = false;
+            }
+        }
+    } unwind{h, tab, chunk_done};
     adh_output_t dev = tab.view;
     dev.n = n;
     hipStream_t sk = h->stream, si = h->stream_in, so = h->stream_out;
@@ -956,7 +980,6 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         tab.partial = true;
     }
-    std::vector<hipEvent_t> chunk_done;
     std::vector<int64_t> cut{0};
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
@@ -1066,7 +1089,6 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         if (ee != hipSuccess) abort.store(true);
         for (std::thread &t : team) t.join();
-        for (hipEvent_t ev : chunk_done) h->free_events.push_back(ev);
         if (ee != hipSuccess) {
             fail(ADH_ERR_HIP, std::string("scoring pipeline (copy-out): ") + hipGetErrorString(ee));
             return fail_sync(ADH_ERR_HIP);
@@ -1090,6 +1112,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
         for (hipEvent_t e : dbg) (void)hipEventDestroy(e);
     }
+    unwind.ok = true;
     return ADH_OK;
 }
 

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "adh_synchronize",
     "adh_kernel_time_ms",
     "adh_fragcomp",
+    "adh_fragcomp_stats",
     "adh_select_candidates",
     "adh_select_time_ms",
     "adh_transpose_timstof",
@@ -573,14 +574,18 @@ class Context:
         return push_out, indptr_out, val_out
 
     def fragcomp(self, window_start, window_stop, rt, frag_start, frag_stop, fragment_mz,
-                 rt_tol_seconds: float, mass_tol_ppm: float) -> np.ndarray:
+                 rt_tol_seconds: float, mass_tol_ppm: float, valid=None) -> np.ndarray:
         ws = _abi.as_c(window_start, np.int64)
         we = _abi.as_c(window_stop, np.int64)
         rtv = _abi.as_c(rt, np.float32)
         fs = _abi.as_c(frag_start, np.int64)
         fe = _abi.as_c(frag_stop, np.int64)
         fm = _abi.as_c(fragment_mz, np.float32)
-        valid = np.ones(rtv.shape[0], dtype=np.uint8)
+        # the reference starts from an all-true column (fragcomp.py:281); `valid` lets a caller start from less
+        valid = (np.ones(rtv.shape[0], dtype=np.uint8) if valid is None
+                 else np.array(valid, dtype=bool).astype(np.uint8))
+        if valid.shape[0] != rtv.shape[0] or fs.shape[0] != rtv.shape[0] or fe.shape[0] != rtv.shape[0]:
+            raise ValueError("rt / fragment ranges / valid must have one entry per PSM")
         p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
         _check(
             lib.adh_fragcomp(
@@ -601,6 +606,16 @@ class Context:
             "adh_fragcomp",
         )
         return valid.view(np.bool_)
+
+    def fragcomp_stats(self) -> dict:
+        """``adh_fragcomp_stats``: device time and work counters of the last competition."""
+        ms = C.c_double(0.0)
+        pairs, waiting = C.c_int64(0), C.c_int64(0)
+        rounds, serial = C.c_int32(0), C.c_int32(0)
+        _check(lib.adh_fragcomp_stats(self._h, C.byref(ms), C.byref(pairs), C.byref(waiting), C.byref(rounds),
+                                      C.byref(serial)), "adh_fragcomp_stats")
+        return dict(kernel_ms=ms.value, pairs=pairs.value, waiting=waiting.value, rounds=rounds.value,
+                    serial=bool(serial.value))
 
 
     # -- FDR stage ---------------------------------------------------------

@@ -153,7 +153,8 @@ class CandidateScoringConfig:
         self.experimental_xic = False
         # not fields of the reference's config: the parameters of a FITTED quadrupole calibration
         # (SimpleQuadrupoleJit.sigma / .delta_mu, quadrupole.py:72-76); None = the class defaults (0.2, 0.0).
-        # HipCandidateScoring sets them from its ``quadrupole_calibration`` argument.
+        # HipCandidateScoring takes them from its ``quadrupole_calibration`` argument (kept on the scorer, this
+        # object is not written to); setting them here by hand works too.
         self.quadrupole_sigma = None
         self.quadrupole_delta_mu = None
 
@@ -597,6 +598,9 @@ class HipCandidateScoring:
         self.fragments_flat = fragments_flat
         self.config = config if config is not None else CandidateScoringConfig()
         self.config.validate()
+        # fitted transfer-function parameters live on the scorer, not in the caller's config object (which
+        # may be reused for a run with another or no calibration); ``_kernel_config`` injects them per call
+        self._quadrupole = None
         if quadrupole_calibration is not None:
             # SimpleQuadrupole (quadrupole.py:116-259): the transfer function of candidate scoring is
             # jit.predict = logistic_rectangle(cycle + delta_mu, sigma) (quadrupole.py:94-113); a fitted
@@ -614,8 +618,7 @@ class HipCandidateScoring:
             if sigma.shape != (2,) or delta_mu.shape != (2,) or not (sigma > 0).all():
                 raise ValueError("quadrupole calibration: sigma and delta_mu must hold two values, sigma > 0")
             if not (np.array_equal(sigma, [0.2, 0.2]) and np.array_equal(delta_mu, [0.0, 0.0])):
-                self.config.quadrupole_sigma = (float(sigma[0]), float(sigma[1]))
-                self.config.quadrupole_delta_mu = (float(delta_mu[0]), float(delta_mu[1]))
+                self._quadrupole = ((float(sigma[0]), float(sigma[1])), (float(delta_mu[0]), float(delta_mu[1])))
         self.rt_column = rt_column
         self.mobility_column = mobility_column
         self.precursor_mz_column = precursor_mz_column
@@ -629,11 +632,19 @@ class HipCandidateScoring:
     def dia_data(self):
         return self._dia_data
 
+    def _kernel_config(self):
+        """The config value object of a call: the caller's settings plus this scorer's calibration (a
+        calibration passed to the constructor wins over parameters set on the config by hand)."""
+        cfg = self.config.to_jitclass()
+        if self._quadrupole is not None:
+            cfg.quadrupole_sigma, cfg.quadrupole_delta_mu = self._quadrupole
+        return cfg
+
     def score_soa(self, soa: dict, with_stats: bool = False, reuse_buffers: bool = False) -> OutputPsmDF:
         """Run the kernels on an assembled candidate SoA; returns host OutputPsmDF.
         ``reuse_buffers``: results live in the context's page-locked buffers until the next call."""
         arrays = self._ctx.score_host(
-            pack_assembled(soa), self.config.to_jitclass(), with_stats=with_stats, reuse_buffers=reuse_buffers
+            pack_assembled(soa), self._kernel_config(), with_stats=with_stats, reuse_buffers=reuse_buffers
         )
         return OutputPsmDF(arrays)
 

@@ -335,14 +335,22 @@ int adh_device_synchronize(adh_handle_t *handle);
  * Fragment competition inside one run (replaces `_compete_for_fragments`,
  * fragcomp/fragcomp.py:51-143).  PSMs are sorted by (window, proba, precursor)
  * and windows are given as [start, stop) row ranges exactly as
- * FragmentCompetition.__call__ prepares them (fragcomp.py:268-289).
- * valid[] is input/output (all ones on entry).
+ * FragmentCompetition.__call__ prepares them (fragcomp.py:268-289); the row ranges of
+ * different windows must not overlap.  valid[] is input/output (all ones on entry; a PSM
+ * that enters with 0 neither removes nor is looked at, as in the reference's loops).
  */
 int adh_fragcomp(adh_handle_t *handle, int64_t n_windows, const int64_t *window_start,
                  const int64_t *window_stop, int64_t n_psm, const float *rt,
                  const int64_t *frag_start_idx, const int64_t *frag_stop_idx,
                  int64_t n_frag, const float *fragment_mz, double rt_tol_seconds,
                  double mass_tol_ppm, uint8_t *valid);
+/* What the last competition on this handle (adh_fragcomp or inside adh_fdr_resident) did: HIP-event
+ * duration of its device work, (PSM, RT neighbour) pairs whose fragment lists were compared, PSMs whose
+ * fate hung on an earlier PSM, rounds that settled those, and whether the one-workgroup-per-window
+ * kernel had to run (the neighbour bitmap did not fit).  Any pointer may be NULL.  No reference
+ * counterpart (the reference times `_compete_for_fragments` with its logger, fragcomp.py:283-289). */
+int adh_fragcomp_stats(adh_handle_t *handle, double *kernel_ms, int64_t *pairs, int64_t *waiting,
+                       int32_t *rounds, int32_t *serial);
 
 /* ------------------------------------------------------------------------
  * Candidate selection - the step before scoring.

@@ -217,14 +217,16 @@ def quadrupole_transfer_function(cycle, observation_indices, scan_indices, isoto
     return out
 
 
-def fragcomp(window_start, window_stop, rt, frag_start, frag_stop, fragment_mz, rt_tol, mass_tol, n_threads=1):
+def fragcomp(window_start, window_stop, rt, frag_start, frag_stop, fragment_mz, rt_tol, mass_tol, n_threads=1,
+             valid=None):
     ws = np.ascontiguousarray(window_start, dtype=np.int64)
     we = np.ascontiguousarray(window_stop, dtype=np.int64)
     rtv = np.ascontiguousarray(rt, dtype=np.float32)
     fs = np.ascontiguousarray(frag_start, dtype=np.int64)
     fe = np.ascontiguousarray(frag_stop, dtype=np.int64)
     fm = np.ascontiguousarray(fragment_mz, dtype=np.float32)
-    valid = np.ones(rtv.shape[0], dtype=np.uint8)
+    valid = (np.ones(rtv.shape[0], dtype=np.uint8) if valid is None
+             else np.array(valid, dtype=bool).astype(np.uint8))
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
     rc = lib().adh_oracle_fragcomp(
         C.c_int64(ws.shape[0]),

@@ -216,17 +216,23 @@ def plant_peptides(
     sigma_cycles: float = 2.5,
     half_width: int = 8,
     n_isotopes: int = 3,
+    apex: np.ndarray | None = None,
 ) -> PlantedPeaks:
-    """Gaussian elution profiles for ``fraction`` of the target precursors."""
+    """Gaussian elution profiles for ``fraction`` of the target precursors (or for the precursors
+    whose entry of ``apex`` is a cycle >= 0: label channels of one peptide elute together)."""
     rng = np.random.default_rng([seed, 2])
     pdf, fdf = library.precursor_df, library.fragment_df
     n = len(pdf)
     L = cycle.shape[1]
-    targets = np.flatnonzero(pdf["decoy"].values == 0)
-    chosen = targets[rng.random(targets.size) < fraction]
-    apex = np.full(n, -1, dtype=np.int64)
-    lo, hi = 16, max(17, n_cycles - 16)
-    apex[chosen] = rng.integers(lo, hi, chosen.size)
+    if apex is not None:
+        apex = np.asarray(apex, dtype=np.int64).copy()
+        chosen = np.flatnonzero(apex >= 0)
+    else:
+        targets = np.flatnonzero(pdf["decoy"].values == 0)
+        chosen = targets[rng.random(targets.size) < fraction]
+        apex = np.full(n, -1, dtype=np.int64)
+        lo, hi = 16, max(17, n_cycles - 16)
+        apex[chosen] = rng.integers(lo, hi, chosen.size)
 
     win_lo = cycle[0, 1:, 0, 0]
     win_hi = cycle[0, 1:, 0, 1]
@@ -450,8 +456,10 @@ def make_case(
     ms1_mz_range: tuple = (350.0, 1100.0),
     ms2_mz_range: tuple = (150.0, 1600.0),
     k_fragments: int | tuple = 12,
+    run: bool = True,
 ) -> SyntheticCase:
-    """One full synthetic workload (run + library + candidates)."""
+    """One full synthetic workload (run + library + candidates).  ``run=False`` leaves the run out
+    (``dia`` is None): library, planted apexes and candidates are the same as with it."""
     seed = BASE_SEED + config_id if seed is None else seed
     cycle = make_cycle(n_ms2=n_ms2, mz_lo=mz_lo, mz_hi=mz_hi)
     lib = make_library(
@@ -476,7 +484,7 @@ def make_case(
         threads=threads,
         ms1_mz_range=ms1_mz_range,
         ms2_mz_range=ms2_mz_range,
-    )
+    ) if run else None
     cands = make_candidates(
         lib,
         n_cycles,
@@ -540,6 +548,44 @@ def multiplex_library(
     precursor_df = precursor_df.iloc[order].reset_index(drop=True)
     fragment_df = pd.concat(frag_parts, ignore_index=True)
     return SyntheticLibrary(precursor_df, fragment_df)
+
+
+@dataclass
+class MultiplexCase:
+    dia: AlphaRawArrays
+    library: SyntheticLibrary      # every elution group in all label channels
+    psm_df: pd.DataFrame           # the identifications multiplex requantification starts from
+    channels: tuple
+    apex_cycle: np.ndarray         # per library precursor, -1 = nothing planted
+
+
+def make_multiplex_case(n_groups: int, n_cycles: int, config_id: int = 5, channels: tuple = (0, 4, 8, 12),
+                        planted_fraction: float = 0.3, threads: int = 8, **run_kwargs) -> MultiplexCase:
+    """BASELINE configs[4] (SURVEY.md section 8d "Multiplex"): ``n_groups`` elution groups in the label
+    channels ``channels`` (y-ions shifted per channel, b-ions shared with ``cardinality = len(channels)``),
+    the channels of a planted peptide eluting together, and one identification per elution group (its
+    reference-channel precursor, the box of rank 0) - the table
+    ``MultiplexingRequantificationHandler`` hands to ``multiplex_candidates``
+    (multiplexing_requantification_handler.py:75-98)."""
+    seed = BASE_SEED + config_id
+    cycle = make_cycle()
+    base = make_library(n_groups, seed, rt_max=n_cycles * 1.5)
+    bp = base.precursor_df
+    bp["decoy"] = np.uint8(0)                       # requantification starts from targets (decoys: a channel)
+    bp["elution_group_idx"] = bp["precursor_idx"].values.astype(np.uint32)
+    lib = multiplex_library(base, channels=channels, seed=seed)
+    C = len(channels)
+    rng = np.random.default_rng([seed, 5])
+    group_apex = np.where(rng.random(n_groups) < planted_fraction, rng.integers(16, max(17, n_cycles - 16), n_groups), -1)
+    apex = group_apex[lib.precursor_df["elution_group_idx"].values.astype(np.int64)]
+    planted = plant_peptides(lib, cycle, n_cycles, seed, apex=apex)
+    dia = make_thermo_run(n_cycles, seed, cycle=cycle, planted=planted, threads=threads, **run_kwargs)
+    # the identification of every group: its channel-0 precursor with the rank-0 box
+    ref = SyntheticLibrary(lib.precursor_df[lib.precursor_df["channel"].values == channels[0]].reset_index(drop=True),
+                           lib.fragment_df)
+    cands = make_candidates(ref, n_cycles, cycle.shape[1], seed, per_precursor=1, apex_cycle=planted.apex_cycle[::C])
+    cands["proba"] = rng.uniform(0.0, 0.01, len(cands)).astype(np.float32)
+    return MultiplexCase(dia, lib, cands, tuple(channels), planted.apex_cycle)
 
 
 # --------------------------------------------------------------------------- timsTOF-style run
@@ -827,3 +873,44 @@ def make_timstof_case(
         }
     )
     return TimsTOFCase(dia, lib, cands)
+
+
+def make_competition_table(n_psm: int, seed: int = 0, n_windows: int = 60, run_seconds: float = 7200.0, k: int = 12,
+                           shared_fraction: float = 0.1) -> dict:
+    """The table fragment competition receives inside FDR (alphadia/fdr/fdr.py:146-163, prepared by
+    FragmentCompetition.__call__, fragcomp.py:268-289): PSMs below the heuristic FDR, sorted by
+    (DIA window, proba), every PSM with `k` observed fragment masses.
+
+    RT uniform over the run, windows equally filled.  Random fragment lists never share three masses, so
+    a `shared_fraction` of the PSMs are made "the same signal seen twice" - the case the step exists
+    for: such a PSM takes 3...k of its fragment masses (ppm-level jitter) and its RT (within a second)
+    from another PSM of its window; half of those donors are themselves copies, which gives the greedy
+    rule chains to resolve.
+    """
+    rng = np.random.default_rng(BASE_SEED + 7000 + seed)
+    per = n_psm // n_windows
+    sizes = np.full(n_windows, per, dtype=np.int64)
+    sizes[: n_psm - per * n_windows] += 1
+    window_stop = np.cumsum(sizes)
+    window_start = window_stop - sizes
+    rt = rng.uniform(0.0, run_seconds, n_psm).astype(np.float32)
+    mz = rng.uniform(200.0, 1800.0, (n_psm, k)).astype(np.float32)
+    window = np.repeat(np.arange(n_windows), sizes)
+    n_copy = int(n_psm * shared_fraction)
+    copies = rng.choice(n_psm, n_copy, replace=False)
+    # donor: another row of the same window (position drawn inside the window)
+    donors = window_start[window[copies]] + (rng.random(n_copy) * sizes[window[copies]]).astype(np.int64)
+    donors = np.where(donors == copies, window_start[window[copies]] + (donors - window_start[window[copies]] + 1)
+                      % sizes[window[copies]], donors)
+    order = np.argsort(rng.random(n_copy))  # copies of copies: apply in a random order, one after another group-wise
+    copies, donors = copies[order], donors[order]
+    n_shared = rng.integers(3, k + 1, n_copy)
+    for lo in range(0, n_copy, 4096):  # small groups so that later copies see earlier ones as donors
+        c, d, m = copies[lo:lo + 4096], donors[lo:lo + 4096], n_shared[lo:lo + 4096]
+        take = np.arange(k)[None, :] < m[:, None]
+        jitter = 1.0 + rng.normal(0.0, 2e-6, (len(c), k))
+        mz[c] = np.where(take, (mz[d] * jitter).astype(np.float32), mz[c])
+        rt[c] = rt[d] + rng.uniform(-1.0, 1.0, len(c)).astype(np.float32)
+    frag_start = np.arange(n_psm, dtype=np.int64) * k
+    return dict(window_start=window_start, window_stop=window_stop, rt=rt, frag_start=frag_start,
+                frag_stop=frag_start + k, mz=mz.reshape(-1), n_windows=n_windows, k=k)

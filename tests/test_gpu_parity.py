@@ -168,7 +168,10 @@ def test_fitted_quadrupole_on_every_kernel(ctx, oracle_lib, monkeypatch):
         quadrupole_calibration=calibration, rt_column="rt_library", mobility_column="mobility_library",
         precursor_mz_column="mz_library", fragment_mz_column="mz_library", config=plain, device=0,
     )
-    assert scorer.config.quadrupole_sigma == g.config.quadrupole_sigma
+    # the calibration stays on the scorer: the caller's config object is not written to (it may serve
+    # another run, with another or no calibration)
+    assert plain.quadrupole_sigma is None and plain.quadrupole_delta_mu is None
+    assert scorer._kernel_config().quadrupole_sigma == g.config.quadrupole_sigma
     fdf, frdf = scorer(g.candidates_df, thread_count=4)
     assert np.array_equal(fdf["precursor_idx"].values, g.z["features_df_precursor_idx"])
     assert np.abs(frdf["mz_observed"].values - g.z["fragments_df_mz_observed"]).max() < 1e-4
