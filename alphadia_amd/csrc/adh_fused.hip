@@ -23,9 +23,12 @@
 //     float64 divisions by a common divisor through one shared reciprocal refinement
 //   * LDS is one union per candidate: selection scratch -> tile -> feature arrays
 //
-// Eligibility (adh_plan_rec_kernel): one or two observations, 3 <= F <= 32, k_cap <= 12, I <= 3, library slice
-// of at most 64 fragments, experimental_xic = True, a single MS1 row per cycle.  Everything else runs
-// through the two-kernel path.
+// Eligibility (adh_plan_rec_kernel): one or two observations (both settings of quant_all), 3 <= F <= 32, k_cap <= 12,
+// I <= 4, library slice of at most 64 fragments, experimental_xic = True, a single MS1 row per cycle.  Everything
+// else runs through the two-kernel path: in particular candidates that keep 13 or more fragments - a group has 16
+// lanes, 12 + 4 is the split that covers the reference's defaults (top_k_fragments 12, default.yaml:185; 3 or 4
+// isotopes); longer lists only occur when a transfer library with more than 12 fragments per precursor is
+// requantified with top_k_fragments = 9999 (transfer_library_requantification_handler.py:117-124).
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
@@ -58,7 +61,11 @@
 namespace fused {
 
 constexpr int GS = 16;
-constexpr int TW = 15;  // tile columns: 12 fragment lanes + at most 3 isotope lanes
+// Tile columns TW (a template parameter): 12 fragment lanes + the isotope lanes.  15 for up to three isotopes
+// (the search: extraction_handler.py:372) - an odd row stride, and lane 15 has no window; 16 for four (round 4:
+// top_k_isotopes = 4 is the class default, config.py:78, which multiplex / transfer-library requantification
+// score with).  One width for both cost the three-isotope candidates of the headline 4 % (same-box A/B: the
+// even stride of 32 words puts the scattered cell updates of the gather on two sets of banks).
 constexpr int ISO0 = ADH_FUSED_ISO0;
 constexpr int NLIB = ADH_FUSED_NLIB;
 
@@ -102,7 +109,7 @@ struct __attribute__((aligned(16))) Keep {
 };
 struct __attribute__((aligned(16))) NoKeep {};
 
-template <int FM, int NO>
+template <int FM, int NO, int TW>
 struct __attribute__((aligned(16))) GroupLds {
     union {
         struct {  // fragment selection
@@ -123,7 +130,7 @@ struct __attribute__((aligned(16))) GroupLds {
             } u;
             double wt[2][FM];  // [scan slot][centred cycle]: exp weights around the template centre
             double merr[16];
-            double red64[12];
+            double red64[14];
             float tpl[FM], tfp[FM], med[FM];
             float g_int[16], g_fin[16], corr[16];
             int fpeak[16][NO];
@@ -381,6 +388,7 @@ __device__ __forceinline__ void task_fetch(const DevRun &run, Task &k) {
 }
 
 // cells: the lane's column of the tile, cells[r * TW] = centred row r; roff = FM/2 - F/2 - c0
+template <int TW>
 __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Task &k, float2 *cells, int roff,
                                          uint32_t &hits) {
     uint32_t idx = k.idx;
@@ -447,10 +455,11 @@ template <int NO>
 __device__ __forceinline__ void precursor_features(float *ft, int I, const float *iso_int_p, const float *iso_mz_p,
                                                    const float *spi_p, const double *hp_p, const double *wme_term_p,
                                                    const float (&oi)[NO]) {
-    float ii[3], mz[3], spi[3];
-    double hp[3], wt[3];
+    constexpr int NI = 4;
+    float ii[NI], mz[NI], spi[NI];
+    double hp[NI], wt[NI];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NI; ++i) {
         ii[i] = iso_int_p[i];
         mz[i] = iso_mz_p[i];
         spi[i] = spi_p[i];
@@ -459,11 +468,11 @@ __device__ __forceinline__ void precursor_features(float *ft, int I, const float
     }
     int amax = 0;
 #pragma unroll
-    for (int i = 1; i < 3; ++i)
-        if (i < I && ii[i] > ii[amax == 0 ? 0 : (amax == 1 ? 1 : 2)]) amax = i;
+    for (int i = 1; i < NI; ++i)
+        if (i < I && ii[i] > (amax == 0 ? ii[0] : (amax == 1 ? ii[1] : ii[2]))) amax = i;
     float w4 = 0, w5 = 0, f6 = 0, f7 = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (i < I) {
             float a = 0;
 #pragma unroll
@@ -480,20 +489,20 @@ __device__ __forceinline__ void precursor_features(float *ft, int I, const float
     ft[7] = f7;
     double wme = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NI; ++i)
         if (i < I) wme += wt[i];
     ft[8] = (float)wme;
     ft[9] = (float)fabs(wme);
     ft[10] = (float)((double)mz[0] + wme * 1e-6 * (double)mz[0]);
     ft[11] = (float)hp[0];
-    ft[12] = (float)(amax == 0 ? hp[0] : (amax == 1 ? hp[1] : hp[2]));
+    ft[12] = (float)(amax == 0 ? hp[0] : (amax == 1 ? hp[1] : (amax == 2 ? hp[2] : hp[3])));
     {
         double a = 0, b = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) a += hp[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) b += hp[i] * (double)ii[i];
         ft[13] = (float)a;
         ft[14] = (float)b;
@@ -503,35 +512,35 @@ __device__ __forceinline__ void precursor_features(float *ft, int I, const float
         float sx = 0, sy = 0;
         double sh = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) sx += ii[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) sy += spi[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) sh += hp[i];
         const Recip rI((double)max(I, 1));
         const float xb = (float)rI.div((double)sx), yb = (float)rI.div((double)sy);
         const double hb = rI.div(sh);
         float num = 0, sxx = 0, syy = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) num += (ii[i] - xb) * (spi[i] - yb);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) sxx += (ii[i] - xb) * (ii[i] - xb);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) syy += (spi[i] - yb) * (spi[i] - yb);
         const float den = sqrtf(sxx * syy);
         ft[15] = (float)((double)num / ((double)den + 1e-12));
         double numd = 0, shh = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) numd += (double)(ii[i] - xb) * (hp[i] - hb);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NI; ++i)
             if (i < I) shh += (hp[i] - hb) * (hp[i] - hb);
         const double dend = sqrt((double)sxx * shh);
         ft[16] = (float)(numd / (dend + 1e-12));
@@ -540,7 +549,7 @@ __device__ __forceinline__ void precursor_features(float *ft, int I, const float
 
 // one gather pass of a candidate: every lane with a window folds the peaks of its (window, cycle row) into
 // its column of the zeroed tile, cycle block after cycle block
-template <int FM>
+template <int FM, int TW>
 __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb, bool task_on, int task_row, bool alive,
                                             int c0, int F, float2 (*tile)[TW], int sub, uint32_t &hits) {
     {
@@ -552,7 +561,7 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
     }
     const int bs = run.block_shift;
     const int blk0 = c0 >> bs, blk1 = alive ? (c0 + F - 1) >> bs : blk0 - 1;  // first / last cycle block
-    float2 *cells = &tile[0][min(sub, TW - 1)];  // (lane 15 never has a window)
+    float2 *cells = &tile[0][min(sub, TW - 1)];  // (TW = 15: lane 15 never has a window)
     const int roff = FM / 2 - F / 2 - c0;       // centred row of absolute cycle x: x + roff
     const int n_bins_l = task_on ? wb.b_hi - wb.b_lo + 1 : 0;
     for (int grp = blk0 >> ADH_SUB_SHIFT; grp <= (blk1 >> ADH_SUB_SHIFT); ++grp) {  // (wave-uniform only per group of lanes:
@@ -569,7 +578,7 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
 #pragma unroll
             for (int u = 0; u < NPAIR; ++u) task_fetch(run, t[u]);
 #pragma unroll
-            for (int u = 0; u < NPAIR; ++u) task_run(run, wb, t[u], cells, roff, hits);
+            for (int u = 0; u < NPAIR; ++u) task_run<TW>(run, wb, t[u], cells, roff, hits);
         }
     }
 }
@@ -577,7 +586,7 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
 }  // namespace fused
 
 // one wavefront = four candidates of a class with FM registers; `block` counts the wavefronts of the class
-template <int FM, int NO>
+template <int FM, int NO, int TW>
 __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan,
                                            int32_t n_cand, int32_t block, const float *__restrict__ iso_table,
                                            int32_t n_iso_cols, const adh_scoring_config_t &cfg,
@@ -587,11 +596,11 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     using feat::Assemble;
     constexpr int RC = FM / 2;
     constexpr int KMAX = ISO0;  // fragments a candidate of this kernel keeps at most
-    GroupLds<FM, NO> *lds = reinterpret_cast<GroupLds<FM, NO> *>(smem);
+    GroupLds<FM, NO, TW> *lds = reinterpret_cast<GroupLds<FM, NO, TW> *>(smem);
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
-    GroupLds<FM, NO> &L = lds[g];
+    GroupLds<FM, NO, TW> &L = lds[g];
     Keep<FM, NO> &KP = L.keep();
     const int ci = block * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
@@ -607,7 +616,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     const int F = alive ? rec.frame_stop / Lc - c0 : 0;
     const int c = F / 2;
     const int shift = c - RC;  // f = r + shift
-    const int I = alive ? min(n_iso_cols, (int)cfg.top_k_isotopes) : 0;
+    const int I = alive ? min(min(n_iso_cols, (int)cfg.top_k_isotopes), TW - ISO0) : 0;  // (the host picks TW for I)
     const int top_k = out.top_k;
     if (stop_phase == 19) {  // developer ablation (ADH_DEBUG_STOP_PHASE): launch + candidate record only
         if (F == -12345) out.valid[row] = 2;
@@ -790,7 +799,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 
     // ================= gather: every lane its window, into its column of the tile =================
     uint32_t hits = 0;
-    gather_pass<FM>(run, wb, task_on, task_row, alive, c0, F, L.u.tile, sub, hits);
+    gather_pass<FM, TW>(run, wb, task_on, task_row, alive, c0, F, L.u.tile, sub, hits);
     // quadrupole_transfer_function_single (quadrupole.py:261-301): logistic(x, lower edge) - logistic(x, upper edge)
     double q_term = 0.0;
     {
@@ -833,13 +842,36 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     double ohe_l[NO], omz_l[NO];
     int fpeak_l[NO];
     float so = 0.0f;
+    // quantification of an enveloped profile (fragment_features.py:252-273): trapezoid area x window and the
+    // intensity inside the window
+    double area = 0.0;
+    float obs_int = 0.0f;
+    const int qw = min(c - 1, (int)cfg.quant_window);
+    auto quantify = [&](const float (&E)[FM]) {
+        double ar = 0.0;
+#pragma unroll
+        for (int r = 1; r < FM - 1; ++r) {
+            const bool in = r >= RC - qw && r + 1 <= RC + qw;
+            const float sm = E[r + 1] + E[r];
+            const float drt = KP.frt[r + 1] - KP.frt[r];
+            const float m = sm * drt;
+            ar += in ? (double)m * 0.5 : 0.0;
+        }
+        area = ar * (double)qw;
+        float oi_sum = 0.0f;
+        FU_FOR_R oi_sum += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
+        obs_int = oi_sum;
+    };
+    // without quant_all the profile of the most important observation is quantified, and - a view in the
+    // reference (fragment_features.py:240-250) - its envelope edit stays in fragments_frame_profile
+    int best_obs = 0;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
         if (o > 0) {
             // the next observation: only the fragment lanes gather (cycle row obs[o]); the tile takes the
             // place of the feature arrays, what has to survive sits in KP
             adh_wave_sync();
-            gather_pass<FM>(run, wb, task_on && !iso_lane, (int)rec.obs[o], alive, c0, F, L.u.tile, sub, hits);
+            gather_pass<FM, TW>(run, wb, task_on && !iso_lane, (int)rec.obs[o], alive, c0, F, L.u.tile, sub, hits);
         }
         // ================= rows into registers (the tile is dead afterwards) =================
         {
@@ -913,14 +945,32 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             adh_wave_sync();
         }
         if (stop_phase == 31) return;
-        // observation importance (quadrupole.py:327-335): template sum of this observation
-        {
+        // observation importance (quadrupole.py:327-335): template sums - all of them in the first round, the
+        // rows of the later observations wait in KP.tpl_next (NO <= 2)
+        if (o == 0) {
             float st = 0.0f;
             FU_FOR_R {
                 st += Q.tpl[r];
                 FU_FENCE(r);
             }
-            tsum[o] = st + st;
+            tsum[0] = st + st;
+            if (NO > 1) {
+                float st1 = 0.0f;
+                FU_FOR_R {
+                    st1 += KP.tpl_next[r];
+                    FU_FENCE(r);
+                }
+                tsum[NO - 1] = st1 + st1;
+                float tot = 0.0f;
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) tot += tsum[oo];
+                float best_v = (tot == 0.0f) ? 1.0f / (float)NO : tsum[0] / tot;
+#pragma unroll
+                for (int oo = 1; oo < NO; ++oo) {  // np.argmax: the first maximum
+                    const float v = (tot == 0.0f) ? 1.0f / (float)NO : tsum[oo] / tot;
+                    if (v > best_v) best_v = v, best_obs = oo;
+                }
+            }
         }
         // ---- template centre of mass (fragment_features.py:20-68; every lane computes it), template frame
         // profile, weights around the centre
@@ -1026,6 +1076,10 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             // template.  With one observation they are taken after the envelope step, whose in-place edit
             // they must see when quant_all is off.
             FU_FOR_R A[r] = frag_lane0 ? A[r] + A[r] : 0.0f;
+            if (!cfg.quant_all && o == best_obs) {  // (the branch is per candidate: a group's lanes agree)
+                center_envelope<FM>(A, F);
+                quantify(A);
+            }
             profile_stats<FM>(A, Q.tfp, F, shift, rt_width, ftc_l[o], fw_l[o], fpeak_l[o]);
             if (o == 0) {
                 FU_FOR_R P[r] = A[r];  // (0 + x for x >= +0)
@@ -1092,25 +1146,13 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     if (present) Q.g_fin[kk] = g_fin_l;
     if (stop_phase == 3 || stop_phase == 4) return;
 
-    // ---- envelope, quantification (fragment_features.py:240-273)
-    double area = 0.0;
-    float obs_int = 0.0f;
-    {
+    // ---- envelope, quantification (fragment_features.py:240-273); several observations without quant_all
+    // were quantified inside the loop above
+    if (NO == 1 || cfg.quant_all) {
         float E[FM];  // np.sum(axis=1) made a copy: with quant_all the profile itself is untouched
         FU_FOR_R E[r] = P[r];
         center_envelope<FM>(E, F);
-        const int qw = min(c - 1, (int)cfg.quant_window);
-        double ar = 0.0;
-#pragma unroll
-        for (int r = 1; r < FM - 1; ++r) {
-            const bool in = r >= RC - qw && r + 1 <= RC + qw;
-            const float sm = E[r + 1] + E[r];
-            const float drt = KP.frt[r + 1] - KP.frt[r];
-            const float m = sm * drt;
-            ar += in ? (double)m * 0.5 : 0.0;
-        }
-        area = ar * (double)qw;
-        FU_FOR_R obs_int += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
+        quantify(E);
         if (NO == 1 && !cfg.quant_all) {
             FU_FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
         }
@@ -1256,8 +1298,8 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         // ---- the quotients: lane -> (numerator, denominator)
         //   0-2 sums of area / height / intensity over K (np.corrcoef means), 3 mass error / K (42),
         //   4, 5 overlap area / mass error over n_ov (44, 45), 6 n_int / K (20), 7 n_hei / K (21),
-        //   8 cosine sum / n_int (24), 11 top-3 mass error / n3 (41), 12 + i the mass error of isotope i
-        //   (precursor_features.py:40-50), 15 n_present / K0 (28, candidate.py:362)
+        //   8 cosine sum / n_int (24), 9 n_present / K0 (28, candidate.py:362), 11 top-3 mass error / n3 (41),
+        //   12 + i the mass error of isotope i (precursor_features.py:40-50)
         double num = s64, den = (double)K;
         if (sub == 4 || sub == 5) den = (double)n_ov;
         if (sub == 6) num = (double)n_int;
@@ -1265,17 +1307,17 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         if (sub == 8) num = (double)s32, den = (double)n_int;
         if (sub == 11) den = (double)n3;
         double omzp_i = 0.0;
-        if (sub >= ISO0 && sub < 15) {
+        if (sub >= ISO0) {
             const int i = sub - ISO0;
             omzp_i = KP.omzp[i];
             num = omzp_i - (double)KP.iso_mz[i];
             den = (double)KP.iso_mz[i];
         }
-        if (sub == 15) num = (double)n_present, den = (double)K0;
+        if (sub == 9) num = (double)n_present, den = (double)K0;
         const double quo = num / den;
         if (sub < 3) Q.red64[sub] = quo;
         if (sub == 1) Q.red64[3] = s64;  // (the sum of the heights decides whether feature 19 is taken)
-        if (sub >= ISO0 && sub < 15) {
+        if (sub >= ISO0) {
             const double me = quo * 1e6;
             Q.red64[4 + sub - ISO0] = (omzp_i > 0) ? me * (double)KP.iso_int[sub - ISO0] : 0.0;
         }
@@ -1294,7 +1336,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
                 ft[16 + sub] = ((sub == 9 ? nb : ny) > 0) ? lg : 0.0f;
             }
             if (sub == 11) ft[41] = (float)quo;
-            if (sub == 15) ft[28] = (float)quo, ft[17] = (float)NO;
+            if (sub == 9) ft[28] = (float)quo, ft[17] = (float)NO;
         }
     }
     adh_wave_sync();
@@ -1319,15 +1361,15 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         for (int k = 0; k < KMAX; ++k) v64[k] = Q.u.at.t64[k][c64];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) s64 += (k < K) ? v64[k] : 0.0;
-        if (sub < 5) Q.red64[7 + sub] = s64;
+        if (sub < 5) Q.red64[8 + sub] = s64;
     }
     adh_wave_sync();
     if (ADH_FUSED_SCALAR && alive && sub < 2) {
         // lane 0: feature 18 (areas), lane 1: feature 19 (heights)
         const double fact = fmax((double)K - 1.0, 0.0);
         const double inv = 1.0 / fact;
-        const double cxx = Q.red64[sub ? 10 : 7] * inv, cyy = Q.red64[8] * inv;
-        const double cxy = Q.red64[sub ? 11 : 9] * inv;
+        const double cxx = Q.red64[sub ? 11 : 8] * inv, cyy = Q.red64[9] * inv;
+        const double cxy = Q.red64[sub ? 12 : 10] * inv;
         const double s0 = sqrt(cxx), s1 = sqrt(cyy);
         double cc = cxy / s1 / s0;
         if (fabs(cc) > 1.0) cc = (cc > 0) ? 1.0 : -1.0;
@@ -1542,9 +1584,10 @@ struct FusedClasses {
     int32_t n_cand[ADH_FUSED_MAX_CLASSES];
     int32_t kind[ADH_FUSED_MAX_CLASSES];             // (FM - 8) / 4 + 7 * (observations - 1)
 };
+template <int TW>
 constexpr size_t adh_fused_lds_bytes(int fm_max, int no) {
-    return (fm_max > 28 ? (no > 1 ? sizeof(fused::GroupLds<32, 2>) : sizeof(fused::GroupLds<32, 1>))
-                        : (no > 1 ? sizeof(fused::GroupLds<28, 2>) : sizeof(fused::GroupLds<28, 1>))) *
+    return (fm_max > 28 ? (no > 1 ? sizeof(fused::GroupLds<32, 2, TW>) : sizeof(fused::GroupLds<32, 1, TW>))
+                        : (no > 1 ? sizeof(fused::GroupLds<28, 2, TW>) : sizeof(fused::GroupLds<28, 1, TW>))) *
            (ADH_WAVE / 16);
 }
 
@@ -1554,12 +1597,12 @@ constexpr size_t adh_fused_lds_bytes(int fm_max, int no) {
 // observation the bodies for 28 and 32 cycles are the only ones that do not fit the registers of three
 // wavefronts per SIMD (120 / 252 bytes of scratch per lane, 2.5 GB of spill stores per 3 M candidates):
 // they run at two, without a spill, in a launch of their own.
-template <int FM_MIN, int FM_MAX, int NO>
+template <int FM_MIN, int FM_MAX, int NO, int TW>
 __global__ __launch_bounds__(ADH_WAVE, (NO == 1 && FM_MAX <= ADH_FUSED_FM3) ? ADH_FUSED_WAVES : ADH_FUSED_WAVES2) void adh_fused_kernel(
     DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, FusedClasses fc,
     const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
     const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
-    __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes(FM_MAX, NO)];
+    __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes<TW>(FM_MAX, NO)];
     const int32_t b = (int32_t)blockIdx.x;
     int c = 0;
     while (c + 1 < fc.n && b >= fc.first_block[c + 1]) ++c;
@@ -1569,7 +1612,7 @@ __global__ __launch_bounds__(ADH_WAVE, (NO == 1 && FM_MAX <= ADH_FUSED_FM3) ? AD
 #define ADH_FUSED_CASE(KIND, FM)                                                                                       \
     if constexpr (FM >= FM_MIN && FM <= FM_MAX) {                                                                      \
         if (kind == KIND) {                                                                                            \
-            fused_body<FM, NO>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
+            fused_body<FM, NO, TW>(run, lib, recs, n, blk, iso_table, n_iso_cols, cfg, wtp_table, out, stop_phase, smem); \
             return;                                                                                                    \
         }                                                                                                              \
     }

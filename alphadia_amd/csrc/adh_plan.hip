@@ -178,12 +178,14 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
             const int F = r.frame_stop / p.L - r.frame_start / p.L;
             // shape handled by the register-resident kernels (adh_features_fast.hip); several
             // observations only with quant_all
-            const bool fast = p.fast_cfg && O >= 1 && O <= ADH_PLAN_FAST_OMAX && (O == 1 || p.quant_all) && F >= 3 &&
-                              F <= ADH_PLAN_FMAX && r.k_cap <= 16 && p.I <= 4;
-            // gather and features in one kernel (adh_fused.hip): lanes 12..15 of a 16-lane group carry the isotopes
-            const bool fused = fast && ((p.fused_cfg >> (O - 1)) & 1) && r.k_cap <= 12 && nl <= 64;  // (p.I <= 3 is part of fused_cfg)
-            cls = !fast ? ADH_CLASS_GENERIC
-                        : (fused ? (O == 1 ? ADH_CLASS_FUSED0 : ADH_CLASS_FUSED2) + max(F - 5, 0) / 4
+            const bool shape = p.fast_cfg && O >= 1 && O <= ADH_PLAN_FAST_OMAX && F >= 3 && F <= ADH_PLAN_FMAX && r.k_cap <= 16 &&
+                               p.I <= 4;
+            const bool fast = shape && (O == 1 || p.quant_all);
+            // gather and features in one kernel (adh_fused.hip): lanes 12..15 of a 16-lane group carry the isotopes;
+            // it quantifies the best of two observations itself when quant_all is off (round 4)
+            const bool fused = shape && ((p.fused_cfg >> (O - 1)) & 1) && r.k_cap <= 12 && nl <= 64;
+            cls = fused ? (O == 1 ? ADH_CLASS_FUSED0 : ADH_CLASS_FUSED2) + max(F - 5, 0) / 4
+                        : (!fast ? ADH_CLASS_GENERIC
                                  : (O == 1 ? ADH_CLASS_FAST1 + max(F - 5, 0) / 4
                                            : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2))));
             bin = (uint32_t)(r.frame_start / p.L);

@@ -317,7 +317,7 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.top_k = cfg->top_k_fragments;
     p.fast_cfg = key.fast_cfg ? 1 : 0;
     p.quant_all = key.quant_all ? 1 : 0;
-    p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 3) ? (getenv("ADH_DEBUG_NO_FUSED2") ? 1 : 3) : 0;
+    p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 4) ? (getenv("ADH_DEBUG_NO_FUSED2") ? 1 : 3) : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(adh_plan_init_kernel, dim3(1), dim3(1), 0, st, s.d_meta, p.I);
     const int64_t n_frames = im ? h->tims.n_frames : h->run.n_spectra;
@@ -601,18 +601,23 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
             }
             first += nc;
         }
-#define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                                                                       \
-    if (fblocks[W] > 0) {                                                                                             \
-        hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, \
-                           h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out,                \
-                           (int32_t)stop_phase);                                                                      \
-        HIP_TRY(hipGetLastError());                                                                                   \
+        // tile width: 15 columns while lane 15 carries no isotope, 16 with four isotopes (adh_fused.hip)
+        const bool wide = std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)n_iso) > 3;
+#define ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, TW)                                                                    \
+    hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st,    \
+                       h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
+#define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                      \
+    if (fblocks[W] > 0) {                                            \
+        if (wide) ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 16);    \
+        else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 15);         \
+        HIP_TRY(hipGetLastError());                                  \
     }
         ADH_LAUNCH_FUSED(0, 8, ADH_FUSED_FM3, 1)
         ADH_LAUNCH_FUSED(1, ADH_FUSED_FM3 + 4, 32, 1)
         ADH_LAUNCH_FUSED(2, 8, 28, 2)
         ADH_LAUNCH_FUSED(3, 32, 32, 2)
 #undef ADH_LAUNCH_FUSED
+#undef ADH_LAUNCH_FUSED_TW
     }
     if (stop_phase != 2 && !fused_only) {
         int64_t first = n_fused;

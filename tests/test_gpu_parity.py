@@ -128,6 +128,39 @@ def test_hip_matches_reference_goldens(ctx, name):
     compare(got, g.expected, PPM_ABS_TOL_GOLDEN, rel_tol=REL_TOL, corr_abs=1e-3)
 
 
+@pytest.mark.parametrize("name", ["handler_default", "multiplex", "edges", "topk6", "fitted_quadrupole"])
+@pytest.mark.parametrize("quant_all", [False, True])
+def test_requantification_configs_take_the_fused_kernel(ctx, oracle_lib, monkeypatch, name, quant_all):
+    """The scoring config of multiplex / transfer-library requantification is ``CandidateScoringConfig()`` with
+    its class defaults - top_k_isotopes = 4, quant_all = False (config.py:70-84,
+    multiplexing_requantification_handler.py:121-125) - plus experimental_xic from the search config.  Since
+    round 4 the fused kernel scores it (isotope 3 on lane 15; with two observations the more important one is
+    quantified and keeps its envelope edit, fragment_features.py:240-250): equal to the oracle, bit for bit
+    equal to the two-kernel path, and no candidate of these tables goes through the gather kernel."""
+    g = H.load_scoring_golden(name)
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(score_grouped=bool(g.config.score_grouped), reference_channel=int(g.config.reference_channel),
+                    exclude_shared_ions=True, experimental_xic=True, quant_all=quant_all))
+    cfg.quadrupole_sigma, cfg.quadrupole_delta_mu = g.config.quadrupole_sigma, g.config.quadrupole_delta_mu
+    assert cfg.top_k_isotopes == 4 and cfg.top_k_fragments == 12
+    ctx.kernel_time_ms(reset=True)
+    got, soa = hip_score(ctx, g, cfg)
+    gather_fused, feature_fused, _ = ctx.kernel_time_ms(reset=True)
+    exp, _ = H.oracle_score(oracle_lib, g, cfg, soa=soa)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert exp["valid"].sum() > (5 if name == "edges" else 20)
+    with monkeypatch.context() as mp:
+        mp.setenv("ADH_DEBUG_NO_FUSED", "1")
+        two_kernel, _ = hip_score(ctx, g, cfg, soa=soa)
+        gather_two, _, _ = ctx.kernel_time_ms(reset=True)
+    for k in got:
+        assert np.array_equal(two_kernel[k], got[k], equal_nan=True), k
+    # (no gather launch between the two events of the fused run: microseconds against a kernel; "edges" holds
+    # shapes outside the fused kernel's on purpose)
+    if name != "edges":
+        assert gather_fused < 0.25 * gather_two and feature_fused > 0, (gather_fused, gather_two)
+
+
 def test_fitted_quadrupole_on_every_kernel(ctx, oracle_lib, monkeypatch):
     """A fitted quadrupole calibration (SimpleQuadrupoleJit.sigma / .delta_mu, quadrupole.py:72-113) reaches all
     four places the transfer function is evaluated: the fused kernel, the two-kernel register path
