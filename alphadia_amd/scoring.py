@@ -17,6 +17,7 @@ library is missing, construction fails.
 from __future__ import annotations
 
 import logging
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -367,10 +368,17 @@ def assemble_candidates(
         lib_rows = np.argsort(lib_pidx, kind="stable")
         precursors_flat_df = precursors_flat_df.iloc[lib_rows]
         lib_pidx = precursors_flat_df["precursor_idx"].values
-    pos = np.searchsorted(lib_pidx, cols["precursor_idx"])
-    pos_c = np.minimum(pos, max(len(lib_pidx) - 1, 0))
-    if n and (len(lib_pidx) == 0 or not np.array_equal(lib_pidx[pos_c], cols["precursor_idx"])):
-        raise ValueError("candidates_df contains precursor_idx values missing from precursors_flat")
+    if len(lib_pidx) and int(lib_pidx[0]) == 0 and int(lib_pidx[-1]) == len(lib_pidx) - 1:
+        # strictly ascending from 0 to len - 1: the index IS the row (a library as alphabase writes it)
+        pos = cols["precursor_idx"].astype(np.intp)
+        if n and int(pos.max()) >= len(lib_pidx):
+            raise ValueError("candidates_df contains precursor_idx values missing from precursors_flat")
+        pos_c = pos
+    else:
+        pos = np.searchsorted(lib_pidx, cols["precursor_idx"])
+        pos_c = np.minimum(pos, max(len(lib_pidx) - 1, 0))
+        if n and (len(lib_pidx) == 0 or not np.array_equal(lib_pidx[pos_c], cols["precursor_idx"])):
+            raise ValueError("candidates_df contains precursor_idx values missing from precursors_flat")
 
     def from_lib(name, dtype, default=None):
         if name in candidates_df.columns:
@@ -381,32 +389,44 @@ def assemble_candidates(
             raise ValueError(f"Columns ['{name}'] must be present in right_df")
         return np.full(n, default, dtype=dtype)
 
-    channel = from_lib("channel", np.uint8, default=0)
-    decoy = from_lib("decoy", np.uint8)
-    frag_start = from_lib("flat_frag_start_idx", np.uint32)
-    frag_stop = from_lib("flat_frag_stop_idx", np.uint32)
-    charge = from_lib("charge", np.uint8)
-    prec_mz = from_lib(precursor_mz_column, np.float32)
     iso_names = get_isotope_column_names(
         list(dict.fromkeys(list(candidates_df.columns) + list(precursors_flat_df.columns)))
     )
+    # library lookups: one gather per column, side by side on the host pool
+    lookups = [("channel", np.uint8, 0), ("decoy", np.uint8, None), ("flat_frag_start_idx", np.uint32, None),
+               ("flat_frag_stop_idx", np.uint32, None), ("charge", np.uint8, None), (precursor_mz_column, np.float32, None)]
+    lookups += [(c, np.float32, None) for c in iso_names]
+    looked = _parallel([(lambda a=a: from_lib(*a)) for a in lookups])
+    channel, decoy, frag_start, frag_stop, charge, prec_mz = looked[:6]
     if iso_names:
-        iso = np.stack([from_lib(c, np.float32) for c in iso_names], axis=1)
+        iso = np.stack(looked[6:], axis=1)
     else:
         iso = np.ones((n, 1), dtype=np.float32)  # scoring.py:322-323
 
-    order = np.lexsort((cols["precursor_idx"], cols["rank"], decoy, cols["elution_group_idx"]))
+    # score-group order (scoring/utils.py:388-410): elution group, decoy, rank, precursor.  A table that is in
+    # that order already - what candidate selection emits for a library sorted by precursor - skips the sort
+    eg0, rk0, pi0 = cols["elution_group_idx"], cols["rank"], cols["precursor_idx"]
+    presorted = n < 2
+    if not presorted:
+        a_eg, b_eg = eg0[:-1], eg0[1:]
+        lt = a_eg < b_eg
+        tie = a_eg == b_eg
+        for a_k, b_k in ((decoy[:-1], decoy[1:]), (rk0[:-1], rk0[1:]), (pi0[:-1], pi0[1:])):
+            lt |= tie & (a_k < b_k)
+            tie &= a_k == b_k
+        presorted = bool((lt | tie).all())
+    order = np.arange(n, dtype=np.intp) if presorted else np.lexsort((pi0, rk0, decoy, eg0))
+    order_arg = None if presorted else order
 
     def ordered(name, col):
         """``col[order]``, in page-locked memory when a pool is given"""
-        return col[order] if pool is None else pool.take("cand:" + name, col, order)
+        if pool is not None:
+            return pool.take("cand:" + name, col, order_arg)
+        return col[order] if order_arg is not None else np.array(col, copy=True)
 
-    eg, dc, rk, pi = (
-        cols["elution_group_idx"][order],
-        decoy[order],
-        ordered("rank", cols["rank"]),
-        ordered("precursor_idx", cols["precursor_idx"]),
-    )
+    eg = eg0 if presorted else eg0[order]
+    dc = decoy if presorted else decoy[order]
+    rk, pi = ordered("rank", rk0), ordered("precursor_idx", pi0)
     if score_grouped and n:
         change = np.ones(n, dtype=bool)
         change[1:] = (eg[1:] != eg[:-1]) | (dc[1:] != dc[:-1]) | (rk[1:] != rk[:-1])
@@ -418,7 +438,7 @@ def assemble_candidates(
         if dup.any():
             raise ValueError("precursor_idx must be unique within a score group")
 
-    ch = channel[order]
+    ch = channel if presorted else channel[order]
     flags = np.zeros(n, dtype=np.uint8) if pool is None else pool.empty("cand:flags", (n,), np.uint8)
     flags[...] = 0
     if reference_channel >= 0 and n:
@@ -426,10 +446,11 @@ def assemble_candidates(
         has_ref[score_group_idx[ch == reference_channel]] = True
         flags[~has_ref[score_group_idx]] = _abi.FLAG_SKIP
 
+    prec_row = pos_c if lib_rows is None else lib_rows[pos_c]
     out = {
         "order": order,
         # row of every candidate in the caller's precursor table
-        "prec_row": (pos_c if lib_rows is None else lib_rows[pos_c])[order],
+        "prec_row": prec_row if presorted else prec_row[order],
         "score_group_idx": score_group_idx,
         "elution_group_idx": eg,
         "decoy": dc,
@@ -437,14 +458,13 @@ def assemble_candidates(
         "precursor_idx": pi,
         "rank": rk,
         "flags": flags,
-        "frag_start_idx": ordered("frag_start_idx", frag_start),
-        "frag_stop_idx": ordered("frag_stop_idx", frag_stop),
-        "charge": ordered("charge", charge),
-        "precursor_mz": ordered("precursor_mz", prec_mz),
-        "isotope_intensity": ordered("isotope_intensity", np.ascontiguousarray(iso)),
     }
-    for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center"):
-        out[c] = ordered(c, cols[c])
+    # the uploaded columns, in processing order (page-locked when a pool is given): side by side as well
+    moves = [("frag_start_idx", frag_start), ("frag_stop_idx", frag_stop), ("charge", charge), ("precursor_mz", prec_mz),
+             ("isotope_intensity", np.ascontiguousarray(iso))]
+    moves += [(c, cols[c]) for c in ("scan_start", "scan_stop", "scan_center", "frame_start", "frame_stop", "frame_center")]
+    for (name, _), arr in zip(moves, _parallel([(lambda m=m: ordered(*m)) for m in moves])):
+        out[name] = arr
     return out
 
 
@@ -487,6 +507,78 @@ def fragment_columns(fragments_flat: pd.DataFrame, fragment_mz_column: str) -> t
     )
 
 
+_HOST_POOL = None
+
+
+def _host_pool():
+    """Threads for the column gathers of ``collect_candidates`` / ``collect_fragments``: numpy releases the
+    GIL inside ``take`` / ``flatnonzero`` on plain dtypes, so the ~90 columns of the result frames are built
+    side by side.  Sized to the CPU quota of the container (at most 16), like the library's own host team."""
+    global _HOST_POOL
+    if _HOST_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = os.cpu_count() or 4
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period))))
+        except (OSError, ValueError):
+            pass
+        n = int(os.environ.get("ADH_HOST_THREADS", min(n, 16)))
+        _HOST_POOL = (ThreadPoolExecutor(max_workers=max(n, 1), thread_name_prefix="adh_collect"), max(n, 1))
+    return _HOST_POOL
+
+
+def _parallel(tasks):
+    """Run callables on the host pool; results in task order."""
+    pool, n = _host_pool()
+    if n == 1 or len(tasks) <= 1:
+        return [t() for t in tasks]
+    return [f.result() for f in [pool.submit(t) for t in tasks]]
+
+
+def _take_chunked(src: np.ndarray, idx: np.ndarray, parts: int) -> np.ndarray:
+    """``src[idx]`` along axis 0, as ``parts`` slices of idx gathered into one result."""
+    out = np.empty((len(idx),) + src.shape[1:], dtype=src.dtype)
+    if src.dtype == object or parts <= 1 or len(idx) < 65536:
+        np.take(src, idx, axis=0, out=out)
+        return out
+    cuts = np.linspace(0, len(idx), parts + 1).astype(np.int64)
+    _parallel([(lambda a=a, b=b: np.take(src, idx[a:b], axis=0, out=out[a:b])) for a, b in zip(cuts[:-1], cuts[1:])])
+    return out
+
+
+def _take_rows_transposed(src: np.ndarray, idx: np.ndarray, parts: int, block: int = 4096) -> np.ndarray:
+    """``src[idx].T`` of a row-major table as a C-contiguous [column][row] array (every column of the result is
+    contiguous): row blocks small enough for the cache are gathered and written transposed, slices of idx in
+    parallel."""
+    m, ncol = len(idx), src.shape[1]
+    out = np.empty((ncol, m), dtype=src.dtype)
+
+    def work(a, b):
+        for lo in range(a, b, block):
+            hi = min(lo + block, b)
+            out[:, lo:hi] = src[idx[lo:hi]].T
+
+    if parts <= 1 or m < 65536:
+        work(0, m)
+        return out
+    cuts = np.linspace(0, m, parts + 1).astype(np.int64)
+    _parallel([(lambda a=a, b=b: work(int(a), int(b))) for a, b in zip(cuts[:-1], cuts[1:])])
+    return out
+
+
+def _flatnonzero_chunked(mask_source: np.ndarray, parts: int) -> np.ndarray:
+    """``np.flatnonzero(mask_source > 0)`` of a flat array, chunk by chunk on the pool."""
+    n = len(mask_source)
+    if parts <= 1 or n < 1 << 20:
+        return np.flatnonzero(mask_source > 0)
+    cuts = np.linspace(0, n, parts + 1).astype(np.int64)
+    found = _parallel([(lambda a=a, b=b: np.flatnonzero(mask_source[a:b] > 0) + a) for a, b in zip(cuts[:-1], cuts[1:])])
+    return np.concatenate(found)
+
+
 def _take_missing_columns(left_df, right_df, right_columns, rows):
     """``merge_missing_columns`` when the matching right row of every left row is known already:
     same columns, order and dtypes as the left merge on a unique key, without the hash join."""
@@ -514,11 +606,6 @@ def collect_candidates(
     ``row_maps = (candidate_row, precursor_row)`` of every row of ``psm_proto_df`` (known from
     ``assemble_candidates``) replaces the two hash joins by gathers; ``sequence_counts`` are the
     per-precursor K / R / P counts (constant per library)."""
-    precursor_idx, rank, features = psm_proto_df.to_precursor_df()
-    df = pd.DataFrame(features, columns=DEFAULT_FEATURE_COLUMNS)
-    df["precursor_idx"] = precursor_idx
-    df["rank"] = rank
-
     candidate_columns = DEFAULT_CANDIDATE_COLUMNS.copy()
     candidate_columns += ["score"] if "score" in candidates_df.columns else []
     if "rank" not in candidates_df.columns:
@@ -530,22 +617,64 @@ def collect_candidates(
         if col not in precursor_df_columns:
             precursor_df_columns.append(col)
     if row_maps is not None:
-        v = np.asarray(psm_proto_df.valid, dtype=bool)
-        cand_rows, prec_rows = row_maps[0][v], row_maps[1][v]
-        df = _take_missing_columns(df, candidates_df, candidate_columns, cand_rows)
-        df = _take_missing_columns(df, precursors_flat_df, precursor_df_columns, prec_rows)
-    else:
-        df = merge_missing_columns(
-            df, candidates_df, candidate_columns, on=["precursor_idx", "rank"], how="left"
-        )
-        df = merge_missing_columns(
-            df, precursors_flat_df, precursor_df_columns, on=["precursor_idx"], how="left"
-        )
+        return _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df, rt_column, candidate_columns,
+                                           precursor_df_columns, row_maps, sequence_counts)
+    precursor_idx, rank, features = psm_proto_df.to_precursor_df()
+    df = pd.DataFrame(features, columns=DEFAULT_FEATURE_COLUMNS)
+    df["precursor_idx"] = precursor_idx
+    df["rank"] = rank
+    df = merge_missing_columns(
+        df, candidates_df, candidate_columns, on=["precursor_idx", "rank"], how="left"
+    )
+    df = merge_missing_columns(
+        df, precursors_flat_df, precursor_df_columns, on=["precursor_idx"], how="left"
+    )
     df["delta_rt"] = df["rt_observed"] - df[rt_column]
-    if row_maps is not None and sequence_counts is not None:
-        for name, counts in zip(("n_K", "n_R", "n_P"), sequence_counts, strict=True):
-            df[name] = counts[prec_rows]
-    else:
+    df["n_K"] = df["sequence"].str.count("K")
+    df["n_R"] = df["sequence"].str.count("R")
+    df["n_P"] = df["sequence"].str.count("P")
+    return df
+
+
+def _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df, rt_column, candidate_columns,
+                                precursor_df_columns, row_maps, sequence_counts) -> pd.DataFrame:
+    """``collect_candidates`` when the candidate row and the precursor row of every table row are known: the same
+    columns, order and dtypes as the two left merges on unique keys give, as gathers - one task per column on
+    the host pool, the 46-column feature block in row slices - and a frame assembled around those arrays
+    without another copy (pandas would otherwise re-stack the columns by dtype)."""
+    _, threads = _host_pool()
+    rows = np.flatnonzero(np.asarray(psm_proto_df.valid, dtype=bool))
+    cand_rows = np.asarray(row_maps[0]).take(rows)
+    prec_rows = np.asarray(row_maps[1]).take(rows)
+    names: list[str] = list(DEFAULT_FEATURE_COLUMNS)
+    jobs: list[tuple[str, np.ndarray, np.ndarray]] = [("precursor_idx", psm_proto_df.precursor_idx, rows),
+                                                      ("rank", psm_proto_df.rank, rows)]
+    have = set(names) | {"precursor_idx", "rank"}
+    for frame, wanted, idx in ((candidates_df, candidate_columns, cand_rows),
+                               (precursors_flat_df, precursor_df_columns, prec_rows)):
+        missing = [c for c in dict.fromkeys(wanted) if c not in have]
+        absent = [c for c in missing if c not in frame.columns]
+        if absent:
+            raise ValueError(f"Columns {absent} must be present in right_df")
+        for c in missing:
+            jobs.append((c, frame[c].values, idx))
+            have.add(c)
+    counts = None
+    if sequence_counts is not None:
+        counts = [(name, np.asarray(cnt), prec_rows) for name, cnt in zip(("n_K", "n_R", "n_P"), sequence_counts, strict=True)]
+    features = _take_rows_transposed(psm_proto_df.features, rows, threads)  # [feature][row]: contiguous columns
+    gathered = _parallel([(lambda src=src, idx=idx: src[idx]) for _, src, idx in jobs + (counts or [])])
+    cols = {name: arr for (name, _, _), arr in zip(jobs + (counts or []), gathered)}
+    frame = {name: features[j] for j, name in enumerate(DEFAULT_FEATURE_COLUMNS)}
+    frame.update({name: cols[name] for name, _, _ in jobs})
+    frame["delta_rt"] = frame["rt_observed"] - frame[rt_column]
+    if counts is not None:
+        for name, _, _ in counts:
+            frame[name] = cols[name]
+    # copy=False: every column stays the array built above (one block per column); the default would re-stack
+    # them by dtype - 0.5 s per million rows for nothing
+    df = pd.DataFrame(frame, copy=False)
+    if counts is None:
         df["n_K"] = df["sequence"].str.count("K")
         df["n_R"] = df["sequence"].str.count("R")
         df["n_P"] = df["sequence"].str.count("P")
@@ -555,14 +684,34 @@ def collect_candidates(
 def collect_fragments(psm_proto_df: OutputPsmDF, precursors_flat_df: pd.DataFrame, prec_rows=None) -> pd.DataFrame:
     """scoring.py:520-580; ``prec_rows`` (precursor row of every row of ``psm_proto_df``) replaces the
     hash join by a gather."""
-    idx = psm_proto_df.fragment_rows()
-    df = pd.DataFrame(dict(zip(FRAGMENT_DF_COLUMNS, psm_proto_df.to_fragment_df(idx), strict=True)))
     if prec_rows is None:
+        idx = psm_proto_df.fragment_rows()
+        df = pd.DataFrame(dict(zip(FRAGMENT_DF_COLUMNS, psm_proto_df.to_fragment_df(idx), strict=True)))
         return merge_missing_columns(
             df, precursors_flat_df, ["elution_group_idx", "decoy"], on=["precursor_idx"], how="left"
         )
-    rows = np.asarray(prec_rows).take(idx // psm_proto_df.fragment_mz_library.shape[1])
-    return _take_missing_columns(df, precursors_flat_df, ["elution_group_idx", "decoy"], rows)
+    # filled slots (output.py:89-97: fragment_mz_library > 0), then one gather per column on the host pool
+    _, threads = _host_pool()
+    top_k = psm_proto_df.fragment_mz_library.shape[1]
+    idx = _flatnonzero_chunked(psm_proto_df.fragment_mz_library.reshape(-1), threads)
+    sources = [getattr(psm_proto_df, "fragment_" + c).reshape(-1) for c in FRAGMENT_DF_COLUMNS]
+    missing = [c for c in ("elution_group_idx", "decoy") if c not in FRAGMENT_DF_COLUMNS]
+    absent = [c for c in missing if c not in precursors_flat_df.columns]
+    if absent:
+        raise ValueError(f"Columns {absent} must be present in right_df")
+    prec_rows = np.asarray(prec_rows)
+    lib_cols = [precursors_flat_df[c].values for c in missing]
+    # precursor row of every filled slot: slot -> candidate (a shift when top_k is a power of two) -> precursor
+    lib_rows = np.empty(len(idx), dtype=prec_rows.dtype)
+    cuts = np.linspace(0, len(idx), (threads if len(idx) > 1 << 20 else 1) + 1).astype(np.int64)
+
+    def slot_rows(a, b):
+        np.take(prec_rows, idx[a:b] // top_k, out=lib_rows[a:b])
+
+    gathered = _parallel([(lambda src=src: src.take(idx)) for src in sources] +
+                         [(lambda a=a, b=b: slot_rows(int(a), int(b))) for a, b in zip(cuts[:-1], cuts[1:])])[:len(sources)]
+    gathered += _parallel([(lambda col=col: col.take(lib_rows)) for col in lib_cols])
+    return pd.DataFrame(dict(zip(list(FRAGMENT_DF_COLUMNS) + missing, gathered, strict=True)), copy=False)
 
 
 def _jit_view(dia_data):
@@ -664,6 +813,9 @@ class HipCandidateScoring:
     ):
         del thread_count, include_decoy_fragment_features  # CPU-threading knobs of the reference
         logger.info("Starting candidate scoring")
+        import time
+
+        t_0 = time.perf_counter()
         soa = assemble_candidates(
             candidates_df,
             self.precursors_flat_df,
@@ -676,7 +828,9 @@ class HipCandidateScoring:
             keep = soa["score_group_idx"] < 10
             soa["flags"] = np.where(keep, soa["flags"], _abi.FLAG_SKIP).astype(np.uint8)
         # the frames below copy what they need out of the pooled page-locked tables
+        t_1 = time.perf_counter()
         psm_proto_df = self.score_soa(soa, reuse_buffers=True)
+        t_2 = time.perf_counter()
         logger.info("Collecting candidate features")
         features_df = collect_candidates(
             candidates_df,
@@ -688,8 +842,14 @@ class HipCandidateScoring:
             row_maps=(soa["order"], soa["prec_row"]),
             sequence_counts=self._sequence_counts(),
         )
+        t_3 = time.perf_counter()
         logger.info("Collecting fragment features")
         fragments_df = collect_fragments(psm_proto_df, self.precursors_flat_df, prec_rows=soa["prec_row"])
+        t_4 = time.perf_counter()
+        # wall time of the stages of this call, in ms (the reference logs them, scoring.py:634-661)
+        self.last_timings = {"assemble_ms": (t_1 - t_0) * 1e3, "score_ms": (t_2 - t_1) * 1e3,
+                             "collect_candidates_ms": (t_3 - t_2) * 1e3, "collect_fragments_ms": (t_4 - t_3) * 1e3,
+                             "total_ms": (t_4 - t_0) * 1e3}
         logger.info("Finished candidate scoring")
         return features_df, fragments_df
 

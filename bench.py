@@ -551,7 +551,13 @@ def main():
 
         t_legs = time.time()
         legs = {}
-        # free the headline's host arrays first (3.9 GB of peaks + page-locked tables)
+        try:  # the operator on the headline table (the run and the library are still staged)
+            legs["operator"] = bench_legs.operator_leg(case, cfg)
+            result["operator_ms"] = legs["operator"]["operator_ms"]
+        except Exception as exc:
+            legs["operator"] = {"skipped": f"{type(exc).__name__}: {exc}"[:300]}
+            log(f"[bench] leg operator skipped: {exc}")
+        # free the headline's host arrays (3.9 GB of peaks + page-locked tables) before the other legs
         del host, features_last, packed, soa, soa_all, per_cand_bytes, matched
         case = None
         for name, fn in (

@@ -105,6 +105,35 @@ def test_assemble_candidates_order_matches_reference():
     assert soa["isotope_intensity"].dtype == np.float32 and soa["frame_start"].dtype == np.int64
 
 
+@pytest.mark.parametrize("name, grouped", [("handler_default", False), ("multiplex", True)])
+def test_assemble_candidates_fast_paths_equal_the_general_one(name, grouped):
+    """A candidate table already in score-group order skips the sort, a library whose precursor_idx is its row
+    number skips the search: both must give the columns the general path gives (a shuffled table, a library
+    with a gap in its index)."""
+    g = H.load_scoring_golden(name)
+    pdf = g.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+    assert np.array_equal(pdf["precursor_idx"].values, np.arange(len(pdf)))  # the dense case
+    kw = dict(score_grouped=grouped, reference_channel=0 if grouped else -1)
+    ref = assemble_candidates(g.candidates_df.sample(frac=1.0, random_state=9).reset_index(drop=True), pdf, "mz_library", **kw)
+    in_order = g.candidates_df.iloc[np.lexsort((g.candidates_df["precursor_idx"].values, g.candidates_df["rank"].values,
+                                                pdf["decoy"].values[g.candidates_df["precursor_idx"].values],
+                                                g.candidates_df["elution_group_idx"].values))].reset_index(drop=True)
+    fast = assemble_candidates(in_order, pdf, "mz_library", **kw)
+    assert np.array_equal(fast["order"], np.arange(len(in_order)))
+    used = np.unique(g.candidates_df["precursor_idx"].values)
+    spare = np.setdiff1d(pdf["precursor_idx"].values, used)
+    gap = pdf[pdf["precursor_idx"].values != spare[0]].reset_index(drop=True) if len(spare) else pdf.iloc[::-1]
+    general = assemble_candidates(in_order, gap, "mz_library", **kw)
+    for k in ref:
+        if k in ("order", "prec_row"):
+            continue
+        assert np.array_equal(ref[k], fast[k]), k
+        assert np.array_equal(ref[k], general[k]), k
+        assert ref[k].dtype == fast[k].dtype == general[k].dtype, k
+    assert np.array_equal(pdf["precursor_idx"].values[fast["prec_row"]], fast["precursor_idx"])
+    assert np.array_equal(gap["precursor_idx"].values[general["prec_row"]], general["precursor_idx"])
+
+
 def test_assemble_candidates_errors_and_reference_channel():
     g = H.load_scoring_golden("handler_default")
     bad = g.candidates_df.copy()

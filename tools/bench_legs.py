@@ -217,6 +217,39 @@ def multiplex_leg(ctx, n_groups: int = 75_000, n_cycles: int = 4800, steps: int 
 
 
 # --------------------------------------------------------------------------------------------
+def operator_leg(case, cfg, reps: int = 3) -> dict:
+    """The plug-in operator itself: ``HipCandidateScoring.__call__`` from the candidate
+    DataFrame to ``(features_df, fragments_df)`` on the headline table - what every call site of the reference
+    enters through (scoring.py:582-661) - with the wall time of its stages."""
+    from alphadia_amd.scoring import HipCandidateScoring
+
+    scorer = HipCandidateScoring(dia_data=case.dia, precursors_flat=case.library.precursor_df,
+                                 fragments_flat=case.library.fragment_df, rt_column="rt_library",
+                                 mobility_column="mobility_library", precursor_mz_column="mz_library",
+                                 fragment_mz_column="mz_library", config=cfg, device=None)
+    runs = []
+    rows = (0, 0)
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        features_df, fragments_df = scorer(case.candidates_df)
+        wall = (time.perf_counter() - t0) * 1e3
+        runs.append(dict(scorer.last_timings, wall_ms=wall))
+        rows = (len(features_df), len(fragments_df))
+        cols = (features_df.shape[1], fragments_df.shape[1])
+        del features_df, fragments_df
+    best = min(runs[1:], key=lambda r: r["wall_ms"])
+    out = {"candidates": int(len(case.candidates_df)), "features_rows": rows[0], "fragments_rows": rows[1],
+           "features_columns": cols[0], "fragments_columns": cols[1],
+           "operator_ms": best["wall_ms"], "stages_ms": {k: v for k, v in best.items() if k != "wall_ms"},
+           "first_call_ms": runs[0]["wall_ms"], "all_calls_ms": [r["wall_ms"] for r in runs],
+           "region": "candidates_df -> assemble (lexsort, library lookup) -> adh_score_candidates -> features_df + "
+                     "fragments_df (valid rows / filled fragment slots gathered column by column)"}
+    _log(f"[bench] operator: {out['operator_ms']:.0f} ms for {out['candidates']} candidates "
+         f"({', '.join(f'{k} {v:.0f}' for k, v in out['stages_ms'].items())}); first call {out['first_call_ms']:.0f} ms")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 def timstof_leg(full_size: bool = True, timeout: float = 600.0) -> dict:
     """BASELINE configs[3] through tools/bench_timstof.py in a process of its own (its run, its 3 GB index
     and its scratch slab do not pile on top of the headline's)."""
