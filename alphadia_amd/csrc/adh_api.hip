@@ -27,6 +27,7 @@
 #include "adh_fused.hip"
 #include "adh_gather_im.hip"
 #include "adh_features_im.hip"
+#include "adh_features_im2.hip"
 #include "adh_fragcomp.hip"
 #include "adh_select.hip"
 #include "adh_select_im.hip"
@@ -263,6 +264,10 @@ int adh_create(adh_handle_t **handle, int device) {
     (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutCommon>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutSmall>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutCommon, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutSmall, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -174,6 +174,25 @@ __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, 
     return adh_im_tiles_end(k_cap, O, S, F, I, Op);
 }
 
+// Hand-over record of the split ion-mobility feature path (round 4): adh_feature_im_kernel<LAY, true> stops
+// after its passes over the tiles and leaves, per candidate, what the profile phase
+// (adh_features_im2.hip: four candidates per wavefront) needs - a few KB of profiles instead of the tile.
+// Rows are zero-padded to the capacities, the frame axis is stored CENTRED (entry r <-> cycle r - FM/2 + F/2),
+// so the reader takes whole rows with vector loads and constant register indices.
+#define ADH_IM_PROF_K 12
+template <int FM, int SM>
+struct __attribute__((aligned(16))) ImProfRec {
+    uint32_t K0, pad0[3];
+    double ohe[ADH_IM_PROF_K], omz[ADH_IM_PROF_K];  // weighted centre means of the (fragment, observation 0) planes
+    double hp[4], omzp[4];                          // ... of the isotope planes
+    float tsum, pad1[3];                            // template sum
+    float spi[4], iso_int[4], iso_mz[4];
+    float tfp_raw[FM];                              // template frame profile (sum over scans), centred
+    float tsp_raw[SM];                              // template scan profile (sum over cycles)
+    float ffp[ADH_IM_PROF_K][FM];                   // fragment frame profiles before the presence mask, centred
+    float fsp[ADH_IM_PROF_K][SM];                   // fragment scan profiles
+};
+
 // Barrier of a ONE-wavefront block whose lanes talk through LDS.  A wavefront issues its LDS
 // instructions in order and the LDS unit completes them in order, so a read that follows a write in
 // program order sees the write, whichever lane made it: nothing has to be waited for.  What is

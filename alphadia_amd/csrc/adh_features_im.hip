@@ -288,11 +288,14 @@ size_t adh_feature_im_lds_bytes(const Caps &c) {
                                           : featim::Layout(c).bytes();
 }
 
-template <class LAY>
+// SPLIT (round 4, fixed layouts only): the kernel ends after the passes over the tiles and writes the candidate's
+// ImProfRec<LAY::Fc, LAY::Sc> to `prof` (record blockIdx.x); adh_feature_im_profiles_kernel does the rest, four
+// candidates per wavefront.
+template <class LAY, bool SPLIT = false>
 __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
     int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
-    DevOut out, Caps caps) {
+    DevOut out, Caps caps, unsigned char *__restrict__ prof = nullptr) {
     using namespace featim;
     extern __shared__ __align__(16) unsigned char smem[];
     // ordered list of the non-zero cells of one 64-cell chunk (see the tile passes below)
@@ -741,6 +744,105 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     }
     adh_wave_sync();
     if (caps.stop_phase == 3) return;
+    // Dense-mode candidates (rare: a tile that had to be materialised): the isotope sums and centre means the
+    // sparse form gets from its precursor pass.  Independent of everything between here and its call.
+    auto dense_precursor_sums = [&]() {
+
+    for (int c = lane; c < I * S; c += ADH_WAVE) {
+        float sf = 0;
+        for (int f = 0; f < F; ++f) sf += prec_int(c / S, (c % S) * F + f);
+        work_b[c] = sf;
+    }
+    adh_wave_sync();
+    if (lane < I) {
+        float ss = 0;
+        for (int sc = 0; sc < S; ++sc) ss += work_b[lane * S + sc];
+        spi[lane] = ss;
+    }
+    // weighted centre means of the precursor planes around (scan, frame) = (S, 1)
+    // (precursor_features.py:52-66): float64 sums over the non-zero cells in (scan, frame) order.  The
+    // 64 lanes look at 64 cells at once, compact the non-zero ones in order into the chunk lists and
+    // lanes 0..3 fold one of the four sums each (intensity plane: values, weights; m/z plane: the same).
+    for (int i = 0; i < I; ++i) {
+        double acc = 0.0;
+        for (int base = 0; base < SF; base += ADH_WAVE) {
+            const int ci = base + lane;
+            const float2 pc = (ci < SF) ? prec_cell(i, ci) : make_float2(0.0f, 0.0f);
+            const float vi = pc.x, vm = pc.y;
+            const bool nz = vi > 0.0f || vm > 0.0f;
+            const unsigned long long mask = __ballot(nz);
+            if (mask == 0ull) continue;
+            if (nz) {
+                const int sc = ci / F, f = ci - sc * F;
+                const double ds = (double)(sc - S), df = (double)(f - 1);
+                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
+                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                l_w[pos] = w;
+                l_ti[pos] = (double)vi * w;
+                l_tm[pos] = (double)vm * w;
+                l_rx[pos] = vi;
+                l_ry[pos] = vm;
+            }
+            adh_wave_sync();
+            const int n_ent = __popcll(mask);
+            if (lane < 4) {
+                const float *flag = (lane < 2) ? l_rx : l_ry;
+                const double *src = (lane & 1) ? l_w : (lane == 0 ? l_ti : l_tm);
+                for (int e = 0; e < n_ent; ++e)
+                    if (flag[e] > 0.0f) acc += src[e];
+            }
+            adh_wave_sync();
+        }
+        const double vh = __shfl(acc, 0), wh = __shfl(acc, 1), vmz = __shfl(acc, 2), wmz = __shfl(acc, 3);
+        if (lane == 0) {
+            hp[i] = (wh > 0) ? vh / wh : 0.0;      // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
+            omzp[i] = (wmz > 0) ? vmz / wmz : 0.0;
+        }
+    }
+        };
+    if constexpr (SPLIT) {
+        if (!compact) {
+            dense_precursor_sums();
+            adh_wave_sync();
+        }
+        // ---- hand-over: profiles, template profiles and the per-plane means of this candidate
+        static_assert(LAY::Oc == 1 && LAY::Kc <= ADH_IM_PROF_K && LAY::Ic <= 4, "the split path is the one-observation shape");
+        typedef ImProfRec<LAY::Fc, LAY::Sc> Rec;
+        Rec &rec = reinterpret_cast<Rec *>(prof)[blockIdx.x];
+        constexpr int FMc = LAY::Fc, SMc = LAY::Sc;
+        const int shift = F / 2 - FMc / 2;  // entry r <-> cycle r + shift
+        // template frame profile: sums over the scans, in scan order (the monolithic kernel takes it below)
+        for (int rr = lane; rr < FMc; rr += ADH_WAVE) {
+            const int f = rr + shift;
+            rec.tfp_raw[rr] = (f >= 0 && f < F) ? osum<SR>(tpl + f, F, S) : 0.0f;
+        }
+        for (int sc = lane; sc < SMc; sc += ADH_WAVE) rec.tsp_raw[sc] = (sc < S) ? tsp_raw[sc] : 0.0f;
+        for (int c = lane; c < K0 * FMc; c += ADH_WAVE) {
+            const int k = c / FMc, rr = c - k * FMc, f = rr + shift;
+            rec.ffp[k][rr] = (f >= 0 && f < F) ? ffp_u[k * F + f] : 0.0f;
+        }
+        for (int c = lane; c < K0 * SMc; c += ADH_WAVE) {
+            const int k = c / SMc, sc = c - k * SMc;
+            rec.fsp[k][sc] = (sc < S) ? fsp_u[k * S + sc] : 0.0f;
+        }
+        if (lane < K0) {
+            rec.ohe[lane] = ohe_u[lane];
+            rec.omz[lane] = omz_u[lane];
+        }
+        if (lane < 4) {
+            const bool on = lane < I;
+            rec.hp[lane] = on ? hp[lane] : 0.0;
+            rec.omzp[lane] = on ? omzp[lane] : 0.0;
+            rec.spi[lane] = on ? spi[lane] : 0.0f;
+            rec.iso_int[lane] = on ? iso_int[lane] : 0.0f;
+            rec.iso_mz[lane] = on ? iso_mz[lane] : 0.0f;
+        }
+        if (lane == 0) {
+            rec.K0 = (uint32_t)K0;
+            rec.tsum = tsum[0];
+        }
+        return;
+    }
     for (int k = lane; k < K0; k += ADH_WAVE) {
         float so = 0;
         for (int o = 0; o < O; ++o) {
@@ -861,61 +963,8 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
 
     if (caps.stop_phase == 4) return;
     // =========================== features ===========================
-    // isotope intensity sums: per-scan sums in parallel, then in scan order (as for the template)
-    // (sparse form: done with the template above)
-    if (!compact) {
-    for (int c = lane; c < I * S; c += ADH_WAVE) {
-        float sf = 0;
-        for (int f = 0; f < F; ++f) sf += prec_int(c / S, (c % S) * F + f);
-        work_b[c] = sf;
-    }
-    adh_wave_sync();
-    if (lane < I) {
-        float ss = 0;
-        for (int sc = 0; sc < S; ++sc) ss += work_b[lane * S + sc];
-        spi[lane] = ss;
-    }
-    // weighted centre means of the precursor planes around (scan, frame) = (S, 1)
-    // (precursor_features.py:52-66): float64 sums over the non-zero cells in (scan, frame) order.  The
-    // 64 lanes look at 64 cells at once, compact the non-zero ones in order into the chunk lists and
-    // lanes 0..3 fold one of the four sums each (intensity plane: values, weights; m/z plane: the same).
-    for (int i = 0; i < I; ++i) {
-        double acc = 0.0;
-        for (int base = 0; base < SF; base += ADH_WAVE) {
-            const int ci = base + lane;
-            const float2 pc = (ci < SF) ? prec_cell(i, ci) : make_float2(0.0f, 0.0f);
-            const float vi = pc.x, vm = pc.y;
-            const bool nz = vi > 0.0f || vm > 0.0f;
-            const unsigned long long mask = __ballot(nz);
-            if (mask == 0ull) continue;
-            if (nz) {
-                const int sc = ci / F, f = ci - sc * F;
-                const double ds = (double)(sc - S), df = (double)(f - 1);
-                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-                l_w[pos] = w;
-                l_ti[pos] = (double)vi * w;
-                l_tm[pos] = (double)vm * w;
-                l_rx[pos] = vi;
-                l_ry[pos] = vm;
-            }
-            adh_wave_sync();
-            const int n_ent = __popcll(mask);
-            if (lane < 4) {
-                const float *flag = (lane < 2) ? l_rx : l_ry;
-                const double *src = (lane & 1) ? l_w : (lane == 0 ? l_ti : l_tm);
-                for (int e = 0; e < n_ent; ++e)
-                    if (flag[e] > 0.0f) acc += src[e];
-            }
-            adh_wave_sync();
-        }
-        const double vh = __shfl(acc, 0), wh = __shfl(acc, 1), vmz = __shfl(acc, 2), wmz = __shfl(acc, 3);
-        if (lane == 0) {
-            hp[i] = (wh > 0) ? vh / wh : 0.0;      // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
-            omzp[i] = (wmz > 0) ? vmz / wmz : 0.0;
-        }
-    }
-    }
+    // isotope intensity sums / centre means of a dense-mode candidate (sparse form: done with the template above)
+    if (!compact) dense_precursor_sums();
     adh_wave_sync();
 
     double *const mzmean = D + lay.d_pk();

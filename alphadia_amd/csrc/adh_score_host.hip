@@ -481,7 +481,34 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                  p.caps_all.k, p.caps_all.o, p.caps_all.s, p.caps_all.f);
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
-    int rc = ensure_scratch(h, p.scratch_bytes);
+    // Split feature path (adh_features_im2.hip): the one-observation classes with a fixed layout leave a profile
+    // record per candidate behind the scratch blocks, and a second kernel with four candidates per wavefront
+    // finishes them.  ADH_DEBUG_IM_NO_SPLIT=1: the one-kernel path for everything (the GPU suite holds both to
+    // identical bits); the developer ablations (ADH_DEBUG_IM stops, layout switch) belong to the one-kernel path.
+    const int32_t n_iso = h->cs.n_iso_cols;
+    const bool fixed_layouts = !getenv("ADH_DEBUG_IM_DYNAMIC_LAYOUT");
+    const bool split_cfg = fixed_layouts && cfg->experimental_xic && (p.caps_all.stop_phase == 0 || p.caps_all.stop_phase == 8) &&
+                           !getenv("ADH_DEBUG_IM_NO_SPLIT") &&  // (8: the gather's dense-tiles switch, no feature-kernel stop)
+                           std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)n_iso) <= 3;
+    auto class_caps = [&](int c) {
+        Caps cc = p.caps_all;
+        if (c == 0 || c == ADH_CLASS_IM_SMALL) cc.o = 1;
+        if (c == 1) cc.o = std::min(cc.o, 2);
+        if (c == ADH_CLASS_IM_SMALL) {  // (what the plan admitted to the class: adh_plan_rec_im_kernel)
+            cc.k = std::min(cc.k, ADH_IM_SMALL_K);
+            cc.s = std::min(cc.s, ADH_IM_SMALL_S);
+            cc.f = std::min(cc.f, ADH_IM_SMALL_F);
+        }
+        return cc;
+    };
+    typedef ImProfRec<featim::DimsCommon::Fc, featim::DimsCommon::Sc> ProfCommon;
+    typedef ImProfRec<featim::DimsSmall::Fc, featim::DimsSmall::Sc> ProfSmall;
+    const bool split_small = split_cfg && p.n_class[ADH_CLASS_IM_SMALL] > 0 && featim::DimsSmall::holds_axes(class_caps(ADH_CLASS_IM_SMALL));
+    const bool split_common = split_cfg && p.n_class[0] > 0 && featim::DimsCommon::holds(class_caps(0)) && class_caps(0).f >= 3;
+    const uint64_t prof_base = (p.scratch_bytes + 255) / 256 * 256;
+    const uint64_t prof_small_off = prof_base + (split_common ? (uint64_t)p.n_class[0] * sizeof(ProfCommon) : 0);
+    const uint64_t prof_bytes = prof_small_off + (split_small ? (uint64_t)p.n_class[ADH_CLASS_IM_SMALL] * sizeof(ProfSmall) : 0);
+    int rc = ensure_scratch(h, prof_bytes);
     if (rc != ADH_OK) return rc;
     unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
     adh_handle::Timed t;
@@ -489,7 +516,6 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     if (rc == ADH_OK) rc = get_event(h, &t.e1);
     if (rc == ADH_OK) rc = get_event(h, &t.e2);
     if (rc != ADH_OK) return rc;
-    const int32_t n_iso = h->cs.n_iso_cols;
     HIP_TRY(hipEventRecord(t.e0, st));
     hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, h->tims, h->d_lib,
                        p.d_recs_im, *cfg, n_iso, d_scratch, *out, p.caps_all);
@@ -501,18 +527,28 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
         for (int c = 0; c < ADH_N_CLASSES; ++c) {
             const int64_t cnt = p.n_class[c];
             if (cnt > 0) {
-                Caps cc = p.caps_all;
-                if (c == 0 || c == ADH_CLASS_IM_SMALL) cc.o = 1;
-                if (c == 1) cc.o = std::min(cc.o, 2);
-                if (c == ADH_CLASS_IM_SMALL) {  // (what the plan admitted to the class: adh_plan_rec_im_kernel)
-                    cc.k = std::min(cc.k, ADH_IM_SMALL_K);
-                    cc.s = std::min(cc.s, ADH_IM_SMALL_S);
-                    cc.f = std::min(cc.f, ADH_IM_SMALL_F);
-                }
+                const Caps cc = class_caps(c);
                 // (capacities fixed at compile time for the common shape: adh_features_im.hip, DimsFix)
-                const bool fixed_ok = !getenv("ADH_DEBUG_IM_DYNAMIC_LAYOUT");
+                const bool fixed_ok = fixed_layouts;
                 const bool common = featim::DimsCommon::holds(cc) && fixed_ok;
-                if (c == ADH_CLASS_IM_SMALL && featim::DimsSmall::holds_axes(cc) && fixed_ok)
+                const unsigned groups = (unsigned)((cnt + ADH_WAVE / 16 - 1) / (ADH_WAVE / 16));
+                if (c == ADH_CLASS_IM_SMALL && split_small) {
+                    unsigned char *prof = d_scratch + prof_small_off;
+                    hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutSmall, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                       *cfg, d_scratch, *out, cc, prof);
+                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), dim3(groups),
+                                       dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, *cfg, n_iso, d_scratch,
+                                       prof, *out);
+                } else if (c == 0 && split_common) {
+                    unsigned char *prof = d_scratch + prof_base;
+                    hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                       *cfg, d_scratch, *out, cc, prof);
+                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), dim3(groups),
+                                       dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, *cfg, n_iso, d_scratch,
+                                       prof, *out);
+                } else if (c == ADH_CLASS_IM_SMALL && featim::DimsSmall::holds_axes(cc) && fixed_ok)
                     hipLaunchKernelGGL(adh_feature_im_kernel<featim::LayoutSmall>, dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc);

@@ -610,6 +610,38 @@ def test_timstof_larger_case_all_configs(ctx, oracle_lib):
         assert got["valid"].sum() > 100
 
 
+@pytest.mark.parametrize("quant_all", [True, False])
+@pytest.mark.parametrize("shape", ["small_tiles", "larger_tiles", "dense_tiles"])
+def test_timstof_split_feature_path_equals_the_one_kernel_path(ctx, oracle_lib, monkeypatch, shape, quant_all):
+    """Round 4 splits the ion-mobility feature kernel after its passes over the tiles; the profile phase runs
+    four candidates per wavefront from a few KB of profiles per candidate (adh_features_im2.hip).  Same numbers,
+    bit for bit, as the one-kernel path (ADH_DEBUG_IM_NO_SPLIT=1) - for the small-tile class, the common class
+    and candidates whose tiles were materialised - and equal to the oracle."""
+    from alphadia_amd.scoring import assemble_candidates
+
+    kw = dict(small_tiles=dict(scan_max_index=64, n_cycles=70), larger_tiles=dict(scan_max_index=96, n_cycles=90, h_range=(8, 14), hs_range=(14, 19)),
+              dense_tiles=dict(scan_max_index=64, n_cycles=70))[shape]
+    case = syn.make_timstof_case(n_precursors=260, config_id=47, per_precursor=2, n_ms2_frames=5, windows_per_frame=2,
+                                 planted_fraction=0.6, **kw)
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library")
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(top_k_isotopes=3, quant_all=quant_all, experimental_xic=True))
+    with monkeypatch.context() as mp:
+        if shape == "dense_tiles":
+            mp.setenv("ADH_DEBUG_IM", "8")  # (the gather kernel materialises every tile)
+        split = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
+        split = {k: np.array(v, copy=True) for k, v in split.items()}
+        mp.setenv("ADH_DEBUG_IM_NO_SPLIT", "1")
+        one = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
+    for name, ref in one.items():
+        assert np.array_equal(np.asarray(split[name]), np.asarray(ref), equal_nan=np.asarray(ref).dtype.kind == "f"), name
+    exp = oracle_lib.score_timstof(case.dia, fragment_columns(case.library.fragment_df, "mz_library"),
+                                   pack_assembled(soa), cfg.to_jitclass(), n_threads=8, with_stats=True)
+    compare(split, exp, PPM_ABS_TOL_ORACLE)
+    v = split["valid"].astype(bool)
+    assert v.sum() > 80 and (split["features"][v][:, 29] != 0).sum() > 30
+
+
 def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     """The staged search indices (m/z lookup table, (TOF bin, cycle) table - one column per cycle or per
     block of cycles), the two forms of the tiles (sparse entry lists, dense tiles), the two forms of the
@@ -626,8 +658,10 @@ def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     base = _hip_score_tims(ctx, case.dia, case.library.fragment_df, soa, cfg, with_stats=True)
     base = {k: np.array(v, copy=True) for k, v in base.items()}
     assert base["valid"].sum() > 100
+    # ADH_DEBUG_IM_NO_SPLIT: the one-kernel feature path against the split one of round 4 (tile passes, then the
+    # profile phase with four candidates per wavefront, adh_features_im2.hip), which is the default `base` ran
     for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8"),
-                dict(ADH_DEBUG_IM="21"), dict(ADH_DEBUG_IM_DYNAMIC_LAYOUT="1")):
+                dict(ADH_DEBUG_IM="21"), dict(ADH_DEBUG_IM_DYNAMIC_LAYOUT="1"), dict(ADH_DEBUG_IM_NO_SPLIT="1")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
