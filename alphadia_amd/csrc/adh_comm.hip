@@ -252,6 +252,46 @@ int adh_comm_all_reduce_max(adh_handle_t *h, double *value) {
     return ADH_OK;
 }
 
+// Every rank contributes `bytes` bytes of a host buffer and receives world x bytes, rank after rank: the
+// exchange of the two other stages that shard (candidate selection by precursor range, fragment competition by
+// DIA window) - one gather of small per-rank results, staged through HBM so that it travels over xGMI like the
+// tables do.  Without a communicator the buffer is its own gather.
+int adh_comm_all_gather_host(adh_handle_t *h, const void *send, uint64_t bytes, void *recv) {
+    if (!h || (bytes > 0 && (!send || !recv))) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    adh_comm_state *c = h->comm;
+    if (!c) {
+        if (bytes > 0 && recv != send) memmove(recv, send, (size_t)bytes);
+        return ADH_OK;
+    }
+    if (bytes == 0) return ADH_OK;  // (every rank passes the same count: nothing to wait for)
+    HIP_TRY(hipSetDevice(h->device));
+    void *d_send = nullptr, *d_recv = nullptr;
+    HIP_TRY(hipMalloc(&d_send, (size_t)bytes));
+    hipError_t e = hipMalloc(&d_recv, (size_t)bytes * (size_t)c->world);
+    if (e != hipSuccess) {
+        (void)hipFree(d_send);
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP, std::string("all-gather staging: ") + hipGetErrorString(e));
+    }
+    int rc = ADH_OK;
+    e = hipMemcpyAsync(d_send, send, (size_t)bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const ncclResult_t r = c->AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, c->stream);
+        if (r != ncclSuccess) rc = fail(ADH_ERR_HIP, std::string("ncclAllGather: ") + c->GetErrorString(r));
+    }
+    if (e == hipSuccess && rc == ADH_OK)
+        e = hipMemcpyAsync(recv, d_recv, (size_t)bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == ADH_OK) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_send);
+    (void)hipFree(d_recv);
+    if (rc == ADH_OK && e != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail(ADH_ERR_HIP, std::string("all-gather: ") + hipGetErrorString(e));
+    }
+    return rc;
+}
+
 int adh_comm_barrier(adh_handle_t *h) {
     double v = 0.0;
     return adh_comm_all_reduce_max(h, &v);

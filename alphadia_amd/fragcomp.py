@@ -92,15 +92,54 @@ def competition_plan(precursor_idx, rank, mz_observed, proba, frag_precursor_idx
                            window_start=first.astype(np.int64), window_stop=stop.astype(np.int64))
 
 
+def compete_sharded(plan: CompetitionPlan, rt, fragment_mz, rt_tol_seconds, mass_tol_ppm, rank: int, world: int,
+                    compete, gather_rows) -> np.ndarray:
+    """The competition of one run on ``world`` GPUs: DIA windows are independent (fragcomp.py:204-229,278 gives
+    every window to its own thread), so rank r competes in the windows ``window_owner == r`` and ONE gather of
+    the flags of everybody's own rows puts the column together on every rank.
+
+    ``compete(window_start, window_stop, rt, frag_start, frag_stop, fragment_mz, rt_tol, mass_tol)`` -> bool per
+    processed row (rows outside the given windows come back True); ``gather_rows(local, rows_per_rank)`` ->
+    concatenation in rank order (``runtime.Context.all_gather_rows``; the CPU tests pass the gloo transport)."""
+    from alphadia_amd.distributed import window_owner
+
+    n_win = len(plan.window_start)
+    if world <= 1 or n_win == 0:
+        return compete(plan.window_start, plan.window_stop, rt, plan.frag_start, plan.frag_stop, fragment_mz,
+                       rt_tol_seconds, mass_tol_ppm)
+    owner = window_owner(n_win, world)
+    mine = np.flatnonzero(owner == rank)
+    valid = compete(plan.window_start[mine], plan.window_stop[mine], rt, plan.frag_start, plan.frag_stop, fragment_mz,
+                    rt_tol_seconds, mass_tol_ppm)
+    # what travels: the flags of the rows of a rank's own windows, window after window
+    sizes = (plan.window_stop - plan.window_start).astype(np.int64)
+    rows_per_rank = [int(sizes[owner == r].sum()) for r in range(world)]
+    local = np.concatenate([valid[plan.window_start[w]:plan.window_stop[w]] for w in mine]) if len(mine) else np.zeros(0, bool)
+    flat = gather_rows(np.ascontiguousarray(local, dtype=np.uint8), rows_per_rank).astype(bool)
+    out = np.ones(len(plan.rows), dtype=bool)
+    at = 0
+    for r in range(world):
+        for w in np.flatnonzero(owner == r):
+            n = int(sizes[w])
+            out[plan.window_start[w]:plan.window_stop[w]] = flat[at:at + n]
+            at += n
+    return out
+
+
 class FragmentCompetition:
-    """Remove PSMs that share fragments with better PSMs (GPU implementation)."""
+    """Remove PSMs that share fragments with better PSMs (GPU implementation).
+
+    ``rank`` / ``world`` (default: the communicator attached to the context, i.e. one rank without one): with
+    several ranks every rank competes in its own DIA windows and the flags are gathered once
+    (:func:`compete_sharded`); every rank returns the complete frame."""
 
     def __init__(self, rt_tol_seconds: int = 3, mass_tol_ppm: int = 15, thread_count: int = 8,
-                 device: int | None = None):
+                 device: int | None = None, rank: int | None = None, world: int | None = None):
         self.rt_tol_seconds = rt_tol_seconds
         self.mass_tol_ppm = mass_tol_ppm
         self.thread_count = thread_count  # CPU knob of the reference; unused on the GPU
         self.device = device
+        self.rank, self.world = rank, world
 
     def __call__(self, psm_df: pd.DataFrame, frag_df: pd.DataFrame, cycle: np.ndarray) -> pd.DataFrame:
         from alphadia_amd import runtime  # raises when the HIP library is missing
@@ -110,11 +149,12 @@ class FragmentCompetition:
             psm_df["proba"].values, frag_df["precursor_idx"].values, frag_df["rank"].values, cycle,
         )
         ctx = runtime.get_context(self.device)
-        valid = ctx.fragcomp(
-            plan.window_start, plan.window_stop, psm_df["rt_observed"].values[plan.rows],
-            plan.frag_start, plan.frag_stop, frag_df["mz_observed"].values,
-            self.rt_tol_seconds, self.mass_tol_ppm,
-        )
+        rank, world = ctx.comm_info() if self.world is None else (int(self.rank or 0), int(self.world))
+        if world > 1 and ctx.comm_info()[1] != world:
+            raise runtime.HipBackendError(f"FragmentCompetition(world={world}) needs a communicator of {world} ranks "
+                                          "on the context (Context.comm_init)")
+        valid = compete_sharded(plan, psm_df["rt_observed"].values[plan.rows], frag_df["mz_observed"].values,
+                                self.rt_tol_seconds, self.mass_tol_ppm, rank, world, ctx.fragcomp, ctx.all_gather_rows)
         # the frame the reference returns: surviving rows in processing order, with the candidate
         # key and the (all-true) flag column it leaves behind (fragcomp.py:291-299)
         out = psm_df.iloc[plan.rows[valid]].copy()

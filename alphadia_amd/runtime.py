@@ -64,6 +64,7 @@ EXPORTED_SYMBOLS = [
     "adh_comm_gathered",
     "adh_comm_all_reduce_max",
     "adh_comm_barrier",
+    "adh_comm_all_gather_host",
     "adh_comm_info",
     "adh_table_layout",
     "adh_device_synchronize",
@@ -295,6 +296,7 @@ class Context:
         if result[0] != 0:
             raise HipBackendError(f"adh_comm_init failed ({result[0]}): {result[1]}")
         self.comm_rank, self.comm_world = int(rank), int(world)
+        self._comm_attached = True
         if unique_id is None and rank == 0:
             # communicator creation is collective: every rank has read the id by now
             try:
@@ -305,12 +307,34 @@ class Context:
     def comm_destroy(self) -> None:
         _check(lib.adh_comm_destroy(self._h), "adh_comm_destroy")
         self.comm_rank, self.comm_world = 0, 1
+        self._comm_attached = False
 
     def comm_wait(self) -> None:
         _check(lib.adh_comm_wait(self._h), "adh_comm_wait")
 
     def barrier(self) -> None:
         _check(lib.adh_comm_barrier(self._h), "adh_comm_barrier")
+
+    def all_gather_rows(self, local: np.ndarray, rows_per_rank: list[int]) -> np.ndarray:
+        """Concatenation, in rank order, of every rank's ``local`` array (``rows_per_rank[r]`` rows on rank r,
+        equal trailing shape and dtype): ``adh_comm_all_gather_host`` with the shards padded to the longest
+        one.  With one rank (no communicator) the array comes back as it is."""
+        rank, world = self.comm_info()
+        if len(rows_per_rank) != world:
+            raise ValueError(f"rows_per_rank has {len(rows_per_rank)} entries for {world} ranks")
+        local = np.ascontiguousarray(local)
+        if local.shape[0] != rows_per_rank[rank]:
+            raise ValueError(f"rank {rank} holds {local.shape[0]} rows, rows_per_rank says {rows_per_rank[rank]}")
+        if world == 1 and not getattr(self, "_comm_attached", False):
+            return local
+        cap = max(int(r) for r in rows_per_rank)
+        row_bytes = int(np.prod(local.shape[1:], dtype=np.int64)) * local.dtype.itemsize
+        send = np.zeros((cap,) + local.shape[1:], dtype=local.dtype)
+        send[: local.shape[0]] = local
+        recv = np.empty((world, cap) + local.shape[1:], dtype=local.dtype)
+        _check(lib.adh_comm_all_gather_host(self._h, send.ctypes.data_as(C.c_void_p), C.c_uint64(cap * row_bytes),
+                                            recv.ctypes.data_as(C.c_void_p)), "adh_comm_all_gather_host")
+        return np.concatenate([recv[r, : int(rows_per_rank[r])] for r in range(world)], axis=0)
 
     def all_reduce_max(self, value: float) -> float:
         v = C.c_double(float(value))

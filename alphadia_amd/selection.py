@@ -95,11 +95,31 @@ def isotope_columns(columns) -> list:
     return [f"i_{i}" for i in sorted(found)]
 
 
+def select_sharded(n_precursors: int, candidate_count: int, rank: int, world: int, select, gather_rows) -> dict:
+    """Candidate selection of one run on ``world`` GPUs: precursors are independent (selection.py:620-660 hands
+    them to threads one by one), so rank r selects for the range ``precursor_bounds(n, r, world)`` of the table
+    sorted by precursor_idx and the candidate columns - ``candidate_count`` rows per precursor - are gathered
+    once, in rank order = precursor order: every rank ends with the table one GPU would have produced.
+
+    ``select(a, b)`` -> the candidate columns of precursors [a, b); ``gather_rows(local, rows_per_rank)`` ->
+    concatenation in rank order (``runtime.Context.all_gather_rows``; the CPU tests pass the gloo transport)."""
+    from alphadia_amd.distributed import precursor_bounds
+
+    if world <= 1:
+        return select(0, n_precursors)
+    a, b = precursor_bounds(n_precursors, rank, world)
+    local = select(a, b)
+    rows = [(precursor_bounds(n_precursors, r, world)[1] - precursor_bounds(n_precursors, r, world)[0]) * candidate_count
+            for r in range(world)]
+    return {k: gather_rows(np.ascontiguousarray(v), rows) for k, v in local.items()}
+
+
 class HipCandidateSelection:
     def __init__(self, dia_data, precursors_flat: pd.DataFrame, fragments_flat: pd.DataFrame,
                  config: CandidateSelectionConfig, rt_column: str, mobility_column: str,
                  precursor_mz_column: str, fragment_mz_column: str, fwhm_rt: float = 5.0,
-                 fwhm_mobility: float = 0.012, device: int | None = None) -> None:
+                 fwhm_mobility: float = 0.012, device: int | None = None, rank: int | None = None,
+                 world: int | None = None) -> None:
         self.dia_data = dia_data.to_jitclass() if hasattr(dia_data, "to_jitclass") else dia_data
         self.precursors_flat = precursors_flat.sort_values("precursor_idx").reset_index(drop=True)
         self.fragments_flat = fragments_flat
@@ -113,9 +133,12 @@ class HipCandidateSelection:
                                       self.config_jit.kernel_size, fwhm_mobility,
                                       self.config_jit.sigma_scale_mobility)
         self._device = device
+        # several GPUs: every rank selects for its own contiguous range of the precursor table and the candidate
+        # columns are gathered once (default: the communicator attached to the context)
+        self.rank, self.world = rank, world
 
-    def _pack_precursors(self) -> _abi.Marshalled:
-        df = self.precursors_flat
+    def _pack_precursors(self, a: int = 0, b: int | None = None) -> _abi.Marshalled:
+        df = self.precursors_flat if (a == 0 and b is None) else self.precursors_flat.iloc[a:b]
         iso = df[isotope_columns(df.columns)].values
         return _abi.pack_precursors(
             df["precursor_idx"].values, df["flat_frag_start_idx"].values, df["flat_frag_stop_idx"].values,
@@ -131,7 +154,13 @@ class HipCandidateSelection:
         if "cardinality" not in self.fragments_flat.columns:
             self.fragments_flat["cardinality"] = np.ones(len(self.fragments_flat), dtype=np.uint8)
         ctx.stage_fragments(*fragment_columns(self.fragments_flat, self.fragment_mz_column))
-        arrays = ctx.select_candidates(self._pack_precursors(), self.config_jit, self.kernel)
+        rank, world = ctx.comm_info() if self.world is None else (int(self.rank or 0), int(self.world))
+        if world > 1 and ctx.comm_info()[1] != world:
+            raise runtime.HipBackendError(f"HipCandidateSelection(world={world}) needs a communicator of {world} ranks "
+                                          "on the context (Context.comm_init)")
+        arrays = select_sharded(len(self.precursors_flat), int(self.config_jit.candidate_count), rank, world,
+                                lambda a, b: ctx.select_candidates(self._pack_precursors(a, b), self.config_jit, self.kernel),
+                                ctx.all_gather_rows)
         keep = arrays["score"] > 0  # candidate_container_to_df (config_df.py:270-298)
         candidate_df = pd.DataFrame({c: arrays[c][keep] for c in CANDIDATE_COLUMNS})
         return candidate_df.merge(

@@ -325,6 +325,13 @@ int adh_comm_gathered(adh_handle_t *handle, int rank, adh_output_t *device_view,
 /* max over ranks of *value (in place); also the barrier of the benchmark.  No-op without a communicator. */
 int adh_comm_all_reduce_max(adh_handle_t *handle, double *value);
 int adh_comm_barrier(adh_handle_t *handle);
+/* Every rank passes `bytes` bytes of host memory (the same count on all ranks) and receives world x bytes in
+ * rank order (recv holds world x bytes; without a communicator recv = send).  The exchange of the two other
+ * stages of the path that shard without touching each other's rows - candidate selection by precursor range
+ * (selection.py:620-660) and fragment competition by DIA window (fragcomp/fragcomp.py:204-229,278): one gather
+ * of the per-rank results (alphadia_amd/selection.py, alphadia_amd/fragcomp.py).  The reference runs both on
+ * the threads of one process and has no counterpart. */
+int adh_comm_all_gather_host(adh_handle_t *handle, const void *send, uint64_t bytes, void *recv);
 /* What RCCL itself reports for the attached communicator (ncclCommUserRank / ncclCommCount): rank 0 of 1
  * without one.  bench.py prints it, so that a run on N GPUs shows that N ranks met. */
 int adh_comm_info(adh_handle_t *handle, int *rank, int *world);

@@ -110,13 +110,15 @@ def _select_worker(rank, world, port, tmpdir):
     z, dia, fdf, pdf = TS._load()
     pdf = pdf.sort_values("precursor_idx").reset_index(drop=True)
     cfg = TS._cfg(z, "default")
-    a, b = precursor_bounds(len(pdf), rank, world)
-    local = oracle.select(dia, fragment_columns(fdf, "mz_library"), TS._pack(pdf.iloc[a:b]), cfg,
-                          z["default_kernel"], n_threads=2)
-    cc = int(cfg.candidate_count)
-    rows = [(precursor_bounds(len(pdf), r, world)[1] - precursor_bounds(len(pdf), r, world)[0]) * cc
-            for r in range(world)]
-    merged = {k: all_gather_rows(v, rows) for k, v in local.items()}
+    # the product's sharding (alphadia_amd/selection.py::select_sharded, what HipCandidateSelection runs with a
+    # communicator) with the oracle as the per-rank selection and gloo as the gather
+    from alphadia_amd.selection import select_sharded
+
+    merged = select_sharded(
+        len(pdf), int(cfg.candidate_count), rank, world,
+        lambda a, b: oracle.select(dia, fragment_columns(fdf, "mz_library"), TS._pack(pdf.iloc[a:b]), cfg,
+                                   z["default_kernel"], n_threads=2),
+        all_gather_rows)
     np.savez(os.path.join(tmpdir, f"sel{rank}.npz"), **merged)
     dist.destroy_process_group()
 
@@ -249,3 +251,51 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
     finally:
         os.environ.pop("LOCAL_WORLD_SIZE", None)
         os.environ.pop("ADH_RUN_NONCE", None)
+
+
+def _fragcomp_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pandas as pd
+
+    from alphadia_amd.fragcomp import compete_sharded, competition_plan
+    from oracle import oracle
+
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    plan = competition_plan(psm["precursor_idx"].values, psm["rank"].values, psm["mz_observed"].values, psm["proba"].values,
+                            frag["precursor_idx"].values, frag["rank"].values, z["cycle"])
+    # the product's sharding (what FragmentCompetition runs with a communicator): the oracle competes in this
+    # rank's windows, gloo gathers the flags
+    valid = compete_sharded(plan, psm["rt_observed"].values[plan.rows], frag["mz_observed"].values, 3, 15, rank, world,
+                            lambda *a: oracle.fragcomp(*a, n_threads=2), all_gather_rows)
+    np.savez(os.path.join(tmpdir, f"fc{rank}.npz"), valid=valid, rows=plan.rows)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fragment_competition_sharded_by_window(tmp_path, oracle_lib, world):
+    """Fragment competition with the DIA windows dealt over the ranks + one gather of the flags == the
+    competition on one rank == the reference's survivors (golden fragcomp.npz)."""
+    import pandas as pd
+
+    from alphadia_amd.fragcomp import competition_plan
+
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_fragcomp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    plan = competition_plan(psm["precursor_idx"].values, psm["rank"].values, psm["mz_observed"].values, psm["proba"].values,
+                            frag["precursor_idx"].values, frag["rank"].values, z["cycle"])
+    one = oracle_lib.fragcomp(plan.window_start, plan.window_stop, psm["rt_observed"].values[plan.rows], plan.frag_start,
+                              plan.frag_stop, frag["mz_observed"].values, 3, 15, n_threads=2)
+    assert len(plan.window_start) > world and 0 < one.sum() < len(one)
+    for r in range(world):
+        got = np.load(tmp_path / f"fc{r}.npz")
+        assert np.array_equal(got["valid"], one), r
+        survivors = psm.iloc[got["rows"][got["valid"]]]
+        assert np.array_equal(survivors["precursor_idx"].values, z["surviving_precursor_idx"])

@@ -153,6 +153,48 @@ def test_tables_stay_in_hbm_and_gather_with_one_rank(ctx, case):
     _same(full, host, names=H.OUT_NAMES)
 
 
+def test_selection_and_fragment_competition_under_a_communicator(ctx, case):
+    """The two other stages that shard - candidate selection by precursor range, fragment competition by DIA
+    window - take their rank and world from the communicator on the context and exchange their results through
+    `adh_comm_all_gather_host`.  With a one-rank RCCL communicator (what a single GPU offers) the exchange runs
+    for real and both operators must return what they return without one; the row partitions themselves are
+    covered at world 2 and 3 over gloo (tests/test_distributed_cpu.py)."""
+    import pandas as pd
+
+    from alphadia_amd import runtime
+    from alphadia_amd.fragcomp import FragmentCompetition
+    from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelection
+
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    scfg = CandidateSelectionConfig()
+    scfg.update(dict(rt_tolerance=60.0, candidate_count=2))
+    names = dict(rt_column="rt_library", mobility_column="mobility_library", precursor_mz_column="mz_library",
+                 fragment_mz_column="mz_library")
+    selector = HipCandidateSelection(case.dia, case.library.precursor_df, case.library.fragment_df, scfg, device=0, **names)
+    plain_sel = selector()
+    plain_fc = FragmentCompetition(device=0)(psm, frag, z["cycle"])
+    uid = C.create_string_buffer(128)
+    runtime._check(runtime.lib.adh_comm_unique_id(uid), "adh_comm_unique_id")
+    ctx.comm_init(0, 1, 1000, unique_id=uid.raw)
+    try:
+        rows = np.arange(21, dtype=np.float32).reshape(7, 3)
+        assert np.array_equal(ctx.all_gather_rows(rows, [7]), rows)           # through ncclAllGather
+        assert ctx.all_gather_rows(np.zeros((0, 3), np.uint8), [0]).shape == (0, 3)
+        with pytest.raises(ValueError):
+            ctx.all_gather_rows(rows, [7, 7])                                   # one entry per rank
+        comm_sel = selector()
+        comm_fc = FragmentCompetition(device=0)(psm, frag, z["cycle"])
+        with pytest.raises(runtime.HipBackendError, match="communicator of 2 ranks"):
+            FragmentCompetition(device=0, rank=0, world=2)(psm, frag, z["cycle"])
+    finally:
+        ctx.comm_destroy()
+    pd.testing.assert_frame_equal(comm_sel, plain_sel)
+    pd.testing.assert_frame_equal(comm_fc, plain_fc)
+    assert len(plain_sel) > 1000 and np.array_equal(plain_fc["precursor_idx"].values, z["surviving_precursor_idx"])
+
+
 def test_uneven_shards_share_one_layout_under_a_communicator(ctx, case):
     """All ranks must lay their tables out alike (the all-gather moves equal byte counts): the layout follows
     ``max_rows_per_rank`` and the agreed table width, not the shard.  A short shard scored through a
