@@ -1059,14 +1059,138 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
     return rc;
 }
 
+namespace {
+
+// adh_transpose_timstof for runs of more events than one sort takes (see adh_transpose.hip): two passes over
+// slabs of whole pushes; the outputs are assembled in HBM (6 bytes per event) and copied out at the end.
+int transpose_in_slabs(adh_handle_t *h, const uint32_t *tof_indices, const int64_t *push_indptr, int64_t n_push, int64_t n_tof,
+                       const uint16_t *values, int64_t n, uint32_t *push_out, int64_t *tof_indptr_out, uint16_t *values_out,
+                       int64_t slab_events) {
+    // slabs of whole pushes, each within the event budget
+    std::vector<int64_t> cut{0};
+    while (cut.back() < n_push) {
+        const int64_t p0 = cut.back(), e0 = push_indptr[p0];
+        // last push whose end is still within e0 + slab_events
+        int64_t p1 = std::upper_bound(push_indptr + p0, push_indptr + n_push + 1, e0 + slab_events) - push_indptr - 1;
+        if (p1 <= p0) return fail(ADH_ERR_UNSUPPORTED, "a single push holds more events than one slab takes");
+        cut.push_back(std::min(p1, n_push));
+    }
+    const int64_t n_slabs = (int64_t)cut.size() - 1;
+    int64_t max_slab = 0;
+    for (int64_t s = 0; s < n_slabs; ++s) max_slab = std::max(max_slab, push_indptr[cut[(size_t)s + 1]] - push_indptr[cut[(size_t)s]]);
+    hipStream_t st = h->stream;
+    DeviceBuffers tmp;
+    int rc = ADH_OK;
+    auto dev_alloc = [&](void **p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+        tmp.ptrs.push_back(*p);
+        return ADH_OK;
+    };
+    uint32_t *d_tof = nullptr, *d_push_of = nullptr, *d_ev_in = nullptr, *d_ev_out = nullptr, *d_tof_out = nullptr, *d_push_out = nullptr;
+    uint16_t *d_val = nullptr, *d_val_out = nullptr;
+    int64_t *d_ptr = nullptr, *d_indptr = nullptr, *d_slab_indptr = nullptr;
+    unsigned long long *d_count = nullptr, *d_running = nullptr, *d_prior = nullptr;
+    int *d_bad = nullptr;
+    void *sort_tmp = nullptr, *scan_tmp = nullptr;
+    const int64_t *d_ptr_c = nullptr;
+    rc = upload(tmp, push_indptr, n_push + 1, &d_ptr_c, st);
+    d_ptr = const_cast<int64_t *>(d_ptr_c);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_tof, (size_t)max_slab * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_val, (size_t)max_slab * 2);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_of, (size_t)max_slab * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_in, (size_t)max_slab * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_ev_out, (size_t)max_slab * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_tof_out, (size_t)max_slab * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_out, (size_t)n * 4);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_val_out, (size_t)n * 2);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_indptr, (size_t)(n_tof + 1) * 8);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_slab_indptr, (size_t)(n_tof + 1) * 8);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_count, (size_t)(n_tof + 1) * 8);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_running, (size_t)(n_tof + 1) * 8);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_prior, (size_t)n_slabs * (size_t)(n_tof + 1) * 8);
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_bad, sizeof(int));
+    if (rc != ADH_OK) {
+        tmp.release();
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(d_running, 0, (size_t)(n_tof + 1) * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), st);
+    const unsigned tof_blocks = (unsigned)((n_tof + 255) / 256);
+    // ---- pass 1: events per TOF bin of every slab -> where the slab's run of a bin starts inside the bin
+    for (int64_t s = 0; s < n_slabs && e == hipSuccess; ++s) {
+        const int64_t e0 = push_indptr[cut[(size_t)s]], ns = push_indptr[cut[(size_t)s + 1]] - e0;
+        e = hipMemcpyAsync(d_tof, tof_indices + e0, (size_t)ns * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, (size_t)(n_tof + 1) * 8, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(adh_tof_count_kernel, dim3(8192), dim3(256), 0, st, d_tof, ns, n_tof, d_count, d_bad);
+        hipLaunchKernelGGL(adh_tof_prior_kernel, dim3(tof_blocks), dim3(256), 0, st, d_count, n_tof, d_running,
+                           d_prior + (size_t)s * (size_t)(n_tof + 1));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the slab buffer is reused)
+    }
+    int bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && bad) {
+        tmp.release();
+        return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indices holds a value >= n_tof");
+    }
+    if (e == hipSuccess) {  // tof_indptr = exclusive sum of the totals (entry n_tof: all events)
+        size_t scan_bytes = 0;
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_running, (unsigned long long *)d_indptr, (int)(n_tof + 1), st);
+        if (e == hipSuccess) rc = dev_alloc(&scan_tmp, scan_bytes);
+        if (e == hipSuccess && rc == ADH_OK)
+            e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, d_running, (unsigned long long *)d_indptr, (int)(n_tof + 1), st);
+    }
+    // ---- pass 2: sort every slab by TOF (stable: pushes stay ascending), scatter its runs
+    int end_bit = 1;
+    while (end_bit < 32 && ((int64_t)1 << end_bit) < std::max<int64_t>(n_tof, 2)) ++end_bit;
+    size_t sort_bytes = 0;
+    if (e == hipSuccess && rc == ADH_OK)
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)max_slab, 0, end_bit, st);
+    if (e == hipSuccess && rc == ADH_OK) rc = dev_alloc(&sort_tmp, sort_bytes);
+    for (int64_t s = 0; s < n_slabs && e == hipSuccess && rc == ADH_OK; ++s) {
+        const int64_t p0 = cut[(size_t)s], p1 = cut[(size_t)s + 1];
+        const int64_t e0 = push_indptr[p0], ns = push_indptr[p1] - e0;
+        if (ns == 0) continue;
+        e = hipMemcpyAsync(d_tof, tof_indices + e0, (size_t)ns * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_val, values + e0, (size_t)ns * 2, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(adh_expand_push_slab_kernel, dim3(4096), dim3(256), 0, st, d_ptr, p0, p1, e0, d_push_of);
+        hipLaunchKernelGGL(adh_iota_kernel, dim3(4096), dim3(256), 0, st, d_ev_in, ns);
+        e = hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, d_tof, d_tof_out, d_ev_in, d_ev_out, (int)ns, 0, end_bit, st);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(adh_tof_indptr_kernel, dim3(1024), dim3(256), 0, st, d_tof_out, ns, n_tof, d_slab_indptr);
+        hipLaunchKernelGGL(adh_transpose_scatter_kernel, dim3(8192), dim3(256), 0, st, d_tof_out, d_ev_out, d_push_of, d_val, ns,
+                           d_slab_indptr, d_indptr, d_prior + (size_t)s * (size_t)(n_tof + 1), d_push_out, d_val_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(push_out, d_push_out, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(values_out, d_val_out, (size_t)n * 2, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == ADH_OK) e = hipMemcpyAsync(tof_indptr_out, d_indptr, (size_t)(n_tof + 1) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == ADH_OK) e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == ADH_OK) {
+        (void)hipGetLastError();
+        rc = fail(e == hipErrorOutOfMemory ? ADH_ERR_OUT_OF_MEMORY : ADH_ERR_HIP, std::string("transpose (slabs): ") + hipGetErrorString(e));
+    }
+    tmp.release();
+    return rc;
+}
+
+}  // namespace
+
 int adh_transpose_timstof(adh_handle_t *h, const uint32_t *tof_indices, const int64_t *push_indptr,
                           int64_t n_push, int64_t n_tof, const uint16_t *values, int64_t n,
                           uint32_t *push_out, int64_t *tof_indptr_out, uint16_t *values_out) {
     if (!h || !push_indptr || !tof_indptr_out || (n > 0 && (!tof_indices || !values || !push_out || !values_out)))
         return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_push < 0 || n_tof < 0 || n < 0) return fail(ADH_ERR_INVALID_ARGUMENT, "negative size");
-    if (n >= (int64_t)0x7FFFFFFFll || n_push >= (int64_t)0xFFFFFFFFll || n_tof >= (int64_t)0xFFFFFFFFll)
-        return fail(ADH_ERR_UNSUPPORTED, "more than 2^31 - 1 detector events per call are not supported");
+    if (n_push >= (int64_t)0xFFFFFFFFll || n_tof >= (int64_t)0xFFFFFFFFll)
+        return fail(ADH_ERR_UNSUPPORTED, "2^32 - 1 pushes / TOF bins or more are not supported (32-bit push_indices, as in the reference)");
     if (push_indptr[0] != 0 || push_indptr[n_push] != n)
         return fail(ADH_ERR_INVALID_ARGUMENT, "push_indptr does not span the event arrays");
     for (int64_t p = 0; p < n_push; ++p)
@@ -1075,6 +1199,14 @@ int adh_transpose_timstof(adh_handle_t *h, const uint32_t *tof_indices, const in
     if (n == 0) {
         for (int64_t t = 0; t <= n_tof; ++t) tof_indptr_out[t] = 0;
         return ADH_OK;
+    }
+    {
+        // one sort handles < 2^31 events (32-bit event numbers, hipCUB item counts): longer runs go slab by slab
+        int64_t slab_events = (int64_t)0x7FFFFFFFll - 1;
+        if (const char *env = getenv("ADH_TRANSPOSE_SLAB_EVENTS")) slab_events = std::max<int64_t>(atoll(env), 1);  // (tests)
+        if (n > slab_events)
+            return transpose_in_slabs(h, tof_indices, push_indptr, n_push, n_tof, values, n, push_out, tof_indptr_out, values_out,
+                                      slab_events);
     }
     hipStream_t st = h->stream;
     DeviceBuffers tmp;
@@ -1102,9 +1234,20 @@ int adh_transpose_timstof(adh_handle_t *h, const uint32_t *tof_indices, const in
     if (rc == ADH_OK) rc = dev_alloc((void **)&d_push_out, (size_t)n * 4);
     if (rc == ADH_OK) rc = dev_alloc((void **)&d_val_out, (size_t)n * 2);
     if (rc == ADH_OK) rc = dev_alloc((void **)&d_indptr, (size_t)(n_tof + 1) * 8);
-    (void)d_bad;
+    if (rc == ADH_OK) rc = dev_alloc((void **)&d_bad, sizeof(int));
     hipError_t e = hipSuccess;
     if (rc == ADH_OK) {
+        e = hipMemsetAsync(d_bad, 0, sizeof(int), st);
+        hipLaunchKernelGGL(adh_tof_range_kernel, dim3(4096), dim3(256), 0, st, d_tof, n, n_tof, d_bad);
+        int bad = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess && bad) {
+            tmp.release();
+            return fail(ADH_ERR_INVALID_ARGUMENT, "tof_indices holds a value >= n_tof");
+        }
+    }
+    if (rc == ADH_OK && e == hipSuccess) {
         hipLaunchKernelGGL(adh_expand_push_kernel, dim3(4096), dim3(256), 0, st, d_ptr, n_push, d_push_of);
         hipLaunchKernelGGL(adh_iota_kernel, dim3(4096), dim3(256), 0, st, d_ev_in, n);
         int end_bit = 1;

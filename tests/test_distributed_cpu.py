@@ -299,3 +299,40 @@ def test_fragment_competition_sharded_by_window(tmp_path, oracle_lib, world):
         assert np.array_equal(got["valid"], one), r
         survivors = psm.iloc[got["rows"][got["valid"]]]
         assert np.array_equal(survivors["precursor_idx"].values, z["surviving_precursor_idx"])
+
+
+def _shared_case_worker(rank, world, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["ADH_RUN_NONCE"] = "shared-case-test-" + os.path.basename(tmpdir)
+    import bench
+
+    case = bench.shared_case(300, 40, 2, rank, rank, world)
+    np.savez(os.path.join(tmpdir, f"case{rank}.npz"), mz=np.asarray(case.dia.mz_values), inten=np.asarray(case.dia.intensity_values),
+             start=np.asarray(case.dia.peak_start_idx_list), rt=np.asarray(case.dia.rt_values),
+             cand=case.candidates_df["frame_start"].values, lib=case.library.precursor_df["mz_library"].values,
+             mapped=np.array([isinstance(case.dia.mz_values, np.memmap)]))
+    if rank == 0:
+        import time
+
+        t0 = time.time()
+        while not os.path.exists(os.path.join(tmpdir, "case1.npz")) and time.time() - t0 < 120:
+            time.sleep(0.1)
+        bench.release_shared_case(0, world, 300, 40)
+
+
+def test_bench_generates_the_run_once_per_node(tmp_path):
+    """bench.py --gpus N: local rank 0 generates the synthetic run, the other ranks map it from /dev/shm and
+    build only the (cheap, deterministic) library and candidate table themselves - same arrays on every rank."""
+    import synthetic as syn
+
+    mp.spawn(_shared_case_worker, args=(2, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "case0.npz"), np.load(tmp_path / "case1.npz")
+    ref = syn.make_case(300, 40, config_id=2, per_precursor=3, threads=2)
+    assert not a["mapped"][0] and b["mapped"][0]
+    for k, v in (("mz", ref.dia.mz_values), ("inten", ref.dia.intensity_values), ("start", ref.dia.peak_start_idx_list),
+                 ("rt", ref.dia.rt_values), ("cand", ref.candidates_df["frame_start"].values),
+                 ("lib", ref.library.precursor_df["mz_library"].values)):
+        assert np.array_equal(a[k], v) and np.array_equal(b[k], v), k
+    import glob
+
+    assert not glob.glob("/dev/shm/adh_bench_*shared-case-test*") and not glob.glob("/dev/shm/adh_bench_*_300_40.*")
