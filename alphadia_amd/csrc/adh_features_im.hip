@@ -427,6 +427,15 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     double *const hp = D + lay.d_pi();
     double *const omzp = hp + Ic;
     if (caps.stop_phase == 11) return;
+    // The template (O, S, F) is as sparse as the precursor tile it is made of: ~20 cells of 1 152.  The split path
+    // (one observation) never builds it: its non-zero cells go to a list in cell order - (scan << 12 | cycle,
+    // value), in the bytes the dense template would take - and ONE lane folds the list into everything the
+    // template is needed for: scan profile, frame profile, centre of mass.  Empty cells add +0 to those sums.
+    constexpr int TL_CAP = 256;
+    const bool sparse_tpl = SPLIT && compact && n_pe <= TL_CAP && lay.Oc == 1 && lay.Oc * lay.SFc * 4 >= TL_CAP * 8;
+    int *const tl_cell = reinterpret_cast<int *>(tpl);
+    float *const tl_val = tpl + TL_CAP;
+    int tl_n = 0;
     if (compact) {
         // ---- everything that reads the precursor tile, in ONE pass over its sparse form: the entries are
         // the non-zero (scan, cycle, isotope) cells in that order, staged ADH_IM_STAGE at a time in the chunk lists.
@@ -439,7 +448,8 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
         uint32_t *const c_cell = reinterpret_cast<uint32_t *>(c_w + ADH_IM_STAGE);
         float *const c_x = reinterpret_cast<float *>(c_cell + ADH_IM_STAGE);
         float *const c_y = c_x + ADH_IM_STAGE;
-        for (int c = lane; c < OSF; c += ADH_WAVE) tpl[c] = 0.0f;
+        if (!sparse_tpl)
+            for (int c = lane; c < OSF; c += ADH_WAVE) tpl[c] = 0.0f;
         const ImEntry *const pent = entries + n_fe;
         const int role = lane / I, iso = lane - role * I;  // role 0: intensity sum; 1, 2: intensity mean; 3, 4: m/z mean
         double acc = 0.0;
@@ -464,19 +474,30 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
                 const unsigned long long st = __ballot((c_cell[e] >> 4) != (c_cell[e - 1] >> 4));
                 cnt = cnt - ADH_WAVE + (63 - __clzll(st));
             }
-            for (int e = lane; e < cnt; e += ADH_WAVE) {
-                const uint32_t cs = c_cell[e] >> 4;
-                if (e > 0 && (c_cell[e - 1] >> 4) == cs) continue;
+            for (int e0 = 0; e0 < cnt; e0 += ADH_WAVE) {  // (every lane makes every trip: the list positions come from a ballot)
+                const int e = e0 + lane;
+                const uint32_t cs = e < cnt ? c_cell[e] >> 4 : 0u;
+                const bool first = e < cnt && !(e > 0 && (c_cell[e - 1] >> 4) == cs);
                 const int sc = (int)(cs >> 12), sf = sc * F + (int)(cs & 0xFFFu);
-                for (int o = 0; o < O; ++o) {
-                    double a = 0;
-                    for (int q = e; q < cnt && (c_cell[q] >> 4) == cs; ++q) {
-                        const int i = (int)(c_cell[q] & 15u);
-                        const float t = c_x[q] * iso_int[i];
-                        a += (double)t * qtf[(i * O + o) * S + sc];
+                const unsigned long long firsts = sparse_tpl ? __ballot(first) : 0ull;
+                if (first) {
+                    for (int o = 0; o < O; ++o) {
+                        double a = 0;
+                        for (int q = e; q < cnt && (c_cell[q] >> 4) == cs; ++q) {
+                            const int i = (int)(c_cell[q] & 15u);
+                            const float t = c_x[q] * iso_int[i];
+                            a += (double)t * qtf[(i * O + o) * S + sc];
+                        }
+                        if (sparse_tpl) {  // (one observation) the cell joins the list, which stays in cell order
+                            const int at = tl_n + __popcll(firsts & ((1ull << lane) - 1ull));
+                            tl_cell[at] = (int)cs;
+                            tl_val[at] = (float)a;
+                        } else {
+                            tpl[o * SF + sf] = (float)a;
+                        }
                     }
-                    tpl[o * SF + sf] = (float)a;
                 }
+                tl_n += __popcll(firsts);
             }
             if (lane < 5 * I) {
                 // four entries per step, all loads first, no branch: the walk is a chain of LDS latencies
@@ -542,6 +563,47 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     // np.sum(np.sum(template, axis=-1), axis=-1): the inner sums (one per scan) are independent, the
     // outer one adds them in scan order
     // (the per-scan sums are the template's scan profile: tsp_raw keeps them)
+    double *const esc = D + lay.d_po();
+    double *const efc = esc + Oc;
+    double *const omz = D + lay.d_omz();
+    double *const ohe = D + lay.d_ohe();
+    double *const omz_u = D + lay.d_omzu();
+    double *const ohe_u = D + lay.d_oheu();
+    if (sparse_tpl) {
+        for (int c = lane; c < S; c += ADH_WAVE) tsp_raw[c] = 0.0f;
+        for (int c = lane; c < F; c += ADH_WAVE) tfp_raw[c] = 0.0f;
+        adh_wave_sync();
+        if (lane == 0) {
+            // the list is in (scan, cycle) order: a scan's cells are consecutive and in cycle order (its sum =
+            // np.sum over the cycle axis), a cycle's cells come in scan order (the sum over the scan axis), and
+            // the centre-of-mass sums take the cells v > 0 in list order (fragment_features.py:20-68)
+            double isum = 0.0, ssum = 0.0, fsum = 0.0;
+            float srow = 0.0f;
+            int cur = -1;
+            for (int e = 0; e < tl_n; ++e) {
+                const int cs = tl_cell[e], sc = cs >> 12, f = cs & 0xFFF;
+                const float v = tl_val[e];
+                if (sc != cur) {
+                    if (cur >= 0) tsp_raw[cur] = srow;
+                    srow = 0.0f;
+                    cur = sc;
+                }
+                srow += v;
+                tfp_raw[f] = tfp_raw[f] + v;
+                if (v > 0.0f) {
+                    isum += (double)v;
+                    ssum += (double)sc * (double)v;
+                    fsum += (double)f * (double)v;
+                }
+            }
+            if (cur >= 0) tsp_raw[cur] = srow;
+            esc[0] = (isum > 0) ? ssum / isum : 0.0;
+            efc[0] = (isum > 0) ? fsum / isum : 0.0;
+        }
+        adh_wave_sync();
+        if (lane < O) tsum[lane] = osum<SR>(tsp_raw + lane * S, 1, S);
+        adh_wave_sync();
+    } else {
     for (int c = lane; c < O * S; c += ADH_WAVE) tsp_raw[c] = osum<FR>(tpl + c * F, 1, F);
     adh_wave_sync();
     if (lane < O) tsum[lane] = osum<SR>(tsp_raw + lane * S, 1, S);
@@ -549,12 +611,6 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     // ---- template centre of mass and the weight tables (fragment_features.py:20-68,
     // features_utils.py:9-25): they only depend on the precursor tile and are needed by the pass
     // over the fragment tile
-    double *const esc = D + lay.d_po();
-    double *const efc = esc + Oc;
-    double *const omz = D + lay.d_omz();
-    double *const ohe = D + lay.d_ohe();
-    double *const omz_u = D + lay.d_omzu();
-    double *const ohe_u = D + lay.d_oheu();
     // sequential float64 sums over the non-zero template cells (s outer, f inner); the terms are
     // computed by all lanes, compacted in order, and lanes 0..2 add up one sum each
     for (int o = 0; o < O; ++o) {
@@ -585,6 +641,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
             esc[o] = (isum > 0) ? ssum / isum : 0.0;
             efc[o] = (isum > 0) ? fsum / isum : 0.0;
         }
+    }
     }
     for (int c = lane; c < K0 * O * F; c += ADH_WAVE) ffp_u[c] = 0.0f;
     for (int c = lane; c < K0 * O * S; c += ADH_WAVE) fsp_u[c] = 0.0f;
@@ -814,7 +871,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
         // template frame profile: sums over the scans, in scan order (the monolithic kernel takes it below)
         for (int rr = lane; rr < FMc; rr += ADH_WAVE) {
             const int f = rr + shift;
-            rec.tfp_raw[rr] = (f >= 0 && f < F) ? osum<SR>(tpl + f, F, S) : 0.0f;
+            rec.tfp_raw[rr] = (f >= 0 && f < F) ? (sparse_tpl ? tfp_raw[f] : osum<SR>(tpl + f, F, S)) : 0.0f;
         }
         for (int sc = lane; sc < SMc; sc += ADH_WAVE) rec.tsp_raw[sc] = (sc < S) ? tsp_raw[sc] : 0.0f;
         for (int c = lane; c < K0 * FMc; c += ADH_WAVE) {
