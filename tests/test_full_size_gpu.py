@@ -3,8 +3,10 @@
 configs[2] (1e6-precursor library x 3 candidates vs the 2 h run, on one GPU) and configs[1] (its first
 100 000 precursors: the same run, the 100k library) through size-independent properties - permutation
 invariance, sub-table == rows of the full table, planted precursors found - and a strided oracle sample that
-includes the ppm features; configs[3] (918 scans x 2 000 cycles, ion mobility) with 20 000 precursors and an
-oracle sample.  The run generators are the bench's (tests/synthetic.py); generation dominates the time.
+includes the ppm features; configs[3] (918 scans x 2 000 cycles, ion mobility) with its 200 000 precursors and an
+oracle sample; configs[4] (75 000 elution groups x 4 label channels, the requantification config) with an
+oracle sample and its four-way score-group split.  The run generators are the bench's (tests/synthetic.py);
+generation dominates the time.
 """
 
 import os
@@ -90,14 +92,16 @@ def test_config1_full_size(ctx, headline):
         assert np.array_equal(shuffled[k], got[k][:n1][perm], equal_nan=True), k
 
 
-def test_config2_score_group_shards_reassemble(ctx, headline):
-    """The 3 000 000-row table cut into score-group shards as `bench.py --gpus N` cuts it (N = 3: uneven), every
+@pytest.mark.parametrize("world", [3, 8])
+def test_config2_score_group_shards_reassemble(ctx, headline, world):
+    """The 3 000 000-row table cut into score-group shards as `bench.py --gpus N` cuts it (N = 3: uneven; N = 8:
+    the split configs[2] names), every
     shard scored on its own - its own chunk cuts of the host -> host pipeline, its own plan - gives the rows of
     the one-GPU table bit for bit: sharding and chunking at a size where both are in play."""
     from alphadia_amd.distributed import shard_bounds, slice_soa
 
     case, cfg, soa, got = headline
-    n, world, pos = len(soa["precursor_idx"]), 3, 0
+    n, pos = len(soa["precursor_idx"]), 0
     for rank in range(world):
         a, b = shard_bounds(soa["score_group_idx"], rank, world)
         assert a == pos and b > a
@@ -109,11 +113,11 @@ def test_config2_score_group_shards_reassemble(ctx, headline):
 
 
 def test_config3_full_size_ion_mobility(ctx, oracle_lib):
-    """configs[3]: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 20 000 precursors x 3
-    candidates of 17-39 scans x 7-29 cycles; every 30th candidate against the oracle; repeated runs identical;
-    permutation invariance."""
+    """configs[3] as specified: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 200 000
+    precursors x 3 candidates of 17-39 scans x 7-29 cycles; every 300th candidate against the oracle; repeated runs
+    identical; permutation invariance."""
     case = syn.make_timstof_case(
-        n_precursors=20_000, n_cycles=2000, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
+        n_precursors=200_000, n_cycles=2000, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
         scan_max_index=918, n_tof=400_000, events_per_push=30.0, mz_lo=400.0, mz_hi=1000.0, frag_mz_lo=200.0,
         frag_mz_hi=1000.0, tof_mz_lo=195.0, tof_mz_hi=1010.0, planted_fraction=0.3, h_range=(3, 14), hs_range=(9, 19),
         candidates_on_window=True, sorted_noise=True, threads=THREADS,
@@ -130,8 +134,8 @@ def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     ctx.stage_fragments(*cols, force=True)
     got = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
     v = got["valid"].astype(bool)
-    assert n == 60_000 and v.mean() > 0.5 and (got["features"][v][:, 29] != 0).mean() > 0.3
-    idx = np.arange(0, n, 30)
+    assert n == 600_000 and v.mean() > 0.5 and (got["features"][v][:, 29] != 0).mean() > 0.3
+    idx = np.arange(0, n, 300)
     exp = oracle_lib.score_timstof(case.dia, cols, pack_assembled(_rows(soa, idx)), cfgj, n_threads=THREADS,
                                    with_stats=True)
     compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
@@ -145,3 +149,49 @@ def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     shuffled = ctx.score_host(pack_assembled(_rows(soa, perm)), cfgj, with_stats=True)
     for k in got:
         assert np.array_equal(shuffled[k], got[k][perm], equal_nan=True), k
+
+
+def test_config4_full_size_multiplex(ctx, oracle_lib):
+    """configs[4] as specified: 75 000 elution groups x label channels {0, 4, 8, 12} = 300 000 precursors against
+    the 2 h run, scored as MultiplexingRequantificationHandler scores them (class-default config + score_grouped,
+    exclude_shared_ions, reference channel 0: multiplexing_requantification_handler.py:95-140): every 100th score
+    group against the oracle, and the four-way score-group split of the configuration (4 GPUs) scored shard by
+    shard gives the rows of the unsharded table - no group is cut."""
+    from alphadia_amd.distributed import shard_bounds, slice_soa
+    from alphadia_amd.scoring import multiplex_candidates
+
+    mc = syn.make_multiplex_case(75_000, 4800, threads=THREADS)
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(score_grouped=True, exclude_shared_ions=True, reference_channel=0, experimental_xic=True))
+    assert cfg.top_k_isotopes == 4 and not cfg.quant_all
+    cfgj = cfg.to_jitclass()
+    pdf = mc.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+    multiplexed = multiplex_candidates(mc.psm_df, pdf, channels=list(mc.channels))
+    multiplexed["rank"] = 0
+    soa = assemble_candidates(multiplexed, pdf, "mz_library", score_grouped=True, reference_channel=0)
+    n = len(soa["precursor_idx"])
+    assert n == 300_000 and int(soa["score_group_idx"][-1]) + 1 == 75_000
+    ctx.stage_run(mc.dia, force=True)
+    cols = fragment_columns(mc.library.fragment_df, "mz_library")
+    ctx.stage_fragments(*cols, force=True)
+    got = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
+    got = {k: np.array(v, copy=True) for k, v in got.items()}
+    v = got["valid"].astype(bool)
+    assert 0.5 < v.mean() < 0.95
+    idx = np.flatnonzero(soa["score_group_idx"] % 100 == 0)  # whole score groups
+    exp = oracle_lib.score(mc.dia, cols, pack_assembled(_rows(soa, idx)), cfgj, n_threads=THREADS, with_stats=True)
+    compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    # (the diagnostic peak counter on the rows that were scored: the label shift moves some channel copies above the
+    # last isolation window - no MS2 observation at all - where the reference still extracts MS1 before the candidate
+    # fails at the presence mask (candidate.py:220-329) and the plan on the device drops the candidate at once)
+    ev = exp["valid"].astype(bool)
+    assert np.array_equal(got["stat_matched_peaks"][idx][ev], exp["stat_matched_peaks"][ev])
+    pos = 0
+    for rank in range(4):
+        a, b = shard_bounds(soa["score_group_idx"], rank, 4)
+        assert a == pos and b > a and (a == 0 or soa["score_group_idx"][a] != soa["score_group_idx"][a - 1])
+        pos = b
+        part = ctx.score_host(pack_assembled(slice_soa(soa, a, b)), cfgj, with_stats=True)
+        for k in got:
+            assert np.array_equal(part[k], got[k][a:b], equal_nan=True), (rank, k)
+    assert pos == n
