@@ -321,51 +321,112 @@ inline uint32_t float_bits(float f) {
     return u;
 }
 
-// sort the peaks of the run into the transposed order and build entries + bin table
-int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, int64_t n_ref,
-                     int64_t n_tab, uint2 *entries, uint32_t *tab, DeviceBuffers &tmp) {
+// Sort the peaks of the run into the transposed order and build entries + bin table, slab by slab: a slab is a
+// range of whole groups of blocks (= a range of spectra = a range of peaks, spectra being stored in time order)
+// with fewer than 2^31 peaks, so that the radix sort and the peak numbers inside it stay 32-bit while the run as
+// a whole may hold 2^32 peaks and more (round 4).  grp_entry0[g] = first entry of group g (host prefix sums).
+int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, int64_t n_ref, int64_t n_tab,
+                     const std::vector<int64_t> &grp_entry0, const int64_t *d_grp_entry0, uint2 *entries, uint32_t *tab,
+                     DeviceBuffers &tmp) {
     hipStream_t st = h->stream;
-    const int64_t n = d->n_peaks;
+    const int64_t L = d->cycle_len;
+    const int64_t n_groups = (int64_t)grp_entry0.size() - 1;
+    const int64_t words_per_group = L * (int64_t)r.n_bins * ADH_SUB;
+    HIP_TRY(hipMemsetAsync(tab, 0, (size_t)n_tab * sizeof(uint32_t), st));
     if (n_ref == 0 || d->n_spectra == 0) {
-        HIP_TRY(hipMemsetAsync(tab, 0, (size_t)n_tab * sizeof(uint32_t), st));
         HIP_TRY(hipStreamSynchronize(st));
         return ADH_OK;
     }
-    const float *d_mz = nullptr, *d_int = nullptr;
-    const int64_t *d_ps = nullptr, *d_pe = nullptr;
-    int rc = upload(tmp, d->mz_values, n, &d_mz, st);
-    if (rc == ADH_OK) rc = upload(tmp, d->intensity_values, n, &d_int, st);
-    if (rc == ADH_OK) rc = upload(tmp, d->peak_start_idx, d->n_spectra, &d_ps, st);
-    if (rc == ADH_OK) rc = upload(tmp, d->peak_stop_idx, d->n_spectra, &d_pe, st);
-    if (rc != ADH_OK) return rc;
+    const int64_t spectra_per_group = L << (r.block_shift + ADH_SUB_SHIFT);
+    // peak range of a group: first referenced peak of its first spectrum .. last of its last (spectra do not share
+    // peaks and ascend, checked by the caller); unreferenced peaks in between get the all-ones key and sort last
+    auto group_peaks = [&](int64_t g0, int64_t g1, int64_t &p0, int64_t &p1) {
+        const int64_t s0 = std::min(g0 * spectra_per_group, d->n_spectra), s1 = std::min(g1 * spectra_per_group, d->n_spectra);
+        p0 = p1 = 0;
+        bool any = false;
+        for (int64_t sp = s0; sp < s1; ++sp)
+            if (d->peak_stop_idx[sp] > d->peak_start_idx[sp]) {
+                if (!any) p0 = d->peak_start_idx[sp];
+                p1 = d->peak_stop_idx[sp];
+                any = true;
+            }
+    };
+    int64_t slab_cap = (int64_t)0x7FFFFFFFll - 1;
+    if (const char *env = getenv("ADH_STAGE_SLAB_PEAKS")) slab_cap = std::max<int64_t>(atoll(env), 1);  // (tests)
+    // slabs of whole groups within the cap (a single group above it is refused)
+    std::vector<int64_t> cut{0};
+    while (cut.back() < n_groups) {
+        int64_t g1 = cut.back() + 1, p0, p1;
+        group_peaks(cut.back(), g1, p0, p1);
+        if (p1 - p0 >= (int64_t)0x7FFFFFFFll)
+            return fail(ADH_ERR_UNSUPPORTED, "one group of cycle blocks holds 2^31 peaks or more");
+        while (g1 < n_groups) {
+            int64_t q0, q1;
+            group_peaks(cut.back(), g1 + 1, q0, q1);
+            if (q1 - q0 > slab_cap) break;
+            ++g1;
+        }
+        cut.push_back(g1);
+    }
+    int64_t max_peaks = 1, max_spec = 1;
+    for (size_t sl = 0; sl + 1 < cut.size(); ++sl) {
+        int64_t p0, p1;
+        group_peaks(cut[sl], cut[sl + 1], p0, p1);
+        max_peaks = std::max(max_peaks, p1 - p0);
+        max_spec = std::max(max_spec, std::min(cut[sl + 1] * spectra_per_group, d->n_spectra) - std::min(cut[sl] * spectra_per_group, d->n_spectra));
+    }
+    float *d_mz = nullptr, *d_int = nullptr;
+    int64_t *d_ps = nullptr, *d_pe = nullptr;
     uint64_t *k_in = nullptr, *k_out = nullptr;
     uint32_t *v_in = nullptr, *v_out = nullptr;
     int *d_bad = nullptr;
+    void *sort_tmp = nullptr;
+    int rc;
     auto dev_alloc = [&](void **p, size_t bytes) -> int {
-        HIP_TRY(hipMalloc(p, bytes));
+        HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 16)));
         tmp.ptrs.push_back(*p);
         return ADH_OK;
     };
-    if ((rc = dev_alloc((void **)&k_in, (size_t)n * 8)) != ADH_OK) return rc;
-    if ((rc = dev_alloc((void **)&k_out, (size_t)n * 8)) != ADH_OK) return rc;
-    if ((rc = dev_alloc((void **)&v_in, (size_t)n * 4)) != ADH_OK) return rc;
-    if ((rc = dev_alloc((void **)&v_out, (size_t)n * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_mz, (size_t)max_peaks * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_int, (size_t)max_peaks * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_ps, (size_t)max_spec * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&d_pe, (size_t)max_spec * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&k_in, (size_t)max_peaks * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&k_out, (size_t)max_peaks * 8)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_in, (size_t)max_peaks * 4)) != ADH_OK) return rc;
+    if ((rc = dev_alloc((void **)&v_out, (size_t)max_peaks * 4)) != ADH_OK) return rc;
     if ((rc = dev_alloc((void **)&d_bad, 4)) != ADH_OK) return rc;
-    // peaks no spectrum refers to keep the all-ones key and sort to the end
-    HIP_TRY(hipMemsetAsync(k_in, 0xFF, (size_t)n * 8, st));
-    HIP_TRY(hipMemsetAsync(v_in, 0, (size_t)n * 4, st));
-    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
-    hipLaunchKernelGGL(adh_peak_key_kernel, dim3((unsigned)d->n_spectra), dim3(256), 0, st, d_mz, d_ps,
-                       d_pe, d->n_spectra, (int)d->cycle_len, (int)r.block_shift, (int)r.bin0,
-                       (int)r.n_bins, k_in, v_in, d_bad);
-    HIP_TRY(hipGetLastError());
     size_t sort_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
-    void *sort_tmp = nullptr;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, v_in, v_out, (int)max_peaks, 0, 64, st));
     if ((rc = dev_alloc(&sort_tmp, std::max<size_t>(sort_bytes, 16))) != ADH_OK) return rc;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, k_in, k_out, v_in, v_out, n, 0, 64, st));
-    hipLaunchKernelGGL(adh_entries_kernel, dim3(8192), dim3(256), 0, st, k_out, v_out, d_int, n_ref,
-                       entries, tab, n_tab, (int)r.block_shift);
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+    for (size_t sl = 0; sl + 1 < cut.size(); ++sl) {
+        const int64_t g0 = cut[sl], g1 = cut[sl + 1];
+        const int64_t s0 = std::min(g0 * spectra_per_group, d->n_spectra), s1 = std::min(g1 * spectra_per_group, d->n_spectra);
+        int64_t p0, p1;
+        group_peaks(g0, g1, p0, p1);
+        const int64_t np = p1 - p0, ns = s1 - s0, n_slab_ref = grp_entry0[(size_t)g1] - grp_entry0[(size_t)g0];
+        const int64_t g_first = g0 * words_per_group, g_last = g1 * words_per_group - 1;
+        if (np > 0 && ns > 0) {
+            HIP_TRY(hipMemcpyAsync(d_mz, d->mz_values + p0, (size_t)np * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_int, d->intensity_values + p0, (size_t)np * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_ps, d->peak_start_idx + s0, (size_t)ns * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_pe, d->peak_stop_idx + s0, (size_t)ns * 8, hipMemcpyHostToDevice, st));
+            // peaks no spectrum refers to keep the all-ones key and sort to the end of the slab
+            HIP_TRY(hipMemsetAsync(k_in, 0xFF, (size_t)np * 8, st));
+            HIP_TRY(hipMemsetAsync(v_in, 0, (size_t)np * 4, st));
+            hipLaunchKernelGGL(adh_peak_key_kernel, dim3((unsigned)ns), dim3(256), 0, st, d_mz, d_ps, d_pe, s0, ns, p0,
+                               (int)d->cycle_len, (int)r.block_shift, (int)r.bin0, (int)r.n_bins, k_in, v_in, d_bad);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, k_in, k_out, v_in, v_out, (int)np, 0, 64, st));
+        }
+        hipLaunchKernelGGL(adh_entries_kernel, dim3(8192), dim3(256), 0, st, k_out, v_out, d_int, n_slab_ref,
+                           grp_entry0[(size_t)g0], entries, tab, g_first, g_last, words_per_group, d_grp_entry0, (int)r.block_shift);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));  // (the slab buffers are reused)
+    }
+    hipLaunchKernelGGL(adh_tab_spare_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, tab, n_groups,
+                       words_per_group, d_grp_entry0);
     HIP_TRY(hipGetLastError());
     int bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
@@ -384,8 +445,6 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
         return fail(ADH_ERR_UNSUPPORTED,
                     "cycle with a scan axis (ion mobility) is not an AlphaRaw run");
     if (d->n_mobility < 1) return fail(ADH_ERR_INVALID_ARGUMENT, "mobility_values is empty");
-    if (d->n_peaks >= (int64_t)0xFFFFFFFFll)
-        return fail(ADH_ERR_UNSUPPORTED, "runs with 2^32 or more peaks are not supported yet");
     if (d->n_spectra >= (int64_t)0x7FFFFFFFll || d->cycle_len > 65535)
         return fail(ADH_ERR_UNSUPPORTED, "too many spectra / cycle positions");
     HIP_TRY(hipSetDevice(h->device));
@@ -457,16 +516,33 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     for (;; ++bs) {
         int64_t nblk = std::max<int64_t>((n_cycles + (1ll << bs) - 1) >> bs, 1);
         nblk = (nblk + ADH_SUB - 1) / ADH_SUB * ADH_SUB;  // whole groups of blocks (adh_device.h)
-        int64_t n_tab = nblk * L * (int64_t)r.n_bins + 1;
+        int64_t n_tab = nblk * L * (int64_t)r.n_bins + nblk / ADH_SUB;
         if (bs >= 20 || (n_tab < (int64_t)0xFFFFFFF0ll && n_tab * 4 <= std::max<int64_t>(2 * n_ref * 8, 64ll << 20))) {
             r.n_blocks = (int32_t)nblk;
             break;
         }
     }
     r.block_shift = bs;
-    const int64_t n_tab = (int64_t)r.n_blocks * L * (int64_t)r.n_bins + 1;
+    // one word per (group, row, bin, block) + one spare word per group (adh_tab_row)
+    const int64_t n_groups = r.n_blocks / ADH_SUB;
+    const int64_t n_tab = (int64_t)r.n_blocks * L * (int64_t)r.n_bins + n_groups;
     if (n_tab >= (int64_t)0xFFFFFFF0ll)
         return fail(ADH_ERR_UNSUPPORTED, "m/z range x cycle positions too large for the bin table");
+    // first entry of every group of blocks: the referenced peaks of the spectra before it
+    std::vector<int64_t> grp_entry0((size_t)n_groups + 1, 0);
+    {
+        const int64_t spectra_per_group = L << (bs + ADH_SUB_SHIFT);
+        int64_t acc = 0;
+        for (int64_t g = 0; g < n_groups; ++g) {
+            grp_entry0[(size_t)g] = acc;
+            const int64_t s0 = std::min(g * spectra_per_group, d->n_spectra), s1 = std::min((g + 1) * spectra_per_group, d->n_spectra);
+            for (int64_t sp = s0; sp < s1; ++sp) acc += d->peak_stop_idx[sp] - d->peak_start_idx[sp];
+            if (acc - grp_entry0[(size_t)g] >= (int64_t)0xFFFFFFFFll)
+                return fail(ADH_ERR_UNSUPPORTED, "one group of cycle blocks holds 2^32 peaks or more");
+        }
+        grp_entry0[(size_t)n_groups] = acc;
+    }
+    UP(h->run_buf, grp_entry0.data(), n_groups + 1, &r.grp_entry0);
 
     uint2 *entries = nullptr;
     uint32_t *tab = nullptr;
@@ -478,7 +554,7 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     r.tab = tab;
 
     DeviceBuffers tmp;
-    int rc = stage_transposed(h, d, r, n_ref, n_tab, entries, tab, tmp);
+    int rc = stage_transposed(h, d, r, n_ref, n_tab, grp_entry0, r.grp_entry0, entries, tab, tmp);
     tmp.release();
     if (rc != ADH_OK) return rc;
     h->run = r;

@@ -38,10 +38,14 @@ struct DevRun {
     // peaks sorted by (group of ADH_SUB blocks, cycle row, m/z bin, cycle, m/z):
     // .x = (cycle inside the GROUP << ADH_BIN_SHIFT) | low m/z bits, .y = intensity bits
     const uint2 *entries;
-    // [((n_blocks / ADH_SUB * cycle_len + row) * n_bins + bin) * ADH_SUB + block in group] (+ 1): first entry of
+    // [((group * cycle_len + row) * n_bins + bin) * ADH_SUB + block in group + group] (adh_tab_row): first entry of
     // the (group, row, bin) that lies in that block or a later one; the word after a bin's last block is the
     // next bin's first, so entries of blocks sb0 .. sb1 of a bin are [t[bin * ADH_SUB + sb0], t[bin * ADH_SUB + sb1 + 1])
     const uint32_t *tab;
+    // Round 4: table words are RELATIVE to the first entry of their group of blocks (grp_entry0[group], 64-bit), so
+    // that a run may hold 2^32 peaks and more (a group holds ~1e7); every group's segment of the table ends with one
+    // extra word, the group's entry count, which is what the last cell's "next word" reads.
+    const int64_t *grp_entry0;  // [n_blocks / ADH_SUB + 1]
     const float *rt;          // [n_spectra]
     const float *mobility;    // [n_mobility]
     const double *cycle;      // [cycle_len * cycle_scans * 2]
@@ -210,7 +214,12 @@ __device__ __forceinline__ void adh_wave_sync() {
 
 // table row of (group of blocks, cycle row): index it with bin * ADH_SUB + block inside the group
 __device__ __forceinline__ const uint32_t *adh_tab_row(const DevRun &run, int row, int blk) {
-    return run.tab + (((int64_t)(blk >> ADH_SUB_SHIFT) * run.cycle_len + row) * (int64_t)run.n_bins << ADH_SUB_SHIFT);
+    const int64_t grp = blk >> ADH_SUB_SHIFT;
+    return run.tab + ((grp * run.cycle_len + row) * (int64_t)run.n_bins << ADH_SUB_SHIFT) + grp;  // (+ one spare word per group)
+}
+// entries of a group of blocks: table words count from here
+__device__ __forceinline__ const uint2 *adh_group_entries(const DevRun &run, int blk) {
+    return run.entries + run.grp_entry0[blk >> ADH_SUB_SHIFT];
 }
 
 typedef adh_output_t DevOut;

@@ -367,29 +367,29 @@ __device__ __forceinline__ void task_begin(const DevRun &run, bool on, int row, 
     }
 }
 
-__device__ __forceinline__ void load2(const DevRun &run, uint32_t i, uint2 &a, uint2 &b) {
-    const Ent2 p = *reinterpret_cast<const Ent2 *>(run.entries + i);
+__device__ __forceinline__ void load2(const uint2 *ent, uint32_t i, uint2 &a, uint2 &b) {
+    const Ent2 p = *reinterpret_cast<const Ent2 *>(ent + i);
     a = p.a;
     b = p.b;
 }
 
-__device__ __forceinline__ void task_fetch(const DevRun &run, Task &k) {
+__device__ __forceinline__ void task_fetch(const uint2 *ent, Task &k) {
     const uint32_t n = k.end - k.idx;  // (idx <= end)
 #pragma unroll
     for (int u = 0; u < EB; u += 2) {
-        if (n > (uint32_t)u) load2(run, k.idx + u, k.e[u], k.e[u + 1]);
+        if (n > (uint32_t)u) load2(ent, k.idx + u, k.e[u], k.e[u + 1]);
     }
 #if ADH_FUSED_AHEAD
 #pragma unroll
     for (int u = 0; u < EB; u += 2) {
-        if (n > (uint32_t)(EB + u)) load2(run, k.idx + EB + u, k.n[u], k.n[u + 1]);
+        if (n > (uint32_t)(EB + u)) load2(ent, k.idx + EB + u, k.n[u], k.n[u + 1]);
     }
 #endif
 }
 
 // cells: the lane's column of the tile, cells[r * TW] = centred row r; roff = FM/2 - F/2 - c0
 template <int TW>
-__device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Task &k, float2 *cells, int roff,
+__device__ __forceinline__ void task_run(const uint2 *ent, const WinBits &w, Task &k, float2 *cells, int roff,
                                          uint32_t &hits) {
     uint32_t idx = k.idx;
     const uint32_t end = k.end;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
             const uint32_t left = end - idx;
 #pragma unroll
             for (int u = 0; u < EB; u += 2) {
-                if (left > (uint32_t)(2 * EB + u)) load2(run, idx + 2 * EB + u, k.n[u], k.n[u + 1]);
+                if (left > (uint32_t)(2 * EB + u)) load2(ent, idx + 2 * EB + u, k.n[u], k.n[u + 1]);
             }
         }
 #else
@@ -420,7 +420,7 @@ __device__ __forceinline__ void task_run(const DevRun &run, const WinBits &w, Ta
             const uint32_t left = end - idx;
 #pragma unroll
             for (int u = 0; u < EB; u += 2) {
-                if (left > (uint32_t)(EB + u)) load2(run, idx + EB + u, k.e[u], k.e[u + 1]);
+                if (left > (uint32_t)(EB + u)) load2(ent, idx + EB + u, k.e[u], k.e[u + 1]);
             }
         }
 #endif
@@ -567,6 +567,7 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
     for (int grp = blk0 >> ADH_SUB_SHIFT; grp <= (blk1 >> ADH_SUB_SHIFT); ++grp) {  // (wave-uniform only per group of lanes:
         // lanes of a candidate that has no such group idle, see `on`)
         const int sb0 = max(blk0 - (grp << ADH_SUB_SHIFT), 0), sb1 = min(blk1 - (grp << ADH_SUB_SHIFT), ADH_SUB - 1);
+        const uint2 *ent = adh_group_entries(run, grp << ADH_SUB_SHIFT);  // (table words count from the group's first entry)
         // two bins of the window at a time: their table words, then their entries, are in flight together
         // (one dependent round trip per pair instead of per bin; a window rarely has a third bin)
         for (int j = 0; __any(j < n_bins_l); j += NPAIR) {
@@ -576,9 +577,9 @@ __device__ __forceinline__ void gather_pass(const DevRun &run, const WinBits &wb
                 task_begin(run, j + u < n_bins_l && sb1 >= sb0, task_row, grp, sb0, max(sb1, sb0), wb.b_lo + j + u, wb.b_lo, c0,
                            F, t[u]);
 #pragma unroll
-            for (int u = 0; u < NPAIR; ++u) task_fetch(run, t[u]);
+            for (int u = 0; u < NPAIR; ++u) task_fetch(ent, t[u]);
 #pragma unroll
-            for (int u = 0; u < NPAIR; ++u) task_run<TW>(run, wb, t[u], cells, roff, hits);
+            for (int u = 0; u < NPAIR; ++u) task_run<TW>(ent, wb, t[u], cells, roff, hits);
         }
     }
 }

@@ -75,6 +75,7 @@ __device__ __forceinline__ void gather_task(const DevRun &run, const Window &w, 
     const int f_lo = max(c0, cyc_base) - grp_base;              // group-relative cycle range inside the block
     const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - grp_base;
     const uint32_t *t = adh_tab_row(run, row, blk) + (blk & (ADH_SUB - 1));
+    const uint2 *ent = adh_group_entries(run, blk);
     for (int b = w.b_lo; b <= w.b_hi; ++b) {  // bin after bin: a cell keeps ascending m/z
         uint32_t idx = t[b * ADH_SUB];
         const uint32_t end = t[b * ADH_SUB + 1];
@@ -84,7 +85,7 @@ __device__ __forceinline__ void gather_task(const DevRun &run, const Window &w, 
             // four entries in flight; the tail repeats the last one (harmless, skipped below)
             uint2 e[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
+            for (int u = 0; u < 4; ++u) e[u] = ent[min(idx + (uint32_t)u, end - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = idx + (uint32_t)u;
@@ -300,21 +301,22 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_kernel(
 
 // ------------------------------------------------------------------ staging kernels
 // sort key of every peak: high word = ((group * L + row) * n_bins + bin), low word =
-// (cycle inside the group << ADH_BIN_SHIFT) | low m/z bits.  One workgroup per spectrum.
+// (cycle inside the group << ADH_BIN_SHIFT) | low m/z bits.  One workgroup per spectrum of the slab
+// [spec0, spec0 + n_spec): peak j of the run is item j - peak0 of the slab.
 __global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t *__restrict__ pstart,
-                                    const int64_t *__restrict__ pstop, int64_t n_spectra, int L,
+                                    const int64_t *__restrict__ pstop, int64_t spec0, int64_t n_spec, int64_t peak0, int L,
                                     int block_shift, int bin0, int n_bins,
                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                     int *__restrict__ bad) {
-    const int64_t spec = blockIdx.x;
-    if (spec >= n_spectra) return;
+    if ((int64_t)blockIdx.x >= n_spec) return;
+    const int64_t spec = spec0 + blockIdx.x;
     const int64_t cyc = spec / L;
     const int row = (int)(spec - cyc * L);
     const int gs = block_shift + ADH_SUB_SHIFT;
     const int64_t grp = cyc >> gs;
     const uint32_t cin = (uint32_t)(cyc - (grp << gs));
     const uint64_t seg = (uint64_t)(grp * L + row) * (uint64_t)n_bins;
-    const int64_t ps = pstart[spec], pe = pstop[spec];
+    const int64_t ps = pstart[blockIdx.x] - peak0, pe = pstop[blockIdx.x] - peak0;
     for (int64_t j = ps + threadIdx.x; j < pe; j += blockDim.x) {
         const uint32_t bits = __float_as_uint(mz[j]);
         const int b = (int)(bits >> ADH_BIN_SHIFT) - bin0;
@@ -328,12 +330,15 @@ __global__ void adh_peak_key_kernel(const float *__restrict__ mz, const int64_t 
     }
 }
 
-// sorted keys -> 8-byte entries (low key word, intensity) + the bin table: with the fine key
-// g = (group, row, bin) * ADH_SUB + block inside the group, tab[g] = index of the first entry whose fine key
-// is >= g, for g = 0..n_tab-1
+// sorted keys of one slab (whole groups of blocks) -> 8-byte entries (low key word, intensity) + the slab's part of
+// the bin table.  With the fine key g = (group, row, bin) * ADH_SUB + block inside the group, the word of g is the
+// index of the first entry whose fine key is >= g, counted from the first entry of g's group (grp_entry0); the
+// word sits at g + group (every group's segment ends with a spare word: adh_tab_row).  The slab's entries start at
+// entry0 of the run; its fine keys are [g_first, g_last].
 __global__ void adh_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                   const float *__restrict__ inten, int64_t n, uint2 *__restrict__ entries,
-                                   uint32_t *__restrict__ tab, int64_t n_tab, int block_shift) {
+                                   const float *__restrict__ inten, int64_t n, int64_t entry0, uint2 *__restrict__ entries,
+                                   uint32_t *__restrict__ tab, int64_t g_first, int64_t g_last, int64_t words_per_group,
+                                   const int64_t *__restrict__ grp_entry0, int block_shift) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto fine = [block_shift](uint64_t key) -> int64_t {
@@ -341,9 +346,19 @@ __global__ void adh_entries_kernel(const uint64_t *__restrict__ keys, const uint
         return (int64_t)((key >> 32) << ADH_SUB_SHIFT) + (int64_t)(cin >> block_shift);
     };
     for (; i <= n; i += stride) {
-        const int64_t g_prev = (i == 0) ? -1 : fine(keys[i - 1]);
-        const int64_t g_cur = (i == n) ? n_tab - 1 : fine(keys[i]);
-        for (int64_t g = g_prev + 1; g <= g_cur; ++g) tab[g] = (uint32_t)i;
-        if (i < n) entries[i] = make_uint2((uint32_t)keys[i], __float_as_uint(inten[vals[i]]));
+        const int64_t g_prev = (i == 0) ? g_first - 1 : fine(keys[i - 1]);
+        const int64_t g_cur = (i == n) ? g_last : fine(keys[i]);
+        for (int64_t g = g_prev + 1; g <= g_cur; ++g) {
+            const int64_t grp = g / words_per_group;
+            tab[g + grp] = (uint32_t)(entry0 + i - grp_entry0[grp]);
+        }
+        if (i < n) entries[entry0 + i] = make_uint2((uint32_t)keys[i], __float_as_uint(inten[vals[i]]));
     }
+}
+
+// the spare word that ends every group's segment of the table: the group's entry count
+__global__ void adh_tab_spare_kernel(uint32_t *__restrict__ tab, int64_t n_groups, int64_t words_per_group,
+                                     const int64_t *__restrict__ grp_entry0) {
+    const int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (grp < n_groups) tab[(grp + 1) * words_per_group + grp] = (uint32_t)(grp_entry0[grp + 1] - grp_entry0[grp]);
 }

@@ -35,13 +35,14 @@ __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window 
     const int f_lo = max(c0, cyc_base) - grp_base;
     const int f_hi = min(c0 + F, cyc_base + (1 << bs)) - grp_base;
     const uint32_t *t = adh_tab_row(run, row, blk) + (blk & (ADH_SUB - 1));
+    const uint2 *ent = adh_group_entries(run, blk);
     for (int b = w.b_lo; b <= w.b_hi; ++b) {  // bin after bin: a cell keeps ascending m/z
         uint32_t idx = t[b * ADH_SUB];
         const uint32_t end = t[b * ADH_SUB + 1];
         while (idx < end) {
             uint2 e[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) e[u] = run.entries[min(idx + (uint32_t)u, end - 1)];
+            for (int u = 0; u < 4; ++u) e[u] = ent[min(idx + (uint32_t)u, end - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = idx + (uint32_t)u;

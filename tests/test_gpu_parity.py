@@ -161,6 +161,50 @@ def test_requantification_configs_take_the_fused_kernel(ctx, oracle_lib, monkeyp
         assert gather_fused < 0.25 * gather_two and feature_fused > 0, (gather_fused, gather_two)
 
 
+@pytest.mark.parametrize("slab_peaks", [20_000, 333_333])
+def test_run_staged_in_slabs_scores_identically(ctx, monkeypatch, slab_peaks):
+    """Runs of 2^32 peaks and more are sorted into the transposed layout slab by slab (whole groups of cycle
+    blocks, < 2^31 peaks each) and the bin table counts from the first entry of every group.  ADH_STAGE_SLAB_PEAKS
+    shrinks the slabs so that a small run is staged that way: every table of the fused kernel, of the two-kernel
+    path and of candidate selection must come out bit for bit as from one slab."""
+    from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelection
+
+    g = H.load_scoring_golden("handler_default")
+    names = dict(rt_column="rt_library", mobility_column="mobility_library", precursor_mz_column="mz_library",
+                 fragment_mz_column="mz_library")
+    scfg = CandidateSelectionConfig()
+    scfg.update(dict(rt_tolerance=30.0, candidate_count=2))
+
+    def everything():
+        fused, soa = hip_score(ctx, g, g.config, with_stats=True)
+        fused = {k: np.array(v, copy=True) for k, v in fused.items()}
+        with monkeypatch.context() as mp:
+            mp.setenv("ADH_DEBUG_NO_FUSED", "1")
+            two, _ = hip_score(ctx, g, g.config, soa=soa, with_stats=True)
+            two = {k: np.array(v, copy=True) for k, v in two.items()}
+        sel = HipCandidateSelection(g.dia, g.library.precursor_df, g.library.fragment_df, scfg, device=0, **names)()
+        return fused, two, sel
+
+    one = everything()
+    assert g.dia.mz_values.size > 3 * slab_peaks or slab_peaks > 100_000
+    with monkeypatch.context() as mp:
+        mp.setenv("ADH_STAGE_SLAB_PEAKS", str(slab_peaks))
+        mp.setenv("ADH_BLOCK_CYCLES", "2")  # small blocks: several groups of blocks, so several slabs
+        many = everything()
+    with monkeypatch.context() as mp:
+        mp.setenv("ADH_BLOCK_CYCLES", "2")
+        same_blocks = everything()
+    for a, b in ((one, many), (same_blocks, many)):
+        for k in a[0]:
+            assert np.array_equal(a[0][k], b[0][k], equal_nan=True), k
+            assert np.array_equal(a[1][k], b[1][k], equal_nan=True), k
+        import pandas as pd
+
+        pd.testing.assert_frame_equal(a[2], b[2])
+    assert one[0]["valid"].sum() > 100 and len(one[2]) > 100
+    ctx.stage_run(g.dia, force=True)  # (leave the handle with the default staging)
+
+
 def test_fitted_quadrupole_on_every_kernel(ctx, oracle_lib, monkeypatch):
     """A fitted quadrupole calibration (SimpleQuadrupoleJit.sigma / .delta_mu, quadrupole.py:72-113) reaches all
     four places the transfer function is evaluated: the fused kernel, the two-kernel register path
