@@ -1,5 +1,5 @@
-"""Runs with more than 2^32 detector events (real diaPASEF runs have them; the reference's arrays are int64
-throughout: bruker_jit.py:22-55).
+"""Runs with more than 2^32 detector events / peaks (real diaPASEF and long Astral runs have them; the reference's
+arrays are int64 throughout: bruker_jit.py:22-55, alpharaw_jit.py:78-97).
 
 The ion-mobility kernels carry event numbers in 64 bits; what they keep in 32 bits counts from the first event
 of a TOF bin (index columns) or of a window's first bin (pair ranges).  The golden run is pushed behind two
@@ -95,3 +95,92 @@ def test_transposition_of_more_than_two_to_the_31_events():
         a, b = int(indptr[t]), int(indptr[t + 1])
         assert np.array_equal(push[a:b], (where // per_push).astype(np.uint32))
         assert np.array_equal(out_val[a:b], val[where])
+
+
+def test_alpharaw_run_of_more_than_two_to_the_32_peaks(monkeypatch):
+    """An AlphaRaw run of 4.5e9 peaks (36 GB): the golden run pushed behind 192 cycles that hold three dummy
+    MS1 spectra of 1.5e9 peaks each (one per group of cycle blocks; below every m/z window of a candidate in
+    time, so nothing reads them), so that every real entry number exceeds 2^32.  The bin table counts from the
+    first entry of every group of blocks and the run is sorted slab by slab (round 4; round 3 refused such a run):
+    the fused kernel, the two-kernel path and candidate selection must give what they give on the run itself."""
+    import pandas as pd
+
+    from alphadia_amd import runtime
+    from alphadia_amd.selection import CandidateSelectionConfig, HipCandidateSelection
+    ctx = runtime.get_context(0)
+    from alphadia_amd.scoring import CandidateScoringConfig
+
+    g = syn.make_case(600, 400, config_id=61, per_precursor=2, planted_fraction=0.5, threads=8)
+    g.config = CandidateScoringConfig()
+    g.config.update(dict(top_k_isotopes=3, precursor_mz_tolerance=10, fragment_mz_tolerance=15, quant_all=True,
+                         experimental_xic=True))
+    names = dict(rt_column="rt_library", mobility_column="mobility_library", precursor_mz_column="mz_library",
+                 fragment_mz_column="mz_library")
+    scfg = CandidateSelectionConfig()
+    scfg.update(dict(rt_tolerance=15.0, candidate_count=2))
+
+    cols = fragment_columns(g.library.fragment_df, "mz_library")
+
+    def everything(case_like, soa):
+        ctx.stage_run(case_like.dia, force=True)  # (once: 36 GB of peaks go through it for the big run)
+        ctx.stage_fragments(*cols, force=True)
+        fused = ctx.score_host(pack_assembled(soa), g.config.to_jitclass(), with_stats=True)
+        fused = {k: np.array(v, copy=True) for k, v in fused.items()}
+        with monkeypatch.context() as mp:
+            mp.setenv("ADH_DEBUG_NO_FUSED", "1")
+            two = ctx.score_host(pack_assembled(soa), g.config.to_jitclass(), with_stats=True)
+            two = {k: np.array(v, copy=True) for k, v in two.items()}
+        sel = HipCandidateSelection(case_like.dia, case_like.library.precursor_df, case_like.library.fragment_df, scfg,
+                                    device=0, **names)()
+        return fused, two, sel
+
+    monkeypatch.setenv("ADH_BLOCK_CYCLES", "8")  # blocks of 8 cycles, groups of 64
+    soa0 = H.soa_for(g, g.config)
+    ref = everything(g, soa0)
+    dia = g.dia
+    L = dia.cycle_len
+    pad_cycles, dummy = 192, 1_500_000_000
+    n0 = int(dia.mz_values.size)
+    try:
+        mz = np.empty(3 * dummy + n0, np.float32)
+        inten = np.empty(3 * dummy + n0, np.float32)
+    except MemoryError:
+        pytest.skip("not enough host memory for a 2^32-peak run")
+    mz[: 3 * dummy] = np.float32(dia.mz_values.min())
+    inten[: 3 * dummy] = 1.0
+    mz[3 * dummy:] = dia.mz_values
+    inten[3 * dummy:] = dia.intensity_values
+    n_pad = pad_cycles * L
+    counts = np.zeros(n_pad, np.int64)
+    counts[[0, 64 * L, 128 * L]] = dummy  # the MS1 spectrum of cycles 0, 64, 128: one dummy spectrum per group of blocks
+    pad_stop = np.cumsum(counts)
+    start = np.concatenate([pad_stop - counts, 3 * dummy + np.asarray(dia.peak_start_idx_list, np.int64)])
+    stop = np.concatenate([pad_stop, 3 * dummy + np.asarray(dia.peak_stop_idx_list, np.int64)])
+    # the time axis runs on backwards with the run's own spacing (the smoothing kernel of the selection is sized
+    # from the mean cycle time)
+    dt = np.float64(dia.rt_values[L] - dia.rt_values[0]) / L
+    rt = np.concatenate([(dia.rt_values[0] - dt * np.arange(n_pad, 0, -1)).astype(np.float32), dia.rt_values])
+    big = syn.AlphaRawArrays(cycle=dia.cycle, rt_values=rt, peak_start_idx_list=start, peak_stop_idx_list=stop,
+                             mz_values=mz, intensity_values=inten)
+    assert big.mz_values.size > 1 << 32 and start[n_pad] > 1 << 32
+    from types import SimpleNamespace
+
+    shifted = dict(soa0)
+    for c in ("frame_start", "frame_stop", "frame_center"):
+        shifted[c] = soa0[c] + n_pad
+    case_big = SimpleNamespace(dia=big, library=g.library, candidates_df=g.candidates_df)
+    got = everything(case_big, shifted)
+    assert ref[0]["valid"].sum() > 100 and len(ref[2]) > 100
+    for a, b in ((ref[0], got[0]), (ref[1], got[1])):
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    sel_ref, sel_big = ref[2], got[2].copy()
+    for c in ("frame_start", "frame_stop", "frame_center"):
+        sel_big[c] = sel_big[c] - n_pad
+    # (a precursor whose search window reaches the first cycles of the run sees a run that starts earlier: the
+    # others - library RT a minute or more into the run - must get the same boxes)
+    late = g.library.precursor_df.loc[g.library.precursor_df["rt_library"].values > 60.0, "precursor_idx"].values
+    inner = lambda df: df[df["precursor_idx"].isin(late)].reset_index(drop=True)  # noqa: E731
+    pd.testing.assert_frame_equal(inner(sel_ref), inner(sel_big))
+    assert len(inner(sel_ref)) > 300
+    ctx.stage_run(g.dia, force=True)  # (release the 36 GB)
