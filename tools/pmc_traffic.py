@@ -1,5 +1,5 @@
 """profiles/pmc_traffic.json from a PMC summary (tools/rocpd_summary.py output of the FETCH_SIZE and WRITE_SIZE
-passes of tools/profile_r3.sh): HBM-side bytes of one scoring step of the headline bench = everything the
+passes of tools/profile_r4.sh): HBM-side bytes of one scoring step of the headline bench = everything the
 scoring kernels (adh_fused_kernel, and the two-kernel fallback: adh_gather_kernel, adh_feature*) moved, divided
 by the number of passes over the candidate table the profiled command made.
 
@@ -37,6 +37,8 @@ def main(path, passes, n_cand):
         "write_bytes": write,
         "per_kernel_fetch_bytes": {k: 2.0 * v for k, v in sorted(per["FETCH_SIZE"].items())},
         "per_kernel_write_bytes": dict(sorted(per["WRITE_SIZE"].items())),
+        "git_head": os.environ.get("GIT_HEAD", "unknown"),
+        "recipe": "tools/profile_r4.sh",
         "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {os.path.basename(path)}), KB -> bytes, summed "
                 f"over all launches of the scoring kernels and divided by the {passes:g} passes over the candidate table the "
                 "profiled command made (one pass = all chunks of one adh_score_candidates call, or one resident step). "
