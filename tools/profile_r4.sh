@@ -1,4 +1,5 @@
 #!/bin/bash
+# (tools/rocpd_summary.py reads a database as kernel statistics when its path holds "stats", as counters otherwise)
 # Profiling recipe of the committed profiles/r04_* files (GPU box, from the repo root via gpurun).  Every PMC pass is a
 # run of its own, never together with a trace domain other than --kernel-trace.
 #   headline  : kernel-trace statistics + PMC passes of `bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extras`
@@ -28,10 +29,10 @@ for i in 1 2 3 4; do python $REPO/tools/rocpd_summary.py /tmp/p4_pmc$i/r4_result
 # ---- configs[3]
 export N_PREC=200000 N_CYCLES=2000 SCAN_MAX=918 N_TOF=400000 EVENTS_PER_PUSH=30 ADH_BENCH_NO_CPU=1 STEPS=3 TOUCHED_SAMPLE=20
 CMD="python $REPO/tools/bench_timstof.py"
-rocprofv3 --kernel-trace --stats -d /tmp/p4_im -o p -- $CMD > $OUT/p4_im.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p4_im_stats -o p -- $CMD > $OUT/p4_im.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d /tmp/p4_imf -o p -- $CMD > $OUT/p4_imf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/p4_imw -o p -- $CMD > $OUT/p4_imw.log 2>&1
-python $REPO/tools/rocpd_summary.py /tmp/p4_im/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_timstof_kernel_stats.csv
+python $REPO/tools/rocpd_summary.py /tmp/p4_im_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_timstof_kernel_stats.csv
 for d in f w; do python $REPO/tools/rocpd_summary.py /tmp/p4_im$d/p_results.db | grep "^#\|kernel,\|adh_gather_im\|adh_feature_im"; done > $OUT/r04_timstof_pmc.csv
 python - <<PY
 import json
@@ -56,10 +57,10 @@ PY
 unset N_PREC N_CYCLES SCAN_MAX N_TOF EVENTS_PER_PUSH ADH_BENCH_NO_CPU STEPS TOUCHED_SAMPLE
 
 # ---- fragment competition, configs[4]
-rocprofv3 --kernel-trace --stats -d /tmp/p4_fc -o p -- python $REPO/tools/bench_legs.py fragcomp > $OUT/p4_fc.log 2>&1
-python $REPO/tools/rocpd_summary.py /tmp/p4_fc/p_results.db | grep -v "rocclr" > $OUT/r04_fragcomp_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d /tmp/p4_mx -o p -- python $REPO/tools/bench_legs.py multiplex > $OUT/p4_mx.log 2>&1
-python $REPO/tools/rocpd_summary.py /tmp/p4_mx/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_multiplex_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d /tmp/p4_fc_stats -o p -- python $REPO/tools/bench_legs.py fragcomp > $OUT/p4_fc.log 2>&1
+python $REPO/tools/rocpd_summary.py /tmp/p4_fc_stats/p_results.db | grep -v "rocclr" > $OUT/r04_fragcomp_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d /tmp/p4_mx_stats -o p -- python $REPO/tools/bench_legs.py multiplex > $OUT/p4_mx.log 2>&1
+python $REPO/tools/rocpd_summary.py /tmp/p4_mx_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_multiplex_kernel_stats.csv
 rm -rf /tmp/p4_*
 
 # ---- the bench line itself (driver style), with the traffic files of this run in place
