@@ -269,6 +269,8 @@ int adh_create(adh_handle_t **handle, int device) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutSmall, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
+    (void)hipFuncSetAttribute((const void *)adh_feature_im_kernel<featim::LayoutCommon2, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - ADH_IM_STATIC_LDS);
     (void)hipFuncSetAttribute((const void *)adh_gather_im_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();

@@ -184,17 +184,17 @@ __host__ __device__ inline uint64_t adh_im_scratch_bytes(uint32_t k_cap, int O, 
 // Rows are zero-padded to the capacities, the frame axis is stored CENTRED (entry r <-> cycle r - FM/2 + F/2),
 // so the reader takes whole rows with vector loads and constant register indices.
 #define ADH_IM_PROF_K 12
-template <int FM, int SM>
+template <int FM, int SM, int NO = 1>
 struct __attribute__((aligned(16))) ImProfRec {
     uint32_t K0, pad0[3];
-    double ohe[ADH_IM_PROF_K], omz[ADH_IM_PROF_K];  // weighted centre means of the (fragment, observation 0) planes
-    double hp[4], omzp[4];                          // ... of the isotope planes
-    float tsum, pad1[3];                            // template sum
+    double ohe[ADH_IM_PROF_K][NO], omz[ADH_IM_PROF_K][NO];  // weighted centre means of the (fragment, observation) planes
+    double hp[4], omzp[4];                                  // ... of the isotope planes
+    float tsum[NO], pad1[4 - NO];                           // template sums
     float spi[4], iso_int[4], iso_mz[4];
-    float tfp_raw[FM];                              // template frame profile (sum over scans), centred
-    float tsp_raw[SM];                              // template scan profile (sum over cycles)
-    float ffp[ADH_IM_PROF_K][FM];                   // fragment frame profiles before the presence mask, centred
-    float fsp[ADH_IM_PROF_K][SM];                   // fragment scan profiles
+    float tfp_raw[NO][FM];                                  // template frame profiles (sum over scans), centred
+    float tsp_raw[NO][SM];                                  // template scan profiles (sum over cycles)
+    float ffp[ADH_IM_PROF_K][NO][FM];                       // fragment frame profiles before the presence mask, centred
+    float fsp[ADH_IM_PROF_K][NO][SM];                       // fragment scan profiles
 };
 
 // Barrier of a ONE-wavefront block whose lanes talk through LDS.  A wavefront issues its LDS

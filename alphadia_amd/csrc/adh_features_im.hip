@@ -274,6 +274,9 @@ using Layout = LayoutT<DimsDyn>;
 // (13 704 + 2 560 static bytes: ten blocks per CU, as the specified 38 x 29 tiles get with run-time capacities)
 using DimsCommon = DimsFix<12, 1, 40, 32, 3, 1152>;
 using LayoutCommon = LayoutT<DimsCommon>;
+// the same shape with two observations (plan class 1; only the tile part of the split path uses it)
+using DimsCommon2 = DimsFix<12, 2, 40, 32, 3, 1152>;
+using LayoutCommon2 = LayoutT<DimsCommon2>;
 // small tiles (plan class ADH_CLASS_IM_SMALL): 10 248 + 2 560 bytes, twelve blocks per CU
 using DimsSmall = DimsFix<ADH_IM_SMALL_K, 1, ADH_IM_SMALL_S, ADH_IM_SMALL_F, 3, ADH_IM_SMALL_SF>;
 using LayoutSmall = LayoutT<DimsSmall>;
@@ -863,28 +866,35 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
             adh_wave_sync();
         }
         // ---- hand-over: profiles, template profiles and the per-plane means of this candidate
-        static_assert(LAY::Oc == 1 && LAY::Kc <= ADH_IM_PROF_K && LAY::Ic <= 4, "the split path is the one-observation shape");
-        typedef ImProfRec<LAY::Fc, LAY::Sc> Rec;
+        static_assert(LAY::Oc <= 2 && LAY::Kc <= ADH_IM_PROF_K && LAY::Ic <= 4, "the split path takes one or two observations");
+        constexpr int NOc = LAY::Oc;
+        typedef ImProfRec<LAY::Fc, LAY::Sc, NOc> Rec;
         Rec &rec = reinterpret_cast<Rec *>(prof)[blockIdx.x];
         constexpr int FMc = LAY::Fc, SMc = LAY::Sc;
         const int shift = F / 2 - FMc / 2;  // entry r <-> cycle r + shift
-        // template frame profile: sums over the scans, in scan order (the monolithic kernel takes it below)
-        for (int rr = lane; rr < FMc; rr += ADH_WAVE) {
-            const int f = rr + shift;
-            rec.tfp_raw[rr] = (f >= 0 && f < F) ? (sparse_tpl ? tfp_raw[f] : osum<SR>(tpl + f, F, S)) : 0.0f;
+        // template frame profiles: sums over the scans, in scan order (the monolithic kernel takes them below);
+        // observations beyond the candidate's own (a launch of up to two) are zero rows
+        for (int c = lane; c < NOc * FMc; c += ADH_WAVE) {
+            const int o = c / FMc, rr = c - o * FMc, f = rr + shift;
+            const bool on = o < O && f >= 0 && f < F;
+            rec.tfp_raw[o][rr] = on ? (sparse_tpl ? tfp_raw[f] : osum<SR>(tpl + o * SF + f, F, S)) : 0.0f;
         }
-        for (int sc = lane; sc < SMc; sc += ADH_WAVE) rec.tsp_raw[sc] = (sc < S) ? tsp_raw[sc] : 0.0f;
-        for (int c = lane; c < K0 * FMc; c += ADH_WAVE) {
-            const int k = c / FMc, rr = c - k * FMc, f = rr + shift;
-            rec.ffp[k][rr] = (f >= 0 && f < F) ? ffp_u[k * F + f] : 0.0f;
+        for (int c = lane; c < NOc * SMc; c += ADH_WAVE) {
+            const int o = c / SMc, sc = c - o * SMc;
+            rec.tsp_raw[o][sc] = (o < O && sc < S) ? tsp_raw[o * S + sc] : 0.0f;
         }
-        for (int c = lane; c < K0 * SMc; c += ADH_WAVE) {
-            const int k = c / SMc, sc = c - k * SMc;
-            rec.fsp[k][sc] = (sc < S) ? fsp_u[k * S + sc] : 0.0f;
+        for (int c = lane; c < K0 * NOc * FMc; c += ADH_WAVE) {
+            const int k = c / (NOc * FMc), rem = c - k * NOc * FMc, o = rem / FMc, rr = rem - o * FMc, f = rr + shift;
+            rec.ffp[k][o][rr] = (o < O && f >= 0 && f < F) ? ffp_u[(k * O + o) * F + f] : 0.0f;
         }
-        if (lane < K0) {
-            rec.ohe[lane] = ohe_u[lane];
-            rec.omz[lane] = omz_u[lane];
+        for (int c = lane; c < K0 * NOc * SMc; c += ADH_WAVE) {
+            const int k = c / (NOc * SMc), rem = c - k * NOc * SMc, o = rem / SMc, sc = rem - o * SMc;
+            rec.fsp[k][o][sc] = (o < O && sc < S) ? fsp_u[(k * O + o) * S + sc] : 0.0f;
+        }
+        for (int c = lane; c < K0 * NOc; c += ADH_WAVE) {
+            const int k = c / NOc, o = c - k * NOc;
+            rec.ohe[k][o] = o < O ? ohe_u[k * O + o] : 0.0;
+            rec.omz[k][o] = o < O ? omz_u[k * O + o] : 0.0;
         }
         if (lane < 4) {
             const bool on = lane < I;
@@ -894,10 +904,8 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
             rec.iso_int[lane] = on ? iso_int[lane] : 0.0f;
             rec.iso_mz[lane] = on ? iso_mz[lane] : 0.0f;
         }
-        if (lane == 0) {
-            rec.K0 = (uint32_t)K0;
-            rec.tsum = tsum[0];
-        }
+        if (lane < NOc) rec.tsum[lane] = lane < O ? tsum[lane] : 0.0f;
+        if (lane == 0) rec.K0 = (uint32_t)K0;
         return;
     }
     for (int k = lane; k < K0; k += ADH_WAVE) {

@@ -15,8 +15,10 @@
 //   * sums over fragments: lane k provides its term of every sum, lane j adds up sum j in fragment order
 //   * the arithmetic is that of adh_feature_im_kernel expression by expression (float64 rt / mobility typing of
 //     the ion-mobility arrays, bruker_jit.py:35,45): the two paths are held to identical bits by the GPU suite
-// One observation, <= 12 fragments, <= 3 isotopes, experimental_xic: plan classes 0 and ADH_CLASS_IM_SMALL with
-// the fixed layouts.  Everything else keeps the one-kernel path.
+// One or two observations (NO; with two, the rows of an observation are taken from the record where they are
+// needed - the profile sum over the observations is what stays in registers), <= 12 fragments, <= 3 isotopes,
+// experimental_xic: plan classes 0, 1 and ADH_CLASS_IM_SMALL with the fixed layouts.  Everything else keeps the
+// one-kernel path.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
@@ -27,7 +29,7 @@ using fused::Recip;
 
 constexpr int KMAX = ADH_IM_PROF_K;
 
-template <int FM, int SM>
+template <int FM, int SM, int NO>
 struct __attribute__((aligned(16))) GroupLds {
     union {
         struct {               // per-fragment terms of the feature sums: [fragment][sum]
@@ -42,16 +44,16 @@ struct __attribute__((aligned(16))) GroupLds {
     double merr[16];
     double red64[14];
     double hp[4], omzp[4];
-    float tfp_raw[FM], tfp[FM], med[FM];
-    float tsp_raw[SM], tsp[SM];
+    float tfp_raw[NO][FM], tfp[NO][FM], med[FM];
+    float tsp_raw[NO][SM], tsp[NO][SM];
     float g_int[16], g_fin[16], corr[16];
-    float mn[16], sd[16], ml[16], ftc2[16];
+    float mn[16], sd[NO][16], ml[16], ftc2[NO][16];
     float iso_int[4], iso_mz[4], spi[4];
     float feat[ADH_NUM_FEATURES + 2];
     float red32[4];
-    int fpeak[16];
+    int fpeak[16][NO];
     int ord[16];
-    int medlo, medhi;
+    int medlo[NO], medhi[NO];
 };
 
 #define F2_FOR_R _Pragma("unroll") for (int r = 0; r < FM; ++r)
@@ -88,18 +90,18 @@ __device__ __forceinline__ void moments(const float (&x)[N], int n, float &mean,
 
 }  // namespace featim2
 
-template <int FM, int SM>
+template <int FM, int SM, int NO>
 __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, adh_scoring_config_t cfg, int32_t n_iso_cols,
     const unsigned char *__restrict__ scratch, const unsigned char *__restrict__ prof, DevOut out) {
     using namespace featim2;
     constexpr int RC = FM / 2;
-    typedef ImProfRec<FM, SM> Rec;
-    __shared__ GroupLds<FM, SM> lds[ADH_WAVE / GS];
+    typedef ImProfRec<FM, SM, NO> Rec;
+    __shared__ GroupLds<FM, SM, NO> lds[ADH_WAVE / GS];
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
-    GroupLds<FM, SM> &Q = lds[g];
+    GroupLds<FM, SM, NO> &Q = lds[g];
     const int ci = (int)blockIdx.x * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
     const CandRecIM &cand = plan[alive ? ci : 0];
@@ -119,21 +121,44 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     const int top_k = out.top_k;
     auto gmask = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gsh) & 0xFFFFull); };
 
-    // ---- rows into registers; the small arrays into the group's LDS
+    // ---- the small arrays into the group's LDS; a fragment lane's rows are taken from the record where needed
     const bool frag_lane0 = alive && sub < K0;
-    float P[FM], Sp[SM];
-    F2_FOR_R P[r] = 0.0f;
-    F2_FOR_S Sp[i] = 0.0f;
-    double ohe_l = 0.0, omz_l = 0.0;
+    const int slot = frag_lane0 ? sub : 0;
+    // frame profile of observation o (centred), raw scan profile of observation o
+    auto load_P = [&](int o, float (&P)[FM]) {
+        F2_FOR_R P[r] = 0.0f;
+        if (frag_lane0) load_row4<FM>(P, rec.ffp[slot][o]);
+    };
+    auto load_Sp = [&](int o, float (&Sp)[SM]) {
+        F2_FOR_S Sp[i] = 0.0f;
+        if (frag_lane0) load_row4<SM>(Sp, rec.fsp[slot][o]);
+    };
+    // OR-envelope of a scan profile (scoring/utils.py:56-66): reads the raw neighbours, writes a copy
+    auto scan_envelope = [&](const float (&Sp)[SM], float (&Se)[SM]) {
+        F2_FOR_S {
+            float v = Sp[i];
+            if (i >= 1 && i + 1 < SM) {
+                const bool inner = i < S - 1;
+                const float xl = Sp[i - 1], xr = Sp[i + 1];
+                if (inner && (v < xl || v < xr)) {
+                    const float sm = xl + xr;
+                    v = (float)((double)sm / 2.0);
+                }
+            }
+            Se[i] = v;
+        }
+    };
+    double ohe_l[NO], omz_l[NO];
     fused::RawRec lrec;
     lrec.a = make_uint4(0u, 0u, 0u, 0u);
     lrec.b = 0u;
     uint32_t lib_slot = 0;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        ohe_l[o] = frag_lane0 ? rec.ohe[slot][o] : 0.0;
+        omz_l[o] = frag_lane0 ? rec.omz[slot][o] : 0.0;
+    }
     if (frag_lane0) {
-        load_row4<FM>(P, rec.ffp[sub]);
-        load_row4<SM>(Sp, rec.fsp[sub]);
-        ohe_l = rec.ohe[sub];
-        omz_l = rec.omz[sub];
         const LibRec *sel = reinterpret_cast<const LibRec *>(block + 32) + sub;
         lrec = fused::load_rec(sel);
         lib_slot = 1u + (uint32_t)sel->pad0 + 256u * (uint32_t)sel->pad1;
@@ -144,13 +169,15 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         const int rr = min(sub + 16 * pass, FM - 1);
         const int f = rr + shift;
         const bool ok = alive && f >= 0 && f < F;
-        Q.tfp_raw[rr] = alive ? rec.tfp_raw[rr] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) Q.tfp_raw[o][rr] = alive ? rec.tfp_raw[o][rr] : 0.0f;
         Q.frt[rr] = ok ? run.rt[cand.frame_start + f * L] : 0.0;
     }
 #pragma unroll
     for (int pass = 0; pass < (SM + 15) / 16; ++pass) {
         const int i = min(sub + 16 * pass, SM - 1);
-        Q.tsp_raw[i] = alive ? rec.tsp_raw[i] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) Q.tsp_raw[o][i] = alive ? rec.tsp_raw[o][i] : 0.0f;
     }
     if (sub < 4) {
         Q.hp[sub] = alive ? rec.hp[sub] : 0.0;
@@ -159,7 +186,9 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         Q.iso_int[sub] = alive ? rec.iso_int[sub] : 0.0f;
         Q.iso_mz[sub] = alive ? rec.iso_mz[sub] : 0.0f;
     }
-    const float tsum0 = alive ? rec.tsum : 0.0f;
+    float tsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) tsum[o] = alive ? rec.tsum[o] : 0.0f;
     // location_features.py:8-33 with float64 mobility / rt arrays
     float loc = 0.0f;
     double rt_width = 0.0, mob_width = 0.0;
@@ -174,20 +203,31 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     adh_wave_sync();
 
     // ---- observation importance (quadrupole.py:327-335), fragment presence (candidate.py:319-329)
-    float oi[1];
+    float oi[NO];
     {
         float tot = 0.0f;
-        tot += tsum0;
-        oi[0] = (tot == 0.0f) ? 1.0f / 1.0f : tsum0 / tot;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) tot += tsum[o];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) oi[o] = (tot == 0.0f) ? 1.0f / (float)NO : tsum[o] / tot;
     }
-    float rowsum_l;
-    {
+    int best_obs = 0;  // np.argmax: the first maximum (fragment_features.py:245)
+#pragma unroll
+    for (int o = 1; o < NO; ++o)
+        if (oi[o] > oi[best_obs]) best_obs = o;
+    // the lane's enveloped scan profile: kept in registers with one observation, taken again per use with two
+    float Se[SM];
+    float rowsum_l[NO], so = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        float Sp[SM];
+        load_Sp(o, Sp);
         float ss = 0.0f;
         F2_FOR_S ss += Sp[i];  // sum of the per-scan sums, in scan order
-        rowsum_l = frag_lane0 ? ss : 0.0f;
+        rowsum_l[o] = frag_lane0 ? ss : 0.0f;
+        so += rowsum_l[o];
+        if (NO == 1) scan_envelope(Sp, Se);
     }
-    float so = 0.0f;
-    so += rowsum_l;
     bool present = frag_lane0 && so > 0.0f;
     const unsigned gm = gmask(present);
     int K = __popc(gm);
@@ -220,59 +260,47 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     adh_wave_sync();
     if (present) Q.g_fin[kk] = g_fin_l;
 
-    // ---- OR-envelopes (scoring/utils.py:46-66): template frame profile, template scan profile (LDS), the
-    // lane's own scan profile (registers; reads the raw neighbours, writes a copy)
+    // ---- OR-envelopes of the template profiles (scoring/utils.py:46-66)
 #pragma unroll
-    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-        const int rr = min(sub + 16 * pass, FM - 1);
-        const int f = rr + shift;
-        const float x = Q.tfp_raw[rr];
-        float v = x;
-        if (f >= 1 && f < F - 1) {
-            const float xl = Q.tfp_raw[rr - 1], xr = Q.tfp_raw[rr + 1];
-            if (x < xl || x < xr) {
-                const float sm = xl + xr;
-                v = (float)((double)sm / 2.0);
-            }
-        }
-        Q.tfp[rr] = (f >= 0 && f < F) ? v : 0.0f;
-    }
+    for (int o = 0; o < NO; ++o) {
 #pragma unroll
-    for (int pass = 0; pass < (SM + 15) / 16; ++pass) {
-        const int i = min(sub + 16 * pass, SM - 1);
-        const float x = Q.tsp_raw[i];
-        float v = x;
-        if (i >= 1 && i < S - 1) {
-            const float xl = Q.tsp_raw[i - 1], xr = Q.tsp_raw[i + 1];
-            if (x < xl || x < xr) {
-                const float sm = xl + xr;
-                v = (float)((double)sm / 2.0);
+        for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+            const int rr = min(sub + 16 * pass, FM - 1);
+            const int f = rr + shift;
+            const float x = Q.tfp_raw[o][rr];
+            float v = x;
+            if (f >= 1 && f < F - 1) {
+                const float xl = Q.tfp_raw[o][rr - 1], xr = Q.tfp_raw[o][rr + 1];
+                if (x < xl || x < xr) {
+                    const float sm = xl + xr;
+                    v = (float)((double)sm / 2.0);
+                }
             }
+            Q.tfp[o][rr] = (f >= 0 && f < F) ? v : 0.0f;
         }
-        Q.tsp[i] = (i < S) ? v : 0.0f;
-    }
-    float Se[SM];
-    F2_FOR_S {
-        float v = Sp[i];
-        if (i >= 1 && i + 1 < SM) {
-            const bool inner = i < S - 1;
-            const float xl = Sp[i - 1], xr = Sp[i + 1];
-            if (inner && (v < xl || v < xr)) {
-                const float sm = xl + xr;
-                v = (float)((double)sm / 2.0);
+#pragma unroll
+        for (int pass = 0; pass < (SM + 15) / 16; ++pass) {
+            const int i = min(sub + 16 * pass, SM - 1);
+            const float x = Q.tsp_raw[o][i];
+            float v = x;
+            if (i >= 1 && i < S - 1) {
+                const float xl = Q.tsp_raw[o][i - 1], xr = Q.tsp_raw[o][i + 1];
+                if (x < xl || x < xr) {
+                    const float sm = xl + xr;
+                    v = (float)((double)sm / 2.0);
+                }
             }
+            Q.tsp[o][i] = (i < S) ? v : 0.0f;
         }
-        Se[i] = v;
     }
 
-    // ---- envelope, quantification (fragment_features.py:240-273; rt_values are float64 here)
+    // ---- envelope, quantification (fragment_features.py:240-273; rt_values are float64 here).  P = the frame
+    // profile summed over the observations, as the profile features see it: with quant_all the sum is quantified
+    // (a copy); without, the most important observation's profile is - a view, its envelope edit stays
     double area = 0.0;
     float obs_int = 0.0f;
-    {
-        float E[FM];  // quant_all: np.sum(axis=1) made a copy (0 + x for the single observation)
-        F2_FOR_R E[r] = P[r];
-        fused::center_envelope<FM>(E, F);
-        const int qw = min(c - 1, (int)cfg.quant_window);
+    const int qw = min(c - 1, (int)cfg.quant_window);
+    auto quantify = [&](const float (&E)[FM]) {
         double ar = 0.0;
 #pragma unroll
         for (int r = 1; r < FM - 1; ++r) {
@@ -283,34 +311,82 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
             ar += in ? m * 0.5 : 0.0;
         }
         area = ar * (double)qw;
-        F2_FOR_R obs_int += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
+        float acc = 0.0f;
+        F2_FOR_R acc += (r >= RC - qw && r <= RC + qw) ? E[r] : 0.0f;
+        obs_int = acc;
+    };
+    float P[FM];
+    if (NO == 1) {
+        load_P(0, P);
+        float E[FM];
+        F2_FOR_R E[r] = P[r];  // (quant_all: 0 + x for the single observation)
+        fused::center_envelope<FM>(E, F);
+        quantify(E);
         if (!cfg.quant_all) {
-            F2_FOR_R P[r] = E[r];  // a VIEW of the best observation's profile: edited in place
+            F2_FOR_R P[r] = E[r];
+        }
+    } else {
+        F2_FOR_R P[r] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            float A[FM];
+            load_P(o, A);
+            if (!cfg.quant_all && o == best_obs) {  // (per candidate: the lanes of a group agree)
+                fused::center_envelope<FM>(A, F);
+                quantify(A);
+            }
+            F2_FOR_R P[r] += A[r];
+        }
+        if (cfg.quant_all) {
+            float E[FM];
+            F2_FOR_R E[r] = P[r];
+            fused::center_envelope<FM>(E, F);
+            quantify(E);
         }
     }
     double m1 = 0.0, m2 = 0.0, merr_l = 0.0;
     bool hrow = false;
     if (present) {
-        // importance-weighted means over observations (fragment_features.py:311-336), one observation
-        if (oi[0] == 1.0f) {
-            hrow = ohe_l > 0;
+        // importance-weighted means over observations (fragment_features.py:311-336)
+        if (NO == 1 && oi[0] == 1.0f) {
+            hrow = ohe_l[0] > 0;
             if (hrow) {
-                m1 = omz_l;
-                m2 = ohe_l;
+                m1 = omz_l[0];
+                m2 = ohe_l[0];
             }
         } else {
-            const bool m = ohe_l > 0;
-            hrow = m;
-            const float w32 = m ? oi[0] : oi[0] * 0.0f;
             float ws = 0.0f;
-            ws += w32;
-            const double wd = (double)w32 / ((double)ws + 1e-20);
-            if (wd > 0) {
-                double msum = 0.0;
-                msum += wd;
-                const double lw = wd / msum;
-                m1 += omz_l * lw;
-                m2 += ohe_l * lw;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const bool m = ohe_l[o] > 0;
+                hrow = hrow || m;
+                const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                ws += w32;
+            }
+            double msum = 0.0;
+            int nm = 0;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const bool m = ohe_l[o] > 0;
+                const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                const double wd = (double)w32 / ((double)ws + 1e-20);
+                if (wd > 0) {
+                    msum += wd;
+                    ++nm;
+                }
+            }
+            if (nm > 0) {
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const bool m = ohe_l[o] > 0;
+                    const float w32 = m ? oi[o] : oi[o] * 0.0f;
+                    const double wd = (double)w32 / ((double)ws + 1e-20);
+                    if (wd > 0) {
+                        const double lw = wd / msum;
+                        m1 += omz_l[o] * lw;
+                        m2 += ohe_l[o] * lw;
+                    }
+                }
             }
         }
         merr_l = (m1 - (double)lrec_mz) / (double)lrec_mz * 1e6;  // fragment_features.py:387
@@ -353,11 +429,14 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         t[5] = ov ? merr_l : 0.0;
         // cosine_similarity_a1 (features_utils.py:40-47) of the observation sums
         float tn = 0.0f, fn = 0.0f, dot = 0.0f;
-        tn += tsum0 * tsum0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) tn += tsum[o] * tsum[o];
         tn = sqrtf(tn);
-        fn += rowsum_l * rowsum_l;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) fn += rowsum_l[o] * rowsum_l[o];
         fn = sqrtf(fn);
-        dot += rowsum_l * tsum0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) dot += rowsum_l[o] * tsum[o];
         const float pr = fn * tn;
         const float score = (float)((double)dot / ((double)pr + 0.0001));
         float *u = Q.u.at.t32[kk];
@@ -428,7 +507,7 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
                 ft[16 + sub] = ((sub == 9 ? nb : ny) > 0) ? lg : 0.0f;
             }
             if (sub == 11) ft[41] = (float)quo;
-            if (sub == 9) ft[28] = (float)quo, ft[17] = 1.0f;
+            if (sub == 9) ft[28] = (float)quo, ft[17] = (float)NO;
         }
     }
     adh_wave_sync();
@@ -467,13 +546,20 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         if (on) Q.feat[18 + sub] = (float)cc;
     }
     if (alive && sub == 2) Q.feat[27] = Q.feat[25] - Q.feat[26];
-    if (alive && sub == 3) fused::precursor_features<1>(Q.feat, I, Q.iso_int, Q.iso_mz, Q.spi, Q.hp, &Q.red64[4], oi);
+    if (alive && sub == 3) fused::precursor_features<NO>(Q.feat, I, Q.iso_int, Q.iso_mz, Q.spi, Q.hp, &Q.red64[4], oi);
     adh_wave_sync();  // (the term tables are dead: the centred scan rows take their place)
 
     // =========================== fragment_mobility_correlation (fragment_features.py:430-480) ============
-    // fragments whose (enveloped) scan profiles hold any signal, in order (fragment_features.py:447-452)
+    // fragments whose (enveloped) scan profiles hold any signal over the observations, in order
+    // (fragment_features.py:447-452)
     float so_m = 0.0f;
-    {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        if (NO > 1) {
+            float Sp[SM];
+            load_Sp(o, Sp);
+            scan_envelope(Sp, Se);
+        }
         float ss = 0.0f;
         F2_FOR_S ss += Se[i];
         so_m += ss;
@@ -493,76 +579,87 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         if (keep) mnorm_l = g_int_l / isum;
     }
     adh_wave_sync();
-    {
-        // centred row + std over the scan axis (scoring/utils.py:545-559) and, with the centred row still in
-        // registers, its correlation with the template's scan profile (scoring/utils.py:574-647)
-        float py[SM];
-        F2_FOR_S py[i] = Q.tsp[i];
-        float mean, sd, ym, ysd;
-        moments<SM>(Se, S, mean, sd);
-        moments<SM>(py, S, ym, ysd);
-        float dot = 0.0f;
-        F2_FOR_S {
-            float d = Se[i] - mean;
-            d = (i < S) ? d : 0.0f;
-            if (keep && corr_on) Q.u.cen[am][i] = d;
-            dot += d * (py[i] - ym);
-        }
-        const float cov = dot / (float)S;
-        const float smm = sd * ysd;
-        if (keep) {
-            Q.mn[am] = mnorm_l;
-            Q.sd[am] = sd;
-            Q.ftc2[am] = (float)((double)cov / ((double)smm + 1e-12));
-        }
-    }
-    adh_wave_sync();
-    // np.dot(profile_centered, profile_centered.T) over the scan axis (BLAS SGEMM in the reference): one MFMA
-    // chain per candidate, as adh_feature_im_kernel issues it (same operands, same order of the scan steps), by
-    // all 64 lanes for each of the wavefront's four candidates in turn.  Every lane gets here: no early return
-    // above, a candidate without a correlation contributes zero operands and ignores the result.
-    {
-        typedef float floatx4 __attribute__((ext_vector_type(4)));
-        const int i = lane & 15, kq = lane >> 4;
-        floatx4 d4[ADH_WAVE / GS];
+    if (keep) Q.mn[am] = mnorm_l;
+    float red_row[KMAX];  // row `am` of the normalised correlation matrix, summed over the observations
 #pragma unroll
-        for (int gg = 0; gg < ADH_WAVE / GS; ++gg) {
-            const int S_g = __shfl(corr_on ? S : 0, gg * GS);
-            const int Km_g = __shfl(Km, gg * GS);
-            floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-            // (a rolled loop: see adh_features_im.hip on what hipcc 7.2 does to the unrolled chain)
-            for (int s0 = 0; s0 < S_g; s0 += 4) {
-                const int sc = s0 + kq;
-                const float v = (i < Km_g && sc < S_g) ? lds[gg].u.cen[i][sc] : 0.0f;
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
+    for (int b = 0; b < KMAX; ++b) red_row[b] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        if (NO > 1) {
+            adh_wave_sync();  // (the previous observation's Gram matrix has been read)
+            float Sp[SM];
+            load_Sp(o, Sp);
+            scan_envelope(Sp, Se);
+        }
+        {
+            // centred row + std over the scan axis (scoring/utils.py:545-559) and, with the centred row still in
+            // registers, its correlation with the template's scan profile (scoring/utils.py:574-647)
+            float py[SM];
+            F2_FOR_S py[i] = Q.tsp[o][i];
+            float mean, sd, ym, ysd;
+            moments<SM>(Se, S, mean, sd);
+            moments<SM>(py, S, ym, ysd);
+            float dot = 0.0f;
+            F2_FOR_S {
+                float d = Se[i] - mean;
+                d = (i < S) ? d : 0.0f;
+                if (keep && corr_on) Q.u.cen[am][i] = d;
+                dot += d * (py[i] - ym);
             }
-            d4[gg] = d;
+            const float cov = dot / (float)S;
+            const float smm = sd * ysd;
+            if (keep) {
+                Q.sd[o][am] = sd;
+                Q.ftc2[o][am] = (float)((double)cov / ((double)smm + 1e-12));
+            }
         }
-        adh_wave_sync();  // every chain has read its rows: the Gram matrices take their place
+        adh_wave_sync();
+        // np.dot(profile_centered, profile_centered.T) over the scan axis (BLAS SGEMM in the reference): one MFMA
+        // chain per candidate and observation, as adh_feature_im_kernel issues it (same operands, same order of the
+        // scan steps), by all 64 lanes for each of the wavefront's four candidates in turn.  Every lane gets here: no
+        // early return above, a candidate without a correlation contributes zero operands and ignores the result.
+        {
+            typedef float floatx4 __attribute__((ext_vector_type(4)));
+            const int i = lane & 15, kq = lane >> 4;
+            floatx4 d4[ADH_WAVE / GS];
 #pragma unroll
-        for (int gg = 0; gg < ADH_WAVE / GS; ++gg) {
+            for (int gg = 0; gg < ADH_WAVE / GS; ++gg) {
+                const int S_g = __shfl(corr_on ? S : 0, gg * GS);
+                const int Km_g = __shfl(Km, gg * GS);
+                floatx4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                // (a rolled loop: see adh_features_im.hip on what hipcc 7.2 does to the unrolled chain)
+                for (int s0 = 0; s0 < S_g; s0 += 4) {
+                    const int sc = s0 + kq;
+                    const float v = (i < Km_g && sc < S_g) ? lds[gg].u.cen[i][sc] : 0.0f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, d, 0, 0, 0);
+                }
+                d4[gg] = d;
+            }
+            adh_wave_sync();  // every chain has read its rows: the Gram matrices take their place
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) lds[gg].u.gram[4 * kq + rr][i] = d4[gg][rr];
+            for (int gg = 0; gg < ADH_WAVE / GS; ++gg) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) lds[gg].u.gram[4 * kq + rr][i] = d4[gg][rr];
+            }
         }
-    }
-    adh_wave_sync();
-    {
-        // row a of the normalised correlation matrix, weighted by the observation importance and the
-        // intensities: one (a, b) pair per step, every pair its own float64 division
-        float acc = 0.0f;
+        adh_wave_sync();
         if (keep && corr_on) {
-            const float sda = Q.sd[am];
+            // one (a, b) pair per step, every pair its own float64 division; weighted by the observation importance
+            const float sda = Q.sd[o][am];
 #pragma unroll
             for (int b = 0; b < KMAX; ++b) {
                 const float cov = Q.u.gram[am][b] / (float)S;
-                const float smm = sda * Q.sd[min(b, max(Km - 1, 0))];
+                const float smm = sda * Q.sd[o][min(b, max(Km - 1, 0))];
                 const float cm = (float)((double)cov / ((double)smm + 1e-12));
-                float red = 0.0f;
-                red += cm * oi[0];
-                acc += (b < Km) ? red * Q.mn[b] : 0.0f;
+                red_row[b] += cm * oi[o];
             }
-            Q.ml[am] = acc;
         }
+    }
+    if (keep && corr_on) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < KMAX; ++b) acc += (b < Km) ? red_row[b] * Q.mn[b] : 0.0f;
+        Q.ml[am] = acc;
     }
     adh_wave_sync();
     if (corr_on && sub == 0) {
@@ -574,7 +671,8 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
 #pragma unroll
         for (int a = 0; a < KMAX; ++a) {
             float rr = 0.0f;
-            rr += Q.ftc2[min(a, max(Km - 1, 0))] * oi[0];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) rr += Q.ftc2[o][min(a, max(Km - 1, 0))] * oi[o];
             dot += (a < Km) ? rr * Q.mn[a] : 0.0f;
         }
         Q.feat[30] = dot;
@@ -659,54 +757,65 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         const double var_xy = var_x * var_y;
         corr_l = (var_xy == 0) ? 0.0f : (float)(cov / sqrt(var_xy));
     }
-    // frame statistics against the template frame profile, FWHM in RT / mobility, apex
+    // frame statistics of every observation against its template frame profile, FWHM in RT / mobility, apex
     // (scoring/utils.py:574-647, profile_features.py:117-193)
-    float ftc_l, fw_l, mfw_l;
-    int fpeak_l;
-    {
+    float ftc_l[NO], fw_l[NO], mfw_l[NO];
+    int fpeak_l[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        float A[FM];
+        if (NO == 1) {
+            F2_FOR_R A[r] = P[r];
+        } else {
+            load_P(o, A);
+            if (!cfg.quant_all && o == best_obs) fused::center_envelope<FM>(A, F);  // (the view's edit, taken again)
+            float Sp[SM];
+            load_Sp(o, Sp);
+            scan_envelope(Sp, Se);
+        }
         const float Ff = (float)F;
         float syt = 0.0f;
-        F2_FOR_R syt += Q.tfp[r];
+        F2_FOR_R syt += Q.tfp[o][r];
         const float ym = syt / Ff;
         float qy = 0.0f;
         F2_FOR_R {
-            float d = Q.tfp[r] - ym;
+            float d = Q.tfp[o][r] - ym;
             d = F2_OK(r) ? d : 0.0f;
             qy += d * d;
         }
         const float ysd = sqrtf(qy / Ff);
         float sy = 0.0f;
-        F2_FOR_R sy += P[r];
+        F2_FOR_R sy += A[r];
         const float xmn = sy / Ff;
         float qx = 0.0f, dot = 0.0f;
         F2_FOR_R {
-            float d = P[r] - xmn;
+            float d = A[r] - xmn;
             d = F2_OK(r) ? d : 0.0f;
             qx += d * d;
         }
         const float xsd = sqrtf(qx / Ff);
         F2_FOR_R {
-            float dx = P[r] - xmn;
-            const float dy = Q.tfp[r] - ym;
+            float dx = A[r] - xmn;
+            const float dy = Q.tfp[o][r] - ym;
             dx = F2_OK(r) ? dx : 0.0f;
             dot += dx * dy;
         }
         const float cv = dot / Ff;
         const float smm = xsd * ysd;
-        ftc_l = (float)((double)cv / ((double)smm + 1e-12));
+        ftc_l[o] = (float)((double)cv / ((double)smm + 1e-12));
         float mxv = -1.0f;
         int am_r = 0;
         F2_FOR_R {
-            const bool up = F2_OK(r) && P[r] > mxv;
-            mxv = up ? P[r] : mxv;
+            const bool up = F2_OK(r) && A[r] > mxv;
+            mxv = up ? A[r] : mxv;
             am_r = up ? r : am_r;
         }
         const double half = (double)mxv / 2.0;
         int n_above = 0;
-        F2_FOR_R n_above += (F2_OK(r) && (double)P[r] > half) ? 1 : 0;
+        F2_FOR_R n_above += (F2_OK(r) && (double)A[r] > half) ? 1 : 0;
         const double frac = (double)n_above / (double)F;
-        fw_l = (float)(frac * rt_width);
-        fpeak_l = am_r + shift;
+        fw_l[o] = (float)(frac * rt_width);
+        fpeak_l[o] = am_r + shift;
         // mobility FWHM (profile_features.py:151-188) on the enveloped scan profile
         float mxs = Se[0];
         F2_FOR_S mxs = (i >= 1 && i < S && Se[i] > mxs) ? Se[i] : mxs;
@@ -714,34 +823,40 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         int n_ab = 0;
         F2_FOR_S n_ab += (i < S && (double)Se[i] > halfs) ? 1 : 0;
         const double fracs = (double)n_ab / (double)S;
-        mfw_l = (float)(fracs * mob_width);
+        mfw_l[o] = (float)(fracs * mob_width);
+        Q.fpeak[sub][o] = fpeak_l[o];
     }
-    Q.fpeak[sub] = fpeak_l;
     if (present) Q.corr[kk] = corr_l;
     adh_wave_sync();
     // ---- features 31-40: sums organised as above
     {
         const int r_lo = (K - 1) / 2, r_hi = K / 2;
         if (present) {
-            // median apex (profile_features.py:196-198): rank of this fragment's apex
-            const int va = fpeak_l;
-            int rk = 0;
+            // median apex per observation (profile_features.py:196-198): rank of this fragment's apex
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if (!((gm >> b) & 1u)) continue;
-                const int vb = Q.fpeak[b];
-                rk += (vb < va) || (vb == va && b < sub);
+            for (int o = 0; o < NO; ++o) {
+                const int va = fpeak_l[o];
+                int rk = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (!((gm >> b) & 1u)) continue;
+                    const int vb = Q.fpeak[b][o];
+                    rk += (vb < va) || (vb == va && b < sub);
+                }
+                if (rk == r_lo) Q.medlo[o] = va;
+                if (rk == r_hi) Q.medhi[o] = va;
             }
-            if (rk == r_lo) Q.medlo = va;
-            if (rk == r_hi) Q.medhi = va;
             const float cr = Q.corr[Q.ord[kk]];  // correlation of the fragment with intensity rank kk
             // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
             const bool b3 = isb && __popc(b_isb & ((1u << sub) - 1u)) < 3;
             const bool y3 = isy && __popc(b_isy & ((1u << sub) - 1u)) < 3;
             float rr = 0.0f, ml = 0.0f, mm = 0.0f;
-            rr += ftc_l * oi[0];
-            ml += fw_l * oi[0];
-            mm += mfw_l * oi[0];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) rr += ftc_l[o] * oi[o];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) ml += fw_l[o] * oi[o];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) mm += mfw_l[o] * oi[o];
             float *u = Q.u.at.t32[kk];  // (the Gram matrix / transpose buffer are dead)
             u[0] = corr_l;
             u[1] = rr * g_int_l;
@@ -777,9 +892,12 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
             if (sub == 7) ft[39] = s39;
             if (sub == 6) {
                 double acc = 0.0;
-                const double med = (K & 1) ? (double)Q.medhi : (double)(Q.medlo + Q.medhi) / 2.0;
-                const float medpk = (float)med;
-                acc += ((double)medpk - floor((double)F / 2.0)) * (double)oi[0];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const double med = (K & 1) ? (double)Q.medhi[o] : (double)(Q.medlo[o] + Q.medhi[o]) / 2.0;
+                    const float medpk = (float)med;
+                    acc += ((double)medpk - floor((double)F / 2.0)) * (double)oi[o];
+                }
                 ft[40] = (float)acc;
             }
         }

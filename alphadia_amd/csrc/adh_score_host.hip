@@ -505,9 +505,13 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     typedef ImProfRec<featim::DimsSmall::Fc, featim::DimsSmall::Sc> ProfSmall;
     const bool split_small = split_cfg && p.n_class[ADH_CLASS_IM_SMALL] > 0 && featim::DimsSmall::holds_axes(class_caps(ADH_CLASS_IM_SMALL));
     const bool split_common = split_cfg && p.n_class[0] > 0 && featim::DimsCommon::holds(class_caps(0)) && class_caps(0).f >= 3;
+    typedef ImProfRec<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2> ProfCommon2;
+    const bool split_two = split_cfg && p.n_class[1] > 0 && featim::DimsCommon2::holds(class_caps(1)) && class_caps(1).f >= 3 &&
+                           !getenv("ADH_DEBUG_IM_NO_SPLIT2");
     const uint64_t prof_base = (p.scratch_bytes + 255) / 256 * 256;
     const uint64_t prof_small_off = prof_base + (split_common ? (uint64_t)p.n_class[0] * sizeof(ProfCommon) : 0);
-    const uint64_t prof_bytes = prof_small_off + (split_small ? (uint64_t)p.n_class[ADH_CLASS_IM_SMALL] * sizeof(ProfSmall) : 0);
+    const uint64_t prof_two_off = prof_small_off + (split_small ? (uint64_t)p.n_class[ADH_CLASS_IM_SMALL] * sizeof(ProfSmall) : 0);
+    const uint64_t prof_bytes = prof_two_off + (split_two ? (uint64_t)p.n_class[1] * sizeof(ProfCommon2) : 0);
     int rc = ensure_scratch(h, prof_bytes);
     if (rc != ADH_OK) return rc;
     unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
@@ -537,15 +541,23 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutSmall, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc, prof);
-                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), dim3(groups),
+                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>), dim3(groups),
                                        dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, *cfg, n_iso, d_scratch,
                                        prof, *out);
+                } else if (c == 1 && split_two) {
+                    unsigned char *prof = d_scratch + prof_two_off;
+                    hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon2, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
+                                       featim::LayoutCommon2(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                       *cfg, d_scratch, *out, cc, prof);
+                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2>),
+                                       dim3(groups), dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, *cfg, n_iso,
+                                       d_scratch, prof, *out);
                 } else if (c == 0 && split_common) {
                     unsigned char *prof = d_scratch + prof_base;
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc, prof);
-                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), dim3(groups),
+                    hipLaunchKernelGGL((adh_feature_im_profiles_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>), dim3(groups),
                                        dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, *cfg, n_iso, d_scratch,
                                        prof, *out);
                 } else if (c == ADH_CLASS_IM_SMALL && featim::DimsSmall::holds_axes(cc) && fixed_ok)

@@ -684,6 +684,8 @@ def test_timstof_split_feature_path_equals_the_one_kernel_path(ctx, oracle_lib, 
     compare(split, exp, PPM_ABS_TOL_ORACLE)
     v = split["valid"].astype(bool)
     assert v.sum() > 80 and (split["features"][v][:, 29] != 0).sum() > 30
+    # two-observation candidates (precursor isotopes across two isolation windows) take the split path too
+    assert (split["features"][v][:, 17] == 2).sum() > 5
 
 
 def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
