@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
 
@@ -140,6 +141,10 @@ struct adh_handle {
                                           // tables are rebuilt from it on the host instead of crossing PCIe
     void *slot_stage = nullptr;           // page-locked fragment_lib_slot staging when the caller passes none
     size_t slot_stage_bytes = 0;
+    // compacted copy-out of the fragment tables (adh_score_host.hip): per-row offsets + the filled slots of the six
+    // wire columns, on the device and in page-locked host memory; scan scratch
+    void *cmp_dev = nullptr, *cmp_host = nullptr, *cmp_scan = nullptr;
+    size_t cmp_dev_bytes = 0, cmp_host_bytes = 0, cmp_scan_bytes = 0;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
@@ -299,6 +304,9 @@ int adh_destroy(adh_handle_t *h) {
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->d_wtp) (void)hipFree(h->d_wtp);
     if (h->slot_stage) (void)hipHostFree(h->slot_stage);
+    if (h->cmp_host) (void)hipHostFree(h->cmp_host);
+    if (h->cmp_dev) (void)hipFree(h->cmp_dev);
+    if (h->cmp_scan) (void)hipFree(h->cmp_scan);
     for (DevTables &t : h->tables)
         if (t.base) (void)hipFree(t.base);
     if (h->cs.base) (void)hipFree(h->cs.base);

@@ -765,6 +765,46 @@ __global__ void adh_rebuild_columns_kernel(DevCands c, const LibRec *__restrict_
     out.fragment_loss_type[t] = l.loss_type;
 }
 
+// ---- compacted copy-out of the fragment tables (round 4).  A candidate fills the first K of its top_k fragment slots
+// (K = fragments with signal: 4.6 of 12 on the headline) and 58 % of the 264 bytes per candidate that the five
+// computed fragment tables + fragment_lib_slot put on PCIe were zeros.  Per chunk of the pipeline: K per row, an
+// exclusive scan, the filled slots of the six columns packed behind each other; the offsets travel first (the host
+// needs the total to size the six copies), the host team expands them into the caller's padded tables.
+__global__ void adh_slot_count_kernel(const uint16_t *__restrict__ lib_slot, int64_t row0, int64_t n, int top_k,
+                                      uint32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t k = 0;
+    if (i < n) {
+        const uint16_t *s = lib_slot + (row0 + i) * (int64_t)top_k;
+        while (k < (uint32_t)top_k && s[k]) ++k;  // (filled slots are the leading ones: candidate.py:403-442)
+    }
+    cnt[i] = k;  // (entry n: 0, so that the scan's last entry is the total)
+}
+
+struct CompactCols {
+    float *f[5];
+    uint16_t *slot;
+};
+
+__global__ void adh_compact_kernel(DevOut t, int64_t row0, int64_t n, int top_k, const uint32_t *__restrict__ off,
+                                   CompactCols c) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n * top_k) return;
+    const int64_t i = id / top_k;
+    const int j = (int)(id - i * top_k);
+    const uint32_t a = off[i], k = off[i + 1] - a;
+    if ((uint32_t)j >= k) return;
+    const int64_t src = (row0 + i) * (int64_t)top_k + j;
+    const size_t dst = (size_t)a + (size_t)j;
+    c.f[0][dst] = t.fragment_mz_observed[src];
+    c.f[1][dst] = t.fragment_height[src];
+    c.f[2][dst] = t.fragment_intensity[src];
+    c.f[3][dst] = t.fragment_mass_error[src];
+    c.f[4][dst] = t.fragment_correlation[src];
+    c.slot[dst] = t.fragment_lib_slot[src];
+}
+
 extern "C" {
 
 namespace {
@@ -905,6 +945,92 @@ void rebuild_host_rows(const adh_handle *h, const adh_candidates_t *c, adh_outpu
     }
 }
 
+// Compact buffers of a call of n rows cut at `cut`: [offsets: one uint32 per row + one per chunk][5 float columns and
+// the slot column, n * top_k entries each, a chunk's packed slots starting at cut[chunk] * top_k]
+struct CompactLayout {
+    size_t off_bytes, col_elems, total;
+    size_t off_of(int64_t a, int64_t ci) const { return (size_t)(a + ci) * 4; }  // byte offset of chunk ci's offsets
+    size_t col_f(int j) const { return off_bytes + (size_t)j * col_elems * 4; }
+    size_t col_slot() const { return off_bytes + 5 * col_elems * 4; }
+    CompactLayout(int64_t n, int64_t n_chunks, int top_k) {
+        off_bytes = ((size_t)(n + n_chunks) * 4 + 255) / 256 * 256;
+        col_elems = ((size_t)n * (size_t)top_k + 63) / 64 * 64;
+        total = off_bytes + col_elems * 22;
+    }
+};
+
+// rows [a, b) of a chunk that starts at row a0: the packed slots back into the caller's padded tables (zeros behind)
+void expand_host_rows(adh_output_t *out, uint16_t *slot_host, const unsigned char *cmp, const CompactLayout &lay, int64_t a0,
+                      int64_t ci, int64_t a, int64_t b) {
+    const int top_k = out->top_k;
+    const uint32_t *off = reinterpret_cast<const uint32_t *>(cmp + lay.off_of(a0, ci));
+    float *dst[5] = {out->fragment_mz_observed, out->fragment_height, out->fragment_intensity, out->fragment_mass_error,
+                     out->fragment_correlation};
+    const size_t base = (size_t)a0 * (size_t)top_k;
+    const float *src[5];
+    for (int j = 0; j < 5; ++j) src[j] = reinterpret_cast<const float *>(cmp + lay.col_f(j)) + base;
+    const uint16_t *src_s = reinterpret_cast<const uint16_t *>(cmp + lay.col_slot()) + base;
+    if (top_k == 12) {
+        // the usual width (default.yaml:185): a row is three 16-byte vectors; the packed source is read unmasked (the
+        // buffer has slack behind its last entry) and cut to the row's k entries with a mask; streaming stores where the
+        // destination allows - the rows are not read again on this side
+        alignas(16) static const uint32_t kMask[13][12] = {
+#define ADH_M(k) {k > 0 ? ~0u : 0u, k > 1 ? ~0u : 0u, k > 2 ? ~0u : 0u, k > 3 ? ~0u : 0u, k > 4 ? ~0u : 0u, k > 5 ? ~0u : 0u, \
+                  k > 6 ? ~0u : 0u, k > 7 ? ~0u : 0u, k > 8 ? ~0u : 0u, k > 9 ? ~0u : 0u, k > 10 ? ~0u : 0u, k > 11 ? ~0u : 0u}
+            ADH_M(0), ADH_M(1), ADH_M(2), ADH_M(3), ADH_M(4), ADH_M(5), ADH_M(6), ADH_M(7), ADH_M(8), ADH_M(9), ADH_M(10), ADH_M(11), ADH_M(12)
+#undef ADH_M
+        };
+        bool aligned = true;
+        for (int j = 0; j < 5; ++j) aligned = aligned && (reinterpret_cast<uintptr_t>(dst[j]) & 15u) == 0;
+        for (int64_t i = a; i < b; ++i) {
+            const uint32_t o = off[i - a0];
+            const uint32_t k = std::min<uint32_t>(off[i - a0 + 1] - o, 12u);
+            const size_t r0 = (size_t)i * 12;
+            const __m128 m0 = _mm_load_ps(reinterpret_cast<const float *>(kMask[k]));
+            const __m128 m1 = _mm_load_ps(reinterpret_cast<const float *>(kMask[k] + 4));
+            const __m128 m2 = _mm_load_ps(reinterpret_cast<const float *>(kMask[k] + 8));
+            for (int j = 0; j < 5; ++j) {
+                const float *sp = src[j] + o;
+                float *row = dst[j] + r0;
+                const __m128 v0 = _mm_and_ps(_mm_loadu_ps(sp), m0), v1 = _mm_and_ps(_mm_loadu_ps(sp + 4), m1),
+                             v2 = _mm_and_ps(_mm_loadu_ps(sp + 8), m2);
+                if (aligned) {
+                    _mm_stream_ps(row, v0);
+                    _mm_stream_ps(row + 4, v1);
+                    _mm_stream_ps(row + 8, v2);
+                } else {
+                    _mm_storeu_ps(row, v0);
+                    _mm_storeu_ps(row + 4, v1);
+                    _mm_storeu_ps(row + 8, v2);
+                }
+            }
+            const uint16_t *sp = src_s + o;
+            uint16_t *row = slot_host + r0;
+            for (uint32_t t = 0; t < 12; ++t) row[t] = t < k ? sp[t] : (uint16_t)0;
+        }
+        _mm_sfence();
+        return;
+    }
+    // any other width: plain loops (a memcpy / memset pair per row and column would be 36 M library calls per 3 M rows)
+    for (int64_t i = a; i < b; ++i) {
+        const uint32_t o = off[i - a0];
+        const int k = (int)(off[i - a0 + 1] - o);
+        const size_t r0 = (size_t)i * (size_t)top_k;
+        for (int j = 0; j < 5; ++j) {
+            const float *sp = src[j] + o;
+            float *row = dst[j] + r0;
+            int t = 0;
+            for (; t < k; ++t) row[t] = sp[t];
+            for (; t < top_k; ++t) row[t] = 0.0f;
+        }
+        const uint16_t *sp = src_s + o;
+        uint16_t *row = slot_host + r0;
+        int t = 0;
+        for (; t < k; ++t) row[t] = sp[t];
+        for (; t < top_k; ++t) row[t] = 0;
+    }
+}
+
 int host_threads_for(int64_t n) {
     int t = 16;
     if (const char *env = getenv("ADH_HOST_THREADS")) t = atoi(env);
@@ -955,14 +1081,18 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     std::vector<hipEvent_t> chunk_done;
     // a call that fails half way leaves no tables behind (a reader would rebuild columns of a half-filled
     // table), and its events go back to the pool
+    std::vector<hipEvent_t> aux_events;  // (events of the compacted copy-out, returned with the others)
     struct Unwind {
         adh_handle *h;
         DevTables &tab;
         std::vector<hipEvent_t> &events;
+        std::vector<hipEvent_t> &aux;
         bool ok = false;
         ~Unwind() {
             for (hipEvent_t ev : events) h->free_events.push_back(ev);
             events.clear();
+            for (hipEvent_t ev : aux) h->free_events.push_back(ev);
+            aux.clear();
             if (!ok) {
                 (void)hipDeviceSynchronize();
                 (void)hipGetLastError();
@@ -971,7 +1101,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
                 tab.partial = false;
             }
         }
-    } unwind{h, tab, chunk_done};
+    } unwind{h, tab, chunk_done, aux_events};
     adh_output_t dev = tab.view;
     dev.n = n;
     hipStream_t sk = h->stream, si = h->stream_in, so = h->stream_out;
@@ -1037,6 +1167,44 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
     const int64_t n_chunks = (int64_t)cut.size() - 1;
+    // compacted copy-out of the fragment tables (see adh_slot_count_kernel).  OFF unless ADH_COMPACT_COPY_OUT=1: it takes
+    // a third of the bytes off PCIe (1.35 -> 0.86 GB per 3 M candidates) but hands the host team 0.9 GB of padded rows
+    // to write, and on the pool's boxes - 16 cores' worth of CPU quota - that costs more than the copies it saves
+    // (40.0 against 38.3 ms per step on the same box, 37.6 with 32 threads).  A host with cores to spare can turn it on.
+    const char *cmp_env = getenv("ADH_COMPACT_COPY_OUT");
+    const bool compact = rebuild && top_k <= 65535 && cmp_env && atoi(cmp_env) != 0;
+    const CompactLayout clay(n, n_chunks, top_k);
+    std::vector<hipEvent_t> &off_ready = aux_events;  // per chunk: its offsets are on the host
+    if (compact) {
+        if (h->cmp_dev_bytes < clay.total) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->cmp_dev) (void)hipFree(h->cmp_dev);
+            h->cmp_dev = nullptr;
+            h->cmp_dev_bytes = 0;
+            HIP_TRY(hipMalloc(&h->cmp_dev, clay.total + clay.total / 8));
+            h->cmp_dev_bytes = clay.total + clay.total / 8;
+        }
+        if (h->cmp_host_bytes < clay.total) {
+            if (h->cmp_host) (void)hipHostFree(h->cmp_host);
+            h->cmp_host = nullptr;
+            h->cmp_host_bytes = 0;
+            HIP_TRY(hipHostMalloc(&h->cmp_host, clay.total + clay.total / 8, hipHostMallocDefault));
+            h->cmp_host_bytes = clay.total + clay.total / 8;
+        }
+        int64_t longest = 0;
+        for (int64_t ci = 0; ci < n_chunks; ++ci) longest = std::max(longest, cut[(size_t)ci + 1] - cut[(size_t)ci]);
+        size_t scan_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)(longest + 1), sk));
+        if (h->cmp_scan_bytes < scan_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->cmp_scan) (void)hipFree(h->cmp_scan);
+            h->cmp_scan = nullptr;
+            h->cmp_scan_bytes = 0;
+            HIP_TRY(hipMalloc(&h->cmp_scan, scan_bytes + 256));
+            h->cmp_scan_bytes = scan_bytes + 256;
+        }
+    }
+    unsigned char *const cmp_dev = static_cast<unsigned char *>(h->cmp_dev), *const cmp_host = static_cast<unsigned char *>(h->cmp_host);
     const double t_1 = now();
     const bool dbg_events = timing && atoi(getenv("ADH_DEBUG_TIMING")) >= 2;  // per-chunk D2H spans
     std::vector<hipEvent_t> dbg;
@@ -1044,6 +1212,28 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
         return code;
+    };
+    // packed fragment columns of chunk ci: wait for its offsets (its kernels are done then; the next chunk's are already
+    // queued), copy the filled part of the six columns, mark the chunk complete for the host team
+    auto flush_compact = [&](int64_t ci) -> int {
+        const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
+        HIP_TRY(hipEventSynchronize(off_ready[(size_t)ci]));
+        const uint32_t total = reinterpret_cast<const uint32_t *>(cmp_host + clay.off_of(a, ci))[b - a];
+        if (total > 0) {
+            const size_t e0 = (size_t)a * (size_t)top_k;
+            for (int j = 0; j < 5; ++j)
+                HIP_TRY(hipMemcpyAsync(cmp_host + clay.col_f(j) + e0 * 4, cmp_dev + clay.col_f(j) + e0 * 4, (size_t)total * 4,
+                                       hipMemcpyDeviceToHost, so));
+            HIP_TRY(hipMemcpyAsync(cmp_host + clay.col_slot() + e0 * 2, cmp_dev + clay.col_slot() + e0 * 2, (size_t)total * 2,
+                                   hipMemcpyDeviceToHost, so));
+            h->d2h_bytes += (uint64_t)total * 22;
+        }
+        hipEvent_t ev = nullptr;
+        int rc_e = get_event(h, &ev);
+        if (rc_e != ADH_OK) return rc_e;
+        HIP_TRY(hipEventRecord(ev, so));
+        chunk_done.push_back(ev);
+        return ADH_OK;
     };
     // Chunk 0: its columns + plan on the copy-in stream.  The columns of ALL later chunks follow in
     // one go right behind it (one H2D per column): H2D copies issued while the D2H copies of earlier
@@ -1067,8 +1257,36 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         rc = plan_finish(h, h->slots[ps], cfg, a, b - a, p);
         if (rc == ADH_OK) rc = launch_scoring(h, p, cfg, &dev_k, sk);
         if (rc != ADH_OK) return fail_sync(rc);
+        if (compact) {  // filled slots per row, their offsets, the packed columns: behind the chunk's kernels
+            uint32_t *d_off = reinterpret_cast<uint32_t *>(cmp_dev + clay.off_of(a, ci));
+            const int64_t nr = b - a;
+            hipLaunchKernelGGL(adh_slot_count_kernel, dim3((unsigned)((nr + 256) / 256)), dim3(256), 0, sk, dev.fragment_lib_slot, a,
+                               nr, top_k, d_off);
+            size_t scan_bytes = h->cmp_scan_bytes;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cmp_scan, scan_bytes, d_off, d_off, (int)(nr + 1), sk));
+            CompactCols cc;
+            for (int j = 0; j < 5; ++j) cc.f[j] = reinterpret_cast<float *>(cmp_dev + clay.col_f(j)) + (size_t)a * top_k;
+            cc.slot = reinterpret_cast<uint16_t *>(cmp_dev + clay.col_slot()) + (size_t)a * top_k;
+            hipLaunchKernelGGL(adh_compact_kernel, dim3((unsigned)((nr * top_k + 255) / 256)), dim3(256), 0, sk, dev, a, nr, top_k,
+                               d_off, cc);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(h->ev_k[ps], sk));
+        if (compact && ci > 0) {  // the packed columns of the previous chunk, now that the host can know their length
+            rc = flush_compact(ci - 1);
+            if (rc != ADH_OK) return fail_sync(rc);
+        }
         HIP_TRY(hipStreamWaitEvent(so, h->ev_k[ps], 0));
+        if (compact) {
+            const size_t ob = clay.off_of(a, ci);
+            HIP_TRY(hipMemcpyAsync(cmp_host + ob, cmp_dev + ob, (size_t)(b - a + 1) * 4, hipMemcpyDeviceToHost, so));
+            h->d2h_bytes += (uint64_t)(b - a + 1) * 4;
+            hipEvent_t ev = nullptr;
+            rc = get_event(h, &ev);
+            if (rc != ADH_OK) return fail_sync(rc);
+            HIP_TRY(hipEventRecord(ev, so));
+            off_ready.push_back(ev);
+        }
         if (dbg_events) {
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0);
@@ -1085,6 +1303,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             if (is_slot && !host && rebuild) host = slot_host;
             if (!host) continue;
             if (rebuild && !f.wire && !is_stat) continue;  // rebuilt on the host below
+            if (compact && f.per_row < 0) continue;        // the fragment tables travel packed (flush_compact)
             const size_t rb = out_row_bytes(f, top_k);
             hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(host) + (size_t)a * rb,
                                           static_cast<unsigned char *>(*out_member(&dev, f)) + (size_t)a * rb,
@@ -1095,7 +1314,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             }
             h->d2h_bytes += (uint64_t)(b - a) * rb;
         }
-        if (rebuild) {
+        if (rebuild && !compact) {
             hipEvent_t ev = nullptr;
             rc = get_event(h, &ev);
             if (rc != ADH_OK) return fail_sync(rc);
@@ -1103,6 +1322,10 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             chunk_done.push_back(ev);
         }
         if (dbg_events) (void)hipEventRecord(dbg.back(), so);
+    }
+    if (compact) {
+        rc = flush_compact(n_chunks - 1);
+        if (rc != ADH_OK) return fail_sync(rc);
     }
     const double t_2 = now();
     rc = comm_gather_slot(h, slot);  // after the last chunk's kernels; overlaps the remaining D2H
@@ -1119,7 +1342,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
                     std::this_thread::yield();
                 }
                 const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
-                rebuild_host_rows(h, c, out, slot_host, a + (b - a) * w / T, a + (b - a) * (w + 1) / T);
+                const int64_t lo = a + (b - a) * w / T, hi = a + (b - a) * (w + 1) / T;
+                if (compact) expand_host_rows(out, slot_host, cmp_host, clay, a, ci, lo, hi);
+                rebuild_host_rows(h, c, out, slot_host, lo, hi);
             }
         };
         std::vector<std::thread> team;
@@ -1137,8 +1362,13 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             if (ee != hipSuccess) break;
             ready.store(ci + 1, std::memory_order_release);
             const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
-            rebuild_host_rows(h, c, out, slot_host, a, a + (b - a) / T);  // stripe 0
-            for (int w = started; w < T; ++w) rebuild_host_rows(h, c, out, slot_host, a + (b - a) * w / T, a + (b - a) * (w + 1) / T);
+            auto stripe = [&](int w) {
+                const int64_t lo = a + (b - a) * w / T, hi = a + (b - a) * (w + 1) / T;
+                if (compact) expand_host_rows(out, slot_host, cmp_host, clay, a, ci, lo, hi);
+                rebuild_host_rows(h, c, out, slot_host, lo, hi);
+            };
+            stripe(0);
+            for (int w = started; w < T; ++w) stripe(w);
         }
         if (ee != hipSuccess) abort.store(true);
         for (std::thread &t : team) t.join();

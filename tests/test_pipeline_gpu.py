@@ -97,6 +97,17 @@ def test_host_rebuilt_columns_equal_the_copied_ones(ctx, case, monkeypatch):
         # production form: page-locked buffers, no host table for the slots (an internal staging buffer is used)
         got = ctx.score_host(pack_assembled(soa), cfg, reuse_buffers=True)
         _same(got, ref, [k for k in TABLES if k in got])
+        # opt-in: the fragment tables leave packed (filled slots only, offsets first) and the host team writes
+        # the padded rows - fewer bytes still, the same tables
+        with monkeypatch.context() as mp:
+            mp.setenv("ADH_COMPACT_COPY_OUT", "1")
+            ctx.d2h_bytes(reset=True)
+            got = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+            packed = ctx.d2h_bytes(reset=True)
+            _same(got, ref)
+            assert packed < 0.9 * rebuilt
+            got = ctx.score_host(pack_assembled(soa), cfg, reuse_buffers=True)
+            _same(got, ref, [k for k in TABLES if k in got])
 
 
 def test_device_plan_matches_oracle_on_mixed_classes(ctx, oracle_lib, monkeypatch):
