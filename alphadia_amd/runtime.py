@@ -71,6 +71,23 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def _process_start_time() -> float:
+    """Wall-clock start of this process (falls back to the import time of this module)."""
+    import time
+
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            uptime = float(f.read().split()[0])
+        return time.time() - (uptime - ticks / os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
+        return time.time()
+
+
+_PROCESS_T0 = _process_start_time()
+
+
 class HipBackendError(RuntimeError):
     pass
 
@@ -186,8 +203,10 @@ def _launch_nonce() -> bytes:
             start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time of the process
     except (OSError, IndexError):
         pass
+    # (the restart count: an elastic restart under the same launcher is a new attempt with a new id file)
     tag = "|".join([os.environ.get("ADH_RUN_NONCE", ""), os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(ppid), start])
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
+                    str(ppid), start])
     return hashlib.sha256(tag.encode()).digest()
 
 
@@ -197,8 +216,10 @@ def rendezvous_path() -> str:
     base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     folder = os.path.join(base, f"adh_{os.getuid()}")  # a directory of this user only: nobody else can pre-create
     os.makedirs(folder, mode=0o700, exist_ok=True)      # or redirect the id file
-    st = os.stat(folder)
-    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+    import stat as _stat
+
+    st = os.lstat(folder)  # (not stat: a planted symlink to some other private directory of the user must not pass)
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise HipBackendError(f"{folder} is not a private directory of this user")
     return os.path.join(folder, f"rccl_id_{_launch_nonce().hex()[:24]}")
 
@@ -241,7 +262,11 @@ def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0, make_id=
         try:
             with open(path, "rb") as f:
                 data = f.read()
-            if len(data) == len(nonce) + 128 and data[: len(nonce)] == nonce:
+                written = os.fstat(f.fileno()).st_mtime
+            # a file older than this process is what an earlier attempt with the same nonce inputs left behind
+            # (rank 0 replaces it): only an id written after this rank started belongs to this attempt
+            fresh = written >= _PROCESS_T0 - 2.0
+            if fresh and len(data) == len(nonce) + 128 and data[: len(nonce)] == nonce:
                 return data[len(nonce):]
         except FileNotFoundError:
             pass

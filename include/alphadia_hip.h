@@ -206,7 +206,10 @@ int adh_stage_alpharaw(adh_handle_t *handle, const adh_alpharaw_t *dia);
  */
 int adh_stage_timstof(adh_handle_t *handle, const adh_timstof_t *dia);
 
-/* Stage the flat fragment library (replaces assemble_fragments, scoring.py:355-392). */
+/* Stage the flat fragment library (replaces assemble_fragments, scoring.py:355-392).  Besides the copy in HBM
+ * (32 bytes per fragment) the handle keeps a host copy of the packed records (another 32 bytes per fragment of
+ * host memory, per handle = per rank): adh_score_candidates rebuilds the library columns of the fragment tables
+ * from it on the host instead of copying them over PCIe.  ADH_DEBUG_COPY_ALL=1 does without the rebuild. */
 int adh_stage_fragments(adh_handle_t *handle, const adh_fragments_t *fragments);
 
 /*

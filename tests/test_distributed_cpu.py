@@ -243,6 +243,29 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
     ids = [open(tmp_path / f"id_{r}", "rb").read() for r in range(3)]
     assert ids[0] == bytes([7]) * 128 and ids[1] == ids[0] and ids[2] == ids[0]
     assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    # (d) a restart under the same launcher: the previous attempt's file carries the SAME nonce but is older than
+    # the restarted readers - they wait for the id rank 0 writes now; a symlinked rendezvous directory is refused
+    path_d = str(tmp_path / "rccl_id_d")
+    out_d = tmp_path / "d"
+    out_d.mkdir()
+    ctx_mp = mp.get_context("spawn")
+    first = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D"))
+    first.start()
+    first.join(60)  # the "previous attempt": its rank 0 left a file with this launch's nonce
+    assert first.exitcode == 0 and os.path.exists(path_d)
+    os.remove(out_d / "id_0")
+    old_t = time.time() - 3600.0
+    os.utime(path_d, (old_t, old_t))
+    reader = ctx_mp.Process(target=_rendezvous_worker, args=(1, 2, path_d, str(out_d), "launch-D"))
+    reader.start()
+    time.sleep(1.5)
+    assert not os.path.exists(out_d / "id_1")  # right nonce, but older than the reader: not this attempt's
+    writer = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D"))
+    writer.start()
+    for p in (reader, writer):
+        p.join(60)
+        assert p.exitcode == 0
+    assert open(out_d / "id_1", "rb").read() == bytes([7]) * 128
     # (c) more than one node is refused (the file is node-local)
     os.environ["LOCAL_WORLD_SIZE"] = "4"
     try:
