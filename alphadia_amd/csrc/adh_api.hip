@@ -572,6 +572,97 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     return ADH_OK;
 }
 
+namespace {
+// The tile-ordered copy of the events for the scoring gather (DevTims::tile_ev, adh_device.h): keys, one stable
+// radix sort, the exclusive scan of the key histogram as the index.  Built when the run is below 2^31 events and
+// keys, values and index fit a quarter of the free device memory; ADH_IM_TILED=0 leaves it out,
+// ADH_IM_TILE_SHIFTS="c,s" fixes the tile shape (2^c cycles x 2^s scans; default: about 1.5 events per (tile,
+// TOF bin), i.e. a run of ~70 bytes for the handful of bins of a 15 ppm window, s = c or c + 1: on configs[3]
+// 32 cycles x 64 scans, measured against 16 x 32 ... 128 x 64).
+int build_tile_layout(adh_handle *h, DevTims &t) {
+    t.tile_ev = nullptr;
+    t.tile_idx = nullptr;
+    const char *env = getenv("ADH_IM_TILED");
+    if ((env && atoi(env) == 0) || t.n_events <= 0 || t.n_events >= 0x7FFFFFFFll || t.n_cycles <= 0) return ADH_OK;
+    int sbits = 1;  // (an event of the layout holds frame << sbits | scan in 32 bits)
+    while ((1ll << sbits) < (int64_t)t.scan_max) ++sbits;
+    if (sbits >= 31 || t.n_frames > (1ll << (32 - sbits))) return ADH_OK;
+    int csh = -1, ssh = -1;
+    if (const char *sh = getenv("ADH_IM_TILE_SHIFTS")) {
+        if (sscanf(sh, "%d,%d", &csh, &ssh) != 2 || csh < 0 || ssh < 0 || csh > 20 || ssh > 20)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "ADH_IM_TILE_SHIFTS must be \"c,s\" with 0 <= c, s <= 20");
+    }
+    auto blocks = [](int64_t n, int sh) { return (n + (1ll << sh) - 1) >> sh; };
+    if (csh < 0) {
+        const double want = (double)t.n_events / (1.5 * (double)t.n_tof);  // tiles
+        double best = 1e300;
+        for (int c = 2; c <= 12; ++c)
+            for (int s = c; s <= c + 1; ++s) {
+                const double tiles = (double)(blocks(t.n_cycles, c) * blocks(t.scan_max, s));
+                const double miss = fabs(log(std::max(tiles, 1.0) / std::max(want, 1.0)));
+                if (miss < best) best = miss, csh = c, ssh = s;
+            }
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    int64_t ncb = blocks(t.n_cycles, csh), nsb = blocks(t.scan_max, ssh);
+    // (coarser tiles until the index fits 32-bit keys and its share of the memory)
+    while ((double)ncb * (double)nsb * (double)(t.n_tof + 1) >= 4.0e9 ||
+           (size_t)(ncb * nsb * (t.n_tof + 1) + 1) * 4 > free_b / 8) {
+        if (ncb == 1 && nsb == 1) return ADH_OK;
+        if (ncb >= nsb) ++csh; else ++ssh;
+        ncb = blocks(t.n_cycles, csh), nsb = blocks(t.scan_max, ssh);
+    }
+    const int64_t n_keys = ncb * nsb * (t.n_tof + 1), n = t.n_events;
+    int key_bits = 1;
+    while (key_bits < 32 && (1ll << key_bits) < n_keys) ++key_bits;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    uint32_t *k_in = nullptr, *k_out = nullptr, *idx = nullptr;
+    uint64_t *v_in = nullptr, *v_out = nullptr;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, v_in, v_out, (int)n, 0, key_bits, h->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, idx, idx, (int)(n_keys + 1), h->stream));
+    const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
+    if ((size_t)n * 24 + (size_t)(n_keys + 1) * 4 + tmp_bytes > free_b / 4) return ADH_OK;  // no room: bin ranges
+    DeviceBuffers work;  // (released on every way out)
+    void *tmp = nullptr;
+    auto grab = [&](void **p, size_t bytes, DeviceBuffers &owner) {
+        if (hipMalloc(p, std::max<size_t>(bytes, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        owner.ptrs.push_back(*p);
+        return true;
+    };
+    if (!grab((void **)&k_in, (size_t)n * 4, work) || !grab((void **)&k_out, (size_t)n * 4, work) ||
+        !grab((void **)&v_in, (size_t)n * 8, work) || !grab(&tmp, tmp_bytes, work) ||
+        !grab((void **)&v_out, (size_t)n * 8, h->run_buf) || !grab((void **)&idx, (size_t)(n_keys + 1) * 4, h->run_buf)) {
+        work.release();
+        return ADH_OK;  // (what went to run_buf goes with the run)
+    }
+    hipError_t e = hipMemsetAsync(idx, 0, (size_t)(n_keys + 1) * 4, h->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<int64_t>(t.n_tof, 1 << 20);
+        hipLaunchKernelGGL(adh_tile_key_kernel, dim3(grid), dim3(ADH_WAVE), 0, h->stream, t.tof_indptr, t.push, t.inten, t.n_tof,
+                           (uint32_t)t.scan_max, (uint32_t)t.cycle_len, (uint32_t)t.zeroth, csh, ssh, sbits, (uint32_t)ncb, (uint32_t)nsb,
+                           k_in, v_in, idx);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, k_in, k_out, v_in, v_out, (int)n, 0, key_bits, h->stream);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, idx, idx, (int)(n_keys + 1), h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    work.release();
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, hipGetErrorString(e));
+    t.tile_ev = reinterpret_cast<const uint2 *>(v_out);
+    t.tile_idx = idx;
+    t.tile_cshift = csh;
+    t.tile_sshift = ssh;
+    t.tile_cblocks = (int32_t)ncb;
+    t.tile_sblocks = (int32_t)nsb;
+    t.tile_sbits = sbits;
+    return ADH_OK;
+}
+}  // namespace
+
 int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (d->cycle_len <= 0 || d->scan_max_index <= 0 || d->n_frames <= 0 || d->n_tof <= 0 || d->n_events < 0)
@@ -680,6 +771,10 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
                 }
             }
         }
+    }
+    {
+        const int rc_t = build_tile_layout(h, t);
+        if (rc_t != ADH_OK) return rc_t;
     }
     h->h_cycle.assign(d->cycle, d->cycle + (size_t)rows * 2);
     h->h_rt_im.assign(d->rt_values, d->rt_values + d->n_frames);

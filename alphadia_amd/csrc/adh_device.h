@@ -131,6 +131,21 @@ struct DevTims {
     double lut_min, lut_inv_step;
     int32_t lut_n, cyc_shift, cyc_cols, n_cycles;
     __device__ __forceinline__ uint32_t cyc_word(int tof, int col) const { return cyc_idx[(size_t)col * (size_t)n_tof + (size_t)tof]; }
+    // Second copy of the events for the scoring gather (round 4), in TILE order: a tile is a block of
+    // 2^tile_cshift cycles x 2^tile_sshift scans (tile = cycle block * tile_sblocks + scan block), its events are
+    // sorted by TOF bin, then push.  In the TOF-major order above a candidate reads, per TOF bin of a window, all
+    // scans and quadrupole windows of its cycles (3 % of what it reads is its own) and every bin costs its own
+    // lines; here the bins of a window are neighbours INSIDE a tile, so a (window, tile) pair is one short
+    // contiguous run and a third of it is the candidate's.
+    //   tile_ev[e]  = {frame << tile_sbits | scan, intensity | (TOF bin & 0xFFFF) << 16}   (frame and scan by a
+    //   shift and a mask where the TOF-major push needs a division; tile_sbits = bits of scan_max - 1)
+    //   tile_idx[tile * (n_tof + 1) + tof] = first event of the tile with TOF bin >= tof (absolute; the layout is
+    //   only built for runs below 2^31 events)
+    // NULL when the layout is not built (ADH_IM_TILED=0, no room, too many events): the kernels use the bin ranges.
+    const uint2 *tile_ev;
+    const uint32_t *tile_idx;
+    int32_t tile_cshift, tile_sshift, tile_cblocks, tile_sblocks, tile_sbits, tile_pad;
+    __device__ __forceinline__ uint32_t tile_word(int tile, int tof) const { return tile_idx[(size_t)tile * (size_t)(n_tof + 1) + (size_t)tof]; }
 };
 
 // candidate record of the ion-mobility plan (processing order)

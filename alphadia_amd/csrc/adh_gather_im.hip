@@ -245,9 +245,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         const uint64_t ph64 = (uint64_t)((int64_t)(c0 + F) * L + z) * (uint64_t)S_max;
         const uint32_t push_lo = (uint32_t)(c0 * L + z) * (uint32_t)S_max;
         const uint32_t push_hi = ph64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ph64;
-        const int P = index_im::pair_setup(
-            run, W, t_lo, t_hi, [&](int w) { return w >= K ? caps.k + (w - K) : w; }, c0, F, push_lo, push_hi, w_p0, w_base, p_lo,
-            p_off, p_win, lane);
+        // the tile layout when the run has it and the candidate's (window, tile) pairs fit (a window of more than 256
+        // TOF bins does not: list entries name their bin by one byte): otherwise the (window, TOF bin) ranges
+        auto slot_of = [&](int w) { return w >= K ? caps.k + (w - K) : w; };
+        index_im::TileBox box{};
+        bool tiled = run.tile_ev != nullptr;
+        if (tiled) {
+            box = index_im::tile_box(run, c0, F, r.scan_start, r.scan_stop);
+            bool wide = false;
+            for (int w = lane; w < W; w += ADH_WAVE) wide |= t_hi[slot_of(w)] - t_lo[slot_of(w)] > 256;
+            tiled = W * box.nT <= ADH_IM_PAIR_CAP && !__any(wide);
+        }
+        const int P = tiled ? index_im::pair_setup_tiled(run, box, W, t_lo, t_hi, slot_of, w_p0, p_lo, p_off, p_win, lane)
+                            : index_im::pair_setup(run, W, t_lo, t_hi, slot_of, c0, F, push_lo, push_hi, w_p0, w_base, p_lo,
+                                                   p_off, p_win, lane);
         bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
@@ -285,7 +296,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     if (owner) {
                         // TOF bin of an event: first bin of its window + pair - first pair of the window
                         const int w = frag ? (int)cell / (O * S * F) : K + (int)((gid - (uint32_t)n_fc) % (uint32_t)I);
-                        const int tof0 = t_lo[frag ? w : caps.k + (w - K)] - w_p0[w];
+                        // (tile layout: the list entry holds bin - first bin of the window)
+                        const int tof0 = t_lo[frag ? w : caps.k + (w - K)] - (tiled ? 0 : w_p0[w]);
                         float acc = 0.0f, last_y = 0.0f;
                         double sum = 0.0;
                         int count = 0;
@@ -320,31 +332,55 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             m = 0;
         };
 
-        int w0 = 0;
-        while (w0 < W && !over) {
-            // the next batch of windows: as many as are certain to fit the free part of the list (every raw
-            // event might survive); the isotope windows go together, whatever their size
-            const bool pg = w0 >= K;
-            int w1 = pg ? W : w0 + 1;
-            if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > ADH_IM_SORT_CAP) {
-                flush();
-                if (over) break;
-            }
-            if (!pg)
-                while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= ADH_IM_SORT_CAP) ++w1;
-            const int pa0 = w_p0[w0], pb0 = w_p0[w1];
+        // ---- stage 1 of the windows [wa, wb): the raw events; those in the scan range (and, in a tile, in the
+        // candidate's cycles) queue up behind the list.  Returns their number (queue entries beyond the list's
+        // capacity are counted, not stored).
+        auto stage_one = [&](int wa, int wb) -> int {
+            const int pa0 = w_p0[wa], pb0 = w_p0[wb];
             const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
-            if (r1 - r0 > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
-                over = true;
-                break;
+            return tiled ? index_im::queue_scan_range<true>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+                                                            p_off, s_key, s_int, s_pair, lane, (uint32_t)(c0 * L + z),
+                                                            (uint32_t)((c0 + F) * L + z))
+                         : index_im::queue_scan_range<false>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+                                                             p_off, s_key, s_int, s_pair, lane);
+        };
+        int w0 = 0;
+        bool try_all = caps.stop_phase != 14;  // (14: developer switch, certain batches only)
+        while (w0 < W && !over) {
+            // The next batch of windows.  First guess: ALL that are left - few raw events survive stage 1, and a
+            // candidate that gets through its windows in one batch has one chain of dependent loads (events ->
+            // quadrupole rows -> m/z of the bins) instead of one per batch, which is what this kernel waits for.
+            // If the survivors do not fit the list: as many windows as are certain to fit its free part (every raw
+            // event might survive); the isotope windows go together, whatever their size.
+            const bool pg = w0 >= K;
+            int w1 = W, nq = -1;
+            if (try_all && p_off[w_p0[W]] - p_off[w_p0[w0]] <= 0xFFFFu) {
+                nq = stage_one(w0, W);
+                if (m + nq > ADH_IM_SORT_CAP) {
+                    nq = -1;
+                    try_all = false;
+                    __syncthreads();
+                }
             }
-            // ---- stage 1: the raw events of the batch; those in the scan range (~3 %) queue up behind the list
-            const int nq = index_im::queue_scan_range(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo, p_off,
-                                                      s_key, s_int, s_pair, lane);
-            if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
-                over = true;
-                break;
+            if (nq < 0) {
+                w1 = pg ? W : w0 + 1;
+                if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > ADH_IM_SORT_CAP) {
+                    flush();
+                    if (over) break;
+                }
+                if (!pg)
+                    while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= ADH_IM_SORT_CAP) ++w1;
+                if (p_off[w_p0[w1]] - p_off[w_p0[w0]] > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
+                    over = true;
+                    break;
+                }
+                nq = stage_one(w0, w1);
+                if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
+                    over = true;
+                    break;
+                }
             }
+            const uint32_t r0 = p_off[w_p0[w0]];
             __syncthreads();
             // ---- stage 2: the queued events look up their quadrupole row, MS1 / MS2 observation and
             // intensity (independent loads) and the survivors take their place in the list, in stream order
@@ -359,18 +395,30 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     const int pa = (int)s_pair[q_base + qi];
                     const uint32_t e = r0 + (uint32_t)s_int[q_base + qi];
                     const int w = (int)p_win[pa];
-                    const int64_t idx = w_base[w] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa]);
                     const bool prec = w >= K;
-                    uint32_t fq = (uint32_t)((double)pvq * inv_smax);
-                    if (pvq - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
-                    const int frame = (int)fq, scan = (int)(pvq - fq * (uint32_t)S_max);
+                    int frame, scan;
+                    if (tiled) {  // (frame << tile_sbits | scan)
+                        frame = (int)(pvq >> run.tile_sbits);
+                        scan = (int)(pvq & ((1u << run.tile_sbits) - 1u));
+                    } else {
+                        uint32_t fq = (uint32_t)((double)pvq * inv_smax);
+                        if (pvq - fq * (uint32_t)S_max >= (uint32_t)S_max) ++fq;
+                        frame = (int)fq, scan = (int)(pvq - fq * (uint32_t)S_max);
+                    }
                     uint32_t cq = (uint32_t)((double)(frame - z) * inv_l);
                     if ((uint32_t)(frame - z) - cq * (uint32_t)L >= (uint32_t)L) ++cq;
                     const int f = (int)cq - c0;
                     const int crow = (frame - z - (int)cq * L) * S_max + scan;
                     const double cy0 = run.cycle[2 * crow], cy1 = run.cycle[2 * crow + 1];
                     const int pc = run.dpc[crow];
-                    ni = run.inten[idx];
+                    if (tiled) {  // (the line was fetched by stage 1)
+                        const uint32_t iw = run.tile_ev[(size_t)p_lo[pa] + (size_t)(e - p_off[pa])].y;
+                        ni = (uint16_t)(iw & 0xFFFFu);
+                        pair = ((iw >> 16) - (uint32_t)t_lo[prec ? caps.k + (w - K) : w]) & 0xFFFFu;
+                    } else {
+                        ni = run.inten[w_base[w] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+                        pair = (uint32_t)pa;
+                    }
                     const double q_lo = prec ? -1.0 : fq_lo, q_hi = prec ? -1.0 : fq_hi;
                     const int n_o = prec ? Op : O;
                     const uint16_t *obs = prec ? r.ms1_obs : r.obs;
@@ -380,7 +428,6 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                     ok = q_lo <= cy1 && q_hi >= cy0 && o < n_o;  // (o < n_o always: the plan lists every overlapping row)
                     cell = prec ? (uint32_t)(n_fc + (((sc * F + f) * I + (w - K)) * Op + o))
                                 : (uint32_t)(((w * O + o) * S + sc) * F + f);
-                    pair = (uint32_t)pa;
                 }
                 __syncthreads();  // the queue slots of this step are in registers: the list may grow over them
                 const unsigned long long mask = __ballot(ok);

@@ -133,17 +133,74 @@ __device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *
     return P;
 }
 
+// The tile layout (DevTims::tile_ev): the tiles that the candidate's box of cycles [c0, c0 + F) x scans
+// [scan_lo, scan_hi) meets.  nT = number of tiles, tile j (j < nT) = tile_at(j).
+struct TileBox {
+    int cb0, sb0, n_sb, nT, stride;
+    __device__ __forceinline__ int tile_at(int j) const { return (cb0 + j / n_sb) * stride + sb0 + j % n_sb; }
+};
+__device__ __forceinline__ TileBox tile_box(const DevTims &run, int c0, int F, int scan_lo, int scan_hi) {
+    TileBox b;
+    const int cbl = run.tile_cblocks - 1;
+    b.cb0 = min(c0 >> run.tile_cshift, cbl);
+    const int cb1 = min((c0 + F - 1) >> run.tile_cshift, cbl);
+    b.sb0 = min(max(scan_lo, 0) >> run.tile_sshift, run.tile_sblocks - 1);
+    const int sb1 = min(max(scan_hi - 1, 0) >> run.tile_sshift, run.tile_sblocks - 1);
+    b.n_sb = sb1 - b.sb0 + 1;
+    b.nT = (cb1 - b.cb0 + 1) * b.n_sb;
+    b.stride = run.tile_sblocks;
+    return b;
+}
+
+// Pairs of the tile layout: (window, tile) - the events of the window's TOF bins inside one tile are ONE run
+// (TOF ascending, then push).  Pair p = w * nT + j; p_lo holds the absolute first event (the layout is only built
+// below 2^31 events), w_base is not used.  Returns the number of pairs.
+template <typename SlotOf>
+__device__ __forceinline__ int pair_setup_tiled(const DevTims &run, const TileBox &box, int W, const int *t_lo,
+                                                const int *t_hi, SlotOf slot_of, int *w_p0, uint32_t *p_lo,
+                                                uint32_t *p_off, uint8_t *p_win, int lane) {
+    const int nT = box.nT, P = W * nT;
+    for (int w = lane; w <= W; w += ADH_WAVE) w_p0[w] = w * nT;
+    for (int p = lane; p < P; p += ADH_WAVE) {
+        const int w = p / nT, j = p - w * nT;
+        const int slot = slot_of(w), tile = box.tile_at(j);
+        const uint32_t lo = run.tile_word(tile, t_lo[slot]), hi = run.tile_word(tile, t_hi[slot]);
+        p_lo[p] = lo;
+        p_win[p] = (uint8_t)w;
+        p_off[p + 1] = hi - lo;
+    }
+    __syncthreads();
+    uint32_t carry = 0;  // inclusive scan of the counts, 64 at a time
+    for (int base = 0; base < P; base += ADH_WAVE) {
+        uint32_t v = base + lane < P ? p_off[base + lane + 1] : 0u;
+        for (int off = 1; off < ADH_WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(v, off);
+            if (lane >= off) v += u;
+        }
+        if (base + lane < P) p_off[base + lane + 1] = carry + v;
+        carry += __shfl(v, ADH_WAVE - 1);
+    }
+    if (lane == 0) p_off[0] = 0u;
+    __syncthreads();
+    return P;
+}
+
 // Stage 1 of a batch of windows (pairs [pa0, pb0), raw events [r0, r1)): eight pushes per lane and step
 // (eight independent loads in flight); the events inside the scan range [scan_lo, scan_hi) - ~3 % - are
 // queued behind the m entries of the list: s_key = push, s_int = raw number - r0, s_pair = pair.  Returns the
 // number of queued events (entries beyond ADH_IM_SORT_CAP are counted, not stored).
+// TILED: the events come from the tile layout (p_lo absolute; s_key = frame << tile_sbits | scan); a tile also
+// holds cycles outside the candidate's, so the frame range [frame_lo, frame_hi) is tested here as well.
+template <bool TILED = false>
 __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int pb0, uint32_t r0, uint32_t r1,
                                                 int scan_lo, int scan_hi, int m, const int64_t *w_base,
                                                 const uint8_t *p_win, const uint32_t *p_lo, const uint32_t *p_off,
-                                                uint32_t *s_key, uint16_t *s_int, uint8_t *s_pair, int lane) {
+                                                uint32_t *s_key, uint16_t *s_int, uint8_t *s_pair, int lane,
+                                                uint32_t frame_lo = 0u, uint32_t frame_hi = 0xFFFFFFFFu) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t S_max = (uint32_t)run.scan_max;
     const double inv_smax = 1.0 / (double)S_max;
+    const uint32_t smask = TILED ? (1u << run.tile_sbits) - 1u : 0u;
     int nq = 0;
     constexpr int U = 8;
     for (uint32_t e0 = r0; e0 < r1; e0 += U * ADH_WAVE) {
@@ -159,16 +216,25 @@ __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int
                 if (p_off[mid] <= e) pa = mid; else pb = mid;
             }
             pa_u[u] = pa;
-            pv[u] = run.push[w_base[p_win[pa]] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
+            if (TILED) pv[u] = run.tile_ev[(size_t)p_lo[pa] + (size_t)(e - p_off[pa])].x;
+            else pv[u] = run.push[w_base[p_win[pa]] + (int64_t)p_lo[pa] + (int64_t)(e - p_off[pa])];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t eu = e0 + (uint32_t)(u * ADH_WAVE + lane);
-            // (exact quotient without the integer-division sequence: float64 estimate, one fix-up)
-            uint32_t fq = (uint32_t)((double)pv[u] * inv_smax);
-            if (pv[u] - fq * S_max >= S_max) ++fq;
-            const int scan = (int)(pv[u] - fq * S_max);
-            const bool pass = eu < r1 && scan >= scan_lo && scan < scan_hi;
+            int scan;
+            bool in_frames = true;
+            if (TILED) {
+                scan = (int)(pv[u] & smask);
+                const uint32_t frame = pv[u] >> run.tile_sbits;
+                in_frames = frame >= frame_lo && frame < frame_hi;
+            } else {
+                // (exact quotient without the integer-division sequence: float64 estimate, one fix-up)
+                uint32_t fq = (uint32_t)((double)pv[u] * inv_smax);
+                if (pv[u] - fq * S_max >= S_max) ++fq;
+                scan = (int)(pv[u] - fq * S_max);
+            }
+            const bool pass = eu < r1 && scan >= scan_lo && scan < scan_hi && in_frames;
             const unsigned long long mask = __ballot(pass);
             if (pass) {
                 const int at = m + nq + __popcll(mask & lt);
@@ -214,5 +280,30 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_index_im_kernel(const int64_t *_
             done = __shfl(g, last);
         }
         for (uint32_t cb = done + lane; cb < cols; cb += ADH_WAVE) row[cb * cs] = (uint32_t)(b - a);
+    }
+}
+
+// ---- the tile layout (DevTims::tile_ev / tile_idx): key = tile * (n_tof + 1) + TOF bin of every event, the event
+// packed as the sort's value, and the histogram of the keys (its exclusive scan is tile_idx).  One wavefront per
+// TOF bin as above; the stable sort keeps the push order inside a (tile, bin).
+__global__ __launch_bounds__(ADH_WAVE) void adh_tile_key_kernel(const int64_t *__restrict__ tof_indptr,
+                                                                  const uint32_t *__restrict__ push,
+                                                                  const uint16_t *__restrict__ inten, int64_t n_tof,
+                                                                  uint32_t S_max, uint32_t L, uint32_t z, int csh, int ssh,
+                                                                  int sbits, uint32_t ncb, uint32_t nsb, uint32_t *__restrict__ keys,
+                                                                  uint64_t *__restrict__ vals, uint32_t *__restrict__ hist) {
+    const int lane = threadIdx.x;
+    for (int64_t tof = blockIdx.x; tof < n_tof; tof += gridDim.x) {
+        const int64_t a = tof_indptr[tof], b = tof_indptr[tof + 1];
+        for (int64_t e = a + lane; e < b; e += ADH_WAVE) {
+            const uint32_t p = push[e];
+            const uint32_t frame = p / S_max, scan = p - frame * S_max;
+            const uint32_t cyc = frame < z ? 0u : (frame - z) / L;
+            const uint32_t cb = min(cyc >> csh, ncb - 1u), sb = min(scan >> ssh, nsb - 1u);
+            const uint32_t key = (cb * nsb + sb) * (uint32_t)(n_tof + 1) + (uint32_t)tof;
+            keys[e] = key;
+            vals[e] = (uint64_t)(frame << sbits | scan) | (uint64_t)inten[e] << 32 | (uint64_t)((uint32_t)tof & 0xFFFFu) << 48;
+            atomicAdd(&hist[key], 1u);
+        }
     }
 }

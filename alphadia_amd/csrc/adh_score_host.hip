@@ -521,7 +521,9 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     if (rc == ADH_OK) rc = get_event(h, &t.e2);
     if (rc != ADH_OK) return rc;
     HIP_TRY(hipEventRecord(t.e0, st));
-    hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, h->tims, h->d_lib,
+    DevTims run_view = h->tims;
+    if (getenv("ADH_DEBUG_IM_NO_TILES")) run_view.tile_ev = nullptr;  // A/B: the (window, TOF bin) ranges of the TOF-major events
+    hipLaunchKernelGGL(adh_gather_im_kernel, dim3((unsigned)p.n), dim3(ADH_WAVE), g_lds, st, run_view, h->d_lib,
                        p.d_recs_im, *cfg, n_iso, d_scratch, *out, p.caps_all);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(t.e1, st));

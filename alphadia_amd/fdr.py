@@ -18,6 +18,7 @@ There is no CPU fallback: every call needs the built library and a GPU.
 from __future__ import annotations
 
 import logging
+import os
 import warnings
 from collections import defaultdict
 from copy import deepcopy
@@ -133,17 +134,32 @@ class HipBinaryClassifier:
 
     def _init_state(self):
         """Initial parameters drawn like FeedForwardNN._build_model does (classifiers.py:514-528)."""
-        import torch
-
-        if self._torch_seed is not None:
-            torch.manual_seed(self._torch_seed)
-            self._torch_seed = None  # the reference seeds once, in the constructor
         d = self.input_dim
         parts = [np.ones(d, np.float32), np.zeros(d, np.float32)]
-        for out_f, in_f in self._linear_shapes():
-            lin = torch.nn.Linear(in_f, out_f)
-            parts.append(lin.weight.detach().numpy().astype(np.float32).ravel())
-            parts.append(lin.bias.detach().numpy().astype(np.float32).ravel())
+        torch = None
+        if not os.environ.get("ADH_FDR_NUMPY_INIT"):
+            try:
+                import torch
+            except ImportError:  # the draw below has torch's distribution, not its random stream
+                torch = None
+        if torch is not None:
+            if self._torch_seed is not None:
+                torch.manual_seed(self._torch_seed)
+                self._torch_seed = None  # the reference seeds once, in the constructor
+            for out_f, in_f in self._linear_shapes():
+                lin = torch.nn.Linear(in_f, out_f)
+                parts.append(lin.weight.detach().numpy().astype(np.float32).ravel())
+                parts.append(lin.bias.detach().numpy().astype(np.float32).ravel())
+        else:
+            # nn.Linear.reset_parameters: weight and bias uniform in +-1 / sqrt(fan_in).  Used where torch is absent
+            # or ADH_FDR_NUMPY_INIT is set (tools/bench_fdr.py in the bench line: an `import torch` costs minutes on
+            # a cold box); same network and training, another random stream than the reference's.
+            rng = np.random.default_rng(self._torch_seed)
+            self._torch_seed = None
+            for out_f, in_f in self._linear_shapes():
+                bound = 1.0 / np.sqrt(in_f)
+                parts.append(rng.uniform(-bound, bound, out_f * in_f).astype(np.float32))
+                parts.append(rng.uniform(-bound, bound, out_f).astype(np.float32))
         self._state = (np.concatenate(parts), np.zeros(d, np.float32), np.ones(d, np.float32), 0)
 
     def _device_mlp(self) -> runtime.DeviceMlp:

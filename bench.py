@@ -565,6 +565,8 @@ def main():
             ("multiplex_configs4", lambda: bench_legs.multiplex_leg(ctx, threads=os.cpu_count() or 8,
                                                                     cpu_seconds=min(args.cpu_seconds, 6.0))),
             ("ion_mobility_configs3", lambda: bench_legs.timstof_leg(full_size=True)),
+            ("candidate_selection", lambda: bench_legs.selection_leg()),
+            ("fdr_stage", lambda: bench_legs.fdr_leg()),
         ):
             if time.time() - t_legs > args.extras_seconds:
                 legs[name] = {"skipped": f"the legs' budget of {args.extras_seconds:.0f} s was spent"}

@@ -707,7 +707,13 @@ def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
     # ADH_DEBUG_IM_NO_SPLIT: the one-kernel feature path against the split one of round 4 (tile passes, then the
     # profile phase with four candidates per wavefront, adh_features_im2.hip), which is the default `base` ran
     for env in (dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"), dict(ADH_DEBUG_IM="8"),
-                dict(ADH_DEBUG_IM="21"), dict(ADH_DEBUG_IM_DYNAMIC_LAYOUT="1"), dict(ADH_DEBUG_IM_NO_SPLIT="1")):
+                dict(ADH_DEBUG_IM="21"), dict(ADH_DEBUG_IM_DYNAMIC_LAYOUT="1"), dict(ADH_DEBUG_IM_NO_SPLIT="1"),
+                # the tile-ordered copy of the events the gather reads by default (DevTims::tile_ev): not built, built
+                # but not used, tiles smaller than any candidate, oblong tiles, one tile for the whole run
+                # (ADH_DEBUG_IM=14: the gather's windows in batches that are certain to fit, never all at once)
+                dict(ADH_DEBUG_IM="14"), dict(ADH_DEBUG_IM="14", ADH_IM_TILED="0"),
+                dict(ADH_IM_TILED="0"), dict(ADH_DEBUG_IM_NO_TILES="1"), dict(ADH_IM_TILE_SHIFTS="2,3"),
+                dict(ADH_IM_TILE_SHIFTS="5,4"), dict(ADH_IM_TILE_SHIFTS="1,6"), dict(ADH_IM_TILE_SHIFTS="12,12")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)

@@ -61,6 +61,30 @@ def main():
     kb_wall = time.perf_counter() - t0
     ids = int(((qval <= 0.01) & (decoy[order] == 0)).sum())
 
+    cpu = None
+    if args.cpu_steps > 0:
+        cpu = cpu_leg(args, fdr, clf, x, decoy, proba, pidx, n, d)
+
+    print(json.dumps({
+        "workload": f"{n} rows x {d} features, {clf.epochs} epochs, batch {clf.batch_size}, lr {clf.learning_rate:g}, "
+                    f"dropout {clf.dropout}, layers {clf.layers}",
+        "train_steps": int(n_steps),
+        "fit_kernels_ms": clf.last_fit_ms,
+        "fit_us_per_step": 1e3 * clf.last_fit_ms / max(n_steps, 1),
+        "fit_rows_per_s": n_steps * clf.batch_size / (clf.last_fit_ms / 1e3) if clf.last_fit_ms else None,
+        "fit_wall_s": fit_wall,
+        "predict_kernel_ms": clf.last_predict_ms,
+        "predict_rows_per_s": n / (clf.last_predict_ms / 1e3) if clf.last_predict_ms else None,
+        "predict_wall_s": predict_wall,
+        "q_values_wall_ms": 1e3 * q_wall,
+        "keep_best_wall_ms": 1e3 * kb_wall,
+        "targets_at_1pct": ids,
+        "train_loss_first_last": [clf.metrics["train_loss"][0], clf.metrics["train_loss"][-1]],
+        "cpu_oracle": cpu,
+    }))
+
+
+def cpu_leg(args, fdr, clf, x, decoy, proba, pidx, n, d):
     # CPU: the torch fp32 oracle, 2 threads (fdr/utils.py:55-94), a bounded number of steps
     from oracle import fdr_oracle
 
@@ -81,29 +105,12 @@ def main():
     t0 = time.perf_counter()
     fdr_oracle.q_values(proba[:1_000_000], decoy[:1_000_000], pidx[:1_000_000])
     cpu_q = time.perf_counter() - t0
-
-    print(json.dumps({
-        "workload": f"{n} rows x {d} features, {clf.epochs} epochs, batch {clf.batch_size}, lr {clf.learning_rate:g}, "
-                    f"dropout {clf.dropout}, layers {clf.layers}",
-        "train_steps": int(n_steps),
-        "fit_kernels_ms": clf.last_fit_ms,
-        "fit_us_per_step": 1e3 * clf.last_fit_ms / max(n_steps, 1),
-        "fit_rows_per_s": n_steps * clf.batch_size / (clf.last_fit_ms / 1e3) if clf.last_fit_ms else None,
-        "fit_wall_s": fit_wall,
-        "predict_kernel_ms": clf.last_predict_ms,
-        "predict_rows_per_s": n / (clf.last_predict_ms / 1e3) if clf.last_predict_ms else None,
-        "predict_wall_s": predict_wall,
-        "q_values_wall_ms": 1e3 * q_wall,
-        "keep_best_wall_ms": 1e3 * kb_wall,
-        "targets_at_1pct": ids,
-        "train_loss_first_last": [clf.metrics["train_loss"][0], clf.metrics["train_loss"][-1]],
-        "cpu_oracle": {
-            "kind": "port (plain PyTorch fp32, 2 threads as the reference)",
-            "fit_steps": steps,
-            "fit_us_per_step": 1e6 * cpu_fit / max(steps, 1),
-            "q_values_1e6_rows_ms": 1e3 * cpu_q,
-        },
-    }))
+    return {
+        "kind": "port (plain PyTorch fp32, 2 threads as the reference)",
+        "fit_steps": steps,
+        "fit_us_per_step": 1e6 * cpu_fit / max(steps, 1),
+        "q_values_1e6_rows_ms": 1e3 * cpu_q,
+    }
 
 
 if __name__ == "__main__":

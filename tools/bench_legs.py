@@ -272,9 +272,48 @@ def timstof_leg(full_size: bool = True, timeout: float = 600.0) -> dict:
     return res
 
 
+# --------------------------------------------------------------------------------------------
+def _tool_leg(script: str, args=(), env_extra=None, timeout: float = 600.0) -> dict:
+    """One of the stand-alone benches under tools/ in a process of its own; its last JSON line."""
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    if p.returncode != 0:
+        raise RuntimeError(f"{script} failed ({p.returncode}): {p.stderr[-400:]}")
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    res["leg_wall_seconds"] = time.time() - t0
+    return res
+
+
+def selection_leg(n_prec: int = 100_000, timeout: float = 600.0) -> dict:
+    """Candidate selection (selection.py:620-660) through tools/bench_select.py: 100 000
+    precursors against the 2 h run, rt tolerance 60 s, 3 candidates each; kernel time, and the CPU oracle on a sample
+    of the same precursors (boxes compared)."""
+    res = _tool_leg("bench_select.py", env_extra={"N_PREC": str(n_prec)}, timeout=timeout)
+    _log(f"[bench] selection: kernels {res['kernel_ms']:.2f} ms per {n_prec} precursors "
+         f"({res['precursors_per_s_kernel'] / 1e6:.1f} M precursors/s), leg took {res['leg_wall_seconds']:.0f} s")
+    return res
+
+
+def fdr_leg(timeout: float = 600.0) -> dict:
+    """The FDR stage on the device at the size of the headline table through
+    tools/bench_fdr.py: classifier training / inference, q-values, best row per group.  Without its CPU leg (the
+    plain-PyTorch oracle needs an `import torch`, minutes on a cold box): profiles/r01_fdr_bench.json holds it."""
+    res = _tool_leg("bench_fdr.py", args=("--cpu-steps", "0"), env_extra={"ADH_FDR_NUMPY_INIT": "1"}, timeout=timeout)
+    _log(f"[bench] fdr: fit {res['fit_kernels_ms']:.0f} ms of kernels ({res['fit_wall_s']:.2f} s wall), predict "
+         f"{res['predict_kernel_ms']:.1f} ms, q-values {res['q_values_wall_ms']:.1f} ms, leg took {res['leg_wall_seconds']:.0f} s")
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "fragcomp"
-    if which == "timstof":
+    if which == "selection":
+        print(json.dumps(selection_leg()))
+    elif which == "fdr":
+        print(json.dumps(fdr_leg()))
+    elif which == "timstof":
         print(json.dumps(timstof_leg(full_size=not os.environ.get("REDUCED"))))
     else:
         from alphadia_amd import runtime
