@@ -1221,8 +1221,22 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, h->stream);
+        sel::Taps taps{};  // (the non-zero columns of a two-row smoothing kernel as float64 scalar operands)
+        if (k_rows == 2) {
+            int lo = k_cols, hi = -1;
+            for (int b = 0; b < k_cols; ++b)
+                if (kernel[b] != 0.0f || kernel[k_cols + b] != 0.0f) lo = std::min(lo, b), hi = std::max(hi, b);
+            if (hi < lo) lo = hi = 0;
+            const int nb = hi - lo + 1;
+            taps.cols = nb <= sel::TAP_COLS ? sel::TAP_COLS : 0;
+            taps.col0 = lo;
+            for (int a = 0; a < 2 && taps.cols; ++a)
+                for (int b = 0; b < nb; ++b) taps.v[a * taps.cols + b] = (double)kernel[a * k_cols + lo + b];
+        }
+        if (const char *env = getenv("ADH_DEBUG_SELECT_STOP")) caps.stop = atoi(env);
+        if (getenv("ADH_DEBUG_SELECT_LDS_TAPS")) taps.cols = 0;  // A/B: the generic smoothing loop
         hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream, h->run, h->d_lib,
-                           dp, n, *cfg, d_kernel, caps, dt);
+                           dp, n, *cfg, d_kernel, taps, caps, dt);
         hipError_t e = hipGetLastError();
         (void)hipEventRecord(e1, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -13,17 +13,33 @@
 // smooths every XIC with a 2-D FFT convolution; both scan slots of an AlphaRaw tile are equal,
 // so the circular convolution collapses to one dimension and is evaluated directly (float64
 // accumulation, rounded to float32 once - the reference's float32 FFT carries ~1e-3 of absolute
-// noise).  Peak picking, joining and the symmetric limits are short scalar loops
-// executed by lane 0 in the reference's order.
+// noise).  Peaks are flagged by all lanes; joining and the symmetric limits are short scalar
+// loops executed by lane 0 in the reference's order.
+//
+// Round 4: fragments and isotopes share a batch of 16 windows (one gather phase per precursor instead of three),
+// the cycle rows of both groups are found by all lanes (the one-lane loop over the cycle table with its dependent
+// loads was most of the kernel's time), the smoothing has its taps in scalar registers (kernel argument) and a
+// lane computes five neighbouring outputs from 34 row values in registers (no margin copy, no modulo), the log
+// is the table-driven one of the ion-mobility selection.  Every sum keeps its order: bit-identical candidates.
 #include "adh_device.h"
+#include "adh_log_f32.h"
 
 namespace sel {
 
 using gather::Window;
 
-constexpr int WB = 8;         // m/z windows gathered per batch
+constexpr int WB = 16;        // m/z windows (fragments, then isotopes) per batch
 constexpr int MAX_ROWS = 16;  // cycle rows overlapping one quadrupole range
 constexpr int MAX_CAND = 16;
+constexpr int CONV_R = 10;    // neighbouring outputs of one lane in the smoothing (80 cycles x 15 windows: two full rounds)
+// The smoothing kernel as a kernel argument (scalar operands): its columns [col0, col0 + NB) - the others are zero
+// in every row, and a zero tap leaves a running fma sum as it is (the reference's Gaussian over 30 cycles has 15
+// non-zero columns) - as float64, NB padded with zeros to 16 columns, two rows.
+constexpr int TAP_COLS = 16;
+struct Taps {
+    double v[2 * TAP_COLS];
+    int32_t col0, cols;  // cols: TAP_COLS, or 0 = the kernel does not fit (more non-zero columns, another row count: taps from LDS)
+};
 
 // intensity-only variant of gather::gather_task: cells[f] += intensity, f = cycle - c0
 __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window &w, int row, int blk, int c0,
@@ -61,25 +77,42 @@ __device__ __forceinline__ void gather_sum_task(const DevRun &run, const Window 
     }
 }
 
-// one output of the smoothing: sum over kernel rows a (outer) and columns b (inner) of
-// kernel[a][b] * row[(f + k1/2 - b) mod F], float64 fused multiply-adds, in this order (the oracle's)
-template <int K1>
-__device__ __forceinline__ double conv_fixed(const float *rp, const double *kd, int k0) {
-    double win[K1];  // the K1 row values this output touches, converted once
+// R neighbouring outputs f0 ... f0 + R - 1 of the smoothing of one row (circular, kernel centred at column k1 / 2,
+// selection/fft.py:163-212): out[f] = sum over kernel rows a (outer) and columns b (inner) of
+// kernel[a][b] * row[(f + k1/2 - b) mod F], float64 fused multiply-adds in this order (the oracle's), over the
+// NB columns from col0 on (Taps).  The NB + R - 1 row values the outputs touch are read and converted once.
+template <int K0, int NB, int R>
+__device__ __forceinline__ void conv_chunk(const float *row, int F, int f0, int k1, const Taps &taps, double (&acc)[R]) {
+    double win[NB + R - 1];  // win[j] = row[(f0 + k1/2 - col0 - (NB - 1) + j) mod F]
+    int idx = (f0 + k1 / 2 - taps.col0 - (NB - 1)) % F;  // (|first term| < F + 64: one division, then steps)
+    idx += idx < 0 ? F : 0;
 #pragma unroll
-    for (int b = 0; b < K1; ++b) win[b] = (double)rp[-b];
-    double acc = 0.0;
-    for (int a = 0; a < k0; ++a) {
-#pragma unroll
-        for (int b = 0; b < K1; ++b) acc = fma(kd[a * K1 + b], win[b], acc);
+    for (int j = 0; j < NB + R - 1; ++j) {
+        win[j] = (double)row[idx];
+        ++idx;
+        idx -= idx >= F ? F : 0;
     }
-    return acc;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+#pragma unroll
+    for (int a = 0; a < K0; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(taps.v[a * NB + b], win[r + NB - 1 - b], acc[r]);
 }
 
-__device__ __forceinline__ double conv_any(const float *rp, const double *kd, int k0, int k1) {
+// one output, any kernel shape (taps in LDS)
+__device__ __forceinline__ double conv_any(const float *row, int F, int f, const double *kd, int k0, int k1) {
     double acc = 0.0;
-    for (int a = 0; a < k0; ++a)
-        for (int b = 0; b < k1; ++b) acc = fma(kd[a * k1 + b], (double)rp[-b], acc);
+    int start = (f + k1 / 2) % F;
+    for (int a = 0; a < k0; ++a) {
+        int idx = start;
+        for (int b = 0; b < k1; ++b) {
+            acc = fma(kd[a * k1 + b], (double)row[idx], acc);
+            idx = idx == 0 ? F - 1 : idx - 1;
+        }
+    }
     return acc;
 }
 
@@ -112,6 +145,7 @@ __device__ inline void symetric_limits_1d(const double *a, int n, int center, do
 }
 
 struct SelCaps {
+    int32_t stop;    // developer ablation (ADH_DEBUG_SELECT_STOP): 1 windows, 2 + cycle rows, 3 + gather, 4 + smoothing, 5 + score
     int32_t n_lib;   // longest fragment slice
     int32_t f;       // largest cycle count of a tile
     int32_t n_iso;   // isotopes used
@@ -126,9 +160,9 @@ __host__ __device__ inline size_t lds_bytes(const SelCaps &c) {
     b += (size_t)((c.n_lib + 1) & ~1) * 4;         // raw fragment m/z (even count: keeps 8-byte alignment)
     b += (size_t)WB * c.f * 4;                     // tile of one batch (>= one float64 row)
     b += (size_t)c.f * 4 * 2;                      // lf, lp
-    b += (size_t)WB * (c.f + 2 * c.k_cols) * 4;    // rows of one batch with wrap-around margins
+    b += (size_t)WB * c.f * 4;                     // log(smooth + 1) of one batch
     b = (b + 7) / 8 * 8;
-    b += (size_t)c.k_rows * c.k_cols * 8;          // kernel (float64)
+    b += (size_t)c.k_rows * c.k_cols * 8;          // kernel (float64; shapes that do not travel as an argument)
     return (b + 15) / 16 * 16;
 }
 
@@ -152,8 +186,8 @@ struct DevCandTable {
 __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const LibRec *__restrict__ lib,
                                                              DevPrecursors pc, int64_t n_prec,
                                                              adh_selection_config_t cfg,
-                                                             const float *__restrict__ kernel_g, sel::SelCaps caps,
-                                                             DevCandTable out) {
+                                                             const float *__restrict__ kernel_g, sel::Taps taps,
+                                                             sel::SelCaps caps, DevCandTable out) {
     using namespace sel;
     extern __shared__ __align__(16) unsigned char smem[];
     double *score = reinterpret_cast<double *>(smem);
@@ -163,19 +197,21 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
     float *tile = raw_mz + ((caps.n_lib + 1) & ~1);
     float *lf = tile + (size_t)WB * caps.f;
     float *lp = lf + caps.f;
-    float *rowbuf = lp + caps.f;
-    const int row_stride = caps.f + 2 * caps.k_cols;
+    float *logt = lp + caps.f;
     double *kern = reinterpret_cast<double *>(
-        smem + ((size_t)(reinterpret_cast<unsigned char *>(rowbuf + (size_t)WB * row_stride) - smem) + 7) / 8 * 8);
-    __shared__ int s_rows[MAX_ROWS];
+        smem + ((size_t)(reinterpret_cast<unsigned char *>(logt + (size_t)WB * caps.f) - smem) + 7) / 8 * 8);
+    __shared__ int s_rows[2][MAX_ROWS];
     __shared__ int s_misc[8];
 
     const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int64_t i = blockIdx.x;
     if (i >= n_prec) return;
     const int L = run.cycle_len;
     const int k0 = caps.k_rows, k1 = caps.k_cols;
-    for (int c = lane; c < k0 * k1; c += ADH_WAVE) kern[c] = (double)kernel_g[c];
+    const bool fixed_taps = k0 == 2 && taps.cols != 0;  // (taps in scalar registers)
+    if (!fixed_taps)
+        for (int c = lane; c < k0 * k1; c += ADH_WAVE) kern[c] = (double)kernel_g[c];
 
     // ---- isotopes (assemble_isotope_mz, selection/utils.py:24-46): float32 array += float64 offsets
     const int n_iso = caps.n_iso;
@@ -193,14 +229,18 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
     // ---- fragments: slice, cardinality filter, sort by m/z (selection.py:124-139); no top-k
     const uint32_t fs = pc.frag_start[i], fe = pc.frag_stop[i];
     const int n_lib = (int)(fe - fs);
-    __syncthreads();
-    for (int j = lane; j < n_lib; j += ADH_WAVE) {
-        const LibRec r = lib[fs + j];
-        raw_mz[j] = (cfg.exclude_shared_ions && r.cardinality > 1) ? -1.0f : r.mz;  // m/z > 0 always
+    int K = 0;
+    for (int j0 = 0; j0 < n_lib; j0 += ADH_WAVE) {
+        const int j = j0 + lane;
+        bool keep = false;
+        if (j < n_lib) {
+            const LibRec r = lib[fs + j];
+            keep = !(cfg.exclude_shared_ions && r.cardinality > 1);
+            raw_mz[j] = keep ? r.mz : -1.0f;  // m/z > 0 always
+        }
+        K += __popcll(__ballot(keep));
     }
     __syncthreads();
-    int K = 0;
-    for (int j = 0; j < n_lib; ++j) K += raw_mz[j] >= 0.0f;
     if (K <= 3) return;  // selection.py:141
     for (int a = lane; a < n_lib; a += ADH_WAVE) {
         const float ma = raw_mz[a];
@@ -217,25 +257,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
         win[slot].hi = ma + q;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (lane < 2) {  // the exclusive lower bounds of a group's windows (lane 0: fragments, lane 1: isotopes)
+        const int base = lane == 0 ? 0 : W0, cnt = lane == 0 ? K : n_iso;
         float e = -INFINITY;
-        for (int k = 0; k < K; ++k) {
-            win[k].excl = e;
-            e = fmaxf(e, win[k].hi);
+        for (int k = 0; k < cnt; ++k) {
+            win[base + k].excl = e;
+            e = fmaxf(e, win[base + k].hi);
         }
-        e = -INFINITY;
-        for (int k = 0; k < n_iso; ++k) {
-            win[W0 + k].excl = e;
-            e = fmaxf(e, win[W0 + k].hi);
-        }
-        // frame limits (get_frame_indices, jitclasses/utils.py:24-88): searched on the host, which
-        // needs them anyway to size the tiles (adh_select_candidates)
-        s_misc[2] = pc.cycle_start[i];
-        s_misc[3] = pc.cycle_count[i];
     }
     __syncthreads();
     for (int w = lane; w < K + n_iso; w += ADH_WAVE) gather::bins_of(run, win[w < K ? w : W0 + (w - K)]);
-    const int cs = s_misc[2], F = s_misc[3];
+    // frame limits (get_frame_indices, jitclasses/utils.py:24-88): searched on the host, which needs them anyway
+    // to size the tiles (adh_select_candidates)
+    if (caps.stop == 1) return;
+    const int cs = pc.cycle_start[i], F = pc.cycle_count[i];
     // _is_valid (selection.py:40-75) with two scan slots
     if (F <= 0 || F > caps.f || n_iso == 0 || 2 < k0 || F < k1) return;
     const double q_lo = (double)__int_as_float(s_misc[0]), q_hi = (double)__int_as_float(s_misc[1]);
@@ -245,66 +280,86 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
         lf[f] = 0.0f;
         lp[f] = 0.0f;
     }
+    // ---- cycle rows of the two groups of windows, ascending (_calculate_valid_scans, alpharaw_jit.py:19-50):
+    // fragments (rows overlapping the isotope range) and isotopes (MS1 rows); a lane per row
+    int n_rows[2] = {0, 0};
+    for (int row0 = 0; row0 < L; row0 += ADH_WAVE) {
+        const int row = row0 + lane;
+        double lo = 0.0, hi = -2.0;
+        if (row < L) {
+            lo = run.cycle[2 * row];
+            hi = run.cycle[2 * row + 1];
+        }
+#pragma unroll
+        for (int group = 0; group < 2; ++group) {
+            const bool ok = row < L && (group == 0 ? (q_lo <= hi && q_hi >= lo) : (-1.0 <= hi && -1.0 >= lo));
+            const unsigned long long mask = __ballot(ok);
+            const int pos = n_rows[group] + __popcll(mask & lt);
+            if (ok && pos < MAX_ROWS) s_rows[group][pos] = row;
+            n_rows[group] += __popcll(mask);
+        }
+    }
+    n_rows[0] = min(n_rows[0], MAX_ROWS);
+    n_rows[1] = min(n_rows[1], MAX_ROWS);
 
-    // ---- two groups of windows: fragments (rows overlapping the isotope range) and isotopes (MS1 rows)
-    for (int group = 0; group < 2; ++group) {
-        // cycle rows of this group, ascending (_calculate_valid_scans, alpharaw_jit.py:19-50)
+    if (caps.stop == 2) return;
+
+    // ---- batches of windows: fragments, then isotopes
+    const int Wt = K + n_iso;
+    const int n_chunk = (F + CONV_R - 1) / CONV_R;
+    for (int w0 = 0; w0 < Wt; w0 += WB) {
+        const int wb = min(WB, Wt - w0);
         __syncthreads();
-        if (lane == 0) {
-            int n = 0;
-            for (int row = 0; row < L; ++row) {
-                const double lo = run.cycle[2 * row], hi = run.cycle[2 * row + 1];
-                const bool ok = group == 0 ? (q_lo <= hi && q_hi >= lo) : (-1.0 <= hi && -1.0 >= lo);
-                if (ok && n < MAX_ROWS) s_rows[n++] = row;
-            }
-            s_misc[4] = n;
+        for (int c = lane; c < wb * F; c += ADH_WAVE) tile[c] = 0.0f;
+        __syncthreads();
+        // one lane per (window, cycle block); the cycle rows are visited in ascending order so
+        // that a cell keeps the reference's running float32 sum (alpharaw_jit.py:392-420)
+        const int n_tasks = wb * n_blk;
+        for (int t = lane; t < n_tasks; t += ADH_WAVE) {
+            const int w = t / n_blk, bi = t - w * n_blk;
+            const int gw = w0 + w, group = gw >= K;
+            const Window &ww = win[group ? W0 + (gw - K) : gw];
+            for (int r = 0; r < n_rows[group]; ++r)
+                gather_sum_task(run, ww, s_rows[group][r], blk0 + bi, cs, F, tile + w * F);
         }
         __syncthreads();
-        const int n_rows = s_misc[4];
-        const int Wn = group == 0 ? K : n_iso;
-        float *lsum = group == 0 ? lf : lp;
-        for (int w0 = 0; w0 < Wn; w0 += WB) {
-            const int wb = min(WB, Wn - w0);
-            for (int c = lane; c < wb * F; c += ADH_WAVE) tile[c] = 0.0f;
-            __syncthreads();
-            // one lane per (window, cycle block); the cycle rows are visited in ascending order so
-            // that a cell keeps the reference's running float32 sum (alpharaw_jit.py:392-420)
-            const int n_tasks = wb * n_blk;
-            for (int t = lane; t < n_tasks; t += ADH_WAVE) {
-                const int bi = t % n_blk, w = t / n_blk;
-                const Window &ww = win[group == 0 ? w0 + w : W0 + w0 + w];
-                for (int r = 0; r < n_rows; ++r)
-                    gather_sum_task(run, ww, s_rows[r], blk0 + bi, cs, F, tile + w * F);
+        if (caps.stop == 3) continue;
+        // circular convolution for all (window, cycle) outputs of the batch, then log(smooth + 1)
+        // (_build_features, selection.py:206-226)
+        auto put = [&](int w, int f, double acc) {
+            const float sm = (float)acc;
+            const float x1 = sm + 1.0f;
+            logt[w * F + f] = (x1 >= 1.0f && x1 < INFINITY) ? (float)adh_log_f32(x1) : (float)log((double)x1);
+        };
+        if (fixed_taps) {
+            for (int c = lane; c < wb * n_chunk; c += ADH_WAVE) {
+                const int w = c / n_chunk, f0 = (c - w * n_chunk) * CONV_R;
+                double acc[CONV_R];
+                conv_chunk<2, TAP_COLS, CONV_R>(tile + w * F, F, f0, k1, taps, acc);
+#pragma unroll
+                for (int r = 0; r < CONV_R; ++r)
+                    if (f0 + r < F) put(w, f0 + r, acc[r]);
             }
-            __syncthreads();
-            // the rows with k1 wrap-around cells on either side: rowbuf[w][k1 + j] = row_w[j mod F]
-            for (int c = lane; c < wb * (F + 2 * k1); c += ADH_WAVE) {
-                const int w = c / (F + 2 * k1), j = c - w * (F + 2 * k1);
-                int src = (j - k1) % F;
-                if (src < 0) src += F;
-                rowbuf[w * row_stride + j] = tile[w * F + src];
-            }
-            __syncthreads();
-            // circular convolution, kernel centred at column k1 / 2 (selection/fft.py:163-212), for
-            // all (window, cycle) outputs of the batch; log(smooth + 1) replaces the tile value
+        } else {
             for (int o = lane; o < wb * F; o += ADH_WAVE) {
                 const int w = o / F, f = o - w * F;
-                const float *rp = rowbuf + w * row_stride + k1 + f + k1 / 2;  // rp[-b] = row[(f + k1/2 - b) mod F]
-                const double acc = (k1 == 30) ? conv_fixed<30>(rp, kern, k0) : conv_any(rp, kern, k0, k1);
-                const float sm = (float)acc;
-                const float x1 = sm + 1.0f;  // _build_features (selection.py:206-226)
-                tile[o] = (float)log((double)x1);
+                put(w, f, conv_any(tile + w * F, F, f, kern, k0, k1));
             }
-            __syncthreads();
-            for (int f = lane; f < F; f += ADH_WAVE) {
-                float a = lsum[f];
-                for (int w = 0; w < wb; ++w) a += tile[w * F + f];  // np.sum over the windows, in order
-                lsum[f] = a;
-            }
-            __syncthreads();
+        }
+        __syncthreads();
+        // np.sum over the windows of a group, in order
+        const int n_frag = max(0, min(K, w0 + wb) - w0);  // fragment windows of this batch come first
+        for (int f = lane; f < F; f += ADH_WAVE) {
+            float a = lf[f];
+            for (int w = 0; w < n_frag; ++w) a += logt[w * F + f];
+            lf[f] = a;
+            a = lp[f];
+            for (int w = n_frag; w < wb; ++w) a += logt[w * F + f];
+            lp[f] = a;
         }
     }
     __syncthreads();
+    if (caps.stop == 3 || caps.stop == 4) return;
     // ---- score (selection.py:396-421), single feature
     {
         double mean = cfg.feature_mean, sd = cfg.feature_std, weight = cfg.feature_weight;
@@ -334,83 +389,95 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
         }
     }
     __syncthreads();
-    if (lane != 0) return;
+    // the cycle profile of symetric_limits_2d (selection/utils.py:283-312) on the (2, F) matrix with equal rows
+    // does not depend on the peak: score[f] added once per scan slot in reach; it goes to the (now free) tile
+    double *cyc = reinterpret_cast<double *>(tile);
+    const int mob_lower = 0, mob_upper = (int)min((int64_t)2, (int64_t)0 + cfg.min_size_mobility);
+    for (int f = lane; f < F; f += ADH_WAVE) {
+        double v = 0.0;
+        for (int sl = mob_lower; sl < mob_upper; ++sl) v += score[f];
+        cyc[f] = v;
+    }
 
-    // ---- peaks, joins, limits: short scalar loops in the reference's order
-    int p_cycle[MAX_CAND];
-    double p_score[MAX_CAND];
-    int p_sl[MAX_CAND][2], p_cl[MAX_CAND][2];
+    if (caps.stop == 5) return;
+    // ---- peaks, joins, limits: the peaks are flagged by all lanes, the rest are short scalar loops in the
+    // reference's order
+    // (the candidate lists live in LDS: indexed at run time, as registers they cost 110 VGPRs and a select chain
+    // per access)
+    __shared__ int p_cycle[MAX_CAND];
+    __shared__ double p_score[MAX_CAND];
+    __shared__ int p_sl[MAX_CAND][2], p_cl[MAX_CAND][2];
     int n_pk = 0;
     const int top_n = (int)min((int64_t)MAX_CAND, cfg.candidate_count);
     // find_peaks_1d (selection/utils.py:49-77): keep the top_n by score, descending; equal scores in
     // reversed index order (argsort()[::-1])
-    for (int p = 2; p < F - 2; ++p) {
-        if (!(score[p - 2] < score[p - 1] && score[p - 1] < score[p] && score[p] > score[p + 1] &&
-              score[p + 1] > score[p + 2]))
-            continue;
-        const double s = score[p];
-        int pos = n_pk;
-        while (pos > 0 && (p_score[pos - 1] < s || (p_score[pos - 1] == s && p_cycle[pos - 1] < p))) --pos;
-        if (pos >= top_n) continue;
-        const int last = min(n_pk, top_n - 1);
-        for (int j = last; j > pos; --j) {
-            p_score[j] = p_score[j - 1];
-            p_cycle[j] = p_cycle[j - 1];
+    for (int pb = 0; pb < F; pb += ADH_WAVE) {
+        const int p = pb + lane;
+        bool pk = false;
+        if (p >= 2 && p < F - 2)
+            pk = score[p - 2] < score[p - 1] && score[p - 1] < score[p] && score[p] > score[p + 1] &&
+                 score[p + 1] > score[p + 2];
+        const unsigned long long flags = __ballot(pk);
+        unsigned long long mask = lane == 0 ? flags : 0ull;  // (lane 0 walks the flags, in ascending order)
+        while (mask) {
+            const int pp = pb + __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const double sc = score[pp];
+            int pos = n_pk;
+            while (pos > 0 && (p_score[pos - 1] < sc || (p_score[pos - 1] == sc && p_cycle[pos - 1] < pp))) --pos;
+            if (pos >= top_n) continue;
+            const int last = min(n_pk, top_n - 1);
+            for (int j = last; j > pos; --j) {
+                p_score[j] = p_score[j - 1];
+                p_cycle[j] = p_cycle[j - 1];
+            }
+            p_score[pos] = sc;
+            p_cycle[pos] = pp;
+            if (n_pk < top_n) ++n_pk;
         }
-        p_score[pos] = s;
-        p_cycle[pos] = p;
-        if (n_pk < top_n) ++n_pk;
     }
+    __syncthreads();  // (cyc is complete)
+    if (lane != 0) return;
     // _join_close_peaks (selection.py:229-278), tolerances 3 / 3; all scans are 0 here
     {
-        bool mask[MAX_CAND];
-        for (int a = 0; a < n_pk; ++a) mask[a] = true;
+        uint32_t mask = 0xFFFFFFFFu;  // (bit a: candidate a is kept)
         for (int a = 0; a < n_pk; ++a) {
-            if (!mask[a]) continue;
+            if (!(mask >> a & 1u)) continue;
             for (int b = a + 1; b < n_pk; ++b) {
-                if (!mask[b]) continue;
+                if (!(mask >> b & 1u)) continue;
                 if (abs(p_cycle[a] - p_cycle[b]) <= 3) {
-                    if (p_score[a] > p_score[b]) mask[b] = false; else mask[a] = false;
+                    if (p_score[a] > p_score[b]) mask &= ~(1u << b); else mask &= ~(1u << a);
                 }
             }
         }
         int m = 0;
         for (int a = 0; a < n_pk; ++a)
-            if (mask[a]) {
+            if (mask >> a & 1u) {
                 p_cycle[m] = p_cycle[a];
                 p_score[m] = p_score[a];
                 ++m;
             }
         n_pk = m;
     }
-    // symetric_limits_2d (selection/utils.py:283-312) on the (2, F) matrix with equal rows;
-    // the cycle profile goes to the (now free) fragment log-sum row as float64 pairs
-    double *cyc = reinterpret_cast<double *>(tile);
+    // symetric_limits_2d (selection/utils.py:283-312) on the (2, F) matrix with equal rows (cyc: above)
     for (int a = 0; a < n_pk; ++a) {
         const int cen = p_cycle[a];
-        const int mob_lower = 0, mob_upper = (int)min((int64_t)2, (int64_t)0 + cfg.min_size_mobility);
         const int cyc_lower = (int)max((int64_t)0, (int64_t)cen - cfg.min_size_rt);
         const int cyc_upper = (int)min((int64_t)F, (int64_t)cen + cfg.min_size_rt);
         double mob[2] = {0.0, 0.0};
         for (int s = 0; s < 2; ++s)
             for (int f = cyc_lower; f < cyc_upper; ++f) mob[s] += score[f];
-        for (int f = 0; f < F; ++f) {
-            double v = 0.0;
-            for (int s = mob_lower; s < mob_upper; ++s) v += score[f];
-            cyc[f] = v;
-        }
         symetric_limits_1d(mob, 2, 0, cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
                            cfg.max_size_mobility, p_sl[a]);
         symetric_limits_1d(cyc, F, cen, cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt, p_cl[a]);
     }
     // _join_overlapping_candidates (selection.py:281-345)
     if (cfg.join_close_candidates) {
-        bool mask[MAX_CAND];
-        for (int a = 0; a < n_pk; ++a) mask[a] = true;
+        uint32_t mask = 0xFFFFFFFFu;
         for (int a = 0; a < n_pk; ++a) {
-            if (!mask[a]) continue;
+            if (!(mask >> a & 1u)) continue;
             for (int b = a + 1; b < n_pk; ++b) {
-                if (!mask[b]) continue;
+                if (!(mask >> b & 1u)) continue;
                 const double cyc_len = (double)(p_cl[a][1] - p_cl[a][0]);
                 const double cyc_ov = (double)(min(p_cl[a][1], p_cl[b][1]) - max(p_cl[a][0], p_cl[b][0])) / cyc_len;
                 const double scan_len = (double)(p_sl[a][1] - p_sl[a][0]);
@@ -422,13 +489,13 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
                     p_sl[a][1] = max(p_sl[a][1], p_sl[b][1]);
                     p_cl[a][0] = min(p_cl[a][0], p_cl[b][0]);
                     p_cl[a][1] = max(p_cl[a][1], p_cl[b][1]);
-                    mask[b] = false;
+                    mask &= ~(1u << b);
                 }
             }
         }
         int m = 0;
         for (int a = 0; a < n_pk; ++a)
-            if (mask[a]) {
+            if (mask >> a & 1u) {
                 p_cycle[m] = p_cycle[a];
                 p_score[m] = p_score[a];
                 p_sl[m][0] = p_sl[a][0];
