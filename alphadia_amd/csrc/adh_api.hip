@@ -152,6 +152,8 @@ struct adh_handle {
     std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
     fragcomp::Stats last_fragcomp;  // of the last adh_fragcomp / adh_fdr_resident call
+    void *sel_slab = nullptr;       // precursor columns + candidate table of adh_select_candidates (grow-only)
+    size_t sel_slab_bytes = 0;
     void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
     uint64_t scratch_slab_bytes = 0;
     DevTables tables[2];            // slot 1 only with a communicator (double-buffered all-gather)
@@ -311,6 +313,7 @@ int adh_destroy(adh_handle_t *h) {
         if (t.base) (void)hipFree(t.base);
     if (h->cs.base) (void)hipFree(h->cs.base);
     if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+    if (h->sel_slab) (void)hipFree(h->sel_slab);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t e : h->ev_k)
@@ -1131,6 +1134,15 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
     if (k_rows <= 0 || k_cols <= 0 || cfg->top_k_precursors <= 0 || pc->n_isotope_cols <= 0)
         return fail(ADH_ERR_INVALID_ARGUMENT, "kernel / isotope dimensions must be positive");
     HIP_TRY(hipSetDevice(h->device));
+    const bool tdbg = getenv("ADH_DEBUG_SELECT_TIMING") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = t_now();
+    auto lap = [&](const char *what) {
+        if (!tdbg) return;
+        const auto t = t_now();
+        fprintf(stderr, "[select] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     const int64_t n = pc->n;
     void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
                         out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
@@ -1139,43 +1151,79 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         if (!host_out[f]) return fail(ADH_ERR_INVALID_ARGUMENT, "candidate table buffer is NULL");
         memset(host_out[f], 0, (size_t)out->n * width[f]);
     }
+    lap("memset");
     if (n == 0) return ADH_OK;
     if (h->tims_staged) return select_candidates_im(h, pc, cfg, kernel, k_rows, k_cols, out);
-    // validate the fragment slices, size the LDS: longest slice, largest tile (the frame limits
-    // of get_frame_indices, jitclasses/utils.py:24-88, depend on the tolerance only through the
-    // number of cycles)
+    // One grow-only slab of the handle holds the precursor columns, the tile limits and the candidate table of a
+    // call (19 allocations and as many frees cost more than the kernel).  The per-precursor limits - two searches
+    // over the retention times of 3e5 spectra each: 17 ms per 100 000 precursors on one host core - and the checks
+    // of the fragment slices are a kernel of their own; three words come back to size the LDS.
     sel::SelCaps caps{};
     caps.n_iso = (int32_t)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
     caps.k_rows = k_rows;
     caps.k_cols = k_cols;
     const int L = h->run.cycle_len;
-    const int64_t cmax = h->run.n_spectra / L;
-    const std::vector<float> &rtv = h->h_rt;
-    std::vector<int32_t> cyc_start((size_t)n), cyc_count((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
-            return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
-        if (pc->charge[i] == 0) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
-        caps.n_lib = std::max<int32_t>(caps.n_lib, (int32_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]));
-        // get_frame_indices_tolerance -> get_frame_indices (alpharaw_jit.py:172-203, jitclasses/utils.py:24-88)
-        const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
-        const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), lo) - rtv.begin();
-        const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), hi) - rtv.begin();
-        const int64_t c_lo = f_lo / L, c_hi = f_hi / L;
-        int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
-        len = 16 * (int64_t)std::ceil((double)len / 16.0);
-        int64_t cs = c_lo, ce = c_lo + len;
-        if (ce > cmax) {
-            ce = cmax;
-            cs = cmax - len;
-            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
-        }
-        cyc_start[(size_t)i] = (int32_t)cs;
-        cyc_count[(size_t)i] = (int32_t)(ce - cs);
-        caps.f = std::max<int32_t>(caps.f, (int32_t)(ce - cs));
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_idx = carve((size_t)n * 4), o_fs = carve((size_t)n * 4), o_fe = carve((size_t)n * 4), o_ch = carve((size_t)n),
+                 o_rt = carve((size_t)n * 4), o_mz = carve((size_t)n * 4), o_iso = carve((size_t)n * pc->n_isotope_cols * 4),
+                 o_cs = carve((size_t)n * 4), o_cc = carve((size_t)n * 4), o_red = carve(16),
+                 o_kern = carve((size_t)k_rows * k_cols * 4);
+    size_t o_out[9];
+    for (int f = 0; f < 9; ++f) o_out[f] = carve((size_t)out->n * width[f]);
+    if (h->sel_slab_bytes < off) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (h->sel_slab) (void)hipFree(h->sel_slab);
+        h->sel_slab = nullptr;
+        h->sel_slab_bytes = 0;
+        const hipError_t e = hipMalloc(&h->sel_slab, off);
+        if (e != hipSuccess) return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection slab): ") + hipGetErrorString(e));
+        h->sel_slab_bytes = off;
     }
-    caps.n_lib = std::max(caps.n_lib, 1);
-    caps.f = std::max(caps.f, 1);
+    unsigned char *slab = static_cast<unsigned char *>(h->sel_slab);
+    auto put = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(slab + at, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+    };
+    hipError_t e = put(o_idx, pc->precursor_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_fs, pc->frag_start_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_fe, pc->frag_stop_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_ch, pc->charge, (size_t)n);
+    if (e == hipSuccess) e = put(o_rt, pc->rt, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_mz, pc->mz, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_iso, pc->isotope_intensity, (size_t)n * pc->n_isotope_cols * 4);
+    if (e == hipSuccess) e = put(o_kern, kernel, (size_t)k_rows * k_cols * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(slab + o_red, 0, 16, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(slab + o_out[0], 0, off - o_out[0], h->stream);  // (the candidate table: rows without a candidate stay zero)
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("selection upload: ") + hipGetErrorString(e));
+    DevPrecursors dp{};
+    dp.n_iso_cols = pc->n_isotope_cols;
+    dp.precursor_idx = reinterpret_cast<const uint32_t *>(slab + o_idx);
+    dp.frag_start = reinterpret_cast<const uint32_t *>(slab + o_fs);
+    dp.frag_stop = reinterpret_cast<const uint32_t *>(slab + o_fe);
+    dp.charge = slab + o_ch;
+    dp.rt = reinterpret_cast<const float *>(slab + o_rt);
+    dp.mz = reinterpret_cast<const float *>(slab + o_mz);
+    dp.iso = reinterpret_cast<const float *>(slab + o_iso);
+    dp.cycle_start = reinterpret_cast<const int32_t *>(slab + o_cs);
+    dp.cycle_count = reinterpret_cast<const int32_t *>(slab + o_cc);
+    int32_t *d_red = reinterpret_cast<int32_t *>(slab + o_red);
+    hipLaunchKernelGGL(adh_select_limits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->run.rt,
+                       h->run.n_spectra, L, dp, n, h->n_lib, cfg->rt_tolerance, cfg->kernel_size,
+                       reinterpret_cast<int32_t *>(slab + o_cs), reinterpret_cast<int32_t *>(slab + o_cc), d_red);
+    e = hipGetLastError();
+    int32_t red[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(red, d_red, sizeof(red), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("selection limits: ") + hipGetErrorString(e));
+    lap("uploads + limits");
+    if (red[2] & 1) return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+    if (red[2] & 2) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+    caps.n_lib = std::max(red[0], 1);
+    caps.f = std::max(red[1], 1);
     const size_t lds = sel::lds_bytes(caps);
     if (lds > 150 * 1024) {
         char buf[200];
@@ -1183,37 +1231,18 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
                  lds, caps.f, caps.n_lib);
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
-    DeviceBuffers tmp;
-    DevPrecursors dp{};
-    dp.n_iso_cols = pc->n_isotope_cols;
-    int rc = upload(tmp, pc->precursor_idx, n, &dp.precursor_idx, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->frag_start_idx, n, &dp.frag_start, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->frag_stop_idx, n, &dp.frag_stop, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->charge, n, &dp.charge, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->rt, n, &dp.rt, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->mz, n, &dp.mz, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, pc->isotope_intensity, n * pc->n_isotope_cols, &dp.iso, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, cyc_start.data(), n, &dp.cycle_start, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, cyc_count.data(), n, &dp.cycle_count, h->stream);
-    const float *d_kernel = nullptr;
-    if (rc == ADH_OK) rc = upload(tmp, kernel, (int64_t)k_rows * k_cols, &d_kernel, h->stream);
     DevCandTable dt{};
-    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
-                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
-                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
-    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (size_t)out->n * width[f]);
-        if (e != hipSuccess) {
-            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
-            break;
-        }
-        tmp.ptrs.push_back(p);
-        *dev_out[f] = p;
-        e = hipMemsetAsync(p, 0, (size_t)out->n * width[f], h->stream);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
-    }
-    if (rc == ADH_OK) {
+    dt.precursor_idx = reinterpret_cast<uint32_t *>(slab + o_out[0]);
+    dt.rank = slab + o_out[1];
+    dt.score = reinterpret_cast<float *>(slab + o_out[2]);
+    dt.scan_center = reinterpret_cast<uint32_t *>(slab + o_out[3]);
+    dt.scan_start = reinterpret_cast<uint32_t *>(slab + o_out[4]);
+    dt.scan_stop = reinterpret_cast<uint32_t *>(slab + o_out[5]);
+    dt.frame_center = reinterpret_cast<uint32_t *>(slab + o_out[6]);
+    dt.frame_start = reinterpret_cast<uint32_t *>(slab + o_out[7]);
+    dt.frame_stop = reinterpret_cast<uint32_t *>(slab + o_out[8]);
+    int rc = ADH_OK;
+    {
         (void)hipFuncSetAttribute((const void *)adh_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024);
         (void)hipGetLastError();
@@ -1236,9 +1265,11 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         if (const char *env = getenv("ADH_DEBUG_SELECT_STOP")) caps.stop = atoi(env);
         if (getenv("ADH_DEBUG_SELECT_LDS_TAPS")) taps.cols = 0;  // A/B: the generic smoothing loop
         hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream, h->run, h->d_lib,
-                           dp, n, *cfg, d_kernel, taps, caps, dt);
-        hipError_t e = hipGetLastError();
+                           dp, n, *cfg, reinterpret_cast<const float *>(slab + o_kern), taps, caps, dt);
+        e = hipGetLastError();
         (void)hipEventRecord(e1, h->stream);
+        for (int f = 0; f < 9 && e == hipSuccess; ++f)
+            e = hipMemcpyAsync(host_out[f], slab + o_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("selection kernel: ") + hipGetErrorString(e));
         float ms = 0.0f;
@@ -1246,11 +1277,7 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
-    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
-        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
-    }
-    tmp.release();
+    lap("kernel + copy out");
     return rc;
 }
 

@@ -522,3 +522,53 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
         out.frame_stop[row] = (uint32_t)wrap0((int64_t)p_cl[r][1] * L + frame0, frame_max);
     }
 }
+
+// Tile limits of every precursor (get_frame_indices_tolerance -> get_frame_indices, alpharaw_jit.py:172-203,
+// jitclasses/utils.py:24-88: the frames of rt +- tolerance by two searches over the retention times, as cycles,
+// at least kernel_size of them, padded to a multiple of 16 and moved inside the run) and the checks of the
+// precursor columns.  red[0] = longest fragment slice, red[1] = largest cycle count, red[2] = error bits
+// (1: fragment slice outside the library, 2: charge 0).
+__global__ void adh_select_limits_kernel(const float *__restrict__ rt, int64_t n_spectra, int L, DevPrecursors pc, int64_t n,
+                                         int64_t n_lib, double rt_tolerance, int64_t kernel_size,
+                                         int32_t *__restrict__ cyc_start, int32_t *__restrict__ cyc_count,
+                                         int32_t *__restrict__ red) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t slice = 0, cnt = 0, err = 0;
+    if (i < n) {
+        const uint32_t fs = pc.frag_start[i], fe = pc.frag_stop[i];
+        if (fe < fs || (int64_t)fe > n_lib) err |= 1;
+        else slice = (int32_t)(fe - fs);
+        if (pc.charge[i] == 0) err |= 2;
+        const float lo = (float)((double)pc.rt[i] - rt_tolerance), hi = (float)((double)pc.rt[i] + rt_tolerance);
+        auto lower_bound = [&](float x) {
+            int64_t a = 0, b = n_spectra;
+            while (a < b) {
+                const int64_t m = (a + b) >> 1;
+                if (rt[m] < x) a = m + 1; else b = m;
+            }
+            return a;
+        };
+        const int64_t cmax = n_spectra / L;
+        const int64_t c_lo = lower_bound(lo) / L, c_hi = lower_bound(hi) / L;
+        int64_t len = max(c_hi - c_lo, kernel_size);
+        len = (len + 15) / 16 * 16;
+        int64_t cs = c_lo, ce = c_lo + len;
+        if (ce > cmax) {
+            ce = cmax;
+            cs = cmax - len;
+            if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+        }
+        cyc_start[i] = (int32_t)cs;
+        cyc_count[i] = cnt = (int32_t)(ce - cs);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        slice = max(slice, __shfl_xor(slice, off));
+        cnt = max(cnt, __shfl_xor(cnt, off));
+        err |= __shfl_xor(err, off);
+    }
+    if ((threadIdx.x & (ADH_WAVE - 1)) == 0) {
+        atomicMax(&red[0], slice);
+        atomicMax(&red[1], cnt);
+        if (err) atomicOr(&red[2], err);
+    }
+}
