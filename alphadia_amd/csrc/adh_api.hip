@@ -856,121 +856,86 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                     return fail(ADH_ERR_UNSUPPORTED, "smoothing kernel is not separable (not an outer product)");
     }
     const int n_iso = (int)std::min<int64_t>(cfg->top_k_precursors, pc->n_isotope_cols);
-    const std::vector<double> &rtv = h->h_rt_im, &mobv = h->h_mobility_im;
-    const double *cyc = h->h_cycle.data();
-    const int64_t cmax = (T.n_frames - 1) / L;  // precursor_cycle_max_index (bruker_jit.py:131)
-    std::vector<selim::PrecRec> recs((size_t)n);
-    int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1;  // LDS capacities of the score kernel (adh_select_im.hip)
-    auto rev_upper = [&](float v) {  // searchsorted(mobility_values[::-1], v, "right")
-        int64_t a = 0, b = SM;
-        while (a < b) {
-            const int64_t m = (a + b) >> 1;
-            if (mobv[(size_t)(SM - 1 - m)] <= (double)v) a = m + 1; else b = m;
-        }
-        return a;
+    // One grow-only slab of the handle: precursor columns, plan records, their scratch sizes, the candidate table.
+    // The plan (limits, validity, empty-query test) is a kernel (adh_select_plan_im_kernel); the host only cuts
+    // the batches.
+    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
+                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
+    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) / 256 * 256;
+        return at;
     };
-    // the per-precursor limits (searches over rt / mobility, the "empty push query" test over L x S window
-    // rows) are independent: spread over the host threads (230 ms on one thread for 200 000 precursors)
-    struct Caps5 { int32_t cap_cells = 1, cap_tp = 1, cap_mp = 1, cap_s = 1, cap_f = 1; };
-    auto plan_range = [&](int64_t i0, int64_t i1, Caps5 &c, int &err) {
-    for (int64_t i = i0; i < i1; ++i) {
-            selim::PrecRec &r = recs[(size_t)i];
-            memset(&r, 0, sizeof(r));
-            if (pc->frag_stop_idx[i] < pc->frag_start_idx[i] || (int64_t)pc->frag_stop_idx[i] > h->n_lib)
-                { err = 1; return; }
-            if (pc->charge[i] == 0) { err = 2; return; }
-            if ((int64_t)(pc->frag_stop_idx[i] - pc->frag_start_idx[i]) + n_iso > selim::MAX_W)
-                { err = 3; return; }
-            r.precursor_idx = pc->precursor_idx[i];
-            r.frag_start = pc->frag_start_idx[i];
-            r.frag_stop = pc->frag_stop_idx[i];
-            r.mz = pc->mz[i];
-            r.charge = pc->charge[i];
-            // frame limits: get_frame_indices (jitclasses/utils.py:24-88) with the zeroth frame
-            const float lo = (float)((double)pc->rt[i] - cfg->rt_tolerance), hi = (float)((double)pc->rt[i] + cfg->rt_tolerance);
-            const int64_t f_lo = std::lower_bound(rtv.begin(), rtv.end(), (double)lo) - rtv.begin();
-            const int64_t f_hi = std::lower_bound(rtv.begin(), rtv.end(), (double)hi) - rtv.begin();
-            const int64_t c_lo = (f_lo + z) / L, c_hi = (f_hi + z) / L;
-            int64_t len = std::max<int64_t>(c_hi - c_lo, cfg->kernel_size);
-            len = 16 * (int64_t)std::ceil((double)len / 16.0);
-            int64_t cs = c_lo, ce = c_lo + len;
-            if (ce > cmax) {
-                ce = cmax;
-                cs = cmax - len;
-                if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
-            }
-            // scan limits: _get_scan_indices (bruker_jit.py:204-245); ceil of a negative quotient
-            const float m_hi = (float)((double)pc->mobility[i] + cfg->mobility_tolerance);
-            const float m_lo = (float)((double)pc->mobility[i] - cfg->mobility_tolerance);
-            const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
-            const int64_t opt_len = 16 * (int64_t)std::ceil((double)(s_first - s_second) / 16.0);
-            int64_t ss = s_first, se = s_first - opt_len;
-            if (se < 0) {
-                se = 0;
-                ss = std::min<int64_t>(opt_len, SM);
-            }
-            const int64_t S = std::max<int64_t>(se - ss, 0), F = ce - cs;
-            r.cycle_start = (int32_t)cs;
-            r.n_cycles = (int32_t)std::max<int64_t>(F, 0);
-            r.scan_start = (int32_t)ss;
-            r.n_scans = (int32_t)S;
-            bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
-            if (ok) {
-                // an empty push query ends the precursor (bruker_jit.py:516-519, selection.py:40-49)
-                const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc->charge[i];
-                const double q_lo = (double)(float)((double)pc->mz[i] + 0.0), q_hi = (double)(float)((double)pc->mz[i] + off);
-                bool any_f = false, any_p = false;
-                for (int row = 0; row < L && !(any_f && any_p); ++row)
-                    for (int64_t sc = ss; sc < ss + S; ++sc) {
-                        const double wl = cyc[2 * ((int64_t)row * SM + sc)], wh = cyc[2 * ((int64_t)row * SM + sc) + 1];
-                        any_f = any_f || (q_lo <= wh && q_hi >= wl);
-                        any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
-                        if (any_f && any_p) break;  // both queries are non-empty: nothing more to learn
-                    }
-                ok = any_f && any_p;
-            }
-            r.ok = ok ? 1 : 0;
-            if (ok) {
-                c.cap_cells = std::max<int32_t>(c.cap_cells, (int32_t)(S * F));
-                c.cap_tp = std::max<int32_t>(c.cap_tp, (int32_t)(S * (F + k1)));
-                c.cap_mp = std::max<int32_t>(c.cap_mp, (int32_t)((S + k0) * F));
-                c.cap_s = std::max<int32_t>(c.cap_s, (int32_t)S);
-                c.cap_f = std::max<int32_t>(c.cap_f, (int32_t)F);
-            }
-        }
-    };
-    {
-        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 2048 + 1}));
-        std::vector<Caps5> caps((size_t)n_thr);
-        std::vector<int> errs((size_t)n_thr, 0);
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_thr; ++t) {
-            const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
-            bool started = false;
-            if (t + 1 < n_thr) {
-                try {  // (no exception may cross the C ABI: a range whose thread cannot be started runs here)
-                    pool.emplace_back(plan_range, i0, i1, std::ref(caps[(size_t)t]), std::ref(errs[(size_t)t]));
-                    started = true;
-                } catch (...) {
-                }
-            }
-            if (!started) plan_range(i0, i1, caps[(size_t)t], errs[(size_t)t]);
-        }
-        for (std::thread &th : pool) th.join();
-        for (int t = 0; t < n_thr; ++t) {
-            if (errs[(size_t)t] == 1) return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
-            if (errs[(size_t)t] == 2) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
-            if (errs[(size_t)t] == 3) return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
-            cap_cells = std::max(cap_cells, caps[(size_t)t].cap_cells);
-            cap_tp = std::max(cap_tp, caps[(size_t)t].cap_tp);
-            cap_mp = std::max(cap_mp, caps[(size_t)t].cap_mp);
-            cap_s = std::max(cap_s, caps[(size_t)t].cap_s);
-            cap_f = std::max(cap_f, caps[(size_t)t].cap_f);
-        }
+    const size_t o_idx = carve((size_t)n * 4), o_fs = carve((size_t)n * 4), o_fe = carve((size_t)n * 4), o_ch = carve((size_t)n),
+                 o_rt = carve((size_t)n * 4), o_mob = carve((size_t)n * 4), o_mz = carve((size_t)n * 4),
+                 o_recs = carve((size_t)n * sizeof(selim::PrecRec)), o_need = carve((size_t)n * 8), o_cum = carve((size_t)n * 8),
+                 o_red = carve(64), o_ku = carve((size_t)k0 * 8), o_kv = carve((size_t)k1 * 8), o_first = carve((size_t)(n + 2) * 8);
+    size_t scan_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n,
+                                             h->stream));
+    const size_t o_tmp = carve(scan_bytes);
+    size_t o_out[9];
+    for (int f = 0; f < 9; ++f) o_out[f] = carve((size_t)out->n * width[f]);
+    if (h->sel_slab_bytes < off) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (h->sel_slab) (void)hipFree(h->sel_slab);
+        h->sel_slab = nullptr;
+        h->sel_slab_bytes = 0;
+        const hipError_t e = hipMalloc(&h->sel_slab, off);
+        if (e != hipSuccess) return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection slab): ") + hipGetErrorString(e));
+        h->sel_slab_bytes = off;
     }
+    unsigned char *slab = static_cast<unsigned char *>(h->sel_slab);
+    auto put = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(slab + at, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+    };
+    hipError_t e = put(o_idx, pc->precursor_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_fs, pc->frag_start_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_fe, pc->frag_stop_idx, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_ch, pc->charge, (size_t)n);
+    if (e == hipSuccess) e = put(o_rt, pc->rt, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_mob, pc->mobility, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_mz, pc->mz, (size_t)n * 4);
+    if (e == hipSuccess) e = put(o_ku, ku.data(), (size_t)k0 * 8);
+    if (e == hipSuccess) e = put(o_kv, kv.data(), (size_t)k1 * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(slab + o_red, 0, 64, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(slab + o_out[0], 0, off - o_out[0], h->stream);  // (rows without a candidate stay zero)
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("selection upload: ") + hipGetErrorString(e));
+    SelPlanIn pin{};
+    pin.precursor_idx = reinterpret_cast<const uint32_t *>(slab + o_idx);
+    pin.frag_start = reinterpret_cast<const uint32_t *>(slab + o_fs);
+    pin.frag_stop = reinterpret_cast<const uint32_t *>(slab + o_fe);
+    pin.charge = slab + o_ch;
+    pin.rt = reinterpret_cast<const float *>(slab + o_rt);
+    pin.mobility = reinterpret_cast<const float *>(slab + o_mob);
+    pin.mz = reinterpret_cast<const float *>(slab + o_mz);
+    selim::PrecRec *d_recs = reinterpret_cast<selim::PrecRec *>(slab + o_recs);
+    unsigned long long *d_need = reinterpret_cast<unsigned long long *>(slab + o_need);
+    unsigned long long *d_cum = reinterpret_cast<unsigned long long *>(slab + o_cum);
+    int32_t *d_red = reinterpret_cast<int32_t *>(slab + o_red);
+    unsigned long long *d_biggest = reinterpret_cast<unsigned long long *>(slab + o_red + 32);
+    hipLaunchKernelGGL(adh_select_plan_im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, T, pin, n, h->n_lib,
+                       n_iso, cfg->rt_tolerance, cfg->mobility_tolerance, cfg->kernel_size, (int)k0, (int)k1, d_recs, d_need, d_red,
+                       d_biggest);
+    e = hipGetLastError();
+    size_t tb = scan_bytes;
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(slab + o_tmp, tb, d_need, d_cum, (int)n, h->stream);
+    struct {
+        int32_t red[8];
+        unsigned long long biggest, pad;
+    } meta;
+    unsigned long long all = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&meta, slab + o_red, 48, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&all, d_cum + (n - 1), 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("selection plan: ") + hipGetErrorString(e));
+    if (meta.red[0] & 1) return fail(ADH_ERR_INVALID_ARGUMENT, "fragment slice outside the staged library");
+    if (meta.red[0] & 2) return fail(ADH_ERR_INVALID_ARGUMENT, "precursor charge must be > 0");
+    if (meta.red[0] & 4) return fail(ADH_ERR_UNSUPPORTED, "more than 64 m/z windows per precursor");
+    int32_t cap_cells = std::max(meta.red[1], 1), cap_s = std::max(meta.red[2], 1), cap_f = std::max(meta.red[3], 1);
     cap_cells = (cap_cells + 1) & ~1;  // the float64 kernel factors follow the float tiles in LDS
-    (void)cap_tp;
-    (void)cap_mp;
     const int tap_budget = adh_select_tap_budget(cap_cells, cap_s, k0, k1);
     const size_t lds_smooth = adh_select_smooth_im_lds_bytes(cap_cells, cap_s, k0, k1, tap_budget);
     const size_t lds = std::max(lds_smooth, adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f));
@@ -980,72 +945,64 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
                  cap_cells, cap_f, lds);
         return fail(ADH_ERR_UNSUPPORTED, buf);
     }
-    // batches of precursors whose tiles fit a bounded scratch slab
-    // the scratch slab of the handle is used (kept between calls; only reserved memory: a precursor's tiles are
-    // normally kept in sparse form and touch a few KB of their block); batches follow each other on the
-    // stream, so a batch may reuse the slab of the one before without the host waiting
+    // batches of precursors whose tiles fit a bounded scratch slab: the scratch slab of the handle is used (kept
+    // between calls; only reserved memory: a precursor's tiles are normally kept in sparse form and touch a few KB of
+    // their block); batches follow each other on the stream, so a batch may reuse the slab of the one before without
+    // the host waiting
     uint64_t budget = 8ull << 30;
     if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
-    {
-        uint64_t all = 0, biggest = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const selim::PrecRec &r = recs[(size_t)i];
-            const uint64_t need = selim::SEL_HEADER +
-                                  (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
-            const uint64_t aligned = (need + 255) / 256 * 256;
-            all += aligned;
-            biggest = std::max(biggest, aligned);
-        }
-        budget = std::max(std::min(budget, all), biggest);
-        budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
-    }
+    budget = std::max<uint64_t>(std::min<uint64_t>(budget, all), meta.biggest);
+    budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
     const double t_plan = now();
-    DeviceBuffers tmp;
-    const double *d_ku = nullptr, *d_kv = nullptr;
-    int rc = upload(tmp, ku.data(), k0, &d_ku, h->stream);
-    if (rc == ADH_OK) rc = upload(tmp, kv.data(), k1, &d_kv, h->stream);
+    int rc = ADH_OK;
+    std::vector<int64_t> first{0};  // first precursor of every batch, then n
+    if (all > budget) {
+        // the longest prefixes that fit: the inclusive sums come back and are cut on the host
+        std::vector<unsigned long long> cum((size_t)n);
+        HIP_TRY(hipMemcpy(cum.data(), d_cum, (size_t)n * 8, hipMemcpyDeviceToHost));
+        while (first.back() < n) {
+            const int64_t f0 = first.back();
+            const unsigned long long base = f0 > 0 ? cum[(size_t)f0 - 1] : 0ull;
+            const int64_t last = std::upper_bound(cum.begin() + f0, cum.end(), base + budget) - cum.begin();
+            if (last == f0) return fail(ADH_ERR_UNSUPPORTED, "one precursor's tiles exceed the selection scratch budget");
+            first.push_back(last);
+        }
+    } else {
+        first.push_back(n);
+    }
+    const int n_batches = (int)first.size() - 1;
+    int64_t *d_first = reinterpret_cast<int64_t *>(slab + o_first);
+    HIP_TRY(hipMemcpyAsync(d_first, first.data(), first.size() * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(adh_select_offsets_im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_recs, d_cum, d_need,
+                       n, d_first, n_batches);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));  // (first lives on this stack frame)
+    const double *d_ku = reinterpret_cast<const double *>(slab + o_ku), *d_kv = reinterpret_cast<const double *>(slab + o_kv);
     DevCandTable dt{};
-    void *host_out[] = {out->precursor_idx, out->rank, out->score, out->scan_center, out->scan_start,
-                        out->scan_stop, out->frame_center, out->frame_start, out->frame_stop};
-    const size_t width[] = {4, 1, 4, 4, 4, 4, 4, 4, 4};
-    void **dev_out[] = {(void **)&dt.precursor_idx, (void **)&dt.rank, (void **)&dt.score, (void **)&dt.scan_center,
-                        (void **)&dt.scan_start, (void **)&dt.scan_stop, (void **)&dt.frame_center,
-                        (void **)&dt.frame_start, (void **)&dt.frame_stop};
-    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>((size_t)out->n * width[f], 16));
-        if (e != hipSuccess) {
-            rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(candidate table): ") + hipGetErrorString(e));
-            break;
-        }
-        tmp.ptrs.push_back(p);
-        *dev_out[f] = p;
-        e = hipMemsetAsync(p, 0, std::max<size_t>((size_t)out->n * width[f], 16), h->stream);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
-    }
+    dt.precursor_idx = reinterpret_cast<uint32_t *>(slab + o_out[0]);
+    dt.rank = slab + o_out[1];
+    dt.score = reinterpret_cast<float *>(slab + o_out[2]);
+    dt.scan_center = reinterpret_cast<uint32_t *>(slab + o_out[3]);
+    dt.scan_start = reinterpret_cast<uint32_t *>(slab + o_out[4]);
+    dt.scan_stop = reinterpret_cast<uint32_t *>(slab + o_out[5]);
+    dt.frame_center = reinterpret_cast<uint32_t *>(slab + o_out[6]);
+    dt.frame_start = reinterpret_cast<uint32_t *>(slab + o_out[7]);
+    dt.frame_stop = reinterpret_cast<uint32_t *>(slab + o_out[8]);
     unsigned char *d_scratch = nullptr;
-    selim::PrecRec *d_recs = nullptr;
-    if (rc == ADH_OK) {
-        if (h->scratch_slab_bytes < budget) {
-            // (exactly the budget: ensure_scratch's head-room is for scoring batches that grow from call to call)
-            hipError_t e = hipDeviceSynchronize();
-            if (h->scratch_slab) (void)hipFree(h->scratch_slab);
-            h->scratch_slab = nullptr;
-            h->scratch_slab_bytes = 0;
-            if (e == hipSuccess) e = hipMalloc(&h->scratch_slab, budget);
-            if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
-            else h->scratch_slab_bytes = budget;
-        }
-        d_scratch = static_cast<unsigned char *>(h->scratch_slab);
+    if (h->scratch_slab_bytes < budget) {
+        // (exactly the budget: ensure_scratch's head-room is for scoring batches that grow from call to call)
+        e = hipDeviceSynchronize();
+        if (h->scratch_slab) (void)hipFree(h->scratch_slab);
+        h->scratch_slab = nullptr;
+        h->scratch_slab_bytes = 0;
+        if (e == hipSuccess) e = hipMalloc(&h->scratch_slab, budget);
+        if (e != hipSuccess) return fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection scratch): ") + hipGetErrorString(e));
+        h->scratch_slab_bytes = budget;
     }
-    if (rc == ADH_OK) {
-        hipError_t e = hipMalloc((void **)&d_recs, std::max<size_t>((size_t)n * sizeof(selim::PrecRec), 16));
-        if (e != hipSuccess) rc = fail(ADH_ERR_OUT_OF_MEMORY, std::string("hipMalloc(selection plan): ") + hipGetErrorString(e));
-        else tmp.ptrs.push_back(d_recs);
-    }
+    d_scratch = static_cast<unsigned char *>(h->scratch_slab);
     double total_ms = 0.0;
     const double t_alloc = now();
-    if (rc == ADH_OK) {
+    {
         (void)hipFuncSetAttribute((const void *)adh_select_score_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024);
         (void)hipFuncSetAttribute((const void *)adh_select_smooth_im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1054,69 +1011,41 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        // plan every batch on the host, one upload, then the kernels of the batches back to back
-        std::vector<std::pair<int64_t, int64_t>> batches;
         int32_t debug_dense = 0;
         if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_DENSE")) debug_dense = atoi(dbg);
         int32_t debug_abl = 0;
         if (const char *dbg = getenv("ADH_DEBUG_SELECT_IM_ABL")) debug_abl = atoi(dbg);
-        int64_t first = 0;
-        while (first < n && rc == ADH_OK) {
-            uint64_t off = 0;
-            int64_t last = first;
-            while (last < n) {
-                selim::PrecRec &r = recs[(size_t)last];
-                const uint64_t need = selim::SEL_HEADER +
-                                      (r.ok ? (uint64_t)(r.frag_stop - r.frag_start + n_iso + 1) * r.n_scans * r.n_cycles * 4 : 0);
-                const uint64_t aligned = (need + 255) / 256 * 256;
-                if (off + aligned > budget) break;
-                r.scratch_off = off;
-                off += aligned;
-                ++last;
-            }
-            if (last == first) {
-                rc = fail(ADH_ERR_UNSUPPORTED, "one precursor's tiles exceed the selection scratch budget");
-                break;
-            }
-            batches.emplace_back(first, last);
-            first = last;
+        e = hipEventRecord(e0, h->stream);
+        for (int b = 0; b < n_batches && e == hipSuccess; ++b) {
+            const int64_t b0 = first[(size_t)b];
+            const int32_t cnt = (int32_t)(first[(size_t)b + 1] - b0);
+            hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
+                               h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
+            hipLaunchKernelGGL(adh_select_smooth_im_kernel, dim3((unsigned)cnt), dim3(selim::SMOOTH_THREADS), lds_smooth,
+                               h->stream, d_recs + b0, cnt, d_ku, d_kv, k0, k1, cap_cells, cap_s, d_scratch, debug_abl,
+                               (int32_t)tap_budget);
+            hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS),
+                               adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f), h->stream, T, d_recs + b0, cnt, b0, *cfg,
+                               cap_cells, cap_s, cap_f, d_scratch, dt);
+            e = hipGetLastError();
         }
-        if (rc == ADH_OK) {
-            hipError_t e = hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(selim::PrecRec), hipMemcpyHostToDevice, h->stream);
-            if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
-            for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) {
-                const int64_t b0 = batches[b].first;
-                const int32_t cnt = (int32_t)(batches[b].second - b0);
-                hipLaunchKernelGGL(adh_select_gather_im_kernel, dim3((unsigned)cnt), dim3(ADH_WAVE), 0, h->stream, T,
-                                   h->d_lib, d_recs + b0, cnt, *cfg, (int32_t)n_iso, d_scratch, debug_dense);
-                hipLaunchKernelGGL(adh_select_smooth_im_kernel, dim3((unsigned)cnt), dim3(selim::SMOOTH_THREADS), lds_smooth,
-                                   h->stream, d_recs + b0, cnt, d_ku, d_kv, k0, k1, cap_cells, cap_s, d_scratch, debug_abl,
-                                   (int32_t)tap_budget);
-                hipLaunchKernelGGL(adh_select_score_im_kernel, dim3((unsigned)cnt), dim3(selim::SCORE_THREADS),
-                                   adh_select_score_im_lds_bytes(cap_cells, cap_s, cap_f), h->stream, T, d_recs + b0, cnt, b0, *cfg,
-                                   cap_cells, cap_s, cap_f, d_scratch, dt);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
-            float ms = 0.0f;
-            if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
-        }
+        if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        for (int f = 0; f < 9 && e == hipSuccess; ++f)
+            e = hipMemcpyAsync(host_out[f], slab + o_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("ion-mobility selection kernels: ") + hipGetErrorString(e));
+        float ms = 0.0f;
+        if (rc == ADH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) total_ms += ms;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
     const double t_kernels = now();
-    for (int f = 0; f < 9 && rc == ADH_OK; ++f) {
-        hipError_t e = hipMemcpy(host_out[f], *dev_out[f], (size_t)out->n * width[f], hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ADH_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
-    }
     if (rc == ADH_OK) h->last_select_ms = total_ms;
     const double t_copy = now();
-    tmp.release();
     if (timing)
-        fprintf(stderr, "[adh] select_candidates_im n=%lld: host plan %.2f ms, allocations %.2f, upload + kernels %.2f (kernels %.2f), D2H %.2f, free %.2f\n",
-                (long long)n, t_plan - t_0, t_alloc - t_plan, t_kernels - t_alloc, total_ms, t_copy - t_kernels, now() - t_copy);
+        fprintf(stderr, "[adh] select_candidates_im n=%lld: upload + plan %.2f ms, batches %.2f, kernels + copy-out %.2f (kernels %.2f)\n",
+                (long long)n, t_plan - t_0, t_alloc - t_plan, t_kernels - t_alloc, total_ms);
+    (void)t_copy;
     return rc;
 }
 

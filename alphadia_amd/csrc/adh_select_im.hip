@@ -842,3 +842,126 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
         out.frame_stop[row] = (uint32_t)wrap0((int64_t)p_cl[q][1] * L + frame0, frame_max);
     }
 }
+
+// ---- the per-precursor plan of the ion-mobility selection on the device (round 4; 16 host threads took 16 ms per
+// 200 000 precursors for it): frame limits (get_frame_indices, jitclasses/utils.py:24-88, with the zeroth frame),
+// scan limits (_get_scan_indices, bruker_jit.py:204-245, with its ceil of a negative quotient), the validity rules
+// of _is_valid (selection.py:40-75) and the "empty push query" exit (bruker_jit.py:516-519): one thread per
+// precursor.  red: [0] error bits (1 slice outside the library, 2 charge 0, 4 more than MAX_W windows), [1] largest
+// S * F, [2] largest S, [3] largest F of the precursors that go on; need[i] = bytes of the precursor's scratch
+// block (a multiple of 256), biggest = the largest of them.
+struct SelPlanIn {
+    const uint32_t *precursor_idx, *frag_start, *frag_stop;
+    const uint8_t *charge;
+    const float *rt, *mobility, *mz;
+};
+__global__ void adh_select_plan_im_kernel(DevTims T, SelPlanIn pc, int64_t n, int64_t n_lib, int n_iso, double rt_tolerance,
+                                          double mobility_tolerance, int64_t kernel_size, int k0, int k1,
+                                          selim::PrecRec *__restrict__ recs, unsigned long long *__restrict__ need,
+                                          int32_t *__restrict__ red, unsigned long long *__restrict__ biggest) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int L = T.cycle_len, SM = T.scan_max, z = T.zeroth;
+    selim::PrecRec r;
+    memset(&r, 0, sizeof(r));
+    int err = 0;
+    const uint32_t fs = pc.frag_start[i], fe = pc.frag_stop[i];
+    if (fe < fs || (int64_t)fe > n_lib) err = 1;
+    else if (pc.charge[i] == 0) err = 2;
+    else if ((int64_t)(fe - fs) + n_iso > selim::MAX_W) err = 4;
+    if (err) {
+        atomicOr(&red[0], err);
+        recs[i] = r;
+        need[i] = 0ull;
+        return;
+    }
+    r.precursor_idx = pc.precursor_idx[i];
+    r.frag_start = fs;
+    r.frag_stop = fe;
+    r.mz = pc.mz[i];
+    r.charge = pc.charge[i];
+    const float lo = (float)((double)pc.rt[i] - rt_tolerance), hi = (float)((double)pc.rt[i] + rt_tolerance);
+    auto rt_lower = [&](double x) {
+        int64_t a = 0, b = T.n_frames;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if (T.rt[m] < x) a = m + 1; else b = m;
+        }
+        return a;
+    };
+    auto rev_upper = [&](float v) {  // searchsorted(mobility_values[::-1], v, "right")
+        int64_t a = 0, b = SM;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if (T.mobility[SM - 1 - m] <= (double)v) a = m + 1; else b = m;
+        }
+        return a;
+    };
+    const int64_t cmax = (T.n_frames - 1) / L;  // precursor_cycle_max_index (bruker_jit.py:131)
+    const int64_t c_lo = (rt_lower((double)lo) + z) / L, c_hi = (rt_lower((double)hi) + z) / L;
+    int64_t len = max(c_hi - c_lo, kernel_size);
+    len = 16 * (int64_t)ceil((double)len / 16.0);
+    int64_t cs = c_lo, ce = c_lo + len;
+    if (ce > cmax) {
+        ce = cmax;
+        cs = cmax - len;
+        if (cs < 0) cs = (cmax % 2 == 0) ? 0 : 1;
+    }
+    const float m_hi = (float)((double)pc.mobility[i] + mobility_tolerance);
+    const float m_lo = (float)((double)pc.mobility[i] - mobility_tolerance);
+    const int64_t s_first = SM - rev_upper(m_hi), s_second = SM - rev_upper(m_lo);
+    const int64_t opt_len = 16 * (int64_t)ceil((double)(s_first - s_second) / 16.0);
+    int64_t ss = s_first, se = s_first - opt_len;
+    if (se < 0) {
+        se = 0;
+        ss = min(opt_len, (int64_t)SM);
+    }
+    const int64_t S = max(se - ss, (int64_t)0), F = ce - cs;
+    r.cycle_start = (int32_t)cs;
+    r.n_cycles = (int32_t)max(F, (int64_t)0);
+    r.scan_start = (int32_t)ss;
+    r.n_scans = (int32_t)S;
+    bool ok = F > 0 && S > 0 && n_iso > 0 && S % 2 == 0 && S >= k0 && F >= k1 && ss >= 0 && ss + S <= SM;
+    if (ok) {
+        const double off = (double)(n_iso - 1) * 1.0033548350700006 / (double)pc.charge[i];
+        const double q_lo = (double)(float)((double)pc.mz[i] + 0.0), q_hi = (double)(float)((double)pc.mz[i] + off);
+        bool any_f = false, any_p = false;
+        for (int row = 0; row < L && !(any_f && any_p); ++row)
+            for (int64_t sc = ss; sc < ss + S; ++sc) {
+                const double wl = T.cycle[2 * ((int64_t)row * SM + sc)], wh = T.cycle[2 * ((int64_t)row * SM + sc) + 1];
+                any_f = any_f || (q_lo <= wh && q_hi >= wl);
+                any_p = any_p || (-1.0 <= wh && -1.0 >= wl);
+                if (any_f && any_p) break;
+            }
+        ok = any_f && any_p;
+    }
+    r.ok = ok ? 1 : 0;
+    recs[i] = r;
+    const unsigned long long bytes =
+        selim::SEL_HEADER + (ok ? (unsigned long long)(fe - fs + (uint32_t)n_iso + 1u) * (unsigned long long)S * (unsigned long long)F * 4ull : 0ull);
+    const unsigned long long aligned = (bytes + 255ull) / 256ull * 256ull;
+    need[i] = aligned;
+    atomicMax(biggest, aligned);
+    if (ok) {
+        atomicMax(&red[1], (int32_t)(S * F));
+        atomicMax(&red[2], (int32_t)S);
+        atomicMax(&red[3], (int32_t)F);
+    }
+}
+
+// scratch offsets of the batches: cum = inclusive sums of need; batch b covers the precursors [first[b], first[b + 1])
+// and its blocks start at 0: offset = cum[i] - need[i] - (cum[first[b] - 1] or 0)
+__global__ void adh_select_offsets_im_kernel(selim::PrecRec *__restrict__ recs, const unsigned long long *__restrict__ cum,
+                                             const unsigned long long *__restrict__ need, int64_t n,
+                                             const int64_t *__restrict__ first, int n_batches) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int a = 0, b = n_batches;  // last batch with first[a] <= i
+    while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (first[m] <= i) a = m; else b = m;
+    }
+    const int64_t f = first[a];
+    const unsigned long long base = f > 0 ? cum[f - 1] : 0ull;
+    recs[i].scratch_off = cum[i] - need[i] - base;
+}

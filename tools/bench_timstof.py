@@ -192,4 +192,50 @@ if not os.environ.get("ADH_BENCH_NO_CPU"):
             and np.array_equal(exp["stat_matched_peaks"], matched[:sample])),
     }
     result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+# ---- candidate selection on the same run and library (SURVEY.md section 8 f-1 on the ion-mobility layout;
+# tools/bench_select_timstof.py is the stand-alone form)
+if not os.environ.get("ADH_BENCH_NO_SELECT"):
+    from alphadia_amd import _abi  # noqa: E402
+    from alphadia_amd.selection import CandidateSelectionConfig, gaussian_kernel  # noqa: E402
+
+    dia.has_mobility = True
+    scfg = CandidateSelectionConfig()
+    scfg.update(dict(rt_tolerance=float(os.environ.get("RT_TOL", 15.0)), mobility_tolerance=0.1, candidate_count=3,
+                     peak_len_rt=3.0, sigma_scale_rt=0.5, peak_len_mobility=0.02))
+    kern = gaussian_kernel(dia, scfg.peak_len_rt, scfg.sigma_scale_rt, scfg.kernel_size, scfg.peak_len_mobility,
+                           scfg.sigma_scale_mobility)
+    pdf = case.library.precursor_df.sort_values("precursor_idx").reset_index(drop=True)
+    iso = pdf[[c for c in pdf.columns if c.startswith("i_")]].values
+
+    def pack(df, iso_rows):
+        return _abi.pack_precursors(df.precursor_idx.values, df.flat_frag_start_idx.values, df.flat_frag_stop_idx.values,
+                                    df.charge.values, df.rt_library.values, df.mobility_library.values,
+                                    df.mz_library.values, iso_rows)
+
+    pm = pack(pdf, iso)
+    got = ctx.select_candidates(pm, scfg, kern)
+    t0 = time.perf_counter()
+    got = ctx.select_candidates(pm, scfg, kern)
+    wall = time.perf_counter() - t0
+    k_ms = ctx.select_time_ms()
+    found = got["score"] > 0
+    sel = {
+        "workload": f"{len(pdf)} precursors, rt tolerance {scfg.rt_tolerance} s, mobility tolerance {scfg.mobility_tolerance}, "
+                    f"kernel {kern.shape[0]}x{kern.shape[1]}, 3 candidates",
+        "candidates_found": int(found.sum()),
+        "tile_scans": int(np.median((got["scan_stop"] - got["scan_start"])[found])) if found.any() else 0,
+        "kernel_ms": k_ms, "precursors_per_s_kernel": len(pdf) / (k_ms * 1e-3), "host_call_ms": wall * 1e3,
+    }
+    if not os.environ.get("ADH_BENCH_NO_CPU"):
+        from oracle import oracle
+
+        sample = min(len(pdf), 600)
+        th = min(64, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        exp = oracle.select_timstof(dia, cols, pack(pdf.iloc[:sample], iso[:sample]), scfg, kern, n_threads=th)
+        dt = time.perf_counter() - t0
+        n_rows = sample * scfg.candidate_count
+        sel["cpu_oracle"] = {"precursors_per_s": sample / dt, "threads": th, "sample": sample,
+                             "boxes_identical_to_gpu": bool(all(np.array_equal(got[c][:n_rows], exp[c]) for c in got if c != "score"))}
+    result["selection"] = sel
 print(json.dumps(result))
