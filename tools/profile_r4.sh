@@ -6,7 +6,8 @@
 #               -> r04_final_kernel_stats.csv, r04_final_pmc.csv, pmc_traffic.json (stamped with the commit)
 #   configs[3]: kernel trace + FETCH_SIZE / WRITE_SIZE of tools/bench_timstof.py at full size
 #               -> r04_timstof_kernel_stats.csv, r04_timstof_pmc.csv, timstof_traffic.json
-#   fragcomp / configs[4]: kernel traces of the bench legs -> r04_fragcomp_kernel_stats.csv, r04_multiplex_kernel_stats.csv
+#   fragcomp / configs[4] / selection: kernel traces of the bench legs -> r04_fragcomp_kernel_stats.csv,
+#               r04_multiplex_kernel_stats.csv, r04_selection_kernel_stats.csv
 #   then the driver-style bench line with all legs -> r04_final_bench.json
 export TMPDIR=/tmp
 REPO=$PWD
@@ -61,6 +62,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/p4_fc_stats -o p -- python $REPO/tools/
 python $REPO/tools/rocpd_summary.py /tmp/p4_fc_stats/p_results.db | grep -v "rocclr" > $OUT/r04_fragcomp_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p4_mx_stats -o p -- python $REPO/tools/bench_legs.py multiplex > $OUT/p4_mx.log 2>&1
 python $REPO/tools/rocpd_summary.py /tmp/p4_mx_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_multiplex_kernel_stats.csv
+# ---- candidate selection on the AlphaRaw run (the ion-mobility selection is part of the configs[3] trace above)
+ADH_BENCH_NO_CPU=1 rocprofv3 --kernel-trace --stats -d /tmp/p4_sel_stats -o p -- python $REPO/tools/bench_select.py > $OUT/p4_sel.log 2>&1
+python $REPO/tools/rocpd_summary.py /tmp/p4_sel_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r04_selection_kernel_stats.csv
 rm -rf /tmp/p4_*
 
 # ---- the bench line itself (driver style), with the traffic files of this run in place
@@ -71,3 +75,4 @@ tail -1 $OUT/r04_final_bench.json | cut -c1-400
 grep -v "at::native\|rocprim\|rocclr" $OUT/r04_final_kernel_stats.csv | sed 's/(DevRun[^)]*)//; s/void //' | cut -c1-130 | head -14
 head -8 $OUT/r04_timstof_kernel_stats.csv | cut -c1-130
 head -12 $OUT/r04_fragcomp_kernel_stats.csv | cut -c1-130
+head -6 $OUT/r04_selection_kernel_stats.csv | cut -c1-130
