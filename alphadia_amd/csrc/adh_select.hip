@@ -329,7 +329,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const 
         auto put = [&](int w, int f, double acc) {
             const float sm = (float)acc;
             const float x1 = sm + 1.0f;
-            logt[w * F + f] = (x1 >= 1.0f && x1 < INFINITY) ? (float)adh_log_f32(x1) : (float)log((double)x1);
+            float lg = 0.0f;  // (log(1) = 0: smoothed values below 6e-8 round away in sm + 1)
+            if (x1 != 1.0f) lg = (x1 >= 1.0f && x1 < INFINITY) ? (float)adh_log_f32(x1) : (float)log((double)x1);
+            logt[w * F + f] = lg;
         };
         if (fixed_taps) {
             for (int c = lane; c < wb * n_chunk; c += ADH_WAVE) {

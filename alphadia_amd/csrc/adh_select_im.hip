@@ -372,6 +372,12 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
     for (int c = tid; c < SF; c += SCORE_THREADS) ls[c] = 0.0f;
     __syncthreads();
     const int h0 = k0 / 2, h1 = k1 / 2;
+    // The factors of a Gaussian over 30 taps are exact zeros outside ~15 of them, and a zero tap leaves a running fma
+    // sum as it is: pass 1 runs over the columns [b_lo, b_hi] only, the tap lists of pass 2 hold the non-zero taps -
+    // and a scan whose list is empty (no event within reach of a non-zero tap) has nothing to smooth.
+    int b_lo = 0, b_hi = k1 - 1;
+    while (b_lo < b_hi && kv[b_lo] == 0.0) ++b_lo;
+    while (b_hi > b_lo && kv[b_hi] == 0.0) --b_hi;
     const double inv_f = 1.0 / (double)F;
     const int rows_per_step = max(SCORE_THREADS / F, 1);  // pass 1: whole rows per step (F <= 256: host check)
     // Windows are taken SEL_BATCH at a time: the block-wide phases (row discovery, row fill, pass 1) and
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                         a += a < 0 ? S : 0;
                         a -= a >= S ? S : 0;
                         if (a >= k0) break;
-                        tp[cnt++] = (uint16_t)(idx << 6 | a);
+                        if (ku[a] != 0.0) tp[cnt++] = (uint16_t)(idx << 6 | a);
                         idx = idx == 0 ? nr - 1 : idx - 1;
                     }
                     tap_cnt[c] = (int16_t)cnt;
@@ -521,9 +527,10 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                 if (act) {
                     const float *rp = rows + slot * F;
                     double acc = 0.0;
-                    int col = f + h1;  // column of tap b: (f + h1 - b) mod F
+                    int col = f + h1 - b_lo;  // column of tap b: (f + h1 - b) mod F
+                    col += col < 0 ? F : 0;
                     col -= col >= F ? F : 0;
-                    for (int bb = 0; bb < k1; ++bb) {
+                    for (int bb = b_lo; bb <= b_hi; ++bb) {
                         acc = fma(kv[bb], (double)rp[col], acc);
                         col = col == 0 ? F - 1 : col - 1;
                     }
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                     if (use_taps) {
                         const uint16_t *tp = tap_tab + tap_base[g] + sc * tap_len[g];
                         const int cnt = debug_abl == 3 ? 0 : (int)tap_cnt[g * S + sc];
+                        if (cnt == 0) continue;  // (nothing within reach: smooth = 0, log(0 + 1) = 0)
                         for (int t = 0; t < cnt; ++t) {
                             const int u = (int)tp[t];
                             acc = fma(ku[u & 63], (double)rw[(u >> 6) * F + f], acc);
@@ -565,8 +573,11 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                         idx = idx == 0 ? n_rows - 1 : idx - 1;
                     }
                     const float sm = (float)acc;
-                    if (sm != 0.0f) {  // _build_features (selection.py:206-226); log(1) = 0
-                        const float x = sm + 1.0f;
+                    // _build_features (selection.py:206-226).  log(1) = 0: the tails of the kernel - a smoothed value below
+                    // 6e-8 - round away in the float32 sum sm + 1, and the rows and columns that hold nothing else
+                    // (most of the reach of a 30 x 30 kernel) never enter the log
+                    const float x = sm + 1.0f;
+                    if (x != 1.0f) {
                         if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
                         else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
                     }
