@@ -950,9 +950,12 @@ int select_candidates_im(adh_handle *h, const adh_precursors_t *pc, const adh_se
     // their block); batches follow each other on the stream, so a batch may reuse the slab of the one before without
     // the host waiting
     uint64_t budget = 8ull << 30;
-    if (const char *mb = getenv("ADH_SELECT_SCRATCH_MB")) budget = (uint64_t)atoll(mb) << 20;
+    const char *budget_env = getenv("ADH_SELECT_SCRATCH_MB");
+    if (budget_env) budget = (uint64_t)atoll(budget_env) << 20;
     budget = std::max<uint64_t>(std::min<uint64_t>(budget, all), meta.biggest);
-    budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);  // (a bigger slab is there already: fewer batches)
+    // (a bigger slab is there already: fewer batches - unless the budget was set by hand, which is how the tests
+    // reach the cutting of batches)
+    if (!budget_env) budget = std::max<uint64_t>(budget, h->scratch_slab_bytes);
     const double t_plan = now();
     int rc = ADH_OK;
     std::vector<int64_t> first{0};  // first precursor of every batch, then n

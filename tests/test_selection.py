@@ -199,7 +199,7 @@ def test_hip_selection_at_bench_density(ctx, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("ADH_FUZZ_SEEDS_SELECT", "6")))))
-def test_hip_selection_randomized(ctx, oracle_lib, seed):
+def test_hip_selection_randomized(ctx, oracle_lib, monkeypatch, seed):
     """Differential test: random run geometry and selection settings, HIP == oracle."""
     import synthetic as syn
 
@@ -232,12 +232,19 @@ def test_hip_selection_randomized(ctx, oracle_lib, seed):
     kern = gaussian_kernel(case.dia, cfg.peak_len_rt, cfg.sigma_scale_rt, cfg.kernel_size)
     pm = _pack(case.library.precursor_df)
     got = ctx.select_candidates(pm, cfg, kern)
+    got = {c: np.array(got[c], copy=True) for c in CANDIDATE_COLUMNS}
     exp = oracle_lib.select(case.dia, cols, pm, cfg, kern, n_threads=4)
     for c in CANDIDATE_COLUMNS:
         if c == "score":
             assert np.allclose(got[c], exp[c], rtol=1e-6, atol=0), c
         else:
             assert np.array_equal(got[c], exp[c]), c
+    # the smoothing with the kernel's non-zero columns as scalar operands (default where they fit) against the
+    # generic loop with the taps in LDS: the same bits
+    monkeypatch.setenv("ADH_DEBUG_SELECT_LDS_TAPS", "1")
+    again = ctx.select_candidates(pm, cfg, kern)
+    for c in CANDIDATE_COLUMNS:
+        assert np.array_equal(again[c], got[c]), c
 
 
 # ---------------------------------------------------------------- ion-mobility runs
@@ -330,8 +337,10 @@ def test_hip_timstof_selection_tile_forms_and_indices_agree(ctx, monkeypatch):
     base = run()
     assert len(base["precursor_idx"]) > 100
     # (ADH_DEBUG_SELECT_IM_ABL=5: pass 2 of the smoothing walks the rows per cell instead of reading its tap lists)
+    # (ADH_SELECT_SCRATCH_MB=1: the precursors go through the kernels in many batches, cut from the device's prefix sums)
     for env in (dict(ADH_DEBUG_SELECT_IM_DENSE="1"), dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"),
-                dict(ADH_DEBUG_SELECT_IM_ABL="5")):
+                dict(ADH_DEBUG_SELECT_IM_ABL="5"), dict(ADH_SELECT_SCRATCH_MB="1"),
+                dict(ADH_SELECT_SCRATCH_MB="1", ADH_DEBUG_SELECT_IM_DENSE="1")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
