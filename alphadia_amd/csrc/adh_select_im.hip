@@ -26,6 +26,7 @@ constexpr int MAX_CAND = 16;
 constexpr int SCORE_THREADS = 512;
 constexpr int SMOOTH_THREADS = 1024;  // threads of the smoothing kernel (16 wavefronts)
 constexpr int SEL_BATCH = 4;  // windows per batch of the smoothing kernel (<= SMOOTH_THREADS / 64)
+constexpr int PAR_PEAKS = 4;  // peaks whose symmetric limits the score kernel works out side by side
 constexpr int SEL_HEADER = 32 + 4 * (MAX_W + 2);  // bytes in front of the tiles of a precursor (see below)
 constexpr uint32_t SEL_DENSE = 0u, SEL_COMPACT = 1u;
 struct SelEntry {
@@ -315,7 +316,7 @@ int adh_select_tap_budget(int cap_cells, int cap_s, int k0, int k1) {
 // LDS of the score kernel
 size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f) {
     size_t b = (size_t)cap_cells * 8;                    // the float64 scores
-    b += (size_t)(cap_s + cap_f) * 8;                    // scan / cycle profiles
+    b += (size_t)selim::PAR_PEAKS * (cap_s + cap_f) * 8; // scan / cycle profiles of PAR_PEAKS peaks at a time
     b += (size_t)((cap_cells + 31) / 32) * 4;            // peak flags, one bit per cell
     return (b + 15) / 16 * 16;
 }
@@ -606,10 +607,11 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     unsigned char *__restrict__ scratch, DevCandTable out) {
     using namespace selim;
     extern __shared__ __align__(16) unsigned char smem[];
-    double *mob = reinterpret_cast<double *>(smem) + cap_cells, *cyc = mob + cap_s;  // scan / cycle profiles of symetric_limits_2d
-    uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + cap_f);   // peak flags, one bit per cell
-    __shared__ double red_v[SCORE_THREADS];
-    __shared__ int red_i[SCORE_THREADS];
+    // scan / cycle profiles of symetric_limits_2d, PAR_PEAKS peaks at a time
+    double *mob = reinterpret_cast<double *>(smem) + cap_cells, *cyc = mob + (size_t)PAR_PEAKS * cap_s;
+    uint32_t *flag = reinterpret_cast<uint32_t *>(cyc + (size_t)PAR_PEAKS * cap_f);   // peak flags, one bit per cell
+    __shared__ double red_v[SCORE_THREADS / ADH_WAVE];  // one entry per wavefront (arg-max rounds)
+    __shared__ int red_i[SCORE_THREADS / ADH_WAVE];
     __shared__ int pk_idx[MAX_CAND];
     __shared__ double pk_val[MAX_CAND];
     __shared__ double s_norm[2];
@@ -703,28 +705,37 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
                     best_i = c;
                 }
             }
-        red_v[tid] = best;
-        red_i[tid] = best_i;
-        __syncthreads();
-        for (int off = SCORE_THREADS / 2; off > 0; off >>= 1) {
-            if (tid < off) {
-                const int j = red_i[tid + off];
-                if (j >= 0) {
-                    const double v = red_v[tid + off];
-                    const int ci = red_i[tid];
-                    if (ci < 0 || v > red_v[tid] || (v == red_v[tid] && j > ci)) {
-                        red_v[tid] = v;
-                        red_i[tid] = j;
-                    }
-                }
+        // the wavefront's best by shuffles, the block's best from one entry per wavefront: two barriers per round
+        // (a tree over 512 LDS slots took ten)
+        auto better = [](double v, int j, double bv, int bj) { return j >= 0 && (bj < 0 || v > bv || (v == bv && j > bj)); };
+#pragma unroll
+        for (int off = ADH_WAVE / 2; off > 0; off >>= 1) {
+            const double v = __shfl_xor(best, off);
+            const int j = __shfl_xor(best_i, off);
+            if (better(v, j, best, best_i)) {
+                best = v;
+                best_i = j;
             }
-            __syncthreads();
         }
-        const int win = red_i[0];
+        if ((tid & (ADH_WAVE - 1)) == 0) {
+            red_v[tid / ADH_WAVE] = best;
+            red_i[tid / ADH_WAVE] = best_i;
+        }
+        __syncthreads();
+        double bv = red_v[0];
+        int bi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < SCORE_THREADS / ADH_WAVE; ++w)
+            if (better(red_v[w], red_i[w], bv, bi)) {
+                bv = red_v[w];
+                bi = red_i[w];
+            }
+        __syncthreads();  // (red_* are rewritten in the next round)
+        const int win = bi;
         if (win < 0) break;  // uniform
         if (tid == 0) {
             pk_idx[n_pk] = win;
-            pk_val[n_pk] = red_v[0];
+            pk_val[n_pk] = bv;
             flag[win >> 5] &= ~(1u << (win & 31));
         }
         ++n_pk;
@@ -773,32 +784,50 @@ __global__ __launch_bounds__(selim::SCORE_THREADS, 4) void adh_select_score_im_k
     }
     __syncthreads();
     n_pk = sh_npk;
-    // symetric_limits_2d (selection/utils.py:283-312)
-    for (int a = 0; a < n_pk; ++a) {
-        const int pa_scan = sh_scan[a], pa_cycle = sh_cycle[a];
-        const int mob_lower = (int)max((int64_t)0, (int64_t)pa_scan - cfg.min_size_mobility);
-        const int mob_upper = (int)min((int64_t)S, (int64_t)pa_scan + cfg.min_size_mobility);
-        const int cyc_lower = (int)max((int64_t)0, (int64_t)pa_cycle - cfg.min_size_rt);
-        const int cyc_upper = (int)min((int64_t)F, (int64_t)pa_cycle + cfg.min_size_rt);
-        for (int sc = tid; sc < S; sc += SCORE_THREADS) {
+    // symetric_limits_2d (selection/utils.py:283-312): the profiles of PAR_PEAKS peaks by all threads, then one lane
+    // per peak walks its two profiles (the walks are chains of dependent LDS reads: side by side they cost one)
+    __shared__ int sh_sl[MAX_CAND][2], sh_cl[MAX_CAND][2];
+    for (int a0 = 0; a0 < n_pk; a0 += PAR_PEAKS) {
+        const int na = min(PAR_PEAKS, n_pk - a0);
+        for (int t = tid; t < na * S; t += SCORE_THREADS) {
+            const int q = t / S, sc = t - q * S;
+            const int pa_cycle = sh_cycle[a0 + q];
+            const int cyc_lower = (int)max((int64_t)0, (int64_t)pa_cycle - cfg.min_size_rt);
+            const int cyc_upper = (int)min((int64_t)F, (int64_t)pa_cycle + cfg.min_size_rt);
             double v = 0.0;
             for (int f = cyc_lower; f < cyc_upper; ++f) v += A(sc, f);
-            mob[sc] = v;
+            mob[q * cap_s + sc] = v;
         }
-        for (int f = tid; f < F; f += SCORE_THREADS) {
+        for (int t = tid; t < na * F; t += SCORE_THREADS) {
+            const int q = t / F, f = t - q * F;
+            const int pa_scan = sh_scan[a0 + q];
+            const int mob_lower = (int)max((int64_t)0, (int64_t)pa_scan - cfg.min_size_mobility);
+            const int mob_upper = (int)min((int64_t)S, (int64_t)pa_scan + cfg.min_size_mobility);
             double v = 0.0;
             for (int sc = mob_lower; sc < mob_upper; ++sc) v += A(sc, f);
-            cyc[f] = v;
+            cyc[q * cap_f + f] = v;
         }
         __syncthreads();
-        if (tid == 0) {
-            sel::symetric_limits_1d(mob, S, pa_scan, cfg.f_mobility, cfg.center_fraction, cfg.min_size_mobility,
-                                    cfg.max_size_mobility, p_sl[a]);
-            sel::symetric_limits_1d(cyc, F, pa_cycle, cfg.f_rt, cfg.center_fraction, cfg.min_size_rt, cfg.max_size_rt,
-                                    p_cl[a]);
+        if (tid < na) {
+            int sl[2], cl[2];
+            sel::symetric_limits_1d(mob + tid * cap_s, S, sh_scan[a0 + tid], cfg.f_mobility, cfg.center_fraction,
+                                    cfg.min_size_mobility, cfg.max_size_mobility, sl);
+            sel::symetric_limits_1d(cyc + tid * cap_f, F, sh_cycle[a0 + tid], cfg.f_rt, cfg.center_fraction, cfg.min_size_rt,
+                                    cfg.max_size_rt, cl);
+            sh_sl[a0 + tid][0] = sl[0];
+            sh_sl[a0 + tid][1] = sl[1];
+            sh_cl[a0 + tid][0] = cl[0];
+            sh_cl[a0 + tid][1] = cl[1];
         }
         __syncthreads();
     }
+    if (tid == 0)
+        for (int a = 0; a < n_pk; ++a) {
+            p_sl[a][0] = sh_sl[a][0];
+            p_sl[a][1] = sh_sl[a][1];
+            p_cl[a][0] = sh_cl[a][0];
+            p_cl[a][1] = sh_cl[a][1];
+        }
     if (tid != 0) return;
     if (cfg.join_close_candidates) {  // _join_overlapping_candidates (selection.py:281-345)
         bool mask[MAX_CAND];
