@@ -156,7 +156,8 @@ int cand_reserve(adh_handle *h, int64_t n, int32_t n_iso) {
 // batches (8 000 precursors host -> host 1.45 -> 1.33 ms: fewer driver calls).  Large ranges stay with the
 // DMA engine: a copy kernel sits on the CUs for the 4-5 ms the 0.2 GB of a 3 M-candidate step take over PCIe
 // and the gather kernel next to it ran 7 % slower, with nothing gained on the step (the host-bound stream
-// is the limit either way).  ADH_H2D_KERNEL=0 switches the kernel off; pageable columns always use
+// is the limit either way; round 4 again, for the burst behind the plan of chunk 1 and for per-chunk uploads: the
+// scoring kernels 14.8 -> 17.7 ... 18.4 ms, the step 33 -> 37 ms).  ADH_H2D_KERNEL=0 switches the kernel off; pageable columns always use
 // hipMemcpyAsync.
 struct CopyJobs {
     const unsigned char *src[16];
@@ -1241,9 +1242,16 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     // one go right behind it (one H2D per column): H2D copies issued while the D2H copies of earlier
     // chunks are in flight slowed those down four-fold for two chunks on MI355X (measured; the
     // copy engines are shared), whereas one early burst overlaps only the kernels of chunk 0.
+    // (ADH_H2D_BURST_LATE=0: the whole burst before the plan of chunk 1, the order of round 3)
+    static const bool late_burst = [] {
+        const char *env = getenv("ADH_H2D_BURST_LATE");
+        return !(env && atoi(env) == 0);
+    }();
     rc = cand_upload_range(h, c, 0, cut[1], si);
     if (rc == ADH_OK) rc = plan_enqueue(h, h->slots[0], cfg, 0, cut[1], si);
-    if (rc == ADH_OK && n_chunks > 1) rc = cand_upload_range(h, c, cut[1], n, si);
+    // ... of which chunk 1's rows go first and the rest behind the plan of chunk 1: its kernels - and with them the
+    // second copy-out - start ~4 ms earlier than behind the whole burst, and the copy-out stream has no gap to wait out
+    if (rc == ADH_OK && n_chunks > 1) rc = cand_upload_range(h, c, cut[1], late_burst ? cut[2] : n, si);
     if (rc != ADH_OK) return fail_sync(rc);
     for (int64_t ci = 0; ci < n_chunks; ++ci) {
         const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
@@ -1253,6 +1261,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             const int64_t a2 = b, b2 = cut[(size_t)ci + 2];
             if (ci >= 1) HIP_TRY(hipStreamWaitEvent(si, h->ev_k[ps ^ 1], 0));
             rc = plan_enqueue(h, h->slots[ps ^ 1], cfg, a2, b2 - a2, si);
+            if (rc == ADH_OK && ci == 0 && late_burst && n_chunks > 2) rc = cand_upload_range(h, c, cut[2], n, si);
             if (rc != ADH_OK) return fail_sync(rc);
         }
         Plan p;
