@@ -1167,7 +1167,16 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         tab.partial = true;
     }
     std::vector<int64_t> cut{0};
-    if (n > chunk) cut.push_back(std::max<int64_t>(chunk / 4, 1));
+    // a short first chunk: its copy-out starts early.  A quarter of a chunk - or half of one for a table of many
+    // chunks, where the copy-out is what the call waits for and the first copy-out should cover the kernels of the
+    // (full) second chunk: 3 M candidates 29.3 -> 28.6 ms; tables of two or three chunks lose with it
+    // (ADH_FIRST_CHUNK_DIV fixes the divisor)
+    static const int first_div_env = [] {
+        const char *env = getenv("ADH_FIRST_CHUNK_DIV");
+        return env && atoi(env) > 0 ? atoi(env) : 0;
+    }();
+    const int first_div = first_div_env ? first_div_env : (n >= 4 * chunk ? 2 : 4);
+    if (n > chunk) cut.push_back(std::max<int64_t>(chunk / first_div, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
     const int64_t n_chunks = (int64_t)cut.size() - 1;
     // compacted copy-out of the fragment tables (see adh_slot_count_kernel).  OFF unless ADH_COMPACT_COPY_OUT=1: it takes
