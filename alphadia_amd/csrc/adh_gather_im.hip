@@ -259,6 +259,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         const int P = tiled ? index_im::pair_setup_tiled(run, box, W, t_lo, t_hi, slot_of, w_p0, p_lo, p_off, p_win, lane)
                             : index_im::pair_setup(run, W, t_lo, t_hi, slot_of, c0, F, push_lo, push_hi, w_p0, w_base, p_lo,
                                                    p_off, p_win, lane);
+        if (caps.stop_phase == 15) {  // developer ablation: ... + pair ranges
+            if (lane == 0) header[0] = 0;
+            return;
+        }
         bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
@@ -382,6 +386,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             }
             const uint32_t r0 = p_off[w_p0[w0]];
             __syncthreads();
+            if (caps.stop_phase == 16) {  // developer ablation: ... + stage 1 (the raw events of the first batch)
+                if (lane == 0) header[0] = 0;
+                return;
+            }
             // ---- stage 2: the queued events look up their quadrupole row, MS1 / MS2 observation and
             // intensity (independent loads) and the survivors take their place in the list, in stream order
             const int q_base = m;
@@ -442,6 +450,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             }
             __syncthreads();
             w0 = w1;
+        }
+        if (caps.stop_phase == 17) {  // developer ablation: ... + stage 2, no sort / fold / entries
+            if (lane == 0) header[0] = 0;
+            return;
         }
         if (!over && m > 0) flush();
         dense = over;  // too many events for the lists: this candidate takes the dense path below
