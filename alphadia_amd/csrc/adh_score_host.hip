@@ -1220,6 +1220,8 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     const double t_1 = now();
     const bool dbg_events = timing && atoi(getenv("ADH_DEBUG_TIMING")) >= 2;  // per-chunk D2H spans
     std::vector<hipEvent_t> dbg;
+    std::vector<uint64_t> dbg_bytes;  // copy-out bytes of every chunk
+    hipEvent_t dbg_start = nullptr;   // on the copy-in stream, before the first column goes up
     auto fail_sync = [&](int code) {
         (void)hipDeviceSynchronize();
         (void)hipGetLastError();
@@ -1256,6 +1258,10 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         const char *env = getenv("ADH_H2D_BURST_LATE");
         return !(env && atoi(env) == 0);
     }();
+    if (dbg_events) {
+        (void)hipEventCreate(&dbg_start);
+        (void)hipEventRecord(dbg_start, si);
+    }
     rc = cand_upload_range(h, c, 0, cut[1], si);
     if (rc == ADH_OK) rc = plan_enqueue(h, h->slots[0], cfg, 0, cut[1], si);
     // ... of which chunk 1's rows go first and the rest behind the plan of chunk 1: its kernels - and with them the
@@ -1314,6 +1320,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             (void)hipEventRecord(e0, so);
             dbg.push_back(e0);
             dbg.push_back(e1);
+            dbg_bytes.push_back(h->d2h_bytes);
         }
         for (int i = 0; i < kNumOutFields; ++i) {
             const OutFieldDesc &f = kOutFields[i];
@@ -1341,7 +1348,10 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             HIP_TRY(hipEventRecord(ev, so));
             chunk_done.push_back(ev);
         }
-        if (dbg_events) (void)hipEventRecord(dbg.back(), so);
+        if (dbg_events) {
+            (void)hipEventRecord(dbg.back(), so);
+            dbg_bytes.back() = h->d2h_bytes - dbg_bytes.back();
+        }
     }
     if (compact) {
         rc = flush_compact(n_chunks - 1);
@@ -1411,8 +1421,14 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             float ms = 0.f, since = 0.f;
             (void)hipEventElapsedTime(&ms, dbg[i], dbg[i + 1]);
             (void)hipEventElapsedTime(&since, dbg[0], dbg[i]);
-            fprintf(stderr, "[adh]   chunk %zu: D2H starts %.2f ms after the first, lasts %.2f ms\n", i / 2, since, ms);
+            float from_start = 0.f;
+            if (dbg_start) (void)hipEventElapsedTime(&from_start, dbg_start, dbg[i]);
+            fprintf(stderr, "[adh]   chunk %zu (%lld rows): D2H starts %.2f ms after the first (%.2f ms after the call's first copy-in), "
+                            "lasts %.2f ms for %.1f MB = %.1f GB/s\n",
+                    i / 2, (long long)(cut[i / 2 + 1] - cut[i / 2]), since, from_start, ms, (double)dbg_bytes[i / 2] / 1e6,
+                    (double)dbg_bytes[i / 2] / 1e6 / std::max(ms, 1e-3f));
         }
+        if (dbg_start) (void)hipEventDestroy(dbg_start);
         for (hipEvent_t e : dbg) (void)hipEventDestroy(e);
     }
     unwind.ok = true;
