@@ -1,0 +1,40 @@
+"""Scratch: copy-out rate of one process scoring tables of different sizes one after the other (ADH_DEBUG_TIMING=2 on
+stderr): does a small table stay slow after a large one, and the other way round?"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+import synthetic as syn
+from alphadia_amd import runtime  # noqa: E402
+from alphadia_amd.distributed import slice_soa  # noqa: E402
+from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
+
+case = syn.make_case(1_000_000, 4800, config_id=2, per_precursor=3, threads=os.cpu_count())
+cfg = CandidateScoringConfig()
+cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
+                fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=True,
+                experimental_xic=True, top_k_fragments=12))
+cfgj = cfg.to_jitclass()
+ctx = runtime.get_context(0)
+soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
+ctx.stage_run(case.dia)
+ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"))
+n = len(soa["precursor_idx"])
+from alphadia_amd import _abi  # noqa: E402
+import numpy as np  # noqa: E402
+
+if os.environ.get("PREALLOC_ROWS"):  # the pool's output buffers sized for a larger table before anything is scored
+    big = int(os.environ["PREALLOC_ROWS"])
+    for name, (shape, dt) in _abi.output_shapes(big, 12).items():
+        ctx.pinned.empty("out:" + name, shape, dt)
+    print(f"==== pool pre-sized for {big} rows", file=sys.stderr, flush=True)
+for rows in [int(x) for x in os.environ.get("ROWS", "1500000,3000000,1500000,600000,3000000").split(",")]:
+    packed = pack_assembled(slice_soa(soa, 0, min(rows, n)))
+    if os.environ.get("SLEEP"):
+        import time
+
+        time.sleep(float(os.environ["SLEEP"]))
+    print(f"==== {rows} rows", file=sys.stderr, flush=True)
+    for _ in range(4):
+        ctx.score_host(packed, cfgj, with_stats=bool(os.environ.get("WITH_STATS")), reuse_buffers=True)
