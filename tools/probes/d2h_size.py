@@ -29,12 +29,28 @@ if os.environ.get("PREALLOC_ROWS"):  # the pool's output buffers sized for a lar
     for name, (shape, dt) in _abi.output_shapes(big, 12).items():
         ctx.pinned.empty("out:" + name, shape, dt)
     print(f"==== pool pre-sized for {big} rows", file=sys.stderr, flush=True)
-for rows in [int(x) for x in os.environ.get("ROWS", "1500000,3000000,1500000,600000,3000000").split(",")]:
+# ROWS: comma-separated groups "rows[:ENV=VALUE[:ENV=VALUE...]]" - the variables are set for that group only
+for group in os.environ.get("ROWS", "1500000,3000000,1500000,600000,3000000").split(","):
+    parts = group.split(":")
+    rows = int(parts[0])
+    extra = dict(p.split("=", 1) for p in parts[1:])
+    for k in [k for k in os.environ if k.startswith("ADH_DEBUG_STOP")]:
+        del os.environ[k]
+    os.environ.update(extra)
     packed = pack_assembled(slice_soa(soa, 0, min(rows, n)))
     if os.environ.get("SLEEP"):
         import time
 
         time.sleep(float(os.environ["SLEEP"]))
     print(f"==== {rows} rows", file=sys.stderr, flush=True)
-    for _ in range(4):
+    import glob
+
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_pcie")) + sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_fclk")) \
+            + sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_socclk")) + sorted(glob.glob("/sys/class/drm/card*/device/current_link_speed")):
+        try:
+            txt = open(f).read().strip().replace("\n", " | ")
+        except OSError as exc:
+            txt = str(exc)
+        print(f"   {f.split('/')[4]} {os.path.basename(f)}: {txt}", file=sys.stderr, flush=True)
+    for _ in range(int(os.environ.get("CALLS", 3))):
         ctx.score_host(packed, cfgj, with_stats=bool(os.environ.get("WITH_STATS")), reuse_buffers=True)
