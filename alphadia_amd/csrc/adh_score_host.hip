@@ -1171,10 +1171,8 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     // chunks, where the copy-out is what the call waits for and the first copy-out should cover the kernels of the
     // (full) second chunk: 3 M candidates 29.3 -> 28.6 ms; tables of two or three chunks lose with it
     // (ADH_FIRST_CHUNK_DIV fixes the divisor)
-    static const int first_div_env = [] {
-        const char *env = getenv("ADH_FIRST_CHUNK_DIV");
-        return env && atoi(env) > 0 ? atoi(env) : 0;
-    }();
+    const char *first_div_str = getenv("ADH_FIRST_CHUNK_DIV");
+    const int first_div_env = first_div_str && atoi(first_div_str) > 0 ? atoi(first_div_str) : 0;
     const int first_div = first_div_env ? first_div_env : (n >= 4 * chunk ? 2 : 4);
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / first_div, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
@@ -1254,10 +1252,8 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     // chunks are in flight slowed those down four-fold for two chunks on MI355X (measured; the
     // copy engines are shared), whereas one early burst overlaps only the kernels of chunk 0.
     // (ADH_H2D_BURST_LATE=0: the whole burst before the plan of chunk 1, the order of round 3)
-    static const bool late_burst = [] {
-        const char *env = getenv("ADH_H2D_BURST_LATE");
-        return !(env && atoi(env) == 0);
-    }();
+    const char *late_env = getenv("ADH_H2D_BURST_LATE");
+    const bool late_burst = !(late_env && atoi(late_env) == 0);
     if (dbg_events) {
         (void)hipEventCreate(&dbg_start);
         (void)hipEventRecord(dbg_start, si);

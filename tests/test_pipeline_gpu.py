@@ -64,6 +64,15 @@ def test_chunked_pipeline_is_bitwise_the_single_pass(ctx, case, monkeypatch, exp
         pinned_soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
         got = ctx.score_host(pack_assembled(pinned_soa), cfg, with_stats=True, reuse_buffers=True)
         _same(got, ref)
+    # the order of the copy-in burst (behind / in front of the plan of chunk 1) and the length of the first chunk
+    monkeypatch.setenv("ADH_CHUNK", "1500")
+    for env in (dict(ADH_H2D_BURST_LATE="0"), dict(ADH_FIRST_CHUNK_DIV="2"), dict(ADH_FIRST_CHUNK_DIV="1"),
+                dict(ADH_FIRST_CHUNK_DIV="7", ADH_H2D_BURST_LATE="0")):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+            _same(got, ref)
 
 
 def test_host_rebuilt_columns_equal_the_copied_ones(ctx, case, monkeypatch):
