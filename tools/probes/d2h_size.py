@@ -10,7 +10,7 @@ from alphadia_amd import runtime  # noqa: E402
 from alphadia_amd.distributed import slice_soa  # noqa: E402
 from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled  # noqa: E402
 
-case = syn.make_case(1_000_000, 4800, config_id=2, per_precursor=3, threads=os.cpu_count())
+case = syn.make_case(int(os.environ.get("PRECURSORS", 1_000_000)), int(os.environ.get("CYCLES", 4800)), config_id=2, per_precursor=3, threads=os.cpu_count())
 cfg = CandidateScoringConfig()
 cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
                 fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=True,
@@ -18,6 +18,11 @@ cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, pre
 cfgj = cfg.to_jitclass()
 ctx = runtime.get_context(0)
 soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
+if os.environ.get("PREALLOC_EARLY"):  # the pool's output buffers exist before the run is staged
+    from alphadia_amd import _abi as _abi_early
+
+    for name, (shape, dt) in _abi_early.output_shapes(int(os.environ["PREALLOC_EARLY"]), 12).items():
+        ctx.pinned.empty("out:" + name, shape, dt)
 ctx.stage_run(case.dia)
 ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"))
 n = len(soa["precursor_idx"])
