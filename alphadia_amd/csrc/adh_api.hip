@@ -152,6 +152,11 @@ struct adh_handle {
     std::vector<double> h_rt_im, h_mobility_im;  // the same for an ion-mobility run
     double last_select_ms = 0.0;    // duration of the last adh_select_kernel launch
     fragcomp::Stats last_fragcomp;  // of the last adh_fragcomp / adh_fdr_resident call
+    // The runtime's DMA copies run at half the link rate (25-29 instead of 55 GB/s) from the moment this process has
+    // freed a device buffer of 2 GB or more - the temporaries of staging a run do - until it page-locks 2 GB of host
+    // memory in one piece (tools/probes/d2h_pattern.hip: BALLAST_CHURN=mf against RESTORE=HF).
+    // Whatever frees large device memory sets the flag, the host -> host entry point settles it.
+    bool copy_path_dirty = false, big_staged = false;
     void *sel_slab = nullptr;       // precursor columns + candidate table of adh_select_candidates (grow-only)
     size_t sel_slab_bytes = 0;
     void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
@@ -450,6 +455,16 @@ int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, in
 
 }  // namespace
 
+namespace {
+// a staging call freed the buffers of what was staged before and its own temporaries: large ones leave the runtime's
+// copies in their slow state (adh_handle::copy_path_dirty)
+void note_staged(adh_handle *h, uint64_t bytes) {
+    const bool big = bytes >= ((uint64_t)1 << 30);
+    if (big || h->big_staged) h->copy_path_dirty = true;
+    h->big_staged = big;
+}
+}  // namespace
+
 int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     if (!h || !d) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (d->cycle_len <= 0 || d->cycle_scans <= 0 || d->n_spectra < 0 || d->n_peaks < 0)
@@ -572,6 +587,7 @@ int adh_stage_alpharaw(adh_handle_t *h, const adh_alpharaw_t *d) {
     if (rc != ADH_OK) return rc;
     h->run = r;
     h->run_staged = true;
+    note_staged(h, (uint64_t)d->n_peaks * 16);  // (the sort's keys and values are the largest temporaries)
     return ADH_OK;
 }
 
@@ -785,6 +801,7 @@ int adh_stage_timstof(adh_handle_t *h, const adh_timstof_t *d) {
     h->h_dpc = dpc;
     h->tims = t;
     h->tims_staged = true;
+    note_staged(h, (uint64_t)d->n_events * 24);
     h->im_scratch_budget = 0;
     return ADH_OK;
 }
@@ -821,6 +838,7 @@ int adh_stage_fragments(adh_handle_t *h, const adh_fragments_t *f) {
     h->h_lib.swap(recs);
     h->n_lib = f->n;
     h->lib_staged = true;
+    note_staged(h, (uint64_t)f->n * 32);
     return ADH_OK;
 }
 

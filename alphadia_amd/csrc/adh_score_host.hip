@@ -86,6 +86,7 @@ int ensure_tables(adh_handle *h, int slot, int64_t rows, int top_k) {
     DevTables &t = h->tables[slot];
     const size_t need = layout_tables(nullptr, rows, top_k, nullptr, nullptr);
     if (t.bytes < need) {
+        if (t.bytes >= ((size_t)1 << 30)) h->copy_path_dirty = true;
         if (t.base) (void)hipFree(t.base);
         t.base = nullptr;
         t.bytes = 0;
@@ -429,9 +430,24 @@ int plan_finish(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int
 }
 
 // the scratch slab is grow-only and shared by all chunks (their kernels are serialised on one stream)
+// see adh_handle::copy_path_dirty
+void settle_copy_path(adh_handle *h) {
+    if (!h->copy_path_dirty) return;
+    h->copy_path_dirty = false;
+    static const bool off = [] {
+        const char *env = getenv("ADH_COPY_PATH_RESET");
+        return env && atoi(env) == 0;
+    }();
+    if (off) return;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)2 << 30, hipHostMallocPortable) == hipSuccess && p) (void)hipHostFree(p);
+    (void)hipGetLastError();  // (no room for it: the copies stay slow, nothing else changes)
+}
+
 int ensure_scratch(adh_handle *h, uint64_t bytes) {
     if (h->scratch_slab_bytes >= bytes) return ADH_OK;
     HIP_TRY(hipDeviceSynchronize());
+    if (h->scratch_slab_bytes >= ((uint64_t)1 << 30)) h->copy_path_dirty = true;
     if (h->scratch_slab) (void)hipFree(h->scratch_slab);
     h->scratch_slab = nullptr;
     h->scratch_slab_bytes = 0;
@@ -1080,6 +1096,12 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     DevTables &tab = h->tables[slot];
     h->last_tables = slot;
     h->last_rows = n;
+    {
+        const double t_s = now();
+        const bool was = h->copy_path_dirty;
+        settle_copy_path(h);
+        if (timing && was) fprintf(stderr, "[adh] copy path settled in %.1f ms\n", now() - t_s);
+    }
     if (n == 0) return comm_gather_slot(h, slot);
     std::vector<hipEvent_t> chunk_done;
     // a call that fails half way leaves no tables behind (a reader would rebuild columns of a half-filled

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <cstring>
 #include <thread>
 #include <atomic>
 
@@ -16,22 +17,74 @@ int main(int argc, char **argv) {
     if (sizes.empty()) sizes = {1500000, 3000000, 1500000, 600000};
     const int widths[8] = {184, 48, 48, 48, 48, 48, 24, 1};  // bytes per row of the eight tables on the wire
     const int in_w = 91;
+    char *dev = nullptr, *dev_in = nullptr, *host_in = nullptr, *host[8] = {};
     hipStream_t si, so, sk;
     hipStreamCreateWithFlags(&sk, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&si, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&so, hipStreamNonBlocking);
     const bool grow = getenv("GROW") != nullptr;  // allocate per size (grow-only) instead of once for the largest
     long cap = grow ? 0 : *std::max_element(sizes.begin(), sizes.end());
-    char *dev = nullptr, *dev_in = nullptr, *host_in = nullptr, *host[8] = {};
     auto reserve = [&](long n) {
-        if (n <= cap && dev) return;
+        if (n <= cap && dev && host_in) return;
         cap = std::max(cap, n);
-        if (dev) { hipFree(dev); hipFree(dev_in); hipHostFree(host_in); for (auto &p : host) hipHostFree(p); }
-        hipMalloc((void **)&dev, (size_t)cap * 646);
-        hipMalloc((void **)&dev_in, (size_t)cap * in_w);
-        hipHostMalloc((void **)&host_in, (size_t)cap * in_w, hipHostMallocPortable);
-        for (int f = 0; f < 8; ++f) hipHostMalloc((void **)&host[f], (size_t)cap * widths[f] * 9 / 8, hipHostMallocPortable);
+        if (!dev) {
+            hipMalloc((void **)&dev, (size_t)cap * 646);
+            hipMalloc((void **)&dev_in, (size_t)cap * in_w);
+        }
+        if (!host_in) {
+            hipHostMalloc((void **)&host_in, (size_t)cap * in_w, hipHostMallocPortable);
+            for (int f = 0; f < 8; ++f) hipHostMalloc((void **)&host[f], (size_t)cap * widths[f] * 9 / 8, hipHostMallocPortable);
+        }
     };
+    // EARLY=all|dev|host: these buffers are allocated before the ballast and its churn (default: all after)
+    const char *early = getenv("EARLY");
+    {
+        const long mx = *std::max_element(sizes.begin(), sizes.end());
+        if (early && (early[0] == 'a' || early[0] == 'd')) {
+            hipMalloc((void **)&dev, (size_t)mx * 646);
+            hipMalloc((void **)&dev_in, (size_t)mx * in_w);
+        }
+        if (early && (early[0] == 'a' || early[0] == 'h')) {
+            hipHostMalloc((void **)&host_in, (size_t)mx * in_w, hipHostMallocPortable);
+            for (int f = 0; f < 8; ++f) hipHostMalloc((void **)&host[f], (size_t)mx * widths[f] * 9 / 8, hipHostMallocPortable);
+        }
+    }
+    if (getenv("BALLAST_GB")) {  // device memory held by the process, in pieces (a staged run is several buffers of GBs)
+        const int gb = atoi(getenv("BALLAST_GB")), pieces = getenv("BALLAST_PIECES") ? atoi(getenv("BALLAST_PIECES")) : 4;
+        for (int i = 0; i < pieces; ++i) {
+            void *b = nullptr;
+            hipMalloc(&b, ((size_t)gb << 30) / pieces);
+            hipMemset(b, i, ((size_t)gb << 30) / pieces);
+        }
+        if (getenv("BALLAST_CHURN")) {  // temporaries of a staging sort: allocated, used, freed
+            // BALLAST_CHURN = letters: m memset, f free, s the memset on a stream; CHURN_MB = size of a temporary
+            const char *mode = getenv("BALLAST_CHURN");
+            const size_t bytes = (size_t)(getenv("CHURN_MB") ? atol(getenv("CHURN_MB")) : 4096) << 20;
+            for (int i = 0; i < 4; ++i) {
+                void *b = nullptr;
+                hipMalloc(&b, bytes);
+                if (strchr(mode, 'm')) hipMemset(b, i, bytes);
+                if (strchr(mode, 's')) { hipMemsetAsync(b, i, bytes, sk); hipStreamSynchronize(sk); }
+                if (strchr(mode, 'f')) hipFree(b);
+            }
+        }
+    }
+    if (const char *r = getenv("RESTORE")) {  // candidates for what puts the copies back to the fast state after the churn
+        const size_t two = (size_t)(getenv("RESTORE_MB") ? atol(getenv("RESTORE_MB")) : 2048) << 20;
+        void *b = nullptr, *hb = nullptr;
+        if (strchr(r, 'M') || strchr(r, 'S') || strchr(r, 'C')) hipMalloc(&b, two);
+        if (strchr(r, 'S')) { hipMemsetAsync(b, 1, two, sk); hipStreamSynchronize(sk); }
+        if (strchr(r, 'H') || strchr(r, 'C')) hipHostMalloc(&hb, two, hipHostMallocPortable);
+        if (strchr(r, 'C')) { hipMemcpyAsync(hb, b, two, hipMemcpyDeviceToHost, so); hipStreamSynchronize(so); }
+        if (strchr(r, 'D')) hipDeviceSynchronize();
+        if (strchr(r, 'F')) { if (b) hipFree(b); if (hb) hipHostFree(hb); }
+    }
+    if (getenv("STREAMS_LATE")) {  // the three streams are made anew after the ballast and its churn
+        hipStreamDestroy(si); hipStreamDestroy(so); hipStreamDestroy(sk);
+        hipStreamCreateWithFlags(&sk, hipStreamNonBlocking);
+        hipStreamCreateWithFlags(&si, hipStreamNonBlocking);
+        hipStreamCreateWithFlags(&so, hipStreamNonBlocking);
+    }
     char *meta = nullptr;
     hipHostMalloc((void **)&meta, 4096, hipHostMallocDefault);
     hipEvent_t ep;

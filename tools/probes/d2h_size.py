@@ -26,6 +26,13 @@ if os.environ.get("PREALLOC_EARLY"):  # the pool's output buffers exist before t
 ctx.stage_run(case.dia)
 ctx.stage_fragments(*fragment_columns(case.library.fragment_df, "mz_library"))
 n = len(soa["precursor_idx"])
+if os.environ.get("RESTORE_HOST_MB"):  # one large page-locked allocation, freed again, after the run is staged
+    import ctypes as C
+
+    p = C.c_void_p()
+    assert runtime.lib.adh_host_alloc(C.byref(p), C.c_uint64(int(os.environ["RESTORE_HOST_MB"]) << 20)) == 0
+    assert runtime.lib.adh_host_free(p) == 0
+    print(f"==== {os.environ['RESTORE_HOST_MB']} MB of page-locked memory allocated and freed", file=sys.stderr, flush=True)
 from alphadia_amd import _abi  # noqa: E402
 import numpy as np  # noqa: E402
 
