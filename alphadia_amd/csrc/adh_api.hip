@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 
 #include <dlfcn.h>

@@ -670,14 +670,23 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         }
         // tile width: 15 columns while lane 15 carries no isotope, 16 with four isotopes (adh_fused.hip)
         const bool wide = std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)n_iso) > 3;
+        // The launches of a chunk write disjoint rows and read nothing of each other: every one after the first goes
+        // out WITHOUT the barrier bit (hipExtAnyOrderLaunch), so its wavefronts fill the compute units the previous
+        // launch's tail leaves idle (a wavefront lives 40-70 us: three drained launches were ~0.18 ms of every chunk,
+        // 1.3 of the 14.8 ms of a 3 M-row step and half the kernel time of a 47 000-row chunk).  The event record
+        // behind the last launch is a barrier packet: it completes when all of them have.  ADH_ANY_ORDER=0: in order.
+        const bool any_order = !(getenv("ADH_ANY_ORDER") && atoi(getenv("ADH_ANY_ORDER")) == 0);
+        int launched = 0;
 #define ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, TW)                                                                    \
-    hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st,    \
-                       h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
+    hipExtLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, \
+                          nullptr, nullptr, (any_order && launched > 0) ? (uint32_t)hipExtAnyOrderLaunch : 0u, h->run,   \
+                          h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
 #define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                      \
     if (fblocks[W] > 0) {                                            \
         if (wide) ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 16);    \
         else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 15);         \
         HIP_TRY(hipGetLastError());                                  \
+        ++launched;                                                  \
     }
         ADH_LAUNCH_FUSED(0, 8, ADH_FUSED_FM3, 1)
         ADH_LAUNCH_FUSED(1, ADH_FUSED_FM3 + 4, 32, 1)
@@ -734,19 +743,34 @@ int check_score_args(adh_handle *h, const adh_scoring_config_t *cfg, const adh_o
 }
 
 int64_t pick_chunk(int64_t n) {
-    // rows per pipeline chunk: large enough to fill the GPU and amortise its launches (every launch drains the GPU
-    // at its end: ~50 us per kernel), small enough that the first H2D / last D2H (not overlapped) stay short.
-    // 3 M candidates, host -> host / kernels (final kernels of round 3, two sweeps on one box): 196608 rows
-    // 37.9, 36.6 / 16.9 ms, 262144 35.0, 36.0 / 16.1, 393216 36.7, 35.9 / 15.2, 524288 35.5, 36.0 / 14.7; 1048576 cost
-    // 2 ms of host -> host time earlier in the round (the un-overlapped first and last copies)
-    int64_t target = 524288;
-    if (const char *env = getenv("ADH_CHUNK")) target = std::max<int64_t>(atoll(env), 1024);
-    // A table of at least ADH_SPLIT_ROWS rows is cut in two at least, however large the target: with one chunk
-    // the copy-out (4-5 ms per 375 000 rows) starts only when the last kernel has ended - the shards of a
-    // multi-GPU run (375 000 rows per GPU at N = 8) are in this range
-    const int64_t split_rows = 196608;
-    int64_t parts = (n + target - 1) / target;
-    if (parts < 2 && n >= split_rows && !getenv("ADH_CHUNK")) parts = 2;
+    // rows per pipeline chunk.  Two regimes (round 5):
+    //  * tables of >= 2 M rows (the one-GPU headline): chunks of 524288 rows - fewer, larger launches suit the fused
+    //    kernel, and the un-overlapped first H2D / last D2H are a small share of the call.  3 M candidates, host -> host /
+    //    kernels (round 3, two sweeps on one box): 196608 rows 37.9, 36.6 / 16.9 ms, 262144 35.0, 36.0 / 16.1, 393216
+    //    36.7, 35.9 / 15.2, 524288 35.5, 36.0 / 14.7; 1048576 cost 2 ms of host -> host time (first and last copies)
+    //  * smaller tables (the 375 000-row shards of an eight-GPU run, the batches of the optimisation loop): the copy-out
+    //    is the longest stage (8.3 ns per row at 54 GB/s against 0.18 ms + 4.7 ns per row of kernels per chunk), so the call
+    //    is as long as the wait for the FIRST copy-out plus every gap of the copy-out stream: about eight chunks, none
+    //    below ADH_CHUNK_MIN rows (below ~50 000 rows a chunk's kernels take longer than its copy-out and the stream
+    //    waits for them).  Round 4 cut such a table in two or three (one short first chunk): the 375 000-row shard took
+    //    5.1 ms = 0.65 ramp + 3.25 copies + 0.63 gap + 0.55 tail; see tools/bench_shard.py
+    const int64_t big = 524288;
+    if (const char *env = getenv("ADH_CHUNK")) {
+        const int64_t target = std::max<int64_t>(atoll(env), 1024);
+        const int64_t parts = (n + target - 1) / target;
+        if (parts <= 1) return std::max<int64_t>(n, 1);
+        return (n + parts - 1) / parts;
+    }
+    if (n >= 4 * big) {
+        const int64_t parts = (n + big - 1) / big;
+        return (n + parts - 1) / parts;
+    }
+    int64_t want_parts = 8, min_rows = 40960;
+    if (const char *env = getenv("ADH_CHUNK_PARTS")) want_parts = std::max<int64_t>(atoll(env), 1);
+    if (const char *env = getenv("ADH_CHUNK_MIN")) min_rows = std::max<int64_t>(atoll(env), 1024);
+    int64_t c = std::max(min_rows, (n + want_parts - 1) / want_parts);
+    c = std::min(c, big);
+    const int64_t parts = (n + c - 1) / c;
     if (parts <= 1) return std::max<int64_t>(n, 1);
     return (n + parts - 1) / parts;
 }
@@ -1051,10 +1075,17 @@ void expand_host_rows(adh_output_t *out, uint16_t *slot_host, const unsigned cha
 }
 
 int host_threads_for(int64_t n) {
+    // the team that rebuilds the id / library columns behind the copy-out: at most 16 threads, and of a node's
+    // hardware threads only this rank's share (LOCAL_WORLD_SIZE ranks run side by side: eight teams of 16 would
+    // fight over a CPU quota that is often far below the visible core count)
     int t = 16;
     if (const char *env = getenv("ADH_HOST_THREADS")) t = atoi(env);
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw > 0) t = std::min<int>(t, (int)hw);
+    else {
+        unsigned hw = std::thread::hardware_concurrency();
+        int ranks = 1;
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(atoi(lw), 1);
+        if (hw > 0) t = std::min<int>(t, std::max<int>((int)hw / ranks, 1));
+    }
     t = (int)std::min<int64_t>(t, n / 16384);  // (a thread per 16 k rows at least: starting one costs ~20 us)
     return std::max(t, 1);
 }

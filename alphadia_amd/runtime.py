@@ -71,21 +71,38 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-def _process_start_time() -> float:
-    """Wall-clock start of this process (falls back to the import time of this module)."""
+def _process_start_time(pid: str | int = "self") -> float:
+    """Wall-clock start of process ``pid`` (this process by default); falls back to now.  Never in the future:
+    where /proc/uptime is virtualised (lxcfs) but the start ticks of /proc/<pid>/stat count from the host's
+    boot, the difference is meaningless and the result is clamped to the current time."""
     import time
 
+    now = time.time()
     try:
-        with open("/proc/self/stat") as f:
+        with open(f"/proc/{pid}/stat") as f:
             ticks = float(f.read().rsplit(")", 1)[1].split()[19])
         with open("/proc/uptime") as f:
             uptime = float(f.read().split()[0])
-        return time.time() - (uptime - ticks / os.sysconf("SC_CLK_TCK"))
+        return min(now - (uptime - ticks / os.sysconf("SC_CLK_TCK")), now)
     except (OSError, ValueError, IndexError):
-        return time.time()
+        return now
 
 
 _PROCESS_T0 = _process_start_time()
+
+
+def _attempt_lower_bound() -> float:
+    """Earliest wall-clock time at which rank 0 of THIS attempt can have written the id file.
+
+    Under a launcher (torchrun, mpirun, a script) every rank is a child of the launcher process, whose pid and
+    start time are part of the nonce: nothing written before the launcher started can belong to this launch,
+    and a rank that starts late (staggered ranks, a slow import) still accepts what rank 0 wrote long before.
+    Ranks started by hand with a shared ``ADH_RUN_NONCE`` have a parent (the shell) that outlives the run; there
+    the bound is this rank's own start minus ``ADH_RENDEZVOUS_STAGGER_S`` (default 600 s) - pick a new nonce
+    per run, a file left by a crashed run of the same nonce inside that window would be accepted."""
+    if os.environ.get("ADH_RUN_NONCE"):
+        return _PROCESS_T0 - float(os.environ.get("ADH_RENDEZVOUS_STAGGER_S", "600"))
+    return min(_process_start_time(os.getppid()), _PROCESS_T0)
 
 
 class HipBackendError(RuntimeError):
@@ -263,9 +280,10 @@ def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0, make_id=
             with open(path, "rb") as f:
                 data = f.read()
                 written = os.fstat(f.fileno()).st_mtime
-            # a file older than this process is what an earlier attempt with the same nonce inputs left behind
-            # (rank 0 replaces it): only an id written after this rank started belongs to this attempt
-            fresh = written >= _PROCESS_T0 - 2.0
+            # a file older than the launch is what an earlier attempt with the same nonce inputs left behind
+            # (rank 0 replaces it); the bound is the LAUNCHER's start, not this rank's: ranks may start seconds
+            # or minutes apart (_attempt_lower_bound)
+            fresh = written >= _attempt_lower_bound() - 2.0
             if fresh and len(data) == len(nonce) + 128 and data[: len(nonce)] == nonce:
                 return data[len(nonce):]
         except FileNotFoundError:

@@ -525,7 +525,9 @@ def _host_pool():
                 n = min(n, max(1, int(float(quota) / float(period))))
         except (OSError, ValueError):
             pass
-        n = int(os.environ.get("ADH_HOST_THREADS", min(n, 16)))
+        # this rank's share of the node: LOCAL_WORLD_SIZE ranks build their frames side by side
+        ranks = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1), 1)
+        n = int(os.environ.get("ADH_HOST_THREADS", min(max(n // ranks, 1), 16)))
         _HOST_POOL = (ThreadPoolExecutor(max_workers=max(n, 1), thread_name_prefix="adh_collect"), max(n, 1))
     return _HOST_POOL
 

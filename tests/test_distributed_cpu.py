@@ -266,6 +266,22 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
         p.join(60)
         assert p.exitcode == 0
     assert open(out_d / "id_1", "rb").read() == bytes([7]) * 128
+    # (e) staggered start: rank 0 wrote its id seconds before rank 1 even started - rank 1 must take it
+    # (the lower bound of an attempt is the launcher's start / the stagger window, not the reader's own start)
+    path_e = str(tmp_path / "rccl_id_e")
+    out_e = tmp_path / "e"
+    out_e.mkdir()
+    w0 = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_e, str(out_e), "launch-E"))
+    w0.start()
+    w0.join(60)
+    assert w0.exitcode == 0
+    time.sleep(3.0)
+    late = ctx_mp.Process(target=_rendezvous_worker, args=(1, 2, path_e, str(out_e), "launch-E"))
+    late.start()
+    late.join(20)
+    assert late.exitcode == 0 and open(out_e / "id_1", "rb").read() == bytes([7]) * 128
+    # ... and under a launcher (no ADH_RUN_NONCE: the parent's start time bounds the attempt) as well
+    assert runtime._attempt_lower_bound() <= runtime._PROCESS_T0 <= time.time()
     # (c) more than one node is refused (the file is node-local)
     os.environ["LOCAL_WORLD_SIZE"] = "4"
     try:

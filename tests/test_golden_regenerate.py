@@ -1,6 +1,6 @@
 """Every committed fixture must regenerate from the committed recipe.
 
-Runs ``tests/golden/make_golden.py`` and ``make_golden_fdr.py`` (the reference itself, imported through
+Runs ``tests/golden/make_golden.py``, ``make_golden_fdr.py`` and ``make_golden_chain.py`` (the reference itself, imported through
 ``ref_shim``) into a temporary directory and compares every array with ``tests/golden/*.npz``.  Build
 container only: the reference tree does not exist on the GPU box (the test skips there).
 """
@@ -32,7 +32,7 @@ def _same(a: np.ndarray, b: np.ndarray) -> bool:
 def test_fixtures_regenerate_from_the_committed_recipe(tmp_path):
     env = dict(os.environ)
     env.pop("ADH_LIB_PATH", None)
-    for script in ("make_golden.py", "make_golden_fdr.py"):
+    for script in ("make_golden.py", "make_golden_fdr.py", "make_golden_chain.py"):
         r = subprocess.run([sys.executable, os.path.join(GOLDEN, script), "--out", str(tmp_path)],
                            capture_output=True, text=True, env=env, timeout=1200)
         assert r.returncode == 0, r.stderr[-2000:]
