@@ -131,6 +131,9 @@ struct adh_handle {
     hipStream_t stream = nullptr;        // compute
     hipStream_t stream_in = nullptr, stream_out = nullptr;  // H2D + plan / D2H of adh_score_candidates
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // side streams of the fused launches of one chunk (adh_score_host.hip: launch_scoring), created on first use
+    hipStream_t stream_aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};
     hipEvent_t ev_k[2] = {nullptr, nullptr};  // kernels of the chunk that used plan slot s are done
     DevRun run{};
     DevTims tims{};
@@ -320,6 +323,10 @@ int adh_destroy(adh_handle_t *h) {
     if (h->cs.base) (void)hipFree(h->cs.base);
     if (h->scratch_slab) (void)hipFree(h->scratch_slab);
     if (h->sel_slab) (void)hipFree(h->sel_slab);
+    for (hipStream_t st : h->stream_aux)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : h->ev_aux)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t e : h->ev_k)

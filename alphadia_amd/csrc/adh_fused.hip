@@ -1577,7 +1577,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 // The classes of one batch in ONE launch: a launch drains the GPU at its end (a wavefront lives ~70 us) and
 // costs ~10 us to start, and a chunk of the host -> host pipeline has up to fourteen classes of them.  Wavefronts are
 // ordered by class (the plan is), so a compute unit runs one class at a time except at the seams.
-#define ADH_FUSED_MAX_CLASSES 6
+#define ADH_FUSED_MAX_CLASSES 7
 struct FusedClasses {
     int32_t n;                                       // classes in this launch
     int32_t first_block[ADH_FUSED_MAX_CLASSES + 1];  // first wavefront of class i; [n] = all

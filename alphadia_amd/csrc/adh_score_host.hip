@@ -655,7 +655,11 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         for (int c = ADH_CLASS_FUSED0; c < ADH_CLASS_FAST2; ++c) {
             const int64_t nc = p.n_class[c];
             const int obs = (c - ADH_CLASS_FUSED0) / 7, fm = 8 + 4 * ((c - ADH_CLASS_FUSED0) % 7);
-            const int which = 2 * obs + (fm > (obs == 0 ? ADH_FUSED_FM3 : 28) ? 1 : 0);
+            // one observation: rows up to ADH_FUSED_FM3 cycles at three wavefronts per SIMD, longer ones at two;
+            // two observations: ONE launch (round 5: rows of 32 cycles used to have their own - 190 wavefronts per
+            // 47 000-row chunk that kept the GPU for a whole wavefront lifetime, 73 us; at two wavefronts per SIMD
+            // the larger LDS block of FM = 32 costs no occupancy)
+            const int which = obs == 0 ? (fm > ADH_FUSED_FM3 ? 1 : 0) : 2;
             FusedClasses &fc = fcs[which];
             if (nc > 0) {
                 fc.first_block[fc.n] = (int32_t)fblocks[which];
@@ -670,28 +674,52 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         }
         // tile width: 15 columns while lane 15 carries no isotope, 16 with four isotopes (adh_fused.hip)
         const bool wide = std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)n_iso) > 3;
-        // The launches of a chunk write disjoint rows and read nothing of each other: every one after the first goes
-        // out WITHOUT the barrier bit (hipExtAnyOrderLaunch), so its wavefronts fill the compute units the previous
-        // launch's tail leaves idle (a wavefront lives 40-70 us: three drained launches were ~0.18 ms of every chunk,
-        // 1.3 of the 14.8 ms of a 3 M-row step and half the kernel time of a 47 000-row chunk).  The event record
-        // behind the last launch is a barrier packet: it completes when all of them have.  ADH_ANY_ORDER=0: in order.
-        const bool any_order = !(getenv("ADH_ANY_ORDER") && atoi(getenv("ADH_ANY_ORDER")) == 0);
+        // The launches of a chunk write disjoint rows and read nothing of each other, and the smaller ones (long rows,
+        // two observations: 10-20 % of a chunk each) keep the GPU for a wavefront lifetime or two (70-100 us) that
+        // they do not fill.  Running them side by side was measured in round 5 and is OFF: on side streams that fork
+        // from the caller's and join it again (ADH_FUSED_STREAMS=2 / 3) one side stream changes nothing (3 M rows:
+        // 14.77 against 14.79 ms of kernels, 375 000 rows in 9 chunks 3.46 against 3.61) and a second one doubles the
+        // kernel time (27.7 ms: its hardware queue is shared with the copy streams and its launches start ~250 us
+        // late, `rocprofv3 --kernel-trace`); without the barrier bit on one stream (hipExtAnyOrderLaunch) nothing
+        // changes on gfx950.  What did help: fewer launches (the two-observation classes in one, above).
+        int n_streams = 1;
+        if (const char *env = getenv("ADH_FUSED_STREAMS")) n_streams = std::min(std::max(atoi(env), 1), 3);
+        int n_launch = 0;
+        for (int w = 0; w < 4; ++w) n_launch += fblocks[w] > 0;
+        if (n_launch < 2) n_streams = 1;
+        for (int a = 0; a + 1 < n_streams; ++a) {
+            if (!h->stream_aux[a]) HIP_TRY(hipStreamCreateWithFlags(&h->stream_aux[a], hipStreamNonBlocking));
+            if (!h->ev_aux[a]) HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[a], hipEventDisableTiming));
+        }
+        bool used[2] = {false, false};
         int launched = 0;
+        hipStream_t lst = st;
+        if (n_streams > 1) HIP_TRY(hipEventRecord(h->ev_fork, st));
 #define ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, TW)                                                                    \
-    hipExtLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, st, \
-                          nullptr, nullptr, (any_order && launched > 0) ? (uint32_t)hipExtAnyOrderLaunch : 0u, h->run,   \
-                          h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
-#define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                      \
-    if (fblocks[W] > 0) {                                            \
-        if (wide) ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 16);    \
-        else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 15);         \
-        HIP_TRY(hipGetLastError());                                  \
-        ++launched;                                                  \
+    hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, lst,   \
+                       h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
+#define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                                                 \
+    if (fblocks[W] > 0) {                                                                       \
+        lst = st;                                                                               \
+        if (n_streams > 1 && launched > 0) {                                                    \
+            const int a = std::min(launched - 1, n_streams - 2);                                \
+            lst = h->stream_aux[a];                                                             \
+            if (!used[a]) HIP_TRY(hipStreamWaitEvent(lst, h->ev_fork, 0));                      \
+            used[a] = true;                                                                     \
+        }                                                                                       \
+        if (wide) ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 16);                               \
+        else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 15);                                    \
+        HIP_TRY(hipGetLastError());                                                             \
+        ++launched;                                                                             \
     }
         ADH_LAUNCH_FUSED(0, 8, ADH_FUSED_FM3, 1)
         ADH_LAUNCH_FUSED(1, ADH_FUSED_FM3 + 4, 32, 1)
-        ADH_LAUNCH_FUSED(2, 8, 28, 2)
-        ADH_LAUNCH_FUSED(3, 32, 32, 2)
+        ADH_LAUNCH_FUSED(2, 8, 32, 2)
+        for (int a = 0; a < 2; ++a) {
+            if (!used[a]) continue;
+            HIP_TRY(hipEventRecord(h->ev_aux[a], h->stream_aux[a]));
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_aux[a], 0));
+        }
 #undef ADH_LAUNCH_FUSED
 #undef ADH_LAUNCH_FUSED_TW
     }
@@ -742,7 +770,7 @@ int check_score_args(adh_handle *h, const adh_scoring_config_t *cfg, const adh_o
     return ADH_OK;
 }
 
-int64_t pick_chunk(int64_t n) {
+int64_t pick_chunk(int64_t n, bool fine) {
     // rows per pipeline chunk.  Two regimes (round 5):
     //  * tables of >= 2 M rows (the one-GPU headline): chunks of 524288 rows - fewer, larger launches suit the fused
     //    kernel, and the un-overlapped first H2D / last D2H are a small share of the call.  3 M candidates, host -> host /
@@ -750,8 +778,9 @@ int64_t pick_chunk(int64_t n) {
     //    36.7, 35.9 / 15.2, 524288 35.5, 36.0 / 14.7; 1048576 cost 2 ms of host -> host time (first and last copies)
     //  * smaller tables (the 375 000-row shards of an eight-GPU run, the batches of the optimisation loop): the copy-out
     //    is the longest stage (8.3 ns per row at 54 GB/s against 0.18 ms + 4.7 ns per row of kernels per chunk), so the call
-    //    is as long as the wait for the FIRST copy-out plus every gap of the copy-out stream: about eight chunks, none
-    //    below ADH_CHUNK_MIN rows (below ~50 000 rows a chunk's kernels take longer than its copy-out and the stream
+    //    is as long as the wait for the FIRST copy-out plus every gap of the copy-out stream: about six chunks (sweep of
+    //    round 5, 375 000 rows: 3 chunks 5.1-5.5 ms, 6 parts 4.66, 7 4.76, 8 4.88, 10 5.36; 750 000 rows: 9.4 / 8.11 /
+    //    8.11 / 8.4 / 8.9), none below ADH_CHUNK_MIN rows (below ~50 000 rows a chunk's kernels take longer than its copy-out and the stream
     //    waits for them).  Round 4 cut such a table in two or three (one short first chunk): the 375 000-row shard took
     //    5.1 ms = 0.65 ramp + 3.25 copies + 0.63 gap + 0.55 tail; see tools/bench_shard.py
     const int64_t big = 524288;
@@ -765,7 +794,16 @@ int64_t pick_chunk(int64_t n) {
         const int64_t parts = (n + big - 1) / big;
         return (n + parts - 1) / parts;
     }
-    int64_t want_parts = 8, min_rows = 40960;
+    if (!fine) {
+        // ion-mobility tables: a chunk is ~7 launches and the gather's pair lists, so fewer chunks win (configs[3],
+        // 600 000 candidates: 18.4 ms host -> host in 3 chunks, 21.3 in 7): the rule of round 4 - chunks of 524288
+        // rows, a table of 196608 rows and more in two at least
+        int64_t parts = (n + big - 1) / big;
+        if (parts < 2 && n >= 196608) parts = 2;
+        if (parts <= 1) return std::max<int64_t>(n, 1);
+        return (n + parts - 1) / parts;
+    }
+    int64_t want_parts = 6, min_rows = 40960;
     if (const char *env = getenv("ADH_CHUNK_PARTS")) want_parts = std::max<int64_t>(atoll(env), 1);
     if (const char *env = getenv("ADH_CHUNK_MIN")) min_rows = std::max<int64_t>(atoll(env), 1024);
     int64_t c = std::max(min_rows, (n + want_parts - 1) / want_parts);
@@ -1166,7 +1204,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
 
     // chunk boundaries: a short first chunk (its H2D, plan and kernels are the un-overlapped ramp
     // of the D2H-bound pipeline), then equal chunks
-    int64_t chunk = pick_chunk(n);
+    int64_t chunk = pick_chunk(n, !h->tims_staged);
     if (h->tims_staged && n > 0) {
         // ion-mobility candidates reserve a scratch block sized for their dense tiles (116 KB at 38 scans x 29
         // cycles, although ~1 % of it is touched): bound the chunk so that the slab stays within a third of the
@@ -1226,7 +1264,8 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     // (ADH_FIRST_CHUNK_DIV fixes the divisor)
     const char *first_div_str = getenv("ADH_FIRST_CHUNK_DIV");
     const int first_div_env = first_div_str && atoi(first_div_str) > 0 ? atoi(first_div_str) : 0;
-    const int first_div = first_div_env ? first_div_env : (n >= 4 * chunk ? 2 : 4);
+    // (tables of up to three chunks: no short first chunk - 48 000 rows 1.45 against 1.65 ms, 96 000 1.93 against 2.02)
+    const int first_div = first_div_env ? first_div_env : (n >= 4 * chunk ? 2 : ((n > 3 * chunk || h->tims_staged) ? 4 : 1));
     if (n > chunk) cut.push_back(std::max<int64_t>(chunk / first_div, 1));
     while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
     const int64_t n_chunks = (int64_t)cut.size() - 1;
@@ -1371,6 +1410,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             dbg.push_back(e1);
             dbg_bytes.push_back(h->d2h_bytes);
         }
+        // (A chunk is up to nine copies and the engine idles ~10 us between two of them - a 47 000-row chunk, 21 MB, takes
+        // 0.46 ms = 46 GB/s where each copy runs at 55, `rocprofv3 --memory-copy-trace` - but a second copy-out stream for
+        // the feature table does not fill the gaps: measured in round 5, same times to the 0.01 ms, and taken out again.)
         for (int i = 0; i < kNumOutFields; ++i) {
             const OutFieldDesc &f = kOutFields[i];
             void *host = *out_member(out, f);

@@ -426,6 +426,23 @@ def main():
         except Exception as exc:  # the metric does not depend on this leg
             log(f"[bench] small-batch leg skipped: {exc}")
 
+    # ---------------- the shards of an eight-GPU run, one after the other on this GPU ----------------
+    # (no 8-GPU node has been available to any round: this is what each rank of `--gpus 8` would do per step, with the
+    # communicator's table layout and all-gather enqueue inside the call - tools/bench_shard.py)
+    if extras and not with_comm:
+        try:
+            from tools import bench_shard
+
+            leg = bench_shard.shard_leg(ctx, soa, cfgj, ms_per_step=elapsed / args.steps * 1e3, ways=8, reps=7)
+            result["shard_8way"] = {k: v for k, v in leg.items() if k != "shards"}
+            result["shard_8way"]["shard_ms"] = [round(s["ms"], 3) for s in leg["shards"]]
+            result["config"]["projected_scaling_8"] = leg["projected_scaling_8"]
+            result["config"]["max_shard_ms_8way"] = leg["max_shard_ms"]
+            # the buffers of the full table come back for the legs below (the shards used smaller ones)
+            ctx.score_host(packed, cfgj, reuse_buffers=reuse)
+        except Exception as exc:  # the metric does not depend on this leg
+            log(f"[bench] shard leg skipped: {type(exc).__name__}: {exc}")
+
     # ---------------- the step before scoring (candidate selection), reported next to the metric ----
     if extras:
         try:

@@ -88,7 +88,7 @@ def sweep(ctx, soa, cfgj, settings, sizes=(24_000, 48_000, 96_000, 192_000, 375_
     from alphadia_amd.distributed import slice_soa
     from alphadia_amd.scoring import pack_assembled
 
-    keys = ("ADH_CHUNK_PARTS", "ADH_CHUNK_MIN", "ADH_FIRST_CHUNK_DIV", "ADH_CHUNK", "ADH_H2D_BURST_LATE")
+    keys = ("ADH_CHUNK_PARTS", "ADH_CHUNK_MIN", "ADH_FIRST_CHUNK_DIV", "ADH_CHUNK", "ADH_H2D_BURST_LATE", "ADH_FUSED_STREAMS", "ADH_ANY_ORDER")
     for size in sizes:
         m = min(size, len(soa["precursor_idx"]))
         sub = slice_soa(soa, 0, m)
