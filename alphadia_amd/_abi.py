@@ -136,6 +136,49 @@ class Output(C.Structure):
     ]
 
 
+class CompactOutput(C.Structure):
+    """adh_compact_output_t (include/alphadia_hip.h): valid candidates and filled fragment slots, column by column."""
+
+    _fields_ = [
+        ("rows_capacity", C.c_int64),
+        ("slots_capacity", C.c_int64),
+        ("top_k", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_rows", C.c_int64),
+        ("n_slots", C.c_int64),
+        ("row", _u32p),
+        ("precursor_idx", _u32p),
+        ("rank", _u8p),
+        ("features", _f32p),
+        ("fragment_row", _u32p),
+        ("fragment_precursor_idx", _u32p),
+        ("fragment_rank", _u8p),
+        ("fragment_mz_library", _f32p),
+        ("fragment_mz", _f32p),
+        ("fragment_mz_observed", _f32p),
+        ("fragment_height", _f32p),
+        ("fragment_intensity", _f32p),
+        ("fragment_mass_error", _f32p),
+        ("fragment_correlation", _f32p),
+        ("fragment_position", _u8p),
+        ("fragment_number", _u8p),
+        ("fragment_type", _u8p),
+        ("fragment_charge", _u8p),
+        ("fragment_loss_type", _u8p),
+    ]
+
+
+# per-row and per-slot columns of CompactOutput: (name, dtype)
+COMPACT_ROW_FIELDS = [("row", np.uint32), ("precursor_idx", np.uint32), ("rank", np.uint8)]
+COMPACT_SLOT_FIELDS = [
+    ("fragment_row", np.uint32), ("fragment_precursor_idx", np.uint32), ("fragment_rank", np.uint8),
+    ("fragment_mz_library", np.float32), ("fragment_mz", np.float32), ("fragment_mz_observed", np.float32),
+    ("fragment_height", np.float32), ("fragment_intensity", np.float32), ("fragment_mass_error", np.float32),
+    ("fragment_correlation", np.float32), ("fragment_position", np.uint8), ("fragment_number", np.uint8),
+    ("fragment_type", np.uint8), ("fragment_charge", np.uint8), ("fragment_loss_type", np.uint8),
+]
+
+
 # (name, dtype, per-row width: 1 | "features" | "top_k")
 OUTPUT_FIELDS = [
     ("valid", np.uint8, 1),

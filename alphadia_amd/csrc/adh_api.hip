@@ -18,6 +18,7 @@
 
 #include <dlfcn.h>
 #include <immintrin.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
 
@@ -149,6 +150,9 @@ struct adh_handle {
     // wire columns, on the device and in page-locked host memory; scan scratch
     void *cmp_dev = nullptr, *cmp_host = nullptr, *cmp_scan = nullptr;
     size_t cmp_dev_bytes = 0, cmp_host_bytes = 0, cmp_scan_bytes = 0;
+    // adh_score_candidates_compact: per-row counts / offsets on the device, scan scratch, page-locked staging block
+    void *cop_cnt = nullptr, *cop_scan = nullptr, *cop_stage = nullptr;
+    size_t cop_cnt_bytes = 0, cop_scan_bytes = 0, cop_stage_bytes = 0;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
@@ -316,6 +320,9 @@ int adh_destroy(adh_handle_t *h) {
     if (h->d_wtp) (void)hipFree(h->d_wtp);
     if (h->slot_stage) (void)hipHostFree(h->slot_stage);
     if (h->cmp_host) (void)hipHostFree(h->cmp_host);
+    if (h->cop_stage) (void)hipHostFree(h->cop_stage);
+    if (h->cop_cnt) (void)hipFree(h->cop_cnt);
+    if (h->cop_scan) (void)hipFree(h->cop_scan);
     if (h->cmp_dev) (void)hipFree(h->cmp_dev);
     if (h->cmp_scan) (void)hipFree(h->cmp_scan);
     for (DevTables &t : h->tables)

@@ -778,8 +778,8 @@ int64_t pick_chunk(int64_t n, bool fine) {
     //    36.7, 35.9 / 15.2, 524288 35.5, 36.0 / 14.7; 1048576 cost 2 ms of host -> host time (first and last copies)
     //  * smaller tables (the 375 000-row shards of an eight-GPU run, the batches of the optimisation loop): the copy-out
     //    is the longest stage (8.3 ns per row at 54 GB/s against 0.18 ms + 4.7 ns per row of kernels per chunk), so the call
-    //    is as long as the wait for the FIRST copy-out plus every gap of the copy-out stream: about six chunks (sweep of
-    //    round 5, 375 000 rows: 3 chunks 5.1-5.5 ms, 6 parts 4.66, 7 4.76, 8 4.88, 10 5.36; 750 000 rows: 9.4 / 8.11 /
+    //    is as long as the wait for the FIRST copy-out plus every gap of the copy-out stream: about five chunks (sweeps of
+    //    round 5, 375 000 rows: 3 chunks 5.1-5.5 ms, 4 parts 4.68, 5 4.57, 6 4.62, 7 4.76, 8 4.88, 10 5.36; 750 000 rows: 9.4 / 8.11 /
     //    8.11 / 8.4 / 8.9), none below ADH_CHUNK_MIN rows (below ~50 000 rows a chunk's kernels take longer than its copy-out and the stream
     //    waits for them).  Round 4 cut such a table in two or three (one short first chunk): the 375 000-row shard took
     //    5.1 ms = 0.65 ramp + 3.25 copies + 0.63 gap + 0.55 tail; see tools/bench_shard.py
@@ -803,7 +803,7 @@ int64_t pick_chunk(int64_t n, bool fine) {
         if (parts <= 1) return std::max<int64_t>(n, 1);
         return (n + parts - 1) / parts;
     }
-    int64_t want_parts = 6, min_rows = 40960;
+    int64_t want_parts = 5, min_rows = 40960;
     if (const char *env = getenv("ADH_CHUNK_PARTS")) want_parts = std::max<int64_t>(atoll(env), 1);
     if (const char *env = getenv("ADH_CHUNK_MIN")) min_rows = std::max<int64_t>(atoll(env), 1024);
     int64_t c = std::max(min_rows, (n + want_parts - 1) / want_parts);
@@ -885,6 +885,144 @@ __global__ void adh_compact_kernel(DevOut t, int64_t row0, int64_t n, int top_k,
     c.f[4][dst] = t.fragment_correlation[src];
     c.slot[dst] = t.fragment_lib_slot[src];
 }
+
+// ---- compacted, column-major copy-out of the operator path (round 5, adh_score_candidates_compact).  What the
+// DataFrames of collect_candidates / collect_fragments keep of the padded tables is 91 % of the rows and 38 % of the
+// fragment slots (headline).  Per chunk: (valid, filled slots) per row as one 64-bit count, an exclusive scan, and ONE
+// kernel on the copy-out stream that writes every column of the chunk's valid rows and filled slots through PCIe into
+// the handle's page-locked staging block - features transposed to [feature][row], the library columns of a slot read
+// from the staged library, ids from the candidate table - at the chunk's own offsets; the chunk's totals go into a
+// header word.  Kernel stores reach the link rate (tools/probes/kcopy_probe.hip: 54-55 GB/s from 64 workgroups, 51-52
+// for the transposing write, against 46 GB/s for nine DMA copies of a small chunk).
+__global__ void adh_cop_count_kernel(const uint8_t *__restrict__ valid, const uint16_t *__restrict__ lib_slot, int64_t row0,
+                                     int64_t n, int top_k, uint64_t *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint64_t v = 0;
+    if (i < n && valid[row0 + i]) {
+        const uint16_t *s = lib_slot + (row0 + i) * (int64_t)top_k;
+        uint32_t k = 0;
+        while (k < (uint32_t)top_k && s[k]) ++k;  // (filled slots are the leading ones: candidate.py:403-442)
+        v = (1ull << 32) | k;
+    }
+    cnt[i] = v;  // (entry n: 0, so that the scan's last entry is the total)
+}
+
+// the staging block of a call of n rows (page-locked; the device writes, host threads read): [one uint64 of totals per
+// chunk, 4 KiB aligned] [row u32 | precursor_idx u32 | rank u8 | features f32 x 46] per row, [fragment_row u32 |
+// precursor_idx u32 | rank u8 | 7 float columns | 5 byte columns] per slot; a chunk's entries start at its first row
+// (x top_k for the slot columns), its feature block is [46][rows of the chunk]
+struct CopLayout {
+    int64_t n, slots;
+    size_t hdr, row, pidx, rank, feat, s_row, s_pidx, s_rank, s_f[7], s_b[5], total;
+    CopLayout(int64_t n_, int top_k, int64_t n_chunks) : n(n_), slots(n_ * (int64_t)top_k) {
+        auto up = [](size_t x) { return (x + 4095) / 4096 * 4096; };
+        size_t o = 0;
+        hdr = o, o += up((size_t)n_chunks * 8);
+        row = o, o += up((size_t)n * 4);
+        pidx = o, o += up((size_t)n * 4);
+        rank = o, o += up((size_t)n);
+        feat = o, o += up((size_t)n * ADH_NUM_FEATURES * 4);
+        s_row = o, o += up((size_t)slots * 4);
+        s_pidx = o, o += up((size_t)slots * 4);
+        s_rank = o, o += up((size_t)slots);
+        for (int j = 0; j < 7; ++j) s_f[j] = o, o += up((size_t)slots * 4);
+        for (int j = 0; j < 5; ++j) s_b[j] = o, o += up((size_t)slots);
+        total = o;
+    }
+};
+
+struct CopStage {  // device-visible pointers into the staging block, already moved to the chunk's first entry
+    uint64_t *totals;
+    uint32_t *row, *pidx;
+    uint8_t *rank;
+    float *feat;  // [46][rows of the chunk]
+    uint32_t *s_row, *s_pidx;
+    uint8_t *s_rank;
+    float *s_f[7];  // mz_library, mz, mz_observed, height, intensity, mass_error, correlation
+    uint8_t *s_b[5];  // position, number, type, charge, loss_type
+};
+
+__global__ void adh_cop_out_kernel(DevOut t, DevCands c, const LibRec *__restrict__ lib, int64_t row0, int64_t n, int top_k,
+                                   const uint64_t *__restrict__ off, CopStage st) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0) st.totals[0] = off[n];
+    // valid rows: ids + the feature row, transposed (consecutive lanes = consecutive output rows of one column)
+    for (int64_t i = tid; i < n; i += stride) {
+        const uint64_t o = off[i], o1 = off[i + 1];
+        if ((o1 >> 32) == (o >> 32)) continue;
+        const int64_t j = (int64_t)(o >> 32), r = row0 + i;
+        st.row[j] = (uint32_t)r;
+        st.pidx[j] = c.precursor_idx[r];
+        st.rank[j] = c.rank[r];
+        const float *f = t.features + r * ADH_NUM_FEATURES;
+#pragma unroll
+        for (int k = 0; k < ADH_NUM_FEATURES; ++k) st.feat[(int64_t)k * n + j] = f[k];
+    }
+    // filled slots
+    const int64_t n_slots = n * (int64_t)top_k;
+    for (int64_t id = tid; id < n_slots; id += stride) {
+        const int64_t i = id / top_k;
+        const int s = (int)(id - i * top_k);
+        const uint64_t o = off[i], o1 = off[i + 1];
+        const uint32_t a = (uint32_t)o, k = (uint32_t)o1 - a;
+        if ((uint32_t)s >= k) continue;
+        const int64_t r = row0 + i, src = r * (int64_t)top_k + s;
+        const size_t dst = (size_t)a + (size_t)s;
+        const LibRec l = lib[c.frag_start[r] + t.fragment_lib_slot[src] - 1];
+        st.s_row[dst] = (uint32_t)r;
+        st.s_pidx[dst] = c.precursor_idx[r];
+        st.s_rank[dst] = c.rank[r];
+        st.s_f[0][dst] = l.mz_library;
+        st.s_f[1][dst] = l.mz;
+        st.s_f[2][dst] = t.fragment_mz_observed[src];
+        st.s_f[3][dst] = t.fragment_height[src];
+        st.s_f[4][dst] = t.fragment_intensity[src];
+        st.s_f[5][dst] = t.fragment_mass_error[src];
+        st.s_f[6][dst] = t.fragment_correlation[src];
+        st.s_b[0][dst] = l.position;
+        st.s_b[1][dst] = l.number;
+        st.s_b[2][dst] = l.type;
+        st.s_b[3][dst] = l.charge;
+        st.s_b[4][dst] = l.loss_type;
+    }
+}
+
+namespace {
+// stripe w of T of a finished chunk: staging -> the caller's arrays (rows at base_r, slots at base_s)
+void cop_copy_stripe(const unsigned char *stage, const CopLayout &lay, int64_t a, int64_t rows_chunk, int top_k, int64_t cnt_r,
+                     int64_t cnt_s, int64_t base_r, int64_t base_s, adh_compact_output_t *out, int w, int T) {
+    auto part = [&](int64_t cnt, int64_t &lo, int64_t &hi) {
+        lo = cnt * w / T;
+        hi = cnt * (w + 1) / T;
+    };
+    int64_t lo, hi;
+    part(cnt_r, lo, hi);
+    if (hi > lo) {
+        memcpy(out->row + base_r + lo, stage + lay.row + (size_t)(a + lo) * 4, (size_t)(hi - lo) * 4);
+        memcpy(out->precursor_idx + base_r + lo, stage + lay.pidx + (size_t)(a + lo) * 4, (size_t)(hi - lo) * 4);
+        memcpy(out->rank + base_r + lo, stage + lay.rank + (size_t)(a + lo), (size_t)(hi - lo));
+        const float *fb = reinterpret_cast<const float *>(stage + lay.feat) + (size_t)a * ADH_NUM_FEATURES;
+        for (int k = 0; k < ADH_NUM_FEATURES; ++k)
+            memcpy(out->features + (size_t)k * (size_t)out->rows_capacity + (size_t)(base_r + lo),
+                   fb + (size_t)k * (size_t)rows_chunk + (size_t)lo, (size_t)(hi - lo) * 4);
+    }
+    part(cnt_s, lo, hi);
+    if (hi > lo) {
+        const size_t e0 = (size_t)a * (size_t)top_k + (size_t)lo, m = (size_t)(hi - lo);
+        memcpy(out->fragment_row + base_s + lo, stage + lay.s_row + e0 * 4, m * 4);
+        memcpy(out->fragment_precursor_idx + base_s + lo, stage + lay.s_pidx + e0 * 4, m * 4);
+        memcpy(out->fragment_rank + base_s + lo, stage + lay.s_rank + e0, m);
+        float *const fcol[7] = {out->fragment_mz_library, out->fragment_mz, out->fragment_mz_observed, out->fragment_height,
+                                out->fragment_intensity, out->fragment_mass_error, out->fragment_correlation};
+        for (int j = 0; j < 7; ++j) memcpy(fcol[j] + base_s + lo, stage + lay.s_f[j] + e0 * 4, m * 4);
+        uint8_t *const bcol[5] = {out->fragment_position, out->fragment_number, out->fragment_type, out->fragment_charge,
+                                  out->fragment_loss_type};
+        for (int j = 0; j < 5; ++j) memcpy(bcol[j] + base_s + lo, stage + lay.s_b[j] + e0, m);
+    }
+}
+}  // namespace
 
 extern "C" {
 
@@ -1130,14 +1268,17 @@ int host_threads_for(int64_t n) {
 
 }  // namespace
 
-int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
-                         adh_output_t *out) {
+namespace {
+// the host -> host pipeline behind adh_score_candidates (padded tables into `out`) and adh_score_candidates_compact
+// (`cop` set: `out` only carries n and top_k, the compacted columns go to `cop`)
+int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg, adh_output_t *out,
+                   adh_compact_output_t *cop) {
     if (!h || !c || !cfg || !out) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (out->n != c->n) return fail(ADH_ERR_INVALID_ARGUMENT, "output rows != candidates");
     int rc = check_candidate_args(h, c);
     if (rc == ADH_OK) rc = check_score_args(h, cfg, out);
     if (rc != ADH_OK) return rc;
-    for (int i = 0; i < kNumOutFields; ++i)
+    for (int i = 0; i < kNumOutFields && !cop; ++i)
         if (!kOutFields[i].optional && *out_member(out, kOutFields[i]) == nullptr)
             return fail(ADH_ERR_INVALID_ARGUMENT, "output buffer is NULL");
     HIP_TRY(hipSetDevice(h->device));
@@ -1171,6 +1312,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         settle_copy_path(h);
         if (timing && was) fprintf(stderr, "[adh] copy path settled in %.1f ms\n", now() - t_s);
     }
+    if (cop) cop->n_rows = cop->n_slots = 0;
     if (n == 0) return comm_gather_slot(h, slot);
     std::vector<hipEvent_t> chunk_done;
     // a call that fails half way leaves no tables behind (a reader would rebuild columns of a half-filled
@@ -1234,7 +1376,9 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         }
     }
     // rebuildable columns: not copied back, rebuilt on the host from fragment_lib_slot (see kOutFields)
-    const bool rebuild = h->h_lib.size() == (size_t)h->n_lib && !getenv("ADH_DEBUG_COPY_ALL");
+    if (cop)  // (a chunk's slot offsets are 32-bit words of the packed count)
+        chunk = std::min<int64_t>(chunk, std::max<int64_t>((int64_t)(0xFFFFFFFFull / (uint64_t)top_k) - 1, 1));
+    const bool rebuild = !cop && h->h_lib.size() == (size_t)h->n_lib && !getenv("ADH_DEBUG_COPY_ALL");
     uint16_t *slot_host = out->fragment_lib_slot;
     if (rebuild && !slot_host) {
         const size_t need = (size_t)n * (size_t)top_k * sizeof(uint16_t);
@@ -1248,7 +1392,7 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         slot_host = static_cast<uint16_t *>(h->slot_stage);
     }
     adh_output_t dev_k = dev;  // what the kernels write
-    if (rebuild && !getenv("ADH_DEBUG_WRITE_ALL")) {
+    if ((rebuild || cop) && !getenv("ADH_DEBUG_WRITE_ALL")) {
         // ... and the kernels need not write them either: nobody on the host waits for them, and a reader of the
         // device tables (adh_get_device_tables, the resident FDR stage) gets them filled in on demand
         for (int i = 0; i < kNumOutFields; ++i) {
@@ -1306,6 +1450,61 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
             h->cmp_scan_bytes = scan_bytes + 256;
         }
     }
+    // operator path: counts / offsets of every chunk (one uint64 per row + one per chunk), scan scratch, staging block
+    const CopLayout cop_lay(n, top_k, n_chunks);
+    if (cop) {
+        if (!cop->row || !cop->precursor_idx || !cop->rank || !cop->features || !cop->fragment_row ||
+            !cop->fragment_precursor_idx || !cop->fragment_rank || !cop->fragment_mz_library || !cop->fragment_mz ||
+            !cop->fragment_mz_observed || !cop->fragment_height || !cop->fragment_intensity || !cop->fragment_mass_error ||
+            !cop->fragment_correlation || !cop->fragment_position || !cop->fragment_number || !cop->fragment_type ||
+            !cop->fragment_charge || !cop->fragment_loss_type)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "compact output buffer is NULL");
+        // the caller's arrays are usually fresh allocations: ask for huge pages where the kernel gives them on request
+        // (270 000 first-touch faults of 4 KiB pages per 3 M candidates otherwise, taken by the copying threads)
+        {
+            auto advise = [](void *p, size_t bytes) {
+                const uintptr_t lo = ((uintptr_t)p + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+                const uintptr_t hi = ((uintptr_t)p + bytes) & ~(uintptr_t)((2u << 20) - 1);
+                if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+            };
+            const size_t rc_ = (size_t)cop->rows_capacity, sc_ = (size_t)cop->slots_capacity;
+            advise(cop->features, rc_ * ADH_NUM_FEATURES * 4);
+            advise(cop->row, rc_ * 4), advise(cop->precursor_idx, rc_ * 4);
+            void *const s4[] = {cop->fragment_row, cop->fragment_precursor_idx, cop->fragment_mz_library, cop->fragment_mz,
+                                cop->fragment_mz_observed, cop->fragment_height, cop->fragment_intensity,
+                                cop->fragment_mass_error, cop->fragment_correlation};
+            for (void *p4 : s4) advise(p4, sc_ * 4);
+            void *const s1[] = {cop->fragment_rank, cop->fragment_position, cop->fragment_number, cop->fragment_type,
+                                cop->fragment_charge, cop->fragment_loss_type};
+            for (void *p1 : s1) advise(p1, sc_);
+        }
+        const size_t cnt_bytes = (size_t)(n + n_chunks) * 8;
+        if (h->cop_cnt_bytes < cnt_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->cop_cnt) (void)hipFree(h->cop_cnt);
+            h->cop_cnt = nullptr, h->cop_cnt_bytes = 0;
+            HIP_TRY(hipMalloc(&h->cop_cnt, cnt_bytes + cnt_bytes / 8));
+            h->cop_cnt_bytes = cnt_bytes + cnt_bytes / 8;
+        }
+        int64_t longest = 0;
+        for (int64_t ci = 0; ci < n_chunks; ++ci) longest = std::max(longest, cut[(size_t)ci + 1] - cut[(size_t)ci]);
+        size_t scan_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)(longest + 1), sk));
+        if (h->cop_scan_bytes < scan_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->cop_scan) (void)hipFree(h->cop_scan);
+            h->cop_scan = nullptr, h->cop_scan_bytes = 0;
+            HIP_TRY(hipMalloc(&h->cop_scan, scan_bytes + 256));
+            h->cop_scan_bytes = scan_bytes + 256;
+        }
+        if (h->cop_stage_bytes < cop_lay.total) {
+            if (h->cop_stage) (void)hipHostFree(h->cop_stage);
+            h->cop_stage = nullptr, h->cop_stage_bytes = 0;
+            HIP_TRY(hipHostMalloc(&h->cop_stage, cop_lay.total + cop_lay.total / 8, hipHostMallocDefault));
+            h->cop_stage_bytes = cop_lay.total + cop_lay.total / 8;
+        }
+    }
+    unsigned char *const cop_stage = static_cast<unsigned char *>(h->cop_stage);
     unsigned char *const cmp_dev = static_cast<unsigned char *>(h->cmp_dev), *const cmp_host = static_cast<unsigned char *>(h->cmp_host);
     const double t_1 = now();
     const bool dbg_events = timing && atoi(getenv("ADH_DEBUG_TIMING")) >= 2;  // per-chunk D2H spans
@@ -1385,6 +1584,14 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
                                d_off, cc);
             HIP_TRY(hipGetLastError());
         }
+        uint64_t *cop_off = cop ? static_cast<uint64_t *>(h->cop_cnt) + a + ci : nullptr;
+        if (cop) {
+            const int64_t nr = b - a;
+            hipLaunchKernelGGL(adh_cop_count_kernel, dim3((unsigned)((nr + 256) / 256)), dim3(256), 0, sk, dev.valid,
+                               dev.fragment_lib_slot, a, nr, top_k, cop_off);
+            size_t scan_bytes = h->cop_scan_bytes;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cop_scan, scan_bytes, cop_off, cop_off, (int)(nr + 1), sk));
+        }
         HIP_TRY(hipEventRecord(h->ev_k[ps], sk));
         if (compact && ci > 0) {  // the packed columns of the previous chunk, now that the host can know their length
             rc = flush_compact(ci - 1);
@@ -1413,7 +1620,36 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
         // (A chunk is up to nine copies and the engine idles ~10 us between two of them - a 47 000-row chunk, 21 MB, takes
         // 0.46 ms = 46 GB/s where each copy runs at 55, `rocprofv3 --memory-copy-trace` - but a second copy-out stream for
         // the feature table does not fill the gaps: measured in round 5, same times to the 0.01 ms, and taken out again.)
-        for (int i = 0; i < kNumOutFields; ++i) {
+        if (cop) {
+            const int64_t nr = b - a;
+            CopStage stg;
+            stg.totals = reinterpret_cast<uint64_t *>(cop_stage + cop_lay.hdr) + ci;
+            stg.row = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.row) + a;
+            stg.pidx = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.pidx) + a;
+            stg.rank = cop_stage + cop_lay.rank + a;
+            stg.feat = reinterpret_cast<float *>(cop_stage + cop_lay.feat) + (size_t)a * ADH_NUM_FEATURES;
+            const size_t e0 = (size_t)a * (size_t)top_k;
+            stg.s_row = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.s_row) + e0;
+            stg.s_pidx = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.s_pidx) + e0;
+            stg.s_rank = cop_stage + cop_lay.s_rank + e0;
+            for (int j = 0; j < 7; ++j) stg.s_f[j] = reinterpret_cast<float *>(cop_stage + cop_lay.s_f[j]) + e0;
+            for (int j = 0; j < 5; ++j) stg.s_b[j] = cop_stage + cop_lay.s_b[j] + e0;
+            // 32 workgroups: enough stores in flight for the link (kcopy_probe: the transposing write reaches 50.7 GB/s
+            // from 32, 51.9 from 64), and the scoring kernels of the next chunks run beside them: a compute unit whose
+            // memory pipeline is backed up with PCIe stores stalls the loads of every wavefront on it - kernels of a
+            // 3 M-row step 14.5 ms alone, 16.8 beside 32 workgroups, 23.5 beside 64, 27.2 beside 128, 30.6 beside 256
+            int blocks = 32;
+            if (const char *env = getenv("ADH_COPY_OUT_BLOCKS")) blocks = std::max(atoi(env), 1);
+            hipLaunchKernelGGL(adh_cop_out_kernel, dim3((unsigned)blocks), dim3(256), 0, so, dev, h->cs.d, h->d_lib, a, nr, top_k,
+                               cop_off, stg);
+            HIP_TRY(hipGetLastError());
+            hipEvent_t ev = nullptr;
+            rc = get_event(h, &ev);
+            if (rc != ADH_OK) return fail_sync(rc);
+            HIP_TRY(hipEventRecord(ev, so));
+            chunk_done.push_back(ev);
+        }
+        for (int i = 0; i < kNumOutFields && !cop; ++i) {
             const OutFieldDesc &f = kOutFields[i];
             void *host = *out_member(out, f);
             const bool is_slot = f.member == offsetof(adh_output_t, fragment_lib_slot);
@@ -1451,6 +1687,71 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     const double t_2 = now();
     rc = comm_gather_slot(h, slot);  // after the last chunk's kernels; overlaps the remaining D2H
     if (rc != ADH_OK) return fail_sync(rc);
+    if (cop) {
+        // host threads follow the copy-out kernels chunk by chunk: totals -> where the chunk goes in the caller's arrays
+        // -> every thread its stripe of every column (plain memcpy from page-locked staging into the caller's memory)
+        const int T = host_threads_for(n);
+        std::vector<int64_t> base_r((size_t)n_chunks + 1, 0), base_s((size_t)n_chunks + 1, 0);
+        std::atomic<int64_t> ready{0};
+        std::atomic<bool> abort{false};
+        const uint64_t *totals = reinterpret_cast<const uint64_t *>(cop_stage + cop_lay.hdr);
+        auto stripe = [&](int64_t ci, int w) {
+            const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
+            cop_copy_stripe(cop_stage, cop_lay, a, b - a, top_k, base_r[(size_t)ci + 1] - base_r[(size_t)ci],
+                            base_s[(size_t)ci + 1] - base_s[(size_t)ci], base_r[(size_t)ci], base_s[(size_t)ci], cop, w, T);
+        };
+        auto worker = [&](int w) {
+            for (int64_t ci = 0; ci < n_chunks; ++ci) {
+                while (ready.load(std::memory_order_acquire) <= ci) {
+                    if (abort.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                stripe(ci, w);
+            }
+        };
+        std::vector<std::thread> team;
+        for (int w = 1; w < T; ++w) {
+            try {
+                team.emplace_back(worker, w);
+            } catch (const std::system_error &) {
+                break;
+            }
+        }
+        const int started = (int)team.size() + 1;
+        hipError_t ee = hipSuccess;
+        bool overflow = false;
+        for (int64_t ci = 0; ci < n_chunks && ee == hipSuccess; ++ci) {
+            ee = hipEventSynchronize(chunk_done[(size_t)ci]);
+            if (ee != hipSuccess) break;
+            const uint64_t tot = totals[ci];
+            base_r[(size_t)ci + 1] = base_r[(size_t)ci] + (int64_t)(tot >> 32);
+            base_s[(size_t)ci + 1] = base_s[(size_t)ci] + (int64_t)(tot & 0xFFFFFFFFull);
+            if (base_r[(size_t)ci + 1] > cop->rows_capacity || base_s[(size_t)ci + 1] > cop->slots_capacity) overflow = true;
+            if (overflow) {  // count on (the caller learns what it needs), copy nothing more
+                base_r[(size_t)ci] = base_r[(size_t)ci + 1];
+                base_s[(size_t)ci] = base_s[(size_t)ci + 1];
+            }
+            ready.store(ci + 1, std::memory_order_release);
+            if (overflow) continue;
+            stripe(ci, 0);
+            for (int w = started; w < T; ++w) stripe(ci, w);
+        }
+        if (ee != hipSuccess) abort.store(true);
+        for (std::thread &t : team) t.join();
+        if (ee != hipSuccess) {
+            fail(ADH_ERR_HIP, std::string("scoring pipeline (compact copy-out): ") + hipGetErrorString(ee));
+            return fail_sync(ADH_ERR_HIP);
+        }
+        cop->n_rows = base_r[(size_t)n_chunks];
+        cop->n_slots = base_s[(size_t)n_chunks];
+        h->d2h_bytes += (uint64_t)cop->n_rows * (9 + 4 * ADH_NUM_FEATURES) + (uint64_t)cop->n_slots * 42;
+        if (overflow) {
+            (void)hipStreamSynchronize(sk);
+            (void)hipStreamSynchronize(so);
+            unwind.ok = true;  // (the device tables are complete)
+            return fail(ADH_ERR_INVALID_ARGUMENT, "compact output: rows_capacity / slots_capacity too small (n_rows / n_slots say what is needed)");
+        }
+    }
     if (rebuild) {
         // host threads follow the copy-out stream chunk by chunk: thread w takes the w-th stripe of every chunk
         const int T = host_threads_for(n);
@@ -1524,6 +1825,23 @@ int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_s
     }
     unwind.ok = true;
     return ADH_OK;
+}
+}  // namespace
+
+int adh_score_candidates(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
+                         adh_output_t *out) {
+    return score_pipeline(h, c, cfg, out, nullptr);
+}
+
+int adh_score_candidates_compact(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring_config_t *cfg,
+                                 adh_compact_output_t *cop) {
+    if (!h || !c || !cfg || !cop) return fail(ADH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (cop->top_k <= 0 || cop->rows_capacity < 0 || cop->slots_capacity < 0)
+        return fail(ADH_ERR_INVALID_ARGUMENT, "compact output: top_k / capacities");
+    adh_output_t shape{};
+    shape.n = c->n;
+    shape.top_k = cop->top_k;
+    return score_pipeline(h, c, cfg, &shape, cop);
 }
 
 int adh_table_layout(int64_t rows, int32_t top_k, int32_t capacity, adh_table_field_t *fields, int32_t *n_fields,
@@ -1748,5 +2066,60 @@ int adh_host_alloc(void **ptr, uint64_t bytes) {
 
 int adh_host_free(void *ptr) {
     if (ptr) HIP_TRY(hipHostFree(ptr));
+    return ADH_OK;
+}
+
+// dst[i] = src[idx[i]] for arrays of reference-counted CPython object pointers (NumPy dtype=object), on several
+// threads: the precursor-side string columns of the features frame (proteins, genes, sequence, mods, mod_sites) are
+// 13.5 M such pointers per 3 M candidates and NumPy gathers them on one thread.  The CALLER HOLDS THE GIL for the
+// whole call (ctypes.PyDLL): nothing else can touch a reference count meanwhile, the threads here only add to them,
+// atomically (ob_refcnt is the first word of an object in CPython <= 3.11; alphadia_amd/runtime.py checks that on a
+// probe object before it uses this).  dst must be fresh: every entry NULL or `fill` (np.empty gives an object array
+// filled with references to None), whose reference count gives back what the gathered pointers replace.
+int adh_host_take_objects(void **dst, void *const *src, const int64_t *idx, int64_t n, int64_t n_src, void *fill,
+                          int32_t threads) {
+    if ((!dst || !src || !idx) && n > 0) return fail(ADH_ERR_INVALID_ARGUMENT, "adh_host_take_objects: NULL argument");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n / 65536));
+    std::atomic<int> bad{0};
+    auto work = [&](int w) {
+        const int64_t a = n * w / T, b = n * (w + 1) / T;
+        intptr_t replaced = 0;
+        // runs of one object (the candidates of a precursor follow each other; a column of empty strings is ONE
+        // interned object) are counted and added once: sixteen threads adding to one reference count one by one spend
+        // their time passing its cache line around (measured: the gather of five columns slower than NumPy's)
+        void *run = nullptr;
+        intptr_t run_len = 0;
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t k = idx[i];
+            void *const old = dst[i];
+            if ((uint64_t)k >= (uint64_t)n_src || (old != nullptr && old != fill)) {
+                bad.store(1, std::memory_order_relaxed);
+                continue;
+            }
+            void *o = src[k];
+            if (o != run) {
+                if (run && run_len) __atomic_fetch_add(reinterpret_cast<intptr_t *>(run), run_len, __ATOMIC_RELAXED);
+                run = o;
+                run_len = 0;
+            }
+            ++run_len;
+            dst[i] = o;
+            replaced += old != nullptr;
+        }
+        if (run && run_len) __atomic_fetch_add(reinterpret_cast<intptr_t *>(run), run_len, __ATOMIC_RELAXED);
+        if (replaced) __atomic_fetch_sub(reinterpret_cast<intptr_t *>(fill), replaced, __ATOMIC_RELAXED);
+    };
+    std::vector<std::thread> team;
+    for (int w = 1; w < T; ++w) {
+        try {
+            team.emplace_back(work, w);
+        } catch (const std::system_error &) {
+            for (int v = w; v < T; ++v) work(v);
+            break;
+        }
+    }
+    work(0);
+    for (std::thread &t : team) t.join();
+    if (bad.load()) return fail(ADH_ERR_INVALID_ARGUMENT, "adh_host_take_objects: index out of range or dst not fresh");
     return ADH_OK;
 }

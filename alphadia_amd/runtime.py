@@ -25,6 +25,8 @@ EXPORTED_SYMBOLS = [
     "adh_stage_timstof",
     "adh_stage_fragments",
     "adh_score_candidates",
+    "adh_score_candidates_compact",
+    "adh_host_take_objects",
     "adh_upload_candidates",
     "adh_score_uploaded",
     "adh_get_stream",
@@ -123,6 +125,56 @@ def _load():
 
 
 lib = _load()
+
+
+_pylib = None       # the same library through ctypes.PyDLL: calls keep the GIL (adh_host_take_objects needs that)
+_OBJ_TAKE = None    # None: not probed yet; True / False: the threaded object gather is usable
+
+
+def _probe_take_objects() -> bool:
+    """Is ``ob_refcnt`` the first word of an object here (CPython <= 3.11, no trace-refs build)?  Checked on a probe
+    object: five references more after a gather of five, and the gathered entries are the object."""
+    global _pylib
+    import sys
+
+    if sys.implementation.name != "cpython" or sys.version_info[:2] > (3, 11) or os.environ.get("ADH_NO_OBJECT_TAKE"):
+        return False
+    try:
+        _pylib = C.PyDLL(LIB_PATH)
+        fn = _pylib.adh_host_take_objects
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
+        probe = object()
+        src = np.empty(1, dtype=object)
+        src[0] = probe
+        idx = np.zeros(5, dtype=np.int64)
+        dst = np.empty(5, dtype=object)
+        before = sys.getrefcount(probe)
+        rc = fn(dst.ctypes.data, src.ctypes.data, idx.ctypes.data, 5, 1, id(None), 1)
+        after = sys.getrefcount(probe)
+        return rc == 0 and after - before == 5 and all(o is probe for o in dst)
+    except Exception:
+        return False
+
+
+def take_objects(src: np.ndarray, idx: np.ndarray, threads: int = 8) -> np.ndarray:
+    """``src[idx]`` for a 1-d object array: on several threads through ``adh_host_take_objects`` where that is safe
+    (see there), NumPy's own gather otherwise (small inputs, other interpreters, negative indices)."""
+    global _OBJ_TAKE
+    src = np.asarray(src)
+    if src.dtype != object or src.ndim != 1 or len(idx) < 262144 or not src.flags.c_contiguous:
+        return src[idx]
+    if _OBJ_TAKE is None:
+        _OBJ_TAKE = _probe_take_objects()
+    if not _OBJ_TAKE:
+        return src[idx]
+    idx64 = np.ascontiguousarray(idx, dtype=np.int64)
+    dst = np.empty(len(idx64), dtype=object)
+    rc = _pylib.adh_host_take_objects(dst.ctypes.data, src.ctypes.data, idx64.ctypes.data, len(idx64), len(src), id(None),
+                                      int(threads))
+    if rc != 0:  # (an index NumPy would wrap or reject: let NumPy decide; entries written so far are dropped with dst)
+        return src[idx]
+    return dst
 
 
 def _check(rc: int, what: str):
@@ -558,6 +610,46 @@ class Context:
         )
         self.n_candidates = n
         return arrays
+
+    def score_host_compact(self, cands: _abi.Marshalled, cfg_jit, slots_per_row: float | None = None) -> dict:
+        """``adh_score_candidates_compact``: the valid candidates and the filled fragment slots, column by column, in
+        arrays this call allocates (the caller owns them): ``row``, ``precursor_idx``, ``rank``, ``features`` as
+        [46, n_rows] (every feature a contiguous row) and the ``fragment_*`` columns per filled slot with
+        ``fragment_row`` = row of the slot's candidate in the candidate table.
+
+        The arrays are allocated at a capacity - all candidates, ``slots_per_row`` filled slots per candidate (default:
+        the width of the padded tables, which always suffices) - and returned as views of their first n entries: the
+        pages behind the unused tail of a large fresh allocation are never touched, so they cost address space only.
+        A call whose ``slots_per_row`` turns out too small is repeated with what it needs."""
+        n = int(cands.struct.n)
+        width = _abi.output_width(cands, int(cfg_jit.top_k_fragments))
+        cfg = _abi.pack_config(cfg_jit)
+        rows_cap = max(n, 1)
+        slots_cap = max(int(n * (width if slots_per_row is None else min(float(slots_per_row), width))) + 1, 1)
+        while True:
+            out = _abi.CompactOutput()
+            out.rows_capacity, out.slots_capacity, out.top_k = rows_cap, slots_cap, width
+            arrays = {}
+            for name, dt in _abi.COMPACT_ROW_FIELDS:
+                arrays[name] = np.empty(rows_cap, dtype=dt)
+            arrays["features"] = np.empty((_abi.NUM_FEATURES, rows_cap), dtype=np.float32)
+            for name, dt in _abi.COMPACT_SLOT_FIELDS:
+                arrays[name] = np.empty(slots_cap, dtype=dt)
+            for name, a in arrays.items():
+                setattr(out, name, a.ctypes.data_as(dict(out._fields_)[name]))
+            rc = lib.adh_score_candidates_compact(self._h, cands.ref(), C.byref(cfg), C.byref(out))
+            if rc != 0 and (int(out.n_rows) > rows_cap or int(out.n_slots) > slots_cap):
+                rows_cap, slots_cap = max(rows_cap, int(out.n_rows)), max(slots_cap, int(out.n_slots))
+                continue  # (only a caller's own slots_per_row can be too small)
+            _check(rc, "adh_score_candidates_compact")
+            break
+        self.n_candidates = n
+        nr, ns = int(out.n_rows), int(out.n_slots)
+        res = {name: arrays[name][:nr] for name, _ in _abi.COMPACT_ROW_FIELDS}
+        res["features"] = arrays["features"][:, :nr]
+        res.update({name: arrays[name][:ns] for name, _ in _abi.COMPACT_SLOT_FIELDS})
+        res["top_k"] = width
+        return res
 
     def upload_candidates(self, cands: _abi.Marshalled) -> None:
         _check(lib.adh_upload_candidates(self._h, cands.ref()), "adh_upload_candidates")

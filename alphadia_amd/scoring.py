@@ -602,6 +602,7 @@ def collect_candidates(
     precursor_mz_column: str,
     row_maps=None,
     sequence_counts=None,
+    compact: dict | None = None,
 ) -> pd.DataFrame:
     """scoring.py:394-467 (column names, order and merges).
 
@@ -620,7 +621,7 @@ def collect_candidates(
             precursor_df_columns.append(col)
     if row_maps is not None:
         return _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df, rt_column, candidate_columns,
-                                           precursor_df_columns, row_maps, sequence_counts)
+                                           precursor_df_columns, row_maps, sequence_counts, compact=compact)
     precursor_idx, rank, features = psm_proto_df.to_precursor_df()
     df = pd.DataFrame(features, columns=DEFAULT_FEATURE_COLUMNS)
     df["precursor_idx"] = precursor_idx
@@ -639,18 +640,20 @@ def collect_candidates(
 
 
 def _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df, rt_column, candidate_columns,
-                                precursor_df_columns, row_maps, sequence_counts) -> pd.DataFrame:
+                                precursor_df_columns, row_maps, sequence_counts, compact: dict | None = None) -> pd.DataFrame:
     """``collect_candidates`` when the candidate row and the precursor row of every table row are known: the same
     columns, order and dtypes as the two left merges on unique keys give, as gathers - one task per column on
     the host pool, the 46-column feature block in row slices - and a frame assembled around those arrays
     without another copy (pandas would otherwise re-stack the columns by dtype)."""
     _, threads = _host_pool()
-    rows = np.flatnonzero(np.asarray(psm_proto_df.valid, dtype=bool))
+    # ``compact`` (Context.score_host_compact): the device already dropped the invalid rows and transposed the feature
+    # table - row ids, ids and the [feature][row] block arrive as they go into the frame
+    rows = compact["row"] if compact is not None else np.flatnonzero(np.asarray(psm_proto_df.valid, dtype=bool))
     cand_rows = np.asarray(row_maps[0]).take(rows)
     prec_rows = np.asarray(row_maps[1]).take(rows)
     names: list[str] = list(DEFAULT_FEATURE_COLUMNS)
-    jobs: list[tuple[str, np.ndarray, np.ndarray]] = [("precursor_idx", psm_proto_df.precursor_idx, rows),
-                                                      ("rank", psm_proto_df.rank, rows)]
+    jobs: list[tuple[str, np.ndarray, np.ndarray]] = [] if compact is not None else [
+        ("precursor_idx", psm_proto_df.precursor_idx, rows), ("rank", psm_proto_df.rank, rows)]
     have = set(names) | {"precursor_idx", "rank"}
     for frame, wanted, idx in ((candidates_df, candidate_columns, cand_rows),
                                (precursors_flat_df, precursor_df_columns, prec_rows)):
@@ -664,10 +667,24 @@ def _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df,
     counts = None
     if sequence_counts is not None:
         counts = [(name, np.asarray(cnt), prec_rows) for name, cnt in zip(("n_K", "n_R", "n_P"), sequence_counts, strict=True)]
-    features = _take_rows_transposed(psm_proto_df.features, rows, threads)  # [feature][row]: contiguous columns
-    gathered = _parallel([(lambda src=src, idx=idx: src[idx]) for _, src, idx in jobs + (counts or [])])
-    cols = {name: arr for (name, _, _), arr in zip(jobs + (counts or []), gathered)}
+    if compact is not None:
+        features = compact["features"]
+    else:
+        features = _take_rows_transposed(psm_proto_df.features, rows, threads)  # [feature][row]: contiguous columns
+    # object columns (proteins ... mod_sites) are reference-counted pointers: NumPy gathers them one column after the
+    # other under the GIL (~10 ms per 2.7 M rows); runtime.take_objects gathers them on several threads
+    obj_jobs = [(name, src, idx) for name, src, idx in jobs if src.dtype == object]
+    num_jobs = [(name, src, idx) for name, src, idx in jobs if src.dtype != object] + (counts or [])
+    from . import runtime as _rt
+
+    gathered = _parallel([(lambda src=src, idx=idx: src[idx]) for _, src, idx in num_jobs])
+    cols = {name: arr for (name, _, _), arr in zip(num_jobs, gathered)}
+    for name, src, idx in obj_jobs:
+        cols[name] = _rt.take_objects(src, idx, threads)
     frame = {name: features[j] for j, name in enumerate(DEFAULT_FEATURE_COLUMNS)}
+    if compact is not None:
+        frame["precursor_idx"] = compact["precursor_idx"]
+        frame["rank"] = compact["rank"]
     frame.update({name: cols[name] for name, _, _ in jobs})
     frame["delta_rt"] = frame["rt_observed"] - frame[rt_column]
     if counts is not None:
@@ -681,6 +698,25 @@ def _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df,
         df["n_R"] = df["sequence"].str.count("R")
         df["n_P"] = df["sequence"].str.count("P")
     return df
+
+
+def collect_fragments_compact(compact: dict, precursors_flat_df: pd.DataFrame, prec_rows) -> pd.DataFrame:
+    """scoring.py:520-580 from the compacted columns of ``Context.score_host_compact``: the filled slots arrive as
+    columns; only ``elution_group_idx`` and ``decoy`` are looked up (slot -> candidate row -> precursor row)."""
+    missing = [c for c in ("elution_group_idx", "decoy") if c not in FRAGMENT_DF_COLUMNS]
+    absent = [c for c in missing if c not in precursors_flat_df.columns]
+    if absent:
+        raise ValueError(f"Columns {absent} must be present in right_df")
+    _, threads = _host_pool()
+    frow = compact["fragment_row"]
+    prec_rows = np.asarray(prec_rows)
+    lib_rows = np.empty(len(frow), dtype=prec_rows.dtype)
+    cuts = np.linspace(0, len(frow), (threads if len(frow) > 1 << 20 else 1) + 1).astype(np.int64)
+    _parallel([(lambda a=int(a), b=int(b): np.take(prec_rows, frow[a:b], out=lib_rows[a:b])) for a, b in zip(cuts[:-1], cuts[1:])])
+    looked_up = [_take_chunked(precursors_flat_df[c].values, lib_rows, threads) for c in missing]
+    frame = {c: compact["fragment_" + c] for c in FRAGMENT_DF_COLUMNS}
+    frame.update(dict(zip(missing, looked_up, strict=True)))
+    return pd.DataFrame(frame, copy=False)
 
 
 def collect_fragments(psm_proto_df: OutputPsmDF, precursors_flat_df: pd.DataFrame, prec_rows=None) -> pd.DataFrame:
@@ -829,8 +865,11 @@ class HipCandidateScoring:
         if debug:  # scoring.py:628-631: first 10 score groups only
             keep = soa["score_group_idx"] < 10
             soa["flags"] = np.where(keep, soa["flags"], _abi.FLAG_SKIP).astype(np.uint8)
-        # the frames below copy what they need out of the pooled page-locked tables
         t_1 = time.perf_counter()
+        if not os.environ.get("ADH_OPERATOR_PADDED"):
+            return self._call_compact(candidates_df, soa, t_0, t_1)
+        # (the round-4 path, kept for comparison: padded tables to the host, then valid rows / filled slots gathered
+        # out of them column by column; the frames copy what they need out of the pooled page-locked tables)
         psm_proto_df = self.score_soa(soa, reuse_buffers=True)
         t_2 = time.perf_counter()
         # The two frames are independent.  The features frame spends most of its time gathering five object
@@ -876,6 +915,49 @@ class HipCandidateScoring:
                              "collect_ms": (t_4 - t_2) * 1e3, "total_ms": (t_4 - t_0) * 1e3}
         logger.info("Finished candidate scoring")
         return features_df, fragments_df
+
+
+def _call_compact(self, candidates_df: pd.DataFrame, soa: dict, t_0: float, t_1: float):
+    """The operator on the compacted copy-out (``adh_score_candidates_compact``): the device drops invalid candidates
+    and empty fragment slots and transposes the feature table, the columns land in arrays the frames wrap as they
+    are; what is left for the host are the columns the frames take over from the candidate and the precursor table."""
+    import threading
+    import time
+
+    comp = self._ctx.score_host_compact(pack_assembled(soa), self._kernel_config())
+    t_2 = time.perf_counter()
+    frag_box: dict = {}
+
+    def fragments_job():
+        t_a = time.perf_counter()
+        try:
+            frag_box["df"] = collect_fragments_compact(comp, self.precursors_flat_df, soa["prec_row"])
+        except BaseException as exc:  # re-raised on the calling thread
+            frag_box["exc"] = exc
+        frag_box["ms"] = (time.perf_counter() - t_a) * 1e3
+
+    logger.info("Collecting candidate and fragment features")
+    worker = threading.Thread(target=fragments_job, name="adh-collect-fragments")
+    worker.start()
+    try:
+        features_df = collect_candidates(
+            candidates_df, None, self.precursors_flat_df, self.rt_column, self.mobility_column, self.precursor_mz_column,
+            row_maps=(soa["order"], soa["prec_row"]), sequence_counts=self._sequence_counts(), compact=comp)
+    finally:
+        t_3 = time.perf_counter()
+        worker.join()
+    if "exc" in frag_box:
+        raise frag_box["exc"]
+    t_4 = time.perf_counter()
+    self.last_timings = {"assemble_ms": (t_1 - t_0) * 1e3, "score_ms": (t_2 - t_1) * 1e3,
+                         "collect_candidates_ms": (t_3 - t_2) * 1e3, "collect_fragments_ms": frag_box["ms"],
+                         "collect_ms": (t_4 - t_2) * 1e3, "total_ms": (t_4 - t_0) * 1e3,
+                         "wire_bytes": int(comp["features"].nbytes + 9 * len(comp["row"]) + 42 * len(comp["fragment_row"]))}
+    logger.info("Finished candidate scoring")
+    return features_df, frag_box["df"]
+
+
+HipCandidateScoring._call_compact = _call_compact
 
 
 def calculate_score_groups(input_df: pd.DataFrame, group_channels: bool = False) -> pd.DataFrame:

@@ -222,6 +222,54 @@ int adh_score_candidates(adh_handle_t *handle, const adh_candidates_t *candidate
                          const adh_scoring_config_t *config, adh_output_t *out);
 
 /*
+ * The same call for the DataFrame operator: only what `collect_candidates` / `collect_fragments`
+ * (search/scoring/scoring.py:394-467,520-580; output.py:89-97) keep of the padded tables comes back - the VALID
+ * candidates (`valid`), column by column, and the FILLED fragment slots (`fragment_mz_library > 0`), in the order
+ * the padded tables hold them.  Per chunk of the pipeline the device counts and scans, and ONE kernel writes the
+ * compacted columns - features transposed to [feature][row], library columns of a slot from the staged library -
+ * through PCIe into a page-locked staging block of the handle (kernel stores reach the link rate:
+ * tools/probes/kcopy_probe.hip); host threads move each finished chunk into the caller's arrays, which may be
+ * pageable.  No padded host table, no host pass over invalid rows or empty slots.
+ *
+ * Capacities: `rows_capacity` >= number of valid candidates, `slots_capacity` >= number of filled slots
+ * (candidates and candidates * top_k always suffice).  A call that would overflow either writes nothing beyond
+ * them, sets n_rows / n_slots to what it needs and fails with ADH_ERR_INVALID_ARGUMENT.
+ * The padded device tables are left in HBM as by adh_score_candidates (adh_get_device_tables, the FDR stage).
+ */
+typedef struct adh_compact_output {
+    int64_t rows_capacity;          /* in */
+    int64_t slots_capacity;         /* in */
+    int32_t top_k;                  /* in: fragment slots per candidate (width of the padded tables) */
+    int32_t reserved;
+    int64_t n_rows;                 /* out: valid candidates */
+    int64_t n_slots;                /* out: filled fragment slots */
+    /* per valid candidate, ascending candidate row */
+    uint32_t *row;                  /* [rows_capacity] row of the candidate in adh_candidates_t */
+    uint32_t *precursor_idx;        /* [rows_capacity] */
+    uint8_t *rank;                  /* [rows_capacity] */
+    float *features;                /* [46][rows_capacity]: feature f of the j-th valid candidate at f * rows_capacity + j */
+    /* per filled fragment slot, ascending (candidate row, slot) */
+    uint32_t *fragment_row;         /* [slots_capacity] row of the slot's candidate in adh_candidates_t */
+    uint32_t *fragment_precursor_idx;
+    uint8_t *fragment_rank;
+    float *fragment_mz_library;
+    float *fragment_mz;
+    float *fragment_mz_observed;
+    float *fragment_height;
+    float *fragment_intensity;
+    float *fragment_mass_error;
+    float *fragment_correlation;
+    uint8_t *fragment_position;
+    uint8_t *fragment_number;
+    uint8_t *fragment_type;
+    uint8_t *fragment_charge;
+    uint8_t *fragment_loss_type;
+} adh_compact_output_t;
+
+int adh_score_candidates_compact(adh_handle_t *handle, const adh_candidates_t *candidates,
+                                 const adh_scoring_config_t *config, adh_compact_output_t *out);
+
+/*
  * The same work split so that tables can stay in HBM:
  *   adh_upload_candidates  - copy the candidate SoA to the GPU (kept in the handle)
  *   adh_score_uploaded     - enqueue the kernels on `hip_stream` (a hipStream_t taken
@@ -276,6 +324,16 @@ int adh_host_alloc(void **ptr, uint64_t bytes);
 /* blocking copy of `bytes` bytes from a device pointer of one of the views above to host memory */
 int adh_copy_to_host(adh_handle_t *handle, void *dst, const void *src_device, uint64_t bytes);
 int adh_host_free(void *ptr);
+
+/*
+ * dst[i] = src[idx[i]] for n entries of arrays of CPython object pointers (NumPy dtype=object) - the string columns
+ * the features frame takes over from the precursor table (scoring.py:430-445 merges them in) - on `threads` host
+ * threads, reference counts raised atomically.  The caller must hold the GIL for the whole call (ctypes.PyDLL) and
+ * pass a fresh dst - every entry NULL or `fill` (np.empty fills an object array with references to None; they are
+ * given back); idx outside [0, n_src) fails.  Host helper of the Python operator: no GPU involved.
+ */
+int adh_host_take_objects(void **dst, void *const *src, const int64_t *idx, int64_t n, int64_t n_src, void *fill,
+                          int32_t threads);
 
 /*
  * Test entry: the dense tile the gather kernels build for ONE query, i.e. what

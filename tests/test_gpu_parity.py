@@ -427,6 +427,79 @@ def test_operator_and_handler_dataframes(ctx):
         create_handler({"search": {"extraction_backend": "python"}}, opt, None, reporter, names)
 
 
+@pytest.mark.parametrize("name", ["handler_default", "class_default", "manyfrag", "edges", "multiplex"])
+def test_compact_operator_frames_equal_the_padded_ones(ctx, monkeypatch, name):
+    """The operator on the compacted copy-out (adh_score_candidates_compact: valid rows and filled slots leave the
+    device as columns) returns the frames of the padded path - same columns, order, dtypes and bits - and the frames
+    own their memory.  Dtypes of the schema columns as validation/schemas.py:76-120 wants them."""
+    from alphadia_amd.scoring import HipCandidateScoring
+
+    g = H.load_scoring_golden(name)
+    scorer = HipCandidateScoring(
+        dia_data=g.dia, precursors_flat=g.library.precursor_df, fragments_flat=g.library.fragment_df,
+        rt_column="rt_library", mobility_column="mobility_library", precursor_mz_column="mz_library",
+        fragment_mz_column="mz_library", config=g.config, device=0,
+    )
+    monkeypatch.setenv("ADH_OPERATOR_PADDED", "1")
+    f_pad, fr_pad = scorer(g.candidates_df, thread_count=4)
+    monkeypatch.delenv("ADH_OPERATOR_PADDED")
+    monkeypatch.setenv("ADH_CHUNK", "1024")  # several chunks even on the small goldens
+    f_cmp, fr_cmp = scorer(g.candidates_df, thread_count=4)
+    assert scorer.last_timings["wire_bytes"] > 0
+    for a, b in ((f_pad, f_cmp), (fr_pad, fr_cmp)):
+        assert list(a.columns) == list(b.columns)
+        assert len(a) == len(b) and len(a) > 0
+        for c in a.columns:
+            assert a[c].dtype == b[c].dtype, c
+            if a[c].dtype == object:
+                assert (a[c].values == b[c].values).all(), c
+            else:
+                assert np.array_equal(a[c].to_numpy(), b[c].to_numpy(), equal_nan=True), c
+    for c, dt in (("precursor_idx", np.uint32), ("rank", np.uint8), ("mz_observed", np.float32), ("elution_group_idx", np.uint32)):
+        assert f_cmp[c].dtype == dt and fr_cmp[c].dtype == dt, c
+    # the frames do not alias pooled buffers: another call leaves them as they are
+    keep = f_cmp["mz_observed"].to_numpy().copy(), fr_cmp["height"].to_numpy().copy()
+    scorer(g.candidates_df.iloc[::2].reset_index(drop=True), thread_count=4)
+    assert np.array_equal(keep[0], f_cmp["mz_observed"].to_numpy(), equal_nan=True)
+    assert np.array_equal(keep[1], fr_cmp["height"].to_numpy(), equal_nan=True)
+
+
+def test_compact_output_capacity_is_checked(ctx):
+    """adh_score_candidates_compact never writes beyond the capacities: a call that needs more fails, says what it
+    needs, and the repeated call (Context.score_host_compact does that itself) succeeds."""
+    import ctypes as C
+
+    from alphadia_amd import _abi, runtime
+
+    g = H.load_scoring_golden("handler_default")
+    ctx.stage_run(g.dia, force=True)
+    ctx.stage_fragments(*fragment_columns(g.library.fragment_df, "mz_library"), force=True)
+    soa = H.soa_for(g, g.config)
+    full = ctx.score_host_compact(pack_assembled(soa), g.config.to_jitclass())
+    assert len(full["row"]) > 50 and len(full["fragment_row"]) > len(full["row"])
+    small = ctx.score_host_compact(pack_assembled(soa), g.config.to_jitclass(), slots_per_row=0.01)  # grows and repeats
+    for k in full:
+        if isinstance(full[k], np.ndarray):
+            assert np.array_equal(full[k], small[k], equal_nan=True), k
+    # the raw call with room for ten rows: error code, needed counts, nothing written past the capacity
+    cands = pack_assembled(soa)
+    width = _abi.output_width(cands, int(g.config.top_k_fragments))
+    out = _abi.CompactOutput()
+    out.rows_capacity, out.slots_capacity, out.top_k = 10, 10, width
+    guard = {}
+    fields = dict(out._fields_)
+    for name, dt in _abi.COMPACT_ROW_FIELDS + _abi.COMPACT_SLOT_FIELDS:
+        guard[name] = np.full(64, 7, dtype=dt)
+        setattr(out, name, guard[name].ctypes.data_as(fields[name]))
+    guard["features"] = np.full((_abi.NUM_FEATURES, 10), 7, dtype=np.float32)
+    out.features = guard["features"].ctypes.data_as(fields["features"])
+    cfg = _abi.pack_config(g.config.to_jitclass())
+    rc = runtime.lib.adh_score_candidates_compact(ctx._h, cands.ref(), C.byref(cfg), C.byref(out))
+    assert rc != 0 and int(out.n_rows) == len(full["row"]) and int(out.n_slots) == len(full["fragment_row"])
+    for name, _ in _abi.COMPACT_ROW_FIELDS + _abi.COMPACT_SLOT_FIELDS:
+        assert (guard[name][10:] == 7).all(), name
+
+
 def test_frame_stop_clipped_to_the_last_frame(ctx, oracle_lib):
     """The selection step clips frame_stop to frame_max_index (selection.py:488-491): scoring takes
     the floor of the cycle count like get_dense does."""
