@@ -151,8 +151,10 @@ struct adh_handle {
     void *cmp_dev = nullptr, *cmp_host = nullptr, *cmp_scan = nullptr;
     size_t cmp_dev_bytes = 0, cmp_host_bytes = 0, cmp_scan_bytes = 0;
     // adh_score_candidates_compact: per-row counts / offsets on the device, scan scratch, page-locked staging block
-    void *cop_cnt = nullptr, *cop_scan = nullptr, *cop_stage = nullptr;
-    size_t cop_cnt_bytes = 0, cop_scan_bytes = 0, cop_stage_bytes = 0;
+    void *cop_cnt = nullptr, *cop_scan = nullptr, *cop_stage = nullptr, *cop_dev = nullptr;
+    size_t cop_cnt_bytes = 0, cop_scan_bytes = 0, cop_stage_bytes = 0, cop_dev_bytes = 0;
+    uint64_t *cop_tot_pinned = nullptr;     // totals of up to 4096 chunks, page-locked
+    std::vector<uint64_t> cop_tot_host;
     int64_t n_lib = 0;
     double *d_wtp = nullptr;        // precursor weight table [2][64]
     uint64_t im_scratch_budget = 0; // bytes the scratch of one ion-mobility chunk may reserve (0: not asked yet)
@@ -322,6 +324,8 @@ int adh_destroy(adh_handle_t *h) {
     if (h->cmp_host) (void)hipHostFree(h->cmp_host);
     if (h->cop_stage) (void)hipHostFree(h->cop_stage);
     if (h->cop_cnt) (void)hipFree(h->cop_cnt);
+    if (h->cop_dev) (void)hipFree(h->cop_dev);
+    if (h->cop_tot_pinned) (void)hipHostFree(h->cop_tot_pinned);
     if (h->cop_scan) (void)hipFree(h->cop_scan);
     if (h->cmp_dev) (void)hipFree(h->cmp_dev);
     if (h->cmp_scan) (void)hipFree(h->cmp_scan);

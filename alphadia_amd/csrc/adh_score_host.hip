@@ -888,12 +888,20 @@ __global__ void adh_compact_kernel(DevOut t, int64_t row0, int64_t n, int top_k,
 
 // ---- compacted, column-major copy-out of the operator path (round 5, adh_score_candidates_compact).  What the
 // DataFrames of collect_candidates / collect_fragments keep of the padded tables is 91 % of the rows and 38 % of the
-// fragment slots (headline).  Per chunk: (valid, filled slots) per row as one 64-bit count, an exclusive scan, and ONE
-// kernel on the copy-out stream that writes every column of the chunk's valid rows and filled slots through PCIe into
-// the handle's page-locked staging block - features transposed to [feature][row], the library columns of a slot read
-// from the staged library, ids from the candidate table - at the chunk's own offsets; the chunk's totals go into a
-// header word.  Kernel stores reach the link rate (tools/probes/kcopy_probe.hip: 54-55 GB/s from 64 workgroups, 51-52
-// for the transposing write, against 46 GB/s for nine DMA copies of a small chunk).
+// fragment slots (headline).  Per chunk, behind its scoring kernels: (valid, filled slots) per row as one 64-bit count,
+// an exclusive scan, and a pack kernel that writes every column of the chunk's valid rows and filled slots - features
+// transposed to [feature][row], the library columns of a slot read from the staged library, ids from the candidate
+// table - DENSELY into the chunk's block of a device staging buffer (CopBlock: where a column starts follows from the
+// chunk's two totals).  The totals reach the host first (8 bytes, stored by the pack kernel straight into page-locked
+// memory); the host then moves the block with ONE DMA copy of exactly its used bytes into a page-locked twin, and host
+// threads unpack finished blocks into the caller's arrays while later chunks are scored.
+// (Measured and dropped: the pack kernel storing through PCIe straight into host memory.  Kernel stores reach the link
+// rate - tools/probes/kcopy_probe.hip: 54-55 GB/s from 64 workgroups - but a copy-out kernel does not run BESIDE the
+// scoring kernels: on a stream of its own its workgroups wait until the scoring stream's backlog has drained (first
+// chunk on the host 15.7 ms into a 36 ms call), on a high-priority stream the launches of the scoring stream stall
+// instead (52 ms), and a compute unit backed up with PCIe stores stalls every wavefront on it: scoring kernels of a step
+// 14.5 ms alone, 16.8 beside 32 copying workgroups, 23.5 beside 64, 27.2 beside 128.  An 8-byte hipMemcpyAsync is such
+// a kernel, too: with the totals fetched that way the first block arrived 57 ms into the call.)
 __global__ void adh_cop_count_kernel(const uint8_t *__restrict__ valid, const uint16_t *__restrict__ lib_slot, int64_t row0,
                                      int64_t n, int top_k, uint64_t *__restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -908,59 +916,61 @@ __global__ void adh_cop_count_kernel(const uint8_t *__restrict__ valid, const ui
     cnt[i] = v;  // (entry n: 0, so that the scan's last entry is the total)
 }
 
-// the staging block of a call of n rows (page-locked; the device writes, host threads read): [one uint64 of totals per
-// chunk, 4 KiB aligned] [row u32 | precursor_idx u32 | rank u8 | features f32 x 46] per row, [fragment_row u32 |
-// precursor_idx u32 | rank u8 | 7 float columns | 5 byte columns] per slot; a chunk's entries start at its first row
-// (x top_k for the slot columns), its feature block is [46][rows of the chunk]
-struct CopLayout {
-    int64_t n, slots;
-    size_t hdr, row, pidx, rank, feat, s_row, s_pidx, s_rank, s_f[7], s_b[5], total;
-    CopLayout(int64_t n_, int top_k, int64_t n_chunks) : n(n_), slots(n_ * (int64_t)top_k) {
-        auto up = [](size_t x) { return (x + 4095) / 4096 * 4096; };
+// a chunk's block, dense: [row u32 | precursor_idx u32 | rank u8 | features f32 [46][R]] for its R valid rows, then
+// [fragment_row u32 | precursor_idx u32 | rank u8 | 7 float columns | 5 byte columns] for its S filled slots; every
+// column starts on a multiple of 16 bytes
+struct CopBlock {
+    size_t row, pidx, rank, feat, s_row, s_pidx, s_rank, s_f[7], s_b[5], total;
+    __host__ __device__ CopBlock(uint64_t R, uint64_t S) {
         size_t o = 0;
-        hdr = o, o += up((size_t)n_chunks * 8);
-        row = o, o += up((size_t)n * 4);
-        pidx = o, o += up((size_t)n * 4);
-        rank = o, o += up((size_t)n);
-        feat = o, o += up((size_t)n * ADH_NUM_FEATURES * 4);
-        s_row = o, o += up((size_t)slots * 4);
-        s_pidx = o, o += up((size_t)slots * 4);
-        s_rank = o, o += up((size_t)slots);
-        for (int j = 0; j < 7; ++j) s_f[j] = o, o += up((size_t)slots * 4);
-        for (int j = 0; j < 5; ++j) s_b[j] = o, o += up((size_t)slots);
+        row = o, o += (R * 4 + 15) & ~(size_t)15;
+        pidx = o, o += (R * 4 + 15) & ~(size_t)15;
+        rank = o, o += (R + 15) & ~(size_t)15;
+        feat = o, o += (R * 4 * ADH_NUM_FEATURES + 15) & ~(size_t)15;
+        s_row = o, o += (S * 4 + 15) & ~(size_t)15;
+        s_pidx = o, o += (S * 4 + 15) & ~(size_t)15;
+        s_rank = o, o += (S + 15) & ~(size_t)15;
+        for (int j = 0; j < 7; ++j) s_f[j] = o, o += (S * 4 + 15) & ~(size_t)15;
+        for (int j = 0; j < 5; ++j) s_b[j] = o, o += (S + 15) & ~(size_t)15;
         total = o;
     }
 };
-
-struct CopStage {  // device-visible pointers into the staging block, already moved to the chunk's first entry
-    uint64_t *totals;
-    uint32_t *row, *pidx;
-    uint8_t *rank;
-    float *feat;  // [46][rows of the chunk]
-    uint32_t *s_row, *s_pidx;
-    uint8_t *s_rank;
-    float *s_f[7];  // mz_library, mz, mz_observed, height, intensity, mass_error, correlation
-    uint8_t *s_b[5];  // position, number, type, charge, loss_type
+// where the block of the chunk that starts at row a sits in the staging buffers (device and host alike): room for
+// every row valid and every slot filled
+struct CopLayout {
+    size_t per_row, total;
+    CopLayout(int64_t n, int top_k, int64_t n_chunks)
+        : per_row(9 + 4 * ADH_NUM_FEATURES + (size_t)top_k * 42), total((size_t)n * per_row + (size_t)(n_chunks + 1) * 1024) {}
+    size_t base(int64_t a, int64_t ci) const { return ((size_t)a * per_row + (size_t)ci * 1024 + 255) & ~(size_t)255; }
 };
 
-__global__ void adh_cop_out_kernel(DevOut t, DevCands c, const LibRec *__restrict__ lib, int64_t row0, int64_t n, int top_k,
-                                   const uint64_t *__restrict__ off, CopStage st) {
+__global__ void adh_cop_pack_kernel(DevOut t, DevCands c, const LibRec *__restrict__ lib, int64_t row0, int64_t n, int top_k,
+                                    const uint64_t *__restrict__ off, unsigned char *__restrict__ block,
+                                    uint64_t *__restrict__ totals) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid == 0) st.totals[0] = off[n];
+    const uint64_t tot = off[n];
+    const uint64_t R = tot >> 32, S = tot & 0xFFFFFFFFull;
+    if (tid == 0) totals[0] = tot;  // (page-locked host memory)
+    const CopBlock L(R, S);
+    uint32_t *const o_row = reinterpret_cast<uint32_t *>(block + L.row), *const o_pidx = reinterpret_cast<uint32_t *>(block + L.pidx);
+    uint8_t *const o_rank = block + L.rank;
+    float *const o_feat = reinterpret_cast<float *>(block + L.feat);
     // valid rows: ids + the feature row, transposed (consecutive lanes = consecutive output rows of one column)
     for (int64_t i = tid; i < n; i += stride) {
         const uint64_t o = off[i], o1 = off[i + 1];
         if ((o1 >> 32) == (o >> 32)) continue;
         const int64_t j = (int64_t)(o >> 32), r = row0 + i;
-        st.row[j] = (uint32_t)r;
-        st.pidx[j] = c.precursor_idx[r];
-        st.rank[j] = c.rank[r];
+        o_row[j] = (uint32_t)r;
+        o_pidx[j] = c.precursor_idx[r];
+        o_rank[j] = c.rank[r];
         const float *f = t.features + r * ADH_NUM_FEATURES;
 #pragma unroll
-        for (int k = 0; k < ADH_NUM_FEATURES; ++k) st.feat[(int64_t)k * n + j] = f[k];
+        for (int k = 0; k < ADH_NUM_FEATURES; ++k) o_feat[(size_t)k * R + (size_t)j] = f[k];
     }
     // filled slots
+    uint32_t *const s_row = reinterpret_cast<uint32_t *>(block + L.s_row), *const s_pidx = reinterpret_cast<uint32_t *>(block + L.s_pidx);
+    uint8_t *const s_rank = block + L.s_rank;
     const int64_t n_slots = n * (int64_t)top_k;
     for (int64_t id = tid; id < n_slots; id += stride) {
         const int64_t i = id / top_k;
@@ -971,28 +981,29 @@ __global__ void adh_cop_out_kernel(DevOut t, DevCands c, const LibRec *__restric
         const int64_t r = row0 + i, src = r * (int64_t)top_k + s;
         const size_t dst = (size_t)a + (size_t)s;
         const LibRec l = lib[c.frag_start[r] + t.fragment_lib_slot[src] - 1];
-        st.s_row[dst] = (uint32_t)r;
-        st.s_pidx[dst] = c.precursor_idx[r];
-        st.s_rank[dst] = c.rank[r];
-        st.s_f[0][dst] = l.mz_library;
-        st.s_f[1][dst] = l.mz;
-        st.s_f[2][dst] = t.fragment_mz_observed[src];
-        st.s_f[3][dst] = t.fragment_height[src];
-        st.s_f[4][dst] = t.fragment_intensity[src];
-        st.s_f[5][dst] = t.fragment_mass_error[src];
-        st.s_f[6][dst] = t.fragment_correlation[src];
-        st.s_b[0][dst] = l.position;
-        st.s_b[1][dst] = l.number;
-        st.s_b[2][dst] = l.type;
-        st.s_b[3][dst] = l.charge;
-        st.s_b[4][dst] = l.loss_type;
+        s_row[dst] = (uint32_t)r;
+        s_pidx[dst] = c.precursor_idx[r];
+        s_rank[dst] = c.rank[r];
+        reinterpret_cast<float *>(block + L.s_f[0])[dst] = l.mz_library;
+        reinterpret_cast<float *>(block + L.s_f[1])[dst] = l.mz;
+        reinterpret_cast<float *>(block + L.s_f[2])[dst] = t.fragment_mz_observed[src];
+        reinterpret_cast<float *>(block + L.s_f[3])[dst] = t.fragment_height[src];
+        reinterpret_cast<float *>(block + L.s_f[4])[dst] = t.fragment_intensity[src];
+        reinterpret_cast<float *>(block + L.s_f[5])[dst] = t.fragment_mass_error[src];
+        reinterpret_cast<float *>(block + L.s_f[6])[dst] = t.fragment_correlation[src];
+        (block + L.s_b[0])[dst] = l.position;
+        (block + L.s_b[1])[dst] = l.number;
+        (block + L.s_b[2])[dst] = l.type;
+        (block + L.s_b[3])[dst] = l.charge;
+        (block + L.s_b[4])[dst] = l.loss_type;
     }
 }
 
 namespace {
-// stripe w of T of a finished chunk: staging -> the caller's arrays (rows at base_r, slots at base_s)
-void cop_copy_stripe(const unsigned char *stage, const CopLayout &lay, int64_t a, int64_t rows_chunk, int top_k, int64_t cnt_r,
-                     int64_t cnt_s, int64_t base_r, int64_t base_s, adh_compact_output_t *out, int w, int T) {
+// stripe w of T of a finished block (page-locked host copy) -> the caller's arrays (rows at base_r, slots at base_s)
+void cop_copy_stripe(const unsigned char *block, int64_t cnt_r, int64_t cnt_s, int64_t base_r, int64_t base_s,
+                     adh_compact_output_t *out, int w, int T) {
+    const CopBlock L((uint64_t)cnt_r, (uint64_t)cnt_s);
     auto part = [&](int64_t cnt, int64_t &lo, int64_t &hi) {
         lo = cnt * w / T;
         hi = cnt * (w + 1) / T;
@@ -1000,26 +1011,26 @@ void cop_copy_stripe(const unsigned char *stage, const CopLayout &lay, int64_t a
     int64_t lo, hi;
     part(cnt_r, lo, hi);
     if (hi > lo) {
-        memcpy(out->row + base_r + lo, stage + lay.row + (size_t)(a + lo) * 4, (size_t)(hi - lo) * 4);
-        memcpy(out->precursor_idx + base_r + lo, stage + lay.pidx + (size_t)(a + lo) * 4, (size_t)(hi - lo) * 4);
-        memcpy(out->rank + base_r + lo, stage + lay.rank + (size_t)(a + lo), (size_t)(hi - lo));
-        const float *fb = reinterpret_cast<const float *>(stage + lay.feat) + (size_t)a * ADH_NUM_FEATURES;
+        memcpy(out->row + base_r + lo, block + L.row + (size_t)lo * 4, (size_t)(hi - lo) * 4);
+        memcpy(out->precursor_idx + base_r + lo, block + L.pidx + (size_t)lo * 4, (size_t)(hi - lo) * 4);
+        memcpy(out->rank + base_r + lo, block + L.rank + (size_t)lo, (size_t)(hi - lo));
+        const float *fb = reinterpret_cast<const float *>(block + L.feat);
         for (int k = 0; k < ADH_NUM_FEATURES; ++k)
             memcpy(out->features + (size_t)k * (size_t)out->rows_capacity + (size_t)(base_r + lo),
-                   fb + (size_t)k * (size_t)rows_chunk + (size_t)lo, (size_t)(hi - lo) * 4);
+                   fb + (size_t)k * (size_t)cnt_r + (size_t)lo, (size_t)(hi - lo) * 4);
     }
     part(cnt_s, lo, hi);
     if (hi > lo) {
-        const size_t e0 = (size_t)a * (size_t)top_k + (size_t)lo, m = (size_t)(hi - lo);
-        memcpy(out->fragment_row + base_s + lo, stage + lay.s_row + e0 * 4, m * 4);
-        memcpy(out->fragment_precursor_idx + base_s + lo, stage + lay.s_pidx + e0 * 4, m * 4);
-        memcpy(out->fragment_rank + base_s + lo, stage + lay.s_rank + e0, m);
+        const size_t m = (size_t)(hi - lo);
+        memcpy(out->fragment_row + base_s + lo, block + L.s_row + (size_t)lo * 4, m * 4);
+        memcpy(out->fragment_precursor_idx + base_s + lo, block + L.s_pidx + (size_t)lo * 4, m * 4);
+        memcpy(out->fragment_rank + base_s + lo, block + L.s_rank + (size_t)lo, m);
         float *const fcol[7] = {out->fragment_mz_library, out->fragment_mz, out->fragment_mz_observed, out->fragment_height,
                                 out->fragment_intensity, out->fragment_mass_error, out->fragment_correlation};
-        for (int j = 0; j < 7; ++j) memcpy(fcol[j] + base_s + lo, stage + lay.s_f[j] + e0 * 4, m * 4);
+        for (int j = 0; j < 7; ++j) memcpy(fcol[j] + base_s + lo, block + L.s_f[j] + (size_t)lo * 4, m * 4);
         uint8_t *const bcol[5] = {out->fragment_position, out->fragment_number, out->fragment_type, out->fragment_charge,
                                   out->fragment_loss_type};
-        for (int j = 0; j < 5; ++j) memcpy(bcol[j] + base_s + lo, stage + lay.s_b[j] + e0, m);
+        for (int j = 0; j < 5; ++j) memcpy(bcol[j] + base_s + lo, block + L.s_b[j] + (size_t)lo, m);
     }
 }
 }  // namespace
@@ -1503,8 +1514,105 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
             HIP_TRY(hipHostMalloc(&h->cop_stage, cop_lay.total + cop_lay.total / 8, hipHostMallocDefault));
             h->cop_stage_bytes = cop_lay.total + cop_lay.total / 8;
         }
+        if (n_chunks > 4096) return fail(ADH_ERR_UNSUPPORTED, "compact output: more than 4096 chunks");
+        if (!h->cop_tot_pinned) HIP_TRY(hipHostMalloc((void **)&h->cop_tot_pinned, 4096 * 8, hipHostMallocDefault));
+        if (h->cop_dev_bytes < cop_lay.total) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->cop_dev) (void)hipFree(h->cop_dev);
+            h->cop_dev = nullptr, h->cop_dev_bytes = 0;
+            const size_t want = cop_lay.total + cop_lay.total / 8 + 4096;
+            HIP_TRY(hipMalloc(&h->cop_dev, want));
+            h->cop_dev_bytes = want;
+        }
     }
     unsigned char *const cop_stage = static_cast<unsigned char *>(h->cop_stage);
+    unsigned char *const cop_dev = static_cast<unsigned char *>(h->cop_dev);
+    std::vector<hipEvent_t> cop_tot_ready;   // per chunk: its totals are on the host (events return with aux_events)
+    std::vector<uint64_t> &cop_tot_host = h->cop_tot_host;
+    if (cop) cop_tot_host.assign((size_t)n_chunks, 0);
+    // the block of chunk ci: wait for its totals (its kernels are done then), ONE copy of the used bytes
+    auto flush_cop = [&](int64_t ci) -> int {
+        HIP_TRY(hipEventSynchronize(cop_tot_ready[(size_t)ci]));
+        const uint64_t tot = h->cop_tot_pinned[ci];
+        cop_tot_host[(size_t)ci] = tot;
+        const CopBlock L(tot >> 32, tot & 0xFFFFFFFFull);
+        const size_t base = cop_lay.base(cut[(size_t)ci], ci);
+        if (L.total > 0) HIP_TRY(hipMemcpyAsync(cop_stage + base, cop_dev + base, L.total, hipMemcpyDeviceToHost, so));
+        h->d2h_bytes += L.total + 8;
+        hipEvent_t ev = nullptr;
+        int rc_e = get_event(h, &ev);
+        if (rc_e != ADH_OK) return rc_e;
+        HIP_TRY(hipEventRecord(ev, so));
+        chunk_done.push_back(ev);
+        return ADH_OK;
+    };
+    // host threads unpack finished blocks into the caller's arrays WHILE the later chunks are enqueued and scored (the
+    // enqueue loop waits for every chunk's totals, so it takes as long as the kernels: with the team started behind it
+    // the unpacking - 2 ms per 450 000-row block - came on top: 32 ms per 3 M candidates).  The calling thread
+    // publishes blocks as their copies complete (cop_publish), thread w takes stripe w of T of every block.
+    std::vector<int64_t> cop_base_r((size_t)n_chunks + 1, 0), cop_base_s((size_t)n_chunks + 1, 0);
+    bool cop_overflow = false;
+    int64_t cop_published = 0;
+    const int cop_T = cop ? host_threads_for(n) : 0;
+    int cop_started = 0;
+    struct CopTeam {  // (declared behind what its threads read: it is destroyed - joined - first)
+        std::vector<std::thread> threads;
+        std::atomic<int64_t> ready{0};
+        std::atomic<bool> abort{false};
+        void join_all() {
+            for (std::thread &t : threads)
+                if (t.joinable()) t.join();
+        }
+        ~CopTeam() {  // (an early return: whoever still waits for a block gives up)
+            abort.store(true);
+            join_all();
+        }
+    } cop_team;
+    auto cop_stripe = [&](int64_t ci, int w) {
+        cop_copy_stripe(cop_stage + cop_lay.base(cut[(size_t)ci], ci), cop_base_r[(size_t)ci + 1] - cop_base_r[(size_t)ci],
+                        cop_base_s[(size_t)ci + 1] - cop_base_s[(size_t)ci], cop_base_r[(size_t)ci], cop_base_s[(size_t)ci], cop, w,
+                        cop_T);
+    };
+    auto cop_worker = [&](int w) {
+        for (int64_t ci = 0; ci < n_chunks; ++ci) {
+            while (cop_team.ready.load(std::memory_order_acquire) <= ci) {
+                if (cop_team.abort.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            cop_stripe(ci, w);
+        }
+    };
+    for (int w = 0; w < cop_T; ++w) {
+        try {
+            cop_team.threads.emplace_back(cop_worker, w);
+            ++cop_started;
+        } catch (const std::system_error &) {
+            break;
+        }
+    }
+    auto cop_publish = [&](bool wait) -> hipError_t {
+        while (cop_published < (int64_t)chunk_done.size()) {
+            const int64_t ci = cop_published;
+            const hipError_t q = wait ? hipEventSynchronize(chunk_done[(size_t)ci]) : hipEventQuery(chunk_done[(size_t)ci]);
+            if (q == hipErrorNotReady) return hipSuccess;
+            if (q != hipSuccess) return q;
+            const uint64_t tot = cop_tot_host[(size_t)ci];
+            cop_base_r[(size_t)ci + 1] = cop_base_r[(size_t)ci] + (int64_t)(tot >> 32);
+            cop_base_s[(size_t)ci + 1] = cop_base_s[(size_t)ci] + (int64_t)(tot & 0xFFFFFFFFull);
+            if (cop_base_r[(size_t)ci + 1] > cop->rows_capacity || cop_base_s[(size_t)ci + 1] > cop->slots_capacity)
+                cop_overflow = true;
+            if (cop_overflow) {  // count on (the caller learns what it needs), copy nothing more
+                cop_base_r[(size_t)ci] = cop_base_r[(size_t)ci + 1];
+                cop_base_s[(size_t)ci] = cop_base_s[(size_t)ci + 1];
+            }
+            if (timing)
+                fprintf(stderr, "[adh]   compact chunk %lld: %lld rows, %lld slots on the host %.2f ms after the call began\n",
+                        (long long)ci, (long long)(tot >> 32), (long long)(tot & 0xFFFFFFFFull), now() - t_0);
+            cop_team.ready.store(ci + 1, std::memory_order_release);
+            ++cop_published;
+        }
+        return hipSuccess;
+    };
     unsigned char *const cmp_dev = static_cast<unsigned char *>(h->cmp_dev), *const cmp_host = static_cast<unsigned char *>(h->cmp_host);
     const double t_1 = now();
     const bool dbg_events = timing && atoi(getenv("ADH_DEBUG_TIMING")) >= 2;  // per-chunk D2H spans
@@ -1558,6 +1666,7 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
     for (int64_t ci = 0; ci < n_chunks; ++ci) {
         const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
         const int ps = (int)(ci & 1);
+        if (cop && cop_publish(false) != hipSuccess) return fail_sync(fail(ADH_ERR_HIP, "scoring pipeline (compact copy-out)"));
         if (ci + 1 < n_chunks) {
             // plan of the next chunk: the other plan slot is free once the kernels of chunk ci - 1 are done
             const int64_t a2 = b, b2 = cut[(size_t)ci + 2];
@@ -1591,8 +1700,21 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
                                dev.fragment_lib_slot, a, nr, top_k, cop_off);
             size_t scan_bytes = h->cop_scan_bytes;
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cop_scan, scan_bytes, cop_off, cop_off, (int)(nr + 1), sk));
+            hipLaunchKernelGGL(adh_cop_pack_kernel, dim3((unsigned)std::min<int64_t>((nr * top_k + 255) / 256, 8192)), dim3(256), 0,
+                               sk, dev, h->cs.d, h->d_lib, a, nr, top_k, cop_off, cop_dev + cop_lay.base(a, ci), h->cop_tot_pinned + ci);
+            HIP_TRY(hipGetLastError());
+            hipEvent_t ev = nullptr;  // (when the totals can be read)
+            rc = get_event(h, &ev);
+            if (rc != ADH_OK) return fail_sync(rc);
+            HIP_TRY(hipEventRecord(ev, sk));
+            aux_events.push_back(ev);
+            cop_tot_ready.push_back(ev);
         }
         HIP_TRY(hipEventRecord(h->ev_k[ps], sk));
+        if (cop && ci > 0) {  // the block of the previous chunk, now that the host can know its size
+            rc = flush_cop(ci - 1);
+            if (rc != ADH_OK) return fail_sync(rc);
+        }
         if (compact && ci > 0) {  // the packed columns of the previous chunk, now that the host can know their length
             rc = flush_compact(ci - 1);
             if (rc != ADH_OK) return fail_sync(rc);
@@ -1620,35 +1742,6 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
         // (A chunk is up to nine copies and the engine idles ~10 us between two of them - a 47 000-row chunk, 21 MB, takes
         // 0.46 ms = 46 GB/s where each copy runs at 55, `rocprofv3 --memory-copy-trace` - but a second copy-out stream for
         // the feature table does not fill the gaps: measured in round 5, same times to the 0.01 ms, and taken out again.)
-        if (cop) {
-            const int64_t nr = b - a;
-            CopStage stg;
-            stg.totals = reinterpret_cast<uint64_t *>(cop_stage + cop_lay.hdr) + ci;
-            stg.row = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.row) + a;
-            stg.pidx = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.pidx) + a;
-            stg.rank = cop_stage + cop_lay.rank + a;
-            stg.feat = reinterpret_cast<float *>(cop_stage + cop_lay.feat) + (size_t)a * ADH_NUM_FEATURES;
-            const size_t e0 = (size_t)a * (size_t)top_k;
-            stg.s_row = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.s_row) + e0;
-            stg.s_pidx = reinterpret_cast<uint32_t *>(cop_stage + cop_lay.s_pidx) + e0;
-            stg.s_rank = cop_stage + cop_lay.s_rank + e0;
-            for (int j = 0; j < 7; ++j) stg.s_f[j] = reinterpret_cast<float *>(cop_stage + cop_lay.s_f[j]) + e0;
-            for (int j = 0; j < 5; ++j) stg.s_b[j] = cop_stage + cop_lay.s_b[j] + e0;
-            // 32 workgroups: enough stores in flight for the link (kcopy_probe: the transposing write reaches 50.7 GB/s
-            // from 32, 51.9 from 64), and the scoring kernels of the next chunks run beside them: a compute unit whose
-            // memory pipeline is backed up with PCIe stores stalls the loads of every wavefront on it - kernels of a
-            // 3 M-row step 14.5 ms alone, 16.8 beside 32 workgroups, 23.5 beside 64, 27.2 beside 128, 30.6 beside 256
-            int blocks = 32;
-            if (const char *env = getenv("ADH_COPY_OUT_BLOCKS")) blocks = std::max(atoi(env), 1);
-            hipLaunchKernelGGL(adh_cop_out_kernel, dim3((unsigned)blocks), dim3(256), 0, so, dev, h->cs.d, h->d_lib, a, nr, top_k,
-                               cop_off, stg);
-            HIP_TRY(hipGetLastError());
-            hipEvent_t ev = nullptr;
-            rc = get_event(h, &ev);
-            if (rc != ADH_OK) return fail_sync(rc);
-            HIP_TRY(hipEventRecord(ev, so));
-            chunk_done.push_back(ev);
-        }
         for (int i = 0; i < kNumOutFields && !cop; ++i) {
             const OutFieldDesc &f = kOutFields[i];
             void *host = *out_member(out, f);
@@ -1684,68 +1777,27 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
         rc = flush_compact(n_chunks - 1);
         if (rc != ADH_OK) return fail_sync(rc);
     }
+    if (cop) {
+        rc = flush_cop(n_chunks - 1);
+        if (rc != ADH_OK) return fail_sync(rc);
+    }
     const double t_2 = now();
     rc = comm_gather_slot(h, slot);  // after the last chunk's kernels; overlaps the remaining D2H
     if (rc != ADH_OK) return fail_sync(rc);
     if (cop) {
-        // host threads follow the copy-out kernels chunk by chunk: totals -> where the chunk goes in the caller's arrays
-        // -> every thread its stripe of every column (plain memcpy from page-locked staging into the caller's memory)
-        const int T = host_threads_for(n);
-        std::vector<int64_t> base_r((size_t)n_chunks + 1, 0), base_s((size_t)n_chunks + 1, 0);
-        std::atomic<int64_t> ready{0};
-        std::atomic<bool> abort{false};
-        const uint64_t *totals = reinterpret_cast<const uint64_t *>(cop_stage + cop_lay.hdr);
-        auto stripe = [&](int64_t ci, int w) {
-            const int64_t a = cut[(size_t)ci], b = cut[(size_t)ci + 1];
-            cop_copy_stripe(cop_stage, cop_lay, a, b - a, top_k, base_r[(size_t)ci + 1] - base_r[(size_t)ci],
-                            base_s[(size_t)ci + 1] - base_s[(size_t)ci], base_r[(size_t)ci], base_s[(size_t)ci], cop, w, T);
-        };
-        auto worker = [&](int w) {
-            for (int64_t ci = 0; ci < n_chunks; ++ci) {
-                while (ready.load(std::memory_order_acquire) <= ci) {
-                    if (abort.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                stripe(ci, w);
-            }
-        };
-        std::vector<std::thread> team;
-        for (int w = 1; w < T; ++w) {
-            try {
-                team.emplace_back(worker, w);
-            } catch (const std::system_error &) {
-                break;
-            }
-        }
-        const int started = (int)team.size() + 1;
-        hipError_t ee = hipSuccess;
-        bool overflow = false;
-        for (int64_t ci = 0; ci < n_chunks && ee == hipSuccess; ++ci) {
-            ee = hipEventSynchronize(chunk_done[(size_t)ci]);
-            if (ee != hipSuccess) break;
-            const uint64_t tot = totals[ci];
-            base_r[(size_t)ci + 1] = base_r[(size_t)ci] + (int64_t)(tot >> 32);
-            base_s[(size_t)ci + 1] = base_s[(size_t)ci] + (int64_t)(tot & 0xFFFFFFFFull);
-            if (base_r[(size_t)ci + 1] > cop->rows_capacity || base_s[(size_t)ci + 1] > cop->slots_capacity) overflow = true;
-            if (overflow) {  // count on (the caller learns what it needs), copy nothing more
-                base_r[(size_t)ci] = base_r[(size_t)ci + 1];
-                base_s[(size_t)ci] = base_s[(size_t)ci + 1];
-            }
-            ready.store(ci + 1, std::memory_order_release);
-            if (overflow) continue;
-            stripe(ci, 0);
-            for (int w = started; w < T; ++w) stripe(ci, w);
-        }
-        if (ee != hipSuccess) abort.store(true);
-        for (std::thread &t : team) t.join();
+        // the blocks still on their way, then the threads (they have been unpacking since the first block landed)
+        hipError_t ee = cop_publish(true);
+        if (ee == hipSuccess) cop_team.join_all();
         if (ee != hipSuccess) {
             fail(ADH_ERR_HIP, std::string("scoring pipeline (compact copy-out): ") + hipGetErrorString(ee));
             return fail_sync(ADH_ERR_HIP);
         }
-        cop->n_rows = base_r[(size_t)n_chunks];
-        cop->n_slots = base_s[(size_t)n_chunks];
-        h->d2h_bytes += (uint64_t)cop->n_rows * (9 + 4 * ADH_NUM_FEATURES) + (uint64_t)cop->n_slots * 42;
-        if (overflow) {
+        for (int64_t ci = 0; ci < n_chunks; ++ci)  // (stripes of threads that could not be started)
+            for (int w = cop_started; w < cop_T; ++w) cop_stripe(ci, w);
+        if (timing) fprintf(stderr, "[adh]   compact: host team done %.2f ms after the call began (%d threads)\n", now() - t_0, cop_T);
+        cop->n_rows = cop_base_r[(size_t)n_chunks];
+        cop->n_slots = cop_base_s[(size_t)n_chunks];
+        if (cop_overflow) {
             (void)hipStreamSynchronize(sk);
             (void)hipStreamSynchronize(so);
             unwind.ok = true;  // (the device tables are complete)

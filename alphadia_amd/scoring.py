@@ -677,10 +677,16 @@ def _collect_candidates_by_rows(candidates_df, psm_proto_df, precursors_flat_df,
     num_jobs = [(name, src, idx) for name, src, idx in jobs if src.dtype != object] + (counts or [])
     from . import runtime as _rt
 
-    gathered = _parallel([(lambda src=src, idx=idx: src[idx]) for _, src, idx in num_jobs])
-    cols = {name: arr for (name, _, _), arr in zip(num_jobs, gathered)}
+    # the numeric gathers run on the pool (NumPy releases the GIL inside take) while this thread gathers the object
+    # columns (which keeps the GIL, but only Python-level code needs it)
+    pool, n_pool = _host_pool()
+    tasks = [(lambda src=src, idx=idx: src[idx]) for _, src, idx in num_jobs]
+    futures = [pool.submit(t) for t in tasks] if n_pool > 1 else None
+    cols = {}
     for name, src, idx in obj_jobs:
         cols[name] = _rt.take_objects(src, idx, threads)
+    gathered = [f.result() for f in futures] if futures is not None else [t() for t in tasks]
+    cols.update({name: arr for (name, _, _), arr in zip(num_jobs, gathered)})
     frame = {name: features[j] for j, name in enumerate(DEFAULT_FEATURE_COLUMNS)}
     if compact is not None:
         frame["precursor_idx"] = compact["precursor_idx"]
