@@ -12,6 +12,8 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 #include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
@@ -55,6 +57,111 @@ int fail(int code, const std::string &msg) {
                             hipGetErrorString(_e));                                         \
         }                                                                                   \
     } while (0)
+
+// ---- large device buffers are kept, not returned (round 5).  Freeing >= 2 GB of device memory leaves the runtime's DMA
+// copies at half the link rate for the rest of the process (tools/probes/d2h_pattern.hip; round 4 cured that by
+// page-locking 2 GB of host memory once after such a free - settle_copy_path, now only with ADH_COPY_PATH_RESET=1).  The
+// trigger was the library itself: staging a run frees two 3.9 GB sort buffers, re-growing tables or scratch frees the old
+// ones.  Every hipMalloc / hipFree of this translation unit goes through adh_dev_malloc / adh_dev_free (the macros
+// below): a freed block of 256 MB or more is parked and handed to the next request it fits (size <= block <= 1.5 x
+// size) - the second staging of a run of similar size allocates nothing - up to ADH_DEV_CACHE_GB (default 48) in all;
+// adh_trim_device_cache() gives everything back.  A request that fails with the cache non-empty empties it and retries.
+struct DevBlockCache {
+    std::mutex m;
+    std::vector<std::pair<void *, size_t>> parked;
+    std::unordered_map<void *, size_t> live;  // blocks of >= kMin bytes handed out
+    size_t parked_bytes = 0;
+    static constexpr size_t kMin = (size_t)256 << 20;
+};
+DevBlockCache &dev_cache() {
+    static DevBlockCache c;
+    return c;
+}
+std::atomic<bool> g_big_free{false};  // a block of 1 GB or more did go back to the runtime
+
+size_t dev_cache_limit() {
+    static const size_t lim = [] {
+        const char *env = getenv("ADH_DEV_CACHE_GB");
+        return (size_t)(env ? std::max(atof(env), 0.0) : 48.0) << 30;
+    }();
+    return lim;
+}
+
+hipError_t adh_dev_trim() {
+    DevBlockCache &c = dev_cache();
+    std::vector<std::pair<void *, size_t>> drop;
+    {
+        std::lock_guard<std::mutex> g(c.m);
+        drop.swap(c.parked);
+        c.parked_bytes = 0;
+    }
+    hipError_t e = hipSuccess;
+    for (auto &b : drop) {
+        if (b.second >= ((size_t)1 << 30)) g_big_free.store(true);
+        const hipError_t f = hipFree(b.first);
+        if (f != hipSuccess) e = f;
+    }
+    return e;
+}
+
+hipError_t adh_dev_malloc(void **p, size_t bytes) {
+    DevBlockCache &c = dev_cache();
+    if (bytes >= DevBlockCache::kMin) {
+        std::lock_guard<std::mutex> g(c.m);
+        size_t best = SIZE_MAX, at = SIZE_MAX;
+        for (size_t i = 0; i < c.parked.size(); ++i)
+            if (c.parked[i].second >= bytes && c.parked[i].second <= bytes + bytes / 2 && c.parked[i].second < best)
+                best = c.parked[i].second, at = i;
+        if (at != SIZE_MAX) {
+            *p = c.parked[at].first;
+            c.live[*p] = best;
+            c.parked_bytes -= best;
+            c.parked.erase(c.parked.begin() + (long)at);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        bool any;
+        {
+            std::lock_guard<std::mutex> g(c.m);
+            any = !c.parked.empty();
+        }
+        if (any) {
+            (void)adh_dev_trim();
+            e = hipMalloc(p, bytes);
+        }
+    }
+    if (e == hipSuccess && bytes >= DevBlockCache::kMin) {
+        std::lock_guard<std::mutex> g(c.m);
+        c.live[*p] = bytes;
+    }
+    return e;
+}
+
+hipError_t adh_dev_free(void *p) {
+    if (!p) return hipSuccess;
+    DevBlockCache &c = dev_cache();
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(c.m);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            bytes = it->second;
+            c.live.erase(it);
+            if (c.parked_bytes + bytes <= dev_cache_limit()) {
+                c.parked.emplace_back(p, bytes);
+                c.parked_bytes += bytes;
+                return hipSuccess;
+            }
+        }
+    }
+    if (bytes >= ((size_t)1 << 30)) g_big_free.store(true);
+    return hipFree(p);
+}
+#define hipMalloc(ptr, bytes) adh_dev_malloc((void **)(ptr), (bytes))
+#define hipFree(ptr) adh_dev_free((void *)(ptr))
 
 struct DeviceBuffers {
     std::vector<void *> ptrs;
@@ -166,7 +273,7 @@ struct adh_handle {
     // freed a device buffer of 2 GB or more - the temporaries of staging a run do - until it page-locks 2 GB of host
     // memory in one piece (tools/probes/d2h_pattern.hip: BALLAST_CHURN=mf against RESTORE=HF).
     // Whatever frees large device memory sets the flag, the host -> host entry point settles it.
-    bool copy_path_dirty = false, big_staged = false;
+    bool big_staged = false;
     void *sel_slab = nullptr;       // precursor columns + candidate table of adh_select_candidates (grow-only)
     size_t sel_slab_bytes = 0;
     void *scratch_slab = nullptr;   // per-candidate scratch blocks (grow-only, shared by all chunks)
@@ -475,12 +582,11 @@ int stage_transposed(adh_handle *h, const adh_alpharaw_t *d, const DevRun &r, in
 }  // namespace
 
 namespace {
-// a staging call freed the buffers of what was staged before and its own temporaries: large ones leave the runtime's
-// copies in their slow state (adh_handle::copy_path_dirty)
+// (round 4 marked the handle here - a staging call frees its temporaries and what was staged before; they are parked
+// now: DevBlockCache above)
 void note_staged(adh_handle *h, uint64_t bytes) {
-    const bool big = bytes >= ((uint64_t)1 << 30);
-    if (big || h->big_staged) h->copy_path_dirty = true;
-    h->big_staged = big;
+    (void)h;
+    (void)bytes;
 }
 }  // namespace
 

@@ -86,7 +86,6 @@ int ensure_tables(adh_handle *h, int slot, int64_t rows, int top_k) {
     DevTables &t = h->tables[slot];
     const size_t need = layout_tables(nullptr, rows, top_k, nullptr, nullptr);
     if (t.bytes < need) {
-        if (t.bytes >= ((size_t)1 << 30)) h->copy_path_dirty = true;
         if (t.base) (void)hipFree(t.base);
         t.base = nullptr;
         t.bytes = 0;
@@ -430,15 +429,17 @@ int plan_finish(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int
 }
 
 // the scratch slab is grow-only and shared by all chunks (their kernels are serialised on one stream)
-// see adh_handle::copy_path_dirty
+// (see DevBlockCache in adh_api.hip)
 void settle_copy_path(adh_handle *h) {
-    if (!h->copy_path_dirty) return;
-    h->copy_path_dirty = false;
-    static const bool off = [] {
+    // Only on request (ADH_COPY_PATH_RESET=1) and only after a block of 1 GB or more really went back to the runtime
+    // (DevBlockCache in adh_api.hip parks them, so that needs a cache overflow or adh_trim_device_cache): page-locking
+    // 2 GB of host memory once brings the DMA copies back to the full link rate on this ROCm (tools/probes/d2h_pattern.hip)
+    (void)h;
+    static const bool on = [] {
         const char *env = getenv("ADH_COPY_PATH_RESET");
-        return env && atoi(env) == 0;
+        return env && atoi(env) != 0;
     }();
-    if (off) return;
+    if (!on || !g_big_free.exchange(false)) return;
     void *p = nullptr;
     if (hipHostMalloc(&p, (size_t)2 << 30, hipHostMallocPortable) == hipSuccess && p) (void)hipHostFree(p);
     (void)hipGetLastError();  // (no room for it: the copies stay slow, nothing else changes)
@@ -447,7 +448,6 @@ void settle_copy_path(adh_handle *h) {
 int ensure_scratch(adh_handle *h, uint64_t bytes) {
     if (h->scratch_slab_bytes >= bytes) return ADH_OK;
     HIP_TRY(hipDeviceSynchronize());
-    if (h->scratch_slab_bytes >= ((uint64_t)1 << 30)) h->copy_path_dirty = true;
     if (h->scratch_slab) (void)hipFree(h->scratch_slab);
     h->scratch_slab = nullptr;
     h->scratch_slab_bytes = 0;
@@ -1319,7 +1319,7 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
     h->last_rows = n;
     {
         const double t_s = now();
-        const bool was = h->copy_path_dirty;
+        const bool was = g_big_free.load();
         settle_copy_path(h);
         if (timing && was) fprintf(stderr, "[adh] copy path settled in %.1f ms\n", now() - t_s);
     }
@@ -2113,6 +2113,12 @@ int adh_host_alloc(void **ptr, uint64_t bytes) {
     if (!ptr) return fail(ADH_ERR_INVALID_ARGUMENT, "ptr is NULL");
     *ptr = nullptr;
     HIP_TRY(hipHostMalloc(ptr, std::max<size_t>((size_t)bytes, 64), hipHostMallocPortable));
+    return ADH_OK;
+}
+
+int adh_trim_device_cache(void) {
+    const hipError_t e = adh_dev_trim();
+    if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("adh_trim_device_cache: ") + hipGetErrorString(e));
     return ADH_OK;
 }
 

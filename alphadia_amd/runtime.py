@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "adh_score_candidates",
     "adh_score_candidates_compact",
     "adh_host_take_objects",
+    "adh_trim_device_cache",
     "adh_upload_candidates",
     "adh_score_uploaded",
     "adh_get_stream",

@@ -327,6 +327,14 @@ int adh_copy_to_host(adh_handle_t *handle, void *dst, const void *src_device, ui
 int adh_host_free(void *ptr);
 
 /*
+ * Device buffers of 256 MB and more that the library no longer needs (sort temporaries of a staging call, tables and
+ * scratch it outgrew, what a destroyed handle held) are parked and reused instead of freed - freeing gigabytes of
+ * device memory leaves the runtime's DMA copies at half the link rate for the rest of the process.  This
+ * call returns everything parked (at most ADH_DEV_CACHE_GB, default 48) to the runtime.
+ */
+int adh_trim_device_cache(void);
+
+/*
  * dst[i] = src[idx[i]] for n entries of arrays of CPython object pointers (NumPy dtype=object) - the string columns
  * the features frame takes over from the precursor table (scoring.py:430-445 merges them in) - on `threads` host
  * threads, reference counts raised atomically.  The caller must hold the GIL for the whole call (ctypes.PyDLL) and
