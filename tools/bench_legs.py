@@ -31,6 +31,14 @@ def _log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _leg_traffic(key: str):
+    """HBM bytes per pass of a leg from the committed PMC passes (profiles/legs_traffic.json, tools/profile_r5.sh)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "legs_traffic.json")))[key]["hbm_bytes_per_pass"]
+    except Exception:
+        return None
+
+
 def _cpu_threads() -> int:
     from bench import cpu_quota_cores
 
@@ -80,7 +88,7 @@ def fragcomp_leg(ctx, sizes=(100_000, 1_000_000), reps: int = 5) -> dict:
             "neighbour_pairs": int(st["pairs"]), "waiting_psms": int(st["waiting"]), "resolve_rounds": int(st["rounds"]),
             "serial_fallback": bool(st["serial"]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _leg_traffic(f"fragment_competition_{n}"),
                          "kernel": "adh_fc_edges_kernel (+ sort, ranges, resolve, final)",
                          "touched_bytes": touched,
                          "reference_rt_scan_bytes": float((sizes_w ** 2).sum() * 4)},
@@ -163,6 +171,14 @@ def multiplex_leg(ctx, n_groups: int = 75_000, n_cycles: int = 4800, steps: int 
     alg = float(algorithmic_bytes(mc.dia, soa, cfgj, matched, lib_len, usable_fragments=usable).sum())
     achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     n_prec = len(np.unique(soa["precursor_idx"]))
+    traffic = traffic_src = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "legs_traffic.json"))).get("multiplex_configs4")
+        if tr and int(tr.get("candidates", -1)) == int(n):
+            traffic, traffic_src = tr["hbm_bytes_per_pass"], {"file": "profiles/legs_traffic.json",
+                                                              "measured_at_commit": tr.get("git_head")}
+    except Exception:
+        pass
     result = {
         "workload": f"BASELINE configs[4]: {n_groups} elution groups x channels {list(mc.channels)} = {n_prec} precursors "
                     f"(one candidate each, score groups of {len(mc.channels)}, reference channel {mc.channels[0]}) vs "
@@ -174,8 +190,8 @@ def multiplex_leg(ctx, n_groups: int = 75_000, n_cycles: int = 4800, steps: int 
         "candidates": int(n), "valid_fraction": float(valid.mean()), "generation_seconds": gen_s, "stage_seconds": stage_s,
         "kernel_ms": kernel_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kernel_ms,
-                     "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel_ms": kernel_ms, "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
                      "algorithmic_bytes_per_candidate": alg / max(n, 1)},
     }
     # CPU oracle on a bounded sample (whole score groups)
@@ -320,7 +336,8 @@ if __name__ == "__main__":
 
         ctx = runtime.get_context(0)
         if which == "fragcomp":
-            print(json.dumps(fragcomp_leg(ctx)))
+            sizes = tuple(int(x) for x in os.environ.get("FC_SIZES", "100000,1000000").split(","))
+            print(json.dumps(fragcomp_leg(ctx, sizes=sizes)))
         elif which == "multiplex":
             print(json.dumps(multiplex_leg(ctx, n_groups=int(os.environ.get("N_GROUPS", 75000)),
                                            n_cycles=int(os.environ.get("N_CYCLES", 4800)))))

@@ -47,6 +47,62 @@ res = {
     "precursors_per_s_kernel": n_prec / (k_ms * 1e-3),
     "host_call_ms": wall * 1e3,
 }
+
+
+def touched_bytes(sample_rows):
+    """What candidate selection has to look at for a precursor, exact on a sample: the peaks inside its 12 fragment and
+    top_k_precursors isotope windows in every cycle of its rt tolerance (8 B each: m/z + intensity) with the two
+    spectrum-index words of every (window, cycle), its dense score tile written and read once by the smoothing pass
+    (4 B per (window, cycle) cell, twice), the library slice (32 B per fragment), the precursor record and the
+    candidate rows it returns."""
+    dia = case.dia
+    L = dia.cycle.shape[1]
+    rt_cycle = dia.rt_values[::L]
+    lo_edge, hi_edge = dia.cycle[0, :, 0, 0], dia.cycle[0, :, 0, 1]
+    fdf = case.library.fragment_df
+    fmz = fdf["mz_library"].values
+    out = np.zeros(len(sample_rows), dtype=np.int64)
+    n_iso = int(cfg.top_k_precursors)
+    for j, i in enumerate(sample_rows):
+        rt = float(pdf.rt_library.values[i])
+        c0 = int(np.searchsorted(rt_cycle, rt - cfg.rt_tolerance))
+        c1 = int(np.searchsorted(rt_cycle, rt + cfg.rt_tolerance))
+        pmz, ch = float(pdf.mz_library.values[i]), float(pdf.charge.values[i])
+        row = int(np.flatnonzero((lo_edge <= pmz) & (pmz < hi_edge))[0]) if ((lo_edge <= pmz) & (pmz < hi_edge)).any() else 1
+        a, b = int(pdf.flat_frag_start_idx.values[i]), int(pdf.flat_frag_stop_idx.values[i])
+        wins = [(row, m, cfg.fragment_mz_tolerance) for m in fmz[a:b]]
+        wins += [(0, pmz + k * 1.0033548350700006 / ch, cfg.precursor_mz_tolerance) for k in range(n_iso)]
+        nbytes = 64 + 32 * (b - a) + 3 * 60
+        for r, m, tol in wins:
+            lo, hi = np.float32(m * (1 - tol * 1e-6)), np.float32(m * (1 + tol * 1e-6))
+            for c in range(c0, c1):
+                sp = c * L + r
+                ps, pe = int(dia.peak_start_idx_list[sp]), int(dia.peak_stop_idx_list[sp])
+                mz = dia.mz_values[ps:pe]
+                nbytes += 16 + 8 * int(np.searchsorted(mz, hi, side="right") - np.searchsorted(mz, lo, side="left"))
+            nbytes += 2 * 4 * (c1 - c0)
+        out[j] = nbytes
+    return out
+
+
+rows_s = np.linspace(0, n_prec - 1, int(os.environ.get("TOUCHED_SAMPLE", 150))).astype(np.int64)
+touched = float(touched_bytes(rows_s).mean()) * n_prec
+res["roofline"] = {"bound": "hbm", "achieved": touched / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                   "frac": touched / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel_ms": k_ms,
+                   "kernel": "adh_select_kernel (+ limits, plan)",
+                   "touched_bytes_per_precursor": touched / n_prec,
+                   "yardstick": "peaks inside the fragment / isotope windows over the rt tolerance x 8 B + index words + the "
+                                "score tile written and read once + library slice + outputs; exact on a sample of "
+                                f"{len(rows_s)} precursors"}
+tfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "legs_traffic.json")
+if os.path.exists(tfile):
+    try:
+        tr = json.load(open(tfile)).get("candidate_selection")
+        if tr:
+            res["roofline"]["traffic"] = tr["hbm_bytes_per_pass"]
+            res["roofline"]["traffic_source"] = {"file": "profiles/legs_traffic.json", "measured_at_commit": tr.get("git_head")}
+    except Exception:
+        pass
 if not os.environ.get("ADH_BENCH_NO_CPU"):
     from oracle import oracle
 

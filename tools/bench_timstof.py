@@ -226,6 +226,53 @@ if not os.environ.get("ADH_BENCH_NO_SELECT"):
         "tile_scans": int(np.median((got["scan_stop"] - got["scan_start"])[found])) if found.any() else 0,
         "kernel_ms": k_ms, "precursors_per_s_kernel": len(pdf) / (k_ms * 1e-3), "host_call_ms": wall * 1e3,
     }
+
+    def selection_touched(sample_rows):
+        """Per precursor: the events of every (window, TOF bin) inside the frames of its rt tolerance and the scans of
+        its mobility tolerance x 6 B (push + intensity), per (window, bin) the two index words + tof_indptr + m/z, two
+        m/z look-ups per window, the library slice, the precursor record and the candidate rows."""
+        push = dia.push_indices
+        L = int(dia.cycle.shape[1])
+        rt_frames = dia.rt_values
+        mob = dia.mobility_values
+        out = np.zeros(len(sample_rows), dtype=np.int64)
+        for j, i in enumerate(sample_rows):
+            rt, im = float(pdf.rt_library.values[i]), float(pdf.mobility_library.values[i])
+            f0 = int(np.searchsorted(rt_frames, rt - scfg.rt_tolerance))
+            f1 = int(np.searchsorted(rt_frames, rt + scfg.rt_tolerance))
+            sc = np.flatnonzero(np.abs(mob - im) <= scfg.mobility_tolerance)
+            s0, s1 = (int(sc.min()), int(sc.max()) + 1) if len(sc) else (0, 1)
+            a, b = int(pdf.flat_frag_start_idx.values[i]), int(pdf.flat_frag_stop_idx.values[i])
+            mzs = [(float(m), float(scfg.fragment_mz_tolerance)) for m in fmz[a:b]]
+            mzs += [(float(pdf.mz_library.values[i]) + k * 1.0033548350700006 / float(pdf.charge.values[i]),
+                     float(scfg.precursor_mz_tolerance)) for k in range(int(scfg.top_k_precursors))]
+            nb = 128 + 32 * (b - a) + 3 * 60
+            p_lo, p_hi = np.uint32(f0 * S_max), np.uint32(f1 * S_max)
+            for m, t in mzs:
+                lo = np.searchsorted(mzv, m * (1 - t * 1e-6))
+                hi = np.searchsorted(mzv, m * (1 + t * 1e-6))
+                nb += 8 + (hi - lo) * 24
+                for tof in range(lo, hi):
+                    a0, a1 = indptr[tof], indptr[tof + 1]
+                    e0 = a0 + np.searchsorted(push[a0:a1], p_lo)
+                    e1 = a0 + np.searchsorted(push[a0:a1], p_hi)
+                    if e1 > e0:
+                        scan = push[e0:e1] % np.uint32(S_max)
+                        nb += 6 * int(((scan >= s0) & (scan < s1)).sum())
+            out[j] = nb
+        return out
+
+    try:
+        rows_sel = np.linspace(0, len(pdf) - 1, int(os.environ.get("TOUCHED_SAMPLE_SEL", 60))).astype(np.int64)
+        t_sel = float(selection_touched(rows_sel).mean()) * len(pdf)
+        sel["roofline"] = {"bound": "hbm", "achieved": t_sel / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": t_sel / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel_ms": k_ms,
+                           "kernel": "adh_select_gather_im_kernel + adh_select_smooth_im_kernel (+ limits, plan)",
+                           "touched_bytes_per_precursor": t_sel / len(pdf),
+                           "yardstick": "events inside the windows' TOF bins, the rt tolerance and the mobility tolerance x 6 B "
+                                        f"+ index words + library slice + outputs; exact on a sample of {len(rows_sel)} precursors"}
+    except Exception as exc:  # the yardstick must not take the leg down
+        sel["roofline"] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
     if not os.environ.get("ADH_BENCH_NO_CPU"):
         from oracle import oracle
 
