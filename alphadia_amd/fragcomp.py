@@ -23,7 +23,11 @@ logger = logging.getLogger(__name__)
 
 def candidate_hash(precursor_idx: np.ndarray, rank: np.ndarray) -> np.ndarray:
     """The reference's candidate key (fragcomp/utils.py:48-58): rank << 32 | precursor_idx."""
-    return (np.asarray(rank).astype(np.uint64) << np.uint64(32)) | np.asarray(precursor_idx).astype(np.uint64)
+    key = np.asarray(precursor_idx).astype(np.uint64)
+    rank = np.asarray(rank)
+    if rank.size and rank.any():  # (a table of first-ranked candidates only: the key is the precursor index)
+        key |= rank.astype(np.uint64) << np.uint64(32)
+    return key
 
 
 @dataclass
@@ -54,17 +58,31 @@ def competition_plan(precursor_idx, rank, mz_observed, proba, frag_precursor_idx
     key = candidate_hash(precursor_idx, rank)
     fkey = candidate_hash(frag_precursor_idx, frag_rank)
     n_frag = fkey.shape[0]
-    # first / last fragment row of every distinct key
-    by_key = np.argsort(fkey, kind="stable")
-    sorted_keys = fkey[by_key]
-    is_first = np.ones(n_frag, dtype=bool)
-    is_first[1:] = sorted_keys[1:] != sorted_keys[:-1]
-    group_first = np.flatnonzero(is_first)
-    uniq = sorted_keys[group_first]
-    # stable sort: inside a group the rows appear in table order -> first is the minimum, last the maximum
-    group_last = np.append(group_first[1:], n_frag) - 1
-    lo = by_key[group_first] if n_frag else np.zeros(0, np.int64)
-    hi = by_key[group_last] + 1 if n_frag else np.zeros(0, np.int64)
+    # first / last fragment row of every distinct key.  The fragment table of collect_fragments holds a candidate's
+    # rows next to each other: then the runs of equal keys ARE the groups, and only their first keys (one per
+    # candidate, a twelfth of the rows) have to be sorted - checked, not assumed: a key that starts two runs sends the
+    # table down the general path (a stable sort of all rows)
+    lo = hi = uniq = None
+    if n_frag:
+        starts = np.flatnonzero(np.concatenate(([True], fkey[1:] != fkey[:-1])))
+        run_keys = fkey[starts]
+        by_run = np.argsort(run_keys, kind="stable")
+        sorted_runs = run_keys[by_run]
+        if len(sorted_runs) < 2 or (sorted_runs[1:] != sorted_runs[:-1]).all():
+            uniq = sorted_runs
+            lo = starts[by_run]
+            hi = np.append(starts[1:], n_frag)[by_run]
+    if uniq is None:
+        by_key = np.argsort(fkey, kind="stable")
+        sorted_keys = fkey[by_key]
+        is_first = np.ones(n_frag, dtype=bool)
+        is_first[1:] = sorted_keys[1:] != sorted_keys[:-1]
+        group_first = np.flatnonzero(is_first)
+        uniq = sorted_keys[group_first]
+        # stable sort: inside a group the rows appear in table order -> first is the minimum, last the maximum
+        group_last = np.append(group_first[1:], n_frag) - 1
+        lo = by_key[group_first] if n_frag else np.zeros(0, np.int64)
+        hi = by_key[group_last] + 1 if n_frag else np.zeros(0, np.int64)
     at = np.searchsorted(uniq, key)
     at_c = np.minimum(at, max(len(uniq) - 1, 0))
     has = (uniq[at_c] == key) if len(uniq) else np.zeros(len(key), dtype=bool)
@@ -81,7 +99,14 @@ def competition_plan(precursor_idx, rank, mz_observed, proba, frag_precursor_idx
         window[inside] = w
         unassigned &= ~inside
 
-    order = np.lexsort((np.asarray(precursor_idx)[rows], np.asarray(proba)[rows], window))
+    # (window, proba) as ONE 64-bit key where the probabilities are non-negative float32 (their bit patterns order like
+    # the values): two sort keys instead of three
+    pr = np.asarray(proba)[rows]
+    if pr.dtype == np.float32 and len(pr) and not (pr < 0).any() and not np.isnan(pr).any():
+        k64 = (window.astype(np.uint64) << np.uint64(32)) | (pr + np.float32(0.0)).view(np.uint32).astype(np.uint64)
+        order = np.lexsort((np.asarray(precursor_idx)[rows], k64))
+    else:
+        order = np.lexsort((np.asarray(precursor_idx)[rows], pr, window))
     rows = rows[order]
     window = window[order]
     occupied, first = np.unique(window, return_index=True)

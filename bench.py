@@ -581,6 +581,8 @@ def main():
             ("fragment_competition", lambda: bench_legs.fragcomp_leg(ctx)),
             ("multiplex_configs4", lambda: bench_legs.multiplex_leg(ctx, threads=os.cpu_count() or 8,
                                                                     cpu_seconds=min(args.cpu_seconds, 6.0))),
+            ("transfer_requant", lambda: bench_legs.transfer_requant_leg(ctx, threads=os.cpu_count() or 8,
+                                                                         cpu_seconds=min(args.cpu_seconds, 4.0))),
             ("ion_mobility_configs3", lambda: bench_legs.timstof_leg(full_size=True)),
             ("candidate_selection", lambda: bench_legs.selection_leg()),
             ("fdr_stage", lambda: bench_legs.fdr_leg()),

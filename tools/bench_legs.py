@@ -78,6 +78,38 @@ def fragcomp_leg(ctx, sizes=(100_000, 1_000_000), reps: int = 5) -> dict:
         exp = oracle.fragcomp(*args, n_threads=threads)
         cpu_s = time.perf_counter() - t0
         k = int(t["k"])
+        # the DataFrame operator on the same table (FragmentCompetition.__call__, fragcomp.py:204-299: candidate keys,
+        # fragment ranges, DIA windows, processing order - competition_plan - then the call above, then the frame)
+        op_ms = plan_ms = None
+        try:
+            import pandas as pd
+            from alphadia_amd.fragcomp import FragmentCompetition, competition_plan
+
+            rng = np.random.default_rng(5)
+            cyc = syn.make_cycle(n_ms2=int(t["n_windows"]), mz_lo=400.0, mz_hi=1000.0)
+            win = np.repeat(np.arange(int(t["n_windows"])), (t["window_stop"] - t["window_start"]))
+            lo_w, hi_w = cyc[0, 1:, 0, 0], cyc[0, 1:, 0, 1]
+            mz_obs = (lo_w[win] + (hi_w[win] - lo_w[win]) * rng.random(int(n))).astype(np.float32)
+            pidx = rng.permutation(int(n)).astype(np.uint32)
+            psm_df = pd.DataFrame({"precursor_idx": pidx, "rank": np.zeros(int(n), np.uint8), "mz_observed": mz_obs,
+                                   "rt_observed": t["rt"], "proba": rng.random(int(n)).astype(np.float32)})
+            frag_df = pd.DataFrame({"precursor_idx": np.repeat(pidx, k), "rank": np.zeros(int(n) * k, np.uint8),
+                                    "mz_observed": t["mz"]})
+            fc = FragmentCompetition()
+            fc(psm_df, frag_df, cyc)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                kept = fc(psm_df, frag_df, cyc)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            op_ms = float(np.median(ts))
+            t0 = time.perf_counter()
+            competition_plan(psm_df["precursor_idx"].values, psm_df["rank"].values, psm_df["mz_observed"].values,
+                             psm_df["proba"].values, frag_df["precursor_idx"].values, frag_df["rank"].values, cyc)
+            plan_ms = (time.perf_counter() - t0) * 1e3
+            del kept
+        except Exception as exc:
+            _log(f"[bench] fragcomp operator timing skipped: {type(exc).__name__}: {exc}")
         sizes_w = (t["window_stop"] - t["window_start"]).astype(np.float64)
         touched = float(n) * (21 + 4 * k) + float(st["pairs"]) * 2 * k * 4
         achieved = touched / (kernel_ms * 1e-3) / 1e9
@@ -85,6 +117,7 @@ def fragcomp_leg(ctx, sizes=(100_000, 1_000_000), reps: int = 5) -> dict:
             "psms": int(n), "windows": int(t["n_windows"]), "fragments_per_psm": k,
             "removed": int(len(exp) - exp.sum()), "identical_to_cpu": bool(np.array_equal(got, exp)),
             "kernel_ms": kernel_ms, "host_to_host_ms": float(np.median(wall)),
+            "operator_ms": op_ms, "operator_plan_ms": plan_ms,
             "neighbour_pairs": int(st["pairs"]), "waiting_psms": int(st["waiting"]), "resolve_rounds": int(st["rounds"]),
             "serial_fallback": bool(st["serial"]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -97,7 +130,8 @@ def fragcomp_leg(ctx, sizes=(100_000, 1_000_000), reps: int = 5) -> dict:
             "psms_per_s": n / (kernel_ms * 1e-3),
             "gpu_over_cpu_kernel": cpu_s * 1e3 / kernel_ms,
         }
-        _log(f"[bench] fragcomp {n}: kernels {kernel_ms:.2f} ms, host->host {np.median(wall):.1f} ms, cpu {cpu_s:.2f} s "
+        _log(f"[bench] fragcomp {n}: kernels {kernel_ms:.2f} ms, host->host {np.median(wall):.1f} ms, operator "
+             f"{op_ms if op_ms is None else round(op_ms, 1)} ms (plan {plan_ms if plan_ms is None else round(plan_ms, 1)}), cpu {cpu_s:.2f} s "
              f"({threads} threads), identical={out[str(n)]['identical_to_cpu']}")
     return out
 
@@ -233,6 +267,92 @@ def multiplex_leg(ctx, n_groups: int = 75_000, n_cycles: int = 4800, steps: int 
 
 
 # --------------------------------------------------------------------------------------------
+def transfer_requant_leg(ctx, n_prec: int = 100_000, n_cycles: int = 4800, steps: int = 5, cpu_seconds: float = 5.0,
+                         threads: int | None = None) -> dict:
+    """The third scoring call site: transfer-library requantification scores the identified candidates again with
+    ``top_k_fragments = 9999`` against a library that carries every predicted fragment
+    (transfer_library_requantification_handler.py:117-124 -> quantify_candidates, extraction_handler.py:488-507:
+    the handler's scoring configuration with only top_k_fragments replaced).  Here: 20-40 fragments per precursor, three
+    candidates each, the 2 h run.  Candidates that keep more than 12 fragments are outside the fused kernel
+    (adh_fused.hip: a 16-lane group holds 12 fragments + 4 isotopes) and take the two-kernel path
+    (adh_gather_kernel -> scratch in HBM -> adh_feature_kernel)."""
+    import synthetic as syn
+    from alphadia_amd.distributed import slice_soa
+    from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
+    from bench import algorithmic_bytes
+    from oracle import oracle
+
+    threads = threads or (os.cpu_count() or 8)
+    case = syn.make_case(n_prec, n_cycles, config_id=2, per_precursor=3, threads=threads, k_fragments=(20, 40))
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
+                    fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=True,
+                    experimental_xic=True, top_k_fragments=9999))
+    cfgj = cfg.to_jitclass()
+    soa = assemble_candidates(case.candidates_df, case.library.precursor_df, "mz_library", pool=ctx.pinned)
+    n = len(soa["precursor_idx"])
+    ctx.stage_run(case.dia)
+    cols = fragment_columns(case.library.fragment_df, "mz_library")
+    ctx.stage_fragments(*cols)
+    packed = pack_assembled(soa)
+    for _ in range(3):
+        host = ctx.score_host(packed, cfgj, reuse_buffers=True)
+    ctx.kernel_time_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        host = ctx.score_host(packed, cfgj, reuse_buffers=True)
+    h2h_ms = (time.perf_counter() - t0) / steps * 1e3
+    g_ms, f_ms, launches = ctx.kernel_time_ms(reset=True)
+    g_ms, f_ms = g_ms * launches / steps, f_ms * launches / steps
+    kernel_ms = g_ms + f_ms
+    valid = host["valid"][:n].astype(bool).copy()
+    feats = host["features"][:n].copy()
+    width = int(host["fragment_mz_observed"].shape[1])
+    filled = float((host["fragment_mz_library"][:n] > 0).sum()) / max(int(valid.sum()), 1)
+    matched = ctx.device_tables_to_host(names=["stat_matched_peaks"])["stat_matched_peaks"][:n]
+    lib_len = soa["frag_stop_idx"].astype(np.int64) - soa["frag_start_idx"].astype(np.int64)
+    alg = float(algorithmic_bytes(case.dia, soa, cfgj, matched, lib_len).sum())
+    achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # CPU oracle on a sample of the same table
+    sample = min(n, 3000)
+    sub = pack_assembled(slice_soa(soa, 0, sample))
+    th = _cpu_threads()
+    oracle.score(case.dia, cols, sub, cfgj, n_threads=th)
+    reps, dt = 0, 0.0
+    while dt < cpu_seconds or reps == 0:
+        t0 = time.perf_counter()
+        exp = oracle.score(case.dia, cols, sub, cfgj, n_threads=th, reuse=oracle.score.last_buffers)
+        dt += time.perf_counter() - t0
+        reps += 1
+    same_valid = bool(np.array_equal(exp["valid"].astype(bool), valid[:sample]))
+    max_rel = None
+    if same_valid and exp["valid"].any():
+        v = exp["valid"].astype(bool)
+        keep = [f for f in range(46) if f not in (8, 9, 41, 42, 45)]
+        fe, fg = exp["features"][v][:, keep].astype(np.float64), feats[:sample][v][:, keep].astype(np.float64)
+        d = np.abs(fe - fg) / np.maximum(np.maximum(np.abs(fe), np.abs(fg)), 1e-6)
+        max_rel = float(np.nanmax(np.where(np.isnan(fe) & np.isnan(fg), 0.0, d)))
+    n_p = len(np.unique(soa["precursor_idx"]))
+    res = {
+        "workload": f"transfer-library requantification: {n_p} precursors x 3 candidates, library of 20-40 fragments per "
+                    f"precursor, top_k_fragments 9999 (tables {width} columns wide, {filled:.1f} filled per valid candidate) vs "
+                    f"{n_cycles} cycles x 61 spectra",
+        "metric": "precursors scored/sec", "value": n_p / (h2h_ms * 1e-3), "unit": "precursors/s", "ms_per_step": h2h_ms,
+        "candidates": int(n), "valid_fraction": float(valid.mean()), "kernel_ms": kernel_ms,
+        "kernel_ns_per_candidate": kernel_ms * 1e6 / max(n, 1),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": _leg_traffic("transfer_requant"), "kernel_ms": kernel_ms, "gather_kernel_ms": g_ms,
+                     "feature_kernel_ms": f_ms, "algorithmic_bytes_per_candidate": alg / max(n, 1),
+                     "kernel": "adh_gather_kernel + adh_feature_kernel (the two-kernel path: more than 12 fragments per candidate)"},
+        "cpu_baseline": {"value": (sample / 3.0) / (dt / reps), "unit": "precursors/s", "cores": th, "kind": "port",
+                         "sample": f"first {sample} candidates, {reps} x {dt / reps:.2f} s, {th} OpenMP threads",
+                         "valid_identical_to_gpu": same_valid, "max_rel_feature_diff_vs_gpu": max_rel},
+    }
+    _log(f"[bench] transfer requant: host->host {h2h_ms:.2f} ms per {n} candidates, kernels {kernel_ms:.2f} ms "
+         f"({res['kernel_ns_per_candidate']:.1f} ns per candidate), frac {res['roofline']['frac']:.3f}, same valid {same_valid}")
+    return res
+
+
 def operator_leg(case, cfg, reps: int = 3) -> dict:
     """The plug-in operator itself: ``HipCandidateScoring.__call__`` from the candidate
     DataFrame to ``(features_df, fragments_df)`` on the headline table - what every call site of the reference
@@ -338,6 +458,8 @@ if __name__ == "__main__":
         if which == "fragcomp":
             sizes = tuple(int(x) for x in os.environ.get("FC_SIZES", "100000,1000000").split(","))
             print(json.dumps(fragcomp_leg(ctx, sizes=sizes)))
+        elif which == "transfer":
+            print(json.dumps(transfer_requant_leg(ctx, n_prec=int(os.environ.get("N_PREC", 100000)))))
         elif which == "multiplex":
             print(json.dumps(multiplex_leg(ctx, n_groups=int(os.environ.get("N_GROUPS", 75000)),
                                            n_cycles=int(os.environ.get("N_CYCLES", 4800)))))

@@ -271,6 +271,10 @@ if not os.environ.get("ADH_BENCH_NO_SELECT"):
                            "touched_bytes_per_precursor": t_sel / len(pdf),
                            "yardstick": "events inside the windows' TOF bins, the rt tolerance and the mobility tolerance x 6 B "
                                         f"+ index words + library slice + outputs; exact on a sample of {len(rows_sel)} precursors"}
+        if tfile and os.path.exists(tfile):  # (FETCH_SIZE / WRITE_SIZE passes of tools/profile_r5.sh)
+            tj = json.load(open(tfile))
+            if tj.get("selection_hbm_bytes_per_pass") and tj.get("candidates") == n:
+                sel["roofline"]["traffic"] = tj["selection_hbm_bytes_per_pass"]
     except Exception as exc:  # the yardstick must not take the leg down
         sel["roofline"] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
     if not os.environ.get("ADH_BENCH_NO_CPU"):

@@ -94,7 +94,7 @@ def mfma(pmc_path, stats_path, out_path, key, flops_per_unit):
         out[short(k)] = {
             "dispatches": c["SQ_INSTS_VALU_MFMA_MOPS_F32"][0], "mfma_mops_f32": mops, "flops": flops,
             "mfma_busy_cycles": busy_mfma, "kernel_clocks_sum": busy,
-            "mfma_busy_share": busy_mfma / (busy * N_SIMD / 4) if busy else None,  # (counted per CU-quad-cycle: see note)
+            "mfma_busy_share": busy_mfma / (busy * N_SIMD) if busy else None,  # (cycles summed over the SIMDs)
             "total_ms": None if tot_ns is None else tot_ns / 1e6,
             "achieved_tflops": None if not tot_ns else flops / tot_ns / 1e3,
             "share_of_f32_mfma_peak_157tf": None if not tot_ns else flops / tot_ns / 1e3 / 157.0,
