@@ -758,6 +758,7 @@ int build_tile_layout(adh_handle *h, DevTims &t) {
         ncb = blocks(t.n_cycles, csh), nsb = blocks(t.scan_max, ssh);
     }
     const int64_t n_keys = ncb * nsb * (t.n_tof + 1), n = t.n_events;
+    if (n_keys >= 0x7FFFFFFFll) return ADH_OK;  // (the scan below counts in int: such a run keeps the bin ranges)
     int key_bits = 1;
     while (key_bits < 32 && (1ll << key_bits) < n_keys) ++key_bits;
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -779,9 +780,14 @@ int build_tile_layout(adh_handle *h, DevTims &t) {
     };
     if (!grab((void **)&k_in, (size_t)n * 4, work) || !grab((void **)&k_out, (size_t)n * 4, work) ||
         !grab((void **)&v_in, (size_t)n * 8, work) || !grab(&tmp, tmp_bytes, work) ||
-        !grab((void **)&v_out, (size_t)n * 8, h->run_buf) || !grab((void **)&idx, (size_t)(n_keys + 1) * 4, h->run_buf)) {
-        work.release();
-        return ADH_OK;  // (what went to run_buf goes with the run)
+        !grab((void **)&v_out, (size_t)n * 8, work) || !grab((void **)&idx, (size_t)(n_keys + 1) * 4, work)) {
+        work.release();  // (v_out / idx included: a layout that was not built must not keep gigabytes)
+        return ADH_OK;
+    }
+    // built from here on: the two arrays stay with the run
+    for (void *keep : {(void *)v_out, (void *)idx}) {
+        work.ptrs.erase(std::find(work.ptrs.begin(), work.ptrs.end(), keep));
+        h->run_buf.ptrs.push_back(keep);
     }
     hipError_t e = hipMemsetAsync(idx, 0, (size_t)(n_keys + 1) * 4, h->stream);
     if (e == hipSuccess) {

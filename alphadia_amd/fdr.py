@@ -33,6 +33,9 @@ logger = logging.getLogger(__name__)
 MAX_DIA_CYCLE_SHAPE = 2  # fdr.py:19
 
 
+_WARNED_NUMPY_INIT = False
+
+
 class TooFewPSMError(ValueError):
     """alphadia.exceptions.TooFewPSMError: the train/test split is empty."""
 
@@ -154,6 +157,14 @@ class HipBinaryClassifier:
             # nn.Linear.reset_parameters: weight and bias uniform in +-1 / sqrt(fan_in).  Used where torch is absent
             # or ADH_FDR_NUMPY_INIT is set (tools/bench_fdr.py in the bench line: an `import torch` costs minutes on
             # a cold box); same network and training, another random stream than the reference's.
+            if not os.environ.get("ADH_FDR_NUMPY_INIT"):  # (asked for: the bench; torch missing: say so, once)
+                global _WARNED_NUMPY_INIT
+                if not _WARNED_NUMPY_INIT:
+                    logger.warning("torch is not importable: the classifier's initial weights are drawn from a NumPy "
+                                   "stream - same distribution and training, but q-values and PSM sets will differ from a "
+                                   "torch-seeded run of the reference with the same random_state")
+                    _WARNED_NUMPY_INIT = True
+            self.init_stream = "numpy"  # (recorded on the classifier: to_state_dict keeps the reference's keys only)
             rng = np.random.default_rng(self._torch_seed)
             self._torch_seed = None
             for out_f, in_f in self._linear_shapes():

@@ -368,7 +368,10 @@ def assemble_candidates(
         lib_rows = np.argsort(lib_pidx, kind="stable")
         precursors_flat_df = precursors_flat_df.iloc[lib_rows]
         lib_pidx = precursors_flat_df["precursor_idx"].values
-    if len(lib_pidx) and int(lib_pidx[0]) == 0 and int(lib_pidx[-1]) == len(lib_pidx) - 1:
+    # (strictly ascending is only certain where the check above passed: after the argsort branch the keys are merely
+    # non-decreasing - a library with a duplicated precursor_idx, e.g. [0, 1, 1, 3], would pass the end-point test and
+    # map the absent index 2 to a wrong row)
+    if lib_rows is None and len(lib_pidx) and int(lib_pidx[0]) == 0 and int(lib_pidx[-1]) == len(lib_pidx) - 1:
         # strictly ascending from 0 to len - 1: the index IS the row (a library as alphabase writes it)
         pos = cols["precursor_idx"].astype(np.intp)
         if n and int(pos.max()) >= len(lib_pidx):

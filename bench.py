@@ -598,6 +598,36 @@ def main():
                 legs[name] = {"skipped": f"{type(exc).__name__}: {exc}"[:300]}
                 log(f"[bench] leg {name} skipped: {exc}")
         result["extras"] = legs
+        # the legs' key numbers once more as flat keys (a reader that keeps only the top of the record sees them)
+        def pick(leg, *path):
+            v = legs.get(leg)
+            for k in path:
+                v = v.get(k) if isinstance(v, dict) else None
+            return v
+
+        result["config"]["legs"] = {
+            "operator_ms": pick("operator", "operator_ms"),
+            "operator_wire_bytes": pick("operator", "stages_ms", "wire_bytes"),
+            "fragcomp_1e6_kernel_ms": pick("fragment_competition", "1000000", "kernel_ms"),
+            "fragcomp_1e6_call_ms": pick("fragment_competition", "1000000", "host_to_host_ms"),
+            "fragcomp_1e6_operator_ms": pick("fragment_competition", "1000000", "operator_ms"),
+            "fragcomp_1e6_frac": pick("fragment_competition", "1000000", "roofline", "frac"),
+            "configs4_ms": pick("multiplex_configs4", "ms_per_step"),
+            "configs4_kernel_ms": pick("multiplex_configs4", "kernel_ms"),
+            "configs4_frac": pick("multiplex_configs4", "roofline", "frac"),
+            "transfer_requant_ms": pick("transfer_requant", "ms_per_step"),
+            "transfer_requant_kernel_ns_per_candidate": pick("transfer_requant", "kernel_ns_per_candidate"),
+            "transfer_requant_frac": pick("transfer_requant", "roofline", "frac"),
+            "configs3_ms": pick("ion_mobility_configs3", "ms_per_step"),
+            "configs3_kernel_ms": pick("ion_mobility_configs3", "roofline", "kernel_ms"),
+            "configs3_frac": pick("ion_mobility_configs3", "roofline", "frac"),
+            "configs3_selection_kernel_ms": pick("ion_mobility_configs3", "selection", "kernel_ms"),
+            "configs3_selection_frac": pick("ion_mobility_configs3", "selection", "roofline", "frac"),
+            "selection_kernel_ms": pick("candidate_selection", "kernel_ms"),
+            "selection_frac": pick("candidate_selection", "roofline", "frac"),
+            "fdr_fit_kernels_ms": pick("fdr_stage", "fit_kernels_ms"),
+            "fdr_predict_kernel_ms": pick("fdr_stage", "predict_kernel_ms"),
+        }
 
     if rank == 0:
         print(json.dumps(result))

@@ -67,6 +67,11 @@ def test_config2_full_size_one_gpu(ctx, oracle_lib, headline):
     idx = np.arange(0, n, 150)
     exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=_rows(soa, idx), n_threads=THREADS, with_stats=True)
     compare({k: v[idx] for k, v in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    # the knife-edge masks of compare() (features 16, 18, 19 where the operands are exactly equal) must stay a
+    # small share of the sample: a comparison that masks most rows would not be one
+    m = compare.last_masked
+    print(f"[full size] knife-edge rows of {m['rows']} compared: {m}")
+    assert max(m[16], m[18], m[19]) <= 0.25 * m["rows"], m
     assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
     planted = case.apex_cycle[soa["precursor_idx"]] >= 0
     r0 = planted & (soa["rank"] == 0)

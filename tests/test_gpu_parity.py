@@ -54,17 +54,25 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     # exp() (device libm vs glibc): rows whose filled slots all show the same value are knife-edge and
     # excluded from the comparison of that feature.
     filled = exp["fragment_type"][v] != 0
+    masked = {}
     for f, table in ((18, "fragment_intensity"), (19, "fragment_height")):
         x = np.where(filled, exp[table][v], np.nan)
         flat = (np.nanmax(x, axis=1) == np.nanmin(x, axis=1)) if x.shape[1] else np.zeros(len(x), bool)
         gf[flat, f] = 0.0
         ef[flat, f] = 0.0
+        masked[f] = int(flat.sum())
     # feature 16 (correlation of the isotope intensities with the isotope heights, save_corrcoeff) is the
     # same kind of knife edge: isotope planes of equal height (e.g. one event of 5 counts each) give
     # numerator / (denominator + 1e-12) with both ~1e-16 or exactly 0, depending on the last bit of exp()
     knife = ((gf[:, 16] == 0.0) | (ef[:, 16] == 0.0)) & (np.abs(gf[:, 16]) < 1e-3) & (np.abs(ef[:, 16]) < 1e-3)
     gf[knife, 16] = 0.0
     ef[knife, 16] = 0.0
+    masked[16] = int(knife.sum())
+    # how many rows the three knife-edge masks took out of the comparison of their feature;
+    # `pytest -s` / the full-size tests show it, compare.last_masked keeps it for assertions
+    compare.last_masked = dict(masked, rows=int(v.sum()))
+    print(f"[compare] {int(v.sum())} valid rows; knife-edge rows left out: feature 16: {masked[16]}, 18: {masked[18]}, "
+          f"19: {masked[19]}")
     assert np.array_equal(np.isnan(gf), np.isnan(ef)), "NaN pattern differs"
     for f in EXACT_FEATURES:
         assert np.array_equal(gf[:, f], ef[:, f]), f"feature {f} must be exact"

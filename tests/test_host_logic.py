@@ -353,3 +353,24 @@ def test_threaded_object_gather_matches_numpy():
     assert sys.getrefcount(probe) == before
     # small inputs and non-object arrays take NumPy's path
     assert np.array_equal(runtime.take_objects(np.arange(10), np.array([3, 1])), np.array([3, 1]))
+
+
+def test_assemble_rejects_an_index_a_library_with_duplicates_lacks():
+    """a library whose precursor_idx column repeats a value ([0, 1, 1, 3]) passes the end-point test of the
+    identity fast path; a candidate with the absent index 2 must still be refused, not mapped to a wrong row."""
+    from alphadia_amd.scoring import assemble_candidates
+
+    lib = pd.DataFrame({"precursor_idx": np.array([0, 1, 1, 3], np.uint32), "elution_group_idx": np.arange(4, dtype=np.uint32),
+                        "decoy": np.zeros(4, np.uint8), "channel": np.zeros(4, np.uint8), "charge": np.full(4, 2, np.uint8),
+                        "flat_frag_start_idx": np.arange(4, dtype=np.uint32) * 5,
+                        "flat_frag_stop_idx": np.arange(1, 5, dtype=np.uint32) * 5,
+                        "mz_library": np.array([500, 600, 700, 800], np.float32), "i_0": np.ones(4, np.float32)})
+    lib = lib.iloc[[3, 0, 1, 2]].reset_index(drop=True)  # unsorted: the argsort branch runs
+    cand = pd.DataFrame({"precursor_idx": np.array([2], np.uint32), "rank": np.zeros(1, np.uint8),
+                         "elution_group_idx": np.zeros(1, np.uint32), "scan_start": [0], "scan_stop": [1], "scan_center": [0],
+                         "frame_start": [0], "frame_stop": [20], "frame_center": [10]})
+    with pytest.raises(ValueError, match="missing from precursors_flat"):
+        assemble_candidates(cand, lib, "mz_library")
+    ok = cand.assign(precursor_idx=np.array([3], np.uint32))
+    soa = assemble_candidates(ok, lib, "mz_library")
+    assert float(soa["precursor_mz"][0]) == 800.0
