@@ -1660,6 +1660,7 @@ int adh_fragcomp_stats(adh_handle_t *h, double *kernel_ms, int64_t *pairs, int64
 
 }  // extern "C"
 
+#include "adh_fragcomp_plan.hip"
 #include "adh_fdr.hip"
 #include "adh_mlp.hip"
 #include "adh_fdr_device.hip"

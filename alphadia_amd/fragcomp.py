@@ -13,6 +13,7 @@ run in a HIP kernel, one workgroup per DIA window.
 from __future__ import annotations
 
 import logging
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -182,12 +183,27 @@ class FragmentCompetition:
     def __call__(self, psm_df: pd.DataFrame, frag_df: pd.DataFrame, cycle: np.ndarray) -> pd.DataFrame:
         from alphadia_amd import runtime  # raises when the HIP library is missing
 
+        ctx = runtime.get_context(self.device)
+        rank, world = ctx.comm_info() if self.world is None else (int(self.rank or 0), int(self.world))
+        # one rank, float32 probabilities (what a classifier's predict_proba gives): the preparation runs on the device
+        # too (adh_fragcomp_frames: 1e6 PSMs / 12 M fragment rows in tens of ms where the NumPy plan below takes 360)
+        if (world <= 1 and psm_df["proba"].dtype == np.float32 and psm_df["mz_observed"].dtype == np.float32
+                and not os.environ.get("ADH_FRAGCOMP_HOST_PLAN")):
+            done = ctx.fragcomp_frames(
+                psm_df["precursor_idx"].values, psm_df["rank"].values, psm_df["mz_observed"].values,
+                psm_df["rt_observed"].values, psm_df["proba"].values, frag_df["precursor_idx"].values,
+                frag_df["rank"].values, frag_df["mz_observed"].values, cycle, self.rt_tol_seconds, self.mass_tol_ppm)
+            if done is not None:
+                rows, valid = done
+                kept = rows[valid]
+                out = psm_df.iloc[kept].copy()
+                out["_candidate_idx"] = candidate_hash(psm_df["precursor_idx"].values[kept], psm_df["rank"].values[kept])
+                out["valid"] = True
+                return out
         plan = competition_plan(
             psm_df["precursor_idx"].values, psm_df["rank"].values, psm_df["mz_observed"].values,
             psm_df["proba"].values, frag_df["precursor_idx"].values, frag_df["rank"].values, cycle,
         )
-        ctx = runtime.get_context(self.device)
-        rank, world = ctx.comm_info() if self.world is None else (int(self.rank or 0), int(self.world))
         if world > 1 and ctx.comm_info()[1] != world:
             raise runtime.HipBackendError(f"FragmentCompetition(world={world}) needs a communicator of {world} ranks "
                                           "on the context (Context.comm_init)")

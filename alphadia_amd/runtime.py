@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "adh_kernel_time_ms",
     "adh_fragcomp",
     "adh_fragcomp_stats",
+    "adh_fragcomp_frames",
     "adh_select_candidates",
     "adh_select_time_ms",
     "adh_transpose_timstof",
@@ -766,6 +767,38 @@ class Context:
             "adh_fragcomp",
         )
         return valid.view(np.bool_)
+
+    def fragcomp_frames(self, psm_precursor_idx, psm_rank, psm_mz_observed, psm_rt_observed, psm_proba,
+                        frag_precursor_idx, frag_rank, frag_mz_observed, cycle, rt_tol_seconds: float, mass_tol_ppm: float):
+        """``adh_fragcomp_frames``: plan and competition on the device from the frames' columns.  Returns
+        ``(rows, valid)`` - input position and flag of every processed PSM in processing order - or ``None`` when the
+        fragment table is not grouped by candidate (the caller prepares the plan itself)."""
+        pp, pr = _abi.as_c(psm_precursor_idx, np.uint32), _abi.as_c(psm_rank, np.uint8)
+        pmz, prt = _abi.as_c(psm_mz_observed, np.float32), _abi.as_c(psm_rt_observed, np.float32)
+        ppb = _abi.as_c(psm_proba, np.float32)
+        fp, fr = _abi.as_c(frag_precursor_idx, np.uint32), _abi.as_c(frag_rank, np.uint8)
+        fmz = _abi.as_c(frag_mz_observed, np.float32)
+        lower = np.ascontiguousarray(cycle[0, :, :, 0].min(axis=1), dtype=np.float64)
+        upper = np.ascontiguousarray(cycle[0, :, :, 1].max(axis=1), dtype=np.float64)
+        n = pp.shape[0]
+        if not (pr.shape[0] == pmz.shape[0] == prt.shape[0] == ppb.shape[0] == n) or fr.shape[0] != fp.shape[0] \
+                or fmz.shape[0] != fp.shape[0]:
+            raise ValueError("columns of one frame differ in length")
+        rows, valid = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.uint8)
+        n_rows, grouped = C.c_int64(0), C.c_int32(1)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+        _check(
+            lib.adh_fragcomp_frames(
+                self._h, C.c_int64(n), p(pp, C.c_uint32), p(pr, C.c_uint8), p(pmz, C.c_float), p(prt, C.c_float),
+                p(ppb, C.c_float), C.c_int64(fp.shape[0]), p(fp, C.c_uint32), p(fr, C.c_uint8), p(fmz, C.c_float),
+                C.c_int32(lower.shape[0]), p(lower, C.c_double), p(upper, C.c_double), C.c_double(float(rt_tol_seconds)),
+                C.c_double(float(mass_tol_ppm)), p(rows, C.c_int64), p(valid, C.c_uint8), C.byref(n_rows), C.byref(grouped)),
+            "adh_fragcomp_frames",
+        )
+        if not grouped.value:
+            return None
+        k = int(n_rows.value)
+        return rows[:k], valid[:k].astype(bool)
 
     def fragcomp_stats(self) -> dict:
         """``adh_fragcomp_stats``: device time and work counters of the last competition."""

@@ -421,6 +421,22 @@ int adh_fragcomp(adh_handle_t *handle, int64_t n_windows, const int64_t *window_
                  const int64_t *frag_start_idx, const int64_t *frag_stop_idx,
                  int64_t n_frag, const float *fragment_mz, double rt_tol_seconds,
                  double mass_tol_ppm, uint8_t *valid);
+/*
+ * FragmentCompetition.__call__ (fragcomp/fragcomp.py:204-299) from the columns of its two frames: the preparation the
+ * reference does with pandas - candidate keys (fragcomp/utils.py:48-58), the fragment range of every PSM
+ * (add_frag_start_stop_idx, utils.py:11-45; PSMs without fragment rows leave), the DIA window of every PSM
+ * (_add_window_idx, fragcomp.py:170-202; `window_lower` / `window_upper` = per cycle row the lowest / highest isolation
+ * limit over its scans), the processing order (window, proba, precursor_idx, input position) - runs on the device, then
+ * the competition.  Out: `rows[0 .. *n_rows)` = input position of every processed PSM in processing order, `valid` its
+ * flag.  `*grouped` = 0 (and nothing else done) when a candidate's fragment rows are not contiguous in the fragment
+ * table or a table has 2^31 rows or more: the caller then prepares the plan itself and calls adh_fragcomp.
+ */
+int adh_fragcomp_frames(adh_handle_t *handle, int64_t n_psm, const uint32_t *psm_precursor_idx, const uint8_t *psm_rank,
+                        const float *psm_mz_observed, const float *psm_rt_observed, const float *psm_proba, int64_t n_frag,
+                        const uint32_t *frag_precursor_idx, const uint8_t *frag_rank, const float *frag_mz_observed,
+                        int32_t n_cycle_rows, const double *window_lower, const double *window_upper, double rt_tol_seconds,
+                        double mass_tol_ppm, int64_t *rows, uint8_t *valid, int64_t *n_rows, int32_t *grouped);
+
 /* What the last competition on this handle (adh_fragcomp or inside adh_fdr_resident) did: HIP-event
  * duration of its device work, (PSM, RT neighbour) pairs whose fragment lists were compared, PSMs whose
  * fate hung on an earlier PSM, rounds that settled those, and whether the one-workgroup-per-window

@@ -124,3 +124,80 @@ def test_search_sized_table(ctx, oracle_lib):
     assert 0.02 * len(exp) < removed < 0.2 * len(exp)
     st = ctx.fragcomp_stats()
     assert st["rounds"] <= 8 and not st["serial"]
+
+
+def _frames(rng, n, n_win=8, ties=True, grouped=True):
+    """psm_df / frag_df / cycle as FragmentCompetition.__call__ receives them: ties in proba (and in proba + precursor_idx
+    across ranks), PSMs without fragment rows, observed m/z outside every isolation window."""
+    import pandas as pd
+
+    import synthetic as syn
+
+    cyc = syn.make_cycle(n_ms2=n_win, mz_lo=400.0, mz_hi=480.0)
+    pidx = rng.permutation((n + 1) // 2).astype(np.uint32).repeat(2)[:n]
+    rank = (np.arange(n) % 2).astype(np.uint8)
+    perm = rng.permutation(n)
+    pidx, rank = pidx[perm], rank[perm]
+    proba = rng.random(n).astype(np.float32)
+    if ties:
+        proba = np.round(proba, 2).astype(np.float32)  # many equal probabilities
+        proba[rng.random(n) < 0.02] = 0.0
+    mz_obs = rng.uniform(395.0, 485.0, n).astype(np.float32)  # some below / above every window -> row 0
+    psm = pd.DataFrame({"precursor_idx": pidx, "rank": rank, "mz_observed": mz_obs,
+                        "rt_observed": rng.uniform(0, 40, n).astype(np.float32), "proba": proba,
+                        "extra": np.arange(n)})
+    has = rng.random(n) < 0.9
+    nf = np.where(has, rng.integers(1, 13, n), 0)
+    pool = np.sort(rng.uniform(200, 1800, 60)).astype(np.float32)
+    f_p = np.repeat(pidx, nf)
+    f_r = np.repeat(rank, nf)
+    f_mz = (rng.choice(pool, int(nf.sum())) * (1 + rng.normal(0, 4e-6, int(nf.sum())))).astype(np.float32)
+    frag = pd.DataFrame({"precursor_idx": f_p, "rank": f_r, "mz_observed": f_mz})
+    if not grouped:
+        # a few candidates whose rows are NOT next to each other (one row of each moved to the end of the table): their
+        # range runs from their first row to the end (first row .. last row + 1 semantics) - keep such tables small, the
+        # competition compares whole ranges
+        moved = rng.choice(len(frag), 5, replace=False)
+        keep = np.setdiff1d(np.arange(len(frag)), moved)
+        frag = frag.iloc[np.concatenate([keep, moved])].reset_index(drop=True)
+    return psm, frag, cyc
+
+
+@pytest.mark.parametrize("seed, n, grouped", [(1, 4000, True), (2, 30000, True), (3, 300, False), (4, 257, True)])
+def test_device_plan_equals_the_numpy_plan(ctx, monkeypatch, seed, n, grouped):
+    """FragmentCompetition.__call__ with the preparation on the device (adh_fragcomp_frames) returns the frame the NumPy
+    plan + adh_fragcomp returns: same rows, same order, same columns; an ungrouped fragment table falls back."""
+    from alphadia_amd.fragcomp import FragmentCompetition
+
+    rng = np.random.default_rng(100 + seed)
+    psm, frag, cyc = _frames(rng, n, grouped=grouped)
+    fc = FragmentCompetition(rt_tol_seconds=3, mass_tol_ppm=15)
+    monkeypatch.setenv("ADH_FRAGCOMP_HOST_PLAN", "1")
+    ref = fc(psm.copy(), frag.copy(), cyc)
+    monkeypatch.delenv("ADH_FRAGCOMP_HOST_PLAN")
+    direct = ctx.fragcomp_frames(psm["precursor_idx"].values, psm["rank"].values, psm["mz_observed"].values,
+                                 psm["rt_observed"].values, psm["proba"].values, frag["precursor_idx"].values,
+                                 frag["rank"].values, frag["mz_observed"].values, cyc, 3, 15)
+    assert (direct is not None) == grouped
+    got = fc(psm.copy(), frag.copy(), cyc)
+    assert 0 < len(ref) < len(psm)
+    assert list(got.columns) == list(ref.columns)
+    for c in ref.columns:
+        assert np.array_equal(got[c].to_numpy(), ref[c].to_numpy()), c
+    assert np.array_equal(got.index.to_numpy(), ref.index.to_numpy())
+
+
+def test_device_plan_reproduces_the_reference_golden(ctx):
+    """The reference's own FragmentCompetition run (tests/golden/fragcomp.npz) through the device-side plan."""
+    import pandas as pd
+
+    import helpers as H
+    from alphadia_amd.fragcomp import FragmentCompetition
+
+    z = np.load(H.golden_path("fragcomp.npz"))
+    psm = pd.DataFrame({k[4:]: z[k] for k in z.files if k.startswith("psm_")})
+    frag = pd.DataFrame({k[5:]: z[k] for k in z.files if k.startswith("frag_")})
+    assert psm["proba"].dtype == np.float32
+    got = FragmentCompetition(rt_tol_seconds=3, mass_tol_ppm=15)(psm, frag, z["cycle"])
+    assert np.array_equal(got["precursor_idx"].values, z["surviving_precursor_idx"])
+    assert np.array_equal(got["rank"].values, z["surviving_rank"])
