@@ -111,6 +111,18 @@ __device__ __forceinline__ void center_envelope(float (&x)[FM], int F) {
     }
 }
 
+// the 12-input sorting network as a list of compare-exchanges (layer by layer)
+#define ADH_SORT12_NETWORK(CE)                                                              \
+    CE(0, 1) CE(2, 3) CE(4, 5) CE(6, 7) CE(8, 9) CE(10, 11)                                  \
+    CE(1, 3) CE(5, 7) CE(9, 11) CE(0, 2) CE(4, 6) CE(8, 10)                                  \
+    CE(1, 2) CE(5, 6) CE(9, 10) CE(0, 4) CE(7, 11)                                           \
+    CE(1, 5) CE(6, 10) CE(3, 7) CE(4, 8)                                                     \
+    CE(5, 9) CE(2, 6) CE(0, 4) CE(7, 11) CE(3, 8)                                            \
+    CE(1, 5) CE(6, 10) CE(2, 3) CE(8, 9)                                                     \
+    CE(1, 4) CE(7, 10) CE(3, 5) CE(6, 8)                                                     \
+    CE(2, 4) CE(7, 9) CE(5, 6)                                                               \
+    CE(3, 4) CE(7, 8)
+
 // ascending bitonic sort of 16 registers
 __device__ __forceinline__ void sort16(float (&v)[16]) {
 #pragma unroll
@@ -130,6 +142,20 @@ __device__ __forceinline__ void sort16(float (&v)[16]) {
             }
         }
     }
+}
+
+// ascending sort of v[0..11] (39 compare-exchanges in 9 layers, the optimal 12-input network; checked against all
+// 4096 zero-one inputs by tests/test_host_logic.py); v[12..15] are left alone - callers hold +inf there
+__device__ __forceinline__ void sort_first12(float (&v)[16]) {
+#define ADH_CE(a, b)                                  \
+    {                                                 \
+        const float lo_ = fminf(v[a], v[b]);          \
+        const float hi_ = fmaxf(v[a], v[b]);          \
+        v[a] = lo_;                                   \
+        v[b] = hi_;                                   \
+    }
+    ADH_SORT12_NETWORK(ADH_CE)
+#undef ADH_CE
 }
 
 // frame-profile statistics of one (fragment, observation) row against the template frame

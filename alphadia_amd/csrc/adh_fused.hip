@@ -177,7 +177,7 @@ __device__ __forceinline__ float row_prefix_max_excl(float x) {
 // index travels with it, so callers never depend on the direction)
 template <int N>
 __device__ __forceinline__ int row_ror(int x) {
-    return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(x, 0x120 + N, 0xF, 0xF, false);  // (every lane has a source: no `old` value to set up)
 }
 #define FU_FOR_OTHER_LANES(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
@@ -671,14 +671,14 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         // ---- every fragment of the slice has its lane: ranks by comparison with the 15 other lanes of
         // the row, values moved by DPP rotations (no LDS round trips in the dependency chain)
         const bool ok_l = sub < n_lib && !(cfg.exclude_shared_ions && rec_cardinality(mine) > 1);
-        const unsigned okm = (unsigned)((__ballot(ok_l) >> gsh) & 0xFFFFull);
-        const int ia = __float_as_int(mine_int);
+        // (a lane that is out travels as -inf: never above, never equal to a library intensity)
+        const int ia = __float_as_int(ok_l ? mine_int : -INFINITY);
         int rk = 0;
 #define FU_RANK_STEP(N)                                                                                \
     {                                                                                                  \
         const int b = row_ror<N>(sub);                                                                 \
         const float ib = __int_as_float(row_ror<N>(ia));                                               \
-        rk += (((okm >> b) & 1u) != 0u) && ((ib > mine_int) || (ib == mine_int && b > sub)); \
+        rk += (ib > mine_int) || (ib == mine_int && b > sub);                                          \
     }
         FU_FOR_OTHER_LANES(FU_RANK_STEP)  // position in argsort()[::-1]
 #undef FU_RANK_STEP
@@ -856,7 +856,8 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             const float sm = E[r + 1] + E[r];
             const float drt = KP.frt[r + 1] - KP.frt[r];
             const float m = sm * drt;
-            ar += in ? (double)m * 0.5 : 0.0;
+            const float mi = in ? m : 0.0f;  // (outside the window the term is +0, as if skipped)
+            ar += (double)mi * 0.5;
         }
         area = ar * (double)qw;
         float oi_sum = 0.0f;
@@ -876,22 +877,33 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
         // ================= rows into registers (the tile is dead afterwards) =================
         {
+            if (o == 0) {
+                // MS1 observation collapse (candidate.py:248-269) with ONE MS1 row per cycle: the sum over the
+                // single observation is the value itself, the mean m/z is y / (count + 1e-6) with count = 1
+                // where y > 0 (y is a weighted mean of m/z values: positive or an untouched 0 = 0 / 1e-6).
+                // In place on the isotope columns of the tile, the I x FM cells dealt to all 16 lanes of the
+                // group (three isotope lanes dividing FM cells each kept the other thirteen waiting).
+                const Recip one(1.0 + 1e-6);
+                constexpr int NISO = TW - ISO0;
+                adh_wave_sync();  // the columns were written by their own lanes
+#pragma unroll
+                for (int pass = 0; pass < (NISO * FM + 15) / 16; ++pass) {
+                    const int idx = sub + 16 * pass;
+                    const int i = idx / FM, r = idx - i * FM;
+                    if (i < I) {
+                        float2 &cell = L.u.tile[r][ISO0 + i];
+                        const float y = cell.y;
+                        if (y > 0.0f) cell.y = (float)one.div((double)y);
+                    }
+                }
+                adh_wave_sync();
+            }
             const float2 *col = &L.u.tile[0][min(sub, TW - 1)];
             const float mq = iso_lane ? 1.0f : qmask[o];  // candidate.py:290 (fragments only)
             FU_FOR_R {
                 const float2 v = col[r * TW];
                 A[r] = v.x * mq;
                 B[r] = v.y;
-            }
-            if (o == 0 && iso_lane) {
-                // MS1 observation collapse (candidate.py:248-269) with ONE MS1 row per cycle: the sum over the
-                // single observation is the value itself, the mean m/z is y / (count + 1e-6) with count = 1
-                // where y > 0 (y is a weighted mean of m/z values: positive or an untouched 0 = 0 / 1e-6)
-                const Recip one(1.0 + 1e-6);
-                FU_FOR_R {
-                    const float b = B[r];
-                    B[r] = (b > 0.0f) ? (float)one.div((double)b) : b;
-                }
             }
         }
         adh_wave_sync();
@@ -980,7 +992,6 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             double isum = 0, ssum = 0, fsum = 0;
 #pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
             for (int sc = 0; sc < 2; ++sc) {
-                const double scd = (double)sc;
                 // the cycle coordinate f = r + shift as a running float64 (exact) that starts from a value the
                 // optimiser cannot see through: left to itself it converts all FM coordinates ahead of the two-trip
                 // loop and keeps them in 2 FM registers next to the rows
@@ -988,14 +999,16 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
                 __asm__ volatile("" : "+v"(fd));
                 FU_FOR_R {
                     float v = Q.tpl[r];
-                    v = (v > 0.0f) ? v : 0.0f;  // the reference skips v <= 0; adding +0 is the same
+                    v = __builtin_fmaxf(v, 0.0f);  // the reference skips v <= 0; adding +0 is the same
                     const double vd = (double)v;
                     isum += vd;
-                    ssum += scd * vd;
                     fsum += fd * vd;
                     fd += 1.0;
                     FU_FENCE(r);
                 }
+                // sum of scan * v: scan 0 adds +0 FM times, scan 1 adds the row from zero in the order isum took
+                // during scan 0 - the same additions, the same bits
+                if (sc == 0) ssum = isum;
             }
             esc = (isum > 0) ? ssum / isum : 0.0;
             efc = (isum > 0) ? fsum / isum : 0.0;
@@ -1019,10 +1032,14 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             Q.tfp[r] = ok ? rr : 0.0f;
         }
         // weight table around the template centre (features_utils.py:9-25), centred index
+        // A centre at scan 0.5 exactly (the two scan slots hold the same row: whenever the float64 sums above are
+        // exact) gives both slots the same weights, (-0.5)^2 = 0.5^2: one evaluation serves both.
+        const bool twin = __all(esc == 0.5 || !alive);
+        const int n_wt = twin ? FM : 2 * FM;
 #pragma unroll 1  // (pass after pass: interleaved float64 exp() evaluations cost registers the rows need)
-        for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
-            const int idx = min(sub + 16 * pass, 2 * FM - 1);
-            const int sc = idx / FM, r = idx - sc * FM;
+        for (int pass = 0; pass * 16 < n_wt; ++pass) {
+            const int idx = min(sub + 16 * pass, n_wt - 1);
+            const int sc = idx >= FM ? 1 : 0, r = idx - sc * FM;
             const int f = r + shift;
             const bool ok = alive && f >= 0 && f < F;
             double wv = 0.0;
@@ -1031,6 +1048,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
                 wv = exp(-0.1 * sqrt(ds * ds + df * df));
             }
             Q.wt[sc][r] = wv;
+            if (twin) Q.wt[1][r] = wv;
         }
         adh_wave_sync();
         if (stop_phase == 32) return;
@@ -1050,13 +1068,15 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             for (int sc = 0; sc < 2; ++sc) {
                 FU_FOR_R {
                     const double wv = wrow[sc * FM + r];
-                    float a = A[r], b = B[r];
-                    FU_OPAQUE(a);
-                    FU_OPAQUE(b);
+                    FU_OPAQUE(A[r]);  // (in place: the conversions below are redone per scan slot, not kept)
+                    FU_OPAQUE(B[r]);
+                    const float a = A[r], b = B[r];
+                    // the weight of a cell that holds something: wv x 1.0 + wo rounds once, like wo + wv; wv x 0.0
+                    // adds +0 (one select on the high word of the indicator instead of two on the weight)
                     vo += (double)a * wv;
-                    if (a > 0.0f) wo += wv;
+                    wo = __builtin_fma(wv, __hiloint2double(a > 0.0f ? 0x3ff00000 : 0, 0), wo);
                     vm += (double)b * wv;
-                    if (b > 0.0f) wm += wv;
+                    wm = __builtin_fma(wv, __hiloint2double(b > 0.0f ? 0x3ff00000 : 0, 0), wm);
                     FU_FENCE(r);
                 }
             }
@@ -1408,7 +1428,8 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             float v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = (j < K) ? Q.u.nrmT[sub][j] : INFINITY;
-            fast::sort16(v);
+            static_assert(KMAX <= 12, "the median network sorts twelve inputs");
+            fast::sort_first12(v);  // (KMAX = 12: v[12..15] are +inf and stay where they are)
             const int r_lo = (K - 1) / 2, r_hi = K / 2;
             float lo_v = 0.0f, hi_v = 0.0f;
 #pragma unroll
@@ -1469,7 +1490,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     }
     if (NO == 1) profile_stats<FM>(P, Q.tfp, F, shift, rt_width, ftc_l[0], fw_l[0], fpeak_l[0]);
 #pragma unroll
-    for (int o = 0; o < NO; ++o) Q.fpeak[sub][o] = fpeak_l[o];
+    for (int o = 0; o < NO; ++o) Q.fpeak[sub][o] = present ? fpeak_l[o] : INT_MAX;  // (an absent lane ranks behind every apex)
     if (stop_phase == 62) return;
     if (present) Q.corr[kk] = corr_l;
     adh_wave_sync();
@@ -1484,8 +1505,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
                 const int va = fpeak_l[o];
                 int rk = 0;
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    if (!((gm >> b) & 1u)) continue;
+                for (int b = 0; b < KMAX; ++b) {  // (fragment lanes only; absent ones hold INT_MAX)
                     const int vb = Q.fpeak[b][o];
                     rk += (vb < va) || (vb == va && b < sub);
                 }

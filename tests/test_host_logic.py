@@ -374,3 +374,22 @@ def test_assemble_rejects_an_index_a_library_with_duplicates_lacks():
     ok = cand.assign(precursor_idx=np.array([3], np.uint32))
     soa = assemble_candidates(ok, lib, "mz_library")
     assert float(soa["precursor_mz"][0]) == 800.0
+
+
+def test_the_median_network_of_the_fused_kernel_sorts_every_zero_one_input():
+    """`ADH_SORT12_NETWORK` (adh_features_fast.hip) replaces the 16-input bitonic sort in the per-cycle median of the
+    fused kernel (scoring_utils.py:120-152 takes np.median of <= 12 fragments): by the zero-one principle a
+    compare-exchange network that sorts all 2^12 zero-one inputs sorts everything."""
+    import os
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alphadia_amd", "csrc",
+                            "adh_features_fast.hip")).read()
+    body = src[src.index("#define ADH_SORT12_NETWORK(CE)"):]
+    body = body[:body.index("\n\n")]
+    pairs = [(int(a), int(b)) for a, b in re.findall(r"CE\((\d+), (\d+)\)", body)]
+    assert len(pairs) == 39 and all(0 <= a < b < 12 for a, b in pairs)
+    bits = ((np.arange(1 << 12)[:, None] >> np.arange(12)[None, :]) & 1).astype(np.int8)
+    for a, b in pairs:
+        lo, hi = np.minimum(bits[:, a], bits[:, b]), np.maximum(bits[:, a], bits[:, b])
+        bits[:, a], bits[:, b] = lo, hi
+    assert (np.diff(bits, axis=1) >= 0).all()
