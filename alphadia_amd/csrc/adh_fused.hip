@@ -1618,11 +1618,37 @@ constexpr size_t adh_fused_lds_bytes(int fm_max, int no) {
 // observation the bodies for 28 and 32 cycles are the only ones that do not fit the registers of three
 // wavefronts per SIMD (120 / 252 bytes of scratch per lane, 2.5 GB of spill stores per 3 M candidates):
 // they run at two, without a spill, in a launch of their own.
+// The arguments travel as ONE struct and the kernel reads them through the kernel-argument segment pointer where it
+// needs them: as formal parameters all ~150 dwords are loaded in the prologue, do not fit the scalar registers beside
+// the rest, get parked in the lanes of three vector registers and come back one v_readlane (a vector-ALU slot in a
+// kernel that is bound by them) per dword and use - ~300 per wavefront.  Scalar loads from the (cached, read-only)
+// segment at the point of use cost the vector ALUs nothing.
+struct FusedArgs {
+    DevRun run;
+    const LibRec *lib;
+    const CandRec *plan;
+    FusedClasses fc;
+    const float *iso_table;
+    int32_t n_iso_cols;
+    adh_scoring_config_t cfg;
+    const double *wtp_table;
+    DevOut out;
+    int32_t stop_phase;
+};
 template <int FM_MIN, int FM_MAX, int NO, int TW>
 __global__ __launch_bounds__(ADH_WAVE, (NO == 1 && FM_MAX <= ADH_FUSED_FM3) ? ADH_FUSED_WAVES : ADH_FUSED_WAVES2) void adh_fused_kernel(
-    DevRun run, const LibRec *__restrict__ lib, const CandRec *__restrict__ plan, FusedClasses fc,
-    const float *__restrict__ iso_table, int32_t n_iso_cols, adh_scoring_config_t cfg,
-    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    FusedArgs formal_args_not_read) {
+    const FusedArgs &A = *(const FusedArgs *)__builtin_amdgcn_kernarg_segment_ptr();  // (the only argument: offset 0)
+    const DevRun &run = A.run;
+    const LibRec *__restrict__ lib = A.lib;
+    const CandRec *__restrict__ plan = A.plan;
+    const FusedClasses &fc = A.fc;
+    const float *__restrict__ iso_table = A.iso_table;
+    const int32_t n_iso_cols = A.n_iso_cols;
+    const adh_scoring_config_t &cfg = A.cfg;
+    const double *__restrict__ wtp_table = A.wtp_table;
+    const DevOut &out = A.out;
+    const int32_t stop_phase = A.stop_phase;
     __shared__ __align__(16) unsigned char smem[adh_fused_lds_bytes<TW>(FM_MAX, NO)];
     const int32_t b = (int32_t)blockIdx.x;
     int c = 0;

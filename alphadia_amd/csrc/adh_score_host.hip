@@ -697,7 +697,7 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         if (n_streams > 1) HIP_TRY(hipEventRecord(h->ev_fork, st));
 #define ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, TW)                                                                    \
     hipLaunchKernelGGL((adh_fused_kernel<FM_MIN, FM_MAX, NO, TW>), dim3((unsigned)fblocks[W]), dim3(ADH_WAVE), 0, lst,   \
-                       h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase)
+                       (FusedArgs{h->run, h->d_lib, p.d_recs, fcs[W], h->cs.iso, (int32_t)n_iso, *cfg, h->d_wtp, *out, (int32_t)stop_phase}))
 #define ADH_LAUNCH_FUSED(W, FM_MIN, FM_MAX, NO)                                                 \
     if (fblocks[W] > 0) {                                                                       \
         lst = st;                                                                               \
