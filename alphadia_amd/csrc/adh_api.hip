@@ -208,6 +208,7 @@ struct Plan {
     uint32_t top_k_fragments = 0, top_k_isotopes = 0;
     bool fast_ok = false;          // register kernels enabled (experimental_xic)
     bool fused_ok = false;         // fused gather + feature kernel enabled
+    bool wide_ok = false;          // wide register kernels (17 ... 64 fragments kept) enabled
     bool quant_all = false;
     int64_t row0 = 0, n = 0;
     CandRec *d_recs = nullptr;

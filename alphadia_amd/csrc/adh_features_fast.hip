@@ -22,8 +22,13 @@
 //     and the rows are added into the fragment's summed profile
 //
 // Eligibility (decided by the host plan): O <= ADH_FAST_OMAX observations (and quant_all when
-// O > 1), 3 <= F <= 32, k_cap <= 16, I <= 4, experimental_xic = True.  Everything else runs
-// through adh_feature_kernel.
+// O > 1), 3 <= F <= 32, k_cap <= 16, I <= 4, experimental_xic = True.
+//
+// The WIDE form (template parameter GS = 64, round 5): the same code with ONE candidate per wavefront and 64
+// fragment lanes, for candidates that keep 17 ... 64 fragments - transfer-library requantification scores with
+// top_k_fragments = 9999 against libraries of 20 - 40 fragments per precursor.  Only the per-cycle median differs:
+// a lane per cycle sorts the column of all K fragments in registers (bitonic network of 32 or 64 inputs).
+// Everything else runs through adh_feature_kernel.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
@@ -40,30 +45,30 @@ __device__ __forceinline__ double logistic(double x, double mu, double sigma) {
     return 1.0 / (1.0 + exp(-a));
 }
 
-template <int FM, int NO>
+template <int FM, int NO, int GS = 16>
 struct __attribute__((aligned(16))) GroupLds {
     union {
         double dT[4][FM];    // isotope contributions to the template of one observation
-        float nrmT[16][17];        // transpose buffer for the per-cycle median (padded rows)
+        float nrmT[GS == 16 ? 16 : FM][GS + 1];  // transpose buffer for the per-cycle median (padded rows)
         struct {                   // per-fragment terms of the feature sums: [fragment][sum]
-            double t64[16][6];
-            float t32[16][6];
+            double t64[GS][6];
+            float t32[GS][6];
         } at;
     } u;
     double wt[2][FM];        // exp weights around the template centre of one observation, centred index
-    double merr[16];
-    double ohe[16][NO], omz[16][NO];  // [fragment lane][observation]
+    double merr[GS];
+    double ohe[GS][NO], omz[GS][NO];  // [fragment lane][observation]
     double hp[4], omzp[4], qtf[4][NO];
     double red64[12];        // results of the float64 sums
     float tpl[NO][FM], tfp[FM], frt[FM], med[FM];  // centred index
-    float g_int[16], g_fin[16], corr[16];
-    float rowsum[16][NO], ftc[16][NO], fw[16][NO];  // [fragment lane][o]
-    int fpeak[16][NO];
+    float g_int[GS], g_fin[GS], corr[GS];
+    float rowsum[GS][NO], ftc[GS][NO], fw[GS][NO];  // [fragment lane][o]
+    int fpeak[GS][NO];
     float iso_mz[4], iso_int[4], spi[4];
     float oi[NO], tsum[NO], qmask[NO];
     float red32[8];          // results of the float32 sums
     float feat[ADH_NUM_FEATURES + 2];
-    int ord[16];
+    int ord[GS];
     int medlo[NO], medhi[NO];
 };
 
@@ -142,6 +147,36 @@ __device__ __forceinline__ void sort16(float (&v)[16]) {
             }
         }
     }
+}
+
+// ascending bitonic sort of N registers (N a power of two)
+template <int N>
+__device__ __forceinline__ void sort_pow2(float (&v)[64]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                int l = i ^ j;
+                if (l > i) {
+                    float a = v[i], b = v[l];
+                    float lo = fminf(a, b), hi = fmaxf(a, b);
+                    bool up = (i & k) == 0;
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+// the lanes of a candidate's group that answer `p`, bit 0 = the group's first lane
+template <int GS>
+__device__ __forceinline__ unsigned long long group_ballot(bool p, unsigned gsh) {
+    const unsigned long long b = __ballot(p);
+    if constexpr (GS == 64) return b;
+    else return (b >> gsh) & ((1ull << GS) - 1ull);
 }
 
 // ascending sort of v[0..11] (39 compare-exchanges in 9 layers, the optimal 12-input network; checked against all
@@ -237,7 +272,7 @@ __global__ void adh_wtp_table_kernel(double *table) {
     table[i] = exp(-0.1 * sqrt(ds * ds + df * df));
 }
 
-template <int FM, int NO>
+template <int FM, int NO, int GS = 16>
 __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     DevRun run, const CandRec *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
     int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
@@ -245,7 +280,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     using namespace fast;
     constexpr int RC = FM / 2;
     constexpr int O = NO;  // every candidate of this launch has NO observations (host plan)
-    __shared__ GroupLds<FM, NO> lds[ADH_WAVE / ADH_GS];
+    static_assert(GS == 16 || GS == 64, "16 lanes per candidate, or the whole wavefront");
+    __shared__ GroupLds<FM, NO, GS> lds[ADH_WAVE / GS];
     __shared__ double wtp_s[2][FM];
     const int lane = threadIdx.x;
     // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), f < F <= FM: the "expected
@@ -255,10 +291,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         wtp_s[1][lane] = wtp_table[64 + lane];
     }
     __syncthreads();
-    const int g = lane / ADH_GS, sub = lane % ADH_GS;
-    const unsigned gsh = (unsigned)(g * ADH_GS);
-    GroupLds<FM, NO> &L = lds[g];
-    const int ci = blockIdx.x * (ADH_WAVE / ADH_GS) + g;
+    const int g = lane / GS, sub = lane % GS;
+    const unsigned gsh = (unsigned)(g * GS);
+    GroupLds<FM, NO, GS> &L = lds[g];
+    const int ci = blockIdx.x * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
     const CandRec &rec = plan[alive ? ci : 0];
     alive = alive && !(rec.flags & ADH_FLAG_SKIP);
@@ -278,8 +314,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     const float rt_width = alive ? run.rt[rec.frame_stop - 1] - run.rt[rec.frame_start] : 0.0f;
     if (alive && sub == 0 && out.stat_matched_peaks) out.stat_matched_peaks[row] = header[1];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (sub + 16 * j < ADH_NUM_FEATURES + 2) L.feat[sub + 16 * j] = 0.0f;
+    for (int j = 0; j < (ADH_NUM_FEATURES + 2 + GS - 1) / GS; ++j)
+        if (sub + GS * j < ADH_NUM_FEATURES + 2) L.feat[sub + GS * j] = 0.0f;
     // location features (location_features.py:8-33) right away: their four table look-ups would
     // otherwise sit, exposed, in the middle of the single-lane feature assembly
     float loc = 0.0f;
@@ -367,8 +403,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             }
             __syncthreads();
 #pragma unroll
-            for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-                int r = sub + 16 * pass;
+            for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+                int r = sub + GS * pass;
                 if (r < FM) {
                     double acc = 0;
                     for (int i = 0; i < I; ++i) acc += L.u.dT[i][r];
@@ -395,8 +431,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     }
     // frame RTs
 #pragma unroll
-    for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-        int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+    for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+        int r = min(sub + GS * pass, FM - 1);  // (duplicates of the last row write the same value)
         int f = r + shift;
         bool ok = alive && f >= 0 && f < F;
         L.frt[r] = ok ? run.rt[rec.frame_start + f * Lc] : 0.0f;
@@ -442,8 +478,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         __syncthreads();  // the previous observation's tables were consumed
         // template frame profile with or_envelope (scoring/utils.py:46-53)
 #pragma unroll
-        for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
-            int r = min(sub + 16 * pass, FM - 1);  // (duplicates of the last row write the same value)
+        for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+            int r = min(sub + GS * pass, FM - 1);  // (duplicates of the last row write the same value)
             int f = r + shift;
             bool ok = alive && f >= 0 && f < F;
             float x = L.tpl[o][r] + L.tpl[o][r];
@@ -460,8 +496,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         }
         // weight table around the template centre (features_utils.py:9-25), centred index
 #pragma unroll
-        for (int pass = 0; pass < (2 * FM + 15) / 16; ++pass) {
-            int idx = min(sub + 16 * pass, 2 * FM - 1);
+        for (int pass = 0; pass < (2 * FM + GS - 1) / GS; ++pass) {
+            int idx = min(sub + GS * pass, 2 * FM - 1);
             int sc = idx / FM, r = idx - sc * FM;
             int f = r + shift;
             bool ok = alive && f >= 0 && f < F;
@@ -540,10 +576,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     LibRec lrec;
     if (frag_lane0) lrec = reinterpret_cast<const LibRec *>(block + 32)[sub];
     bool present = frag_lane0 && so > 0.0f;
-    const unsigned long long bal = __ballot(present);
-    const unsigned gm = (unsigned)((bal >> gsh) & 0xFFFFull);
-    int K = __popc(gm);
-    const int kk = __popc(gm & ((1u << sub) - 1u));
+    const unsigned long long gm = group_ballot<GS>(present, gsh);
+    int K = __popcll(gm);
+    const int kk = __popcll(gm & ((1ull << sub) - 1ull));
     const int n_present = K;
     if (K < 2) {  // candidate.py:323
         alive = false;
@@ -666,20 +701,20 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     const bool ipos = present && obs_int > 0.0f;
     const bool hpos = present && m2 > 0.0;
     const bool isb = present && lrec.type == 98, isy = present && lrec.type == 121;
-    const unsigned b_isb = (unsigned)((__ballot(isb) >> gsh) & 0xFFFFull);
-    const unsigned b_isy = (unsigned)((__ballot(isy) >> gsh) & 0xFFFFull);
-    const int n_int = __popc((unsigned)((__ballot(ipos) >> gsh) & 0xFFFFull));
-    const int n_hei = __popc((unsigned)((__ballot(hpos) >> gsh) & 0xFFFFull));
-    const int n_hrows = __popc((unsigned)((__ballot(present && hrow) >> gsh) & 0xFFFFull));
-    const int nb = __popc(b_isb), ny = __popc(b_isy);
+    const unsigned long long b_isb = group_ballot<GS>(isb, gsh);
+    const unsigned long long b_isy = group_ballot<GS>(isy, gsh);
+    const int n_int = __popcll(group_ballot<GS>(ipos, gsh));
+    const int n_hei = __popcll(group_ballot<GS>(hpos, gsh));
+    const int n_hrows = __popcll(group_ballot<GS>(present && hrow, gsh));
+    const int nb = __popcll(b_isb), ny = __popcll(b_isy);
     int min_y = isy ? (int)lrec.position : 255, max_b = isb ? (int)lrec.position : 0;
 #pragma unroll
-    for (int m = 8; m > 0; m >>= 1) {
-        min_y = min(min_y, __shfl_xor(min_y, m, ADH_GS));
-        max_b = max(max_b, __shfl_xor(max_b, m, ADH_GS));
+    for (int m = GS / 2; m > 0; m >>= 1) {
+        min_y = min(min_y, __shfl_xor(min_y, m, GS));
+        max_b = max(max_b, __shfl_xor(max_b, m, GS));
     }
     const bool ov = (isy && (int)lrec.position < max_b) || (isb && (int)lrec.position > min_y);
-    const int n_ov = __popc((unsigned)((__ballot(ov) >> gsh) & 0xFFFFull));
+    const int n_ov = __popcll(group_ballot<GS>(ov, gsh));
     const int n3 = min(K, 3);
     if (present) {
         double *t = L.u.at.t64[kk];
@@ -793,6 +828,51 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         sm += P[RC + 1];
         const double cn = (double)sm / 3.0;
         // median over fragments per cycle (scoring_utils.py:120-152): 16x16 transposes via LDS
+        if constexpr (GS == 64) {
+            // wide form: the whole [cycle][fragment] table at once, then lane r < FM sorts column r
+            __syncthreads();  // previous users of the union are done
+            if (present) {
+                FOR_R {
+                    float x = P[r];
+                    L.u.nrmT[r][kk] = (cn > 0) ? (float)((double)x / cn) : 0.0f;
+                    if ((r & 3) == 3) __asm__ volatile("" ::: "memory");  // bound the in-flight divisions
+                }
+            }
+            __syncthreads();
+            const int r_lo = (K - 1) / 2, r_hi = K / 2;
+            float lo_v = 0.0f, hi_v = 0.0f;
+            if (sub < FM) {
+                float v[64];
+                if (K <= 32) {  // (one candidate per wavefront: the branch is uniform)
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) v[j] = (j < K) ? L.u.nrmT[sub][j] : INFINITY;
+                    sort_pow2<32>(v);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        lo_v = (j == r_lo) ? v[j] : lo_v;
+                        hi_v = (j == r_hi) ? v[j] : hi_v;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 64; ++j) v[j] = (j < K) ? L.u.nrmT[sub][j] : INFINITY;
+                    sort_pow2<64>(v);
+#pragma unroll
+                    for (int j = 0; j < 64; ++j) {
+                        lo_v = (j == r_lo) ? v[j] : lo_v;
+                        hi_v = (j == r_hi) ? v[j] : hi_v;
+                    }
+                }
+                float m;
+                if (K & 1) {
+                    m = hi_v;
+                } else {
+                    float s2 = lo_v + hi_v;
+                    m = (float)((double)s2 / 2.0);
+                }
+                const int f = sub + shift;
+                L.med[sub] = (alive && f >= 0 && f < F) ? m : 0.0f;
+            }
+        } else {
 #pragma unroll
         for (int half = 0; half < (FM + 15) / 16; ++half) {
             __syncthreads();  // previous users of the union are done
@@ -827,6 +907,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             const int r = half * 16 + sub;
             const int f = r + shift;
             if (r < FM) L.med[r] = (alive && f >= 0 && f < F) ? m : 0.0f;
+        }
         }
     }
     __syncthreads();
@@ -893,8 +974,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
                 const int va = L.fpeak[sub][o];
                 int rk = 0;
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    if (!((gm >> b) & 1u)) continue;
+                for (int b = 0; b < GS; ++b) {
+                    if (GS > 16 && b >= K0) break;  // (wide form: a real loop over the lanes that hold a fragment)
+                    if (!((gm >> b) & 1ull)) continue;
                     int vb = L.fpeak[b][o];
                     rk += (vb < va) || (vb == va && b < sub);
                 }
@@ -903,8 +985,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             }
             const float cr = L.corr[L.ord[kk]];  // correlation of the fragment with intensity rank kk
             // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
-            const bool b3 = isb && __popc(b_isb & ((1u << sub) - 1u)) < 3;
-            const bool y3 = isy && __popc(b_isy & ((1u << sub) - 1u)) < 3;
+            const bool b3 = isb && __popcll(b_isb & ((1ull << sub) - 1ull)) < 3;
+            const bool y3 = isy && __popcll(b_isy & ((1ull << sub) - 1ull)) < 3;
             float rr = 0.0f, ml = 0.0f;
 #pragma unroll
             for (int o = 0; o < NO; ++o) rr += L.ftc[sub][o] * L.oi[o];
@@ -954,8 +1036,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     // ---- output row (candidate.py:403-481)
     if (alive) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            int idx = sub + 16 * j;
+        for (int j = 0; j < (ADH_NUM_FEATURES + GS - 1) / GS; ++j) {
+            int idx = sub + GS * j;
             if (idx < ADH_NUM_FEATURES) out.features[(int64_t)row * ADH_NUM_FEATURES + idx] = L.feat[idx];
         }
         if (cfg.collect_fragments && present && kk < top_k) {

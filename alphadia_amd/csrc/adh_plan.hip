@@ -27,7 +27,11 @@
 //  14 .. 16  register kernels for two observations (FM = 16, 24, 32) behind the gather kernel: shapes the
 //            fused kernel does not take (more than 12 fragments kept, library slices beyond 64)
 //  17 .. 23  register kernels for one observation (FM = 8 ... 32) behind the gather kernel, likewise
-//  24        the generic LDS kernel behind the gather kernel
+//  24 .. 26  the WIDE register kernels (one candidate per wavefront, 64 fragment lanes; FM = 16, 24, 32) for two
+//            observations: candidates of the register shape that keep 17 ... 64 fragments (transfer-library
+//            requantification, top_k_fragments = 9999)
+//  27 .. 29  the same for one observation
+//  30        the generic LDS kernel behind the gather kernel
 // ion-mobility plans use classes 0 (one observation), 1 (two), ADH_CLASS_IM_SMALL (one observation, a tile
 // within the limits below: a feature-kernel instantiation with 12.8 KB of LDS instead of 16.3) and the generic one
 #define ADH_CLASS_IM_SMALL 2
@@ -39,8 +43,11 @@
 #define ADH_CLASS_FUSED2 7
 #define ADH_CLASS_FAST2 14
 #define ADH_CLASS_FAST1 17
-#define ADH_CLASS_GENERIC 24
-#define ADH_N_CLASSES 25
+#define ADH_CLASS_WIDE2 24
+#define ADH_CLASS_WIDE1 27
+#define ADH_CLASS_GENERIC 30
+#define ADH_N_CLASSES 31
+#define ADH_PLAN_WIDE_KMAX 64
 
 // mirrors of the register-kernel limits (adh_features_fast.hip)
 #define ADH_PLAN_FMAX 32
@@ -85,7 +92,7 @@ struct PlanArgs {
     int32_t zeroth;         // ion mobility: 1 when frame 0 is the empty alphatims frame
     int32_t I;              // isotopes used
     uint32_t top_k;
-    int32_t fast_cfg, quant_all;
+    int32_t fast_cfg, quant_all;  // fast_cfg: bit 0 the register kernels, bit 1 their wide form
     int32_t fused_cfg;      // the fused kernel may be used (one MS1 row per cycle, <= 3 isotopes): bit 0 for one, bit 1 for two observations
     int32_t n_cyc_bins;     // first-cycle bins per class in the sort key
 };
@@ -178,16 +185,18 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
             const int F = r.frame_stop / p.L - r.frame_start / p.L;
             // shape handled by the register-resident kernels (adh_features_fast.hip); several
             // observations only with quant_all
-            const bool shape = p.fast_cfg && O >= 1 && O <= ADH_PLAN_FAST_OMAX && F >= 3 && F <= ADH_PLAN_FMAX && r.k_cap <= 16 &&
-                               p.I <= 4;
+            const bool shape_any_k = (p.fast_cfg & 1) && O >= 1 && O <= ADH_PLAN_FAST_OMAX && F >= 3 && F <= ADH_PLAN_FMAX && p.I <= 4;
+            const bool shape = shape_any_k && r.k_cap <= 16;
             const bool fast = shape && (O == 1 || p.quant_all);
+            const bool wide = shape_any_k && (p.fast_cfg & 2) && r.k_cap > 16 && r.k_cap <= ADH_PLAN_WIDE_KMAX && (O == 1 || p.quant_all);
             // gather and features in one kernel (adh_fused.hip): lanes 12..15 of a 16-lane group carry the isotopes;
             // it quantifies the best of two observations itself when quant_all is off (round 4)
             const bool fused = shape && ((p.fused_cfg >> (O - 1)) & 1) && r.k_cap <= 12 && nl <= 64;
             cls = fused ? (O == 1 ? ADH_CLASS_FUSED0 : ADH_CLASS_FUSED2) + max(F - 5, 0) / 4
-                        : (!fast ? ADH_CLASS_GENERIC
-                                 : (O == 1 ? ADH_CLASS_FAST1 + max(F - 5, 0) / 4
-                                           : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2))));
+                        : (wide ? (O == 1 ? ADH_CLASS_WIDE1 : ADH_CLASS_WIDE2) + (F <= 16 ? 0 : (F <= 24 ? 1 : 2))
+                           : (!fast ? ADH_CLASS_GENERIC
+                                    : (O == 1 ? ADH_CLASS_FAST1 + max(F - 5, 0) / 4
+                                              : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)))));
             bin = (uint32_t)(r.frame_start / p.L);
             nbytes = fused ? 0 : adh_scratch_bytes(r.k_cap, O, max(F, 0), p.I);  // nothing leaves the CU there
             if (live) {

@@ -295,13 +295,14 @@ int plan_reserve(adh_handle *h, PlanSlot &s, int64_t n, bool im) {
 
 struct PlanKey {
     uint32_t top_k_fragments, top_k_isotopes;
-    bool fast_cfg, quant_all, fused_cfg;
+    bool fast_cfg, quant_all, fused_cfg, wide_cfg;
 };
 
 PlanKey plan_key(const adh_scoring_config_t *cfg) {
     const bool fast = cfg->experimental_xic != 0 && !getenv("ADH_DEBUG_NO_FAST");
     return PlanKey{cfg->top_k_fragments, cfg->top_k_isotopes, fast, cfg->quant_all != 0,
-                   fast && !getenv("ADH_DEBUG_NO_FUSED")};  // developer switches: two-kernel path only
+                   fast && !getenv("ADH_DEBUG_NO_FUSED"),   // developer switches: two-kernel path only
+                   fast && !getenv("ADH_DEBUG_NO_WIDE")};   // ... more than 16 kept fragments through the generic kernel
 }
 
 // enqueue the plan of rows [row0, row0 + n) on `st`; plan_finish() waits for it
@@ -316,7 +317,7 @@ int plan_enqueue(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, in
     p.n_lib = h->n_lib;
     p.I = (int32_t)std::min<uint32_t>(cfg->top_k_isotopes, (uint32_t)h->cs.n_iso_cols);
     p.top_k = cfg->top_k_fragments;
-    p.fast_cfg = key.fast_cfg ? 1 : 0;
+    p.fast_cfg = (key.fast_cfg ? 1 : 0) | (key.wide_cfg ? 2 : 0);
     p.quant_all = key.quant_all ? 1 : 0;
     p.fused_cfg = (key.fused_cfg && !im && h->run.n_ms1_obs == 1 && p.I <= 4) ? (getenv("ADH_DEBUG_NO_FUSED2") ? 1 : 3) : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -423,6 +424,7 @@ int plan_finish(adh_handle *h, PlanSlot &s, const adh_scoring_config_t *cfg, int
     p.top_k_isotopes = key.top_k_isotopes;
     p.fast_ok = key.fast_cfg;
     p.fused_ok = key.fused_cfg;
+    p.wide_ok = key.wide_cfg;
     p.quant_all = key.quant_all;
     p.ready = true;
     return ADH_OK;
@@ -734,10 +736,19 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                 } else {
                     const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                     const int32_t nc = (int32_t)p.n_class[c];
+#define ADH_LAUNCH_WIDE(FM, NO)                                                                                       \
+    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO, 64>), dim3((unsigned)nc), dim3(ADH_WAVE), 0, st, h->run, recs, \
+                       nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
 #define ADH_LAUNCH_FAST(FM, NO)                                                                              \
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
                        nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
                     switch (c) {
+                        case ADH_CLASS_WIDE2 + 0: ADH_LAUNCH_WIDE(16, 2); break;
+                        case ADH_CLASS_WIDE2 + 1: ADH_LAUNCH_WIDE(24, 2); break;
+                        case ADH_CLASS_WIDE2 + 2: ADH_LAUNCH_WIDE(32, 2); break;
+                        case ADH_CLASS_WIDE1 + 0: ADH_LAUNCH_WIDE(16, 1); break;
+                        case ADH_CLASS_WIDE1 + 1: ADH_LAUNCH_WIDE(24, 1); break;
+                        case ADH_CLASS_WIDE1 + 2: ADH_LAUNCH_WIDE(32, 1); break;
                         case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
                         case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
                         case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
@@ -750,6 +761,7 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                         default: ADH_LAUNCH_FAST(32, 1); break;
                     }
 #undef ADH_LAUNCH_FAST
+#undef ADH_LAUNCH_WIDE
                 }
                 HIP_TRY(hipGetLastError());
             }
@@ -1094,7 +1106,7 @@ int adh_score_uploaded(adh_handle_t *h, const adh_scoring_config_t *cfg, adh_out
     Plan &p = h->plan;
     const PlanKey key = plan_key(cfg);
     if (!(p.ready && p.top_k_fragments == key.top_k_fragments && p.top_k_isotopes == key.top_k_isotopes &&
-          p.fast_ok == key.fast_cfg && p.fused_ok == key.fused_cfg && p.quant_all == key.quant_all)) {
+          p.fast_ok == key.fast_cfg && p.fused_ok == key.fused_cfg && p.wide_ok == key.wide_cfg && p.quant_all == key.quant_all)) {
         p = Plan();
         rc = plan_enqueue(h, h->slots[0], cfg, 0, h->cs.n, st);
         if (rc == ADH_OK) rc = plan_finish(h, h->slots[0], cfg, 0, h->cs.n, p);
