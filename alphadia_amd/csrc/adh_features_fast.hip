@@ -24,8 +24,8 @@
 // Eligibility (decided by the host plan): O <= ADH_FAST_OMAX observations (and quant_all when
 // O > 1), 3 <= F <= 32, k_cap <= 16, I <= 4, experimental_xic = True.
 //
-// The WIDE form (template parameter GS = 64, round 5): the same code with ONE candidate per wavefront and 64
-// fragment lanes, for candidates that keep 17 ... 64 fragments - transfer-library requantification scores with
+// The WIDE forms (template parameter GS = 32 / 64, round 5): the same code with two candidates per wavefront and 32
+// fragment lanes each, or ONE candidate and 64 lanes, for candidates that keep 17 ... 32 / 33 ... 64 fragments - transfer-library requantification scores with
 // top_k_fragments = 9999 against libraries of 20 - 40 fragments per precursor.  Only the per-cycle median differs:
 // a lane per cycle sorts the column of all K fragments in registers (bitonic network of 32 or 64 inputs).
 // Everything else runs through adh_feature_kernel.
@@ -150,8 +150,9 @@ __device__ __forceinline__ void sort16(float (&v)[16]) {
 }
 
 // ascending bitonic sort of N registers (N a power of two)
-template <int N>
-__device__ __forceinline__ void sort_pow2(float (&v)[64]) {
+template <int N, int M>
+__device__ __forceinline__ void sort_pow2(float (&v)[M]) {
+    static_assert(N <= M, "sorts the first N of M registers");
 #pragma unroll
     for (int k = 2; k <= N; k <<= 1) {
 #pragma unroll
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     using namespace fast;
     constexpr int RC = FM / 2;
     constexpr int O = NO;  // every candidate of this launch has NO observations (host plan)
-    static_assert(GS == 16 || GS == 64, "16 lanes per candidate, or the whole wavefront");
+    static_assert(GS == 16 || GS == 32 || GS == 64, "16 or 32 lanes per candidate, or the whole wavefront");
     __shared__ GroupLds<FM, NO, GS> lds[ADH_WAVE / GS];
     __shared__ double wtp_s[2][FM];
     const int lane = threadIdx.x;
@@ -828,8 +829,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         sm += P[RC + 1];
         const double cn = (double)sm / 3.0;
         // median over fragments per cycle (scoring_utils.py:120-152): 16x16 transposes via LDS
-        if constexpr (GS == 64) {
-            // wide form: the whole [cycle][fragment] table at once, then lane r < FM sorts column r
+        if constexpr (GS > 16) {
+            // wide forms: the whole [cycle][fragment] table at once, then lane r < FM sorts column r
             __syncthreads();  // previous users of the union are done
             if (present) {
                 FOR_R {
@@ -842,8 +843,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
             const int r_lo = (K - 1) / 2, r_hi = K / 2;
             float lo_v = 0.0f, hi_v = 0.0f;
             if (sub < FM) {
-                float v[64];
-                if (K <= 32) {  // (one candidate per wavefront: the branch is uniform)
+                float v[GS];
+                if (GS == 32 || K <= 32) {  // (GS = 64: one candidate per wavefront, the branch is uniform)
 #pragma unroll
                     for (int j = 0; j < 32; ++j) v[j] = (j < K) ? L.u.nrmT[sub][j] : INFINITY;
                     sort_pow2<32>(v);
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
                         lo_v = (j == r_lo) ? v[j] : lo_v;
                         hi_v = (j == r_hi) ? v[j] : hi_v;
                     }
-                } else {
+                } else if constexpr (GS == 64) {
 #pragma unroll
                     for (int j = 0; j < 64; ++j) v[j] = (j < K) ? L.u.nrmT[sub][j] : INFINITY;
                     sort_pow2<64>(v);

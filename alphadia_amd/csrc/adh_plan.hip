@@ -28,10 +28,11 @@
 //            fused kernel does not take (more than 12 fragments kept, library slices beyond 64)
 //  17 .. 23  register kernels for one observation (FM = 8 ... 32) behind the gather kernel, likewise
 //  24 .. 26  the WIDE register kernels (one candidate per wavefront, 64 fragment lanes; FM = 16, 24, 32) for two
-//            observations: candidates of the register shape that keep 17 ... 64 fragments (transfer-library
+//            observations: candidates of the register shape that keep 33 ... 64 fragments (transfer-library
 //            requantification, top_k_fragments = 9999)
 //  27 .. 29  the same for one observation
-//  30        the generic LDS kernel behind the gather kernel
+//  30 .. 35  the same pair with two candidates per wavefront, 32 lanes each: 17 ... 32 fragments kept
+//  36        the generic LDS kernel behind the gather kernel
 // ion-mobility plans use classes 0 (one observation), 1 (two), ADH_CLASS_IM_SMALL (one observation, a tile
 // within the limits below: a feature-kernel instantiation with 12.8 KB of LDS instead of 16.3) and the generic one
 #define ADH_CLASS_IM_SMALL 2
@@ -45,8 +46,10 @@
 #define ADH_CLASS_FAST1 17
 #define ADH_CLASS_WIDE2 24
 #define ADH_CLASS_WIDE1 27
-#define ADH_CLASS_GENERIC 30
-#define ADH_N_CLASSES 31
+#define ADH_CLASS_MID2 30
+#define ADH_CLASS_MID1 33
+#define ADH_CLASS_GENERIC 36
+#define ADH_N_CLASSES 37
 #define ADH_PLAN_WIDE_KMAX 64
 
 // mirrors of the register-kernel limits (adh_features_fast.hip)
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256) void adh_plan_rec_kernel(DevCands c, const dou
             // it quantifies the best of two observations itself when quant_all is off (round 4)
             const bool fused = shape && ((p.fused_cfg >> (O - 1)) & 1) && r.k_cap <= 12 && nl <= 64;
             cls = fused ? (O == 1 ? ADH_CLASS_FUSED0 : ADH_CLASS_FUSED2) + max(F - 5, 0) / 4
-                        : (wide ? (O == 1 ? ADH_CLASS_WIDE1 : ADH_CLASS_WIDE2) + (F <= 16 ? 0 : (F <= 24 ? 1 : 2))
+                        : (wide ? (r.k_cap <= 32 ? (O == 1 ? ADH_CLASS_MID1 : ADH_CLASS_MID2) : (O == 1 ? ADH_CLASS_WIDE1 : ADH_CLASS_WIDE2)) +
+                                      (F <= 16 ? 0 : (F <= 24 ? 1 : 2))
                            : (!fast ? ADH_CLASS_GENERIC
                                     : (O == 1 ? ADH_CLASS_FAST1 + max(F - 5, 0) / 4
                                               : ADH_CLASS_FAST2 + (F <= 16 ? 0 : (F <= 24 ? 1 : 2)))));

@@ -736,9 +736,12 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                 } else {
                     const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                     const int32_t nc = (int32_t)p.n_class[c];
-#define ADH_LAUNCH_WIDE(FM, NO)                                                                                       \
-    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO, 64>), dim3((unsigned)nc), dim3(ADH_WAVE), 0, st, h->run, recs, \
-                       nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
+#define ADH_LAUNCH_WIDE_GS(FM, NO, GS)                                                                                    \
+    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO, GS>), dim3((unsigned)((nc + ADH_WAVE / GS - 1) / (ADH_WAVE / GS))), \
+                       dim3(ADH_WAVE), 0, st, h->run, recs, nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out,          \
+                       (int32_t)stop_phase)
+#define ADH_LAUNCH_WIDE(FM, NO) ADH_LAUNCH_WIDE_GS(FM, NO, 64)
+#define ADH_LAUNCH_MID(FM, NO) ADH_LAUNCH_WIDE_GS(FM, NO, 32)
 #define ADH_LAUNCH_FAST(FM, NO)                                                                              \
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
                        nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
@@ -749,6 +752,12 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                         case ADH_CLASS_WIDE1 + 0: ADH_LAUNCH_WIDE(16, 1); break;
                         case ADH_CLASS_WIDE1 + 1: ADH_LAUNCH_WIDE(24, 1); break;
                         case ADH_CLASS_WIDE1 + 2: ADH_LAUNCH_WIDE(32, 1); break;
+                        case ADH_CLASS_MID2 + 0: ADH_LAUNCH_MID(16, 2); break;
+                        case ADH_CLASS_MID2 + 1: ADH_LAUNCH_MID(24, 2); break;
+                        case ADH_CLASS_MID2 + 2: ADH_LAUNCH_MID(32, 2); break;
+                        case ADH_CLASS_MID1 + 0: ADH_LAUNCH_MID(16, 1); break;
+                        case ADH_CLASS_MID1 + 1: ADH_LAUNCH_MID(24, 1); break;
+                        case ADH_CLASS_MID1 + 2: ADH_LAUNCH_MID(32, 1); break;
                         case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
                         case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
                         case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
@@ -762,6 +771,8 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                     }
 #undef ADH_LAUNCH_FAST
 #undef ADH_LAUNCH_WIDE
+#undef ADH_LAUNCH_MID
+#undef ADH_LAUNCH_WIDE_GS
                 }
                 HIP_TRY(hipGetLastError());
             }
