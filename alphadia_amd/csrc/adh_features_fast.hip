@@ -273,17 +273,26 @@ __global__ void adh_wtp_table_kernel(double *table) {
     table[i] = exp(-0.1 * sqrt(ds * ds + df * df));
 }
 
-template <int FM, int NO, int GS = 16>
-__global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
-    DevRun run, const CandRec *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
-    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
-    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+// LDS of one wavefront: the groups' blocks and the precursor weight table
+template <int FM, int NO, int GS>
+constexpr size_t adh_fast_lds_bytes() {
+    return sizeof(fast::GroupLds<FM, NO, GS>) * (ADH_WAVE / GS) + 2 * FM * sizeof(double);
+}
+
+// one wavefront = ADH_WAVE / GS candidates of a class; `wave_idx` counts the wavefronts of the class
+template <int FM, int NO, int GS>
+__device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *__restrict__ plan, int32_t n_cand, int32_t wave_idx,
+                                              const float *__restrict__ iso_table, int32_t n_iso_cols,
+                                              const adh_scoring_config_t &cfg, const unsigned char *__restrict__ scratch,
+                                              const double *__restrict__ wtp_table, const DevOut &out, int32_t stop_phase,
+                                              unsigned char *smem) {
     using namespace fast;
     constexpr int RC = FM / 2;
     constexpr int O = NO;  // every candidate of this launch has NO observations (host plan)
     static_assert(GS == 16 || GS == 32 || GS == 64, "16 or 32 lanes per candidate, or the whole wavefront");
-    __shared__ GroupLds<FM, NO, GS> lds[ADH_WAVE / GS];
-    __shared__ double wtp_s[2][FM];
+    static_assert(sizeof(GroupLds<FM, NO, GS>) % 16 == 0, "the blocks of the groups follow each other");
+    GroupLds<FM, NO, GS> *const lds = reinterpret_cast<GroupLds<FM, NO, GS> *>(smem);
+    double(*const wtp_s)[FM] = reinterpret_cast<double(*)[FM]>(smem + sizeof(GroupLds<FM, NO, GS>) * (ADH_WAVE / GS));
     const int lane = threadIdx.x;
     // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), f < F <= FM: the "expected
     // centre" (S, 1) of precursor_features.py:52-57 does not depend on the candidate
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
     GroupLds<FM, NO, GS> &L = lds[g];
-    const int ci = blockIdx.x * (ADH_WAVE / GS) + g;
+    const int ci = wave_idx * (ADH_WAVE / GS) + g;
     bool alive = ci < n_cand;
     const CandRec &rec = plan[alive ? ci : 0];
     alive = alive && !(rec.flags & ADH_FLAG_SKIP);
@@ -1063,4 +1072,56 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
         }
         if (sub == 0) out.valid[row] = 1;
     }
+}
+
+template <int FM, int NO, int GS = 16>
+__global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
+    DevRun run, const CandRec *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
+    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    __shared__ __align__(16) unsigned char smem[adh_fast_lds_bytes<FM, NO, GS>()];
+    adh_fast_body<FM, NO, GS>(run, plan, n_cand, (int32_t)blockIdx.x, iso_table, n_iso_cols, cfg, scratch, wtp_table, out,
+                              stop_phase, smem);
+}
+
+// The wide classes of one batch (17 ... 64 fragments kept) in ONE launch per observation count: a chunk of the
+// host -> host pipeline holds a few thousand candidates of each (cycles, lanes) class, a wavefront lives ~50 us, and
+// six launches of two rounds each spent most of their time filling and draining the GPU.
+#define ADH_WIDE_MAX_CLASSES 6
+struct WideClasses {
+    int32_t n;                                      // classes in this launch
+    int32_t first_block[ADH_WIDE_MAX_CLASSES + 1];  // first wavefront of class i; [n] = all
+    int32_t first_cand[ADH_WIDE_MAX_CLASSES];       // first candidate of the class, counted from `plan`
+    int32_t n_cand[ADH_WIDE_MAX_CLASSES];
+    int32_t kind[ADH_WIDE_MAX_CLASSES];             // (FM - 16) / 8 + 3 * (lanes per candidate == 32)
+};
+template <int NO>
+constexpr size_t adh_wide_lds_bytes() {
+    return adh_fast_lds_bytes<32, NO, 32>() > adh_fast_lds_bytes<32, NO, 64>() ? adh_fast_lds_bytes<32, NO, 32>()
+                                                                                 : adh_fast_lds_bytes<32, NO, 64>();
+}
+template <int NO>
+__global__ __launch_bounds__(ADH_WAVE) void adh_feature_wide_kernel(
+    DevRun run, const CandRec *__restrict__ plan, WideClasses wc, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
+    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+    __shared__ __align__(16) unsigned char smem[adh_wide_lds_bytes<NO>()];
+    const int32_t b = (int32_t)blockIdx.x;
+    int c = 0;
+    while (c + 1 < wc.n && b >= wc.first_block[c + 1]) ++c;
+    const CandRec *recs = plan + wc.first_cand[c];
+    const int32_t n = wc.n_cand[c], blk = b - wc.first_block[c];
+#define ADH_WIDE_CASE(KIND, FM, GS)                                                                                        \
+    if (wc.kind[c] == KIND) {                                                                                              \
+        static_assert(adh_fast_lds_bytes<FM, NO, GS>() <= adh_wide_lds_bytes<NO>(), "the block of the largest class");    \
+        adh_fast_body<FM, NO, GS>(run, recs, n, blk, iso_table, n_iso_cols, cfg, scratch, wtp_table, out, stop_phase, smem); \
+        return;                                                                                                            \
+    }
+    ADH_WIDE_CASE(0, 16, 64)
+    ADH_WIDE_CASE(1, 24, 64)
+    ADH_WIDE_CASE(2, 32, 64)
+    ADH_WIDE_CASE(3, 16, 32)
+    ADH_WIDE_CASE(4, 24, 32)
+    ADH_WIDE_CASE(5, 32, 32)
+#undef ADH_WIDE_CASE
 }

@@ -728,7 +728,43 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
     if (stop_phase != 2 && !fused_only) {
         int64_t first = n_fused;
         for (int c = ADH_CLASS_FAST2; c <= ADH_CLASS_GENERIC; ++c) {
-            if (p.n_class[c] > 0 && (c == ADH_CLASS_GENERIC ? run_generic : run_fast)) {
+            const bool wide_class = c >= ADH_CLASS_WIDE2 && c < ADH_CLASS_GENERIC;
+            if (wide_class && run_fast && (c == ADH_CLASS_WIDE2 || c == ADH_CLASS_WIDE1)) {
+                // the wide classes of one observation count in ONE launch: classes c .. c + 2 (one candidate per
+                // wavefront) and their 32-lane twins six classes further on
+                const int twin = c == ADH_CLASS_WIDE2 ? ADH_CLASS_MID2 : ADH_CLASS_MID1;
+                int64_t twin_first = first;
+                for (int q = c; q < twin; ++q) twin_first += p.n_class[q];
+                WideClasses wcs{};
+                int64_t blocks = 0, pos = first;
+                for (int j = 0; j < 6; ++j) {
+                    const int q = j < 3 ? c + j : twin + (j - 3);
+                    if (j == 3) pos = twin_first;
+                    const int64_t nq = p.n_class[q];
+                    if (nq > 0) {
+                        const int per = j < 3 ? 1 : 2;
+                        wcs.first_block[wcs.n] = (int32_t)blocks;
+                        wcs.first_cand[wcs.n] = (int32_t)(pos - n_fused);
+                        wcs.n_cand[wcs.n] = (int32_t)nq;
+                        wcs.kind[wcs.n] = j;
+                        ++wcs.n;
+                        blocks += (nq + per - 1) / per;
+                    }
+                    pos += nq;
+                }
+                wcs.first_block[wcs.n] = (int32_t)blocks;
+                if (blocks > 0) {
+                    const CandRec *base = p.d_recs + n_fused;
+                    if (c == ADH_CLASS_WIDE2)
+                        hipLaunchKernelGGL((adh_feature_wide_kernel<2>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, base, wcs,
+                                           h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase);
+                    else
+                        hipLaunchKernelGGL((adh_feature_wide_kernel<1>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, base, wcs,
+                                           h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase);
+                    HIP_TRY(hipGetLastError());
+                }
+            }
+            if (!wide_class && p.n_class[c] > 0 && (c == ADH_CLASS_GENERIC ? run_generic : run_fast)) {
                 const CandRec *recs = p.d_recs + first;
                 if (c == ADH_CLASS_GENERIC) {
                     hipLaunchKernelGGL(adh_feature_kernel, dim3((unsigned)p.n_class[c]), dim3(ADH_WAVE), f_lds, st, h->run, recs,
@@ -736,28 +772,10 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                 } else {
                     const unsigned blocks = (unsigned)((p.n_class[c] + per_block - 1) / per_block);
                     const int32_t nc = (int32_t)p.n_class[c];
-#define ADH_LAUNCH_WIDE_GS(FM, NO, GS)                                                                                    \
-    hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO, GS>), dim3((unsigned)((nc + ADH_WAVE / GS - 1) / (ADH_WAVE / GS))), \
-                       dim3(ADH_WAVE), 0, st, h->run, recs, nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out,          \
-                       (int32_t)stop_phase)
-#define ADH_LAUNCH_WIDE(FM, NO) ADH_LAUNCH_WIDE_GS(FM, NO, 64)
-#define ADH_LAUNCH_MID(FM, NO) ADH_LAUNCH_WIDE_GS(FM, NO, 32)
 #define ADH_LAUNCH_FAST(FM, NO)                                                                              \
     hipLaunchKernelGGL((adh_feature_fast_kernel<FM, NO>), dim3(blocks), dim3(ADH_WAVE), 0, st, h->run, recs, \
                        nc, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase)
                     switch (c) {
-                        case ADH_CLASS_WIDE2 + 0: ADH_LAUNCH_WIDE(16, 2); break;
-                        case ADH_CLASS_WIDE2 + 1: ADH_LAUNCH_WIDE(24, 2); break;
-                        case ADH_CLASS_WIDE2 + 2: ADH_LAUNCH_WIDE(32, 2); break;
-                        case ADH_CLASS_WIDE1 + 0: ADH_LAUNCH_WIDE(16, 1); break;
-                        case ADH_CLASS_WIDE1 + 1: ADH_LAUNCH_WIDE(24, 1); break;
-                        case ADH_CLASS_WIDE1 + 2: ADH_LAUNCH_WIDE(32, 1); break;
-                        case ADH_CLASS_MID2 + 0: ADH_LAUNCH_MID(16, 2); break;
-                        case ADH_CLASS_MID2 + 1: ADH_LAUNCH_MID(24, 2); break;
-                        case ADH_CLASS_MID2 + 2: ADH_LAUNCH_MID(32, 2); break;
-                        case ADH_CLASS_MID1 + 0: ADH_LAUNCH_MID(16, 1); break;
-                        case ADH_CLASS_MID1 + 1: ADH_LAUNCH_MID(24, 1); break;
-                        case ADH_CLASS_MID1 + 2: ADH_LAUNCH_MID(32, 1); break;
                         case ADH_CLASS_FAST2 + 0: ADH_LAUNCH_FAST(16, 2); break;
                         case ADH_CLASS_FAST2 + 1: ADH_LAUNCH_FAST(24, 2); break;
                         case ADH_CLASS_FAST2 + 2: ADH_LAUNCH_FAST(32, 2); break;
@@ -770,9 +788,6 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                         default: ADH_LAUNCH_FAST(32, 1); break;
                     }
 #undef ADH_LAUNCH_FAST
-#undef ADH_LAUNCH_WIDE
-#undef ADH_LAUNCH_MID
-#undef ADH_LAUNCH_WIDE_GS
                 }
                 HIP_TRY(hipGetLastError());
             }
