@@ -169,6 +169,37 @@ def test_requantification_configs_take_the_fused_kernel(ctx, oracle_lib, monkeyp
         assert gather_fused < 0.25 * gather_two and feature_fused > 0, (gather_fused, gather_two)
 
 
+@pytest.mark.parametrize("seed,k_fragments,quant_all", [(11, (17, 32), True), (12, (33, 61), True), (13, (14, 61), False)])
+def test_wide_register_kernels_equal_the_generic_kernel(ctx, oracle_lib, monkeypatch, seed, k_fragments, quant_all):
+    """Transfer-library requantification scores with ``top_k_fragments = 9999`` against libraries that carry every
+    predicted fragment (transfer_library_requantification_handler.py:117-124): candidates keep 17 ... 64 fragments.
+    The wide forms of the register kernel (adh_feature_fast_kernel<FM, NO, 32 / 64>, one launch per observation count)
+    take them since round 5: equal to the oracle, bit for bit equal to the generic LDS kernel they replace
+    (ADH_DEBUG_NO_WIDE), and several times faster."""
+    case = syn.make_case(1500, 400, config_id=2, per_precursor=2, threads=8, seed=seed, k_fragments=k_fragments)
+    cfg = CandidateScoringConfig()
+    cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
+                    fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=quant_all,
+                    experimental_xic=True, top_k_fragments=9999))
+    ctx.kernel_time_ms(reset=True)
+    got, soa = hip_score(ctx, case, cfg, with_stats=True)
+    got = {k: np.array(v, copy=True) for k, v in got.items()}
+    _, feature_wide, _ = ctx.kernel_time_ms(reset=True)
+    exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=soa, n_threads=4, with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"])
+    assert exp["valid"].sum() > 1000
+    kept = (got["fragment_mz_library"] > 0).sum(axis=1)
+    assert kept.max() > 12  # (rows the fused kernel cannot hold)
+    with monkeypatch.context() as mp:
+        mp.setenv("ADH_DEBUG_NO_WIDE", "1")
+        generic, _ = hip_score(ctx, case, cfg, soa=soa, with_stats=True)
+        _, feature_generic, _ = ctx.kernel_time_ms(reset=True)
+    for k in got:
+        assert np.array_equal(generic[k], got[k], equal_nan=True), k
+    assert feature_wide < feature_generic, (feature_wide, feature_generic)
+
+
 @pytest.mark.parametrize("slab_peaks", [20_000, 333_333])
 def test_run_staged_in_slabs_scores_identically(ctx, monkeypatch, slab_peaks):
     """Runs of 2^32 peaks and more are sorted into the transposed layout slab by slab (whole groups of cycle

@@ -275,7 +275,8 @@ def transfer_requant_leg(ctx, n_prec: int = 100_000, n_cycles: int = 4800, steps
     the handler's scoring configuration with only top_k_fragments replaced).  Here: 20-40 fragments per precursor, three
     candidates each, the 2 h run.  Candidates that keep more than 12 fragments are outside the fused kernel
     (adh_fused.hip: a 16-lane group holds 12 fragments + 4 isotopes) and take the two-kernel path
-    (adh_gather_kernel -> scratch in HBM -> adh_feature_kernel)."""
+    (adh_gather_kernel -> scratch in HBM -> the wide register kernels of adh_features_fast.hip, 32 or 64 lanes per
+    candidate; before round 5 the generic LDS kernel, 5 x slower)."""
     import synthetic as syn
     from alphadia_amd.distributed import slice_soa
     from alphadia_amd.scoring import CandidateScoringConfig, assemble_candidates, fragment_columns, pack_assembled
@@ -343,7 +344,7 @@ def transfer_requant_leg(ctx, n_prec: int = 100_000, n_cycles: int = 4800, steps
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": _leg_traffic("transfer_requant"), "kernel_ms": kernel_ms, "gather_kernel_ms": g_ms,
                      "feature_kernel_ms": f_ms, "algorithmic_bytes_per_candidate": alg / max(n, 1),
-                     "kernel": "adh_gather_kernel + adh_feature_kernel (the two-kernel path: more than 12 fragments per candidate)"},
+                     "kernel": "adh_gather_kernel + adh_feature_wide_kernel<observations> (the two-kernel path: more than 12 fragments per candidate; the wide register kernels hold 17 ... 64)"},
         "cpu_baseline": {"value": (sample / 3.0) / (dt / reps), "unit": "precursors/s", "cores": th, "kind": "port",
                          "sample": f"first {sample} candidates, {reps} x {dt / reps:.2f} s, {th} OpenMP threads",
                          "valid_identical_to_gpu": same_valid, "max_rel_feature_diff_vs_gpu": max_rel},

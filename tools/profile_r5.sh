@@ -5,7 +5,7 @@
 #               -> r05_final_kernel_stats.csv, r05_final_pmc.csv, pmc_traffic.json, r05_valu_busy.json
 #   MFMA      : SQ_INSTS_VALU_MFMA_MOPS_F32 / SQ_VALU_MFMA_BUSY_CYCLES of the ion-mobility profile kernel (configs[3])
 #               and of the classifier fit (tools/bench_fdr.py) -> r05_mfma_pmc.csv, r05_mfma.json
-#   legs      : FETCH_SIZE / WRITE_SIZE of configs[4], fragment competition (1e6 PSMs), candidate selection
+#   legs      : FETCH_SIZE / WRITE_SIZE of configs[4], fragment competition (1e6 PSMs), candidate selection, transfer requantification
 #               -> r05_legs_pmc.csv, legs_traffic.json; configs[3] as in round 4 -> timstof_traffic.json
 #   then the driver-style bench line with all legs -> r05_final_bench.json
 export TMPDIR=/tmp
@@ -78,6 +78,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/p5_fc_stats -o p -- python $REPO/tools/
 $S /tmp/p5_fc_stats/p_results.db | grep -v "rocclr" > $OUT/r05_fragcomp_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d /tmp/p5_mx_stats -o p -- python $REPO/tools/bench_legs.py multiplex > $OUT/p5_mx.log 2>&1
 $S /tmp/p5_mx_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r05_multiplex_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d /tmp/p5_tr_stats -o p -- python $REPO/tools/bench_legs.py transfer > $OUT/p5_tr.log 2>&1
+$S /tmp/p5_tr_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r05_transfer_kernel_stats.csv
 ADH_BENCH_NO_CPU=1 rocprofv3 --kernel-trace --stats -d /tmp/p5_sel_stats -o p -- python $REPO/tools/bench_select.py > $OUT/p5_sel.log 2>&1
 $S /tmp/p5_sel_stats/p_results.db | grep -v "rocprim\|rocclr" > $OUT/r05_selection_kernel_stats.csv
 : > $OUT/r05_legs_pmc.csv
@@ -86,17 +88,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   $S /tmp/p5_fc_$c/p_results.db | grep "adh_fc\|adh_fragcomp" > $OUT/p5_fc_$c.csv
   rocprofv3 --pmc $c -d /tmp/p5_mx_$c -o p -- python $REPO/tools/bench_legs.py multiplex > $OUT/p5_mx_$c.log 2>&1
   $S /tmp/p5_mx_$c/p_results.db | grep "adh_fused\|adh_gather_kernel\|adh_feature" > $OUT/p5_mx_$c.csv
+  rocprofv3 --pmc $c -d /tmp/p5_tr_$c -o p -- python $REPO/tools/bench_legs.py transfer > $OUT/p5_tr_$c.log 2>&1
+  $S /tmp/p5_tr_$c/p_results.db | grep "adh_gather_kernel\|adh_feature" > $OUT/p5_tr_$c.csv
   ADH_BENCH_NO_CPU=1 rocprofv3 --pmc $c -d /tmp/p5_sel_$c -o p -- python $REPO/tools/bench_select.py > $OUT/p5_sel_$c.log 2>&1
   $S /tmp/p5_sel_$c/p_results.db | grep "adh_select" > $OUT/p5_sel_$c.csv
 done
 cat $OUT/p5_fc_FETCH_SIZE.csv $OUT/p5_fc_WRITE_SIZE.csv > $OUT/p5_fc.csv
 cat $OUT/p5_mx_FETCH_SIZE.csv $OUT/p5_mx_WRITE_SIZE.csv > $OUT/p5_mx.csv
 cat $OUT/p5_sel_FETCH_SIZE.csv $OUT/p5_sel_WRITE_SIZE.csv > $OUT/p5_sel.csv
-cat $OUT/p5_fc.csv $OUT/p5_mx.csv $OUT/p5_sel.csv > $OUT/r05_legs_pmc.csv
-# passes: fragment competition 1 + 5 calls; configs[4] 4 + 5 host -> host + 6 resident; selection 1 + 3 calls
+cat $OUT/p5_tr_FETCH_SIZE.csv $OUT/p5_tr_WRITE_SIZE.csv > $OUT/p5_tr.csv
+cat $OUT/p5_fc.csv $OUT/p5_mx.csv $OUT/p5_sel.csv $OUT/p5_tr.csv > $OUT/r05_legs_pmc.csv
+# passes: fragment competition 1 + 5 calls; configs[4] 4 + 5 host -> host + 6 resident; selection 1 + 3 calls;
+# transfer requantification 3 + 5 host -> host calls
 ( cd $REPO && rm -f $OUT/legs_traffic.json && python tools/pmc_derive.py legs $OUT/legs_traffic.json \
     fragment_competition_1000000=$OUT/p5_fc.csv:6:adh_fc,adh_fragcomp multiplex_configs4=$OUT/p5_mx.csv:15:adh_:candidates@300000 \
-    candidate_selection=$OUT/p5_sel.csv:4:adh_select )
+    candidate_selection=$OUT/p5_sel.csv:4:adh_select transfer_requant=$OUT/p5_tr.csv:8:adh_:candidates@300000 )
 rm -rf /tmp/p5_*
 
 # ---- the bench line itself (driver style), with the traffic files of this run in place
