@@ -1068,9 +1068,11 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
             for (int sc = 0; sc < 2; ++sc) {
                 FU_FOR_R {
                     const double wv = wrow[sc * FM + r];
-                    FU_OPAQUE(A[r]);  // (in place: the conversions below are redone per scan slot, not kept)
-                    FU_OPAQUE(B[r]);
-                    const float a = A[r], b = B[r];
+                    // (opaque copies, not the rows themselves: marking A[r] / B[r] saves the two moves but costs
+                    // 44 bytes of scratch per lane - 25 more spill instructions and 1.2 GB of write traffic per step)
+                    float a = A[r], b = B[r];
+                    FU_OPAQUE(a);
+                    FU_OPAQUE(b);
                     // the weight of a cell that holds something: wv x 1.0 + wo rounds once, like wo + wv; wv x 0.0
                     // adds +0 (one select on the high word of the indicator instead of two on the weight)
                     vo += (double)a * wv;
