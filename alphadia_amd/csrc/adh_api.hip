@@ -1346,8 +1346,8 @@ int adh_select_candidates(adh_handle_t *h, const adh_precursors_t *pc, const adh
         }
         if (const char *env = getenv("ADH_DEBUG_SELECT_STOP")) caps.stop = atoi(env);
         if (getenv("ADH_DEBUG_SELECT_LDS_TAPS")) taps.cols = 0;  // A/B: the generic smoothing loop
-        hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream, h->run, h->d_lib,
-                           dp, n, *cfg, reinterpret_cast<const float *>(slab + o_kern), taps, caps, dt);
+        hipLaunchKernelGGL(adh_select_kernel, dim3((unsigned)n), dim3(ADH_WAVE), lds, h->stream,
+                           (SelectArgs{h->run, h->d_lib, dp, (int64_t)n, *cfg, reinterpret_cast<const float *>(slab + o_kern), taps, caps, dt}));
         e = hipGetLastError();
         (void)hipEventRecord(e1, h->stream);
         for (int f = 0; f < 9 && e == hipSuccess; ++f)

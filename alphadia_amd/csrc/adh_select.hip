@@ -183,11 +183,30 @@ struct DevCandTable {
     uint32_t *scan_center, *scan_start, *scan_stop, *frame_center, *frame_start, *frame_stop;
 };
 
-__global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(DevRun run, const LibRec *__restrict__ lib,
-                                                             DevPrecursors pc, int64_t n_prec,
-                                                             adh_selection_config_t cfg,
-                                                             const float *__restrict__ kernel_g, sel::Taps taps,
-                                                             sel::SelCaps caps, DevCandTable out) {
+// (arguments as ONE struct, read through the kernel-argument segment where they are needed - adh_fused.hip, FusedArgs:
+// as formal parameters they are loaded in the prologue, spilled to vector-register lanes and read back by v_readlane)
+struct SelectArgs {
+    DevRun run;
+    const LibRec *lib;
+    DevPrecursors pc;
+    int64_t n_prec;
+    adh_selection_config_t cfg;
+    const float *kernel_g;
+    sel::Taps taps;
+    sel::SelCaps caps;
+    DevCandTable out;
+};
+__global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(SelectArgs formal_args_not_read) {
+    const SelectArgs &KA = *(const SelectArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const DevRun &run = KA.run;
+    const LibRec *__restrict__ lib = KA.lib;
+    const DevPrecursors &pc = KA.pc;
+    const int64_t n_prec = KA.n_prec;
+    const adh_selection_config_t &cfg = KA.cfg;
+    const float *__restrict__ kernel_g = KA.kernel_g;
+    const sel::Taps &taps = KA.taps;
+    const sel::SelCaps &caps = KA.caps;
+    const DevCandTable &out = KA.out;
     using namespace sel;
     extern __shared__ __align__(16) unsigned char smem[];
     double *score = reinterpret_cast<double *>(smem);
