@@ -678,7 +678,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
     {                                                                                                  \
         const int b = row_ror<N>(sub);                                                                 \
         const float ib = __int_as_float(row_ror<N>(ia));                                               \
-        rk += (ib > mine_int) || (ib == mine_int && b > sub);                                          \
+        rk += (int)((ib > mine_int) | ((ib == mine_int) & (b > sub))); /* (no short circuit: no branches) */ \
     }
         FU_FOR_OTHER_LANES(FU_RANK_STEP)  // position in argsort()[::-1]
 #undef FU_RANK_STEP
@@ -691,12 +691,13 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
         }
         if (__ballot(alive) == 0ull) return;
         int slot = 0;
-        const int ma = __float_as_int(mine_mz);
+        // (a lane that is not kept travels as +inf: never below, never equal to a library m/z)
+        const int ma = __float_as_int(rk >= 0 ? mine_mz : INFINITY);
 #define FU_SLOT_STEP(N)                                                                           \
     {                                                                                             \
         const int rb = row_ror<N>(rk);                                                            \
         const float mb = __int_as_float(row_ror<N>(ma));                                          \
-        slot += (rb >= 0) && ((mb < mine_mz) || (mb == mine_mz && rb < rk));                      \
+        slot += (int)((mb < mine_mz) | ((mb == mine_mz) & (rb < rk)));                            \
     }
         FU_FOR_OTHER_LANES(FU_SLOT_STEP)  // stable argsort(mz) of the top-k list
 #undef FU_SLOT_STEP
@@ -1233,7 +1234,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {  // (all reads first: one LDS round trip, not K)
             const float ib = Q.g_int[j];
-            rk += (j < K) && ((ib > g_int_l) || (ib == g_int_l && j > kk));
+            rk += (int)((j < K) & ((ib > g_int_l) | ((ib == g_int_l) & (j > kk))));
         }
         Q.ord[rk] = kk;  // position in argsort(intensity)[::-1]
     }
@@ -1509,7 +1510,7 @@ __device__ __forceinline__ void fused_body(const DevRun &run, const LibRec *__re
 #pragma unroll
                 for (int b = 0; b < KMAX; ++b) {  // (fragment lanes only; absent ones hold INT_MAX)
                     const int vb = Q.fpeak[b][o];
-                    rk += (vb < va) || (vb == va && b < sub);
+                    rk += (int)((vb < va) | ((vb == va) & (b < sub)));
                 }
                 if (rk == r_lo) Q.medlo[o] = va;
                 if (rk == r_hi) Q.medhi[o] = va;
