@@ -603,6 +603,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     float g_int_l = 0.0f, g_fin_l = 0.0f;
     {
         float sum1 = 0.0f;
+#pragma unroll 4
         for (int j = 0; j < K; ++j) sum1 += L.g_fin[j];
         if (present) {
             g_int_l = lrec.intensity / sum1;
@@ -612,6 +613,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     __syncthreads();
     {
         float sum2 = 0.0f;
+#pragma unroll 4
         for (int j = 0; j < K; ++j) sum2 += L.g_int[j];
         if (present) g_fin_l = g_int_l / sum2;
     }
@@ -684,9 +686,10 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         merr_l = (m1 - (double)lrec.mz) / (double)lrec.mz * 1e6;  // fragment_features.py:387
         L.merr[kk] = merr_l;
         int rk = 0;
+#pragma unroll 4
         for (int j = 0; j < K; ++j) {
             float ib = L.g_int[j];
-            rk += (ib > g_int_l) || (ib == g_int_l && j > kk);
+            rk += (int)((ib > g_int_l) | ((ib == g_int_l) & (j > kk)));
         }
         L.ord[rk] = kk;  // position in argsort(intensity)[::-1]
     }
@@ -758,9 +761,11 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         double s64 = 0.0;
         float s32 = 0.0f;
         if (sub < 6) {
+#pragma unroll 4
             for (int k = 0; k < K; ++k) s64 += L.u.at.t64[k][sub];
             L.red64[sub] = s64;
         } else if (sub < 11) {
+#pragma unroll 4
             for (int k = 0; k < K; ++k) s32 += L.u.at.t32[k][sub - 6];
             L.red32[sub - 6] = s32;
         } else if (sub == 11) {
@@ -786,6 +791,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     __syncthreads();
     if (sub < 5) {
         double s64 = 0.0;
+#pragma unroll 4
         for (int k = 0; k < K; ++k) s64 += L.u.at.t64[k][sub];
         L.red64[7 + sub] = s64;
     }
@@ -988,7 +994,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
                     if (GS > 16 && b >= K0) break;  // (wide form: a real loop over the lanes that hold a fragment)
                     if (!((gm >> b) & 1ull)) continue;
                     int vb = L.fpeak[b][o];
-                    rk += (vb < va) || (vb == va && b < sub);
+                    rk += (int)((vb < va) | ((vb == va) & (b < sub)));
                 }
                 if (rk == r_lo) L.medlo[o] = va;
                 if (rk == r_hi) L.medhi[o] = va;
@@ -1014,6 +1020,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     __syncthreads();
     if (sub < 6) {
         float s32 = 0.0f;
+#pragma unroll 4
         for (int k = 0; k < K; ++k) s32 += L.u.at.t32[k][sub];
         L.red32[sub] = s32;
     }
