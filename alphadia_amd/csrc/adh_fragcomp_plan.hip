@@ -164,9 +164,20 @@ int adh_fragcomp_frames(adh_handle_t *h, int64_t n_psm, const uint32_t *psm_prec
     const uint8_t *d_pr, *d_fr;
     const float *d_pmz, *d_prt, *d_pproba, *d_fmz;
     const double *d_lo, *d_up;
-#define FP_UP(host, n, dev)                      \
-    rc = upload(tmp, host, n, dev, st);          \
-    if (rc != ADH_OK) return rc;
+    // device copies of the frames' columns: allocated one by one, filled together through page-locked staging
+    // (the columns of a DataFrame are pageable: 125 MB for 1e6 PSMs / 12 M fragment rows)
+    std::vector<UpJob> jobs;
+    auto dev_copy = [&](auto *host, int64_t n, auto **dev) -> int {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(host)>>;
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
+        tmp.ptrs.push_back(p);
+        *dev = static_cast<const T *>(p);
+        if (n > 0) jobs.push_back(UpJob{p, host, (size_t)n * sizeof(T)});
+        return ADH_OK;
+    };
+#define FP_UP(host, n, dev)                        \
+    if ((rc = dev_copy(host, n, dev)) != ADH_OK) return rc;
     FP_UP(psm_precursor_idx, n_psm, &d_pp);
     FP_UP(psm_rank, n_psm, &d_pr);
     FP_UP(psm_mz_observed, n_psm, &d_pmz);
@@ -178,6 +189,7 @@ int adh_fragcomp_frames(adh_handle_t *h, int64_t n_psm, const uint32_t *psm_prec
     FP_UP(window_lower, (int64_t)n_cycle_rows, &d_lo);
     FP_UP(window_upper, (int64_t)n_cycle_rows, &d_up);
 #undef FP_UP
+    if ((rc = upload_staged(h, jobs)) != ADH_OK) return rc;
     auto dev_alloc = [&](void **p, size_t bytes) -> int {
         HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 16)));
         tmp.ptrs.push_back(*p);
