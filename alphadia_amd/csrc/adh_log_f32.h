@@ -27,3 +27,9 @@ __device__ __forceinline__ double adh_log_f32(float x) {
     const double ed = (double)e;
     return ed * 6.93147180369123816490e-01 + ((adh_log_tab[i][1] + p) + ed * 1.90821492927058770002e-10);
 }
+
+// float32-rounded log of an argument outside [1, inf) (a smoothed value that is negative, NaN or overflowed: only a
+// caller's kernel with negative factors gets here).  Out of line on purpose: the library routine is ~200
+// instructions and a dozen live float64 constants, which inlined into every log site of the smoothing kernel
+// cost its hot paths their registers.
+__device__ __attribute__((noinline)) float adh_log_f32_rare(float x) { return (float)log((double)x); }

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_kernel(SelectArgs formal_
             const float sm = (float)acc;
             const float x1 = sm + 1.0f;
             float lg = 0.0f;  // (log(1) = 0: smoothed values below 6e-8 round away in sm + 1)
-            if (x1 != 1.0f) lg = (x1 >= 1.0f && x1 < INFINITY) ? (float)adh_log_f32(x1) : (float)log((double)x1);
+            if (x1 != 1.0f) lg = (x1 >= 1.0f && x1 < INFINITY) ? (float)adh_log_f32(x1) : adh_log_f32_rare(x1);
             logt[w * F + f] = lg;
         };
         if (fixed_taps) {

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                     const float x = sm + 1.0f;
                     if (x != 1.0f) {
                         if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
-                        else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : (float)log((double)x);
+                        else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : adh_log_f32_rare(x);
                     }
                 }
             }
