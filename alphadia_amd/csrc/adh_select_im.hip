@@ -442,11 +442,48 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
             }
         }
         if (tot > 0) {
+            // Pass 1 from the entries themselves (sparse tiles, the normal case): a row holds one or two events, and a
+            // zero input leaves a running fma sum as it is, so output cell f of a row needs the row's EVENTS in tap order
+            // (descending column, circularly, from column f + k1/2 - b_lo), not the 15 columns of the kernel's support
+            // read back from a zero-filled row.  The entries are sorted by cell = (window, scan, cycle): a row is a
+            // run of entries; the first entry and the first cell of every row are noted behind the rows (the tail of
+            // the row storage), and the support must not be longer than a row (no column met twice).  No zero fill, no
+            // scatter of the events, one barrier instead of two per step.
+            const int e_end = compact ? (int)header[4 + w0 + gc] : 0;
+            // (at most four events per row on average - denser batches take the dense pass -, and the entries themselves
+            // are staged behind the row starts: 10 tot words in all)
+            const bool sparse1 = compact && e_end - e_lo <= 4 * tot && tot * (F + 10) <= SF && b_hi - b_lo + 1 <= F &&
+                                 debug_abl != 8;  // (8: developer switch, always the dense pass)
+            int *row_e0 = reinterpret_cast<int *>(rows) + (SF - 10 * tot);  // first entry of every row, counted from e_lo
+            int *row_c0 = row_e0 + tot;                                     // first cell of every row
+            uint32_t *ent_w = reinterpret_cast<uint32_t *>(row_c0 + tot);   // the batch's entries: (cell, intensity bits)
+            if (sparse1) {
+                for (int e = e_lo + tid; e < e_end; e += SCORE_THREADS) {
+                    const SelEntry en = entries[e];
+                    ent_w[2 * (e - e_lo)] = en.cell;
+                    ent_w[2 * (e - e_lo) + 1] = __float_as_uint(en.x);
+                    const int cell = (int)en.cell;
+                    const int rem = cell - w0 * SF;
+                    int g = (int)((double)rem * inv_sf);
+                    if (rem - g * SF >= SF) ++g;
+                    const int r2 = rem - g * SF;
+                    int sc = (int)((double)r2 * inv_f);
+                    if (r2 - sc * F >= F) ++sc;
+                    const int c0 = cell - (r2 - sc * F);  // first cell of the row
+                    if (e == e_lo || (int)entries[e - 1].cell < c0) {
+                        int br = 0;
+#pragma unroll
+                        for (int q = 0; q < SEL_BATCH; ++q) br = q == g ? base_r[q] : br;
+                        const int slot = br + (int)row_slot[g * S + sc];
+                        row_e0[slot] = e - e_lo;
+                        row_c0[slot] = c0;
+                    }
+                }
+            } else {
             // the rows of the events, dense along the cycles
             for (int c = tid; c < tot * F; c += SCORE_THREADS) rows[c] = 0.0f;
             __syncthreads();
             if (compact) {
-                const int e_end = (int)header[4 + w0 + gc];
                 for (int e = e_lo + tid; e < e_end; e += SCORE_THREADS) {
                     const SelEntry en = entries[e];
                     const int rem = (int)en.cell - w0 * SF;
@@ -470,6 +507,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                             rows[(base_r[g] + slot) * F + (c - slot * F)] =
                                 tiles[(size_t)(w0 + g) * SF + (int)row_list[g * S + slot] * F + (c - slot * F)];
                         }
+            }
             }
             // for every scan: the last row at or below (s + h0) mod S, circularly
             for (int c = tid; c < gc * S; c += SCORE_THREADS) {
@@ -520,6 +558,35 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
             __syncthreads();
             // ---- pass 1, in place: along the cycles, kernel centred at column k1 / 2.  A step takes whole rows:
             // every thread reads the taps of its cell, then all write.
+            if (sparse1) {
+                const int lr = tid / F, f = tid - lr * F;
+                int cs = f + h1 - b_lo;  // column of the first tap of the support
+                cs += cs < 0 ? F : 0;
+                cs -= cs >= F ? F : 0;
+                for (int slot = lr; slot < (lr < rows_per_step ? tot : 0); slot += rows_per_step) {
+                    const int e0 = row_e0[slot], e1 = slot + 1 < tot ? row_e0[slot + 1] : e_end - e_lo, c0 = row_c0[slot];
+                    const int n = e1 - e0;
+                    const uint32_t *ew = ent_w + 2 * e0;
+                    // the last event at or below column cs (none: the row's last event, one turn earlier)
+                    int i = n - 1;
+                    for (int j = n - 1; j >= 0; --j)
+                        if ((int)ew[2 * j] - c0 <= cs) {
+                            i = j;
+                            break;
+                        }
+                    double acc = 0.0;
+                    for (int t = 0; t < n; ++t) {
+                        int bb = cs - ((int)ew[2 * i] - c0);  // tap of this event, counted from b_lo: ascending along the walk
+                        bb += bb < 0 ? F : 0;
+                        bb += b_lo;
+                        if (bb > b_hi) break;
+                        acc = fma(kv[bb], (double)__uint_as_float(ew[2 * i + 1]), acc);
+                        i = i == 0 ? n - 1 : i - 1;
+                    }
+                    rows[slot * F + f] = (float)acc;
+                }
+                __syncthreads();
+            } else
             for (int base = 0; base < tot; base += rows_per_step) {
                 const int lr = tid / F, f = tid - lr * F;
                 const int slot = base + lr;

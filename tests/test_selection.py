@@ -336,10 +336,11 @@ def test_hip_timstof_selection_tile_forms_and_indices_agree(ctx, monkeypatch):
 
     base = run()
     assert len(base["precursor_idx"]) > 100
-    # (ADH_DEBUG_SELECT_IM_ABL=5: pass 2 of the smoothing walks the rows per cell instead of reading its tap lists)
+    # (ADH_DEBUG_SELECT_IM_ABL=5: pass 2 of the smoothing walks the rows per cell instead of reading its tap lists;
+    #  8: pass 1 runs over zero-filled rows instead of the rows' events)
     # (ADH_SELECT_SCRATCH_MB=1: the precursors go through the kernels in many batches, cut from the device's prefix sums)
     for env in (dict(ADH_DEBUG_SELECT_IM_DENSE="1"), dict(ADH_IM_INDEX="0"), dict(ADH_IM_INDEX_MB="1"),
-                dict(ADH_DEBUG_SELECT_IM_ABL="5"), dict(ADH_SELECT_SCRATCH_MB="1"),
+                dict(ADH_DEBUG_SELECT_IM_ABL="5"), dict(ADH_DEBUG_SELECT_IM_ABL="8"), dict(ADH_SELECT_SCRATCH_MB="1"),
                 dict(ADH_SELECT_SCRATCH_MB="1", ADH_DEBUG_SELECT_IM_DENSE="1")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
