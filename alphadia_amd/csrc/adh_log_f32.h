@@ -8,13 +8,16 @@
 // >= 0 (no cancellation) and entry 0 is exact, so values next to 1 keep their relative accuracy.  The
 // smoothing needs one log per non-zero output cell, 127 000 per precursor: this is about half the
 // instructions of the general routine.
-__device__ __forceinline__ double adh_log_f32(float x) {
+// (`tab`: the table as 256 doubles - adh_log_tab itself, or a copy of it in LDS: a table look-up per log is a global load
+// in the middle of a dependent chain, and the smoothing kernel of the ion-mobility selection takes one log per cell)
+__device__ __forceinline__ double adh_log_f32(float x, const double *tab = &adh_log_tab[0][0]) {
     const uint32_t bits = __float_as_uint(x);
     const int e = (int)(bits >> 23) - 127;
     const uint32_t mant = bits & 0x007FFFFFu;
     const int i = (int)(mant >> 16);
     const double m = (double)__uint_as_float(mant | 0x3F800000u);
-    const double r = fma(m, adh_log_tab[i][0], -1.0);
+    const double t_inv = tab[2 * i], t_log = tab[2 * i + 1];
+    const double r = fma(m, t_inv, -1.0);
     double q = 1.0 / 9.0;
     q = fma(q, r, -1.0 / 8.0);
     q = fma(q, r, 1.0 / 7.0);
@@ -25,7 +28,7 @@ __device__ __forceinline__ double adh_log_f32(float x) {
     q = fma(q, r, -1.0 / 2.0);
     const double p = fma(r * r, q, r);
     const double ed = (double)e;
-    return ed * 6.93147180369123816490e-01 + ((adh_log_tab[i][1] + p) + ed * 1.90821492927058770002e-10);
+    return ed * 6.93147180369123816490e-01 + ((t_log + p) + ed * 1.90821492927058770002e-10);
 }
 
 // float32-rounded log of an argument outside [1, inf) (a smoothed value that is negative, NaN or overflowed: only a

@@ -19,6 +19,13 @@
 #include "adh_device.h"
 #include "adh_log_f32.h"
 
+#ifndef ADH_SEL_TAP_FIT
+#define ADH_SEL_TAP_FIT 1  // batches of the smoothing kernel are cut so that their tap lists fit (0: by the row storage only)
+#endif
+#ifndef ADH_SEL_LOG_LDS
+#define ADH_SEL_LOG_LDS 0  // 1: the log table of the smoothing kernel in LDS - measured 4 % slower: its 2 KB come out of the tap lists
+#endif
+
 namespace selim {
 
 constexpr int MAX_W = 64;    // m/z windows (fragments + isotopes) per precursor
@@ -298,6 +305,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
 size_t adh_select_smooth_im_lds_bytes(int cap_cells, int cap_s, int k0, int k1, int tap_budget) {
     size_t b = (size_t)cap_cells * 8;                    // rows + log-sum tile
     b += (size_t)(k0 + k1) * 8;                          // kernel factors
+#if ADH_SEL_LOG_LDS
+    b += 256 * 8;                                        // the log table
+#endif
     b += (size_t)cap_s * 4 * 2 * selim::SEL_BATCH + 16;  // row tables and tap counts of a batch of windows
     b += (size_t)tap_budget * 2 + 8;                     // tap lists of pass 2 (uint16 entries)
     return (b + 15) / 16 * 16;
@@ -325,11 +335,16 @@ size_t adh_select_score_im_lds_bytes(int cap_cells, int cap_s, int cap_f) {
 // scratch block.  Separate from the peak search (kernel 3) because it is bound by LDS latency and needs
 // wavefronts: 1024 threads at <= 64 VGPRs, two blocks = 32 wavefronts per CU (the peak search carries
 // per-candidate arrays in registers and would cap the whole at half of that).
+// (DBG: the instantiation that honours the developer switches ADH_DEBUG_SELECT_IM_ABL; the product runs the one in which
+// they are compile-time zeros - their tests sat in the innermost loops and their flags in scalar registers the kernel
+// has to spill)
+template <bool DBG>
 __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im_kernel(
     const selim::PrecRec *__restrict__ recs, int32_t n_prec, const double *__restrict__ ku_g,
     const double *__restrict__ kv_g, int32_t k0, int32_t k1, int32_t cap_cells, int32_t cap_s,
-    unsigned char *__restrict__ scratch, int32_t debug_abl, int32_t tap_budget) {
+    unsigned char *__restrict__ scratch, int32_t debug_abl_arg, int32_t tap_budget) {
     using namespace selim;
+    const int32_t debug_abl = DBG ? debug_abl_arg : 0;
     constexpr int SCORE_THREADS = SMOOTH_THREADS;  // (this kernel's block size, under the name the loops use)
     extern __shared__ __align__(16) unsigned char smem[];
     // The smoothing is the separable circular convolution
@@ -343,8 +358,15 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
     float *ls = rows + cap_cells;                       // log-sum tile: fragments first (parked in HBM when done), then isotopes
     double *ku = reinterpret_cast<double *>(ls + cap_cells);
     double *kv = ku + k0;
+#if ADH_SEL_LOG_LDS
+    double *ltab = kv + k1;  // adh_log_tab, 2 KB: the look-up of a log is an LDS read instead of a global load
+    double *after_k = ltab + 256;
+#else
+    const double *ltab = &adh_log_tab[0][0];
+    double *after_k = kv + k1;
+#endif
     // per window g of a batch, at [g * S ...]:
-    int16_t *row_slot = reinterpret_cast<int16_t *>(kv + k1);  // [S] slot of a scan, -1: no event
+    int16_t *row_slot = reinterpret_cast<int16_t *>(after_k);  // [S] slot of a scan, -1: no event
     int16_t *row_list = row_slot + SEL_BATCH * cap_s;   // [n_rows] scans with events, ascending
     int16_t *row_top = row_list + SEL_BATCH * cap_s;    // [S] last row <= (s + k0/2) mod S (circular), as index into row_list
     // Tap lists of pass 2, per (window of the batch, scan): the rows within the kernel's reach in tap order, as
@@ -370,6 +392,9 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
     float *park = reinterpret_cast<float *>(scratch + r.scratch_off + SEL_HEADER) + (size_t)W * SF;  // the parked tile
     for (int c = tid; c < k0; c += SCORE_THREADS) ku[c] = ku_g[c];
     for (int c = tid; c < k1; c += SCORE_THREADS) kv[c] = kv_g[c];
+#if ADH_SEL_LOG_LDS
+    if (tid < 256) ltab[tid] = adh_log_tab[tid >> 1][tid & 1];
+#endif
     for (int c = tid; c < SF; c += SCORE_THREADS) ls[c] = 0.0f;
     __syncthreads();
     const int h0 = k0 / 2, h1 = k1 / 2;
@@ -432,12 +457,17 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
         }
         __syncthreads();
         // the windows of the batch whose rows fit the row storage together (S rows; one window always fits)
-        int gc = 0, tot = 0, base_r[SEL_BATCH];
+        // ... and whose tap lists fit what LDS is left (S lists of min(rows, k0) entries per window): a window that would
+        // push the batch into the per-cell walk of pass 2 waits for the next batch - batches are cheap, the walk is not
+        int gc = 0, tot = 0, base_r[SEL_BATCH], taps = 0;
 #pragma unroll
         for (int g = 0; g < SEL_BATCH; ++g) {
             base_r[g] = tot;
-            if (g < gmax && gc == g && tot + batch_rows[g] <= S) {
+            const int tl = g < gmax ? min(batch_rows[g], k0) : 0;
+            const bool lists_fit = !ADH_SEL_TAP_FIT || g == 0 || S * (taps + tl) <= tap_budget;
+            if (g < gmax && gc == g && tot + batch_rows[g] <= S && lists_fit) {
                 tot += batch_rows[g];
+                taps += tl;
                 gc = g + 1;
             }
         }
@@ -647,7 +677,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                     const float x = sm + 1.0f;
                     if (x != 1.0f) {
                         if (debug_abl == 1) ls[c] += x;  // (developer ablation: no log)
-                        else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x) : adh_log_f32_rare(x);
+                        else ls[c] += (x >= 1.0f && x < INFINITY) ? (float)adh_log_f32(x, ltab) : adh_log_f32_rare(x);
                     }
                 }
             }

@@ -126,6 +126,31 @@ def test_search_sized_table(ctx, oracle_lib):
     assert st["rounds"] <= 8 and not st["serial"]
 
 
+@pytest.mark.parametrize("lanes", ["1", "3", "16"])
+def test_staged_upload_lanes(ctx, oracle_lib, monkeypatch, lanes):
+    """The columns of a competition go up through page-locked staging lanes (upload_staged, tables of 16 MB and more);
+    ADH_UPLOAD_MIN_MB=0 sends this small table the same way, on 1, 3 and 16 lanes: slices that are empty, shorter
+    than a page, and not a multiple of the element size apart."""
+    import synthetic as syn
+
+    t = syn.make_competition_table(30_011, seed=11)
+    args = (t["window_start"], t["window_stop"], t["rt"], t["frag_start"], t["frag_stop"], t["mz"], 3, 15)
+    base = ctx.fragcomp(*args)
+    monkeypatch.setenv("ADH_UPLOAD_MIN_MB", "0")
+    monkeypatch.setenv("ADH_UPLOAD_LANES", lanes)
+    got = ctx.fragcomp(*args)
+    assert np.array_equal(got, base)
+    assert np.array_equal(got, oracle_lib.fragcomp(*args, n_threads=8))
+    rng = np.random.default_rng(77)
+    psm, frag, cyc = _frames(rng, 20_003)
+    cols = (psm["precursor_idx"].values, psm["rank"].values, psm["mz_observed"].values, psm["rt_observed"].values,
+            psm["proba"].values, frag["precursor_idx"].values, frag["rank"].values, frag["mz_observed"].values)
+    staged = ctx.fragcomp_frames(*cols, cyc, 3, 15)
+    monkeypatch.delenv("ADH_UPLOAD_MIN_MB")
+    plain = ctx.fragcomp_frames(*cols, cyc, 3, 15)
+    assert np.array_equal(staged[0], plain[0]) and np.array_equal(staged[1], plain[1])
+
+
 def _frames(rng, n, n_win=8, ties=True, grouped=True):
     """psm_df / frag_df / cycle as FragmentCompetition.__call__ receives them: ties in proba (and in proba + precursor_idx
     across ranks), PSMs without fragment rows, observed m/z outside every isolation window."""
