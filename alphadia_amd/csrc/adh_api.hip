@@ -353,12 +353,27 @@ int upload_staged(adh_handle *h, const std::vector<UpJob> &jobs) {
     }
     while ((int)h->up_lanes.size() < lanes) {
         adh_handle::UpLane l;
-        HIP_TRY(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipHostMalloc(&l.buf[k], UP_PIECE, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming));
+        hipError_t e = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipHostMalloc(&l.buf[k], UP_PIECE, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {  // (no page-locked memory to be had: fewer lanes, or the runtime's copy)
+            for (int k = 0; k < 2; ++k) {
+                if (l.buf[k]) (void)hipHostFree(l.buf[k]);
+                if (l.ev[k]) (void)hipEventDestroy(l.ev[k]);
+            }
+            if (l.st) (void)hipStreamDestroy(l.st);
+            (void)hipGetLastError();
+            lanes = (int)h->up_lanes.size();
+            break;
         }
         h->up_lanes.push_back(l);
+    }
+    if (lanes == 0) {
+        for (const UpJob &j : jobs)
+            if (j.bytes) HIP_TRY(hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice));
+        return ADH_OK;
     }
     std::atomic<int> err{(int)hipSuccess};
     auto work = [&](int t) {
