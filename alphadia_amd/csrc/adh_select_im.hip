@@ -613,7 +613,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                         acc = fma(kv[bb], (double)__uint_as_float(ew[2 * i + 1]), acc);
                         i = i == 0 ? n - 1 : i - 1;
                     }
-                    rows[slot * F + f] = (float)acc;
+                    rows[__mul24(slot, F) + f] = (float)acc;
                 }
                 __syncthreads();
             } else
@@ -649,16 +649,16 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                 const int16_t *rl = row_list + g * S, *rt = row_top + g * S;
                 const float *rw = rows + base_r[g] * F;
                 for (int sc = p2_lr; sc < (debug_abl == 2 || p2_lr >= p2_rows ? 0 : S); sc += p2_rows) {  // (2: developer ablation, no pass 2)
-                    const int f = p2_f, c = sc * F + f;
+                    const int f = p2_f, c = __mul24(sc, F) + f;  // (24-bit multiply-adds in the cell and tap loops: one instruction each)
                     int idx = (int)rt[sc];
                     double acc = 0.0;
                     if (use_taps) {
-                        const uint16_t *tp = tap_tab + tap_base[g] + sc * tap_len[g];
+                        const uint16_t *tp = tap_tab + tap_base[g] + __mul24(sc, tap_len[g]);
                         const int cnt = debug_abl == 3 ? 0 : (int)tap_cnt[g * S + sc];
                         if (cnt == 0) continue;  // (nothing within reach: smooth = 0, log(0 + 1) = 0)
                         for (int t = 0; t < cnt; ++t) {
                             const int u = (int)tp[t];
-                            acc = fma(ku[u & 63], (double)rw[(u >> 6) * F + f], acc);
+                            acc = fma(ku[u & 63], (double)rw[__mul24(u >> 6, F) + f], acc);
                         }
                     } else
                     for (int t = 0; t < (debug_abl == 3 ? 0 : n_rows); ++t) {  // (3: developer ablation, no row walk)
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(selim::SMOOTH_THREADS, 8) void adh_select_smooth_im
                         a -= a >= S ? S : 0;
                         if (a >= k0) break;
                         if (debug_abl == 4) acc += 1.0;  // (4: developer ablation, the walk without the taps)
-                        else acc = fma(ku[a], (double)rw[idx * F + f], acc);
+                        else acc = fma(ku[a], (double)rw[__mul24(idx, F) + f], acc);
                         idx = idx == 0 ? n_rows - 1 : idx - 1;
                     }
                     const float sm = (float)acc;
