@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch driver: per-kernel times of the ion-mobility selection under the smoothing kernel's ablation switches
-# (ADH_DEBUG_SELECT_IM_ABL: 0 product, 1 no log, 2 no pass 2, 3 no taps, 6 the exact log only)
+# (ADH_DEBUG_SELECT_IM_ABL: 0 product, 1 no log, 2 no pass 2, 3 no taps, 4 the walk without the taps, 5 per-cell row walk instead of tap lists, 8 dense pass 1; any non-zero value runs the developer instantiation of the kernel)
 export TMPDIR=/tmp
 REPO=$PWD
 OUT=$REPO/gpurun_out
