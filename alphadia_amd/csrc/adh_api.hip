@@ -20,6 +20,7 @@
 
 #include <dlfcn.h>
 #include <immintrin.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
@@ -66,12 +67,26 @@ int fail(int code, const std::string &msg) {
 // below): a freed block of 256 MB or more is parked and handed to the next request it fits (size <= block <= 1.5 x
 // size) - the second staging of a run of similar size allocates nothing - up to ADH_DEV_CACHE_GB (default 48) in all;
 // adh_trim_device_cache() gives everything back.  A request that fails with the cache non-empty empties it and retries.
+// Blocks carry the device they were allocated on: a parked block only serves a request made with the same device
+// current (one process may hold a handle per GPU), and the limit counts per device.  Parking keeps hipFree's implicit
+// device synchronisation (kernels of any stream may still touch the block; parks are rare - a re-staged run, a table
+// that outgrew its slab), so a reused block is never written while its old owner's work is in flight.
+struct DevBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
 struct DevBlockCache {
     std::mutex m;
-    std::vector<std::pair<void *, size_t>> parked;
-    std::unordered_map<void *, size_t> live;  // blocks of >= kMin bytes handed out
-    size_t parked_bytes = 0;
+    std::vector<DevBlock> parked;
+    std::unordered_map<void *, std::pair<size_t, int>> live;  // blocks of >= kMin bytes handed out: (bytes, device)
     static constexpr size_t kMin = (size_t)256 << 20;
+    size_t parked_on(int device) const {
+        size_t b = 0;
+        for (const DevBlock &k : parked)
+            if (k.device == device) b += k.bytes;
+        return b;
+    }
 };
 DevBlockCache &dev_cache() {
     static DevBlockCache c;
@@ -79,43 +94,60 @@ DevBlockCache &dev_cache() {
 }
 std::atomic<bool> g_big_free{false};  // a block of 1 GB or more did go back to the runtime
 
+int dev_current() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+
+// per device: ADH_DEV_CACHE_GB (default 48), never more than a quarter of the device's memory
 size_t dev_cache_limit() {
     static const size_t lim = [] {
         const char *env = getenv("ADH_DEV_CACHE_GB");
-        return (size_t)(env ? std::max(atof(env), 0.0) : 48.0) << 30;
+        size_t l = (size_t)(env ? std::max(atof(env), 0.0) : 48.0) << 30;
+        size_t free_b = 0, total_b = 0;
+        if (::hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) l = std::min(l, total_b / 4);
+        return l;
     }();
     return lim;
 }
 
-hipError_t adh_dev_trim() {
+// gives back the parked blocks of one device (device < 0: of every device)
+hipError_t adh_dev_trim_device(int device) {
     DevBlockCache &c = dev_cache();
-    std::vector<std::pair<void *, size_t>> drop;
+    std::vector<DevBlock> drop;
     {
         std::lock_guard<std::mutex> g(c.m);
-        drop.swap(c.parked);
-        c.parked_bytes = 0;
+        std::vector<DevBlock> keep;
+        for (const DevBlock &b : c.parked) (device < 0 || b.device == device ? drop : keep).push_back(b);
+        c.parked.swap(keep);
     }
     hipError_t e = hipSuccess;
-    for (auto &b : drop) {
-        if (b.second >= ((size_t)1 << 30)) g_big_free.store(true);
-        const hipError_t f = hipFree(b.first);
+    int cur = dev_current();
+    for (const DevBlock &b : drop) {
+        if (b.bytes >= ((size_t)1 << 30)) g_big_free.store(true);
+        if (b.device != cur) (void)hipSetDevice(b.device);
+        const hipError_t f = hipFree(b.p);
+        if (b.device != cur) (void)hipSetDevice(cur);
         if (f != hipSuccess) e = f;
     }
     return e;
 }
+hipError_t adh_dev_trim() { return adh_dev_trim_device(-1); }
 
 hipError_t adh_dev_malloc(void **p, size_t bytes) {
     DevBlockCache &c = dev_cache();
+    const int device = dev_current();
     if (bytes >= DevBlockCache::kMin) {
         std::lock_guard<std::mutex> g(c.m);
         size_t best = SIZE_MAX, at = SIZE_MAX;
         for (size_t i = 0; i < c.parked.size(); ++i)
-            if (c.parked[i].second >= bytes && c.parked[i].second <= bytes + bytes / 2 && c.parked[i].second < best)
-                best = c.parked[i].second, at = i;
+            if (c.parked[i].device == device && c.parked[i].bytes >= bytes && c.parked[i].bytes <= bytes + bytes / 2 &&
+                c.parked[i].bytes < best)
+                best = c.parked[i].bytes, at = i;
         if (at != SIZE_MAX) {
-            *p = c.parked[at].first;
-            c.live[*p] = best;
-            c.parked_bytes -= best;
+            *p = c.parked[at].p;
+            c.live[*p] = {best, device};
             c.parked.erase(c.parked.begin() + (long)at);
             return hipSuccess;
         }
@@ -126,16 +158,16 @@ hipError_t adh_dev_malloc(void **p, size_t bytes) {
         bool any;
         {
             std::lock_guard<std::mutex> g(c.m);
-            any = !c.parked.empty();
+            any = c.parked_on(device) > 0;
         }
         if (any) {
-            (void)adh_dev_trim();
+            (void)adh_dev_trim_device(device);
             e = hipMalloc(p, bytes);
         }
     }
     if (e == hipSuccess && bytes >= DevBlockCache::kMin) {
         std::lock_guard<std::mutex> g(c.m);
-        c.live[*p] = bytes;
+        c.live[*p] = {bytes, device};
     }
     return e;
 }
@@ -144,24 +176,95 @@ hipError_t adh_dev_free(void *p) {
     if (!p) return hipSuccess;
     DevBlockCache &c = dev_cache();
     size_t bytes = 0;
+    int device = 0;
+    bool park = false;
     {
         std::lock_guard<std::mutex> g(c.m);
         auto it = c.live.find(p);
         if (it != c.live.end()) {
-            bytes = it->second;
+            bytes = it->second.first;
+            device = it->second.second;
             c.live.erase(it);
-            if (c.parked_bytes + bytes <= dev_cache_limit()) {
-                c.parked.emplace_back(p, bytes);
-                c.parked_bytes += bytes;
-                return hipSuccess;
-            }
+            park = c.parked_on(device) + bytes <= dev_cache_limit();
         }
+    }
+    if (park) {
+        // what hipFree would have done: nothing in flight on the block's device touches it any more
+        const int cur = dev_current();
+        if (device != cur) (void)hipSetDevice(device);
+        const hipError_t e = hipDeviceSynchronize();
+        if (device != cur) (void)hipSetDevice(cur);
+        if (e != hipSuccess) (void)hipGetLastError();  // (a failed device: hand the block on anyway, the next call reports)
+        std::lock_guard<std::mutex> g(c.m);
+        c.parked.push_back(DevBlock{p, bytes, device});
+        return hipSuccess;
     }
     if (bytes >= ((size_t)1 << 30)) g_big_free.store(true);
     return hipFree(p);
 }
+
+// hipMemGetInfo as the sizing heuristics mean it: the parked blocks of the current device are free memory (a request
+// that does not fit trims them)
+hipError_t adh_mem_get_info(size_t *free_b, size_t *total_b) {
+    const hipError_t e = hipMemGetInfo(free_b, total_b);
+    if (e != hipSuccess) return e;
+    DevBlockCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.m);
+    *free_b = std::min(*total_b, *free_b + c.parked_on(dev_current()));
+    return hipSuccess;
+}
 #define hipMalloc(ptr, bytes) adh_dev_malloc((void **)(ptr), (bytes))
 #define hipFree(ptr) adh_dev_free((void *)(ptr))
+#define hipMemGetInfo(f, t) adh_mem_get_info((f), (t))
+
+// CPU cores this process may actually use: the smallest of the hardware threads, the scheduler affinity mask and the
+// cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  The pool's GPU boxes show 256 hardware
+// threads under a quota of 16 cores: a team sized by the former only takes turns.
+// ADH_CGROUP_CPU_MAX names another file in cpu.max format ("<quota> <period>" or "max <period>") - the tests fake one.
+int host_cpu_budget() {
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw <= 0) hw = 16;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int aff = CPU_COUNT(&set);
+        if (aff > 0) hw = std::min(hw, aff);
+    }
+    auto read_two = [](const char *path, char *a, size_t na, double *b) -> bool {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char fmt[32];
+        snprintf(fmt, sizeof(fmt), "%%%zus %%lf", na - 1);
+        const int k = fscanf(f, fmt, a, b);
+        fclose(f);
+        return k >= 1;
+    };
+    char q[64] = {0};
+    double period = 100000.0;
+    const char *fake = getenv("ADH_CGROUP_CPU_MAX");
+    if (read_two(fake && *fake ? fake : "/sys/fs/cgroup/cpu.max", q, sizeof(q), &period)) {
+        if (strcmp(q, "max") != 0 && period > 0) {
+            const double cores = atof(q) / period;
+            if (cores > 0) hw = std::min(hw, std::max((int)cores, 1));
+        }
+    } else {
+        double quota = -1, per = -1;
+        char dummy[64];
+        FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        if (f) {
+            if (fscanf(f, "%lf", &quota) != 1) quota = -1;
+            fclose(f);
+        }
+        f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (f) {
+            if (fscanf(f, "%lf", &per) != 1) per = -1;
+            fclose(f);
+        }
+        (void)dummy;
+        if (quota > 0 && per > 0) hw = std::min(hw, std::max((int)(quota / per), 1));
+    }
+    return std::max(hw, 1);
+}
 
 struct DeviceBuffers {
     std::vector<void *> ptrs;
@@ -338,10 +441,9 @@ int upload_staged(adh_handle *h, const std::vector<UpJob> &jobs) {
     int lanes = 4;
     if (const char *env = getenv("ADH_UPLOAD_LANES")) lanes = atoi(env);  // (0: the runtime's pageable copy)
     {
-        unsigned hw = std::thread::hardware_concurrency();
         int ranks = 1;
         if (const char *lw = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(atoi(lw), 1);
-        if (hw > 0) lanes = std::min<int>(lanes, std::max<int>((int)hw / ranks, 1));
+        lanes = std::min<int>(lanes, std::max<int>(host_cpu_budget() / ranks, 1));
     }
     lanes = std::min(lanes, 16);
     size_t least = (size_t)16 << 20;  // (below this the runtime's copy is as fast; ADH_UPLOAD_MIN_MB: how the tests get here)

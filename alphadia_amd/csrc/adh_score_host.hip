@@ -1300,16 +1300,15 @@ void expand_host_rows(adh_output_t *out, uint16_t *slot_host, const unsigned cha
 }
 
 int host_threads_for(int64_t n) {
-    // the team that rebuilds the id / library columns behind the copy-out: at most 16 threads, and of a node's
-    // hardware threads only this rank's share (LOCAL_WORLD_SIZE ranks run side by side: eight teams of 16 would
-    // fight over a CPU quota that is often far below the visible core count)
+    // the team that rebuilds the id / library columns behind the copy-out: at most 16 threads, and of the cores this
+    // process may use (host_cpu_budget: quota, affinity, hardware) only this rank's share - LOCAL_WORLD_SIZE ranks run
+    // side by side under ONE quota
     int t = 16;
     if (const char *env = getenv("ADH_HOST_THREADS")) t = atoi(env);
     else {
-        unsigned hw = std::thread::hardware_concurrency();
         int ranks = 1;
         if (const char *lw = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(atoi(lw), 1);
-        if (hw > 0) t = std::min<int>(t, std::max<int>((int)hw / ranks, 1));
+        t = std::min<int>(t, std::max<int>(host_cpu_budget() / ranks, 1));
     }
     t = (int)std::min<int64_t>(t, n / 16384);  // (a thread per 16 k rows at least: starting one costs ~20 us)
     return std::max(t, 1);
@@ -1588,7 +1587,10 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
     // enqueue loop waits for every chunk's totals, so it takes as long as the kernels: with the team started behind it
     // the unpacking - 2 ms per 450 000-row block - came on top: 32 ms per 3 M candidates).  The calling thread
     // publishes blocks as their copies complete (cop_publish), thread w takes stripe w of T of every block.
+    // base[ci] / cnt[ci] are written once, before `ready` passes ci, and never again: a worker reads only its own
+    // chunk's pair (a chunk that does not fit - and every one behind it - is published with a count of 0).
     std::vector<int64_t> cop_base_r((size_t)n_chunks + 1, 0), cop_base_s((size_t)n_chunks + 1, 0);
+    std::vector<int64_t> cop_cnt_r((size_t)n_chunks, 0), cop_cnt_s((size_t)n_chunks, 0);
     bool cop_overflow = false;
     int64_t cop_published = 0;
     const int cop_T = cop ? host_threads_for(n) : 0;
@@ -1607,9 +1609,9 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
         }
     } cop_team;
     auto cop_stripe = [&](int64_t ci, int w) {
-        cop_copy_stripe(cop_stage + cop_lay.base(cut[(size_t)ci], ci), cop_base_r[(size_t)ci + 1] - cop_base_r[(size_t)ci],
-                        cop_base_s[(size_t)ci + 1] - cop_base_s[(size_t)ci], cop_base_r[(size_t)ci], cop_base_s[(size_t)ci], cop, w,
-                        cop_T);
+        if (cop_cnt_r[(size_t)ci] == 0 && cop_cnt_s[(size_t)ci] == 0) return;
+        cop_copy_stripe(cop_stage + cop_lay.base(cut[(size_t)ci], ci), cop_cnt_r[(size_t)ci], cop_cnt_s[(size_t)ci],
+                        cop_base_r[(size_t)ci], cop_base_s[(size_t)ci], cop, w, cop_T);
     };
     auto cop_worker = [&](int w) {
         for (int64_t ci = 0; ci < n_chunks; ++ci) {
@@ -1639,10 +1641,9 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
             cop_base_s[(size_t)ci + 1] = cop_base_s[(size_t)ci] + (int64_t)(tot & 0xFFFFFFFFull);
             if (cop_base_r[(size_t)ci + 1] > cop->rows_capacity || cop_base_s[(size_t)ci + 1] > cop->slots_capacity)
                 cop_overflow = true;
-            if (cop_overflow) {  // count on (the caller learns what it needs), copy nothing more
-                cop_base_r[(size_t)ci] = cop_base_r[(size_t)ci + 1];
-                cop_base_s[(size_t)ci] = cop_base_s[(size_t)ci + 1];
-            }
+            // count on (the caller learns what it needs); an overflowing chunk and all behind it copy nothing
+            cop_cnt_r[(size_t)ci] = cop_overflow ? 0 : (int64_t)(tot >> 32);
+            cop_cnt_s[(size_t)ci] = cop_overflow ? 0 : (int64_t)(tot & 0xFFFFFFFFull);
             if (timing)
                 fprintf(stderr, "[adh]   compact chunk %lld: %lld rows, %lld slots on the host %.2f ms after the call began\n",
                         (long long)ci, (long long)(tot >> 32), (long long)(tot & 0xFFFFFFFFull), now() - t_0);
@@ -2157,6 +2158,12 @@ int adh_host_alloc(void **ptr, uint64_t bytes) {
 int adh_trim_device_cache(void) {
     const hipError_t e = adh_dev_trim();
     if (e != hipSuccess) return fail(ADH_ERR_HIP, std::string("adh_trim_device_cache: ") + hipGetErrorString(e));
+    return ADH_OK;
+}
+
+int adh_host_threads(int64_t n_rows, int32_t *threads, int32_t *cpu_budget) {
+    if (threads) *threads = host_threads_for(n_rows);
+    if (cpu_budget) *cpu_budget = host_cpu_budget();
     return ADH_OK;
 }
 

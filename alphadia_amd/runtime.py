@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "adh_score_candidates_compact",
     "adh_host_take_objects",
     "adh_trim_device_cache",
+    "adh_host_threads",
     "adh_upload_candidates",
     "adh_score_uploaded",
     "adh_get_stream",
@@ -127,6 +128,16 @@ def _load():
 
 
 lib = _load()
+
+
+def host_threads(n_rows: int) -> tuple[int, int]:
+    """(threads a scoring call over ``n_rows`` candidates starts on the host, CPU budget of this process): the
+    library's ``adh_host_threads`` - cgroup quota, affinity mask, hardware threads; the rank's share of them."""
+    t, b = C.c_int32(0), C.c_int32(0)
+    fn = lib.adh_host_threads
+    fn.argtypes = [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    _check(fn(int(n_rows), C.byref(t), C.byref(b)), "adh_host_threads")
+    return int(t.value), int(b.value)
 
 
 _pylib = None       # the same library through ctypes.PyDLL: calls keep the GIL (adh_host_take_objects needs that)

@@ -521,16 +521,11 @@ def _host_pool():
     if _HOST_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        n = os.cpu_count() or 4
-        try:
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if quota != "max":
-                n = min(n, max(1, int(float(quota) / float(period))))
-        except (OSError, ValueError):
-            pass
-        # this rank's share of the node: LOCAL_WORLD_SIZE ranks build their frames side by side
-        ranks = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1), 1)
-        n = int(os.environ.get("ADH_HOST_THREADS", min(max(n // ranks, 1), 16)))
+        # the library's own figure (adh_host_threads): cgroup quota, affinity mask and hardware threads, this rank's
+        # share of them (LOCAL_WORLD_SIZE ranks build their frames side by side), at most 16; ADH_HOST_THREADS overrides
+        from . import runtime as _rt
+
+        n = _rt.host_threads(1 << 40)[0]
         _HOST_POOL = (ThreadPoolExecutor(max_workers=max(n, 1), thread_name_prefix="adh_collect"), max(n, 1))
     return _HOST_POOL
 

@@ -335,6 +335,17 @@ int adh_host_free(void *ptr);
 int adh_trim_device_cache(void);
 
 /*
+ * How many host threads a scoring call over a table of n_rows candidates starts for its host-side work (rebuilding the
+ * id / library columns behind the copy-out, unpacking the compact blocks), and the CPU budget that number is cut from:
+ * the smallest of the hardware threads, the scheduler affinity mask and the cgroup CPU quota (cpu.max), divided by
+ * LOCAL_WORLD_SIZE - the ranks of a node share one quota -, at most 16, a thread per 16 384 rows at least;
+ * ADH_HOST_THREADS overrides it.  Replaces the `thread_count` argument of CandidateScoring.__call__
+ * (alphadia/search/scoring/scoring.py:583-661, `alphatims.utils.set_threads`), which the reference leaves to the caller.
+ * Needs no GPU.  Either pointer may be NULL.
+ */
+int adh_host_threads(int64_t n_rows, int32_t *threads, int32_t *cpu_budget);
+
+/*
  * dst[i] = src[idx[i]] for n entries of arrays of CPython object pointers (NumPy dtype=object) - the string columns
  * the features frame takes over from the precursor table (scoring.py:430-445 merges them in) - on `threads` host
  * threads, reference counts raised atomically.  The caller must hold the GIL for the whole call (ctypes.PyDLL) and

@@ -40,6 +40,19 @@ def _cfg():
     return cfg
 
 
+ORACLE_STRIDE_CONFIG2 = int(os.environ.get("ADH_TEST_ORACLE_STRIDE", "5"))
+# Share of the compared rows the knife-edge masks of compare() may leave out of THEIR feature (16, 18, 19: 0 / 0 forms
+# that hang on the last bit of a float64 exp).  Measured on the pool (gpurun_out/parity_masks.jsonl, round 6): see
+# MASK_BOUNDS below - the bound is the measured share plus a margin, not a quarter of the sample.
+MASK_BOUNDS = {16: 0.02, 18: 0.02, 19: 0.02}
+
+
+def _bound_masked(m: dict) -> None:
+    print(f"[full size] knife-edge rows of {m['rows']} compared: {m}")
+    for f, share in MASK_BOUNDS.items():
+        assert m[f] <= share * m["rows"], (f, m)
+
+
 def _rows(soa: dict, idx) -> dict:
     n = len(soa["precursor_idx"])
     return {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in soa.items()}
@@ -58,20 +71,21 @@ def headline(ctx):
 
 
 def test_config2_full_size_one_gpu(ctx, oracle_lib, headline):
-    """configs[2] on one GPU: all 3 000 000 candidates; every 150th row against the oracle (all 46 features
-    incl. the ppm ones, every fragment table, matched-peak counts); planted precursors are found."""
+    """configs[2] on one GPU: all 3 000 000 candidates; every 5th row (600 000) against the oracle (all 46 features
+    incl. the ppm ones, every fragment table, matched-peak counts; bench.py compares all 3 M); planted precursors
+    are found."""
     case, cfg, soa, got = headline
     n = len(soa["precursor_idx"])
     assert n == 3_000_000 and case.dia.mz_values.size > 4.5e8
     assert 0.85 < got["valid"].mean() <= 1.0
-    idx = np.arange(0, n, 150)
+    idx = np.arange(0, n, ORACLE_STRIDE_CONFIG2)
     exp, _ = H.oracle_score(oracle_lib, case, cfg, soa=_rows(soa, idx), n_threads=THREADS, with_stats=True)
     compare({k: v[idx] for k, v in got.items()}, exp, PPM_ABS_TOL_ORACLE)
     # the knife-edge masks of compare() (features 16, 18, 19 where the operands are exactly equal) must stay a
     # small share of the sample: a comparison that masks most rows would not be one
     m = compare.last_masked
     print(f"[full size] knife-edge rows of {m['rows']} compared: {m}")
-    assert max(m[16], m[18], m[19]) <= 0.25 * m["rows"], m
+    _bound_masked(m)
     assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
     planted = case.apex_cycle[soa["precursor_idx"]] >= 0
     r0 = planted & (soa["rank"] == 0)
@@ -119,7 +133,7 @@ def test_config2_score_group_shards_reassemble(ctx, headline, world):
 
 def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     """configs[3] as specified: 918 scans x 2 000 cycles (1 MS1 + 8 diaPASEF frames per cycle), 200 000
-    precursors x 3 candidates of 17-39 scans x 7-29 cycles; every 300th candidate against the oracle; repeated runs
+    precursors x 3 candidates of 17-39 scans x 7-29 cycles; EVERY candidate against the oracle; repeated runs
     identical; permutation invariance."""
     case = syn.make_timstof_case(
         n_precursors=200_000, n_cycles=2000, config_id=4, per_precursor=3, n_ms2_frames=8, windows_per_frame=3,
@@ -140,11 +154,10 @@ def test_config3_full_size_ion_mobility(ctx, oracle_lib):
     got = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
     v = got["valid"].astype(bool)
     assert n == 600_000 and v.mean() > 0.5 and (got["features"][v][:, 29] != 0).mean() > 0.3
-    idx = np.arange(0, n, 300)
-    exp = oracle_lib.score_timstof(case.dia, cols, pack_assembled(_rows(soa, idx)), cfgj, n_threads=THREADS,
-                                   with_stats=True)
-    compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
-    assert np.array_equal(got["stat_matched_peaks"][idx], exp["stat_matched_peaks"])
+    exp = oracle_lib.score_timstof(case.dia, cols, pack_assembled(soa), cfgj, n_threads=THREADS, with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)  # all 600 000 candidates
+    _bound_masked(compare.last_masked)
+    assert np.array_equal(got["stat_matched_peaks"], exp["stat_matched_peaks"])
     got = {k: np.array(x, copy=True) for k, x in got.items()}
     for _ in range(3):  # run-to-run identical (a register hazard in an unrolled MFMA chain once broke this for feature 29)
         again = ctx.score_host(pack_assembled(soa), cfgj, with_stats=True)
@@ -159,7 +172,7 @@ def test_config3_full_size_ion_mobility(ctx, oracle_lib):
 def test_config4_full_size_multiplex(ctx, oracle_lib):
     """configs[4] as specified: 75 000 elution groups x label channels {0, 4, 8, 12} = 300 000 precursors against
     the 2 h run, scored as MultiplexingRequantificationHandler scores them (class-default config + score_grouped,
-    exclude_shared_ions, reference channel 0: multiplexing_requantification_handler.py:95-140): every 100th score
+    exclude_shared_ions, reference channel 0: multiplexing_requantification_handler.py:95-140): every score
     group against the oracle, and the four-way score-group split of the configuration (4 GPUs) scored shard by
     shard gives the rows of the unsharded table - no group is cut."""
     from alphadia_amd.distributed import shard_bounds, slice_soa
@@ -183,9 +196,10 @@ def test_config4_full_size_multiplex(ctx, oracle_lib):
     got = {k: np.array(v, copy=True) for k, v in got.items()}
     v = got["valid"].astype(bool)
     assert 0.5 < v.mean() < 0.95
-    idx = np.flatnonzero(soa["score_group_idx"] % 100 == 0)  # whole score groups
-    exp = oracle_lib.score(mc.dia, cols, pack_assembled(_rows(soa, idx)), cfgj, n_threads=THREADS, with_stats=True)
-    compare({k: x[idx] for k, x in got.items()}, exp, PPM_ABS_TOL_ORACLE)
+    idx = np.arange(n)  # every score group
+    exp = oracle_lib.score(mc.dia, cols, pack_assembled(soa), cfgj, n_threads=THREADS, with_stats=True)
+    compare(got, exp, PPM_ABS_TOL_ORACLE)
+    _bound_masked(compare.last_masked)
     # (the diagnostic peak counter on the rows that were scored: the label shift moves some channel copies above the
     # last isolation window - no MS2 observation at all - where the reference still extracts MS1 before the candidate
     # fails at the presence mask (candidate.py:220-329) and the plan on the device drops the candidate at once)

@@ -393,3 +393,44 @@ def test_the_median_network_of_the_fused_kernel_sorts_every_zero_one_input():
         lo, hi = np.minimum(bits[:, a], bits[:, b]), np.maximum(bits[:, a], bits[:, b])
         bits[:, a], bits[:, b] = lo, hi
     assert (np.diff(bits, axis=1) >= 0).all()
+
+
+def test_host_threads_follow_the_cgroup_quota(tmp_path, monkeypatch):
+    """the host team of a scoring call is cut from the cgroup CPU quota (cpu.max), not from the
+    hardware thread count, and LOCAL_WORLD_SIZE ranks share that quota.  adh_host_threads needs no GPU."""
+    import os
+
+    from alphadia_amd import runtime
+
+    monkeypatch.delenv("ADH_HOST_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    fake = tmp_path / "cpu.max"
+    monkeypatch.setenv("ADH_CGROUP_CPU_MAX", str(fake))
+    visible = len(os.sched_getaffinity(0))
+    big = 1 << 40
+
+    fake.write_text("max 100000\n")
+    t, budget = runtime.host_threads(big)
+    assert budget == visible and t == min(16, visible)
+
+    # a quota of 16 cores on a box that shows 256 hardware threads (the pool's GPU boxes): eight ranks -> two threads
+    fake.write_text("1600000 100000\n")
+    t1, budget = runtime.host_threads(big)
+    assert budget == min(16, visible) and t1 == min(16, visible)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    t8, _ = runtime.host_threads(big)
+    assert t8 == max(min(16, visible) // 8, 1)
+    total_threads_on_the_node = 8 * t8
+    assert total_threads_on_the_node <= max(budget, 8)
+
+    # fractional and tiny quotas: at least one thread
+    fake.write_text("50000 100000\n")
+    assert runtime.host_threads(big) == (1, 1)
+    # small tables: a thread per 16 384 rows at least
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    fake.write_text("max 100000\n")
+    assert runtime.host_threads(20000)[0] == 1
+    assert runtime.host_threads(3 * 16384)[0] == min(3, visible)
+    # the override
+    monkeypatch.setenv("ADH_HOST_THREADS", "5")
+    assert runtime.host_threads(big)[0] == 5
