@@ -294,11 +294,12 @@ size_t adh_feature_im_lds_bytes(const Caps &c) {
 // SPLIT (round 4, fixed layouts only): the kernel ends after the passes over the tiles and writes the candidate's
 // ImProfRec<LAY::Fc, LAY::Sc> to `prof` (record blockIdx.x); adh_feature_im_profiles_kernel does the rest, four
 // candidates per wavefront.
-template <class LAY, bool SPLIT = false>
-__global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
-    DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
-    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
-    DevOut out, Caps caps, unsigned char *__restrict__ prof = nullptr) {
+// The kernel's body for candidate `ci` of `plan` (the kernels below: one block per candidate, or a block per list entry)
+template <class LAY, bool SPLIT>
+__device__ __forceinline__ void adh_feature_im_body(
+    const int ci, const DevTims &run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, const adh_scoring_config_t &cfg, const unsigned char *__restrict__ scratch, const DevOut &out,
+    const Caps &caps, unsigned char *__restrict__ prof) {
     using namespace featim;
     extern __shared__ __align__(16) unsigned char smem[];
     // ordered list of the non-zero cells of one 64-cell chunk (see the tile passes below)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     uint8_t *const By = reinterpret_cast<uint8_t *>(In) + ((size_t)lay.n_int() * 4 + 7) / 8 * 8;
 
     const int lane = threadIdx.x;
-    const CandRecIM &r = plan[blockIdx.x];
+    const CandRecIM &r = plan[ci];
     if (r.flags & ADH_FLAG_SKIP) return;
     const unsigned char *block = scratch + r.scratch_off;
     const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
         static_assert(LAY::Oc <= 2 && LAY::Kc <= ADH_IM_PROF_K && LAY::Ic <= 4, "the split path takes one or two observations");
         constexpr int NOc = LAY::Oc;
         typedef ImProfRec<LAY::Fc, LAY::Sc, NOc> Rec;
-        Rec &rec = reinterpret_cast<Rec *>(prof)[blockIdx.x];
+        Rec &rec = reinterpret_cast<Rec *>(prof)[ci];
         constexpr int FMc = LAY::Fc, SMc = LAY::Sc;
         const int shift = F / 2 - FMc / 2;  // entry r <-> cycle r + shift
         // template frame profiles: sums over the scans, in scan order (the monolithic kernel takes them below);
@@ -1826,4 +1827,27 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
         }
     }
     if (lane == 0) out.valid[row] = 1;
+}
+
+template <class LAY, bool SPLIT = false>
+__global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
+    DevOut out, Caps caps, unsigned char *__restrict__ prof = nullptr) {
+    adh_feature_im_body<LAY, SPLIT>((int)blockIdx.x, run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
+}
+
+// The candidates adh_feature_im_tile4_kernel (adh_features_im4.hip) left aside - tiles that had to be materialised,
+// ADH_IM_MODE_DENSE - by the split body above: list[0] candidates at plan positions list[1 ...], the blocks of a
+// small fixed grid take them in turn (the host does not know the count).
+template <class LAY>
+__global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_list_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
+    DevOut out, Caps caps, unsigned char *__restrict__ prof, const uint32_t *__restrict__ list) {
+    const uint32_t n = list[0];
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        adh_feature_im_body<LAY, true>((int)list[1u + j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
+        __syncthreads();  // (the next candidate reuses the LDS arrays)
+    }
 }

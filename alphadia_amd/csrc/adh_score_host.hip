@@ -530,7 +530,15 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     const uint64_t prof_base = (p.scratch_bytes + 255) / 256 * 256;
     const uint64_t prof_small_off = prof_base + (split_common ? (uint64_t)p.n_class[0] * sizeof(ProfCommon) : 0);
     const uint64_t prof_two_off = prof_small_off + (split_small ? (uint64_t)p.n_class[ADH_CLASS_IM_SMALL] * sizeof(ProfSmall) : 0);
-    const uint64_t prof_bytes = prof_two_off + (split_two ? (uint64_t)p.n_class[1] * sizeof(ProfCommon2) : 0);
+    const uint64_t prof_end = prof_two_off + (split_two ? (uint64_t)p.n_class[1] * sizeof(ProfCommon2) : 0);
+    // Round 6: the one-observation split classes go through adh_feature_im_tile4_kernel (four candidates per
+    // wavefront, adh_features_im4.hip); the candidates it leaves aside (materialised tiles) are listed behind the
+    // records - per class a counter and the plan positions - and taken by adh_feature_im_list_kernel.
+    // ADH_DEBUG_IM_TILE1=1: the one-candidate-per-wavefront tile kernel everywhere.
+    const bool tile4 = !getenv("ADH_DEBUG_IM_TILE1");
+    const uint64_t list_common_off = (prof_end + 255) / 256 * 256;
+    const uint64_t list_small_off = list_common_off + (tile4 && split_common ? ((uint64_t)p.n_class[0] + 1 + 63) / 64 * 256 : 0);
+    const uint64_t prof_bytes = list_small_off + (tile4 && split_small ? ((uint64_t)p.n_class[ADH_CLASS_IM_SMALL] + 1 + 63) / 64 * 256 : 0);
     int rc = ensure_scratch(h, prof_bytes);
     if (rc != ADH_OK) return rc;
     unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
@@ -557,8 +565,19 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                 const bool fixed_ok = fixed_layouts;
                 const bool common = featim::DimsCommon::holds(cc) && fixed_ok;
                 const unsigned groups = (unsigned)((cnt + ADH_WAVE / 16 - 1) / (ADH_WAVE / 16));
+                const unsigned list_blocks = (unsigned)std::min<int64_t>(cnt, 2048);  // (they take the listed candidates in turn)
                 if (c == ADH_CLASS_IM_SMALL && split_small) {
                     unsigned char *prof = d_scratch + prof_small_off;
+                    if (tile4) {
+                        uint32_t *list = reinterpret_cast<uint32_t *>(d_scratch + list_small_off);
+                        HIP_TRY(hipMemsetAsync(list, 0, 4, st));
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), dim3(groups),
+                                           dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, h->cs.iso, n_iso, *cfg,
+                                           d_scratch, *out, prof, list);
+                        hipLaunchKernelGGL((adh_feature_im_list_kernel<featim::LayoutSmall>), dim3(list_blocks), dim3(ADH_WAVE),
+                                           featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                           *cfg, d_scratch, *out, cc, prof, list);
+                    } else
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutSmall, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc, prof);
@@ -575,6 +594,16 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                        d_scratch, prof, *out);
                 } else if (c == 0 && split_common) {
                     unsigned char *prof = d_scratch + prof_base;
+                    if (tile4) {
+                        uint32_t *list = reinterpret_cast<uint32_t *>(d_scratch + list_common_off);
+                        HIP_TRY(hipMemsetAsync(list, 0, 4, st));
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), dim3(groups),
+                                           dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, h->cs.iso, n_iso, *cfg,
+                                           d_scratch, *out, prof, list);
+                        hipLaunchKernelGGL((adh_feature_im_list_kernel<featim::LayoutCommon>), dim3(list_blocks), dim3(ADH_WAVE),
+                                           featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
+                                           *cfg, d_scratch, *out, cc, prof, list);
+                    } else
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc, prof);

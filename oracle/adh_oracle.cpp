@@ -1348,6 +1348,16 @@ bool process_candidate(const RunView &rv, const adh_fragments_t &lib, const Cand
  * ===================================================================================== */
 namespace select_oracle {
 
+/* Test hooks (tests/test_selection.py).  `smooth_log`: replaces the exact float64 circular
+   convolution AND the log: given one dense (S, F) float32 tile it returns log(smooth + 1) as float32 - the test passes
+   the float32 FFT smoothing the golden was made with (tests/golden/ref_shim.py convolve_fourier: rfft2 / irfft2 of the
+   tile's own shape, selection/fft.py:119-212), so that everything BEHIND the smoothing is this restatement.  `score`:
+   receives every precursor's (S, F) score matrix.  Both NULL outside those tests; not thread-safe (n_threads = 1). */
+typedef void (*smooth_log_hook_t)(const float *tile, int32_t S, int32_t F, float *out);
+typedef void (*score_hook_t)(int64_t precursor, int32_t S, int32_t F, const double *score);
+static smooth_log_hook_t g_smooth_log_hook = nullptr;
+static score_hook_t g_score_hook = nullptr;
+
 struct Box {
     int scan, cycle;
     double score;
@@ -1481,11 +1491,26 @@ static void select_one(const adh_alpharaw_t &d, const adh_fragments_t &fr, const
     {
         std::vector<float> lf(F, 0.0f), lp(F, 0.0f);
         const int K = (int)fmz.size();
+        /* (test hook: the (2, F) tile - both scan slots the same row - through the caller's smoothing + log) */
+        auto hooked = [&](const float *row, std::vector<float> &lsum) {
+            std::vector<float> tile2((size_t)2 * F), out2((size_t)2 * F);
+            for (int f = 0; f < F; ++f) tile2[f] = tile2[(size_t)F + f] = row[f];
+            g_smooth_log_hook(tile2.data(), 2, F, out2.data());
+            for (int f = 0; f < F; ++f) lsum[f] += out2[f];
+        };
         for (int k = 0; k < K; ++k) {
+            if (g_smooth_log_hook) {
+                hooked(&tf[(size_t)k * F], lf);
+                continue;
+            }
             smooth_row(&tf[(size_t)k * F], 0, tmp);
             for (int f = 0; f < F; ++f) lf[f] += (float)std::log((double)(tmp[f] + 1.0f));
         }
         for (int k = 0; k < n_iso; ++k) {
+            if (g_smooth_log_hook) {
+                hooked(&tp[(size_t)k * F], lp);
+                continue;
+            }
             smooth_row(&tp[(size_t)k * F], 0, tmp);
             for (int f = 0; f < F; ++f) lp[f] += (float)std::log((double)(tmp[f] + 1.0f));
         }
@@ -1509,6 +1534,7 @@ static void select_one(const adh_alpharaw_t &d, const adh_fragments_t &fr, const
     }
     std::vector<double> score(F);
     for (int f = 0; f < F; ++f) score[f] = weight * ((double)feat[f] - mean) / (sd + 1e-6);
+    if (g_score_hook) g_score_hook(i, 1, F, score.data());
 
     /* find_peaks_1d (selection/utils.py:49-77) on scan row 0 */
     std::vector<Box> peaks;
@@ -1821,6 +1847,12 @@ static void select_one_im(const adh_timstof_t &d, const adh_fragments_t &fr, con
     /* separable circular smoothing, kernel centred at (k0/2, k1/2): first along the cycles, then
        along the scans; each pass accumulates in float64 and rounds to float32 once */
     auto smooth_add_log = [&](const std::vector<float> &tile, std::vector<float> &lsum) {
+        if (g_smooth_log_hook) {
+            std::vector<float> lg((size_t)S * F);
+            g_smooth_log_hook(tile.data(), S, F, lg.data());
+            for (size_t c = 0; c < lg.size(); ++c) lsum[c] += lg[c];
+            return;
+        }
         std::vector<float> tmp((size_t)S * F);
         for (int s = 0; s < S; ++s)
             for (int f = 0; f < F; ++f) {
@@ -1878,6 +1910,7 @@ static void select_one_im(const adh_timstof_t &d, const adh_fragments_t &fr, con
     }
     std::vector<double> score((size_t)S * F);
     for (size_t c = 0; c < score.size(); ++c) score[c] = weight * ((double)(lf[c] + lp[c]) - mean) / (sd + 1e-6);
+    if (g_score_hook) g_score_hook(i, S, F, score.data());
     std::vector<Box> peaks;
     candidates_from_score(score, S, F, cfg, peaks);
     auto wrap0 = [](int64_t v, int64_t limit) { return v < 0 ? (int64_t)0 : std::min(v, limit); };
@@ -2067,6 +2100,13 @@ int adh_oracle_select_timstof(const adh_timstof_t *run, const adh_fragments_t *f
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
     for (int64_t i = 0; i < n; ++i) select_oracle::select_one_im(*run, *fragments, *precursors, *config, ku, kv, i, *out);
     return 0;
+}
+
+/* test hooks of the selection restatement (see select_oracle::smooth_log_hook_t); NULL switches a hook off */
+void adh_oracle_set_selection_hooks(void (*smooth_log)(const float *, int32_t, int32_t, float *),
+                                    void (*score)(int64_t, int32_t, int32_t, const double *)) {
+    select_oracle::g_smooth_log_hook = smooth_log;
+    select_oracle::g_score_hook = score;
 }
 
 /* ---- known-answer helpers of the selection restatement (tests only) ---- */

@@ -302,3 +302,31 @@ def select_timstof(dia, fragment_cols, precursors_marshalled, cfg, kernel, n_thr
     if rc != 0:
         raise RuntimeError(f"adh_oracle_select_timstof failed ({rc})")
     return arrays
+
+
+# ---- test hooks of the selection restatement (adh_oracle.cpp: select_oracle::smooth_log_hook_t) -------------------
+_SMOOTH_LOG_T = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float))
+_SCORE_T = C.CFUNCTYPE(None, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double))
+_hooks_alive = []  # (ctypes callbacks must outlive their registration)
+
+
+def set_selection_hooks(smooth_log=None, score=None) -> None:
+    """``smooth_log(tile: float32 (S, F)) -> float32 (S, F)`` replaces the restatement's exact circular convolution AND
+    the log (it returns ``log(smooth + 1)``); ``score(precursor: int, matrix: float64 (S, F))`` sees every score
+    matrix.  ``None`` switches a hook off.  Single-threaded calls only (``n_threads=1``)."""
+    def wrap_smooth(tile, S, F, out):
+        a = np.ctypeslib.as_array(tile, shape=(S, F))
+        res = np.ascontiguousarray(smooth_log(a), dtype=np.float32)
+        assert res.shape == (S, F)
+        np.ctypeslib.as_array(out, shape=(S, F))[:] = res
+
+    def wrap_score(i, S, F, p):
+        score(int(i), np.ctypeslib.as_array(p, shape=(S, F)).copy())
+
+    cs = _SMOOTH_LOG_T(wrap_smooth) if smooth_log is not None else C.cast(None, _SMOOTH_LOG_T)
+    cc = _SCORE_T(wrap_score) if score is not None else C.cast(None, _SCORE_T)
+    _hooks_alive[:] = [cs, cc]
+    fn = lib().adh_oracle_set_selection_hooks
+    fn.argtypes = [_SMOOTH_LOG_T, _SCORE_T]
+    fn.restype = None
+    fn(cs, cc)

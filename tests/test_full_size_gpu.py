@@ -41,16 +41,18 @@ def _cfg():
 
 
 ORACLE_STRIDE_CONFIG2 = int(os.environ.get("ADH_TEST_ORACLE_STRIDE", "5"))
-# Share of the compared rows the knife-edge masks of compare() may leave out of THEIR feature (16, 18, 19: 0 / 0 forms
-# that hang on the last bit of a float64 exp).  Measured on the pool (gpurun_out/parity_masks.jsonl, round 6): see
-# MASK_BOUNDS below - the bound is the measured share plus a margin, not a quarter of the sample.
-MASK_BOUNDS = {16: 0.02, 18: 0.02, 19: 0.02}
+# The knife-edge masks of compare() (features 16, 18, 19: 0 / 0 forms that hang on the last bit of a float64 exp).
+# Most ELIGIBLE rows are candidates without signal, where both sides agree anyway; what is bounded here is the share of
+# the compared rows a mask actually RESCUED - rows that would have failed the comparison of that feature.  Measured on
+# the pool (gpurun_out/parity_masks.jsonl, round 6) - see DESIGN.md section 5; the bound is the measured share plus a
+# margin, not a quarter of the sample.
+RESCUED_BOUND = 2e-3
 
 
 def _bound_masked(m: dict) -> None:
     print(f"[full size] knife-edge rows of {m['rows']} compared: {m}")
-    for f, share in MASK_BOUNDS.items():
-        assert m[f] <= share * m["rows"], (f, m)
+    for f, n in m["rescued"].items():
+        assert n <= RESCUED_BOUND * m["rows"], (f, m)
 
 
 def _rows(soa: dict, idx) -> dict:

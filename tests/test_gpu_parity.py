@@ -44,8 +44,9 @@ def _log_masked(masked: dict) -> None:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "parity_masks.jsonl"), "a") as f:
             f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0],
-                                "rows": masked["rows"], "masked_16": masked[16], "masked_18": masked[18],
-                                "masked_19": masked[19]}) + "\n")
+                                "rows": masked["rows"], "eligible_16": masked[16], "eligible_18": masked[18],
+                                "eligible_19": masked[19], "differing_16": masked["rescued"][16],
+                                "differing_18": masked["rescued"][18], "differing_19": masked["rescued"][19]}) + "\n")
     except OSError:
         pass
 
@@ -70,10 +71,18 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     # exp() (device libm vs glibc): rows whose filled slots all show the same value are knife-edge and
     # excluded from the comparison of that feature.
     filled = exp["fragment_type"][v] != 0
-    masked = {}
+    masked, rescued = {}, {}
+
+    def _disagree(a, b):  # rows a comparison would have failed on: NaN on one side only, or beyond the tolerance
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        with np.errstate(invalid="ignore"):
+            far = np.abs(a - b) > rel_tol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+        return (np.isnan(a) != np.isnan(b)) | (far & ~np.isnan(a) & ~np.isnan(b))
+
     for f, table in ((18, "fragment_intensity"), (19, "fragment_height")):
         x = np.where(filled, exp[table][v], np.nan)
         flat = (np.nanmax(x, axis=1) == np.nanmin(x, axis=1)) if x.shape[1] else np.zeros(len(x), bool)
+        rescued[f] = int((flat & _disagree(gf[:, f], ef[:, f])).sum())
         gf[flat, f] = 0.0
         ef[flat, f] = 0.0
         masked[f] = int(flat.sum())
@@ -81,15 +90,18 @@ def compare(got, exp, ppm_tol, rel_tol=REL_TOL, corr_abs=0.0):
     # same kind of knife edge: isotope planes of equal height (e.g. one event of 5 counts each) give
     # numerator / (denominator + 1e-12) with both ~1e-16 or exactly 0, depending on the last bit of exp()
     knife = ((gf[:, 16] == 0.0) | (ef[:, 16] == 0.0)) & (np.abs(gf[:, 16]) < 1e-3) & (np.abs(ef[:, 16]) < 1e-3)
+    rescued[16] = int((knife & _disagree(gf[:, 16], ef[:, 16])).sum())
     gf[knife, 16] = 0.0
     ef[knife, 16] = 0.0
     masked[16] = int(knife.sum())
-    # how many rows the three knife-edge masks took out of the comparison of their feature;
-    # `pytest -s` / the full-size tests show it, compare.last_masked keeps it for assertions
-    compare.last_masked = dict(masked, rows=int(v.sum()))
+    # `masked`: rows ELIGIBLE for a mask (mostly candidates without signal: every filled slot 0, both sides NaN or 0
+    # alike - the mask changes nothing there); `rescued`: rows the mask actually took out of a comparison that would
+    # have failed.  compare.last_masked keeps both, gpurun_out/parity_masks.jsonl logs both, the
+    # full-size tests bound the second.
+    compare.last_masked = dict(masked, rows=int(v.sum()), rescued=rescued)
     _log_masked(compare.last_masked)
-    print(f"[compare] {int(v.sum())} valid rows; knife-edge rows left out: feature 16: {masked[16]}, 18: {masked[18]}, "
-          f"19: {masked[19]}")
+    print(f"[compare] {int(v.sum())} valid rows; knife-edge rows eligible / actually differing: feature 16: {masked[16]} / "
+          f"{rescued[16]}, 18: {masked[18]} / {rescued[18]}, 19: {masked[19]} / {rescued[19]}")
     assert np.array_equal(np.isnan(gf), np.isnan(ef)), "NaN pattern differs"
     for f in EXACT_FEATURES:
         assert np.array_equal(gf[:, f], ef[:, f]), f"feature {f} must be exact"

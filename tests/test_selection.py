@@ -1,14 +1,20 @@
 """Candidate selection: oracle vs goldens produced by running the reference,
 HIP vs oracle.
 
-The reference smooths with a float32 FFT (selection/fft.py); the golden was produced with
-``np.fft`` as a stand-in for rocket_fft (tests/golden/ref_shim.py).  Either carries ~1e-3 of
-absolute noise on tiles whose intensities reach 1e3-1e4, which (a) moves scores by up to ~1e-3
-relative and (b) creates a few extra low-score peaks in flat regions.  The exact convolution of
-the oracle / HIP kernel has neither, so the comparison with the golden is:
-every produced row exists in the golden with identical boxes (a few near-tie rank swaps
-allowed), scores within 5e-3 relative, and the golden rows that are not reproduced are few and
-never a precursor's best candidate.  HIP vs oracle is exact."""
+The reference smooths with a float32 FFT (selection/fft.py:119-212); the golden was produced with
+``np.fft`` as a stand-in for rocket_fft (tests/golden/ref_shim.py), results cast to complex64 / float32.
+The oracle and the HIP kernels evaluate the same circular convolution exactly (float64, rounded once).
+Round 6 pins what that difference is and nothing more:
+
+* with the golden's own smoothing plugged in (``oracle.set_selection_hooks``: rfft2 / irfft2 of the tile's shape in
+  complex64 / float32, then ``log(smooth + 1)``) the restatement reproduces EVERY row of all three goldens - boxes,
+  ranks and the bits of the score: everything behind the smoothing is pinned exactly;
+* with the exact convolution a few rows differ (9 of 649, 4 of 1 134, 8 of 167): each belongs to a precursor whose
+  score matrix the two smoothings move apart by at most ``NEAR_TIE_SCORE`` (5e-3 in units of the standardised score,
+  whose range is +-130: 4e-5 of it; 3.7e-3 / 2.7e-3 / 1.8e-4 measured) - a perturbation of that size flips the
+  outcome, i.e. a near-tie - and no precursor's best candidate is among them.
+
+HIP vs oracle is exact, so the same holds for the product."""
 import os
 import types
 
@@ -52,25 +58,134 @@ def _frame(arrays):
     return pd.DataFrame({c: arrays[c][keep] for c in CANDIDATE_COLUMNS})
 
 
-def _compare_with_golden(got: pd.DataFrame, z, name):
-    exp = pd.DataFrame({c: z[f"{name}_out_{c}"] for c in CANDIDATE_COLUMNS})
+NEAR_TIE_SCORE = 5e-3  # largest move of a score matrix between the two smoothings that explains a differing row
+
+
+def golden_fft_smooth_log(kernel):
+    """The smoothing + log the goldens were made with (ref_shim.py convolve_fourier, selection.py:206-226), for one
+    (S, F) float32 tile: circular convolution through rfft2 / irfft2 of the tile's own shape in complex64 / float32,
+    the kernel centred by the four-quadrant copy of selection/fft.py:163-212."""
+    k0, k1 = kernel.shape
+    d0, d1 = -k0 // 2, -k1 // 2
+
+    def smooth_log(tile):
+        shape = tile.shape
+        ff = np.fft.rfft2(kernel.astype(np.float32), shape).astype(np.complex64)
+        spec = np.fft.rfft2(tile).astype(np.complex64)
+        layer = np.fft.irfft2(spec * ff, shape).astype(np.float32)
+        o = np.zeros_like(tile)
+        o[d0:, d1:] = layer[:-d0, :-d1]
+        o[:d0, d1:] = layer[-d0:, :-d1]
+        o[d0:, :d1] = layer[:-d0, -d1:]
+        o[:d0, :d1] = layer[-d0:, -d1:]
+        return np.log(o + 1)
+
+    return smooth_log
+
+
+def _golden_case(kind, name):
+    if kind == "raw":
+        z, dia, fdf, pdf = _load()
+        return z, dia, fdf, pdf, _cfg(z, name), z[name + "_kernel"], name + "_out_"
+    z, dia, fdf, pdf, cfg = _load_tims()
+    return z, dia, fdf, pdf, cfg, z["kernel"], "out_"
+
+
+def _differing_rows(got: pd.DataFrame, exp: pd.DataFrame) -> pd.DataFrame:
+    """Rows (precursor_idx, rank) that are not in both tables with the same box."""
     m = got.merge(exp, on=["precursor_idx", "rank"], how="outer", suffixes=("_g", "_e"), indicator=True)
-    both = m[m["_merge"] == "both"]
+    diff = (m["_merge"] != "both").values
+    for c in BOX:
+        diff |= (m[c + "_g"] != m[c + "_e"]).values
+    return m[diff]
+
+
+_EXPLAINED = {}
+
+
+def near_tie_precursors(oracle, kind, name):
+    """precursor_idx -> largest absolute difference between the score matrix under the exact convolution and under the
+    golden's FFT smoothing (both through the restatement, single-threaded; the score hook collects the matrices)."""
+    key = (kind, name)
+    if key not in _EXPLAINED:
+        z, dia, fdf, pdf, cfg, kernel, _ = _golden_case(kind, name)
+        sel = oracle.select if kind == "raw" else oracle.select_timstof
+        cols, pm = fragment_columns(fdf, "mz_library"), _pack(pdf)
+        exact, fft = {}, {}
+        try:
+            oracle.set_selection_hooks(None, lambda i, m: exact.__setitem__(i, m))
+            sel(dia, cols, pm, cfg, kernel, n_threads=1)
+            oracle.set_selection_hooks(golden_fft_smooth_log(kernel), lambda i, m: fft.__setitem__(i, m))
+            sel(dia, cols, pm, cfg, kernel, n_threads=1)
+        finally:
+            oracle.set_selection_hooks(None, None)
+        pidx = np.sort(pdf.precursor_idx.values)
+        _EXPLAINED[key] = {int(pidx[i]): float(np.abs(fft[i] - exact[i]).max()) for i in exact if i in fft}
+    return _EXPLAINED[key]
+
+
+def _compare_with_golden(got: pd.DataFrame, z, name, oracle=None, kind="raw", prefix=None):
+    """`got` (exact smoothing: the oracle's or the HIP kernels' table) against the reference golden: no row the
+    reference does not have; every row that is missing or has another box belongs to a precursor whose score matrix
+    the golden's FFT smoothing moves by at most NEAR_TIE_SCORE (and by more than 0), and is never a precursor's best
+    candidate; scores of the rows with the same box within that move (relative to the score: 5e-3)."""
+    from oracle import oracle as oracle_mod
+
+    oracle = oracle or oracle_mod
+    prefix = prefix if prefix is not None else name + "_out_"
+    exp = pd.DataFrame({c: z[prefix + c] for c in CANDIDATE_COLUMNS})
+    m = got.merge(exp, on=["precursor_idx", "rank"], how="outer", suffixes=("_g", "_e"), indicator=True)
     assert (m["_merge"] == "left_only").sum() == 0, "rows the reference does not have"
-    missing = m[m["_merge"] == "right_only"]
-    assert len(missing) <= 0.02 * len(exp), f"{len(missing)} reference rows not reproduced"
-    assert (missing["rank"] > 0).all(), "a precursor's best candidate is missing"
+    diff = _differing_rows(got, exp)
+    moved = near_tie_precursors(oracle, kind, name)
+    for p in sorted(set(diff["precursor_idx"])):
+        assert 0.0 < moved[int(p)] <= NEAR_TIE_SCORE, (p, moved[int(p)])
+    assert (diff["rank"] > 0).all(), "a precursor's best candidate differs"
+    both = m[m["_merge"] == "both"]
     same_box = np.ones(len(both), dtype=bool)
     for c in BOX:
         same_box &= (both[c + "_g"] == both[c + "_e"]).values
-    assert same_box.mean() >= 0.99, f"only {same_box.mean():.4f} of the boxes agree"
     rel = np.abs(both["score_g"] - both["score_e"]) / np.abs(both["score_e"])
     assert rel[same_box].max() <= 5e-3
-    # the best candidate of every precursor is identical
-    top = both[both["rank"] == 0]
-    for c in BOX:
-        assert (top[c + "_g"] == top[c + "_e"]).all(), c
-    return len(both), len(missing)
+    return len(both), len(diff)
+
+
+@pytest.mark.parametrize("kind,name", [("raw", "default"), ("raw", "wide"), ("tims", None)])
+def test_oracle_with_the_goldens_smoothing_reproduces_the_golden_exactly(oracle_lib, kind, name):
+    """Everything behind the smoothing is pinned bit for bit: with the float32 FFT smoothing the golden was made with
+    plugged into the restatement, every row of the golden comes out - boxes, ranks and the bits of the score."""
+    z, dia, fdf, pdf, cfg, kernel, prefix = _golden_case(kind, name)
+    sel = oracle_lib.select if kind == "raw" else oracle_lib.select_timstof
+    try:
+        oracle_lib.set_selection_hooks(golden_fft_smooth_log(kernel), None)
+        got = _frame(sel(dia, fragment_columns(fdf, "mz_library"), _pack(pdf), cfg, kernel, n_threads=1))
+    finally:
+        oracle_lib.set_selection_hooks(None, None)
+    exp = pd.DataFrame({c: z[prefix + c] for c in CANDIDATE_COLUMNS})
+    assert len(got) == len(exp) > 150
+    got = got.sort_values(["precursor_idx", "rank"]).reset_index(drop=True)
+    exp = exp.sort_values(["precursor_idx", "rank"]).reset_index(drop=True)
+    for c in CANDIDATE_COLUMNS:
+        assert np.array_equal(got[c].to_numpy(), exp[c].to_numpy()), c
+
+
+@pytest.mark.parametrize("kind,name,n_diff", [("raw", "default", 9), ("raw", "wide", 4), ("tims", None, 8)])
+def test_every_box_that_differs_from_the_reference_is_a_near_tie(oracle_lib, kind, name, n_diff):
+    """The exact convolution against the golden: the rows that differ are counted, each sits in a precursor whose score
+    matrix the two smoothings move apart by <= NEAR_TIE_SCORE, none is a best candidate; every other precursor's rows
+    are identical."""
+    z, dia, fdf, pdf, cfg, kernel, prefix = _golden_case(kind, name)
+    sel = oracle_lib.select if kind == "raw" else oracle_lib.select_timstof
+    got = _frame(sel(dia, fragment_columns(fdf, "mz_library"), _pack(pdf), cfg, kernel, n_threads=4))
+    exp = pd.DataFrame({c: z[prefix + c] for c in CANDIDATE_COLUMNS})
+    diff = _differing_rows(got, exp)
+    assert len(diff) == n_diff
+    moved = near_tie_precursors(oracle_lib, kind, name)
+    assert max(moved.values()) <= NEAR_TIE_SCORE  # (the move is small everywhere; it only matters where it flips a decision)
+    worst = max(moved[int(p)] for p in set(diff["precursor_idx"]))
+    print(f"[selection {kind} {name}] {len(diff)} rows of {len(exp)} differ, in {diff['precursor_idx'].nunique()} precursors; "
+          f"largest score move among them {worst:.2e}, anywhere {max(moved.values()):.2e}")
+    _compare_with_golden(got, z, name, oracle_lib, kind, prefix)
 
 
 def test_kernel_matches_reference_kernel():
@@ -264,19 +379,7 @@ def _load_tims():
 
 
 def _compare_tims_with_golden(got: pd.DataFrame, z):
-    exp = pd.DataFrame({c: z[f"out_{c}"] for c in CANDIDATE_COLUMNS})
-    m = got.merge(exp, on=["precursor_idx", "rank"], how="outer", suffixes=("_g", "_e"), indicator=True)
-    both = m[m["_merge"] == "both"]
-    assert (m["_merge"] == "left_only").sum() == 0
-    missing = m[m["_merge"] == "right_only"]
-    assert len(missing) <= 0.03 * len(exp) and (missing["rank"] > 0).all()
-    same_box = np.ones(len(both), dtype=bool)
-    for c in BOX:
-        same_box &= (both[c + "_g"] == both[c + "_e"]).values
-    # flat (signal-free) tiles produce peaks of exactly equal score whose order is implementation defined
-    assert same_box.mean() >= 0.97, same_box.mean()
-    rel = np.abs(both["score_g"] - both["score_e"]) / np.abs(both["score_e"])
-    assert rel[same_box].max() <= 5e-3
+    return _compare_with_golden(got, z, None, None, "tims", "out_")
 
 
 def test_timstof_kernel_matches_reference_kernel():
