@@ -1836,18 +1836,3 @@ __global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_kernel(
     DevOut out, Caps caps, unsigned char *__restrict__ prof = nullptr) {
     adh_feature_im_body<LAY, SPLIT>((int)blockIdx.x, run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
 }
-
-// The candidates adh_feature_im_tile4_kernel (adh_features_im4.hip) left aside - tiles that had to be materialised,
-// ADH_IM_MODE_DENSE - by the split body above: list[0] candidates at plan positions list[1 ...], the blocks of a
-// small fixed grid take them in turn (the host does not know the count).
-template <class LAY>
-__global__ __launch_bounds__(ADH_WAVE, 3) void adh_feature_im_list_kernel(
-    DevTims run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
-    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
-    DevOut out, Caps caps, unsigned char *__restrict__ prof, const uint32_t *__restrict__ list) {
-    const uint32_t n = list[0];
-    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
-        adh_feature_im_body<LAY, true>((int)list[1u + j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
-        __syncthreads();  // (the next candidate reuses the LDS arrays)
-    }
-}

@@ -2,106 +2,140 @@
 //
 // adh_feature_im_kernel<LAY, true> (adh_features_im.hip) reduces a candidate's sparse tiles - the sorted
 // (cell, intensity, m/z) entries the gather leaves - to an ImProfRec with ONE candidate per wavefront: its serial
-// walks keep 12 - 15 lanes of 64 busy (the precursor entries: one lane per (sum, isotope); the fragment planes: one
-// lane per plane; the template list: one lane).  This kernel does the same arithmetic, expression by expression and
-// in the same order, in the shape of adh_feature_im_profiles_kernel and adh_fused_kernel: 16 lanes per candidate,
-//   * transfer function (quadrupole.py:261-301) and its scan mask: the group's 16 lanes share the (isotope, scan) cells
-//   * precursor entries (candidate.py:248-269 collapsed by the gather; precursor_features.py:52-66, quadrupole.py:304-324):
-//     staged 16 at a time - every lane decodes one entry and computes its weight exp(-0.1 * distance) and its template
-//     term - then lane 3 * role + isotope (15 lanes) walks the staged entries for its one sum and lane 15 folds the
-//     template cells, in cell order, into scan profile, frame profile and centre of mass as they complete (no template
-//     tile, no cell list)
-//   * fragment planes (scoring/utils.py:26-66 inputs, features_utils.py:9-37): lane k < 12 owns plane k and walks ITS
-//     entries straight from the scratch block (they are sorted by cell, a plane is a range), with the running sums in
-//     registers and the two profiles as [row][fragment] columns in LDS
-// so a wavefront's serial chain is the longest list of FOUR candidates, where the old kernel's was one candidate's.
+// walks keep 12 - 15 lanes of 64 busy and every candidate pays the transfer function of all its scans.  This file
+// does the same arithmetic, expression by expression and in the same order, in the shape of
+// adh_feature_im_profiles_kernel and adh_fused_kernel - 16 lanes per candidate - and splits every step into a
+// BALANCED part (all 64 lanes, whichever candidate has the work) and a serial part that only adds:
+//   * precursor entries (candidate.py:248-269 collapsed by the gather; precursor_features.py:52-66,
+//     quadrupole.py:261-324): staged 16 at a time per candidate - every lane decodes one entry and computes its weight
+//     exp(-0.1 * distance), its transfer-function value (one logistic pair for ITS (isotope, scan): a candidate has
+//     ~40 precursor entries and 120 (isotope, scan) cells) and its template term - then lane 3 * role + isotope
+//     (15 lanes) walks the staged entries for its one sum and lane 15 folds the template cells, in cell order, into
+//     scan profile, frame profile and centre of mass as they complete (no template tile, no cell list)
+//   * fragment entries (scoring/utils.py:26-66 inputs, features_utils.py:9-37), the entries of the wavefront's FOUR
+//     candidates as one list: lane l takes entries l, l + 64, ... whichever candidate they belong to, decodes
+//     (plane, scan, cycle), computes the weight around the template centre and leaves (weight, intensity, m/z,
+//     scan << 8 | cycle) in an LDS pool; the scans that occur are collected in a bit mask per candidate and the scan mask of the transfer
+//     function (candidate.py:287-290) is evaluated for THOSE scans only (~10 of 40), again one (candidate, scan) per
+//     lane; then lane k < 12 of a candidate folds plane k - its entries are a range of the list - with the running
+//     sums in registers, the weights from the pool and the two profiles as [row][fragment] columns in LDS
+// so the expensive float64 exp / logistic work runs on full wavefronts and a wavefront's serial chain is the longest
+// plane of four candidates, a dozen instructions per entry.
 // One observation (plan classes 0 and ADH_CLASS_IM_SMALL with the fixed layouts), up to three isotopes, sparse
 // tiles.  A candidate whose tiles had to be materialised (ADH_IM_MODE_DENSE, rare) is put on a list and handled by
-// the old kernel's body (adh_feature_im_list_kernel); two observations keep the old kernel.  ADH_DEBUG_IM_TILE1=1
-// brings the old kernel back everywhere; the GPU suite holds both to identical records.
+// the old kernel's body in the first blocks of the same grid; two observations keep the old kernel.  ADH_DEBUG_IM_TILE1=1
+// brings the old kernel back everywhere; the GPU suite holds both to identical output tables.
 #include "adh_device.h"
 #include "adh_feature_common.h"
 
 namespace featim4 {
 
 constexpr int GS = 16;
+constexpr int NG = ADH_WAVE / GS;
 constexpr int KMAX = ADH_IM_PROF_K;
+constexpr int NP = 256;  // fragment entries of a wavefront's candidates per pass of the pool
+
+// precursor entries of the wavefront's candidates, PP per pass, as the balanced pass leaves them (they live in the
+// pool's bytes: the precursor entries come first)
+constexpr int PP = 128;
+struct __attribute__((aligned(16))) PrecPool {
+    double t[PP];                 // template term of the entry: (intensity * library isotope intensity) * transfer function
+    double r[4][PP];              // x > 0 ? x * w : 0, x > 0 ? w : 0, y > 0 ? y * w : 0, y > 0 ? w : 0  (w: weight around (S, 1))
+    uint32_t cell[PP];            // scan << 16 | cycle << 4 | isotope
+    float x[PP];
+};
 
 template <int FM, int SM>
-struct __attribute__((aligned(16))) TileLds {
-    union {
-        double qtf[3][SM];        // transfer function per (isotope, scan): dead once the precursor entries are folded ...
-        float ffp[FM][KMAX];      // ... fragment frame profiles [cycle][fragment]
-    } u;
+struct __attribute__((aligned(16))) GroupTile {
+    float ffp[FM][KMAX];          // fragment frame profiles [cycle][fragment]
     float fsp[SM][KMAX];          // fragment scan profiles [scan][fragment]
-    double s_w[GS], s_t[GS];      // staged precursor entries: weight, template term
-    uint32_t s_cell[GS];          //   scan << 16 | cycle << 4 | isotope
-    float s_x[GS], s_y[GS];
+    double cy[2][SM];             // the quadrupole rows of the candidate's scans (lower, upper limit)
     float qmask[SM];
     float tsp_raw[SM], tfp_raw[FM];
     float iso_int[4], iso_mz[4];
     int pl_beg[GS], pl_end[GS];
+    // what the balanced passes need to know about the candidate
+    const ImEntry *entries;
+    double esc, efc, inv_f;
+    float inv_sf;
+    int n_fe, off, F, SF, S;
+    const ImEntry *pent;
+    int n_pe, poff;
+    unsigned long long scans, scans_done;
 };
 
-}  // namespace featim4
-
-// `dense_list`: [0] = number of candidates left to adh_feature_im_list_kernel, [1 ...] their positions in `plan`
 template <int FM, int SM>
-__global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
-    DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
-    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch, DevOut out,
-    unsigned char *__restrict__ prof, uint32_t *__restrict__ dense_list) {
-    using namespace featim4;
-    typedef ImProfRec<FM, SM, 1> Rec;
-    __shared__ TileLds<FM, SM> lds[ADH_WAVE / GS];
+struct __attribute__((aligned(16))) WaveTile {
+    static_assert(SM <= 64 && FM <= 256, "scan bit masks are 64 bits wide, a pool entry names its cycle by a byte");
+    GroupTile<FM, SM> g[NG];
+    union {
+        struct {
+            double w[NP];         // weight of a fragment entry around the template centre
+            float x[NP], y[NP];   // its intensity and m/z
+            uint16_t scf[NP];     // scan << 8 | cycle
+        } pool;
+        PrecPool prec;
+    } u;
+    uint8_t need[NG * SM];        // (candidate, scan) pairs whose scan mask is due
+    uint8_t owner[NP];            // lane (candidate, plane) a pool slot belongs to
+    uint16_t seg_base[ADH_WAVE];  // first pool slot of a lane's plane in this pass ...
+    int seg_src[ADH_WAVE];        // ... and the entry it holds
+};
+
+// what a group's lanes hold when the tile phase is over (beside the LDS arrays of GroupTile)
+struct TileOut {
+    bool alive;
+    int K0, F, S, I;
+    double ohe, omz;      // lane k < K0: weighted centre means of plane k
+    double hp, omzp;      // lane i < I: ... of isotope plane i
+    float spi;            // lane i < I: isotope intensity sum
+    float tsum;           // template sum
+};
+
+// The tile phase of four candidates (group g of the wavefront = candidate first + 4 * block + g of `plan`).
+template <int FM, int SM>
+__device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTims &run, const CandRecIM *__restrict__ plan,
+                                               int32_t n_cand, int32_t block, const float *__restrict__ iso_table,
+                                               int32_t n_iso_cols, const adh_scoring_config_t &cfg,
+                                               const unsigned char *__restrict__ scratch, const DevOut &out,
+                                               const uint32_t *__restrict__ order, int &ci_out, const int stop = 0) {
+    // (`stop`: developer ablation, ADH_DEBUG_IM4 = 1 tables, 6 + the balanced pass over the precursor entries, 2 + their folds, 3 + weights, 4 + scan masks, 5 + folds)
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const int gbase = g * GS;
-    TileLds<FM, SM> &Q = lds[g];
-    const int ci = (int)blockIdx.x * (ADH_WAVE / GS) + g;
-    bool alive = ci < n_cand;
-    const CandRecIM &r = plan[alive ? ci : 0];
+    GroupTile<FM, SM> &Q = W.g[g];
+    // (`order`: the candidates with sparse tiles, heaviest first - adh_im_order_*_kernel below; n_cand of them)
+    const int oi = block * NG + g;
+    bool alive = oi < n_cand;
+    const int ci = alive ? (int)order[oi] : 0;
+    ci_out = ci;
+    const CandRecIM &r = plan[ci];
     alive = alive && !(r.flags & ADH_FLAG_SKIP);
-    const unsigned char *block = scratch + r.scratch_off;
-    const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
+    const unsigned char *block_p = scratch + r.scratch_off;
     uint4 h4 = make_uint4(0u, 0u, 0u, 0u);
     uint32_t h_pe = 0u;
     if (alive) {
-        h4 = *reinterpret_cast<const uint4 *>(header);
-        h_pe = header[4];
+        h4 = *reinterpret_cast<const uint4 *>(block_p);
+        h_pe = reinterpret_cast<const uint32_t *>(block_p)[4];
     }
     const int K0 = (int)h4.x;
     alive = alive && K0 > 0;
     if (alive && sub == 0 && out.stat_matched_peaks) out.stat_matched_peaks[r.row] = h4.y;
-    if (alive && h4.w != ADH_IM_MODE_COMPACT) {  // materialised tiles: the old kernel's body takes this candidate
-        if (sub == 0) dense_list[1u + atomicAdd(dense_list, 1u)] = (uint32_t)ci;
-        alive = false;
-    }
+    alive = alive && h4.w == ADH_IM_MODE_COMPACT;  // (materialised tiles are not in `order`)
     const int n_fe = alive ? (int)h4.z : 0, n_pe = alive ? (int)h_pe : 0;
     const int L = run.cycle_len, z = run.zeroth;
     const int c0 = (r.frame_start - z) / L;
     const int F = alive ? (r.frame_stop - z) / L - c0 : 1;
     const int S = alive ? r.scan_stop - r.scan_start : 1;
-    const int I = min(min(n_iso_cols, (int)cfg.top_k_isotopes), 3);
+    const int I = max(min(min(n_iso_cols, (int)cfg.top_k_isotopes), 3), 1);
     const int SF = S * F;
-    const ImEntry *const entries = reinterpret_cast<const ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
+    const ImEntry *const entries = reinterpret_cast<const ImEntry *>(block_p + adh_scratch_frag_off(r.k_cap));
+    const QuadParams qp = adh_quad_params(cfg);
 
-    if (sub < I) {
-        Q.iso_int[sub] = alive ? iso_table[(int64_t)r.row * n_iso_cols + sub] : 0.0f;
-        const double off = (double)sub * 1.0033548350700006 / (double)r.charge;
-        Q.iso_mz[sub] = (float)off + r.precursor_mz;
-    }
-    adh_wave_sync();
-
-    // ---- quadrupole transfer function per (isotope, scan) (quadrupole.py:261-301), its mean over the isotopes
-    // (candidate.py:287-289: the mask the fragment tile is multiplied with, candidate.py:290)
+    // ---- the candidate's small tables: isotopes, the quadrupole rows of its scans (all loads in flight together)
     {
-        // (the quadrupole rows of the candidate's scans first, all loads in flight together: the scan profiles' bytes
-        // are idle until the fragment planes)
-        double *const cy_lo = reinterpret_cast<double *>(&Q.fsp[0][0]), *const cy_hi = cy_lo + SM;
-        static_assert(sizeof(Q.fsp) >= 2 * SM * sizeof(double), "the cycle rows fit the scan profiles");
-        const int obs0 = (int)r.obs[0];
         double2 cyv[(SM + GS - 1) / GS];
+        const int obs0 = (int)r.obs[0];
 #pragma unroll
         for (int j = 0; j < (SM + GS - 1) / GS; ++j) {
             const int sc = sub + j * GS;
@@ -109,34 +143,47 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
             if (alive && sc < S)
                 cyv[j] = *reinterpret_cast<const double2 *>(run.cycle + 2 * ((int64_t)obs0 * run.scan_max + (r.scan_start + sc)));
         }
+        if (sub < I) {
+            Q.iso_int[sub] = alive ? iso_table[(int64_t)r.row * n_iso_cols + sub] : 0.0f;
+            const double off = (double)sub * 1.0033548350700006 / (double)r.charge;
+            Q.iso_mz[sub] = (float)off + r.precursor_mz;
+        }
 #pragma unroll
         for (int j = 0; j < (SM + GS - 1) / GS; ++j) {
             const int sc = sub + j * GS;
             if (sc < SM) {
-                cy_lo[sc] = cyv[j].x;
-                cy_hi[sc] = cyv[j].y;
+                Q.cy[0][sc] = cyv[j].x;
+                Q.cy[1][sc] = cyv[j].y;
+                Q.tsp_raw[sc] = 0.0f;
+                Q.qmask[sc] = 0.0f;
             }
         }
-        adh_wave_sync();
-        if (alive) {
-            const QuadParams qp = adh_quad_params(cfg);
-            for (int c = sub; c < I * S; c += GS) {
-                const int i = c / S, sc = c - i * S;
-                const double x = (double)Q.iso_mz[i];
-                Q.u.qtf[i][sc] = featim::logistic(x, cy_lo[sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, cy_hi[sc] + qp.delta_hi, qp.sigma_hi);
-            }
+        for (int f = sub; f < FM; f += GS) Q.tfp_raw[f] = 0.0f;
+        Q.pl_beg[sub] = 0x7FFFFFFF;
+        Q.pl_end[sub] = 0;
+        if (sub == 0) {
+            Q.entries = entries;
+            Q.pent = entries + n_fe;
+            Q.n_pe = n_pe;
+            Q.n_fe = n_fe;
+            Q.F = F;
+            Q.SF = SF;
+            Q.S = S;
+            Q.inv_f = 1.0 / (double)F;
+            Q.inv_sf = 1.0f / (float)SF;
+            Q.scans = 0ull;
+            Q.scans_done = 0ull;
         }
     }
     adh_wave_sync();
-    for (int sc = sub; sc < SM; sc += GS) {
-        double sum = 0;
-        if (sc < S && alive)
-            for (int i = 0; i < I; ++i) sum += Q.u.qtf[i][sc];
-        Q.qmask[sc] = (float)(sum / (double)I);
-        Q.tsp_raw[sc] = 0.0f;
-    }
-    for (int f = sub; f < FM; f += GS) Q.tfp_raw[f] = 0.0f;
-    adh_wave_sync();
+    TileOut res;
+    res.alive = false;
+    if (stop == 1) return res;
+    // transfer function of (isotope i, scan sc) (quadrupole.py:261-301)
+    auto qtf_at = [&](const GroupTile<FM, SM> &T, int i, int sc) -> double {
+        const double x = (double)T.iso_mz[i];
+        return featim::logistic(x, T.cy[0][sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, T.cy[1][sc] + qp.delta_hi, qp.sigma_hi);
+    };
 
     // ---- the precursor entries: non-zero (scan, cycle, isotope) cells in that order.
     //   lanes 0 .. 5I-1 (role = lane / I: 0 intensity sum per scan and over the scans; 1, 2 weighted intensity mean;
@@ -144,7 +191,6 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
     //   lane 15: the template cell (quadrupole.py:304-324) of consecutive entries of one (scan, cycle), folded when the
     //   cell is complete - scan profile (np.sum over the cycle axis), frame profile (over the scan axis), centre of
     //   mass over the cells v > 0 (fragment_features.py:20-68)
-    const ImEntry *const pent = entries + n_fe;
     const int role = sub / I, iso = sub - role * I;
     double acc = 0.0;
     float part = 0.0f, tot = 0.0f;
@@ -172,59 +218,115 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
             t_fsum += (double)f * (double)v;
         }
     };
-    int n_pe_max = n_pe;
+    {
+        PrecPool &P = W.u.prec;
+        // passes over the four candidates SIDE BY SIDE: every candidate that has entries left puts its next
+        // PP / (candidates still busy) of them into the pool - slots [q * share, q * share + take_q) - so that the
+        // serial folds of the four run at once
+        int pat = 0;  // next precursor entry of this group's candidate
+        for (;;) {
+            const int prem = max(n_pe - pat, 0);
+            const unsigned long long busy = __ballot(prem > 0);
+            if (busy == 0ull) break;
+            int n_busy = 0;
 #pragma unroll
-    for (int off = 32; off >= GS; off >>= 1) n_pe_max = max(n_pe_max, __shfl_xor(n_pe_max, off));
-    ImEntry pnext;
-    pnext.cell = 0u, pnext.x = 0.0f, pnext.y = 0.0f;
-    if (sub < n_pe) pnext = pent[sub];
-    for (int base = 0; base < n_pe_max; base += GS) {
-        const int cnt = min(GS, n_pe - base);  // (<= 0: this group is through)
-        const ImEntry en = pnext;
-        if (base + GS + sub < n_pe) pnext = pent[base + GS + sub];  // (the next round's entry, in flight meanwhile)
-        if (sub < cnt) {
-            const int sf = (int)en.cell / I, i = (int)en.cell - sf * I, sc = sf / F, f = sf - sc * F;
-            const double ds = (double)(sc - S), df = (double)(f - 1);
-            Q.s_cell[sub] = (uint32_t)(sc << 16 | f << 4 | i);
-            Q.s_x[sub] = en.x;
-            Q.s_y[sub] = en.y;
-            Q.s_w[sub] = exp(-0.1 * sqrt(ds * ds + df * df));
-            const float t = en.x * Q.iso_int[i];
-            Q.s_t[sub] = (double)t * Q.u.qtf[i][sc];
-        }
-        adh_wave_sync();
-        if (sub < 5 * I) {
-#pragma unroll 4
-            for (int u = 0; u < GS; ++u) {
-                const uint32_t cp = Q.s_cell[u];
-                const float xs = Q.s_x[u], ys = Q.s_y[u];
-                const double ws = Q.s_w[u];
-                const bool mine = u < cnt && (int)(cp & 15u) == iso;
-                const int sc = (int)(cp >> 16);
-                const bool fresh = mine && sc != cur_sc;  // role 0: per-scan sums, added up in scan order
-                tot += fresh ? part : 0.0f;
-                part = fresh ? 0.0f : part;
-                cur_sc = fresh ? sc : cur_sc;
-                part += mine ? xs : 0.0f;
-                const float flag = role <= 2 ? xs : ys;
-                const double term = role == 1 ? (double)xs * ws : (role == 3 ? (double)ys * ws : ws);
-                acc += mine && flag > 0.0f ? term : 0.0;
+            for (int q = 0; q < NG; ++q) n_busy += (int)((busy >> (q * GS)) & 1ull);
+            const int share = PP / n_busy;
+            const int take = min(prem, share);
+            int my_rank = 0;  // this group's place among the busy ones
+#pragma unroll
+            for (int q = 0; q < NG; ++q) my_rank += (q < g) ? (int)((busy >> (q * GS)) & 1ull) : 0;
+            const int slot0 = my_rank * share;
+            if (sub == 0) {
+                Q.poff = slot0;      // (first pool slot of the candidate in this pass ...)
+                Q.n_pe = take;       // (... and how many it holds)
+                Q.pent = entries + n_fe + pat;
             }
-        } else if (sub == GS - 1) {
-            for (int u = 0; u < cnt; ++u) {
-                const uint32_t cp = Q.s_cell[u];
-                const int cs = (int)((cp >> 16) << 12 | ((cp >> 4) & 0xFFFu));
-                if (cs != t_cell) {
-                    if (t_cell >= 0) template_cell_done();
-                    t_cell = cs;
-                    t_a = 0.0;
+            adh_wave_sync();
+            // (a) balanced: lane l takes slots l, l + 64, ... whichever candidate's they are
+            for (int s_ = lane; s_ < n_busy * share; s_ += ADH_WAVE) {
+                // the s_ / share-th busy candidate
+                int q = 0, seen = -1;
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const int on = (int)((busy >> (c * GS)) & 1ull);
+                    seen += on;
+                    if (on && seen == s_ / share) q = c;
                 }
-                t_a += Q.s_t[u];
+                const GroupTile<FM, SM> &T = W.g[q];
+                const int e = s_ - T.poff;
+                if (e >= T.n_pe) continue;
+                const ImEntry en = T.pent[e];
+                const int tF = T.F;
+                const int sf = (int)en.cell / I, i = (int)en.cell - sf * I, sc = sf / tF, f = sf - sc * tF;
+                const double ds = (double)(sc - T.S), df = (double)(f - 1);
+                const double w = exp(-0.1 * sqrt(ds * ds + df * df));
+                const float t = en.x * T.iso_int[i];
+                P.t[s_] = (double)t * qtf_at(T, i, sc);
+                P.r[0][s_] = en.x > 0.0f ? (double)en.x * w : 0.0;
+                P.r[1][s_] = en.x > 0.0f ? w : 0.0;
+                P.r[2][s_] = en.y > 0.0f ? (double)en.y * w : 0.0;
+                P.r[3][s_] = en.y > 0.0f ? w : 0.0;
+                P.cell[s_] = (uint32_t)(sc << 16 | f << 4 | i);
+                P.x[s_] = en.x;
             }
+            pat += take;
+            adh_wave_sync();
+            if (stop == 6) continue;
+            // (b) serial, adds only: the candidate's entries of this pass, four per step with their loads first
+            const int lo = slot0, hi = slot0 + take;
+            if (sub < 5 * I) {
+                const int ri = max(role - 1, 0);
+                for (int u0 = lo; __any(u0 < hi); u0 += 4) {
+                    uint32_t cp[4];
+                    float xs[4];
+                    double rr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int u = min(max(min(u0 + j, hi - 1), 0), PP - 1);
+                        cp[j] = P.cell[u];
+                        xs[j] = P.x[u];
+                        rr[j] = P.r[ri][u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool mine = u0 + j < hi && (int)(cp[j] & 15u) == iso;
+                        const int sc = (int)(cp[j] >> 16);
+                        const bool fresh = mine && sc != cur_sc;  // role 0: per-scan sums, added up in scan order
+                        tot += fresh ? part : 0.0f;
+                        part = fresh ? 0.0f : part;
+                        cur_sc = fresh ? sc : cur_sc;
+                        part += mine ? xs[j] : 0.0f;
+                        acc += mine ? rr[j] : 0.0;  // (roles 1 .. 4; the zero terms of cells without signal add nothing)
+                    }
+                }
+            } else if (sub == GS - 1) {
+                for (int u0 = lo; __any(u0 < hi); u0 += 4) {
+                    uint32_t cp[4];
+                    double tt[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int u = min(max(min(u0 + j, hi - 1), 0), PP - 1);
+                        cp[j] = P.cell[u];
+                        tt[j] = P.t[u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (u0 + j < hi) {
+                            const int cs = (int)((cp[j] >> 16) << 12 | ((cp[j] >> 4) & 0xFFFu));
+                            if (cs != t_cell) {
+                                if (t_cell >= 0) template_cell_done();
+                                t_cell = cs;
+                                t_a = 0.0;
+                            }
+                            t_a += tt[j];
+                        }
+                    }
+                }
+            }
+            adh_wave_sync();
         }
-        adh_wave_sync();
     }
-    double esc = 0.0, efc = 0.0;
     float tsum = 0.0f;
     if (sub == GS - 1) {
         if (t_cell >= 0) template_cell_done();
@@ -232,102 +334,173 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
             Q.tsp_raw[t_row] = t_srow;
             t_tsum += t_srow;
         }
-        esc = (t_isum > 0) ? t_ssum / t_isum : 0.0;
-        efc = (t_isum > 0) ? t_fsum / t_isum : 0.0;
+        Q.esc = (t_isum > 0) ? t_ssum / t_isum : 0.0;  // template centre of mass
+        Q.efc = (t_isum > 0) ? t_fsum / t_isum : 0.0;
         tsum = t_tsum;
     }
-    esc = __shfl(esc, gbase + GS - 1);
-    efc = __shfl(efc, gbase + GS - 1);
     tsum = __shfl(tsum, gbase + GS - 1);
     // isotope lane i < I: the sums of roles 1 .. 4 of its isotope
     const int il = sub < I ? sub : 0;
     const double vh = __shfl(acc, gbase + I + il), wh = __shfl(acc, gbase + 2 * I + il);
     const double vmz = __shfl(acc, gbase + 3 * I + il), wmz = __shfl(acc, gbase + 4 * I + il);
-    const float spi_l = tot + part;
-    const double hp_l = (wh > 0) ? vh / wh : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
-    const double omzp_l = (wmz > 0) ? vmz / wmz : 0.0;
-    adh_wave_sync();
-
-    // ---- the fragment planes.  qtf is dead: its bytes become the frame profiles.
-    for (int c = sub; c < FM * KMAX; c += GS) (&Q.u.ffp[0][0])[c] = 0.0f;
-    for (int c = sub; c < SM * KMAX; c += GS) (&Q.fsp[0][0])[c] = 0.0f;
-    Q.pl_beg[sub] = 0;
-    Q.pl_end[sub] = 0;
-    adh_wave_sync();
-    {
-        // a plane's entries are a range of the list (cell = (k * S + scan) * F + cycle, sorted): the group looks at
-        // every entry's plane once
-        const float inv_sf = 1.0f / (float)SF;
-        auto plane_of = [&](uint32_t cell) -> int {
-            int q = (int)((float)cell * inv_sf);
-            const int rem = (int)cell - q * SF;
-            q += rem >= SF ? 1 : (rem < 0 ? -1 : 0);
-            return q;
-        };
-        for (int e0 = sub; e0 < n_fe; e0 += 4 * GS) {
-            uint32_t cc[4], cp[4];
+    res.spi = tot + part;
+    res.hp = (wh > 0) ? vh / wh : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
+    res.omzp = (wmz > 0) ? vmz / wmz : 0.0;
+    res.tsum = tsum;
+    if (stop == 2 || stop == 6) return res;
+    // where the candidates' fragment entries start in the wavefront's list
+    if (lane == 0) {
+        int o = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * GS;
-                cc[u] = e < n_fe ? entries[e].cell : 0u;
-                cp[u] = (e < n_fe && e > 0) ? entries[e - 1].cell : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * GS;
-                if (e < n_fe) {
-                    const int pc = plane_of(cc[u]);
-                    const int pp = e > 0 ? plane_of(cp[u]) : -1;
-                    if (pc != pp) {
-                        Q.pl_beg[pc] = e;
-                        if (pp >= 0) Q.pl_end[pp] = e;
-                    }
-                    if (e == n_fe - 1) Q.pl_end[pc] = n_fe;
-                }
-            }
+        for (int q = 0; q < NG; ++q) {
+            W.g[q].off = o;
+            o += W.g[q].n_fe;
         }
     }
+    for (int c = sub; c < FM * KMAX; c += GS) (&Q.ffp[0][0])[c] = 0.0f;
+    for (int c = sub; c < SM * KMAX; c += GS) (&Q.fsp[0][0])[c] = 0.0f;
     adh_wave_sync();
-    double ohe_l = 0.0, omz_l = 0.0;
-    {
-        const bool fl = alive && sub < K0;
-        const int beg = fl ? Q.pl_beg[sub] : 0, end = fl ? Q.pl_end[sub] : 0;
-        const int psf = sub * SF;
-        const double inv_f = 1.0 / (double)F;
-        double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
-        float fs = 0.0f;
-        int cur = -1;
-        // a lane's entries arrive through a ring of PF registers: PF loads in flight per lane (the walk is a chain of
-        // memory latencies otherwise: one dependent 12-byte load per entry)
-        constexpr int PF = 8;
-        ImEntry ring[PF];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            ring[j].cell = 0u, ring[j].x = 0.0f, ring[j].y = 0.0f;
-            if (beg + j < end) ring[j] = entries[beg + j];
+
+    // ---- the fragment entries.  First every entry's plane, balanced over the wavefront's list: a plane is a range
+    const int total = W.g[NG - 1].off + W.g[NG - 1].n_fe;
+    const int off1 = W.g[1].off, off2 = W.g[2].off, off3 = W.g[3].off;
+    for (int j = lane; j < total; j += ADH_WAVE) {
+        const int q = (j >= off1) + (j >= off2) + (j >= off3);
+        GroupTile<FM, SM> &T = W.g[q];
+        const int e = j - T.off;
+        const ImEntry *E = T.entries;
+        const uint32_t cell = E[e].cell, pcell = e > 0 ? E[e - 1].cell : 0u;
+        const int tSF = T.SF;
+        const float isf = T.inv_sf;
+        auto plane_of = [&](uint32_t c) -> int {
+            int k = (int)((float)c * isf);
+            const int rem = (int)c - k * tSF;
+            k += rem >= tSF ? 1 : (rem < 0 ? -1 : 0);
+            return k;
+        };
+        const int pc = plane_of(cell), pp = e > 0 ? plane_of(pcell) : -1;
+        if (pc != pp) {
+            T.pl_beg[pc] = e;
+            if (pp >= 0) T.pl_end[pp] = e;
         }
-        for (int e0 = beg; __any(e0 < end); e0 += PF) {
+        if (e == T.n_fe - 1) T.pl_end[pc] = T.n_fe;
+    }
+    adh_wave_sync();
+    // Then passes over the planes SIDE BY SIDE: every plane that has entries left puts its next R of them into the pool
+    // (R = pool size / planes still busy), so the serial folds below advance all planes of all four candidates at once
+    // - a contiguous piece of the list would hold three planes of one signal-rich candidate and the other lanes
+    // would wait - and a pass is: (a) balanced over the pool's slots: decode, weight around the template centre,
+    // scans that occur; (b) balanced: the scan mask of the transfer function (candidate.py:287-290) for the scans
+    // that are new, applied to the intensities; (c) serial per plane, adds only.
+    const bool fl = alive && sub < K0;
+    const int psf = sub * SF;
+    double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
+    float fs = 0.0f;
+    int cur = -1;      // scan of the running scan sum
+    int at = fl ? Q.pl_beg[sub] : 0x7FFFFFFF;      // next entry of the lane's plane
+    const int at_end = (fl && at != 0x7FFFFFFF) ? Q.pl_end[sub] : 0;
+    if (at == 0x7FFFFFFF) at = 0;
+    for (;;) {
+        const int rem = max(at_end - at, 0);
+        const int n_busy = __popcll(__ballot(rem > 0));
+        if (n_busy == 0) break;
+        const int R = min(NP / n_busy, 64);
+        const int take = min(rem, R);
+        int incl = take;  // slots [base, base + take) of the pool are this plane's
 #pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                const int e = e0 + j;
-                const ImEntry en = ring[j];
-                if (e + PF < end) ring[j] = entries[e + PF];
-                if (e < end) {
-                    const int rem = (int)en.cell - psf;
-                    int sc = (int)((double)rem * inv_f);  // exact quotient: float64 estimate, one fix-up
-                    if (rem - sc * F >= F) ++sc;
-                    const int f = rem - sc * F;
-                    const double ds = (double)sc - esc, df = (double)f - efc;
-                    const double w = exp(-0.1 * sqrt(ds * ds + df * df));
-                    const float v = en.x * Q.qmask[sc];  // candidate.py:290
-                    const float y = en.y;
+        for (int o = 1; o < ADH_WAVE; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        const int base = incl - take, n_slots = __shfl(incl, ADH_WAVE - 1);
+        for (int rr = 0; rr < take; ++rr) W.owner[base + rr] = (uint8_t)lane;
+        W.seg_base[lane] = (uint16_t)base;
+        W.seg_src[lane] = at;
+        adh_wave_sync();
+        // (a)
+        for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {
+            const int o = (int)W.owner[s_];
+            const int q = o / GS, k = o % GS;
+            GroupTile<FM, SM> &T = W.g[q];
+            const int e = W.seg_src[o] + (s_ - (int)W.seg_base[o]);
+            const ImEntry en = T.entries[e];
+            const int tF = T.F;
+            const int rem_c = (int)en.cell - k * T.SF;
+            int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
+            if (rem_c - sc * tF >= tF) ++sc;
+            const int f = rem_c - sc * tF;
+            const double ds = (double)sc - T.esc, df = (double)f - T.efc;
+            W.u.pool.w[s_] = exp(-0.1 * sqrt(ds * ds + df * df));
+            W.u.pool.x[s_] = en.x;
+            W.u.pool.y[s_] = en.y;
+            W.u.pool.scf[s_] = (uint16_t)(sc << 8 | f);
+            atomicOr(&T.scans, 1ull << sc);
+        }
+        adh_wave_sync();
+        if (stop == 3) {
+            at += take;
+            continue;
+        }
+        // (b)
+        {
+            int n_need = 0;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < (NG * SM + ADH_WAVE - 1) / ADH_WAVE; ++k) {
+                const int slot = k * ADH_WAVE + lane;
+                const int q = min(slot / SM, NG - 1), sc = slot - q * SM;
+                const bool due = slot < NG * SM && (((W.g[q].scans & ~W.g[q].scans_done) >> sc) & 1ull);
+                const unsigned long long m = __ballot(due);
+                if (due) W.need[n_need + __popcll(m & lt)] = (uint8_t)slot;
+                n_need += __popcll(m);
+            }
+            adh_wave_sync();
+            for (int t = lane; t < n_need; t += ADH_WAVE) {
+                const int slot = (int)W.need[t];
+                const int q = slot / SM, sc = slot - q * SM;
+                GroupTile<FM, SM> &T = W.g[q];
+                double sum = 0;
+                for (int i = 0; i < I; ++i) sum += qtf_at(T, i, sc);
+                T.qmask[sc] = (float)(sum / (double)I);
+            }
+            adh_wave_sync();
+            if (sub == 0) Q.scans_done = Q.scans;
+            for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE)  // candidate.py:290
+                W.u.pool.x[s_] = W.u.pool.x[s_] * W.g[(int)W.owner[s_] / GS].qmask[(int)W.u.pool.scf[s_] >> 8];
+            adh_wave_sync();
+        }
+        if (stop == 4) {
+            at += take;
+            continue;
+        }
+        // (c) four entries per step, their loads first (the walk is a chain of LDS latencies otherwise); the frame
+        // profile takes its terms through ds_add_f32 (no answer to wait for; a lane's adds to one address arrive in
+        // program order)
+        for (int e = 0; __any(e < take); e += 4) {
+            double w4[4];
+            float v4[4], y4[4];
+            int s4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = min(base + min(e + j, max(take - 1, 0)), NP - 1);
+                w4[j] = W.u.pool.w[slot];
+                v4[j] = W.u.pool.x[slot];
+                y4[j] = W.u.pool.y[slot];
+                s4[j] = (int)W.u.pool.scf[slot];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e + j < take) {
+                    const double w = w4[j];
+                    const float v = v4[j], y = y4[j];
+                    const int sc = s4[j] >> 8, f = s4[j] & 0xFF;
                     if (sc != cur) {  // the cells of a scan are consecutive: its sum is complete
                         if (cur >= 0) Q.fsp[cur][sub] = fs;
                         fs = 0.0f;
                         cur = sc;
                     }
                     fs += v;
-                    Q.u.ffp[f][sub] = Q.u.ffp[f][sub] + v;
+                    (void)__hip_atomic_fetch_add(&Q.ffp[f][sub], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const double tm = (double)y * w;  // (w > 0: the product is > 0 exactly when the m/z channel is)
                     vi += v > 0.0f ? (double)v * w : 0.0;  // (adding 0.0 leaves a sum as it is)
                     wi += v > 0.0f ? w : 0.0;
@@ -336,16 +509,127 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
                 }
             }
         }
-        if (fl) {
-            if (cur >= 0) Q.fsp[cur][sub] = fs;
-            ohe_l = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
-            omz_l = (wm > 0) ? vm / wm : 0.0;
+        at += take;
+        adh_wave_sync();
+    }
+    (void)psf;
+    if (fl) {
+        if (cur >= 0) Q.fsp[cur][sub] = fs;
+    }
+    res.ohe = (fl && wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
+    res.omz = (fl && wm > 0) ? vm / wm : 0.0;
+    adh_wave_sync();
+    res.alive = alive && !(stop >= 3 && stop <= 5);
+    res.K0 = K0;
+    res.F = F;
+    res.S = S;
+    res.I = I;
+    return res;
+}
+
+}  // namespace featim4
+
+// ---- the order of work.  A wavefront's serial walks take as long as the longest list of its four candidates, and
+// the lists are very unequal (a candidate on a planted peptide holds a few hundred entries, one on noise a handful):
+// in plan order three of four wavefronts hold a long list and all wait for it.  Two small kernels bucket the
+// candidates of a launch by the length of their lists (log scale, longest first: long wavefronts start first) and
+// leave aside what adh_feature_im_tile4_kernel does not take - candidates that failed in the gather (nothing to do)
+// and materialised tiles (-> `dense`, for the first blocks of the grid: the one-candidate body).
+// side[0] materialised candidates, side[1] ordered candidates, side[2 .. 2 + NB) bucket sizes, side[2 + NB .. 2 + 2 NB)
+// bucket fill, then order[n] and dense[n]
+namespace featim4 {
+constexpr int NB = 32;
+constexpr int SIDE_HEAD = 2 + 2 * NB;
+__host__ __device__ inline uint64_t side_bytes(int64_t n) { return ((uint64_t)(SIDE_HEAD + 2 * n) * 4 + 255) / 256 * 256; }
+// -2: nothing to do, -1: materialised tiles, else the bucket
+__device__ __forceinline__ int order_class(const CandRecIM &r, const unsigned char *__restrict__ scratch) {
+    if (r.flags & ADH_FLAG_SKIP) return -2;
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(scratch + r.scratch_off);
+    const uint4 h4 = *reinterpret_cast<const uint4 *>(h);
+    if (h4.x == 0u) return -2;
+    if (h4.w != ADH_IM_MODE_COMPACT) return -1;
+    const float key = (float)(h[4] + (h4.z >> 2));  // precursor entries + a quarter of the fragment entries: ~ the longest walk
+    return min(NB - 1, (int)(__log2f(key + 1.0f) * 3.0f));
+}
+}  // namespace featim4
+
+__global__ __launch_bounds__(256) void adh_im_order_hist_kernel(const CandRecIM *__restrict__ plan, int32_t n,
+                                                                const unsigned char *__restrict__ scratch,
+                                                                uint32_t *__restrict__ side) {
+    using namespace featim4;
+    __shared__ uint32_t h[NB];
+    if (threadIdx.x < NB) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int ci = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int c = ci < n ? order_class(plan[ci], scratch) : -2;
+    if (c >= 0) atomicAdd(&h[c], 1u);
+    __syncthreads();
+    if (threadIdx.x < NB && h[threadIdx.x]) atomicAdd(&side[2 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void adh_im_order_scatter_kernel(const CandRecIM *__restrict__ plan, int32_t n,
+                                                                   const unsigned char *__restrict__ scratch,
+                                                                   uint32_t *__restrict__ side) {
+    using namespace featim4;
+    __shared__ uint32_t cnt[NB], base[NB];
+    if (threadIdx.x < NB) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int ci = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int c = ci < n ? order_class(plan[ci], scratch) : -2;
+    uint32_t rank = 0u;
+    if (c >= 0) rank = atomicAdd(&cnt[c], 1u);
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int b = (int)threadIdx.x;
+        uint32_t start = 0u;  // buckets in descending order: the longest lists first
+        for (int q = b + 1; q < NB; ++q) start += side[2 + q];
+        base[b] = cnt[b] ? start + atomicAdd(&side[2 + NB + b], cnt[b]) : 0u;
+        if (blockIdx.x == 0 && b == 0) {
+            uint32_t tot = side[2];
+            for (int q = 1; q < NB; ++q) tot += side[2 + q];
+            side[1] = tot;
         }
     }
-    adh_wave_sync();
+    __syncthreads();
+    uint32_t *order = side + SIDE_HEAD, *dense = order + n;
+    if (c >= 0) order[base[c] + rank] = (uint32_t)ci;
+    else if (c == -1) dense[atomicAdd(&side[0], 1u)] = (uint32_t)ci;
+}
 
+// `side`: see above (side[1] candidates in `order`).  The first `list_blocks` blocks of the grid take the candidates
+// with materialised tiles through the one-candidate body (adh_feature_im_body<LAY, true>, adh_features_im.hip) - they
+// are the longest walks of a launch (a dense tile is 1 152 cells per plane) and start first, beside the others,
+// instead of in a launch of their own behind this one; the LDS of a block is the larger of the two layouts.
+template <int FM, int SM, class LAY>
+__global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch, DevOut out,
+    unsigned char *__restrict__ prof, const uint32_t *__restrict__ side, Caps caps, int32_t list_blocks, int32_t stop) {
+    using namespace featim4;
+    typedef ImProfRec<FM, SM, 1> Rec;
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int32_t)blockIdx.x < list_blocks) {
+        const uint32_t n = side[0];
+        const uint32_t *list = side + SIDE_HEAD + n_cand;
+        for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {
+            adh_feature_im_body<LAY, true>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
+            __syncthreads();  // (the next candidate reuses the LDS arrays)
+        }
+        return;
+    }
+    WaveTile<FM, SM> &W = *reinterpret_cast<WaveTile<FM, SM> *>(smem);
+    const int32_t block = (int32_t)blockIdx.x - list_blocks;
+    const int32_t n_order = (int32_t)side[1];
+    if (block * NG >= n_order) return;
+    int ci = 0;
+    const TileOut t = tile4_phase<FM, SM>(W, run, plan, n_order, block, iso_table, n_iso_cols, cfg, scratch, out,
+                                          side + SIDE_HEAD, ci, stop);
     // ---- hand-over: the record adh_feature_im_profiles_kernel reads (frame axis centred: entry r <-> cycle r + shift)
-    if (!alive) return;
+    if (!t.alive) return;
+    const int lane = threadIdx.x;
+    const int g = lane / GS, sub = lane % GS;
+    const GroupTile<FM, SM> &Q = W.g[g];
+    const int K0 = t.K0, F = t.F, S = t.S, I = t.I;
     Rec &rec = reinterpret_cast<Rec *>(prof)[ci];
     const int shift = F / 2 - FM / 2;
     for (int rr = sub; rr < FM; rr += GS) {
@@ -355,26 +639,26 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
     for (int sc = sub; sc < SM; sc += GS) rec.tsp_raw[0][sc] = sc < S ? Q.tsp_raw[sc] : 0.0f;
     for (int c = sub; c < K0 * FM; c += GS) {
         const int k = c / FM, rr = c - k * FM, f = rr + shift;
-        rec.ffp[k][0][rr] = (f >= 0 && f < F) ? Q.u.ffp[f][k] : 0.0f;
+        rec.ffp[k][0][rr] = (f >= 0 && f < F) ? Q.ffp[f][k] : 0.0f;
     }
     for (int c = sub; c < K0 * SM; c += GS) {
         const int k = c / SM, sc = c - k * SM;
         rec.fsp[k][0][sc] = sc < S ? Q.fsp[sc][k] : 0.0f;
     }
     if (sub < K0) {
-        rec.ohe[sub][0] = ohe_l;
-        rec.omz[sub][0] = omz_l;
+        rec.ohe[sub][0] = t.ohe;
+        rec.omz[sub][0] = t.omz;
     }
     if (sub < 4) {
         const bool on = sub < I;
-        rec.hp[sub] = on ? hp_l : 0.0;
-        rec.omzp[sub] = on ? omzp_l : 0.0;
-        rec.spi[sub] = on ? spi_l : 0.0f;
+        rec.hp[sub] = on ? t.hp : 0.0;
+        rec.omzp[sub] = on ? t.omzp : 0.0;
+        rec.spi[sub] = on ? t.spi : 0.0f;
         rec.iso_int[sub] = on ? Q.iso_int[sub] : 0.0f;
         rec.iso_mz[sub] = on ? Q.iso_mz[sub] : 0.0f;
     }
     if (sub == 0) {
-        rec.tsum[0] = tsum;
+        rec.tsum[0] = t.tsum;
         rec.K0 = (uint32_t)K0;
     }
 }

@@ -533,12 +533,13 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     const uint64_t prof_end = prof_two_off + (split_two ? (uint64_t)p.n_class[1] * sizeof(ProfCommon2) : 0);
     // Round 6: the one-observation split classes go through adh_feature_im_tile4_kernel (four candidates per
     // wavefront, adh_features_im4.hip); the candidates it leaves aside (materialised tiles) are listed behind the
-    // records - per class a counter and the plan positions - and taken by adh_feature_im_list_kernel.
+    // records - per class a counter and the plan positions - and taken by the first blocks of the same grid with the old body.
     // ADH_DEBUG_IM_TILE1=1: the one-candidate-per-wavefront tile kernel everywhere.
     const bool tile4 = !getenv("ADH_DEBUG_IM_TILE1");
+    const int32_t stop4 = getenv("ADH_DEBUG_IM4") ? atoi(getenv("ADH_DEBUG_IM4")) : 0;  // developer ablation (tile4_phase)
     const uint64_t list_common_off = (prof_end + 255) / 256 * 256;
-    const uint64_t list_small_off = list_common_off + (tile4 && split_common ? ((uint64_t)p.n_class[0] + 1 + 63) / 64 * 256 : 0);
-    const uint64_t prof_bytes = list_small_off + (tile4 && split_small ? ((uint64_t)p.n_class[ADH_CLASS_IM_SMALL] + 1 + 63) / 64 * 256 : 0);
+    const uint64_t list_small_off = list_common_off + (tile4 && split_common ? featim4::side_bytes(p.n_class[0]) : 0);
+    const uint64_t prof_bytes = list_small_off + (tile4 && split_small ? featim4::side_bytes(p.n_class[ADH_CLASS_IM_SMALL]) : 0);
     int rc = ensure_scratch(h, prof_bytes);
     if (rc != ADH_OK) return rc;
     unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
@@ -565,18 +566,22 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                 const bool fixed_ok = fixed_layouts;
                 const bool common = featim::DimsCommon::holds(cc) && fixed_ok;
                 const unsigned groups = (unsigned)((cnt + ADH_WAVE / 16 - 1) / (ADH_WAVE / 16));
-                const unsigned list_blocks = (unsigned)std::min<int64_t>(cnt, 2048);  // (they take the listed candidates in turn)
+                const unsigned list_blocks = (unsigned)std::min<int64_t>(cnt, 1024);  // (blocks that take the materialised tiles in turn)
                 if (c == ADH_CLASS_IM_SMALL && split_small) {
                     unsigned char *prof = d_scratch + prof_small_off;
                     if (tile4) {
-                        uint32_t *list = reinterpret_cast<uint32_t *>(d_scratch + list_small_off);
-                        HIP_TRY(hipMemsetAsync(list, 0, 4, st));
-                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), dim3(groups),
-                                           dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, h->cs.iso, n_iso, *cfg,
-                                           d_scratch, *out, prof, list);
-                        hipLaunchKernelGGL((adh_feature_im_list_kernel<featim::LayoutSmall>), dim3(list_blocks), dim3(ADH_WAVE),
-                                           featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
-                                           *cfg, d_scratch, *out, cc, prof, list);
+                        uint32_t *side = reinterpret_cast<uint32_t *>(d_scratch + list_small_off);
+                        const unsigned ob = (unsigned)((cnt + 255) / 256);
+                        HIP_TRY(hipMemsetAsync(side, 0, featim4::SIDE_HEAD * 4, st));
+                        hipLaunchKernelGGL(adh_im_order_hist_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), featim::LayoutSmall(cc).bytes() + f_pad);
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, featim::LayoutSmall>),
+                                           dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
+                                           (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
+                                           (int32_t)list_blocks, stop4);
                     } else
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutSmall, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutSmall(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
@@ -595,14 +600,18 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                 } else if (c == 0 && split_common) {
                     unsigned char *prof = d_scratch + prof_base;
                     if (tile4) {
-                        uint32_t *list = reinterpret_cast<uint32_t *>(d_scratch + list_common_off);
-                        HIP_TRY(hipMemsetAsync(list, 0, 4, st));
-                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), dim3(groups),
-                                           dim3(ADH_WAVE), 0, st, h->tims, p.d_recs_im + first, (int32_t)cnt, h->cs.iso, n_iso, *cfg,
-                                           d_scratch, *out, prof, list);
-                        hipLaunchKernelGGL((adh_feature_im_list_kernel<featim::LayoutCommon>), dim3(list_blocks), dim3(ADH_WAVE),
-                                           featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
-                                           *cfg, d_scratch, *out, cc, prof, list);
+                        uint32_t *side = reinterpret_cast<uint32_t *>(d_scratch + list_common_off);
+                        const unsigned ob = (unsigned)((cnt + 255) / 256);
+                        HIP_TRY(hipMemsetAsync(side, 0, featim4::SIDE_HEAD * 4, st));
+                        hipLaunchKernelGGL(adh_im_order_hist_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), featim::LayoutCommon(cc).bytes() + f_pad);
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, featim::LayoutCommon>),
+                                           dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
+                                           (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
+                                           (int32_t)list_blocks, stop4);
                     } else
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutCommon(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,

@@ -437,6 +437,9 @@ def main():
             result["shard_8way"] = {k: v for k, v in leg.items() if k != "shards"}
             result["shard_8way"]["shard_ms"] = [round(s["ms"], 3) for s in leg["shards"]]
             result["config"]["projected_scaling_8"] = leg["projected_scaling_8"]
+            result["config"]["projected_scaling_8_contended"] = leg["projected_scaling_8_contended"]
+            result["config"]["all_gather_bytes_per_rank"] = leg["all_gather"]["bytes_contributed_per_rank"]
+            result["config"]["all_gather_ms_estimate"] = leg["all_gather"]["ms_at_70pct_of_link_rate"]
             result["config"]["max_shard_ms_8way"] = leg["max_shard_ms"]
             # the buffers of the full table come back for the legs below (the shards used smaller ones)
             ctx.score_host(packed, cfgj, reuse_buffers=reuse)

@@ -74,12 +74,18 @@ def _worker(rank, world, port, tmpdir, golden="handler_default"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("golden", ["handler_default", "multiplex"])
-def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib, golden):
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + (7 if golden == "multiplex" else 0)
+@pytest.mark.parametrize("golden,world", [("handler_default", 2), ("multiplex", 2), ("handler_default", 8), ("multiplex", 8)])
+def test_two_rank_sharding_and_all_gather(tmp_path, oracle_lib, golden, world):
+    """World 2, and world 8 - the split BASELINE configs[2] names: score-group shards of UNEVEN size (the padded
+    gather count is agreed on, the tail of a short shard is dropped when the tables are merged)."""
+    port = 29500 + (os.getpid() % 2000) + (7 if golden == "multiplex" else 0) + 13 * world
     mp.spawn(_worker, args=(world, port, str(tmp_path), golden), nprocs=world, join=True)
     g = H.load_scoring_golden(golden)
+    soa_all = H.soa_for(g, g.config)
+    sizes = [b - a for a, b in (shard_bounds(soa_all["score_group_idx"], r, world) for r in range(world))]
+    assert sum(sizes) == len(soa_all["precursor_idx"]) and min(sizes) > 0
+    if world == 8 and golden == "multiplex":
+        assert len(set(sizes)) > 1, sizes  # uneven: whole score groups of several channels
     full, _ = H.oracle_score(oracle_lib, g, g.config)
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")

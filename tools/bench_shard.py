@@ -33,32 +33,55 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
     if with_comm and not getattr(ctx, "_comm_attached", False):
         ctx.comm_init(0, 1, max_rows)
         attached = True
-    per_shard = []
+    from alphadia_amd import runtime
+
+    # CONTENDED pass: eight ranks of one node share ONE CPU quota, so each rank's host team is
+    # the eighth part of it (what adh_host_threads gives under LOCAL_WORLD_SIZE = 8) - the first pass, with this
+    # process's whole budget, is the optimistic figure
+    budget = runtime.host_threads(1 << 40)[1]
+    contended_threads = max(1, budget // ways)
+
+    def one_pass(host_threads: int | None):
+        out = []
+        old = os.environ.get("ADH_HOST_THREADS")
+        if host_threads is not None:
+            os.environ["ADH_HOST_THREADS"] = str(host_threads)
+        try:
+            for r, (a, b) in enumerate(bounds):
+                sub = slice_soa(soa_all, a, b)
+                sub = {k: (ctx.pinned.take("shard:" + k, v) if isinstance(v, np.ndarray) and v.shape[:1] == (b - a,) else v)
+                       for k, v in sub.items()}
+                packed = pack_assembled(sub)
+                for _ in range(3):
+                    ctx.score_host(packed, cfgj, reuse_buffers=True)
+                ctx.comm_wait()
+                ctx.device_synchronize()
+                ctx.kernel_time_ms(reset=True)
+                d2h0 = ctx.d2h_bytes(reset=True)
+                del d2h0
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    ctx.score_host(packed, cfgj, reuse_buffers=True)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ctx.comm_wait()
+                ctx.device_synchronize()
+                g, f, nl = ctx.kernel_time_ms(reset=True)
+                wire = ctx.d2h_bytes(reset=True) / reps
+                out.append({"rank": r, "rows": int(b - a), "ms": float(np.median(ts)), "min_ms": float(min(ts)),
+                            "kernel_ms": float((g + f) * nl / reps), "launches": float(nl / reps),
+                            "d2h_bytes": float(wire), "d2h_ms_at_55GBps": float(wire / 55e9 * 1e3)})
+        finally:
+            if host_threads is not None:
+                if old is None:
+                    os.environ.pop("ADH_HOST_THREADS", None)
+                else:
+                    os.environ["ADH_HOST_THREADS"] = old
+        return out
+
     try:
-        for r, (a, b) in enumerate(bounds):
-            sub = slice_soa(soa_all, a, b)
-            sub = {k: (ctx.pinned.take("shard:" + k, v) if isinstance(v, np.ndarray) and v.shape[:1] == (b - a,) else v)
-                   for k, v in sub.items()}
-            packed = pack_assembled(sub)
-            for _ in range(3):
-                ctx.score_host(packed, cfgj, reuse_buffers=True)
-            ctx.comm_wait()
-            ctx.device_synchronize()
-            ctx.kernel_time_ms(reset=True)
-            d2h0 = ctx.d2h_bytes(reset=True)
-            del d2h0
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                ctx.score_host(packed, cfgj, reuse_buffers=True)
-                ts.append((time.perf_counter() - t0) * 1e3)
-            ctx.comm_wait()
-            ctx.device_synchronize()
-            g, f, nl = ctx.kernel_time_ms(reset=True)
-            wire = ctx.d2h_bytes(reset=True) / reps
-            per_shard.append({"rank": r, "rows": int(b - a), "ms": float(np.median(ts)), "min_ms": float(min(ts)),
-                              "kernel_ms": float((g + f) * nl / reps), "launches": float(nl / reps),
-                              "d2h_bytes": float(wire), "d2h_ms_at_55GBps": float(wire / 55e9 * 1e3)})
+        per_shard = one_pass(None)
+        contended = one_pass(contended_threads)
     finally:
         if attached:
             ctx.comm_wait()
@@ -76,9 +99,28 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
         "note": "every shard scored host -> host on ONE GPU, one after the other; max_shard_ms is what an "
                 f"{ways}-GPU step would wait for before the all-gather costs anything (the gather is enqueued, one rank)",
     }
+    worst_c = max(contended, key=lambda s: s["ms"])
+    # the all-gather this leg does not time: every rank contributes its wire tables and receives the other ways - 1
+    # shards; point-to-point xGMI (7 links per GPU, ~153 GB/s each in both directions = ~76 GB/s in): a direct
+    # all-gather moves one shard per link, side by side
+    shard_bytes = max(s["d2h_bytes"] for s in per_shard)
+    rec["contended"] = {
+        "host_threads_per_rank": int(contended_threads), "cpu_budget": int(budget),
+        "max_shard_ms": worst_c["ms"], "median_shard_ms": float(np.median([s["ms"] for s in contended])),
+        "shard_ms": [round(s["ms"], 3) for s in contended],
+    }
+    rec["all_gather"] = {
+        "bytes_contributed_per_rank": float(shard_bytes),
+        "bytes_received_per_rank": float(shard_bytes * (ways - 1)),
+        "ms_at_xgmi_link_rate_76GBps": float(shard_bytes / 76e9 * 1e3),
+        "ms_at_70pct_of_link_rate": float(shard_bytes / (0.7 * 76e9) * 1e3),
+        "note": "estimate, not measured: enqueued after a rank's last chunk, it overlaps that rank's remaining "
+                "copy-out and the next step; exposed only if longer than those",
+    }
     if ms_per_step:
         rec["ms_per_step_1gpu"] = float(ms_per_step)
         rec["projected_scaling_8"] = float(ms_per_step / worst["ms"])
+        rec["projected_scaling_8_contended"] = float(ms_per_step / worst_c["ms"])
     return rec
 
 
