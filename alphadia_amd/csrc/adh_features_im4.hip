@@ -361,15 +361,21 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
     for (int c = sub; c < SM * KMAX; c += GS) (&Q.fsp[0][0])[c] = 0.0f;
     adh_wave_sync();
 
-    // ---- the fragment entries.  First every entry's plane, balanced over the wavefront's list: a plane is a range
+    // ---- the fragment entries.  First every entry's plane, balanced over the wavefront's list: a plane is a range.
+    // When the four candidates' entries fit the pool together (nearly always) this pass is also pass (a) below: the
+    // list's order IS the pool's order then, and an entry is fetched once.
     const int total = W.g[NG - 1].off + W.g[NG - 1].n_fe;
+    const bool single = total <= NP;
     const int off1 = W.g[1].off, off2 = W.g[2].off, off3 = W.g[3].off;
     for (int j = lane; j < total; j += ADH_WAVE) {
         const int q = (j >= off1) + (j >= off2) + (j >= off3);
         GroupTile<FM, SM> &T = W.g[q];
         const int e = j - T.off;
         const ImEntry *E = T.entries;
-        const uint32_t cell = E[e].cell, pcell = e > 0 ? E[e - 1].cell : 0u;
+        ImEntry en;
+        en.cell = E[e].cell, en.x = 0.0f, en.y = 0.0f;
+        if (single) en = E[e];
+        const uint32_t cell = en.cell, pcell = e > 0 ? E[e - 1].cell : 0u;
         const int tSF = T.SF;
         const float isf = T.inv_sf;
         auto plane_of = [&](uint32_t c) -> int {
@@ -384,6 +390,20 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             if (pp >= 0) T.pl_end[pp] = e;
         }
         if (e == T.n_fe - 1) T.pl_end[pc] = T.n_fe;
+        if (single) {
+            const int tF = T.F;
+            const int rem_c = (int)cell - pc * tSF;
+            int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
+            if (rem_c - sc * tF >= tF) ++sc;
+            const int f = rem_c - sc * tF;
+            const double ds = (double)sc - T.esc, df = (double)f - T.efc;
+            W.u.pool.w[j] = exp(-0.1 * sqrt(ds * ds + df * df));
+            W.u.pool.x[j] = en.x;
+            W.u.pool.y[j] = en.y;
+            W.u.pool.scf[j] = (uint16_t)(sc << 8 | f);
+            W.owner[j] = (uint8_t)(q * GS + pc);
+            atomicOr(&T.scans, 1ull << sc);
+        }
     }
     adh_wave_sync();
     // Then passes over the planes SIDE BY SIDE: every plane that has entries left puts its next R of them into the pool
@@ -404,39 +424,43 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
         const int rem = max(at_end - at, 0);
         const int n_busy = __popcll(__ballot(rem > 0));
         if (n_busy == 0) break;
-        const int R = min(NP / n_busy, 64);
-        const int take = min(rem, R);
-        int incl = take;  // slots [base, base + take) of the pool are this plane's
+        int take = rem, base = Q.off + at, n_slots = total;  // (one pass: the pool was filled above)
+        if (!single) {
+            const int R = min(NP / n_busy, 64);
+            take = min(rem, R);
+            int incl = take;  // slots [base, base + take) of the pool are this plane's
 #pragma unroll
-        for (int o = 1; o < ADH_WAVE; o <<= 1) {
-            const int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
+            for (int o = 1; o < ADH_WAVE; o <<= 1) {
+                const int u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            base = incl - take;
+            n_slots = __shfl(incl, ADH_WAVE - 1);
+            for (int rr = 0; rr < take; ++rr) W.owner[base + rr] = (uint8_t)lane;
+            W.seg_base[lane] = (uint16_t)base;
+            W.seg_src[lane] = at;
+            adh_wave_sync();
+            // (a)
+            for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {
+                const int o = (int)W.owner[s_];
+                const int q = o / GS, k = o % GS;
+                GroupTile<FM, SM> &T = W.g[q];
+                const int e = W.seg_src[o] + (s_ - (int)W.seg_base[o]);
+                const ImEntry en = T.entries[e];
+                const int tF = T.F;
+                const int rem_c = (int)en.cell - k * T.SF;
+                int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
+                if (rem_c - sc * tF >= tF) ++sc;
+                const int f = rem_c - sc * tF;
+                const double ds = (double)sc - T.esc, df = (double)f - T.efc;
+                W.u.pool.w[s_] = exp(-0.1 * sqrt(ds * ds + df * df));
+                W.u.pool.x[s_] = en.x;
+                W.u.pool.y[s_] = en.y;
+                W.u.pool.scf[s_] = (uint16_t)(sc << 8 | f);
+                atomicOr(&T.scans, 1ull << sc);
+            }
+            adh_wave_sync();
         }
-        const int base = incl - take, n_slots = __shfl(incl, ADH_WAVE - 1);
-        for (int rr = 0; rr < take; ++rr) W.owner[base + rr] = (uint8_t)lane;
-        W.seg_base[lane] = (uint16_t)base;
-        W.seg_src[lane] = at;
-        adh_wave_sync();
-        // (a)
-        for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {
-            const int o = (int)W.owner[s_];
-            const int q = o / GS, k = o % GS;
-            GroupTile<FM, SM> &T = W.g[q];
-            const int e = W.seg_src[o] + (s_ - (int)W.seg_base[o]);
-            const ImEntry en = T.entries[e];
-            const int tF = T.F;
-            const int rem_c = (int)en.cell - k * T.SF;
-            int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
-            if (rem_c - sc * tF >= tF) ++sc;
-            const int f = rem_c - sc * tF;
-            const double ds = (double)sc - T.esc, df = (double)f - T.efc;
-            W.u.pool.w[s_] = exp(-0.1 * sqrt(ds * ds + df * df));
-            W.u.pool.x[s_] = en.x;
-            W.u.pool.y[s_] = en.y;
-            W.u.pool.scf[s_] = (uint16_t)(sc << 8 | f);
-            atomicOr(&T.scans, 1ull << sc);
-        }
-        adh_wave_sync();
         if (stop == 3) {
             at += take;
             continue;
@@ -609,6 +633,7 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
     typedef ImProfRec<FM, SM, 1> Rec;
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int32_t)blockIdx.x < list_blocks) {
+        if (stop) return;  // (developer ablation: the four-candidate path alone)
         const uint32_t n = side[0];
         const uint32_t *list = side + SIDE_HEAD + n_cand;
         for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {

@@ -19,7 +19,17 @@
 // (window, cycle) tasks, one per lane, each the only one to touch its cells.
 #include "adh_device.h"
 
+// Events of one batch of windows the sort list holds (the isotope windows always go together; a candidate over the
+// limit takes the materialised tiles).  Round 6 measured 1 024 against 512 on configs[3] (the isotope windows of a
+// candidate ON a peptide hold 300 - 800 events, so most of those candidates are over 512): features 8.84 -> 8.34 ms
+// (fewer materialised tiles), gather 4.73 -> 5.72 ms (3.6 KB more LDS per block) - worse in sum, so it stays 512.
+#ifndef ADH_IM_GATHER_SORT_CAP
+#define ADH_IM_GATHER_SORT_CAP ADH_IM_SORT_CAP
+#endif
 namespace gather_im {
+constexpr int GCAP = ADH_IM_GATHER_SORT_CAP;
+constexpr int GBITS = GCAP <= 512 ? 9 : 10;  // a list entry: cell << GBITS | position in the list
+static_assert(GCAP <= 1024 && (GCAP & (GCAP - 1)) == 0, "list positions are 9 or 10 bits");
 constexpr double ISOTOPE_DELTA = 1.0033548350700006;  // candidate.py:160
 
 // Bitonic sort of the first m keys of an LDS array (m <= 64 * NR) by one wavefront, in registers:
@@ -70,7 +80,7 @@ __device__ __forceinline__ void sort_keys(uint32_t *keys, int m, int lane) {
 // (Occupancy is what this latency-bound kernel lives on: 10 KB -> 20 KB per block costs 70 %.)
 namespace gather_im {
 constexpr size_t kCompactBytes = (size_t)ADH_IM_PAIR_CAP * 4 + (size_t)(ADH_IM_PAIR_CAP + 1) * 4 + 4 +  // p_lo, p_off
-                                 (size_t)ADH_IM_SORT_CAP * (4 + 2 + 1) + ADH_IM_PAIR_CAP;                // s_key, s_int, s_pair, p_win
+                                 (size_t)GCAP * (4 + 2 + 1) + ADH_IM_PAIR_CAP;                // s_key, s_int, s_pair, p_win
 }
 size_t adh_gather_im_lds_bytes(const Caps &c) {
     size_t b = (size_t)(c.k + c.i) * (4 + 4 + 4);  // window m/z, tof start, tof stop
@@ -104,10 +114,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
     // compact mode: event ranges of the (window, TOF bin) pairs, and the list of surviving events
     uint32_t *p_lo = reinterpret_cast<uint32_t *>(region);   // [ADH_IM_PAIR_CAP] first event of the range
     uint32_t *p_off = p_lo + ADH_IM_PAIR_CAP;                 // [ADH_IM_PAIR_CAP + 1] events before the pair
-    uint32_t *s_key = p_off + ADH_IM_PAIR_CAP + 2;            // [ADH_IM_SORT_CAP] cell << 9 | position in the list
-    uint16_t *s_int = reinterpret_cast<uint16_t *>(s_key + ADH_IM_SORT_CAP);
-    uint8_t *s_pair = reinterpret_cast<uint8_t *>(s_int + ADH_IM_SORT_CAP);
-    uint8_t *p_win = s_pair + ADH_IM_SORT_CAP;                // [ADH_IM_PAIR_CAP] window of the pair
+    uint32_t *s_key = p_off + ADH_IM_PAIR_CAP + 2;            // [GCAP] cell << GBITS | position in the list
+    uint16_t *s_int = reinterpret_cast<uint16_t *>(s_key + GCAP);
+    uint8_t *s_pair = reinterpret_cast<uint8_t *>(s_int + GCAP);
+    uint8_t *p_win = s_pair + GCAP;                // [ADH_IM_PAIR_CAP] window of the pair
 
     const int lane = threadIdx.x;
     const CandRecIM &r = plan[blockIdx.x];
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             if (lane == 0) header[0] = 0;
             return;
         }
-        bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << 23) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
+        bool over = P > ADH_IM_PAIR_CAP || W > 255 || run.n_events >= 0xFFFFFFFFll || (int64_t)n_fc + n_pc >= (1 << (32 - GBITS)) || I > 12 || F >= 4096 || S >= 32768;  // (limits of the packed cell ids)
         const double inv_smax = 1.0 / (double)S_max, inv_l = 1.0 / (double)L;
         ImEntry *out_list = reinterpret_cast<ImEntry *>(block + adh_scratch_frag_off(r.k_cap));
         const uint32_t out_cap =
@@ -281,7 +291,8 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 if (m <= ADH_WAVE) sort_keys<1>(s_key, m, lane);
                 else if (m <= 2 * ADH_WAVE) sort_keys<2>(s_key, m, lane);
                 else if (m <= 4 * ADH_WAVE) sort_keys<4>(s_key, m, lane);
-                else sort_keys<8>(s_key, m, lane);
+                else if (m <= 8 * ADH_WAVE) sort_keys<8>(s_key, m, lane);
+                else sort_keys<16>(s_key, m, lane);
             }
             __syncthreads();
             auto group_of = [&](uint32_t cell) -> uint32_t {
@@ -293,9 +304,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 ImEntry en;
                 en.cell = 0u, en.x = 0.0f, en.y = 0.0f;
                 if (e < m) {
-                    const uint32_t cell = s_key[e] >> 9;
+                    const uint32_t cell = s_key[e] >> GBITS;
                     const uint32_t gid = group_of(cell);
-                    owner = e == 0 || group_of(s_key[e - 1] >> 9) != gid;
+                    owner = e == 0 || group_of(s_key[e - 1] >> GBITS) != gid;
                     frag = cell < (uint32_t)n_fc;
                     if (owner) {
                         // TOF bin of an event: first bin of its window + pair - first pair of the window
@@ -306,11 +317,11 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                         double sum = 0.0;
                         int count = 0;
                         int q = e;
-                        while (q < m && group_of(s_key[q] >> 9) == gid) {
-                            const uint32_t c = s_key[q] >> 9;
+                        while (q < m && group_of(s_key[q] >> GBITS) == gid) {
+                            const uint32_t c = s_key[q] >> GBITS;
                             float vx = 0.0f, vy = 0.0f;
-                            for (; q < m && (s_key[q] >> 9) == c; ++q) {
-                                const int pos = (int)(s_key[q] & 511u);
+                            for (; q < m && (s_key[q] >> GBITS) == c; ++q) {
+                                const int pos = (int)(s_key[q] & (uint32_t)(GCAP - 1));
                                 fold(vx, vy, (int64_t)s_int[pos], run.mz[tof0 + (int)s_pair[pos]]);
                             }
                             acc += vx;
@@ -342,10 +353,10 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         auto stage_one = [&](int wa, int wb) -> int {
             const int pa0 = w_p0[wa], pb0 = w_p0[wb];
             const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
-            return tiled ? index_im::queue_scan_range<true>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+            return tiled ? index_im::queue_scan_range<true, GCAP>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
                                                             p_off, s_key, s_int, s_pair, lane, (uint32_t)(c0 * L + z),
                                                             (uint32_t)((c0 + F) * L + z))
-                         : index_im::queue_scan_range<false>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+                         : index_im::queue_scan_range<false, GCAP>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
                                                              p_off, s_key, s_int, s_pair, lane);
         };
         int w0 = 0;
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             int w1 = W, nq = -1;
             if (try_all && p_off[w_p0[W]] - p_off[w_p0[w0]] <= 0xFFFFu) {
                 nq = stage_one(w0, W);
-                if (m + nq > ADH_IM_SORT_CAP) {
+                if (m + nq > GCAP) {
                     nq = -1;
                     try_all = false;
                     __syncthreads();
@@ -368,18 +379,18 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             }
             if (nq < 0) {
                 w1 = pg ? W : w0 + 1;
-                if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > ADH_IM_SORT_CAP) {
+                if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > GCAP) {
                     flush();
                     if (over) break;
                 }
                 if (!pg)
-                    while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= ADH_IM_SORT_CAP) ++w1;
+                    while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= GCAP) ++w1;
                 if (p_off[w_p0[w1]] - p_off[w_p0[w0]] > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
                     over = true;
                     break;
                 }
                 nq = stage_one(w0, w1);
-                if (m + nq > ADH_IM_SORT_CAP) {  // (only a single window or the isotope group can be this full)
+                if (m + nq > GCAP) {  // (only a single window or the isotope group can be this full)
                     over = true;
                     break;
                 }
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 const unsigned long long mask = __ballot(ok);
                 if (ok) {
                     const int pos = m + __popcll(mask & lt);
-                    s_key[pos] = (cell << 9) | (uint32_t)pos;
+                    s_key[pos] = (cell << GBITS) | (uint32_t)pos;
                     s_pair[pos] = (uint8_t)pair;
                     s_int[pos] = ni;
                 }

@@ -188,10 +188,10 @@ __device__ __forceinline__ int pair_setup_tiled(const DevTims &run, const TileBo
 // Stage 1 of a batch of windows (pairs [pa0, pb0), raw events [r0, r1)): eight pushes per lane and step
 // (eight independent loads in flight); the events inside the scan range [scan_lo, scan_hi) - ~3 % - are
 // queued behind the m entries of the list: s_key = push, s_int = raw number - r0, s_pair = pair.  Returns the
-// number of queued events (entries beyond ADH_IM_SORT_CAP are counted, not stored).
+// number of queued events (entries beyond CAP are counted, not stored).
 // TILED: the events come from the tile layout (p_lo absolute; s_key = frame << tile_sbits | scan); a tile also
 // holds cycles outside the candidate's, so the frame range [frame_lo, frame_hi) is tested here as well.
-template <bool TILED = false>
+template <bool TILED = false, int CAP = ADH_IM_SORT_CAP>
 __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int pb0, uint32_t r0, uint32_t r1,
                                                 int scan_lo, int scan_hi, int m, const int64_t *w_base,
                                                 const uint8_t *p_win, const uint32_t *p_lo, const uint32_t *p_off,
@@ -238,7 +238,7 @@ __device__ __forceinline__ int queue_scan_range(const DevTims &run, int pa0, int
             const unsigned long long mask = __ballot(pass);
             if (pass) {
                 const int at = m + nq + __popcll(mask & lt);
-                if (at < ADH_IM_SORT_CAP) {
+                if (at < CAP) {
                     s_key[at] = pv[u];
                     s_int[at] = (uint16_t)(eu - r0);
                     s_pair[at] = (uint8_t)pa_u[u];
