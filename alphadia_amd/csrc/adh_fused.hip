@@ -35,6 +35,9 @@
 #include <type_traits>
 
 #define ADH_FUSED_ISO0 12      // first isotope lane of a 16-lane group
+#ifndef ADH_FUSED_TW3
+#define ADH_FUSED_TW3 15       // tile columns of the three-isotope launches (A/B of round 6: 17)
+#endif
 #define ADH_FUSED_NLIB 64      // longest library slice handled here
 #ifndef ADH_FUSED_WAVES
 #define ADH_FUSED_WAVES 3      // wavefronts per SIMD the register budget is held to

@@ -748,7 +748,7 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
             used[a] = true;                                                                     \
         }                                                                                       \
         if (wide) ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 16);                               \
-        else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, 15);                                    \
+        else ADH_LAUNCH_FUSED_TW(W, FM_MIN, FM_MAX, NO, ADH_FUSED_TW3);                         \
         HIP_TRY(hipGetLastError());                                                             \
         ++launched;                                                                             \
     }
@@ -992,22 +992,21 @@ __global__ void adh_cop_count_kernel(const uint8_t *__restrict__ valid, const ui
     cnt[i] = v;  // (entry n: 0, so that the scan's last entry is the total)
 }
 
-// a chunk's block, dense: [row u32 | precursor_idx u32 | rank u8 | features f32 [46][R]] for its R valid rows, then
-// [fragment_row u32 | precursor_idx u32 | rank u8 | 7 float columns | 5 byte columns] for its S filled slots; every
-// column starts on a multiple of 16 bytes
+// a chunk's block, dense: [row u32 | filled slots u8 | features f32 [46][R]] for its R valid rows, then
+// [fragment_lib_slot u16 | 5 computed float columns] for its S filled slots; every column starts on a multiple of 16
+// bytes.  Round 6: what repeats the candidate table (precursor_idx, rank, and fragment_row = the row of a slot's
+// candidate) and the seven library columns of a slot stay off the wire - 26 instead of 42 bytes per slot, 188 instead of
+// 193 per row - and are rebuilt by the unpack team from the caller's candidate columns and the host copy of the
+// library, as the padded path does (rebuild_host_rows).
 struct CopBlock {
-    size_t row, pidx, rank, feat, s_row, s_pidx, s_rank, s_f[7], s_b[5], total;
+    size_t row, cnt, feat, s_slot, s_f[5], total;
     __host__ __device__ CopBlock(uint64_t R, uint64_t S) {
         size_t o = 0;
         row = o, o += (R * 4 + 15) & ~(size_t)15;
-        pidx = o, o += (R * 4 + 15) & ~(size_t)15;
-        rank = o, o += (R + 15) & ~(size_t)15;
+        cnt = o, o += (R + 15) & ~(size_t)15;
         feat = o, o += (R * 4 * ADH_NUM_FEATURES + 15) & ~(size_t)15;
-        s_row = o, o += (S * 4 + 15) & ~(size_t)15;
-        s_pidx = o, o += (S * 4 + 15) & ~(size_t)15;
-        s_rank = o, o += (S + 15) & ~(size_t)15;
-        for (int j = 0; j < 7; ++j) s_f[j] = o, o += (S * 4 + 15) & ~(size_t)15;
-        for (int j = 0; j < 5; ++j) s_b[j] = o, o += (S + 15) & ~(size_t)15;
+        s_slot = o, o += (S * 2 + 15) & ~(size_t)15;
+        for (int j = 0; j < 5; ++j) s_f[j] = o, o += (S * 4 + 15) & ~(size_t)15;
         total = o;
     }
 };
@@ -1016,7 +1015,7 @@ struct CopBlock {
 struct CopLayout {
     size_t per_row, total;
     CopLayout(int64_t n, int top_k, int64_t n_chunks)
-        : per_row(9 + 4 * ADH_NUM_FEATURES + (size_t)top_k * 42), total((size_t)n * per_row + (size_t)(n_chunks + 1) * 1024) {}
+        : per_row(5 + 4 * ADH_NUM_FEATURES + (size_t)top_k * 22), total((size_t)n * per_row + (size_t)(n_chunks + 1) * 1024) {}
     size_t base(int64_t a, int64_t ci) const { return ((size_t)a * per_row + (size_t)ci * 1024 + 255) & ~(size_t)255; }
 };
 
@@ -1029,24 +1028,23 @@ __global__ void adh_cop_pack_kernel(DevOut t, DevCands c, const LibRec *__restri
     const uint64_t R = tot >> 32, S = tot & 0xFFFFFFFFull;
     if (tid == 0) totals[0] = tot;  // (page-locked host memory)
     const CopBlock L(R, S);
-    uint32_t *const o_row = reinterpret_cast<uint32_t *>(block + L.row), *const o_pidx = reinterpret_cast<uint32_t *>(block + L.pidx);
-    uint8_t *const o_rank = block + L.rank;
+    uint32_t *const o_row = reinterpret_cast<uint32_t *>(block + L.row);
+    uint8_t *const o_cnt = block + L.cnt;
     float *const o_feat = reinterpret_cast<float *>(block + L.feat);
-    // valid rows: ids + the feature row, transposed (consecutive lanes = consecutive output rows of one column)
+    // valid rows: row id, number of filled slots, the feature row transposed (consecutive lanes = consecutive output
+    // rows of one column)
     for (int64_t i = tid; i < n; i += stride) {
         const uint64_t o = off[i], o1 = off[i + 1];
         if ((o1 >> 32) == (o >> 32)) continue;
         const int64_t j = (int64_t)(o >> 32), r = row0 + i;
         o_row[j] = (uint32_t)r;
-        o_pidx[j] = c.precursor_idx[r];
-        o_rank[j] = c.rank[r];
+        o_cnt[j] = (uint8_t)((uint32_t)o1 - (uint32_t)o);
         const float *f = t.features + r * ADH_NUM_FEATURES;
 #pragma unroll
         for (int k = 0; k < ADH_NUM_FEATURES; ++k) o_feat[(size_t)k * R + (size_t)j] = f[k];
     }
     // filled slots
-    uint32_t *const s_row = reinterpret_cast<uint32_t *>(block + L.s_row), *const s_pidx = reinterpret_cast<uint32_t *>(block + L.s_pidx);
-    uint8_t *const s_rank = block + L.s_rank;
+    uint16_t *const s_slot = reinterpret_cast<uint16_t *>(block + L.s_slot);
     const int64_t n_slots = n * (int64_t)top_k;
     for (int64_t id = tid; id < n_slots; id += stride) {
         const int64_t i = id / top_k;
@@ -1056,57 +1054,62 @@ __global__ void adh_cop_pack_kernel(DevOut t, DevCands c, const LibRec *__restri
         if ((uint32_t)s >= k) continue;
         const int64_t r = row0 + i, src = r * (int64_t)top_k + s;
         const size_t dst = (size_t)a + (size_t)s;
-        const LibRec l = lib[c.frag_start[r] + t.fragment_lib_slot[src] - 1];
-        s_row[dst] = (uint32_t)r;
-        s_pidx[dst] = c.precursor_idx[r];
-        s_rank[dst] = c.rank[r];
-        reinterpret_cast<float *>(block + L.s_f[0])[dst] = l.mz_library;
-        reinterpret_cast<float *>(block + L.s_f[1])[dst] = l.mz;
-        reinterpret_cast<float *>(block + L.s_f[2])[dst] = t.fragment_mz_observed[src];
-        reinterpret_cast<float *>(block + L.s_f[3])[dst] = t.fragment_height[src];
-        reinterpret_cast<float *>(block + L.s_f[4])[dst] = t.fragment_intensity[src];
-        reinterpret_cast<float *>(block + L.s_f[5])[dst] = t.fragment_mass_error[src];
-        reinterpret_cast<float *>(block + L.s_f[6])[dst] = t.fragment_correlation[src];
-        (block + L.s_b[0])[dst] = l.position;
-        (block + L.s_b[1])[dst] = l.number;
-        (block + L.s_b[2])[dst] = l.type;
-        (block + L.s_b[3])[dst] = l.charge;
-        (block + L.s_b[4])[dst] = l.loss_type;
+        s_slot[dst] = t.fragment_lib_slot[src];
+        reinterpret_cast<float *>(block + L.s_f[0])[dst] = t.fragment_mz_observed[src];
+        reinterpret_cast<float *>(block + L.s_f[1])[dst] = t.fragment_height[src];
+        reinterpret_cast<float *>(block + L.s_f[2])[dst] = t.fragment_intensity[src];
+        reinterpret_cast<float *>(block + L.s_f[3])[dst] = t.fragment_mass_error[src];
+        reinterpret_cast<float *>(block + L.s_f[4])[dst] = t.fragment_correlation[src];
     }
 }
 
 namespace {
-// stripe w of T of a finished block (page-locked host copy) -> the caller's arrays (rows at base_r, slots at base_s)
+// stripe w of T of a finished block (page-locked host copy) -> the caller's arrays (rows at base_r, slots at base_s): the
+// stripe is a range of the block's valid rows together with their slots; what the block leaves out - ids, the row of a
+// slot's candidate, the library columns - comes from the candidate columns `c` and the library `lib`
 void cop_copy_stripe(const unsigned char *block, int64_t cnt_r, int64_t cnt_s, int64_t base_r, int64_t base_s,
-                     adh_compact_output_t *out, int w, int T) {
+                     adh_compact_output_t *out, int w, int T, const adh_candidates_t *c, const LibRec *lib) {
     const CopBlock L((uint64_t)cnt_r, (uint64_t)cnt_s);
-    auto part = [&](int64_t cnt, int64_t &lo, int64_t &hi) {
-        lo = cnt * w / T;
-        hi = cnt * (w + 1) / T;
-    };
-    int64_t lo, hi;
-    part(cnt_r, lo, hi);
-    if (hi > lo) {
-        memcpy(out->row + base_r + lo, block + L.row + (size_t)lo * 4, (size_t)(hi - lo) * 4);
-        memcpy(out->precursor_idx + base_r + lo, block + L.pidx + (size_t)lo * 4, (size_t)(hi - lo) * 4);
-        memcpy(out->rank + base_r + lo, block + L.rank + (size_t)lo, (size_t)(hi - lo));
-        const float *fb = reinterpret_cast<const float *>(block + L.feat);
-        for (int k = 0; k < ADH_NUM_FEATURES; ++k)
-            memcpy(out->features + (size_t)k * (size_t)out->rows_capacity + (size_t)(base_r + lo),
-                   fb + (size_t)k * (size_t)cnt_r + (size_t)lo, (size_t)(hi - lo) * 4);
+    const int64_t lo = cnt_r * w / T, hi = cnt_r * (w + 1) / T;
+    if (hi <= lo) return;
+    const uint32_t *rows = reinterpret_cast<const uint32_t *>(block + L.row);
+    const uint8_t *cnt = block + L.cnt;
+    int64_t s_lo = 0;  // slots of the rows before the stripe
+    for (int64_t j = 0; j < lo; ++j) s_lo += cnt[j];
+    memcpy(out->row + base_r + lo, rows + lo, (size_t)(hi - lo) * 4);
+    const float *fb = reinterpret_cast<const float *>(block + L.feat);
+    for (int k = 0; k < ADH_NUM_FEATURES; ++k)
+        memcpy(out->features + (size_t)k * (size_t)out->rows_capacity + (size_t)(base_r + lo),
+               fb + (size_t)k * (size_t)cnt_r + (size_t)lo, (size_t)(hi - lo) * 4);
+    const uint16_t *slot = reinterpret_cast<const uint16_t *>(block + L.s_slot);
+    int64_t d = base_s + s_lo, at = s_lo;
+    for (int64_t j = lo; j < hi; ++j) {
+        const uint32_t r = rows[j];
+        const uint32_t p = c->precursor_idx[r];
+        const uint8_t rk = c->rank ? c->rank[r] : (uint8_t)0;
+        out->precursor_idx[base_r + j] = p;
+        out->rank[base_r + j] = rk;
+        const LibRec *base = lib + c->frag_start_idx[r];
+        const int k = (int)cnt[j];
+        for (int q = 0; q < k; ++q, ++d, ++at) {
+            const LibRec &l = base[slot[at] - 1];
+            out->fragment_row[d] = r;
+            out->fragment_precursor_idx[d] = p;
+            out->fragment_rank[d] = rk;
+            out->fragment_mz_library[d] = l.mz_library;
+            out->fragment_mz[d] = l.mz;
+            out->fragment_position[d] = l.position;
+            out->fragment_number[d] = l.number;
+            out->fragment_type[d] = l.type;
+            out->fragment_charge[d] = l.charge;
+            out->fragment_loss_type[d] = l.loss_type;
+        }
     }
-    part(cnt_s, lo, hi);
-    if (hi > lo) {
-        const size_t m = (size_t)(hi - lo);
-        memcpy(out->fragment_row + base_s + lo, block + L.s_row + (size_t)lo * 4, m * 4);
-        memcpy(out->fragment_precursor_idx + base_s + lo, block + L.s_pidx + (size_t)lo * 4, m * 4);
-        memcpy(out->fragment_rank + base_s + lo, block + L.s_rank + (size_t)lo, m);
-        float *const fcol[7] = {out->fragment_mz_library, out->fragment_mz, out->fragment_mz_observed, out->fragment_height,
-                                out->fragment_intensity, out->fragment_mass_error, out->fragment_correlation};
-        for (int j = 0; j < 7; ++j) memcpy(fcol[j] + base_s + lo, block + L.s_f[j] + (size_t)lo * 4, m * 4);
-        uint8_t *const bcol[5] = {out->fragment_position, out->fragment_number, out->fragment_type, out->fragment_charge,
-                                  out->fragment_loss_type};
-        for (int j = 0; j < 5; ++j) memcpy(bcol[j] + base_s + lo, block + L.s_b[j] + (size_t)lo, m);
+    const size_t m = (size_t)(at - s_lo);
+    if (m) {
+        float *const fcol[5] = {out->fragment_mz_observed, out->fragment_height, out->fragment_intensity, out->fragment_mass_error,
+                                out->fragment_correlation};
+        for (int j = 0; j < 5; ++j) memcpy(fcol[j] + base_s + s_lo, block + L.s_f[j] + (size_t)s_lo * 4, m * 4);
     }
 }
 }  // namespace
@@ -1649,7 +1652,7 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
     auto cop_stripe = [&](int64_t ci, int w) {
         if (cop_cnt_r[(size_t)ci] == 0 && cop_cnt_s[(size_t)ci] == 0) return;
         cop_copy_stripe(cop_stage + cop_lay.base(cut[(size_t)ci], ci), cop_cnt_r[(size_t)ci], cop_cnt_s[(size_t)ci],
-                        cop_base_r[(size_t)ci], cop_base_s[(size_t)ci], cop, w, cop_T);
+                        cop_base_r[(size_t)ci], cop_base_s[(size_t)ci], cop, w, cop_T, c, h->h_lib.data());
     };
     auto cop_worker = [&](int w) {
         for (int64_t ci = 0; ci < n_chunks; ++ci) {

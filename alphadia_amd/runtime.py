@@ -152,6 +152,14 @@ def _probe_take_objects() -> bool:
 
     if sys.implementation.name != "cpython" or sys.version_info[:2] > (3, 11) or os.environ.get("ADH_NO_OBJECT_TAKE"):
         return False
+    #  the gather writes ``ob_refcnt`` as the first word of an object: debug and trace-refs builds put two
+    # list pointers in front of it, and free-threaded builds keep the count elsewhere - refuse them by their build
+    # flags, not only by the probe below
+    import sysconfig
+
+    if (sysconfig.get_config_var("Py_DEBUG") or sysconfig.get_config_var("Py_TRACE_REFS")
+            or sysconfig.get_config_var("Py_GIL_DISABLED") or hasattr(sys, "gettotalrefcount")):
+        return False
     try:
         _pylib = C.PyDLL(LIB_PATH)
         fn = _pylib.adh_host_take_objects
@@ -172,7 +180,12 @@ def _probe_take_objects() -> bool:
 
 def take_objects(src: np.ndarray, idx: np.ndarray, threads: int = 8) -> np.ndarray:
     """``src[idx]`` for a 1-d object array: on several threads through ``adh_host_take_objects`` where that is safe
-    (see there), NumPy's own gather otherwise (small inputs, other interpreters, negative indices)."""
+    (see there), NumPy's own gather otherwise (small inputs, other interpreters, negative indices).
+
+    The call keeps the GIL for its whole duration (``ctypes.PyDLL``: the C threads touch reference counts): Python-level
+    code of other threads - the fragments frame's worker, the futures of the host pool when they finish a NumPy call -
+    waits meanwhile; only work already inside a GIL-free NumPy loop runs beside it.  ``ADH_NO_OBJECT_TAKE=1`` switches
+    it off."""
     global _OBJ_TAKE
     src = np.asarray(src)
     if src.dtype != object or src.ndim != 1 or len(idx) < 262144 or not src.flags.c_contiguous:
@@ -292,6 +305,50 @@ def _launch_nonce() -> bytes:
     return hashlib.sha256(tag.encode()).digest()
 
 
+def _proc_start_ticks(pid: int) -> int:
+    """Start time of process ``pid`` in clock ticks since boot (field 22 of /proc/<pid>/stat); -1 when it is gone."""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, IndexError, ValueError):
+        return -1
+
+
+def _writer_tag(pid: int) -> bytes:
+    """16 bytes that name the process that wrote an id file: pid and its start time (a recycled pid differs in the latter)."""
+    import struct
+
+    return struct.pack("<qq", int(pid), _proc_start_ticks(pid))
+
+
+def _writer_alive(tag: bytes) -> bool:
+    import struct
+
+    pid, start = struct.unpack("<qq", tag)
+    return pid > 0 and start >= 0 and _proc_start_ticks(pid) == start
+
+
+_EXIT_REMOVALS: list = []
+
+
+def _remove_at_exit(path: str) -> None:
+    import atexit
+
+    if not _EXIT_REMOVALS:
+        def _cleanup():
+            for p, tag in _EXIT_REMOVALS:
+                try:  # (only a file this process wrote: a later attempt may have replaced it)
+                    with open(p, "rb") as f:
+                        data = f.read()
+                    if data[32:48] == tag:
+                        os.remove(p)
+                except OSError:
+                    pass
+
+        atexit.register(_cleanup)
+    _EXIT_REMOVALS.append((path, _writer_tag(os.getpid())))
+
+
 def rendezvous_path() -> str:
     if os.environ.get("ADH_RENDEZVOUS_FILE"):
         return os.environ["ADH_RENDEZVOUS_FILE"]
@@ -336,8 +393,9 @@ def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0, make_id=
         tmp = f"{path}.{os.getpid()}.tmp"
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(nonce + uid)
+            f.write(nonce + _writer_tag(os.getpid()) + uid)
         os.replace(tmp, path)  # atomic: readers see all of it or nothing
+        _remove_at_exit(path)  # (a rank 0 that fails before Context.comm_init removes the file still cleans up)
         return uid
     t0 = time.time()
     while True:
@@ -349,8 +407,12 @@ def rendezvous_unique_id(rank: int, world: int, timeout: float = 300.0, make_id=
             # (rank 0 replaces it); the bound is the LAUNCHER's start, not this rank's: ranks may start seconds
             # or minutes apart (_attempt_lower_bound)
             fresh = written >= _attempt_lower_bound() - 2.0
-            if fresh and len(data) == len(nonce) + 128 and data[: len(nonce)] == nonce:
-                return data[len(nonce):]
+            if fresh and len(data) == len(nonce) + 16 + 128 and data[: len(nonce)] == nonce:
+                # ... and a file whose writer is gone is what a crashed attempt of THIS launch left (same launcher,
+                # same port, seconds ago): rank 0 is alive while its peers read - it waits for them inside
+                # ncclCommInitRank - so a dead writer means "not this attempt's"; the new rank 0 replaces the file
+                if _writer_alive(data[len(nonce): len(nonce) + 16]):
+                    return data[len(nonce) + 16:]
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:

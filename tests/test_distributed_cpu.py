@@ -201,7 +201,9 @@ def test_packed_layout_is_the_librarys(tmp_path):
     assert per_row == 449  # bytes per candidate on the wire and over PCIe at top_k = 12
 
 
-def _rendezvous_worker(rank, world, path_env, out_dir, nonce):
+def _rendezvous_worker(rank, world, path_env, out_dir, nonce, linger_for=None):
+    """``linger_for``: a file this process waits for before it exits (rank 0 of a real run is alive while its peers
+    read the id - it waits for them inside the collective communicator creation)."""
     os.environ["ADH_RUN_NONCE"] = nonce
     os.environ["MASTER_PORT"] = "29555"
     os.environ.pop("LOCAL_WORLD_SIZE", None)
@@ -213,6 +215,14 @@ def _rendezvous_worker(rank, world, path_env, out_dir, nonce):
     uid = runtime.rendezvous_unique_id(rank, world, timeout=30.0, make_id=lambda: bytes([7 + rank]) * 128)
     with open(os.path.join(out_dir, f"id_{rank}"), "wb") as f:
         f.write(uid)
+    if linger_for:
+        import time
+
+        t0 = time.time()
+        while not all(os.path.exists(p) for p in linger_for) and time.time() - t0 < 60:
+            time.sleep(0.05)
+        if os.environ.get("ADH_TEST_HARD_EXIT"):
+            os._exit(0)  # (a crash: no exit handlers, the id file stays)
 
 
 def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
@@ -241,32 +251,38 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
 
     time.sleep(1.0)  # the readers are polling: they must not have taken the stale id
     assert not os.path.exists(tmp_path / "id_1") and not os.path.exists(tmp_path / "id_2")
-    p0 = mp.get_context("spawn").Process(target=_rendezvous_worker, args=(0, 3, path, str(tmp_path), "launch-C"))
+    p0 = mp.get_context("spawn").Process(target=_rendezvous_worker, args=(0, 3, path, str(tmp_path), "launch-C",
+                                                                           [str(tmp_path / "id_1"), str(tmp_path / "id_2")]))
     p0.start()
     for p in procs + [p0]:
         p.join(60)
         assert p.exitcode == 0
     ids = [open(tmp_path / f"id_{r}", "rb").read() for r in range(3)]
     assert ids[0] == bytes([7]) * 128 and ids[1] == ids[0] and ids[2] == ids[0]
-    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    assert not os.path.exists(path)  # (rank 0 removes its id file when it exits, if comm_init has not already)
     # (d) a restart under the same launcher: the previous attempt's file carries the SAME nonce but is older than
     # the restarted readers - they wait for the id rank 0 writes now; a symlinked rendezvous directory is refused
     path_d = str(tmp_path / "rccl_id_d")
     out_d = tmp_path / "d"
     out_d.mkdir()
     ctx_mp = mp.get_context("spawn")
-    first = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D"))
+    os.environ["ADH_TEST_HARD_EXIT"] = "1"
+    first = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D", [str(out_d / "id_0")]))
     first.start()
-    first.join(60)  # the "previous attempt": its rank 0 left a file with this launch's nonce
+    first.join(60)  # the "previous attempt": its rank 0 crashed and left a file with this launch's nonce
+    os.environ.pop("ADH_TEST_HARD_EXIT")
     assert first.exitcode == 0 and os.path.exists(path_d)
     os.remove(out_d / "id_0")
-    old_t = time.time() - 3600.0
-    os.utime(path_d, (old_t, old_t))
+    stat_mode = stat.S_IMODE(os.stat(path_d).st_mode)
+    assert stat_mode == 0o600
+    # (the crash was SECONDS ago - the file is fresh and carries the right nonce; its writer is gone)
     reader = ctx_mp.Process(target=_rendezvous_worker, args=(1, 2, path_d, str(out_d), "launch-D"))
     reader.start()
     time.sleep(1.5)
-    assert not os.path.exists(out_d / "id_1")  # right nonce, but older than the reader: not this attempt's
-    writer = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D"))
+    assert not os.path.exists(out_d / "id_1")  # right nonce, fresh, but nobody behind it: not this attempt's
+    old_t = time.time() - 3600.0
+    os.utime(path_d, (old_t, old_t))  # (... and an old one is refused on its age as well)
+    writer = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_d, str(out_d), "launch-D", [str(out_d / "id_1")]))
     writer.start()
     for p in (reader, writer):
         p.join(60)
@@ -277,14 +293,17 @@ def test_rendezvous_hands_rank0s_id_to_every_rank(tmp_path):
     path_e = str(tmp_path / "rccl_id_e")
     out_e = tmp_path / "e"
     out_e.mkdir()
-    w0 = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_e, str(out_e), "launch-E"))
+    w0 = ctx_mp.Process(target=_rendezvous_worker, args=(0, 2, path_e, str(out_e), "launch-E", [str(out_e / "id_1")]))
     w0.start()
-    w0.join(60)
-    assert w0.exitcode == 0
+    t_w = time.time()
+    while not os.path.exists(out_e / "id_0") and time.time() - t_w < 60:
+        time.sleep(0.05)
     time.sleep(3.0)
     late = ctx_mp.Process(target=_rendezvous_worker, args=(1, 2, path_e, str(out_e), "launch-E"))
     late.start()
     late.join(20)
+    w0.join(20)
+    assert w0.exitcode == 0
     assert late.exitcode == 0 and open(out_e / "id_1", "rb").read() == bytes([7]) * 128
     # ... and under a launcher (no ADH_RUN_NONCE: the parent's start time bounds the attempt) as well
     assert runtime._attempt_lower_bound() <= runtime._PROCESS_T0 <= time.time()

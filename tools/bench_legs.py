@@ -315,7 +315,7 @@ def transfer_requant_leg(ctx, n_prec: int = 100_000, n_cycles: int = 4800, steps
     alg = float(algorithmic_bytes(case.dia, soa, cfgj, matched, lib_len).sum())
     achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     # CPU oracle on a sample of the same table
-    sample = min(n, 3000)
+    sample = min(n, int(os.environ.get("CPU_SAMPLE", 100_000)))  # (>= 100 000 candidates)
     sub = pack_assembled(slice_soa(soa, 0, sample))
     th = _cpu_threads()
     oracle.score(case.dia, cols, sub, cfgj, n_threads=th)

@@ -178,7 +178,7 @@ if not os.environ.get("ADH_BENCH_NO_CPU"):
 
     quota = cpu_quota_cores()
     cores = int(min(os.cpu_count() or 1, 2 * quota if quota else 64))
-    sample = min(n, int(os.environ.get("CPU_SAMPLE", 6000)))
+    sample = min(n, int(os.environ.get("CPU_SAMPLE", 100_000)))  # (>= 100 000 candidates)
     sub = slice_soa(soa, 0, sample)
     oracle.score_timstof(dia, cols, pack_assembled(slice_soa(soa, 0, 500)), cfgj, n_threads=cores)
     t0 = time.perf_counter()
