@@ -35,66 +35,68 @@ constexpr int NG = ADH_WAVE / GS;
 constexpr int KMAX = ADH_IM_PROF_K;
 constexpr int NP = 256;  // fragment entries of a wavefront's candidates per pass of the pool
 
-// precursor entries of the wavefront's candidates, PP per pass, as the balanced pass leaves them (they live in the
-// pool's bytes: the precursor entries come first)
+// precursor entries of the wavefront's candidates, PP per pass, as the balanced pass leaves them (PrecPoolT below; they
+// live in the pool's bytes: the precursor entries come first)
 constexpr int PP = 128;
-struct __attribute__((aligned(16))) PrecPool {
-    double t[PP];                 // template term of the entry: (intensity * library isotope intensity) * transfer function
+
+template <int FM, int SM, int NO>
+struct __attribute__((aligned(16))) GroupTile {
+    float ffp[NO][FM][KMAX];      // fragment frame profiles [observation][cycle][fragment]
+    float fsp[NO][SM][KMAX];      // fragment scan profiles [observation][scan][fragment]
+    double cy[NO][2][SM];         // the quadrupole rows of the candidate's scans (lower, upper limit) per observation
+    float qmask[NO][SM];
+    float tsp_raw[NO][SM], tfp_raw[NO][FM];
+    float iso_int[4], iso_mz[4];
+    int pl_beg[NO * GS], pl_end[NO * GS];  // entries of plane p = fragment * O + observation
+    // what the balanced passes need to know about the candidate
+    const ImEntry *entries;
+    double esc[NO], efc[NO], inv_f;
+    float inv_sf;
+    int n_fe, off, F, SF, S, O;
+    const ImEntry *pent;
+    int n_pe, poff;
+    unsigned long long scans[NO], scans_done[NO];
+};
+
+template <int NO>
+struct __attribute__((aligned(16))) PrecPoolT {
+    double t[NO][PP];             // template term of the entry: (intensity * library isotope intensity) * transfer function
     double r[4][PP];              // x > 0 ? x * w : 0, x > 0 ? w : 0, y > 0 ? y * w : 0, y > 0 ? w : 0  (w: weight around (S, 1))
     uint32_t cell[PP];            // scan << 16 | cycle << 4 | isotope
     float x[PP];
 };
 
-template <int FM, int SM>
-struct __attribute__((aligned(16))) GroupTile {
-    float ffp[FM][KMAX];          // fragment frame profiles [cycle][fragment]
-    float fsp[SM][KMAX];          // fragment scan profiles [scan][fragment]
-    double cy[2][SM];             // the quadrupole rows of the candidate's scans (lower, upper limit)
-    float qmask[SM];
-    float tsp_raw[SM], tfp_raw[FM];
-    float iso_int[4], iso_mz[4];
-    int pl_beg[GS], pl_end[GS];
-    // what the balanced passes need to know about the candidate
-    const ImEntry *entries;
-    double esc, efc, inv_f;
-    float inv_sf;
-    int n_fe, off, F, SF, S;
-    const ImEntry *pent;
-    int n_pe, poff;
-    unsigned long long scans, scans_done;
-};
-
-template <int FM, int SM>
+template <int FM, int SM, int NO>
 struct __attribute__((aligned(16))) WaveTile {
-    static_assert(SM <= 64 && FM <= 256, "scan bit masks are 64 bits wide, a pool entry names its cycle by a byte");
-    GroupTile<FM, SM> g[NG];
+    static_assert(SM <= 64 && FM <= 256 && NO <= 2, "scan bit masks are 64 bits wide, a pool entry names its cycle by a byte and its observation by a bit");
+    GroupTile<FM, SM, NO> g[NG];
     union {
         struct {
             double w[NP];         // weight of a fragment entry around the template centre
             float x[NP], y[NP];   // its intensity and m/z
-            uint16_t scf[NP];     // scan << 8 | cycle
+            uint16_t scf[NP];     // observation << 15 | scan << 8 | cycle
         } pool;
-        PrecPool prec;
+        PrecPoolT<NO> prec;
     } u;
-    uint8_t need[NG * SM];        // (candidate, scan) pairs whose scan mask is due
-    uint8_t owner[NP];            // lane (candidate, plane) a pool slot belongs to
-    uint16_t seg_base[ADH_WAVE];  // first pool slot of a lane's plane in this pass ...
+    uint16_t need[NG * NO * SM];  // (candidate, observation, scan) triples whose scan mask is due
+    uint8_t owner[NP];            // lane (candidate, fragment) a pool slot belongs to
+    uint16_t seg_base[ADH_WAVE];  // first pool slot of a lane's planes in this pass ...
     int seg_src[ADH_WAVE];        // ... and the entry it holds
 };
 
 // what a group's lanes hold when the tile phase is over (beside the LDS arrays of GroupTile)
 struct TileOut {
     bool alive;
-    int K0, F, S, I;
-    double ohe, omz;      // lane k < K0: weighted centre means of plane k
-    double hp, omzp;      // lane i < I: ... of isotope plane i
-    float spi;            // lane i < I: isotope intensity sum
-    float tsum;           // template sum
+    int K0, F, S, I, O;
+    double ohe[2], omz[2];  // lane k < K0: weighted centre means of planes (k, o)
+    double hp, omzp;        // lane i < I: ... of isotope plane i
+    float spi;              // lane i < I: isotope intensity sum
+    float tsum[2];          // template sums
 };
 
-// The tile phase of four candidates (group g of the wavefront = candidate first + 4 * block + g of `plan`).
-template <int FM, int SM>
-__device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTims &run, const CandRecIM *__restrict__ plan,
+// The tile phase of four candidates (group g of the wavefront = candidate order[4 * block + g] of `plan`).
+template <int FM, int SM, int NO>
+__device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const DevTims &run, const CandRecIM *__restrict__ plan,
                                                int32_t n_cand, int32_t block, const float *__restrict__ iso_table,
                                                int32_t n_iso_cols, const adh_scoring_config_t &cfg,
                                                const unsigned char *__restrict__ scratch, const DevOut &out,
@@ -103,7 +105,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const int gbase = g * GS;
-    GroupTile<FM, SM> &Q = W.g[g];
+    GroupTile<FM, SM, NO> &Q = W.g[g];
     // (`order`: the candidates with sparse tiles, heaviest first - adh_im_order_*_kernel below; n_cand of them)
     const int oi = block * NG + g;
     bool alive = oi < n_cand;
@@ -127,6 +129,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
     const int c0 = (r.frame_start - z) / L;
     const int F = alive ? (r.frame_stop - z) / L - c0 : 1;
     const int S = alive ? r.scan_stop - r.scan_start : 1;
+    const int O = NO == 1 ? 1 : (alive ? min((int)r.n_obs, NO) : 1);
     const int I = max(min(min(n_iso_cols, (int)cfg.top_k_isotopes), 3), 1);
     const int SF = S * F;
     const ImEntry *const entries = reinterpret_cast<const ImEntry *>(block_p + adh_scratch_frag_off(r.k_cap));
@@ -134,14 +137,18 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
 
     // ---- the candidate's small tables: isotopes, the quadrupole rows of its scans (all loads in flight together)
     {
-        double2 cyv[(SM + GS - 1) / GS];
-        const int obs0 = (int)r.obs[0];
+        constexpr int NJ = (SM + GS - 1) / GS;
+        double2 cyv[NO][NJ];
 #pragma unroll
-        for (int j = 0; j < (SM + GS - 1) / GS; ++j) {
-            const int sc = sub + j * GS;
-            cyv[j] = make_double2(0.0, 0.0);
-            if (alive && sc < S)
-                cyv[j] = *reinterpret_cast<const double2 *>(run.cycle + 2 * ((int64_t)obs0 * run.scan_max + (r.scan_start + sc)));
+        for (int o = 0; o < NO; ++o) {
+            const int obs_o = (int)r.obs[o < O ? o : 0];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int sc = sub + j * GS;
+                cyv[o][j] = make_double2(0.0, 0.0);
+                if (alive && sc < S)
+                    cyv[o][j] = *reinterpret_cast<const double2 *>(run.cycle + 2 * ((int64_t)obs_o * run.scan_max + (r.scan_start + sc)));
+            }
         }
         if (sub < I) {
             Q.iso_int[sub] = alive ? iso_table[(int64_t)r.row * n_iso_cols + sub] : 0.0f;
@@ -149,77 +156,92 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             Q.iso_mz[sub] = (float)off + r.precursor_mz;
         }
 #pragma unroll
-        for (int j = 0; j < (SM + GS - 1) / GS; ++j) {
-            const int sc = sub + j * GS;
-            if (sc < SM) {
-                Q.cy[0][sc] = cyv[j].x;
-                Q.cy[1][sc] = cyv[j].y;
-                Q.tsp_raw[sc] = 0.0f;
-                Q.qmask[sc] = 0.0f;
+        for (int o = 0; o < NO; ++o) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int sc = sub + j * GS;
+                if (sc < SM) {
+                    Q.cy[o][0][sc] = cyv[o][j].x;
+                    Q.cy[o][1][sc] = cyv[o][j].y;
+                    Q.tsp_raw[o][sc] = 0.0f;
+                    Q.qmask[o][sc] = 0.0f;
+                }
             }
+            for (int f = sub; f < FM; f += GS) Q.tfp_raw[o][f] = 0.0f;
         }
-        for (int f = sub; f < FM; f += GS) Q.tfp_raw[f] = 0.0f;
-        Q.pl_beg[sub] = 0x7FFFFFFF;
-        Q.pl_end[sub] = 0;
+        for (int c = sub; c < NO * GS; c += GS) {
+            Q.pl_beg[c] = 0x7FFFFFFF;
+            Q.pl_end[c] = 0;
+        }
         if (sub == 0) {
             Q.entries = entries;
-            Q.pent = entries + n_fe;
-            Q.n_pe = n_pe;
             Q.n_fe = n_fe;
             Q.F = F;
             Q.SF = SF;
             Q.S = S;
+            Q.O = O;
             Q.inv_f = 1.0 / (double)F;
             Q.inv_sf = 1.0f / (float)SF;
-            Q.scans = 0ull;
-            Q.scans_done = 0ull;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                Q.scans[o] = 0ull;
+                Q.scans_done[o] = 0ull;
+                Q.esc[o] = 0.0;
+                Q.efc[o] = 0.0;
+            }
         }
     }
     adh_wave_sync();
     TileOut res;
     res.alive = false;
     if (stop == 1) return res;
-    // transfer function of (isotope i, scan sc) (quadrupole.py:261-301)
-    auto qtf_at = [&](const GroupTile<FM, SM> &T, int i, int sc) -> double {
+    // transfer function of (isotope i, observation o, scan sc) (quadrupole.py:261-301)
+    auto qtf_at = [&](const GroupTile<FM, SM, NO> &T, int i, int o, int sc) -> double {
         const double x = (double)T.iso_mz[i];
-        return featim::logistic(x, T.cy[0][sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, T.cy[1][sc] + qp.delta_hi, qp.sigma_hi);
+        return featim::logistic(x, T.cy[o][0][sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, T.cy[o][1][sc] + qp.delta_hi, qp.sigma_hi);
     };
 
     // ---- the precursor entries: non-zero (scan, cycle, isotope) cells in that order.
     //   lanes 0 .. 5I-1 (role = lane / I: 0 intensity sum per scan and over the scans; 1, 2 weighted intensity mean;
     //   3, 4 weighted m/z mean around (scan, frame) = (S, 1), precursor_features.py:52-66): sequential sums, one each
-    //   lane 15: the template cell (quadrupole.py:304-324) of consecutive entries of one (scan, cycle), folded when the
-    //   cell is complete - scan profile (np.sum over the cycle axis), frame profile (over the scan axis), centre of
-    //   mass over the cells v > 0 (fragment_features.py:20-68)
+    //   lane 15: the template cell (quadrupole.py:304-324) of consecutive entries of one (scan, cycle), per
+    //   observation, folded when the cell is complete - scan profile (np.sum over the cycle axis), frame profile
+    //   (over the scan axis), centre of mass over the cells v > 0 (fragment_features.py:20-68)
     const int role = sub / I, iso = sub - role * I;
     double acc = 0.0;
     float part = 0.0f, tot = 0.0f;
     int cur_sc = -1;
     // (lane 15)
-    double t_a = 0.0, t_isum = 0.0, t_ssum = 0.0, t_fsum = 0.0;
-    float t_srow = 0.0f, t_tsum = 0.0f;
+    double t_a[NO], t_isum[NO], t_ssum[NO], t_fsum[NO];
+    float t_srow[NO], t_tsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) t_a[o] = t_isum[o] = t_ssum[o] = t_fsum[o] = 0.0, t_srow[o] = t_tsum[o] = 0.0f;
     int t_cell = -1, t_row = -1;
-    auto template_cell_done = [&]() {  // the finished cell t_cell (scan << 12 | cycle) with value (float)t_a
+    auto template_cell_done = [&]() {  // the finished cell t_cell (scan << 12 | cycle) with the values (float)t_a[o]
         const int sc = t_cell >> 12, f = t_cell & 0xFFF;
-        const float v = (float)t_a;
-        if (sc != t_row) {
-            if (t_row >= 0) {
-                Q.tsp_raw[t_row] = t_srow;
-                t_tsum += t_srow;  // (the sum of the scan profile in scan order: untouched scans add +0)
+        const bool new_row = sc != t_row;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float v = (float)t_a[o];
+            if (new_row) {
+                if (t_row >= 0) {
+                    Q.tsp_raw[o][t_row] = t_srow[o];
+                    t_tsum[o] += t_srow[o];  // (the sum of the scan profile in scan order: untouched scans add +0)
+                }
+                t_srow[o] = 0.0f;
             }
-            t_srow = 0.0f;
-            t_row = sc;
+            t_srow[o] += v;
+            Q.tfp_raw[o][f] = Q.tfp_raw[o][f] + v;
+            if (v > 0.0f) {
+                t_isum[o] += (double)v;
+                t_ssum[o] += (double)sc * (double)v;
+                t_fsum[o] += (double)f * (double)v;
+            }
         }
-        t_srow += v;
-        Q.tfp_raw[f] = Q.tfp_raw[f] + v;
-        if (v > 0.0f) {
-            t_isum += (double)v;
-            t_ssum += (double)sc * (double)v;
-            t_fsum += (double)f * (double)v;
-        }
+        t_row = sc;
     };
     {
-        PrecPool &P = W.u.prec;
+        PrecPoolT<NO> &P = W.u.prec;
         // passes over the four candidates SIDE BY SIDE: every candidate that has entries left puts its next
         // PP / (candidates still busy) of them into the pool - slots [q * share, q * share + take_q) - so that the
         // serial folds of the four run at once
@@ -253,7 +275,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
                     seen += on;
                     if (on && seen == s_ / share) q = c;
                 }
-                const GroupTile<FM, SM> &T = W.g[q];
+                const GroupTile<FM, SM, NO> &T = W.g[q];
                 const int e = s_ - T.poff;
                 if (e >= T.n_pe) continue;
                 const ImEntry en = T.pent[e];
@@ -262,7 +284,8 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
                 const double ds = (double)(sc - T.S), df = (double)(f - 1);
                 const double w = exp(-0.1 * sqrt(ds * ds + df * df));
                 const float t = en.x * T.iso_int[i];
-                P.t[s_] = (double)t * qtf_at(T, i, sc);
+#pragma unroll
+                for (int o = 0; o < NO; ++o) P.t[o][s_] = o < T.O ? (double)t * qtf_at(T, i, o, sc) : 0.0;
                 P.r[0][s_] = en.x > 0.0f ? (double)en.x * w : 0.0;
                 P.r[1][s_] = en.x > 0.0f ? w : 0.0;
                 P.r[2][s_] = en.y > 0.0f ? (double)en.y * w : 0.0;
@@ -303,12 +326,13 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             } else if (sub == GS - 1) {
                 for (int u0 = lo; __any(u0 < hi); u0 += 4) {
                     uint32_t cp[4];
-                    double tt[4];
+                    double tt[NO][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int u = min(max(min(u0 + j, hi - 1), 0), PP - 1);
                         cp[j] = P.cell[u];
-                        tt[j] = P.t[u];
+#pragma unroll
+                        for (int o = 0; o < NO; ++o) tt[o][j] = P.t[o][u];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -317,9 +341,11 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
                             if (cs != t_cell) {
                                 if (t_cell >= 0) template_cell_done();
                                 t_cell = cs;
-                                t_a = 0.0;
+#pragma unroll
+                                for (int o = 0; o < NO; ++o) t_a[o] = 0.0;
                             }
-                            t_a += tt[j];
+#pragma unroll
+                            for (int o = 0; o < NO; ++o) t_a[o] += tt[o][j];
                         }
                     }
                 }
@@ -327,18 +353,25 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             adh_wave_sync();
         }
     }
-    float tsum = 0.0f;
+    float tsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) tsum[o] = 0.0f;
     if (sub == GS - 1) {
         if (t_cell >= 0) template_cell_done();
-        if (t_row >= 0) {
-            Q.tsp_raw[t_row] = t_srow;
-            t_tsum += t_srow;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (t_row >= 0) {
+                Q.tsp_raw[o][t_row] = t_srow[o];
+                t_tsum[o] += t_srow[o];
+            }
+            Q.esc[o] = (t_isum[o] > 0) ? t_ssum[o] / t_isum[o] : 0.0;  // template centre of mass
+            Q.efc[o] = (t_isum[o] > 0) ? t_fsum[o] / t_isum[o] : 0.0;
+            tsum[o] = t_tsum[o];
         }
-        Q.esc = (t_isum > 0) ? t_ssum / t_isum : 0.0;  // template centre of mass
-        Q.efc = (t_isum > 0) ? t_fsum / t_isum : 0.0;
-        tsum = t_tsum;
     }
-    tsum = __shfl(tsum, gbase + GS - 1);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) res.tsum[o] = __shfl(tsum[o], gbase + GS - 1);
+    if (NO == 1) res.tsum[1] = 0.0f;
     // isotope lane i < I: the sums of roles 1 .. 4 of its isotope
     const int il = sub < I ? sub : 0;
     const double vh = __shfl(acc, gbase + I + il), wh = __shfl(acc, gbase + 2 * I + il);
@@ -346,7 +379,6 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
     res.spi = tot + part;
     res.hp = (wh > 0) ? vh / wh : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "w sum > 0"
     res.omzp = (wmz > 0) ? vmz / wmz : 0.0;
-    res.tsum = tsum;
     if (stop == 2 || stop == 6) return res;
     // where the candidates' fragment entries start in the wavefront's list
     if (lane == 0) {
@@ -357,69 +389,99 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             o += W.g[q].n_fe;
         }
     }
-    for (int c = sub; c < FM * KMAX; c += GS) (&Q.ffp[0][0])[c] = 0.0f;
-    for (int c = sub; c < SM * KMAX; c += GS) (&Q.fsp[0][0])[c] = 0.0f;
+    for (int c = sub; c < NO * FM * KMAX; c += GS) (&Q.ffp[0][0][0])[c] = 0.0f;
+    for (int c = sub; c < NO * SM * KMAX; c += GS) (&Q.fsp[0][0][0])[c] = 0.0f;
     adh_wave_sync();
 
-    // ---- the fragment entries.  First every entry's plane, balanced over the wavefront's list: a plane is a range.
-    // When the four candidates' entries fit the pool together (nearly always) this pass is also pass (a) below: the
-    // list's order IS the pool's order then, and an entry is fetched once.
+    // ---- the fragment entries.  First every entry's plane (fragment * O + observation), balanced over the
+    // wavefront's list: a plane is a range.  When the four candidates' entries fit the pool together (nearly always)
+    // this pass is also pass (a) below: the list's order IS the pool's order then, and an entry is fetched once.
     const int total = W.g[NG - 1].off + W.g[NG - 1].n_fe;
     const bool single = total <= NP;
     const int off1 = W.g[1].off, off2 = W.g[2].off, off3 = W.g[3].off;
+    // plane of a cell (float estimate of cell / SF, one fix-up either way)
+    auto plane_of = [](uint32_t c, int tSF, float isf) -> int {
+        int k = (int)((float)c * isf);
+        const int rem = (int)c - k * tSF;
+        k += rem >= tSF ? 1 : (rem < 0 ? -1 : 0);
+        return k;
+    };
+    // pool slot `at` <- entry `en` of plane `pc` of candidate T
+    auto to_pool = [&](GroupTile<FM, SM, NO> &T, const ImEntry &en, int pc, int at) {
+        const int tF = T.F;
+        const int o = NO == 1 ? 0 : pc - (pc / T.O) * T.O;
+        const int rem_c = (int)en.cell - pc * T.SF;
+        int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
+        if (rem_c - sc * tF >= tF) ++sc;
+        const int f = rem_c - sc * tF;
+        const double ds = (double)sc - T.esc[o], df = (double)f - T.efc[o];
+        W.u.pool.w[at] = exp(-0.1 * sqrt(ds * ds + df * df));
+        W.u.pool.x[at] = en.x;
+        W.u.pool.y[at] = en.y;
+        W.u.pool.scf[at] = (uint16_t)(o << 15 | sc << 8 | f);
+        atomicOr(&T.scans[o], 1ull << sc);
+    };
     for (int j = lane; j < total; j += ADH_WAVE) {
         const int q = (j >= off1) + (j >= off2) + (j >= off3);
-        GroupTile<FM, SM> &T = W.g[q];
+        GroupTile<FM, SM, NO> &T = W.g[q];
         const int e = j - T.off;
         const ImEntry *E = T.entries;
         ImEntry en;
         en.cell = E[e].cell, en.x = 0.0f, en.y = 0.0f;
         if (single) en = E[e];
-        const uint32_t cell = en.cell, pcell = e > 0 ? E[e - 1].cell : 0u;
-        const int tSF = T.SF;
-        const float isf = T.inv_sf;
-        auto plane_of = [&](uint32_t c) -> int {
-            int k = (int)((float)c * isf);
-            const int rem = (int)c - k * tSF;
-            k += rem >= tSF ? 1 : (rem < 0 ? -1 : 0);
-            return k;
-        };
-        const int pc = plane_of(cell), pp = e > 0 ? plane_of(pcell) : -1;
+        const uint32_t pcell = e > 0 ? E[e - 1].cell : 0u;
+        const int pc = plane_of(en.cell, T.SF, T.inv_sf), pp = e > 0 ? plane_of(pcell, T.SF, T.inv_sf) : -1;
         if (pc != pp) {
             T.pl_beg[pc] = e;
             if (pp >= 0) T.pl_end[pp] = e;
         }
         if (e == T.n_fe - 1) T.pl_end[pc] = T.n_fe;
         if (single) {
-            const int tF = T.F;
-            const int rem_c = (int)cell - pc * tSF;
-            int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
-            if (rem_c - sc * tF >= tF) ++sc;
-            const int f = rem_c - sc * tF;
-            const double ds = (double)sc - T.esc, df = (double)f - T.efc;
-            W.u.pool.w[j] = exp(-0.1 * sqrt(ds * ds + df * df));
-            W.u.pool.x[j] = en.x;
-            W.u.pool.y[j] = en.y;
-            W.u.pool.scf[j] = (uint16_t)(sc << 8 | f);
-            W.owner[j] = (uint8_t)(q * GS + pc);
-            atomicOr(&T.scans, 1ull << sc);
+            to_pool(T, en, pc, j);
+            W.owner[j] = (uint8_t)(q * GS + (NO == 1 ? pc : pc / T.O));
         }
     }
     adh_wave_sync();
-    // Then passes over the planes SIDE BY SIDE: every plane that has entries left puts its next R of them into the pool
-    // (R = pool size / planes still busy), so the serial folds below advance all planes of all four candidates at once
-    // - a contiguous piece of the list would hold three planes of one signal-rich candidate and the other lanes
+    // Then passes over the fragments SIDE BY SIDE: every fragment lane that has entries left puts its next R of them into
+    // the pool (R = pool size / lanes still busy), so the serial folds below advance all planes of all four candidates
+    // at once - a contiguous piece of the list would hold three planes of one signal-rich candidate and the other lanes
     // would wait - and a pass is: (a) balanced over the pool's slots: decode, weight around the template centre,
     // scans that occur; (b) balanced: the scan mask of the transfer function (candidate.py:287-290) for the scans
-    // that are new, applied to the intensities; (c) serial per plane, adds only.
+    // that are new, applied to the intensities; (c) serial per fragment lane (its O planes are neighbours), adds only.
     const bool fl = alive && sub < K0;
-    const int psf = sub * SF;
     double vi = 0.0, wi = 0.0, vm = 0.0, wm = 0.0;
     float fs = 0.0f;
     int cur = -1;      // scan of the running scan sum
-    int at = fl ? Q.pl_beg[sub] : 0x7FFFFFFF;      // next entry of the lane's plane
-    const int at_end = (fl && at != 0x7FFFFFFF) ? Q.pl_end[sub] : 0;
-    if (at == 0x7FFFFFFF) at = 0;
+    int cur_o = 0;     // observation of the plane the lane is in
+#pragma unroll
+    for (int o = 0; o < 2; ++o) res.ohe[o] = res.omz[o] = 0.0;
+    int at = 0x7FFFFFFF, at_end = 0;  // entries of the lane's planes
+    if (fl) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (o < O) {
+                at = min(at, Q.pl_beg[sub * O + o]);
+                at_end = max(at_end, Q.pl_end[sub * O + o]);
+            }
+        }
+    }
+    if (at == 0x7FFFFFFF) at = 0, at_end = 0;
+    auto plane_done = [&]() {  // the lane leaves plane (sub, cur_o)
+        if (cur >= 0) Q.fsp[cur_o][cur][sub] = fs;
+        if (NO == 1) {
+            res.ohe[0] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
+            res.omz[0] = (wm > 0) ? vm / wm : 0.0;
+        } else {
+            const double a = (wi > 0) ? vi / wi : 0.0, b = (wm > 0) ? vm / wm : 0.0;
+            res.ohe[0] = cur_o == 0 ? a : res.ohe[0];
+            res.ohe[1] = cur_o == 1 ? a : res.ohe[1];
+            res.omz[0] = cur_o == 0 ? b : res.omz[0];
+            res.omz[1] = cur_o == 1 ? b : res.omz[1];
+        }
+        vi = wi = vm = wm = 0.0;
+        fs = 0.0f;
+        cur = -1;
+    };
     for (;;) {
         const int rem = max(at_end - at, 0);
         const int n_busy = __popcll(__ballot(rem > 0));
@@ -428,7 +490,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
         if (!single) {
             const int R = min(NP / n_busy, 64);
             take = min(rem, R);
-            int incl = take;  // slots [base, base + take) of the pool are this plane's
+            int incl = take;  // slots [base, base + take) of the pool are this lane's
 #pragma unroll
             for (int o = 1; o < ADH_WAVE; o <<= 1) {
                 const int u = __shfl_up(incl, o);
@@ -443,21 +505,10 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
             // (a)
             for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {
                 const int o = (int)W.owner[s_];
-                const int q = o / GS, k = o % GS;
-                GroupTile<FM, SM> &T = W.g[q];
+                GroupTile<FM, SM, NO> &T = W.g[o / GS];
                 const int e = W.seg_src[o] + (s_ - (int)W.seg_base[o]);
                 const ImEntry en = T.entries[e];
-                const int tF = T.F;
-                const int rem_c = (int)en.cell - k * T.SF;
-                int sc = (int)((double)rem_c * T.inv_f);  // exact quotient: float64 estimate, one fix-up
-                if (rem_c - sc * tF >= tF) ++sc;
-                const int f = rem_c - sc * tF;
-                const double ds = (double)sc - T.esc, df = (double)f - T.efc;
-                W.u.pool.w[s_] = exp(-0.1 * sqrt(ds * ds + df * df));
-                W.u.pool.x[s_] = en.x;
-                W.u.pool.y[s_] = en.y;
-                W.u.pool.scf[s_] = (uint16_t)(sc << 8 | f);
-                atomicOr(&T.scans, 1ull << sc);
+                to_pool(T, en, plane_of(en.cell, T.SF, T.inv_sf), s_);
             }
             adh_wave_sync();
         }
@@ -469,28 +520,33 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
         {
             int n_need = 0;
             const unsigned long long lt = (1ull << lane) - 1ull;
+            constexpr int NSLOT = NG * NO * SM;
 #pragma unroll
-            for (int k = 0; k < (NG * SM + ADH_WAVE - 1) / ADH_WAVE; ++k) {
+            for (int k = 0; k < (NSLOT + ADH_WAVE - 1) / ADH_WAVE; ++k) {
                 const int slot = k * ADH_WAVE + lane;
-                const int q = min(slot / SM, NG - 1), sc = slot - q * SM;
-                const bool due = slot < NG * SM && (((W.g[q].scans & ~W.g[q].scans_done) >> sc) & 1ull);
+                const int qo = min(slot / SM, NG * NO - 1), sc = slot - qo * SM;
+                const int q = qo / NO, o = qo - q * NO;
+                const bool due = slot < NSLOT && (((W.g[q].scans[o] & ~W.g[q].scans_done[o]) >> sc) & 1ull);
                 const unsigned long long m = __ballot(due);
-                if (due) W.need[n_need + __popcll(m & lt)] = (uint8_t)slot;
+                if (due) W.need[n_need + __popcll(m & lt)] = (uint16_t)slot;
                 n_need += __popcll(m);
             }
             adh_wave_sync();
             for (int t = lane; t < n_need; t += ADH_WAVE) {
                 const int slot = (int)W.need[t];
-                const int q = slot / SM, sc = slot - q * SM;
-                GroupTile<FM, SM> &T = W.g[q];
+                const int qo = slot / SM, sc = slot - qo * SM;
+                const int q = qo / NO, o = qo - q * NO;
+                GroupTile<FM, SM, NO> &T = W.g[q];
                 double sum = 0;
-                for (int i = 0; i < I; ++i) sum += qtf_at(T, i, sc);
-                T.qmask[sc] = (float)(sum / (double)I);
+                for (int i = 0; i < I; ++i) sum += qtf_at(T, i, o, sc);
+                T.qmask[o][sc] = (float)(sum / (double)I);
             }
             adh_wave_sync();
-            if (sub == 0) Q.scans_done = Q.scans;
-            for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE)  // candidate.py:290
-                W.u.pool.x[s_] = W.u.pool.x[s_] * W.g[(int)W.owner[s_] / GS].qmask[(int)W.u.pool.scf[s_] >> 8];
+            if (sub < NO) Q.scans_done[sub] = Q.scans[sub];
+            for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {  // candidate.py:290
+                const int scf = (int)W.u.pool.scf[s_];
+                W.u.pool.x[s_] = W.u.pool.x[s_] * W.g[(int)W.owner[s_] / GS].qmask[scf >> 15][(scf >> 8) & 0x7F];
+            }
             adh_wave_sync();
         }
         if (stop == 4) {
@@ -517,14 +573,18 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
                 if (e + j < take) {
                     const double w = w4[j];
                     const float v = v4[j], y = y4[j];
-                    const int sc = s4[j] >> 8, f = s4[j] & 0xFF;
+                    const int o = NO == 1 ? 0 : s4[j] >> 15, sc = (s4[j] >> 8) & 0x7F, f = s4[j] & 0xFF;
+                    if (NO > 1 && o != cur_o) {  // (the lane's planes follow each other: observation 0, then 1)
+                        plane_done();
+                        cur_o = o;
+                    }
                     if (sc != cur) {  // the cells of a scan are consecutive: its sum is complete
-                        if (cur >= 0) Q.fsp[cur][sub] = fs;
+                        if (cur >= 0) Q.fsp[cur_o][cur][sub] = fs;
                         fs = 0.0f;
                         cur = sc;
                     }
                     fs += v;
-                    (void)__hip_atomic_fetch_add(&Q.ffp[f][sub], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    (void)__hip_atomic_fetch_add(&Q.ffp[cur_o][f][sub], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const double tm = (double)y * w;  // (w > 0: the product is > 0 exactly when the m/z channel is)
                     vi += v > 0.0f ? (double)v * w : 0.0;  // (adding 0.0 leaves a sum as it is)
                     wi += v > 0.0f ? w : 0.0;
@@ -536,18 +596,14 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM> &W, const DevTim
         at += take;
         adh_wave_sync();
     }
-    (void)psf;
-    if (fl) {
-        if (cur >= 0) Q.fsp[cur][sub] = fs;
-    }
-    res.ohe = (fl && wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
-    res.omz = (fl && wm > 0) ? vm / wm : 0.0;
+    if (fl) plane_done();
     adh_wave_sync();
     res.alive = alive && !(stop >= 3 && stop <= 5);
     res.K0 = K0;
     res.F = F;
     res.S = S;
     res.I = I;
+    res.O = O;
     return res;
 }
 
@@ -624,55 +680,64 @@ __global__ __launch_bounds__(256) void adh_im_order_scatter_kernel(const CandRec
 // with materialised tiles through the one-candidate body (adh_feature_im_body<LAY, true>, adh_features_im.hip) - they
 // are the longest walks of a launch (a dense tile is 1 152 cells per plane) and start first, beside the others,
 // instead of in a launch of their own behind this one; the LDS of a block is the larger of the two layouts.
-template <int FM, int SM, class LAY>
+template <int FM, int SM, int NO, class LAY>
 __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
     DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
     int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch, DevOut out,
     unsigned char *__restrict__ prof, const uint32_t *__restrict__ side, Caps caps, int32_t list_blocks, int32_t stop) {
     using namespace featim4;
-    typedef ImProfRec<FM, SM, 1> Rec;
+    typedef ImProfRec<FM, SM, NO> Rec;
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int32_t)blockIdx.x < list_blocks) {
         if (stop) return;  // (developer ablation: the four-candidate path alone)
+#ifndef ADH_IM4_STANDALONE
         const uint32_t n = side[0];
         const uint32_t *list = side + SIDE_HEAD + n_cand;
         for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {
             adh_feature_im_body<LAY, true>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
             __syncthreads();  // (the next candidate reuses the LDS arrays)
         }
+#endif
         return;
     }
-    WaveTile<FM, SM> &W = *reinterpret_cast<WaveTile<FM, SM> *>(smem);
+    WaveTile<FM, SM, NO> &W = *reinterpret_cast<WaveTile<FM, SM, NO> *>(smem);
     const int32_t block = (int32_t)blockIdx.x - list_blocks;
     const int32_t n_order = (int32_t)side[1];
     if (block * NG >= n_order) return;
     int ci = 0;
-    const TileOut t = tile4_phase<FM, SM>(W, run, plan, n_order, block, iso_table, n_iso_cols, cfg, scratch, out,
-                                          side + SIDE_HEAD, ci, stop);
-    // ---- hand-over: the record adh_feature_im_profiles_kernel reads (frame axis centred: entry r <-> cycle r + shift)
+    const TileOut t = tile4_phase<FM, SM, NO>(W, run, plan, n_order, block, iso_table, n_iso_cols, cfg, scratch, out,
+                                              side + SIDE_HEAD, ci, stop);
+    // ---- hand-over: the record adh_feature_im_profiles_kernel reads (frame axis centred: entry r <-> cycle r + shift);
+    // observations beyond the candidate's own (a launch of up to two) are zero rows
     if (!t.alive) return;
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
-    const GroupTile<FM, SM> &Q = W.g[g];
-    const int K0 = t.K0, F = t.F, S = t.S, I = t.I;
+    const GroupTile<FM, SM, NO> &Q = W.g[g];
+    const int K0 = t.K0, F = t.F, S = t.S, I = t.I, O = t.O;
     Rec &rec = reinterpret_cast<Rec *>(prof)[ci];
     const int shift = F / 2 - FM / 2;
-    for (int rr = sub; rr < FM; rr += GS) {
-        const int f = rr + shift;
-        rec.tfp_raw[0][rr] = (f >= 0 && f < F) ? Q.tfp_raw[f] : 0.0f;
+    for (int c = sub; c < NO * FM; c += GS) {
+        const int o = c / FM, rr = c - o * FM, f = rr + shift;
+        rec.tfp_raw[o][rr] = (o < O && f >= 0 && f < F) ? Q.tfp_raw[o][f] : 0.0f;
     }
-    for (int sc = sub; sc < SM; sc += GS) rec.tsp_raw[0][sc] = sc < S ? Q.tsp_raw[sc] : 0.0f;
-    for (int c = sub; c < K0 * FM; c += GS) {
-        const int k = c / FM, rr = c - k * FM, f = rr + shift;
-        rec.ffp[k][0][rr] = (f >= 0 && f < F) ? Q.ffp[f][k] : 0.0f;
+    for (int c = sub; c < NO * SM; c += GS) {
+        const int o = c / SM, sc = c - o * SM;
+        rec.tsp_raw[o][sc] = (o < O && sc < S) ? Q.tsp_raw[o][sc] : 0.0f;
     }
-    for (int c = sub; c < K0 * SM; c += GS) {
-        const int k = c / SM, sc = c - k * SM;
-        rec.fsp[k][0][sc] = sc < S ? Q.fsp[sc][k] : 0.0f;
+    for (int c = sub; c < K0 * NO * FM; c += GS) {
+        const int k = c / (NO * FM), rem = c - k * NO * FM, o = rem / FM, rr = rem - o * FM, f = rr + shift;
+        rec.ffp[k][o][rr] = (o < O && f >= 0 && f < F) ? Q.ffp[o][f][k] : 0.0f;
+    }
+    for (int c = sub; c < K0 * NO * SM; c += GS) {
+        const int k = c / (NO * SM), rem = c - k * NO * SM, o = rem / SM, sc = rem - o * SM;
+        rec.fsp[k][o][sc] = (o < O && sc < S) ? Q.fsp[o][sc][k] : 0.0f;
     }
     if (sub < K0) {
-        rec.ohe[sub][0] = t.ohe;
-        rec.omz[sub][0] = t.omz;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            rec.ohe[sub][o] = o < O ? t.ohe[o] : 0.0;
+            rec.omz[sub][o] = o < O ? t.omz[o] : 0.0;
+        }
     }
     if (sub < 4) {
         const bool on = sub < I;
@@ -682,8 +747,6 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
         rec.iso_int[sub] = on ? Q.iso_int[sub] : 0.0f;
         rec.iso_mz[sub] = on ? Q.iso_mz[sub] : 0.0f;
     }
-    if (sub == 0) {
-        rec.tsum[0] = t.tsum;
-        rec.K0 = (uint32_t)K0;
-    }
+    if (sub < NO) rec.tsum[sub] = sub < O ? (sub == 0 ? t.tsum[0] : t.tsum[1]) : 0.0f;
+    if (sub == 0) rec.K0 = (uint32_t)K0;
 }

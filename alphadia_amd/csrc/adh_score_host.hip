@@ -539,7 +539,9 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     const int32_t stop4 = getenv("ADH_DEBUG_IM4") ? atoi(getenv("ADH_DEBUG_IM4")) : 0;  // developer ablation (tile4_phase)
     const uint64_t list_common_off = (prof_end + 255) / 256 * 256;
     const uint64_t list_small_off = list_common_off + (tile4 && split_common ? featim4::side_bytes(p.n_class[0]) : 0);
-    const uint64_t prof_bytes = list_small_off + (tile4 && split_small ? featim4::side_bytes(p.n_class[ADH_CLASS_IM_SMALL]) : 0);
+    const uint64_t list_two_off = list_small_off + (tile4 && split_small ? featim4::side_bytes(p.n_class[ADH_CLASS_IM_SMALL]) : 0);
+    const bool tile4_two = tile4 && !getenv("ADH_DEBUG_IM_TILE1_TWO");  // (A/B: the two-observation class through the one-candidate kernel)
+    const uint64_t prof_bytes = list_two_off + (tile4_two && split_two ? featim4::side_bytes(p.n_class[1]) : 0);
     int rc = ensure_scratch(h, prof_bytes);
     if (rc != ADH_OK) return rc;
     unsigned char *d_scratch = static_cast<unsigned char *>(h->scratch_slab);
@@ -577,8 +579,8 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                            d_scratch, side);
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
-                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc>), featim::LayoutSmall(cc).bytes() + f_pad);
-                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, featim::LayoutSmall>),
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>), featim::LayoutSmall(cc).bytes() + f_pad);
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1, featim::LayoutSmall>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
                                            (int32_t)list_blocks, stop4);
@@ -591,6 +593,21 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                        prof, *out);
                 } else if (c == 1 && split_two) {
                     unsigned char *prof = d_scratch + prof_two_off;
+                    if (tile4_two) {
+                        uint32_t *side = reinterpret_cast<uint32_t *>(d_scratch + list_two_off);
+                        const unsigned ob = (unsigned)((cnt + 255) / 256);
+                        HIP_TRY(hipMemsetAsync(side, 0, featim4::SIDE_HEAD * 4, st));
+                        hipLaunchKernelGGL(adh_im_order_hist_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
+                                           d_scratch, side);
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2>),
+                                                       featim::LayoutCommon2(cc).bytes() + f_pad);
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2, featim::LayoutCommon2>),
+                                           dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
+                                           (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
+                                           (int32_t)list_blocks, stop4);
+                    } else
                     hipLaunchKernelGGL((adh_feature_im_kernel<featim::LayoutCommon2, true>), dim3((unsigned)cnt), dim3(ADH_WAVE),
                                        featim::LayoutCommon2(cc).bytes() + f_pad, st, h->tims, p.d_recs_im + first, h->cs.iso, n_iso,
                                        *cfg, d_scratch, *out, cc, prof);
@@ -607,8 +624,8 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                            d_scratch, side);
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
-                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc>), featim::LayoutCommon(cc).bytes() + f_pad);
-                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, featim::LayoutCommon>),
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>), featim::LayoutCommon(cc).bytes() + f_pad);
+                        hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1, featim::LayoutCommon>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
                                            (int32_t)list_blocks, stop4);
@@ -1340,10 +1357,9 @@ void expand_host_rows(adh_output_t *out, uint16_t *slot_host, const unsigned cha
     }
 }
 
-int host_threads_for(int64_t n) {
-    // the team that rebuilds the id / library columns behind the copy-out: at most 16 threads, and of the cores this
-    // process may use (host_cpu_budget: quota, affinity, hardware) only this rank's share - LOCAL_WORLD_SIZE ranks run
-    // side by side under ONE quota
+// this rank's share of the host: at most 16 threads, and of the cores this process may use (host_cpu_budget: quota,
+// affinity, hardware) only the LOCAL_WORLD_SIZE-th part - the ranks of a node run side by side under ONE quota
+int host_thread_share() {
     int t = 16;
     if (const char *env = getenv("ADH_HOST_THREADS")) t = atoi(env);
     else {
@@ -1351,8 +1367,25 @@ int host_threads_for(int64_t n) {
         if (const char *lw = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(atoi(lw), 1);
         t = std::min<int>(t, std::max<int>(host_cpu_budget() / ranks, 1));
     }
-    t = (int)std::min<int64_t>(t, n / 16384);  // (a thread per 16 k rows at least: starting one costs ~20 us)
     return std::max(t, 1);
+}
+
+int host_threads_for(int64_t n) {
+    // the team that rebuilds the id / library columns behind the copy-out (or unpacks the compact blocks)
+    const int t = (int)std::min<int64_t>(host_thread_share(), n / 16384);  // (a thread per 16 k rows at least: starting one costs ~20 us)
+    return std::max(t, 1);
+}
+
+// Does the host rebuild the id / library columns of the padded tables (197 of 646 bytes per candidate stay off PCIe),
+// or does the device write them and the link carry everything?  A thread rebuilds ~23 000 rows per ms, the link delivers
+// 122 000 rows per ms of wire tables: below ~6 threads the team is what the call waits for (measured with 2 threads -
+// the eighth part of the pool's 16-core quota: a 375 000-row shard takes 8.9 ms against 4.6), and the 44 % more bytes
+// cost less (every GPU of a node has its own link, the ranks share the CPU quota).  ADH_REBUILD_MIN_THREADS moves the
+// threshold (0: always rebuild).
+bool host_rebuild_pays() {
+    int least = 6;
+    if (const char *env = getenv("ADH_REBUILD_MIN_THREADS")) least = atoi(env);
+    return host_thread_share() >= least;
 }
 
 }  // namespace
@@ -1467,7 +1500,7 @@ int score_pipeline(adh_handle_t *h, const adh_candidates_t *c, const adh_scoring
     // rebuildable columns: not copied back, rebuilt on the host from fragment_lib_slot (see kOutFields)
     if (cop)  // (a chunk's slot offsets are 32-bit words of the packed count)
         chunk = std::min<int64_t>(chunk, std::max<int64_t>((int64_t)(0xFFFFFFFFull / (uint64_t)top_k) - 1, 1));
-    const bool rebuild = !cop && h->h_lib.size() == (size_t)h->n_lib && !getenv("ADH_DEBUG_COPY_ALL");
+    const bool rebuild = !cop && h->h_lib.size() == (size_t)h->n_lib && !getenv("ADH_DEBUG_COPY_ALL") && host_rebuild_pays();
     uint16_t *slot_host = out->fragment_lib_slot;
     if (rebuild && !slot_host) {
         const size_t need = (size_t)n * (size_t)top_k * sizeof(uint16_t);

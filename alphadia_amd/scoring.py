@@ -956,7 +956,7 @@ def _call_compact(self, candidates_df: pd.DataFrame, soa: dict, t_0: float, t_1:
     self.last_timings = {"assemble_ms": (t_1 - t_0) * 1e3, "score_ms": (t_2 - t_1) * 1e3,
                          "collect_candidates_ms": (t_3 - t_2) * 1e3, "collect_fragments_ms": frag_box["ms"],
                          "collect_ms": (t_4 - t_2) * 1e3, "total_ms": (t_4 - t_0) * 1e3,
-                         "wire_bytes": int(comp["features"].nbytes + 9 * len(comp["row"]) + 42 * len(comp["fragment_row"]))}
+                         "wire_bytes": int(comp["features"].nbytes + 5 * len(comp["row"]) + 22 * len(comp["fragment_row"]))}
     logger.info("Finished candidate scoring")
     return features_df, frag_box["df"]
 

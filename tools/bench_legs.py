@@ -32,7 +32,7 @@ def _log(*a):
 
 
 def _leg_traffic(key: str):
-    """HBM bytes per pass of a leg from the committed PMC passes (profiles/legs_traffic.json, tools/profile_r5.sh)."""
+    """HBM bytes per pass of a leg from the committed PMC passes (profiles/legs_traffic.json, tools/profile_r6.sh)."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "legs_traffic.json")))[key]["hbm_bytes_per_pass"]
     except Exception:

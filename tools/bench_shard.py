@@ -41,11 +41,13 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
     budget = runtime.host_threads(1 << 40)[1]
     contended_threads = max(1, budget // ways)
 
-    def one_pass(host_threads: int | None):
+    def one_pass(host_threads: int | None, force_rebuild: bool = False):
         out = []
         old = os.environ.get("ADH_HOST_THREADS")
         if host_threads is not None:
             os.environ["ADH_HOST_THREADS"] = str(host_threads)
+        if force_rebuild:
+            os.environ["ADH_REBUILD_MIN_THREADS"] = "0"
         try:
             for r, (a, b) in enumerate(bounds):
                 sub = slice_soa(soa_all, a, b)
@@ -72,6 +74,7 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
                             "kernel_ms": float((g + f) * nl / reps), "launches": float(nl / reps),
                             "d2h_bytes": float(wire), "d2h_ms_at_55GBps": float(wire / 55e9 * 1e3)})
         finally:
+            os.environ.pop("ADH_REBUILD_MIN_THREADS", None)
             if host_threads is not None:
                 if old is None:
                     os.environ.pop("ADH_HOST_THREADS", None)
@@ -81,7 +84,8 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
 
     try:
         per_shard = one_pass(None)
-        contended = one_pass(contended_threads)
+        contended = one_pass(contended_threads)                       # (the library's policy: few threads -> the link carries all columns)
+        contended_rb = one_pass(contended_threads, force_rebuild=True)  # (the same team made to rebuild the columns)
     finally:
         if attached:
             ctx.comm_wait()
@@ -108,6 +112,10 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
         "host_threads_per_rank": int(contended_threads), "cpu_budget": int(budget),
         "max_shard_ms": worst_c["ms"], "median_shard_ms": float(np.median([s["ms"] for s in contended])),
         "shard_ms": [round(s["ms"], 3) for s in contended],
+        "d2h_bytes": max(s["d2h_bytes"] for s in contended),
+        "policy": "below 6 host threads per rank the device writes the id / library columns and the link carries all "
+                  "646 bytes per candidate (host_rebuild_pays, adh_score_host.hip)",
+        "max_shard_ms_if_the_team_rebuilds": max(s["ms"] for s in contended_rb),
     }
     rec["all_gather"] = {
         "bytes_contributed_per_rank": float(shard_bytes),
@@ -121,6 +129,7 @@ def shard_leg(ctx, soa_all: dict, cfgj, ms_per_step: float | None = None, ways: 
         rec["ms_per_step_1gpu"] = float(ms_per_step)
         rec["projected_scaling_8"] = float(ms_per_step / worst["ms"])
         rec["projected_scaling_8_contended"] = float(ms_per_step / worst_c["ms"])
+        rec["projected_scaling_8_contended_rebuild"] = float(ms_per_step / max(s["ms"] for s in contended_rb))
     return rec
 
 

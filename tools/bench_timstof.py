@@ -156,7 +156,7 @@ result = {
     "roofline": {
         "bound": "hbm", "achieved": touched / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
         "frac": touched / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
-        "kernel": "adh_gather_im_kernel + adh_feature_im_kernel", "kernel_ms": kernel_ms,
+        "kernel": "adh_gather_im_kernel + adh_feature_im_tile4_kernel (four candidates per wavefront, with the order kernels) + adh_feature_im_profiles_kernel", "kernel_ms": kernel_ms,
         "gather_kernel_ms": g_ms, "feature_kernel_ms": f_ms,
         # the gather kernel against the lines it makes HBM fill (PMC traffic of that kernel / its duration)
         "gather_kernel_traffic": gather_traffic,
@@ -271,7 +271,7 @@ if not os.environ.get("ADH_BENCH_NO_SELECT"):
                            "touched_bytes_per_precursor": t_sel / len(pdf),
                            "yardstick": "events inside the windows' TOF bins, the rt tolerance and the mobility tolerance x 6 B "
                                         f"+ index words + library slice + outputs; exact on a sample of {len(rows_sel)} precursors"}
-        if tfile and os.path.exists(tfile):  # (FETCH_SIZE / WRITE_SIZE passes of tools/profile_r5.sh)
+        if tfile and os.path.exists(tfile):  # (FETCH_SIZE / WRITE_SIZE passes of tools/profile_r6.sh)
             tj = json.load(open(tfile))
             if tj.get("selection_hbm_bytes_per_pass") and tj.get("candidates") == n:
                 sel["roofline"]["traffic"] = tj["selection_hbm_bytes_per_pass"]

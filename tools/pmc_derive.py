@@ -1,6 +1,6 @@
-"""Derived figures from the PMC summaries of tools/profile_r5.sh (tools/rocpd_summary.py output).
+"""Derived figures from the PMC summaries of tools/profile_r6.sh (tools/rocpd_summary.py output).
 
-    python tools/pmc_derive.py valu  <pmc.csv> <kernel_stats.csv>     -> profiles/r05_valu_busy.json
+    python tools/pmc_derive.py valu  <pmc.csv> <kernel_stats.csv>     -> profiles/r06_valu_busy.json
     python tools/pmc_derive.py mfma  <pmc.csv> <kernel_stats.csv> <out.json> <kernel substring> <flops per MOPS unit>
     python tools/pmc_derive.py legs  <out.json> key=pmc.csv:passes[:kernel substrings,...] ...
 
@@ -71,9 +71,9 @@ def valu(pmc_path, stats_path):
             "clock_ghz_implied": None if avg_ns is None else busy / avg_ns,
         }
         out[short(k)] = rec
-    res = {"kernels": out, "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": "tools/profile_r5.sh",
+    res = {"kernels": out, "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": os.environ.get("ADH_PROFILE_RECIPE", "tools/profile_r6.sh"),
            "note": __doc__.split("valu:")[1].strip()}
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r05_valu_busy.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "profiles", os.environ.get("ADH_PROFILE_ROUND", "r06") + "_valu_busy.json"), "w"), indent=1)
     for k, v in out.items():
         print(f"{k}: VALU busy per SIMD {v['valu_busy_per_simd']:.3f}, {v['resident_wavefronts_per_simd']:.2f} wavefronts per SIMD, "
               f"a wavefront issues VALU {v['wavefront_share_issuing_valu']:.3f} of its life, "
@@ -99,7 +99,7 @@ def mfma(pmc_path, stats_path, out_path, key, flops_per_unit):
             "achieved_tflops": None if not tot_ns else flops / tot_ns / 1e3,
             "share_of_f32_mfma_peak_157tf": None if not tot_ns else flops / tot_ns / 1e3 / 157.0,
         }
-    res = {"kernels": out, "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": "tools/profile_r5.sh",
+    res = {"kernels": out, "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": os.environ.get("ADH_PROFILE_RECIPE", "tools/profile_r6.sh"),
            "note": "SQ_INSTS_VALU_MFMA_MOPS_F32 counts MFMA operations in units of 512 flops (MI355X_MICROARCH.md); "
                    "achieved = flops / summed kernel time of the traced run of the same command; the f32 MFMA peak is 157 TFLOP/s"}
     json.dump(res, open(out_path, "w"), indent=1)
@@ -125,7 +125,7 @@ def legs(out_path, specs):
             per[short(k)] = per.get(short(k), 0.0) + ff + ww
         res[key] = {"hbm_bytes_per_pass": f + w, "fetch_bytes_per_pass": f, "write_bytes_per_pass": w, "passes": passes,
                     "per_kernel_bytes_per_pass": dict(sorted(per.items(), key=lambda kv: -kv[1])[:8]),
-                    "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": "tools/profile_r5.sh",
+                    "git_head": os.environ.get("GIT_HEAD", "unknown"), "recipe": os.environ.get("ADH_PROFILE_RECIPE", "tools/profile_r6.sh"),
                     "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes) of the leg's kernels / passes of the profiled command", **extra}
         print(key, f"{(f + w) / 1e9:.3f} GB per pass")
     json.dump(res, open(out_path, "w"), indent=1)

@@ -38,7 +38,7 @@ def main(path, passes, n_cand):
         "per_kernel_fetch_bytes": {k: 2.0 * v for k, v in sorted(per["FETCH_SIZE"].items())},
         "per_kernel_write_bytes": dict(sorted(per["WRITE_SIZE"].items())),
         "git_head": os.environ.get("GIT_HEAD", "unknown"),
-        "recipe": os.environ.get("ADH_PROFILE_RECIPE", "tools/profile_r5.sh"),
+        "recipe": os.environ.get("ADH_PROFILE_RECIPE", "tools/profile_r6.sh"),
         "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {os.path.basename(path)}), KB -> bytes, summed "
                 f"over all launches of the scoring kernels and divided by the {passes:g} passes over the candidate table the "
                 "profiled command made (one pass = all chunks of one adh_score_candidates call, or one resident step). "
