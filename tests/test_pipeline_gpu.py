@@ -95,6 +95,14 @@ def test_host_rebuilt_columns_equal_the_copied_ones(ctx, case, monkeypatch):
     copied = ctx.d2h_bytes(reset=True)
     monkeypatch.delenv("ADH_DEBUG_COPY_ALL")
     assert ref["valid"].sum() > n // 4 and (ref["precursor_idx"][::17] == 0).all()
+    # (round 6) a team of fewer than six threads does not rebuild: the device writes the columns, the link carries them
+    # (host_rebuild_pays; ADH_REBUILD_MIN_THREADS moves the threshold)
+    monkeypatch.setenv("ADH_HOST_THREADS", "2")
+    ctx.d2h_bytes(reset=True)
+    got = ctx.score_host(pack_assembled(soa), cfg, with_stats=True)
+    assert ctx.d2h_bytes(reset=True) == copied
+    _same(got, ref)
+    monkeypatch.setenv("ADH_REBUILD_MIN_THREADS", "0")  # from here on: the team rebuilds whatever its size
     for threads, chunk in (("1", "1500"), ("3", "1777"), ("16", str(10 * n))):
         monkeypatch.setenv("ADH_HOST_THREADS", threads)
         monkeypatch.setenv("ADH_CHUNK", chunk)
