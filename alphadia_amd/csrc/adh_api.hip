@@ -33,8 +33,8 @@
 #include "adh_fused.hip"
 #include "adh_gather_im.hip"
 #include "adh_features_im.hip"
-#include "adh_features_im2.hip"
 #include "adh_features_im4.hip"
+#include "adh_features_im2.hip"
 #include "adh_fragcomp.hip"
 #include "adh_select.hip"
 #include "adh_select_im.hip"

@@ -90,26 +90,31 @@ __device__ __forceinline__ void moments(const float (&x)[N], int n, float &mean,
 
 }  // namespace featim2
 
-template <int FM, int SM, int NO>
-__global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
-    DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, adh_scoring_config_t cfg, int32_t n_iso_cols,
-    const unsigned char *__restrict__ scratch, const unsigned char *__restrict__ prof, DevOut out) {
+// What the profile phase starts from: the hand-over record of the tile kernels (ImProfRec in HBM), or - FUSED, one
+// observation - the LDS arrays and lane results of featim4::tile4_phase of the SAME wavefront (adh_features_im4.hip).
+// FUSED: the group LDS of this phase (`lds`) lies over the tile phase's arrays, so everything the phase needs of them
+// is taken into registers before the first write.
+template <int FM, int SM, int NO, bool FUSED>
+__device__ __forceinline__ void adh_im_profiles_body(
+    featim2::GroupLds<FM, SM, NO> *const lds, const int ci, const bool in_range, const DevTims &run,
+    const CandRecIM *__restrict__ plan, const adh_scoring_config_t &cfg, int32_t n_iso_cols,
+    const unsigned char *__restrict__ scratch, const unsigned char *__restrict__ prof, const DevOut &out,
+    const featim4::GroupTile<FM, SM, 1> *const tile, const featim4::TileOut *const tout) {
     using namespace featim2;
     constexpr int RC = FM / 2;
     typedef ImProfRec<FM, SM, NO> Rec;
-    __shared__ GroupLds<FM, SM, NO> lds[ADH_WAVE / GS];
+    static_assert(!FUSED || NO == 1, "the fused path takes one observation");
     const int lane = threadIdx.x;
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
     GroupLds<FM, SM, NO> &Q = lds[g];
-    const int ci = (int)blockIdx.x * (ADH_WAVE / GS) + g;
-    bool alive = ci < n_cand;
+    bool alive = in_range;
     const CandRecIM &cand = plan[alive ? ci : 0];
     alive = alive && !(cand.flags & ADH_FLAG_SKIP);
     const unsigned char *block = scratch + cand.scratch_off;
-    const int K0 = alive ? (int)reinterpret_cast<const uint32_t *>(block)[0] : 0;
+    const int K0 = alive ? (FUSED ? tout->K0 : (int)reinterpret_cast<const uint32_t *>(block)[0]) : 0;
     alive = alive && K0 > 0;
-    const Rec &rec = reinterpret_cast<const Rec *>(prof)[alive ? ci : 0];
+    const Rec &rec = reinterpret_cast<const Rec *>(prof)[(alive && !FUSED) ? ci : 0];
     const uint32_t row = cand.row;
     const int L = run.cycle_len, z = run.zeroth;
     const int c0 = (cand.frame_start - z) / L;
@@ -124,14 +129,47 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     // ---- the small arrays into the group's LDS; a fragment lane's rows are taken from the record where needed
     const bool frag_lane0 = alive && sub < K0;
     const int slot = frag_lane0 ? sub : 0;
+    // (FUSED) everything of the tile phase's LDS arrays, into registers, before this phase writes its own
+    float P0[FUSED ? FM : 1], Sp0[FUSED ? SM : 1], tfpv[(FM + 15) / 16], tspv[(SM + 15) / 16], isov[2] = {0.0f, 0.0f};
+    if constexpr (FUSED) {
+        F2_FOR_R P0[r] = (frag_lane0 && F2_OK(r)) ? tile->ffp[0][min(max(r + shift, 0), FM - 1)][slot] : 0.0f;
+        F2_FOR_S Sp0[i] = (frag_lane0 && i < S) ? tile->fsp[0][i][slot] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
+            const int f = min(sub + 16 * pass, FM - 1) + shift;
+            tfpv[pass] = (alive && f >= 0 && f < F) ? tile->tfp_raw[0][min(max(f, 0), FM - 1)] : 0.0f;
+        }
+#pragma unroll
+        for (int pass = 0; pass < (SM + 15) / 16; ++pass) {
+            const int i = min(sub + 16 * pass, SM - 1);
+            tspv[pass] = (alive && i < S) ? tile->tsp_raw[0][i] : 0.0f;
+        }
+        if (sub < 4) {
+            isov[0] = (alive && sub < I) ? tile->iso_int[sub] : 0.0f;
+            isov[1] = (alive && sub < I) ? tile->iso_mz[sub] : 0.0f;
+        }
+        adh_wave_sync();
+        // (the frame profile is not needed before the quantification: it waits in the rows of the scan-correlation
+        // operands, idle until then - 32 registers less across the presence / envelope steps, where the kernel spilled)
+        static_assert(SM + 1 >= FM, "a frame profile fits a row of the centred scan rows");
+        F2_FOR_R Q.u.cen[sub][r] = P0[r];
+    }
     // frame profile of observation o (centred), raw scan profile of observation o
     auto load_P = [&](int o, float (&P)[FM]) {
-        F2_FOR_R P[r] = 0.0f;
-        if (frag_lane0) load_row4<FM>(P, rec.ffp[slot][o]);
+        if constexpr (FUSED) {
+            F2_FOR_R P[r] = Q.u.cen[sub][r];
+        } else {
+            F2_FOR_R P[r] = 0.0f;
+            if (frag_lane0) load_row4<FM>(P, rec.ffp[slot][o]);
+        }
     };
     auto load_Sp = [&](int o, float (&Sp)[SM]) {
-        F2_FOR_S Sp[i] = 0.0f;
-        if (frag_lane0) load_row4<SM>(Sp, rec.fsp[slot][o]);
+        if constexpr (FUSED) {
+            F2_FOR_S Sp[i] = Sp0[i];
+        } else {
+            F2_FOR_S Sp[i] = 0.0f;
+            if (frag_lane0) load_row4<SM>(Sp, rec.fsp[slot][o]);
+        }
     };
     // OR-envelope of a scan profile (scoring/utils.py:56-66): reads the raw neighbours, writes a copy
     auto scan_envelope = [&](const float (&Sp)[SM], float (&Se)[SM]) {
@@ -155,8 +193,13 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
     uint32_t lib_slot = 0;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-        ohe_l[o] = frag_lane0 ? rec.ohe[slot][o] : 0.0;
-        omz_l[o] = frag_lane0 ? rec.omz[slot][o] : 0.0;
+        if constexpr (FUSED) {
+            ohe_l[o] = frag_lane0 ? tout->ohe[o] : 0.0;
+            omz_l[o] = frag_lane0 ? tout->omz[o] : 0.0;
+        } else {
+            ohe_l[o] = frag_lane0 ? rec.ohe[slot][o] : 0.0;
+            omz_l[o] = frag_lane0 ? rec.omz[slot][o] : 0.0;
+        }
     }
     if (frag_lane0) {
         const LibRec *sel = reinterpret_cast<const LibRec *>(block + 32) + sub;
@@ -170,25 +213,34 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         const int f = rr + shift;
         const bool ok = alive && f >= 0 && f < F;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) Q.tfp_raw[o][rr] = alive ? rec.tfp_raw[o][rr] : 0.0f;
+        for (int o = 0; o < NO; ++o) Q.tfp_raw[o][rr] = FUSED ? tfpv[pass] : (alive ? rec.tfp_raw[o][rr] : 0.0f);
         Q.frt[rr] = ok ? run.rt[cand.frame_start + f * L] : 0.0;
     }
 #pragma unroll
     for (int pass = 0; pass < (SM + 15) / 16; ++pass) {
         const int i = min(sub + 16 * pass, SM - 1);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) Q.tsp_raw[o][i] = alive ? rec.tsp_raw[o][i] : 0.0f;
+        for (int o = 0; o < NO; ++o) Q.tsp_raw[o][i] = FUSED ? tspv[pass] : (alive ? rec.tsp_raw[o][i] : 0.0f);
     }
     if (sub < 4) {
-        Q.hp[sub] = alive ? rec.hp[sub] : 0.0;
-        Q.omzp[sub] = alive ? rec.omzp[sub] : 0.0;
-        Q.spi[sub] = alive ? rec.spi[sub] : 0.0f;
-        Q.iso_int[sub] = alive ? rec.iso_int[sub] : 0.0f;
-        Q.iso_mz[sub] = alive ? rec.iso_mz[sub] : 0.0f;
+        if constexpr (FUSED) {
+            const bool on = alive && sub < I;
+            Q.hp[sub] = on ? tout->hp : 0.0;
+            Q.omzp[sub] = on ? tout->omzp : 0.0;
+            Q.spi[sub] = on ? tout->spi : 0.0f;
+            Q.iso_int[sub] = isov[0];
+            Q.iso_mz[sub] = isov[1];
+        } else {
+            Q.hp[sub] = alive ? rec.hp[sub] : 0.0;
+            Q.omzp[sub] = alive ? rec.omzp[sub] : 0.0;
+            Q.spi[sub] = alive ? rec.spi[sub] : 0.0f;
+            Q.iso_int[sub] = alive ? rec.iso_int[sub] : 0.0f;
+            Q.iso_mz[sub] = alive ? rec.iso_mz[sub] : 0.0f;
+        }
     }
     float tsum[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) tsum[o] = alive ? rec.tsum[o] : 0.0f;
+    for (int o = 0; o < NO; ++o) tsum[o] = FUSED ? (alive ? tout->tsum[o] : 0.0f) : (alive ? rec.tsum[o] : 0.0f);
     // location_features.py:8-33 with float64 mobility / rt arrays
     float loc = 0.0f;
     double rt_width = 0.0, mob_width = 0.0;
@@ -933,4 +985,43 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
         }
         if (sub == 0) out.valid[row] = 1;
     }
+}
+
+template <int FM, int SM, int NO>
+__global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_profiles_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, adh_scoring_config_t cfg, int32_t n_iso_cols,
+    const unsigned char *__restrict__ scratch, const unsigned char *__restrict__ prof, DevOut out) {
+    __shared__ featim2::GroupLds<FM, SM, NO> lds[ADH_WAVE / featim2::GS];
+    const int ci = (int)blockIdx.x * (ADH_WAVE / featim2::GS) + (int)threadIdx.x / featim2::GS;
+    adh_im_profiles_body<FM, SM, NO, false>(lds, ci, ci < n_cand, run, plan, cfg, n_iso_cols, scratch, prof, out, nullptr, nullptr);
+}
+
+// Tile phase and profile phase of four one-observation candidates in ONE kernel (round 6): the profiles never leave
+// the CU - no ImProfRec (4 KB per candidate written and read), one set of fixed costs.  The grid is that of
+// adh_feature_im_tile4_kernel: the first `list_blocks` blocks take the materialised tiles, here through the
+// one-kernel body (adh_feature_im_body<LAY, false>: tiles -> output row); `side`: order of work, see adh_features_im4.hip.
+template <int FM, int SM, class LAY>
+__global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_fused4_kernel(
+    DevTims run, const CandRecIM *__restrict__ plan, int32_t n_cand, const float *__restrict__ iso_table,
+    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch, DevOut out,
+    const uint32_t *__restrict__ side, Caps caps, int32_t list_blocks) {
+    using namespace featim4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int32_t)blockIdx.x < list_blocks) {
+        const uint32_t n = side[0];
+        const uint32_t *list = side + SIDE_HEAD + n_cand;
+        for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {
+            adh_feature_im_body<LAY, false>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, nullptr);
+            __syncthreads();  // (the next candidate reuses the LDS arrays)
+        }
+        return;
+    }
+    WaveTile<FM, SM, 1> &W = *reinterpret_cast<WaveTile<FM, SM, 1> *>(smem);
+    const int32_t block = (int32_t)blockIdx.x - list_blocks;
+    const int32_t n_order = (int32_t)side[1];
+    if (block * NG >= n_order) return;
+    int ci = 0;
+    const TileOut t = tile4_phase<FM, SM, 1>(W, run, plan, n_order, block, iso_table, n_iso_cols, cfg, scratch, out, side + SIDE_HEAD, ci);
+    adh_im_profiles_body<FM, SM, 1, true>(reinterpret_cast<featim2::GroupLds<FM, SM, 1> *>(smem), ci, t.alive, run, plan, cfg,
+                                          n_iso_cols, scratch, nullptr, out, &W.g[threadIdx.x / GS], &t);
 }

@@ -540,6 +540,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
     const uint64_t list_common_off = (prof_end + 255) / 256 * 256;
     const uint64_t list_small_off = list_common_off + (tile4 && split_common ? featim4::side_bytes(p.n_class[0]) : 0);
     const uint64_t list_two_off = list_small_off + (tile4 && split_small ? featim4::side_bytes(p.n_class[ADH_CLASS_IM_SMALL]) : 0);
+    const bool fuse4 = tile4 && !getenv("ADH_DEBUG_IM_NO_FUSE4") && stop4 == 0;  // (tile + profile phase in one kernel, one observation)
     const bool tile4_two = tile4 && !getenv("ADH_DEBUG_IM_TILE1_TWO");  // (A/B: the two-observation class through the one-candidate kernel)
     const uint64_t prof_bytes = list_two_off + (tile4_two && split_two ? featim4::side_bytes(p.n_class[1]) : 0);
     int rc = ensure_scratch(h, prof_bytes);
@@ -579,6 +580,17 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                            d_scratch, side);
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
+                        if (fuse4) {
+                            const size_t f4_lds = std::max({sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>),
+                                                            sizeof(featim2::GroupLds<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>) * (ADH_WAVE / 16),
+                                                            featim::LayoutSmall(cc).bytes() + f_pad});
+                            hipLaunchKernelGGL((adh_feature_im_fused4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, featim::LayoutSmall>),
+                                               dim3(groups + list_blocks), dim3(ADH_WAVE), f4_lds, st, h->tims, p.d_recs_im + first,
+                                               (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, side, cc, (int32_t)list_blocks);
+                            HIP_TRY(hipGetLastError());
+                            first += cnt;
+                            continue;
+                        }
                         const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>), featim::LayoutSmall(cc).bytes() + f_pad);
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1, featim::LayoutSmall>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
@@ -624,6 +636,17 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                            d_scratch, side);
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
+                        if (fuse4) {
+                            const size_t f4_lds = std::max({sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>),
+                                                            sizeof(featim2::GroupLds<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>) * (ADH_WAVE / 16),
+                                                            featim::LayoutCommon(cc).bytes() + f_pad});
+                            hipLaunchKernelGGL((adh_feature_im_fused4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, featim::LayoutCommon>),
+                                               dim3(groups + list_blocks), dim3(ADH_WAVE), f4_lds, st, h->tims, p.d_recs_im + first,
+                                               (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, side, cc, (int32_t)list_blocks);
+                            HIP_TRY(hipGetLastError());
+                            first += cnt;
+                            continue;
+                        }
                         const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>), featim::LayoutCommon(cc).bytes() + f_pad);
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1, featim::LayoutCommon>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
