@@ -941,27 +941,42 @@ int build_tile_layout(adh_handle *h, DevTims &t) {
             return fail(ADH_ERR_INVALID_ARGUMENT, "ADH_IM_TILE_SHIFTS must be \"c,s\" with 0 <= c, s <= 20");
     }
     auto blocks = [](int64_t n, int sh) { return (n + (1ll << sh) - 1) >> sh; };
+    // Round 6: the frame of the cycle as part of the tile (DevTims::tile_frames).  A candidate's windows live in one or two
+    // of the cycle's frames, so with the frames apart it streams a cycle_len-th of the events per (cycles x scans) box;
+    // the index grows by the same factor - affordable where HBM is 288 GB (ADH_IM_TILE_FRAMES=0: frames share a tile, the
+    // layout of round 4; cycles of more than 32 frames keep that as well: the plan names a candidate's frames by a mask)
+    const char *fenv = getenv("ADH_IM_TILE_FRAMES");
+    int64_t n_fr = (t.cycle_len <= 32 && !(fenv && atoi(fenv) == 0)) ? t.cycle_len : 1;
     if (csh < 0) {
-        const double want = (double)t.n_events / (1.5 * (double)t.n_tof);  // tiles
+        // ~1.5 events per (tile, TOF bin) where the frames share a tile; keyed by frame the boxes stay as they are and
+        // the tile count grows by the frames (capped below by the 2^31 keys of the index)
+        const double want = (double)t.n_events / (1.5 * (double)t.n_tof) * (double)n_fr;  // tiles
         double best = 1e300;
         for (int c = 2; c <= 12; ++c)
-            for (int s = c; s <= c + 1; ++s) {
-                const double tiles = (double)(blocks(t.n_cycles, c) * blocks(t.scan_max, s));
+            for (int s = c; s <= c + (n_fr > 1 ? 2 : 1); ++s) {
+                const double tiles = (double)(blocks(t.n_cycles, c) * blocks(t.scan_max, s) * n_fr);
+                if (tiles * (double)(t.n_tof + 1) >= 2.0e9) continue;
                 const double miss = fabs(log(std::max(tiles, 1.0) / std::max(want, 1.0)));
                 if (miss < best) best = miss, csh = c, ssh = s;
             }
+        if (csh < 0) csh = 12, ssh = 14;
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     int64_t ncb = blocks(t.n_cycles, csh), nsb = blocks(t.scan_max, ssh);
     // (coarser tiles until the index fits 32-bit keys and its share of the memory)
-    while ((double)ncb * (double)nsb * (double)(t.n_tof + 1) >= 4.0e9 ||
-           (size_t)(ncb * nsb * (t.n_tof + 1) + 1) * 4 > free_b / 8) {
-        if (ncb == 1 && nsb == 1) return ADH_OK;
+    while ((double)ncb * (double)nsb * (double)n_fr * (double)(t.n_tof + 1) >= 2.0e9 ||
+           (size_t)(ncb * nsb * n_fr * (t.n_tof + 1) + 1) * 4 > free_b / 8) {
+        if (ncb == 1 && nsb == 1) {
+            if (n_fr == 1) return ADH_OK;
+            n_fr = 1;  // (no room for the frames: share the tiles)
+            continue;
+        }
         if (ncb >= nsb) ++csh; else ++ssh;
         ncb = blocks(t.n_cycles, csh), nsb = blocks(t.scan_max, ssh);
     }
-    const int64_t n_keys = ncb * nsb * (t.n_tof + 1), n = t.n_events;
+    const int64_t n_tiles = ncb * nsb * n_fr;
+    const int64_t n_keys = n_tiles * (t.n_tof + 1), n = t.n_events;
     if (n_keys >= 0x7FFFFFFFll) return ADH_OK;  // (the scan below counts in int: such a run keeps the bin ranges)
     int key_bits = 1;
     while (key_bits < 32 && (1ll << key_bits) < n_keys) ++key_bits;
@@ -998,7 +1013,7 @@ int build_tile_layout(adh_handle *h, DevTims &t) {
         const unsigned grid = (unsigned)std::min<int64_t>(t.n_tof, 1 << 20);
         hipLaunchKernelGGL(adh_tile_key_kernel, dim3(grid), dim3(ADH_WAVE), 0, h->stream, t.tof_indptr, t.push, t.inten, t.n_tof,
                            (uint32_t)t.scan_max, (uint32_t)t.cycle_len, (uint32_t)t.zeroth, csh, ssh, sbits, (uint32_t)ncb, (uint32_t)nsb,
-                           k_in, v_in, idx);
+                           (uint32_t)n_fr, k_in, v_in, idx);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, k_in, k_out, v_in, v_out, (int)n, 0, key_bits, h->stream);
@@ -1013,6 +1028,7 @@ int build_tile_layout(adh_handle *h, DevTims &t) {
     t.tile_cblocks = (int32_t)ncb;
     t.tile_sblocks = (int32_t)nsb;
     t.tile_sbits = sbits;
+    t.tile_frames = (int32_t)n_fr;
     return ADH_OK;
 }
 }  // namespace

@@ -144,7 +144,11 @@ struct DevTims {
     // NULL when the layout is not built (ADH_IM_TILED=0, no room, too many events): the kernels use the bin ranges.
     const uint2 *tile_ev;
     const uint32_t *tile_idx;
-    int32_t tile_cshift, tile_sshift, tile_cblocks, tile_sblocks, tile_sbits, tile_pad;
+    // Round 6: with tile_frames = cycle_len the frame of the cycle is part of the tile (tile = (cycle block *
+    // tile_sblocks + scan block) * tile_frames + frame inside the cycle): a candidate reads the frames its quadrupole
+    // windows are in - one of nine in configs[3] - instead of all of them, at the price of a tile_frames times larger
+    // index for the same (cycles x scans) footprint: HBM spent on an index (6.6 GB on configs[3]).  1: frames share a tile.
+    int32_t tile_cshift, tile_sshift, tile_cblocks, tile_sblocks, tile_sbits, tile_frames;
     __device__ __forceinline__ uint32_t tile_word(int tile, int tof) const { return tile_idx[(size_t)tile * (size_t)(n_tof + 1) + (size_t)tof]; }
 };
 
@@ -160,7 +164,9 @@ struct __attribute__((aligned(16))) CandRecIM {
     uint16_t ms1_obs[ADH_MAX_MS1_OBS];  // the same for the (-1, -1) precursor query
     uint32_t row, k_cap;
     uint64_t scratch_off;
-    uint64_t pad64;
+    // frames of the cycle (bit fr) with a push of the candidate's scans whose quadrupole window meets the fragment range /
+    // is the MS1 window (-1, -1): the tiles the gather visits when the tile layout is keyed by frame (cycle_len <= 32)
+    uint32_t frames_f, frames_p;
 };
 static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 

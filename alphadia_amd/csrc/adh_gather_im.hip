@@ -264,9 +264,12 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
             box = index_im::tile_box(run, c0, F, r.scan_start, r.scan_stop);
             bool wide = false;
             for (int w = lane; w < W; w += ADH_WAVE) wide |= t_hi[slot_of(w)] - t_lo[slot_of(w)] > 256;
-            tiled = W * box.nT <= ADH_IM_PAIR_CAP && !__any(wide);
+            // (a frame-keyed layout: a window visits the boxes of its own frames)
+            const int per_f = run.tile_frames > 1 ? __popc(r.frames_f) : 1, per_p = run.tile_frames > 1 ? __popc(r.frames_p) : 1;
+            tiled = (K * per_f + I * per_p) * box.nT <= ADH_IM_PAIR_CAP && !__any(wide);
         }
-        const int P = tiled ? index_im::pair_setup_tiled(run, box, W, t_lo, t_hi, slot_of, w_p0, p_lo, p_off, p_win, lane)
+        const int P = tiled ? index_im::pair_setup_tiled(run, box, W, t_lo, t_hi, slot_of, w_p0, p_lo, p_off, p_win, lane, K,
+                                                         r.frames_f, r.frames_p)
                             : index_im::pair_setup(run, W, t_lo, t_hi, slot_of, c0, F, push_lo, push_hi, w_p0, w_base, p_lo,
                                                    p_off, p_win, lane);
         if (caps.stop_phase == 15) {  // developer ablation: ... + pair ranges

@@ -136,9 +136,14 @@ __device__ __forceinline__ int pair_setup(const DevTims &run, int W, const int *
 // The tile layout (DevTims::tile_ev): the tiles that the candidate's box of cycles [c0, c0 + F) x scans
 // [scan_lo, scan_hi) meets.  nT = number of tiles, tile j (j < nT) = tile_at(j).
 struct TileBox {
-    int cb0, sb0, n_sb, nT, stride;
+    int cb0, sb0, n_sb, nT, stride;  // nT: (cycle block, scan block) boxes the candidate meets
     __device__ __forceinline__ int tile_at(int j) const { return (cb0 + j / n_sb) * stride + sb0 + j % n_sb; }
 };
+// the i-th set bit of a frame mask
+__device__ __forceinline__ int nth_frame(uint32_t mask, int i) {
+    for (int k = 0; k < i; ++k) mask &= mask - 1u;
+    return __ffs((int)mask) - 1;
+}
 __device__ __forceinline__ TileBox tile_box(const DevTims &run, int c0, int F, int scan_lo, int scan_hi) {
     TileBox b;
     const int cbl = run.tile_cblocks - 1;
@@ -155,15 +160,30 @@ __device__ __forceinline__ TileBox tile_box(const DevTims &run, int c0, int F, i
 // Pairs of the tile layout: (window, tile) - the events of the window's TOF bins inside one tile are ONE run
 // (TOF ascending, then push).  Pair p = w * nT + j; p_lo holds the absolute first event (the layout is only built
 // below 2^31 events), w_base is not used.  Returns the number of pairs.
+// `n_frag`: windows [0, n_frag) are fragment windows, the rest isotope windows; with a frame-keyed layout
+// (run.tile_frames > 1) a window visits the boxes of ITS frames (masks frames_f / frames_p of the plan record): pair
+// p of window w = (box j, k-th frame of the window's mask), boxes outer.
 template <typename SlotOf>
 __device__ __forceinline__ int pair_setup_tiled(const DevTims &run, const TileBox &box, int W, const int *t_lo,
                                                 const int *t_hi, SlotOf slot_of, int *w_p0, uint32_t *p_lo,
-                                                uint32_t *p_off, uint8_t *p_win, int lane) {
-    const int nT = box.nT, P = W * nT;
-    for (int w = lane; w <= W; w += ADH_WAVE) w_p0[w] = w * nT;
+                                                uint32_t *p_off, uint8_t *p_win, int lane, int n_frag = 0,
+                                                uint32_t frames_f = 1u, uint32_t frames_p = 1u) {
+    const bool keyed = run.tile_frames > 1;
+    const int nf_f = keyed ? __popc(frames_f) : 1, nf_p = keyed ? __popc(frames_p) : 1;
+    const int per_f = box.nT * nf_f, per_p = box.nT * nf_p;
+    const int n_fw = keyed ? n_frag : W;  // (not keyed: every window counts as a "fragment" window with one frame)
+    const int P = n_fw * per_f + (W - n_fw) * per_p;
+    for (int w = lane; w <= W; w += ADH_WAVE) w_p0[w] = w <= n_fw ? w * per_f : n_fw * per_f + (w - n_fw) * per_p;
+    if (P > ADH_IM_PAIR_CAP) return P;
     for (int p = lane; p < P; p += ADH_WAVE) {
-        const int w = p / nT, j = p - w * nT;
-        const int slot = slot_of(w), tile = box.tile_at(j);
+        const bool fw = p < n_fw * per_f;
+        const int per = fw ? per_f : per_p, q = fw ? p : p - n_fw * per_f;
+        const int w = (fw ? 0 : n_fw) + q / per, jj = q - (q / per) * per;
+        const int nf = fw ? nf_f : nf_p;
+        const int j = jj / nf, k = jj - j * nf;
+        const int slot = slot_of(w);
+        int tile = box.tile_at(j);
+        if (keyed) tile = tile * run.tile_frames + nth_frame(fw ? frames_f : frames_p, k);
         const uint32_t lo = run.tile_word(tile, t_lo[slot]), hi = run.tile_word(tile, t_hi[slot]);
         p_lo[p] = lo;
         p_win[p] = (uint8_t)w;
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_tile_key_kernel(const int64_t *_
                                                                   const uint32_t *__restrict__ push,
                                                                   const uint16_t *__restrict__ inten, int64_t n_tof,
                                                                   uint32_t S_max, uint32_t L, uint32_t z, int csh, int ssh,
-                                                                  int sbits, uint32_t ncb, uint32_t nsb, uint32_t *__restrict__ keys,
+                                                                  int sbits, uint32_t ncb, uint32_t nsb, uint32_t n_fr, uint32_t *__restrict__ keys,
                                                                   uint64_t *__restrict__ vals, uint32_t *__restrict__ hist) {
     const int lane = threadIdx.x;
     for (int64_t tof = blockIdx.x; tof < n_tof; tof += gridDim.x) {
@@ -299,8 +319,9 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_tile_key_kernel(const int64_t *_
             const uint32_t p = push[e];
             const uint32_t frame = p / S_max, scan = p - frame * S_max;
             const uint32_t cyc = frame < z ? 0u : (frame - z) / L;
+            const uint32_t fr = (n_fr > 1u && frame >= z) ? (frame - z) - cyc * L : 0u;  // frame inside the cycle (keyed layout)
             const uint32_t cb = min(cyc >> csh, ncb - 1u), sb = min(scan >> ssh, nsb - 1u);
-            const uint32_t key = (cb * nsb + sb) * (uint32_t)(n_tof + 1) + (uint32_t)tof;
+            const uint32_t key = ((cb * nsb + sb) * n_fr + fr) * (uint32_t)(n_tof + 1) + (uint32_t)tof;
             keys[e] = key;
             vals[e] = (uint64_t)(frame << sbits | scan) | (uint64_t)inten[e] << 32 | (uint64_t)((uint32_t)tof & 0xFFFFu) << 48;
             atomicAdd(&hist[key], 1u);

@@ -278,8 +278,14 @@ __global__ __launch_bounds__(256) void adh_plan_rec_im_kernel(DevCands c, const 
                     const int64_t rowi = (int64_t)fr * p.scan_max + s;
                     const double wl = cyc[2 * rowi], wh = cyc[2 * rowi + 1];
                     const int v = dpc[rowi];
-                    if (q_lo <= wh && q_hi >= wl) seen_f[v >> 5] |= 1u << (v & 31);
-                    if (-1.0 <= wh && -1.0 >= wl) seen_p[v >> 5] |= 1u << (v & 31);
+                    if (q_lo <= wh && q_hi >= wl) {
+                        seen_f[v >> 5] |= 1u << (v & 31);
+                        if (fr < 32) r.frames_f |= 1u << fr;
+                    }
+                    if (-1.0 <= wh && -1.0 >= wl) {
+                        seen_p[v >> 5] |= 1u << (v & 31);
+                        if (fr < 32) r.frames_p |= 1u << fr;
+                    }
                 }
             int nf = 0, np = 0;
             for (int v = 0; v < p.L && !err; ++v) {

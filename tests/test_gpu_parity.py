@@ -905,7 +905,13 @@ def test_timstof_search_indices_and_tile_modes_agree(ctx, monkeypatch):
                 # (ADH_DEBUG_IM=14: the gather's windows in batches that are certain to fit, never all at once)
                 dict(ADH_DEBUG_IM="14"), dict(ADH_DEBUG_IM="14", ADH_IM_TILED="0"),
                 dict(ADH_IM_TILED="0"), dict(ADH_DEBUG_IM_NO_TILES="1"), dict(ADH_IM_TILE_SHIFTS="2,3"),
-                dict(ADH_IM_TILE_SHIFTS="5,4"), dict(ADH_IM_TILE_SHIFTS="1,6"), dict(ADH_IM_TILE_SHIFTS="12,12")):
+                dict(ADH_IM_TILE_SHIFTS="5,4"), dict(ADH_IM_TILE_SHIFTS="1,6"), dict(ADH_IM_TILE_SHIFTS="12,12"),
+                # (round 6) the tiles keyed by the frame of the cycle (the default) against frames sharing a tile, in
+                # several shapes; the tile phase four candidates per wavefront against the one-candidate kernel; tile
+                # and profile phase in one kernel against two
+                dict(ADH_IM_TILE_FRAMES="0"), dict(ADH_IM_TILE_FRAMES="0", ADH_IM_TILE_SHIFTS="2,3"),
+                dict(ADH_IM_TILE_FRAMES="0", ADH_DEBUG_IM="14"), dict(ADH_DEBUG_IM_TILE1="1"), dict(ADH_DEBUG_IM_NO_FUSE4="1"),
+                dict(ADH_DEBUG_IM_TILE1_TWO="1"), dict(ADH_DEBUG_IM_NO_FUSE4="1", ADH_DEBUG_IM="8")):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
