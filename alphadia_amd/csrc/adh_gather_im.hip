@@ -353,59 +353,18 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
         // ---- stage 1 of the windows [wa, wb): the raw events; those in the scan range (and, in a tile, in the
         // candidate's cycles) queue up behind the list.  Returns their number (queue entries beyond the list's
         // capacity are counted, not stored).
-        auto stage_one = [&](int wa, int wb) -> int {
+        auto stage_one = [&](int wa, int wb, int scan_a, int scan_b) -> int {
             const int pa0 = w_p0[wa], pb0 = w_p0[wb];
             const uint32_t r0 = p_off[pa0], r1 = p_off[pb0];
-            return tiled ? index_im::queue_scan_range<true, GCAP>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+            return tiled ? index_im::queue_scan_range<true, GCAP>(run, pa0, pb0, r0, r1, scan_a, scan_b, m, w_base, p_win, p_lo,
                                                             p_off, s_key, s_int, s_pair, lane, (uint32_t)(c0 * L + z),
                                                             (uint32_t)((c0 + F) * L + z))
-                         : index_im::queue_scan_range<false, GCAP>(run, pa0, pb0, r0, r1, r.scan_start, r.scan_stop, m, w_base, p_win, p_lo,
+                         : index_im::queue_scan_range<false, GCAP>(run, pa0, pb0, r0, r1, scan_a, scan_b, m, w_base, p_win, p_lo,
                                                              p_off, s_key, s_int, s_pair, lane);
         };
-        int w0 = 0;
-        bool try_all = caps.stop_phase != 14;  // (14: developer switch, certain batches only)
-        while (w0 < W && !over) {
-            // The next batch of windows.  First guess: ALL that are left - few raw events survive stage 1, and a
-            // candidate that gets through its windows in one batch has one chain of dependent loads (events ->
-            // quadrupole rows -> m/z of the bins) instead of one per batch, which is what this kernel waits for.
-            // If the survivors do not fit the list: as many windows as are certain to fit its free part (every raw
-            // event might survive); the isotope windows go together, whatever their size.
-            const bool pg = w0 >= K;
-            int w1 = W, nq = -1;
-            if (try_all && p_off[w_p0[W]] - p_off[w_p0[w0]] <= 0xFFFFu) {
-                nq = stage_one(w0, W);
-                if (m + nq > GCAP) {
-                    nq = -1;
-                    try_all = false;
-                    __syncthreads();
-                }
-            }
-            if (nq < 0) {
-                w1 = pg ? W : w0 + 1;
-                if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > GCAP) {
-                    flush();
-                    if (over) break;
-                }
-                if (!pg)
-                    while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= GCAP) ++w1;
-                if (p_off[w_p0[w1]] - p_off[w_p0[w0]] > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
-                    over = true;
-                    break;
-                }
-                nq = stage_one(w0, w1);
-                if (m + nq > GCAP) {  // (only a single window or the isotope group can be this full)
-                    over = true;
-                    break;
-                }
-            }
-            const uint32_t r0 = p_off[w_p0[w0]];
-            __syncthreads();
-            if (caps.stop_phase == 16) {  // developer ablation: ... + stage 1 (the raw events of the first batch)
-                if (lane == 0) header[0] = 0;
-                return;
-            }
-            // ---- stage 2: the queued events look up their quadrupole row, MS1 / MS2 observation and
-            // intensity (independent loads) and the survivors take their place in the list, in stream order
+        // ---- stage 2 of a batch whose first raw event is r0: the nq queued events look up their quadrupole row, MS1 /
+        // MS2 observation and intensity (independent loads) and the survivors take their place in the list, in stream order
+        auto stage_two = [&](const int nq, const uint32_t r0) {
             const int q_base = m;
             for (int q0 = 0; q0 < nq; q0 += ADH_WAVE) {
                 const int qi = q0 + lane;
@@ -462,6 +421,86 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
                 m += __popcll(mask);
                 hits += (uint32_t)__popcll(mask);
             }
+        };
+        int w0 = 0;
+        bool try_all = caps.stop_phase != 14;  // (14: developer switch, certain batches only)
+        while (w0 < W && !over) {
+            // The next batch of windows.  First guess: ALL that are left - few raw events survive stage 1, and a
+            // candidate that gets through its windows in one batch has one chain of dependent loads (events ->
+            // quadrupole rows -> m/z of the bins) instead of one per batch, which is what this kernel waits for.
+            // If the survivors do not fit the list: as many windows as are certain to fit its free part (every raw
+            // event might survive); the isotope windows go together, whatever their size.
+            const bool pg = w0 >= K;
+            int w1 = W, nq = -1;
+            if (try_all && p_off[w_p0[W]] - p_off[w_p0[w0]] <= 0xFFFFu) {
+                nq = stage_one(w0, W, r.scan_start, r.scan_stop);
+                if (m + nq > GCAP) {
+                    nq = -1;
+                    try_all = false;
+                    __syncthreads();
+                }
+            }
+            if (nq < 0) {
+                w1 = pg ? W : w0 + 1;
+                if (m > 0 && (uint32_t)m + (p_off[w_p0[w1]] - p_off[w_p0[w0]]) > GCAP) {
+                    flush();
+                    if (over) break;
+                }
+                if (!pg)
+                    while (w1 < K && (uint32_t)m + (p_off[w_p0[w1 + 1]] - p_off[w_p0[w0]]) <= GCAP) ++w1;
+                if (p_off[w_p0[w1]] - p_off[w_p0[w0]] > 0xFFFFu) {  // (raw numbers are queued as 16-bit offsets)
+                    over = true;
+                    break;
+                }
+                nq = stage_one(w0, w1, r.scan_start, r.scan_stop);
+                if (m + nq > GCAP) {
+                    // Only a single window or the isotope group can be this full (m = 0 here: what was in the list has
+                    // been flushed) - a candidate ON a peptide: 300 - 800 isotope events.  Round 6: its scans in 2, 4,
+                    // ... 32 parts, each sorted, folded and emitted by itself, lowest scans first.  The entries of the
+                    // isotope group are in (scan, cycle, isotope) order and those of one fragment window with one
+                    // observation in (scan, cycle) order, so the parts' entries ARE the sorted list; only what is left
+                    // (two observations in one overfull window, a part of one scan that does not fit) takes the
+                    // materialised tiles, which cost 110 KB of zeros written and read per candidate and the slowest
+                    // path of the feature kernels.
+                    bool fit = false;
+                    int parts = 2;
+                    if (pg || O == 1) {
+                        for (; parts <= 32 && !fit; parts *= 2) {
+                            fit = true;
+                            for (int q = 0; q < parts && fit; ++q) {
+                                const int sa = r.scan_start + (int)((int64_t)S * q / parts), sb = r.scan_start + (int)((int64_t)S * (q + 1) / parts);
+                                if (sb > sa && stage_one(w0, w1, sa, sb) > GCAP) fit = false;
+                                __syncthreads();
+                            }
+                            if (fit) break;
+                        }
+                    }
+                    if (!fit) {
+                        over = true;
+                        break;
+                    }
+                    const uint32_t r0p = p_off[w_p0[w0]];
+                    for (int q = 0; q < parts && !over; ++q) {
+                        const int sa = r.scan_start + (int)((int64_t)S * q / parts), sb = r.scan_start + (int)((int64_t)S * (q + 1) / parts);
+                        if (sb <= sa) continue;
+                        const int nq_p = stage_one(w0, w1, sa, sb);
+                        __syncthreads();
+                        stage_two(nq_p, r0p);
+                        __syncthreads();
+                        if (m > 0) flush();
+                    }
+                    if (over) break;
+                    w0 = w1;
+                    continue;
+                }
+            }
+            const uint32_t r0 = p_off[w_p0[w0]];
+            __syncthreads();
+            if (caps.stop_phase == 16) {  // developer ablation: ... + stage 1 (the raw events of the first batch)
+                if (lane == 0) header[0] = 0;
+                return;
+            }
+            stage_two(nq, r0);
             __syncthreads();
             w0 = w1;
         }
