@@ -295,7 +295,10 @@ size_t adh_feature_im_lds_bytes(const Caps &c) {
 // ImProfRec<LAY::Fc, LAY::Sc> to `prof` (record blockIdx.x); adh_feature_im_profiles_kernel does the rest, four
 // candidates per wavefront.
 // The kernel's body for candidate `ci` of `plan` (the kernels below: one block per candidate, or a block per list entry)
-template <class LAY, bool SPLIT>
+// DYNPOOL: the 2.5 KB of chunk lists behind the layout in the dynamic LDS block instead of a static array - for the
+// kernels that take the rare materialised tiles through this body in a few blocks of a grid whose other blocks should
+// not pay for it (adh_feature_im_fused4_kernel, adh_feature_im_tile4_kernel: LDS is their occupancy).
+template <class LAY, bool SPLIT, bool DYNPOOL = false>
 __device__ __forceinline__ void adh_feature_im_body(
     const int ci, const DevTims &run, const CandRecIM *__restrict__ plan, const float *__restrict__ iso_table,
     int32_t n_iso_cols, const adh_scoring_config_t &cfg, const unsigned char *__restrict__ scratch, const DevOut &out,
@@ -306,7 +309,8 @@ __device__ __forceinline__ void adh_feature_im_body(
     // static LDS: the chunk lists of the tile pass; the two 16 x 17 matrices of the scan
     // correlation reuse the same bytes later (an extra 2 KB of LDS per wavefront cost 22 % of the
     // kernel's throughput in resident waves)
-    __shared__ __align__(16) unsigned char pool[ADH_IM_STATIC_LDS];
+    __shared__ __align__(16) unsigned char pool_static[DYNPOOL ? 16 : ADH_IM_STATIC_LDS];
+    unsigned char *const pool = DYNPOOL ? smem + ((LAY(caps).bytes() + 15) / 16 * 16) : pool_static;
     double *const l_ti = reinterpret_cast<double *>(pool);
     double *const l_tm = l_ti + ADH_WAVE;
     double *const l_w = l_tm + ADH_WAVE;

@@ -133,7 +133,7 @@ __device__ __forceinline__ void adh_im_profiles_body(
     float P0[FUSED ? FM : 1], Sp0[FUSED ? SM : 1], tfpv[(FM + 15) / 16], tspv[(SM + 15) / 16], isov[2] = {0.0f, 0.0f};
     if constexpr (FUSED) {
         F2_FOR_R P0[r] = (frag_lane0 && F2_OK(r)) ? tile->ffp[0][min(max(r + shift, 0), FM - 1)][slot] : 0.0f;
-        F2_FOR_S Sp0[i] = (frag_lane0 && i < S) ? tile->fsp[0][i][slot] : 0.0f;
+        F2_FOR_S Sp0[i] = (frag_lane0 && i < S) ? tile->v.fsp[0][i][slot] : 0.0f;
 #pragma unroll
         for (int pass = 0; pass < (FM + 15) / 16; ++pass) {
             const int f = min(sub + 16 * pass, FM - 1) + shift;
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_fused4_kernel(
         const uint32_t n = side[0];
         const uint32_t *list = side + SIDE_HEAD + n_cand;
         for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {
-            adh_feature_im_body<LAY, false>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, nullptr);
+            adh_feature_im_body<LAY, false, true>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, nullptr);
             __syncthreads();  // (the next candidate reuses the LDS arrays)
         }
         return;

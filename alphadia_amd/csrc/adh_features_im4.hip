@@ -33,17 +33,19 @@ namespace featim4 {
 constexpr int GS = 16;
 constexpr int NG = ADH_WAVE / GS;
 constexpr int KMAX = ADH_IM_PROF_K;
-constexpr int NP = 256;  // fragment entries of a wavefront's candidates per pass of the pool
+constexpr int NP = 144;  // fragment entries of a wavefront's candidates per pass of the pool (LDS is the kernel's occupancy)
 
 // precursor entries of the wavefront's candidates, PP per pass, as the balanced pass leaves them (PrecPoolT below; they
 // live in the pool's bytes: the precursor entries come first)
-constexpr int PP = 128;
+constexpr int PP = 56;
 
 template <int FM, int SM, int NO>
 struct __attribute__((aligned(16))) GroupTile {
     float ffp[NO][FM][KMAX];      // fragment frame profiles [observation][cycle][fragment]
-    float fsp[NO][SM][KMAX];      // fragment scan profiles [observation][scan][fragment]
-    double cy[NO][2][SM];         // the quadrupole rows of the candidate's scans (lower, upper limit) per observation
+    union {
+        float fsp[NO][SM][KMAX];  // fragment scan profiles [observation][scan][fragment] ...
+        double cy[NO][2][SM];     // ... before them: the quadrupole rows of the candidate's scans (lower, upper limit) per
+    } v;                          //     observation - dead once the scan masks are known (LDS is this kernel's occupancy)
     float qmask[NO][SM];
     float tsp_raw[NO][SM], tfp_raw[NO][FM];
     float iso_int[4], iso_mz[4];
@@ -161,8 +163,8 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
             for (int j = 0; j < NJ; ++j) {
                 const int sc = sub + j * GS;
                 if (sc < SM) {
-                    Q.cy[o][0][sc] = cyv[o][j].x;
-                    Q.cy[o][1][sc] = cyv[o][j].y;
+                    Q.v.cy[o][0][sc] = cyv[o][j].x;
+                    Q.v.cy[o][1][sc] = cyv[o][j].y;
                     Q.tsp_raw[o][sc] = 0.0f;
                     Q.qmask[o][sc] = 0.0f;
                 }
@@ -198,7 +200,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
     // transfer function of (isotope i, observation o, scan sc) (quadrupole.py:261-301)
     auto qtf_at = [&](const GroupTile<FM, SM, NO> &T, int i, int o, int sc) -> double {
         const double x = (double)T.iso_mz[i];
-        return featim::logistic(x, T.cy[o][0][sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, T.cy[o][1][sc] + qp.delta_hi, qp.sigma_hi);
+        return featim::logistic(x, T.v.cy[o][0][sc] + qp.delta_lo, qp.sigma_lo) - featim::logistic(x, T.v.cy[o][1][sc] + qp.delta_hi, qp.sigma_hi);
     };
 
     // ---- the precursor entries: non-zero (scan, cycle, isotope) cells in that order.
@@ -390,7 +392,6 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
         }
     }
     for (int c = sub; c < NO * FM * KMAX; c += GS) (&Q.ffp[0][0][0])[c] = 0.0f;
-    for (int c = sub; c < NO * SM * KMAX; c += GS) (&Q.fsp[0][0][0])[c] = 0.0f;
     adh_wave_sync();
 
     // ---- the fragment entries.  First every entry's plane (fragment * O + observation), balanced over the
@@ -398,6 +399,9 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
     // this pass is also pass (a) below: the list's order IS the pool's order then, and an entry is fetched once.
     const int total = W.g[NG - 1].off + W.g[NG - 1].n_fe;
     const bool single = total <= NP;
+    // (more than one pass: the scan masks of ALL the candidates' scans are taken in the first pass - the quadrupole rows
+    // they are computed from share their bytes with the scan profiles, which the first fold writes)
+    if (!single && sub < NO) Q.scans[sub] = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
     const int off1 = W.g[1].off, off2 = W.g[2].off, off3 = W.g[3].off;
     // plane of a cell (float estimate of cell / SF, one fix-up either way)
     auto plane_of = [](uint32_t c, int tSF, float isf) -> int {
@@ -466,8 +470,9 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
         }
     }
     if (at == 0x7FFFFFFF) at = 0, at_end = 0;
+    bool fsp_ready = false;
     auto plane_done = [&]() {  // the lane leaves plane (sub, cur_o)
-        if (cur >= 0) Q.fsp[cur_o][cur][sub] = fs;
+        if (cur >= 0) Q.v.fsp[cur_o][cur][sub] = fs;
         if (NO == 1) {
             res.ohe[0] = (wi > 0) ? vi / wi : 0.0;  // weights are exp(...) > 0: "any non-zero cell" == "wi > 0"
             res.omz[0] = (wm > 0) ? vm / wm : 0.0;
@@ -543,6 +548,10 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
             }
             adh_wave_sync();
             if (sub < NO) Q.scans_done[sub] = Q.scans[sub];
+            if (!fsp_ready) {  // (the quadrupole rows are dead: their bytes become the scan profiles)
+                for (int c = sub; c < NO * SM * KMAX; c += GS) (&Q.v.fsp[0][0][0])[c] = 0.0f;
+                fsp_ready = true;
+            }
             for (int s_ = lane; s_ < n_slots; s_ += ADH_WAVE) {  // candidate.py:290
                 const int scf = (int)W.u.pool.scf[s_];
                 W.u.pool.x[s_] = W.u.pool.x[s_] * W.g[(int)W.owner[s_] / GS].qmask[scf >> 15][(scf >> 8) & 0x7F];
@@ -579,7 +588,7 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
                         cur_o = o;
                     }
                     if (sc != cur) {  // the cells of a scan are consecutive: its sum is complete
-                        if (cur >= 0) Q.fsp[cur_o][cur][sub] = fs;
+                        if (cur >= 0) Q.v.fsp[cur_o][cur][sub] = fs;
                         fs = 0.0f;
                         cur = sc;
                     }
@@ -594,6 +603,10 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
             }
         }
         at += take;
+        adh_wave_sync();
+    }
+    if (!fsp_ready) {  // (no fragment entry in any of the four candidates, or an ablation stop)
+        for (int c = sub; c < NO * SM * KMAX; c += GS) (&Q.v.fsp[0][0][0])[c] = 0.0f;
         adh_wave_sync();
     }
     if (fl) plane_done();
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
         const uint32_t n = side[0];
         const uint32_t *list = side + SIDE_HEAD + n_cand;
         for (uint32_t j = blockIdx.x; j < n; j += (uint32_t)list_blocks) {
-            adh_feature_im_body<LAY, true>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
+            adh_feature_im_body<LAY, true, true>((int)list[j], run, plan, iso_table, n_iso_cols, cfg, scratch, out, caps, prof);
             __syncthreads();  // (the next candidate reuses the LDS arrays)
         }
 #endif
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(ADH_WAVE, 2) void adh_feature_im_tile4_kernel(
     }
     for (int c = sub; c < K0 * NO * SM; c += GS) {
         const int k = c / (NO * SM), rem = c - k * NO * SM, o = rem / SM, sc = rem - o * SM;
-        rec.fsp[k][o][sc] = (o < O && sc < S) ? Q.fsp[o][sc][k] : 0.0f;
+        rec.fsp[k][o][sc] = (o < O && sc < S) ? Q.v.fsp[o][sc][k] : 0.0f;
     }
     if (sub < K0) {
 #pragma unroll

@@ -583,7 +583,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                         if (fuse4) {
                             const size_t f4_lds = std::max({sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>),
                                                             sizeof(featim2::GroupLds<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>) * (ADH_WAVE / 16),
-                                                            featim::LayoutSmall(cc).bytes() + f_pad});
+                                                            featim::LayoutSmall(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16});
                             hipLaunchKernelGGL((adh_feature_im_fused4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, featim::LayoutSmall>),
                                                dim3(groups + list_blocks), dim3(ADH_WAVE), f4_lds, st, h->tims, p.d_recs_im + first,
                                                (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, side, cc, (int32_t)list_blocks);
@@ -591,7 +591,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                             first += cnt;
                             continue;
                         }
-                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>), featim::LayoutSmall(cc).bytes() + f_pad);
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1>), featim::LayoutSmall(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16);
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsSmall::Fc, featim::DimsSmall::Sc, 1, featim::LayoutSmall>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
@@ -614,7 +614,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
                         const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2>),
-                                                       featim::LayoutCommon2(cc).bytes() + f_pad);
+                                                       featim::LayoutCommon2(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16);
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2, featim::LayoutCommon2>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
@@ -639,7 +639,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                         if (fuse4) {
                             const size_t f4_lds = std::max({sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>),
                                                             sizeof(featim2::GroupLds<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>) * (ADH_WAVE / 16),
-                                                            featim::LayoutCommon(cc).bytes() + f_pad});
+                                                            featim::LayoutCommon(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16});
                             hipLaunchKernelGGL((adh_feature_im_fused4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, featim::LayoutCommon>),
                                                dim3(groups + list_blocks), dim3(ADH_WAVE), f4_lds, st, h->tims, p.d_recs_im + first,
                                                (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, side, cc, (int32_t)list_blocks);
@@ -647,7 +647,7 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                             first += cnt;
                             continue;
                         }
-                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>), featim::LayoutCommon(cc).bytes() + f_pad);
+                        const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1>), featim::LayoutCommon(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16);
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon::Fc, featim::DimsCommon::Sc, 1, featim::LayoutCommon>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
