@@ -93,7 +93,10 @@ size_t adh_gather_im_lds_bytes(const Caps &c) {
     return (b + 15) / 16 * 16;
 }
 
-__global__ __launch_bounds__(ADH_WAVE) void adh_gather_im_kernel(
+#ifndef ADH_GATHER_IM_WAVES
+#define ADH_GATHER_IM_WAVES 1  // wavefronts per SIMD the register allocation is held to (A/B of round 6: 8)
+#endif
+__global__ __launch_bounds__(ADH_WAVE, ADH_GATHER_IM_WAVES) void adh_gather_im_kernel(
     DevTims run, const LibRec *__restrict__ lib, const CandRecIM *__restrict__ plan,
     adh_scoring_config_t cfg, int32_t n_iso_cols, unsigned char *__restrict__ scratch, DevOut out,
     Caps caps) {
