@@ -1107,11 +1107,42 @@ constexpr size_t adh_wide_lds_bytes() {
     return adh_fast_lds_bytes<32, NO, 32>() > adh_fast_lds_bytes<32, NO, 64>() ? adh_fast_lds_bytes<32, NO, 32>()
                                                                                  : adh_fast_lds_bytes<32, NO, 64>();
 }
+// The arguments travel as ONE struct read through the kernel-argument segment where they are needed (round 6, as
+// adh_fused_kernel since round 5): as formal parameters the ~120 dwords (DevRun, the class table, the config, the output
+// pointers) are loaded in the prologue of a kernel that holds six bodies, do not fit the scalar registers beside the
+// rest - 848 spilled scalar registers - and come back one v_readlane (a vector-ALU slot) per dword and use.
+struct WideArgs {
+    DevRun run;
+    const CandRec *plan;
+    WideClasses wc;
+    const float *iso_table;
+    int32_t n_iso_cols;
+    adh_scoring_config_t cfg;
+    const unsigned char *scratch;
+    const double *wtp_table;
+    DevOut out;
+    int32_t stop_phase;
+};
+// Two wavefronts per SIMD as the register budget of the two-observation kernel: left alone it takes 256 + 6 registers
+// and runs ONE wavefront per SIMD (round 6: 364 -> 274 us per launch of the transfer-requantification leg; the same
+// budget on the one-observation kernel, which fits two anyway, moves its allocation and costs 8 %).
+#ifndef ADH_WIDE1_WAVES
+#define ADH_WIDE1_WAVES 1  // (build switch for the A/B: 3 = 168 registers, the 32-cycle bodies spill)
+#endif
+#define ADH_WIDE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NO == 2 ? 2 : ADH_WIDE1_WAVES)))
 template <int NO>
-__global__ __launch_bounds__(ADH_WAVE) void adh_feature_wide_kernel(
-    DevRun run, const CandRec *__restrict__ plan, WideClasses wc, const float *__restrict__ iso_table,
-    int32_t n_iso_cols, adh_scoring_config_t cfg, const unsigned char *__restrict__ scratch,
-    const double *__restrict__ wtp_table, DevOut out, int32_t stop_phase) {
+__global__ __launch_bounds__(ADH_WAVE) ADH_WIDE_WAVES_ATTR void adh_feature_wide_kernel(WideArgs formal_args_not_read) {
+    const WideArgs &A = *(const WideArgs *)__builtin_amdgcn_kernarg_segment_ptr();  // (the only argument: offset 0)
+    const DevRun &run = A.run;
+    const CandRec *__restrict__ plan = A.plan;
+    const WideClasses &wc = A.wc;
+    const float *__restrict__ iso_table = A.iso_table;
+    const int32_t n_iso_cols = A.n_iso_cols;
+    const adh_scoring_config_t &cfg = A.cfg;
+    const unsigned char *__restrict__ scratch = A.scratch;
+    const double *__restrict__ wtp_table = A.wtp_table;
+    const DevOut &out = A.out;
+    const int32_t stop_phase = A.stop_phase;
     __shared__ __align__(16) unsigned char smem[adh_wide_lds_bytes<NO>()];
     const int32_t b = (int32_t)blockIdx.x;
     int c = 0;

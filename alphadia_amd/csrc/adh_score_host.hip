@@ -833,12 +833,11 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                 wcs.first_block[wcs.n] = (int32_t)blocks;
                 if (blocks > 0) {
                     const CandRec *base = p.d_recs + n_fused;
+                    const WideArgs wa{h->run, base, wcs, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase};
                     if (c == ADH_CLASS_WIDE2)
-                        hipLaunchKernelGGL((adh_feature_wide_kernel<2>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, base, wcs,
-                                           h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase);
+                        hipLaunchKernelGGL((adh_feature_wide_kernel<2>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, wa);
                     else
-                        hipLaunchKernelGGL((adh_feature_wide_kernel<1>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, h->run, base, wcs,
-                                           h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase);
+                        hipLaunchKernelGGL((adh_feature_wide_kernel<1>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, wa);
                     HIP_TRY(hipGetLastError());
                 }
             }
