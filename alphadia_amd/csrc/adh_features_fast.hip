@@ -296,11 +296,12 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     const int lane = threadIdx.x;
     // precursor weight table exp(-0.1 * sqrt((s - 2)^2 + (f - 1)^2)), f < F <= FM: the "expected
     // centre" (S, 1) of precursor_features.py:52-57 does not depend on the candidate
+    // (requested here, stored behind the plan record and the header: one round trip instead of two before the tile)
+    double wtp_l0 = 0.0, wtp_l1 = 0.0;
     if (lane < FM) {
-        wtp_s[0][lane] = wtp_table[lane];
-        wtp_s[1][lane] = wtp_table[64 + lane];
+        wtp_l0 = wtp_table[lane];
+        wtp_l1 = wtp_table[64 + lane];
     }
-    __syncthreads();
     const int g = lane / GS, sub = lane % GS;
     const unsigned gsh = (unsigned)(g * GS);
     GroupLds<FM, NO, GS> &L = lds[g];
@@ -312,6 +313,11 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     const uint32_t *header = reinterpret_cast<const uint32_t *>(block);
     int K0 = alive ? (int)header[0] : 0;
     alive = alive && K0 != 0;
+    if (lane < FM) {
+        wtp_s[0][lane] = wtp_l0;
+        wtp_s[1][lane] = wtp_l1;
+    }
+    __syncthreads();
     if (__ballot(alive) == 0ull) return;  // (every lane of a dead candidate walks the whole kernel masked: four dead ones need not)
     const uint32_t row = rec.row;
     const int Lc = run.cycle_len;
