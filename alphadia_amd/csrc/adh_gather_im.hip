@@ -160,7 +160,9 @@ __global__ __launch_bounds__(ADH_WAVE, ADH_GATHER_IM_WAVES) void adh_gather_im_k
     }
     __syncthreads();
     int K = 0;
-    for (int a = 0; a < n_lib; ++a) K += l_rank[a] >= 0;
+    if (n_lib <= ADH_WAVE) K = __popcll(__ballot(lane < n_lib && l_rank[lane] >= 0));  // (l_rank[lane]: this lane's own write)
+    else
+        for (int a = 0; a < n_lib; ++a) K += l_rank[a] >= 0;
     const int L = run.cycle_len, S_max = run.scan_max, z = run.zeroth;
     const int c0 = (r.frame_start - z) / L;
     const int F = (r.frame_stop - z) / L - c0;
@@ -197,6 +199,25 @@ __global__ __launch_bounds__(ADH_WAVE, ADH_GATHER_IM_WAVES) void adh_gather_im_k
     }
     __syncthreads();
     // TOF index limits: searchsorted(mz_values, mass_range(...), "left") (bruker_jit.py:273-278)
+    if (K + I <= ADH_WAVE / 2) {
+        // two lanes per window, one per end: the two searches are dependent look-ups of a wavefront that has nothing else
+        // to do (lane w: the lower end, lane w + 32: the upper end)
+        const int w = lane & (ADH_WAVE / 2 - 1);
+        const bool upper = lane >= ADH_WAVE / 2, act = w < K + I;
+        const bool prec = w >= K;
+        const int slot = prec ? caps.k + (w - K) : w;
+        int bound = 0;
+        if (act) {
+            float mzq = w_mz[slot];
+            float tol = prec ? cfg.precursor_mz_tolerance : cfg.fragment_mz_tolerance;
+            float t = tol * mzq;
+            float q = t / 1000000.0f;
+            bound = index_im::tof_lower_bound(run, (double)(upper ? mzq + q : mzq - q));
+        }
+        const int other = __shfl(bound, lane ^ (ADH_WAVE / 2));  // the lower end, seen from the upper lane
+        if (act && !upper) t_lo[slot] = bound;
+        if (act && upper) t_hi[slot] = bound > other ? bound : other;
+    } else
     for (int w = lane; w < K + I; w += ADH_WAVE) {
         const bool prec = w >= K;
         const int slot = prec ? caps.k + (w - K) : w;
