@@ -344,90 +344,101 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
 
     float A[FM], B[FM];
 
-    // ================= precursor phase: lanes 0..I-1 hold one isotope row each =================
+    // ================= precursor phase =================
+    // Three steps since round 6 (before: lane i < I held isotope row i in registers and walked it alone, 3 of a candidate's
+    // 32 or 64 lanes busy for a quarter of the wide kernels' time):
+    //  1. lanes 0..I-1: the isotope's m/z, library intensity and quadrupole transfer (one logistic pair per observation)
+    //  2. lane = cycle: the I cells of the cycle from the scratch block (coalesced), kept in LDS, and the template row
+    //     of every observation (the sum over the isotopes, in isotope order)
+    //  3. lane = (isotope, sum): the four sequential float64 sums of an isotope row - value and weight of the intensity
+    //     and of the m/z channel (precursor_features.py:52-66) - are independent chains: one lane each, side by side
     const bool iso_lane = alive && sub < I;
     {
         const float2 *pcells =
             reinterpret_cast<const float2 *>(block + adh_scratch_prec_off(rec.k_cap, O, F));
-        FOR_R {
-            int f = r + shift;
-            bool ok = iso_lane && f >= 0 && f < F;
-            float2 v = pcells[ok ? sub * F + f : 0];  // branch-free: clamp the index, mask the value
-            A[r] = ok ? v.x : 0.0f;
-            B[r] = ok ? v.y : 0.0f;
-        }
-        float iso_int_l = 0.0f, iso_mz_l = 0.0f;
-        double q[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) q[o] = 0.0;
         if (iso_lane) {
-            iso_int_l = iso_table[(int64_t)row * n_iso_cols + sub];
+            const float iso_int_l = iso_table[(int64_t)row * n_iso_cols + sub];
             double off = (double)sub * 1.0033548350700006 / (double)rec.charge;  // candidate.py:158-163
-            iso_mz_l = (float)off + rec.precursor_mz;
+            const float iso_mz_l = (float)off + rec.precursor_mz;
             // quadrupole_transfer_function_single (quadrupole.py:261-301), n_scans == 1
             double x = (double)iso_mz_l;
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
                 const double *cy = run.cycle + 2 * ((int64_t)rec.obs[o] * run.cycle_scans + rec.scan_start);
                 const QuadParams qp = adh_quad_params(cfg);
-                q[o] = logistic(x, cy[0] + qp.delta_lo, qp.sigma_lo) - logistic(x, cy[1] + qp.delta_hi, qp.sigma_hi);
-                L.qtf[sub][o] = q[o];
+                L.qtf[sub][o] = logistic(x, cy[0] + qp.delta_lo, qp.sigma_lo) - logistic(x, cy[1] + qp.delta_hi, qp.sigma_hi);
             }
             L.iso_mz[sub] = iso_mz_l;
             L.iso_int[sub] = iso_int_l;
         }
-        float sf = 0.0f;
-        FOR_R sf += A[r];
-        // weighted centre means around (S, 1) (precursor_features.py:52-66)
-        double vh = 0, wh = 0, vm = 0, wm = 0;
-        bool anyh = false, anym = false;
-#pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
-        for (int sc = 0; sc < 2; ++sc) {
-            FOR_R {
-                int f = r + shift;
-                bool ok = iso_lane && f >= 0 && f < F;
-                double w = ok ? wtp_s[sc][f] : 0.0;
-                float a = A[r], b = B[r];
-                OPAQUE(a);
-                OPAQUE(b);
-                if (ok && a > 0.0f) {
-                    anyh = true;
-                    vh += (double)a * w;
-                    wh += w;
+        __syncthreads();
+        // (the isotope rows take the bytes of the template contributions they replace)
+        static_assert(sizeof(L.u.dT) >= 2 * 4 * FM * sizeof(float), "isotope rows: intensity and m/z of four isotopes");
+        float(*const PA)[FM] = reinterpret_cast<float(*)[FM]>(&L.u.dT[0][0]);  // [4][FM] intensity, centred index
+        float(*const PB)[FM] = PA + 4;                                          // [4][FM] m/z
+#pragma unroll
+        for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+            const int r = sub + GS * pass;
+            if (r < FM) {
+                const int f = r + shift;
+                const bool ok = alive && f >= 0 && f < F;
+                double acc[NO];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) acc[o] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool oki = ok && i < I;
+                    const float2 v = pcells[oki ? i * F + f : 0];  // branch-free: clamp the index, mask the value
+                    const float a = oki ? v.x : 0.0f;
+                    PA[i][r] = a;
+                    PB[i][r] = oki ? v.y : 0.0f;
+                    if (i < I) {
+                        // template rows of every observation (quadrupole.py:304-324): zero outside [0, F)
+                        const float ai = a * L.iso_int[i];
+#pragma unroll
+                        for (int o = 0; o < NO; ++o) acc[o] += (double)ai * L.qtf[i][o];
+                    }
                 }
-                if (ok && b > 0.0f) {
-                    anym = true;
-                    vm += (double)b * w;
-                    wm += w;
-                }
-                R_FENCE(r);
+#pragma unroll
+                for (int o = 0; o < NO; ++o) L.tpl[o][r] = (float)acc[o];
             }
         }
-        if (iso_lane) {
-            L.spi[sub] = sf + sf;
-            L.hp[sub] = (anyh && wh > 0) ? vh / wh : 0.0;
-            L.omzp[sub] = (anym && wm > 0) ? vm / wm : 0.0;
-        }
-        // template rows of every observation (quadrupole.py:304-324) and the qtf mask
-        // (candidate.py:287-289)
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            __syncthreads();  // the previous observation's contributions were consumed
-            FOR_R {
-                float a = A[r] * iso_int_l;
-                if (iso_lane) L.u.dT[sub][r] = (double)a * q[o];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
-                int r = sub + GS * pass;
-                if (r < FM) {
-                    double acc = 0;
-                    for (int i = 0; i < I; ++i) acc += L.u.dT[i][r];
-                    L.tpl[o][r] = (float)acc;  // zero outside [0, F)
+        __syncthreads();
+        // weighted centre means around (S, 1) (precursor_features.py:52-66): lane 4 i + c walks isotope row i for
+        // sum c (0: intensity x weight, 1: weight where the intensity is positive, 2 / 3: the same of the m/z channel).
+        // A skipped term is an added + 0.0 (the sums start at + 0.0 and their terms are positive: never - 0.0), a
+        // weight sum adds 1.0 * w = w.
+        {
+            const int ci_ = sub >> 2, ch = sub & 3;
+            const bool chain = alive && ci_ < I;  // (4 I <= 16 <= GS lanes)
+            const float *X = (ch < 2 ? PA : PB)[ci_ & 3];
+            const bool is_value = (ch & 1) == 0;
+            double acc = 0.0;
+            float sfa = 0.0f;
+#pragma unroll 1
+            for (int sc = 0; sc < 2; ++sc) {
+#pragma unroll 4
+                for (int r = 0; r < FM; ++r) {
+                    const int f = r + shift;
+                    const bool ok = chain && f >= 0 && f < F;
+                    const float x = X[r];
+                    const double w = wtp_s[sc][ok ? f : 0];
+                    const double m = is_value ? (double)x : 1.0;
+                    acc += (ok && x > 0.0f) ? m * w : 0.0;
+                    sfa += sc == 0 ? x : 0.0f;  // the row sum over the cycles (the second scan slot doubles it below)
                 }
             }
-            if (sub == 0) {
+            const double wsum = __shfl_down(acc, 1);  // the weight sum of the lane's value sum
+            if (chain && ch == 0) {
+                L.spi[ci_] = sfa + sfa;
+                L.hp[ci_] = wsum > 0 ? acc / wsum : 0.0;
+            }
+            if (chain && ch == 2) L.omzp[ci_] = wsum > 0 ? acc / wsum : 0.0;
+        }
+        // the qtf mask (candidate.py:287-289)
+        if (sub == 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
                 double qs = 0;
                 for (int i = 0; i < I; ++i) qs += L.qtf[i][o];
                 L.qmask[o] = (I > 0) ? (float)(qs / (double)I) : 0.0f;

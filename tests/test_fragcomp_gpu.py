@@ -212,6 +212,29 @@ def test_device_plan_equals_the_numpy_plan(ctx, monkeypatch, seed, n, grouped):
     assert np.array_equal(got.index.to_numpy(), ref.index.to_numpy())
 
 
+@pytest.mark.parametrize("columns", [("proba",), ("mz_observed",), ("proba", "mz_observed", "rt_observed")])
+def test_float64_columns_take_the_numpy_plan_and_give_the_same_frame(ctx, columns):
+    """Frames whose probability / m/z columns are float64 (a classifier that returns doubles) do not qualify for the
+    device-side plan (adh_fragcomp_frames is float32): they go through the NumPy plan and adh_fragcomp, and - the values
+    being the same numbers - must return the frame the float32 columns return (the fallback had no test)."""
+    from alphadia_amd.fragcomp import FragmentCompetition
+
+    rng = np.random.default_rng(4242)
+    psm, frag, cyc = _frames(rng, 6000, grouped=True)
+    fc = FragmentCompetition(rt_tol_seconds=3, mass_tol_ppm=15)
+    ref = fc(psm.copy(), frag.copy(), cyc)
+    psm64, frag64 = psm.copy(), frag.copy()
+    for c in columns:
+        psm64[c] = psm64[c].astype(np.float64)
+        if c in frag64.columns:
+            frag64[c] = frag64[c].astype(np.float64)
+    got = fc(psm64, frag64, cyc)
+    assert 0 < len(ref) < len(psm)
+    assert np.array_equal(got.index.to_numpy(), ref.index.to_numpy())
+    for c in ("precursor_idx", "rank", "_candidate_idx", "valid"):
+        assert np.array_equal(got[c].to_numpy(), ref[c].to_numpy()), c
+
+
 def test_device_plan_reproduces_the_reference_golden(ctx):
     """The reference's own FragmentCompetition run (tests/golden/fragcomp.npz) through the device-side plan."""
     import pandas as pd
