@@ -419,12 +419,10 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
             for (int sc = 0; sc < 2; ++sc) {
 #pragma unroll 4
                 for (int r = 0; r < FM; ++r) {
-                    const int f = r + shift;
-                    const bool ok = chain && f >= 0 && f < F;
-                    const float x = X[r];
-                    const double w = wtp_s[sc][ok ? f : 0];
+                    const float x = X[r];  // (zero outside the candidate's cycles: a positive cell is a cell of the window)
+                    const double w = wtp_s[sc][min(max(r + shift, 0), FM - 1)];
                     const double m = is_value ? (double)x : 1.0;
-                    acc += (ok && x > 0.0f) ? m * w : 0.0;
+                    acc += x > 0.0f ? m * w : 0.0;
                     sfa += sc == 0 ? x : 0.0f;  // the row sum over the cycles (the second scan slot doubles it below)
                 }
             }
@@ -484,23 +482,27 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         // every lane computes it), template frame profile, weights around the centre
         double esc, efc;
         {
-            double isum = 0, ssum = 0, fsum = 0;
-            bool any = false;
+            // The three sequential float64 sums (intensity; scan slot x intensity; cycle x intensity) are independent
+            // chains: lanes 4 j, 4 j + 1, 4 j + 2 of every four walk one each (lane 4 j + 3 repeats the first) and the
+            // four share the results - a third of the instructions of every lane walking all three (round 6).  A cell
+            // that is not positive enters as 0 (its term +-0 changes no sum: they start at + 0.0); 1.0 * v = v.
+            const int ch = sub & 3;
+            double acc = 0.0;
 #pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
             for (int sc = 0; sc < 2; ++sc) {
+                double mr = ch == 2 ? (double)shift : (ch == 1 ? (double)sc : 1.0);  // factor of cycle r: f, sc or 1
+                const double inc = ch == 2 ? 1.0 : 0.0;
                 FOR_R {
-                    float v = L.tpl[o][r];
-                    if (v > 0.0f) {
-                        any = true;
-                        isum += (double)v;
-                        ssum += (double)sc * (double)v;
-                        fsum += (double)(r + shift) * (double)v;
-                    }
+                    const float v = L.tpl[o][r];
+                    acc += mr * (double)__builtin_fmaxf(v, 0.0f);  // (the reference skips v <= 0: its term here is +-0)
+                    mr += inc;
                     R_FENCE(r);
                 }
             }
-            esc = (any && isum > 0) ? ssum / isum : 0.0;
-            efc = (any && isum > 0) ? fsum / isum : 0.0;
+            const int l4 = lane & ~3;
+            const double isum = __shfl(acc, l4), ssum = __shfl(acc, l4 + 1), fsum = __shfl(acc, l4 + 2);
+            esc = isum > 0 ? ssum / isum : 0.0;  // (isum > 0 exactly when a cell is positive)
+            efc = isum > 0 ? fsum / isum : 0.0;
         }
         __syncthreads();  // the previous observation's tables were consumed
         // template frame profile with or_envelope (scoring/utils.py:46-53)
@@ -559,7 +561,6 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         // weighted centre means of both channels (features_utils.py:9-37)
         {
             double vo = 0, wo = 0, vm = 0, wm = 0;
-            bool anyo = false, anym = false;
 #pragma unroll 1  // a real loop: unrolling lets hipcc keep 2 x 32 converted values live
             for (int sc = 0; sc < 2; ++sc) {
                 FOR_R {
@@ -567,21 +568,19 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
                     float a = A[r], b = B[r];
                     OPAQUE(a);
                     OPAQUE(b);
-                    if (a > 0.0f) {
-                        anyo = true;
-                        vo += (double)a * w;
-                        wo += w;
-                    }
-                    if (b > 0.0f) {
-                        anym = true;
-                        vm += (double)b * w;
-                        wm += w;
-                    }
+                    // A skipped cell (value <= 0, features_utils.py:9-37) enters as 0: its product + 0 changes no sum.  Its
+                    // weight stays out: w x 1.0 + wo rounds once, like wo + w; w x 0.0 adds + 0 (one select on the high
+                    // word of the indicator instead of two on the weight; as in adh_fused.hip)
+                    vo += (double)__builtin_fmaxf(a, 0.0f) * w;
+                    wo = __builtin_fma(w, __hiloint2double(a > 0.0f ? 0x3ff00000 : 0, 0), wo);
+                    vm += (double)__builtin_fmaxf(b, 0.0f) * w;
+                    wm = __builtin_fma(w, __hiloint2double(b > 0.0f ? 0x3ff00000 : 0, 0), wm);
                     R_FENCE(r);
                 }
             }
-            L.ohe[sub][o] = (anyo && wo > 0) ? vo / wo : 0.0;
-            L.omz[sub][o] = (anym && wm > 0) ? vm / wm : 0.0;
+            // (the weights of the window's cells are positive: a weight sum is positive exactly when a cell counted)
+            L.ohe[sub][o] = wo > 0 ? vo / wo : 0.0;
+            L.omz[sub][o] = wm > 0 ? vm / wm : 0.0;
         }
         if (NO > 1) {
             // per-observation frame profile (frame_profile_2d): statistics against this
