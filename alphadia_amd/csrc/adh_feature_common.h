@@ -116,6 +116,114 @@ __device__ __forceinline__ void assemble_precursor(const Assemble &q, int I, int
         }
 }
 
+// assemble_precursor for at most four isotopes and OM observations with every table read ONCE, up front, and the loops
+// over isotopes / observations unrolled under predicates - the same operations in the same order.  The loop form above
+// is a chain of ~80 dependent LDS reads of a single lane, which the register kernels' wavefronts (two per SIMD) cannot
+// hide: half of the "fragment features" step of the wide kernels (round 6).  Features 0-3 are the caller's.
+template <int OM>
+__device__ __forceinline__ void assemble_precursor_regs(const Assemble &q, int I, int O) {
+    float *ft = q.featv;
+    ft[28] = (float)((double)q.n_present / (double)q.K0);  // candidate.py:362
+    float ii[4], im[4], sp[4], oi[OM];
+    double oz[4], hp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // (entries at and above I are never used)
+        ii[i] = q.iso_int[i];
+        im[i] = q.iso_mz[i];
+        sp[i] = q.spi[i];
+        oz[i] = q.omzp[i];
+        hp[i] = q.hp[i];
+    }
+#pragma unroll
+    for (int o = 0; o < OM; ++o) oi[o] = q.oi[o];
+    // precursor_features.py:13-102
+    int amax = 0;
+    float best = ii[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < I && ii[i] > best) best = ii[i], amax = i;
+    float w4 = 0, w5 = 0, f6 = 0, f7 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < I) {
+            float a = 0;
+#pragma unroll
+            for (int o = 0; o < OM; ++o)
+                if (o < O) a += sp[i] * oi[o];
+            if (i == 0) w4 = a;
+            if (i == amax) w5 = a;
+            f6 += a;
+            f7 += a * ii[i];
+        }
+    ft[4] = w4;
+    ft[5] = w5;
+    ft[6] = f6;
+    ft[7] = f7;
+    double wme = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < I && oz[i] > 0) {
+            double me = (oz[i] - (double)im[i]) / (double)im[i] * 1e6;
+            wme += me * (double)ii[i];
+        }
+    ft[8] = (float)wme;
+    ft[9] = (float)fabs(wme);
+    ft[10] = (float)((double)im[0] + wme * 1e-6 * (double)im[0]);
+    ft[11] = (float)hp[0];
+    double hp_amax = hp[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) hp_amax = i == amax ? hp[i] : hp_amax;
+    ft[12] = (float)hp_amax;
+    {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) a += hp[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) b += hp[i] * (double)ii[i];
+        ft[13] = (float)a;
+        ft[14] = (float)b;
+    }
+    {
+        // save_corrcoeff (scoring/utils.py:478-510): (f32, f32) and (f32, f64)
+        float sx = 0, sy = 0;
+        double sh = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) sx += ii[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) sy += sp[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) sh += hp[i];
+        float xb = (float)((double)sx / (double)I), yb = (float)((double)sy / (double)I);
+        double hb = sh / (double)I;
+        float num = 0, sxx = 0, syy = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) num += (ii[i] - xb) * (sp[i] - yb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) sxx += (ii[i] - xb) * (ii[i] - xb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) syy += (sp[i] - yb) * (sp[i] - yb);
+        float den = sqrtf(sxx * syy);
+        ft[15] = (float)((double)num / ((double)den + 1e-12));
+        double numd = 0, shh = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) numd += (double)(ii[i] - xb) * (hp[i] - hb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I) shh += (hp[i] - hb) * (hp[i] - hb);
+        double dend = sqrt((double)sxx * shh);
+        ft[16] = (float)(numd / (dend + 1e-12));
+    }
+}
+
 // features 17-27, 41-45 (fragment_features.py:198-427)
 __device__ __forceinline__ void assemble_fragments(const Assemble &q, int O, int K) {
         float *ft = q.featv;

@@ -356,6 +356,20 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     {
         const float2 *pcells =
             reinterpret_cast<const float2 *>(block + adh_scratch_prec_off(rec.k_cap, O, F));
+        // (the cells of step 2 are requested first: their round trip runs beside the logistic pairs of step 1)
+        constexpr int PP = (FM + GS - 1) / GS;
+        float2 pv[PP][4];
+#pragma unroll
+        for (int pass = 0; pass < PP; ++pass) {
+            const int f = sub + GS * pass + shift;
+            const bool ok = alive && sub + GS * pass < FM && f >= 0 && f < F;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool oki = ok && i < I;
+                const float2 v = pcells[oki ? i * F + f : 0];  // branch-free: clamp the index, mask the value
+                pv[pass][i] = oki ? v : make_float2(0.0f, 0.0f);
+            }
+        }
         if (iso_lane) {
             const float iso_int_l = iso_table[(int64_t)row * n_iso_cols + sub];
             double off = (double)sub * 1.0033548350700006 / (double)rec.charge;  // candidate.py:158-163
@@ -377,21 +391,17 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         float(*const PA)[FM] = reinterpret_cast<float(*)[FM]>(&L.u.dT[0][0]);  // [4][FM] intensity, centred index
         float(*const PB)[FM] = PA + 4;                                          // [4][FM] m/z
 #pragma unroll
-        for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+        for (int pass = 0; pass < PP; ++pass) {
             const int r = sub + GS * pass;
             if (r < FM) {
-                const int f = r + shift;
-                const bool ok = alive && f >= 0 && f < F;
                 double acc[NO];
 #pragma unroll
                 for (int o = 0; o < NO; ++o) acc[o] = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool oki = ok && i < I;
-                    const float2 v = pcells[oki ? i * F + f : 0];  // branch-free: clamp the index, mask the value
-                    const float a = oki ? v.x : 0.0f;
+                    const float a = pv[pass][i].x;
                     PA[i][r] = a;
-                    PB[i][r] = oki ? v.y : 0.0f;
+                    PB[i][r] = pv[pass][i].y;
                     if (i < I) {
                         // template rows of every observation (quadrupole.py:304-324): zero outside [0, F)
                         const float ai = a * L.iso_int[i];
@@ -721,7 +731,7 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         asmv.iso_int = L.iso_int; asmv.iso_mz = L.iso_mz; asmv.spi = L.spi; asmv.oi = L.oi;
         asmv.omzp = L.omzp; asmv.hp = L.hp;
         asmv.n_present = n_present; asmv.K0 = K0;
-        feat::assemble_precursor(asmv, I, O);
+        feat::assemble_precursor_regs<NO>(asmv, I, O);  // (I <= 4: the host plan)
     }
     // ---- fragment features 17-27, 41-45 (fragment_features.py:198-427; the scalar form is
     // feat::assemble_fragments).  Every sum over fragments keeps the reference's order
@@ -999,21 +1009,38 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     // feat::assemble_part2), sums organised as above
     {
         const int r_lo = (K - 1) / 2, r_hi = K / 2;
-        if (present) {
-            // median apex per observation (profile_features.py:196-198): rank of this fragment's apex
+        // median apex per observation (profile_features.py:196-198): rank of this fragment's apex
+        int apex[NO], apex_rk[NO];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                const int va = L.fpeak[sub][o];
-                int rk = 0;
+        for (int o = 0; o < NO; ++o) {
+            const int va = L.fpeak[sub][o];
+            int rk = 0;
+            if constexpr (GS > 16) {
+                // wide form: a real loop over the lanes that hold a fragment; lane b's apex is a lane read of the
+                // register it sits in (b is uniform), not an LDS read whose latency every trip would wait for (round 6)
+                const int kmax = __builtin_amdgcn_readfirstlane(GS == 64 ? K0 : max(K0, __shfl_xor(K0, 32)));
+                for (int b = 0; b < kmax; ++b) {
+                    int vb = __builtin_amdgcn_readlane(va, b);
+                    if constexpr (GS == 32) vb = g ? __builtin_amdgcn_readlane(va, 32 + b) : vb;
+                    const bool pb = (gm >> b) & 1ull;  // (no bit at or above K0)
+                    rk += (int)(pb & ((vb < va) | ((vb == va) & (b < sub))));
+                }
+            } else {
 #pragma unroll
                 for (int b = 0; b < GS; ++b) {
-                    if (GS > 16 && b >= K0) break;  // (wide form: a real loop over the lanes that hold a fragment)
                     if (!((gm >> b) & 1ull)) continue;
                     int vb = L.fpeak[b][o];
                     rk += (int)((vb < va) | ((vb == va) & (b < sub)));
                 }
-                if (rk == r_lo) L.medlo[o] = va;
-                if (rk == r_hi) L.medhi[o] = va;
+            }
+            apex[o] = va;
+            apex_rk[o] = rk;
+        }
+        if (present) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                if (apex_rk[o] == r_lo) L.medlo[o] = apex[o];
+                if (apex_rk[o] == r_hi) L.medhi[o] = apex[o];
             }
             const float cr = L.corr[L.ord[kk]];  // correlation of the fragment with intensity rank kk
             // b / y: mask in original order applied to the sorted index array (profile_features.py:94-113)
