@@ -343,6 +343,28 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     }
 
     float A[FM], B[FM];
+    // The fragment rows of the first observation are requested HERE, ahead of the precursor phase that does not use the
+    // registers: their round trip runs beside it instead of behind it (two wavefronts per SIMD hide nothing; round 6).
+    // The quadrupole mask (a result of the precursor phase) is applied where the rows are used.
+    float frt_l[(FM + GS - 1) / GS];  // frame RTs of the cycles sub, sub + GS, ...
+#pragma unroll
+    for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
+        int r = min(sub + GS * pass, FM - 1);  // (duplicates of the last row hold the same value)
+        int f = r + shift;
+        bool ok = alive && f >= 0 && f < F;
+        frt_l[pass] = ok ? run.rt[rec.frame_start + f * Lc] : 0.0f;
+    }
+    const bool frag_lane0 = alive && sub < K0;
+    {
+        const float2 *fcells = reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(rec.k_cap));
+        FOR_R {
+            int f = r + shift;
+            bool ok = frag_lane0 && f >= 0 && f < F;
+            float2 v = fcells[ok ? f * K0 + sub : 0];  // branch-free: clamp the index, mask the value
+            A[r] = ok ? v.x : 0.0f;
+            B[r] = ok ? v.y : 0.0f;
+        }
+    }
 
     // ================= precursor phase =================
     // Three steps since round 6 (before: lane i < I held isotope row i in registers and walked it alone, 3 of a candidate's
@@ -464,14 +486,9 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         }
         L.tsum[sub] = st + st;
     }
-    // frame RTs
+    // frame RTs (requested ahead of the precursor phase)
 #pragma unroll
-    for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) {
-        int r = min(sub + GS * pass, FM - 1);  // (duplicates of the last row write the same value)
-        int f = r + shift;
-        bool ok = alive && f >= 0 && f < F;
-        L.frt[r] = ok ? run.rt[rec.frame_start + f * Lc] : 0.0f;
-    }
+    for (int pass = 0; pass < (FM + GS - 1) / GS; ++pass) L.frt[min(sub + GS * pass, FM - 1)] = frt_l[pass];
     __syncthreads();
     {
         float tot = 0.0f;
@@ -482,7 +499,6 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
     if (stop_phase == 32) return;
 
     // ================= fragment phase: lane = fragment, one pass per observation =================
-    const bool frag_lane0 = alive && sub < K0;
     float P[FM];  // frame profile summed over observations (frame_profile_2d + sum over o)
     FOR_R P[r] = 0.0f;
     float so = 0.0f;
@@ -554,12 +570,20 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
             const float2 *fcells =
                 reinterpret_cast<const float2 *>(block + adh_scratch_frag_off(rec.k_cap));
             const float qmask = L.qmask[o];
-            FOR_R {
-                int f = r + shift;
-                bool ok = frag_lane0 && f >= 0 && f < F;
-                float2 v = fcells[ok ? (o * F + f) * K0 + sub : 0];
-                A[r] = ok ? v.x * qmask : 0.0f;  // candidate.py:290
-                B[r] = ok ? v.y : 0.0f;
+            if (o == 0) {  // (requested ahead of the precursor phase)
+                FOR_R {
+                    int f = r + shift;
+                    bool ok = frag_lane0 && f >= 0 && f < F;
+                    A[r] = ok ? A[r] * qmask : 0.0f;  // candidate.py:290
+                }
+            } else {
+                FOR_R {
+                    int f = r + shift;
+                    bool ok = frag_lane0 && f >= 0 && f < F;
+                    float2 v = fcells[ok ? (o * F + f) * K0 + sub : 0];
+                    A[r] = ok ? v.x * qmask : 0.0f;  // candidate.py:290
+                    B[r] = ok ? v.y : 0.0f;
+                }
             }
         }
         // presence (candidate.py:319-329): row sum over the two identical scan slots
