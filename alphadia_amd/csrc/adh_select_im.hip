@@ -92,8 +92,7 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
         s_raw[lane] = (cfg.exclude_shared_ions && f.cardinality > 1) ? -1.0f : f.mz;
     }
     __syncthreads();
-    int K = 0;
-    for (int j = 0; j < n_lib; ++j) K += s_raw[j] >= 0.0f;
+    const int K = __popcll(__ballot(lane < n_lib && s_raw[lane] >= 0.0f));  // (n_lib <= MAX_W <= 64; this lane's own write)
     if (K <= 3 || K + n_iso > MAX_W) {  // selection.py:141 (more than MAX_W windows: rejected by the host)
         if (lane == 0) header[0] = 0;
         return;
@@ -113,7 +112,23 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_select_gather_im_kernel(
     __syncthreads();
     const int W = K + n_iso;
     // TOF index limits of every window: searchsorted(mz_values, mass_range(...), "left")
-    if (lane < W) {
+    if (W <= ADH_WAVE / 2) {
+        // two lanes per window, one per end (as adh_gather_im_kernel: the searches are dependent look-ups of a wavefront
+        // with nothing else to do)
+        const int w = lane & (ADH_WAVE / 2 - 1);
+        const bool upper = lane >= ADH_WAVE / 2, act = w < W;
+        int bound = 0;
+        if (act) {
+            const float m = s_mz[w];
+            const float tol = (float)(w < K ? cfg.fragment_mz_tolerance : cfg.precursor_mz_tolerance);
+            float t = tol * m;
+            float q = t / 1000000.0f;
+            bound = index_im::tof_lower_bound(run, (double)(upper ? m + q : m - q));
+        }
+        const int other = __shfl(bound, lane ^ (ADH_WAVE / 2));  // the lower end, seen from the upper lane
+        if (act && !upper) s_tlo[w] = bound;
+        if (act && upper) s_thi[w] = bound > other ? bound : other;
+    } else if (lane < W) {
         const float m = s_mz[lane];
         const float tol = (float)(lane < K ? cfg.fragment_mz_tolerance : cfg.precursor_mz_tolerance);
         float t = tol * m;
