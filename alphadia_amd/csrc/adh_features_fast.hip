@@ -206,34 +206,24 @@ __device__ __forceinline__ void profile_stats(const float (&P)[FM], const float 
         R_FENCE(r);
     }
     const float ym = syt / (float)F;
-    float qy = 0.0f;
-    FOR_R {
-        int f = r + shift;
-        bool ok = f >= 0 && f < F;
-        float d = ok ? tfp[r] - ym : 0.0f;
-        qy += d * d;
-        R_FENCE(r);
-    }
-    const float ysd = sqrtf(qy / (float)F);
     float sy = 0.0f;
     FOR_R sy += P[r];
     const float xmn = sy / (float)F;
-    float qx = 0.0f, dot = 0.0f;
-    FOR_R {
-        int f = r + shift;
-        bool ok = f >= 0 && f < F;
-        float d = ok ? P[r] - xmn : 0.0f;
-        qx += d * d;
-    }
-    const float xsd = sqrtf(qx / (float)F);
+    // the three sums of squares and products in ONE pass (each keeps its own order; round 6: the deviations were
+    // computed twice and the template row read three times)
+    float qy = 0.0f, qx = 0.0f, dot = 0.0f;
     FOR_R {
         int f = r + shift;
         bool ok = f >= 0 && f < F;
         float dx = ok ? P[r] - xmn : 0.0f;
         float dy = ok ? tfp[r] - ym : 0.0f;
+        qy += dy * dy;
+        qx += dx * dx;
         dot += dx * dy;
         R_FENCE(r);
     }
+    const float ysd = sqrtf(qy / (float)F);
+    const float xsd = sqrtf(qx / (float)F);
     const float cv = dot / (float)F;
     const float smm = xsd * ysd;
     ftc = (float)((double)cv / ((double)smm + 1e-12));
@@ -988,31 +978,20 @@ __device__ __forceinline__ void adh_fast_body(const DevRun &run, const CandRec *
         }
         const float mx = (float)((double)sx / (double)F);
         float sxx = 0.0f, sy = 0.0f;
-        FOR_R {
-            int f = r + shift;
-            bool ok = f >= 0 && f < F;
-            float xm = ok ? L.med[r] - mx : 0.0f;
-            sxx += xm * xm;
-            R_FENCE(r);
-        }
-        const double var_x = (double)sxx / (double)F;
         FOR_R sy += P[r];
         const float my = (float)((double)sy / (double)F);
         float sxy = 0.0f, syy = 0.0f;
-        FOR_R {
+        FOR_R {  // (one pass for the three sums, each in its own order)
             int f = r + shift;
             bool ok = f >= 0 && f < F;
             float xm = ok ? L.med[r] - mx : 0.0f;
             float ym = ok ? P[r] - my : 0.0f;
+            sxx += xm * xm;
             sxy += xm * ym;
+            syy += ym * ym;
             R_FENCE(r);
         }
-        FOR_R {
-            int f = r + shift;
-            bool ok = f >= 0 && f < F;
-            float ym = ok ? P[r] - my : 0.0f;
-            syy += ym * ym;
-        }
+        const double var_x = (double)sxx / (double)F;
         const double cov = (double)sxy / (double)F;
         const double var_y = (double)syy / (double)F;
         const double var_xy = var_x * var_y;
