@@ -813,31 +813,40 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
                 const int twin = c == ADH_CLASS_WIDE2 ? ADH_CLASS_MID2 : ADH_CLASS_MID1;
                 int64_t twin_first = first;
                 for (int q = c; q < twin; ++q) twin_first += p.n_class[q];
-                WideClasses wcs{};
-                int64_t blocks = 0, pos = first;
-                for (int j = 0; j < 6; ++j) {
-                    const int q = j < 3 ? c + j : twin + (j - 3);
-                    if (j == 3) pos = twin_first;
-                    const int64_t nq = p.n_class[q];
-                    if (nq > 0) {
-                        const int per = j < 3 ? 1 : 2;
-                        wcs.first_block[wcs.n] = (int32_t)blocks;
-                        wcs.first_cand[wcs.n] = (int32_t)(pos - n_fused);
-                        wcs.n_cand[wcs.n] = (int32_t)nq;
-                        wcs.kind[wcs.n] = j;
-                        ++wcs.n;
-                        blocks += (nq + per - 1) / per;
+                // two launches: the heavy bodies first, then the ones that fit three wavefronts per SIMD
+                // (adh_wide_light_kinds; without the split the second set is empty)
+                const int light = c == ADH_CLASS_WIDE2 ? adh_wide_light_kinds<2>() : adh_wide_light_kinds<1>();
+                for (int part = 0; part < 2; ++part) {
+                    const int kinds = part == 0 ? (ADH_WIDE_ALL & ~light) : light;
+                    WideClasses wcs{};
+                    int64_t blocks = 0, pos = first;
+                    for (int j = 0; j < 6; ++j) {
+                        const int q = j < 3 ? c + j : twin + (j - 3);
+                        if (j == 3) pos = twin_first;
+                        const int64_t nq = p.n_class[q];
+                        if (nq > 0 && ((kinds >> j) & 1)) {
+                            const int per = j < 3 ? 1 : 2;
+                            wcs.first_block[wcs.n] = (int32_t)blocks;
+                            wcs.first_cand[wcs.n] = (int32_t)(pos - n_fused);
+                            wcs.n_cand[wcs.n] = (int32_t)nq;
+                            wcs.kind[wcs.n] = j;
+                            ++wcs.n;
+                            blocks += (nq + per - 1) / per;
+                        }
+                        pos += nq;
                     }
-                    pos += nq;
-                }
-                wcs.first_block[wcs.n] = (int32_t)blocks;
-                if (blocks > 0) {
+                    wcs.first_block[wcs.n] = (int32_t)blocks;
+                    if (blocks == 0) continue;
                     const CandRec *base = p.d_recs + n_fused;
                     const WideArgs wa{h->run, base, wcs, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase};
-                    if (c == ADH_CLASS_WIDE2)
-                        hipLaunchKernelGGL((adh_feature_wide_kernel<2>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, wa);
-                    else
-                        hipLaunchKernelGGL((adh_feature_wide_kernel<1>), dim3((unsigned)blocks), dim3(ADH_WAVE), 0, st, wa);
+                    const dim3 grid((unsigned)blocks), wave(ADH_WAVE);
+                    if (c == ADH_CLASS_WIDE2) {
+                        if (part == 0) hipLaunchKernelGGL((adh_feature_wide_kernel<2, ADH_WIDE_ALL & ~adh_wide_light_kinds<2>()>), grid, wave, 0, st, wa);
+                        else hipLaunchKernelGGL((adh_feature_wide_kernel<2, adh_wide_light_kinds<2>()>), grid, wave, 0, st, wa);
+                    } else {
+                        if (part == 0) hipLaunchKernelGGL((adh_feature_wide_kernel<1, ADH_WIDE_ALL & ~adh_wide_light_kinds<1>()>), grid, wave, 0, st, wa);
+                        else hipLaunchKernelGGL((adh_feature_wide_kernel<1, adh_wide_light_kinds<1>()>), grid, wave, 0, st, wa);
+                    }
                     HIP_TRY(hipGetLastError());
                 }
             }
