@@ -1137,44 +1137,46 @@ __global__ __launch_bounds__(ADH_WAVE) void adh_feature_fast_kernel(
                               stop_phase, smem);
 }
 
-// The wide classes of one batch (17 ... 64 fragments kept) in ONE launch per observation count: a chunk of the
-// host -> host pipeline holds a few thousand candidates of each (cycles, lanes) class, a wavefront lives ~50 us, and
-// six launches of two rounds each spent most of their time filling and draining the GPU.
-#define ADH_WIDE_MAX_CLASSES 6
+// The wide classes of one batch (17 ... 64 fragments kept) in TWO launches: a chunk of the host -> host pipeline holds a
+// few thousand candidates of each (observations, cycles, lanes) class, a wavefront lives ~50 us, and twelve launches
+// of two rounds each spent most of their time filling and draining the GPU (round 5: one launch per observation
+// count).  Round 6: one kernel runs at the register count and LDS block of its LARGEST body, and the wide kernels wait
+// for dependent round trips - two wavefronts per SIMD hide little.  The bodies that fit three wavefronts per SIMD (16
+// cycles with either lane count; 24 cycles on 64 lanes for one observation: <= 157 registers, <= 12.7 KB) of BOTH
+// observation counts go out as one launch behind the heavy ones of both.  ADH_WIDE_SPLIT=0: everything in one launch.
+// A kind is (FM - 16) / 8 + 3 * (lanes per candidate == 32) + 6 * (observations == 2).
+#define ADH_WIDE_MAX_CLASSES 12
 struct WideClasses {
     int32_t n;                                      // classes in this launch
     int32_t first_block[ADH_WIDE_MAX_CLASSES + 1];  // first wavefront of class i; [n] = all
     int32_t first_cand[ADH_WIDE_MAX_CLASSES];       // first candidate of the class, counted from `plan`
     int32_t n_cand[ADH_WIDE_MAX_CLASSES];
-    int32_t kind[ADH_WIDE_MAX_CLASSES];             // (FM - 16) / 8 + 3 * (lanes per candidate == 32)
+    int32_t kind[ADH_WIDE_MAX_CLASSES];
 };
-// The bodies of a launch as a bit set of kinds.  One kernel runs at the register count and LDS block of its LARGEST body,
-// and the wide kernels wait for dependent round trips (two wavefronts per SIMD hide little): the bodies that fit three
-// wavefronts per SIMD - 16 cycles with either lane count, 24 cycles on 64 lanes for one observation: 132 ... 157
-// registers, <= 11.5 KB - go out as a launch of their own behind the heavy ones (round 6).  ADH_WIDE_SPLIT=0: one launch.
 #ifndef ADH_WIDE_SPLIT
 #define ADH_WIDE_SPLIT 1
 #endif
-#define ADH_WIDE_ALL 0x3F
-template <int NO>
-constexpr int adh_wide_light_kinds() {
-    // kinds {0, 1, 3} of one observation.  Two observations stay in one launch: their light bodies {0, 3} are a fifth
-    // of the launch and the second launch's fill and drain cost more than three wavefronts per SIMD return (measured:
-    // 194 -> 157 + 74 us)
-    return ADH_WIDE_SPLIT && NO == 1 ? 0x0B : 0;
-}
-template <int NO, int KINDS>
+#define ADH_WIDE_ALL 0xFFF
+#define ADH_WIDE_LIGHT (ADH_WIDE_SPLIT ? (0x00B | (0x009 << 6)) : 0)  // kinds {0, 1, 3} of one, {0, 3} of two observations
+#define ADH_WIDE_HEAVY (ADH_WIDE_ALL & ~ADH_WIDE_LIGHT)
+template <int KINDS>
 constexpr size_t adh_wide_lds_bytes() {
     size_t b = 0;
     auto take = [&](int kind, size_t bytes) {
         if (((KINDS >> kind) & 1) && bytes > b) b = bytes;
     };
-    take(0, adh_fast_lds_bytes<16, NO, 64>());
-    take(1, adh_fast_lds_bytes<24, NO, 64>());
-    take(2, adh_fast_lds_bytes<32, NO, 64>());
-    take(3, adh_fast_lds_bytes<16, NO, 32>());
-    take(4, adh_fast_lds_bytes<24, NO, 32>());
-    take(5, adh_fast_lds_bytes<32, NO, 32>());
+    take(0, adh_fast_lds_bytes<16, 1, 64>());
+    take(1, adh_fast_lds_bytes<24, 1, 64>());
+    take(2, adh_fast_lds_bytes<32, 1, 64>());
+    take(3, adh_fast_lds_bytes<16, 1, 32>());
+    take(4, adh_fast_lds_bytes<24, 1, 32>());
+    take(5, adh_fast_lds_bytes<32, 1, 32>());
+    take(6, adh_fast_lds_bytes<16, 2, 64>());
+    take(7, adh_fast_lds_bytes<24, 2, 64>());
+    take(8, adh_fast_lds_bytes<32, 2, 64>());
+    take(9, adh_fast_lds_bytes<16, 2, 32>());
+    take(10, adh_fast_lds_bytes<24, 2, 32>());
+    take(11, adh_fast_lds_bytes<32, 2, 32>());
     return b ? b : 16;  // (no bodies: the empty second launch of a build without the split)
 }
 // The arguments travel as ONE struct read through the kernel-argument segment where they are needed (round 6, as
@@ -1193,15 +1195,11 @@ struct WideArgs {
     DevOut out;
     int32_t stop_phase;
 };
-// Two wavefronts per SIMD as the register budget of the two-observation kernel's heavy bodies: left alone they take
-// 256 + 6 registers and run ONE wavefront per SIMD (round 6: 364 -> 274 us per launch of the transfer-requantification
-// leg; the same budget on the one-observation kernel, which fits two anyway, moves its allocation and costs 8 %).
-#ifndef ADH_WIDE1_WAVES
-#define ADH_WIDE1_WAVES 1  // (build switch for the A/B: 3 = 168 registers, the 32-cycle bodies spill)
-#endif
-#define ADH_WIDE_WAVES_ATTR \
-    __attribute__((amdgpu_waves_per_eu(KINDS == adh_wide_light_kinds<NO>() ? 1 : (NO == 2 ? 2 : ADH_WIDE1_WAVES))))
-template <int NO, int KINDS>
+// Two wavefronts per SIMD as the register budget of the heavy launch: left alone the two-observation bodies of 24 cycles
+// take 256 + 6 registers and run ONE wavefront per SIMD (round 6: 364 -> 274 us per launch of the
+// transfer-requantification leg).
+#define ADH_WIDE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(KINDS == ADH_WIDE_LIGHT ? 1 : 2)))
+template <int KINDS>
 __global__ __launch_bounds__(ADH_WAVE) ADH_WIDE_WAVES_ATTR void adh_feature_wide_kernel(WideArgs formal_args_not_read) {
     const WideArgs &A = *(const WideArgs *)__builtin_amdgcn_kernarg_segment_ptr();  // (the only argument: offset 0)
     const DevRun &run = A.run;
@@ -1214,26 +1212,32 @@ __global__ __launch_bounds__(ADH_WAVE) ADH_WIDE_WAVES_ATTR void adh_feature_wide
     const double *__restrict__ wtp_table = A.wtp_table;
     const DevOut &out = A.out;
     const int32_t stop_phase = A.stop_phase;
-    __shared__ __align__(16) unsigned char smem[adh_wide_lds_bytes<NO, KINDS>()];
+    __shared__ __align__(16) unsigned char smem[adh_wide_lds_bytes<KINDS>()];
     const int32_t b = (int32_t)blockIdx.x;
     int c = 0;
     while (c + 1 < wc.n && b >= wc.first_block[c + 1]) ++c;
     const CandRec *recs = plan + wc.first_cand[c];
     const int32_t n = wc.n_cand[c], blk = b - wc.first_block[c];
-#define ADH_WIDE_CASE(KIND, FM, GS)                                                                                        \
+#define ADH_WIDE_CASE(KIND, NO, FM, GS)                                                                                    \
     if constexpr ((KINDS >> KIND) & 1) {                                                                                   \
         if (wc.kind[c] == KIND) {                                                                                          \
-            static_assert(adh_fast_lds_bytes<FM, NO, GS>() <= adh_wide_lds_bytes<NO, KINDS>(), "the largest body's block"); \
+            static_assert(adh_fast_lds_bytes<FM, NO, GS>() <= adh_wide_lds_bytes<KINDS>(), "the largest body's block");    \
             adh_fast_body<FM, NO, GS>(run, recs, n, blk, iso_table, n_iso_cols, cfg, scratch, wtp_table, out, stop_phase,  \
                                       smem);                                                                               \
             return;                                                                                                        \
         }                                                                                                                  \
     }
-    ADH_WIDE_CASE(0, 16, 64)
-    ADH_WIDE_CASE(1, 24, 64)
-    ADH_WIDE_CASE(2, 32, 64)
-    ADH_WIDE_CASE(3, 16, 32)
-    ADH_WIDE_CASE(4, 24, 32)
-    ADH_WIDE_CASE(5, 32, 32)
+    ADH_WIDE_CASE(0, 1, 16, 64)
+    ADH_WIDE_CASE(1, 1, 24, 64)
+    ADH_WIDE_CASE(2, 1, 32, 64)
+    ADH_WIDE_CASE(3, 1, 16, 32)
+    ADH_WIDE_CASE(4, 1, 24, 32)
+    ADH_WIDE_CASE(5, 1, 32, 32)
+    ADH_WIDE_CASE(6, 2, 16, 64)
+    ADH_WIDE_CASE(7, 2, 24, 64)
+    ADH_WIDE_CASE(8, 2, 32, 64)
+    ADH_WIDE_CASE(9, 2, 16, 32)
+    ADH_WIDE_CASE(10, 2, 24, 32)
+    ADH_WIDE_CASE(11, 2, 32, 32)
 #undef ADH_WIDE_CASE
 }

@@ -807,46 +807,40 @@ int launch_scoring(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, adh_
         int64_t first = n_fused;
         for (int c = ADH_CLASS_FAST2; c <= ADH_CLASS_GENERIC; ++c) {
             const bool wide_class = c >= ADH_CLASS_WIDE2 && c < ADH_CLASS_GENERIC;
-            if (wide_class && run_fast && (c == ADH_CLASS_WIDE2 || c == ADH_CLASS_WIDE1)) {
-                // the wide classes of one observation count in ONE launch: classes c .. c + 2 (one candidate per
-                // wavefront) and their 32-lane twins six classes further on
-                const int twin = c == ADH_CLASS_WIDE2 ? ADH_CLASS_MID2 : ADH_CLASS_MID1;
-                int64_t twin_first = first;
-                for (int q = c; q < twin; ++q) twin_first += p.n_class[q];
-                // two launches: the heavy bodies first, then the ones that fit three wavefronts per SIMD
-                // (adh_wide_light_kinds; without the split the second set is empty)
-                const int light = c == ADH_CLASS_WIDE2 ? adh_wide_light_kinds<2>() : adh_wide_light_kinds<1>();
+            if (wide_class && run_fast && c == ADH_CLASS_WIDE2) {
+                // the wide classes in two launches (adh_features_fast.hip): classes WIDE2 .. WIDE2 + 2 / WIDE1 .. WIDE1 + 2
+                // (one candidate per wavefront) and their 32-lane twins MID2 .. / MID1 .., which follow each other in
+                // the plan's order: the heavy bodies first, then the ones that fit three wavefronts per SIMD
+                int64_t class_first[ADH_N_CLASSES];
+                {
+                    int64_t at = first;
+                    for (int q = c; q < ADH_CLASS_GENERIC; ++q) class_first[q] = at, at += p.n_class[q];
+                }
                 for (int part = 0; part < 2; ++part) {
-                    const int kinds = part == 0 ? (ADH_WIDE_ALL & ~light) : light;
+                    const int kinds = part == 0 ? ADH_WIDE_HEAVY : ADH_WIDE_LIGHT;
                     WideClasses wcs{};
-                    int64_t blocks = 0, pos = first;
-                    for (int j = 0; j < 6; ++j) {
-                        const int q = j < 3 ? c + j : twin + (j - 3);
-                        if (j == 3) pos = twin_first;
+                    int64_t blocks = 0;
+                    for (int kind = 0; kind < 12; ++kind) {
+                        const int j = kind % 6, two = kind / 6;
+                        const int q = (j < 3 ? (two ? ADH_CLASS_WIDE2 : ADH_CLASS_WIDE1) : (two ? ADH_CLASS_MID2 : ADH_CLASS_MID1)) + j % 3;
                         const int64_t nq = p.n_class[q];
-                        if (nq > 0 && ((kinds >> j) & 1)) {
+                        if (nq > 0 && ((kinds >> kind) & 1)) {
                             const int per = j < 3 ? 1 : 2;
                             wcs.first_block[wcs.n] = (int32_t)blocks;
-                            wcs.first_cand[wcs.n] = (int32_t)(pos - n_fused);
+                            wcs.first_cand[wcs.n] = (int32_t)(class_first[q] - n_fused);
                             wcs.n_cand[wcs.n] = (int32_t)nq;
-                            wcs.kind[wcs.n] = j;
+                            wcs.kind[wcs.n] = kind;
                             ++wcs.n;
                             blocks += (nq + per - 1) / per;
                         }
-                        pos += nq;
                     }
                     wcs.first_block[wcs.n] = (int32_t)blocks;
                     if (blocks == 0) continue;
                     const CandRec *base = p.d_recs + n_fused;
                     const WideArgs wa{h->run, base, wcs, h->cs.iso, n_iso, *cfg, d_scratch, h->d_wtp, *out, (int32_t)stop_phase};
                     const dim3 grid((unsigned)blocks), wave(ADH_WAVE);
-                    if (c == ADH_CLASS_WIDE2) {
-                        if (part == 0) hipLaunchKernelGGL((adh_feature_wide_kernel<2, ADH_WIDE_ALL & ~adh_wide_light_kinds<2>()>), grid, wave, 0, st, wa);
-                        else hipLaunchKernelGGL((adh_feature_wide_kernel<2, adh_wide_light_kinds<2>()>), grid, wave, 0, st, wa);
-                    } else {
-                        if (part == 0) hipLaunchKernelGGL((adh_feature_wide_kernel<1, ADH_WIDE_ALL & ~adh_wide_light_kinds<1>()>), grid, wave, 0, st, wa);
-                        else hipLaunchKernelGGL((adh_feature_wide_kernel<1, adh_wide_light_kinds<1>()>), grid, wave, 0, st, wa);
-                    }
+                    if (part == 0) hipLaunchKernelGGL((adh_feature_wide_kernel<ADH_WIDE_HEAVY>), grid, wave, 0, st, wa);
+                    else hipLaunchKernelGGL((adh_feature_wide_kernel<ADH_WIDE_LIGHT>), grid, wave, 0, st, wa);
                     HIP_TRY(hipGetLastError());
                 }
             }

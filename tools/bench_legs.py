@@ -344,7 +344,7 @@ def transfer_requant_leg(ctx, n_prec: int = 100_000, n_cycles: int = 4800, steps
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": _leg_traffic("transfer_requant"), "kernel_ms": kernel_ms, "gather_kernel_ms": g_ms,
                      "feature_kernel_ms": f_ms, "algorithmic_bytes_per_candidate": alg / max(n, 1),
-                     "kernel": "adh_gather_kernel + adh_feature_wide_kernel<observations> (the two-kernel path: more than 12 fragments per candidate; the wide register kernels hold 17 ... 64)"},
+                     "kernel": "adh_gather_kernel + adh_feature_wide_kernel<heavy bodies>, <light bodies> (the two-kernel path: more than 12 fragments per candidate; the wide register kernels hold 17 ... 64)"},
         "cpu_baseline": {"value": (sample / 3.0) / (dt / reps), "unit": "precursors/s", "cores": th, "kind": "port",
                          "sample": f"first {sample} candidates, {reps} x {dt / reps:.2f} s, {th} OpenMP threads",
                          "valid_identical_to_gpu": same_valid, "max_rel_feature_diff_vs_gpu": max_rel},
