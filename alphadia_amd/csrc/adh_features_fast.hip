@@ -1157,7 +1157,13 @@ struct WideClasses {
 #define ADH_WIDE_SPLIT 1
 #endif
 #define ADH_WIDE_ALL 0xFFF
-#define ADH_WIDE_LIGHT (ADH_WIDE_SPLIT ? (0x00B | (0x009 << 6)) : 0)  // kinds {0, 1, 3} of one, {0, 3} of two observations
+#ifndef ADH_WIDE_LIGHT_SET
+#define ADH_WIDE_LIGHT_SET (0x00B | (0x009 << 6))
+#endif
+#ifndef ADH_WIDE_LIGHT_WAVES
+#define ADH_WIDE_LIGHT_WAVES 1
+#endif
+#define ADH_WIDE_LIGHT (ADH_WIDE_SPLIT ? ADH_WIDE_LIGHT_SET : 0)  // kinds {0, 1, 3} of one, {0, 3} of two observations
 #define ADH_WIDE_HEAVY (ADH_WIDE_ALL & ~ADH_WIDE_LIGHT)
 template <int KINDS>
 constexpr size_t adh_wide_lds_bytes() {
@@ -1198,7 +1204,7 @@ struct WideArgs {
 // Two wavefronts per SIMD as the register budget of the heavy launch: left alone the two-observation bodies of 24 cycles
 // take 256 + 6 registers and run ONE wavefront per SIMD (round 6: 364 -> 274 us per launch of the
 // transfer-requantification leg).
-#define ADH_WIDE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(KINDS == ADH_WIDE_LIGHT ? 1 : 2)))
+#define ADH_WIDE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(KINDS == ADH_WIDE_LIGHT ? ADH_WIDE_LIGHT_WAVES : 2)))
 template <int KINDS>
 __global__ __launch_bounds__(ADH_WAVE) ADH_WIDE_WAVES_ATTR void adh_feature_wide_kernel(WideArgs formal_args_not_read) {
     const WideArgs &A = *(const WideArgs *)__builtin_amdgcn_kernarg_segment_ptr();  // (the only argument: offset 0)
