@@ -686,7 +686,8 @@ class Context:
         self.n_candidates = n
         return arrays
 
-    def score_host_compact(self, cands: _abi.Marshalled, cfg_jit, slots_per_row: float | None = None) -> dict:
+    def score_host_compact(self, cands: _abi.Marshalled, cfg_jit, slots_per_row: float | None = None,
+                           buffers: dict | None = None) -> dict:
         """``adh_score_candidates_compact``: the valid candidates and the filled fragment slots, column by column, in
         arrays this call allocates (the caller owns them): ``row``, ``precursor_idx``, ``rank``, ``features`` as
         [46, n_rows] (every feature a contiguous row) and the ``fragment_*`` columns per filled slot with
@@ -695,7 +696,11 @@ class Context:
         The arrays are allocated at a capacity - all candidates, ``slots_per_row`` filled slots per candidate (default:
         the width of the padded tables, which always suffices) - and returned as views of their first n entries: the
         pages behind the unused tail of a large fresh allocation are never touched, so they cost address space only.
-        A call whose ``slots_per_row`` turns out too small is repeated with what it needs."""
+        A call whose ``slots_per_row`` turns out too small is repeated with what it needs.
+
+        ``buffers``: a dict a caller keeps between calls of the same shape; the capacity arrays of the first call are
+        parked in it and written again by the next ones (a steady-state loop - a benchmark, a search that scores batch
+        after batch - then touches no fresh pages; the returned views are overwritten by the next call)."""
         n = int(cands.struct.n)
         width = _abi.output_width(cands, int(cfg_jit.top_k_fragments))
         cfg = _abi.pack_config(cfg_jit)
@@ -704,12 +709,18 @@ class Context:
         while True:
             out = _abi.CompactOutput()
             out.rows_capacity, out.slots_capacity, out.top_k = rows_cap, slots_cap, width
-            arrays = {}
-            for name, dt in _abi.COMPACT_ROW_FIELDS:
-                arrays[name] = np.empty(rows_cap, dtype=dt)
-            arrays["features"] = np.empty((_abi.NUM_FEATURES, rows_cap), dtype=np.float32)
-            for name, dt in _abi.COMPACT_SLOT_FIELDS:
-                arrays[name] = np.empty(slots_cap, dtype=dt)
+            key = (rows_cap, slots_cap)
+            arrays = buffers.get(key) if buffers is not None else None
+            if arrays is None:
+                arrays = {}
+                for name, dt in _abi.COMPACT_ROW_FIELDS:
+                    arrays[name] = np.empty(rows_cap, dtype=dt)
+                arrays["features"] = np.empty((_abi.NUM_FEATURES, rows_cap), dtype=np.float32)
+                for name, dt in _abi.COMPACT_SLOT_FIELDS:
+                    arrays[name] = np.empty(slots_cap, dtype=dt)
+                if buffers is not None:
+                    buffers.clear()
+                    buffers[key] = arrays
             for name, a in arrays.items():
                 setattr(out, name, a.ctypes.data_as(dict(out._fields_)[name]))
             rc = lib.adh_score_candidates_compact(self._h, cands.ref(), C.byref(cfg), C.byref(out))

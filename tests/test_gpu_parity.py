@@ -549,6 +549,15 @@ def test_compact_output_capacity_is_checked(ctx):
     for k in full:
         if isinstance(full[k], np.ndarray):
             assert np.array_equal(full[k], small[k], equal_nan=True), k
+    # capacity arrays kept between calls (``buffers``): the same tables, written into the same memory
+    keep: dict = {}
+    first = ctx.score_host_compact(pack_assembled(soa), g.config.to_jitclass(), buffers=keep)
+    snapshot = {k: v.copy() for k, v in first.items() if isinstance(v, np.ndarray)}
+    again = ctx.score_host_compact(pack_assembled(soa), g.config.to_jitclass(), buffers=keep)
+    assert len(keep) == 1
+    for k, v in snapshot.items():
+        assert np.array_equal(v, full[k], equal_nan=True) and np.array_equal(again[k], full[k], equal_nan=True), k
+        assert np.shares_memory(first[k], again[k]), k
     # the raw call with room for ten rows: error code, needed counts, nothing written past the capacity
     cands = pack_assembled(soa)
     width = _abi.output_width(cands, int(g.config.top_k_fragments))
