@@ -17,6 +17,7 @@ mkdir -p $OUT
 cd /tmp
 rm -rf /tmp/p6_*
 S="python $REPO/tools/rocpd_summary.py"
+export ADH_BENCH_NO_COMPACT=1  # (the profiled passes: the padded step and the resident leg only, 19 passes as tools/pmc_traffic.py counts them)
 CMD="python $REPO/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d /tmp/p6_stats -o r5 -- $CMD > $OUT/p6_stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM -d /tmp/p6_pmc1 -o r5 -- $CMD > $OUT/p6_pmc1.log 2>&1
@@ -109,6 +110,7 @@ rm -rf /tmp/p6_*
 cd $REPO
 cp $OUT/timstof_traffic.json profiles/timstof_traffic.json
 cp $OUT/legs_traffic.json profiles/legs_traffic.json
+unset ADH_BENCH_NO_COMPACT
 python bench.py --steps 20 --warmup 5 > $OUT/r06_final_bench.json 2> $OUT/r06_final_bench.log
 tail -1 $OUT/r06_final_bench.json | cut -c1-400
 grep -v "at::native\|rocprim\|rocclr" $OUT/r06_final_kernel_stats.csv | sed 's/(DevRun[^)]*)//; s/void //' | cut -c1-130 | head -10
