@@ -613,8 +613,10 @@ int launch_scoring_im(adh_handle *h, Plan &p, const adh_scoring_config_t *cfg, a
                                            d_scratch, side);
                         hipLaunchKernelGGL(adh_im_order_scatter_kernel, dim3(ob), dim3(256), 0, st, p.d_recs_im + first, (int32_t)cnt,
                                            d_scratch, side);
+                        // (ADH_DEBUG_IM_TILE4_TWO_LDS_PAD: extra LDS for this launch alone, to see what its occupancy is worth)
+                        const size_t t42_pad = getenv("ADH_DEBUG_IM_TILE4_TWO_LDS_PAD") ? (size_t)atoi(getenv("ADH_DEBUG_IM_TILE4_TWO_LDS_PAD")) : 0;
                         const size_t t4_lds = std::max(sizeof(featim4::WaveTile<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2>),
-                                                       featim::LayoutCommon2(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16);
+                                                       featim::LayoutCommon2(cc).bytes() + f_pad + ADH_IM_STATIC_LDS + 16) + t42_pad;
                         hipLaunchKernelGGL((adh_feature_im_tile4_kernel<featim::DimsCommon2::Fc, featim::DimsCommon2::Sc, 2, featim::LayoutCommon2>),
                                            dim3(groups + list_blocks), dim3(ADH_WAVE), t4_lds, st, h->tims, p.d_recs_im + first,
                                            (int32_t)cnt, h->cs.iso, n_iso, *cfg, d_scratch, *out, prof, side, cc,
