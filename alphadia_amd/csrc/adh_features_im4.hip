@@ -109,7 +109,17 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
     const int gbase = g * GS;
     GroupTile<FM, SM, NO> &Q = W.g[g];
     // (`order`: the candidates with sparse tiles, heaviest first - adh_im_order_*_kernel below; n_cand of them)
-    const int oi = block * NG + g;
+    // Four of a kind per wavefront (one observation) or the ordered candidates dealt out column by column (two
+    // observations: a wavefront holds one of every quarter of the order, so a long list has the wavefront's pools to
+    // itself).  The one-observation launches are bound by their throughput - a light candidate beside a long list waits
+    // for it: fused kernels 841 / 723 -> 942 / 828 us dealt out -, the two-observation launch by its longest
+    // wavefront, whose lanes fold two planes each: 444 -> 277 us dealt out (round 6; ADH_IM4_SPREAD: 0 = four of a
+    // kind everywhere, 1 = dealt out everywhere, 2 = by observation count)
+#ifndef ADH_IM4_SPREAD
+#define ADH_IM4_SPREAD 2
+#endif
+    int oi = block * NG + g;
+    if (ADH_IM4_SPREAD == 1 || (ADH_IM4_SPREAD == 2 && NO == 2)) oi = g * ((n_cand + NG - 1) / NG) + block;
     bool alive = oi < n_cand;
     const int ci = alive ? (int)order[oi] : 0;
     ci_out = ci;
