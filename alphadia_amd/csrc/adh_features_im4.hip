@@ -119,7 +119,9 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
 #define ADH_IM4_SPREAD 2
 #endif
     int oi = block * NG + g;
-    if (ADH_IM4_SPREAD == 1 || (ADH_IM4_SPREAD == 2 && NO == 2)) oi = g * ((n_cand + NG - 1) / NG) + block;
+    if (ADH_IM4_SPREAD == 1 || (ADH_IM4_SPREAD >= 2 && NO == 2)) oi = g * ((n_cand + NG - 1) / NG) + block;
+    // (3, measured: one observation in pairs - two of the front half of the order, two of the back half per wavefront)
+    if (ADH_IM4_SPREAD == 3 && NO == 1) oi = (g >> 1) * 2 * ((n_cand + NG - 1) / NG) + 2 * block + (g & 1);
     bool alive = oi < n_cand;
     const int ci = alive ? (int)order[oi] : 0;
     ci_out = ci;
