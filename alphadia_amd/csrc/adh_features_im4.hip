@@ -119,10 +119,11 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
 #define ADH_IM4_SPREAD 2
 #endif
     int oi = block * NG + g;
-    if (ADH_IM4_SPREAD == 1 || (ADH_IM4_SPREAD >= 2 && NO == 2)) oi = g * ((n_cand + NG - 1) / NG) + block;
+    const int n_waves = (n_cand + NG - 1) / NG;  // (the grid may hold more: it is sized before the order is known)
+    if (ADH_IM4_SPREAD == 1 || (ADH_IM4_SPREAD >= 2 && NO == 2)) oi = g * n_waves + block;
     // (3, measured: one observation in pairs - two of the front half of the order, two of the back half per wavefront)
-    if (ADH_IM4_SPREAD == 3 && NO == 1) oi = (g >> 1) * 2 * ((n_cand + NG - 1) / NG) + 2 * block + (g & 1);
-    bool alive = oi < n_cand;
+    if (ADH_IM4_SPREAD == 3 && NO == 1) oi = (g >> 1) * 2 * n_waves + 2 * block + (g & 1);
+    bool alive = block < n_waves && oi < n_cand;
     const int ci = alive ? (int)order[oi] : 0;
     ci_out = ci;
     const CandRecIM &r = plan[ci];
