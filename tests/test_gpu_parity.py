@@ -198,8 +198,9 @@ def test_requantification_configs_take_the_fused_kernel(ctx, oracle_lib, monkeyp
         assert gather_fused < 0.25 * gather_two and feature_fused > 0, (gather_fused, gather_two)
 
 
-@pytest.mark.parametrize("seed,k_fragments,quant_all", [(11, (17, 32), True), (12, (33, 61), True), (13, (14, 61), False)])
-def test_wide_register_kernels_equal_the_generic_kernel(ctx, oracle_lib, monkeypatch, seed, k_fragments, quant_all):
+@pytest.mark.parametrize("seed,k_fragments,quant_all,n_iso", [(11, (17, 32), True, 3), (12, (33, 61), True, 3), (13, (14, 61), False, 3),
+                                                              (14, (17, 45), True, 4), (15, (20, 50), False, 2), (16, (17, 40), True, 1)])
+def test_wide_register_kernels_equal_the_generic_kernel(ctx, oracle_lib, monkeypatch, seed, k_fragments, quant_all, n_iso):
     """Transfer-library requantification scores with ``top_k_fragments = 9999`` against libraries that carry every
     predicted fragment (transfer_library_requantification_handler.py:117-124): candidates keep 17 ... 64 fragments.
     The wide forms of the register kernel (adh_feature_fast_kernel<FM, NO, 32 / 64>, one launch per observation count)
@@ -207,7 +208,8 @@ def test_wide_register_kernels_equal_the_generic_kernel(ctx, oracle_lib, monkeyp
     (ADH_DEBUG_NO_WIDE), and several times faster."""
     case = syn.make_case(1500, 400, config_id=2, per_precursor=2, threads=8, seed=seed, k_fragments=k_fragments)
     cfg = CandidateScoringConfig()
-    cfg.update(dict(score_grouped=False, top_k_isotopes=3, reference_channel=-1, precursor_mz_tolerance=10,
+    # (n_iso: the precursor phase of the register kernels walks 4 x n_iso sequential sums on as many lanes: round 6)
+    cfg.update(dict(score_grouped=False, top_k_isotopes=n_iso, reference_channel=-1, precursor_mz_tolerance=10,
                     fragment_mz_tolerance=15, exclude_shared_ions=True, quant_window=3, quant_all=quant_all,
                     experimental_xic=True, top_k_fragments=9999))
     ctx.kernel_time_ms(reset=True)
