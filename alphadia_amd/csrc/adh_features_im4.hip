@@ -246,12 +246,14 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
                 t_srow[o] = 0.0f;
             }
             t_srow[o] += v;
-            Q.tfp_raw[o][f] = Q.tfp_raw[o][f] + v;
-            if (v > 0.0f) {
-                t_isum[o] += (double)v;
-                t_ssum[o] += (double)sc * (double)v;
-                t_fsum[o] += (double)f * (double)v;
-            }
+            // (this lane alone adds to the template's frame profile: through ds_add_f32 - no answer to wait for, the adds
+            // to one address arrive in program order - instead of a read, an add and a write in the lane's chain; a cell
+            // that is not positive enters the centre-of-mass sums as + 0: round 6, the chain of a long list's wavefront)
+            (void)__hip_atomic_fetch_add(&Q.tfp_raw[o][f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const double vd = (double)__builtin_fmaxf(v, 0.0f);
+            t_isum[o] += vd;
+            t_ssum[o] += (double)sc * vd;
+            t_fsum[o] += (double)f * vd;
         }
         t_row = sc;
     };
@@ -608,10 +610,13 @@ __device__ __forceinline__ TileOut tile4_phase(WaveTile<FM, SM, NO> &W, const De
                     fs += v;
                     (void)__hip_atomic_fetch_add(&Q.ffp[cur_o][f][sub], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const double tm = (double)y * w;  // (w > 0: the product is > 0 exactly when the m/z channel is)
-                    vi += v > 0.0f ? (double)v * w : 0.0;  // (adding 0.0 leaves a sum as it is)
-                    wi += v > 0.0f ? w : 0.0;
-                    vm += tm > 0.0 ? tm : 0.0;
-                    wm += tm > 0.0 ? w : 0.0;
+                    // (a cell without signal enters as 0 - adding + 0.0 leaves a sum as it is - and its weight through
+                    // an indicator: w x 1.0 + wi rounds once, like wi + w; one select on the indicator's high word
+                    // instead of two on the weight, as in the register kernels)
+                    vi += (double)__builtin_fmaxf(v, 0.0f) * w;
+                    wi = __builtin_fma(w, __hiloint2double(v > 0.0f ? 0x3ff00000 : 0, 0), wi);
+                    vm += __builtin_fmax(tm, 0.0);
+                    wm = __builtin_fma(w, __hiloint2double(tm > 0.0 ? 0x3ff00000 : 0, 0), wm);
                 }
             }
         }
