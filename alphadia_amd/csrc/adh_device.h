@@ -181,7 +181,9 @@ static_assert(sizeof(CandRecIM) == 128, "CandRecIM must be 128 bytes");
 // ADH_IM_PAIR_CAP TOF bins in all windows, or more entries than fit where the tiles would be (a small
 // tile full of signal) gets the dense tiles (zero fill + scatter; mode ADH_IM_MODE_DENSE).
 #define ADH_IM_SORT_CAP 512
-#define ADH_IM_PAIR_CAP 256
+#ifndef ADH_IM_PAIR_CAP
+#define ADH_IM_PAIR_CAP 256  // (a build switch since round 6: LDS per wavefront of the gathers)
+#endif
 #define ADH_IM_MODE_DENSE 0u
 #define ADH_IM_MODE_COMPACT 1u
 struct ImEntry {
